@@ -1,0 +1,716 @@
+/*
+ * fitch_oracle.c -- CPU restatement of the reference's Fitch parsimony path.
+ * TEST INFRASTRUCTURE ONLY (see fitch_oracle.h).  Parity status: PINNED against
+ * oracle/_ref/pll_ref_driver (the reference's PLL parsimony sources compiled
+ * where they lie) through tests/golden/ fixtures.
+ *
+ * Reference files restated (all under /root/reference):
+ *   sprparsimony.cpp             -- mpboot's engine (variant ORC_TIE_RANDOM)
+ *   pllrepo/src/fastDNAparsimony.c -- PLL original (variant ORC_TIE_FIRST)
+ * The two differ on this path only by (a) the tie rule and (b) the extra
+ * evaluateParsimony(p) at the top of rearrangeParsimony (sprparsimony.cpp:2285),
+ * both switched by o->tie_mode below.
+ *
+ * Data model (ours): node records rec = 3*number + slot, back[rec], x[rec]
+ * (the xPars flag, pll.h:622-660), one vector per node vec[number][S][W] as in
+ * parsVect (sprparsimony.cpp:732-734).
+ */
+#include "fitch_oracle.h"
+#include "rng.h"
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+
+struct orc {
+  int n, P, S, W, datatype, keep_all, nrec;
+  unsigned char *codes;
+  int *wgt, *inf, ninf;
+  uint32_t *vec;
+  unsigned *score;
+  uint32_t *persite;          /* [2n][W*32] or NULL */
+  int persite_on;
+  int *back;
+  unsigned char *x;
+  int *nodep;
+  int start, ntips, nextnode;
+  int *ti;
+  unsigned best;
+  int insert_rec, remove_rec;
+  unsigned long hits;         /* bestTreeScoreHits */
+  int tie_mode;
+  orc_lcg64 rng;
+  double (*rand_fn)(void *);
+  void *rand_arg;
+  long randum_seed;
+  int trace_on, trace_len, trace_cap;
+  int *trace_q;
+  unsigned *trace_mp;
+  int moves_len, moves_cap;
+  int *moves_rem, *moves_ins;
+  unsigned *moves_score;
+  unsigned long long c_newview, c_eval, c_test;
+};
+
+#define NUM(r) ((r) / 3)
+#define TIP(o, r) (NUM(r) <= (o)->n)
+static inline int NX(int r) { int v = r / 3, s = r % 3; return 3 * v + (s + 1) % 3; }
+
+/* PLL tip code -> state set. DNA: bitVectorIdentity; AA: bitVectorAA (pllrepo/src/globalVariables.h:60-78) */
+static uint32_t state_mask(int datatype, unsigned code)
+{
+  if (datatype == ORC_DNA) return code;
+  if (code < 20) return 1u << code;
+  if (code == 20) return 12u;        /* B = N|D */
+  if (code == 21) return 96u;        /* Z = Q|E */
+  return 1048575u;                   /* 22: - ? * X */
+}
+static int undetermined_code(int datatype) { return datatype == ORC_DNA ? 15 : 22; } /* globalVariables.h pLengths */
+
+static double tie_draw(orc *o)
+{
+  if (o->rand_fn) return o->rand_fn(o->rand_arg);
+  return orc_lcg64_next(&o->rng);
+}
+
+/* ---- isInformative / determineUninformativeSites: sprparsimony.cpp:2460-2499, :2596-2634 ---- */
+static int is_informative(const orc *o, int site)
+{
+  int check[256], j, cnt = 0, und = undetermined_code(o->datatype);
+  if (o->keep_all) return 1;                      /* !sort_alignment, :2462-2463 */
+  memset(check, 0, sizeof check);
+  for (j = 0; j < o->n; j++) check[o->codes[(size_t)j * o->P + site]] = 1;
+  for (j = 0; j < und; j++) if (check[j]) cnt++;
+  return cnt > 1;
+}
+
+/* ---- compressDNA: sprparsimony.cpp:2828-2973 (PLL: fastDNAparsimony.c:1647-1774) ---- */
+static void pack_tips(orc *o)
+{
+  size_t entries = 0, ce, cep;
+  int i, k, site, S = o->S;
+  o->ninf = 0;
+  for (site = 0; site < o->P; site++) {
+    o->inf[site] = is_informative(o, site);
+    if (o->inf[site]) { entries += (size_t)o->wgt[site]; o->ninf++; }
+  }
+  ce = entries / 32 + (entries % 32 != 0);
+  cep = (ce % 8) ? ce + (8 - ce % 8) : ce;        /* INTS_PER_VECTOR = 8 (AVX), :2870-2882 */
+  if ((int)cep != o->W || !o->vec) {
+    free(o->vec);
+    o->W = (int)cep;
+    o->vec = (uint32_t *)calloc((size_t)2 * o->n * S * o->W + 1, sizeof(uint32_t));
+    free(o->persite);
+    o->persite = NULL;
+  } else {
+    memset(o->vec, 0, sizeof(uint32_t) * 2 * o->n * S * o->W);
+  }
+  if (o->persite_on && !o->persite)
+    o->persite = (uint32_t *)calloc((size_t)2 * o->n * o->W * 32 + 1, sizeof(uint32_t));
+  for (i = 0; i < o->n; i++) {
+    uint32_t *tip = o->vec + (size_t)o->W * S * (i + 1), val[32];
+    size_t ci = 0;
+    int cc = 0, w;
+    memset(val, 0, sizeof val);
+    for (site = 0; site < o->P; site++) {
+      uint32_t m;
+      if (!o->inf[site]) continue;
+      m = state_mask(o->datatype, o->codes[(size_t)i * o->P + site]);
+      for (w = 0; w < o->wgt[site]; w++) {
+        for (k = 0; k < S; k++) if (m & (1u << k)) val[k] |= 1u << cc;
+        if (++cc == 32) {
+          for (k = 0; k < S; k++) { tip[(size_t)k * o->W + ci] = val[k]; val[k] = 0; }
+          cc = 0; ci++;
+        }
+      }
+    }
+    for (; ci < (size_t)o->W; ci++) {               /* padding bits all ones, :2947-2960 */
+      for (; cc < 32; cc++) for (k = 0; k < S; k++) val[k] |= 1u << cc;
+      for (k = 0; k < S; k++) { tip[(size_t)k * o->W + ci] = val[k]; val[k] = 0; }
+      cc = 0;
+    }
+  }
+  memset(o->score, 0, sizeof(unsigned) * 2 * o->n);
+}
+
+orc *orc_create(int n, int P, int datatype, const unsigned char *codes, const int *weights, int keep_all)
+{
+  orc *o = (orc *)calloc(1, sizeof(orc));
+  int i;
+  o->n = n; o->P = P; o->datatype = datatype; o->keep_all = keep_all;
+  o->S = datatype == ORC_DNA ? 4 : 20;
+  o->nrec = 3 * (2 * n - 1) + 3;
+  o->codes = (unsigned char *)malloc((size_t)n * P);
+  memcpy(o->codes, codes, (size_t)n * P);
+  o->wgt = (int *)malloc(sizeof(int) * P);
+  memcpy(o->wgt, weights, sizeof(int) * P);
+  o->inf = (int *)calloc(P, sizeof(int));
+  o->score = (unsigned *)calloc(2 * n, sizeof(unsigned));
+  o->back = (int *)malloc(sizeof(int) * o->nrec);
+  for (i = 0; i < o->nrec; i++) o->back[i] = -1;
+  o->x = (unsigned char *)calloc(o->nrec, 1);
+  o->nodep = (int *)calloc(2 * n, sizeof(int));
+  o->ti = (int *)calloc((size_t)4 * n + 8, sizeof(int));
+  o->W = -1;
+  pack_tips(o);
+  orc_reset_nodep(o);
+  orc_lcg64_init(&o->rng, 1);
+  o->tie_mode = ORC_TIE_FIRST;
+  o->randum_seed = 12345;
+  o->start = 3;
+  o->ntips = n;
+  return o;
+}
+
+void orc_destroy(orc *o)
+{
+  if (!o) return;
+  free(o->codes); free(o->wgt); free(o->inf); free(o->vec); free(o->score); free(o->persite);
+  free(o->back); free(o->x); free(o->nodep); free(o->ti); free(o->trace_q); free(o->trace_mp);
+  free(o->moves_rem); free(o->moves_ins); free(o->moves_score);
+  free(o);
+}
+
+int orc_words(const orc *o) { return o->W; }
+int orc_states(const orc *o) { return o->S; }
+int orc_num_informative(const orc *o) { return o->ninf; }
+const int *orc_informative(const orc *o) { return o->inf; }
+const uint32_t *orc_node_vector(const orc *o, int node) { return o->vec + (size_t)o->W * o->S * node; }
+
+/* orientation flags as _allocateParsimonyDataStructures leaves them: sprparsimony.cpp:3047-3055 */
+static void reset_flags(orc *o)
+{
+  int i;
+  for (i = o->n + 1; i <= 2 * o->n - 1; i++) {
+    int p = o->nodep[i];
+    o->x[p] = 1; o->x[NX(p)] = 0; o->x[NX(NX(p))] = 0;
+  }
+}
+
+/* _updateInternalPllOnRatchet + _allocateParsimonyDataStructures: sprparsimony.cpp:3022-3060 */
+void orc_set_weights(orc *o, const int *weights)
+{
+  memcpy(o->wgt, weights, sizeof(int) * o->P);
+  pack_tips(o);
+  reset_flags(o);
+}
+
+void orc_enable_persite(orc *o, int on)
+{
+  o->persite_on = on;
+  if (on && !o->persite) o->persite = (uint32_t *)calloc((size_t)2 * o->n * o->W * 32 + 1, sizeof(uint32_t));
+}
+
+/* nodep / orientation flags as left by pllTreeInitDefaults (utils.c:2019-2044) + _allocate (:3047-3055) */
+void orc_reset_nodep(orc *o)
+{
+  int i;
+  memset(o->x, 0, o->nrec);
+  for (i = 1; i <= 2 * o->n - 1; i++) {
+    o->nodep[i] = 3 * i;
+    if (i > o->n) o->x[3 * i] = 1;
+  }
+}
+
+void orc_get_nodep(const orc *o, int *nodep) { memcpy(nodep, o->nodep, sizeof(int) * 2 * o->n); }
+
+void orc_set_tree(orc *o, const int *back)
+{
+  memcpy(o->back, back, sizeof(int) * 3 * (2 * o->n - 1));
+  o->start = o->nodep[1];
+  o->ntips = o->n;
+}
+void orc_get_tree(const orc *o, int *back) { memcpy(back, o->back, sizeof(int) * 3 * (2 * o->n - 1)); }
+
+static void hookup(orc *o, int p, int q) { o->back[p] = q; o->back[q] = p; }  /* hookupDefault utils.c:456 */
+
+/* ---- per-site helpers: sprparsimony.cpp:294-376 ---- */
+static void ps_reset(orc *o, int node) { memset(o->persite + (size_t)o->W * 32 * node, 0, sizeof(uint32_t) * o->W * 32); }
+static void ps_add(orc *o, int p, int q, int r)
+{
+  size_t L = (size_t)o->W * 32, k;
+  uint32_t *pb = o->persite + L * p, *qb = o->persite + L * q, *rb = o->persite + L * r;
+  for (k = 0; k < L; k++) pb[k] += qb[k] + rb[k];
+}
+static void ps_store(orc *o, uint32_t vN, int word, int node)
+{
+  uint32_t *b = o->persite + (size_t)o->W * 32 * node + (size_t)word * 32;
+  int j;
+  for (j = 0; j < 32; j++) b[j] += (vN >> j) & 1u;
+}
+
+/* ---- getxnodeLocal / computeTraversalInfoParsimony: sprparsimony.cpp:420-467 ---- */
+static void getx(orc *o, int p)
+{
+  int s = NX(p);
+  if (o->x[s] || o->x[(s = NX(s))]) { o->x[p] = o->x[s]; o->x[s] = 0; }
+  assert(o->x[p] || o->x[NX(p)] || o->x[NX(NX(p))]);
+}
+
+static void traversal(orc *o, int p, int *counter, int full)
+{
+  int q, r;
+  if (o->persite_on) ps_reset(o, NUM(p));             /* :437-439 */
+  q = o->back[NX(p)];
+  r = o->back[NX(NX(p))];
+  if (!o->x[p]) getx(o, p);
+  if (full) {
+    if (!TIP(o, q)) traversal(o, q, counter, full);
+    if (!TIP(o, r)) traversal(o, r, counter, full);
+  } else {
+    if (!TIP(o, q) && !o->x[q]) traversal(o, q, counter, full);
+    if (!TIP(o, r) && !o->x[r]) traversal(o, r, counter, full);
+  }
+  o->ti[*counter] = NUM(p);
+  o->ti[*counter + 1] = NUM(q);
+  o->ti[*counter + 2] = NUM(r);
+  *counter += 4;
+}
+
+/* ---- newviewParsimonyIterativeFast, Fitch: sprparsimony.cpp:554-878 (generic-S body :841-869) ---- */
+static void newview_iter(orc *o)
+{
+  int idx, count = o->ti[0], S = o->S, W = o->W, k, i;
+  for (idx = 4; idx < count; idx += 4) {
+    size_t pN = (size_t)o->ti[idx], qN = (size_t)o->ti[idx + 1], rN = (size_t)o->ti[idx + 2];
+    const uint32_t *L = o->vec + (size_t)W * S * qN, *R = o->vec + (size_t)W * S * rN;
+    uint32_t *C = o->vec + (size_t)W * S * pN;
+    unsigned total = 0;
+    if (o->persite_on) {                              /* :660-663 */
+      if ((int)qN <= o->n) ps_reset(o, (int)qN);
+      if ((int)rN <= o->n) ps_reset(o, (int)rN);
+    }
+    for (i = 0; i < W; i++) {
+      uint32_t lA[32], vA[32], vN = 0;
+      for (k = 0; k < S; k++) {
+        uint32_t sl = L[(size_t)k * W + i], sr = R[(size_t)k * W + i];
+        lA[k] = sl & sr; vA[k] = sl | sr; vN |= lA[k];
+      }
+      for (k = 0; k < S; k++) C[(size_t)k * W + i] = lA[k] | (~vN & vA[k]);
+      vN = ~vN;
+      total += (unsigned)__builtin_popcount(vN);
+      if (o->persite_on) ps_store(o, vN, i, (int)pN);
+    }
+    o->score[pN] = total + o->score[rN] + o->score[qN];   /* :874 */
+    if (o->persite_on) ps_add(o, (int)pN, (int)qN, (int)rN);
+    o->c_newview++;
+  }
+}
+
+/* ---- evaluateParsimonyIterativeFast, Fitch: sprparsimony.cpp:965-1206 (no early exit, :1122-1123) ---- */
+static unsigned evaluate_iter(orc *o)
+{
+  size_t pN = (size_t)o->ti[1], qN = (size_t)o->ti[2];
+  int S = o->S, W = o->W, k, i;
+  unsigned sum;
+  const uint32_t *L, *R;
+  if (o->ti[0] > 4) newview_iter(o);
+  sum = o->score[pN] + o->score[qN];
+  if (o->persite_on) {                                /* :1051-1054 */
+    ps_reset(o, NUM(o->start));
+    ps_add(o, NUM(o->start), (int)pN, (int)qN);
+  }
+  L = o->vec + (size_t)W * S * qN;
+  R = o->vec + (size_t)W * S * pN;
+  for (i = 0; i < W; i++) {
+    uint32_t vN = 0;
+    for (k = 0; k < S; k++) vN |= L[(size_t)k * W + i] & R[(size_t)k * W + i];
+    vN = ~vN;
+    sum += (unsigned)__builtin_popcount(vN);
+    if (o->persite_on) ps_store(o, vN, i, NUM(o->start));
+  }
+  o->c_eval++;
+  return sum;
+}
+
+/* ---- evaluateParsimony / newviewParsimony: sprparsimony.cpp:1889-1934 ---- */
+unsigned orc_evaluate(orc *o, int p, int full)
+{
+  int q = o->back[p], counter = 4;
+  o->ti[1] = NUM(p);
+  o->ti[2] = NUM(q);
+  if (full) {
+    if (!TIP(o, p)) traversal(o, p, &counter, full);
+    if (!TIP(o, q)) traversal(o, q, &counter, full);
+  } else {
+    if (!TIP(o, p) && !o->x[p]) traversal(o, p, &counter, full);
+    if (!TIP(o, q) && !o->x[q]) traversal(o, q, &counter, full);
+  }
+  o->ti[0] = counter;
+  return evaluate_iter(o);
+}
+
+static void newview(orc *o, int p)
+{
+  int counter = 4;
+  if (TIP(o, p)) return;
+  traversal(o, p, &counter, 0);
+  o->ti[0] = counter;
+  newview_iter(o);
+}
+
+/* ---- reorderNodes / nodeRectifierPars: sprparsimony.cpp:2046-2101 ---- */
+static void reorder(orc *o, int p, int *count)
+{
+  if (TIP(o, p)) return;
+  o->nodep[*count + o->n + 1] = p;     /* the record reached from the parent */
+  (*count)++;
+  reorder(o, o->back[NX(p)], count);
+  reorder(o, o->back[NX(NX(p))], count);
+}
+void orc_node_rectifier(orc *o)
+{
+  int count = 0;
+  o->start = o->nodep[1];
+  reorder(o, o->back[o->start], &count);
+}
+
+unsigned orc_score_tree(orc *o)
+{
+  orc_node_rectifier(o);
+  return orc_evaluate(o, o->start, 1);
+}
+
+/* ---- pllComputePatternParsimony: sprparsimony.cpp:3363-3392 ---- */
+int orc_pattern_scores(orc *o, unsigned short *ptn)
+{
+  const uint32_t *p = o->persite + (size_t)o->W * 32 * NUM(o->start);
+  int k, site = 0, sum = 0, upper = o->keep_all ? o->P : o->ninf, j = 0;
+  /* the reference indexes ptn by sorted-pattern position and assumes the first
+     numInformativePatterns patterns are the kept ones (:3380-3387); we return the
+     score at each KEPT pattern's original index and 0 elsewhere, which is the same
+     thing whenever the reference's assumption holds. */
+  for (k = 0; k < o->P; k++) ptn[k] = 0;
+  for (k = 0; k < o->P && j < upper; k++) {
+    if (!o->inf[k]) continue;
+    ptn[k] = (unsigned short)p[site];
+    sum += (int)ptn[k] * o->wgt[k];
+    site += o->wgt[k];
+    j++;
+  }
+  return sum;
+}
+
+void orc_seed_ties(orc *o, int tie_mode, int seed)
+{
+  o->tie_mode = tie_mode;
+  orc_lcg64_init(&o->rng, seed);
+}
+void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg) { o->rand_fn = fn; o->rand_arg = arg; }
+
+/* ---- traces ---- */
+void orc_trace(orc *o, int on) { o->trace_on = on; o->trace_len = 0; o->moves_len = 0; }
+int orc_trace_len(const orc *o) { return o->trace_len; }
+void orc_trace_get(const orc *o, int *q, unsigned *mp)
+{
+  memcpy(q, o->trace_q, sizeof(int) * o->trace_len);
+  memcpy(mp, o->trace_mp, sizeof(unsigned) * o->trace_len);
+}
+static void trace_push(orc *o, int q, unsigned mp)
+{
+  if (!o->trace_on) return;
+  if (o->trace_len == o->trace_cap) {
+    o->trace_cap = o->trace_cap ? 2 * o->trace_cap : 1024;
+    o->trace_q = (int *)realloc(o->trace_q, sizeof(int) * o->trace_cap);
+    o->trace_mp = (unsigned *)realloc(o->trace_mp, sizeof(unsigned) * o->trace_cap);
+  }
+  o->trace_q[o->trace_len] = q;
+  o->trace_mp[o->trace_len++] = mp;
+}
+int orc_moves_len(const orc *o) { return o->moves_len; }
+void orc_moves_get(const orc *o, int *rem, int *ins, unsigned *score)
+{
+  memcpy(rem, o->moves_rem, sizeof(int) * o->moves_len);
+  memcpy(ins, o->moves_ins, sizeof(int) * o->moves_len);
+  memcpy(score, o->moves_score, sizeof(unsigned) * o->moves_len);
+}
+static void moves_push(orc *o, int rem, int ins, unsigned score)
+{
+  if (!o->trace_on) return;
+  if (o->moves_len == o->moves_cap) {
+    o->moves_cap = o->moves_cap ? 2 * o->moves_cap : 256;
+    o->moves_rem = (int *)realloc(o->moves_rem, sizeof(int) * o->moves_cap);
+    o->moves_ins = (int *)realloc(o->moves_ins, sizeof(int) * o->moves_cap);
+    o->moves_score = (unsigned *)realloc(o->moves_score, sizeof(unsigned) * o->moves_cap);
+  }
+  o->moves_rem[o->moves_len] = rem;
+  o->moves_ins[o->moves_len] = ins;
+  o->moves_score[o->moves_len++] = score;
+}
+
+/* ---- insertParsimony / testInsertParsimony: sprparsimony.cpp:1942-1952, :2106-2188 ---- */
+static void insert_node(orc *o, int p, int q)
+{
+  int r = o->back[q];
+  hookup(o, NX(p), q);
+  hookup(o, NX(NX(p)), r);
+  newview(o, p);
+}
+
+static void test_insert(orc *o, int p, int q)
+{
+  int r = o->back[q];
+  unsigned mp;
+  insert_node(o, p, q);
+  mp = orc_evaluate(o, NX(NX(p)), 0);
+  o->c_test++;
+  trace_push(o, q, mp);
+  if (o->tie_mode == ORC_TIE_RANDOM) {                /* :2168-2176 */
+    if (mp < o->best) o->hits = 1;
+    else if (mp == o->best) o->hits++;
+    if (mp < o->best || (mp == o->best && tie_draw(o) <= 1.0 / (double)o->hits)) {
+      o->best = mp; o->insert_rec = q; o->remove_rec = p;
+    }
+  } else if (mp < o->best) {                          /* fastDNAparsimony.c:1224-1229 */
+    o->best = mp; o->insert_rec = q; o->remove_rec = p;
+  }
+  hookup(o, q, r);
+  o->back[NX(NX(p))] = o->back[NX(p)] = -1;
+}
+
+/* ---- addTraverseParsimony: sprparsimony.cpp:2208-2218 (doAll = FALSE) ---- */
+static void add_traverse(orc *o, int p, int q, int mintrav, int maxtrav)
+{
+  if (--mintrav <= 0) test_insert(o, p, q);
+  if (!TIP(o, q) && --maxtrav > 0) {
+    add_traverse(o, p, o->back[NX(q)], mintrav, maxtrav);
+    add_traverse(o, p, o->back[NX(NX(q))], mintrav, maxtrav);
+  }
+}
+
+/* ---- removeNodeParsimony: sprparsimony.cpp:2245-2257 ---- */
+static void remove_node(orc *o, int p)
+{
+  int q = o->back[NX(p)], r = o->back[NX(NX(p))];
+  hookup(o, q, r);
+  o->back[NX(NX(p))] = o->back[NX(p)] = -1;
+}
+
+/* ---- rearrangeParsimony: sprparsimony.cpp:2259-2376 (PLL: fastDNAparsimony.c:1316-1428) ---- */
+int orc_rearrange(orc *o, int p, int mintrav, int maxtrav)
+{
+  int q, p1, p2, q1, q2, mintrav2;
+  if (maxtrav > o->ntips - 3) maxtrav = o->ntips - 3;
+  assert(mintrav == 1);
+  if (maxtrav < mintrav) return 0;
+  q = o->back[p];
+  if (o->tie_mode == ORC_TIE_RANDOM) orc_evaluate(o, p, 0);   /* :2285, mpboot only */
+  trace_push(o, -1, 0);
+  if (!TIP(o, p)) {
+    p1 = o->back[NX(p)];
+    p2 = o->back[NX(NX(p))];
+    if (!TIP(o, p1) || !TIP(o, p2)) {
+      remove_node(o, p);
+      if (!TIP(o, p1)) {
+        add_traverse(o, p, o->back[NX(p1)], mintrav, maxtrav);
+        add_traverse(o, p, o->back[NX(NX(p1))], mintrav, maxtrav);
+      }
+      if (!TIP(o, p2)) {
+        add_traverse(o, p, o->back[NX(p2)], mintrav, maxtrav);
+        add_traverse(o, p, o->back[NX(NX(p2))], mintrav, maxtrav);
+      }
+      hookup(o, NX(p), p1);
+      hookup(o, NX(NX(p)), p2);
+      newview(o, p);
+    }
+  }
+  trace_push(o, -2, 0);
+  if (!TIP(o, q) && maxtrav > 0) {
+    q1 = o->back[NX(q)];
+    q2 = o->back[NX(NX(q))];
+    if ((!TIP(o, q1) && (!TIP(o, o->back[NX(q1)]) || !TIP(o, o->back[NX(NX(q1))]))) ||
+        (!TIP(o, q2) && (!TIP(o, o->back[NX(q2)]) || !TIP(o, o->back[NX(NX(q2))])))) {
+      remove_node(o, q);
+      mintrav2 = mintrav > 2 ? mintrav : 2;
+      if (!TIP(o, q1)) {
+        add_traverse(o, q, o->back[NX(q1)], mintrav2, maxtrav);
+        add_traverse(o, q, o->back[NX(NX(q1))], mintrav2, maxtrav);
+      }
+      if (!TIP(o, q2)) {
+        add_traverse(o, q, o->back[NX(q2)], mintrav2, maxtrav);
+        add_traverse(o, q, o->back[NX(NX(q2))], mintrav2, maxtrav);
+      }
+      hookup(o, NX(q), q1);
+      hookup(o, NX(NX(q)), q2);
+      newview(o, q);
+    }
+  }
+  return 1;
+}
+
+void orc_set_best(orc *o, unsigned best) { o->best = best; o->insert_rec = o->remove_rec = -1; o->hits = 1; }
+unsigned orc_get_best(const orc *o, int *remove_rec, int *insert_rec)
+{
+  if (remove_rec) *remove_rec = o->remove_rec;
+  if (insert_rec) *insert_rec = o->insert_rec;
+  return o->best;
+}
+
+/* ---- restoreTreeParsimony / restoreTreeRearrangeParsimony: sprparsimony.cpp:2191-2205, :2379-2384 ---- */
+static void restore_rearrange(orc *o)
+{
+  int p = o->remove_rec, q = o->insert_rec, r, counter = 4;
+  remove_node(o, p);
+  r = o->back[q];
+  hookup(o, NX(p), q);
+  hookup(o, NX(NX(p)), r);
+  traversal(o, p, &counter, 0);
+  o->ti[0] = counter;
+  newview_iter(o);
+}
+
+/* ---- the sweep loop shared by pllOptimizeSprParsimony (:3295-3316) and
+        _pllMakeParsimonyTreeFast (:3185-3206); PLL original: fastDNAparsimony.c:1919-1938 ---- */
+static unsigned spr_sweeps(orc *o, int mintrav, int maxtrav, unsigned randomMP)
+{
+  unsigned startMP;
+  unsigned iter_hits = 1;
+  int i;
+  do {
+    startMP = randomMP;
+    orc_node_rectifier(o);
+    for (i = 1; i <= 2 * o->n - 2; i++) {
+      if (o->tie_mode == ORC_TIE_RANDOM) {
+        o->insert_rec = o->remove_rec = -1;
+        o->hits = 1;
+        orc_rearrange(o, o->nodep[i], mintrav, maxtrav);
+        if (o->best == randomMP) iter_hits++;
+        if (o->best < randomMP) iter_hits = 1;
+        if ((o->best < randomMP || (o->best == randomMP && tie_draw(o) <= 1.0 / (double)iter_hits)) &&
+            o->remove_rec >= 0 && o->insert_rec >= 0) {
+          moves_push(o, o->remove_rec, o->insert_rec, o->best);
+          restore_rearrange(o);
+          randomMP = o->best;
+        }
+      } else {
+        orc_rearrange(o, o->nodep[i], mintrav, maxtrav);
+        if (o->best < randomMP) {
+          moves_push(o, o->remove_rec, o->insert_rec, o->best);
+          restore_rearrange(o);
+          randomMP = o->best;
+        }
+      }
+    }
+  } while (randomMP < startMP);
+  return startMP;
+}
+
+/* ---- pllOptimizeSprParsimony: sprparsimony.cpp:3244-3319 ---- */
+unsigned orc_optimize_spr(orc *o, int mintrav, int maxtrav)
+{
+  orc_node_rectifier(o);
+  o->best = UINT_MAX;
+  o->best = orc_evaluate(o, o->start, 1);
+  o->ntips = o->n;
+  o->insert_rec = o->remove_rec = -1;
+  return spr_sweeps(o, mintrav, maxtrav, o->best);
+}
+
+/* ---- makePermutationFast: sprparsimony.cpp:2221-2242 ---- */
+static void make_permutation(orc *o, int *perm)
+{
+  int i, j, k, n = o->n;
+  for (i = 1; i <= n; i++) perm[i] = i;
+  for (i = 1; i <= n; i++) {
+    double d = orc_randum(&o->randum_seed);
+    k = (int)((double)(n + 1 - i) * d);
+    j = perm[i]; perm[i] = perm[i + k]; perm[i + k] = j;
+  }
+}
+
+/* ---- stepwiseAddition: sprparsimony.cpp:2977-3019 (PLL: fastDNAparsimony.c:1776-1814) ---- */
+static void stepwise(orc *o, int p, int q)
+{
+  int r = o->back[q], counter = 4;
+  unsigned mp;
+  o->back[NX(p)] = q; o->back[q] = NX(p);
+  o->back[NX(NX(p))] = r; o->back[r] = NX(NX(p));
+  traversal(o, p, &counter, 0);
+  o->ti[0] = counter;
+  o->ti[1] = NUM(p);
+  o->ti[2] = NUM(o->back[p]);
+  mp = evaluate_iter(o);
+  o->c_test++;
+  trace_push(o, q, mp);
+  if (o->tie_mode == ORC_TIE_RANDOM) {
+    if (mp < o->best) o->hits = 1;
+    else if (mp == o->best) o->hits++;
+    if (mp < o->best || (mp == o->best && tie_draw(o) <= 1.0 / (double)o->hits)) { o->best = mp; o->insert_rec = q; }
+  } else if (mp < o->best) { o->best = mp; o->insert_rec = q; }
+  o->back[q] = r; o->back[r] = q;
+  if (!TIP(o, q) && o->score[NUM(q)] > 0) {
+    stepwise(o, p, o->back[NX(q)]);
+    stepwise(o, p, o->back[NX(NX(q))]);
+  }
+}
+
+/* ---- buildNewTip / buildSimpleTree + the addition loop of _pllMakeParsimonyTreeFast:
+        sprparsimony.cpp:1955-1981, :3107-3181 ---- */
+static void addition_phase(orc *o, long seed, int *perm, unsigned *best_per_step, int *insert_per_step)
+{
+  int n = o->n, ip, iq, ir, i, p, s, f, nextsp;
+  reset_flags(o);                                    /* _allocateParsimonyDataStructures, :3228 */
+  memset(o->score, 0, sizeof(unsigned) * 2 * o->n);
+  o->randum_seed = seed;
+  make_permutation(o, perm);
+  o->ntips = 0;
+  o->nextnode = n + 1;
+  ip = perm[1]; iq = perm[2]; ir = perm[3];
+  i = ip < iq ? ip : iq;
+  if (ir < i) i = ir;
+  o->start = o->nodep[i];
+  o->ntips = 3;
+  p = o->nodep[ip];
+  hookup(o, p, o->nodep[iq]);
+  s = o->nodep[o->nextnode++];                       /* buildNewTip */
+  hookup(o, o->nodep[ir], s);
+  o->back[NX(s)] = o->back[NX(NX(s))] = -1;
+  insert_node(o, s, p);
+  f = o->start;
+  o->hits = 1;
+  while (o->ntips < n) {
+    int q, r, counter = 4;
+    o->best = INT_MAX;
+    nextsp = ++o->ntips;
+    p = o->nodep[perm[nextsp]];
+    q = o->nodep[o->nextnode++];
+    o->back[p] = q; o->back[q] = p;
+    trace_push(o, -1, 0);
+    stepwise(o, q, o->back[f]);
+    if (best_per_step) best_per_step[nextsp] = o->best;
+    if (insert_per_step) insert_per_step[nextsp] = o->insert_rec;
+    r = o->back[o->insert_rec];
+    hookup(o, NX(q), o->insert_rec);
+    hookup(o, NX(NX(q)), r);
+    traversal(o, q, &counter, 0);
+    o->ti[0] = counter;
+    newview_iter(o);
+  }
+}
+
+unsigned orc_stepwise(orc *o, long seed, unsigned *best_per_step, int *insert_per_step)
+{
+  int *perm = (int *)malloc(sizeof(int) * (o->n + 2));
+  addition_phase(o, seed, perm, best_per_step, insert_per_step);
+  free(perm);
+  return o->best;
+}
+
+unsigned orc_make_tree(orc *o, long seed, int spr_dist, int *perm_out)
+{
+  int *perm = (int *)malloc(sizeof(int) * (o->n + 2));
+  addition_phase(o, seed, perm, NULL, NULL);
+  if (perm_out) memcpy(perm_out, perm, sizeof(int) * (o->n + 1));
+  free(perm);
+  orc_node_rectifier(o);
+  spr_sweeps(o, 1, spr_dist, o->best);
+  return o->best;
+}
+
+void orc_counters(const orc *o, unsigned long long *nv, unsigned long long *ev, unsigned long long *ts)
+{
+  if (nv) *nv = o->c_newview;
+  if (ev) *ev = o->c_eval;
+  if (ts) *ts = o->c_test;
+}

@@ -1,0 +1,74 @@
+/*
+ * fitch_oracle.h -- CPU restatement of the reference's Fitch parsimony path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (libmpfitch.so) never
+ * links, loads or calls it.
+ *
+ * It follows the reference's own algorithm (one vector per node, lazy
+ * re-orientation through per-record xPars flags, traversal descriptors, one
+ * insertion test at a time) on a flat-array data model of our own, each function
+ * citing the reference lines it restates.  Parity status: PINNED -- checked
+ * against the reference's PLL parsimony path compiled from its sources
+ * (oracle/_ref/pll_ref_driver, see oracle/Makefile) on the fixtures under
+ * tests/golden/, see tests/test_oracle_golden.py.
+ */
+#ifndef FITCH_ORACLE_H
+#define FITCH_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_DNA = 0, ORC_AA = 1 };
+enum { ORC_TIE_FIRST = 0,   /* PLL original: strict '<' (pllrepo/src/fastDNAparsimony.c:1224, :1803, :1925) */
+       ORC_TIE_RANDOM = 1 };/* mpboot: uniform random among ties (sprparsimony.cpp:2168-2176, :3001-3008, :3306-3311) */
+
+typedef struct orc orc;
+
+orc *orc_create(int n_taxa, int n_patterns, int datatype, const unsigned char *codes /* [n][P] PLL tip codes */,
+                const int *weights /* [P] */, int keep_all_sites);
+void orc_destroy(orc *o);
+int orc_words(const orc *o);                 /* parsimonyLength W */
+int orc_states(const orc *o);
+int orc_num_informative(const orc *o);
+const int *orc_informative(const orc *o);    /* [P] 0/1 */
+const uint32_t *orc_node_vector(const orc *o, int node); /* S*W words */
+void orc_set_weights(orc *o, const int *weights);        /* re-pack tips (ratchet / bootstrap re-weighting) */
+void orc_enable_persite(orc *o, int on);
+
+void orc_set_tree(orc *o, const int *back);  /* [3*(2n-1)] */
+void orc_get_tree(const orc *o, int *back);
+void orc_reset_nodep(orc *o);
+void orc_get_nodep(const orc *o, int *nodep /* [2n] */);
+void orc_node_rectifier(orc *o);
+unsigned orc_evaluate(orc *o, int rec, int full);
+unsigned orc_score_tree(orc *o);             /* nodeRectifier + evaluate(start, full) */
+int orc_pattern_scores(orc *o, unsigned short *ptn /* [P] */);  /* returns sum(ptn*weight) */
+
+void orc_seed_ties(orc *o, int tie_mode, int seed);
+void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg);
+
+/* trace of the insertion tests performed by the calls below: (q rec, mp), -1/-2 separators */
+void orc_trace(orc *o, int on);
+int orc_trace_len(const orc *o);
+void orc_trace_get(const orc *o, int *q, unsigned *mp);
+/* trace of accepted moves: (remove rec, insert rec, score) */
+int orc_moves_len(const orc *o);
+void orc_moves_get(const orc *o, int *rem, int *ins, unsigned *score);
+
+int orc_rearrange(orc *o, int rec, int mintrav, int maxtrav);   /* one prune node; updates best/insert/remove */
+void orc_set_best(orc *o, unsigned best);
+unsigned orc_get_best(const orc *o, int *remove_rec, int *insert_rec);
+unsigned orc_optimize_spr(orc *o, int mintrav, int maxtrav);     /* pllOptimizeSprParsimony */
+unsigned orc_make_tree(orc *o, long seed, int spr_dist, int *perm_out /* [n+1] or NULL */);
+/* stepwise addition only; per added taxon: best score and insertion record */
+unsigned orc_stepwise(orc *o, long seed, unsigned *best_per_step, int *insert_per_step);
+
+void orc_counters(const orc *o, unsigned long long *newviews, unsigned long long *evaluates, unsigned long long *tests);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
