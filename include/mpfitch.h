@@ -1,0 +1,155 @@
+/*
+ * mpfitch.h -- C-ABI of libmpfitch.so, the MI355X-native Fitch parsimony engine
+ * that sits behind the parsimony entry points of diepthihoang/mpboot.
+ *
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.  All
+ * state lives in an opaque engine handle that owns its HBM buffers.  Every
+ * call returns MPF_OK (0) or a negative MPF_E_* code; mpf_last_error() gives the
+ * text.  The library needs a HIP device: mpf_engine_create fails with
+ * MPF_E_NO_DEVICE when none is present -- there is no CPU fallback.
+ *
+ * Conventions shared with the reference (all file:line under the reference tree)
+ * ---------------------------------------------------------------------------
+ * tip codes   : PLL yVector bytes (pllrepo/src/utils.c:98-137): DNA = 4-bit state
+ *               masks 1..15 (15 = gap/N), protein = 0..22 (20 = B, 21 = Z, 22 = gap/X).
+ * weights     : tr->aliaswgt, one int per pattern (sprparsimony.cpp:2922-2943).
+ * topology    : `back` = int32[3*(2n-1)], record rec = 3*number + slot; number 1..n are
+ *               tips (slot 0), n+1..2n-2 inner nodes whose three slots form PLL's
+ *               `next` ring (slot -> (slot+1)%3); back[rec] is PLL's `->back`
+ *               (pllrepo/src/pll.h:622-701), -1 where unused.
+ * tie rule    : MPF_TIE_RANDOM = mpboot (sprparsimony.cpp:2168-2176, :3001-3008,
+ *               :3306-3311) drawing random_double(); MPF_TIE_FIRST = strict '<' as in
+ *               pllrepo/src/fastDNAparsimony.c:1224, :1803, :1925.
+ *
+ * Each entry point names the reference interface it replaces.
+ */
+#ifndef MPFITCH_H
+#define MPFITCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPF_ABI_VERSION 1
+
+enum {
+  MPF_OK = 0,
+  MPF_E_NO_DEVICE = -1,   /* no HIP device / HIP runtime failure at start-up            */
+  MPF_E_INVALID = -2,     /* bad argument (reference: assert / exit(EXIT_FAILURE))      */
+  MPF_E_HIP = -3,         /* a HIP call failed                                          */
+  MPF_E_NOMEM = -4,
+  MPF_E_STATE = -5,       /* call out of order (e.g. no tree set)                       */
+  MPF_E_UNSUPPORTED = -6  /* e.g. states outside {4,20}; reference sprparsimony.cpp:575 */
+};
+
+enum { MPF_DNA = 0, MPF_AA = 1 };
+enum { MPF_TIE_FIRST = 0, MPF_TIE_RANDOM = 1 };
+
+typedef struct mpf_engine mpf_engine;
+
+typedef struct mpf_config {
+  int32_t device;          /* HIP device ordinal                                         */
+  int32_t n_taxa;          /* tr->mxtips                                                 */
+  int32_t n_patterns;      /* tr->originalCrunchedLength                                 */
+  int32_t datatype;        /* MPF_DNA | MPF_AA                                           */
+  int32_t keep_all_sites;  /* 1 = !globalParam->sort_alignment (sprparsimony.cpp:2462)   */
+  int32_t reserved[3];
+} mpf_config;
+
+typedef struct mpf_stats {
+  uint64_t insertion_tests;   /* candidates scored (testInsertParsimony equivalents)     */
+  uint64_t newview_ops;       /* directional vectors recomputed                          */
+  uint64_t scan_launches;
+  uint64_t view_launches;
+  uint64_t moves_applied;
+  uint64_t algorithmic_bytes; /* 6*S*W*4 per insertion test + 3*S*W*4 per newview        */
+  double   last_scan_kernel_ms; /* HIP-event time of the most recent scan launch         */
+  double   scan_kernel_ms_total;
+  double   view_kernel_ms_total;
+} mpf_stats;
+
+const char *mpf_last_error(void);
+int mpf_abi_version(void);
+
+/* _allocateParsimonyDataStructures + compressDNA (sprparsimony.cpp:3032-3060, :2828-2973):
+   upload codes/weights, drop uninformative sites, bit-pack the tips in HBM. */
+int mpf_engine_create(mpf_engine **out, const mpf_config *cfg, const uint8_t *codes /* [n][P] */,
+                      const int32_t *weights /* [P] */);
+/* _pllFreeParsimonyDataStructures (sprparsimony.cpp:3062-3104) */
+void mpf_engine_destroy(mpf_engine *e);
+
+/* _updateInternalPllOnRatchet + re-allocate (sprparsimony.cpp:3022-3029, :3249-3252):
+   new pattern weights (ratchet / bootstrap replicate), tips re-packed on the device. */
+int mpf_set_weights(mpf_engine *e, const int32_t *weights);
+
+/* packing geometry and test hooks (tips as the reference lays them out, rows of W words) */
+int mpf_get_geometry(const mpf_engine *e, int32_t *states, int32_t *words_per_row /* W, multiple of 8 as the
+                     reference's parsimonyLength */, int32_t *n_informative, int32_t *words_padded);
+int mpf_get_informative(const mpf_engine *e, int32_t *flags /* [P] */);
+int mpf_get_tip_vector(mpf_engine *e, int32_t tip /* 1..n */, uint32_t *out /* [S][W] */);
+
+/* pllTreeInitTopologyNewick's result, handed over as record links instead of a Newick string
+   (iqtree.cpp:2127-2129). */
+int mpf_set_tree(mpf_engine *e, const int32_t *back);
+int mpf_get_tree(const mpf_engine *e, int32_t *back);
+/* tr->nodep[] as left by earlier calls matters to the reference's visiting order
+   (sprparsimony.cpp:2046-2101); this resets it to the state of a fresh PLL instance. */
+int mpf_reset_node_order(mpf_engine *e);
+
+/* evaluateParsimony(tr, pr, tr->start, PLL_TRUE) (sprparsimony.cpp:1889-1917, :3277):
+   Fitch length of the current tree. */
+int mpf_score_tree(mpf_engine *e, uint32_t *score);
+/* the same for many topologies in one call (replicates / candidate trees) */
+int mpf_score_trees(mpf_engine *e, int32_t n_trees, const int32_t *backs, uint32_t *scores);
+
+/* pllComputePatternParsimony (sprparsimony.cpp:3363-3392): per-pattern Fitch lengths of the
+   current tree, ptn_pars[P] (0 for dropped patterns); *total = sum(ptn * weight). */
+int mpf_pattern_scores(mpf_engine *e, uint16_t *ptn_pars, int32_t *total);
+
+/* random_double() source for MPF_TIE_RANDOM.  Default: our restatement of the SPRNG lcg64
+   stream the reference creates in init_random(seed) (tools.cpp:3320-3331).  A host that
+   wants to share ITS stream passes a callback (drop-in inside mpboot: random_double). */
+int mpf_seed_ties(mpf_engine *e, int32_t tie_mode, int32_t seed);
+int mpf_set_rand_callback(mpf_engine *e, double (*fn)(void *), void *arg);
+
+/* rearrangeParsimony(tr, pr, p, mintrav, maxtrav) candidates (sprparsimony.cpp:2259-2376):
+   every insertion test of prune record `rec`, in the reference's DFS order (p side, then q
+   side); q_recs[i] = record q of testInsertParsimony(p, q), mp[i] = tree length after the move.
+   *n_p = number of p-side candidates.  Does not change the tree. */
+int mpf_spr_scan(mpf_engine *e, int32_t rec, int32_t mintrav, int32_t maxtrav, int32_t cap,
+                 int32_t *q_recs, uint32_t *mp, int32_t *n_p, int32_t *n_total);
+
+/* one full sweep of scans over every prune node of the current tree WITHOUT applying moves:
+   the throughput primitive bench.py times.  Returns the number of insertion tests and the
+   minimum mp seen. */
+int mpf_spr_sweep_scan(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint64_t *n_tests, uint32_t *min_mp);
+
+/* int pllOptimizeSprParsimony(tr, pr, mintrav, maxtrav, iqtree) (sprparsimony.cpp:3244-3319):
+   SPR hill climb on the current tree until no sweep improves; the tree is modified in place
+   (read it back with mpf_get_tree).  *score = final length (tr->bestParsimony); the function's
+   own return value in the reference (startMP) equals it. */
+int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *score);
+
+/* _pllComputeRandomizedStepwiseAdditionParsimonyTree(tr, pr, sprDist, iqtree)
+   (sprparsimony.cpp:3224-3235, :3107-3209): random addition order from PLL randum(seed),
+   stepwise addition, then SPR sweeps with radius spr_dist. */
+int mpf_make_parsimony_tree(mpf_engine *e, int64_t seed, int32_t spr_dist, uint32_t *score);
+/* stepwise addition only, with the per-taxon checkpoints (best length, insertion record) */
+int mpf_stepwise_addition(mpf_engine *e, int64_t seed, uint32_t *best_per_step /* [n+1] */,
+                          int32_t *insert_per_step /* [n+1] */, uint32_t *score);
+
+/* accepted moves of the last mpf_optimize_spr / mpf_make_parsimony_tree: (remove rec, insert rec, length) */
+int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t *insert_rec, uint32_t *score,
+                  int32_t *n_moves);
+
+int mpf_get_stats(const mpf_engine *e, mpf_stats *out);
+int mpf_reset_stats(mpf_engine *e);
+/* tuning knobs: "scan_batch" (prune nodes speculated per launch), "words_per_lane" (1|2|4) */
+int mpf_set_option(mpf_engine *e, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPFITCH_H */

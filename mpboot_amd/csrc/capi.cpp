@@ -1,0 +1,162 @@
+// capi.cpp -- the extern "C" boundary declared in include/mpfitch.h.
+#include <cstring>
+#include <new>
+
+#include "engine.hpp"
+
+namespace mpf { const std::string &last_error(); }
+
+struct mpf_engine {
+  mpf::Engine eng;
+};
+
+using mpf::set_error;
+
+#define NEED(e) do { if (!(e)) { set_error("null engine handle"); return MPF_E_INVALID; } } while (0)
+
+extern "C" {
+
+const char *mpf_last_error(void) { return mpf::last_error().c_str(); }
+int mpf_abi_version(void) { return MPF_ABI_VERSION; }
+
+int mpf_engine_create(mpf_engine **out, const mpf_config *cfg, const uint8_t *codes, const int32_t *weights)
+{
+  if (!out || !cfg) { set_error("mpf_engine_create: null argument"); return MPF_E_INVALID; }
+  *out = nullptr;
+  mpf_engine *e = new (std::nothrow) mpf_engine();
+  if (!e) { set_error("out of host memory"); return MPF_E_NOMEM; }
+  int rc = e->eng.init(*cfg, codes, weights);
+  if (rc != MPF_OK) { delete e; return rc; }
+  *out = e;
+  return MPF_OK;
+}
+
+void mpf_engine_destroy(mpf_engine *e) { delete e; }
+
+int mpf_set_weights(mpf_engine *e, const int32_t *weights)
+{
+  NEED(e);
+  if (!weights) { set_error("null weights"); return MPF_E_INVALID; }
+  return e->eng.set_weights(weights);
+}
+
+int mpf_get_geometry(const mpf_engine *e, int32_t *states, int32_t *words_per_row, int32_t *n_informative, int32_t *words_padded)
+{
+  NEED(e);
+  if (states) *states = e->eng.S();
+  if (words_per_row) *words_per_row = e->eng.Wref();
+  if (n_informative) *n_informative = e->eng.n_informative();
+  if (words_padded) *words_padded = e->eng.Wp();
+  return MPF_OK;
+}
+
+int mpf_get_informative(const mpf_engine *e, int32_t *flags)
+{
+  NEED(e);
+  const auto &v = e->eng.informative();
+  std::memcpy(flags, v.data(), v.size() * sizeof(int32_t));
+  return MPF_OK;
+}
+
+int mpf_get_tip_vector(mpf_engine *e, int32_t tip, uint32_t *out) { NEED(e); return e->eng.tip_vector(tip, out); }
+
+int mpf_set_tree(mpf_engine *e, const int32_t *back)
+{
+  NEED(e);
+  if (!back) { set_error("null topology"); return MPF_E_INVALID; }
+  return e->eng.set_tree(back);
+}
+
+int mpf_get_tree(const mpf_engine *e, int32_t *back) { NEED(e); e->eng.get_tree(back); return MPF_OK; }
+int mpf_reset_node_order(mpf_engine *e) { NEED(e); e->eng.reset_node_order(); return MPF_OK; }
+int mpf_score_tree(mpf_engine *e, uint32_t *score) { NEED(e); return e->eng.score_tree(score); }
+
+int mpf_score_trees(mpf_engine *e, int32_t n_trees, const int32_t *backs, uint32_t *scores)
+{
+  NEED(e);
+  const size_t len = 3 * (size_t)(2 * e->eng.n() - 1);
+  for (int t = 0; t < n_trees; t++) {
+    int rc = e->eng.set_tree(backs + (size_t)t * len);
+    if (rc) return rc;
+    rc = e->eng.score_tree(scores + t);
+    if (rc) return rc;
+  }
+  return MPF_OK;
+}
+
+int mpf_pattern_scores(mpf_engine *e, uint16_t *ptn_pars, int32_t *total) { NEED(e); return e->eng.pattern_scores(ptn_pars, total); }
+
+int mpf_seed_ties(mpf_engine *e, int32_t tie_mode, int32_t seed)
+{
+  NEED(e);
+  if (tie_mode != MPF_TIE_FIRST && tie_mode != MPF_TIE_RANDOM) { set_error("bad tie mode"); return MPF_E_INVALID; }
+  e->eng.seed_ties(tie_mode, seed);
+  return MPF_OK;
+}
+
+int mpf_set_rand_callback(mpf_engine *e, double (*fn)(void *), void *arg) { NEED(e); e->eng.set_rand(fn, arg); return MPF_OK; }
+
+int mpf_spr_scan(mpf_engine *e, int32_t rec, int32_t mintrav, int32_t maxtrav, int32_t cap, int32_t *q_recs,
+                 uint32_t *mp, int32_t *n_p, int32_t *n_total)
+{
+  NEED(e);
+  std::vector<int32_t> q;
+  std::vector<uint32_t> m;
+  int np = 0;
+  int rc = e->eng.spr_scan(rec, mintrav, maxtrav, q, m, np);
+  if (rc) return rc;
+  if (n_total) *n_total = (int32_t)q.size();
+  if (n_p) *n_p = np;
+  if ((int)q.size() > cap) { set_error("mpf_spr_scan: output capacity too small"); return MPF_E_INVALID; }
+  if (!q.empty()) {
+    std::memcpy(q_recs, q.data(), q.size() * sizeof(int32_t));
+    std::memcpy(mp, m.data(), m.size() * sizeof(uint32_t));
+  }
+  return MPF_OK;
+}
+
+int mpf_spr_sweep_scan(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint64_t *n_tests, uint32_t *min_mp)
+{
+  NEED(e);
+  return e->eng.sweep_scan(mintrav, maxtrav, n_tests, min_mp);
+}
+
+int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *score) { NEED(e); return e->eng.optimize_spr(mintrav, maxtrav, score); }
+
+int mpf_make_parsimony_tree(mpf_engine *e, int64_t seed, int32_t spr_dist, uint32_t *score)
+{
+  NEED(e);
+  return e->eng.make_parsimony_tree(seed, spr_dist, score);
+}
+
+int mpf_stepwise_addition(mpf_engine *e, int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step, uint32_t *score)
+{
+  NEED(e);
+  return e->eng.stepwise_addition(seed, best_per_step, insert_per_step, score);
+}
+
+int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t *insert_rec, uint32_t *score, int32_t *n_moves)
+{
+  NEED(e);
+  const auto &mv = e->eng.moves();
+  if (n_moves) *n_moves = (int32_t)mv.size();
+  const size_t k = std::min((size_t)std::max(cap, 0), mv.size());
+  for (size_t i = 0; i < k; i++) {
+    if (remove_rec) remove_rec[i] = mv[i].remove_rec;
+    if (insert_rec) insert_rec[i] = mv[i].insert_rec;
+    if (score) score[i] = mv[i].score;
+  }
+  return MPF_OK;
+}
+
+int mpf_get_stats(const mpf_engine *e, mpf_stats *out) { NEED(e); *out = e->eng.stats; return MPF_OK; }
+int mpf_reset_stats(mpf_engine *e) { NEED(e); e->eng.stats = mpf_stats{}; return MPF_OK; }
+
+int mpf_set_option(mpf_engine *e, const char *key, int64_t value)
+{
+  NEED(e);
+  if (!key) { set_error("null option key"); return MPF_E_INVALID; }
+  return e->eng.set_option(key, value);
+}
+
+}  // extern "C"

@@ -1,0 +1,489 @@
+// engine.cpp -- device state, tip packing, directional views and SPR-scan programs.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+
+namespace mpf {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const std::string &last_error() { return g_err; }
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" +      \
+                std::to_string(__LINE__) + ")");                                                  \
+      return MPF_E_HIP;                                                                           \
+    }                                                                                             \
+  } while (0)
+
+Engine::~Engine()
+{
+  if (d_codes_) (void)hipFree(d_codes_);
+  if (d_vec_) (void)hipFree(d_vec_);
+  if (d_cnt_) (void)hipFree(d_cnt_);
+  if (d_tipslots_) (void)hipFree(d_tipslots_);
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (st_) (void)hipStreamDestroy(st_);
+}
+
+int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *weights)
+{
+  if (cfg.n_taxa < 4 || cfg.n_patterns < 1 || !codes || !weights) {
+    set_error("mpf_engine_create: need n_taxa >= 4, n_patterns >= 1, codes and weights");
+    return MPF_E_INVALID;
+  }
+  if (cfg.datatype != MPF_DNA && cfg.datatype != MPF_AA) {
+    set_error("mpf_engine_create: only DNA (4 states) and protein (20 states) are supported");
+    return MPF_E_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available: libmpfitch has no CPU fallback");
+    return MPF_E_NO_DEVICE;
+  }
+  if (cfg.device < 0 || cfg.device >= ndev) {
+    set_error("mpf_engine_create: device ordinal out of range");
+    return MPF_E_INVALID;
+  }
+  dev_ = cfg.device;
+  HIPCHK(hipSetDevice(dev_));
+  n_ = cfg.n_taxa;
+  P_ = cfg.n_patterns;
+  datatype_ = cfg.datatype;
+  keep_all_ = cfg.keep_all_sites;
+  g_.S = datatype_ == MPF_DNA ? 4 : 20;
+  g_.vw = 1;
+  g_.reduce = 0;
+  g_.map = 0;
+  const int und = datatype_ == MPF_DNA ? 15 : 22;
+  for (size_t i = 0; i < (size_t)n_ * P_; i++)
+    if (codes[i] > und || (datatype_ == MPF_DNA && codes[i] == 0)) {
+      set_error("mpf_engine_create: tip code outside the PLL alphabet");   // reference: assert(bitVector[nucleotide] > 0)
+      return MPF_E_INVALID;
+    }
+  codes_.assign(codes, codes + (size_t)n_ * P_);
+  wgt_.assign(weights, weights + P_);
+  inf_.assign(P_, 0);
+  first_site_.assign(P_, -1);
+  HIPCHK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&ev0_));
+  HIPCHK(hipEventCreate(&ev1_));
+  HIPCHK(hipMalloc((void **)&d_codes_, (size_t)n_ * P_));
+  HIPCHK(hipMemcpy(d_codes_, codes_.data(), (size_t)n_ * P_, hipMemcpyHostToDevice));
+  nslots_ = (size_t)n_ + 3 * (size_t)(n_ - 1);
+  HIPCHK(hipMalloc((void **)&d_cnt_, nslots_ * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void **)&d_tipslots_, (size_t)n_ * sizeof(uint32_t)));
+  {
+    std::vector<uint32_t> ts(n_);
+    for (int i = 0; i < n_; i++) ts[i] = (uint32_t)i;
+    HIPCHK(hipMemcpy(d_tipslots_, ts.data(), n_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  HIPCHK(h_cnt_.reserve(nslots_));
+  back_.assign(3 * (size_t)(2 * n_ - 1) + 3, -1);
+  nodep_.assign(2 * (size_t)n_, 0);
+  sc_.assign(back_.size(), 0);
+  reset_node_order();
+  rng_.seed(1);
+  return pack();
+}
+
+// ---- determineUninformativeSites + compressDNA (reference sprparsimony.cpp:2460-2499, :2596-2634, :2828-2973)
+// The filter runs on the host (one pass over the codes); the bit transposition runs on the device.
+int Engine::pack()
+{
+  const int und = datatype_ == MPF_DNA ? 15 : 22;
+  long entries = 0;
+  ninf_ = 0;
+  for (int s = 0; s < P_; s++) {
+    int keep = 1;
+    if (!keep_all_) {
+      bool seen[32] = {false};
+      int distinct = 0;
+      for (int t = 0; t < n_; t++) {
+        const int c = codes_[(size_t)t * P_ + s];
+        if (c < und && !seen[c]) { seen[c] = true; distinct++; }
+      }
+      keep = distinct > 1;
+    }
+    inf_[s] = keep;
+    if (wgt_[s] < 0) { set_error("negative pattern weight"); return MPF_E_INVALID; }
+    if (keep) { first_site_[s] = (int32_t)entries; entries += wgt_[s]; ninf_++; } else first_site_[s] = -1;
+  }
+  nsites_ = (int)entries;
+  const int ce = (int)((entries + 31) / 32);
+  Wref_ = (ce % 8) ? ce + (8 - ce % 8) : ce;           // the reference's parsimonyLength (AVX build)
+  int wp = ((ce + 31) / 32) * 32;                      // our row pitch: whole 128-byte lines
+  if (wp == 0) wp = 32;
+  if (wp != g_.Wp || !d_vec_) {
+    if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
+    g_.Wp = wp;
+    vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
+    HIPCHK(hipMalloc((void **)&d_vec_, vec_words_ * sizeof(uint32_t)));
+  }
+  std::vector<int32_t> s2p((size_t)std::max(nsites_, 1));
+  for (int s = 0; s < P_; s++)
+    if (inf_[s])
+      for (int w = 0; w < wgt_[s]; w++) s2p[(size_t)first_site_[s] + w] = s;
+  HIPCHK(d_site2ptn_.reserve(s2p.size()));
+  HIPCHK(hipMemcpyAsync(d_site2ptn_.p, s2p.data(), s2p.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  HIPCHK(launch_pack_tips(st_, g_, d_vec_, d_codes_, n_, P_, d_site2ptn_.p, nsites_, datatype_, d_tipslots_));
+  HIPCHK(hipStreamSynchronize(st_));
+  views_valid_ = false;
+  return MPF_OK;
+}
+
+int Engine::set_weights(const int32_t *weights)
+{
+  wgt_.assign(weights, weights + P_);
+  return pack();
+}
+
+int Engine::tip_vector(int tipno, uint32_t *out)
+{
+  if (tipno < 1 || tipno > n_) { set_error("tip out of range"); return MPF_E_INVALID; }
+  std::vector<uint32_t> tmp((size_t)g_.S * g_.Wp);
+  HIPCHK(hipMemcpy(tmp.data(), d_vec_ + (size_t)(tipno - 1) * g_.S * g_.Wp, tmp.size() * sizeof(uint32_t),
+                   hipMemcpyDeviceToHost));
+  // hand back rows of the reference's length W (its padding words are all ones as well)
+  for (int k = 0; k < g_.S; k++)
+    for (int w = 0; w < Wref_; w++) out[(size_t)k * Wref_ + w] = w < g_.Wp ? tmp[(size_t)k * g_.Wp + w] : 0xFFFFFFFFu;
+  return MPF_OK;
+}
+
+// ---- tree plumbing
+void Engine::reset_node_order()
+{
+  for (int i = 1; i <= 2 * n_ - 1; i++) nodep_[i] = 3 * i;
+}
+
+int Engine::set_tree(const int32_t *back)
+{
+  const size_t len = 3 * (size_t)(2 * n_ - 1);
+  for (int v = 1; v <= 2 * n_ - 2; v++)
+    for (int s = 0; s < (v <= n_ ? 1 : 3); s++) {
+      const int r = 3 * v + s, b = back[r];
+      if (b < 3 || b >= (int)len || back[b] != r) { set_error("mpf_set_tree: inconsistent back links"); return MPF_E_INVALID; }
+    }
+  std::copy(back, back + len, back_.begin());
+  start_ = nodep_[1];
+  ntips_ = n_;
+  have_tree_ = true;
+  views_valid_ = false;
+  return MPF_OK;
+}
+
+void Engine::get_tree(int32_t *back) const { std::copy(back_.begin(), back_.begin() + 3 * (size_t)(2 * n_ - 1), back); }
+
+// reorderNodes / nodeRectifierPars (reference sprparsimony.cpp:2046-2101): nodep[n+1+k] = the record by
+// which the k-th inner node is entered in a preorder walk from start->back
+void Engine::node_rectifier()
+{
+  start_ = nodep_[1];
+  int count = 0;
+  std::vector<int> stack;
+  stack.push_back(back_[start_]);
+  while (!stack.empty()) {
+    const int p = stack.back();
+    stack.pop_back();
+    if (tip(p)) continue;
+    nodep_[count + n_ + 1] = p;
+    count++;
+    stack.push_back(back_[nx(nx(p))]);
+    stack.push_back(back_[nx(p)]);
+  }
+}
+
+// ---- directional views ---------------------------------------------------------------------
+// vec[r] (r inner) = fitch(vec[back[nx r]], vec[back[nx nx r]]); dependency levels are launched
+// one after another on the engine stream (each level is one k_newview launch).
+int Engine::update_views()
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  // inner nodes of the component containing start_
+  std::vector<int> inner;
+  {
+    std::vector<int> stack;
+    std::vector<char> seen(2 * (size_t)n_ + 1, 0);
+    stack.push_back(back_[start_]);
+    if (tip(back_[start_]) ) { /* two-tip tree: nothing to do */ }
+    while (!stack.empty()) {
+      const int r = stack.back();
+      stack.pop_back();
+      if (r < 0 || tip(r) || seen[num(r)]) continue;
+      seen[num(r)] = 1;
+      inner.push_back(num(r));
+      for (int s = 0; s < 3; s++) stack.push_back(back_[3 * num(r) + s]);
+    }
+  }
+  // level of every inner record, iterative post-order with memo
+  std::vector<int> level(back_.size(), -1);
+  std::vector<int> order;                  // records in dependency order
+  order.reserve(inner.size() * 3);
+  std::vector<std::pair<int, int>> stack;  // (record, state)
+  for (int v : inner)
+    for (int s = 0; s < 3; s++) {
+      const int r0 = 3 * v + s;
+      if (level[r0] >= 0) continue;
+      stack.emplace_back(r0, 0);
+      while (!stack.empty()) {
+        auto &top = stack.back();
+        const int r = top.first;
+        const int a = back_[nx(r)], b = back_[nx(nx(r))];
+        if (top.second == 0) {
+          top.second = 1;
+          if (!tip(a) && level[a] < 0) stack.emplace_back(a, 0);
+          continue;
+        }
+        if (top.second == 1) {
+          top.second = 2;
+          if (!tip(b) && level[b] < 0) stack.emplace_back(b, 0);
+          continue;
+        }
+        const int la = tip(a) ? 0 : level[a], lb = tip(b) ? 0 : level[b];
+        level[r] = 1 + std::max(la, lb);
+        order.push_back(r);
+        stack.pop_back();
+      }
+    }
+  int maxlev = 0;
+  for (int r : order) maxlev = std::max(maxlev, level[r]);
+  std::vector<int> lev_count(maxlev + 2, 0);
+  for (int r : order) lev_count[level[r]]++;
+  std::vector<int> lev_off(maxlev + 2, 0);
+  for (int l = 1; l <= maxlev; l++) lev_off[l + 1] = lev_off[l] + lev_count[l];
+  const size_t nops = order.size();
+  HIPCHK(h_nvops_.reserve(nops));
+  HIPCHK(d_nvops_.reserve(nops));
+  {
+    std::vector<int> fill(lev_off);
+    for (int r : order) {
+      NvOp &o = h_nvops_.p[fill[level[r]]++];
+      o.dst = slot(r);
+      o.a = slot(back_[nx(r)]);
+      o.b = slot(back_[nx(nx(r))]);
+      o.pad = (uint32_t)r;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(d_nvops_.p, h_nvops_.p, nops * sizeof(NvOp), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemsetAsync(d_cnt_, 0, nslots_ * sizeof(uint32_t), st_));
+  HIPCHK(hipEventRecord(ev0_, st_));
+  for (int l = 1; l <= maxlev; l++) {
+    HIPCHK(launch_newview(st_, g_, d_vec_, d_nvops_.p + lev_off[l], lev_count[l], d_cnt_));
+    stats.view_launches++;
+  }
+  HIPCHK(hipEventRecord(ev1_, st_));
+  HIPCHK(hipMemcpyAsync(h_cnt_.p, d_cnt_, nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(hipStreamSynchronize(st_));
+  {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) stats.view_kernel_ms_total += ms;
+  }
+  stats.newview_ops += nops;
+  stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  // subtree scores in dependency order (reference: tr->parsimonyScore[p] = total + score[q] + score[r], :874)
+  for (size_t i = 0; i < nops; i++) {
+    const int r = (int)h_nvops_.p[i].pad;
+    const int a = back_[nx(r)], b = back_[nx(nx(r))];
+    sc_[r] = h_cnt_.p[slot(r)] + (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]);
+  }
+  views_valid_ = true;
+  return MPF_OK;
+}
+
+// Fitch length of the current tree = score(x) + score(back x) + #empty(vec x, vec back x) on any branch;
+// on the branch start--back[start] (start is a tip) that is score(back[start]) + one evaluate.
+int Engine::tree_length(uint32_t *len)
+{
+  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+  const int a = start_, b = back_[start_];
+  EvOp op{slot(a), slot(b), 0, 0};
+  HIPCHK(d_evops_.reserve(1));
+  HIPCHK(d_out_.reserve(1));
+  HIPCHK(h_out_.reserve(1));
+  HIPCHK(hipMemcpyAsync(d_evops_.p, &op, sizeof(op), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemsetAsync(d_out_.p, 0, sizeof(uint32_t), st_));
+  HIPCHK(launch_evaluate(st_, g_, d_vec_, d_evops_.p, 1, d_out_.p));
+  HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(hipStreamSynchronize(st_));
+  tree_len_ = (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]) + h_out_.p[0];
+  *len = tree_len_;
+  return MPF_OK;
+}
+
+int Engine::score_tree(uint32_t *score)
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  node_rectifier();
+  views_valid_ = false;
+  return tree_length(score);
+}
+
+// ---- SPR scan programs ------------------------------------------------------------------------
+// addTraverseParsimony (reference sprparsimony.cpp:2208-2218) turned into a list of chain steps
+void Engine::add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan)
+{
+  const bool test = (--mintrav <= 0);
+  ScanOp o;
+  o.own = slot(q);
+  o.sib = slot(sib);
+  o.meta = (uint32_t)depth | ((test ? 1u : 0u) << 8) | ((uint32_t)SCAN_CHAIN << 16);
+  o.out = test ? prog_out_ : 0u;
+  prog_ops_.push_back(o);
+  prog_max_depth_ = std::max(prog_max_depth_, depth);
+  if (test) plan.cands.push_back(Candidate{q, prog_out_++});
+  if (!tip(q) && --maxtrav > 0) {
+    const int c1 = back_[nx(q)], c2 = back_[nx(nx(q))];
+    add_traverse(c1, c2, depth + 1, mintrav, maxtrav, plan);
+    add_traverse(c2, c1, depth + 1, mintrav, maxtrav, plan);
+  }
+}
+
+// rearrangeParsimony (reference sprparsimony.cpp:2259-2376) as two scan programs (p side, q side)
+int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
+{
+  plan.rec = p;
+  plan.cands.clear();
+  plan.n_p = 0;
+  if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
+  if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
+  if (maxtrav > kMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
+  const int q = back_[p];
+  plan.base = (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);
+  if (maxtrav < mintrav) return MPF_OK;
+  auto one_side = [&](int x, int mt) {
+    const int x1 = back_[nx(x)], x2 = back_[nx(nx(x))];
+    ScanHdr h;
+    h.op_begin = (uint32_t)prog_ops_.size();
+    h.s_slot = slot(back_[x]);
+    h.pad = 0;
+    auto side = [&](int a, int other) {
+      if (tip(a)) return;
+      ScanOp r;
+      r.own = slot(other);
+      r.sib = 0;
+      r.meta = (uint32_t)SCAN_ROOT << 16;
+      r.out = 0;
+      prog_ops_.push_back(r);
+      const int c1 = back_[nx(a)], c2 = back_[nx(nx(a))];
+      add_traverse(c1, c2, 1, mt, maxtrav, plan);
+      add_traverse(c2, c1, 1, mt, maxtrav, plan);
+    };
+    side(x1, x2);
+    side(x2, x1);
+    h.op_end = (uint32_t)prog_ops_.size();
+    if (h.op_end > h.op_begin) prog_hdr_.push_back(h);
+  };
+  if (!tip(p)) {
+    const int p1 = back_[nx(p)], p2 = back_[nx(nx(p))];
+    if (!tip(p1) || !tip(p2)) one_side(p, mintrav);
+  }
+  plan.n_p = (int)plan.cands.size();
+  if (!tip(q) && maxtrav > 0) {
+    const int q1 = back_[nx(q)], q2 = back_[nx(nx(q))];
+    if ((!tip(q1) && (!tip(back_[nx(q1)]) || !tip(back_[nx(nx(q1))]))) ||
+        (!tip(q2) && (!tip(back_[nx(q2)]) || !tip(back_[nx(nx(q2))]))))
+      one_side(q, mintrav > 2 ? mintrav : 2);
+  }
+  return MPF_OK;
+}
+
+int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host)
+{
+  (void)plans;
+  const size_t nops = prog_ops_.size(), nh = prog_hdr_.size(), nout = prog_out_;
+  out_host.assign(nout, 0);
+  if (nh == 0 || nout == 0) { prog_ops_.clear(); prog_hdr_.clear(); prog_out_ = 0; prog_max_depth_ = 0; return MPF_OK; }
+  HIPCHK(d_scanops_.reserve(nops));
+  HIPCHK(d_scanhdr_.reserve(nh));
+  HIPCHK(d_out_.reserve(nout));
+  HIPCHK(h_out_.reserve(nout));
+  HIPCHK(hipMemcpyAsync(d_scanops_.p, prog_ops_.data(), nops * sizeof(ScanOp), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemcpyAsync(d_scanhdr_.p, prog_hdr_.data(), nh * sizeof(ScanHdr), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemsetAsync(d_out_.p, 0, nout * sizeof(uint32_t), st_));
+  HIPCHK(hipEventRecord(ev0_, st_));
+  HIPCHK(launch_scan(st_, g_, d_vec_, d_scanhdr_.p, (int)nh, d_scanops_.p, d_out_.p, prog_max_depth_));
+  HIPCHK(hipEventRecord(ev1_, st_));
+  HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(hipStreamSynchronize(st_));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+  std::copy(h_out_.p, h_out_.p + nout, out_host.begin());
+  stats.scan_launches++;
+  stats.insertion_tests += nout;
+  stats.algorithmic_bytes += (uint64_t)nout * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  prog_ops_.clear();
+  prog_hdr_.clear();
+  prog_out_ = 0;
+  prog_max_depth_ = 0;
+  return MPF_OK;
+}
+
+int Engine::spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p)
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  if (rec < 3 || rec >= 3 * (2 * n_ - 1) || back_[rec] < 0) { set_error("bad prune record"); return MPF_E_INVALID; }
+  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+  std::vector<ScanPlan> plans(1);
+  int rc = plan_scan(rec, mintrav, maxtrav, plans[0]);
+  if (rc) return rc;
+  std::vector<uint32_t> out;
+  rc = run_scans(plans, out);
+  if (rc) return rc;
+  q.clear();
+  mp.clear();
+  for (const Candidate &c : plans[0].cands) { q.push_back(c.q); mp.push_back(plans[0].base + out[c.out]); }
+  n_p = plans[0].n_p;
+  return MPF_OK;
+}
+
+int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp)
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  node_rectifier();
+  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+  std::vector<ScanPlan> plans(2 * (size_t)n_ - 2);
+  for (int i = 1; i <= 2 * n_ - 2; i++) {
+    int rc = plan_scan(nodep_[i], mintrav, maxtrav, plans[i - 1]);
+    if (rc) return rc;
+  }
+  std::vector<uint32_t> out;
+  int rc = run_scans(plans, out);
+  if (rc) return rc;
+  uint32_t best = UINT_MAX;
+  uint64_t tests = 0;
+  for (const ScanPlan &pl : plans)
+    for (const Candidate &c : pl.cands) { best = std::min(best, pl.base + out[c.out]); tests++; }
+  if (n_tests) *n_tests = tests;
+  if (min_mp) *min_mp = best;
+  return MPF_OK;
+}
+
+int Engine::pattern_scores(uint16_t *ptn, int32_t *total)
+{
+  (void)ptn; (void)total;
+  set_error("mpf_pattern_scores: not implemented yet");
+  return MPF_E_UNSUPPORTED;
+}
+
+int Engine::set_option(const std::string &key, int64_t v)
+{
+  if (key == "scan_batch") { if (v < 1) return MPF_E_INVALID; scan_batch_ = (int)v; return MPF_OK; }
+  if (key == "words_per_lane") {
+    if (!(v == 1 || v == 2 || v == 4) || (g_.S == 20 && v == 4)) { set_error("words_per_lane: 1|2|4 (protein: 1|2)"); return MPF_E_INVALID; }
+    g_.vw = (int)v;
+    return MPF_OK;
+  }
+  if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
+  if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
+  set_error("unknown option " + key);
+  return MPF_E_INVALID;
+}
+
+}  // namespace mpf

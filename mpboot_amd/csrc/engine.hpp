@@ -1,0 +1,183 @@
+// engine.hpp -- host side of the MI355X Fitch engine (one instance = one alignment on one GPU).
+//
+// The engine keeps, for the CURRENT tree, every directional vector in HBM: for each node
+// record r the Fitch state sets of the subtree seen when looking from back[r] towards r
+// (tips: the packed tip itself).  With those resident, every quantity the reference obtains
+// by lazy re-orientation (xPars flags, sprparsimony.cpp:420-467) is a pure function of
+// already-computed vectors, so whole neighbourhoods of SPR candidates are scored by one
+// launch (kernels.hip, k_scan) and the host only replays the reference's accept/tie logic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mpfitch.h"
+#include "../host/rng.hpp"
+#include "kernels.hpp"
+
+namespace mpf {
+
+void set_error(const std::string &msg);
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap) return hipSuccess;
+    release();
+    size_t want = n + n / 2 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+};
+
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  ~PinBuf() { release(); }
+  void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap) return hipSuccess;
+    release();
+    size_t want = n + n / 2 + 64;
+    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+};
+
+struct Candidate {
+  int32_t q;       // record q of testInsertParsimony(p, q)
+  uint32_t out;    // index into the scan output buffer
+};
+
+// the insertion tests of one prune record, in the reference's order
+struct ScanPlan {
+  int32_t rec = -1;
+  uint32_t base = 0;        // length(rest) + length(pruned subtree)
+  int n_p = 0;              // candidates of the p side come first
+  std::vector<Candidate> cands;
+};
+
+struct Move { int32_t remove_rec, insert_rec; uint32_t score; };
+
+class Engine {
+ public:
+  Engine() = default;
+  ~Engine();
+  int init(const mpf_config &cfg, const uint8_t *codes, const int32_t *weights);
+
+  // ---- alignment
+  int set_weights(const int32_t *weights);
+  int tip_vector(int tip, uint32_t *out);
+  int n() const { return n_; }
+  int P() const { return P_; }
+  int S() const { return g_.S; }
+  int Wref() const { return Wref_; }
+  int Wp() const { return g_.Wp; }
+  int n_informative() const { return ninf_; }
+  const std::vector<int32_t> &informative() const { return inf_; }
+
+  // ---- tree state (mirrors the PLL instance: back links, nodep order, start)
+  int set_tree(const int32_t *back);
+  void get_tree(int32_t *back) const;
+  void reset_node_order();
+  void node_rectifier();                       // sprparsimony.cpp:2046-2101
+
+  // ---- scoring
+  int score_tree(uint32_t *score);             // evaluateParsimony(start, full)
+  int pattern_scores(uint16_t *ptn, int32_t *total);
+  int update_views();                          // all directional vectors of the current tree
+  int tree_length(uint32_t *len);              // from valid views
+
+  // ---- SPR neighbourhoods
+  int plan_scan(int rec, int mintrav, int maxtrav, ScanPlan &plan);   // appends ops to the staging program
+  int run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host);
+  int spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p);
+  int sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp);
+
+  // ---- search (host/search.cpp)
+  void seed_ties(int mode, int seed) { tie_mode_ = mode; rng_.seed(seed); }
+  void set_rand(double (*fn)(void *), void *arg) { rand_fn_ = fn; rand_arg_ = arg; }
+  int optimize_spr(int mintrav, int maxtrav, uint32_t *score);
+  int make_parsimony_tree(int64_t seed, int spr_dist, uint32_t *score);
+  int stepwise_addition(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step, uint32_t *score);
+  const std::vector<Move> &moves() const { return moves_; }
+
+  mpf_stats stats{};
+  int set_option(const std::string &key, int64_t v);
+
+ private:
+  // helpers
+  inline int num(int r) const { return r / 3; }
+  inline bool tip(int r) const { return r / 3 <= n_; }
+  static inline int nx(int r) { int v = r / 3, s = r % 3; return 3 * v + (s + 1) % 3; }
+  inline uint32_t slot(int r) const { int v = r / 3; return v <= n_ ? (uint32_t)(v - 1) : (uint32_t)(n_ + 3 * (v - n_ - 1) + r % 3); }
+  inline void hookup(int a, int b) { back_[a] = b; back_[b] = a; }
+  double tie_draw() { return rand_fn_ ? rand_fn_(rand_arg_) : rng_.next(); }
+
+  int pack();                                   // compressDNA on the device
+  void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
+  int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step);
+  void apply_move(int remove_rec, int insert_rec);
+
+  // ---- configuration / alignment
+  int n_ = 0, P_ = 0, datatype_ = 0, keep_all_ = 0, dev_ = 0;
+  Geometry g_{};
+  int Wref_ = 0, nsites_ = 0, ninf_ = 0;
+  std::vector<uint8_t> codes_;
+  std::vector<int32_t> wgt_, inf_, first_site_;
+  size_t nslots_ = 0, vec_words_ = 0;
+
+  hipStream_t st_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  uint8_t *d_codes_ = nullptr;
+  uint32_t *d_vec_ = nullptr, *d_cnt_ = nullptr, *d_tipslots_ = nullptr;
+  DevBuf<int32_t> d_site2ptn_;
+  DevBuf<NvOp> d_nvops_;
+  DevBuf<EvOp> d_evops_;
+  DevBuf<ScanOp> d_scanops_;
+  DevBuf<ScanHdr> d_scanhdr_;
+  DevBuf<uint32_t> d_out_;
+  PinBuf<uint32_t> h_cnt_, h_out_;
+  PinBuf<ScanOp> h_scanops_;
+  PinBuf<ScanHdr> h_scanhdr_;
+  PinBuf<NvOp> h_nvops_;
+
+  // staging program being built
+  std::vector<ScanOp> prog_ops_;
+  std::vector<ScanHdr> prog_hdr_;
+  uint32_t prog_out_ = 0;
+  int prog_max_depth_ = 0;
+
+  // ---- tree
+  std::vector<int32_t> back_, nodep_;
+  int start_ = 3, ntips_ = 0, nextnode_ = 0;
+  bool have_tree_ = false, views_valid_ = false;
+  std::vector<uint32_t> sc_;                    // directional subtree score per record
+  uint32_t tree_len_ = 0;
+
+  // ---- search state (reference globals: bestParsimony, insertNode, removeNode, bestTreeScoreHits)
+  uint32_t best_ = 0;
+  int insert_rec_ = -1, remove_rec_ = -1;
+  unsigned long hits_ = 1;
+  int tie_mode_ = MPF_TIE_RANDOM;
+  TieRng rng_;
+  double (*rand_fn_)(void *) = nullptr;
+  void *rand_arg_ = nullptr;
+  int64_t randum_seed_ = 12345;
+  std::vector<Move> moves_;
+  int scan_batch_ = 32;
+};
+
+}  // namespace mpf

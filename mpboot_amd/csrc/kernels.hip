@@ -1,0 +1,410 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Fitch engine.
+//
+// Everything here is bitwise integer work bounded by memory traffic (no MFMA):
+//   fitch(a,b):  t_k = a_k & b_k ; N = ~OR_k t_k ; c_k = t_k | (N & (a_k | b_k)) ; cost = popcount(N)
+// the arithmetic of newviewParsimonyIterativeFast (reference sprparsimony.cpp:737-776, :841-869)
+// and evaluateParsimonyIterativeFast (:1108-1124, :1178-1203).
+//
+// Work decomposition: sites are independent, so a wavefront owns a TILE of 64*VW
+// consecutive words of every state row and never needs another wave's data; the second
+// grid dimension is the batch (newview ops of one dependency level, or SPR scans).
+// Per-candidate mutation counts are reduced across the 64 lanes with DPP row operations
+// and leave the wave as ONE integer atomic (integer adds commute: results are exact and
+// run-to-run identical).
+#include "kernels.hpp"
+
+namespace mpf {
+
+// ---------------------------------------------------------------- wave-level helpers
+
+// Sum over the 64 lanes of a wavefront, result valid in lane 63 (DPP) -- the classic GCN
+// reduction: xor-1, xor-2 inside quads, half-row mirror, row mirror, then row broadcasts.
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+template <int RED>
+__device__ __forceinline__ uint32_t wave_total(uint32_t v)
+{
+  if constexpr (RED == 0) {
+    v = wave_sum_dpp(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  } else {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  }
+}
+
+__device__ __forceinline__ void atomic_add_u32(uint32_t *p, uint32_t v)
+{
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------- vector tiles in registers
+
+template <int S, int VW>
+struct Tile {
+  uint32_t v[S][VW];
+};
+
+template <int S, int VW>
+__device__ __forceinline__ void load_tile(Tile<S, VW> &t, const uint32_t *__restrict__ vec, uint32_t slot, int Wp, int w0)
+{
+  const uint32_t *p = vec + (size_t)slot * (size_t)(S * Wp) + w0;
+#pragma unroll
+  for (int k = 0; k < S; k++) {
+    if constexpr (VW == 1) {
+      t.v[k][0] = p[(size_t)k * Wp];
+    } else if constexpr (VW == 2) {
+      uint2 x = *reinterpret_cast<const uint2 *>(p + (size_t)k * Wp);
+      t.v[k][0] = x.x; t.v[k][1] = x.y;
+    } else {
+      uint4 x = *reinterpret_cast<const uint4 *>(p + (size_t)k * Wp);
+      t.v[k][0] = x.x; t.v[k][1] = x.y; t.v[k][2] = x.z; t.v[k][3] = x.w;
+    }
+  }
+}
+
+template <int S, int VW>
+__device__ __forceinline__ void store_tile(const Tile<S, VW> &t, uint32_t *__restrict__ vec, uint32_t slot, int Wp, int w0)
+{
+  uint32_t *p = vec + (size_t)slot * (size_t)(S * Wp) + w0;
+#pragma unroll
+  for (int k = 0; k < S; k++) {
+    if constexpr (VW == 1) {
+      p[(size_t)k * Wp] = t.v[k][0];
+    } else if constexpr (VW == 2) {
+      *reinterpret_cast<uint2 *>(p + (size_t)k * Wp) = make_uint2(t.v[k][0], t.v[k][1]);
+    } else {
+      *reinterpret_cast<uint4 *>(p + (size_t)k * Wp) = make_uint4(t.v[k][0], t.v[k][1], t.v[k][2], t.v[k][3]);
+    }
+  }
+}
+
+// c = fitch(a, b); returns the number of sites of this lane's words whose intersection is empty
+template <int S, int VW>
+__device__ __forceinline__ uint32_t fitch(Tile<S, VW> &c, const Tile<S, VW> &a, const Tile<S, VW> &b)
+{
+  uint32_t cost = 0;
+#pragma unroll
+  for (int j = 0; j < VW; j++) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < S; k++) any |= a.v[k][j] & b.v[k][j];
+    const uint32_t N = ~any;
+#pragma unroll
+    for (int k = 0; k < S; k++) c.v[k][j] = (a.v[k][j] & b.v[k][j]) | (N & (a.v[k][j] | b.v[k][j]));
+    cost += (uint32_t)__builtin_popcount(N);
+  }
+  return cost;
+}
+
+// popcount(~OR_k(a_k & b_k))
+template <int S, int VW>
+__device__ __forceinline__ uint32_t empty_count(const Tile<S, VW> &a, const Tile<S, VW> &b)
+{
+  uint32_t cost = 0;
+#pragma unroll
+  for (int j = 0; j < VW; j++) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < S; k++) any |= a.v[k][j] & b.v[k][j];
+    cost += (uint32_t)__builtin_popcount(~any);
+  }
+  return cost;
+}
+
+// cost of joining subtree vector s onto the node x = fitch(u, d) without materialising x:
+//   x_k & s_k = (t_k & s_k) | (N & o_k & s_k)
+template <int S, int VW>
+__device__ __forceinline__ uint32_t join_cost(const Tile<S, VW> &u, const Tile<S, VW> &d, const Tile<S, VW> &s)
+{
+  uint32_t cost = 0;
+#pragma unroll
+  for (int j = 0; j < VW; j++) {
+    uint32_t any = 0, hit_t = 0, hit_o = 0;
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+      const uint32_t t = u.v[k][j] & d.v[k][j];
+      any |= t;
+      hit_t |= t & s.v[k][j];
+      hit_o |= (u.v[k][j] | d.v[k][j]) & s.v[k][j];
+    }
+    cost += (uint32_t)__builtin_popcount(~(hit_t | (~any & hit_o)));
+  }
+  return cost;
+}
+
+// tile index -> first word of this lane; lanes past the row end are clamped onto the last
+// valid group (they load real data but contribute nothing), so EXEC stays full for the DPP ops
+template <int VW>
+__device__ __forceinline__ int lane_word(int tile, int lane, int Wp, bool &valid)
+{
+  int w0 = (tile * 64 + lane) * VW;
+  valid = w0 < Wp;
+  return valid ? w0 : Wp - VW;
+}
+
+// ---------------------------------------------------------------- K7: tip packing (compressDNA)
+
+// state set of a PLL tip code: DNA bitVectorIdentity, protein bitVectorAA
+// (reference pllrepo/src/globalVariables.h:60-78)
+__device__ __forceinline__ uint32_t state_mask(int datatype, uint32_t code)
+{
+  if (datatype == 0) return code;
+  if (code < 20u) return 1u << code;
+  if (code == 20u) return 12u;
+  if (code == 21u) return 96u;
+  return 1048575u;
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_pack_tips(uint32_t *__restrict__ vec, const uint8_t *__restrict__ codes,
+                                                   int n_taxa, int n_patterns, const int32_t *__restrict__ site2ptn,
+                                                   int n_sites, int datatype, const uint32_t *__restrict__ tip_slots,
+                                                   int Wp)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tip = blockIdx.y;
+  if (w >= Wp || tip >= n_taxa) return;
+  uint32_t val[S];
+#pragma unroll
+  for (int k = 0; k < S; k++) val[k] = 0;
+  const uint8_t *row = codes + (size_t)tip * n_patterns;
+  for (int b = 0; b < 32; b++) {
+    const int site = 32 * w + b;
+    // expanded sites beyond the alignment are all-ones in every state row so that they
+    // never count (reference sprparsimony.cpp:2947-2960)
+    const uint32_t m = site < n_sites ? state_mask(datatype, row[site2ptn[site]]) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < S; k++) val[k] |= ((m >> k) & 1u) << b;
+  }
+  uint32_t *dst = vec + (size_t)tip_slots[tip] * (size_t)(S * Wp) + w;
+#pragma unroll
+  for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = val[k];
+}
+
+// ---------------------------------------------------------------- K1: batched newview
+
+template <int S, int VW, int RED>
+__global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops, int n_ops,
+                                                 uint32_t *__restrict__ cnt, int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_ops * tiles) return;
+  const int op = gw / tiles, tile = gw - op * tiles;
+  const NvOp o = ops[op];
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  Tile<S, VW> a, b, c;
+  load_tile<S, VW>(a, vec, o.a, Wp, w0);
+  load_tile<S, VW>(b, vec, o.b, Wp, w0);
+  uint32_t cost = fitch<S, VW>(c, a, b);
+  if (valid) store_tile<S, VW>(c, vec, o.dst, Wp, w0);
+  cost = valid ? cost : 0u;
+  const uint32_t tot = wave_total<RED>(cost);
+  if (lane == 0 && tot) atomic_add_u32(cnt + o.dst, tot);
+}
+
+// ---------------------------------------------------------------- K2: batched evaluate
+
+template <int S, int VW, int RED>
+__global__ __launch_bounds__(256) void k_evaluate(const uint32_t *__restrict__ vec, const EvOp *__restrict__ ops,
+                                                  int n_ops, uint32_t *__restrict__ out, int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_ops * tiles) return;
+  const int op = gw / tiles, tile = gw - op * tiles;
+  const EvOp o = ops[op];
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  Tile<S, VW> a, b;
+  load_tile<S, VW>(a, vec, o.a, Wp, w0);
+  load_tile<S, VW>(b, vec, o.b, Wp, w0);
+  uint32_t cost = empty_count<S, VW>(a, b);
+  cost = valid ? cost : 0u;
+  const uint32_t tot = wave_total<RED>(cost);
+  if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+}
+
+// ---------------------------------------------------------------- SPR scan (K1+K2 fused over a DFS program)
+//
+// One wavefront = one (scan, tile).  A scan is the radius-limited neighbourhood of one prune
+// record (reference rearrangeParsimony, sprparsimony.cpp:2259-2376).  With the pruned
+// subtree's vector s fixed in registers, the candidate on branch (own, parent) costs
+//     popcount(~OR_k( fitch(U_d, vec[own])_k & s_k )),    U_d = fitch(U_{d-1}, vec[sibling])
+// where U_d ("up" vector of the remaining tree at depth d of the DFS) lives in registers:
+// U is indexed by the wave-uniform depth through a switch so that every access is a
+// compile-time register name.  Per candidate the wave reads two vectors and writes none.
+
+template <int S, int VW, int MAXD, int RED>
+__global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
+                                              int n_scans, const ScanOp *__restrict__ ops, uint32_t *__restrict__ out,
+                                              int Wp, int tiles, int map)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  int scan, tile;
+  if (map == 0) {
+    if (gw >= n_scans * tiles) return;
+    scan = gw / tiles;
+    tile = gw - scan * tiles;
+  } else {
+    // tiles pinned to XCD classes: workgroups are dealt round-robin over the 8 XCDs, so all
+    // workgroups with equal blockIdx%8 share one L2; class c owns tiles {c, c+8, ...} and walks
+    // the scans in order, which keeps a tile's slice of the directional vectors L2-resident
+    const int wpb = blockDim.x >> 6;
+    const int cls = blockIdx.x & 7;
+    const int idx = (blockIdx.x >> 3) * wpb + (threadIdx.x >> 6);
+    const int ntc = (tiles - cls + 7) >> 3;            // tiles in this class
+    if (ntc <= 0 || idx >= n_scans * ntc) return;
+    scan = idx / ntc;
+    tile = cls + 8 * (idx - scan * ntc);
+  }
+  const ScanHdr h = hdr[scan];
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+
+  Tile<S, VW> sv, U[MAXD + 1], dsib, down;
+  load_tile<S, VW>(sv, vec, h.s_slot, Wp, w0);
+
+  for (uint32_t i = h.op_begin; i < h.op_end; i++) {
+    const ScanOp o = ops[i];
+    const int d = (int)(o.meta & 0xFFu);
+    const bool test = (o.meta >> 8) & 1u;
+    const int kind = (int)((o.meta >> 16) & 0xFFu);
+    if (kind == SCAN_ROOT) {
+      load_tile<S, VW>(U[0], vec, o.own, Wp, w0);
+      continue;
+    }
+    load_tile<S, VW>(dsib, vec, o.sib, Wp, w0);
+    uint32_t cost = 0;
+    if (kind == SCAN_JOIN) {
+      load_tile<S, VW>(down, vec, o.own, Wp, w0);
+      cost = join_cost<S, VW>(dsib, down, sv);
+    } else {
+      if (test) load_tile<S, VW>(down, vec, o.own, Wp, w0);
+#define MPF_LEVEL(c)                                           \
+  case c:                                                      \
+    if constexpr (c <= MAXD) {                                 \
+      fitch<S, VW>(U[c], U[c - 1], dsib);                      \
+      if (test) cost = join_cost<S, VW>(U[c], down, sv);       \
+    }                                                          \
+    break;
+      switch (d) {
+        MPF_LEVEL(1) MPF_LEVEL(2) MPF_LEVEL(3) MPF_LEVEL(4) MPF_LEVEL(5) MPF_LEVEL(6)
+        MPF_LEVEL(7) MPF_LEVEL(8) MPF_LEVEL(9) MPF_LEVEL(10) MPF_LEVEL(11) MPF_LEVEL(12)
+        default: break;
+      }
+#undef MPF_LEVEL
+    }
+    if (test || kind == SCAN_JOIN) {
+      cost = valid ? cost : 0u;
+      const uint32_t tot = wave_total<RED>(cost);
+      if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- launch wrappers
+
+static inline int tiles_of(const Geometry &g) { return (g.Wp + 64 * g.vw - 1) / (64 * g.vw); }
+
+hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
+                            int n_patterns, const int32_t *site2ptn, int n_sites, int datatype,
+                            const uint32_t *tip_slots)
+{
+  dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);
+  if (g.S == 4)
+    hipLaunchKernelGGL(k_pack_tips<4>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
+                       tip_slots, g.Wp);
+  else
+    hipLaunchKernelGGL(k_pack_tips<20>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
+                       tip_slots, g.Wp);
+  return hipGetLastError();
+}
+
+#define MPF_DISPATCH_SV(FN, ...)                                                   \
+  do {                                                                             \
+    if (g.S == 4) {                                                                \
+      if (g.vw == 1) { FN(4, 1, __VA_ARGS__); }                                    \
+      else if (g.vw == 2) { FN(4, 2, __VA_ARGS__); }                               \
+      else { FN(4, 4, __VA_ARGS__); }                                              \
+    } else {                                                                       \
+      if (g.vw == 1) { FN(20, 1, __VA_ARGS__); }                                   \
+      else { FN(20, 2, __VA_ARGS__); }                                             \
+    }                                                                              \
+  } while (0)
+
+hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cnt)
+{
+  if (n_ops <= 0) return hipSuccess;
+  const int tiles = tiles_of(g);
+  const long waves = (long)n_ops * tiles;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define NV(S_, VW_, RED_) hipLaunchKernelGGL((k_newview<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, cnt, g.Wp, tiles)
+#define NV2(S_, VW_, dummy) do { if (g.reduce == 0) NV(S_, VW_, 0); else NV(S_, VW_, 1); } while (0)
+  MPF_DISPATCH_SV(NV2, 0);
+#undef NV2
+#undef NV
+  return hipGetLastError();
+}
+
+hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
+                           uint32_t *out)
+{
+  if (n_ops <= 0) return hipSuccess;
+  const int tiles = tiles_of(g);
+  const long waves = (long)n_ops * tiles;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define EV(S_, VW_, RED_) hipLaunchKernelGGL((k_evaluate<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, out, g.Wp, tiles)
+#define EV2(S_, VW_, dummy) do { if (g.reduce == 0) EV(S_, VW_, 0); else EV(S_, VW_, 1); } while (0)
+  MPF_DISPATCH_SV(EV2, 0);
+#undef EV2
+#undef EV
+  return hipGetLastError();
+}
+
+hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
+                       const ScanOp *ops, uint32_t *out, int max_depth)
+{
+  if (n_scans <= 0) return hipSuccess;
+  const int tiles = tiles_of(g);
+  dim3 block(256);
+  unsigned nblocks;
+  if (g.map == 0) {
+    const long waves = (long)n_scans * tiles;
+    nblocks = (unsigned)((waves + 3) / 4);
+  } else {
+    const int ntc0 = (tiles + 7) / 8;                    // largest class
+    const long per_class = ((long)n_scans * ntc0 + 3) / 4;
+    nblocks = (unsigned)(per_class * 8);
+  }
+  dim3 grid(nblocks);
+#define SC(S_, VW_, MAXD_, RED_) \
+  hipLaunchKernelGGL((k_scan<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, hdr, n_scans, ops, out, g.Wp, tiles, g.map)
+#define SC2(S_, VW_, dummy)                                                          \
+  do {                                                                               \
+    if (max_depth <= 6) { if (g.reduce == 0) SC(S_, VW_, 6, 0); else SC(S_, VW_, 6, 1); } \
+    else { if (g.reduce == 0) SC(S_, VW_, 12, 0); else SC(S_, VW_, 12, 1); }         \
+  } while (0)
+  MPF_DISPATCH_SV(SC2, 0);
+#undef SC2
+#undef SC
+  return hipGetLastError();
+}
+
+}  // namespace mpf

@@ -1,0 +1,50 @@
+// kernels.hpp -- launch interface of the gfx950 Fitch kernels (kernels.hip).
+//
+// Data layout in HBM: one "directional vector" per node record,
+// stored at a compact slot index; a vector is S rows (one per state) of Wp 32-bit
+// words, bit j of word i = "state k possible at site 32*i+j" -- the reference's
+// parsVect row layout (sprparsimony.cpp:732-734, :2926-2927), site-major so that a
+// wavefront reading one row touches 64*VW consecutive words (256 B .. 1 KiB).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpf {
+
+// recompute dst = fitch(a, b); cnt[dst] += #sites with empty intersection   (K1, newview)
+struct NvOp { uint32_t dst, a, b, pad; };
+
+// popcount(~OR_k(a_k & b_k)) -> out[out]                                      (K2, evaluate)
+struct EvOp { uint32_t a, b, out, pad; };
+
+// one step of an SPR-scan program
+//   kind 0  CHAIN : U[d] = fitch(U[d-1], vec[sib]); if test: out[out] += cost(fitch(U[d], vec[own]), S)
+//   kind 1  ROOT  : U[0] = vec[own]
+//   kind 2  JOIN  : out[out] += cost(fitch(vec[own], vec[sib]), S)            (stepwise addition)
+struct ScanOp { uint32_t own, sib, meta, out; };   // meta = depth | test<<8 | kind<<16
+struct ScanHdr { uint32_t op_begin, op_end, s_slot, pad; };
+
+enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2 };
+constexpr int kMaxDepth = 12;   // deepest chain the register-resident scan kernel supports
+
+struct Geometry {
+  int S;        // states (4 | 20)
+  int Wp;       // words per row, multiple of 32
+  int vw;       // words per lane (1 | 2 | 4)
+  int reduce;   // 0 = DPP wave reduction, 1 = ds_bpermute (__shfl) reduction
+  int map;      // 0 = scan-major wave mapping, 1 = tiles pinned to XCD classes
+};
+
+hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
+                            int n_patterns, const int32_t *site2ptn, int n_sites, int datatype,
+                            const uint32_t *tip_slots);
+hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cnt);
+hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
+                           uint32_t *out);
+hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
+                       const ScanOp *ops, uint32_t *out, int max_depth);
+// per-site mutation counts of the current tree: for every op (a,b) adds the empty-intersection mask bits
+hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
+                              const int32_t *ptn_first_site, int n_ptn, uint16_t *ptn_out);
+
+}  // namespace mpf

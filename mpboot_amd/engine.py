@@ -1,0 +1,233 @@
+"""ctypes binding of libmpfitch.so (include/mpfitch.h) -- the product's Python face.
+
+There is no fallback: if the HIP library is missing or no GPU is present the
+calls raise.  Nothing here imports the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmpfitch.so")
+
+DNA, AA = 0, 1
+TIE_FIRST, TIE_RANDOM = 0, 1
+
+EXPORTS = [
+    "mpf_last_error", "mpf_abi_version", "mpf_engine_create", "mpf_engine_destroy", "mpf_set_weights",
+    "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
+    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_seed_ties",
+    "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
+    "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
+    "mpf_set_option",
+]
+
+
+class MpfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmpfitch error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_taxa", C.c_int32), ("n_patterns", C.c_int32), ("datatype", C.c_int32),
+                ("keep_all_sites", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("insertion_tests", C.c_uint64), ("newview_ops", C.c_uint64), ("scan_launches", C.c_uint64),
+                ("view_launches", C.c_uint64), ("moves_applied", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("last_scan_kernel_ms", C.c_double), ("scan_kernel_ms_total", C.c_double),
+                ("view_kernel_ms_total", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmpfitch.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.mpf_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        L.mpf_engine_create.argtypes = [C.POINTER(vp), C.POINTER(Config), vp, vp]
+        L.mpf_engine_destroy.argtypes = [vp]
+        L.mpf_engine_destroy.restype = None
+        L.mpf_set_weights.argtypes = [vp, vp]
+        L.mpf_get_geometry.argtypes = [vp, vp, vp, vp, vp]
+        L.mpf_get_informative.argtypes = [vp, vp]
+        L.mpf_get_tip_vector.argtypes = [vp, C.c_int32, vp]
+        L.mpf_set_tree.argtypes = [vp, vp]
+        L.mpf_get_tree.argtypes = [vp, vp]
+        L.mpf_reset_node_order.argtypes = [vp]
+        L.mpf_score_tree.argtypes = [vp, vp]
+        L.mpf_score_trees.argtypes = [vp, C.c_int32, vp, vp]
+        L.mpf_pattern_scores.argtypes = [vp, vp, vp]
+        L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
+        L.mpf_spr_scan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        L.mpf_spr_sweep_scan.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+        L.mpf_optimize_spr.argtypes = [vp, C.c_int32, C.c_int32, vp]
+        L.mpf_make_parsimony_tree.argtypes = [vp, C.c_int64, C.c_int32, vp]
+        L.mpf_stepwise_addition.argtypes = [vp, C.c_int64, vp, vp, vp]
+        L.mpf_get_moves.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+        L.mpf_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mpf_reset_stats.argtypes = [vp]
+        L.mpf_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MpfError(rc, load_library().mpf_last_error().decode())
+
+
+class FitchEngine:
+    """One alignment resident on one MI355X; mirrors the reference's PLL-instance-level calls."""
+
+    def __init__(self, codes: np.ndarray, weights=None, datatype: int = DNA, keep_all: bool = False, device: int = 0):
+        L = load_library()
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.n, self.P = codes.shape
+        if weights is None:
+            weights = np.ones(self.P, dtype=np.int32)
+        weights = np.ascontiguousarray(weights, dtype=np.int32)
+        cfg = Config(device, self.n, self.P, datatype, int(keep_all))
+        h = C.c_void_p()
+        _chk(L.mpf_engine_create(C.byref(h), C.byref(cfg), _p(codes), _p(weights)))
+        self.h = h
+        self.nrec = 3 * (2 * self.n - 1)
+        s, w, ni, wp = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(L.mpf_get_geometry(self.h, C.byref(s), C.byref(w), C.byref(ni), C.byref(wp)))
+        self.S, self.W, self.num_informative, self.Wp = s.value, w.value, ni.value, wp.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mpf_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _refresh_geometry(self):
+        s, w, ni, wp = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(load_library().mpf_get_geometry(self.h, C.byref(s), C.byref(w), C.byref(ni), C.byref(wp)))
+        self.S, self.W, self.num_informative, self.Wp = s.value, w.value, ni.value, wp.value
+
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.int32)
+        _chk(load_library().mpf_set_weights(self.h, _p(w)))
+        self._refresh_geometry()
+
+    def informative(self):
+        f = np.zeros(self.P, dtype=np.int32)
+        _chk(load_library().mpf_get_informative(self.h, _p(f)))
+        return f
+
+    def tip_vector(self, tip: int):
+        out = np.zeros((self.S, self.W), dtype=np.uint32)
+        _chk(load_library().mpf_get_tip_vector(self.h, tip, _p(out)))
+        return out
+
+    def set_tree(self, back):
+        back = np.ascontiguousarray(back, dtype=np.int32)
+        assert len(back) == self.nrec
+        _chk(load_library().mpf_set_tree(self.h, _p(back)))
+
+    def get_tree(self):
+        back = np.empty(self.nrec, dtype=np.int32)
+        _chk(load_library().mpf_get_tree(self.h, _p(back)))
+        return back
+
+    def reset_node_order(self):
+        _chk(load_library().mpf_reset_node_order(self.h))
+
+    def score_tree(self, back=None) -> int:
+        if back is not None:
+            self.set_tree(back)
+        s = C.c_uint32()
+        _chk(load_library().mpf_score_tree(self.h, C.byref(s)))
+        return s.value
+
+    def score_trees(self, backs):
+        backs = np.ascontiguousarray(backs, dtype=np.int32)
+        out = np.zeros(len(backs), dtype=np.uint32)
+        _chk(load_library().mpf_score_trees(self.h, len(backs), _p(backs), _p(out)))
+        return out
+
+    def pattern_scores(self):
+        out = np.zeros(self.P, dtype=np.uint16)
+        tot = C.c_int32()
+        _chk(load_library().mpf_pattern_scores(self.h, _p(out), C.byref(tot)))
+        return out, tot.value
+
+    def seed_ties(self, mode: int, seed: int = 1):
+        _chk(load_library().mpf_seed_ties(self.h, mode, seed))
+
+    def spr_scan(self, rec: int, mintrav: int = 1, maxtrav: int = 6, cap: int = 1 << 16):
+        q = np.zeros(cap, dtype=np.int32)
+        mp = np.zeros(cap, dtype=np.uint32)
+        n_p, n_t = C.c_int32(), C.c_int32()
+        _chk(load_library().mpf_spr_scan(self.h, rec, mintrav, maxtrav, cap, _p(q), _p(mp), C.byref(n_p), C.byref(n_t)))
+        return q[:n_t.value].copy(), mp[:n_t.value].copy(), n_p.value
+
+    def sweep_scan(self, mintrav: int = 1, maxtrav: int = 6):
+        n = C.c_uint64()
+        m = C.c_uint32()
+        _chk(load_library().mpf_spr_sweep_scan(self.h, mintrav, maxtrav, C.byref(n), C.byref(m)))
+        return n.value, m.value
+
+    def optimize_spr(self, mintrav: int = 1, maxtrav: int = 6) -> int:
+        s = C.c_uint32()
+        _chk(load_library().mpf_optimize_spr(self.h, mintrav, maxtrav, C.byref(s)))
+        return s.value
+
+    def make_parsimony_tree(self, seed: int, spr_dist: int) -> int:
+        s = C.c_uint32()
+        _chk(load_library().mpf_make_parsimony_tree(self.h, seed, spr_dist, C.byref(s)))
+        return s.value
+
+    def stepwise_addition(self, seed: int):
+        best = np.zeros(self.n + 1, dtype=np.uint32)
+        ins = np.zeros(self.n + 1, dtype=np.int32)
+        s = C.c_uint32()
+        _chk(load_library().mpf_stepwise_addition(self.h, seed, _p(best), _p(ins), C.byref(s)))
+        return s.value, best, ins
+
+    def moves(self):
+        k = C.c_int32()
+        L = load_library()
+        _chk(L.mpf_get_moves(self.h, 0, None, None, None, C.byref(k)))
+        a = np.zeros(k.value, dtype=np.int32)
+        b = np.zeros(k.value, dtype=np.int32)
+        s = np.zeros(k.value, dtype=np.uint32)
+        if k.value:
+            _chk(L.mpf_get_moves(self.h, k.value, _p(a), _p(b), _p(s), C.byref(k)))
+        return a, b, s
+
+    def stats(self) -> dict:
+        st = Stats()
+        _chk(load_library().mpf_get_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def reset_stats(self):
+        _chk(load_library().mpf_reset_stats(self.h))
+
+    def set_option(self, key: str, value: int):
+        _chk(load_library().mpf_set_option(self.h, key.encode(), int(value)))

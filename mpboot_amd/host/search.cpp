@@ -1,0 +1,232 @@
+// search.cpp -- the reference's host-side search loops, driven by batched device scans.
+//
+// What stays on the host is exactly what is sequential in the reference: the order in which
+// prune nodes are visited, the accept / tie-break rules with their random draws, and the
+// topology edits.  What the reference does one insertion test at a time (insertParsimony +
+// evaluateParsimony per candidate) arrives here as arrays of scores computed by k_scan for a
+// whole batch of prune nodes; the batch is speculative -- as soon as a move is accepted the
+// remaining scans of the batch are discarded, the views are refreshed and scanning resumes at
+// the next prune node, so the trajectory is the reference's.
+#include <algorithm>
+#include <climits>
+
+#include "../csrc/engine.hpp"
+
+namespace mpf {
+
+// restoreTreeRearrangeParsimony (reference sprparsimony.cpp:2379-2384, :2191-2205)
+void Engine::apply_move(int p, int q)
+{
+  const int a = back_[nx(p)], b = back_[nx(nx(p))];
+  hookup(a, b);                                  // removeNodeParsimony :2245-2257
+  const int r = back_[q];
+  hookup(nx(p), q);
+  hookup(nx(nx(p)), r);
+  views_valid_ = false;
+  stats.moves_applied++;
+}
+
+// the sweep loop shared by pllOptimizeSprParsimony (reference sprparsimony.cpp:3295-3316) and
+// _pllMakeParsimonyTreeFast (:3185-3206); MPF_TIE_FIRST follows pllrepo/src/fastDNAparsimony.c:1919-1938
+int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
+{
+  uint32_t startMP;
+  unsigned iter_hits = 1;                         // bestIterationScoreHits
+  const int total = 2 * n_ - 2;
+  std::vector<ScanPlan> plans;
+  std::vector<uint32_t> out;
+  int batch = std::max(1, scan_batch_);
+  do {
+    startMP = randomMP;
+    node_rectifier();
+    int i = 1;
+    while (i <= total) {
+      if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+      const int hi = std::min(total, i + batch - 1);
+      plans.assign((size_t)(hi - i + 1), ScanPlan());
+      for (int j = i; j <= hi; j++) {
+        int rc = plan_scan(nodep_[j], mintrav, maxtrav, plans[(size_t)(j - i)]);
+        if (rc) return rc;
+      }
+      int rc = run_scans(plans, out);
+      if (rc) return rc;
+      bool moved = false;
+      int j = i;
+      for (; j <= hi && !moved; j++) {
+        const ScanPlan &pl = plans[(size_t)(j - i)];
+        if (tie_mode_ == MPF_TIE_RANDOM) {
+          insert_rec_ = remove_rec_ = -1;
+          hits_ = 1;
+        }
+        // testInsertParsimony's bookkeeping (reference :2168-2176 / fastDNAparsimony.c:1224-1229)
+        for (size_t c = 0; c < pl.cands.size(); c++) {
+          const uint32_t mp = pl.base + out[pl.cands[c].out];
+          const int prune = (int)c < pl.n_p ? pl.rec : back_[pl.rec];
+          if (tie_mode_ == MPF_TIE_RANDOM) {
+            if (mp < best_) hits_ = 1;
+            else if (mp == best_) hits_++;
+            if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) {
+              best_ = mp; insert_rec_ = pl.cands[c].q; remove_rec_ = prune;
+            }
+          } else if (mp < best_) {
+            best_ = mp; insert_rec_ = pl.cands[c].q; remove_rec_ = prune;
+          }
+        }
+        bool accept;
+        if (tie_mode_ == MPF_TIE_RANDOM) {
+          if (best_ == randomMP) iter_hits++;
+          if (best_ < randomMP) iter_hits = 1;
+          accept = (best_ < randomMP || (best_ == randomMP && tie_draw() <= 1.0 / (double)iter_hits)) &&
+                   remove_rec_ >= 0 && insert_rec_ >= 0;
+        } else {
+          accept = best_ < randomMP;
+        }
+        if (accept) {
+          moves_.push_back(Move{remove_rec_, insert_rec_, best_});
+          apply_move(remove_rec_, insert_rec_);
+          randomMP = best_;
+          moved = true;
+        }
+      }
+      i = j;
+      if (moved) batch = std::max(1, scan_batch_ / 4);
+      else batch = std::min(total, batch * 2);
+    }
+  } while (randomMP < startMP);
+  if (final_score) *final_score = randomMP;
+  return MPF_OK;
+}
+
+// pllOptimizeSprParsimony (reference sprparsimony.cpp:3244-3319)
+int Engine::optimize_spr(int mintrav, int maxtrav, uint32_t *score)
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  moves_.clear();
+  node_rectifier();
+  uint32_t len = 0;
+  views_valid_ = false;
+  int rc = tree_length(&len);
+  if (rc) return rc;
+  best_ = len;
+  ntips_ = n_;
+  insert_rec_ = remove_rec_ = -1;
+  return spr_sweeps(mintrav, maxtrav, best_, score);
+}
+
+// makePermutationFast + buildSimpleTree + the addition loop of _pllMakeParsimonyTreeFast
+// (reference sprparsimony.cpp:2221-2242, :1955-1981, :3107-3181) with stepwiseAddition (:2977-3019)
+// evaluated as one JOIN scan per added taxon.
+int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step)
+{
+  const int n = n_;
+  std::vector<int> perm((size_t)n + 2);
+  randum_seed_ = seed;
+  for (int i = 1; i <= n; i++) perm[i] = i;
+  for (int i = 1; i <= n; i++) {
+    const double d = randum(&randum_seed_);
+    const int k = (int)((double)(n + 1 - i) * d);
+    std::swap(perm[i], perm[i + k]);
+  }
+  ntips_ = 0;
+  nextnode_ = n + 1;
+  const int ip = perm[1], iq = perm[2], ir = perm[3];
+  start_ = nodep_[std::min(ip, std::min(iq, ir))];
+  ntips_ = 3;
+  {
+    const int p = nodep_[ip];
+    hookup(p, nodep_[iq]);
+    const int s = nodep_[nextnode_++];
+    hookup(nodep_[ir], s);
+    back_[nx(s)] = back_[nx(nx(s))] = -1;
+    const int r = back_[p];
+    hookup(nx(s), p);
+    hookup(nx(nx(s)), r);
+  }
+  have_tree_ = true;
+  const int f = start_;
+  hits_ = 1;
+  std::vector<ScanPlan> plans(1);
+  std::vector<uint32_t> out;
+  std::vector<int> stack;
+  while (ntips_ < n) {
+    best_ = (uint32_t)INT_MAX;
+    const int nextsp = ++ntips_;
+    const int p = nodep_[perm[nextsp]];
+    const int q = nodep_[nextnode_++];
+    back_[p] = q;
+    back_[q] = p;
+    // views + length of the tree built so far (the new tip is not part of it yet)
+    views_valid_ = false;
+    uint32_t len = 0;
+    int rc = tree_length(&len);
+    if (rc) return rc;
+    // candidate branches in the reference's DFS order with its descent cut (:3014)
+    ScanPlan &pl = plans[0];
+    pl.cands.clear();
+    ScanHdr h;
+    h.op_begin = (uint32_t)prog_ops_.size();
+    h.s_slot = slot(p);
+    h.pad = 0;
+    stack.clear();
+    stack.push_back(back_[f]);
+    while (!stack.empty()) {
+      const int c = stack.back();
+      stack.pop_back();
+      ScanOp o;
+      o.own = slot(c);
+      o.sib = slot(back_[c]);
+      o.meta = (uint32_t)SCAN_JOIN << 16;
+      o.out = prog_out_;
+      prog_ops_.push_back(o);
+      pl.cands.push_back(Candidate{c, prog_out_++});
+      if (!tip(c) && sc_[c] > 0) {
+        stack.push_back(back_[nx(nx(c))]);
+        stack.push_back(back_[nx(c)]);
+      }
+    }
+    h.op_end = (uint32_t)prog_ops_.size();
+    prog_hdr_.push_back(h);
+    rc = run_scans(plans, out);
+    if (rc) return rc;
+    for (const Candidate &c : pl.cands) {
+      const uint32_t mp = len + out[c.out];
+      if (tie_mode_ == MPF_TIE_RANDOM) {
+        if (mp < best_) hits_ = 1;
+        else if (mp == best_) hits_++;
+        if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; insert_rec_ = c.q; }
+      } else if (mp < best_) { best_ = mp; insert_rec_ = c.q; }
+    }
+    if (best_per_step) best_per_step[nextsp] = best_;
+    if (insert_per_step) insert_per_step[nextsp] = insert_rec_;
+    const int r = back_[insert_rec_];
+    hookup(nx(q), insert_rec_);
+    hookup(nx(nx(q)), r);
+    views_valid_ = false;
+  }
+  return MPF_OK;
+}
+
+int Engine::stepwise_addition(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step, uint32_t *score)
+{
+  moves_.clear();
+  int rc = addition_phase(seed, best_per_step, insert_per_step);
+  if (rc) return rc;
+  if (score) *score = best_;
+  return MPF_OK;
+}
+
+// _pllComputeRandomizedStepwiseAdditionParsimonyTree (reference sprparsimony.cpp:3224-3235)
+int Engine::make_parsimony_tree(int64_t seed, int spr_dist, uint32_t *score)
+{
+  moves_.clear();
+  int rc = addition_phase(seed, nullptr, nullptr);
+  if (rc) return rc;
+  node_rectifier();
+  uint32_t fin = best_;
+  rc = spr_sweeps(1, spr_dist, best_, &fin);
+  if (rc) return rc;
+  if (score) *score = fin;
+  return MPF_OK;
+}
+
+}  // namespace mpf

@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports what include/mpfitch.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from helpers import ROOT
+
+
+def _declared():
+    with open(os.path.join(ROOT, "include", "mpfitch.h")) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpf_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    for must in ("mpf_engine_create", "mpf_optimize_spr", "mpf_make_parsimony_tree", "mpf_score_tree", "mpf_spr_scan"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    lib_path = os.path.join(ROOT, "mpboot_amd", "libmpfitch.so")
+    if not os.path.exists(lib_path):
+        g.build()
+    lib = ctypes.CDLL(lib_path)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    lib.mpf_abi_version.restype = ctypes.c_int
+    assert lib.mpf_abi_version() == 1
+
+
+def test_python_binding_lists_the_same_symbols():
+    from mpboot_amd import engine
+    assert sorted(engine.EXPORTS) == _declared()
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a device the product must refuse to run (no CPU fallback)."""
+    import numpy as np
+    from mpboot_amd import engine
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    codes = np.ones((4, 8), dtype=np.uint8)
+    with pytest.raises(engine.MpfError) as ei:
+        engine.FitchEngine(codes)
+    assert ei.value.code == -1
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "mpboot_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                with open(os.path.join(dirpath, f)) as fh:
+                    txt = fh.read()
+                assert "pyoracle" not in txt and "fitch_oracle" not in txt and "liboracle" not in txt, f

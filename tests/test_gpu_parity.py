@@ -1,0 +1,163 @@
+"""GPU parity: libmpfitch.so (through its C-ABI) against the oracle and the golden fixtures.
+
+Integer work -- every comparison is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import FIXTURES, hex_words, load_fixture, trace_tokens
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mpboot_amd import engine, synth, trees
+    from oracle import pyoracle as po
+    return engine, po, synth, trees
+
+
+@pytest.fixture(scope="module", params=FIXTURES)
+def fx(request):
+    return load_fixture(request.param)
+
+
+def eng_of(engine, fx, **kw):
+    return engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], **kw)
+
+
+def orc_of(po, fx, **kw):
+    return po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], **kw)
+
+
+def test_native_library_is_loaded(mods):
+    engine = mods[0]
+    lib = engine.load_library()
+    assert lib.mpf_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libmpfitch.so" in f.read()
+
+
+def test_tip_packing_matches_reference(mods, fx):
+    engine = mods[0]
+    e = eng_of(engine, fx)
+    assert (e.S, e.W) == (fx["S"], fx["W"])
+    assert e.informative().tolist() == fx["informative"]
+    for i, hx in enumerate(fx["tipvec_hex"]):
+        assert (e.tip_vector(i + 1).ravel() == hex_words(hx)).all()
+
+
+def test_tree_scores_match_reference(mods, fx):
+    engine = mods[0]
+    e = eng_of(engine, fx)
+    for t in fx["trees"]:
+        assert e.score_tree(np.array(t["back"], dtype=np.int32)) == t["score"]
+    backs = np.array([t["back"] for t in fx["trees"]], dtype=np.int32)
+    assert e.score_trees(backs).tolist() == [t["score"] for t in fx["trees"]]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("opts", [dict(), dict(reduce=1), dict(words_per_lane=2), dict(xcd_map=1)])
+def test_spr_scan_candidates_match_reference(mods, fx, which, opts):
+    """every insertion test's tree length, in the reference's order (fixture 'cands' lines)"""
+    engine = mods[0]
+    sc = fx["scan"][which]
+    e = eng_of(engine, fx)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    e.set_tree(np.array(sc["back"], dtype=np.int32))
+    assert e.score_tree() == sc["score"]
+    for rec, exp in zip(sc["order"], sc["cands"]):
+        q, mp, n_p = e.spr_scan(rec, 1, sc["maxtrav"])
+        toks = ["P"] + [f"{a}:{b}" for a, b in zip(q[:n_p], mp[:n_p])] + ["Q"] + [f"{a}:{b}" for a, b in zip(q[n_p:], mp[n_p:])]
+        assert toks == exp, rec
+
+
+def test_stepwise_addition_matches_reference(mods, fx):
+    engine = mods[0]
+    rx = fx["rasx"]
+    e = eng_of(engine, fx)
+    e.seed_ties(engine.TIE_FIRST)
+    s, best, ins = e.stepwise_addition(rx["seed"])
+    for step, _tip, b, i in rx["adds"]:
+        assert (int(best[step]), int(ins[step])) == (b, i), step
+    assert e.get_tree().tolist() == rx["back"]
+    assert e.score_tree() == rx["score"]
+
+
+@pytest.mark.parametrize("seed", [1, 7, 2024])
+def test_spr_hill_climb_matches_oracle_trajectory(mods, fx, seed):
+    """pllOptimizeSprParsimony with mpboot's random tie-breaks: same moves, same final topology"""
+    engine, po = mods[0], mods[1]
+    start = np.array(fx["spr"]["start_back"], dtype=np.int32)
+    e = eng_of(engine, fx)
+    o = orc_of(po, fx)
+    e.set_tree(start)
+    o.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, seed)
+    o.seed_ties(po.TIE_RANDOM, seed)
+    o.trace(True)
+    se = e.optimize_spr(1, 6)
+    so = o.optimize_spr(1, 6)
+    assert se == so
+    em, om = e.moves(), o.get_moves()
+    assert [x.tolist() for x in em] == [x.tolist() for x in om]
+    assert (e.get_tree() == o.get_tree()).all()
+    assert e.score_tree() == se
+
+
+@pytest.mark.parametrize("seed,dist", [(42, 6), (7, 1), (99, 0), (5, 3)])
+def test_randomized_stepwise_addition_tree_matches_oracle(mods, fx, seed, dist):
+    """_pllComputeRandomizedStepwiseAdditionParsimonyTree, mpboot tie rule"""
+    engine, po = mods[0], mods[1]
+    e = eng_of(engine, fx)
+    o = orc_of(po, fx)
+    e.seed_ties(engine.TIE_RANDOM, seed)
+    o.seed_ties(po.TIE_RANDOM, seed)
+    se = e.make_parsimony_tree(seed, dist)
+    so, _perm = o.make_tree(seed, dist)
+    assert se == so
+    assert (e.get_tree() == o.get_tree()).all()
+
+
+def test_reweighting_matches_oracle(mods, fx):
+    """ratchet / bootstrap re-weighting: re-pack on the device, same scores"""
+    engine, po = mods[0], mods[1]
+    rng = np.random.default_rng(5)
+    w = rng.integers(0, 4, size=len(fx["weights"])).astype(np.int32)
+    e = eng_of(engine, fx)
+    o = orc_of(po, fx)
+    e.set_weights(w)
+    o.set_weights(w)
+    assert e.W == o.W
+    for t in fx["trees"][:3]:
+        b = np.array(t["back"], dtype=np.int32)
+        assert e.score_tree(b) == o.score_tree(b)
+
+
+def test_midsize_random_alignment_against_oracle(mods):
+    """a 120-taxon case: scan of every prune node + hill climb, engine vs oracle"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(120, 3000, "DNA", 0.06, seed=12)
+    codes = synth.letters_to_codes(letters)
+    back = trees.random_topology(120, np.random.default_rng(8))
+    e = engine.FitchEngine(codes)
+    o = po.Oracle(codes)
+    assert e.score_tree(back) == o.score_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 3)
+    cur = o.score_tree()
+    order = o.nodep()[1:2 * 120 - 1]
+    for rec in order[::7]:
+        o.set_best(cur)
+        o.trace(True)
+        o.rearrange(int(rec), 1, 6)
+        toks = trace_tokens(*o.get_trace())
+        q, mp, n_p = e.spr_scan(int(rec), 1, 6)
+        mine = ["P"] + [f"{a}:{b}" for a, b in zip(q[:n_p], mp[:n_p])] + ["Q"] + [f"{a}:{b}" for a, b in zip(q[n_p:], mp[n_p:])]
+        assert mine == toks
+    e.seed_ties(engine.TIE_RANDOM, 11)
+    o2 = po.Oracle(codes)
+    o2.set_tree(back)
+    o2.seed_ties(po.TIE_RANDOM, 11)
+    assert e.optimize_spr(1, 6) == o2.optimize_spr(1, 6)
+    assert (e.get_tree() == o2.get_tree()).all()
