@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- Fitch site-ops/s of the SPR neighbourhood scan on MI355X.
+
+A "step" = one full radius-6 SPR sweep scan of one tree (every prune node, both
+sides: what pllOptimizeSprParsimony does between two accepted moves,
+reference sprparsimony.cpp:3295-3316): refresh of all directional vectors,
+scan programs, the k_scan launch and the copy-back of every candidate's score.
+Inputs (packed tips, topology) are resident in HBM before the timed region.
+
+Metric (BASELINE.json): Fitch site-ops/s = taxa x patterns x SPR-evals/s.
+N > 1: every rank holds the alignment and scans its own start tree
+(independent units, no data-path collective) -> weak scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+
+def cpu_baseline(codes, back, names, letters, alphabet, maxtrav, budget_s):
+    """Reference AVX code if oracle/_ref travelled with the snapshot, else the scalar port (oracle)."""
+    from mpboot_amd import synth, trees
+    n, P = codes.shape
+    drv = os.path.join(ROOT, "oracle", "_ref", "pll_ref_driver")
+    if os.path.exists(drv) and os.access(drv, os.X_OK):
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                aln = os.path.join(tmp, "a.phy")
+                synth.write_phylip(aln, synth.letters_to_text(letters, alphabet), names)
+                tf = os.path.join(tmp, "t.nwk")
+                with open(tf, "w") as f:
+                    f.write(trees.back_to_newick(back, names) + "\n")
+                out = subprocess.run([drv, "time", aln, "DNA" if alphabet == "DNA" else "WAG", "0", tf, str(maxtrav),
+                                      str(budget_s)], capture_output=True, text=True, check=True, timeout=600).stdout
+            for l in out.splitlines():
+                t = l.split()
+                if t and t[0] == "timed":
+                    tests, secs, done, tot = int(t[6]), float(t[8]), int(t[2]), int(t[4])
+                    return {"value": n * P * tests / secs, "unit": "site-ops/s", "cores": 1, "kind": "reference",
+                            "evals_per_s": tests / secs,
+                            "sample": f"reference PLL AVX testInsertParsimony over the first {done} of {tot} prune nodes "
+                                      f"of the same tree, radius {maxtrav} ({tests} insertion tests, {secs:.1f} s, 1 thread)"}
+        except Exception as exc:  # fall through to the port
+            print(f"[bench] reference driver failed ({exc}); using the scalar port", file=sys.stderr)
+    from oracle import pyoracle as po
+    o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
+    o.set_tree(back)
+    cur = o.score_tree()
+    o.seed_ties(po.TIE_RANDOM, 1)
+    order = o.nodep()[1:2 * n - 1]
+    t0 = time.perf_counter()
+    done = 0
+    for rec in order:
+        o.set_best(cur)
+        o.rearrange(int(rec), 1, maxtrav)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    secs = time.perf_counter() - t0
+    tests = o.counters()[2]
+    return {"value": n * P * tests / secs, "unit": "site-ops/s", "cores": 1, "kind": "port",
+            "evals_per_s": tests / secs,
+            "sample": f"scalar C oracle over the first {done} of {len(order)} prune nodes of the same tree, radius {maxtrav} "
+                      f"({tests} insertion tests, {secs:.1f} s, 1 thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--maxtrav", type=int, default=6)
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libmpfitch has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mpboot_amd import engine, synth, trees
+
+    cfg = synth.WORKLOADS[args.workload]
+    alphabet = cfg["alphabet"]
+    letters, names = synth.workload(args.workload)
+    codes = synth.letters_to_codes(letters, alphabet)
+    n, P = codes.shape
+    # each rank scans its own start tree (independent SPR start trees shard across GPUs)
+    back = trees.random_topology(n, np.random.default_rng(1000 + rank))
+
+    eng = engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    eng.set_tree(back)
+    start_score = eng.score_tree()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.set_tree(back)
+        eng.sweep_scan(1, args.maxtrav)
+    eng.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    tests = 0
+    for _ in range(args.steps):
+        eng.set_tree(back)                       # invalidates the views: the step recomputes them
+        k, _best = eng.sweep_scan(1, args.maxtrav)
+        tests += k
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+
+    tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_all, tests_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_all, tests_all = dt, float(tests)
+
+    if rank == 0:
+        evals_per_s = tests_all / dt_all
+        W = eng.W                                          # the reference's parsimonyLength
+        bytes_per_eval = 6 * eng.S * W * 4                 # 1 chain newview + 1 three-vector join-evaluate
+        launches = max(1, st["scan_launches"])
+        scan_ms = st["scan_kernel_ms_total"] / launches
+        evals_per_launch = st["insertion_tests"] / launches
+        achieved = evals_per_launch * bytes_per_eval / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        # what the kernel is obliged to move per eval with the chain kept in registers: two vector reads
+        compulsory = evals_per_launch * 2 * eng.S * eng.Wp * 4 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        res = {
+            "metric": "Fitch site-ops/sec (taxa x patterns x SPR-evals/s)",
+            "value": n * P * evals_per_s,
+            "unit": "site-ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_all / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
+                                   "one full sweep scan per step (all prune nodes, both sides)",
+                       "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
+                       "start_tree_score": start_score, "parallelism": f"independent start trees x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_scan", "kernel_ms_per_launch": scan_ms,
+                         "algorithmic_bytes_per_eval": bytes_per_eval,
+                         "loaded_GBps": compulsory,
+                         "note": "achieved = SURVEY §8(d) bytes (6 vectors per eval) / HIP-event kernel time; the kernel "
+                                 "itself loads 2 vectors per eval (chain in registers) = loaded_GBps, mostly L2/Infinity-Cache hits"},
+            "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": st["view_kernel_ms_total"] / args.steps,
+                      "launches_per_step": st["view_launches"] / args.steps},
+        }
+        if not args.no_cpu and world == 1:
+            res["cpu_baseline"] = cpu_baseline(codes, back, names, letters, alphabet, args.maxtrav, args.cpu_budget)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

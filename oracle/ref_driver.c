@@ -164,13 +164,16 @@ static void cmd_score(const char *treefile)
 }
 
 /* ---- own enumeration of one side, one candidate at a time ---- */
+static int QUIET = 0;
+static unsigned long long NTESTS = 0;
 static void enum_side(nodeptr p, nodeptr q, int mintrav, int maxtrav)
 {
   if (--mintrav <= 0) {
     TR->bestParsimony = UINT_MAX;
     TR->insertNode = TR->removeNode = NULL;
     testInsertParsimony(TR, PR, p, q, PLL_FALSE);
-    printf(" %d:%u", rec_of(q), TR->bestParsimony);
+    NTESTS++;
+    if (!QUIET) printf(" %d:%u", rec_of(q), TR->bestParsimony);
   }
   if (q->number > TR->mxtips && --maxtrav > 0) {
     enum_side(p, q->next->back, mintrav, maxtrav);
@@ -244,6 +247,63 @@ static void cmd_scan(const char *treefile, int maxtrav)
   }
   TR->bestParsimony = UINT_MAX;
   printf("score_after %u\n", evaluateParsimony(TR, PR, TR->start, PLL_TRUE));
+}
+
+/* ---- time: wall-clock of the reference's insertion tests (AVX) over the prune nodes of one tree,
+        bounded by a time budget; bench.py's cpu_baseline leg ("kind": "reference") ---- */
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void cmd_time(const char *treefile, int maxtrav, double budget)
+{
+  FILE *f = fopen(treefile, "r");
+  static char line[1 << 22];
+  int i, n, done = 0;
+  double t0, t1;
+  if (!f) { perror(treefile); exit(2); }
+  if (!fgets(line, sizeof line, f)) exit(2);
+  fclose(f);
+  allocateParsimonyDataStructures(TR, PR);
+  load_newick(line);
+  reset_orientation();
+  n = TR->mxtips;
+  TR->ntips = n;
+  nodeRectifierPars(TR);
+  TR->bestParsimony = UINT_MAX;
+  printf("score %u\n", evaluateParsimony(TR, PR, TR->start, PLL_TRUE));
+  QUIET = 1;
+  NTESTS = 0;
+  t0 = now_s();
+  for (i = 1; i <= 2 * n - 2; i++) {
+    nodeptr p = TR->nodep[i], q = p->back;
+    int mt = maxtrav;
+    if (mt > TR->ntips - 3) mt = TR->ntips - 3;
+    evaluateParsimony(TR, PR, p, PLL_FALSE);
+    if (p->number > n) {
+      nodeptr p1 = p->next->back, p2 = p->next->next->back;
+      if (p1->number > n || p2->number > n) {
+        removeNodeParsimony(p);
+        if (p1->number > n) { enum_side(p, p1->next->back, 1, mt); enum_side(p, p1->next->next->back, 1, mt); }
+        if (p2->number > n) { enum_side(p, p2->next->back, 1, mt); enum_side(p, p2->next->next->back, 1, mt); }
+        hookupDefault(p->next, p1); hookupDefault(p->next->next, p2);
+        newviewParsimony(TR, PR, p);
+      }
+    }
+    if (q->number > n && mt > 0) {
+      nodeptr q1 = q->next->back, q2 = q->next->next->back;
+      if ((q1->number > n && (q1->next->back->number > n || q1->next->next->back->number > n)) ||
+          (q2->number > n && (q2->next->back->number > n || q2->next->next->back->number > n))) {
+        removeNodeParsimony(q);
+        if (q1->number > n) { enum_side(q, q1->next->back, 2, mt); enum_side(q, q1->next->next->back, 2, mt); }
+        if (q2->number > n) { enum_side(q, q2->next->back, 2, mt); enum_side(q, q2->next->next->back, 2, mt); }
+        hookupDefault(q->next, q1); hookupDefault(q->next->next, q2);
+        newviewParsimony(TR, PR, q);
+      }
+    }
+    done = i;
+    if (now_s() - t0 > budget) break;
+  }
+  t1 = now_s();
+  printf("timed prune_nodes %d of %d tests %llu seconds %.6f\n", done, 2 * n - 2, NTESTS, t1 - t0);
 }
 
 /* ---- spr: PLL-original hill climb from a user tree (loop of fastDNAparsimony.c:1919-1938) ---- */
@@ -352,7 +412,7 @@ int main(int argc, char **argv)
   if (argc < 5) {
     fprintf(stderr,
       "usage: %s <cmd> <aln.phy> <DNA|WAG> <dedup 0|1> [args]\n"
-      "  dump | score <trees> | scan <tree> <maxtrav> | spr <tree> <maxtrav> | ras <seed> <sprDist> | rasx <seed>\n",
+      "  dump | score <trees> | scan <tree> <maxtrav> | spr <tree> <maxtrav> | time <tree> <maxtrav> <seconds> | ras <seed> <sprDist> | rasx <seed>\n",
       argv[0]);
     return 2;
   }
@@ -361,6 +421,7 @@ int main(int argc, char **argv)
   else if (!strcmp(argv[1], "score")) cmd_score(argv[5]);
   else if (!strcmp(argv[1], "scan")) cmd_scan(argv[5], atoi(argv[6]));
   else if (!strcmp(argv[1], "spr")) cmd_spr(argv[5], atoi(argv[6]));
+  else if (!strcmp(argv[1], "time")) cmd_time(argv[5], atoi(argv[6]), atof(argv[7]));
   else if (!strcmp(argv[1], "ras")) cmd_ras(atol(argv[5]), atoi(argv[6]));
   else if (!strcmp(argv[1], "rasx")) cmd_rasx(atol(argv[5]));
   else { fprintf(stderr, "unknown command %s\n", argv[1]); return 2; }
