@@ -68,6 +68,9 @@ typedef struct mpf_stats {
   double   last_scan_kernel_ms; /* HIP-event time of the most recent scan launch         */
   double   scan_kernel_ms_total;
   double   view_kernel_ms_total;
+  double   host_plan_ms_total;   /* wall time spent building scan programs                  */
+  double   host_views_ms_total;  /* wall time of update_views() incl. launches and sync     */
+  double   host_scan_ms_total;   /* wall time of run_scans() incl. copies and sync         */
 } mpf_stats;
 
 const char *mpf_last_error(void);

@@ -2,11 +2,22 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstring>
 
 namespace mpf {
+
+static inline double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct ScopedMs {
+  double &acc, t0;
+  explicit ScopedMs(double &a) : acc(a), t0(now_ms()) {}
+  ~ScopedMs() { acc += now_ms() - t0; }
+};
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -206,6 +217,7 @@ void Engine::node_rectifier()
 int Engine::update_views()
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  ScopedMs timer(stats.host_views_ms_total);
   // inner nodes of the component containing start_
   std::vector<int> inner;
   {
@@ -272,6 +284,9 @@ int Engine::update_views()
     }
   }
   HIPCHK(hipMemcpyAsync(d_nvops_.p, h_nvops_.p, nops * sizeof(NvOp), hipMemcpyHostToDevice, st_));
+  HIPCHK(d_back_.reserve(back_.size()));
+  HIPCHK(hipMemcpyAsync(d_back_.p, back_.data(), back_.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  back_on_device_ = true;
   HIPCHK(hipMemsetAsync(d_cnt_, 0, nslots_ * sizeof(uint32_t), st_));
   HIPCHK(hipEventRecord(ev0_, st_));
   for (int l = 1; l <= maxlev; l++) {
@@ -349,8 +364,9 @@ void Engine::add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, S
 int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
 {
   plan.rec = p;
+  plan.walked = false;
   plan.cands.clear();
-  plan.n_p = 0;
+  plan.n_p = plan.n_total = 0;
   if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
   if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
   if (maxtrav > kMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
@@ -391,12 +407,14 @@ int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
         (!tip(q2) && (!tip(back_[nx(q2)]) || !tip(back_[nx(nx(q2))]))))
       one_side(q, mintrav > 2 ? mintrav : 2);
   }
+  plan.n_total = (int)plan.cands.size();
   return MPF_OK;
 }
 
 int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host)
 {
   (void)plans;
+  ScopedMs timer(stats.host_scan_ms_total);
   const size_t nops = prog_ops_.size(), nh = prog_hdr_.size(), nout = prog_out_;
   out_host.assign(nout, 0);
   if (nh == 0 || nout == 0) { prog_ops_.clear(); prog_hdr_.clear(); prog_out_ = 0; prog_max_depth_ = 0; return MPF_OK; }
@@ -425,21 +443,171 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   return MPF_OK;
 }
 
+
+// ---- device-walked scans -------------------------------------------------------------------
+// the same enumeration as add_traverse, host side, only to NAME a candidate (needed when a move is accepted)
+void Engine::enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const
+{
+  struct Fr { int q, d; };
+  std::vector<Fr> st;
+  const int x1 = back_[nx(x)], x2 = back_[nx(nx(x))];
+  for (int side = 0; side < 2; side++) {
+    const int a = side ? x2 : x1;
+    if (tip(a)) continue;
+    st.push_back(Fr{back_[nx(nx(a))], 1});
+    st.push_back(Fr{back_[nx(a)], 1});
+    while (!st.empty()) {
+      const Fr f = st.back();
+      st.pop_back();
+      if (f.d >= mintrav) q.push_back(f.q);
+      if (!tip(f.q) && f.d < maxtrav) {
+        st.push_back(Fr{back_[nx(nx(f.q))], f.d + 1});
+        st.push_back(Fr{back_[nx(f.q)], f.d + 1});
+      }
+    }
+  }
+}
+
+int Engine::candidate_record(const ScanPlan &plan, size_t c)
+{
+  if (!plan.walked) return plan.cands[c].q;
+  std::vector<int32_t> q;
+  if ((int)c < plan.n_p) {
+    enumerate_side(plan.rec, 1, plan.maxtrav, q);
+    return q[c];
+  }
+  enumerate_side(back_[plan.rec], plan.mintrav_q, plan.maxtrav, q);
+  return q[c - (size_t)plan.n_p];
+}
+
+// rearrangeParsimony's applicability tests (reference sprparsimony.cpp:2304-2310, :2330-2347) decide which
+// of the two scans of a prune record exist; the kernel does the rest
+int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan)
+{
+  plan.rec = p;
+  plan.walked = true;
+  plan.cands.clear();
+  plan.n_p = plan.n_total = 0;
+  plan.walk_p = plan.walk_q = -1;
+  if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
+  if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
+  if (maxtrav > kWalkMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
+  plan.maxtrav = maxtrav;
+  const int q = back_[p];
+  plan.base = (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);
+  if (maxtrav < mintrav) return MPF_OK;
+  const uint32_t stride = 4u * ((1u << maxtrav) - 1u);
+  auto add = [&](int x, int mt) -> int {
+    if (h_walk_.cap < n_walk_ + 1) {
+      PinBuf<WalkDesc> bigger;
+      if (bigger.reserve(2 * (n_walk_ + 1) + 4096) != hipSuccess) return -1;
+      if (n_walk_) std::memcpy(bigger.p, h_walk_.p, n_walk_ * sizeof(WalkDesc));
+      std::swap(bigger.p, h_walk_.p);
+      std::swap(bigger.cap, h_walk_.cap);
+    }
+    WalkDesc &d = h_walk_.p[n_walk_];
+    d.x = x; d.mintrav = mt; d.maxtrav = maxtrav; d.out_base = walk_out_;
+    walk_out_ += stride;
+    return (int)n_walk_++;
+  };
+  if (!tip(p)) {
+    const int p1 = back_[nx(p)], p2 = back_[nx(nx(p))];
+    if (!tip(p1) || !tip(p2)) { plan.walk_p = add(p, mintrav); if (plan.walk_p < 0) { set_error("pinned alloc failed"); return MPF_E_NOMEM; } plan.off_p = h_walk_.p[plan.walk_p].out_base; }
+  }
+  if (!tip(q) && maxtrav > 0) {
+    const int q1 = back_[nx(q)], q2 = back_[nx(nx(q))];
+    if ((!tip(q1) && (!tip(back_[nx(q1)]) || !tip(back_[nx(nx(q1))]))) ||
+        (!tip(q2) && (!tip(back_[nx(q2)]) || !tip(back_[nx(nx(q2))])))) {
+      plan.mintrav_q = mintrav > 2 ? mintrav : 2;
+      plan.walk_q = add(q, plan.mintrav_q);
+      if (plan.walk_q < 0) { set_error("pinned alloc failed"); return MPF_E_NOMEM; }
+      plan.off_q = h_walk_.p[plan.walk_q].out_base;
+    }
+  }
+  return MPF_OK;
+}
+
+int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
+{
+  ScopedMs timer(stats.host_scan_ms_total);
+  const size_t nd = n_walk_, nout = walk_out_;
+  *out_host = nullptr;
+  int maxd = 0;
+  for (size_t i = 0; i < nd; i++) maxd = std::max(maxd, h_walk_.p[i].maxtrav);
+  if (nd > 0) {
+    HIPCHK(d_walk_.reserve(nd));
+    HIPCHK(d_ncand_.reserve(nd));
+    HIPCHK(h_ncand_.reserve(nd));
+    HIPCHK(d_out_.reserve(nout));
+    HIPCHK(h_out_.reserve(nout));
+    HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_));
+    HIPCHK(hipMemsetAsync(d_out_.p, 0, nout * sizeof(uint32_t), st_));
+    HIPCHK(hipEventRecord(ev0_, st_));
+    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_back_.p, n_, d_walk_.p, (int)nd, d_out_.p, d_ncand_.p, maxd));
+    HIPCHK(hipEventRecord(ev1_, st_));
+    HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipMemcpyAsync(h_ncand_.p, d_ncand_.p, nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipStreamSynchronize(st_));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+    stats.scan_launches++;
+  }
+  uint64_t tests = 0;
+  for (ScanPlan &pl : plans) {
+    pl.n_p = pl.walk_p >= 0 ? (int)h_ncand_.p[pl.walk_p] : 0;
+    pl.n_total = pl.n_p + (pl.walk_q >= 0 ? (int)h_ncand_.p[pl.walk_q] : 0);
+    tests += (uint64_t)pl.n_total;
+  }
+  stats.insertion_tests += tests;
+  stats.algorithmic_bytes += tests * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  *out_host = h_out_.p;
+  n_walk_ = 0;
+  walk_out_ = 0;
+  return MPF_OK;
+}
+
+// plan + run the scans of `count` prune records in the configured mode
+int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out)
+{
+  int mt = std::min(maxtrav, ntips_ - 3);
+  const bool walk = scan_mode_ == 1 && mt <= 8;
+  plans.resize((size_t)count);
+  {
+    ScopedMs timer(stats.host_plan_ms_total);
+    for (int i = 0; i < count; i++) {
+      int rc = walk ? plan_walk(recs[i], mintrav, maxtrav, plans[(size_t)i]) : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);
+      if (rc) return rc;
+    }
+  }
+  if (walk) return run_walks(plans, out);
+  int rc = run_scans(plans, out_scratch_);
+  *out = out_scratch_.data();
+  return rc;
+}
+
 int Engine::spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   if (rec < 3 || rec >= 3 * (2 * n_ - 1) || back_[rec] < 0) { set_error("bad prune record"); return MPF_E_INVALID; }
   if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
-  std::vector<ScanPlan> plans(1);
-  int rc = plan_scan(rec, mintrav, maxtrav, plans[0]);
+  std::vector<ScanPlan> plans;
+  const uint32_t *out = nullptr;
+  int rc = scan_batch(plans, &rec, 1, mintrav, maxtrav, &out);
   if (rc) return rc;
-  std::vector<uint32_t> out;
-  rc = run_scans(plans, out);
-  if (rc) return rc;
+  const ScanPlan &pl = plans[0];
   q.clear();
   mp.clear();
-  for (const Candidate &c : plans[0].cands) { q.push_back(c.q); mp.push_back(plans[0].base + out[c.out]); }
-  n_p = plans[0].n_p;
+  if (pl.walked) {
+    enumerate_side(pl.rec, 1, pl.maxtrav, q);
+    if ((int)q.size() != pl.n_p && pl.walk_p >= 0) { set_error("device/host enumeration mismatch"); return MPF_E_STATE; }
+    if (pl.walk_p < 0) q.clear();
+    if (pl.walk_q >= 0) enumerate_side(back_[pl.rec], pl.mintrav_q, pl.maxtrav, q);
+    if ((int)q.size() != pl.n_total) { set_error("device/host enumeration mismatch"); return MPF_E_STATE; }
+    for (size_t c = 0; c < q.size(); c++) mp.push_back(pl.base + pl.cost(c, out));
+  } else {
+    for (size_t c = 0; c < pl.cands.size(); c++) { q.push_back(pl.cands[c].q); mp.push_back(pl.base + pl.cost(c, out)); }
+  }
+  n_p = pl.n_p;
   return MPF_OK;
 }
 
@@ -448,18 +616,17 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   node_rectifier();
   if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
-  std::vector<ScanPlan> plans(2 * (size_t)n_ - 2);
-  for (int i = 1; i <= 2 * n_ - 2; i++) {
-    int rc = plan_scan(nodep_[i], mintrav, maxtrav, plans[i - 1]);
-    if (rc) return rc;
-  }
-  std::vector<uint32_t> out;
-  int rc = run_scans(plans, out);
+  std::vector<ScanPlan> plans;
+  const uint32_t *out = nullptr;
+  int rc = scan_batch(plans, nodep_.data() + 1, 2 * n_ - 2, mintrav, maxtrav, &out);
   if (rc) return rc;
   uint32_t best = UINT_MAX;
   uint64_t tests = 0;
-  for (const ScanPlan &pl : plans)
-    for (const Candidate &c : pl.cands) { best = std::min(best, pl.base + out[c.out]); tests++; }
+  for (const ScanPlan &pl : plans) {
+    const size_t nc = pl.walked ? (size_t)pl.n_total : pl.cands.size();
+    for (size_t c = 0; c < nc; c++) best = std::min(best, pl.base + pl.cost(c, out));
+    tests += nc;
+  }
   if (n_tests) *n_tests = tests;
   if (min_mp) *min_mp = best;
   return MPF_OK;
@@ -482,6 +649,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
+  if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
   set_error("unknown option " + key);
   return MPF_E_INVALID;
 }

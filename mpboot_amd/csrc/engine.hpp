@@ -65,7 +65,18 @@ struct ScanPlan {
   int32_t rec = -1;
   uint32_t base = 0;        // length(rest) + length(pruned subtree)
   int n_p = 0;              // candidates of the p side come first
-  std::vector<Candidate> cands;
+  int n_total = 0;
+  std::vector<Candidate> cands;     // host-planned mode only
+  // device-walked mode: descriptor indices (-1 = phase not applicable) and output offsets
+  bool walked = false;
+  int walk_p = -1, walk_q = -1;
+  uint32_t off_p = 0, off_q = 0;
+  int mintrav_q = 2, maxtrav = 0;
+  inline uint32_t cost(size_t c, const uint32_t *out) const
+  {
+    if (!walked) return out[cands[c].out];
+    return (int)c < n_p ? out[off_p + c] : out[off_q + (c - (size_t)n_p)];
+  }
 };
 
 struct Move { int32_t remove_rec, insert_rec; uint32_t score; };
@@ -102,6 +113,12 @@ class Engine {
   // ---- SPR neighbourhoods
   int plan_scan(int rec, int mintrav, int maxtrav, ScanPlan &plan);   // appends ops to the staging program
   int run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host);
+  // device-walked variant: the kernel enumerates the neighbourhood itself (k_scan_walk)
+  int plan_walk(int rec, int mintrav, int maxtrav, ScanPlan &plan);
+  int run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host);
+  int scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out);
+  int candidate_record(const ScanPlan &plan, size_t c);               // q of the c-th insertion test
+  void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const;
   int spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p);
   int sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp);
 
@@ -148,8 +165,16 @@ class Engine {
   DevBuf<EvOp> d_evops_;
   DevBuf<ScanOp> d_scanops_;
   DevBuf<ScanHdr> d_scanhdr_;
-  DevBuf<uint32_t> d_out_;
-  PinBuf<uint32_t> h_cnt_, h_out_;
+  DevBuf<uint32_t> d_out_, d_ncand_;
+  DevBuf<int32_t> d_back_;
+  DevBuf<WalkDesc> d_walk_;
+  PinBuf<uint32_t> h_cnt_, h_out_, h_ncand_;
+  PinBuf<WalkDesc> h_walk_;
+  size_t n_walk_ = 0;
+  uint32_t walk_out_ = 0;
+  bool back_on_device_ = false;
+  int scan_mode_ = 1;                           // 1 = device-walked scans, 0 = host-planned programs
+  std::vector<uint32_t> out_scratch_;
   PinBuf<ScanOp> h_scanops_;
   PinBuf<ScanHdr> h_scanhdr_;
   PinBuf<NvOp> h_nvops_;

@@ -319,6 +319,120 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, 
   }
 }
 
+
+// ---------------------------------------------------------------- SPR scan, device-walked
+//
+// Same arithmetic as k_scan, but the wave enumerates the neighbourhood itself: the DFS of
+// addTraverseParsimony (reference sprparsimony.cpp:2208-2218) runs on the scalar unit over the
+// `back` links, its frame stack lives in LDS (one small stack per wave), and the two children of
+// a node are expanded TOGETHER: their vectors d1, d2 are loaded once and give both
+//     U(c1) = fitch(U(parent), d2),  U(c2) = fitch(U(parent), d1)
+// and both candidates' costs, i.e. one vector read per candidate.  U lives in registers, two slots per
+// depth, selected by a wave-uniform switch.  Candidate costs are emitted in the reference's order
+// (the second child's cost waits in its stack frame until its turn).
+
+__device__ __forceinline__ int rec_next(int r)
+{
+  const int v = r / 3, s = r - 3 * v;
+  return 3 * v + (s == 2 ? 0 : s + 1);
+}
+__device__ __forceinline__ uint32_t rec_slot(int r, int n)
+{
+  const int v = r / 3;
+  return v <= n ? (uint32_t)(v - 1) : (uint32_t)(n + 3 * (v - n - 1) + (r - 3 * v));
+}
+
+template <int S, int VW, int MAXD, int RED>
+__global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ vec, const int32_t *__restrict__ back,
+                                                   int n, const WalkDesc *__restrict__ desc, int n_scans,
+                                                   uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
+                                                   int tiles)
+{
+  constexpr int STK = MAXD + 2;
+  __shared__ int s_q[4][STK];
+  __shared__ uint32_t s_meta[4][STK];   // depth | cost<<16
+
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  int gw = blockIdx.x * (blockDim.x >> 6) + wib;
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_scans * tiles) return;
+  const int scan = gw / tiles, tile = gw - scan * tiles;
+  const WalkDesc de = desc[scan];
+  const int x = de.x, mintrav = de.mintrav, maxtrav = de.maxtrav;
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+
+  // sv: pruned subtree; par: U of the node being expanded; pend[d]: U of the not-yet-expanded second
+  // child at depth d (one per depth suffices: the first child is expanded immediately)
+  Tile<S, VW> sv, par, u1, u2, d1, d2, pend[MAXD];
+  load_tile<S, VW>(sv, vec, rec_slot(__builtin_amdgcn_readfirstlane(back[x]), n), Wp, w0);
+  const int xa = __builtin_amdgcn_readfirstlane(back[rec_next(x)]);
+  const int xb = __builtin_amdgcn_readfirstlane(back[rec_next(rec_next(x))]);
+  uint32_t k = de.out_base;
+  int *stq = s_q[wib];
+  uint32_t *stm = s_meta[wib];
+
+  for (int side = 0; side < 2; side++) {
+    const int a = side ? xb : xa, other = side ? xa : xb;
+    if (a / 3 <= n) continue;                       // a tip: nothing behind it
+    load_tile<S, VW>(par, vec, rec_slot(other, n), Wp, w0);
+    int sp = 0, node = a, d = 0;
+    while (true) {
+      // ---- expand `node` (inner, depth d < maxtrav): both children at once
+      const int c1 = __builtin_amdgcn_readfirstlane(back[rec_next(node)]);
+      const int c2 = __builtin_amdgcn_readfirstlane(back[rec_next(rec_next(node))]);
+      load_tile<S, VW>(d1, vec, rec_slot(c1, n), Wp, w0);
+      load_tile<S, VW>(d2, vec, rec_slot(c2, n), Wp, w0);
+      const int dd = d + 1;
+      const bool test = dd >= mintrav;
+      const bool deeper = dd < maxtrav;
+      fitch<S, VW>(u1, par, d2);
+      fitch<S, VW>(u2, par, d1);
+      uint32_t tot = 0;
+      if (test) {
+        uint32_t cost = join_cost<S, VW>(u1, d1, sv) | (join_cost<S, VW>(u2, d2, sv) << 16);
+        cost = valid ? cost : 0u;
+        tot = wave_total<RED>(cost);
+      }
+      if (deeper && c2 / 3 > n) {
+#define MPF_PUT(D) case D: if constexpr (D < MAXD) pend[D] = u2; break;
+        switch (dd) { MPF_PUT(1) MPF_PUT(2) MPF_PUT(3) MPF_PUT(4) MPF_PUT(5) MPF_PUT(6) MPF_PUT(7) MPF_PUT(8) MPF_PUT(9) MPF_PUT(10) MPF_PUT(11) default: break; }
+#undef MPF_PUT
+      }
+      stq[sp] = c2; stm[sp] = (uint32_t)dd | ((tot >> 16) << 16); sp++;
+      if (test) {
+        const uint32_t c = tot & 0xFFFFu;
+        if (lane == 0 && c) atomic_add_u32(out + k, c);
+        k++;
+      }
+      if (deeper && c1 / 3 > n) { par = u1; node = c1; d = dd; continue; }
+      // ---- unwind: emit pending second children until one of them has to be expanded
+      bool more = false;
+      while (sp > 0) {
+        sp--;
+        const int q = __builtin_amdgcn_readfirstlane(stq[sp]);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)stm[sp]);
+        const int dq = (int)(m & 0xFFu);
+        if (dq >= mintrav) {
+          const uint32_t c = m >> 16;
+          if (lane == 0 && c) atomic_add_u32(out + k, c);
+          k++;
+        }
+        if (dq < maxtrav && q / 3 > n) {
+#define MPF_GET(D) case D: if constexpr (D < MAXD) par = pend[D]; break;
+          switch (dq) { MPF_GET(1) MPF_GET(2) MPF_GET(3) MPF_GET(4) MPF_GET(5) MPF_GET(6) MPF_GET(7) MPF_GET(8) MPF_GET(9) MPF_GET(10) MPF_GET(11) default: break; }
+#undef MPF_GET
+          node = q; d = dq; more = true;
+          break;
+        }
+      }
+      if (!more) break;
+    }
+  }
+  if (tile == 0 && lane == 0) ncand[scan] = k - de.out_base;
+}
+
 // ---------------------------------------------------------------- launch wrappers
 
 static inline int tiles_of(const Geometry &g) { return (g.Wp + 64 * g.vw - 1) / (64 * g.vw); }
@@ -404,6 +518,31 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
   MPF_DISPATCH_SV(SC2, 0);
 #undef SC2
 #undef SC
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const int32_t *back, int n_taxa,
+                            const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth)
+{
+  if (n_scans <= 0) return hipSuccess;
+  if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;
+  const int tiles = tiles_of(g);
+  const long waves = (long)n_scans * tiles;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define SW(S_, VW_, MAXD_, RED_) \
+  hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, back, n_taxa, desc, n_scans, out, ncand, g.Wp, tiles)
+#define SW2(S_, VW_, dummy)                                                                  \
+  do {                                                                                       \
+    if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0); else SW(S_, VW_, 6, 1); }    \
+    else { if (g.reduce == 0) SW(S_, VW_, 12, 0); else SW(S_, VW_, 12, 1); }                 \
+  } while (0)
+  if (g.S == 4) {
+    if (g.vw == 1) SW2(4, 1, 0); else SW2(4, 2, 0);
+  } else {
+    SW2(20, 1, 0);
+  }
+#undef SW2
+#undef SW
   return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
   unsigned iter_hits = 1;                         // bestIterationScoreHits
   const int total = 2 * n_ - 2;
   std::vector<ScanPlan> plans;
-  std::vector<uint32_t> out;
+  const uint32_t *out = nullptr;
   int batch = std::max(1, scan_batch_);
   do {
     startMP = randomMP;
@@ -43,12 +43,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
     while (i <= total) {
       if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
       const int hi = std::min(total, i + batch - 1);
-      plans.assign((size_t)(hi - i + 1), ScanPlan());
-      for (int j = i; j <= hi; j++) {
-        int rc = plan_scan(nodep_[j], mintrav, maxtrav, plans[(size_t)(j - i)]);
-        if (rc) return rc;
-      }
-      int rc = run_scans(plans, out);
+      int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
       if (rc) return rc;
       bool moved = false;
       int j = i;
@@ -58,19 +53,23 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
           insert_rec_ = remove_rec_ = -1;
           hits_ = 1;
         }
-        // testInsertParsimony's bookkeeping (reference :2168-2176 / fastDNAparsimony.c:1224-1229)
-        for (size_t c = 0; c < pl.cands.size(); c++) {
-          const uint32_t mp = pl.base + out[pl.cands[c].out];
-          const int prune = (int)c < pl.n_p ? pl.rec : back_[pl.rec];
+        // testInsertParsimony's bookkeeping (reference :2168-2176 / fastDNAparsimony.c:1224-1229);
+        // the chosen candidate is remembered by index and only named (record q) if the move is applied
+        long sel = -1;
+        const size_t nc = (size_t)pl.n_total;
+        for (size_t c = 0; c < nc; c++) {
+          const uint32_t mp = pl.base + pl.cost(c, out);
           if (tie_mode_ == MPF_TIE_RANDOM) {
             if (mp < best_) hits_ = 1;
             else if (mp == best_) hits_++;
-            if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) {
-              best_ = mp; insert_rec_ = pl.cands[c].q; remove_rec_ = prune;
-            }
+            if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; sel = (long)c; }
           } else if (mp < best_) {
-            best_ = mp; insert_rec_ = pl.cands[c].q; remove_rec_ = prune;
+            best_ = mp; sel = (long)c;
           }
+        }
+        if (sel >= 0) {
+          insert_rec_ = candidate_record(pl, (size_t)sel);
+          remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
         }
         bool accept;
         if (tie_mode_ == MPF_TIE_RANDOM) {
