@@ -284,8 +284,11 @@ int Engine::update_views()
     }
   }
   HIPCHK(hipMemcpyAsync(d_nvops_.p, h_nvops_.p, nops * sizeof(NvOp), hipMemcpyHostToDevice, st_));
-  HIPCHK(d_back_.reserve(back_.size()));
-  HIPCHK(hipMemcpyAsync(d_back_.p, back_.data(), back_.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  // topology for the device-walked scans: kids[cid] = the two records behind an inner record
+  kids_host_.assign(nslots_, make_uint2(0u, 0u));
+  for (int r : order) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
+  HIPCHK(d_kids_.reserve(nslots_));
+  HIPCHK(hipMemcpyAsync(d_kids_.p, kids_host_.data(), nslots_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
   back_on_device_ = true;
   HIPCHK(hipMemsetAsync(d_cnt_, 0, nslots_ * sizeof(uint32_t), st_));
   HIPCHK(hipEventRecord(ev0_, st_));
@@ -496,7 +499,7 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan)
   const int q = back_[p];
   plan.base = (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);
   if (maxtrav < mintrav) return MPF_OK;
-  const uint32_t stride = 4u * ((1u << maxtrav) - 1u);
+  const uint32_t stride = maxtrav <= 6 ? 256u : 4u * ((1u << maxtrav) - 1u);   // <=6: lane-accumulated outputs (4 x 64)
   auto add = [&](int x, int mt) -> int {
     if (h_walk_.cap < n_walk_ + 1) {
       PinBuf<WalkDesc> bigger;
@@ -506,7 +509,12 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan)
       std::swap(bigger.cap, h_walk_.cap);
     }
     WalkDesc &d = h_walk_.p[n_walk_];
-    d.x = x; d.mintrav = mt; d.maxtrav = maxtrav; d.out_base = walk_out_;
+    d.s_cid = slot(back_[x]);
+    d.xa_cid = slot(back_[nx(x)]);
+    d.xb_cid = slot(back_[nx(nx(x))]);
+    d.trav = (uint32_t)mt | ((uint32_t)maxtrav << 8);
+    d.out_base = walk_out_;
+    d.pad0 = d.pad1 = d.pad2 = 0;
     walk_out_ += stride;
     return (int)n_walk_++;
   };
@@ -533,7 +541,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
   const size_t nd = n_walk_, nout = walk_out_;
   *out_host = nullptr;
   int maxd = 0;
-  for (size_t i = 0; i < nd; i++) maxd = std::max(maxd, h_walk_.p[i].maxtrav);
+  for (size_t i = 0; i < nd; i++) maxd = std::max(maxd, (int)(h_walk_.p[i].trav >> 8));
   if (nd > 0) {
     HIPCHK(d_walk_.reserve(nd));
     HIPCHK(d_ncand_.reserve(nd));
@@ -543,7 +551,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_));
     HIPCHK(hipMemsetAsync(d_out_.p, 0, nout * sizeof(uint32_t), st_));
     HIPCHK(hipEventRecord(ev0_, st_));
-    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_back_.p, n_, d_walk_.p, (int)nd, d_out_.p, d_ncand_.p, maxd));
+    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids_.p, n_, d_walk_.p, (int)nd, d_out_.p, d_ncand_.p, maxd));
     HIPCHK(hipEventRecord(ev1_, st_));
     HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
     HIPCHK(hipMemcpyAsync(h_ncand_.p, d_ncand_.p, nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));

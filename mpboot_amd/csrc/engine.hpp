@@ -166,7 +166,8 @@ class Engine {
   DevBuf<ScanOp> d_scanops_;
   DevBuf<ScanHdr> d_scanhdr_;
   DevBuf<uint32_t> d_out_, d_ncand_;
-  DevBuf<int32_t> d_back_;
+  DevBuf<uint2> d_kids_;
+  std::vector<uint2> kids_host_;
   DevBuf<WalkDesc> d_walk_;
   PinBuf<uint32_t> h_cnt_, h_out_, h_ncand_;
   PinBuf<WalkDesc> h_walk_;

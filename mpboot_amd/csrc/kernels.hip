@@ -331,60 +331,105 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, 
 // depth, selected by a wave-uniform switch.  Candidate costs are emitted in the reference's order
 // (the second child's cost waits in its stack frame until its turn).
 
-__device__ __forceinline__ int rec_next(int r)
+// uniform-base tile load: `base` = vec + cid * S * Wp is wave-uniform (SGPR pair), the lane supplies a
+// 32-bit element offset -> global_load with scalar base + vector offset, no 64-bit vector address math
+template <int S, int VW>
+__device__ __forceinline__ void load_tile_u(Tile<S, VW> &t, const uint32_t *__restrict__ base, uint32_t w0, uint32_t Wp)
 {
-  const int v = r / 3, s = r - 3 * v;
-  return 3 * v + (s == 2 ? 0 : s + 1);
-}
-__device__ __forceinline__ uint32_t rec_slot(int r, int n)
-{
-  const int v = r / 3;
-  return v <= n ? (uint32_t)(v - 1) : (uint32_t)(n + 3 * (v - n - 1) + (r - 3 * v));
+#pragma unroll
+  for (int k = 0; k < S; k++) {
+    const uint32_t off = w0 + (uint32_t)k * Wp;
+    if constexpr (VW == 1) {
+      t.v[k][0] = base[off];
+    } else if constexpr (VW == 2) {
+      uint2 x = *reinterpret_cast<const uint2 *>(base + off);
+      t.v[k][0] = x.x; t.v[k][1] = x.y;
+    } else {
+      uint4 x = *reinterpret_cast<const uint4 *>(base + off);
+      t.v[k][0] = x.x; t.v[k][1] = x.y; t.v[k][2] = x.z; t.v[k][3] = x.w;
+    }
+  }
 }
 
 template <int S, int VW, int MAXD, int RED>
-__global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ vec, const int32_t *__restrict__ back,
-                                                   int n, const WalkDesc *__restrict__ desc, int n_scans,
+__global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
+                                                   uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
-                                                   int tiles)
+                                                   int tiles, int map)
 {
   constexpr int STK = MAXD + 2;
-  __shared__ int s_q[4][STK];
-  __shared__ uint32_t s_meta[4][STK];   // depth | cost<<16
+  constexpr bool LANEACC = MAXD <= 6;      // <= 4*(2^6-1) = 252 candidates: one output slot per (lane, register)
+  __shared__ uint2 s_frame[4][STK];        // x = cid | depth<<24, y = cost
 
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  int gw = blockIdx.x * (blockDim.x >> 6) + wib;
-  gw = __builtin_amdgcn_readfirstlane(gw);
-  if (gw >= n_scans * tiles) return;
-  const int scan = gw / tiles, tile = gw - scan * tiles;
+  int scan, tile;
+  if (map == 0) {
+    int gw = blockIdx.x * (blockDim.x >> 6) + wib;
+    gw = __builtin_amdgcn_readfirstlane(gw);
+    if (gw >= n_scans * tiles) return;
+    scan = gw / tiles;
+    tile = gw - scan * tiles;
+  } else {
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the groups that
+    // share an L2).  The (tile, scan) items, tile-major, are cut into 8 equal contiguous chunks, one per
+    // XCD class, and each class walks its chunk in order.  Affects speed only.
+    const long total = (long)n_scans * tiles;
+    const long chunk = (total + 7) / 8;
+    const int cls = blockIdx.x & 7;
+    long idx = (long)(blockIdx.x >> 3) * (blockDim.x >> 6) + wib;
+    idx = __builtin_amdgcn_readfirstlane((int)idx);
+    if (idx >= chunk) return;
+    const long item = (long)cls * chunk + idx;
+    if (item >= total) return;
+    tile = (int)(item / n_scans);
+    scan = (int)(item - (long)tile * n_scans);
+  }
   const WalkDesc de = desc[scan];
-  const int x = de.x, mintrav = de.mintrav, maxtrav = de.maxtrav;
+  const uint32_t mintrav = de.trav & 0xFFu, maxtrav = de.trav >> 8;
   bool valid;
-  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  const uint32_t w0 = (uint32_t)lane_word<VW>(tile, lane, Wp, valid);
+  const uint32_t SW = (uint32_t)S * (uint32_t)Wp;
+#define MPF_VEC(cid) (vec + (size_t)((uint32_t)(cid) * SW))
 
   // sv: pruned subtree; par: U of the node being expanded; pend[d]: U of the not-yet-expanded second
   // child at depth d (one per depth suffices: the first child is expanded immediately)
   Tile<S, VW> sv, par, u1, u2, d1, d2, pend[MAXD];
-  load_tile<S, VW>(sv, vec, rec_slot(__builtin_amdgcn_readfirstlane(back[x]), n), Wp, w0);
-  const int xa = __builtin_amdgcn_readfirstlane(back[rec_next(x)]);
-  const int xb = __builtin_amdgcn_readfirstlane(back[rec_next(rec_next(x))]);
-  uint32_t k = de.out_base;
-  int *stq = s_q[wib];
-  uint32_t *stm = s_meta[wib];
+  load_tile_u<S, VW>(sv, MPF_VEC(de.s_cid), w0, Wp);
+  uint32_t k = 0;                              // candidates emitted so far (scan-local index)
+  uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+  uint2 *stk = s_frame[wib];
+
+  auto emit = [&](uint32_t c) {
+    if constexpr (LANEACC) {
+      // candidate k belongs to lane k&63, register k>>6: a lane select instead of a memory atomic
+      const bool mine = (uint32_t)lane == (k & 63u);
+      switch (k >> 6) {
+        case 0: acc0 = mine ? c : acc0; break;
+        case 1: acc1 = mine ? c : acc1; break;
+        case 2: acc2 = mine ? c : acc2; break;
+        default: acc3 = mine ? c : acc3; break;
+      }
+    } else {
+      if (lane == 0 && c) atomic_add_u32(out + de.out_base + k, c);
+    }
+    k++;
+  };
 
   for (int side = 0; side < 2; side++) {
-    const int a = side ? xb : xa, other = side ? xa : xb;
-    if (a / 3 <= n) continue;                       // a tip: nothing behind it
-    load_tile<S, VW>(par, vec, rec_slot(other, n), Wp, w0);
-    int sp = 0, node = a, d = 0;
+    const uint32_t a = side ? de.xb_cid : de.xa_cid, other = side ? de.xa_cid : de.xb_cid;
+    if (a < n) continue;                       // a tip: nothing behind it
+    load_tile_u<S, VW>(par, MPF_VEC(other), w0, Wp);
+    int sp = 0;
+    uint32_t node = a, d = 0;
     while (true) {
       // ---- expand `node` (inner, depth d < maxtrav): both children at once
-      const int c1 = __builtin_amdgcn_readfirstlane(back[rec_next(node)]);
-      const int c2 = __builtin_amdgcn_readfirstlane(back[rec_next(rec_next(node))]);
-      load_tile<S, VW>(d1, vec, rec_slot(c1, n), Wp, w0);
-      load_tile<S, VW>(d2, vec, rec_slot(c2, n), Wp, w0);
-      const int dd = d + 1;
+      const uint2 kc = kids[node];
+      const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.x);
+      const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.y);
+      load_tile_u<S, VW>(d1, MPF_VEC(c1), w0, Wp);
+      load_tile_u<S, VW>(d2, MPF_VEC(c2), w0, Wp);
+      const uint32_t dd = d + 1;
       const bool test = dd >= mintrav;
       const bool deeper = dd < maxtrav;
       fitch<S, VW>(u1, par, d2);
@@ -395,31 +440,24 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
         cost = valid ? cost : 0u;
         tot = wave_total<RED>(cost);
       }
-      if (deeper && c2 / 3 > n) {
+      if (deeper && c2 >= n) {
 #define MPF_PUT(D) case D: if constexpr (D < MAXD) pend[D] = u2; break;
         switch (dd) { MPF_PUT(1) MPF_PUT(2) MPF_PUT(3) MPF_PUT(4) MPF_PUT(5) MPF_PUT(6) MPF_PUT(7) MPF_PUT(8) MPF_PUT(9) MPF_PUT(10) MPF_PUT(11) default: break; }
 #undef MPF_PUT
       }
-      stq[sp] = c2; stm[sp] = (uint32_t)dd | ((tot >> 16) << 16); sp++;
-      if (test) {
-        const uint32_t c = tot & 0xFFFFu;
-        if (lane == 0 && c) atomic_add_u32(out + k, c);
-        k++;
-      }
-      if (deeper && c1 / 3 > n) { par = u1; node = c1; d = dd; continue; }
+      stk[sp] = make_uint2(c2 | (dd << 24), tot >> 16);
+      sp++;
+      if (test) emit(tot & 0xFFFFu);
+      if (deeper && c1 >= n) { par = u1; node = c1; d = dd; continue; }
       // ---- unwind: emit pending second children until one of them has to be expanded
       bool more = false;
       while (sp > 0) {
         sp--;
-        const int q = __builtin_amdgcn_readfirstlane(stq[sp]);
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)stm[sp]);
-        const int dq = (int)(m & 0xFFu);
-        if (dq >= mintrav) {
-          const uint32_t c = m >> 16;
-          if (lane == 0 && c) atomic_add_u32(out + k, c);
-          k++;
-        }
-        if (dq < maxtrav && q / 3 > n) {
+        const uint2 fr = stk[sp];
+        const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)fr.x);
+        const uint32_t q = fx & 0xFFFFFFu, dq = fx >> 24;
+        if (dq >= mintrav) emit((uint32_t)__builtin_amdgcn_readfirstlane((int)fr.y));
+        if (dq < maxtrav && q >= n) {
 #define MPF_GET(D) case D: if constexpr (D < MAXD) par = pend[D]; break;
           switch (dq) { MPF_GET(1) MPF_GET(2) MPF_GET(3) MPF_GET(4) MPF_GET(5) MPF_GET(6) MPF_GET(7) MPF_GET(8) MPF_GET(9) MPF_GET(10) MPF_GET(11) default: break; }
 #undef MPF_GET
@@ -430,7 +468,15 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
       if (!more) break;
     }
   }
-  if (tile == 0 && lane == 0) ncand[scan] = k - de.out_base;
+#undef MPF_VEC
+  if constexpr (LANEACC) {
+    uint32_t *o = out + de.out_base + lane;
+    if ((uint32_t)lane < k && acc0) atomic_add_u32(o, acc0);
+    if ((uint32_t)lane + 64u < k && acc1) atomic_add_u32(o + 64, acc1);
+    if ((uint32_t)lane + 128u < k && acc2) atomic_add_u32(o + 128, acc2);
+    if ((uint32_t)lane + 192u < k && acc3) atomic_add_u32(o + 192, acc3);
+  }
+  if (tile == 0 && lane == 0) ncand[scan] = k;
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -521,16 +567,20 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
   return hipGetLastError();
 }
 
-hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const int32_t *back, int n_taxa,
+hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth)
 {
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;
   const int tiles = tiles_of(g);
   const long waves = (long)n_scans * tiles;
-  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  dim3 block(256);
+  unsigned nblocks;
+  if (g.map == 0) nblocks = (unsigned)((waves + 3) / 4);
+  else { const long chunk = (waves + 7) / 8; nblocks = (unsigned)(((chunk + 3) / 4) * 8); }
+  dim3 grid(nblocks);
 #define SW(S_, VW_, MAXD_, RED_) \
-  hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, back, n_taxa, desc, n_scans, out, ncand, g.Wp, tiles)
+  hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc, n_scans, out, ncand, g.Wp, tiles, g.map)
 #define SW2(S_, VW_, dummy)                                                                  \
   do {                                                                                       \
     if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0); else SW(S_, VW_, 6, 1); }    \

@@ -29,7 +29,9 @@ enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2 };
 // device-walked scan: the kernel enumerates the neighbourhood of prune record x itself from the
 // topology (back links) resident in HBM; candidate i of the scan lands in out[out_base + i] in the
 // reference's DFS order, ncand[scan] = number of candidates
-struct WalkDesc { int32_t x, mintrav, maxtrav; uint32_t out_base; };
+// All ids are compact vector slots ("cid"): tips 0..n-1, inner record 3v+s -> n + 3(v-n-1) + s.
+// kids[cid] = cids of the two records behind an inner record (back[next], back[next next]).
+struct WalkDesc { uint32_t s_cid, xa_cid, xb_cid, trav /* mintrav | maxtrav<<8 */, out_base, pad0, pad1, pad2; };
 constexpr int kWalkMaxDepth = 12;
 constexpr int kMaxDepth = 12;   // deepest chain the register-resident scan kernel supports
 
@@ -49,7 +51,7 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
                            uint32_t *out);
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
                        const ScanOp *ops, uint32_t *out, int max_depth);
-hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const int32_t *back, int n_taxa,
+hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth);
 // per-site mutation counts of the current tree: for every op (a,b) adds the empty-intersection mask bits
 hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,

@@ -162,10 +162,6 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     // candidate branches in the reference's DFS order with its descent cut (:3014)
     ScanPlan &pl = plans[0];
     pl.cands.clear();
-    ScanHdr h;
-    h.op_begin = (uint32_t)prog_ops_.size();
-    h.s_slot = slot(p);
-    h.pad = 0;
     stack.clear();
     stack.push_back(back_[f]);
     while (!stack.empty()) {
@@ -183,8 +179,16 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
         stack.push_back(back_[nx(c)]);
       }
     }
-    h.op_end = (uint32_t)prog_ops_.size();
-    prog_hdr_.push_back(h);
+    // the joins are independent of each other: cut them into short programs so that the launch
+    // has (candidates/4 x tiles) waves instead of one wave per tile
+    for (size_t b = 0; b < prog_ops_.size(); b += 4) {
+      ScanHdr h;
+      h.op_begin = (uint32_t)b;
+      h.op_end = (uint32_t)std::min(prog_ops_.size(), b + 4);
+      h.s_slot = slot(p);
+      h.pad = 0;
+      prog_hdr_.push_back(h);
+    }
     rc = run_scans(plans, out);
     if (rc) return rc;
     for (const Candidate &c : pl.cands) {
