@@ -52,8 +52,9 @@ def cpu_baseline(codes, back, names, letters, alphabet, maxtrav, budget_s):
                     tests, secs, done, tot = int(t[6]), float(t[8]), int(t[2]), int(t[4])
                     return {"value": n * P * tests / secs, "unit": "site-ops/s", "cores": 1, "kind": "reference",
                             "evals_per_s": tests / secs,
-                            "sample": f"reference PLL AVX testInsertParsimony over the first {done} of {tot} prune nodes "
-                                      f"of the same tree, radius {maxtrav} ({tests} insertion tests, {secs:.1f} s, 1 thread)"}
+                            "sample": f"reference PLL AVX testInsertParsimony (oracle/_ref/pll_ref_driver time), {done} prune-node "
+                                      f"scans cycling over the {tot} prune nodes of the same tree, radius {maxtrav} "
+                                      f"({tests} insertion tests in {secs:.1f} s, 1 thread)"}
         except Exception as exc:  # fall through to the port
             print(f"[bench] reference driver failed ({exc}); using the scalar port", file=sys.stderr)
     from oracle import pyoracle as po

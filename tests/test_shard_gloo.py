@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: two gloo ranks shard independent start trees; the result must equal the
+single-process run.  The per-unit work is done by the oracle here (no GPU in this test)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from helpers import ROOT
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MPF_ROOT"])
+import torch.distributed as dist
+from mpboot_amd import shard, synth
+from oracle import pyoracle as po
+
+class OracleAsEngine:
+    def __init__(self, codes):
+        self.o = po.Oracle(codes)
+    def seed_ties(self, mode, seed):
+        self.o.seed_ties(mode, seed)
+    def make_parsimony_tree(self, seed, dist_):
+        self.o.reset_nodep()
+        return self.o.make_tree(seed, dist_)[0]
+    def get_tree(self):
+        return self.o.get_tree()
+
+ws = int(os.environ.get("WORLD_SIZE", "1"))
+if ws > 1:
+    dist.init_process_group("gloo")
+letters, _ = synth.synth_alignment(16, 300, "DNA", 0.15, seed=2)
+codes = synth.letters_to_codes(letters)
+scores, best, tree = shard.search_start_trees(lambda: OracleAsEngine(codes), 6, 77, 3)
+if shard.world()[0] == 0:
+    print("RESULT " + json.dumps({"scores": scores.tolist(), "best": best, "tree": tree.tolist()}))
+if ws > 1:
+    dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nproc, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MPF_ROOT=ROOT)
+    if nproc == 1:
+        cmd = [sys.executable, str(script)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    import json
+    return json.loads(line[7:])
+
+
+def test_unit_assignment_and_seeds():
+    from mpboot_amd import shard
+    assert shard.units_of_rank(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard.units_of_rank(10, r, 4) for r in range(4)), [])) == list(range(10))
+    assert shard.unit_seed(5, 3) == 5 + 3 * 12345
+
+
+def test_two_gloo_ranks_equal_single_process(tmp_path):
+    one = _run(1, tmp_path)
+    two = _run(2, tmp_path)
+    assert one["scores"] == two["scores"]
+    assert one["best"] == two["best"]
+    assert one["tree"] == two["tree"]
+    assert min(one["scores"]) == one["scores"][one["best"]]

@@ -13,4 +13,8 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCL
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py $ARGS > $OUT/bench_pmc_$N.json 2> $OUT/pmc_$N.err
 done
 python3 tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
+# keep only the small artefacts (the raw per-dispatch CSVs exceed gpurun's 64 MiB return limit)
+mkdir -p $OUT/keep
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/keep/kernel_stats.csv \;
+rm -rf $OUT/trace $OUT/pmc_*
 cat $OUT/summary.txt
