@@ -41,6 +41,8 @@ Engine::~Engine()
   if (d_tipslots_) (void)hipFree(d_tipslots_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
+  if (ev2_) (void)hipEventDestroy(ev2_);
+  if (ev3_) (void)hipEventDestroy(ev3_);
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -86,6 +88,8 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   HIPCHK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&ev0_));
   HIPCHK(hipEventCreate(&ev1_));
+  HIPCHK(hipEventCreate(&ev2_));
+  HIPCHK(hipEventCreate(&ev3_));
   HIPCHK(hipMalloc((void **)&d_codes_, (size_t)n_ * P_));
   HIPCHK(hipMemcpy(d_codes_, codes_.data(), (size_t)n_ * P_, hipMemcpyHostToDevice));
   nslots_ = (size_t)n_ + 3 * (size_t)(n_ - 1);
@@ -100,6 +104,9 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   back_.assign(3 * (size_t)(2 * n_ - 1) + 3, -1);
   nodep_.assign(2 * (size_t)n_, 0);
   sc_.assign(back_.size(), 0);
+  valid_.assign(back_.size(), 0);
+  lev_.assign(back_.size(), 0);
+  lev_epoch_.assign(back_.size(), 0);
   reset_node_order();
   rng_.seed(1);
   return pack();
@@ -146,7 +153,7 @@ int Engine::pack()
   HIPCHK(hipMemcpyAsync(d_site2ptn_.p, s2p.data(), s2p.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
   HIPCHK(launch_pack_tips(st_, g_, d_vec_, d_codes_, n_, P_, d_site2ptn_.p, nsites_, datatype_, d_tipslots_));
   HIPCHK(hipStreamSynchronize(st_));
-  views_valid_ = false;
+  invalidate_all();
   return MPF_OK;
 }
 
@@ -186,7 +193,7 @@ int Engine::set_tree(const int32_t *back)
   start_ = nodep_[1];
   ntips_ = n_;
   have_tree_ = true;
-  views_valid_ = false;
+  invalidate_all();
   return MPF_OK;
 }
 
@@ -212,107 +219,228 @@ void Engine::node_rectifier()
 }
 
 // ---- directional views ---------------------------------------------------------------------
-// vec[r] (r inner) = fitch(vec[back[nx r]], vec[back[nx nx r]]); dependency levels are launched
-// one after another on the engine stream (each level is one k_newview launch).
-int Engine::update_views()
+// vec[r] (r inner) = fitch(vec[back[nx r]], vec[back[nx nx r]]).  Every vector carries a validity flag;
+// a topology edit invalidates exactly the vectors whose subtree contains an edited node, and a refresh
+// recomputes only the invalid vectors that the requested roots depend on, level by level.
+
+void Engine::invalidate_all()
+{
+  std::fill(valid_.begin(), valid_.end(), 0);
+  n_invalid_ = -1;
+  views_valid_ = false;
+  kids_dirty_ = true;
+}
+
+// Invariant: a valid vector has valid inputs.  The vectors containing `node` are its own three and, walking
+// outwards, the two outward-looking vectors of every node reached; the walk stops at vectors that are
+// already invalid (everything beyond them is invalid by the invariant).
+void Engine::invalidate_node(int node)
+{
+  if (node <= n_) return;
+  std::vector<int> stack;
+  for (int s = 0; s < 3; s++) {
+    const int r = 3 * node + s;
+    if (valid_[r]) { valid_[r] = 0; if (n_invalid_ >= 0) n_invalid_++; }
+    const int w = back_[r];
+    if (w >= 0 && !tip(w)) stack.push_back(w);
+  }
+  while (!stack.empty()) {
+    const int w = stack.back();           // record on a neighbouring node, looking back at where we came from
+    stack.pop_back();
+    const int o[2] = {nx(w), nx(nx(w))};
+    for (int k = 0; k < 2; k++) {
+      const int r = o[k];
+      if (!valid_[r]) continue;
+      valid_[r] = 0;
+      if (n_invalid_ >= 0) n_invalid_++;
+      const int u = back_[r];
+      if (u >= 0 && !tip(u)) stack.push_back(u);
+    }
+  }
+  views_valid_ = false;
+  kids_dirty_ = true;
+}
+
+int Engine::schedule_views(const std::vector<int> *roots)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   ScopedMs timer(stats.host_views_ms_total);
-  // inner nodes of the component containing start_
-  std::vector<int> inner;
-  {
+  std::vector<int> all;
+  if (!roots) {
+    // every record of the component containing start_
     std::vector<int> stack;
     std::vector<char> seen(2 * (size_t)n_ + 1, 0);
     stack.push_back(back_[start_]);
-    if (tip(back_[start_]) ) { /* two-tip tree: nothing to do */ }
     while (!stack.empty()) {
       const int r = stack.back();
       stack.pop_back();
       if (r < 0 || tip(r) || seen[num(r)]) continue;
       seen[num(r)] = 1;
-      inner.push_back(num(r));
-      for (int s = 0; s < 3; s++) stack.push_back(back_[3 * num(r) + s]);
+      for (int s = 0; s < 3; s++) { all.push_back(3 * num(r) + s); stack.push_back(back_[3 * num(r) + s]); }
+    }
+    roots = &all;
+  }
+  // closure of invalid inputs, post-order, with dependency levels (epoch-stamped scratch arrays)
+  epoch_++;
+  std::vector<int> order;
+  std::vector<std::pair<int, int>> stack;
+  auto lev_of = [&](int r) { return (tip(r) || lev_epoch_[r] != epoch_) ? 0 : lev_[r]; };
+  for (int r0 : *roots) {
+    if (r0 < 0 || tip(r0) || valid_[r0] || lev_epoch_[r0] == epoch_) continue;
+    stack.emplace_back(r0, 0);
+    while (!stack.empty()) {
+      auto &top = stack.back();
+      const int r = top.first;
+      const int a = back_[nx(r)], b = back_[nx(nx(r))];
+      if (top.second == 0) {
+        top.second = 1;
+        if (!tip(a) && !valid_[a] && lev_epoch_[a] != epoch_) { stack.emplace_back(a, 0); continue; }
+      }
+      if (top.second == 1) {
+        top.second = 2;
+        if (!tip(b) && !valid_[b] && lev_epoch_[b] != epoch_) { stack.emplace_back(b, 0); continue; }
+      }
+      if (lev_epoch_[r] != epoch_) {
+        lev_[r] = 1 + std::max(lev_of(a), lev_of(b));
+        lev_epoch_[r] = epoch_;
+        order.push_back(r);
+      }
+      stack.pop_back();
     }
   }
-  // level of every inner record, iterative post-order with memo
-  std::vector<int> level(back_.size(), -1);
-  std::vector<int> order;                  // records in dependency order
-  order.reserve(inner.size() * 3);
-  std::vector<std::pair<int, int>> stack;  // (record, state)
-  for (int v : inner)
-    for (int s = 0; s < 3; s++) {
-      const int r0 = 3 * v + s;
-      if (level[r0] >= 0) continue;
-      stack.emplace_back(r0, 0);
-      while (!stack.empty()) {
-        auto &top = stack.back();
-        const int r = top.first;
-        const int a = back_[nx(r)], b = back_[nx(nx(r))];
-        if (top.second == 0) {
-          top.second = 1;
-          if (!tip(a) && level[a] < 0) stack.emplace_back(a, 0);
-          continue;
-        }
-        if (top.second == 1) {
-          top.second = 2;
-          if (!tip(b) && level[b] < 0) stack.emplace_back(b, 0);
-          continue;
-        }
-        const int la = tip(a) ? 0 : level[a], lb = tip(b) ? 0 : level[b];
-        level[r] = 1 + std::max(la, lb);
-        order.push_back(r);
-        stack.pop_back();
-      }
-    }
-  int maxlev = 0;
-  for (int r : order) maxlev = std::max(maxlev, level[r]);
-  std::vector<int> lev_count(maxlev + 2, 0);
-  for (int r : order) lev_count[level[r]]++;
-  std::vector<int> lev_off(maxlev + 2, 0);
-  for (int l = 1; l <= maxlev; l++) lev_off[l + 1] = lev_off[l] + lev_count[l];
   const size_t nops = order.size();
+  if (kids_dirty_) {
+    // topology for the device-walked scans: kids[cid] = the two records behind an inner record
+    if (kids_host_.size() != nslots_) kids_host_.assign(nslots_, make_uint2(0u, 0u));
+    for (int r : *roots)
+      if (r >= 0 && !tip(r)) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
+    for (int r : order) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
+    HIPCHK(d_kids_.reserve(nslots_));
+    HIPCHK(hipMemcpyAsync(d_kids_.p, kids_host_.data(), nslots_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
+    if (roots == &all) kids_dirty_ = false;
+  }
+  if (nops == 0) {
+    if (roots == &all) { n_invalid_ = 0; views_valid_ = true; }
+    return MPF_OK;
+  }
+  int maxlev = 0;
+  for (int r : order) maxlev = std::max(maxlev, lev_[r]);
+  HIPCHK(h_levoff_.reserve((size_t)maxlev + 2));
+  HIPCHK(d_levoff_.reserve((size_t)maxlev + 2));
+  int32_t *lo = h_levoff_.p;                 // lo[l-1]..lo[l] = ops of level l (levels are 1-based)
+  for (int l = 0; l <= maxlev; l++) lo[l] = 0;
+  for (int r : order) lo[lev_[r]]++;
+  {
+    int acc = 0;
+    for (int l = 1; l <= maxlev; l++) { const int c = lo[l]; lo[l] = acc; acc += c; }
+    lo[0] = 0;
+  }
+  // lo[l] now = start of level l (for l>=1); shift into [0..maxlev] = offsets, fill ops
   HIPCHK(h_nvops_.reserve(nops));
   HIPCHK(d_nvops_.reserve(nops));
   {
-    std::vector<int> fill(lev_off);
+    std::vector<int> fill(lo, lo + maxlev + 1);
+    upd_order_.resize(nops);
     for (int r : order) {
-      NvOp &o = h_nvops_.p[fill[level[r]]++];
+      const int at = fill[lev_[r]]++;
+      NvOp &o = h_nvops_.p[at];
       o.dst = slot(r);
       o.a = slot(back_[nx(r)]);
       o.b = slot(back_[nx(nx(r))]);
       o.pad = (uint32_t)r;
+      upd_order_[(size_t)at] = r;
+    }
+    for (int l = 1; l <= maxlev; l++) lo[l - 1] = lo[l];
+    lo[maxlev] = (int32_t)nops;            // lo[0..maxlev]: offsets of levels 1..maxlev
+  }
+  const int tiles = tiles_for(g_);
+  HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
+  HIPCHK(hipMemcpyAsync(d_nvops_.p, h_nvops_.p, nops * sizeof(NvOp), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipEventRecord(ev2_, st_));
+  if (views_mode_ == 1) {
+    HIPCHK(hipMemcpyAsync(d_levoff_.p, lo, ((size_t)maxlev + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, d_nvops_.p, d_levoff_.p, maxlev, d_cntp_.p, (uint32_t)nslots_));
+    stats.view_launches++;
+  } else {
+    for (int l = 0; l < maxlev; l++) {
+      HIPCHK(launch_newview(st_, g_, d_vec_, d_nvops_.p + lo[l], lo[l + 1] - lo[l], d_cntp_.p, (uint32_t)nslots_));
+      stats.view_launches++;
     }
   }
-  HIPCHK(hipMemcpyAsync(d_nvops_.p, h_nvops_.p, nops * sizeof(NvOp), hipMemcpyHostToDevice, st_));
-  // topology for the device-walked scans: kids[cid] = the two records behind an inner record
-  kids_host_.assign(nslots_, make_uint2(0u, 0u));
-  for (int r : order) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
-  HIPCHK(d_kids_.reserve(nslots_));
-  HIPCHK(hipMemcpyAsync(d_kids_.p, kids_host_.data(), nslots_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
-  back_on_device_ = true;
-  HIPCHK(hipMemsetAsync(d_cnt_, 0, nslots_ * sizeof(uint32_t), st_));
-  HIPCHK(hipEventRecord(ev0_, st_));
-  for (int l = 1; l <= maxlev; l++) {
-    HIPCHK(launch_newview(st_, g_, d_vec_, d_nvops_.p + lev_off[l], lev_count[l], d_cnt_));
-    stats.view_launches++;
-  }
-  HIPCHK(hipEventRecord(ev1_, st_));
+  HIPCHK(launch_cntsum(st_, g_, d_nvops_.p, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt_));
+  HIPCHK(hipEventRecord(ev3_, st_));
+  view_events_pending_ = true;
   HIPCHK(hipMemcpyAsync(h_cnt_.p, d_cnt_, nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-  HIPCHK(hipStreamSynchronize(st_));
-  {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) stats.view_kernel_ms_total += ms;
-  }
+  for (int r : order) valid_[r] = 1;
+  if (roots == &all) { n_invalid_ = 0; views_valid_ = true; }
+  else if (n_invalid_ > 0) { n_invalid_ -= (long)nops; if (n_invalid_ <= 0) { n_invalid_ = 0; views_valid_ = true; } }
+  pending_scores_ = true;
   stats.newview_ops += nops;
   stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
-  // subtree scores in dependency order (reference: tr->parsimonyScore[p] = total + score[q] + score[r], :874)
-  for (size_t i = 0; i < nops; i++) {
-    const int r = (int)h_nvops_.p[i].pad;
+  return MPF_OK;
+}
+
+// subtree scores in dependency order (reference: tr->parsimonyScore[p] = total + score[q] + score[r], :874);
+// call only after the stream has been synchronised
+void Engine::finish_views()
+{
+  if (view_events_pending_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) stats.view_kernel_ms_total += ms;
+    view_events_pending_ = false;
+  }
+  if (!pending_scores_) return;
+  for (int r : upd_order_) {
     const int a = back_[nx(r)], b = back_[nx(nx(r))];
     sc_[r] = h_cnt_.p[slot(r)] + (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]);
   }
-  views_valid_ = true;
+  pending_scores_ = false;
+}
+
+int Engine::update_views()
+{
+  int rc = schedule_views(nullptr);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(st_));
+  finish_views();
   return MPF_OK;
+}
+
+// the vectors the scans of prune record p will read: pruned-subtree vector, the two gap ends, and every
+// record the DFS of addTraverseParsimony visits (both sides)
+void Engine::collect_scan_roots(int p, int mintrav, int maxtrav, std::vector<int> &roots) const
+{
+  (void)mintrav;
+  if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
+  if (maxtrav < 1) return;
+  struct Fr { int q, d; };
+  std::vector<Fr> st;
+  const int xs[2] = {p, back_[p]};
+  roots.push_back(p);            // the scores of both ends of the prune branch give the base length
+  roots.push_back(back_[p]);
+  for (int k = 0; k < 2; k++) {
+    const int x = xs[k];
+    if (tip(x)) continue;
+    roots.push_back(back_[x]);
+    const int x1 = back_[nx(x)], x2 = back_[nx(nx(x))];
+    roots.push_back(x1);
+    roots.push_back(x2);
+    for (int side = 0; side < 2; side++) {
+      const int a = side ? x2 : x1;
+      if (tip(a)) continue;
+      st.push_back(Fr{back_[nx(nx(a))], 1});
+      st.push_back(Fr{back_[nx(a)], 1});
+      while (!st.empty()) {
+        const Fr f = st.back();
+        st.pop_back();
+        roots.push_back(f.q);
+        if (!tip(f.q) && f.d < maxtrav) {
+          st.push_back(Fr{back_[nx(nx(f.q))], f.d + 1});
+          st.push_back(Fr{back_[nx(f.q)], f.d + 1});
+        }
+      }
+    }
+  }
 }
 
 // Fitch length of the current tree = score(x) + score(back x) + #empty(vec x, vec back x) on any branch;
@@ -339,7 +467,7 @@ int Engine::score_tree(uint32_t *score)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   node_rectifier();
-  views_valid_ = false;
+  invalidate_all();
   return tree_length(score);
 }
 
@@ -485,25 +613,29 @@ int Engine::candidate_record(const ScanPlan &plan, size_t c)
 
 // rearrangeParsimony's applicability tests (reference sprparsimony.cpp:2304-2310, :2330-2347) decide which
 // of the two scans of a prune record exist; the kernel does the rest
-int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan)
+int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool split)
 {
   plan.rec = p;
   plan.walked = true;
   plan.cands.clear();
   plan.n_p = plan.n_total = 0;
-  plan.walk_p = plan.walk_q = -1;
+  plan.n_parts = plan.n_parts_p = 0;
   if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
   if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
   if (maxtrav > kWalkMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
   plan.maxtrav = maxtrav;
   const int q = back_[p];
-  plan.base = (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);
+  plan.base = 0;                                   // filled in after the refresh has been synchronised
   if (maxtrav < mintrav) return MPF_OK;
-  const uint32_t stride = maxtrav <= 6 ? 256u : 4u * ((1u << maxtrav) - 1u);   // <=6: lane-accumulated outputs (4 x 64)
-  auto add = [&](int x, int mt) -> int {
+  if (maxtrav > 6) split = false;
+  // whole scan: one output block of 4*(2^maxtrav - 1) slots (256 for radius <= 6: lane-accumulated outputs);
+  // split scan (latency, small batches): four parts (gap end x first-level child), 64 slots each
+  const uint32_t stride = maxtrav <= 6 ? 256u : 4u * ((1u << maxtrav) - 1u);
+  bool oom = false;
+  auto add = [&](int x, int mt, uint32_t side_mask, uint32_t child_mask, uint32_t slots) {
     if (h_walk_.cap < n_walk_ + 1) {
       PinBuf<WalkDesc> bigger;
-      if (bigger.reserve(2 * (n_walk_ + 1) + 4096) != hipSuccess) return -1;
+      if (bigger.reserve(2 * (n_walk_ + 1) + 4096) != hipSuccess) { oom = true; return; }
       if (n_walk_) std::memcpy(bigger.p, h_walk_.p, n_walk_ * sizeof(WalkDesc));
       std::swap(bigger.p, h_walk_.p);
       std::swap(bigger.cap, h_walk_.cap);
@@ -512,26 +644,39 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan)
     d.s_cid = slot(back_[x]);
     d.xa_cid = slot(back_[nx(x)]);
     d.xb_cid = slot(back_[nx(nx(x))]);
-    d.trav = (uint32_t)mt | ((uint32_t)maxtrav << 8);
+    d.trav = (uint32_t)mt | ((uint32_t)maxtrav << 8) | (side_mask << 16) | (child_mask << 18);
     d.out_base = walk_out_;
     d.pad0 = d.pad1 = d.pad2 = 0;
-    walk_out_ += stride;
-    return (int)n_walk_++;
+    plan.part_desc[plan.n_parts] = (int)n_walk_;
+    plan.part_off[plan.n_parts] = walk_out_;
+    plan.part_cnt[plan.n_parts] = 0;
+    plan.n_parts++;
+    walk_out_ += slots;
+    n_walk_++;
+  };
+  auto phase = [&](int x, int mt) {
+    if (!split) { add(x, mt, 3u, 3u, stride); return; }
+    const int xs[2] = {back_[nx(x)], back_[nx(nx(x))]};
+    for (uint32_t side = 0; side < 2; side++) {
+      if (tip(xs[side])) continue;
+      add(x, mt, 1u << side, 1u, 64u);
+      add(x, mt, 1u << side, 2u, 64u);
+    }
   };
   if (!tip(p)) {
     const int p1 = back_[nx(p)], p2 = back_[nx(nx(p))];
-    if (!tip(p1) || !tip(p2)) { plan.walk_p = add(p, mintrav); if (plan.walk_p < 0) { set_error("pinned alloc failed"); return MPF_E_NOMEM; } plan.off_p = h_walk_.p[plan.walk_p].out_base; }
+    if (!tip(p1) || !tip(p2)) phase(p, mintrav);
   }
+  plan.n_parts_p = plan.n_parts;
   if (!tip(q) && maxtrav > 0) {
     const int q1 = back_[nx(q)], q2 = back_[nx(nx(q))];
     if ((!tip(q1) && (!tip(back_[nx(q1)]) || !tip(back_[nx(nx(q1))]))) ||
         (!tip(q2) && (!tip(back_[nx(q2)]) || !tip(back_[nx(nx(q2))])))) {
       plan.mintrav_q = mintrav > 2 ? mintrav : 2;
-      plan.walk_q = add(q, plan.mintrav_q);
-      if (plan.walk_q < 0) { set_error("pinned alloc failed"); return MPF_E_NOMEM; }
-      plan.off_q = h_walk_.p[plan.walk_q].out_base;
+      phase(q, plan.mintrav_q);
     }
   }
+  if (oom) { set_error("pinned alloc failed"); return MPF_E_NOMEM; }
   return MPF_OK;
 }
 
@@ -541,7 +686,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
   const size_t nd = n_walk_, nout = walk_out_;
   *out_host = nullptr;
   int maxd = 0;
-  for (size_t i = 0; i < nd; i++) maxd = std::max(maxd, (int)(h_walk_.p[i].trav >> 8));
+  for (size_t i = 0; i < nd; i++) maxd = std::max(maxd, (int)((h_walk_.p[i].trav >> 8) & 0xFFu));
   if (nd > 0) {
     HIPCHK(d_walk_.reserve(nd));
     HIPCHK(d_ncand_.reserve(nd));
@@ -560,10 +705,18 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
     stats.scan_launches++;
   }
+  else if (pending_scores_) HIPCHK(hipStreamSynchronize(st_));
+  finish_views();
   uint64_t tests = 0;
   for (ScanPlan &pl : plans) {
-    pl.n_p = pl.walk_p >= 0 ? (int)h_ncand_.p[pl.walk_p] : 0;
-    pl.n_total = pl.n_p + (pl.walk_q >= 0 ? (int)h_ncand_.p[pl.walk_q] : 0);
+    const int q = back_[pl.rec];
+    pl.base = (tip(pl.rec) ? 0u : sc_[pl.rec]) + (tip(q) ? 0u : sc_[q]);
+    pl.n_p = pl.n_total = 0;
+    for (int i = 0; i < pl.n_parts; i++) {
+      pl.part_cnt[i] = (int)h_ncand_.p[pl.part_desc[i]];
+      pl.n_total += pl.part_cnt[i];
+      if (i < pl.n_parts_p) pl.n_p += pl.part_cnt[i];
+    }
     tests += (uint64_t)pl.n_total;
   }
   stats.insertion_tests += tests;
@@ -580,10 +733,21 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
   int mt = std::min(maxtrav, ntips_ - 3);
   const bool walk = scan_mode_ == 1 && mt <= 8;
   plans.resize((size_t)count);
+  if (!views_valid_) {
+    if (!walk) { int rc = update_views(); if (rc) return rc; }      // host-planned programs need the scores first
+    else if (count >= n_ / 2) { int rc = schedule_views(nullptr); if (rc) return rc; }
+    else {
+      std::vector<int> roots;
+      for (int i = 0; i < count; i++) collect_scan_roots(recs[i], mintrav, maxtrav, roots);
+      int rc = schedule_views(&roots);
+      if (rc) return rc;
+    }
+  }
   {
     ScopedMs timer(stats.host_plan_ms_total);
     for (int i = 0; i < count; i++) {
-      int rc = walk ? plan_walk(recs[i], mintrav, maxtrav, plans[(size_t)i]) : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);
+      int rc = walk ? plan_walk(recs[i], mintrav, maxtrav, plans[(size_t)i], count <= split_below_)
+                    : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);
       if (rc) return rc;
     }
   }
@@ -597,7 +761,6 @@ int Engine::spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q,
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   if (rec < 3 || rec >= 3 * (2 * n_ - 1) || back_[rec] < 0) { set_error("bad prune record"); return MPF_E_INVALID; }
-  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
   std::vector<ScanPlan> plans;
   const uint32_t *out = nullptr;
   int rc = scan_batch(plans, &rec, 1, mintrav, maxtrav, &out);
@@ -606,10 +769,9 @@ int Engine::spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q,
   q.clear();
   mp.clear();
   if (pl.walked) {
-    enumerate_side(pl.rec, 1, pl.maxtrav, q);
-    if ((int)q.size() != pl.n_p && pl.walk_p >= 0) { set_error("device/host enumeration mismatch"); return MPF_E_STATE; }
-    if (pl.walk_p < 0) q.clear();
-    if (pl.walk_q >= 0) enumerate_side(back_[pl.rec], pl.mintrav_q, pl.maxtrav, q);
+    if (pl.n_parts_p > 0) enumerate_side(pl.rec, 1, pl.maxtrav, q);
+    if ((int)q.size() != pl.n_p) { set_error("device/host enumeration mismatch"); return MPF_E_STATE; }
+    if (pl.n_parts > pl.n_parts_p) enumerate_side(back_[pl.rec], pl.mintrav_q, pl.maxtrav, q);
     if ((int)q.size() != pl.n_total) { set_error("device/host enumeration mismatch"); return MPF_E_STATE; }
     for (size_t c = 0; c < q.size(); c++) mp.push_back(pl.base + pl.cost(c, out));
   } else {
@@ -623,7 +785,6 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   node_rectifier();
-  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
   std::vector<ScanPlan> plans;
   const uint32_t *out = nullptr;
   int rc = scan_batch(plans, nodep_.data() + 1, 2 * n_ - 2, mintrav, maxtrav, &out);
@@ -658,6 +819,8 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "views_mode") { views_mode_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   set_error("unknown option " + key);
   return MPF_E_INVALID;
 }

@@ -67,15 +67,21 @@ struct ScanPlan {
   int n_p = 0;              // candidates of the p side come first
   int n_total = 0;
   std::vector<Candidate> cands;     // host-planned mode only
-  // device-walked mode: descriptor indices (-1 = phase not applicable) and output offsets
+  // device-walked mode: up to 8 parts (P phase first), each a descriptor with its own output block
   bool walked = false;
-  int walk_p = -1, walk_q = -1;
-  uint32_t off_p = 0, off_q = 0;
+  int n_parts = 0, n_parts_p = 0;
+  int part_desc[8];
+  uint32_t part_off[8];
+  int part_cnt[8];
   int mintrav_q = 2, maxtrav = 0;
   inline uint32_t cost(size_t c, const uint32_t *out) const
   {
     if (!walked) return out[cands[c].out];
-    return (int)c < n_p ? out[off_p + c] : out[off_q + (c - (size_t)n_p)];
+    for (int i = 0; i < n_parts; i++) {
+      if (c < (size_t)part_cnt[i]) return out[part_off[i] + c];
+      c -= (size_t)part_cnt[i];
+    }
+    return 0;
   }
 };
 
@@ -107,14 +113,20 @@ class Engine {
   // ---- scoring
   int score_tree(uint32_t *score);             // evaluateParsimony(start, full)
   int pattern_scores(uint16_t *ptn, int32_t *total);
-  int update_views();                          // all directional vectors of the current tree
+  int update_views();                          // make every directional vector of the current tree valid (syncs)
   int tree_length(uint32_t *len);              // from valid views
+  // validity-tracked refresh: only invalid vectors that the given roots depend on are recomputed
+  void invalidate_all();
+  void invalidate_node(int node);              // every vector whose subtree contains `node`
+  int schedule_views(const std::vector<int> *roots);   // enqueue (no sync); nullptr = every record of the tree
+  void finish_views();                         // after a stream sync: subtree scores of the refreshed vectors
+  void collect_scan_roots(int p, int mintrav, int maxtrav, std::vector<int> &roots) const;
 
   // ---- SPR neighbourhoods
   int plan_scan(int rec, int mintrav, int maxtrav, ScanPlan &plan);   // appends ops to the staging program
   int run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host);
   // device-walked variant: the kernel enumerates the neighbourhood itself (k_scan_walk)
-  int plan_walk(int rec, int mintrav, int maxtrav, ScanPlan &plan);
+  int plan_walk(int rec, int mintrav, int maxtrav, ScanPlan &plan, bool split);
   int run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host);
   int scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out);
   int candidate_record(const ScanPlan &plan, size_t c);               // q of the c-th insertion test
@@ -157,7 +169,7 @@ class Engine {
   size_t nslots_ = 0, vec_words_ = 0;
 
   hipStream_t st_ = nullptr;
-  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev2_ = nullptr, ev3_ = nullptr;
   uint8_t *d_codes_ = nullptr;
   uint32_t *d_vec_ = nullptr, *d_cnt_ = nullptr, *d_tipslots_ = nullptr;
   DevBuf<int32_t> d_site2ptn_;
@@ -167,6 +179,17 @@ class Engine {
   DevBuf<ScanHdr> d_scanhdr_;
   DevBuf<uint32_t> d_out_, d_ncand_;
   DevBuf<uint2> d_kids_;
+  DevBuf<uint32_t> d_cntp_;
+  DevBuf<int32_t> d_levoff_;
+  PinBuf<int32_t> h_levoff_;
+  std::vector<uint8_t> valid_;
+  std::vector<int32_t> lev_, lev_epoch_;
+  int32_t epoch_ = 0;
+  std::vector<int> upd_order_;
+  bool pending_scores_ = false, kids_dirty_ = true, view_events_pending_ = false;
+  long n_invalid_ = -1;                         // -1 = unknown/many, 0 = every vector valid
+  int split_below_ = 64;                        // batches of at most this many prune nodes are cut into 4 parts per scan
+  int views_mode_ = 1;                          // 1 = all levels in one launch, 0 = one launch per level
   std::vector<uint2> kids_host_;
   DevBuf<WalkDesc> d_walk_;
   PinBuf<uint32_t> h_cnt_, h_out_, h_ncand_;

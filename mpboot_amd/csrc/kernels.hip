@@ -193,17 +193,14 @@ __global__ __launch_bounds__(256) void k_pack_tips(uint32_t *__restrict__ vec, c
 }
 
 // ---------------------------------------------------------------- K1: batched newview
+//
+// Per-(op, tile) mutation counts go to cntp[tile][dst] with plain stores (no zeroing, no atomics);
+// k_cntsum folds the tiles afterwards.
 
 template <int S, int VW, int RED>
-__global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops, int n_ops,
-                                                 uint32_t *__restrict__ cnt, int Wp, int tiles)
+__device__ __forceinline__ void newview_one(uint32_t *__restrict__ vec, const NvOp o, uint32_t *__restrict__ cntp,
+                                            uint32_t nslots, int Wp, int tile, int lane)
 {
-  const int lane = threadIdx.x & 63;
-  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  gw = __builtin_amdgcn_readfirstlane(gw);
-  if (gw >= n_ops * tiles) return;
-  const int op = gw / tiles, tile = gw - op * tiles;
-  const NvOp o = ops[op];
   bool valid;
   const int w0 = lane_word<VW>(tile, lane, Wp, valid);
   Tile<S, VW> a, b, c;
@@ -213,7 +210,51 @@ __global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, con
   if (valid) store_tile<S, VW>(c, vec, o.dst, Wp, w0);
   cost = valid ? cost : 0u;
   const uint32_t tot = wave_total<RED>(cost);
-  if (lane == 0 && tot) atomic_add_u32(cnt + o.dst, tot);
+  if (lane == 0) cntp[(size_t)tile * nslots + o.dst] = tot;
+}
+
+// one dependency level per launch: grid = ops x tiles waves
+template <int S, int VW, int RED>
+__global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops, int n_ops,
+                                                 uint32_t *__restrict__ cntp, uint32_t nslots, int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_ops * tiles) return;
+  const int op = gw / tiles, tile = gw - op * tiles;
+  newview_one<S, VW, RED>(vec, ops[op], cntp, nslots, Wp, tile, lane);
+}
+
+// ALL levels in one launch: one 16-wave workgroup per tile walks the levels, the waves share a level's
+// ops, and a workgroup barrier separates levels -- sites are independent, so no other workgroup's data
+// is ever needed.  Replaces one launch per level (launch-latency-bound for the short levels of an
+// incremental refresh).
+template <int S, int VW, int RED>
+__global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+                                                     const int32_t *__restrict__ lev_off, int n_lev,
+                                                     uint32_t *__restrict__ cntp, uint32_t nslots, int Wp)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = (int)(blockDim.x >> 6);
+  const int tile = blockIdx.x;
+  for (int l = 0; l < n_lev; l++) {
+    const int b = lev_off[l], e = lev_off[l + 1];
+    for (int i = b + wave; i < e; i += nw) newview_one<S, VW, RED>(vec, ops[i], cntp, nslots, Wp, tile, lane);
+    __syncthreads();
+  }
+}
+
+__global__ void k_cntsum(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp, uint32_t nslots,
+                         int tiles, uint32_t *__restrict__ cnt)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ops) return;
+  const uint32_t dst = ops[i].dst;
+  uint32_t s = 0;
+  for (int t = 0; t < tiles; t++) s += cntp[(size_t)t * nslots + dst];
+  cnt[dst] = s;
 }
 
 // ---------------------------------------------------------------- K2: batched evaluate
@@ -386,7 +427,10 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
     scan = (int)(item - (long)tile * n_scans);
   }
   const WalkDesc de = desc[scan];
-  const uint32_t mintrav = de.trav & 0xFFu, maxtrav = de.trav >> 8;
+  const uint32_t mintrav = de.trav & 0xFFu, maxtrav = (de.trav >> 8) & 0xFFu;
+  // a scan may be cut into parts for latency (small batches): side_mask selects the gap ends to walk,
+  // child_mask the first-level children whose candidate and subtree this part owns
+  const uint32_t side_mask = (de.trav >> 16) & 3u, child_mask = (de.trav >> 18) & 3u;
   bool valid;
   const uint32_t w0 = (uint32_t)lane_word<VW>(tile, lane, Wp, valid);
   const uint32_t SW = (uint32_t)S * (uint32_t)Wp;
@@ -418,7 +462,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
 
   for (int side = 0; side < 2; side++) {
     const uint32_t a = side ? de.xb_cid : de.xa_cid, other = side ? de.xa_cid : de.xb_cid;
-    if (a < n) continue;                       // a tip: nothing behind it
+    if (a < n || !((side_mask >> side) & 1u)) continue;   // a tip has nothing behind it
     load_tile_u<S, VW>(par, MPF_VEC(other), w0, Wp);
     int sp = 0;
     uint32_t node = a, d = 0;
@@ -445,10 +489,10 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
         switch (dd) { MPF_PUT(1) MPF_PUT(2) MPF_PUT(3) MPF_PUT(4) MPF_PUT(5) MPF_PUT(6) MPF_PUT(7) MPF_PUT(8) MPF_PUT(9) MPF_PUT(10) MPF_PUT(11) default: break; }
 #undef MPF_PUT
       }
-      stk[sp] = make_uint2(c2 | (dd << 24), tot >> 16);
-      sp++;
-      if (test) emit(tot & 0xFFFFu);
-      if (deeper && c1 >= n) { par = u1; node = c1; d = dd; continue; }
+      const bool own1 = dd > 1u || (child_mask & 1u), own2 = dd > 1u || (child_mask & 2u);
+      if (own2) { stk[sp] = make_uint2(c2 | (dd << 24), tot >> 16); sp++; }
+      if (test && own1) emit(tot & 0xFFFFu);
+      if (own1 && deeper && c1 >= n) { par = u1; node = c1; d = dd; continue; }
       // ---- unwind: emit pending second children until one of them has to be expanded
       bool more = false;
       while (sp > 0) {
@@ -509,19 +553,43 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
     }                                                                              \
   } while (0)
 
-hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cnt)
+hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cntp,
+                          uint32_t nslots)
 {
   if (n_ops <= 0) return hipSuccess;
   const int tiles = tiles_of(g);
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-#define NV(S_, VW_, RED_) hipLaunchKernelGGL((k_newview<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, cnt, g.Wp, tiles)
+#define NV(S_, VW_, RED_) hipLaunchKernelGGL((k_newview<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, cntp, nslots, g.Wp, tiles)
 #define NV2(S_, VW_, dummy) do { if (g.reduce == 0) NV(S_, VW_, 0); else NV(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NV2, 0);
 #undef NV2
 #undef NV
   return hipGetLastError();
 }
+
+hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
+                                 int n_lev, uint32_t *cntp, uint32_t nslots)
+{
+  if (n_lev <= 0) return hipSuccess;
+  dim3 grid((unsigned)tiles_of(g)), block(1024);
+#define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp)
+#define NW2(S_, VW_, dummy) do { if (g.reduce == 0) NW(S_, VW_, 0); else NW(S_, VW_, 1); } while (0)
+  MPF_DISPATCH_SV(NW2, 0);
+#undef NW2
+#undef NW
+  return hipGetLastError();
+}
+
+hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
+                         uint32_t nslots, uint32_t *cnt)
+{
+  if (n_ops <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 255) / 256), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles_of(g), cnt);
+  return hipGetLastError();
+}
+
+int tiles_for(const Geometry &g) { return tiles_of(g); }
 
 hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
                            uint32_t *out)

@@ -31,7 +31,8 @@ enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2 };
 // reference's DFS order, ncand[scan] = number of candidates
 // All ids are compact vector slots ("cid"): tips 0..n-1, inner record 3v+s -> n + 3(v-n-1) + s.
 // kids[cid] = cids of the two records behind an inner record (back[next], back[next next]).
-struct WalkDesc { uint32_t s_cid, xa_cid, xb_cid, trav /* mintrav | maxtrav<<8 */, out_base, pad0, pad1, pad2; };
+struct WalkDesc { uint32_t s_cid, xa_cid, xb_cid, trav /* mintrav | maxtrav<<8 | side_mask<<16 | child_mask<<18 */,
+                  out_base, pad0, pad1, pad2; };
 constexpr int kWalkMaxDepth = 12;
 constexpr int kMaxDepth = 12;   // deepest chain the register-resident scan kernel supports
 
@@ -46,7 +47,15 @@ struct Geometry {
 hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
                             int n_patterns, const int32_t *site2ptn, int n_sites, int datatype,
                             const uint32_t *tip_slots);
-hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cnt);
+// cntp[tile][slot]: per-tile mutation counts of the recomputed vectors, folded by launch_cntsum into cnt[slot]
+hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cntp,
+                          uint32_t nslots);
+// every level in ONE launch (one 16-wave workgroup per tile, workgroup barrier between levels)
+hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
+                                 int n_lev, uint32_t *cntp, uint32_t nslots);
+hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
+                         uint32_t nslots, uint32_t *cnt);
+int tiles_for(const Geometry &g);
 hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
                            uint32_t *out);
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,

@@ -22,7 +22,12 @@ void Engine::apply_move(int p, int q)
   const int r = back_[q];
   hookup(nx(p), q);
   hookup(nx(nx(p)), r);
-  views_valid_ = false;
+  // the vectors whose subtree contains an edited node are stale; everything else stays valid
+  invalidate_node(num(a));
+  invalidate_node(num(b));
+  invalidate_node(num(p));
+  invalidate_node(num(q));
+  invalidate_node(num(r));
   stats.moves_applied++;
 }
 
@@ -41,7 +46,6 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
     node_rectifier();
     int i = 1;
     while (i <= total) {
-      if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
       const int hi = std::min(total, i + batch - 1);
       int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
       if (rc) return rc;
@@ -103,7 +107,7 @@ int Engine::optimize_spr(int mintrav, int maxtrav, uint32_t *score)
   moves_.clear();
   node_rectifier();
   uint32_t len = 0;
-  views_valid_ = false;
+  invalidate_all();
   int rc = tree_length(&len);
   if (rc) return rc;
   best_ = len;
@@ -142,6 +146,7 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     hookup(nx(nx(s)), r);
   }
   have_tree_ = true;
+  invalidate_all();
   const int f = start_;
   hits_ = 1;
   std::vector<ScanPlan> plans(1);
@@ -155,7 +160,6 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     back_[p] = q;
     back_[q] = p;
     // views + length of the tree built so far (the new tip is not part of it yet)
-    views_valid_ = false;
     uint32_t len = 0;
     int rc = tree_length(&len);
     if (rc) return rc;
@@ -204,7 +208,9 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     const int r = back_[insert_rec_];
     hookup(nx(q), insert_rec_);
     hookup(nx(nx(q)), r);
-    views_valid_ = false;
+    invalidate_node(num(q));
+    invalidate_node(num(insert_rec_));
+    invalidate_node(num(r));
   }
   return MPF_OK;
 }
