@@ -801,11 +801,43 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
   return MPF_OK;
 }
 
+// pllComputePatternParsimony (reference sprparsimony.cpp:3363-3392) for the current tree: the joins of the
+// traversal rooted on the branch start--back[start] are counted per site on the device
 int Engine::pattern_scores(uint16_t *ptn, int32_t *total)
 {
-  (void)ptn; (void)total;
-  set_error("mpf_pattern_scores: not implemented yet");
-  return MPF_E_UNSUPPORTED;
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+  std::vector<EvOp> ops;
+  ops.push_back(EvOp{slot(start_), slot(back_[start_]), 0, 0});
+  std::vector<int> stack;
+  stack.push_back(back_[start_]);
+  while (!stack.empty()) {
+    const int r = stack.back();
+    stack.pop_back();
+    if (tip(r)) continue;
+    const int a = back_[nx(r)], b = back_[nx(nx(r))];
+    ops.push_back(EvOp{slot(a), slot(b), 0, 0});
+    stack.push_back(a);
+    stack.push_back(b);
+  }
+  DevBuf<uint32_t> planes;
+  DevBuf<int32_t> d_first;
+  DevBuf<uint16_t> d_ptn;
+  HIPCHK(d_evops_.reserve(ops.size()));
+  HIPCHK(planes.reserve(site_planes_words(g_, (int)ops.size())));
+  HIPCHK(d_first.reserve((size_t)P_));
+  HIPCHK(d_ptn.reserve((size_t)P_));
+  HIPCHK(hipMemcpyAsync(d_evops_.p, ops.data(), ops.size() * sizeof(EvOp), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemcpyAsync(d_first.p, first_site_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  HIPCHK(launch_site_counts(st_, g_, d_vec_, d_evops_.p, (int)ops.size(), planes.p, d_first.p, P_, d_ptn.p));
+  HIPCHK(hipMemcpyAsync(ptn, d_ptn.p, (size_t)P_ * sizeof(uint16_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(hipStreamSynchronize(st_));
+  if (total) {
+    long sum = 0;
+    for (int k = 0; k < P_; k++) sum += (long)ptn[k] * wgt_[k];
+    *total = (int32_t)sum;
+  }
+  return MPF_OK;
 }
 
 int Engine::set_option(const std::string &key, int64_t v)

@@ -280,6 +280,77 @@ __global__ __launch_bounds__(256) void k_evaluate(const uint32_t *__restrict__ v
   if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
 }
 
+// ---------------------------------------------------------------- K4: per-pattern scores
+//
+// Per-site Fitch length = number of (a, b) joins of the rooted traversal whose state sets do not
+// intersect at that site (reference storePerSiteNodeScores / addPerSiteSubtreeScores,
+// sprparsimony.cpp:294-376, which keeps a 32-bit counter per site per node: 401 MB at 1000 x 50k).
+// Here a wave takes a chunk of <= 63 joins for its tile and adds their mutation masks into SIX
+// bit-sliced counter planes (carry-save ripple), i.e. 32 sites are counted per instruction;
+// k_pattern_sum then reads each pattern's first site out of the planes.
+constexpr int kPlaneChunk = 63;
+constexpr int kPlanes = 6;
+
+template <int S, int VW>
+__global__ __launch_bounds__(256) void k_site_planes(const uint32_t *__restrict__ vec, const EvOp *__restrict__ ops,
+                                                     int n_ops, uint32_t *__restrict__ planes, int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  const int n_chunks = (n_ops + kPlaneChunk - 1) / kPlaneChunk;
+  if (gw >= n_chunks * tiles) return;
+  const int chunk = gw / tiles, tile = gw - chunk * tiles;
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  uint32_t c[kPlanes][VW];
+#pragma unroll
+  for (int j = 0; j < kPlanes; j++)
+#pragma unroll
+    for (int v = 0; v < VW; v++) c[j][v] = 0;
+  const int b = chunk * kPlaneChunk, e = min(n_ops, b + kPlaneChunk);
+  for (int i = b; i < e; i++) {
+    const EvOp o = ops[i];
+    Tile<S, VW> x, y;
+    load_tile<S, VW>(x, vec, o.a, Wp, w0);
+    load_tile<S, VW>(y, vec, o.b, Wp, w0);
+#pragma unroll
+    for (int v = 0; v < VW; v++) {
+      uint32_t any = 0;
+#pragma unroll
+      for (int k = 0; k < S; k++) any |= x.v[k][v] & y.v[k][v];
+      uint32_t carry = ~any;
+#pragma unroll
+      for (int j = 0; j < kPlanes; j++) {
+        const uint32_t t = c[j][v] & carry;
+        c[j][v] ^= carry;
+        carry = t;
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < kPlanes; j++)
+#pragma unroll
+      for (int v = 0; v < VW; v++) planes[((size_t)chunk * kPlanes + j) * Wp + w0 + v] = c[j][v];
+  }
+}
+
+__global__ void k_pattern_sum(const uint32_t *__restrict__ planes, int n_chunks, int Wp,
+                              const int32_t *__restrict__ first_site, int n_patterns, uint16_t *__restrict__ ptn)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_patterns) return;
+  const int site = first_site[p];
+  if (site < 0) { ptn[p] = 0; return; }
+  const int w = site >> 5, bit = site & 31;
+  uint32_t total = 0;
+  for (int ch = 0; ch < n_chunks; ch++)
+#pragma unroll
+    for (int j = 0; j < kPlanes; j++) total += ((planes[((size_t)ch * kPlanes + j) * Wp + w] >> bit) & 1u) << j;
+  ptn[p] = (uint16_t)total;
+}
+
 // ---------------------------------------------------------------- SPR scan (K1+K2 fused over a DFS program)
 //
 // One wavefront = one (scan, tile).  A scan is the radius-limited neighbourhood of one prune
@@ -662,6 +733,28 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 #undef SW2
 #undef SW
   return hipGetLastError();
+}
+
+hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
+                              uint32_t *planes, const int32_t *ptn_first_site, int n_ptn, uint16_t *ptn_out)
+{
+  if (n_ops <= 0) return hipSuccess;
+  const int tiles = tiles_of(g);
+  const int n_chunks = (n_ops + kPlaneChunk - 1) / kPlaneChunk;
+  const long waves = (long)n_chunks * tiles;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define SP(S_, VW_, dummy) hipLaunchKernelGGL((k_site_planes<S_, VW_>), grid, block, 0, st, vec, ops, n_ops, planes, g.Wp, tiles)
+  MPF_DISPATCH_SV(SP, 0);
+#undef SP
+  hipLaunchKernelGGL(k_pattern_sum, dim3((n_ptn + 255) / 256), dim3(256), 0, st, planes, n_chunks, g.Wp, ptn_first_site,
+                     n_ptn, ptn_out);
+  return hipGetLastError();
+}
+
+size_t site_planes_words(const Geometry &g, int n_ops)
+{
+  const int n_chunks = (n_ops + kPlaneChunk - 1) / kPlaneChunk;
+  return (size_t)n_chunks * kPlanes * (size_t)g.Wp;
 }
 
 }  // namespace mpf

@@ -62,8 +62,10 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
                        const ScanOp *ops, uint32_t *out, int max_depth);
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth);
-// per-site mutation counts of the current tree: for every op (a,b) adds the empty-intersection mask bits
+// per-pattern Fitch lengths: ops = the (a, b) joins of a rooted traversal of the current tree; `planes` is
+// scratch of site_planes_words() words; ptn_out[p] = length of pattern p (0 where first_site[p] < 0)
 hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
-                              const int32_t *ptn_first_site, int n_ptn, uint16_t *ptn_out);
+                              uint32_t *planes, const int32_t *ptn_first_site, int n_ptn, uint16_t *ptn_out);
+size_t site_planes_words(const Geometry &g, int n_ops);
 
 }  // namespace mpf

@@ -166,3 +166,39 @@ def test_midsize_random_alignment_against_oracle(mods):
     o2.seed_ties(po.TIE_RANDOM, 11)
     assert e.optimize_spr(1, 6) == o2.optimize_spr(1, 6)
     assert (e.get_tree() == o2.get_tree()).all()
+
+
+def test_pattern_scores_match_oracle(mods, fx):
+    """pllComputePatternParsimony: per-pattern Fitch lengths; sum(ptn * weight) == tree length"""
+    engine, po = mods[0], mods[1]
+    e = eng_of(engine, fx)
+    o = orc_of(po, fx)
+    o.enable_persite(True)
+    for t in fx["trees"][:4]:
+        b = np.array(t["back"], dtype=np.int32)
+        assert e.score_tree(b) == t["score"]
+        ptn, total = e.pattern_scores()
+        o.score_tree(b)
+        optn, ototal = o.pattern_scores()
+        assert total == ototal == t["score"]
+        assert (ptn == optn).all()
+
+
+def test_pattern_scores_after_reweighting_and_moves(mods, fx):
+    engine, po = mods[0], mods[1]
+    rng = np.random.default_rng(9)
+    w = rng.integers(0, 3, size=len(fx["weights"])).astype(np.int32)
+    e = eng_of(engine, fx)
+    o = orc_of(po, fx)
+    o.enable_persite(True)
+    e.set_weights(w)
+    o.set_weights(w)
+    start = np.array(fx["spr"]["start_back"], dtype=np.int32)
+    e.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, 5)
+    s = e.optimize_spr(1, 6)
+    ptn, total = e.pattern_scores()
+    assert total == s
+    assert o.score_tree(e.get_tree()) == s
+    optn, _ = o.pattern_scores()
+    assert (ptn == optn).all()
