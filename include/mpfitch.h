@@ -111,6 +111,18 @@ int mpf_score_trees(mpf_engine *e, int32_t n_trees, const int32_t *backs, uint32
    current tree, ptn_pars[P] (0 for dropped patterns); *total = sum(ptn * weight). */
 int mpf_pattern_scores(mpf_engine *e, uint16_t *ptn_pars, int32_t *total);
 
+/* int PhyloTree::computeParsimony() (phylotree.cpp:1049-1061; callers precede it with
+   initializeAllPartialPars(); clearAllPartialLH(), e.g. iqtree.cpp:2141-2143): Fitch length of the given
+   tree from scratch plus the per-pattern lengths the reference leaves in _pattern_pars
+   (phylotree.cpp:956-957, :986-987).  `back` may be NULL to use the current tree. */
+int mpf_compute_parsimony(mpf_engine *e, const int32_t *back, uint32_t *score, uint16_t *pattern_pars /* [P] or NULL */);
+
+/* The IQ-TREE side of the reference stores Alignment::convertState codes (alignment.cpp:839-916):
+   DNA 0..3, ambiguity = 4-bit mask + 3, STATE_UNKNOWN 18; protein 0..19, B 20, Z 21, STATE_UNKNOWN 22.
+   This maps them to the PLL tip codes the engine takes (the reference does it through a PHYLIP text
+   round trip, iqtree.cpp:557-564).  No device needed. */
+int mpf_encode_iqtree_states(int32_t datatype, const int8_t *states, int64_t count, uint8_t *codes);
+
 /* random_double() source for MPF_TIE_RANDOM.  Default: our restatement of the SPRNG lcg64
    stream the reference creates in init_random(seed) (tools.cpp:3320-3331).  A host that
    wants to share ITS stream passes a callback (drop-in inside mpboot: random_double). */

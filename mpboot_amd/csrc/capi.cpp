@@ -86,6 +86,46 @@ int mpf_score_trees(mpf_engine *e, int32_t n_trees, const int32_t *backs, uint32
 
 int mpf_pattern_scores(mpf_engine *e, uint16_t *ptn_pars, int32_t *total) { NEED(e); return e->eng.pattern_scores(ptn_pars, total); }
 
+int mpf_compute_parsimony(mpf_engine *e, const int32_t *back, uint32_t *score, uint16_t *pattern_pars)
+{
+  NEED(e);
+  if (back) { int rc = e->eng.set_tree(back); if (rc) return rc; }
+  uint32_t s = 0;
+  int rc = e->eng.score_tree(&s);
+  if (rc) return rc;
+  if (score) *score = s;
+  if (pattern_pars) {
+    int32_t total = 0;
+    rc = e->eng.pattern_scores(pattern_pars, &total);
+    if (rc) return rc;
+    if ((uint32_t)total != s) { set_error("per-pattern lengths do not add up to the tree length"); return MPF_E_STATE; }  // iqtree.cpp:3366-3367
+  }
+  return MPF_OK;
+}
+
+int mpf_encode_iqtree_states(int32_t datatype, const int8_t *states, int64_t count, uint8_t *codes)
+{
+  if (!states || !codes || count < 0) { set_error("mpf_encode_iqtree_states: null argument"); return MPF_E_INVALID; }
+  for (int64_t i = 0; i < count; i++) {
+    const int st = states[i];
+    int code = -1;
+    if (datatype == MPF_DNA) {
+      if (st >= 0 && st < 4) code = 1 << st;
+      else if (st == 18) code = 15;                       // STATE_UNKNOWN
+      else if (st >= 4 && st <= 17) code = st - 3;        // ambiguity: mask + 3 (phylotree.cpp:1135-1137)
+      if (code == 15 && st != 18) code = -1;              // 1+2+4+8+3 is not produced by convertState
+    } else if (datatype == MPF_AA) {
+      if (st >= 0 && st <= 22) code = st;                 // same numbering, B = 20, Z = 21, unknown = 22
+    } else {
+      set_error("mpf_encode_iqtree_states: unsupported data type");
+      return MPF_E_UNSUPPORTED;
+    }
+    if (code <= 0 && !(datatype == MPF_AA && code == 0)) { set_error("state outside the alphabet (STATE_INVALID)"); return MPF_E_INVALID; }
+    codes[i] = (uint8_t)code;
+  }
+  return MPF_OK;
+}
+
 int mpf_seed_ties(mpf_engine *e, int32_t tie_mode, int32_t seed)
 {
   NEED(e);

@@ -19,7 +19,8 @@ TIE_FIRST, TIE_RANDOM = 0, 1
 EXPORTS = [
     "mpf_last_error", "mpf_abi_version", "mpf_engine_create", "mpf_engine_destroy", "mpf_set_weights",
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
-    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_seed_ties",
+    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_compute_parsimony",
+    "mpf_encode_iqtree_states", "mpf_seed_ties",
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option",
@@ -73,6 +74,8 @@ def load_library():
         L.mpf_score_tree.argtypes = [vp, vp]
         L.mpf_score_trees.argtypes = [vp, C.c_int32, vp, vp]
         L.mpf_pattern_scores.argtypes = [vp, vp, vp]
+        L.mpf_compute_parsimony.argtypes = [vp, vp, vp, vp]
+        L.mpf_encode_iqtree_states.argtypes = [C.c_int32, vp, C.c_int64, vp]
         L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
         L.mpf_spr_scan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_spr_sweep_scan.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
@@ -94,6 +97,14 @@ def _p(a):
 def _chk(rc):
     if rc != 0:
         raise MpfError(rc, load_library().mpf_last_error().decode())
+
+
+def encode_iqtree_states(states: np.ndarray, datatype: int = DNA) -> np.ndarray:
+    """Alignment::convertState codes -> PLL tip codes (host only, no GPU needed)."""
+    states = np.ascontiguousarray(states, dtype=np.int8)
+    out = np.zeros(states.shape, dtype=np.uint8)
+    _chk(load_library().mpf_encode_iqtree_states(datatype, _p(states), states.size, _p(out)))
+    return out
 
 
 class FitchEngine:
@@ -177,6 +188,17 @@ class FitchEngine:
         tot = C.c_int32()
         _chk(load_library().mpf_pattern_scores(self.h, _p(out), C.byref(tot)))
         return out, tot.value
+
+    def compute_parsimony(self, back=None, want_patterns: bool = True):
+        """PhyloTree::computeParsimony(): (score, _pattern_pars)"""
+        s = C.c_uint32()
+        ptn = np.zeros(self.P, dtype=np.uint16) if want_patterns else None
+        bp = None
+        if back is not None:
+            back = np.ascontiguousarray(back, dtype=np.int32)
+            bp = _p(back)
+        _chk(load_library().mpf_compute_parsimony(self.h, bp, C.byref(s), _p(ptn) if want_patterns else None))
+        return s.value, ptn
 
     def seed_ties(self, mode: int, seed: int = 1):
         _chk(load_library().mpf_seed_ties(self.h, mode, seed))

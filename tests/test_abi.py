@@ -62,3 +62,36 @@ def test_product_never_imports_the_oracle():
                 with open(os.path.join(dirpath, f)) as fh:
                     txt = fh.read()
                 assert "pyoracle" not in txt and "fitch_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_iqtree_state_encoding_matches_reference_tip_codes():
+    """Alignment::convertState codes -> PLL tip codes, against the codes the reference's own PLL parser produced
+    (fixture 'codes', dumped from tr->yVector by oracle/_ref/pll_ref_driver)."""
+    import numpy as np
+    from helpers import load_fixture
+    from mpboot_amd import engine
+    from oracle import iqtree_fitch
+    for name, alpha, dt in (("dna_clean", "DNA", engine.DNA), ("dna_ambig", "DNA", engine.DNA), ("aa", "AA", engine.AA)):
+        fx = load_fixture(name)
+        states = iqtree_fitch.convert_states(fx["rows"], alpha)
+        codes = engine.encode_iqtree_states(states, dt)
+        assert (codes == fx["codes_np"]).all(), name
+    with pytest.raises(engine.MpfError):
+        engine.encode_iqtree_states(np.array([[19]], dtype=np.int8), engine.DNA)
+
+
+def test_slow_iqtree_fitch_agrees_with_pinned_oracle():
+    import numpy as np
+    from helpers import load_fixture
+    from oracle import iqtree_fitch, pyoracle as po
+    for name, alpha, ns in (("dna_ambig", "DNA", 4), ("aa", "AA", 20)):
+        fx = load_fixture(name)
+        states = iqtree_fitch.convert_states(fx["rows"], alpha)
+        o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+        o.enable_persite(True)
+        for t in fx["trees"][:3]:
+            back = np.array(t["back"], dtype=np.int32)
+            score, ptn = iqtree_fitch.compute_parsimony(states, fx["weights"], back, ns)
+            assert score == t["score"] == o.score_tree(back)
+            optn, _ = o.pattern_scores()
+            assert (ptn == optn).all()

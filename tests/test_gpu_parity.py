@@ -202,3 +202,21 @@ def test_pattern_scores_after_reweighting_and_moves(mods, fx):
     assert o.score_tree(e.get_tree()) == s
     optn, _ = o.pattern_scores()
     assert (ptn == optn).all()
+
+
+def test_compute_parsimony_dropin(mods, fx):
+    """PhyloTree::computeParsimony(): tree score + _pattern_pars from IQ-TREE-encoded states"""
+    engine = mods[0]
+    from oracle import iqtree_fitch
+    if fx["dedup"]:
+        pytest.skip("fixture columns were re-ordered by PLL's duplicate removal")
+    alpha = "DNA" if fx["datatype"] == 0 else "AA"
+    states = iqtree_fitch.convert_states(fx["rows"], alpha)
+    codes = engine.encode_iqtree_states(states, fx["datatype"])
+    e = engine.FitchEngine(codes, fx["weights_np"], datatype=fx["datatype"])
+    for t in fx["trees"][:3]:
+        back = np.array(t["back"], dtype=np.int32)
+        score, ptn = e.compute_parsimony(back)
+        rs, rptn = iqtree_fitch.compute_parsimony(states, fx["weights"], back, 4 if alpha == "DNA" else 20)
+        assert score == t["score"] == rs
+        assert (ptn == rptn).all()
