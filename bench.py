@@ -197,7 +197,8 @@ def main():
             "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": st["view_kernel_ms_total"] / args.steps,
                       "launches_per_step": st["view_launches"] / args.steps},
             "host_ms_per_step": {"plan": st["host_plan_ms_total"] / args.steps, "views": st["host_views_ms_total"] / args.steps,
-                                 "scan": st["host_scan_ms_total"] / args.steps},
+                                 "scan": st["host_scan_ms_total"] / args.steps,
+                                 "sweep_call": st["host_sweep_ms_total"] / args.steps},
         }
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(codes, back, names, letters, alphabet, args.maxtrav, args.cpu_budget)

@@ -71,6 +71,7 @@ typedef struct mpf_stats {
   double   host_plan_ms_total;   /* wall time spent building scan programs                  */
   double   host_views_ms_total;  /* wall time of update_views() incl. launches and sync     */
   double   host_scan_ms_total;   /* wall time of run_scans() incl. copies and sync         */
+  double   host_sweep_ms_total;  /* wall time inside mpf_spr_sweep_scan                      */
 } mpf_stats;
 
 const char *mpf_last_error(void);

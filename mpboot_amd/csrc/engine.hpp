@@ -199,6 +199,12 @@ class Engine {
   bool back_on_device_ = false;
   int scan_mode_ = 1;                           // 1 = device-walked scans, 0 = host-planned programs
   std::vector<uint32_t> out_scratch_;
+  std::vector<ScanPlan> sweep_plans_;
+  // number of records addTraverseParsimony visits below record q with m levels left (memo per topology epoch)
+  std::vector<int32_t> nvis_val_, nvis_epoch_;
+  int32_t topo_epoch_ = 1;
+  int count_visits(int q, int m);
+  int check_counts_ = 0;                         // 1 = copy the kernel's own candidate counts back and compare
   PinBuf<ScanOp> h_scanops_;
   PinBuf<ScanHdr> h_scanhdr_;
   PinBuf<NvOp> h_nvops_;

@@ -239,9 +239,30 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = (int)(blockDim.x >> 6);
   const int tile = blockIdx.x;
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
   for (int l = 0; l < n_lev; l++) {
     const int b = lev_off[l], e = lev_off[l + 1];
-    for (int i = b + wave; i < e; i += nw) newview_one<S, VW, RED>(vec, ops[i], cntp, nslots, Wp, tile, lane);
+    int i = b + wave;
+    // two independent ops in flight per wave: their four operand tiles are requested before either is combined
+    for (; i + nw < e; i += 2 * nw) {
+      const NvOp o0 = ops[i], o1 = ops[i + nw];
+      Tile<S, VW> a0, b0, a1, b1, c0, c1;
+      load_tile<S, VW>(a0, vec, o0.a, Wp, w0);
+      load_tile<S, VW>(b0, vec, o0.b, Wp, w0);
+      load_tile<S, VW>(a1, vec, o1.a, Wp, w0);
+      load_tile<S, VW>(b1, vec, o1.b, Wp, w0);
+      uint32_t k0 = fitch<S, VW>(c0, a0, b0);
+      uint32_t k1 = fitch<S, VW>(c1, a1, b1);
+      if (valid) { store_tile<S, VW>(c0, vec, o0.dst, Wp, w0); store_tile<S, VW>(c1, vec, o1.dst, Wp, w0); }
+      const uint32_t packed = valid ? (k0 | (k1 << 16)) : 0u;       // <= 64*32*VW per wave each: fits 16 bits
+      const uint32_t tot = wave_total<RED>(packed);
+      if (lane == 0) {
+        cntp[(size_t)tile * nslots + o0.dst] = tot & 0xFFFFu;
+        cntp[(size_t)tile * nslots + o1.dst] = tot >> 16;
+      }
+    }
+    if (i < e) newview_one<S, VW, RED>(vec, ops[i], cntp, nslots, Wp, tile, lane);
     __syncthreads();
   }
 }

@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("view_launches", C.c_uint64), ("moves_applied", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("last_scan_kernel_ms", C.c_double), ("scan_kernel_ms_total", C.c_double),
                 ("view_kernel_ms_total", C.c_double), ("host_plan_ms_total", C.c_double),
-                ("host_views_ms_total", C.c_double), ("host_scan_ms_total", C.c_double)]
+                ("host_views_ms_total", C.c_double), ("host_scan_ms_total", C.c_double),
+                ("host_sweep_ms_total", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -57,7 +57,8 @@ def test_tree_scores_match_reference(mods, fx):
 
 
 @pytest.mark.parametrize("which", [0, 1])
-@pytest.mark.parametrize("opts", [dict(), dict(reduce=1), dict(words_per_lane=2), dict(split_below=0), dict(scan_mode=0),
+@pytest.mark.parametrize("opts", [dict(check_counts=1), dict(reduce=1), dict(words_per_lane=2),
+                                  dict(split_below=0, check_counts=1), dict(scan_mode=0),
                                   dict(scan_mode=0, xcd_map=1), dict(scan_mode=0, words_per_lane=2, reduce=1)])
 def test_spr_scan_candidates_match_reference(mods, fx, which, opts):
     """every insertion test's tree length, in the reference's order (fixture 'cands' lines)"""
@@ -87,7 +88,8 @@ def test_stepwise_addition_matches_reference(mods, fx):
 
 
 @pytest.mark.parametrize("seed,mode,extra", [(1, 1, {}), (7, 1, {}), (2024, 1, {}), (7, 0, {}),
-                                             (7, 1, dict(split_below=0)), (7, 1, dict(views_mode=0, scan_batch=4))])
+                                             (7, 1, dict(split_below=0, check_counts=1)),
+                                             (7, 1, dict(views_mode=0, scan_batch=4, check_counts=1))])
 def test_spr_hill_climb_matches_oracle_trajectory(mods, fx, seed, mode, extra):
     """pllOptimizeSprParsimony with mpboot's random tie-breaks: same moves, same final topology"""
     engine, po = mods[0], mods[1]
