@@ -107,6 +107,8 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   valid_.assign(back_.size(), 0);
   lev_.assign(back_.size(), 0);
   lev_epoch_.assign(back_.size(), 0);
+  nvis_val_.assign(back_.size() * 16, 0);
+  nvis_epoch_.assign(back_.size() * 16, 0);
   reset_node_order();
   rng_.seed(1);
   return pack();
@@ -229,6 +231,7 @@ void Engine::invalidate_all()
   n_invalid_ = -1;
   views_valid_ = false;
   kids_dirty_ = true;
+  topo_epoch_++;
 }
 
 // Invariant: a valid vector has valid inputs.  The vectors containing `node` are its own three and, walking
@@ -259,6 +262,20 @@ void Engine::invalidate_node(int node)
   }
   views_valid_ = false;
   kids_dirty_ = true;
+  topo_epoch_++;
+}
+
+// N(q, m) = 1 + [q inner and m > 1] * (N(c1, m-1) + N(c2, m-1)): the records addTraverseParsimony visits
+// from q with m levels left (reference sprparsimony.cpp:2208-2218); depends on the topology only
+int Engine::count_visits(int q, int m)
+{
+  if (m <= 1 || tip(q)) return 1;
+  const size_t key = (size_t)q * 16 + (size_t)m;
+  if (nvis_epoch_[key] == topo_epoch_) return nvis_val_[key];
+  const int v = 1 + count_visits(back_[nx(q)], m - 1) + count_visits(back_[nx(nx(q))], m - 1);
+  nvis_val_[key] = v;
+  nvis_epoch_[key] = topo_epoch_;
+  return v;
 }
 
 int Engine::schedule_views(const std::vector<int> *roots)
@@ -628,11 +645,11 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
   plan.base = 0;                                   // filled in after the refresh has been synchronised
   if (maxtrav < mintrav) return MPF_OK;
   if (maxtrav > 6) split = false;
-  // whole scan: one output block of 4*(2^maxtrav - 1) slots (256 for radius <= 6: lane-accumulated outputs);
-  // split scan (latency, small batches): four parts (gap end x first-level child), 64 slots each
-  const uint32_t stride = maxtrav <= 6 ? 256u : 4u * ((1u << maxtrav) - 1u);
+  // candidate counts are known from the topology (count_visits), so the outputs of all parts are laid
+  // out back to back.  whole scan = one part; split scan (latency, small batches) = four parts
+  // (gap end x first-level child)
   bool oom = false;
-  auto add = [&](int x, int mt, uint32_t side_mask, uint32_t child_mask, uint32_t slots) {
+  auto add = [&](int x, int mt, uint32_t side_mask, uint32_t child_mask, int count) {
     if (h_walk_.cap < n_walk_ + 1) {
       PinBuf<WalkDesc> bigger;
       if (bigger.reserve(2 * (n_walk_ + 1) + 4096) != hipSuccess) { oom = true; return; }
@@ -646,21 +663,30 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
     d.xb_cid = slot(back_[nx(nx(x))]);
     d.trav = (uint32_t)mt | ((uint32_t)maxtrav << 8) | (side_mask << 16) | (child_mask << 18);
     d.out_base = walk_out_;
-    d.pad0 = d.pad1 = d.pad2 = 0;
+    d.pad0 = (uint32_t)count;
+    d.pad1 = d.pad2 = 0;
     plan.part_desc[plan.n_parts] = (int)n_walk_;
     plan.part_off[plan.n_parts] = walk_out_;
-    plan.part_cnt[plan.n_parts] = 0;
+    plan.part_cnt[plan.n_parts] = count;
     plan.n_parts++;
-    walk_out_ += slots;
+    plan.n_total += count;
+    walk_out_ += (uint32_t)count;
     n_walk_++;
   };
   auto phase = [&](int x, int mt) {
-    if (!split) { add(x, mt, 3u, 3u, stride); return; }
     const int xs[2] = {back_[nx(x)], back_[nx(nx(x))]};
+    const int skip = mt > 1 ? 1 : 0;                  // the q side does not test the first level (mintrav2 = 2)
+    int cnt[2][2] = {{0, 0}, {0, 0}};
+    for (int side = 0; side < 2; side++) {
+      if (tip(xs[side])) continue;
+      cnt[side][0] = count_visits(back_[nx(xs[side])], maxtrav) - skip;
+      cnt[side][1] = count_visits(back_[nx(nx(xs[side]))], maxtrav) - skip;
+    }
+    if (!split) { add(x, mt, 3u, 3u, cnt[0][0] + cnt[0][1] + cnt[1][0] + cnt[1][1]); return; }
     for (uint32_t side = 0; side < 2; side++) {
       if (tip(xs[side])) continue;
-      add(x, mt, 1u << side, 1u, 64u);
-      add(x, mt, 1u << side, 2u, 64u);
+      add(x, mt, 1u << side, 1u, cnt[side][0]);
+      add(x, mt, 1u << side, 2u, cnt[side][1]);
     }
   };
   if (!tip(p)) {
@@ -668,6 +694,7 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
     if (!tip(p1) || !tip(p2)) phase(p, mintrav);
   }
   plan.n_parts_p = plan.n_parts;
+  plan.n_p = plan.n_total;
   if (!tip(q) && maxtrav > 0) {
     const int q1 = back_[nx(q)], q2 = back_[nx(nx(q))];
     if ((!tip(q1) && (!tip(back_[nx(q1)]) || !tip(back_[nx(nx(q1))]))) ||
@@ -698,9 +725,12 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(hipEventRecord(ev0_, st_));
     HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids_.p, n_, d_walk_.p, (int)nd, d_out_.p, d_ncand_.p, maxd));
     HIPCHK(hipEventRecord(ev1_, st_));
-    HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-    HIPCHK(hipMemcpyAsync(h_ncand_.p, d_ncand_.p, nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    if (nout) HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    if (check_counts_) HIPCHK(hipMemcpyAsync(h_ncand_.p, d_ncand_.p, nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
     HIPCHK(hipStreamSynchronize(st_));
+    if (check_counts_)
+      for (size_t i = 0; i < nd; i++)
+        if (h_ncand_.p[i] != h_walk_.p[i].pad0) { set_error("device/host candidate count mismatch"); return MPF_E_STATE; }
     float ms = 0;
     if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
     stats.scan_launches++;
@@ -711,12 +741,6 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
   for (ScanPlan &pl : plans) {
     const int q = back_[pl.rec];
     pl.base = (tip(pl.rec) ? 0u : sc_[pl.rec]) + (tip(q) ? 0u : sc_[q]);
-    pl.n_p = pl.n_total = 0;
-    for (int i = 0; i < pl.n_parts; i++) {
-      pl.part_cnt[i] = (int)h_ncand_.p[pl.part_desc[i]];
-      pl.n_total += pl.part_cnt[i];
-      if (i < pl.n_parts_p) pl.n_p += pl.part_cnt[i];
-    }
     tests += (uint64_t)pl.n_total;
   }
   stats.insertion_tests += tests;
@@ -784,8 +808,9 @@ int Engine::spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q,
 int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  ScopedMs sweep_timer(stats.host_sweep_ms_total);
   node_rectifier();
-  std::vector<ScanPlan> plans;
+  std::vector<ScanPlan> &plans = sweep_plans_;
   const uint32_t *out = nullptr;
   int rc = scan_batch(plans, nodep_.data() + 1, 2 * n_ - 2, mintrav, maxtrav, &out);
   if (rc) return rc;
@@ -793,7 +818,17 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
   uint64_t tests = 0;
   for (const ScanPlan &pl : plans) {
     const size_t nc = pl.walked ? (size_t)pl.n_total : pl.cands.size();
-    for (size_t c = 0; c < nc; c++) best = std::min(best, pl.base + pl.cost(c, out));
+    if (pl.walked) {
+      uint32_t m = UINT_MAX;
+      for (int i = 0; i < pl.n_parts; i++) {
+        const uint32_t *o = out + pl.part_off[i];
+        const int cnt = pl.part_cnt[i];
+        for (int c = 0; c < cnt; c++) m = std::min(m, o[c]);
+      }
+      if (nc) best = std::min(best, pl.base + m);
+    } else {
+      for (size_t c = 0; c < nc; c++) best = std::min(best, pl.base + pl.cost(c, out));
+    }
     tests += nc;
   }
   if (n_tests) *n_tests = tests;
@@ -853,6 +888,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "views_mode") { views_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
+  if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
   set_error("unknown option " + key);
   return MPF_E_INVALID;
 }
