@@ -74,7 +74,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   g_.S = datatype_ == MPF_DNA ? 4 : 20;
   g_.vw = 1;
   g_.reduce = 0;
-  g_.map = 0;
+  g_.map = 1;            // XCD-aware work mapping (speed only)
   const int und = datatype_ == MPF_DNA ? 15 : 22;
   for (size_t i = 0; i < (size_t)n_ * P_; i++)
     if (codes[i] > und || (datatype_ == MPF_DNA && codes[i] == 0)) {

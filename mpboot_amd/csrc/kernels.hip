@@ -89,20 +89,32 @@ __device__ __forceinline__ void store_tile(const Tile<S, VW> &t, uint32_t *__res
   }
 }
 
-// c = fitch(a, b); returns the number of sites of this lane's words whose intersection is empty
+// gfx950 has a three-input bitwise op (v_bitop3_b32); truth table with src0 = 0xF0, src1 = 0xCC, src2 = 0xAA
+#define MPF_B3_ANDOR 0xEA   // (a & b) | c
+#define MPF_B3_FITCH 0xD4   // c ? (a & b) : (a | b)
+__device__ __forceinline__ uint32_t b3_andor(uint32_t a, uint32_t b, uint32_t c)
+{
+  return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, MPF_B3_ANDOR);
+}
+__device__ __forceinline__ uint32_t b3_fitch(uint32_t a, uint32_t b, uint32_t any)
+{
+  return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)any, MPF_B3_FITCH);
+}
+
+// c = fitch(a, b); returns the number of sites of this lane's words whose intersection is empty.
+// any = OR_k(a_k & b_k) as an and-or chain, then c_k = any ? a_k & b_k : a_k | b_k: 2 ops per state.
 template <int S, int VW>
 __device__ __forceinline__ uint32_t fitch(Tile<S, VW> &c, const Tile<S, VW> &a, const Tile<S, VW> &b)
 {
   uint32_t cost = 0;
 #pragma unroll
   for (int j = 0; j < VW; j++) {
-    uint32_t any = 0;
+    uint32_t any = a.v[0][j] & b.v[0][j];
 #pragma unroll
-    for (int k = 0; k < S; k++) any |= a.v[k][j] & b.v[k][j];
-    const uint32_t N = ~any;
+    for (int k = 1; k < S; k++) any = b3_andor(a.v[k][j], b.v[k][j], any);
 #pragma unroll
-    for (int k = 0; k < S; k++) c.v[k][j] = (a.v[k][j] & b.v[k][j]) | (N & (a.v[k][j] | b.v[k][j]));
-    cost += (uint32_t)__builtin_popcount(N);
+    for (int k = 0; k < S; k++) c.v[k][j] = b3_fitch(a.v[k][j], b.v[k][j], any);
+    cost += (uint32_t)__builtin_popcount(~any);
   }
   return cost;
 }
@@ -114,31 +126,29 @@ __device__ __forceinline__ uint32_t empty_count(const Tile<S, VW> &a, const Tile
   uint32_t cost = 0;
 #pragma unroll
   for (int j = 0; j < VW; j++) {
-    uint32_t any = 0;
+    uint32_t any = a.v[0][j] & b.v[0][j];
 #pragma unroll
-    for (int k = 0; k < S; k++) any |= a.v[k][j] & b.v[k][j];
+    for (int k = 1; k < S; k++) any = b3_andor(a.v[k][j], b.v[k][j], any);
     cost += (uint32_t)__builtin_popcount(~any);
   }
   return cost;
 }
 
-// cost of joining subtree vector s onto the node x = fitch(u, d) without materialising x:
-//   x_k & s_k = (t_k & s_k) | (N & o_k & s_k)
+// cost of joining subtree vector s onto the node x = fitch(u, d):  popcount(~OR_k(x_k & s_k)),
+// x_k formed in registers and consumed at once (3 ops per state + 2)
 template <int S, int VW>
 __device__ __forceinline__ uint32_t join_cost(const Tile<S, VW> &u, const Tile<S, VW> &d, const Tile<S, VW> &s)
 {
   uint32_t cost = 0;
 #pragma unroll
   for (int j = 0; j < VW; j++) {
-    uint32_t any = 0, hit_t = 0, hit_o = 0;
+    uint32_t any = u.v[0][j] & d.v[0][j];
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-      const uint32_t t = u.v[k][j] & d.v[k][j];
-      any |= t;
-      hit_t |= t & s.v[k][j];
-      hit_o |= (u.v[k][j] | d.v[k][j]) & s.v[k][j];
-    }
-    cost += (uint32_t)__builtin_popcount(~(hit_t | (~any & hit_o)));
+    for (int k = 1; k < S; k++) any = b3_andor(u.v[k][j], d.v[k][j], any);
+    uint32_t hit = b3_fitch(u.v[0][j], d.v[0][j], any) & s.v[0][j];
+#pragma unroll
+    for (int k = 1; k < S; k++) hit = b3_andor(b3_fitch(u.v[k][j], d.v[k][j], any), s.v[k][j], hit);
+    cost += (uint32_t)__builtin_popcount(~hit);
   }
   return cost;
 }
@@ -484,8 +494,28 @@ __device__ __forceinline__ void load_tile_u(Tile<S, VW> &t, const uint32_t *__re
   }
 }
 
+// buffer-addressed tile load: scalar byte offset of the vector + per-lane byte offsets of the rows held in
+// registers -> one buffer_load per row with no per-load address arithmetic
+template <int S, int VW>
+__device__ __forceinline__ void load_tile_b(Tile<S, VW> &t, __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&voff)[S],
+                                            uint32_t soff)
+{
+#pragma unroll
+  for (int k = 0; k < S; k++) {
+    if constexpr (VW == 1) {
+      t.v[k][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[k], soff, 0);
+    } else if constexpr (VW == 2) {
+      auto x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[k], soff, 0);
+      t.v[k][0] = x[0]; t.v[k][1] = x[1];
+    } else {
+      auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], soff, 0);
+      t.v[k][0] = x[0]; t.v[k][1] = x[1]; t.v[k][2] = x[2]; t.v[k][3] = x[3];
+    }
+  }
+}
+
 template <int S, int VW, int MAXD, int RED>
-__global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
+__global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                    uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
                                                    int tiles, int map)
@@ -526,12 +556,22 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
   bool valid;
   const uint32_t w0 = (uint32_t)lane_word<VW>(tile, lane, Wp, valid);
   const uint32_t SW = (uint32_t)S * (uint32_t)Wp;
-#define MPF_VEC(cid) (vec + (size_t)((uint32_t)(cid) * SW))
+  // the whole vector array as one raw buffer (< 4 GiB, checked by the host): loads take a scalar byte
+  // offset (vector) plus a per-lane byte offset (row, word)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vec, 0, 0x7FFFFFFF, 0x00020000);
+  uint32_t voff[S];
+#pragma unroll
+  for (int k = 0; k < S; k++) voff[k] = (w0 + (uint32_t)k * (uint32_t)Wp) * 4u;
+#define MPF_LOAD(T, cid)                                                                       \
+  do {                                                                                         \
+    if constexpr (S == 4) load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);        \
+    else load_tile_u<S, VW>(T, vec + (size_t)((uint32_t)(cid) * SW), w0, Wp);                  \
+  } while (0)
 
   // sv: pruned subtree; par: U of the node being expanded; pend[d]: U of the not-yet-expanded second
   // child at depth d (one per depth suffices: the first child is expanded immediately)
   Tile<S, VW> sv, par, u1, u2, d1, d2, pend[MAXD];
-  load_tile_u<S, VW>(sv, MPF_VEC(de.s_cid), w0, Wp);
+  MPF_LOAD(sv, de.s_cid);
   uint32_t k = 0;                              // candidates emitted so far (scan-local index)
   uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
   uint2 *stk = s_frame[wib];
@@ -555,7 +595,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
   for (int side = 0; side < 2; side++) {
     const uint32_t a = side ? de.xb_cid : de.xa_cid, other = side ? de.xa_cid : de.xb_cid;
     if (a < n || !((side_mask >> side) & 1u)) continue;   // a tip has nothing behind it
-    load_tile_u<S, VW>(par, MPF_VEC(other), w0, Wp);
+    MPF_LOAD(par, other);
     int sp = 0;
     uint32_t node = a, d = 0;
     while (true) {
@@ -563,8 +603,8 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
       const uint2 kc = kids[node];
       const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.x);
       const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc.y);
-      load_tile_u<S, VW>(d1, MPF_VEC(c1), w0, Wp);
-      load_tile_u<S, VW>(d2, MPF_VEC(c2), w0, Wp);
+      MPF_LOAD(d1, c1);
+      MPF_LOAD(d2, c2);
       const uint32_t dd = d + 1;
       const bool test = dd >= mintrav;
       const bool deeper = dd < maxtrav;
@@ -604,7 +644,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const uint32_t *__restrict__ 
       if (!more) break;
     }
   }
-#undef MPF_VEC
+#undef MPF_LOAD
   if constexpr (LANEACC) {
     uint32_t *o = out + de.out_base + lane;
     if ((uint32_t)lane < k && acc0) atomic_add_u32(o, acc0);
