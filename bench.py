@@ -159,6 +159,13 @@ def main():
         dt_all, tests_all = dt, float(tests)
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+        if os.path.exists(tpath) and not args.opt:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload") == args.workload:
+                traffic = tj["bytes_per_launch"]          # from the committed rocprofv3 PMC passes, not live
         evals_per_s = tests_all / dt_all
         W = eng.W                                          # the reference's parsimonyLength
         bytes_per_eval = 6 * eng.S * W * 4                 # 1 chain newview + 1 three-vector join-evaluate
@@ -186,14 +193,16 @@ def main():
                        "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
                        "start_tree_score": start_score, "parallelism": f"independent start trees x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_scan_walk", "kernel_ms_per_launch": scan_ms,
                          "algorithmic_bytes_per_eval": bytes_per_eval,
                          "loaded_GBps": compulsory,
                          "note": "achieved = SURVEY §8(d) algorithmic bytes (6 vectors per eval) / HIP-event kernel time; "
                                  "the kernel itself loads 1 vector per eval (chain in registers, sibling pairs share loads) "
-                                 "= loaded_GBps, largely L2/Infinity-Cache hits: frac > 1 means it beats the HBM roofline of "
-                                 "the 6-vector formulation, not that HBM delivered more than its peak"},
+                                 "= loaded_GBps, 93 % of it L2 hits under the XCD-aware mapping (traffic = bytes that left the "
+                                 "L2s per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1): frac > 1 means the kernel beats "
+                                 "the HBM roofline of the 6-vector formulation, not that HBM delivered more than its peak; the "
+                                 "kernel is bound by VALU issue + memory latency (DESIGN.md section 5)"},
             "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": st["view_kernel_ms_total"] / args.steps,
                       "launches_per_step": st["view_launches"] / args.steps},
             "host_ms_per_step": {"plan": st["host_plan_ms_total"] / args.steps, "views": st["host_views_ms_total"] / args.steps,
