@@ -81,6 +81,15 @@ int mpf_abi_version(void);
    upload codes/weights, drop uninformative sites, bit-pack the tips in HBM. */
 int mpf_engine_create(mpf_engine **out, const mpf_config *cfg, const uint8_t *codes /* [n][P] */,
                       const int32_t *weights /* [P] */);
+/* Weighted (Sankoff) parsimony, the reference's `-cost <file|e>` mode: same entry points, scores are sums of
+   cost-matrix entries.  cost[i*S+j] = cost of i -> j (pllCostMatrix, sprparsimony.cpp:190; loaded and closed under
+   the triangle inequality as ParsTree::loadCostMatrixFile does, parstree.cpp:31-95; initializeCostMatrix
+   sprparsimony.cpp:159-188).  Kernels: newviewSankoffParsimonyIterativeFastSIMD / evaluateSankoff... (:477-551,
+   :880-961), tips as compressSankoffDNA (:2636-2825).  Arithmetic is exact 32-bit (the reference's -short_off
+   mode).  The matrix must be symmetric (MPF_E_UNSUPPORTED otherwise): only then is the length independent of
+   root placement.  Serves ParsTree::computeParsimony (parstree.cpp:101-116) through mpf_compute_parsimony. */
+int mpf_engine_create_sankoff(mpf_engine **out, const mpf_config *cfg, const uint8_t *codes, const int32_t *weights,
+                              const uint32_t *cost /* [S*S] */);
 /* _pllFreeParsimonyDataStructures (sprparsimony.cpp:3062-3104) */
 void mpf_engine_destroy(mpf_engine *e);
 

@@ -31,6 +31,19 @@ int mpf_engine_create(mpf_engine **out, const mpf_config *cfg, const uint8_t *co
   return MPF_OK;
 }
 
+int mpf_engine_create_sankoff(mpf_engine **out, const mpf_config *cfg, const uint8_t *codes, const int32_t *weights,
+                              const uint32_t *cost)
+{
+  if (!out || !cfg || !cost) { set_error("mpf_engine_create_sankoff: null argument"); return MPF_E_INVALID; }
+  *out = nullptr;
+  mpf_engine *e = new (std::nothrow) mpf_engine();
+  if (!e) { set_error("out of host memory"); return MPF_E_NOMEM; }
+  int rc = e->eng.init(*cfg, codes, weights, cost);
+  if (rc != MPF_OK) { delete e; return rc; }
+  *out = e;
+  return MPF_OK;
+}
+
 void mpf_engine_destroy(mpf_engine *e) { delete e; }
 
 int mpf_set_weights(mpf_engine *e, const int32_t *weights)

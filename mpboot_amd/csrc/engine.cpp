@@ -46,7 +46,7 @@ Engine::~Engine()
   if (st_) (void)hipStreamDestroy(st_);
 }
 
-int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *weights)
+int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *weights, const uint32_t *cost)
 {
   if (cfg.n_taxa < 4 || cfg.n_patterns < 1 || !codes || !weights) {
     set_error("mpf_engine_create: need n_taxa >= 4, n_patterns >= 1, codes and weights");
@@ -72,6 +72,26 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   datatype_ = cfg.datatype;
   keep_all_ = cfg.keep_all_sites;
   g_.S = datatype_ == MPF_DNA ? 4 : 20;
+  if (cost) {
+    // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80), then the
+    // symmetry requirement of the directional-view formulation
+    const int S = g_.S;
+    cost_.assign(cost, cost + S * S);
+    for (int k = 0; k < S; k++)
+      for (int i = 0; i < S; i++)
+        for (int j = 0; j < S; j++)
+          if (cost_[i * S + j] > cost_[i * S + k] + cost_[k * S + j]) cost_[i * S + j] = cost_[i * S + k] + cost_[k * S + j];
+    uint32_t hi = 0;
+    for (int i = 0; i < S; i++)
+      for (int j = 0; j < S; j++) {
+        if (cost_[i * S + j] != cost_[j * S + i]) { set_error("Sankoff cost matrix must be symmetric"); return MPF_E_UNSUPPORTED; }
+        hi = std::max(hi, cost_[i * S + j]);
+      }
+    if (hi >= 65535u) { set_error("Sankoff costs too large"); return MPF_E_UNSUPPORTED; }
+    sankoff_ = true;
+    g_.sankoff = 1;
+    g_.highest_cost = hi + 1;                   // highest_cost, reference sprparsimony.cpp:160
+  }
   g_.vw = 1;
   g_.reduce = 0;
   g_.map = 1;            // XCD-aware work mapping (speed only)
@@ -121,6 +141,53 @@ int Engine::pack()
   const int und = datatype_ == MPF_DNA ? 15 : 22;
   long entries = 0;
   ninf_ = 0;
+  if (sankoff_) {
+    // compressSankoffDNA (reference sprparsimony.cpp:2636-2825): informative patterns are kept once each, their
+    // weights go to informativePtnWgt; one 32-bit cost per state and pattern
+    inf_index_.clear();
+    for (int s = 0; s < P_; s++) {
+      int keep = 1;
+      if (!keep_all_) {
+        bool seen[32] = {false};
+        int distinct = 0;
+        for (int t = 0; t < n_; t++) {
+          const int c = codes_[(size_t)t * P_ + s];
+          if (c < und && !seen[c]) { seen[c] = true; distinct++; }
+        }
+        keep = distinct > 1;
+      }
+      inf_[s] = keep;
+      first_site_[s] = keep ? (int32_t)inf_index_.size() : -1;
+      if (wgt_[s] < 0) { set_error("negative pattern weight"); return MPF_E_INVALID; }
+      if (keep) inf_index_.push_back(s);
+    }
+    ninf_ = (int)inf_index_.size();
+    nsites_ = ninf_;
+    Wref_ = (ninf_ % 16) ? ninf_ + (16 - ninf_ % 16) : ninf_;     // parsimonyLength with VECSIZE = 16 (u16, AVX)
+    int wp = ((ninf_ + 31) / 32) * 32;
+    if (wp == 0) wp = 32;
+    if (wp != g_.Wp || !d_vec_) {
+      if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
+      g_.Wp = wp;
+      vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
+      HIPCHK(hipMalloc((void **)&d_vec_, vec_words_ * sizeof(uint32_t)));
+    }
+    std::vector<uint32_t> pw((size_t)g_.Wp, 0u);
+    for (int j = 0; j < ninf_; j++) pw[(size_t)j] = (uint32_t)wgt_[(size_t)inf_index_[(size_t)j]];
+    HIPCHK(d_pwgt_.reserve(pw.size()));
+    HIPCHK(d_cost_.reserve(cost_.size()));
+    HIPCHK(d_infidx_.reserve(std::max<size_t>(inf_index_.size(), 1)));
+    HIPCHK(hipMemcpyAsync(d_pwgt_.p, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+    HIPCHK(hipMemcpyAsync(d_cost_.p, cost_.data(), cost_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+    if (!inf_index_.empty())
+      HIPCHK(hipMemcpyAsync(d_infidx_.p, inf_index_.data(), inf_index_.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+    g_.cost = d_cost_.p;
+    g_.pwgt = d_pwgt_.p;
+    HIPCHK(launch_pack_tips_sankoff(st_, g_, d_vec_, d_codes_, n_, P_, d_infidx_.p, ninf_, datatype_));
+    HIPCHK(hipStreamSynchronize(st_));
+    invalidate_all();
+    return MPF_OK;
+  }
   for (int s = 0; s < P_; s++) {
     int keep = 1;
     if (!keep_all_) {
@@ -168,6 +235,7 @@ int Engine::set_weights(const int32_t *weights)
 int Engine::tip_vector(int tipno, uint32_t *out)
 {
   if (tipno < 1 || tipno > n_) { set_error("tip out of range"); return MPF_E_INVALID; }
+  if (sankoff_) { set_error("mpf_get_tip_vector: bit-packed tips exist in Fitch mode only"); return MPF_E_UNSUPPORTED; }
   std::vector<uint32_t> tmp((size_t)g_.S * g_.Wp);
   HIPCHK(hipMemcpy(tmp.data(), d_vec_ + (size_t)(tipno - 1) * g_.S * g_.Wp, tmp.size() * sizeof(uint32_t),
                    hipMemcpyDeviceToHost));
@@ -409,7 +477,8 @@ void Engine::finish_views()
   if (!pending_scores_) return;
   for (int r : upd_order_) {
     const int a = back_[nx(r)], b = back_[nx(nx(r))];
-    sc_[r] = h_cnt_.p[slot(r)] + (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]);
+    // weighted mode: parsimonyScore[p] is the node's own unweighted minimum sum only (reference :490, :544-548)
+    sc_[r] = sankoff_ ? h_cnt_.p[slot(r)] : h_cnt_.p[slot(r)] + (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]);
   }
   pending_scores_ = false;
 }
@@ -475,7 +544,7 @@ int Engine::tree_length(uint32_t *len)
   HIPCHK(launch_evaluate(st_, g_, d_vec_, d_evops_.p, 1, d_out_.p));
   HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   HIPCHK(hipStreamSynchronize(st_));
-  tree_len_ = (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]) + h_out_.p[0];
+  tree_len_ = sankoff_ ? h_out_.p[0] : (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]) + h_out_.p[0];
   *len = tree_len_;
   return MPF_OK;
 }
@@ -519,7 +588,7 @@ int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
   if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
   if (maxtrav > kMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
   const int q = back_[p];
-  plan.base = (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);
+  plan.base = sankoff_ ? 0u : (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);   // weighted: the kernel returns full lengths
   if (maxtrav < mintrav) return MPF_OK;
   auto one_side = [&](int x, int mt) {
     const int x1 = back_[nx(x)], x2 = back_[nx(nx(x))];
@@ -755,7 +824,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
 int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out)
 {
   int mt = std::min(maxtrav, ntips_ - 3);
-  const bool walk = scan_mode_ == 1 && mt <= 8;
+  const bool walk = scan_mode_ == 1 && mt <= 8 && !sankoff_;
   plans.resize((size_t)count);
   if (!views_valid_) {
     if (!walk) { int rc = update_views(); if (rc) return rc; }      // host-planned programs need the scores first
@@ -842,6 +911,24 @@ int Engine::pattern_scores(uint16_t *ptn, int32_t *total)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+  if (sankoff_) {
+    // pllComputeSankoffPatternParsimony (reference :3341-3355): the per-pattern cost of the root branch
+    DevBuf<uint16_t> d_p;
+    std::vector<uint16_t> hp((size_t)g_.Wp);
+    HIPCHK(d_p.reserve((size_t)g_.Wp));
+    HIPCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), d_p.p));
+    HIPCHK(hipMemcpyAsync(hp.data(), d_p.p, hp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipStreamSynchronize(st_));
+    long sum = 0;
+    for (int k = 0; k < P_; k++) ptn[k] = 0;
+    for (int j = 0; j < ninf_; j++) {
+      const int k = inf_index_[(size_t)j];
+      ptn[k] = hp[(size_t)j];
+      sum += (long)ptn[k] * wgt_[k];
+    }
+    if (total) *total = (int32_t)sum;
+    return MPF_OK;
+  }
   std::vector<EvOp> ops;
   ops.push_back(EvOp{slot(start_), slot(back_[start_]), 0, 0});
   std::vector<int> stack;
@@ -879,6 +966,7 @@ int Engine::set_option(const std::string &key, int64_t v)
 {
   if (key == "scan_batch") { if (v < 1) return MPF_E_INVALID; scan_batch_ = (int)v; return MPF_OK; }
   if (key == "words_per_lane") {
+    if (sankoff_ && v != 1) { set_error("words_per_lane: weighted mode uses one pattern per lane"); return MPF_E_INVALID; }
     if (!(v == 1 || v == 2 || v == 4) || (g_.S == 20 && v == 4)) { set_error("words_per_lane: 1|2|4 (protein: 1|2)"); return MPF_E_INVALID; }
     g_.vw = (int)v;
     return MPF_OK;

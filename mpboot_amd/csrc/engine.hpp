@@ -91,7 +91,7 @@ class Engine {
  public:
   Engine() = default;
   ~Engine();
-  int init(const mpf_config &cfg, const uint8_t *codes, const int32_t *weights);
+  int init(const mpf_config &cfg, const uint8_t *codes, const int32_t *weights, const uint32_t *cost = nullptr);
 
   // ---- alignment
   int set_weights(const int32_t *weights);
@@ -166,6 +166,12 @@ class Engine {
   int Wref_ = 0, nsites_ = 0, ninf_ = 0;
   std::vector<uint8_t> codes_;
   std::vector<int32_t> wgt_, inf_, first_site_;
+  // Sankoff mode
+  bool sankoff_ = false;
+  std::vector<uint32_t> cost_;
+  std::vector<int32_t> inf_index_;               // informative pattern j -> original pattern index
+  DevBuf<uint32_t> d_cost_, d_pwgt_;
+  DevBuf<int32_t> d_infidx_;
   size_t nslots_ = 0, vec_words_ = 0;
 
   hipStream_t st_ = nullptr;

@@ -655,6 +655,235 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
   if (tile == 0 && lane == 0) ncand[scan] = k;
 }
 
+// ================================================================ Sankoff (weighted parsimony) kernels
+//
+// reference: newviewSankoffParsimonyIterativeFastSIMD / evaluateSankoffParsimonyIterativeFastSIMD
+// (sprparsimony.cpp:477-551, :880-961).  A vector is S rows of Wp 32-bit costs (one per pattern); a lane owns
+// a pattern.  The min-plus transform  m[z] = min_x(v[x] + cost[z][x])  is the whole arithmetic: packed in
+// registers per lane, the cost matrix read through the scalar cache (wave-uniform).  VALU-bound by
+// nature (2*S*S add/min per transform), not MFMA-shaped (min-plus, not multiply-add).
+// Exact 32-bit arithmetic (the reference's -short_off mode).  Cost matrices must be symmetric: only then
+// is the length independent of root placement, which the directional-view formulation relies on.
+
+template <int S>
+struct Costs { uint32_t v[S]; };
+
+template <int S>
+__device__ __forceinline__ void load_costs(Costs<S> &t, const uint32_t *__restrict__ vec, uint32_t slot, int Wp, int w0)
+{
+  const uint32_t *p = vec + (size_t)slot * (size_t)(S * Wp) + w0;
+#pragma unroll
+  for (int k = 0; k < S; k++) t.v[k] = p[(size_t)k * Wp];
+}
+
+template <int S>
+__device__ __forceinline__ void mplus(Costs<S> &m, const Costs<S> &v, const uint32_t *__restrict__ cost)
+{
+#pragma unroll
+  for (int z = 0; z < S; z++) {
+    uint32_t acc = v.v[0] + cost[z * S];
+#pragma unroll
+    for (int x = 1; x < S; x++) acc = min(acc, v.v[x] + cost[z * S + x]);
+    m.v[z] = acc;
+  }
+}
+
+template <int S>
+__device__ __forceinline__ uint32_t min_of(const Costs<S> &a)
+{
+  uint32_t m = a.v[0];
+#pragma unroll
+  for (int k = 1; k < S; k++) m = min(m, a.v[k]);
+  return m;
+}
+
+template <int S>
+__device__ __forceinline__ void newview_one_snk(uint32_t *__restrict__ vec, const NvOp o, const uint32_t *__restrict__ cost,
+                                                uint32_t *__restrict__ cntp, uint32_t nslots, int Wp, int tile, int lane)
+{
+  bool valid;
+  const int w0 = lane_word<1>(tile, lane, Wp, valid);
+  Costs<S> a, b, ma, mb;
+  load_costs<S>(a, vec, o.a, Wp, w0);
+  load_costs<S>(b, vec, o.b, Wp, w0);
+  mplus<S>(ma, a, cost);
+  mplus<S>(mb, b, cost);
+  uint32_t *dst = vec + (size_t)o.dst * (size_t)(S * Wp) + w0;
+  uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+  for (int z = 0; z < S; z++) {
+    const uint32_t c = ma.v[z] + mb.v[z];
+    cur = min(cur, c);
+    if (valid) dst[(size_t)z * Wp] = c;
+  }
+  cur = valid ? cur : 0u;
+  const uint32_t tot = wave_total<0>(cur);
+  if (lane == 0) cntp[(size_t)tile * nslots + o.dst] = tot;
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_snk_newview(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops, int n_ops,
+                                                     const uint32_t *__restrict__ cost, uint32_t *__restrict__ cntp,
+                                                     uint32_t nslots, int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_ops * tiles) return;
+  const int op = gw / tiles, tile = gw - op * tiles;
+  newview_one_snk<S>(vec, ops[op], cost, cntp, nslots, Wp, tile, lane);
+}
+
+template <int S>
+__global__ __launch_bounds__(1024) void k_snk_newview_wg(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+                                                         const int32_t *__restrict__ lev_off, int n_lev,
+                                                         const uint32_t *__restrict__ cost, uint32_t *__restrict__ cntp,
+                                                         uint32_t nslots, int Wp)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = (int)(blockDim.x >> 6);
+  const int tile = blockIdx.x;
+  for (int l = 0; l < n_lev; l++) {
+    const int b = lev_off[l], e = lev_off[l + 1];
+    for (int i = b + wave; i < e; i += nw) newview_one_snk<S>(vec, ops[i], cost, cntp, nslots, Wp, tile, lane);
+    __syncthreads();
+  }
+}
+
+// weighted length across branch (a, b): sum_ptn w * min_x(A[x] + m(B)[x])
+template <int S>
+__global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict__ vec, const EvOp *__restrict__ ops,
+                                                      int n_ops, const uint32_t *__restrict__ cost,
+                                                      const uint32_t *__restrict__ pwgt, uint32_t *__restrict__ out,
+                                                      int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_ops * tiles) return;
+  const int op = gw / tiles, tile = gw - op * tiles;
+  const EvOp o = ops[op];
+  bool valid;
+  const int w0 = lane_word<1>(tile, lane, Wp, valid);
+  Costs<S> a, b, mb;
+  load_costs<S>(a, vec, o.a, Wp, w0);
+  load_costs<S>(b, vec, o.b, Wp, w0);
+  mplus<S>(mb, b, cost);
+  uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+  for (int x = 0; x < S; x++) best = min(best, a.v[x] + mb.v[x]);
+  const uint32_t c = valid ? best * pwgt[w0] : 0u;
+  const uint32_t tot = wave_total<0>(c);
+  if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+}
+
+// SPR / stepwise scan over a host-planned program (same ops as k_scan).  With m() the min-plus transform:
+//   CHAIN : U[d] = m(U[d-1]) + m(vec[sib]);  test: out += sum_ptn w * min_s(m(U[d])[s] + m(vec[own])[s] + m(S)[s])
+//   JOIN  : out += sum_ptn w * min_s(m(vec[own])[s] + m(vec[sib])[s] + m(S)[s])
+// and out is the FULL length of the rearranged tree (there is no additive base in the weighted case).
+template <int S, int MAXD>
+__global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
+                                                  int n_scans, const ScanOp *__restrict__ ops,
+                                                  const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
+                                                  uint32_t *__restrict__ out, int Wp, int tiles)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_scans * tiles) return;
+  const int scan = gw / tiles, tile = gw - scan * tiles;
+  const ScanHdr h = hdr[scan];
+  bool valid;
+  const int w0 = lane_word<1>(tile, lane, Wp, valid);
+  const uint32_t w = valid ? pwgt[w0] : 0u;
+
+  Costs<S> ms, U[MAXD + 1], t0, t1, t2;
+  load_costs<S>(t0, vec, h.s_slot, Wp, w0);
+  mplus<S>(ms, t0, cost);
+
+  for (uint32_t i = h.op_begin; i < h.op_end; i++) {
+    const ScanOp o = ops[i];
+    const int d = (int)(o.meta & 0xFFu);
+    const bool test = (o.meta >> 8) & 1u;
+    const int kind = (int)((o.meta >> 16) & 0xFFu);
+    if (kind == SCAN_ROOT) {
+      load_costs<S>(U[0], vec, o.own, Wp, w0);
+      continue;
+    }
+    uint32_t best = 0xFFFFFFFFu;
+    load_costs<S>(t0, vec, o.sib, Wp, w0);
+    mplus<S>(t1, t0, cost);                       // m(vec[sib])
+    if (kind == SCAN_JOIN) {
+      load_costs<S>(t0, vec, o.own, Wp, w0);
+      mplus<S>(t2, t0, cost);
+#pragma unroll
+      for (int s = 0; s < S; s++) best = min(best, t1.v[s] + t2.v[s] + ms.v[s]);
+    } else {
+#define MPF_SLEVEL(c)                                                                  \
+  case c:                                                                              \
+    if constexpr (c <= MAXD) {                                                         \
+      mplus<S>(t2, U[c - 1], cost);                                                    \
+      _Pragma("unroll") for (int s = 0; s < S; s++) U[c].v[s] = t1.v[s] + t2.v[s];     \
+      if (test) {                                                                      \
+        load_costs<S>(t0, vec, o.own, Wp, w0);                                         \
+        mplus<S>(t1, t0, cost);                                                        \
+        mplus<S>(t2, U[c], cost);                                                      \
+        _Pragma("unroll") for (int s = 0; s < S; s++) best = min(best, t1.v[s] + t2.v[s] + ms.v[s]); \
+      }                                                                                \
+    }                                                                                  \
+    break;
+      switch (d) {
+        MPF_SLEVEL(1) MPF_SLEVEL(2) MPF_SLEVEL(3) MPF_SLEVEL(4) MPF_SLEVEL(5) MPF_SLEVEL(6)
+        MPF_SLEVEL(7) MPF_SLEVEL(8) MPF_SLEVEL(9) MPF_SLEVEL(10) MPF_SLEVEL(11) MPF_SLEVEL(12)
+        default: break;
+      }
+#undef MPF_SLEVEL
+    }
+    if (test || kind == SCAN_JOIN) {
+      const uint32_t c = valid ? best * w : 0u;
+      const uint32_t tot = wave_total<0>(c);
+      if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+    }
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict__ vec, uint32_t a_slot, uint32_t b_slot,
+                                                     const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int Wp)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Wp) return;
+  Costs<S> a, b, mb;
+  load_costs<S>(a, vec, a_slot, Wp, j);
+  load_costs<S>(b, vec, b_slot, Wp, j);
+  mplus<S>(mb, b, cost);
+  uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+  for (int x = 0; x < S; x++) best = min(best, a.v[x] + mb.v[x]);
+  ptn[j] = (uint16_t)best;
+}
+
+// compressSankoffDNA (reference sprparsimony.cpp:2636-2825): cost 0 for states in the tip's set, highest_cost otherwise
+template <int S>
+__global__ __launch_bounds__(256) void k_snk_pack(uint32_t *__restrict__ vec, const uint8_t *__restrict__ codes, int n_taxa,
+                                                  int n_patterns, const int32_t *__restrict__ inf_index, int n_inf,
+                                                  int datatype, uint32_t highest, int Wp)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tip = blockIdx.y;
+  if (j >= Wp || tip >= n_taxa) return;
+  uint32_t *dst = vec + (size_t)tip * (size_t)(S * Wp) + j;
+  if (j >= n_inf) {
+#pragma unroll
+    for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = 0u;        // padded patterns, :2766-2775
+    return;
+  }
+  const uint32_t m = state_mask(datatype, codes[(size_t)tip * n_patterns + inf_index[j]]);
+#pragma unroll
+  for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = ((m >> k) & 1u) ? 0u : highest;
+}
+
 // ---------------------------------------------------------------- launch wrappers
 
 static inline int tiles_of(const Geometry &g) { return (g.Wp + 64 * g.vw - 1) / (64 * g.vw); }
@@ -692,6 +921,11 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
   const int tiles = tiles_of(g);
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (g.sankoff) {
+    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview<4>, grid, block, 0, st, vec, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
+    else hipLaunchKernelGGL(k_snk_newview<20>, grid, block, 0, st, vec, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
+    return hipGetLastError();
+  }
 #define NV(S_, VW_, RED_) hipLaunchKernelGGL((k_newview<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, cntp, nslots, g.Wp, tiles)
 #define NV2(S_, VW_, dummy) do { if (g.reduce == 0) NV(S_, VW_, 0); else NV(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NV2, 0);
@@ -705,6 +939,11 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 {
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
+  if (g.sankoff) {
+    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview_wg<4>, grid, block, 0, st, vec, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
+    else hipLaunchKernelGGL(k_snk_newview_wg<20>, grid, block, 0, st, vec, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
+    return hipGetLastError();
+  }
 #define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp)
 #define NW2(S_, VW_, dummy) do { if (g.reduce == 0) NW(S_, VW_, 0); else NW(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NW2, 0);
@@ -730,6 +969,11 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
   const int tiles = tiles_of(g);
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (g.sankoff) {
+    if (g.S == 4) hipLaunchKernelGGL(k_snk_evaluate<4>, grid, block, 0, st, vec, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    else hipLaunchKernelGGL(k_snk_evaluate<20>, grid, block, 0, st, vec, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    return hipGetLastError();
+  }
 #define EV(S_, VW_, RED_) hipLaunchKernelGGL((k_evaluate<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, out, g.Wp, tiles)
 #define EV2(S_, VW_, dummy) do { if (g.reduce == 0) EV(S_, VW_, 0); else EV(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(EV2, 0);
@@ -745,6 +989,18 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
   const int tiles = tiles_of(g);
   dim3 block(256);
   unsigned nblocks;
+  if (g.sankoff) {
+    const long waves = (long)n_scans * tiles;
+    dim3 sgrid((unsigned)((waves + 3) / 4));
+    if (g.S == 4) {
+      if (max_depth <= 6) hipLaunchKernelGGL((k_snk_scan<4, 6>), sgrid, block, 0, st, vec, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+      else hipLaunchKernelGGL((k_snk_scan<4, 12>), sgrid, block, 0, st, vec, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    } else {
+      if (max_depth > 6) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((k_snk_scan<20, 6>), sgrid, block, 0, st, vec, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    }
+    return hipGetLastError();
+  }
   if (g.map == 0) {
     const long waves = (long)n_scans * tiles;
     nblocks = (unsigned)((waves + 3) / 4);
@@ -816,6 +1072,28 @@ size_t site_planes_words(const Geometry &g, int n_ops)
 {
   const int n_chunks = (n_ops + kPlaneChunk - 1) / kPlaneChunk;
   return (size_t)n_chunks * kPlanes * (size_t)g.Wp;
+}
+
+hipError_t launch_sankoff_pattern(hipStream_t st, const Geometry &g, const uint32_t *vec, uint32_t a, uint32_t b,
+                                  uint16_t *ptn_out)
+{
+  dim3 grid((g.Wp + 255) / 256), block(256);
+  if (g.S == 4) hipLaunchKernelGGL(k_snk_pattern<4>, grid, block, 0, st, vec, a, b, g.cost, ptn_out, g.Wp);
+  else hipLaunchKernelGGL(k_snk_pattern<20>, grid, block, 0, st, vec, a, b, g.cost, ptn_out, g.Wp);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_tips_sankoff(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
+                                    int n_patterns, const int32_t *inf_index, int n_inf, int datatype)
+{
+  dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);
+  if (g.S == 4)
+    hipLaunchKernelGGL(k_snk_pack<4>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
+                       g.highest_cost, g.Wp);
+  else
+    hipLaunchKernelGGL(k_snk_pack<20>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
+                       g.highest_cost, g.Wp);
+  return hipGetLastError();
 }
 
 }  // namespace mpf

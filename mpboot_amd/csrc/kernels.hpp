@@ -38,10 +38,15 @@ constexpr int kMaxDepth = 12;   // deepest chain the register-resident scan kern
 
 struct Geometry {
   int S;        // states (4 | 20)
-  int Wp;       // words per row, multiple of 32
+  int Wp;       // elements per row, multiple of 32 (Fitch: 32-site words; Sankoff: patterns)
   int vw;       // words per lane (1 | 2 | 4)
   int reduce;   // 0 = DPP wave reduction, 1 = ds_bpermute (__shfl) reduction
   int map;      // 0 = scan-major wave mapping, 1 = tiles pinned to XCD classes
+  // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
+  int sankoff = 0;
+  const uint32_t *cost = nullptr;   // device, [S][S]
+  const uint32_t *pwgt = nullptr;   // device, [Wp] pattern weights (0 on padding)
+  uint32_t highest_cost = 0;
 };
 
 hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
@@ -67,5 +72,11 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
                               uint32_t *planes, const int32_t *ptn_first_site, int n_ptn, uint16_t *ptn_out);
 size_t site_planes_words(const Geometry &g, int n_ops);
+
+// Sankoff: per-pattern cost of the branch (a, b): ptn[j] = min_x(A[x] + min_y(cost[x][y] + B[y]))
+hipError_t launch_sankoff_pattern(hipStream_t st, const Geometry &g, const uint32_t *vec, uint32_t a, uint32_t b,
+                                  uint16_t *ptn_out);
+hipError_t launch_pack_tips_sankoff(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
+                                    int n_patterns, const int32_t *inf_index, int n_inf, int datatype);
 
 }  // namespace mpf

@@ -17,7 +17,8 @@ DNA, AA = 0, 1
 TIE_FIRST, TIE_RANDOM = 0, 1
 
 EXPORTS = [
-    "mpf_last_error", "mpf_abi_version", "mpf_engine_create", "mpf_engine_destroy", "mpf_set_weights",
+    "mpf_last_error", "mpf_abi_version", "mpf_engine_create", "mpf_engine_create_sankoff", "mpf_engine_destroy",
+    "mpf_set_weights",
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
     "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_compute_parsimony",
     "mpf_encode_iqtree_states", "mpf_seed_ties",
@@ -63,6 +64,7 @@ def load_library():
         L.mpf_last_error.restype = C.c_char_p
         vp = C.c_void_p
         L.mpf_engine_create.argtypes = [C.POINTER(vp), C.POINTER(Config), vp, vp]
+        L.mpf_engine_create_sankoff.argtypes = [C.POINTER(vp), C.POINTER(Config), vp, vp, vp]
         L.mpf_engine_destroy.argtypes = [vp]
         L.mpf_engine_destroy.restype = None
         L.mpf_set_weights.argtypes = [vp, vp]
@@ -111,7 +113,9 @@ def encode_iqtree_states(states: np.ndarray, datatype: int = DNA) -> np.ndarray:
 class FitchEngine:
     """One alignment resident on one MI355X; mirrors the reference's PLL-instance-level calls."""
 
-    def __init__(self, codes: np.ndarray, weights=None, datatype: int = DNA, keep_all: bool = False, device: int = 0):
+    def __init__(self, codes: np.ndarray, weights=None, datatype: int = DNA, keep_all: bool = False, device: int = 0,
+                 cost=None):
+        """cost: optional [S, S] matrix -> weighted (Sankoff) parsimony, the reference's `-cost` mode"""
         L = load_library()
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         self.n, self.P = codes.shape
@@ -120,7 +124,11 @@ class FitchEngine:
         weights = np.ascontiguousarray(weights, dtype=np.int32)
         cfg = Config(device, self.n, self.P, datatype, int(keep_all))
         h = C.c_void_p()
-        _chk(L.mpf_engine_create(C.byref(h), C.byref(cfg), _p(codes), _p(weights)))
+        if cost is None:
+            _chk(L.mpf_engine_create(C.byref(h), C.byref(cfg), _p(codes), _p(weights)))
+        else:
+            cost = np.ascontiguousarray(cost, dtype=np.uint32)
+            _chk(L.mpf_engine_create_sankoff(C.byref(h), C.byref(cfg), _p(codes), _p(weights), _p(cost)))
         self.h = h
         self.nrec = 3 * (2 * self.n - 1)
         s, w, ni, wp = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

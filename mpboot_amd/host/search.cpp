@@ -196,7 +196,7 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     rc = run_scans(plans, out);
     if (rc) return rc;
     for (const Candidate &c : pl.cands) {
-      const uint32_t mp = len + out[c.out];
+      const uint32_t mp = (sankoff_ ? 0u : len) + out[c.out];   // weighted: the join kernel returns the full length
       if (tie_mode_ == MPF_TIE_RANDOM) {
         if (mp < best_) hits_ = 1;
         else if (mp == best_) hits_++;

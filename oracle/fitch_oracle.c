@@ -31,6 +31,14 @@ struct orc {
   unsigned *score;
   uint32_t *persite;          /* [2n][W*32] or NULL */
   int persite_on;
+  /* Sankoff (weighted) mode: cost matrix given (reference pllCostMatrix != NULL) */
+  int sankoff;
+  uint32_t *cost;             /* [S][S], cost[i*S+j] = cost i -> j (sprparsimony.cpp:190) */
+  uint32_t highest_cost;      /* max(cost) + 1 (sprparsimony.cpp:160) */
+  int Pinf;                   /* informative patterns kept (not weight-replicated) */
+  uint32_t *svec;             /* [2n][S][Pinf] state costs per pattern */
+  uint32_t *pwgt;             /* [Pinf] informativePtnWgt */
+  uint32_t *pscore;           /* [Pinf] informativePtnScore (per-pattern score of the last evaluate) */
   int *back;
   unsigned char *x;
   int *nodep;
@@ -86,10 +94,44 @@ static int is_informative(const orc *o, int site)
 }
 
 /* ---- compressDNA: sprparsimony.cpp:2828-2973 (PLL: fastDNAparsimony.c:1647-1774) ---- */
+/* ---- compressSankoffDNA: sprparsimony.cpp:2636-2825 (values per pattern and state: 0 if the state is in the
+        tip's set, highest_cost otherwise; patterns are NOT weight-replicated, weights go to informativePtnWgt).
+        The SIMD block interleaving of the reference (:2738-2764) is a layout detail we do not restate;
+        arithmetic is exact 32-bit (the reference's -short_off mode; identical to its 16-bit default
+        whenever that does not wrap, SURVEY parity hazard 4). ---- */
+static void pack_tips_sankoff(orc *o)
+{
+  int i, k, site, S = o->S, j;
+  o->ninf = 0;
+  for (site = 0; site < o->P; site++) {
+    o->inf[site] = is_informative(o, site);
+    if (o->inf[site]) o->ninf++;
+  }
+  o->Pinf = o->ninf;
+  o->W = o->Pinf;                              /* parsimonyLength counts patterns in this mode (:2805) */
+  free(o->svec); free(o->pwgt); free(o->pscore);
+  o->svec = (uint32_t *)calloc((size_t)2 * o->n * S * (o->Pinf + 1) + 1, sizeof(uint32_t));
+  o->pwgt = (uint32_t *)calloc((size_t)o->Pinf + 1, sizeof(uint32_t));
+  o->pscore = (uint32_t *)calloc((size_t)o->Pinf + 1, sizeof(uint32_t));
+  for (i = 0; i < o->n; i++) {
+    uint32_t *tip = o->svec + (size_t)S * o->Pinf * (i + 1);
+    for (site = 0, j = 0; site < o->P; site++) {
+      uint32_t m;
+      if (!o->inf[site]) continue;
+      m = state_mask(o->datatype, o->codes[(size_t)i * o->P + site]);
+      for (k = 0; k < S; k++) tip[(size_t)k * o->Pinf + j] = (m & (1u << k)) ? 0u : o->highest_cost;   /* :2748-2756 */
+      if (i == 0) o->pwgt[j] = (uint32_t)o->wgt[site];
+      j++;
+    }
+  }
+  memset(o->score, 0, sizeof(unsigned) * 2 * o->n);
+}
+
 static void pack_tips(orc *o)
 {
   size_t entries = 0, ce, cep;
   int i, k, site, S = o->S;
+  if (o->sankoff) { pack_tips_sankoff(o); return; }
   o->ninf = 0;
   for (site = 0; site < o->P; site++) {
     o->inf[site] = is_informative(o, site);
@@ -163,9 +205,31 @@ orc *orc_create(int n, int P, int datatype, const unsigned char *codes, const in
   return o;
 }
 
+/* Sankoff engine: cost[S*S] as loaded by ParsTree::loadCostMatrixFile (parstree.cpp:31-95), which also closes
+   it under the triangle inequality (:74-80); initializeCostMatrix (sprparsimony.cpp:159-188) */
+orc *orc_create_sankoff(int n, int P, int datatype, const unsigned char *codes, const int *weights, int keep_all,
+                        const unsigned *cost)
+{
+  orc *o = orc_create(n, P, datatype, codes, weights, keep_all);
+  int S = o->S, i, j, k;
+  o->cost = (uint32_t *)malloc(sizeof(uint32_t) * S * S);
+  for (i = 0; i < S * S; i++) o->cost[i] = cost[i];
+  for (k = 0; k < S; k++)
+    for (i = 0; i < S; i++)
+      for (j = 0; j < S; j++)
+        if (o->cost[i * S + j] > o->cost[i * S + k] + o->cost[k * S + j]) o->cost[i * S + j] = o->cost[i * S + k] + o->cost[k * S + j];
+  o->highest_cost = 0;
+  for (i = 0; i < S * S; i++) if (o->cost[i] > o->highest_cost) o->highest_cost = o->cost[i];
+  o->highest_cost += 1;
+  o->sankoff = 1;
+  pack_tips(o);
+  return o;
+}
+
 void orc_destroy(orc *o)
 {
   if (!o) return;
+  free(o->cost); free(o->svec); free(o->pwgt); free(o->pscore);
   free(o->codes); free(o->wgt); free(o->inf); free(o->vec); free(o->score); free(o->persite);
   free(o->back); free(o->x); free(o->nodep); free(o->ti); free(o->trace_q); free(o->trace_mp);
   free(o->moves_rem); free(o->moves_ins); free(o->moves_score);
@@ -251,7 +315,7 @@ static void getx(orc *o, int p)
 static void traversal(orc *o, int p, int *counter, int full)
 {
   int q, r;
-  if (o->persite_on) ps_reset(o, NUM(p));             /* :437-439 */
+  if (o->persite_on && !o->sankoff) ps_reset(o, NUM(p));   /* :437-439 (perSiteScores && pllCostMatrix == NULL) */
   q = o->back[NX(p)];
   r = o->back[NX(NX(p))];
   if (!o->x[p]) getx(o, p);
@@ -269,9 +333,74 @@ static void traversal(orc *o, int p, int *counter, int full)
 }
 
 /* ---- newviewParsimonyIterativeFast, Fitch: sprparsimony.cpp:554-878 (generic-S body :841-869) ---- */
+/* ---- newviewSankoffParsimonyIterativeFastSIMD: sprparsimony.cpp:477-551 ----
+        cur[z] = min_x(left[x] + cost[z][x]) + min_x(right[x] + cost[z][x]);
+        parsimonyScore[p] = sum over patterns of min_z cur[z] (unweighted; only tested > 0, :544-548, :3014) */
+static void newview_iter_sankoff(orc *o)
+{
+  int idx, count = o->ti[0], S = o->S, P = o->Pinf, z, x, i;
+  for (idx = 4; idx < count; idx += 4) {
+    size_t pN = (size_t)o->ti[idx], qN = (size_t)o->ti[idx + 1], rN = (size_t)o->ti[idx + 2];
+    const uint32_t *L = o->svec + (size_t)S * P * qN, *R = o->svec + (size_t)S * P * rN;
+    uint32_t *C = o->svec + (size_t)S * P * pN;
+    unsigned total = 0;
+    for (i = 0; i < P; i++) {
+      uint32_t cur_contrib = UINT32_MAX;
+      for (z = 0; z < S; z++) {
+        const uint32_t *c = o->cost + (size_t)z * S;
+        uint32_t lc = L[i] + c[0], rc = R[i] + c[0];
+        for (x = 1; x < S; x++) {
+          uint32_t v = L[(size_t)x * P + i] + c[x];
+          if (v < lc) lc = v;
+          v = R[(size_t)x * P + i] + c[x];
+          if (v < rc) rc = v;
+        }
+        C[(size_t)z * P + i] = lc + rc;
+        if (lc + rc < cur_contrib) cur_contrib = lc + rc;
+      }
+      total += cur_contrib;
+    }
+    o->score[pN] = total;
+    o->c_newview++;
+  }
+}
+
+/* ---- evaluateSankoffParsimonyIterativeFastSIMD: sprparsimony.cpp:880-961 ----
+        sum over patterns of w * min_x(left[x] + min_y(cost[x][y] + right[y])), left = q, right = p.
+        The segment-wise early return of a lower-bound estimate (:946-955) is not restated: it only changes
+        the value reported for moves that are rejected anyway (SURVEY parity hazard 5). */
+static unsigned evaluate_iter_sankoff(orc *o)
+{
+  size_t pN = (size_t)o->ti[1], qN = (size_t)o->ti[2];
+  int S = o->S, P = o->Pinf, x, y, i;
+  const uint32_t *L, *R;
+  unsigned total = 0;
+  if (o->ti[0] > 4) newview_iter_sankoff(o);
+  L = o->svec + (size_t)S * P * qN;
+  R = o->svec + (size_t)S * P * pN;
+  for (i = 0; i < P; i++) {
+    uint32_t best = UINT32_MAX;
+    for (x = 0; x < S; x++) {
+      const uint32_t *c = o->cost + (size_t)x * S;
+      uint32_t t = c[0] + R[i];
+      for (y = 1; y < S; y++) {
+        uint32_t v = c[y] + R[(size_t)y * P + i];
+        if (v < t) t = v;
+      }
+      t += L[(size_t)x * P + i];
+      if (t < best) best = t;
+    }
+    o->pscore[i] = best;
+    total += best * o->pwgt[i];
+  }
+  o->c_eval++;
+  return total;
+}
+
 static void newview_iter(orc *o)
 {
   int idx, count = o->ti[0], S = o->S, W = o->W, k, i;
+  if (o->sankoff) { newview_iter_sankoff(o); return; }
   for (idx = 4; idx < count; idx += 4) {
     size_t pN = (size_t)o->ti[idx], qN = (size_t)o->ti[idx + 1], rN = (size_t)o->ti[idx + 2];
     const uint32_t *L = o->vec + (size_t)W * S * qN, *R = o->vec + (size_t)W * S * rN;
@@ -305,6 +434,7 @@ static unsigned evaluate_iter(orc *o)
   int S = o->S, W = o->W, k, i;
   unsigned sum;
   const uint32_t *L, *R;
+  if (o->sankoff) return evaluate_iter_sankoff(o);
   if (o->ti[0] > 4) newview_iter(o);
   sum = o->score[pN] + o->score[qN];
   if (o->persite_on) {                                /* :1051-1054 */
@@ -375,8 +505,19 @@ unsigned orc_score_tree(orc *o)
 /* ---- pllComputePatternParsimony: sprparsimony.cpp:3363-3392 ---- */
 int orc_pattern_scores(orc *o, unsigned short *ptn)
 {
-  const uint32_t *p = o->persite + (size_t)o->W * 32 * NUM(o->start);
+  const uint32_t *p;
   int k, site = 0, sum = 0, upper = o->keep_all ? o->P : o->ninf, j = 0;
+  if (o->sankoff) {                                   /* pllComputeSankoffPatternParsimony :3341-3355 */
+    for (k = 0; k < o->P; k++) ptn[k] = 0;
+    for (k = 0; k < o->P; k++) {
+      if (!o->inf[k]) continue;
+      ptn[k] = (unsigned short)o->pscore[j];
+      sum += (int)ptn[k] * o->wgt[k];
+      j++;
+    }
+    return sum;
+  }
+  p = o->persite + (size_t)o->W * 32 * NUM(o->start);
   /* the reference indexes ptn by sorted-pattern position and assumes the first
      numInformativePatterns patterns are the kept ones (:3380-3387); we return the
      score at each KEPT pattern's original index and 0 elsewhere, which is the same

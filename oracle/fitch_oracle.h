@@ -29,6 +29,9 @@ typedef struct orc orc;
 
 orc *orc_create(int n_taxa, int n_patterns, int datatype, const unsigned char *codes /* [n][P] PLL tip codes */,
                 const int *weights /* [P] */, int keep_all_sites);
+/* weighted (Sankoff) parsimony: same search code, cost-matrix arithmetic (sprparsimony.cpp:477-551, :880-961) */
+orc *orc_create_sankoff(int n_taxa, int n_patterns, int datatype, const unsigned char *codes, const int *weights,
+                        int keep_all_sites, const unsigned *cost /* [S*S], cost[i*S+j] = i -> j */);
 void orc_destroy(orc *o);
 int orc_words(const orc *o);                 /* parsimonyLength W */
 int orc_states(const orc *o);

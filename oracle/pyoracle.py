@@ -37,6 +37,8 @@ def lib():
         vp, ci, cu = C.c_void_p, C.c_int, C.c_uint
         L.orc_create.restype = vp
         L.orc_create.argtypes = [ci, ci, ci, vp, vp, ci]
+        L.orc_create_sankoff.restype = vp
+        L.orc_create_sankoff.argtypes = [ci, ci, ci, vp, vp, ci, vp]
         L.orc_destroy.argtypes = [vp]
         for f in ("orc_words", "orc_states", "orc_num_informative", "orc_trace_len", "orc_moves_len"):
             getattr(L, f).restype = ci
@@ -85,13 +87,17 @@ def _p(a):
 class Oracle:
     """One alignment packed the reference's way; mirrors the PLL instance state."""
 
-    def __init__(self, codes: np.ndarray, weights=None, datatype: int = DNA, keep_all: bool = False):
+    def __init__(self, codes: np.ndarray, weights=None, datatype: int = DNA, keep_all: bool = False, cost=None):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         self.n, self.P = codes.shape
         if weights is None:
             weights = np.ones(self.P, dtype=np.int32)
         weights = np.ascontiguousarray(weights, dtype=np.int32)
-        self.h = lib().orc_create(self.n, self.P, datatype, _p(codes), _p(weights), int(keep_all))
+        if cost is None:
+            self.h = lib().orc_create(self.n, self.P, datatype, _p(codes), _p(weights), int(keep_all))
+        else:
+            cost = np.ascontiguousarray(cost, dtype=np.uint32)
+            self.h = lib().orc_create_sankoff(self.n, self.P, datatype, _p(codes), _p(weights), int(keep_all), _p(cost))
         self.nrec = 3 * (2 * self.n - 1)
 
     def __del__(self):

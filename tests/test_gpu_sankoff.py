@@ -1,0 +1,117 @@
+"""GPU parity of the weighted (Sankoff) mode: libmpfitch.so against the oracle's Sankoff mode."""
+import numpy as np
+import pytest
+
+from helpers import FIXTURES, load_fixture, trace_tokens
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_cost(S):
+    return (1 - np.eye(S, dtype=np.uint32)).astype(np.uint32)
+
+
+def tstv_cost():
+    c = np.full((4, 4), 2, dtype=np.uint32)
+    np.fill_diagonal(c, 0)
+    c[0, 2] = c[2, 0] = c[1, 3] = c[3, 1] = 1
+    return c
+
+
+def random_metric(S, seed):
+    rng = np.random.default_rng(seed)
+    pts = rng.integers(0, 12, size=(S, 3))
+    c = np.abs(pts[:, None, :] - pts[None, :, :]).sum(axis=2).astype(np.uint32)
+    c[c == 0] = 1
+    np.fill_diagonal(c, 0)
+    return c
+
+
+def cost_for(fx, kind):
+    S = fx["S"]
+    if kind == "unit":
+        return unit_cost(S)
+    return tstv_cost() if S == 4 else random_metric(20, 4)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    return engine, po
+
+
+@pytest.fixture(scope="module", params=FIXTURES)
+def fx(request):
+    return load_fixture(request.param)
+
+
+@pytest.mark.parametrize("kind", ["unit", "general"])
+def test_scores_patterns_and_scans(mods, fx, kind):
+    engine, po = mods
+    cost = cost_for(fx, kind)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    for t in fx["trees"][:4]:
+        b = np.array(t["back"], dtype=np.int32)
+        s = e.score_tree(b)
+        assert s == o.score_tree(b)
+        if kind == "unit":
+            assert s == t["score"]                      # unit costs == Fitch == the reference's number
+        ptn, total = e.pattern_scores()
+        optn, ototal = o.pattern_scores()
+        assert total == ototal == s and (ptn == optn).all()
+    sc = fx["scan"][0]
+    back = np.array(sc["back"], dtype=np.int32)
+    e.set_tree(back)
+    cur = e.score_tree()
+    o.reset_nodep()
+    o.set_tree(back)
+    assert o.score_tree() == cur
+    o.seed_ties(po.TIE_RANDOM, 1)
+    for rec in sc["order"]:
+        o.set_best(cur)
+        o.trace(True)
+        o.rearrange(rec, 1, 6)
+        toks = trace_tokens(*o.get_trace())
+        q, mp, n_p = e.spr_scan(rec, 1, 6)
+        mine = ["P"] + [f"{a}:{b}" for a, b in zip(q[:n_p], mp[:n_p])] + ["Q"] + [f"{a}:{b}" for a, b in zip(q[n_p:], mp[n_p:])]
+        assert mine == toks, rec
+
+
+@pytest.mark.parametrize("kind", ["unit", "general"])
+def test_hill_climb_and_ras_trajectories(mods, fx, kind):
+    engine, po = mods
+    cost = cost_for(fx, kind)
+    start = np.array(fx["spr"]["start_back"], dtype=np.int32)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    e.set_tree(start)
+    o.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, 9)
+    o.seed_ties(po.TIE_RANDOM, 9)
+    o.trace(True)
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    e2 = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    o2 = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    e2.seed_ties(engine.TIE_RANDOM, 4)
+    o2.seed_ties(po.TIE_RANDOM, 4)
+    assert e2.make_parsimony_tree(42, 3) == o2.make_tree(42, 3)[0]
+    assert (e2.get_tree() == o2.get_tree()).all()
+    if kind == "unit":
+        f = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+        f.seed_ties(engine.TIE_RANDOM, 4)
+        f.make_parsimony_tree(42, 3)
+        assert (f.get_tree() == e2.get_tree()).all()     # `-cost e` == Fitch trajectory
+
+
+def test_asymmetric_matrix_is_refused(mods):
+    engine = mods[0]
+    fx = load_fixture("dna_clean")
+    c = tstv_cost()
+    c[0, 1] = 3
+    with pytest.raises(engine.MpfError) as ei:
+        engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=c)
+    assert ei.value.code == -6
