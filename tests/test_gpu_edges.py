@@ -1,0 +1,148 @@
+"""Edge cases of the GPU path: tiny trees, clamped radius, keep-all-sites, large radius (host-planned and
+device-walked), zero weights, error behaviour."""
+import numpy as np
+import pytest
+
+from helpers import load_fixture, trace_tokens
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mpboot_amd import engine, synth, trees
+    from oracle import pyoracle as po
+    return engine, po, synth, trees
+
+
+def scan_tokens(e, rec, maxtrav):
+    q, mp, n_p = e.spr_scan(int(rec), 1, maxtrav)
+    return ["P"] + [f"{a}:{b}" for a, b in zip(q[:n_p], mp[:n_p])] + ["Q"] + [f"{a}:{b}" for a, b in zip(q[n_p:], mp[n_p:])]
+
+
+@pytest.mark.parametrize("n", [4, 5, 6, 9])
+def test_tiny_trees(mods, n):
+    """maxtrav is clamped to ntips-3 (reference sprparsimony.cpp:2277-2278); with 4 taxa nothing can move"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(n, 80, "DNA", 0.3, seed=n)
+    codes = synth.letters_to_codes(letters)
+    back = trees.random_topology(n, np.random.default_rng(n))
+    e = engine.FitchEngine(codes)
+    o = po.Oracle(codes)
+    assert e.score_tree(back) == o.score_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 1)
+    cur = o.score_tree()
+    for rec in o.nodep()[1:2 * n - 1]:
+        o.set_best(cur)
+        o.trace(True)
+        o.rearrange(int(rec), 1, 6)
+        assert scan_tokens(e, rec, 6) == trace_tokens(*o.get_trace())
+    e.seed_ties(engine.TIE_RANDOM, 3)
+    o2 = po.Oracle(codes)
+    o2.set_tree(back)
+    o2.seed_ties(po.TIE_RANDOM, 3)
+    assert e.optimize_spr(1, 6) == o2.optimize_spr(1, 6)
+    assert (e.get_tree() == o2.get_tree()).all()
+    e3, o3 = engine.FitchEngine(codes), po.Oracle(codes)
+    e3.seed_ties(engine.TIE_RANDOM, 8)
+    o3.seed_ties(po.TIE_RANDOM, 8)
+    assert e3.make_parsimony_tree(5, 6) == o3.make_tree(5, 6)[0]
+    assert (e3.get_tree() == o3.get_tree()).all()
+
+
+@pytest.mark.parametrize("maxtrav,mode", [(1, 1), (2, 1), (7, 1), (8, 1), (9, 1), (12, 0), (10, 0)])
+def test_radii(mods, maxtrav, mode):
+    """radius 7-8 uses the deep device-walked kernel, 9-12 the host-planned one"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(40, 500, "DNA", 0.1, seed=31)
+    codes = synth.letters_to_codes(letters)
+    back = trees.random_topology(40, np.random.default_rng(5))
+    e = engine.FitchEngine(codes)
+    e.set_option("scan_mode", mode)
+    e.set_option("check_counts", 1)
+    o = po.Oracle(codes)
+    assert e.score_tree(back) == o.score_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 1)
+    cur = o.score_tree()
+    for rec in o.nodep()[1:79:3]:
+        o.set_best(cur)
+        o.trace(True)
+        o.rearrange(int(rec), 1, maxtrav)
+        assert scan_tokens(e, rec, maxtrav) == trace_tokens(*o.get_trace())
+    e.seed_ties(engine.TIE_RANDOM, 2)
+    o2 = po.Oracle(codes)
+    o2.set_tree(back)
+    o2.seed_ties(po.TIE_RANDOM, 2)
+    assert e.optimize_spr(1, maxtrav) == o2.optimize_spr(1, maxtrav)
+    assert (e.get_tree() == o2.get_tree()).all()
+
+
+def test_keep_all_sites_and_zero_weights(mods):
+    """-keep_aln (sort_alignment off: every site kept, sprparsimony.cpp:2462) and weights with zeros"""
+    engine, po = mods[0], mods[1]
+    fx = load_fixture("dna_ambig")
+    w = fx["weights_np"].copy()
+    w[::3] = 0
+    e = engine.FitchEngine(fx["codes_np"], w, keep_all=True)
+    o = po.Oracle(fx["codes_np"], w, keep_all=True)
+    assert e.W == o.W and e.num_informative == o.num_informative == len(w)
+    for t in fx["trees"][:3]:
+        b = np.array(t["back"], dtype=np.int32)
+        assert e.score_tree(b) == o.score_tree(b)
+    o.enable_persite(True)
+    o.score_tree()
+    ptn, total = e.pattern_scores()
+    optn, ototal = o.pattern_scores()
+    assert total == ototal and (ptn == optn).all()
+
+
+def test_all_patterns_uninformative(mods):
+    engine, po = mods[0], mods[1]
+    codes = np.full((6, 10), 1, dtype=np.uint8)
+    codes[0, :] = 15
+    e = engine.FitchEngine(codes)
+    assert e.num_informative == 0
+    from mpboot_amd import trees
+    back = trees.random_topology(6, np.random.default_rng(1))
+    assert e.score_tree(back) == 0
+    e.seed_ties(engine.TIE_RANDOM, 1)
+    assert e.optimize_spr(1, 6) == 0
+
+
+def test_error_behaviour(mods):
+    engine = mods[0]
+    fx = load_fixture("dna_clean")
+    e = engine.FitchEngine(fx["codes_np"])
+    with pytest.raises(engine.MpfError) as ei:
+        e.score_tree()                                   # no tree yet
+    assert ei.value.code == -5
+    bad = np.array(fx["trees"][0]["back"], dtype=np.int32)
+    bad[3] = 7                                           # tip 1 now points at an unused record
+    with pytest.raises(engine.MpfError) as ei:
+        e.set_tree(bad)
+    assert ei.value.code == -2
+    with pytest.raises(engine.MpfError):
+        engine.FitchEngine(np.zeros((5, 8), dtype=np.uint8))          # code 0 is not a DNA state set
+    with pytest.raises(engine.MpfError):
+        engine.FitchEngine(fx["codes_np"], -np.ones(fx["codes_np"].shape[1], dtype=np.int32))
+    e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    with pytest.raises(engine.MpfError):
+        e.spr_scan(6, 1, 13)                             # beyond the supported radius
+
+
+def test_engine_reuse_across_trees_and_rebuilds(mods):
+    """state carried in the engine (nodep order, views) must not leak between calls"""
+    engine, po = mods[0], mods[1]
+    fx = load_fixture("dna_dups")
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"])
+    o = po.Oracle(fx["codes_np"], fx["weights_np"])
+    for k, t in enumerate(fx["trees"]):
+        b = np.array(t["back"], dtype=np.int32)
+        e.set_tree(b)
+        o.set_tree(b)
+        e.seed_ties(engine.TIE_RANDOM, k)
+        o.seed_ties(po.TIE_RANDOM, k)
+        assert e.optimize_spr(1, 4) == o.optimize_spr(1, 4)
+        assert (e.get_tree() == o.get_tree()).all()
+        assert e.make_parsimony_tree(k, 2) == o.make_tree(k, 2)[0]
+        assert (e.get_tree() == o.get_tree()).all()
