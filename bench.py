@@ -101,10 +101,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmpfitch has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; MPF_BENCH_SHARE_GPU=1 (testing only) lets several ranks share the visible GPUs
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev if os.environ.get("MPF_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(device)
+    backend = os.environ.get("MPF_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     from mpboot_amd import engine, synth, trees
 
@@ -113,7 +120,7 @@ def main():
     letters, names = synth.workload(args.workload)
     codes = synth.letters_to_codes(letters, alphabet)
     n, P = codes.shape
-    eng = engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=local_rank)
+    eng = engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
@@ -148,7 +155,7 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
 
-    tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
