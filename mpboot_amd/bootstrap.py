@@ -1,0 +1,47 @@
+"""Bootstrap replicates on the engine: resampling weights + per-replicate SPR climbs, sharded over ranks.
+
+Reference flow: the B replicates of `-bb` are refined one after another by
+IQTree::optimizeBootTrees (iqtree.cpp:2475-2915): the alignment is re-weighted with the replicate's pattern
+frequencies (modifyPatternFreq :2520), the parsimony structures are rebuilt, and ONE SPR hill climb is run from
+the replicate's best tree (:2837).  Standard bootstrap (phyloanalysis.cpp:1945-2085) instead searches every
+resampled alignment from scratch.  Both are independent per replicate: replicate b goes to rank b % world.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import shard
+from .rng import Lcg64
+
+
+def bootstrap_weights(weights: np.ndarray, rng: Lcg64) -> np.ndarray:
+    """Alignment::createBootstrapAlignment(int *pattern_freq) (alignment.cpp:1981-1990): nsite draws of
+    random_int(nsite), each incrementing the frequency of the drawn site's pattern."""
+    weights = np.asarray(weights, dtype=np.int64)
+    nsite = int(weights.sum())
+    site_pattern = np.repeat(np.arange(len(weights)), weights)        # getPatternID(site) for pattern-sorted sites
+    draws = rng.ints(nsite, nsite)
+    return np.bincount(site_pattern[draws], minlength=len(weights)).astype(np.int32)
+
+
+def run_replicates(eng, weights, n_rep: int, base_seed: int, radius: int = 6, start_tree=None, mode: str = "refine"):
+    """mode "refine": SPR climb from start_tree on every re-weighted alignment (optimizeBootTrees);
+    mode "search": randomized stepwise addition + SPR on every re-weighted alignment (standard bootstrap).
+    Returns (scores[n_rep] with INT_MAX for other ranks' units before reduction, trees dict)."""
+    rank, ws = shard.world()
+    local, trees = {}, {}
+    for b in shard.units_of_rank(n_rep, rank, ws):
+        seed = shard.unit_seed(base_seed, b)
+        w = bootstrap_weights(weights, Lcg64(seed))
+        eng.set_weights(w)
+        eng.seed_ties(1, seed)
+        eng.reset_node_order()          # every replicate starts from a fresh instance state: results do not depend on sharding
+        if mode == "refine":
+            eng.set_tree(start_tree)
+            local[b] = eng.optimize_spr(1, radius)
+        else:
+            r = eng.make_parsimony_tree(seed, radius)
+            local[b] = r[0] if isinstance(r, tuple) else r
+        trees[b] = eng.get_tree()
+    scores, _best, _owner = shard.reduce_best(local, n_rep)
+    return scores, trees

@@ -145,18 +145,17 @@ int Engine::pack()
     // compressSankoffDNA (reference sprparsimony.cpp:2636-2825): informative patterns are kept once each, their
     // weights go to informativePtnWgt; one 32-bit cost per state and pattern
     inf_index_.clear();
-    for (int s = 0; s < P_; s++) {
-      int keep = 1;
-      if (!keep_all_) {
-        bool seen[32] = {false};
-        int distinct = 0;
-        for (int t = 0; t < n_; t++) {
-          const int c = codes_[(size_t)t * P_ + s];
-          if (c < und && !seen[c]) { seen[c] = true; distinct++; }
-        }
-        keep = distinct > 1;
+    if (!inf_known_) {
+      std::vector<uint32_t> seen((size_t)P_, 0u);
+      for (int t = 0; t < n_; t++) {
+        const uint8_t *row = codes_.data() + (size_t)t * P_;
+        for (int s = 0; s < P_; s++) if (row[s] < und) seen[(size_t)s] |= 1u << row[s];
       }
-      inf_[s] = keep;
+      for (int s = 0; s < P_; s++) inf_[s] = keep_all_ ? 1 : (__builtin_popcount(seen[(size_t)s]) > 1);
+      inf_known_ = true;
+    }
+    for (int s = 0; s < P_; s++) {
+      const int keep = inf_[s];
       first_site_[s] = keep ? (int32_t)inf_index_.size() : -1;
       if (wgt_[s] < 0) { set_error("negative pattern weight"); return MPF_E_INVALID; }
       if (keep) inf_index_.push_back(s);
@@ -188,18 +187,18 @@ int Engine::pack()
     invalidate_all();
     return MPF_OK;
   }
-  for (int s = 0; s < P_; s++) {
-    int keep = 1;
-    if (!keep_all_) {
-      bool seen[32] = {false};
-      int distinct = 0;
-      for (int t = 0; t < n_; t++) {
-        const int c = codes_[(size_t)t * P_ + s];
-        if (c < und && !seen[c]) { seen[c] = true; distinct++; }
-      }
-      keep = distinct > 1;
+  if (!inf_known_) {
+    // one pass over the codes, taxon-major so that the rows stream
+    std::vector<uint32_t> seen((size_t)P_, 0u);
+    for (int t = 0; t < n_; t++) {
+      const uint8_t *row = codes_.data() + (size_t)t * P_;
+      for (int s = 0; s < P_; s++) if (row[s] < und) seen[(size_t)s] |= 1u << row[s];
     }
-    inf_[s] = keep;
+    for (int s = 0; s < P_; s++) inf_[s] = keep_all_ ? 1 : (__builtin_popcount(seen[(size_t)s]) > 1);
+    inf_known_ = true;
+  }
+  for (int s = 0; s < P_; s++) {
+    const int keep = inf_[s];
     if (wgt_[s] < 0) { set_error("negative pattern weight"); return MPF_E_INVALID; }
     if (keep) { first_site_[s] = (int32_t)entries; entries += wgt_[s]; ninf_++; } else first_site_[s] = -1;
   }

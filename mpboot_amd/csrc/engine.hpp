@@ -166,6 +166,7 @@ class Engine {
   int Wref_ = 0, nsites_ = 0, ninf_ = 0;
   std::vector<uint8_t> codes_;
   std::vector<int32_t> wgt_, inf_, first_site_;
+  bool inf_known_ = false;                       // informative flags depend on the codes only: computed once
   // Sankoff mode
   bool sankoff_ = false;
   std::vector<uint32_t> cost_;

@@ -76,6 +76,8 @@ def search_start_trees(make_engine, n_units: int, base_seed: int, spr_radius: in
     for u in units_of_rank(n_units, rank, ws):
         seed = unit_seed(base_seed, u)
         eng.seed_ties(1, seed)
+        if hasattr(eng, "reset_node_order"):
+            eng.reset_node_order()      # fresh instance state per unit: results do not depend on the sharding
         local[u] = eng.make_parsimony_tree(seed, spr_radius)
         if isinstance(local[u], tuple):
             local[u] = local[u][0]

@@ -95,3 +95,35 @@ def test_slow_iqtree_fitch_agrees_with_pinned_oracle():
             assert score == t["score"] == o.score_tree(back)
             optn, _ = o.pattern_scores()
             assert (ptn == optn).all()
+
+
+def test_vectorised_lcg64_matches_sprng_fixture_and_scalar():
+    import json
+    import numpy as np
+    from helpers import GOLDEN
+    from mpboot_amd.rng import Lcg64
+    from oracle import pyoracle as po
+    with open(os.path.join(GOLDEN, "sprng_lcg64.json")) as f:
+        ref = json.load(f)
+    for seed, vals in ref.items():
+        got = Lcg64(int(seed)).doubles(len(vals))
+        assert [float.fromhex(v) for v in vals] == got.tolist()
+    g = Lcg64(77)
+    a = np.concatenate([g.doubles(5), g.doubles(1000), g.doubles(3)])
+    assert a.tolist() == po.lcg64_doubles(77, 1008)
+
+
+def test_bootstrap_weights_resample_sites():
+    import numpy as np
+    from mpboot_amd.bootstrap import bootstrap_weights
+    from mpboot_amd.rng import Lcg64
+    w = np.array([1, 0, 3, 2, 1], dtype=np.int32)
+    b = bootstrap_weights(w, Lcg64(5))
+    assert b.sum() == w.sum() and b[1] == 0
+    # the same draws, one at a time (alignment.cpp:1981-1990)
+    g = Lcg64(5)
+    site_pattern = np.repeat(np.arange(5), w)
+    exp = np.zeros(5, dtype=np.int64)
+    for d in g.doubles(int(w.sum())):
+        exp[site_pattern[int(np.floor(d * w.sum()))]] += 1
+    assert b.tolist() == exp.tolist()

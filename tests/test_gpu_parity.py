@@ -222,3 +222,26 @@ def test_compute_parsimony_dropin(mods, fx):
         rs, rptn = iqtree_fitch.compute_parsimony(states, fx["weights"], back, 4 if alpha == "DNA" else 20)
         assert score == t["score"] == rs
         assert (ptn == rptn).all()
+
+
+def test_bootstrap_replicates_match_oracle(mods, fx):
+    """re-weighted refinement climbs (optimizeBootTrees) and from-scratch searches per replicate"""
+    engine, po = mods[0], mods[1]
+    from mpboot_amd import bootstrap, shard
+    from mpboot_amd.rng import Lcg64
+    start = np.array(fx["spr"]["final_back"], dtype=np.int32)
+    for mode in ("refine", "search"):
+        e = eng_of(engine, fx)
+        scores, trs = bootstrap.run_replicates(e, fx["weights_np"], 3, 17, 6, start, mode)
+        for b in range(3):
+            seed = shard.unit_seed(17, b)
+            o = orc_of(po, fx)
+            o.set_weights(bootstrap.bootstrap_weights(fx["weights_np"], Lcg64(seed)))
+            o.seed_ties(po.TIE_RANDOM, seed)
+            if mode == "refine":
+                o.set_tree(start)
+                s = o.optimize_spr(1, 6)
+            else:
+                s = o.make_tree(seed, 6)[0]
+            assert s == scores[b]
+            assert (o.get_tree() == trs[b]).all()

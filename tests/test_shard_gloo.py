@@ -22,8 +22,9 @@ class OracleAsEngine:
         self.o = po.Oracle(codes)
     def seed_ties(self, mode, seed):
         self.o.seed_ties(mode, seed)
-    def make_parsimony_tree(self, seed, dist_):
+    def reset_node_order(self):
         self.o.reset_nodep()
+    def make_parsimony_tree(self, seed, dist_):
         return self.o.make_tree(seed, dist_)[0]
     def get_tree(self):
         return self.o.get_tree()
