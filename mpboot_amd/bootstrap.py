@@ -24,24 +24,46 @@ def bootstrap_weights(weights: np.ndarray, rng: Lcg64) -> np.ndarray:
     return np.bincount(site_pattern[draws], minlength=len(weights)).astype(np.int32)
 
 
+def _one_replicate(eng, weights, b, base_seed, radius, start_tree, mode):
+    seed = shard.unit_seed(base_seed, b)
+    w = bootstrap_weights(weights, Lcg64(seed))
+    eng.set_weights(w)
+    eng.seed_ties(1, seed)
+    eng.reset_node_order()          # every replicate starts from a fresh instance state: results do not depend on sharding
+    if mode == "refine":
+        eng.set_tree(start_tree)
+        s = eng.optimize_spr(1, radius)
+    else:
+        r = eng.make_parsimony_tree(seed, radius)
+        s = r[0] if isinstance(r, tuple) else r
+    return s, eng.get_tree()
+
+
 def run_replicates(eng, weights, n_rep: int, base_seed: int, radius: int = 6, start_tree=None, mode: str = "refine"):
     """mode "refine": SPR climb from start_tree on every re-weighted alignment (optimizeBootTrees);
     mode "search": randomized stepwise addition + SPR on every re-weighted alignment (standard bootstrap).
-    Returns (scores[n_rep] with INT_MAX for other ranks' units before reduction, trees dict)."""
+    `eng` may be a list of engines on the same GPU: replicates are then spread over one host thread per engine
+    (each engine has its own HIP stream; small alignments are launch-latency-bound, concurrent climbs fill the GPU).
+    Returns (scores[n_rep] after the all-reduce, {replicate: tree} of this rank's units)."""
     rank, ws = shard.world()
+    units = shard.units_of_rank(n_rep, rank, ws)
     local, trees = {}, {}
-    for b in shard.units_of_rank(n_rep, rank, ws):
-        seed = shard.unit_seed(base_seed, b)
-        w = bootstrap_weights(weights, Lcg64(seed))
-        eng.set_weights(w)
-        eng.seed_ties(1, seed)
-        eng.reset_node_order()          # every replicate starts from a fresh instance state: results do not depend on sharding
-        if mode == "refine":
-            eng.set_tree(start_tree)
-            local[b] = eng.optimize_spr(1, radius)
-        else:
-            r = eng.make_parsimony_tree(seed, radius)
-            local[b] = r[0] if isinstance(r, tuple) else r
-        trees[b] = eng.get_tree()
+    engines = eng if isinstance(eng, (list, tuple)) else [eng]
+    if len(engines) == 1:
+        for b in units:
+            local[b], trees[b] = _one_replicate(engines[0], weights, b, base_seed, radius, start_tree, mode)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(k):
+            out = {}
+            for b in units[k::len(engines)]:
+                out[b] = _one_replicate(engines[k], weights, b, base_seed, radius, start_tree, mode)
+            return out
+
+        with ThreadPoolExecutor(len(engines)) as ex:
+            for part in ex.map(work, range(len(engines))):
+                for b, (s, t) in part.items():
+                    local[b], trees[b] = s, t
     scores, _best, _owner = shard.reduce_best(local, n_rep)
     return scores, trees

@@ -13,6 +13,7 @@ ap.add_argument("--mode", default="refine", choices=["refine", "search"])
 ap.add_argument("--radius", type=int, default=6)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--cpu-replicates", type=int, default=0)
+ap.add_argument("--workers", type=int, default=1, help="engines (host threads, HIP streams) per GPU")
 a = ap.parse_args()
 
 import torch
@@ -38,13 +39,16 @@ if world > 1:
     dist.barrier()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-scores, trees = bootstrap.run_replicates(eng, w0, a.replicates, a.seed, a.radius, start, a.mode)
+engines = [eng] + [engine.FitchEngine(codes, datatype=dt, device=local_rank) for _ in range(a.workers - 1)]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+scores, trees = bootstrap.run_replicates(engines if a.workers > 1 else eng, w0, a.replicates, a.seed, a.radius, start, a.mode)
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
 dt_s = time.perf_counter() - t0
 if rank == 0:
-    res = {"workload": a.workload, "mode": a.mode, "replicates": a.replicates, "n_gpus": world, "seconds": dt_s,
+    res = {"workload": a.workload, "mode": a.mode, "replicates": a.replicates, "n_gpus": world, "workers": a.workers, "seconds": dt_s,
            "replicates_per_s": a.replicates / dt_s, "per_1000_replicates_s": 1000.0 * dt_s / a.replicates,
            "original_tree_score": int(best), "mean_replicate_score": float(np.mean(scores))}
     if a.cpu_replicates:
