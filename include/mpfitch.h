@@ -169,6 +169,15 @@ int mpf_stepwise_addition(mpf_engine *e, int64_t seed, uint32_t *best_per_step /
 int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t *insert_rec, uint32_t *score,
                   int32_t *n_moves);
 
+/* REPS -- resampling parsimony scores of candidate trees under B bootstrap weight vectors, the inner loop of
+   IQTree::saveCurrentTree (iqtree.cpp:3411-3449): rell[m][b] = -sum_ptn pattern_pars[m][ptn] * boot[b][ptn].
+   boot_samples_pars as IQTree::setParams builds them (iqtree.cpp:213-313), uploaded once; pattern_pars rows as
+   mpf_pattern_scores / mpf_compute_parsimony return them.  Exact 32-bit sums. */
+typedef struct mpf_reps mpf_reps;
+int mpf_reps_create(mpf_reps **out, int32_t device, int32_t n_samples, int32_t n_patterns, const uint16_t *boot /* [B][P] */);
+int mpf_reps_scores(mpf_reps *r, int32_t n_trees, const uint16_t *pattern_pars /* [M][P] */, int32_t *rell /* [M][B] */);
+void mpf_reps_destroy(mpf_reps *r);
+
 int mpf_get_stats(const mpf_engine *e, mpf_stats *out);
 int mpf_reset_stats(mpf_engine *e);
 /* tuning knobs: "scan_batch" (prune nodes speculated per launch), "words_per_lane" (1|2|4) */

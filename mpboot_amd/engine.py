@@ -24,7 +24,7 @@ EXPORTS = [
     "mpf_encode_iqtree_states", "mpf_seed_ties",
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
-    "mpf_set_option",
+    "mpf_set_option", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
 ]
 
 
@@ -89,6 +89,10 @@ def load_library():
         L.mpf_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mpf_reset_stats.argtypes = [vp]
         L.mpf_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.mpf_reps_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp]
+        L.mpf_reps_scores.argtypes = [vp, C.c_int32, vp, vp]
+        L.mpf_reps_destroy.argtypes = [vp]
+        L.mpf_reps_destroy.restype = None
         _lib = L
     return _lib
 
@@ -108,6 +112,35 @@ def encode_iqtree_states(states: np.ndarray, datatype: int = DNA) -> np.ndarray:
     out = np.zeros(states.shape, dtype=np.uint8)
     _chk(load_library().mpf_encode_iqtree_states(datatype, _p(states), states.size, _p(out)))
     return out
+
+
+class Reps:
+    """REPS contraction (IQTree::saveCurrentTree, iqtree.cpp:3411-3449): boot weights resident on the GPU."""
+
+    def __init__(self, boot: np.ndarray, device: int = 0):
+        boot = np.ascontiguousarray(boot, dtype=np.uint16)
+        self.B, self.P = boot.shape
+        h = C.c_void_p()
+        _chk(load_library().mpf_reps_create(C.byref(h), device, self.B, self.P, _p(boot)))
+        self.h = h
+
+    def scores(self, pattern_pars: np.ndarray) -> np.ndarray:
+        pp = np.ascontiguousarray(np.atleast_2d(pattern_pars), dtype=np.uint16)
+        assert pp.shape[1] == self.P
+        out = np.zeros((pp.shape[0], self.B), dtype=np.int32)
+        _chk(load_library().mpf_reps_scores(self.h, pp.shape[0], _p(pp), _p(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mpf_reps_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FitchEngine:

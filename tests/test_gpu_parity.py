@@ -245,3 +245,35 @@ def test_bootstrap_replicates_match_oracle(mods, fx):
                 s = o.make_tree(seed, 6)[0]
             assert s == scores[b]
             assert (o.get_tree() == trs[b]).all()
+
+
+def test_reps_contraction_exact(mods):
+    """K10: rell[m][b] = -sum_ptn pattern_pars[m][ptn] * boot[b][ptn] (iqtree.cpp:3411-3449), odd sizes included"""
+    engine = mods[0]
+    rng = np.random.default_rng(3)
+    for (M, B, P) in ((1, 7, 33), (5, 1000, 2001), (37, 130, 4096)):
+        pars = rng.integers(0, 400, size=(M, P)).astype(np.uint16)
+        boot = rng.integers(0, 9, size=(B, P)).astype(np.uint16)
+        boot[0, :5] = 65535
+        pars[0, :5] = 65535 if M > 1 else pars[0, :5]
+        r = engine.Reps(boot)
+        got = r.scores(pars)
+        exp = -(pars.astype(np.int64) @ boot.astype(np.int64).T)
+        assert (got.astype(np.int64) == (exp & 0xFFFFFFFF).astype(np.uint32).astype(np.int32).astype(np.int64)).all() or (got == exp).all()
+        r.close()
+
+
+def test_reps_of_real_pattern_scores(mods, fx):
+    """pattern scores of a tree x bootstrap resamples == the tree's length under each resample"""
+    engine, po = mods[0], mods[1]
+    from mpboot_amd import bootstrap
+    from mpboot_amd.rng import Lcg64
+    e = eng_of(engine, fx)
+    back = np.array(fx["trees"][0]["back"], dtype=np.int32)
+    score, ptn = e.compute_parsimony(back)
+    boots = np.stack([bootstrap.bootstrap_weights(fx["weights_np"], Lcg64(s)) for s in range(6)]).astype(np.uint16)
+    rell = engine.Reps(boots).scores(ptn)[0]
+    for b in range(6):
+        o = orc_of(po, fx)
+        o.set_weights(boots[b].astype(np.int32))
+        assert -rell[b] == o.score_tree(back)
