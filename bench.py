@@ -121,6 +121,7 @@ def main():
     codes = synth.letters_to_codes(letters, alphabet)
     n, P = codes.shape
     eng = engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
+    eng.set_option("timing", 1)                # HIP events around the kernels (roofline.achieved needs their duration)
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))

@@ -37,7 +37,6 @@ Engine::~Engine()
 {
   if (d_codes_) (void)hipFree(d_codes_);
   if (d_vec_) (void)hipFree(d_vec_);
-  if (d_cnt_) (void)hipFree(d_cnt_);
   if (d_tipslots_) (void)hipFree(d_tipslots_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -113,14 +112,13 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   HIPCHK(hipMalloc((void **)&d_codes_, (size_t)n_ * P_));
   HIPCHK(hipMemcpy(d_codes_, codes_.data(), (size_t)n_ * P_, hipMemcpyHostToDevice));
   nslots_ = (size_t)n_ + 3 * (size_t)(n_ - 1);
-  HIPCHK(hipMalloc((void **)&d_cnt_, nslots_ * sizeof(uint32_t)));
+  HIPCHK(reserve_results(4096));
   HIPCHK(hipMalloc((void **)&d_tipslots_, (size_t)n_ * sizeof(uint32_t)));
   {
     std::vector<uint32_t> ts(n_);
     for (int i = 0; i < n_; i++) ts[i] = (uint32_t)i;
     HIPCHK(hipMemcpy(d_tipslots_, ts.data(), n_ * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  HIPCHK(h_cnt_.reserve(nslots_));
   back_.assign(3 * (size_t)(2 * n_ - 1) + 3, -1);
   nodep_.assign(2 * (size_t)n_, 0);
   sc_.assign(back_.size(), 0);
@@ -393,41 +391,37 @@ int Engine::schedule_views(const std::vector<int> *roots)
     }
   }
   const size_t nops = order.size();
+  const bool full = roots == &all;
+  if (kids_host_.size() != nslots_) kids_host_.assign(nslots_, make_uint2(0u, 0u));
   if (kids_dirty_) {
     // topology for the device-walked scans: kids[cid] = the two records behind an inner record
-    if (kids_host_.size() != nslots_) kids_host_.assign(nslots_, make_uint2(0u, 0u));
     for (int r : *roots)
       if (r >= 0 && !tip(r)) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
     for (int r : order) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
-    HIPCHK(d_kids_.reserve(nslots_));
-    HIPCHK(hipMemcpyAsync(d_kids_.p, kids_host_.data(), nslots_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
-    if (roots == &all) kids_dirty_ = false;
-  }
-  if (nops == 0) {
-    if (roots == &all) { n_invalid_ = 0; views_valid_ = true; }
-    return MPF_OK;
   }
   int maxlev = 0;
   for (int r : order) maxlev = std::max(maxlev, lev_[r]);
-  HIPCHK(h_levoff_.reserve((size_t)maxlev + 2));
-  HIPCHK(d_levoff_.reserve((size_t)maxlev + 2));
-  int32_t *lo = h_levoff_.p;                 // lo[l-1]..lo[l] = ops of level l (levels are 1-based)
-  for (int l = 0; l <= maxlev; l++) lo[l] = 0;
-  for (int r : order) lo[lev_[r]]++;
-  {
+  // staging layout: [kids][ops][level offsets], one upload
+  const size_t kids_bytes = nslots_ * sizeof(uint2);
+  const size_t ops_off = (kids_bytes + 15) & ~(size_t)15;
+  const size_t lev_off_b = ops_off + ((nops * sizeof(NvOp) + 15) & ~(size_t)15);
+  const size_t total_b = lev_off_b + ((size_t)maxlev + 2) * sizeof(int32_t);
+  HIPCHK(h_vstage_.reserve(total_b));
+  HIPCHK(d_vstage_.reserve(total_b));
+  std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
+  NvOp *hops = reinterpret_cast<NvOp *>(h_vstage_.p + ops_off);
+  int32_t *lo = reinterpret_cast<int32_t *>(h_vstage_.p + lev_off_b);   // lo[0..maxlev]: offsets of levels 1..maxlev
+  if (nops) {
+    for (int l = 0; l <= maxlev + 1; l++) lo[l] = 0;
+    for (int r : order) lo[lev_[r]]++;
     int acc = 0;
     for (int l = 1; l <= maxlev; l++) { const int c = lo[l]; lo[l] = acc; acc += c; }
     lo[0] = 0;
-  }
-  // lo[l] now = start of level l (for l>=1); shift into [0..maxlev] = offsets, fill ops
-  HIPCHK(h_nvops_.reserve(nops));
-  HIPCHK(d_nvops_.reserve(nops));
-  {
     std::vector<int> fill(lo, lo + maxlev + 1);
     upd_order_.resize(nops);
     for (int r : order) {
       const int at = fill[lev_[r]]++;
-      NvOp &o = h_nvops_.p[at];
+      NvOp &o = hops[at];
       o.dst = slot(r);
       o.a = slot(back_[nx(r)]);
       o.b = slot(back_[nx(nx(r))]);
@@ -435,28 +429,36 @@ int Engine::schedule_views(const std::vector<int> *roots)
       upd_order_[(size_t)at] = r;
     }
     for (int l = 1; l <= maxlev; l++) lo[l - 1] = lo[l];
-    lo[maxlev] = (int32_t)nops;            // lo[0..maxlev]: offsets of levels 1..maxlev
+    lo[maxlev] = (int32_t)nops;
   }
+  if (kids_dirty_ || nops) {
+    const size_t up = nops ? total_b : kids_bytes;
+    HIPCHK(hipMemcpyAsync(d_vstage_.p, h_vstage_.p, up, hipMemcpyHostToDevice, st_));
+    if (full) kids_dirty_ = false;
+  }
+  if (nops == 0) {
+    if (full) { n_invalid_ = 0; views_valid_ = true; }
+    return MPF_OK;
+  }
+  const NvOp *dops = reinterpret_cast<const NvOp *>(d_vstage_.p + ops_off);
+  const int32_t *dlo = reinterpret_cast<const int32_t *>(d_vstage_.p + lev_off_b);
   const int tiles = tiles_for(g_);
   HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
-  HIPCHK(hipMemcpyAsync(d_nvops_.p, h_nvops_.p, nops * sizeof(NvOp), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipEventRecord(ev2_, st_));
+  if (timing_) HIPCHK(hipEventRecord(ev2_, st_));
   if (views_mode_ == 1) {
-    HIPCHK(hipMemcpyAsync(d_levoff_.p, lo, ((size_t)maxlev + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st_));
-    HIPCHK(launch_newview_levels(st_, g_, d_vec_, d_nvops_.p, d_levoff_.p, maxlev, d_cntp_.p, (uint32_t)nslots_));
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_));
     stats.view_launches++;
   } else {
     for (int l = 0; l < maxlev; l++) {
-      HIPCHK(launch_newview(st_, g_, d_vec_, d_nvops_.p + lo[l], lo[l + 1] - lo[l], d_cntp_.p, (uint32_t)nslots_));
+      HIPCHK(launch_newview(st_, g_, d_vec_, dops + lo[l], lo[l + 1] - lo[l], d_cntp_.p, (uint32_t)nslots_));
       stats.view_launches++;
     }
   }
-  HIPCHK(launch_cntsum(st_, g_, d_nvops_.p, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt_));
-  HIPCHK(hipEventRecord(ev3_, st_));
-  view_events_pending_ = true;
-  HIPCHK(hipMemcpyAsync(h_cnt_.p, d_cnt_, nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt()));
+  if (timing_) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
+  cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;
-  if (roots == &all) { n_invalid_ = 0; views_valid_ = true; }
+  if (full) { n_invalid_ = 0; views_valid_ = true; }
   else if (n_invalid_ > 0) { n_invalid_ -= (long)nops; if (n_invalid_ <= 0) { n_invalid_ = 0; views_valid_ = true; } }
   pending_scores_ = true;
   stats.newview_ops += nops;
@@ -477,7 +479,7 @@ void Engine::finish_views()
   for (int r : upd_order_) {
     const int a = back_[nx(r)], b = back_[nx(nx(r))];
     // weighted mode: parsimonyScore[p] is the node's own unweighted minimum sum only (reference :490, :544-548)
-    sc_[r] = sankoff_ ? h_cnt_.p[slot(r)] : h_cnt_.p[slot(r)] + (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]);
+    sc_[r] = sankoff_ ? h_cnt()[slot(r)] : h_cnt()[slot(r)] + (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]);
   }
   pending_scores_ = false;
 }
@@ -486,6 +488,10 @@ int Engine::update_views()
 {
   int rc = schedule_views(nullptr);
   if (rc) return rc;
+  if (cnt_copy_pending_) {
+    HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    cnt_copy_pending_ = false;
+  }
   HIPCHK(hipStreamSynchronize(st_));
   finish_views();
   return MPF_OK;
@@ -536,14 +542,13 @@ int Engine::tree_length(uint32_t *len)
   const int a = start_, b = back_[start_];
   EvOp op{slot(a), slot(b), 0, 0};
   HIPCHK(d_evops_.reserve(1));
-  HIPCHK(d_out_.reserve(1));
-  HIPCHK(h_out_.reserve(1));
+  HIPCHK(reserve_results(1));
   HIPCHK(hipMemcpyAsync(d_evops_.p, &op, sizeof(op), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(d_out_.p, 0, sizeof(uint32_t), st_));
-  HIPCHK(launch_evaluate(st_, g_, d_vec_, d_evops_.p, 1, d_out_.p));
-  HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(hipMemsetAsync(d_out(), 0, sizeof(uint32_t), st_));
+  HIPCHK(launch_evaluate(st_, g_, d_vec_, d_evops_.p, 1, d_out()));
+  HIPCHK(hipMemcpyAsync(h_out(), d_out(), sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   HIPCHK(hipStreamSynchronize(st_));
-  tree_len_ = sankoff_ ? h_out_.p[0] : (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]) + h_out_.p[0];
+  tree_len_ = sankoff_ ? h_out()[0] : (tip(a) ? 0u : sc_[a]) + (tip(b) ? 0u : sc_[b]) + h_out()[0];
   *len = tree_len_;
   return MPF_OK;
 }
@@ -636,19 +641,18 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   if (nh == 0 || nout == 0) { prog_ops_.clear(); prog_hdr_.clear(); prog_out_ = 0; prog_max_depth_ = 0; return MPF_OK; }
   HIPCHK(d_scanops_.reserve(nops));
   HIPCHK(d_scanhdr_.reserve(nh));
-  HIPCHK(d_out_.reserve(nout));
-  HIPCHK(h_out_.reserve(nout));
+  HIPCHK(reserve_results(nout));
   HIPCHK(hipMemcpyAsync(d_scanops_.p, prog_ops_.data(), nops * sizeof(ScanOp), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(d_scanhdr_.p, prog_hdr_.data(), nh * sizeof(ScanHdr), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(d_out_.p, 0, nout * sizeof(uint32_t), st_));
-  HIPCHK(hipEventRecord(ev0_, st_));
-  HIPCHK(launch_scan(st_, g_, d_vec_, d_scanhdr_.p, (int)nh, d_scanops_.p, d_out_.p, prog_max_depth_));
-  HIPCHK(hipEventRecord(ev1_, st_));
-  HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  HIPCHK(hipMemsetAsync(d_out(), 0, nout * sizeof(uint32_t), st_));
+  if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
+  HIPCHK(launch_scan(st_, g_, d_vec_, d_scanhdr_.p, (int)nh, d_scanops_.p, d_out(), prog_max_depth_));
+  if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
+  HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   HIPCHK(hipStreamSynchronize(st_));
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
-  std::copy(h_out_.p, h_out_.p + nout, out_host.begin());
+  if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+  std::copy(h_out(), h_out() + nout, out_host.begin());
   stats.scan_launches++;
   stats.insertion_tests += nout;
   stats.algorithmic_bytes += (uint64_t)nout * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
@@ -786,24 +790,35 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(d_walk_.reserve(nd));
     HIPCHK(d_ncand_.reserve(nd));
     HIPCHK(h_ncand_.reserve(nd));
-    HIPCHK(d_out_.reserve(nout));
-    HIPCHK(h_out_.reserve(nout));
+    HIPCHK(reserve_results(nout));
     HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_));
-    HIPCHK(hipMemsetAsync(d_out_.p, 0, nout * sizeof(uint32_t), st_));
-    HIPCHK(hipEventRecord(ev0_, st_));
-    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids_.p, n_, d_walk_.p, (int)nd, d_out_.p, d_ncand_.p, maxd));
-    HIPCHK(hipEventRecord(ev1_, st_));
-    if (nout) HIPCHK(hipMemcpyAsync(h_out_.p, d_out_.p, nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipMemsetAsync(d_out(), 0, (nout ? nout : 1) * sizeof(uint32_t), st_));
+    if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
+    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, d_walk_.p, (int)nd, d_out(), d_ncand_.p, maxd));
+    if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
+    // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
+    if (cnt_copy_pending_) {
+      HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (nslots_ + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+      cnt_copy_pending_ = false;
+    } else if (nout) {
+      HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    }
     if (check_counts_) HIPCHK(hipMemcpyAsync(h_ncand_.p, d_ncand_.p, nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
     HIPCHK(hipStreamSynchronize(st_));
     if (check_counts_)
       for (size_t i = 0; i < nd; i++)
         if (h_ncand_.p[i] != h_walk_.p[i].pad0) { set_error("device/host candidate count mismatch"); return MPF_E_STATE; }
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+    if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
     stats.scan_launches++;
   }
-  else if (pending_scores_) HIPCHK(hipStreamSynchronize(st_));
+  else if (pending_scores_) {
+    if (cnt_copy_pending_) {
+      HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+      cnt_copy_pending_ = false;
+    }
+    HIPCHK(hipStreamSynchronize(st_));
+  }
   finish_views();
   uint64_t tests = 0;
   for (ScanPlan &pl : plans) {
@@ -813,7 +828,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
   }
   stats.insertion_tests += tests;
   stats.algorithmic_bytes += tests * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
-  *out_host = h_out_.p;
+  *out_host = h_out();
   n_walk_ = 0;
   walk_out_ = 0;
   return MPF_OK;
@@ -976,6 +991,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "views_mode") { views_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "timing") { timing_ = v ? 1 : 0; return MPF_OK; }
   set_error("unknown option " + key);
   return MPF_E_INVALID;
 }

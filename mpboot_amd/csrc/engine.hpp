@@ -11,6 +11,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mpfitch.h"
@@ -178,17 +179,52 @@ class Engine {
   hipStream_t st_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev2_ = nullptr, ev3_ = nullptr;
   uint8_t *d_codes_ = nullptr;
-  uint32_t *d_vec_ = nullptr, *d_cnt_ = nullptr, *d_tipslots_ = nullptr;
+  uint32_t *d_vec_ = nullptr, *d_tipslots_ = nullptr;
+  // results buffer: [cnt: nslots][out: ...] so that one copy brings back both
+  DevBuf<uint32_t> d_res_;
+  PinBuf<uint32_t> h_res_;
+  // refresh staging: [kids: nslots x 8 B][ops][level offsets] uploaded with ONE copy
+  DevBuf<uint8_t> d_vstage_;
+  PinBuf<uint8_t> h_vstage_;
+  bool cnt_copy_pending_ = false;
+  int timing_ = 0;                               // 1 = bracket kernels with HIP events (bench / profiling)
+  uint32_t *d_cnt() { return d_res_.p; }
+  uint32_t *d_out() { return d_res_.p + nslots_; }
+  uint32_t *h_cnt() { return h_res_.p; }
+  uint32_t *h_out() { return h_res_.p + nslots_; }
+  hipError_t reserve_results(size_t nout)
+  {
+    const size_t need = nslots_ + nout;
+    if (need > d_res_.cap) {
+      // grow without losing the mutation counts a pending refresh has already written to the head of the buffer
+      DevBuf<uint32_t> bigger;
+      hipError_t e = bigger.reserve(need + need / 2);
+      if (e != hipSuccess) return e;
+      if (d_res_.p && cnt_copy_pending_) {
+        e = hipMemcpyAsync(bigger.p, d_res_.p, nslots_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, st_);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st_);
+        if (e != hipSuccess) return e;
+      }
+      std::swap(bigger.p, d_res_.p);
+      std::swap(bigger.cap, d_res_.cap);
+    }
+    if (need > h_res_.cap) {
+      PinBuf<uint32_t> bigger;
+      hipError_t e = bigger.reserve(need + need / 2);
+      if (e != hipSuccess) return e;
+      std::swap(bigger.p, h_res_.p);
+      std::swap(bigger.cap, h_res_.cap);
+    }
+    return hipSuccess;
+  }
   DevBuf<int32_t> d_site2ptn_;
-  DevBuf<NvOp> d_nvops_;
   DevBuf<EvOp> d_evops_;
   DevBuf<ScanOp> d_scanops_;
   DevBuf<ScanHdr> d_scanhdr_;
-  DevBuf<uint32_t> d_out_, d_ncand_;
-  DevBuf<uint2> d_kids_;
+  DevBuf<uint32_t> d_ncand_;
   DevBuf<uint32_t> d_cntp_;
-  DevBuf<int32_t> d_levoff_;
-  PinBuf<int32_t> h_levoff_;
+  const uint2 *d_kids() const { return reinterpret_cast<const uint2 *>(d_vstage_.p); }
   std::vector<uint8_t> valid_;
   std::vector<int32_t> lev_, lev_epoch_;
   int32_t epoch_ = 0;
@@ -199,7 +235,7 @@ class Engine {
   int views_mode_ = 1;                          // 1 = all levels in one launch, 0 = one launch per level
   std::vector<uint2> kids_host_;
   DevBuf<WalkDesc> d_walk_;
-  PinBuf<uint32_t> h_cnt_, h_out_, h_ncand_;
+  PinBuf<uint32_t> h_ncand_;
   PinBuf<WalkDesc> h_walk_;
   size_t n_walk_ = 0;
   uint32_t walk_out_ = 0;
@@ -214,7 +250,6 @@ class Engine {
   int check_counts_ = 0;                         // 1 = copy the kernel's own candidate counts back and compare
   PinBuf<ScanOp> h_scanops_;
   PinBuf<ScanHdr> h_scanhdr_;
-  PinBuf<NvOp> h_nvops_;
 
   // staging program being built
   std::vector<ScanOp> prog_ops_;

@@ -277,3 +277,25 @@ def test_reps_of_real_pattern_scores(mods, fx):
         o = orc_of(po, fx)
         o.set_weights(boots[b].astype(np.int32))
         assert -rell[b] == o.score_tree(back)
+
+
+def test_long_climb_from_random_tree_matches_oracle(mods):
+    """hundreds of accepted moves, growing speculative batches, incremental view refreshes (buffers regrow mid-climb)"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(260, 1800, "DNA", 0.07, seed=21)
+    codes = synth.letters_to_codes(letters)
+    back = trees.random_topology(260, np.random.default_rng(4))
+    for opts in (dict(), dict(scan_batch=4), dict(scan_batch=256, split_below=0)):
+        e = engine.FitchEngine(codes)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        o = po.Oracle(codes)
+        e.set_tree(back)
+        o.set_tree(back)
+        e.seed_ties(engine.TIE_RANDOM, 6)
+        o.seed_ties(po.TIE_RANDOM, 6)
+        o.trace(True)
+        assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+        assert len(e.moves()[0]) > 300
+        assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+        assert (e.get_tree() == o.get_tree()).all()

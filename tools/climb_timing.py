@@ -18,6 +18,7 @@ letters, names = synth.workload(a.workload)
 codes = synth.letters_to_codes(letters, cfg["alphabet"])
 dt = engine.DNA if cfg["alphabet"] == "DNA" else engine.AA
 e = engine.FitchEngine(codes, datatype=dt)
+e.set_option("timing", 0)
 for kv in a.opt:
     k, v = kv.split("="); e.set_option(k, int(v))
 e.seed_ties(engine.TIE_RANDOM, a.seed)
