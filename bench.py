@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--start-tree", default="ras", choices=["ras", "random"])
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    ap.add_argument("--bootstrap-replicates", type=int, default=48,
+                    help="per GPU: re-weighted refinement climbs timed after the main metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +158,24 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
 
+    # second half of BASELINE.json's metric ("bootstrap wall-clock"): bootstrap-refinement replicates
+    # (IQTree::optimizeBootTrees: re-weight, re-pack, one SPR climb from the best tree), sharded over the ranks
+    boot = None
+    if args.bootstrap_replicates > 0:
+        from mpboot_amd import bootstrap
+        n_rep = args.bootstrap_replicates * world
+        engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
+                           for _ in range(3)]
+        w0 = np.ones(P, dtype=np.int32)
+        bootstrap.run_replicates(engines, w0, 4 * world, 999, args.maxtrav, back, "refine")      # warm-up
+        barrier()
+        tb0 = time.perf_counter()
+        bscores, _ = bootstrap.run_replicates(engines, w0, n_rep, 7, args.maxtrav, back, "refine")
+        barrier()
+        tb = time.perf_counter() - tb0
+        boot = (n_rep, tb, float(np.mean(bscores)))
+        eng.set_weights(w0)
+
     tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
@@ -217,6 +237,28 @@ def main():
                                  "scan": st["host_scan_ms_total"] / args.steps,
                                  "sweep_call": st["host_sweep_ms_total"] / args.steps},
         }
+        if boot is not None:
+            res["bootstrap_wall_clock"] = {
+                "replicates": boot[0], "seconds": boot[1], "per_1000_replicates_s": 1000.0 * boot[1] / boot[0],
+                "mean_replicate_score": boot[2], "engines_per_gpu": 4,
+                "what": "bootstrap-refinement replicates (optimizeBootTrees): multinomial re-weighting, tips re-packed on the "
+                        "device, one SPR hill climb (radius %d) from the start tree; replicate b on rank b %% n_gpus" % args.maxtrav}
+        if boot is not None and not args.no_cpu and world == 1:
+            # CPU side of the same replicate work: the scalar C port (oracle) on replicate 0, one thread
+            from mpboot_amd import bootstrap, shard
+            from mpboot_amd.rng import Lcg64
+            from oracle import pyoracle as po
+            o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
+            tc0 = time.perf_counter()
+            seed0 = shard.unit_seed(7, 0)
+            o.set_weights(bootstrap.bootstrap_weights(np.ones(P, dtype=np.int32), Lcg64(seed0)))
+            o.seed_ties(po.TIE_RANDOM, seed0)
+            o.set_tree(back)
+            s_cpu = o.optimize_spr(1, args.maxtrav)
+            tc = time.perf_counter() - tc0
+            res["bootstrap_wall_clock"]["cpu_baseline"] = {
+                "per_1000_replicates_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "replicate 0 on the scalar C oracle",
+                "same_score_as_gpu": bool(int(bscores[0]) == int(s_cpu))}
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(codes, back, names, letters, alphabet, args.maxtrav, args.cpu_budget)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
