@@ -209,6 +209,11 @@ int Engine::pack()
     if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
     g_.Wp = wp;
     vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
+    if (vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) {
+      // the scan kernel addresses the vector store through one raw buffer with 32-bit offsets
+      set_error("taxa x sites too large: the directional-vector store would exceed 2 GiB");
+      return MPF_E_UNSUPPORTED;
+    }
     HIPCHK(hipMalloc((void **)&d_vec_, vec_words_ * sizeof(uint32_t)));
   }
   std::vector<int32_t> s2p((size_t)std::max(nsites_, 1));

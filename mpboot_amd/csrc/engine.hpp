@@ -239,7 +239,6 @@ class Engine {
   PinBuf<WalkDesc> h_walk_;
   size_t n_walk_ = 0;
   uint32_t walk_out_ = 0;
-  bool back_on_device_ = false;
   int scan_mode_ = 1;                           // 1 = device-walked scans, 0 = host-planned programs
   std::vector<uint32_t> out_scratch_;
   std::vector<ScanPlan> sweep_plans_;
@@ -248,8 +247,6 @@ class Engine {
   int32_t topo_epoch_ = 1;
   int count_visits(int q, int m);
   int check_counts_ = 0;                         // 1 = copy the kernel's own candidate counts back and compare
-  PinBuf<ScanOp> h_scanops_;
-  PinBuf<ScanHdr> h_scanhdr_;
 
   // staging program being built
   std::vector<ScanOp> prog_ops_;

@@ -103,7 +103,9 @@ __device__ __forceinline__ uint32_t b3_fitch(uint32_t a, uint32_t b, uint32_t an
 
 // c = fitch(a, b); returns the number of sites of this lane's words whose intersection is empty.
 // any = OR_k(a_k & b_k) as an and-or chain, then c_k = any ? a_k & b_k : a_k | b_k: 2 ops per state.
-template <int S, int VW>
+// SPLIT: the states of a word are spread over lanes l and l^32 (protein: 10 + 10), the two partial `any`
+// words are exchanged across the wave halves.
+template <int S, int VW, bool SPLIT = false>
 __device__ __forceinline__ uint32_t fitch(Tile<S, VW> &c, const Tile<S, VW> &a, const Tile<S, VW> &b)
 {
   uint32_t cost = 0;
@@ -112,6 +114,7 @@ __device__ __forceinline__ uint32_t fitch(Tile<S, VW> &c, const Tile<S, VW> &a, 
     uint32_t any = a.v[0][j] & b.v[0][j];
 #pragma unroll
     for (int k = 1; k < S; k++) any = b3_andor(a.v[k][j], b.v[k][j], any);
+    if constexpr (SPLIT) any |= (uint32_t)__shfl_xor((int)any, 32, 64);
 #pragma unroll
     for (int k = 0; k < S; k++) c.v[k][j] = b3_fitch(a.v[k][j], b.v[k][j], any);
     cost += (uint32_t)__builtin_popcount(~any);
@@ -136,7 +139,7 @@ __device__ __forceinline__ uint32_t empty_count(const Tile<S, VW> &a, const Tile
 
 // cost of joining subtree vector s onto the node x = fitch(u, d):  popcount(~OR_k(x_k & s_k)),
 // x_k formed in registers and consumed at once (3 ops per state + 2)
-template <int S, int VW>
+template <int S, int VW, bool SPLIT = false>
 __device__ __forceinline__ uint32_t join_cost(const Tile<S, VW> &u, const Tile<S, VW> &d, const Tile<S, VW> &s)
 {
   uint32_t cost = 0;
@@ -145,9 +148,11 @@ __device__ __forceinline__ uint32_t join_cost(const Tile<S, VW> &u, const Tile<S
     uint32_t any = u.v[0][j] & d.v[0][j];
 #pragma unroll
     for (int k = 1; k < S; k++) any = b3_andor(u.v[k][j], d.v[k][j], any);
+    if constexpr (SPLIT) any |= (uint32_t)__shfl_xor((int)any, 32, 64);
     uint32_t hit = b3_fitch(u.v[0][j], d.v[0][j], any) & s.v[0][j];
 #pragma unroll
     for (int k = 1; k < S; k++) hit = b3_andor(b3_fitch(u.v[k][j], d.v[k][j], any), s.v[k][j], hit);
+    if constexpr (SPLIT) hit |= (uint32_t)__shfl_xor((int)hit, 32, 64);
     cost += (uint32_t)__builtin_popcount(~hit);
   }
   return cost;
@@ -514,7 +519,9 @@ __device__ __forceinline__ void load_tile_b(Tile<S, VW> &t, __amdgpu_buffer_rsrc
   }
 }
 
-template <int S, int VW, int MAXD, int RED>
+// S = states held per lane.  SPLIT (protein): lanes l and l^32 share a word and hold states 0..9 / 10..19, a
+// wave covers 32 words; this keeps the protein kernel at DNA-like register counts instead of one wave per SIMD.
+template <int S, int VW, int MAXD, int RED, bool SPLIT = false>
 __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                    uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
@@ -554,17 +561,26 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
   // child_mask the first-level children whose candidate and subtree this part owns
   const uint32_t side_mask = (de.trav >> 16) & 3u, child_mask = (de.trav >> 18) & 3u;
   bool valid;
-  const uint32_t w0 = (uint32_t)lane_word<VW>(tile, lane, Wp, valid);
-  const uint32_t SW = (uint32_t)S * (uint32_t)Wp;
+  uint32_t w0, row0 = 0;
+  if constexpr (SPLIT) {
+    const int w = tile * 32 + (lane & 31);
+    valid = w < Wp && lane < 32;                         // the low half counts a word's mutations once
+    w0 = (uint32_t)(w < Wp ? w : Wp - 1);
+    row0 = (uint32_t)(lane >> 5) * (uint32_t)S;
+  } else {
+    w0 = (uint32_t)lane_word<VW>(tile, lane, Wp, valid);
+  }
+  constexpr uint32_t ST = SPLIT ? 2u * (uint32_t)S : (uint32_t)S;    // states per vector
+  const uint32_t SW = ST * (uint32_t)Wp;
   // the whole vector array as one raw buffer (< 4 GiB, checked by the host): loads take a scalar byte
   // offset (vector) plus a per-lane byte offset (row, word)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vec, 0, 0x7FFFFFFF, 0x00020000);
   uint32_t voff[S];
 #pragma unroll
-  for (int k = 0; k < S; k++) voff[k] = (w0 + (uint32_t)k * (uint32_t)Wp) * 4u;
+  for (int k = 0; k < S; k++) voff[k] = (w0 + (row0 + (uint32_t)k) * (uint32_t)Wp) * 4u;
 #define MPF_LOAD(T, cid)                                                                       \
   do {                                                                                         \
-    if constexpr (S == 4) load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);        \
+    if constexpr (S <= 10) load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);       \
     else load_tile_u<S, VW>(T, vec + (size_t)((uint32_t)(cid) * SW), w0, Wp);                  \
   } while (0)
 
@@ -608,11 +624,11 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
       const uint32_t dd = d + 1;
       const bool test = dd >= mintrav;
       const bool deeper = dd < maxtrav;
-      fitch<S, VW>(u1, par, d2);
-      fitch<S, VW>(u2, par, d1);
+      fitch<S, VW, SPLIT>(u1, par, d2);
+      fitch<S, VW, SPLIT>(u2, par, d1);
       uint32_t tot = 0;
       if (test) {
-        uint32_t cost = join_cost<S, VW>(u1, d1, sv) | (join_cost<S, VW>(u2, d2, sv) << 16);
+        uint32_t cost = join_cost<S, VW, SPLIT>(u1, d1, sv) | (join_cost<S, VW, SPLIT>(u2, d2, sv) << 16);
         cost = valid ? cost : 0u;
         tot = wave_total<RED>(cost);
       }
@@ -1028,24 +1044,25 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 {
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;
-  const int tiles = tiles_of(g);
+  const bool split = g.S == 20;                                    // protein: states split over the wave halves
+  const int tiles = split ? (g.Wp + 31) / 32 : tiles_of(g);
   const long waves = (long)n_scans * tiles;
   dim3 block(256);
   unsigned nblocks;
   if (g.map == 0) nblocks = (unsigned)((waves + 3) / 4);
   else { const long chunk = (waves + 7) / 8; nblocks = (unsigned)(((chunk + 3) / 4) * 8); }
   dim3 grid(nblocks);
-#define SW(S_, VW_, MAXD_, RED_) \
-  hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc, n_scans, out, ncand, g.Wp, tiles, g.map)
-#define SW2(S_, VW_, dummy)                                                                  \
-  do {                                                                                       \
-    if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0); else SW(S_, VW_, 6, 1); }    \
-    else { if (g.reduce == 0) SW(S_, VW_, 12, 0); else SW(S_, VW_, 12, 1); }                 \
+#define SW(S_, VW_, MAXD_, RED_, SPLIT_) \
+  hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc, n_scans, out, ncand, g.Wp, tiles, g.map)
+#define SW2(S_, VW_, SPLIT_)                                                                                 \
+  do {                                                                                                       \
+    if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0, SPLIT_); else SW(S_, VW_, 6, 1, SPLIT_); }    \
+    else { if (g.reduce == 0) SW(S_, VW_, 12, 0, SPLIT_); else SW(S_, VW_, 12, 1, SPLIT_); }                 \
   } while (0)
   if (g.S == 4) {
-    if (g.vw == 1) SW2(4, 1, 0); else SW2(4, 2, 0);
+    if (g.vw == 1) SW2(4, 1, false); else SW2(4, 2, false);
   } else {
-    SW2(20, 1, 0);
+    SW2(10, 1, true);
   }
 #undef SW2
 #undef SW
