@@ -653,8 +653,14 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
   HIPCHK(launch_scan(st_, g_, d_vec_, d_scanhdr_.p, (int)nh, d_scanops_.p, d_out(), prog_max_depth_));
   if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
-  HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  if (cnt_copy_pending_) {     // a refresh was enqueued just before: bring its mutation counts back in the same copy
+    HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (nslots_ + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    cnt_copy_pending_ = false;
+  } else {
+    HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  }
   HIPCHK(hipStreamSynchronize(st_));
+  finish_views();
   float ms = 0;
   if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
   std::copy(h_out(), h_out() + nout, out_host.begin());

@@ -152,6 +152,14 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
   std::vector<ScanPlan> plans(1);
   std::vector<uint32_t> out;
   std::vector<int> stack;
+  std::vector<uint32_t> out_of(back_.size(), 0u);
+  // length of the three-taxon tree; afterwards the length of the tree built so far is the best score of the
+  // previous addition (Fitch/Sankoff length of the tree with the tip inserted IS that candidate's score)
+  uint32_t len = 0;
+  {
+    int rc = tree_length(&len);
+    if (rc) return rc;
+  }
   while (ntips_ < n) {
     best_ = (uint32_t)INT_MAX;
     const int nextsp = ++ntips_;
@@ -159,13 +167,11 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     const int q = nodep_[nextnode_++];
     back_[p] = q;
     back_[q] = p;
-    // views + length of the tree built so far (the new tip is not part of it yet)
-    uint32_t len = 0;
-    int rc = tree_length(&len);
+    // refresh the views of the tree built so far (asynchronously), score the insertion on EVERY branch in
+    // the same submission, and apply the reference's descent cut (:3014) afterwards on the host: one
+    // synchronisation per added taxon
+    int rc = schedule_views(nullptr);
     if (rc) return rc;
-    // candidate branches in the reference's DFS order with its descent cut (:3014)
-    ScanPlan &pl = plans[0];
-    pl.cands.clear();
     stack.clear();
     stack.push_back(back_[f]);
     while (!stack.empty()) {
@@ -176,9 +182,9 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
       o.sib = slot(back_[c]);
       o.meta = (uint32_t)SCAN_JOIN << 16;
       o.out = prog_out_;
+      out_of[(size_t)c] = prog_out_++;
       prog_ops_.push_back(o);
-      pl.cands.push_back(Candidate{c, prog_out_++});
-      if (!tip(c) && sc_[c] > 0) {
+      if (!tip(c)) {
         stack.push_back(back_[nx(nx(c))]);
         stack.push_back(back_[nx(c)]);
       }
@@ -195,14 +201,24 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     }
     rc = run_scans(plans, out);
     if (rc) return rc;
-    for (const Candidate &c : pl.cands) {
-      const uint32_t mp = (sankoff_ ? 0u : len) + out[c.out];   // weighted: the join kernel returns the full length
+    // candidate branches in the reference's DFS order with its descent cut
+    stack.clear();
+    stack.push_back(back_[f]);
+    while (!stack.empty()) {
+      const int c = stack.back();
+      stack.pop_back();
+      const uint32_t mp = (sankoff_ ? 0u : len) + out[out_of[(size_t)c]];   // weighted: the join kernel returns the full length
       if (tie_mode_ == MPF_TIE_RANDOM) {
         if (mp < best_) hits_ = 1;
         else if (mp == best_) hits_++;
-        if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; insert_rec_ = c.q; }
-      } else if (mp < best_) { best_ = mp; insert_rec_ = c.q; }
+        if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; insert_rec_ = c; }
+      } else if (mp < best_) { best_ = mp; insert_rec_ = c; }
+      if (!tip(c) && sc_[c] > 0) {
+        stack.push_back(back_[nx(nx(c))]);
+        stack.push_back(back_[nx(c)]);
+      }
     }
+    len = best_;
     if (best_per_step) best_per_step[nextsp] = best_;
     if (insert_per_step) insert_per_step[nextsp] = insert_rec_;
     const int r = back_[insert_rec_];
