@@ -12,7 +12,7 @@ struct mpf_engine {
 
 using mpf::set_error;
 
-#define NEED(e) do { if (!(e)) { set_error("null engine handle"); return MPF_E_INVALID; } } while (0)
+#define NEED(e) do { if (!(e)) { set_error("null engine handle"); return MPF_E_INVALID; } (e)->eng.activate(); } while (0)
 
 extern "C" {
 
@@ -44,7 +44,11 @@ int mpf_engine_create_sankoff(mpf_engine **out, const mpf_config *cfg, const uin
   return MPF_OK;
 }
 
-void mpf_engine_destroy(mpf_engine *e) { delete e; }
+void mpf_engine_destroy(mpf_engine *e)
+{
+  if (e) e->eng.activate();
+  delete e;
+}
 
 int mpf_set_weights(mpf_engine *e, const int32_t *weights)
 {

@@ -97,6 +97,8 @@ class Engine {
   // ---- alignment
   int set_weights(const int32_t *weights);
   int tip_vector(int tip, uint32_t *out);
+  // HIP's current device is per host thread: every entry point re-selects the engine's device first
+  void activate() const { (void)hipSetDevice(dev_); }
   int n() const { return n_; }
   int P() const { return P_; }
   int S() const { return g_.S; }
