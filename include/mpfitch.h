@@ -169,6 +169,29 @@ int mpf_stepwise_addition(mpf_engine *e, int64_t seed, uint32_t *best_per_step /
 int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t *insert_rec, uint32_t *score,
                   int32_t *n_moves);
 
+/* Online UFBoot-MP bookkeeping -- what IQTree::saveCurrentTree (iqtree.cpp:3271-3785, default options) does when
+   testInsertParsimony calls it after EVERY insertion test of pllOptimizeSprParsimony (sprparsimony.cpp:2163-2166,
+   perSiteScores = gbo_replicates > 0, :3245).  With a tracker attached, mpf_optimize_spr additionally
+     - applies the logl_cutoff filter (:3343) and appends the candidate's score to treels_logl (:3345-3348),
+     - computes its REPS against all n_samples weight vectors on the device (ufboot.hip),
+     - applies the per-sample update rule (:3684-3731) in the reference's order, drawing its tie-breaks from the same
+       random stream as the SPR tie-breaks (mpf_seed_ties / mpf_set_rand_callback).
+   samples = boot_samples_pars (iqtree.cpp:213-313), [n_samples][n_patterns] uint16.  epsilon = params->ufboot_epsilon
+   (0.5, tools.cpp:725); any value in (0, 1) is equivalent for integer scores, others are MPF_E_UNSUPPORTED.
+   Fitch mode only.  mpf_set_weights detaches the tracker. */
+int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples, double epsilon);
+int mpf_ufboot_detach(mpf_engine *e);
+int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff);            /* IQTree::logl_cutoff; 0 = none */
+/* the main loop's per-iteration cut-off update, "top percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10) */
+int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff);
+int mpf_ufboot_num_trees(const mpf_engine *e, int64_t *n_trees);         /* treels_logl.size() */
+int mpf_ufboot_tree_logl(const mpf_engine *e, double *out /* [n_trees] */);
+/* boot_logl / boot_counts / boot_trees (any may be NULL) */
+int mpf_ufboot_get_state(const mpf_engine *e, double *boot_logl, int32_t *boot_counts, int32_t *boot_trees);
+/* topology of a tree some sample currently points to (boot_trees[b]), as back[] */
+int mpf_ufboot_get_tree(const mpf_engine *e, int64_t tree_index, int32_t *back);
+int mpf_ufboot_get_counters(const mpf_engine *e, uint64_t *tie_draws, uint64_t *events, uint64_t *reps_rows, double *reps_kernel_ms);
+
 /* REPS -- resampling parsimony scores of candidate trees under B bootstrap weight vectors, the inner loop of
    IQTree::saveCurrentTree (iqtree.cpp:3411-3449): rell[m][b] = -sum_ptn pattern_pars[m][ptn] * boot[b][ptn].
    boot_samples_pars as IQTree::setParams builds them (iqtree.cpp:213-313), uploaded once; pattern_pars rows as

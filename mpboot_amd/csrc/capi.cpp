@@ -206,6 +206,47 @@ int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t
   return MPF_OK;
 }
 
+int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples, double epsilon)
+{
+  NEED(e);
+  return e->eng.ufboot_attach(n_samples, samples, epsilon);
+}
+int mpf_ufboot_detach(mpf_engine *e) { NEED(e); e->eng.ufboot_detach(); return MPF_OK; }
+int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff) { NEED(e); return e->eng.ufboot_set_cutoff(logl_cutoff); }
+int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff)
+{
+  NEED(e);
+  if (!logl_cutoff || percent < 0 || percent > 100) { set_error("mpf_ufboot_next_cutoff: bad argument"); return MPF_E_INVALID; }
+  if (!e->eng.ufboot_attached()) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  *logl_cutoff = e->eng.ufboot_next_cutoff(percent);
+  return MPF_OK;
+}
+int mpf_ufboot_num_trees(const mpf_engine *e, int64_t *n_trees)
+{
+  NEED(e);
+  if (!n_trees) { set_error("null output"); return MPF_E_INVALID; }
+  if (!e->eng.ufboot_attached()) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  *n_trees = e->eng.ufboot_n_trees();
+  return MPF_OK;
+}
+int mpf_ufboot_tree_logl(const mpf_engine *e, double *out) { NEED(e); if (!out) { set_error("null output"); return MPF_E_INVALID; } return e->eng.ufboot_tree_logl(out); }
+int mpf_ufboot_get_state(const mpf_engine *e, double *boot_logl, int32_t *boot_counts, int32_t *boot_trees)
+{
+  NEED(e);
+  return e->eng.ufboot_state(boot_logl, boot_counts, boot_trees);
+}
+int mpf_ufboot_get_tree(const mpf_engine *e, int64_t tree_index, int32_t *back)
+{
+  NEED(e);
+  if (!back) { set_error("null output"); return MPF_E_INVALID; }
+  return e->eng.ufboot_tree(tree_index, back);
+}
+int mpf_ufboot_get_counters(const mpf_engine *e, uint64_t *tie_draws, uint64_t *events, uint64_t *reps_rows, double *reps_kernel_ms)
+{
+  NEED(e);
+  return e->eng.ufboot_counters(tie_draws, events, reps_rows, reps_kernel_ms);
+}
+
 int mpf_get_stats(const mpf_engine *e, mpf_stats *out) { NEED(e); *out = e->eng.stats; return MPF_OK; }
 int mpf_reset_stats(mpf_engine *e) { NEED(e); e->eng.stats = mpf_stats{}; return MPF_OK; }
 

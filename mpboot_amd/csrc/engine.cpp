@@ -231,6 +231,7 @@ int Engine::pack()
 int Engine::set_weights(const int32_t *weights)
 {
   wgt_.assign(weights, weights + P_);
+  ufboot_detach();                               // the sample weights are laid out by site position: re-attach after re-weighting
   return pack();
 }
 
@@ -753,7 +754,7 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
     plan.part_cnt[plan.n_parts] = count;
     plan.n_parts++;
     plan.n_total += count;
-    walk_out_ += (uint32_t)count;
+    walk_out_ += (uint32_t)count + (scan_masks_ ? 1u : 0u);     // masked scans: one extra slot per part (home edge)
     n_walk_++;
   };
   auto phase = [&](int x, int mt) {
@@ -805,7 +806,16 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_));
     HIPCHK(hipMemsetAsync(d_out(), 0, (nout ? nout : 1) * sizeof(uint32_t), st_));
     if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
-    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, d_walk_.p, (int)nd, d_out(), d_ncand_.p, maxd));
+    uint32_t *mask_ptr = nullptr;
+    uint2 *info_ptr = nullptr;
+    if (scan_masks_) {
+      int rc = ufb_reserve_scan(nout);
+      if (rc) return rc;
+      mask_ptr = ufb_->masks.p;
+      info_ptr = ufb_->info.p;
+      ufb_rows_ = (uint32_t)nout;
+    }
+    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, d_walk_.p, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr));
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
     if (cnt_copy_pending_) {

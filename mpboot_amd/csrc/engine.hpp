@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -17,6 +19,7 @@
 #include "../../include/mpfitch.h"
 #include "../host/rng.hpp"
 #include "kernels.hpp"
+#include "ufboot.hpp"
 
 namespace mpf {
 
@@ -88,6 +91,36 @@ struct ScanPlan {
 
 struct Move { int32_t remove_rec, insert_rec; uint32_t score; };
 
+// online UFBoot-MP: the arrays IQTree keeps per bootstrap sample (iqtree.cpp:213-262) plus the device buffers of
+// the masked scan, the REPS product and the event extraction (ufboot.hip)
+struct UfbState {
+  int B = 0, Bp = 0, planes = 1;
+  double eps = 0.5;                              // params->ufboot_epsilon (tools.cpp:725)
+  double logl_cutoff = 0.0;                      // IQTree::logl_cutoff, 0 = none (iqtree.cpp:68, :3343)
+  // host bookkeeping (scores are parsimony lengths, i.e. -boot_logl; UINT32_MAX = "-LONG_MAX")
+  std::vector<uint32_t> boot_score;
+  std::vector<int32_t> boot_counts;
+  std::vector<int64_t> boot_trees;
+  std::vector<uint32_t> treels;                  // treels_logl as lengths
+  std::map<int64_t, std::vector<int32_t>> store; // topologies of the trees some sample currently points to
+  std::map<int64_t, int> refs;
+  uint64_t draws = 0, events = 0, gemm_rows = 0;
+  double gemm_ms = 0.0;
+  // device
+  DevBuf<uint8_t> wt;                            // [planes][Wp/2][Bp/16][4][16][16] signed bytes
+  size_t plane_bytes = 0;
+  DevBuf<uint32_t> masks;                        // [rows padded to kUfbRowTile][Wp]
+  DevBuf<uint2> info;                            // per scan output index: (mask row, part) | (.., ~0) for a home slot
+  DevBuf<int32_t> C;                             // [rows padded][Bp]
+  DevBuf<int32_t> rt;                            // [Bp] REPS of the current tree (lengths)
+  DevBuf<uint32_t> best;                         // [Bp] boot_score on the device (padding columns: 0 -> never an event)
+  DevBuf<uint32_t> thr, home, cmin, pre, evcount;
+  DevBuf<UfbEvent> ev;
+  PinBuf<UfbEvent> h_ev;
+  PinBuf<uint32_t> h_small;                      // staging: thr | home | best | event count
+  bool rt_valid = false;
+};
+
 class Engine {
  public:
   Engine() = default;
@@ -145,6 +178,19 @@ class Engine {
   int stepwise_addition(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step, uint32_t *score);
   const std::vector<Move> &moves() const { return moves_; }
 
+  // ---- online UFBoot-MP bookkeeping (host/ufboot.cpp; reference IQTree::saveCurrentTree, iqtree.cpp:3271-3785)
+  int ufboot_attach(int n_samples, const uint16_t *samples, double epsilon);
+  void ufboot_detach();
+  bool ufboot_attached() const { return (bool)ufb_; }
+  int ufboot_set_cutoff(double logl_cutoff);
+  double ufboot_next_cutoff(int percent) const;
+  int ufboot_n_samples() const;
+  int64_t ufboot_n_trees() const;
+  int ufboot_tree_logl(double *out) const;
+  int ufboot_state(double *boot_logl, int32_t *boot_counts, int32_t *boot_trees) const;
+  int ufboot_tree(int64_t tree_index, int32_t *back) const;
+  int ufboot_counters(uint64_t *draws, uint64_t *events, uint64_t *gemm_rows, double *gemm_ms) const;
+
   mpf_stats stats{};
   int set_option(const std::string &key, int64_t v);
 
@@ -160,6 +206,15 @@ class Engine {
   int pack();                                   // compressDNA on the device
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  // online UFBoot-MP
+  std::unique_ptr<UfbState> ufb_;
+  bool scan_masks_ = false;                      // the next scan_batch also writes candidate masks (k_scan_walk<MASKS>)
+  uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
+  int ufb_reserve_scan(size_t n_idx);
+  int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)
+  void ufb_store_tree(int64_t tree_index, int remove_rec, int insert_rec);
+
   int addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step);
   void apply_move(int remove_rec, int insert_rec);
 

@@ -158,6 +158,27 @@ __device__ __forceinline__ uint32_t join_cost(const Tile<S, VW> &u, const Tile<S
   return cost;
 }
 
+// same as join_cost, also handing back the "no common state" words themselves (UFBoot masks)
+template <int S, int VW, bool SPLIT = false>
+__device__ __forceinline__ uint32_t join_mask(const Tile<S, VW> &u, const Tile<S, VW> &d, const Tile<S, VW> &s, uint32_t (&m)[VW])
+{
+  uint32_t cost = 0;
+#pragma unroll
+  for (int j = 0; j < VW; j++) {
+    uint32_t any = u.v[0][j] & d.v[0][j];
+#pragma unroll
+    for (int k = 1; k < S; k++) any = b3_andor(u.v[k][j], d.v[k][j], any);
+    if constexpr (SPLIT) any |= (uint32_t)__shfl_xor((int)any, 32, 64);
+    uint32_t hit = b3_fitch(u.v[0][j], d.v[0][j], any) & s.v[0][j];
+#pragma unroll
+    for (int k = 1; k < S; k++) hit = b3_andor(b3_fitch(u.v[k][j], d.v[k][j], any), s.v[k][j], hit);
+    if constexpr (SPLIT) hit |= (uint32_t)__shfl_xor((int)hit, 32, 64);
+    m[j] = ~hit;
+    cost += (uint32_t)__builtin_popcount(~hit);
+  }
+  return cost;
+}
+
 // tile index -> first word of this lane; lanes past the row end are clamped onto the last
 // valid group (they load real data but contribute nothing), so EXEC stays full for the DPP ops
 template <int VW>
@@ -521,11 +542,15 @@ __device__ __forceinline__ void load_tile_b(Tile<S, VW> &t, __amdgpu_buffer_rsrc
 
 // S = states held per lane.  SPLIT (protein): lanes l and l^32 share a word and hold states 0..9 / 10..19, a
 // wave covers 32 words; this keeps the protein kernel at DNA-like register counts instead of one wave per SIMD.
-template <int S, int VW, int MAXD, int RED, bool SPLIT = false>
-__global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
+// MASKS (online UFBoot, ufboot.hip): every candidate's "no common state" words go to masks[out_base + m][Wp], m
+// counting candidates in the order they are COMPUTED; info[out_base + k] = (out_base + m, scan) names the row of the
+// k-th EMITTED candidate.  The part's last slot (index out_base + count) receives the join of the pruned subtree
+// onto its home edge, fitch(vec[xa], vec[xb]).
+template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false>
+__global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                    uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
-                                                   int tiles, int map)
+                                                   int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info)
 {
   constexpr int STK = MAXD + 2;
   constexpr bool LANEACC = MAXD <= 6;      // <= 4*(2^6-1) = 252 candidates: one output slot per (lane, register)
@@ -592,7 +617,35 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
   uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
   uint2 *stk = s_frame[wib];
 
-  auto emit = [&](uint32_t c) {
+  uint32_t mrow = 0;                           // MASKS: candidates computed so far
+  auto put_mask = [&](const uint32_t (&m)[VW], uint32_t row) {
+    if constexpr (MASKS) {
+      const bool wr = SPLIT ? (valid && lane < 32) : valid;
+      if (wr) {
+        uint32_t *p = masks + (size_t)(de.out_base + row) * (size_t)Wp + w0;
+#pragma unroll
+        for (int j = 0; j < VW; j++) p[j] = m[j];
+      }
+    }
+  };
+  if constexpr (MASKS) {
+    // home edge: the pruned subtree joined onto fitch(vec[xa], vec[xb])
+    Tile<S, VW> ha, hb;
+    uint32_t m0[VW];
+    MPF_LOAD(ha, de.xa_cid);
+    MPF_LOAD(hb, de.xb_cid);
+    uint32_t c0 = join_mask<S, VW, SPLIT>(ha, hb, sv, m0);
+    put_mask(m0, de.pad0);
+    c0 = valid ? c0 : 0u;
+    if constexpr (SPLIT) c0 = lane < 32 ? c0 : 0u;
+    const uint32_t t0 = wave_total<RED>(c0);
+    if (lane == 0 && t0) atomic_add_u32(out + de.out_base + de.pad0, t0);
+    if (tile == 0 && lane == 0) info[de.out_base + de.pad0] = make_uint2(de.out_base + de.pad0, 0xFFFFFFFFu);
+  }
+  auto emit = [&](uint32_t c, uint32_t row) {
+    if constexpr (MASKS) {
+      if (tile == 0 && lane == 0) info[de.out_base + k] = make_uint2(de.out_base + row, (uint32_t)scan);
+    }
     if constexpr (LANEACC) {
       // candidate k belongs to lane k&63, register k>>6: a lane select instead of a memory atomic
       const bool mine = (uint32_t)lane == (k & 63u);
@@ -627,8 +680,18 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
       fitch<S, VW, SPLIT>(u1, par, d2);
       fitch<S, VW, SPLIT>(u2, par, d1);
       uint32_t tot = 0;
+      const bool own1 = dd > 1u || (child_mask & 1u), own2 = dd > 1u || (child_mask & 2u);
+      uint32_t r1 = 0, r2 = 0;
       if (test) {
-        uint32_t cost = join_cost<S, VW, SPLIT>(u1, d1, sv) | (join_cost<S, VW, SPLIT>(u2, d2, sv) << 16);
+        uint32_t cost;
+        if constexpr (MASKS) {
+          uint32_t m1[VW], m2[VW];
+          cost = join_mask<S, VW, SPLIT>(u1, d1, sv, m1) | (join_mask<S, VW, SPLIT>(u2, d2, sv, m2) << 16);
+          if (own1) { r1 = mrow++; put_mask(m1, r1); }
+          if (own2) { r2 = mrow++; put_mask(m2, r2); }
+        } else {
+          cost = join_cost<S, VW, SPLIT>(u1, d1, sv) | (join_cost<S, VW, SPLIT>(u2, d2, sv) << 16);
+        }
         cost = valid ? cost : 0u;
         tot = wave_total<RED>(cost);
       }
@@ -637,9 +700,8 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
         switch (dd) { MPF_PUT(1) MPF_PUT(2) MPF_PUT(3) MPF_PUT(4) MPF_PUT(5) MPF_PUT(6) MPF_PUT(7) MPF_PUT(8) MPF_PUT(9) MPF_PUT(10) MPF_PUT(11) default: break; }
 #undef MPF_PUT
       }
-      const bool own1 = dd > 1u || (child_mask & 1u), own2 = dd > 1u || (child_mask & 2u);
-      if (own2) { stk[sp] = make_uint2(c2 | (dd << 24), tot >> 16); sp++; }
-      if (test && own1) emit(tot & 0xFFFFu);
+      if (own2) { stk[sp] = make_uint2(c2 | (dd << 24), (tot >> 16) | (r2 << 16)); sp++; }
+      if (test && own1) emit(tot & 0xFFFFu, r1);
       if (own1 && deeper && c1 >= n) { par = u1; node = c1; d = dd; continue; }
       // ---- unwind: emit pending second children until one of them has to be expanded
       bool more = false;
@@ -648,7 +710,10 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6) ? 8 : 1) void
         const uint2 fr = stk[sp];
         const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)fr.x);
         const uint32_t q = fx & 0xFFFFFFu, dq = fx >> 24;
-        if (dq >= mintrav) emit((uint32_t)__builtin_amdgcn_readfirstlane((int)fr.y));
+        if (dq >= mintrav) {
+          const uint32_t fy = (uint32_t)__builtin_amdgcn_readfirstlane((int)fr.y);
+          emit(fy & 0xFFFFu, fy >> 16);
+        }
         if (dq < maxtrav && q >= n) {
 #define MPF_GET(D) case D: if constexpr (D < MAXD) par = pend[D]; break;
           switch (dq) { MPF_GET(1) MPF_GET(2) MPF_GET(3) MPF_GET(4) MPF_GET(5) MPF_GET(6) MPF_GET(7) MPF_GET(8) MPF_GET(9) MPF_GET(10) MPF_GET(11) default: break; }
@@ -1040,7 +1105,8 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
 }
 
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
-                            const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth)
+                            const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
+                            uint32_t *masks, uint2 *info)
 {
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;
@@ -1052,8 +1118,15 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
   if (g.map == 0) nblocks = (unsigned)((waves + 3) / 4);
   else { const long chunk = (waves + 7) / 8; nblocks = (unsigned)(((chunk + 3) / 4) * 8); }
   dim3 grid(nblocks);
-#define SW(S_, VW_, MAXD_, RED_, SPLIT_) \
-  hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc, n_scans, out, ncand, g.Wp, tiles, g.map)
+#define SW(S_, VW_, MAXD_, RED_, SPLIT_)                                                                                              \
+  do {                                                                                                                                \
+    if (masks)                                                                                                                        \
+      hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, true>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc,    \
+                         n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                       \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, false>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc,   \
+                         n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                       \
+  } while (0)
 #define SW2(S_, VW_, SPLIT_)                                                                                 \
   do {                                                                                                       \
     if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0, SPLIT_); else SW(S_, VW_, 6, 1, SPLIT_); }    \

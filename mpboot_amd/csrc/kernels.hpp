@@ -66,7 +66,8 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
                        const ScanOp *ops, uint32_t *out, int max_depth);
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
-                            const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth);
+                            const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
+                            uint32_t *masks = nullptr, uint2 *info = nullptr);   // masks != nullptr: UFBoot variant (ufboot.hip)
 // per-pattern Fitch lengths: ops = the (a, b) joins of a rooted traversal of the current tree; `planes` is
 // scratch of site_planes_words() words; ptn_out[p] = length of pattern p (0 where first_site[p] < 0)
 hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,

@@ -1,0 +1,285 @@
+// ufboot.hip -- device side of the online UFBoot-MP bookkeeping (SURVEY §8f rank 1 + 2).
+//
+// Reference: for every insertion test of the SPR scan, IQTree::saveCurrentTree (iqtree.cpp:3271-3785) extracts the
+// per-pattern parsimony lengths of the tentatively re-inserted tree (pllComputePatternParsimony,
+// sprparsimony.cpp:3363-3392, fed by the 401 MB per-site counter arrays :294-376) and contracts them with every
+// bootstrap weight vector (REPS, :3411-3449).
+//
+// Here neither the per-site counters nor a per-candidate pattern vector exist.  The per-site Fitch length of an
+// unrooted tree does not depend on where it is rooted, so for the prune node p of a scan and any candidate edge e
+//     pattern_pars(T with p re-inserted at e) = pattern_pars(T) - M(p, home) + M(p, e)
+// where M(p, e) is the 1-bit-per-site "no common state" mask of joining p's subtree onto edge e -- exactly the
+// word whose popcount the scan kernel already takes.  The scan kernel writes those masks (k_scan_walk<MASKS>),
+// and the REPS of all candidates of a batch is ONE binary x small-integer matrix product
+//     C[row][b] = sum_bit mask[row][bit] * w[b][bit]          (k_bitgemm, v_mfma_i32_16x16x64_i8)
+//     rell(cand, b) = -( R_T[b] - C[home(cand)][b] + C[cand][b] )
+// with R_T the REPS vector of the current tree.  The per-sample "new best or tie" decisions of the reference are
+// order dependent (they draw random numbers on ties), so the device only extracts, per sample, the candidates
+// that reach the running minimum in scan order (a chunked prefix-min), and the host replays just those events.
+#include "ufboot.hpp"
+
+namespace mpf {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ join masks
+// mask[op][w] = ~OR_k(vec[a]_k & vec[b]_k): the sites that mutate on the join (a, b) of a rooted traversal;
+// their sum over the n-1 joins of the tree is the per-site length, so R_T = column sums of the product below.
+__global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__ vec, const EvOp *__restrict__ ops,
+                                                    int n_ops, int S, int Wp, uint32_t *__restrict__ masks)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int op = blockIdx.y;
+  if (w >= Wp || op >= n_ops) return;
+  const EvOp o = ops[op];
+  const uint32_t *a = vec + (size_t)o.a * (size_t)(S * Wp) + w, *b = vec + (size_t)o.b * (size_t)(S * Wp) + w;
+  uint32_t any = 0;
+  for (int k = 0; k < S; k++) any |= a[(size_t)k * Wp] & b[(size_t)k * Wp];
+  masks[(size_t)op * Wp + w] = ~any;
+}
+
+// ------------------------------------------------------------------------------------------------ bit GEMM
+// A: masks [R][Wp] 32-bit words (row-major, bit j of word i = site 32 i + j), R padded to the workgroup tile.
+// Wt: bootstrap weights as signed bytes (<= 127 per plane), laid out so that one k-block (64 sites = 2 words) of a
+// 16-column group is the 1 KiB the MFMA B-fragments of a wave read lane-linearly:
+//     Wt[((kblk * (Bp/16) + cg) * 4 + h) * 16 + c][j]  = weight of site 64 kblk + 16 h + j in sample 16 cg + c
+// (h = lane >> 4, c = lane & 15, j = byte in the lane's 16-byte fragment).  The A fragment of lane (r = lane & 15, h)
+// is the same 16 sites of row r, expanded from bits to bytes in registers: nibble * 0x00204081 & 0x01010101.
+// Workgroup = 2 x 2 waves, wave tile = (16 MT) x (16 NT); C = acc * mult (+ C if accumulate).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
+                                                 int Bp, int32_t *__restrict__ C, int mult, int accumulate, int row_blocks)
+{
+  constexpr int TM = 32 * MT, TN = 32 * NT;          // workgroup tile
+  constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile
+  __shared__ __attribute__((aligned(16))) uint8_t s_b[2][BT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // column block fastest: with Bp / TN == 8 every XCD (blockIdx % 8) streams ONE column block of Wt through its L2
+  const int col_blocks = Bp / TN;
+  const int cb = blockIdx.x % col_blocks, rb = blockIdx.x / col_blocks;
+  if (rb >= row_blocks) return;
+  const int r = lane & 15, h = lane >> 4;
+  const int row0 = rb * TM + wr * 16 * MT, col0 = cb * TN + wc * 16 * NT;
+  const int nkb = Wp >> 1;
+
+  v4i acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = (v4i){0, 0, 0, 0};
+
+  // B tile of k-block kb: the TN/16 column groups of this block are contiguous in Wt
+  const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
+  const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
+  constexpr int LD = BT / (256 * 16);                // 16-byte loads per thread per k-block
+  uint4 breg[LD];
+  uint32_t areg[MT];
+  const uint32_t *arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) arow[i] = masks + (size_t)(row0 + 16 * i + r) * Wp + (h >> 1);
+
+  auto gload = [&](int kb) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(wt_tile + (size_t)kb * wt_kstride);
+#pragma unroll
+    for (int i = 0; i < LD; i++) breg[i] = src[threadIdx.x + 256 * i];
+#pragma unroll
+    for (int i = 0; i < MT; i++) areg[i] = arow[i][2 * kb];
+  };
+  gload(0);
+  {
+    uint4 *dst = reinterpret_cast<uint4 *>(s_b[0]);
+#pragma unroll
+    for (int i = 0; i < LD; i++) dst[threadIdx.x + 256 * i] = breg[i];
+  }
+  uint32_t acur[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) acur[i] = areg[i];
+  __syncthreads();
+
+  for (int kb = 0; kb < nkb; kb++) {
+    const int cur = kb & 1;
+    if (kb + 1 < nkb) gload(kb + 1);
+    // B fragments: column group (wc * NT + j) of the tile, lane-linear 16 bytes
+    v4i bf[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      bf[j] = *reinterpret_cast<const v4i *>(s_b[cur] + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const uint32_t bits = (acur[i] >> ((h & 1) * 16)) & 0xFFFFu;
+      v4i af;
+      af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
+      af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+      af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+      af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kb + 1 < nkb) {
+      uint4 *dst = reinterpret_cast<uint4 *>(s_b[cur ^ 1]);
+#pragma unroll
+      for (int i = 0; i < LD; i++) dst[threadIdx.x + 256 * i] = breg[i];
+#pragma unroll
+      for (int i = 0; i < MT; i++) acur[i] = areg[i];
+    }
+    __syncthreads();
+  }
+
+  // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const int col = col0 + 16 * j + r;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int row = row0 + 16 * i + 4 * h + q;
+        int32_t *p = C + (size_t)row * Bp + col;
+        const int v = acc[i][j][q] * mult;
+        *p = accumulate ? *p + v : v;
+      }
+    }
+}
+
+// R_T[b] = sum over rows of C[row][b]
+__global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  int32_t s = 0;
+  for (int r = 0; r < rows; r++) s += C[(size_t)r * Bp + b];
+  rt[b] = s;
+}
+
+// R_T += C[row] - C[home]   (the accepted move's candidate becomes the current tree)
+__global__ __launch_bounds__(256) void k_rt_update(int32_t *__restrict__ rt, const int32_t *__restrict__ C, int Bp,
+                                                   const uint2 *__restrict__ info, uint32_t idx, uint32_t home)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  const uint32_t row = info[idx].x;
+  rt[b] += C[(size_t)row * Bp + b] - C[(size_t)home * Bp + b];
+}
+
+// ------------------------------------------------------------------------------------------------ events
+// Index space: the scan's output indices (candidates in the reference's order, each part followed by its home
+// slot).  info[i] = (mask row, part) for a candidate, (.., 0xFFFFFFFF) for a home slot; a candidate takes part in
+// the bookkeeping iff cost[i] < thr[part] (the logl_cutoff filter, iqtree.cpp:3343; thr = largest admissible cost + 1).
+// score(i, b) = R_T[b] - C[home(part)][b] + C[row(i)][b]   (parsimony length of candidate i under sample b)
+__device__ __forceinline__ bool ufb_score(uint32_t i, int b, const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
+                                          const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
+                                          const int32_t *__restrict__ C, int Bp, int32_t rt, int32_t &s)
+{
+  const uint2 in = info[i];
+  if (in.y == 0xFFFFFFFFu) return false;
+  if (cost[i] >= thr[in.y]) return false;
+  s = rt - C[(size_t)home[in.y] * Bp + b] + C[(size_t)in.x * Bp + b];
+  return true;
+}
+
+constexpr int kUfbChunk = 64;
+
+__global__ __launch_bounds__(256) void k_ufb_chunkmin(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
+                                                      const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
+                                                      const int32_t *__restrict__ C, int Bp, const int32_t *__restrict__ rt,
+                                                      uint32_t n_idx, uint32_t *__restrict__ cmin)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.y;
+  if (b >= Bp) return;
+  const uint32_t i0 = chunk * kUfbChunk, i1 = min(n_idx, i0 + kUfbChunk);
+  const int32_t r = rt[b];
+  uint32_t m = 0xFFFFFFFFu;
+  for (uint32_t i = i0; i < i1; i++) {
+    int32_t s;
+    if (ufb_score(i, b, info, cost, thr, home, C, Bp, r, s)) m = min(m, (uint32_t)s);
+  }
+  cmin[(size_t)chunk * Bp + b] = m;
+}
+
+// pre[chunk][b] = min(best[b], cmin[0..chunk)[b])
+__global__ __launch_bounds__(256) void k_ufb_prefix(const uint32_t *__restrict__ cmin, const uint32_t *__restrict__ best, int Bp,
+                                                    uint32_t n_chunks, uint32_t *__restrict__ pre)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  uint32_t run = best[b];
+  for (uint32_t c = 0; c < n_chunks; c++) {
+    pre[(size_t)c * Bp + b] = run;
+    run = min(run, cmin[(size_t)c * Bp + b]);
+  }
+}
+
+// every (candidate, sample) whose score reaches the running minimum in scan order: the only pairs for which the
+// reference's update rule can fire (rell > boot_logl - epsilon with 0 < epsilon < 1 and integer scores)
+__global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
+                                                    const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
+                                                    const int32_t *__restrict__ C, int Bp, int B, const int32_t *__restrict__ rt,
+                                                    uint32_t n_idx, const uint32_t *__restrict__ pre,
+                                                    UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.y;
+  if (b >= B) return;
+  const uint32_t i0 = chunk * kUfbChunk, i1 = min(n_idx, i0 + kUfbChunk);
+  const int32_t r = rt[b];
+  uint32_t run = pre[(size_t)chunk * Bp + b];
+  for (uint32_t i = i0; i < i1; i++) {
+    int32_t s;
+    if (!ufb_score(i, b, info, cost, thr, home, C, Bp, r, s)) continue;
+    if ((uint32_t)s <= run) {
+      const uint32_t at = atomicAdd(ev_count, 1u);
+      if (at < ev_cap) ev[at] = UfbEvent{i, (uint32_t)b, (uint32_t)s};
+      run = (uint32_t)s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops, uint32_t *masks)
+{
+  if (n_ops <= 0) return hipSuccess;
+  const int S = g.S;
+  hipLaunchKernelGGL(k_join_masks, dim3((g.Wp + 255) / 256, n_ops), dim3(256), 0, st, vec, ops, n_ops, S, g.Wp, masks);
+  return hipGetLastError();
+}
+
+hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
+                          int mult, int accumulate)
+{
+  if (rows_padded <= 0) return hipSuccess;
+  const int row_blocks = rows_padded / kUfbRowTile, col_blocks = Bp / kUfbColTile;
+  hipLaunchKernelGGL((k_bitgemm<kUfbRowTile / 32, kUfbColTile / 32>), dim3((unsigned)(row_blocks * col_blocks)), dim3(256), 0, st,
+                     masks, Wp, Wt, Bp, C, mult, accumulate, row_blocks);
+  return hipGetLastError();
+}
+
+hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)
+{
+  hipLaunchKernelGGL(k_colsum, dim3((Bp + 255) / 256), dim3(256), 0, st, C, rows, Bp, rt);
+  return hipGetLastError();
+}
+
+hipError_t launch_rt_update(hipStream_t st, int32_t *rt, const int32_t *C, int Bp, const uint2 *info, uint32_t idx, uint32_t home)
+{
+  hipLaunchKernelGGL(k_rt_update, dim3((Bp + 255) / 256), dim3(256), 0, st, rt, C, Bp, info, idx, home);
+  return hipGetLastError();
+}
+
+uint32_t ufb_chunks(uint32_t n_idx) { return (n_idx + kUfbChunk - 1) / kUfbChunk; }
+
+hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
+                             const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
+                             uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count)
+{
+  if (n_idx == 0) return hipSuccess;
+  const uint32_t nc = ufb_chunks(n_idx);
+  dim3 grid((Bp + 255) / 256, nc), block(256);
+  hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, C, Bp, rt, n_idx, cmin);
+  hipLaunchKernelGGL(k_ufb_prefix, dim3((Bp + 255) / 256), block, 0, st, cmin, best, Bp, nc, pre);
+  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count);
+  return hipGetLastError();
+}
+
+}  // namespace mpf

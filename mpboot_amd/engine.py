@@ -25,6 +25,8 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
+    "mpf_ufboot_attach", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
+    "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
 ]
 
 
@@ -93,6 +95,15 @@ def load_library():
         L.mpf_reps_scores.argtypes = [vp, C.c_int32, vp, vp]
         L.mpf_reps_destroy.argtypes = [vp]
         L.mpf_reps_destroy.restype = None
+        L.mpf_ufboot_attach.argtypes = [vp, C.c_int32, vp, C.c_double]
+        L.mpf_ufboot_detach.argtypes = [vp]
+        L.mpf_ufboot_set_cutoff.argtypes = [vp, C.c_double]
+        L.mpf_ufboot_next_cutoff.argtypes = [vp, C.c_int32, vp]
+        L.mpf_ufboot_num_trees.argtypes = [vp, vp]
+        L.mpf_ufboot_tree_logl.argtypes = [vp, vp]
+        L.mpf_ufboot_get_state.argtypes = [vp, vp, vp, vp]
+        L.mpf_ufboot_get_tree.argtypes = [vp, C.c_int64, vp]
+        L.mpf_ufboot_get_counters.argtypes = [vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -285,6 +296,51 @@ class FitchEngine:
         if k.value:
             _chk(L.mpf_get_moves(self.h, k.value, _p(a), _p(b), _p(s), C.byref(k)))
         return a, b, s
+
+    # ---- online UFBoot-MP bookkeeping (IQTree::saveCurrentTree during optimize_spr)
+    def ufboot_attach(self, samples, epsilon: float = 0.5):
+        samples = np.ascontiguousarray(samples, dtype=np.uint16)
+        if samples.ndim != 2 or samples.shape[1] != self.P:
+            raise ValueError("samples must be [n_samples][n_patterns]")
+        self.ufb_B = samples.shape[0]
+        _chk(load_library().mpf_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon)))
+
+    def ufboot_detach(self):
+        _chk(load_library().mpf_ufboot_detach(self.h))
+
+    def ufboot_set_cutoff(self, logl_cutoff: float):
+        _chk(load_library().mpf_ufboot_set_cutoff(self.h, float(logl_cutoff)))
+
+    def ufboot_next_cutoff(self, percent: int = 10) -> float:
+        c = C.c_double()
+        _chk(load_library().mpf_ufboot_next_cutoff(self.h, percent, C.byref(c)))
+        return c.value
+
+    def ufboot_tree_logl(self):
+        k = C.c_int64()
+        L = load_library()
+        _chk(L.mpf_ufboot_num_trees(self.h, C.byref(k)))
+        out = np.zeros(k.value, dtype=np.float64)
+        if k.value:
+            _chk(L.mpf_ufboot_tree_logl(self.h, _p(out)))
+        return out
+
+    def ufboot_state(self):
+        logl = np.zeros(self.ufb_B, dtype=np.float64)
+        counts = np.zeros(self.ufb_B, dtype=np.int32)
+        trees = np.zeros(self.ufb_B, dtype=np.int32)
+        _chk(load_library().mpf_ufboot_get_state(self.h, _p(logl), _p(counts), _p(trees)))
+        return logl, counts, trees
+
+    def ufboot_tree(self, tree_index: int):
+        back = np.empty(self.nrec, dtype=np.int32)
+        _chk(load_library().mpf_ufboot_get_tree(self.h, int(tree_index), _p(back)))
+        return back
+
+    def ufboot_counters(self) -> dict:
+        d, e, r, ms = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
+        _chk(load_library().mpf_ufboot_get_counters(self.h, C.byref(d), C.byref(e), C.byref(r), C.byref(ms)))
+        return {"tie_draws": d.value, "events": e.value, "reps_rows": r.value, "reps_kernel_ms": ms.value}
 
     def stats(self) -> dict:
         st = Stats()

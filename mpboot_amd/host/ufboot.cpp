@@ -1,0 +1,385 @@
+// ufboot.cpp -- online UFBoot-MP bookkeeping around the batched SPR scans.
+//
+// Reference: with -bb, testInsertParsimony calls IQTree::saveCurrentTree for EVERY insertion test
+// (sprparsimony.cpp:2163-2166 -> iqtree.cpp:3271-3785): cut-off filter, per-pattern lengths of the tentative tree,
+// REPS against every bootstrap sample, and the per-sample update rule with its random tie-breaks (drawn from
+// the same stream as the SPR tie-breaks).  Here the arithmetic runs on the device for a whole batch of scans
+// (ufboot.hip) and the host replays only the order-dependent part: the candidates in scan order, and for each of
+// them the few (sample) events where its score reaches that sample's running best.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+#include "../csrc/engine.hpp"
+
+namespace mpf {
+
+#define UCHK(expr)                                                                                   \
+  do {                                                                                               \
+    hipError_t e__ = (expr);                                                                         \
+    if (e__ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e__)); return MPF_E_HIP; } \
+  } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon)
+{
+  if (sankoff_) { set_error("online UFBoot: Fitch mode only (weighted per-pattern lengths are not 0/1 increments)"); return MPF_E_UNSUPPORTED; }
+  if (n_samples < 1 || !samples) { set_error("ufboot_attach: bad argument"); return MPF_E_INVALID; }
+  if (!(epsilon > 0.0 && epsilon < 1.0)) {
+    set_error("ufboot_attach: epsilon must lie in (0, 1) -- with integer scores every such value acts like the default 0.5");
+    return MPF_E_UNSUPPORTED;
+  }
+  ufboot_detach();
+  std::unique_ptr<UfbState> u(new UfbState());
+  u->B = n_samples;
+  u->Bp = round_up(n_samples, kUfbColTile);
+  u->eps = epsilon;
+  uint32_t wmax = 0;
+  for (size_t i = 0; i < (size_t)n_samples * (size_t)P_; i++) wmax = std::max<uint32_t>(wmax, samples[i]);
+  u->planes = wmax < 128 ? 1 : (wmax < 16384 ? 2 : 3);
+  const int nkb = g_.Wp / 2;
+  u->plane_bytes = (size_t)nkb * (size_t)u->Bp * 64;
+  std::vector<uint8_t> wt(u->plane_bytes * (size_t)u->planes, 0);
+  const size_t kstride = (size_t)(u->Bp / 16) * 1024;
+  for (int ptn = 0; ptn < P_; ptn++) {
+    const int site = first_site_[(size_t)ptn];
+    if (site < 0) continue;                                  // uninformative: its length is 0 in every tree
+    const int word = site >> 5, bit = site & 31;
+    const int kb = word >> 1, within = (word & 1) * 32 + bit, h = within >> 4, j = within & 15;
+    uint8_t *base = wt.data() + (size_t)kb * kstride + (size_t)h * 256 + (size_t)j;
+    for (int b = 0; b < n_samples; b++) {
+      const uint32_t w = samples[(size_t)b * (size_t)P_ + (size_t)ptn];
+      if (!w) continue;
+      const size_t off = (size_t)(b >> 4) * 1024 + (size_t)(b & 15) * 16;
+      for (int pl = 0; pl < u->planes; pl++) base[(size_t)pl * u->plane_bytes + off] = (uint8_t)((w >> (7 * pl)) & 0x7Fu);
+    }
+  }
+  UCHK(u->wt.reserve(wt.size()));
+  UCHK(hipMemcpyAsync(u->wt.p, wt.data(), wt.size(), hipMemcpyHostToDevice, st_));
+  UCHK(u->rt.reserve((size_t)u->Bp));
+  UCHK(u->best.reserve((size_t)u->Bp));
+  UCHK(u->evcount.reserve(4));
+  UCHK(hipMemsetAsync(u->rt.p, 0, (size_t)u->Bp * sizeof(int32_t), st_));
+  UCHK(hipStreamSynchronize(st_));
+  u->boot_score.assign((size_t)n_samples, UINT32_MAX);       // boot_logl = -LONG_MAX (iqtree.cpp:248)
+  u->boot_counts.assign((size_t)n_samples, 0);               // :253
+  u->boot_trees.assign((size_t)n_samples, -1);               // :252
+  ufb_ = std::move(u);
+  return MPF_OK;
+}
+
+void Engine::ufboot_detach() { ufb_.reset(); }
+
+int Engine::ufboot_set_cutoff(double logl_cutoff)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  ufb_->logl_cutoff = logl_cutoff;
+  return MPF_OK;
+}
+
+// "top cutoff_percent %" rule of the main loop (reference iqtree.cpp:1662-1676; treels_logl.size() > 1000)
+double Engine::ufboot_next_cutoff(int percent) const
+{
+  if (!ufb_) return 0.0;
+  const std::vector<uint32_t> &t = ufb_->treels;
+  if (t.size() <= 1000) return ufb_->logl_cutoff;
+  std::vector<uint32_t> l(t);
+  const size_t k = l.size() * (size_t)percent / 100;
+  std::nth_element(l.begin(), l.begin() + (long)k, l.end());   // k-th smallest length = k-th largest logl
+  return -(double)l[k];
+}
+
+int Engine::ufboot_n_samples() const { return ufb_ ? ufb_->B : 0; }
+int64_t Engine::ufboot_n_trees() const { return ufb_ ? (int64_t)ufb_->treels.size() : 0; }
+
+int Engine::ufboot_tree_logl(double *out) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  for (size_t i = 0; i < ufb_->treels.size(); i++) out[i] = -(double)ufb_->treels[i];
+  return MPF_OK;
+}
+
+int Engine::ufboot_state(double *boot_logl, int32_t *boot_counts, int32_t *boot_trees) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  for (int b = 0; b < ufb_->B; b++) {
+    if (boot_logl) boot_logl[b] = ufb_->boot_score[(size_t)b] == UINT32_MAX ? -(double)LONG_MAX : -(double)ufb_->boot_score[(size_t)b];
+    if (boot_counts) boot_counts[b] = ufb_->boot_counts[(size_t)b];
+    if (boot_trees) boot_trees[b] = (int32_t)ufb_->boot_trees[(size_t)b];
+  }
+  return MPF_OK;
+}
+
+int Engine::ufboot_tree(int64_t tree_index, int32_t *back) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  auto it = ufb_->store.find(tree_index);
+  if (it == ufb_->store.end()) { set_error("tree is not referenced by any bootstrap sample"); return MPF_E_INVALID; }
+  std::memcpy(back, it->second.data(), it->second.size() * sizeof(int32_t));
+  return MPF_OK;
+}
+
+int Engine::ufboot_counters(uint64_t *draws, uint64_t *events, uint64_t *gemm_rows, double *gemm_ms) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (draws) *draws = ufb_->draws;
+  if (events) *events = ufb_->events;
+  if (gemm_rows) *gemm_rows = ufb_->gemm_rows;
+  if (gemm_ms) *gemm_ms = ufb_->gemm_ms;
+  return MPF_OK;
+}
+
+int Engine::ufb_reserve_scan(size_t n_idx)
+{
+  UfbState &u = *ufb_;
+  const size_t rows = (size_t)round_up((int)std::max<size_t>(n_idx, 1), kUfbRowTile);
+  UCHK(u.masks.reserve(rows * (size_t)g_.Wp));
+  UCHK(u.info.reserve(rows));
+  return MPF_OK;
+}
+
+// R_T[b] = sum_ptn w_b[ptn] * pattern_pars(current tree)[ptn]: the n-1 joins of a rooted traversal, one mask each
+int Engine::ufb_current_tree_reps()
+{
+  UfbState &u = *ufb_;
+  if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
+  std::vector<EvOp> ops;
+  ops.push_back(EvOp{slot(start_), slot(back_[start_]), 0, 0});
+  std::vector<int> stack;
+  stack.push_back(back_[start_]);
+  while (!stack.empty()) {
+    const int r = stack.back();
+    stack.pop_back();
+    if (tip(r)) continue;
+    const int a = back_[nx(r)], b = back_[nx(nx(r))];
+    ops.push_back(EvOp{slot(a), slot(b), 0, 0});
+    stack.push_back(a);
+    stack.push_back(b);
+  }
+  const int rows = (int)ops.size(), rows_p = round_up(rows, kUfbRowTile);
+  UCHK(d_evops_.reserve(ops.size()));
+  UCHK(u.masks.reserve((size_t)rows_p * (size_t)g_.Wp));
+  UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
+  UCHK(hipMemcpyAsync(d_evops_.p, ops.data(), ops.size() * sizeof(EvOp), hipMemcpyHostToDevice, st_));
+  UCHK(hipMemsetAsync(u.masks.p + (size_t)rows * g_.Wp, 0, (size_t)(rows_p - rows) * g_.Wp * sizeof(uint32_t), st_));
+  UCHK(launch_join_masks(st_, g_, d_vec_, d_evops_.p, rows, u.masks.p));
+  for (int pl = 0; pl < u.planes; pl++)
+    UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0));
+  UCHK(launch_colsum(st_, u.C.p, rows, u.Bp, u.rt.p));
+  UCHK(hipStreamSynchronize(st_));     // ops (host vector) must outlive the copy
+  u.rt_valid = true;
+  return MPF_OK;
+}
+
+void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
+{
+  UfbState &u = *ufb_;
+  if (u.store.count(tree_index)) return;
+  std::vector<int32_t> bk(back_);
+  auto hk = [&](int a, int b) { bk[(size_t)a] = b; bk[(size_t)b] = a; };
+  const int a = bk[(size_t)nx(p)], b = bk[(size_t)nx(nx(p))];
+  hk(a, b);
+  const int r = bk[(size_t)q];
+  hk(nx(p), q);
+  hk(nx(nx(p)), r);
+  u.store.emplace(tree_index, std::move(bk));
+}
+
+// pllOptimizeSprParsimony's sweep loop (reference sprparsimony.cpp:3295-3316) with perSiteScores = 1, i.e. with
+// saveCurrentTree after every insertion test.  Same speculative batching as Engine::spr_sweeps.
+int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
+{
+  UfbState &u = *ufb_;
+  uint32_t startMP;
+  unsigned iter_hits = 1;
+  const int total = 2 * n_ - 2;
+  std::vector<ScanPlan> plans;
+  const uint32_t *out = nullptr;
+  int batch = std::max(1, scan_batch_);
+  std::vector<UfbEvent> events;
+  std::vector<uint32_t> small;
+  if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
+  do {
+    startMP = randomMP;
+    node_rectifier();
+    int i = 1;
+    while (i <= total) {
+      const int hi = std::min(total, i + batch - 1);
+      scan_masks_ = true;
+      int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
+      scan_masks_ = false;
+      if (rc) return rc;
+      const int np = hi - i + 1;
+      // ---- the first prune node with a strictly better candidate ends the batch for certain: nothing behind it
+      //      needs REPS (a tie may end it earlier; then the tail of the product is simply not used)
+      int jstar = np - 1;
+      for (int j = 0; j < np; j++) {
+        const ScanPlan &pl = plans[(size_t)j];
+        uint32_t m = UINT32_MAX;
+        for (int pi = 0; pi < pl.n_parts; pi++)
+          for (int k = 0; k < pl.part_cnt[pi]; k++) m = std::min(m, out[pl.part_off[pi] + (uint32_t)k]);
+        if (m != UINT32_MAX && pl.base + m < randomMP) { jstar = j; break; }
+      }
+      // cut-off filter (reference iqtree.cpp:3343): a candidate is saved iff  -mp > logl_cutoff - 1e-4
+      const bool have_cut = u.logl_cutoff != 0.0;
+      const double lim = -u.logl_cutoff + 1e-4;
+      const uint32_t mp_max = have_cut ? (lim <= 0.0 ? 0u : (uint32_t)std::ceil(lim) - 1u) : UINT32_MAX;
+      const bool none_pass = have_cut && lim <= 0.0;
+      // ---- device: REPS of every candidate of plans [0, jstar], then the (candidate, sample) events
+      uint32_t n_idx = 0, n_parts = 0;
+      for (int j = 0; j <= jstar; j++) {
+        const ScanPlan &pl = plans[(size_t)j];
+        for (int pi = 0; pi < pl.n_parts; pi++) {
+          n_idx = std::max(n_idx, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
+          n_parts = std::max(n_parts, (uint32_t)pl.part_desc[pi] + 1u);
+        }
+      }
+      uint32_t n_ev = 0;
+      if (n_idx > 0 && !none_pass) {
+        const int rows_p = round_up((int)n_idx, kUfbRowTile);
+        // staging: thr[n_parts] | home[n_parts] | best[Bp]
+        small.assign((size_t)2 * n_parts + (size_t)u.Bp, 0u);
+        for (int j = 0; j <= jstar; j++) {
+          const ScanPlan &pl = plans[(size_t)j];
+          for (int pi = 0; pi < pl.n_parts; pi++) {
+            const uint32_t d = (uint32_t)pl.part_desc[pi];
+            small[d] = !have_cut ? UINT32_MAX : (mp_max >= pl.base ? mp_max - pl.base + 1u : 0u);   // max cost + 1
+            small[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
+          }
+        }
+        for (int b = 0; b < u.B; b++) small[(size_t)2 * n_parts + (size_t)b] = u.boot_score[(size_t)b];
+        UCHK(u.h_small.reserve(small.size() + 4));
+        std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
+        UCHK(u.thr.reserve(small.size() + 4));
+        UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
+        const uint32_t nch = ufb_chunks(n_idx);
+        UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
+        UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
+        if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
+        UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+        const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
+        if (timing_) UCHK(hipEventRecord(ev2_, st_));
+        for (int pl = 0; pl < u.planes; pl++)
+          UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0));
+        if (timing_) UCHK(hipEventRecord(ev3_, st_));
+        u.gemm_rows += (uint64_t)rows_p;
+        while (true) {
+          UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
+          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, u.C.p, u.Bp, u.B, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
+                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p));
+          UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+          UCHK(hipStreamSynchronize(st_));
+          n_ev = u.h_small.p[0];
+          if (n_ev <= u.ev.cap) break;
+          UCHK(u.ev.reserve((size_t)n_ev));              // more events than room: grow and extract again
+          UCHK(u.h_ev.reserve((size_t)n_ev));
+        }
+        if (timing_) {
+          float ms = 0;
+          if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
+        }
+        if (n_ev) {
+          UCHK(u.h_ev.reserve((size_t)n_ev));
+          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
+          UCHK(hipStreamSynchronize(st_));
+        }
+        events.assign(u.h_ev.p, u.h_ev.p + n_ev);
+        std::sort(events.begin(), events.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
+        u.events += n_ev;
+      } else {
+        events.clear();
+      }
+      // ---- host replay in the reference's order
+      size_t ep = 0;
+      bool moved = false;
+      int j = i;
+      for (; j <= hi && !moved; j++) {
+        const ScanPlan &pl = plans[(size_t)(j - i)];
+        if (tie_mode_ == MPF_TIE_RANDOM) {
+          insert_rec_ = remove_rec_ = -1;
+          hits_ = 1;
+        }
+        long sel = -1;
+        uint32_t sel_idx = 0, sel_home = 0;
+        size_t c = 0;
+        for (int pi = 0; pi < pl.n_parts; pi++) {
+          const uint32_t home = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
+          for (int k = 0; k < pl.part_cnt[pi]; k++, c++) {
+            const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
+            const uint32_t mp = pl.base + out[idx];
+            // saveCurrentTree(-mp) (reference sprparsimony.cpp:2163-2166), before the SPR tie rule
+            if (!none_pass && mp <= mp_max) {
+              const int64_t tree_index = (int64_t)u.treels.size();          // iqtree.cpp:3345-3348
+              u.treels.push_back(mp);
+              while (ep < events.size() && events[ep].idx < idx) ep++;
+              for (; ep < events.size() && events[ep].idx == idx; ep++) {
+                const uint32_t b = events[ep].b, s = events[ep].s;
+                uint32_t &bs = u.boot_score[b];
+                bool accept = false;
+                if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (:3686)
+                else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
+                  u.draws++;
+                  accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
+                }
+                if (accept) {
+                  ufb_store_tree(tree_index, c < (size_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, c));
+                  if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
+                  int64_t &bt = u.boot_trees[b];
+                  if (bt != tree_index) {
+                    if (bt >= 0 && --u.refs[bt] == 0) { u.refs.erase(bt); u.store.erase(bt); }
+                    u.refs[tree_index]++;
+                    bt = tree_index;                                          // :3720
+                  }
+                }
+                if (s == bs) u.boot_counts[b]++;                              // :3728-3730
+              }
+              // a tree nobody kept is not stored
+              if (u.store.count(tree_index) && !u.refs.count(tree_index)) u.store.erase(tree_index);
+            }
+            // testInsertParsimony's tie rule (reference :2168-2176 / fastDNAparsimony.c:1224-1229)
+            if (tie_mode_ == MPF_TIE_RANDOM) {
+              if (mp < best_) hits_ = 1;
+              else if (mp == best_) hits_++;
+              if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; sel = (long)c; sel_idx = idx; sel_home = home; }
+            } else if (mp < best_) {
+              best_ = mp; sel = (long)c; sel_idx = idx; sel_home = home;
+            }
+          }
+        }
+        if (sel >= 0) {
+          insert_rec_ = candidate_record(pl, (size_t)sel);
+          remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
+        }
+        bool accept;
+        if (tie_mode_ == MPF_TIE_RANDOM) {
+          if (best_ == randomMP) iter_hits++;
+          if (best_ < randomMP) iter_hits = 1;
+          accept = (best_ < randomMP || (best_ == randomMP && tie_draw() <= 1.0 / (double)iter_hits)) &&
+                   remove_rec_ >= 0 && insert_rec_ >= 0;
+        } else {
+          accept = best_ < randomMP;
+        }
+        if (accept) {
+          if (sel < 0) { set_error("online UFBoot: accepted move without a candidate of this prune node"); return MPF_E_STATE; }
+          // the accepted candidate becomes the current tree: R_T += C[cand] - C[home]
+          if (none_pass || (j - i) > jstar) { u.rt_valid = false; }
+          else UCHK(launch_rt_update(st_, u.rt.p, u.C.p, u.Bp, u.info.p, sel_idx, sel_home));
+          moves_.push_back(Move{remove_rec_, insert_rec_, best_});
+          apply_move(remove_rec_, insert_rec_);
+          randomMP = best_;
+          moved = true;
+          if (!u.rt_valid) { int rc2 = ufb_current_tree_reps(); if (rc2) return rc2; }
+        }
+      }
+      i = j;
+      if (moved) batch = std::max(1, scan_batch_ / 4);
+      else batch = std::min(total, batch * 2);
+    }
+  } while (randomMP < startMP);
+  if (final_score) *final_score = randomMP;
+  return MPF_OK;
+}
+
+}  // namespace mpf

@@ -59,6 +59,17 @@ struct orc {
   int *moves_rem, *moves_ins;
   unsigned *moves_score;
   unsigned long long c_newview, c_eval, c_test;
+  /* UFBoot-MP online bookkeeping (IQTree::saveCurrentTree, iqtree.cpp:3271-3785, default options) */
+  int ufb_on, ufb_B, ufb_bad;
+  unsigned short *ufb_samples;    /* boot_samples_pars [B][P] */
+  double ufb_eps, ufb_cutoff;     /* params->ufboot_epsilon (0.5, tools.cpp:725), logl_cutoff */
+  double *ufb_logl;               /* boot_logl */
+  int *ufb_counts, *ufb_trees;    /* boot_counts, boot_trees */
+  double *ufb_treels;             /* treels_logl */
+  int ufb_ntrees, ufb_treels_cap;
+  int *ufb_store_idx, **ufb_store_back, ufb_nstore, ufb_store_cap;   /* topologies of the trees some sample accepted */
+  unsigned short *ufb_ptn;
+  unsigned long long ufb_draws;
 };
 
 #define NUM(r) ((r) / 3)
@@ -226,9 +237,11 @@ orc *orc_create_sankoff(int n, int P, int datatype, const unsigned char *codes, 
   return o;
 }
 
+void orc_ufboot_detach(orc *o);
 void orc_destroy(orc *o)
 {
   if (!o) return;
+  orc_ufboot_detach(o);
   free(o->cost); free(o->svec); free(o->pwgt); free(o->pscore);
   free(o->codes); free(o->wgt); free(o->inf); free(o->vec); free(o->score); free(o->persite);
   free(o->back); free(o->x); free(o->nodep); free(o->ti); free(o->trace_q); free(o->trace_mp);
@@ -580,6 +593,58 @@ static void moves_push(orc *o, int rem, int ins, unsigned score)
   o->moves_score[o->moves_len++] = score;
 }
 
+/* ---- IQTree::saveCurrentTree, maximum-parsimony branch with the default options (iqtree.cpp:3271-3785):
+        store_candidate_trees off (tools.cpp:736) => no string lookup before the cut-off test (:3343);
+        pattern scores from pllComputePatternParsimony (:3365); REPS as the exact integer sum (the auto_vectorize
+        loop :3418-3422; the Vec16us segment sums :3423-3449 are the same number whenever they do not wrap, and the
+        remain-bound skip :3435-3445 only skips samples for which neither branch below can fire); then the DEFAULT
+        update rule (:3684-3731).  The tree "string" of the reference is kept here as the back[] of the tentatively
+        inserted topology. ---- */
+static void ufb_store_tree(orc *o, int tree_index)
+{
+  int nrec = 3 * (2 * o->n - 1);
+  if (o->ufb_nstore && o->ufb_store_idx[o->ufb_nstore - 1] == tree_index) return;
+  if (o->ufb_nstore == o->ufb_store_cap) {
+    o->ufb_store_cap = o->ufb_store_cap ? 2 * o->ufb_store_cap : 64;
+    o->ufb_store_idx = (int *)realloc(o->ufb_store_idx, sizeof(int) * o->ufb_store_cap);
+    o->ufb_store_back = (int **)realloc(o->ufb_store_back, sizeof(int *) * o->ufb_store_cap);
+  }
+  o->ufb_store_idx[o->ufb_nstore] = tree_index;
+  o->ufb_store_back[o->ufb_nstore] = (int *)malloc(sizeof(int) * nrec);
+  memcpy(o->ufb_store_back[o->ufb_nstore], o->back, sizeof(int) * nrec);
+  o->ufb_nstore++;
+}
+
+static void ufb_save_current_tree(orc *o, double cur_logl)
+{
+  int tree_index, sample, ptn, test_pars;
+  if (o->ufb_cutoff != 0.0 && cur_logl <= o->ufb_cutoff - 1e-4) return;     /* :3343 */
+  tree_index = o->ufb_ntrees;                                                /* :3345-3348 */
+  if (o->ufb_ntrees == o->ufb_treels_cap) {
+    o->ufb_treels_cap = o->ufb_treels_cap ? 2 * o->ufb_treels_cap : 1024;
+    o->ufb_treels = (double *)realloc(o->ufb_treels, sizeof(double) * o->ufb_treels_cap);
+  }
+  o->ufb_treels[o->ufb_ntrees++] = cur_logl;
+  test_pars = orc_pattern_scores(o, o->ufb_ptn);                             /* :3365 */
+  if (test_pars != -(int)cur_logl) o->ufb_bad++;                             /* :3366-3367 outError */
+  for (sample = 0; sample < o->ufb_B; sample++) {                            /* :3411 */
+    const unsigned short *bs = o->ufb_samples + (size_t)sample * o->P;
+    int res = 0;
+    double rell;
+    for (ptn = 0; ptn < o->P; ptn++) res += (int)o->ufb_ptn[ptn] * (int)bs[ptn];
+    rell = -(double)res;
+    if (rell > o->ufb_logl[sample] + o->ufb_eps ||                           /* :3686-3688 */
+        (rell > o->ufb_logl[sample] - o->ufb_eps &&
+         (o->ufb_draws++, tie_draw(o)) <= 1.0 / (double)(o->ufb_counts[sample] + 1))) {
+      ufb_store_tree(o, tree_index);                                         /* :3689-3707 */
+      if (rell > o->ufb_logl[sample]) o->ufb_counts[sample] = 1;             /* :3710-3713 */
+      if (rell > o->ufb_logl[sample]) o->ufb_logl[sample] = rell;            /* :3719 max() */
+      o->ufb_trees[sample] = tree_index;                                     /* :3720 */
+    }
+    if (rell == o->ufb_logl[sample]) o->ufb_counts[sample]++;                /* :3728-3730 */
+  }
+}
+
 /* ---- insertParsimony / testInsertParsimony: sprparsimony.cpp:1942-1952, :2106-2188 ---- */
 static void insert_node(orc *o, int p, int q)
 {
@@ -597,6 +662,7 @@ static void test_insert(orc *o, int p, int q)
   mp = orc_evaluate(o, NX(NX(p)), 0);
   o->c_test++;
   trace_push(o, q, mp);
+  if (o->ufb_on) ufb_save_current_tree(o, -(double)mp);   /* :2163-2166 pllSaveCurrentTreeSprParsimony, before the tie rule */
   if (o->tie_mode == ORC_TIE_RANDOM) {                /* :2168-2176 */
     if (mp < o->best) o->hits = 1;
     else if (mp == o->best) o->hits++;
@@ -854,4 +920,67 @@ void orc_counters(const orc *o, unsigned long long *nv, unsigned long long *ev, 
   if (nv) *nv = o->c_newview;
   if (ev) *ev = o->c_eval;
   if (ts) *ts = o->c_test;
+}
+
+/* ---- UFBoot-MP attachment (IQTree::setParams' allocation, iqtree.cpp:213-262) ---- */
+void orc_ufboot_detach(orc *o)
+{
+  int i;
+  for (i = 0; i < o->ufb_nstore; i++) free(o->ufb_store_back[i]);
+  free(o->ufb_store_back); free(o->ufb_store_idx);
+  free(o->ufb_samples); free(o->ufb_logl); free(o->ufb_counts); free(o->ufb_trees); free(o->ufb_treels); free(o->ufb_ptn);
+  o->ufb_store_back = NULL; o->ufb_store_idx = NULL; o->ufb_nstore = o->ufb_store_cap = 0;
+  o->ufb_samples = NULL; o->ufb_logl = NULL; o->ufb_counts = NULL; o->ufb_trees = NULL; o->ufb_treels = NULL; o->ufb_ptn = NULL;
+  o->ufb_ntrees = o->ufb_treels_cap = 0;
+  o->ufb_on = 0;
+}
+void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsilon)
+{
+  int b;
+  orc_ufboot_detach(o);
+  o->ufb_B = B;
+  o->ufb_samples = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)B * o->P);
+  memcpy(o->ufb_samples, samples, sizeof(unsigned short) * (size_t)B * o->P);
+  o->ufb_eps = epsilon;
+  o->ufb_cutoff = 0.0;                                   /* iqtree.cpp:68 */
+  o->ufb_logl = (double *)malloc(sizeof(double) * B);
+  o->ufb_counts = (int *)calloc(B, sizeof(int));
+  o->ufb_trees = (int *)malloc(sizeof(int) * B);
+  for (b = 0; b < B; b++) { o->ufb_logl[b] = -(double)LONG_MAX; o->ufb_trees[b] = -1; }   /* :248-253 */
+  o->ufb_ptn = (unsigned short *)calloc((size_t)o->P + 16, sizeof(unsigned short));
+  o->ufb_bad = 0;
+  o->ufb_draws = 0;
+  o->ufb_on = 1;
+  orc_enable_persite(o, 1);                              /* perSiteScores = gbo_replicates > 0, sprparsimony.cpp:3245 */
+}
+void orc_ufboot_set_cutoff(orc *o, double logl_cutoff) { o->ufb_cutoff = logl_cutoff; }
+int orc_ufboot_ntrees(const orc *o) { return o->ufb_ntrees; }
+int orc_ufboot_bad(const orc *o) { return o->ufb_bad; }
+unsigned long long orc_ufboot_draws(const orc *o) { return o->ufb_draws; }
+void orc_ufboot_tree_logl(const orc *o, double *out) { memcpy(out, o->ufb_treels, sizeof(double) * o->ufb_ntrees); }
+void orc_ufboot_state(const orc *o, double *boot_logl, int *boot_counts, int *boot_trees)
+{
+  memcpy(boot_logl, o->ufb_logl, sizeof(double) * o->ufb_B);
+  memcpy(boot_counts, o->ufb_counts, sizeof(int) * o->ufb_B);
+  memcpy(boot_trees, o->ufb_trees, sizeof(int) * o->ufb_B);
+}
+int orc_ufboot_tree(const orc *o, int tree_index, int *back)
+{
+  int i;
+  for (i = o->ufb_nstore - 1; i >= 0; i--)
+    if (o->ufb_store_idx[i] == tree_index) { memcpy(back, o->ufb_store_back[i], sizeof(int) * 3 * (2 * o->n - 1)); return 1; }
+  return 0;
+}
+/* the per-iteration cut-off update, "top cutoff_percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10 tools.cpp:793) */
+static int cmp_desc(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return x < y ? 1 : x > y ? -1 : 0; }
+double orc_ufboot_next_cutoff(const orc *o, int percent)
+{
+  double *l, c;
+  if (o->ufb_ntrees <= 1000) return o->ufb_cutoff;
+  l = (double *)malloc(sizeof(double) * o->ufb_ntrees);
+  memcpy(l, o->ufb_treels, sizeof(double) * o->ufb_ntrees);
+  qsort(l, o->ufb_ntrees, sizeof(double), cmp_desc);     /* nth_element(..., greater) then [k]: the k-th largest */
+  c = l[(size_t)o->ufb_ntrees * percent / 100];
+  free(l);
+  return c;
 }

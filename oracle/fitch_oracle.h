@@ -69,6 +69,21 @@ unsigned orc_make_tree(orc *o, long seed, int spr_dist, int *perm_out /* [n+1] o
 /* stepwise addition only; per added taxon: best score and insertion record */
 unsigned orc_stepwise(orc *o, long seed, unsigned *best_per_step, int *insert_per_step);
 
+/* UFBoot-MP online bookkeeping: IQTree::saveCurrentTree (iqtree.cpp:3271-3785, default options) as called from
+   testInsertParsimony (sprparsimony.cpp:2163-2166) during orc_optimize_spr.  Parity status of this part: UNPINNED
+   (the C++ layer of the reference is not buildable from its sources alone, oracle/Makefile); restated line by line,
+   and its per-pattern vectors are cross-checked against an independent from-scratch recomputation in the tests. */
+void orc_ufboot_attach(orc *o, int B, const unsigned short *samples /* [B][P] boot_samples_pars */, double epsilon);
+void orc_ufboot_detach(orc *o);
+void orc_ufboot_set_cutoff(orc *o, double logl_cutoff);       /* 0 = none (iqtree.cpp:3343) */
+int orc_ufboot_ntrees(const orc *o);                          /* treels_logl.size() */
+int orc_ufboot_bad(const orc *o);                             /* # candidates whose pattern-score sum != mp (:3366) */
+unsigned long long orc_ufboot_draws(const orc *o);
+void orc_ufboot_tree_logl(const orc *o, double *out);
+void orc_ufboot_state(const orc *o, double *boot_logl, int *boot_counts, int *boot_trees);
+int orc_ufboot_tree(const orc *o, int tree_index, int *back); /* 1 if that tree was accepted by some sample */
+double orc_ufboot_next_cutoff(const orc *o, int percent);     /* iqtree.cpp:1662-1676 */
+
 void orc_counters(const orc *o, unsigned long long *newviews, unsigned long long *evaluates, unsigned long long *tests);
 
 #ifdef __cplusplus

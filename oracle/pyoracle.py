@@ -76,6 +76,21 @@ def lib():
         L.orc_stepwise.restype = cu
         L.orc_stepwise.argtypes = [vp, C.c_long, vp, vp]
         L.orc_counters.argtypes = [vp, vp, vp, vp]
+        L.orc_ufboot_attach.argtypes = [vp, ci, vp, C.c_double]
+        L.orc_ufboot_detach.argtypes = [vp]
+        L.orc_ufboot_set_cutoff.argtypes = [vp, C.c_double]
+        L.orc_ufboot_ntrees.restype = ci
+        L.orc_ufboot_ntrees.argtypes = [vp]
+        L.orc_ufboot_bad.restype = ci
+        L.orc_ufboot_bad.argtypes = [vp]
+        L.orc_ufboot_draws.restype = C.c_ulonglong
+        L.orc_ufboot_draws.argtypes = [vp]
+        L.orc_ufboot_tree_logl.argtypes = [vp, vp]
+        L.orc_ufboot_state.argtypes = [vp, vp, vp, vp]
+        L.orc_ufboot_tree.restype = ci
+        L.orc_ufboot_tree.argtypes = [vp, ci, vp]
+        L.orc_ufboot_next_cutoff.restype = C.c_double
+        L.orc_ufboot_next_cutoff.argtypes = [vp, ci]
         _lib = L
     return _lib
 
@@ -214,6 +229,43 @@ class Oracle:
         ins = np.zeros(self.n + 1, dtype=np.int32)
         s = lib().orc_stepwise(self.h, seed, _p(best), _p(ins))
         return int(s), best, ins
+
+    # ---- UFBoot-MP online bookkeeping (IQTree::saveCurrentTree)
+    def ufboot_attach(self, samples, epsilon: float = 0.5):
+        samples = np.ascontiguousarray(samples, dtype=np.uint16)
+        assert samples.ndim == 2 and samples.shape[1] == self.P
+        self.ufb_B = samples.shape[0]
+        lib().orc_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon))
+
+    def ufboot_set_cutoff(self, logl_cutoff: float):
+        lib().orc_ufboot_set_cutoff(self.h, float(logl_cutoff))
+
+    def ufboot_state(self):
+        logl = np.zeros(self.ufb_B, dtype=np.float64)
+        counts = np.zeros(self.ufb_B, dtype=np.int32)
+        trees = np.zeros(self.ufb_B, dtype=np.int32)
+        lib().orc_ufboot_state(self.h, _p(logl), _p(counts), _p(trees))
+        return logl, counts, trees
+
+    def ufboot_tree_logl(self):
+        out = np.zeros(lib().orc_ufboot_ntrees(self.h), dtype=np.float64)
+        if len(out):
+            lib().orc_ufboot_tree_logl(self.h, _p(out))
+        return out
+
+    def ufboot_tree(self, tree_index: int):
+        back = np.empty(self.nrec, dtype=np.int32)
+        ok = lib().orc_ufboot_tree(self.h, int(tree_index), _p(back))
+        return back if ok else None
+
+    def ufboot_bad(self):
+        return lib().orc_ufboot_bad(self.h)
+
+    def ufboot_draws(self):
+        return int(lib().orc_ufboot_draws(self.h))
+
+    def ufboot_next_cutoff(self, percent: int = 10):
+        return float(lib().orc_ufboot_next_cutoff(self.h, percent))
 
     def counters(self):
         a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()

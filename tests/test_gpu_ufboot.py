@@ -1,0 +1,151 @@
+"""Online UFBoot-MP bookkeeping (IQTree::saveCurrentTree inside pllOptimizeSprParsimony) -- device vs oracle.
+
+The oracle follows the reference literally: per-site counter arrays, pllComputePatternParsimony after every
+insertion test, REPS loop, DEFAULT update rule with its random tie-breaks.  The engine never forms a pattern vector
+per candidate: scan masks x weights on the matrix cores + an event replay.  Everything observable must be identical:
+scores, moves, the saved-tree list, boot_logl / boot_counts / boot_trees (and the topologies they name), and the
+number of random draws consumed (the SPR trajectory is coupled to it).
+"""
+import numpy as np
+import pytest
+
+from helpers import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+
+    return engine, po
+
+
+def boot_samples(P, B, seed, weights=None, heavy=False):
+    rng = np.random.default_rng(seed)
+    w = np.ones(P) if weights is None else np.asarray(weights, dtype=np.float64)
+    nsite = int(w.sum())
+    s = rng.multinomial(nsite, w / w.sum(), size=B)
+    if heavy:
+        s[:, : max(1, P // 50)] += rng.integers(100, 400, size=(B, max(1, P // 50)))   # > 127: second weight plane
+    return s.astype(np.uint16)
+
+
+def run_both(engine, po, fx, start_back, samples, seed, maxtrav=6, cutoff=0.0, eps=0.5, keep_all=False, opts=None):
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], keep_all=keep_all)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], keep_all=keep_all)
+    for k, v in (opts or {}).items():
+        e.set_option(k, v)
+    e.set_tree(start_back)
+    o.set_tree(start_back)
+    e.seed_ties(engine.TIE_RANDOM, seed)
+    o.seed_ties(po.TIE_RANDOM, seed)
+    e.ufboot_attach(samples, eps)
+    o.ufboot_attach(samples, eps)
+    if cutoff:
+        e.ufboot_set_cutoff(cutoff)
+        o.ufboot_set_cutoff(cutoff)
+    o.trace(True)
+    se = e.optimize_spr(1, maxtrav)
+    so = o.optimize_spr(1, maxtrav)
+    return e, o, se, so
+
+
+def assert_same(e, o, se, so):
+    assert se == so
+    assert o.ufboot_bad() == 0
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+    le, ce, te = e.ufboot_state()
+    lo, co, to = o.ufboot_state()
+    assert le.tolist() == lo.tolist()
+    assert ce.tolist() == co.tolist()
+    assert te.tolist() == to.tolist()
+    assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+    for t in sorted(set(te.tolist())):
+        if t >= 0:
+            assert (e.ufboot_tree(t) == o.ufboot_tree(t)).all()
+
+
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa"])
+@pytest.mark.parametrize("seed", [3, 11])
+def test_online_bookkeeping_matches_oracle(mods, name, seed):
+    engine, po = mods
+    fx = load_fixture(name)
+    samples = boot_samples(len(fx["weights"]), 37, seed, fx["weights"])
+    start = np.array(fx["trees"][seed % len(fx["trees"])]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, seed)
+    assert_same(e, o, se, so)
+    assert e.ufboot_counters()["events"] > 0
+
+
+@pytest.mark.parametrize("opts", [{"scan_batch": 1}, {"scan_batch": 7, "split_below": 0}, {"scan_batch": 64, "split_below": 1000},
+                                  {"words_per_lane": 2}, {"reduce": 1, "xcd_map": 0}])
+def test_batching_and_kernel_options_do_not_change_the_result(mods, opts):
+    engine, po = mods
+    fx = load_fixture("dna_ambig")
+    samples = boot_samples(len(fx["weights"]), 20, 5, fx["weights"])
+    start = np.array(fx["trees"][1]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 17, opts=opts)
+    assert_same(e, o, se, so)
+
+
+def test_cutoff_filter_and_next_cutoff(mods):
+    engine, po = mods
+    fx = load_fixture("dna_clean")
+    samples = boot_samples(len(fx["weights"]), 25, 9, fx["weights"])
+    start = np.array(fx["trees"][2]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 21)
+    assert_same(e, o, se, so)
+    cut_e, cut_o = e.ufboot_next_cutoff(10), o.ufboot_next_cutoff(10)
+    assert cut_e == cut_o and cut_e != 0.0
+    # second climb (as the next search iteration would) under that cut-off, from another tree
+    n_before = len(o.ufboot_tree_logl())
+    start2 = np.array(fx["trees"][3]["back"], dtype=np.int32)
+    for x in (e, o):
+        x.ufboot_set_cutoff(cut_e)
+        x.set_tree(start2)
+    se, so = e.optimize_spr(1, 6), o.optimize_spr(1, 6)
+    assert se == so
+    assert len(o.ufboot_tree_logl()) > n_before
+    le, ce, te = e.ufboot_state()
+    lo, co, to = o.ufboot_state()
+    assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+    assert (le.tolist(), ce.tolist(), te.tolist()) == (lo.tolist(), co.tolist(), to.tolist())
+    assert (e.ufboot_tree_logl()[n_before:] > cut_e - 1e-4).all()
+
+
+def test_heavy_weights_use_a_second_plane(mods):
+    engine, po = mods
+    fx = load_fixture("dna_clean")
+    samples = boot_samples(len(fx["weights"]), 18, 2, fx["weights"], heavy=True)
+    assert samples.max() > 127
+    start = np.array(fx["trees"][0]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 5)
+    assert_same(e, o, se, so)
+
+
+def test_keep_all_sites_and_small_radius(mods):
+    engine, po = mods
+    fx = load_fixture("dna_ambig")
+    samples = boot_samples(len(fx["weights"]), 12, 4, fx["weights"])
+    start = np.array(fx["trees"][4]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 8, maxtrav=3, keep_all=True)
+    assert_same(e, o, se, so)
+
+
+def test_unsupported_configurations_fail_loudly(mods):
+    engine, po = mods
+    fx = load_fixture("dna_clean")
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    samples = boot_samples(len(fx["weights"]), 4, 1)
+    with pytest.raises(engine.MpfError):
+        e.ufboot_attach(samples, 2.0)
+    with pytest.raises(engine.MpfError):
+        e.ufboot_next_cutoff(10)
+    cost = (1 - np.eye(4)).astype(np.uint32)
+    s = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    with pytest.raises(engine.MpfError):
+        s.ufboot_attach(samples)
