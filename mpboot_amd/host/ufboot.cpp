@@ -117,7 +117,7 @@ int Engine::ufboot_tree(int64_t tree_index, int32_t *back) const
   if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
   auto it = ufb_->store.find(tree_index);
   if (it == ufb_->store.end()) { set_error("tree is not referenced by any bootstrap sample"); return MPF_E_INVALID; }
-  std::memcpy(back, it->second.data(), it->second.size() * sizeof(int32_t));
+  std::memcpy(back, it->second.data(), 3 * (size_t)(2 * n_ - 1) * sizeof(int32_t));
   return MPF_OK;
 }
 
