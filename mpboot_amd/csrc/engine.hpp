@@ -11,6 +11,7 @@
 
 #include <cstdint>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <string>
 #include <utility>
@@ -102,10 +103,13 @@ struct UfbState {
   std::vector<int32_t> boot_counts;
   std::vector<int64_t> boot_trees;
   std::vector<uint32_t> treels;                  // treels_logl as lengths
-  std::map<int64_t, std::vector<int32_t>> store; // topologies of the trees some sample currently points to
-  std::map<int64_t, int> refs;
-  uint64_t draws = 0, events = 0, gemm_rows = 0;
+  std::unordered_map<int64_t, std::vector<int32_t>> store;   // topologies of the trees some sample currently points to
+  std::vector<int32_t> refs;                     // per saved tree: number of samples whose boot_trees entry names it
+  struct Pending { int64_t tree_index; uint32_t cand; };      // accepted during the current prune node, not yet materialised
+  std::vector<Pending> pending;
+  uint64_t draws = 0, events = 0, gemm_rows = 0, batches = 0, stored = 0;
   double gemm_ms = 0.0;
+  double t_scan = 0, t_prep = 0, t_dev = 0, t_sort = 0, t_replay = 0, t_rt = 0;   // host wall-clock split (ms), MPF_UFB_PROFILE=1 prints it
   // device
   DevBuf<uint8_t> wt;                            // [planes][Wp/2][Bp/16][4][16][16] signed bytes
   size_t plane_bytes = 0;
@@ -214,6 +218,7 @@ class Engine {
   int ufb_reserve_scan(size_t n_idx);
   int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)
   void ufb_store_tree(int64_t tree_index, int remove_rec, int insert_rec);
+  void ufb_flush_pending(const ScanPlan &pl);
 
   int addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step);
   void apply_move(int remove_rec, int insert_rec);

@@ -18,6 +18,8 @@
 // that reach the running minimum in scan order (a chunked prefix-min), and the host replays just those events.
 #include "ufboot.hpp"
 
+#include <algorithm>
+
 namespace mpf {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -44,24 +46,39 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // 16-column group is the 1 KiB the MFMA B-fragments of a wave read lane-linearly:
 //     Wt[((kblk * (Bp/16) + cg) * 4 + h) * 16 + c][j]  = weight of site 64 kblk + 16 h + j in sample 16 cg + c
 // (h = lane >> 4, c = lane & 15, j = byte in the lane's 16-byte fragment).  The A fragment of lane (r = lane & 15, h)
-// is the same 16 sites of row r, expanded from bits to bytes in registers: nibble * 0x00204081 & 0x01010101.
-// Workgroup = 2 x 2 waves, wave tile = (16 MT) x (16 NT); C = acc * mult (+ C if accumulate).
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
-                                                 int Bp, int32_t *__restrict__ C, int mult, int accumulate, int row_blocks)
+// is the same 16 sites of row r, expanded from bits to bytes in registers: nibble * 0x00204081 & 0x01010101
+// (both operands use the same (h, j) -> site map, so the sum over k is the intended one whatever order the
+// hardware assigns to the 64 k values).
+// Workgroup = 8 waves (4 x 2), tile 256 rows x 256 samples, wave tile 64 x 128 (4 x 8 MFMA tiles, 128 accumulator
+// registers): each weight byte is fetched once per 256 rows and each expanded A fragment feeds 8 MFMAs.  Two k-blocks
+// per stage, double-buffered in LDS (global -> registers -> LDS while the previous stage is multiplied).
+// blockIdx.y splits K; partial products are added with integer atomics (exact, order-independent).
+constexpr int kGemmKS = 2;                           // k-blocks per stage
+constexpr int kGemmAStride = 2 * kGemmKS + 1;        // words per row of the A stage tile (+1: bank spread)
+
+__global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
+                                                 int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
+                                                 int kb_per_split)
 {
-  constexpr int TM = 32 * MT, TN = 32 * NT;          // workgroup tile
-  constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile
-  __shared__ __attribute__((aligned(16))) uint8_t s_b[2][BT];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int MT = 4, NT = 8, TM = 256, TN = 256, KS = kGemmKS;
+  constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
+  __shared__ __attribute__((aligned(16))) uint8_t s_b[2][KS][BT];
+  __shared__ uint32_t s_a[2][TM * kGemmAStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  // column block fastest: with Bp / TN == 8 every XCD (blockIdx % 8) streams ONE column block of Wt through its L2
+  // workgroups are dealt round-robin to the 8 XCDs: the 32 concurrent workgroups of an XCD share ONE column block,
+  // so its slab of Wt streams through that XCD's L2 once per round
   const int col_blocks = Bp / TN;
-  const int cb = blockIdx.x % col_blocks, rb = blockIdx.x / col_blocks;
+  const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+  const int per = 8 / (col_blocks < 8 ? col_blocks : 8);       // XCDs per column block (col_blocks in {1,2,4,8,...})
+  int cb, rb;
+  if (col_blocks <= 8 && (8 % col_blocks) == 0) { cb = xcd % col_blocks; rb = grp * per + xcd / col_blocks; }
+  else { cb = (int)(blockIdx.x % (unsigned)col_blocks); rb = (int)(blockIdx.x / (unsigned)col_blocks); }
   if (rb >= row_blocks) return;
   const int r = lane & 15, h = lane >> 4;
-  const int row0 = rb * TM + wr * 16 * MT, col0 = cb * TN + wc * 16 * NT;
   const int nkb = Wp >> 1;
+  const int kb_begin = blockIdx.y * kb_per_split, kb_end = min(nkb, kb_begin + kb_per_split);
+  if (kb_begin >= kb_end) return;
 
   v4i acc[MT][NT];
 #pragma unroll
@@ -69,64 +86,67 @@ __global__ __launch_bounds__(256) void k_bitgemm(const uint32_t *__restrict__ ma
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[i][j] = (v4i){0, 0, 0, 0};
 
-  // B tile of k-block kb: the TN/16 column groups of this block are contiguous in Wt
   const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
   const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
-  constexpr int LD = BT / (256 * 16);                // 16-byte loads per thread per k-block
-  uint4 breg[LD];
-  uint32_t areg[MT];
-  const uint32_t *arow[MT];
-#pragma unroll
-  for (int i = 0; i < MT; i++) arow[i] = masks + (size_t)(row0 + 16 * i + r) * Wp + (h >> 1);
-
-  auto gload = [&](int kb) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(wt_tile + (size_t)kb * wt_kstride);
-#pragma unroll
-    for (int i = 0; i < LD; i++) breg[i] = src[threadIdx.x + 256 * i];
-#pragma unroll
-    for (int i = 0; i < MT; i++) areg[i] = arow[i][2 * kb];
-  };
-  gload(0);
-  {
-    uint4 *dst = reinterpret_cast<uint4 *>(s_b[0]);
-#pragma unroll
-    for (int i = 0; i < LD; i++) dst[threadIdx.x + 256 * i] = breg[i];
-  }
-  uint32_t acur[MT];
-#pragma unroll
-  for (int i = 0; i < MT; i++) acur[i] = areg[i];
+  // stage registers (named scalars: arrays captured by a lambda end up in scratch)
+  uint4 b00, b01, b10, b11, areg = make_uint4(0, 0, 0, 0);
+  const uint32_t *arow = masks + (size_t)(rb * TM + (tid & 255)) * Wp;
+  static_assert(BT == 512 * 16 * 2 && KS == 2, "stage copy below is written for 2 k-blocks of 16 KiB and 512 threads");
+#define MPF_GLOAD(kb_)                                                                                   \
+  do {                                                                                                   \
+    const int k0_ = min((kb_), nkb - 2), k1_ = min((kb_) + 1, nkb - 1);                                   \
+    const uint4 *s0_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)k0_ * wt_kstride);              \
+    const uint4 *s1_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)k1_ * wt_kstride);              \
+    b00 = s0_[tid]; b01 = s0_[tid + 512]; b10 = s1_[tid]; b11 = s1_[tid + 512];                          \
+    if (tid < 256) areg = *reinterpret_cast<const uint4 *>(arow + 2 * k0_);                               \
+  } while (0)
+#define MPF_LSTORE(buf_)                                                                                 \
+  do {                                                                                                   \
+    uint4 *d0_ = reinterpret_cast<uint4 *>(s_b[buf_][0]);                                                 \
+    uint4 *d1_ = reinterpret_cast<uint4 *>(s_b[buf_][1]);                                                 \
+    d0_[tid] = b00; d0_[tid + 512] = b01; d1_[tid] = b10; d1_[tid + 512] = b11;                          \
+    if (tid < 256) {                                                                                     \
+      uint32_t *a_ = s_a[buf_] + tid * kGemmAStride;                                                      \
+      a_[0] = areg.x; a_[1] = areg.y; a_[2] = areg.z; a_[3] = areg.w;                                    \
+    }                                                                                                    \
+  } while (0)
+  MPF_GLOAD(kb_begin);
+  MPF_LSTORE(0);
   __syncthreads();
 
-  for (int kb = 0; kb < nkb; kb++) {
-    const int cur = kb & 1;
-    if (kb + 1 < nkb) gload(kb + 1);
-    // B fragments: column group (wc * NT + j) of the tile, lane-linear 16 bytes
-    v4i bf[NT];
+  int buf = 0;
+  for (int kb = kb_begin; kb < kb_end; kb += KS) {
+    MPF_GLOAD(kb + KS);                              // clamped: the last stage prefetches a valid block it never uses
 #pragma unroll
-    for (int j = 0; j < NT; j++)
-      bf[j] = *reinterpret_cast<const v4i *>(s_b[cur] + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+    for (int s = 0; s < KS; s++) {
+      if (kb + s < kb_end) {
+        v4i bf[NT];
 #pragma unroll
-    for (int i = 0; i < MT; i++) {
-      const uint32_t bits = (acur[i] >> ((h & 1) * 16)) & 0xFFFFu;
-      v4i af;
-      af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
-      af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-      af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-      af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+        for (int j = 0; j < NT; j++)
+          bf[j] = *reinterpret_cast<const v4i *>(s_b[buf][s] + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
 #pragma unroll
-      for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; i++) {
+          const uint32_t word = s_a[buf][(wr * 64 + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
+          const uint32_t bits = (word >> ((h & 1) * 16)) & 0xFFFFu;
+          v4i af;
+          af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
+          af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+          af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+          af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+#pragma unroll
+          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
     }
-    if (kb + 1 < nkb) {
-      uint4 *dst = reinterpret_cast<uint4 *>(s_b[cur ^ 1]);
-#pragma unroll
-      for (int i = 0; i < LD; i++) dst[threadIdx.x + 256 * i] = breg[i];
-#pragma unroll
-      for (int i = 0; i < MT; i++) acur[i] = areg[i];
-    }
+    MPF_LSTORE(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
 
+#undef MPF_GLOAD
+#undef MPF_LSTORE
   // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
+  const int row0 = rb * TM + wr * 64, col0 = cb * TN + wc * 128;
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -137,7 +157,8 @@ __global__ __launch_bounds__(256) void k_bitgemm(const uint32_t *__restrict__ ma
         const int row = row0 + 16 * i + 4 * h + q;
         int32_t *p = C + (size_t)row * Bp + col;
         const int v = acc[i][j][q] * mult;
-        *p = accumulate ? *p + v : v;
+        if (atomic) { if (v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else *p = v;
       }
     }
 }
@@ -250,8 +271,24 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
 {
   if (rows_padded <= 0) return hipSuccess;
   const int row_blocks = rows_padded / kUfbRowTile, col_blocks = Bp / kUfbColTile;
-  hipLaunchKernelGGL((k_bitgemm<kUfbRowTile / 32, kUfbColTile / 32>), dim3((unsigned)(row_blocks * col_blocks)), dim3(256), 0, st,
-                     masks, Wp, Wt, Bp, C, mult, accumulate, row_blocks);
+  const int nkb = Wp / 2;
+  // small batches: split K so that the launch still has a few workgroups per CU
+  long tiles = (long)row_blocks * col_blocks;
+  int ksplit = 1;
+  if (tiles < 512) ksplit = (int)std::min<long>((512 + tiles - 1) / tiles, std::max(1, nkb / 16));
+  int per = (nkb + ksplit - 1) / ksplit;
+  per = (per + 1) & ~1;                                  // stages start on even k-blocks (16-byte aligned A loads)
+  ksplit = (nkb + per - 1) / per;
+  const int atomic = (ksplit > 1 || accumulate) ? 1 : 0;
+  if (atomic && !accumulate) {
+    hipError_t e = hipMemsetAsync(C, 0, (size_t)rows_padded * (size_t)Bp * sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+  }
+  // grid.x covers the XCD-aware (row block, column block) map of the kernel
+  unsigned gx;
+  if (col_blocks <= 8 && 8 % col_blocks == 0) { const int per_x = 8 / col_blocks; gx = (unsigned)(((row_blocks + per_x - 1) / per_x) * 8); }
+  else gx = (unsigned)(row_blocks * col_blocks);
+  hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), 0, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per);
   return hipGetLastError();
 }
 

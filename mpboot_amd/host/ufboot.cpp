@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../csrc/engine.hpp"
@@ -22,6 +25,7 @@ namespace mpf {
   } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon)
 {
@@ -70,7 +74,14 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   return MPF_OK;
 }
 
-void Engine::ufboot_detach() { ufb_.reset(); }
+void Engine::ufboot_detach()
+{
+  if (ufb_ && std::getenv("MPF_UFB_PROFILE"))
+    std::fprintf(stderr, "[ufboot] batches %llu events %llu stored %llu | ms: scan %.1f prep %.1f device %.1f sort %.1f replay %.1f rt %.1f (product kernels %.1f)\n",
+                 (unsigned long long)ufb_->batches, (unsigned long long)ufb_->events, (unsigned long long)ufb_->stored, ufb_->t_scan,
+                 ufb_->t_prep, ufb_->t_dev, ufb_->t_sort, ufb_->t_replay, ufb_->t_rt, ufb_->gemm_ms);
+  ufb_.reset();
+}
 
 int Engine::ufboot_set_cutoff(double logl_cutoff)
 {
@@ -173,6 +184,17 @@ int Engine::ufb_current_tree_reps()
   return MPF_OK;
 }
 
+// topologies of the trees accepted during the scan of one prune node that are still some sample's boot tree
+void Engine::ufb_flush_pending(const ScanPlan &pl)
+{
+  UfbState &u = *ufb_;
+  for (const UfbState::Pending &pe : u.pending) {
+    if (u.refs[(size_t)pe.tree_index] <= 0) continue;
+    ufb_store_tree(pe.tree_index, pe.cand < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, (size_t)pe.cand));
+  }
+  u.pending.clear();
+}
+
 void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
 {
   UfbState &u = *ufb_;
@@ -185,6 +207,7 @@ void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
   hk(nx(p), q);
   hk(nx(nx(p)), r);
   u.store.emplace(tree_index, std::move(bk));
+  u.stored++;
 }
 
 // pllOptimizeSprParsimony's sweep loop (reference sprparsimony.cpp:3295-3316) with perSiteScores = 1, i.e. with
@@ -207,10 +230,14 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     int i = 1;
     while (i <= total) {
       const int hi = std::min(total, i + batch - 1);
+      double t0 = now_ms();
       scan_masks_ = true;
       int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
       scan_masks_ = false;
       if (rc) return rc;
+      double t1 = now_ms();
+      u.t_scan += t1 - t0;
+      u.batches++;
       const int np = hi - i + 1;
       // ---- the first prune node with a strictly better candidate ends the batch for certain: nothing behind it
       //      needs REPS (a tie may end it earlier; then the tail of the product is simply not used)
@@ -237,6 +264,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         }
       }
       uint32_t n_ev = 0;
+      t0 = now_ms();
+      u.t_prep += t0 - t1;
       if (n_idx > 0 && !none_pass) {
         const int rows_p = round_up((int)n_idx, kUfbRowTile);
         // staging: thr[n_parts] | home[n_parts] | best[Bp]
@@ -285,12 +314,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
         }
+        t1 = now_ms();
+        u.t_dev += t1 - t0;
         events.assign(u.h_ev.p, u.h_ev.p + n_ev);
         std::sort(events.begin(), events.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
         u.events += n_ev;
+        t0 = now_ms();
+        u.t_sort += t0 - t1;
       } else {
         events.clear();
       }
+      t0 = now_ms();
       // ---- host replay in the reference's order
       size_t ep = 0;
       bool moved = false;
@@ -313,6 +347,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             if (!none_pass && mp <= mp_max) {
               const int64_t tree_index = (int64_t)u.treels.size();          // iqtree.cpp:3345-3348
               u.treels.push_back(mp);
+              u.refs.push_back(0);
               while (ep < events.size() && events[ep].idx < idx) ep++;
               for (; ep < events.size() && events[ep].idx == idx; ep++) {
                 const uint32_t b = events[ep].b, s = events[ep].s;
@@ -324,19 +359,19 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
                   accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
                 }
                 if (accept) {
-                  ufb_store_tree(tree_index, c < (size_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, c));
+                  // the tree "string" (:3689-3707): remembered as (prune node, candidate) and materialised after this
+                  // prune node's scan only if some sample still points to it by then
+                  if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, (uint32_t)c});
                   if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
                   int64_t &bt = u.boot_trees[b];
                   if (bt != tree_index) {
-                    if (bt >= 0 && --u.refs[bt] == 0) { u.refs.erase(bt); u.store.erase(bt); }
-                    u.refs[tree_index]++;
+                    if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
+                    u.refs[(size_t)tree_index]++;
                     bt = tree_index;                                          // :3720
                   }
                 }
                 if (s == bs) u.boot_counts[b]++;                              // :3728-3730
               }
-              // a tree nobody kept is not stored
-              if (u.store.count(tree_index) && !u.refs.count(tree_index)) u.store.erase(tree_index);
             }
             // testInsertParsimony's tie rule (reference :2168-2176 / fastDNAparsimony.c:1224-1229)
             if (tie_mode_ == MPF_TIE_RANDOM) {
@@ -352,6 +387,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           insert_rec_ = candidate_record(pl, (size_t)sel);
           remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
         }
+        ufb_flush_pending(pl);
         bool accept;
         if (tie_mode_ == MPF_TIE_RANDOM) {
           if (best_ == randomMP) iter_hits++;
@@ -376,6 +412,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       i = j;
       if (moved) batch = std::max(1, scan_batch_ / 4);
       else batch = std::min(total, batch * 2);
+      u.t_replay += now_ms() - t0;
     }
   } while (randomMP < startMP);
   if (final_score) *final_score = randomMP;
