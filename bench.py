@@ -28,6 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+I8_PEAK_TOPS = 5000.0      # dense int8 MFMA, 2 x bf16 (MI355X_MICROARCH.md, matrix cores)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
     ap.add_argument("--bootstrap-replicates", type=int, default=48,
                     help="per GPU: re-weighted refinement climbs timed after the main metric (0 = skip)")
+    ap.add_argument("--ufboot-samples", type=int, default=1000,
+                    help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
+                         "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,6 +180,29 @@ def main():
         boot = (n_rep, tb, float(np.mean(bscores)))
         eng.set_weights(w0)
 
+    # online UFBoot-MP (-bb 1000): the SPR climb from the rank's start tree with IQTree::saveCurrentTree's bookkeeping
+    # after EVERY insertion test (candidate masks -> binary x int8 MFMA product -> event replay)
+    ufb = None
+    if args.ufboot_samples > 0:
+        B = args.ufboot_samples
+        samples = np.random.default_rng(4242 + rank).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
+        for timed in (False, True):                # first pass: allocations, code load
+            eng.ufboot_attach(samples)
+            eng.set_tree(back)
+            eng.reset_node_order()
+            eng.seed_ties(engine.TIE_RANDOM, 1 + rank)
+            eng.reset_stats()
+            barrier()
+            tu0 = time.perf_counter()
+            us = eng.optimize_spr(1, args.maxtrav)
+            barrier()
+            tu = time.perf_counter() - tu0
+        ust, ucn = eng.stats(), eng.ufboot_counters()
+        ufb = {"samples": B, "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
+               "saved_trees": len(eng.ufboot_tree_logl()), **ucn}
+        eng.ufboot_detach()
+        eng.set_tree(back)
+
     tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
@@ -259,6 +286,40 @@ def main():
             res["bootstrap_wall_clock"]["cpu_baseline"] = {
                 "per_1000_replicates_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "replicate 0 on the scalar C oracle",
                 "same_score_as_gpu": bool(int(bscores[0]) == int(s_cpu))}
+        if ufb is not None:
+            algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples"]
+            kms = ufb["reps_kernel_ms"]
+            top = algo_ops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+            res["ufboot_online"] = {
+                "what": "one pllOptimizeSprParsimony call (radius %d) from this rank's start tree with online UFBoot-MP bookkeeping "
+                        "for %d bootstrap samples: cut-off filter, REPS of every insertion test, per-sample update rule with the "
+                        "reference's tie draws (rank 0 shown; every rank runs its own start tree)" % (args.maxtrav, ufb["samples"]),
+                "seconds": ufb["seconds"], "insertion_tests": ufb["insertion_tests"], "moves": ufb["moves"],
+                "tests_per_s": ufb["insertion_tests"] / ufb["seconds"], "saved_trees": ufb["saved_trees"],
+                "events": ufb["events"], "tie_draws": ufb["tie_draws"], "score": ufb["score"],
+                "roofline": {"bound": "mfma", "achieved": top, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": top / I8_PEAK_TOPS,
+                             "kernel": "k_bitgemm", "kernel_ms_total": kms, "rows": ufb["reps_rows"],
+                             "note": "achieved = 2 x insertion tests x sites x samples (the algorithmic REPS work; padding rows, "
+                                     "home-edge rows and padding samples not counted) / HIP-event time of the product kernels; "
+                                     "peak = dense int8 MFMA (2 x the 2.5 PFLOP/s bf16 figure)"}}
+            if not args.no_cpu and world == 1:
+                from oracle import pyoracle as po
+                o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
+                o.seed_ties(po.TIE_RANDOM, 1)
+                o.ufboot_attach(np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=ufb["samples"]).astype(np.uint16))
+                o.set_best(o.score_tree(back))
+                nodep = o.nodep()
+                tc0 = time.perf_counter()
+                k0, i = o.counters()[2], 1
+                while time.perf_counter() - tc0 < min(args.cpu_budget, 10.0) and i <= 2 * n - 2:
+                    o.rearrange(int(nodep[i]), 1, args.maxtrav)
+                    i += 1
+                tc = time.perf_counter() - tc0
+                kc = o.counters()[2] - k0
+                res["ufboot_online"]["cpu_baseline"] = {
+                    "value": kc / tc, "unit": "insertion tests/s (with REPS for all samples)", "cores": 1, "kind": "port",
+                    "sample": "%d prune nodes (%d insertion tests) of the same sweep on the C oracle, AVX2 REPS loop" % (i - 1, kc)}
+                res["ufboot_online"]["gpu_over_cpu"] = res["ufboot_online"]["tests_per_s"] / (kc / tc)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(codes, back, names, letters, alphabet, args.maxtrav, args.cpu_budget)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
