@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // registers): each weight byte is fetched once per 256 rows and each expanded A fragment feeds 8 MFMAs.  Two k-blocks
 // per stage, double-buffered in LDS (global -> registers -> LDS while the previous stage is multiplied).
 // blockIdx.y splits K; partial products are added with integer atomics (exact, order-independent).
-constexpr int kGemmKS = 2;                           // k-blocks per stage
+constexpr int kGemmKS = 4;                           // k-blocks per stage
 constexpr int kGemmAStride = 2 * kGemmKS + 1;        // words per row of the A stage tile (+1: bank spread)
 
 __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
@@ -62,17 +62,20 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
 {
   constexpr int MT = 4, NT = 8, TM = 256, TN = 256, KS = kGemmKS;
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
-  __shared__ __attribute__((aligned(16))) uint8_t s_b[2][KS][BT];
-  __shared__ uint32_t s_a[2][TM * kGemmAStride];
+  constexpr int LD = BT / (512 * 16);                // 16-byte loads per thread per k-block (2)
+  constexpr int AL = KS / 2;                         // 16-byte loads per row of the A stage tile
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+  // [2][KS][BT] weights, then [2][TM * kGemmAStride] mask words
+  uint8_t *s_b = s_raw;
+  uint32_t *s_a = reinterpret_cast<uint32_t *>(s_raw + 2 * KS * BT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   // workgroups are dealt round-robin to the 8 XCDs: the 32 concurrent workgroups of an XCD share ONE column block,
   // so its slab of Wt streams through that XCD's L2 once per round
   const int col_blocks = Bp / TN;
   const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
-  const int per = 8 / (col_blocks < 8 ? col_blocks : 8);       // XCDs per column block (col_blocks in {1,2,4,8,...})
   int cb, rb;
-  if (col_blocks <= 8 && (8 % col_blocks) == 0) { cb = xcd % col_blocks; rb = grp * per + xcd / col_blocks; }
+  if (col_blocks <= 8 && (8 % col_blocks) == 0) { cb = xcd % col_blocks; rb = grp * (8 / col_blocks) + xcd / col_blocks; }
   else { cb = (int)(blockIdx.x % (unsigned)col_blocks); rb = (int)(blockIdx.x / (unsigned)col_blocks); }
   if (rb >= row_blocks) return;
   const int r = lane & 15, h = lane >> 4;
@@ -88,27 +91,37 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
 
   const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
   const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
-  // stage registers (named scalars: arrays captured by a lambda end up in scratch)
-  uint4 b00, b01, b10, b11, areg = make_uint4(0, 0, 0, 0);
   const uint32_t *arow = masks + (size_t)(rb * TM + (tid & 255)) * Wp;
-  static_assert(BT == 512 * 16 * 2 && KS == 2, "stage copy below is written for 2 k-blocks of 16 KiB and 512 threads");
-#define MPF_GLOAD(kb_)                                                                                   \
-  do {                                                                                                   \
-    const int k0_ = min((kb_), nkb - 2), k1_ = min((kb_) + 1, nkb - 1);                                   \
-    const uint4 *s0_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)k0_ * wt_kstride);              \
-    const uint4 *s1_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)k1_ * wt_kstride);              \
-    b00 = s0_[tid]; b01 = s0_[tid + 512]; b10 = s1_[tid]; b11 = s1_[tid + 512];                          \
-    if (tid < 256) areg = *reinterpret_cast<const uint4 *>(arow + 2 * k0_);                               \
+  uint4 breg[KS][LD], areg[AL];
+#pragma unroll
+  for (int i = 0; i < AL; i++) areg[i] = make_uint4(0, 0, 0, 0);
+
+  // stage copy, written inline (constant indices only, so the stage registers stay registers).
+  // kb_ is a multiple of KS below nkb (nkb % KS == 0): blocks past kb_end are fetched but never multiplied.
+#define MPF_GLOAD(kb_)                                                                            \
+  do {                                                                                            \
+    const int kq_ = min((kb_), nkb - KS);                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
+      const uint4 *src_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)(kq_ + s_) * wt_kstride); \
+      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) breg[s_][i_] = src_[tid + 512 * i_];      \
+    }                                                                                             \
+    if (tid < 256) {                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++)                                           \
+        areg[i_] = *reinterpret_cast<const uint4 *>(arow + 2 * kq_ + 4 * i_);                     \
+    }                                                                                             \
   } while (0)
-#define MPF_LSTORE(buf_)                                                                                 \
-  do {                                                                                                   \
-    uint4 *d0_ = reinterpret_cast<uint4 *>(s_b[buf_][0]);                                                 \
-    uint4 *d1_ = reinterpret_cast<uint4 *>(s_b[buf_][1]);                                                 \
-    d0_[tid] = b00; d0_[tid + 512] = b01; d1_[tid] = b10; d1_[tid + 512] = b11;                          \
-    if (tid < 256) {                                                                                     \
-      uint32_t *a_ = s_a[buf_] + tid * kGemmAStride;                                                      \
-      a_[0] = areg.x; a_[1] = areg.y; a_[2] = areg.z; a_[3] = areg.w;                                    \
-    }                                                                                                    \
+#define MPF_LSTORE(buf_)                                                                          \
+  do {                                                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
+      uint4 *dst_ = reinterpret_cast<uint4 *>(s_b + ((size_t)(buf_) * KS + s_) * BT);             \
+      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) dst_[tid + 512 * i_] = breg[s_][i_];      \
+    }                                                                                             \
+    if (tid < 256) {                                                                              \
+      uint32_t *a_ = s_a + (size_t)(buf_) * (TM * kGemmAStride) + tid * kGemmAStride;             \
+      _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++) {                                         \
+        a_[4 * i_] = areg[i_].x; a_[4 * i_ + 1] = areg[i_].y; a_[4 * i_ + 2] = areg[i_].z; a_[4 * i_ + 3] = areg[i_].w; \
+      }                                                                                           \
+    }                                                                                             \
   } while (0)
   MPF_GLOAD(kb_begin);
   MPF_LSTORE(0);
@@ -117,16 +130,18 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
   int buf = 0;
   for (int kb = kb_begin; kb < kb_end; kb += KS) {
     MPF_GLOAD(kb + KS);                              // clamped: the last stage prefetches a valid block it never uses
+    const uint8_t *sb = s_b + (size_t)buf * KS * BT;
+    const uint32_t *sa = s_a + (size_t)buf * (TM * kGemmAStride);
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       if (kb + s < kb_end) {
         v4i bf[NT];
 #pragma unroll
         for (int j = 0; j < NT; j++)
-          bf[j] = *reinterpret_cast<const v4i *>(s_b[buf][s] + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+          bf[j] = *reinterpret_cast<const v4i *>(sb + (size_t)s * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
 #pragma unroll
         for (int i = 0; i < MT; i++) {
-          const uint32_t word = s_a[buf][(wr * 64 + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
+          const uint32_t word = sa[(wr * 64 + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
           const uint32_t bits = (word >> ((h & 1) * 16)) & 0xFFFFu;
           v4i af;
           af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
@@ -142,9 +157,9 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
     __syncthreads();
     buf ^= 1;
   }
-
 #undef MPF_GLOAD
 #undef MPF_LSTORE
+
   // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
   const int row0 = rb * TM + wr * 64, col0 = cb * TN + wc * 128;
 #pragma unroll
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
       }
     }
 }
+constexpr size_t kGemmLds = 2 * (size_t)kGemmKS * 256 * 64 + 2 * (size_t)256 * kGemmAStride * sizeof(uint32_t);
 
 // R_T[b] = sum over rows of C[row][b]
 __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
@@ -277,7 +293,7 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   int ksplit = 1;
   if (tiles < 512) ksplit = (int)std::min<long>((512 + tiles - 1) / tiles, std::max(1, nkb / 16));
   int per = (nkb + ksplit - 1) / ksplit;
-  per = (per + 1) & ~1;                                  // stages start on even k-blocks (16-byte aligned A loads)
+  per = (per + kGemmKS - 1) / kGemmKS * kGemmKS;         // stages start on multiples of the stage depth
   ksplit = (nkb + per - 1) / per;
   const int atomic = (ksplit > 1 || accumulate) ? 1 : 0;
   if (atomic && !accumulate) {
@@ -288,7 +304,13 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   unsigned gx;
   if (col_blocks <= 8 && 8 % col_blocks == 0) { const int per_x = 8 / col_blocks; gx = (unsigned)(((row_blocks + per_x - 1) / per_x) * 8); }
   else gx = (unsigned)(row_blocks * col_blocks);
-  hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), 0, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per);
+  static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs the opt-in once per process
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), kGemmLds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per);
   return hipGetLastError();
 }
 
