@@ -825,6 +825,10 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
     }
     if (check_counts_) HIPCHK(hipMemcpyAsync(h_ncand_.p, d_ncand_.p, nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    if (scan_masks_ && nout) {
+      HIPCHK(ufb_->h_info.reserve(nout));
+      HIPCHK(hipMemcpyAsync(ufb_->h_info.p, ufb_->info.p, nout * sizeof(uint2), hipMemcpyDeviceToHost, st_));
+    }
     HIPCHK(hipStreamSynchronize(st_));
     if (check_counts_)
       for (size_t i = 0; i < nd; i++)

@@ -116,6 +116,10 @@ struct UfbState {
   DevBuf<uint32_t> masks;                        // [rows padded to kUfbRowTile][Wp]
   DevBuf<uint2> info;                            // per scan output index: (mask row, part) | (.., ~0) for a home slot
   DevBuf<int32_t> C;                             // [rows padded][Bp]
+  DevBuf<uint32_t> jmasks;                       // join masks of the current tree (R_T from scratch)
+  DevBuf<int32_t> C2;                            // [kUfbRowTile][Bp]: product of single rows (move outside the saved set)
+  DevBuf<uint32_t> sel2;
+  PinBuf<uint2> h_info;                          // host copy of info (same synchronisation as the scan results)
   DevBuf<int32_t> rt;                            // [Bp] REPS of the current tree (lengths)
   DevBuf<uint32_t> best;                         // [Bp] boot_score on the device (padding columns: 0 -> never an event)
   DevBuf<uint32_t> thr, home, cmin, pre, evcount;

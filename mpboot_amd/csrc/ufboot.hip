@@ -58,7 +58,7 @@ constexpr int kGemmAStride = 2 * kGemmKS + 1;        // words per row of the A s
 
 __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
-                                                 int kb_per_split)
+                                                 int kb_per_split, const uint32_t *__restrict__ rowsel)
 {
   constexpr int MT = 4, NT = 8, TM = 256, TN = 256, KS = kGemmKS;
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
@@ -91,7 +91,9 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
 
   const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
   const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
-  const uint32_t *arow = masks + (size_t)(rb * TM + (tid & 255)) * Wp;
+  // output row i multiplies mask row rowsel[i] (cut-off filter: only the candidates that are saved), or row i itself
+  const uint32_t arow_id = rowsel ? rowsel[rb * TM + (tid & 255)] : (uint32_t)(rb * TM + (tid & 255));
+  const uint32_t *arow = masks + (size_t)arow_id * Wp;
   uint4 breg[KS][LD], areg[AL];
 #pragma unroll
   for (int i = 0; i < AL; i++) areg[i] = make_uint4(0, 0, 0, 0);
@@ -191,11 +193,10 @@ __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, i
 
 // R_T += C[row] - C[home]   (the accepted move's candidate becomes the current tree)
 __global__ __launch_bounds__(256) void k_rt_update(int32_t *__restrict__ rt, const int32_t *__restrict__ C, int Bp,
-                                                   const uint2 *__restrict__ info, uint32_t idx, uint32_t home)
+                                                   uint32_t row, uint32_t home)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
-  const uint32_t row = info[idx].x;
   rt[b] += C[(size_t)row * Bp + b] - C[(size_t)home * Bp + b];
 }
 
@@ -204,14 +205,18 @@ __global__ __launch_bounds__(256) void k_rt_update(int32_t *__restrict__ rt, con
 // slot).  info[i] = (mask row, part) for a candidate, (.., 0xFFFFFFFF) for a home slot; a candidate takes part in
 // the bookkeeping iff cost[i] < thr[part] (the logl_cutoff filter, iqtree.cpp:3343; thr = largest admissible cost + 1).
 // score(i, b) = R_T[b] - C[home(part)][b] + C[row(i)][b]   (parsimony length of candidate i under sample b)
+// crow (optional): scan output index -> row of C when only the saved candidates were multiplied
 __device__ __forceinline__ bool ufb_score(uint32_t i, int b, const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
                                           const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
-                                          const int32_t *__restrict__ C, int Bp, int32_t rt, int32_t &s)
+                                          const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int32_t rt,
+                                          int32_t &s)
 {
   const uint2 in = info[i];
   if (in.y == 0xFFFFFFFFu) return false;
   if (cost[i] >= thr[in.y]) return false;
-  s = rt - C[(size_t)home[in.y] * Bp + b] + C[(size_t)in.x * Bp + b];
+  const uint32_t hi = home[in.y];
+  const uint32_t rc = crow ? crow[i] : in.x, rh = crow ? crow[hi] : hi;
+  s = rt - C[(size_t)rh * Bp + b] + C[(size_t)rc * Bp + b];
   return true;
 }
 
@@ -219,8 +224,8 @@ constexpr int kUfbChunk = 64;
 
 __global__ __launch_bounds__(256) void k_ufb_chunkmin(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
                                                       const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
-                                                      const int32_t *__restrict__ C, int Bp, const int32_t *__restrict__ rt,
-                                                      uint32_t n_idx, uint32_t *__restrict__ cmin)
+                                                      const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp,
+                                                      const int32_t *__restrict__ rt, uint32_t n_idx, uint32_t *__restrict__ cmin)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t chunk = blockIdx.y;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void k_ufb_chunkmin(const uint2 *__restrict__ 
   uint32_t m = 0xFFFFFFFFu;
   for (uint32_t i = i0; i < i1; i++) {
     int32_t s;
-    if (ufb_score(i, b, info, cost, thr, home, C, Bp, r, s)) m = min(m, (uint32_t)s);
+    if (ufb_score(i, b, info, cost, thr, home, crow, C, Bp, r, s)) m = min(m, (uint32_t)s);
   }
   cmin[(size_t)chunk * Bp + b] = m;
 }
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(256) void k_ufb_prefix(const uint32_t *__restrict__
 // reference's update rule can fire (rell > boot_logl - epsilon with 0 < epsilon < 1 and integer scores)
 __global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
                                                     const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
-                                                    const int32_t *__restrict__ C, int Bp, int B, const int32_t *__restrict__ rt,
-                                                    uint32_t n_idx, const uint32_t *__restrict__ pre,
+                                                    const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int B,
+                                                    const int32_t *__restrict__ rt, uint32_t n_idx, const uint32_t *__restrict__ pre,
                                                     UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ in
   uint32_t run = pre[(size_t)chunk * Bp + b];
   for (uint32_t i = i0; i < i1; i++) {
     int32_t s;
-    if (!ufb_score(i, b, info, cost, thr, home, C, Bp, r, s)) continue;
+    if (!ufb_score(i, b, info, cost, thr, home, crow, C, Bp, r, s)) continue;
     if ((uint32_t)s <= run) {
       const uint32_t at = atomicAdd(ev_count, 1u);
       if (at < ev_cap) ev[at] = UfbEvent{i, (uint32_t)b, (uint32_t)s};
@@ -283,7 +288,7 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
 }
 
 hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                          int mult, int accumulate)
+                          int mult, int accumulate, const uint32_t *rowsel)
 {
   if (rows_padded <= 0) return hipSuccess;
   const int row_blocks = rows_padded / kUfbRowTile, col_blocks = Bp / kUfbColTile;
@@ -310,7 +315,7 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), kGemmLds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per);
+  hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), kGemmLds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
 }
 
@@ -320,24 +325,24 @@ hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int
   return hipGetLastError();
 }
 
-hipError_t launch_rt_update(hipStream_t st, int32_t *rt, const int32_t *C, int Bp, const uint2 *info, uint32_t idx, uint32_t home)
+hipError_t launch_rt_update(hipStream_t st, int32_t *rt, const int32_t *C, int Bp, uint32_t row, uint32_t home)
 {
-  hipLaunchKernelGGL(k_rt_update, dim3((Bp + 255) / 256), dim3(256), 0, st, rt, C, Bp, info, idx, home);
+  hipLaunchKernelGGL(k_rt_update, dim3((Bp + 255) / 256), dim3(256), 0, st, rt, C, Bp, row, home);
   return hipGetLastError();
 }
 
 uint32_t ufb_chunks(uint32_t n_idx) { return (n_idx + kUfbChunk - 1) / kUfbChunk; }
 
 hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
-                             const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
+                             const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
                              uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count)
 {
   if (n_idx == 0) return hipSuccess;
   const uint32_t nc = ufb_chunks(n_idx);
   dim3 grid((Bp + 255) / 256, nc), block(256);
-  hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, C, Bp, rt, n_idx, cmin);
+  hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, rt, n_idx, cmin);
   hipLaunchKernelGGL(k_ufb_prefix, dim3((Bp + 255) / 256), block, 0, st, cmin, best, Bp, nc, pre);
-  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count);
+  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count);
   return hipGetLastError();
 }
 

@@ -14,15 +14,17 @@ constexpr int kUfbRowTile = 256, kUfbColTile = 256;   // k_bitgemm workgroup til
 // masks[op][Wp] = sites mutating on join (a, b)
 hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops, uint32_t *masks);
 // C[rows_padded][Bp] = (accumulate ? C : 0) + mult * masks x Wt; rows_padded % kUfbRowTile == 0, Bp % kUfbColTile == 0
+// rowsel (optional, rows_padded entries): output row i multiplies mask row rowsel[i]
 hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                          int mult, int accumulate);
+                          int mult, int accumulate, const uint32_t *rowsel = nullptr);
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt);
-// rt += C[info[idx].x] - C[home]
-hipError_t launch_rt_update(hipStream_t st, int32_t *rt, const int32_t *C, int Bp, const uint2 *info, uint32_t idx, uint32_t home);
+// rt += C[row] - C[home]
+hipError_t launch_rt_update(hipStream_t st, int32_t *rt, const int32_t *C, int Bp, uint32_t row, uint32_t home);
 uint32_t ufb_chunks(uint32_t n_idx);
 // cmin, pre: scratch of ufb_chunks(n_idx) * Bp words each
+// crow (optional): scan output index -> row of C (compacted product)
 hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
-                             const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
+                             const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
                              uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count);
 
 }  // namespace mpf

@@ -171,13 +171,13 @@ int Engine::ufb_current_tree_reps()
   }
   const int rows = (int)ops.size(), rows_p = round_up(rows, kUfbRowTile);
   UCHK(d_evops_.reserve(ops.size()));
-  UCHK(u.masks.reserve((size_t)rows_p * (size_t)g_.Wp));
+  UCHK(u.jmasks.reserve((size_t)rows_p * (size_t)g_.Wp));
   UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
   UCHK(hipMemcpyAsync(d_evops_.p, ops.data(), ops.size() * sizeof(EvOp), hipMemcpyHostToDevice, st_));
-  UCHK(hipMemsetAsync(u.masks.p + (size_t)rows * g_.Wp, 0, (size_t)(rows_p - rows) * g_.Wp * sizeof(uint32_t), st_));
-  UCHK(launch_join_masks(st_, g_, d_vec_, d_evops_.p, rows, u.masks.p));
+  UCHK(hipMemsetAsync(u.jmasks.p + (size_t)rows * g_.Wp, 0, (size_t)(rows_p - rows) * g_.Wp * sizeof(uint32_t), st_));
+  UCHK(launch_join_masks(st_, g_, d_vec_, d_evops_.p, rows, u.jmasks.p));
   for (int pl = 0; pl < u.planes; pl++)
-    UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0));
+    UCHK(launch_bitgemm(st_, u.jmasks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0));
   UCHK(launch_colsum(st_, u.C.p, rows, u.Bp, u.rt.p));
   UCHK(hipStreamSynchronize(st_));     // ops (host vector) must outlive the copy
   u.rt_valid = true;
@@ -222,7 +222,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   const uint32_t *out = nullptr;
   int batch = std::max(1, scan_batch_);
   std::vector<UfbEvent> events;
-  std::vector<uint32_t> small;
+  std::vector<uint32_t> small, sel, crow;
+  bool have_C = false;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
   do {
     startMP = randomMP;
@@ -266,10 +267,42 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       uint32_t n_ev = 0;
       t0 = now_ms();
       u.t_prep += t0 - t1;
-      if (n_idx > 0 && !none_pass) {
-        const int rows_p = round_up((int)n_idx, kUfbRowTile);
-        // staging: thr[n_parts] | home[n_parts] | best[Bp]
-        small.assign((size_t)2 * n_parts + (size_t)u.Bp, 0u);
+      // with a cut-off only the saved candidates (and the home rows of their parts) are multiplied: `sel` lists their
+      // mask rows, crow maps a scan output index to its row of C
+      const uint2 *hinfo = u.h_info.p;
+      const bool compact = have_cut && !none_pass;
+      uint32_t n_rows = n_idx;
+      if (compact) {
+        sel.clear();
+        crow.assign((size_t)n_idx, 0xFFFFFFFFu);
+        for (int j = 0; j <= jstar; j++) {
+          const ScanPlan &pl = plans[(size_t)j];
+          if (mp_max < pl.base) continue;
+          const uint32_t lim_cost = mp_max - pl.base;
+          for (int pi = 0; pi < pl.n_parts; pi++) {
+            bool any = false;
+            for (int k = 0; k < pl.part_cnt[pi]; k++) {
+              const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
+              if (out[idx] > lim_cost) continue;
+              crow[idx] = (uint32_t)sel.size();
+              sel.push_back(hinfo[idx].x);
+              any = true;
+            }
+            if (any) {
+              const uint32_t hidx = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
+              crow[hidx] = (uint32_t)sel.size();
+              sel.push_back(hidx);
+            }
+          }
+        }
+        n_rows = (uint32_t)sel.size();
+      }
+      have_C = false;
+      if (n_idx > 0 && !none_pass && n_rows > 0) {
+        const int rows_p = round_up((int)n_rows, kUfbRowTile);
+        // staging: thr[n_parts] | home[n_parts] | best[Bp] | crow[n_idx] | sel[rows_p]
+        const size_t o_crow = (size_t)2 * n_parts + (size_t)u.Bp, o_sel = o_crow + (compact ? (size_t)n_idx : 0);
+        small.assign(o_sel + (compact ? (size_t)rows_p : 0), 0u);
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
           for (int pi = 0; pi < pl.n_parts; pi++) {
@@ -279,6 +312,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           }
         }
         for (int b = 0; b < u.B; b++) small[(size_t)2 * n_parts + (size_t)b] = u.boot_score[(size_t)b];
+        if (compact) {
+          std::memcpy(small.data() + o_crow, crow.data(), (size_t)n_idx * sizeof(uint32_t));
+          std::memcpy(small.data() + o_sel, sel.data(), sel.size() * sizeof(uint32_t));      // padding rows multiply mask row 0
+        }
         UCHK(u.h_small.reserve(small.size() + 4));
         std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
         UCHK(u.thr.reserve(small.size() + 4));
@@ -289,14 +326,16 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
         UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
         const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
+        const uint32_t *d_crow = compact ? u.thr.p + o_crow : nullptr, *d_sel = compact ? u.thr.p + o_sel : nullptr;
         if (timing_) UCHK(hipEventRecord(ev2_, st_));
         for (int pl = 0; pl < u.planes; pl++)
-          UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0));
+          UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0, d_sel));
         if (timing_) UCHK(hipEventRecord(ev3_, st_));
         u.gemm_rows += (uint64_t)rows_p;
+        have_C = true;
         while (true) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
-          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, u.C.p, u.Bp, u.B, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
+          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.B, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
                                  u.ev.p, (uint32_t)u.ev.cap, u.evcount.p));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
@@ -400,13 +439,32 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         if (accept) {
           if (sel < 0) { set_error("online UFBoot: accepted move without a candidate of this prune node"); return MPF_E_STATE; }
           // the accepted candidate becomes the current tree: R_T += C[cand] - C[home]
-          if (none_pass || (j - i) > jstar) { u.rt_valid = false; }
-          else UCHK(launch_rt_update(st_, u.rt.p, u.C.p, u.Bp, u.info.p, sel_idx, sel_home));
+          {
+            uint32_t rc_ = 0xFFFFFFFFu, rh_ = 0xFFFFFFFFu;
+            if (have_C && sel_idx < n_idx) {
+              if (compact) { rc_ = crow[sel_idx]; rh_ = crow[sel_home]; }
+              else { rc_ = hinfo[sel_idx].x; rh_ = sel_home; }
+            }
+            if (rc_ != 0xFFFFFFFFu && rh_ != 0xFFFFFFFFu) {
+              UCHK(launch_rt_update(st_, u.rt.p, u.C.p, u.Bp, rc_, rh_));
+            } else {
+              // its rows were not part of the product (outside the saved set): multiply just these two mask rows
+              UCHK(u.sel2.reserve((size_t)kUfbRowTile));
+              UCHK(u.C2.reserve((size_t)kUfbRowTile * (size_t)u.Bp));
+              UCHK(u.h_small.reserve((size_t)kUfbRowTile + 4));
+              for (int z = 0; z < kUfbRowTile; z++) u.h_small.p[z] = sel_home;
+              u.h_small.p[0] = hinfo[sel_idx].x;
+              UCHK(hipMemcpyAsync(u.sel2.p, u.h_small.p, (size_t)kUfbRowTile * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+              for (int pl2 = 0; pl2 < u.planes; pl2++)
+                UCHK(launch_bitgemm(st_, u.masks.p, kUfbRowTile, g_.Wp, u.wt.p + (size_t)pl2 * u.plane_bytes, u.Bp, u.C2.p, 1 << (7 * pl2), pl2 > 0, u.sel2.p));
+              UCHK(launch_rt_update(st_, u.rt.p, u.C2.p, u.Bp, 0u, 1u));
+              UCHK(hipStreamSynchronize(st_));       // h_small is reused by the next batch
+            }
+          }
           moves_.push_back(Move{remove_rec_, insert_rec_, best_});
           apply_move(remove_rec_, insert_rec_);
           randomMP = best_;
           moved = true;
-          if (!u.rt_valid) { int rc2 = ufb_current_tree_reps(); if (rc2) return rc2; }
         }
       }
       i = j;

@@ -201,3 +201,33 @@ def parse_topology_line(tokens: list[str], n: int) -> np.ndarray:
         r, b = tok.split(":")
         back[int(r)] = int(b)
     return back
+
+
+def apply_spr(back: np.ndarray, p: int, q: int) -> np.ndarray:
+    """Prune node record p (it keeps the subtree behind back[p]) and regraft it on branch (q, back[q])
+    -- removeNodeParsimony + insertParsimony of the reference (sprparsimony.cpp:2245-2257, :1942-1952)."""
+    b = np.array(back, dtype=np.int32).copy()
+    a1, a2 = int(b[nxt(p)]), int(b[nxt(nxt(p))])
+    b[a1], b[a2] = a2, a1
+    r = int(b[q])
+    b[nxt(p)], b[q] = q, nxt(p)
+    b[nxt(nxt(p))], b[r] = r, nxt(nxt(p))
+    return b
+
+
+def random_spr_moves(engine_obj, back: np.ndarray, rng: np.random.Generator, k: int, maxtrav: int = 6) -> np.ndarray:
+    """k random SPR moves within the given radius (a stand-in for the search's perturbation step): the prune node
+    and the regraft branch are drawn uniformly from what rearrangeParsimony would test."""
+    n = n_taxa_of(back)
+    b = np.array(back, dtype=np.int32).copy()
+    done = 0
+    while done < k:
+        v = int(rng.integers(n + 1, 2 * n - 1))
+        rec = 3 * v + int(rng.integers(0, 3))
+        engine_obj.set_tree(b)
+        q, _mp, n_p = engine_obj.spr_scan(rec, 1, maxtrav)
+        if n_p == 0:
+            continue
+        b = apply_spr(b, rec, int(q[int(rng.integers(0, n_p))]))
+        done += 1
+    return b

@@ -62,4 +62,17 @@ for b in range(min(a.verify, a.samples)):
     rell = -int((ptn.astype(np.int64) * samples[b]).sum())
     assert rell == int(logl[b]), (b, rell, logl[b])
 print(f"verified {min(a.verify, a.samples)} samples: boot_logl equals the REPS of the kept tree recomputed from per-pattern lengths")
+
+# a later search iteration: cut-off from the saved trees (top 10 %), perturbed tree, climb again
+from mpboot_amd import trees as _trees
+cut = e.ufboot_next_cutoff(10)
+e.ufboot_set_cutoff(cut)
+pert = _trees.random_spr_moves(e, final, np.random.default_rng(a.seed + 5), 30)
+e.set_tree(pert); e.reset_node_order()
+s_pert = e.score_tree()
+n_before = len(e.ufboot_tree_logl()); c0 = e.ufboot_counters(); e.reset_stats()
+t4 = time.perf_counter(); s2 = e.optimize_spr(1, 6); t5 = time.perf_counter()
+st2 = e.stats(); c1 = e.ufboot_counters()
+print(f"next iteration: cut-off {-cut:.0f}; 30 random SPR moves -> {s_pert}; climb -> {s2} in {t5-t4:.3f}s ({st2['insertion_tests']} tests, {st2['moves_applied']} moves, "
+      f"{len(e.ufboot_tree_logl()) - n_before} saved, REPS rows {c1['reps_rows'] - c0['reps_rows']}, product {c1['reps_kernel_ms'] - c0['reps_kernel_ms']:.1f} ms, events {c1['events'] - c0['events']})")
 e.ufboot_detach()
