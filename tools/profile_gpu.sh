@@ -1,20 +1,34 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + separate PMC passes of the bench command.
+#   main leg   : bench.py --steps 5 --warmup 1 with the bootstrap/UFBoot legs off, so that every k_scan_walk dispatch is
+#                one of the timed sweep scans and the per-kernel averages are comparable with bench.py's own HIP-event timing
+#   ufboot leg : bench.py --steps 1 --warmup 0 with only the online-UFBoot leg on (k_bitgemm and friends)
 # Usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
-  N=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py $ARGS > $OUT/bench_pmc_$N.json 2> $OUT/pmc_$N.err
-done
-python3 tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
-# keep only the small artefacts (the raw per-dispatch CSVs exceed gpurun's 64 MiB return limit)
-mkdir -p $OUT/keep
-find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/keep/kernel_stats.csv \;
-rm -rf $OUT/trace $OUT/pmc_*
-cat $OUT/summary.txt
+run_leg () {   # name, bench args, counter groups...
+  local NAME=$1 ARGS=$2; shift 2
+  local D=$OUT/$NAME
+  mkdir -p $D
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 bench.py $ARGS > $D/bench_trace.json 2> $D/trace.err
+  for C in "$@"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-60)
+    rocprofv3 --pmc $C --output-format csv -d $D/pmc_$N -- python3 bench.py $ARGS > $D/bench_pmc_$N.json 2> $D/pmc_$N.err
+  done
+  python3 tools/profile_summary.py $D > $D/summary.txt 2>&1
+  # keep only the small artefacts (the raw per-dispatch CSVs exceed gpurun's 64 MiB return limit)
+  find $D/trace -name "*kernel_stats.csv" -exec cp {} $D/kernel_stats.csv \;
+  rm -rf $D/trace $D/pmc_*
+}
+run_leg main "--steps 5 --warmup 1 --no-cpu --bootstrap-replicates 0 --ufboot-samples 0 $*" \
+  FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
+  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
+  "SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" GRBM_GUI_ACTIVE
+run_leg ufboot "--steps 1 --warmup 0 --no-cpu --bootstrap-replicates 0 $*" \
+  FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
+  "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES" \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" GRBM_GUI_ACTIVE
+cat $OUT/main/summary.txt $OUT/ufboot/summary.txt
