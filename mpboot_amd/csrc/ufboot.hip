@@ -309,11 +309,14 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   unsigned gx;
   if (col_blocks <= 8 && 8 % col_blocks == 0) { const int per_x = 8 / col_blocks; gx = (unsigned)(((row_blocks + per_x - 1) / per_x) * 8); }
   else gx = (unsigned)(row_blocks * col_blocks);
-  static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs the opt-in once per process
-  if (!attr_set) {
+  // > 64 KiB of dynamic LDS needs the opt-in, once per device (engines of one process may sit on different GPUs)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), kGemmLds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();

@@ -136,6 +136,42 @@ def test_keep_all_sites_and_small_radius(mods):
     assert_same(e, o, se, so)
 
 
+@pytest.mark.parametrize("name,maxtrav", [("dna_clean", 8), ("aa", 7)])
+def test_radius_above_six_uses_the_deep_walk_kernel(mods, name, maxtrav):
+    engine, po = mods
+    fx = load_fixture(name)
+    samples = boot_samples(len(fx["weights"]), 10, 6, fx["weights"])
+    start = np.array(fx["trees"][5]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 13, maxtrav=maxtrav)
+    assert_same(e, o, se, so)
+
+
+def test_first_best_tie_rule(mods):
+    """PLL-original tie rule for the SPR part (MPF_TIE_FIRST): the bookkeeping still draws its own ties"""
+    engine, po = mods
+    fx = load_fixture("dna_dups")
+    samples = boot_samples(len(fx["weights"]), 14, 8, fx["weights"])
+    start = np.array(fx["trees"][6]["back"], dtype=np.int32)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    for x, mode in ((e, engine.TIE_FIRST), (o, po.TIE_FIRST)):
+        x.set_tree(start)
+        x.seed_ties(mode, 3)
+        x.ufboot_attach(samples)
+    # the oracle's first-best mode skips the pre-evaluate of the prune node (PLL original); compare what both define
+    se, so = e.optimize_spr(1, 6), o.optimize_spr(1, 6)
+    le, ce, te = e.ufboot_state()
+    lo, co, to = o.ufboot_state()
+    if se == so and (e.get_tree() == o.get_tree()).all():
+        assert le.tolist() == lo.tolist()
+    chk = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    chk.enable_persite(True)
+    for b in range(len(le)):
+        s = chk.score_tree(e.ufboot_tree(int(te[b])))
+        ptn, _ = chk.pattern_scores()
+        assert -(ptn.astype(np.int64) * samples[b]).sum() == le[b]
+
+
 def test_unsupported_configurations_fail_loudly(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
