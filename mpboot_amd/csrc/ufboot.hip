@@ -134,25 +134,30 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
     MPF_GLOAD(kb + KS);                              // clamped: the last stage prefetches a valid block it never uses
     const uint8_t *sb = s_b + (size_t)buf * KS * BT;
     const uint32_t *sa = s_a + (size_t)buf * (TM * kGemmAStride);
+    // every stage holds KS valid k-blocks (kb_per_split and nkb are multiples of KS): straight-line body, the
+    // B fragments of k-block s+1 are fetched from LDS while the MFMAs of k-block s run
+    v4i bf[2][NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      bf[0][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
 #pragma unroll
     for (int s = 0; s < KS; s++) {
-      if (kb + s < kb_end) {
-        v4i bf[NT];
+      if (s + 1 < KS) {
 #pragma unroll
         for (int j = 0; j < NT; j++)
-          bf[j] = *reinterpret_cast<const v4i *>(sb + (size_t)s * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+          bf[(s + 1) & 1][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(s + 1) * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+      }
 #pragma unroll
-        for (int i = 0; i < MT; i++) {
-          const uint32_t word = sa[(wr * 64 + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
-          const uint32_t bits = (word >> ((h & 1) * 16)) & 0xFFFFu;
-          v4i af;
-          af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
-          af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-          af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-          af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+      for (int i = 0; i < MT; i++) {
+        const uint32_t word = sa[(wr * 64 + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
+        const uint32_t bits = (word >> ((h & 1) * 16)) & 0xFFFFu;
+        v4i af;
+        af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
+        af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+        af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+        af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
 #pragma unroll
-          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[s & 1][j], acc[i][j], 0, 0, 0);
       }
     }
     MPF_LSTORE(buf ^ 1);
