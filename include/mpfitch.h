@@ -169,6 +169,23 @@ int mpf_stepwise_addition(mpf_engine *e, int64_t seed, uint32_t *best_per_step /
 int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t *insert_rec, uint32_t *score,
                   int32_t *n_moves);
 
+/* Lower-bound helpers of the reference's parsimony path (host arithmetic, no device needed).  The reference uses them
+   to leave its CPU loops early (REPS skip iqtree.cpp:3435-3445, Sankoff evaluate sprparsimony.cpp:946-955); the engine
+   computes exact full sums, so nothing in this library depends on them.
+     mpf_min_pars_score_patterns : pllCalcMinParsScorePattern (sprparsimony.cpp:2513-2547) for every pattern
+     mpf_mst_scores              : ParsTree::findMstScore (parstree.cpp:606-680) for every pattern
+     mpf_segment_patterns        : IQTree::doSegmenting (iqtree.cpp:3793-3820)
+     mpf_remain_bounds           : IQTree::pllComputeRellRemainBound (iqtree.cpp:3842-3853) / pllRemainderLowerBounds
+                                   (sprparsimony.cpp:2813-2819) for one weight vector */
+int mpf_min_pars_score_patterns(int32_t datatype, int32_t n_taxa, int32_t n_patterns, const uint8_t *codes /* [n][P] PLL tip codes */,
+                                int32_t *min_score /* [P] */);
+int mpf_mst_scores(int32_t n_states, const uint32_t *cost /* [S*S] */, int32_t n_taxa, int32_t n_patterns,
+                   const int8_t *states /* [n][P] IQ-TREE state codes */, uint32_t *mst /* [P] */);
+int mpf_segment_patterns(int32_t n_patterns, int32_t n_informative, int32_t vcsize, const int32_t *ras_pars_score,
+                         const int32_t *frequency, int32_t *segment_upper /* [P] */, int32_t *n_segments);
+int mpf_remain_bounds(int32_t n_units, int32_t n_segments, const int32_t *segment_upper, const int32_t *min_unit_pars,
+                      const uint16_t *weight, int32_t *remain /* [n_segments - 1] */);
+
 /* Online UFBoot-MP bookkeeping -- what IQTree::saveCurrentTree (iqtree.cpp:3271-3785, default options) does when
    testInsertParsimony calls it after EVERY insertion test of pllOptimizeSprParsimony (sprparsimony.cpp:2163-2166,
    perSiteScores = gbo_replicates > 0, :3245).  With a tracker attached, mpf_optimize_spr additionally

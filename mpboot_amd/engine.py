@@ -27,6 +27,7 @@ EXPORTS = [
     "mpf_set_option", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
     "mpf_ufboot_attach", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
+    "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
 ]
 
 
@@ -104,6 +105,10 @@ def load_library():
         L.mpf_ufboot_get_state.argtypes = [vp, vp, vp, vp]
         L.mpf_ufboot_get_tree.argtypes = [vp, C.c_int64, vp]
         L.mpf_ufboot_get_counters.argtypes = [vp, vp, vp, vp, vp]
+        L.mpf_min_pars_score_patterns.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp]
+        L.mpf_mst_scores.argtypes = [C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
+        L.mpf_segment_patterns.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        L.mpf_remain_bounds.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -115,6 +120,43 @@ def _p(a):
 def _chk(rc):
     if rc != 0:
         raise MpfError(rc, load_library().mpf_last_error().decode())
+
+
+def min_pars_score_patterns(codes: np.ndarray, datatype: int = DNA) -> np.ndarray:
+    """pllCalcMinParsScorePattern for every pattern (host only)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(codes.shape[1], dtype=np.int32)
+    _chk(load_library().mpf_min_pars_score_patterns(datatype, codes.shape[0], codes.shape[1], _p(codes), _p(out)))
+    return out
+
+
+def mst_scores(states: np.ndarray, cost: np.ndarray) -> np.ndarray:
+    """ParsTree::findMstScore for every pattern (host only); states = IQ-TREE codes [n][P]."""
+    states = np.ascontiguousarray(states, dtype=np.int8)
+    cost = np.ascontiguousarray(cost, dtype=np.uint32)
+    out = np.zeros(states.shape[1], dtype=np.uint32)
+    _chk(load_library().mpf_mst_scores(cost.shape[0], _p(cost), states.shape[0], states.shape[1], _p(states), _p(out)))
+    return out
+
+
+def segment_patterns(ras_pars_score, frequency, n_informative: int, vcsize: int = 16) -> np.ndarray:
+    """IQTree::doSegmenting: returns segment_upper[0 .. n_segments)."""
+    r = np.ascontiguousarray(ras_pars_score, dtype=np.int32)
+    f = np.ascontiguousarray(frequency, dtype=np.int32)
+    up = np.zeros(len(r), dtype=np.int32)
+    k = C.c_int32()
+    _chk(load_library().mpf_segment_patterns(len(r), n_informative, vcsize, _p(r), _p(f), _p(up), C.byref(k)))
+    return up[:k.value].copy()
+
+
+def remain_bounds(segment_upper, min_unit_pars, weight) -> np.ndarray:
+    """remain[s] = sum over positions >= segment_upper[s] of min_unit_pars * weight (all but the last segment)."""
+    up = np.ascontiguousarray(segment_upper, dtype=np.int32)
+    m = np.ascontiguousarray(min_unit_pars, dtype=np.int32)
+    w = np.ascontiguousarray(weight, dtype=np.uint16)
+    out = np.zeros(max(len(up) - 1, 1), dtype=np.int32)
+    _chk(load_library().mpf_remain_bounds(len(m), len(up), _p(up), _p(m), _p(w), _p(out)))
+    return out[:len(up) - 1]
 
 
 def encode_iqtree_states(states: np.ndarray, datatype: int = DNA) -> np.ndarray:
