@@ -67,3 +67,43 @@ def run_replicates(eng, weights, n_rep: int, base_seed: int, radius: int = 6, st
                     local[b], trees[b] = s, t
     scores, _best, _owner = shard.reduce_best(local, n_rep)
     return scores, trees
+
+
+def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6):
+    """The refinement step of UFBoot-MP, IQTree::optimizeBootTrees default branch (iqtree.cpp:2797-2862): for every
+    bootstrap sample b the alignment is re-weighted with boot_samples_pars[b] (modifyPatternFreq :2520), the sample's
+    tree from the online phase (boot_trees[b]) is read back and ONE SPR hill climb is run from it (:2837); the result
+    replaces boot_trees[b] / boot_logl[b] (:2860-2861).
+
+    samples: [B][P] weights; boot_trees: [B][nrec] topologies (mpf_ufboot_get_tree per sample).  Sample b is refined on
+    rank b % world (and on engine k of that rank's list); every replicate draws its ties from its own stream so the
+    result does not depend on the sharding.  Returns (scores[B] after the all-reduce, {b: refined tree} of this rank)."""
+    samples = np.asarray(samples)
+    B = samples.shape[0]
+    rank, ws = shard.world()
+    units = shard.units_of_rank(B, rank, ws)
+    engines = eng if isinstance(eng, (list, tuple)) else [eng]
+
+    def one(e, b):
+        e.set_weights(samples[b].astype(np.int32))
+        e.seed_ties(1, shard.unit_seed(base_seed, b))
+        e.reset_node_order()
+        e.set_tree(np.asarray(boot_trees[b], dtype=np.int32))
+        return e.optimize_spr(1, radius), e.get_tree()
+
+    local, trees = {}, {}
+    if len(engines) == 1:
+        for b in units:
+            local[b], trees[b] = one(engines[0], b)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(k):
+            return {b: one(engines[k], b) for b in units[k::len(engines)]}
+
+        with ThreadPoolExecutor(len(engines)) as ex:
+            for part in ex.map(work, range(len(engines))):
+                for b, (sc, t) in part.items():
+                    local[b], trees[b] = sc, t
+    scores, _best, _owner = shard.reduce_best(local, B)
+    return scores, trees

@@ -172,6 +172,53 @@ def test_first_best_tie_rule(mods):
         assert -(ptn.astype(np.int64) * samples[b]).sum() == le[b]
 
 
+def test_online_phase_then_refinement_matches_oracle(mods):
+    """-bb end of run: boot trees of the online phase refined per sample (IQTree::optimizeBootTrees, default branch)"""
+    engine, po = mods
+    from mpboot_amd import bootstrap
+
+    fx = load_fixture("dna_ambig")
+    B = 9
+    samples = boot_samples(len(fx["weights"]), B, 12, fx["weights"])
+    start = np.array(fx["trees"][2]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 4)
+    assert_same(e, o, se, so)
+    _l, _c, te = e.ufboot_state()
+    boot_trees = [e.ufboot_tree(int(t)) for t in te]
+    # engine side: two engines on the GPU, oracle side: the same call on the CPU stand-in
+    e2 = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    e3 = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    sc_e, tr_e = bootstrap.refine_boot_trees([e2, e3], samples, boot_trees, 77, 6)
+
+    class OracleAsEngine:
+        def __init__(self):
+            self.o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+
+        def set_weights(self, w):
+            self.o.set_weights(w)
+
+        def seed_ties(self, mode, seed):
+            self.o.seed_ties(mode, seed)
+
+        def reset_node_order(self):
+            self.o.reset_nodep()
+
+        def set_tree(self, back):
+            self.o.set_tree(back)
+
+        def optimize_spr(self, a, b):
+            return self.o.optimize_spr(a, b)
+
+        def get_tree(self):
+            return self.o.get_tree()
+
+    sc_o, tr_o = bootstrap.refine_boot_trees(OracleAsEngine(), samples, boot_trees, 77, 6)
+    assert sc_e.tolist() == sc_o.tolist()
+    for b in range(B):
+        assert (tr_e[b] == tr_o[b]).all()
+        assert sc_e[b] <= -_l[b]                    # refinement never makes a sample's tree worse under its own weights
+
+
 def test_unsupported_configurations_fail_loudly(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")

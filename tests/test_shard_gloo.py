@@ -78,3 +78,67 @@ def test_two_gloo_ranks_equal_single_process(tmp_path):
     assert one["best"] == two["best"]
     assert one["tree"] == two["tree"]
     assert min(one["scores"]) == one["scores"][one["best"]]
+
+
+REFINE_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MPF_ROOT"])
+import torch.distributed as dist
+from mpboot_amd import shard, synth, bootstrap, trees
+from oracle import pyoracle as po
+
+class OracleAsEngine:
+    def __init__(self, codes):
+        self.o = po.Oracle(codes)
+    def set_weights(self, w):
+        self.o.set_weights(w)
+    def seed_ties(self, mode, seed):
+        self.o.seed_ties(mode, seed)
+    def reset_node_order(self):
+        self.o.reset_nodep()
+    def set_tree(self, back):
+        self.o.set_tree(back)
+    def optimize_spr(self, a, b):
+        return self.o.optimize_spr(a, b)
+    def get_tree(self):
+        return self.o.get_tree()
+
+ws = int(os.environ.get("WORLD_SIZE", "1"))
+if ws > 1:
+    dist.init_process_group("gloo")
+letters, _ = synth.synth_alignment(14, 250, "DNA", 0.2, seed=4)
+codes = synth.letters_to_codes(letters)
+rng = np.random.default_rng(11)
+B, P = 7, codes.shape[1]
+samples = rng.multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
+starts = [trees.random_topology(14, np.random.default_rng(100 + b)) for b in range(B)]
+scores, local = bootstrap.refine_boot_trees(OracleAsEngine(codes), samples, starts, 5, 6)
+mine = {int(b): t.tolist() for b, t in local.items()}
+allt = [None] * ws
+if ws > 1:
+    dist.all_gather_object(allt, mine)
+else:
+    allt = [mine]
+if shard.world()[0] == 0:
+    merged = {}
+    for d in allt:
+        merged.update(d)
+    print("RESULT " + json.dumps({"scores": scores.tolist(), "trees": [merged[b] for b in range(B)]}))
+if ws > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_boot_tree_refinement_shards_over_two_gloo_ranks(tmp_path):
+    global WORKER
+    saved = WORKER
+    try:
+        WORKER = REFINE_WORKER
+        one = _run(1, tmp_path)
+        two = _run(2, tmp_path)
+    finally:
+        WORKER = saved
+    assert one["scores"] == two["scores"]
+    assert one["trees"] == two["trees"]
+    assert all(s < 2 ** 31 for s in one["scores"])
