@@ -91,8 +91,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--start-tree", default="ras", choices=["ras", "random"])
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
-    ap.add_argument("--bootstrap-replicates", type=int, default=48,
-                    help="per GPU: re-weighted refinement climbs timed after the main metric (0 = skip)")
+    ap.add_argument("--bootstrap-replicates", type=int, default=1000,
+                    help="samples of the online phase whose trees are refined afterwards (IQTree::optimizeBootTrees), "
+                         "sharded over the GPUs; capped by --ufboot-samples (0 = skip)")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
@@ -162,35 +163,28 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
 
-    # second half of BASELINE.json's metric ("bootstrap wall-clock"): bootstrap-refinement replicates
-    # (IQTree::optimizeBootTrees: re-weight, re-pack, one SPR climb from the best tree), sharded over the ranks
-    boot = None
-    if args.bootstrap_replicates > 0:
-        from mpboot_amd import bootstrap
-        n_rep = args.bootstrap_replicates * world
-        engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
-                           for _ in range(3)]
-        w0 = np.ones(P, dtype=np.int32)
-        bootstrap.run_replicates(engines, w0, 4 * world, 999, args.maxtrav, back, "refine")      # warm-up
-        barrier()
-        tb0 = time.perf_counter()
-        bscores, _ = bootstrap.run_replicates(engines, w0, n_rep, 7, args.maxtrav, back, "refine")
-        barrier()
-        tb = time.perf_counter() - tb0
-        boot = (n_rep, tb, float(np.mean(bscores)))
-        eng.set_weights(w0)
-
-    # online UFBoot-MP (-bb 1000): the SPR climb from the rank's start tree with IQTree::saveCurrentTree's bookkeeping
-    # after EVERY insertion test (candidate masks -> binary x int8 MFMA product -> event replay)
+    # ---- second half of BASELINE.json's metric ("bootstrap wall-clock"): the -bb flow on this alignment.
+    # (1) online phase: ONE search chain (sequential by nature: every rank runs the same chain -- "replicas only"),
+    #     pllOptimizeSprParsimony from the start tree with IQTree::saveCurrentTree's bookkeeping after every insertion
+    #     test (candidate masks -> binary x int8 MFMA product -> event replay);
+    # (2) refinement: IQTree::optimizeBootTrees -- every sample's tree from (1) re-weighted + one SPR climb, sample b on
+    #     rank b % n_gpus (strong scaling: the total number of samples is fixed).
     ufb = None
+    boot = None
     if args.ufboot_samples > 0:
         B = args.ufboot_samples
-        samples = np.random.default_rng(4242 + rank).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
+        samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
+        if rank == 0 or args.start_tree != "ras":
+            back_u = back if rank == 0 else trees.random_topology(n, np.random.default_rng(1000))
+        else:                                      # the chain starts from rank 0's tree on every rank
+            eng.seed_ties(engine.TIE_RANDOM, 1)
+            eng.make_parsimony_tree(12345, 0)
+            back_u = eng.get_tree()
         for timed in (False, True):                # first pass: allocations, code load
             eng.ufboot_attach(samples)
-            eng.set_tree(back)
+            eng.set_tree(back_u)
             eng.reset_node_order()
-            eng.seed_ties(engine.TIE_RANDOM, 1 + rank)
+            eng.seed_ties(engine.TIE_RANDOM, 1)
             eng.reset_stats()
             barrier()
             tu0 = time.perf_counter()
@@ -200,7 +194,30 @@ def main():
         ust, ucn = eng.stats(), eng.ufboot_counters()
         ufb = {"samples": B, "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
                "saved_trees": len(eng.ufboot_tree_logl()), **ucn}
+        n_rep = min(B, args.bootstrap_replicates)
+        if n_rep > 0:
+            from mpboot_amd import bootstrap
+            _logl, _cnt, bt = eng.ufboot_state()
+            cache = {}
+            boot_trees = []
+            for b in range(n_rep):
+                t = int(bt[b])
+                if t not in cache:
+                    cache[t] = eng.ufboot_tree(t)
+                boot_trees.append(cache[t])
+            online_best = -_logl[:n_rep]
         eng.ufboot_detach()
+        if n_rep > 0:
+            engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
+                               for _ in range(3)]
+            bootstrap.refine_boot_trees(engines, samples[:min(n_rep, 8 * world)], boot_trees[:min(n_rep, 8 * world)], 999, args.maxtrav)  # warm-up
+            barrier()
+            tb0 = time.perf_counter()
+            bscores, _ = bootstrap.refine_boot_trees(engines, samples[:n_rep], boot_trees, 7, args.maxtrav)
+            barrier()
+            tb = time.perf_counter() - tb0
+            boot = (n_rep, tb, float(np.mean(bscores)), float(np.mean(online_best)), bool((bscores <= online_best).all()))
+            eng.set_weights(np.ones(P, dtype=np.int32))
         eng.set_tree(back)
 
     tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -266,34 +283,36 @@ def main():
         }
         if boot is not None:
             res["bootstrap_wall_clock"] = {
-                "replicates": boot[0], "seconds": boot[1], "per_1000_replicates_s": 1000.0 * boot[1] / boot[0],
-                "mean_replicate_score": boot[2], "engines_per_gpu": 4,
-                "what": "bootstrap-refinement replicates (optimizeBootTrees): multinomial re-weighting, tips re-packed on the "
-                        "device, one SPR hill climb (radius %d) from the start tree; replicate b on rank b %% n_gpus" % args.maxtrav}
+                "samples": ufb["samples"], "online_phase_s": ufb["seconds"], "refined_samples": boot[0], "refinement_s": boot[1],
+                "seconds": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
+                "scaling": "strong", "engines_per_gpu": 4,
+                "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
+                "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
+                        "replicated on every rank) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "
+                        "sample b on rank b %% n_gpus, 4 engines per GPU).  seconds = online + refinement scaled to all samples"
+                        % (ufb["samples"], args.maxtrav)}
         if boot is not None and not args.no_cpu and world == 1:
-            # CPU side of the same replicate work: the scalar C port (oracle) on replicate 0, one thread
-            from mpboot_amd import bootstrap, shard
-            from mpboot_amd.rng import Lcg64
+            # CPU side of the refinement: the scalar C port (oracle) on sample 0, one thread
             from oracle import pyoracle as po
+            from mpboot_amd import shard
             o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
             tc0 = time.perf_counter()
-            seed0 = shard.unit_seed(7, 0)
-            o.set_weights(bootstrap.bootstrap_weights(np.ones(P, dtype=np.int32), Lcg64(seed0)))
-            o.seed_ties(po.TIE_RANDOM, seed0)
-            o.set_tree(back)
+            o.set_weights(samples[0].astype(np.int32))
+            o.seed_ties(po.TIE_RANDOM, shard.unit_seed(7, 0))
+            o.set_tree(boot_trees[0])
             s_cpu = o.optimize_spr(1, args.maxtrav)
             tc = time.perf_counter() - tc0
             res["bootstrap_wall_clock"]["cpu_baseline"] = {
-                "per_1000_replicates_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "replicate 0 on the scalar C oracle",
+                "refinement_per_1000_samples_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "sample 0 on the scalar C oracle",
                 "same_score_as_gpu": bool(int(bscores[0]) == int(s_cpu))}
         if ufb is not None:
             algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples"]
             kms = ufb["reps_kernel_ms"]
             top = algo_ops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             res["ufboot_online"] = {
-                "what": "one pllOptimizeSprParsimony call (radius %d) from this rank's start tree with online UFBoot-MP bookkeeping "
+                "what": "one pllOptimizeSprParsimony call (radius %d) from rank 0's start tree with online UFBoot-MP bookkeeping "
                         "for %d bootstrap samples: cut-off filter, REPS of every insertion test, per-sample update rule with the "
-                        "reference's tie draws (rank 0 shown; every rank runs its own start tree)" % (args.maxtrav, ufb["samples"]),
+                        "reference's tie draws (the search chain is sequential: every rank runs this same call)" % (args.maxtrav, ufb["samples"]),
                 "seconds": ufb["seconds"], "insertion_tests": ufb["insertion_tests"], "moves": ufb["moves"],
                 "tests_per_s": ufb["insertion_tests"] / ufb["seconds"], "saved_trees": ufb["saved_trees"],
                 "events": ufb["events"], "tie_draws": ufb["tie_draws"], "score": ufb["score"],
