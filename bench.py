@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--bootstrap-replicates", type=int, default=1000,
                     help="samples of the online phase whose trees are refined afterwards (IQTree::optimizeBootTrees), "
                          "sharded over the GPUs; capped by --ufboot-samples (0 = skip)")
+    ap.add_argument("--engines-per-gpu", type=int, default=4, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
@@ -209,7 +210,7 @@ def main():
         eng.ufboot_detach()
         if n_rep > 0:
             engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
-                               for _ in range(3)]
+                               for _ in range(max(0, args.engines_per_gpu - 1))]
             bootstrap.refine_boot_trees(engines, samples[:min(n_rep, 8 * world)], boot_trees[:min(n_rep, 8 * world)], 999, args.maxtrav)  # warm-up
             barrier()
             tb0 = time.perf_counter()
@@ -285,11 +286,11 @@ def main():
             res["bootstrap_wall_clock"] = {
                 "samples": ufb["samples"], "online_phase_s": ufb["seconds"], "refined_samples": boot[0], "refinement_s": boot[1],
                 "seconds": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
-                "scaling": "strong", "engines_per_gpu": 4,
+                "scaling": "strong", "engines_per_gpu": args.engines_per_gpu,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
                 "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
                         "replicated on every rank) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "
-                        "sample b on rank b %% n_gpus, 4 engines per GPU).  seconds = online + refinement scaled to all samples"
+                        "sample b on rank b %% n_gpus, several engines per GPU).  seconds = online + refinement scaled to all samples"
                         % (ufb["samples"], args.maxtrav)}
         if boot is not None and not args.no_cpu and world == 1:
             # CPU side of the refinement: the scalar C port (oracle) on sample 0, one thread

@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <map>
 #include <unordered_map>
@@ -338,6 +340,34 @@ class Engine {
   int64_t randum_seed_ = 12345;
   std::vector<Move> moves_;
   int scan_batch_ = 32;
+  // speculative batch size: prune nodes scanned per launch.  A batch is wasted behind the first accepted move, a small
+  // batch costs a launch + synchronisation, so the size follows the observed distance between accepted moves (an
+  // engine that has just refined a nearly optimal tree starts the next climb with whole sweeps).  Never changes a result.
+  double gap_est_ = -1.0;                        // running estimate of prune nodes between accepted moves (-1: none yet)
+  long since_move_ = 0;
+  // a launch + synchronisation costs about as much as scanning ~60 prune nodes of a small batch; with moves g prune
+  // nodes apart the cost per move, (g / b) launches + b / 2 wasted scans, is least near b = sqrt(2 * 60 * g); once
+  // moves are more than a sweep apart (refinement of nearly optimal trees) whole sweeps are scanned
+  int batch_for_gap(int total) const
+  {
+    const int lo = std::max(1, scan_batch_ / 4);
+    if (gap_est_ >= (double)total) return total;
+    if (gap_est_ < 64.0) return std::min(total, lo);          // busy climb: moves cluster, restart small and double
+    const double b = std::sqrt(120.0 * std::max(gap_est_, 0.0));
+    return std::min(total, std::max(lo, (int)std::min(b, 1e9)));
+  }
+  int first_batch() const { return gap_est_ < 0 ? std::max(1, scan_batch_) : batch_for_gap(1 << 30); }
+  int next_batch(int batch, bool moved, int consumed, int total)
+  {
+    since_move_ += consumed;
+    if (moved) {
+      // geometric running mean: one long gap (the end of a sweep) must not inflate the batches of a busy climb
+      gap_est_ = gap_est_ < 0 ? (double)since_move_ : std::exp(0.7 * std::log(gap_est_ + 1.0) + 0.3 * std::log((double)since_move_ + 1.0)) - 1.0;
+      since_move_ = 0;
+      return batch_for_gap(total);
+    }
+    return std::min(total, batch * 2);
+  }
 };
 
 }  // namespace mpf

@@ -40,7 +40,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
   const int total = 2 * n_ - 2;
   std::vector<ScanPlan> plans;
   const uint32_t *out = nullptr;
-  int batch = std::max(1, scan_batch_);
+  int batch = first_batch();
   do {
     startMP = randomMP;
     node_rectifier();
@@ -91,9 +91,8 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
           moved = true;
         }
       }
+      batch = next_batch(batch, moved, j - i, total);
       i = j;
-      if (moved) batch = std::max(1, scan_batch_ / 4);
-      else batch = std::min(total, batch * 2);
     }
   } while (randomMP < startMP);
   if (final_score) *final_score = randomMP;

@@ -220,7 +220,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   const int total = 2 * n_ - 2;
   std::vector<ScanPlan> plans;
   const uint32_t *out = nullptr;
-  int batch = std::max(1, scan_batch_);
+  int batch = first_batch();
   std::vector<UfbEvent> events;
   std::vector<uint32_t> small, sel, crow;
   bool have_C = false;
@@ -467,9 +467,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           moved = true;
         }
       }
+      batch = next_batch(batch, moved, j - i, total);
       i = j;
-      if (moved) batch = std::max(1, scan_batch_ / 4);
-      else batch = std::min(total, batch * 2);
       u.t_replay += now_ms() - t0;
     }
   } while (randomMP < startMP);
