@@ -356,6 +356,8 @@ class Engine {
     const double b = std::sqrt(120.0 * std::max(gap_est_, 0.0));
     return std::min(total, std::max(lo, (int)std::min(b, 1e9)));
   }
+  // a climb always ends with a sweep without moves: remember that long gaps are normal for this engine's trees
+  void climb_finished(int total) { if (since_move_ >= total) gap_est_ = std::max(gap_est_, (double)since_move_); }
   int first_batch() const { return gap_est_ < 0 ? std::max(1, scan_batch_) : batch_for_gap(1 << 30); }
   int next_batch(int batch, bool moved, int consumed, int total)
   {

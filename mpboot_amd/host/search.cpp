@@ -95,6 +95,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
       i = j;
     }
   } while (randomMP < startMP);
+  climb_finished(total);
   if (final_score) *final_score = randomMP;
   return MPF_OK;
 }

@@ -472,6 +472,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       u.t_replay += now_ms() - t0;
     }
   } while (randomMP < startMP);
+  climb_finished(total);
   if (final_score) *final_score = randomMP;
   return MPF_OK;
 }
