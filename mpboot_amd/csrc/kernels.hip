@@ -202,30 +202,43 @@ __device__ __forceinline__ uint32_t state_mask(int datatype, uint32_t code)
   return 1048575u;
 }
 
+// One wavefront = (tip, 64 words = 2048 expanded sites).  64 lanes read 64 consecutive sites at a time (site -> pattern
+// map coalesced, tip codes gathered within a few cache lines), and one ballot per state turns the 64 membership bits
+// into two finished words, kept by lanes 2c and 2c + 1; the 64 words of each state row leave as one 256-byte store.
 template <int S>
 __global__ __launch_bounds__(256) void k_pack_tips(uint32_t *__restrict__ vec, const uint8_t *__restrict__ codes,
                                                    int n_taxa, int n_patterns, const int32_t *__restrict__ site2ptn,
                                                    int n_sites, int datatype, const uint32_t *__restrict__ tip_slots,
                                                    int Wp)
 {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tip = blockIdx.y;
-  if (w >= Wp || tip >= n_taxa) return;
+  if (tile * 64 >= Wp || tip >= n_taxa) return;          // wave-uniform
   uint32_t val[S];
 #pragma unroll
   for (int k = 0; k < S; k++) val[k] = 0;
   const uint8_t *row = codes + (size_t)tip * n_patterns;
-  for (int b = 0; b < 32; b++) {
-    const int site = 32 * w + b;
+  const int site0 = tile * 64 * 32;
+  for (int c = 0; c < 32; c++) {
+    const int site = site0 + 64 * c + lane;
     // expanded sites beyond the alignment are all-ones in every state row so that they
     // never count (reference sprparsimony.cpp:2947-2960)
-    const uint32_t m = site < n_sites ? state_mask(datatype, row[site2ptn[site]]) : 0xFFFFFFFFu;
+    uint32_t m = 0xFFFFFFFFu;
+    if (site < n_sites) m = state_mask(datatype, row[site2ptn[site]]);
 #pragma unroll
-    for (int k = 0; k < S; k++) val[k] |= ((m >> k) & 1u) << b;
+    for (int k = 0; k < S; k++) {
+      const unsigned long long bal = __ballot((int)((m >> k) & 1u));
+      const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+      val[k] = lane == 2 * c ? lo : (lane == 2 * c + 1 ? hi : val[k]);
+    }
   }
-  uint32_t *dst = vec + (size_t)tip_slots[tip] * (size_t)(S * Wp) + w;
+  const int w = tile * 64 + lane;
+  if (w < Wp) {
+    uint32_t *dst = vec + (size_t)tip_slots[tip] * (size_t)(S * Wp) + w;
 #pragma unroll
-  for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = val[k];
+    for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = val[k];
+  }
 }
 
 // ---------------------------------------------------------------- K1: batched newview
@@ -973,7 +986,7 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
                             int n_patterns, const int32_t *site2ptn, int n_sites, int datatype,
                             const uint32_t *tip_slots)
 {
-  dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);
+  dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);          // 4 waves x 64 words per block
   if (g.S == 4)
     hipLaunchKernelGGL(k_pack_tips<4>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
                        tip_slots, g.Wp);
