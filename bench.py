@@ -264,7 +264,11 @@ def main():
             "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
                                    "one full sweep scan per step (all prune nodes, both sides)",
                        "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
-                       "start_tree_score": start_score, "parallelism": f"independent start trees x{world}"},
+                       "start_tree_score": start_score, "parallelism": f"independent start trees x{world}",
+                       # the three rates side by side.  value = effective (n x P x evals/s, as defined);
+                       # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
+                       # running up-vector with a sibling) + one join, plus the directional-vector refresh of the step
+                       "touched_site_ops_per_s": (2.0 * tests_all + st["newview_ops"] * world) * P / dt_all},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_scan_walk", "kernel_ms_per_launch": scan_ms,
