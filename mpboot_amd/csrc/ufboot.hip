@@ -19,6 +19,7 @@
 #include "ufboot.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace mpf {
 
@@ -53,16 +54,16 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // registers): each weight byte is fetched once per 256 rows and each expanded A fragment feeds 8 MFMAs.  Two k-blocks
 // per stage, double-buffered in LDS (global -> registers -> LDS while the previous stage is multiplied).
 // blockIdx.y splits K; partial products are added with integer atomics (exact, order-independent).
-constexpr int kGemmKS = 4;                           // k-blocks per stage
-constexpr int kGemmAStride = 2 * kGemmKS + 1;        // words per row of the A stage tile (+1: bank spread)
-
-__global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
+// WM = waves along the rows (tile = 64 WM rows), KS = k-blocks per LDS stage.
+template <int WM, int KS>
+__global__ __launch_bounds__(128 * WM) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
                                                  int kb_per_split, const uint32_t *__restrict__ rowsel)
 {
-  constexpr int MT = 4, NT = 8, TM = 256, TN = 256, KS = kGemmKS;
+  constexpr int MT = 4, NT = 8, TM = 64 * WM, TN = 256, NTH = 128 * WM;
+  constexpr int kGemmAStride = 2 * KS + 1;           // words per row of the A stage tile (+1: bank spread)
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
-  constexpr int LD = BT / (512 * 16);                // 16-byte loads per thread per k-block (2)
+  constexpr int LD = BT / (NTH * 16);                // 16-byte loads per thread per k-block
   constexpr int AL = KS / 2;                         // 16-byte loads per row of the A stage tile
   extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
   // [2][KS][BT] weights, then [2][TM * kGemmAStride] mask words
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
   const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
   const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
   // output row i multiplies mask row rowsel[i] (cut-off filter: only the candidates that are saved), or row i itself
-  const uint32_t arow_id = rowsel ? rowsel[rb * TM + (tid & 255)] : (uint32_t)(rb * TM + (tid & 255));
+  const uint32_t arow_id = rowsel ? rowsel[rb * TM + (tid % TM)] : (uint32_t)(rb * TM + (tid % TM));
   const uint32_t *arow = masks + (size_t)arow_id * Wp;
   uint4 breg[KS][LD], areg[AL];
 #pragma unroll
@@ -105,9 +106,9 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
     const int kq_ = min((kb_), nkb - KS);                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
       const uint4 *src_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)(kq_ + s_) * wt_kstride); \
-      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) breg[s_][i_] = src_[tid + 512 * i_];      \
+      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) breg[s_][i_] = src_[tid + NTH * i_];      \
     }                                                                                             \
-    if (tid < 256) {                                                                              \
+    if (tid < TM) {                                                                               \
       _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++)                                           \
         areg[i_] = *reinterpret_cast<const uint4 *>(arow + 2 * kq_ + 4 * i_);                     \
     }                                                                                             \
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
   do {                                                                                            \
     _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
       uint4 *dst_ = reinterpret_cast<uint4 *>(s_b + ((size_t)(buf_) * KS + s_) * BT);             \
-      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) dst_[tid + 512 * i_] = breg[s_][i_];      \
+      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) dst_[tid + NTH * i_] = breg[s_][i_];      \
     }                                                                                             \
-    if (tid < 256) {                                                                              \
+    if (tid < TM) {                                                                               \
       uint32_t *a_ = s_a + (size_t)(buf_) * (TM * kGemmAStride) + tid * kGemmAStride;             \
       _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++) {                                         \
         a_[4 * i_] = areg[i_].x; a_[4 * i_ + 1] = areg[i_].y; a_[4 * i_ + 2] = areg[i_].z; a_[4 * i_ + 3] = areg[i_].w; \
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(512) void k_bitgemm(const uint32_t *__restrict__ ma
       }
     }
 }
-constexpr size_t kGemmLds = 2 * (size_t)kGemmKS * 256 * 64 + 2 * (size_t)256 * kGemmAStride * sizeof(uint32_t);
+template <int WM, int KS>
+constexpr size_t gemm_lds() { return 2 * (size_t)KS * 256 * 64 + 2 * (size_t)(64 * WM) * (2 * KS + 1) * sizeof(uint32_t); }
 
 // R_T[b] = sum over rows of C[row][b]
 __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
@@ -292,18 +294,20 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
   return hipGetLastError();
 }
 
-hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                          int mult, int accumulate, const uint32_t *rowsel)
+template <int WM, int KS>
+static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
+                                   int mult, int accumulate, const uint32_t *rowsel)
 {
-  if (rows_padded <= 0) return hipSuccess;
-  const int row_blocks = rows_padded / kUfbRowTile, col_blocks = Bp / kUfbColTile;
+  constexpr int TM = 64 * WM;
+  const int row_blocks = rows_padded / TM, col_blocks = Bp / kUfbColTile;
   const int nkb = Wp / 2;
   // small batches: split K so that the launch still has a few workgroups per CU
   long tiles = (long)row_blocks * col_blocks;
+  const long want = 512 * (4 / WM);
   int ksplit = 1;
-  if (tiles < 512) ksplit = (int)std::min<long>((512 + tiles - 1) / tiles, std::max(1, nkb / 16));
+  if (tiles < want) ksplit = (int)std::min<long>((want + tiles - 1) / tiles, std::max(1, nkb / 16));
   int per = (nkb + ksplit - 1) / ksplit;
-  per = (per + kGemmKS - 1) / kGemmKS * kGemmKS;         // stages start on multiples of the stage depth
+  per = (per + KS - 1) / KS * KS;                        // stages start on multiples of the stage depth
   ksplit = (nkb + per - 1) / per;
   const int atomic = (ksplit > 1 || accumulate) ? 1 : 0;
   if (atomic && !accumulate) {
@@ -318,13 +322,25 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
+  constexpr size_t lds = gemm_lds<WM, KS>();
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<WM, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(k_bitgemm, dim3(gx, (unsigned)ksplit), dim3(512), kGemmLds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
+  hipLaunchKernelGGL((k_bitgemm<WM, KS>), dim3(gx, (unsigned)ksplit), dim3(128 * WM), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
+}
+
+hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
+                          int mult, int accumulate, const uint32_t *rowsel)
+{
+  if (rows_padded <= 0) return hipSuccess;
+  static int variant = -1;
+  if (variant < 0) { const char *v = std::getenv("MPF_GEMM_VARIANT"); variant = v ? std::atoi(v) : 0; }
+  if (variant == 1) return launch_bitgemm_t<2, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  if (variant == 2) return launch_bitgemm_t<4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  return launch_bitgemm_t<4, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
 }
 
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)
