@@ -13,6 +13,7 @@ ap.add_argument("--samples", type=int, default=1000)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--start", default="ras")
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--check", action="store_true", help="replay the first climb on the CPU oracle and compare every observable")
 ap.add_argument("--verify", type=int, default=8, help="number of samples whose kept tree is re-scored independently")
 a = ap.parse_args()
 cfg = synth.WORKLOADS[a.workload]
@@ -62,6 +63,20 @@ for b in range(min(a.verify, a.samples)):
     rell = -int((ptn.astype(np.int64) * samples[b]).sum())
     assert rell == int(logl[b]), (b, rell, logl[b])
 print(f"verified {min(a.verify, a.samples)} samples: boot_logl equals the REPS of the kept tree recomputed from per-pattern lengths")
+
+if a.check:
+    from oracle import pyoracle as po
+    o = po.Oracle(codes, datatype=po.DNA if dt == engine.DNA else po.AA)
+    o.set_tree(back0); o.seed_ties(po.TIE_RANDOM, a.seed); o.ufboot_attach(samples); o.trace(True)
+    tc0 = time.perf_counter(); so = o.optimize_spr(1, 6); tc1 = time.perf_counter()
+    lo, co, to = o.ufboot_state()
+    ok = (so == s_ufb and (o.get_tree() == final).all() and lo.tolist() == logl.tolist() and co.tolist() == counts.tolist()
+          and to.tolist() == tr.tolist() and o.ufboot_tree_logl().tolist() == e.ufboot_tree_logl().tolist()
+          and o.ufboot_draws() == cn["tie_draws"] and o.ufboot_bad() == 0)
+    for t in sorted(set(tr.tolist())):
+        ok = ok and (o.ufboot_tree(t) == e.ufboot_tree(t)).all()
+    print(f"oracle (CPU, {tc1-tc0:.1f}s): identical score, final tree, saved-tree list, boot_logl/boot_counts/boot_trees (+ topologies) and draw count: {ok}")
+    assert ok
 
 # a later search iteration: cut-off from the saved trees (top 10 %), perturbed tree, climb again
 from mpboot_amd import trees as _trees
