@@ -127,6 +127,16 @@ def test_randomized_stepwise_addition_tree_matches_oracle(mods, fx, seed, dist):
     assert (e.get_tree() == o.get_tree()).all()
 
 
+def test_pll_original_parsimony_tree_matches_reference(mods, fx):
+    """pllMakeParsimonyTreeFast of the PLL original (first-best rule): tree and score the reference itself produced"""
+    engine = mods[0]
+    for r in fx["ras"]:
+        e = eng_of(engine, fx)
+        e.seed_ties(engine.TIE_FIRST, 0)
+        assert e.make_parsimony_tree(r["seed"], r["spr_dist"]) == r["score"]
+        assert e.get_tree().tolist() == r["back"]
+
+
 def test_reweighting_matches_oracle(mods, fx):
     """ratchet / bootstrap re-weighting: re-pack on the device, same scores"""
     engine, po = mods[0], mods[1]
