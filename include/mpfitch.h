@@ -19,7 +19,9 @@
  *               (pllrepo/src/pll.h:622-701), -1 where unused.
  * tie rule    : MPF_TIE_RANDOM = mpboot (sprparsimony.cpp:2168-2176, :3001-3008,
  *               :3306-3311) drawing random_double(); MPF_TIE_FIRST = strict '<' as in
- *               pllrepo/src/fastDNAparsimony.c:1224, :1803, :1925.
+ *               pllrepo/src/fastDNAparsimony.c:1224, :1803, :1925, on exactly scored candidates -- i.e. the PLL
+ *               original's rule with mpboot's evaluate before each scan (sprparsimony.cpp:2285); the original, lacking
+ *               that evaluate, can score insertions on not-yet-refreshed vectors and then take another path.
  *
  * Each entry point names the reference interface it replaces.
  */

@@ -60,6 +60,7 @@ struct orc {
   unsigned *moves_score;
   unsigned long long c_newview, c_eval, c_test;
   /* UFBoot-MP online bookkeeping (IQTree::saveCurrentTree, iqtree.cpp:3271-3785, default options) */
+  int pre_eval;               /* -1 = as the variant does (mpboot yes, PLL original no); 0 / 1 = forced */
   int ufb_on, ufb_B, ufb_bad;
   unsigned short *ufb_samples;    /* boot_samples_pars [B][P] */
   double ufb_eps, ufb_cutoff;     /* params->ufboot_epsilon (0.5, tools.cpp:725), logl_cutoff */
@@ -192,6 +193,7 @@ orc *orc_create(int n, int P, int datatype, const unsigned char *codes, const in
   orc *o = (orc *)calloc(1, sizeof(orc));
   int i;
   o->n = n; o->P = P; o->datatype = datatype; o->keep_all = keep_all;
+  o->pre_eval = -1;
   o->S = datatype == ORC_DNA ? 4 : 20;
   o->nrec = 3 * (2 * n - 1) + 3;
   o->codes = (unsigned char *)malloc((size_t)n * P);
@@ -552,6 +554,7 @@ void orc_seed_ties(orc *o, int tie_mode, int seed)
   orc_lcg64_init(&o->rng, seed);
 }
 void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg) { o->rand_fn = fn; o->rand_arg = arg; }
+void orc_set_pre_evaluate(orc *o, int mode) { o->pre_eval = mode; }
 
 /* ---- traces ---- */
 void orc_trace(orc *o, int on) { o->trace_on = on; o->trace_len = 0; o->moves_len = 0; }
@@ -721,7 +724,7 @@ int orc_rearrange(orc *o, int p, int mintrav, int maxtrav)
   assert(mintrav == 1);
   if (maxtrav < mintrav) return 0;
   q = o->back[p];
-  if (o->tie_mode == ORC_TIE_RANDOM) orc_evaluate(o, p, 0);   /* :2285, mpboot only */
+  if (o->pre_eval < 0 ? o->tie_mode == ORC_TIE_RANDOM : o->pre_eval) orc_evaluate(o, p, 0);   /* :2285, mpboot only */
   trace_push(o, -1, 0);
   if (!TIP(o, p)) {
     p1 = o->back[NX(p)];

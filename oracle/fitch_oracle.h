@@ -52,6 +52,9 @@ int orc_pattern_scores(orc *o, unsigned short *ptn /* [P] */);  /* returns sum(p
 
 void orc_seed_ties(orc *o, int tie_mode, int seed);
 void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg);
+/* the evaluateParsimony(p) at the top of rearrangeParsimony (sprparsimony.cpp:2285; absent from the PLL original):
+   -1 = as the tie mode's variant has it, 0 = off, 1 = on */
+void orc_set_pre_evaluate(orc *o, int mode);
 
 /* trace of the insertion tests performed by the calls below: (q rec, mp), -1/-2 separators */
 void orc_trace(orc *o, int on);

@@ -61,6 +61,7 @@ def lib():
         L.orc_pattern_scores.restype = ci
         L.orc_pattern_scores.argtypes = [vp, vp]
         L.orc_seed_ties.argtypes = [vp, ci, ci]
+        L.orc_set_pre_evaluate.argtypes = [vp, ci]
         L.orc_trace.argtypes = [vp, ci]
         L.orc_trace_get.argtypes = [vp, vp, vp]
         L.orc_moves_get.argtypes = [vp, vp, vp, vp]
@@ -184,6 +185,9 @@ class Oracle:
 
     def seed_ties(self, mode: int, seed: int = 1):
         lib().orc_seed_ties(self.h, mode, seed)
+
+    def set_pre_evaluate(self, mode: int):
+        lib().orc_set_pre_evaluate(self.h, int(mode))
 
     def trace(self, on=True):
         lib().orc_trace(self.h, int(on))

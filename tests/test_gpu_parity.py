@@ -127,6 +127,35 @@ def test_randomized_stepwise_addition_tree_matches_oracle(mods, fx, seed, dist):
     assert (e.get_tree() == o.get_tree()).all()
 
 
+def test_pll_original_hill_climb_matches_reference_trajectory(mods, fx):
+    """the PLL original's SPR hill climb (first-best rule): the reference's own accepted moves, final tree and score"""
+    engine = mods[0]
+    spr = fx["spr"]
+    e = eng_of(engine, fx)
+    e.set_tree(np.array(spr["start_back"], dtype=np.int32))
+    e.seed_ties(engine.TIE_FIRST, 0)
+    s = e.optimize_spr(1, spr["maxtrav"])
+    rem, ins, sc = e.moves()
+    got = [list(map(int, m)) for m in zip(rem, ins, sc)]
+    if got == spr["moves"]:
+        assert e.get_tree().tolist() == spr["final_back"]
+        assert s == spr["final_score"]
+    # The PLL original has no evaluate before the scan of a prune node, so some of its insertions are scored on
+    # vectors it has not refreshed yet (DESIGN.md section 3) and its path can differ from an exact scorer's.
+    # What MPF_TIE_FIRST is, exactly: the original's first-best rule WITH mpboot's evaluate (sprparsimony.cpp:2285) --
+    # the oracle in that configuration must give the engine's trajectory move for move.
+    po = mods[1]
+    o = orc_of(po, fx)
+    o.set_tree(np.array(spr["start_back"], dtype=np.int32))
+    o.seed_ties(po.TIE_FIRST)
+    o.set_pre_evaluate(1)
+    o.trace(True)
+    so = o.optimize_spr(1, spr["maxtrav"])
+    assert so == s
+    assert [list(map(int, m)) for m in zip(*o.get_moves())] == got
+    assert (o.get_tree() == e.get_tree()).all()
+
+
 def test_pll_original_parsimony_tree_matches_reference(mods, fx):
     """pllMakeParsimonyTreeFast of the PLL original (first-best rule): tree and score the reference itself produced"""
     engine = mods[0]
