@@ -566,8 +566,13 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
                                                    int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info)
 {
   constexpr int STK = MAXD + 2;
-  constexpr bool LANEACC = MAXD <= 6;      // <= 4*(2^6-1) = 252 candidates: one output slot per (lane, register)
+  constexpr bool LANEACC = MAXD <= 6;      // short walks: candidate costs gathered in a lane register, 64 per flush
   __shared__ uint2 s_frame[4][STK];        // x = cid | depth<<24, y = cost
+  // U of the not-yet-expanded second child, one slot per depth: [wave][depth][state, word][lane] (a lane reads back
+  // what it wrote: no synchronisation, no bank conflicts).  Indexed by the wave-uniform depth -- in registers the same
+  // indexing costs a cascade of compares and register copies per expansion.
+  // (depth 1 stays in registers: it is touched once per side, and without its slot 8 workgroups fit a CU)
+  __shared__ uint32_t s_pend[4][MAXD - 2][S * VW][64];
 
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -624,10 +629,10 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
 
   // sv: pruned subtree; par: U of the node being expanded; pend[d]: U of the not-yet-expanded second
   // child at depth d (one per depth suffices: the first child is expanded immediately)
-  Tile<S, VW> sv, par, u1, u2, d1, d2, pend[MAXD];
+  Tile<S, VW> sv, par, u1, u2, d1, d2, pend1;
   MPF_LOAD(sv, de.s_cid);
   uint32_t k = 0;                              // candidates emitted so far (scan-local index)
-  uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+  uint32_t acc0 = 0;
   uint2 *stk = s_frame[wib];
 
   uint32_t mrow = 0;                           // MASKS: candidates computed so far
@@ -660,13 +665,12 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
       if (tile == 0 && lane == 0) info[de.out_base + k] = make_uint2(de.out_base + row, (uint32_t)scan);
     }
     if constexpr (LANEACC) {
-      // candidate k belongs to lane k&63, register k>>6: a lane select instead of a memory atomic
-      const bool mine = (uint32_t)lane == (k & 63u);
-      switch (k >> 6) {
-        case 0: acc0 = mine ? c : acc0; break;
-        case 1: acc1 = mine ? c : acc1; break;
-        case 2: acc2 = mine ? c : acc2; break;
-        default: acc3 = mine ? c : acc3; break;
+      // candidate k is kept by lane k & 63 (a lane select instead of a memory atomic per candidate); every 64
+      // candidates the wave adds its partial costs to the output with one atomic per lane
+      acc0 = (uint32_t)lane == (k & 63u) ? c : acc0;
+      if ((k & 63u) == 63u) {
+        if (acc0) atomic_add_u32(out + de.out_base + (k - 63u) + (uint32_t)lane, acc0);
+        acc0 = 0;
       }
     } else {
       if (lane == 0 && c) atomic_add_u32(out + de.out_base + k, c);
@@ -708,10 +712,14 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
         cost = valid ? cost : 0u;
         tot = wave_total<RED>(cost);
       }
-      if (deeper && c2 >= n) {
-#define MPF_PUT(D) case D: if constexpr (D < MAXD) pend[D] = u2; break;
-        switch (dd) { MPF_PUT(1) MPF_PUT(2) MPF_PUT(3) MPF_PUT(4) MPF_PUT(5) MPF_PUT(6) MPF_PUT(7) MPF_PUT(8) MPF_PUT(9) MPF_PUT(10) MPF_PUT(11) default: break; }
-#undef MPF_PUT
+      if (deeper && c2 >= n) {             // dd in [1, MAXD - 1]
+        if (dd == 1u) pend1 = u2;
+        else {
+#pragma unroll
+          for (int kk = 0; kk < S; kk++)
+#pragma unroll
+            for (int j = 0; j < VW; j++) s_pend[wib][dd - 2][kk * VW + j][lane] = u2.v[kk][j];
+        }
       }
       if (own2) { stk[sp] = make_uint2(c2 | (dd << 24), (tot >> 16) | (r2 << 16)); sp++; }
       if (test && own1) emit(tot & 0xFFFFu, r1);
@@ -728,9 +736,13 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
           emit(fy & 0xFFFFu, fy >> 16);
         }
         if (dq < maxtrav && q >= n) {
-#define MPF_GET(D) case D: if constexpr (D < MAXD) par = pend[D]; break;
-          switch (dq) { MPF_GET(1) MPF_GET(2) MPF_GET(3) MPF_GET(4) MPF_GET(5) MPF_GET(6) MPF_GET(7) MPF_GET(8) MPF_GET(9) MPF_GET(10) MPF_GET(11) default: break; }
-#undef MPF_GET
+          if (dq == 1u) par = pend1;
+          else {
+#pragma unroll
+            for (int kk = 0; kk < S; kk++)
+#pragma unroll
+              for (int j = 0; j < VW; j++) par.v[kk][j] = s_pend[wib][dq - 2][kk * VW + j][lane];
+          }
           node = q; d = dq; more = true;
           break;
         }
@@ -740,11 +752,7 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
   }
 #undef MPF_LOAD
   if constexpr (LANEACC) {
-    uint32_t *o = out + de.out_base + lane;
-    if ((uint32_t)lane < k && acc0) atomic_add_u32(o, acc0);
-    if ((uint32_t)lane + 64u < k && acc1) atomic_add_u32(o + 64, acc1);
-    if ((uint32_t)lane + 128u < k && acc2) atomic_add_u32(o + 128, acc2);
-    if ((uint32_t)lane + 192u < k && acc3) atomic_add_u32(o + 192, acc3);
+    if ((uint32_t)lane < (k & 63u) && acc0) atomic_add_u32(out + de.out_base + (k & ~63u) + (uint32_t)lane, acc0);
   }
   if (tile == 0 && lane == 0) ncand[scan] = k;
 }
@@ -1122,7 +1130,7 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
                             uint32_t *masks, uint2 *info)
 {
   if (n_scans <= 0) return hipSuccess;
-  if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;
+  if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;   // 8: the per-depth LDS slots of the walk are sized for it
   const bool split = g.S == 20;                                    // protein: states split over the wave halves
   const int tiles = split ? (g.Wp + 31) / 32 : tiles_of(g);
   const long waves = (long)n_scans * tiles;
@@ -1143,7 +1151,7 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 #define SW2(S_, VW_, SPLIT_)                                                                                 \
   do {                                                                                                       \
     if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0, SPLIT_); else SW(S_, VW_, 6, 1, SPLIT_); }    \
-    else { if (g.reduce == 0) SW(S_, VW_, 12, 0, SPLIT_); else SW(S_, VW_, 12, 1, SPLIT_); }                 \
+    else { if (g.reduce == 0) SW(S_, VW_, 8, 0, SPLIT_); else SW(S_, VW_, 8, 1, SPLIT_); }                   \
   } while (0)
   if (g.S == 4) {
     if (g.vw == 1) SW2(4, 1, false); else SW2(4, 2, false);

@@ -33,7 +33,7 @@ enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2 };
 // kids[cid] = cids of the two records behind an inner record (back[next], back[next next]).
 struct WalkDesc { uint32_t s_cid, xa_cid, xb_cid, trav /* mintrav | maxtrav<<8 | side_mask<<16 | child_mask<<18 */,
                   out_base, pad0, pad1, pad2; };
-constexpr int kWalkMaxDepth = 12;
+constexpr int kWalkMaxDepth = 8;    // deepest device-walked scan (k_scan_walk); longer radii use the host-planned k_scan
 constexpr int kMaxDepth = 12;   // deepest chain the register-resident scan kernel supports
 
 struct Geometry {
