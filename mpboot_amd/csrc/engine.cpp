@@ -338,6 +338,28 @@ void Engine::invalidate_node(int node)
 
 // N(q, m) = 1 + [q inner and m > 1] * (N(c1, m-1) + N(c2, m-1)): the records addTraverseParsimony visits
 // from q with m levels left (reference sprparsimony.cpp:2208-2218); depends on the topology only
+// the whole table in one bottom-up sweep (a full-sweep plan asks for nearly every entry anyway)
+void Engine::fill_visit_counts(int maxm)
+{
+  const size_t nrec = back_.size();
+  for (int m = 2; m <= maxm; m++)
+    for (size_t q = 3; q < nrec; q++) {
+      if (back_[q] < 0) continue;
+      const size_t key = q * 16 + (size_t)m;
+      int v = 1;
+      if (!tip((int)q)) {
+        const int a = back_[nx((int)q)], b = back_[nx(nx((int)q))];
+        if (a >= 0 && b >= 0) {
+          const int va = (m - 1 <= 1 || tip(a)) ? 1 : nvis_val_[(size_t)a * 16 + (size_t)(m - 1)];
+          const int vb = (m - 1 <= 1 || tip(b)) ? 1 : nvis_val_[(size_t)b * 16 + (size_t)(m - 1)];
+          v = 1 + va + vb;
+        }
+      }
+      nvis_val_[key] = v;
+      nvis_epoch_[key] = topo_epoch_;
+    }
+}
+
 int Engine::count_visits(int q, int m)
 {
   if (m <= 1 || tip(q)) return 1;
@@ -877,6 +899,10 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
   }
   {
     ScopedMs timer(stats.host_plan_ms_total);
+    if (walk && count >= n_ / 2 && visits_filled_epoch_ != topo_epoch_) {
+      fill_visit_counts(std::min(mt, 15));
+      visits_filled_epoch_ = topo_epoch_;
+    }
     for (int i = 0; i < count; i++) {
       int rc = walk ? plan_walk(recs[i], mintrav, maxtrav, plans[(size_t)i], count <= split_below_)
                     : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);

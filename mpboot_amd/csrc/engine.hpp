@@ -314,6 +314,8 @@ class Engine {
   std::vector<int32_t> nvis_val_, nvis_epoch_;
   int32_t topo_epoch_ = 1;
   int count_visits(int q, int m);
+  void fill_visit_counts(int maxm);
+  int32_t visits_filled_epoch_ = 0;
   int check_counts_ = 0;                         // 1 = copy the kernel's own candidate counts back and compare
 
   // staging program being built
