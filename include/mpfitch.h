@@ -199,6 +199,18 @@ int mpf_remain_bounds(int32_t n_units, int32_t n_segments, const int32_t *segmen
    (0.5, tools.cpp:725); any value in (0, 1) is equivalent for integer scores, others are MPF_E_UNSUPPORTED.
    Fitch mode only.  mpf_set_weights detaches the tracker. */
 int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples, double epsilon);
+/* Multi-GPU online phase: the samples are sharded over the GPUs, the search chain is not.  Every rank runs the same
+   mpf_optimize_spr calls (same tree, same tie seed) on its own engine, which holds only n_local of the n_samples weight
+   vectors (sample_ids[c] = run-wide index of local vector c) and so does 1/n_gpus of the REPS work.  After each scan batch
+   the engine hands its (candidate, sample, score) events to `exchange`, which must return the events of ALL ranks (any
+   order; an all-gather -- RCCL on the GPU box); every rank then replays the same merged list, so tie draws, accepted
+   moves and all bookkeeping arrays are identical on every rank and identical to the unsharded run. */
+typedef struct { uint32_t idx, sample, score; } mpf_ufb_event;
+typedef int (*mpf_ufb_exchange_fn)(void *arg, const mpf_ufb_event *local, uint32_t n_local, const mpf_ufb_event **all,
+                                   uint32_t *n_all);   /* returns 0 on success; *all stays valid until the next call */
+int mpf_ufboot_attach_sharded(mpf_engine *e, int32_t n_samples, int32_t n_local, const int32_t *sample_ids,
+                              const uint16_t *samples_local /* [n_local][n_patterns] */, double epsilon,
+                              mpf_ufb_exchange_fn exchange, void *arg);
 int mpf_ufboot_detach(mpf_engine *e);
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff);            /* IQTree::logl_cutoff; 0 = none */
 /* the main loop's per-iteration cut-off update, "top percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10) */

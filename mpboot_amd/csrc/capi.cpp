@@ -211,6 +211,13 @@ int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples,
   NEED(e);
   return e->eng.ufboot_attach(n_samples, samples, epsilon);
 }
+int mpf_ufboot_attach_sharded(mpf_engine *e, int32_t n_samples, int32_t n_local, const int32_t *sample_ids,
+                              const uint16_t *samples_local, double epsilon, mpf_ufb_exchange_fn exchange, void *arg)
+{
+  NEED(e);
+  if (n_local < 1 || n_local > n_samples || !sample_ids || !exchange) { set_error("mpf_ufboot_attach_sharded: bad argument"); return MPF_E_INVALID; }
+  return e->eng.ufboot_attach(n_samples, samples_local, epsilon, n_local, sample_ids, exchange, arg);
+}
 int mpf_ufboot_detach(mpf_engine *e) { NEED(e); e->eng.ufboot_detach(); return MPF_OK; }
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff) { NEED(e); return e->eng.ufboot_set_cutoff(logl_cutoff); }
 int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff)

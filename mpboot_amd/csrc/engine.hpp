@@ -97,7 +97,13 @@ struct Move { int32_t remove_rec, insert_rec; uint32_t score; };
 // online UFBoot-MP: the arrays IQTree keeps per bootstrap sample (iqtree.cpp:213-262) plus the device buffers of
 // the masked scan, the REPS product and the event extraction (ufboot.hip)
 struct UfbState {
-  int B = 0, Bp = 0, planes = 1;
+  int B = 0, Bp = 0, planes = 1;                 // B = all samples of the run (host arrays); Bp = padded LOCAL columns
+  // sample sharding (multi-GPU online phase): this engine multiplies only its own samples, ids[c] = global sample of
+  // local column c; every rank replays the merged events of all ranks, so the search chain stays identical everywhere
+  int Bl = 0;
+  std::vector<int32_t> ids;
+  mpf_ufb_exchange_fn exchange = nullptr;
+  void *exchange_arg = nullptr;
   double eps = 0.5;                              // params->ufboot_epsilon (tools.cpp:725)
   double logl_cutoff = 0.0;                      // IQTree::logl_cutoff, 0 = none (iqtree.cpp:68, :3343)
   // host bookkeeping (scores are parsimony lengths, i.e. -boot_logl; UINT32_MAX = "-LONG_MAX")
@@ -189,7 +195,8 @@ class Engine {
   const std::vector<Move> &moves() const { return moves_; }
 
   // ---- online UFBoot-MP bookkeeping (host/ufboot.cpp; reference IQTree::saveCurrentTree, iqtree.cpp:3271-3785)
-  int ufboot_attach(int n_samples, const uint16_t *samples, double epsilon);
+  int ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local = -1, const int32_t *sample_ids = nullptr,
+                    mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
   bool ufboot_attached() const { return (bool)ufb_; }
   int ufboot_set_cutoff(double logl_cutoff);

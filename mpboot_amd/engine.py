@@ -25,7 +25,7 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
-    "mpf_ufboot_attach", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
+    "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
 ]
@@ -97,6 +97,7 @@ def load_library():
         L.mpf_reps_destroy.argtypes = [vp]
         L.mpf_reps_destroy.restype = None
         L.mpf_ufboot_attach.argtypes = [vp, C.c_int32, vp, C.c_double]
+        L.mpf_ufboot_attach_sharded.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp]
         L.mpf_ufboot_detach.argtypes = [vp]
         L.mpf_ufboot_set_cutoff.argtypes = [vp, C.c_double]
         L.mpf_ufboot_next_cutoff.argtypes = [vp, C.c_int32, vp]
@@ -340,12 +341,27 @@ class FitchEngine:
         return a, b, s
 
     # ---- online UFBoot-MP bookkeeping (IQTree::saveCurrentTree during optimize_spr)
-    def ufboot_attach(self, samples, epsilon: float = 0.5):
+    def ufboot_attach(self, samples, epsilon: float = 0.5, shard=None, exchange=None):
+        """samples: [n_samples][n_patterns] bootstrap weights (all of them, on every rank).
+        shard = (rank, world): multi-GPU online phase -- this engine keeps samples rank, rank + world, ... and
+        `exchange` (default: mpboot_amd.shard.event_exchange(), an all-gather over torch.distributed) merges the
+        per-batch events of all ranks; every rank must then make the same optimize_spr calls."""
         samples = np.ascontiguousarray(samples, dtype=np.uint16)
         if samples.ndim != 2 or samples.shape[1] != self.P:
             raise ValueError("samples must be [n_samples][n_patterns]")
         self.ufb_B = samples.shape[0]
-        _chk(load_library().mpf_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon)))
+        if shard is None or shard[1] == 1:
+            _chk(load_library().mpf_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon)))
+            return
+        rank, world = shard
+        ids = np.arange(rank, self.ufb_B, world, dtype=np.int32)
+        local = np.ascontiguousarray(samples[ids])
+        if exchange is None:
+            from . import shard as _shard
+            exchange = _shard.event_exchange()
+        self._ufb_exchange = exchange            # keep the ctypes callback alive as long as the tracker
+        _chk(load_library().mpf_ufboot_attach_sharded(self.h, self.ufb_B, len(ids), _p(ids), _p(local), float(epsilon),
+                                                      C.cast(exchange, C.c_void_p), None))
 
     def ufboot_detach(self):
         _chk(load_library().mpf_ufboot_detach(self.h))

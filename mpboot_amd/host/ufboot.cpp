@@ -27,7 +27,8 @@ namespace mpf {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon)
+int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local, const int32_t *sample_ids,
+                          mpf_ufb_exchange_fn exchange, void *exchange_arg)
 {
   if (sankoff_) { set_error("online UFBoot: Fitch mode only (weighted per-pattern lengths are not 0/1 increments)"); return MPF_E_UNSUPPORTED; }
   if (n_samples < 1 || !samples) { set_error("ufboot_attach: bad argument"); return MPF_E_INVALID; }
@@ -37,7 +38,18 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   }
   ufboot_detach();
   std::unique_ptr<UfbState> u(new UfbState());
-  u->B = n_samples;
+  const int n_all = n_samples;
+  u->B = n_all;
+  if (n_local < 0) n_local = n_all;                        // unsharded: every sample is local, ids = identity
+  u->Bl = n_local;
+  u->ids.resize((size_t)n_local);
+  for (int c = 0; c < n_local; c++) {
+    u->ids[(size_t)c] = sample_ids ? sample_ids[c] : c;
+    if (u->ids[(size_t)c] < 0 || u->ids[(size_t)c] >= n_all) { set_error("ufboot_attach: sample id out of range"); return MPF_E_INVALID; }
+  }
+  u->exchange = exchange;
+  u->exchange_arg = exchange_arg;
+  n_samples = n_local;                                     // from here on: the local weight vectors
   u->Bp = round_up(n_samples, kUfbColTile);
   u->eps = epsilon;
   uint32_t wmax = 0;
@@ -67,9 +79,9 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   UCHK(u->evcount.reserve(4));
   UCHK(hipMemsetAsync(u->rt.p, 0, (size_t)u->Bp * sizeof(int32_t), st_));
   UCHK(hipStreamSynchronize(st_));
-  u->boot_score.assign((size_t)n_samples, UINT32_MAX);       // boot_logl = -LONG_MAX (iqtree.cpp:248)
-  u->boot_counts.assign((size_t)n_samples, 0);               // :253
-  u->boot_trees.assign((size_t)n_samples, -1);               // :252
+  u->boot_score.assign((size_t)n_all, UINT32_MAX);           // boot_logl = -LONG_MAX (iqtree.cpp:248)
+  u->boot_counts.assign((size_t)n_all, 0);                   // :253
+  u->boot_trees.assign((size_t)n_all, -1);                   // :252
   ufb_ = std::move(u);
   return MPF_OK;
 }
@@ -311,7 +323,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             small[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
           }
         }
-        for (int b = 0; b < u.B; b++) small[(size_t)2 * n_parts + (size_t)b] = u.boot_score[(size_t)b];
+        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = u.boot_score[(size_t)u.ids[(size_t)c2]];
         if (compact) {
           std::memcpy(small.data() + o_crow, crow.data(), (size_t)n_idx * sizeof(uint32_t));
           std::memcpy(small.data() + o_sel, sel.data(), sel.size() * sizeof(uint32_t));      // padding rows multiply mask row 0
@@ -335,7 +347,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         have_C = true;
         while (true) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
-          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.B, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
+          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
                                  u.ev.p, (uint32_t)u.ev.cap, u.evcount.p));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
@@ -356,6 +368,19 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         t1 = now_ms();
         u.t_dev += t1 - t0;
         events.assign(u.h_ev.p, u.h_ev.p + n_ev);
+        for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];       // local column -> sample of the run
+        if (u.exchange) {
+          // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
+          static_assert(sizeof(UfbEvent) == sizeof(mpf_ufb_event), "event layouts must match");
+          const mpf_ufb_event *all = nullptr;
+          uint32_t n_all_ev = 0;
+          if (u.exchange(u.exchange_arg, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
+            set_error("online UFBoot: event exchange failed");
+            return MPF_E_STATE;
+          }
+          const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
+          events.assign(pa, pa + n_all_ev);
+        }
         std::sort(events.begin(), events.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
         u.events += n_ev;
         t0 = now_ms();

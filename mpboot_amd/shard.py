@@ -90,3 +90,57 @@ def search_start_trees(make_engine, n_units: int, base_seed: int, spr_radius: in
         nrec = int(ln.item())
     best_tree = broadcast_tree(trees.get(best_unit), owner, nrec)
     return scores, best_unit, best_tree
+
+
+# ---------------------------------------------------------------- online UFBoot: per-batch event exchange
+import ctypes as _C
+
+EXCHANGE_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_uint32, _C.POINTER(_C.c_void_p), _C.POINTER(_C.c_uint32))
+
+
+def gather_events(local: np.ndarray) -> np.ndarray:
+    """All-gather of the (candidate index, sample, score) triples of one scan batch: [n_local, 3] uint32 in,
+    [n_all, 3] out, identical on every rank.  Two small collectives (counts, then the padded triples) on the default
+    process group -- RCCL over xGMI on the GPU box ("nccl"), gloo in the CPU tests."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    dev = _device()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.zeros(ws, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n)
+    counts = counts.cpu().numpy()
+    m = int(counts.max())
+    if m == 0:
+        return local
+    buf = torch.zeros((m, 3), dtype=torch.int32, device=dev)
+    if local.shape[0]:
+        buf[:local.shape[0]] = torch.from_numpy(local.view(np.int32)).to(dev)
+    out = torch.zeros((ws, m, 3), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out.view(ws * m, 3), buf)
+    out = out.cpu().numpy().view(np.uint32)
+    return np.concatenate([out[r, :int(counts[r])] for r in range(ws)], axis=0)
+
+
+def event_exchange():
+    """The callback mpf_ufboot_attach_sharded takes (include/mpfitch.h: mpf_ufb_exchange_fn)."""
+    keep = {}
+
+    def fn(_arg, local_ptr, n_local, all_ptr, n_all_ptr):
+        try:
+            if n_local:
+                local = np.ctypeslib.as_array(_C.cast(local_ptr, _C.POINTER(_C.c_uint32)), shape=(n_local, 3)).copy()
+            else:
+                local = np.zeros((0, 3), dtype=np.uint32)
+            merged = np.ascontiguousarray(gather_events(local), dtype=np.uint32)
+            keep["buf"] = merged                         # valid until the next call
+            all_ptr[0] = merged.ctypes.data if merged.shape[0] else None
+            n_all_ptr[0] = merged.shape[0]
+            return 0
+        except Exception as exc:                         # never let an exception cross the C boundary
+            keep["error"] = exc
+            return 1
+
+    cb = EXCHANGE_FN(fn)
+    cb._keep = keep
+    return cb

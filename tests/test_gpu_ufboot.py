@@ -6,6 +6,8 @@ per candidate: scan masks x weights on the matrix cores + an event replay.  Ever
 scores, moves, the saved-tree list, boot_logl / boot_counts / boot_trees (and the topologies they name), and the
 number of random draws consumed (the SPR trajectory is coupled to it).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -217,6 +219,84 @@ def test_online_phase_then_refinement_matches_oracle(mods):
     for b in range(B):
         assert (tr_e[b] == tr_o[b]).all()
         assert sc_e[b] <= -_l[b]                    # refinement never makes a sample's tree worse under its own weights
+
+
+SHARD_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MPF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MPF_ROOT"], "tests"))
+import torch.distributed as dist
+from helpers import load_fixture
+from mpboot_amd import engine, shard
+dist.init_process_group("gloo")
+rank, ws = shard.world()
+fx = load_fixture(os.environ["MPF_FX"])
+P = len(fx["weights"])
+w = np.asarray(fx["weights"], dtype=np.float64)
+samples = np.random.default_rng(31).multinomial(int(w.sum()), w / w.sum(), size=23).astype(np.uint16)
+e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
+e.seed_ties(engine.TIE_RANDOM, 19)
+e.ufboot_attach(samples, 0.5, shard=(rank, ws))
+s = e.optimize_spr(1, 6)
+cut = e.ufboot_next_cutoff(10)
+e.ufboot_set_cutoff(cut)
+e.set_tree(np.array(fx["trees"][5]["back"], dtype=np.int32))
+s2 = e.optimize_spr(1, 6)
+logl, cnt, tr = e.ufboot_state()
+res = {"s": [s, s2], "moves": [x.tolist() for x in e.moves()], "logl": logl.tolist(), "cnt": cnt.tolist(), "tr": tr.tolist(),
+       "saved": e.ufboot_tree_logl().tolist(), "draws": e.ufboot_counters()["tie_draws"],
+       "trees": {str(t): e.ufboot_tree(int(t)).tolist() for t in sorted(set(tr.tolist()))}}
+allr = [None] * ws
+dist.all_gather_object(allr, res)
+if rank == 0:
+    assert all(r == allr[0] for r in allr), "ranks disagree"
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("name", ["dna_ambig", "aa"])
+def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, name):
+    """two ranks (sharing this GPU) hold half of the samples each and exchange their events per batch: every rank must
+    end with the state of the single-engine run -- scores, moves, saved trees, boot arrays, topologies, draw count"""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    engine, po = mods
+    fx = load_fixture(name)
+    w = np.asarray(fx["weights"], dtype=np.float64)
+    samples = np.random.default_rng(31).multinomial(int(w.sum()), w / w.sum(), size=23).astype(np.uint16)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
+    e.seed_ties(engine.TIE_RANDOM, 19)
+    e.ufboot_attach(samples)
+    s = e.optimize_spr(1, 6)
+    e.ufboot_set_cutoff(e.ufboot_next_cutoff(10))
+    e.set_tree(np.array(fx["trees"][5]["back"], dtype=np.int32))
+    s2 = e.optimize_spr(1, 6)
+    logl, cnt, tr = e.ufboot_state()
+    script = tmp_path / "worker.py"
+    script.write_text(SHARD_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MPF_ROOT=ROOT, MPF_FX=name)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert got["s"] == [s, s2]
+    assert got["moves"] == [x.tolist() for x in e.moves()]
+    assert got["logl"] == logl.tolist() and got["cnt"] == cnt.tolist() and got["tr"] == tr.tolist()
+    assert got["saved"] == e.ufboot_tree_logl().tolist()
+    assert got["draws"] == e.ufboot_counters()["tie_draws"]
+    for t, back in got["trees"].items():
+        assert back == e.ufboot_tree(int(t)).tolist()
 
 
 def test_unsupported_configurations_fail_loudly(mods):

@@ -142,3 +142,45 @@ def test_boot_tree_refinement_shards_over_two_gloo_ranks(tmp_path):
     assert one["scores"] == two["scores"]
     assert one["trees"] == two["trees"]
     assert all(s < 2 ** 31 for s in one["scores"])
+
+
+GATHER_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MPF_ROOT"])
+import torch.distributed as dist
+from mpboot_amd import shard
+ws = int(os.environ.get("WORLD_SIZE", "1"))
+if ws > 1:
+    dist.init_process_group("gloo")
+rank = shard.world()[0]
+out = []
+for rnd in range(4):
+    rng = np.random.default_rng(100 * rnd + rank)
+    n = [5, 0, 3, 17][(rnd + rank) % 4] if rnd != 2 else 0          # round 2: nobody has events
+    local = rng.integers(0, 1000, size=(n, 3)).astype(np.uint32)
+    merged = shard.gather_events(local)
+    out.append(sorted(map(tuple, merged.tolist())))
+if rank == 0:
+    print("RESULT " + json.dumps(out))
+if ws > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_event_gather_over_two_gloo_ranks(tmp_path):
+    """the per-batch exchange of the sample-sharded online UFBoot phase: uneven and empty contributions"""
+    global WORKER
+    saved = WORKER
+    try:
+        WORKER = GATHER_WORKER
+        two = _run(2, tmp_path)
+    finally:
+        WORKER = saved
+    for rnd in range(4):
+        want = []
+        for rank in range(2):
+            rng = np.random.default_rng(100 * rnd + rank)
+            n = [5, 0, 3, 17][(rnd + rank) % 4] if rnd != 2 else 0
+            want += list(map(tuple, rng.integers(0, 1000, size=(n, 3)).astype(np.uint32).tolist()))
+        assert [tuple(x) for x in two[rnd]] == sorted(want)
