@@ -165,9 +165,10 @@ def main():
     st = eng.stats()
 
     # ---- second half of BASELINE.json's metric ("bootstrap wall-clock"): the -bb flow on this alignment.
-    # (1) online phase: ONE search chain (sequential by nature: every rank runs the same chain -- "replicas only"),
-    #     pllOptimizeSprParsimony from the start tree with IQTree::saveCurrentTree's bookkeeping after every insertion
-    #     test (candidate masks -> binary x int8 MFMA product -> event replay);
+    # (1) online phase: ONE search chain, sequential by nature: every rank makes the same pllOptimizeSprParsimony call from
+    #     the same start tree with IQTree::saveCurrentTree's bookkeeping after every insertion test (candidate masks ->
+    #     binary x int8 MFMA product -> event replay), but holds only every n_gpus-th bootstrap sample; the ranks
+    #     all-gather their per-batch events (RCCL) and replay the merged list, so the chain is identical everywhere;
     # (2) refinement: IQTree::optimizeBootTrees -- every sample's tree from (1) re-weighted + one SPR climb, sample b on
     #     rank b % n_gpus (strong scaling: the total number of samples is fixed).
     ufb = None
@@ -182,7 +183,7 @@ def main():
             eng.make_parsimony_tree(12345, 0)
             back_u = eng.get_tree()
         for timed in (False, True):                # first pass: allocations, code load
-            eng.ufboot_attach(samples)
+            eng.ufboot_attach(samples, 0.5, shard=(rank, world))   # samples rank, rank + world, ... ; events all-gathered per batch
             eng.set_tree(back_u)
             eng.reset_node_order()
             eng.seed_ties(engine.TIE_RANDOM, 1)
@@ -193,7 +194,7 @@ def main():
             barrier()
             tu = time.perf_counter() - tu0
         ust, ucn = eng.stats(), eng.ufboot_counters()
-        ufb = {"samples": B, "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
+        ufb = {"samples": B, "samples_local": len(range(rank, B, world)), "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
                "saved_trees": len(eng.ufboot_tree_logl()), **ucn}
         n_rep = min(B, args.bootstrap_replicates)
         if n_rep > 0:
@@ -293,7 +294,7 @@ def main():
                 "scaling": "strong", "engines_per_gpu": args.engines_per_gpu,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
                 "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
-                        "replicated on every rank) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "
+                        "samples sharded over the ranks) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "
                         "sample b on rank b %% n_gpus, several engines per GPU).  seconds = online + refinement scaled to all samples"
                         % (ufb["samples"], args.maxtrav)}
         if boot is not None and not args.no_cpu and world == 1:
@@ -311,13 +312,14 @@ def main():
                 "refinement_per_1000_samples_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "sample 0 on the scalar C oracle",
                 "same_score_as_gpu": bool(int(bscores[0]) == int(s_cpu))}
         if ufb is not None:
-            algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples"]
+            algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples_local"]
             kms = ufb["reps_kernel_ms"]
             top = algo_ops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             res["ufboot_online"] = {
                 "what": "one pllOptimizeSprParsimony call (radius %d) from rank 0's start tree with online UFBoot-MP bookkeeping "
                         "for %d bootstrap samples: cut-off filter, REPS of every insertion test, per-sample update rule with the "
-                        "reference's tie draws (the search chain is sequential: every rank runs this same call)" % (args.maxtrav, ufb["samples"]),
+                        "reference's tie draws.  The search chain is sequential: every rank runs this same call on its share of the "
+                        "samples (%d on rank 0) and the events are all-gathered per scan batch" % (args.maxtrav, ufb["samples"], ufb["samples_local"]),
                 "seconds": ufb["seconds"], "insertion_tests": ufb["insertion_tests"], "moves": ufb["moves"],
                 "tests_per_s": ufb["insertion_tests"] / ufb["seconds"], "saved_trees": ufb["saved_trees"],
                 "events": ufb["events"], "tie_draws": ufb["tie_draws"], "score": ufb["score"],

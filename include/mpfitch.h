@@ -206,8 +206,11 @@ int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples,
    order; an all-gather -- RCCL on the GPU box); every rank then replays the same merged list, so tie draws, accepted
    moves and all bookkeeping arrays are identical on every rank and identical to the unsharded run. */
 typedef struct { uint32_t idx, sample, score; } mpf_ufb_event;
-typedef int (*mpf_ufb_exchange_fn)(void *arg, const mpf_ufb_event *local, uint32_t n_local, const mpf_ufb_event **all,
-                                   uint32_t *n_all);   /* returns 0 on success; *all stays valid until the next call */
+/* tag: position of the call in the run (batch counter; 0xFFFFFFFF closes a climb).  The ranks advance in lock step, so
+   an exchange that sees different tags must fail (return non-zero): the engine then stops with MPF_E_STATE instead of
+   waiting forever.  Returns 0 on success; *all stays valid until the next call. */
+typedef int (*mpf_ufb_exchange_fn)(void *arg, uint32_t tag, const mpf_ufb_event *local, uint32_t n_local,
+                                   const mpf_ufb_event **all, uint32_t *n_all);
 int mpf_ufboot_attach_sharded(mpf_engine *e, int32_t n_samples, int32_t n_local, const int32_t *sample_ids,
                               const uint16_t *samples_local /* [n_local][n_patterns] */, double epsilon,
                               mpf_ufb_exchange_fn exchange, void *arg);

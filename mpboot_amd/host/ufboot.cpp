@@ -236,6 +236,13 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   std::vector<UfbEvent> events;
   std::vector<uint32_t> small, sel, crow;
   bool have_C = false;
+  uint32_t exchange_tag = 0;
+  if (u.exchange) {
+    // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy
+    // state instead of this engine's own history
+    gap_est_ = -1.0;
+    since_move_ = 0;
+  }
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
   do {
     startMP = randomMP;
@@ -374,8 +381,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           static_assert(sizeof(UfbEvent) == sizeof(mpf_ufb_event), "event layouts must match");
           const mpf_ufb_event *all = nullptr;
           uint32_t n_all_ev = 0;
-          if (u.exchange(u.exchange_arg, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
-            set_error("online UFBoot: event exchange failed");
+          if (u.exchange(u.exchange_arg, exchange_tag++, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
+            set_error("online UFBoot: event exchange failed (ranks out of step?)");
             return MPF_E_STATE;
           }
           const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
@@ -498,6 +505,12 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     }
   } while (randomMP < startMP);
   climb_finished(total);
+  if (u.exchange) {
+    // closing handshake: a rank that took another path would be in the middle of a batch here
+    const mpf_ufb_event *all = nullptr;
+    uint32_t n_all_ev = 0;
+    if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
+  }
   if (final_score) *final_score = randomMP;
   return MPF_OK;
 }

@@ -95,21 +95,25 @@ def search_start_trees(make_engine, n_units: int, base_seed: int, spr_radius: in
 # ---------------------------------------------------------------- online UFBoot: per-batch event exchange
 import ctypes as _C
 
-EXCHANGE_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_uint32, _C.POINTER(_C.c_void_p), _C.POINTER(_C.c_uint32))
+EXCHANGE_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_uint32, _C.c_void_p, _C.c_uint32, _C.POINTER(_C.c_void_p), _C.POINTER(_C.c_uint32))
 
 
-def gather_events(local: np.ndarray) -> np.ndarray:
+def gather_events(local: np.ndarray, tag: int = 0) -> np.ndarray:
     """All-gather of the (candidate index, sample, score) triples of one scan batch: [n_local, 3] uint32 in,
-    [n_all, 3] out, identical on every rank.  Two small collectives (counts, then the padded triples) on the default
-    process group -- RCCL over xGMI on the GPU box ("nccl"), gloo in the CPU tests."""
+    [n_all, 3] out, identical on every rank.  Two small collectives (counts + tag, then the padded triples) on the default
+    process group -- RCCL over xGMI on the GPU box ("nccl"), gloo in the CPU tests.  Ranks whose tags differ are not at
+    the same point of the run: everybody raises instead of running on."""
     rank, ws = world()
     if ws == 1:
         return local
     dev = _device()
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = torch.zeros(ws, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, n)
-    counts = counts.cpu().numpy()
+    n = torch.tensor([local.shape[0], int(tag)], dtype=torch.int64, device=dev)
+    both = torch.zeros(2 * ws, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(both, n)
+    both = both.cpu().numpy().reshape(ws, 2)
+    if (both[:, 1] != both[0, 1]).any():
+        raise RuntimeError(f"ranks out of step in the event exchange: tags {both[:, 1].tolist()}")
+    counts = both[:, 0]
     m = int(counts.max())
     if m == 0:
         return local
@@ -126,13 +130,13 @@ def event_exchange():
     """The callback mpf_ufboot_attach_sharded takes (include/mpfitch.h: mpf_ufb_exchange_fn)."""
     keep = {}
 
-    def fn(_arg, local_ptr, n_local, all_ptr, n_all_ptr):
+    def fn(_arg, tag, local_ptr, n_local, all_ptr, n_all_ptr):
         try:
             if n_local:
                 local = np.ctypeslib.as_array(_C.cast(local_ptr, _C.POINTER(_C.c_uint32)), shape=(n_local, 3)).copy()
             else:
                 local = np.zeros((0, 3), dtype=np.uint32)
-            merged = np.ascontiguousarray(gather_events(local), dtype=np.uint32)
+            merged = np.ascontiguousarray(gather_events(local, tag), dtype=np.uint32)
             keep["buf"] = merged                         # valid until the next call
             all_ptr[0] = merged.ctypes.data if merged.shape[0] else None
             n_all_ptr[0] = merged.shape[0]

@@ -235,6 +235,13 @@ P = len(fx["weights"])
 w = np.asarray(fx["weights"], dtype=np.float64)
 samples = np.random.default_rng(31).multinomial(int(w.sum()), w / w.sum(), size=23).astype(np.uint16)
 e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+if rank == 1:
+    # a different past on this engine (its batch-size estimate, node order ...) must not change how it cuts the climb
+    e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    e.seed_ties(engine.TIE_RANDOM, 5)
+    e.optimize_spr(1, 6)
+    e.optimize_spr(1, 6)
+    e.reset_node_order()
 e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
 e.seed_ties(engine.TIE_RANDOM, 19)
 e.ufboot_attach(samples, 0.5, shard=(rank, ws))
