@@ -173,54 +173,55 @@ def main():
     #     rank b % n_gpus (strong scaling: the total number of samples is fixed).
     ufb = None
     boot = None
+    legs_error = None
     if args.ufboot_samples > 0:
-        B = args.ufboot_samples
-        samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
-        if rank == 0 or args.start_tree != "ras":
-            back_u = back if rank == 0 else trees.random_topology(n, np.random.default_rng(1000))
-        else:                                      # the chain starts from rank 0's tree on every rank
-            eng.seed_ties(engine.TIE_RANDOM, 1)
-            eng.make_parsimony_tree(12345, 0)
-            back_u = eng.get_tree()
-        for timed in (False, True):                # first pass: allocations, code load
-            eng.ufboot_attach(samples, 0.5, shard=(rank, world))   # samples rank, rank + world, ... ; events all-gathered per batch
-            eng.set_tree(back_u)
-            eng.reset_node_order()
-            eng.seed_ties(engine.TIE_RANDOM, 1)
-            eng.reset_stats()
-            barrier()
-            tu0 = time.perf_counter()
-            us = eng.optimize_spr(1, args.maxtrav)
-            barrier()
-            tu = time.perf_counter() - tu0
-        ust, ucn = eng.stats(), eng.ufboot_counters()
-        ufb = {"samples": B, "samples_local": len(range(rank, B, world)), "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
-               "saved_trees": len(eng.ufboot_tree_logl()), **ucn}
-        n_rep = min(B, args.bootstrap_replicates)
-        if n_rep > 0:
-            from mpboot_amd import bootstrap
-            _logl, _cnt, bt = eng.ufboot_state()
-            cache = {}
-            boot_trees = []
-            for b in range(n_rep):
-                t = int(bt[b])
-                if t not in cache:
-                    cache[t] = eng.ufboot_tree(t)
-                boot_trees.append(cache[t])
-            online_best = -_logl[:n_rep]
-        eng.ufboot_detach()
-        if n_rep > 0:
-            engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
-                               for _ in range(max(0, args.engines_per_gpu - 1))]
-            bootstrap.refine_boot_trees(engines, samples[:min(n_rep, 8 * world)], boot_trees[:min(n_rep, 8 * world)], 999, args.maxtrav)  # warm-up
-            barrier()
-            tb0 = time.perf_counter()
-            bscores, _ = bootstrap.refine_boot_trees(engines, samples[:n_rep], boot_trees, 7, args.maxtrav)
-            barrier()
-            tb = time.perf_counter() - tb0
-            boot = (n_rep, tb, float(np.mean(bscores)), float(np.mean(online_best)), bool((bscores <= online_best).all()))
-            eng.set_weights(np.ones(P, dtype=np.int32))
-        eng.set_tree(back)
+        try:
+            B = args.ufboot_samples
+            samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
+            from mpboot_amd import shard
+            back_u = shard.broadcast_tree(back, 0, len(back))      # the chain starts from rank 0's tree on every rank
+            for timed in (False, True):                # first pass: allocations, code load
+                eng.ufboot_attach(samples, 0.5, shard=(rank, world))   # samples rank, rank + world, ... ; events all-gathered per batch
+                eng.set_tree(back_u)
+                eng.reset_node_order()
+                eng.seed_ties(engine.TIE_RANDOM, 1)
+                eng.reset_stats()
+                barrier()
+                tu0 = time.perf_counter()
+                us = eng.optimize_spr(1, args.maxtrav)
+                barrier()
+                tu = time.perf_counter() - tu0
+            ust, ucn = eng.stats(), eng.ufboot_counters()
+            ufb = {"samples": B, "samples_local": len(range(rank, B, world)), "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
+                   "saved_trees": len(eng.ufboot_tree_logl()), **ucn}
+            n_rep = min(B, args.bootstrap_replicates)
+            if n_rep > 0:
+                from mpboot_amd import bootstrap
+                _logl, _cnt, bt = eng.ufboot_state()
+                cache = {}
+                boot_trees = []
+                for b in range(n_rep):
+                    t = int(bt[b])
+                    if t not in cache:
+                        cache[t] = eng.ufboot_tree(t)
+                    boot_trees.append(cache[t])
+                online_best = -_logl[:n_rep]
+            eng.ufboot_detach()
+            if n_rep > 0:
+                engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
+                                   for _ in range(max(0, args.engines_per_gpu - 1))]
+                bootstrap.refine_boot_trees(engines, samples[:min(n_rep, 8 * world)], boot_trees[:min(n_rep, 8 * world)], 999, args.maxtrav)  # warm-up
+                barrier()
+                tb0 = time.perf_counter()
+                bscores, _ = bootstrap.refine_boot_trees(engines, samples[:n_rep], boot_trees, 7, args.maxtrav)
+                barrier()
+                tb = time.perf_counter() - tb0
+                boot = (n_rep, tb, float(np.mean(bscores)), float(np.mean(online_best)), bool((bscores <= online_best).all()))
+                eng.set_weights(np.ones(P, dtype=np.int32))
+            eng.set_tree(back)
+        except Exception as exc:        # the headline metric above must survive a failing secondary leg
+            legs_error = repr(exc)
+            ufb = boot = None
 
     tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
@@ -287,6 +288,8 @@ def main():
                                  "scan": st["host_scan_ms_total"] / args.steps,
                                  "sweep_call": st["host_sweep_ms_total"] / args.steps},
         }
+        if legs_error is not None:
+            res["bootstrap_legs_error"] = legs_error
         if boot is not None:
             res["bootstrap_wall_clock"] = {
                 "samples": ufb["samples"], "online_phase_s": ufb["seconds"], "refined_samples": boot[0], "refinement_s": boot[1],
