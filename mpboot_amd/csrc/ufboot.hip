@@ -54,13 +54,13 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // registers): each weight byte is fetched once per 256 rows and each expanded A fragment feeds 8 MFMAs.  Two k-blocks
 // per stage, double-buffered in LDS (global -> registers -> LDS while the previous stage is multiplied).
 // blockIdx.y splits K; partial products are added with integer atomics (exact, order-independent).
-// WM = waves along the rows (tile = 64 WM rows), KS = k-blocks per LDS stage.
-template <int WM, int KS>
-__global__ __launch_bounds__(128 * WM) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
+// WM x WN waves (tile = 64 WM rows x 128 WN samples), KS = k-blocks per LDS stage.
+template <int WM, int WN, int KS>
+__global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
                                                  int kb_per_split, const uint32_t *__restrict__ rowsel)
 {
-  constexpr int MT = 4, NT = 8, TM = 64 * WM, TN = 256, NTH = 128 * WM;
+  constexpr int MT = 4, NT = 8, TM = 64 * WM, TN = 128 * WN, NTH = 64 * WM * WN;
   constexpr int kGemmAStride = 2 * KS + 1;           // words per row of the A stage tile (+1: bank spread)
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
   constexpr int LD = BT / (NTH * 16);                // 16-byte loads per thread per k-block
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(128 * WM) void k_bitgemm(const uint32_t *__restrict
   uint8_t *s_b = s_raw;
   uint32_t *s_a = reinterpret_cast<uint32_t *>(s_raw + 2 * KS * BT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   // workgroups are dealt round-robin to the 8 XCDs: the 32 concurrent workgroups of an XCD share ONE column block,
   // so its slab of Wt streams through that XCD's L2 once per round
   const int col_blocks = Bp / TN;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(128 * WM) void k_bitgemm(const uint32_t *__restrict
       }
     }
 }
-template <int WM, int KS>
-constexpr size_t gemm_lds() { return 2 * (size_t)KS * 256 * 64 + 2 * (size_t)(64 * WM) * (2 * KS + 1) * sizeof(uint32_t); }
+template <int WM, int WN, int KS>
+constexpr size_t gemm_lds() { return 2 * (size_t)KS * (128 * WN) * 64 + 2 * (size_t)(64 * WM) * (2 * KS + 1) * sizeof(uint32_t); }
 
 // R_T[b] = sum over rows of C[row][b]
 __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
@@ -294,16 +294,16 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
   return hipGetLastError();
 }
 
-template <int WM, int KS>
+template <int WM, int WN, int KS>
 static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
                                    int mult, int accumulate, const uint32_t *rowsel)
 {
   constexpr int TM = 64 * WM;
-  const int row_blocks = rows_padded / TM, col_blocks = Bp / kUfbColTile;
+  const int row_blocks = rows_padded / TM, col_blocks = Bp / (128 * WN);
   const int nkb = Wp / 2;
   // small batches: split K so that the launch still has a few workgroups per CU
   long tiles = (long)row_blocks * col_blocks;
-  const long want = 512 * (4 / WM);
+  const long want = 512;
   int ksplit = 1;
   if (tiles < want) ksplit = (int)std::min<long>((want + tiles - 1) / tiles, std::max(1, nkb / 16));
   int per = (nkb + ksplit - 1) / ksplit;
@@ -322,13 +322,13 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  constexpr size_t lds = gemm_lds<WM, KS>();
+  constexpr size_t lds = gemm_lds<WM, WN, KS>();
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<WM, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<WM, WN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_bitgemm<WM, KS>), dim3(gx, (unsigned)ksplit), dim3(128 * WM), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
+  hipLaunchKernelGGL((k_bitgemm<WM, WN, KS>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
 }
 
@@ -336,11 +336,10 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
                           int mult, int accumulate, const uint32_t *rowsel)
 {
   if (rows_padded <= 0) return hipSuccess;
-  static int variant = -1;
-  if (variant < 0) { const char *v = std::getenv("MPF_GEMM_VARIANT"); variant = v ? std::atoi(v) : 0; }
-  if (variant == 1) return launch_bitgemm_t<2, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-  if (variant == 2) return launch_bitgemm_t<4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-  return launch_bitgemm_t<4, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  // 256-sample column blocks when the (padded) sample count allows, else 128-sample blocks with twice the rows per
+  // workgroup (sample-sharded runs: 1000 samples over 8 GPUs = 125 per rank)
+  if (Bp % 256 == 0) return launch_bitgemm_t<4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  return launch_bitgemm_t<8, 1, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
 }
 
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)

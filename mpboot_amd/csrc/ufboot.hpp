@@ -9,7 +9,7 @@ namespace mpf {
 
 struct UfbEvent { uint32_t idx, b, s; };     // scan output index, sample, parsimony length under that sample
 
-constexpr int kUfbRowTile = 256, kUfbColTile = 256;   // k_bitgemm workgroup tile (rows x samples)
+constexpr int kUfbRowTile = 512, kUfbColTile = 128;   // padding units of k_bitgemm: rows of the mask matrix, samples
 
 // masks[op][Wp] = sites mutating on join (a, b)
 hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops, uint32_t *masks);

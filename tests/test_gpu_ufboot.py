@@ -119,6 +119,15 @@ def test_cutoff_filter_and_next_cutoff(mods):
     assert (e.ufboot_tree_logl()[n_before:] > cut_e - 1e-4).all()
 
 
+def test_more_than_128_samples_use_the_wide_column_tile(mods):
+    engine, po = mods
+    fx = load_fixture("dna_dups")
+    samples = boot_samples(len(fx["weights"]), 150, 21, fx["weights"])
+    start = np.array(fx["trees"][7]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 2)
+    assert_same(e, o, se, so)
+
+
 def test_heavy_weights_use_a_second_plane(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
