@@ -188,14 +188,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
 template <int WM, int WN, int KS>
 constexpr size_t gemm_lds() { return 2 * (size_t)KS * (128 * WN) * 64 + 2 * (size_t)(64 * WM) * (2 * KS + 1) * sizeof(uint32_t); }
 
-// R_T[b] = sum over rows of C[row][b]
+// R_T[b] = sum over rows of C[row][b]   (rt zeroed by the launcher; 64 rows per thread, integer atomics)
 __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
+  const int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
   int32_t s = 0;
-  for (int r = 0; r < rows; r++) s += C[(size_t)r * Bp + b];
-  rt[b] = s;
+  for (int r = r0; r < r1; r++) s += C[(size_t)r * Bp + b];
+  if (s) __hip_atomic_fetch_add(rt + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // R_T += C[row] - C[home]   (the accepted move's candidate becomes the current tree)
@@ -227,7 +228,7 @@ __device__ __forceinline__ bool ufb_score(uint32_t i, int b, const uint2 *__rest
   return true;
 }
 
-constexpr int kUfbChunk = 64;
+constexpr int kUfbChunk = 256;
 
 __global__ __launch_bounds__(256) void k_ufb_chunkmin(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
                                                       const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
@@ -344,7 +345,9 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
 
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)
 {
-  hipLaunchKernelGGL(k_colsum, dim3((Bp + 255) / 256), dim3(256), 0, st, C, rows, Bp, rt);
+  hipError_t e = hipMemsetAsync(rt, 0, (size_t)Bp * sizeof(int32_t), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_colsum, dim3((Bp + 255) / 256, (rows + 63) / 64), dim3(256), 0, st, C, rows, Bp, rt);
   return hipGetLastError();
 }
 
