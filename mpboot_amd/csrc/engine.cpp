@@ -375,11 +375,15 @@ int Engine::schedule_views(const std::vector<int> *roots)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   ScopedMs timer(stats.host_views_ms_total);
-  std::vector<int> all;
+  // scratch vectors are members: this runs once per scan batch, allocations would show
+  std::vector<int> &all = sv_all_;
+  all.clear();
   if (!roots) {
     // every record of the component containing start_
-    std::vector<int> stack;
-    std::vector<char> seen(2 * (size_t)n_ + 1, 0);
+    std::vector<int> &stack = sv_stack_;
+    std::vector<char> &seen = sv_seen_;
+    stack.clear();
+    seen.assign(2 * (size_t)n_ + 1, 0);
     stack.push_back(back_[start_]);
     while (!stack.empty()) {
       const int r = stack.back();
@@ -392,8 +396,10 @@ int Engine::schedule_views(const std::vector<int> *roots)
   }
   // closure of invalid inputs, post-order, with dependency levels (epoch-stamped scratch arrays)
   epoch_++;
-  std::vector<int> order;
-  std::vector<std::pair<int, int>> stack;
+  std::vector<int> &order = sv_order_;
+  std::vector<std::pair<int, int>> &stack = sv_pairs_;
+  order.clear();
+  stack.clear();
   auto lev_of = [&](int r) { return (tip(r) || lev_epoch_[r] != epoch_) ? 0 : lev_[r]; };
   for (int r0 : *roots) {
     if (r0 < 0 || tip(r0) || valid_[r0] || lev_epoch_[r0] == epoch_) continue;
@@ -445,7 +451,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
     int acc = 0;
     for (int l = 1; l <= maxlev; l++) { const int c = lo[l]; lo[l] = acc; acc += c; }
     lo[0] = 0;
-    std::vector<int> fill(lo, lo + maxlev + 1);
+    std::vector<int> &fill = sv_fill_;
+    fill.assign(lo, lo + maxlev + 1);
     upd_order_.resize(nops);
     for (int r : order) {
       const int at = fill[lev_[r]]++;

@@ -304,6 +304,9 @@ class Engine {
   std::vector<int32_t> lev_, lev_epoch_;
   int32_t epoch_ = 0;
   std::vector<int> upd_order_;
+  std::vector<int> sv_all_, sv_stack_, sv_order_, sv_fill_;      // schedule_views scratch
+  std::vector<char> sv_seen_;
+  std::vector<std::pair<int, int>> sv_pairs_;
   bool pending_scores_ = false, kids_dirty_ = true, view_events_pending_ = false;
   long n_invalid_ = -1;                         // -1 = unknown/many, 0 = every vector valid
   int split_below_ = 64;                        // batches of at most this many prune nodes are cut into 4 parts per scan
