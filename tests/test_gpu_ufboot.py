@@ -328,3 +328,17 @@ def test_unsupported_configurations_fail_loudly(mods):
     s = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
     with pytest.raises(engine.MpfError):
         s.ufboot_attach(samples)
+    # the bookkeeping lives in the device-walked scan: other scan modes / longer radii refuse instead of skipping it
+    e.ufboot_attach(samples)
+    e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    with pytest.raises(engine.MpfError):
+        e.optimize_spr(1, 9)
+    e.set_option("scan_mode", 0)
+    with pytest.raises(engine.MpfError):
+        e.optimize_spr(1, 6)
+    e.set_option("scan_mode", 1)
+    assert e.optimize_spr(1, 6) > 0
+    # re-weighting re-packs the sites the sample weights are laid out by: the tracker is dropped, not left stale
+    e.set_weights(fx["weights_np"])
+    with pytest.raises(engine.MpfError):
+        e.ufboot_state()
