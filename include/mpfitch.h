@@ -122,6 +122,10 @@ int mpf_score_trees(mpf_engine *e, int32_t n_trees, const int32_t *backs, uint32
 /* pllComputePatternParsimony (sprparsimony.cpp:3363-3392): per-pattern Fitch lengths of the
    current tree, ptn_pars[P] (0 for dropped patterns); *total = sum(ptn * weight). */
 int mpf_pattern_scores(mpf_engine *e, uint16_t *ptn_pars, int32_t *total);
+/* pllComputeSiteParsimony (sprparsimony.cpp:3403-3450): the same lengths per EXPANDED site, i.e. in the packed order
+   of the kept patterns with a pattern of weight w repeated w times (the reference's perSitePartialPars row of
+   tr->start); entries from the number of expanded sites up to n_sites are 0; *total = their sum. */
+int mpf_site_scores(mpf_engine *e, int32_t *site_pars, int32_t n_sites, int32_t *total);
 
 /* int PhyloTree::computeParsimony() (phylotree.cpp:1049-1061; callers precede it with
    initializeAllPartialPars(); clearAllPartialLH(), e.g. iqtree.cpp:2141-2143): Fitch length of the given

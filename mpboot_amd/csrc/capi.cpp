@@ -103,6 +103,13 @@ int mpf_score_trees(mpf_engine *e, int32_t n_trees, const int32_t *backs, uint32
 
 int mpf_pattern_scores(mpf_engine *e, uint16_t *ptn_pars, int32_t *total) { NEED(e); return e->eng.pattern_scores(ptn_pars, total); }
 
+int mpf_site_scores(mpf_engine *e, int32_t *site_pars, int32_t n_sites, int32_t *total)
+{
+  NEED(e);
+  if (!site_pars || n_sites < 0) { set_error("mpf_site_scores: bad argument"); return MPF_E_INVALID; }
+  return e->eng.site_scores(site_pars, n_sites, total);
+}
+
 int mpf_compute_parsimony(mpf_engine *e, const int32_t *back, uint32_t *score, uint16_t *pattern_pars)
 {
   NEED(e);

@@ -1034,6 +1034,24 @@ int Engine::pattern_scores(uint16_t *ptn, int32_t *total)
   return MPF_OK;
 }
 
+// pllComputeSiteParsimony (reference sprparsimony.cpp:3403-3450): per expanded site, from the per-pattern lengths
+int Engine::site_scores(int32_t *site_pars, int n_sites, int32_t *total)
+{
+  if (sankoff_) { set_error("mpf_site_scores: Fitch mode only (the weighted engine keeps patterns, not expanded sites)"); return MPF_E_UNSUPPORTED; }
+  std::vector<uint16_t> ptn((size_t)P_);
+  int rc = pattern_scores(ptn.data(), nullptr);
+  if (rc) return rc;
+  long sum = 0;
+  int site = 0;
+  for (int k = 0; k < P_ && site < n_sites; k++) {
+    if (first_site_[(size_t)k] < 0) continue;
+    for (int w = 0; w < wgt_[(size_t)k] && site < n_sites; w++) { site_pars[site++] = ptn[(size_t)k]; sum += ptn[(size_t)k]; }
+  }
+  for (; site < n_sites; site++) site_pars[site] = 0;
+  if (total) *total = (int32_t)sum;
+  return MPF_OK;
+}
+
 int Engine::set_option(const std::string &key, int64_t v)
 {
   if (key == "scan_batch") { if (v < 1) return MPF_E_INVALID; scan_batch_ = (int)v; return MPF_OK; }

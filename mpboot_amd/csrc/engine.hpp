@@ -165,6 +165,7 @@ class Engine {
   // ---- scoring
   int score_tree(uint32_t *score);             // evaluateParsimony(start, full)
   int pattern_scores(uint16_t *ptn, int32_t *total);
+  int site_scores(int32_t *site_pars, int n_sites, int32_t *total);   // pllComputeSiteParsimony
   int update_views();                          // make every directional vector of the current tree valid (syncs)
   int tree_length(uint32_t *len);              // from valid views
   // validity-tracked refresh: only invalid vectors that the given roots depend on are recomputed

@@ -20,7 +20,7 @@ EXPORTS = [
     "mpf_last_error", "mpf_abi_version", "mpf_engine_create", "mpf_engine_create_sankoff", "mpf_engine_destroy",
     "mpf_set_weights",
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
-    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_compute_parsimony",
+    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_site_scores", "mpf_compute_parsimony",
     "mpf_encode_iqtree_states", "mpf_seed_ties",
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
@@ -80,6 +80,7 @@ def load_library():
         L.mpf_score_tree.argtypes = [vp, vp]
         L.mpf_score_trees.argtypes = [vp, C.c_int32, vp, vp]
         L.mpf_pattern_scores.argtypes = [vp, vp, vp]
+        L.mpf_site_scores.argtypes = [vp, vp, C.c_int32, vp]
         L.mpf_compute_parsimony.argtypes = [vp, vp, vp, vp]
         L.mpf_encode_iqtree_states.argtypes = [C.c_int32, vp, C.c_int64, vp]
         L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
@@ -298,6 +299,13 @@ class FitchEngine:
 
     def seed_ties(self, mode: int, seed: int = 1):
         _chk(load_library().mpf_seed_ties(self.h, mode, seed))
+
+    def site_scores(self, n_sites: int):
+        """pllComputeSiteParsimony: lengths per expanded (weight-replicated) site of the kept patterns."""
+        out = np.zeros(n_sites, dtype=np.int32)
+        tot = C.c_int32()
+        _chk(load_library().mpf_site_scores(self.h, _p(out), n_sites, C.byref(tot)))
+        return out, tot.value
 
     def spr_scan(self, rec: int, mintrav: int = 1, maxtrav: int = 6, cap: int = 1 << 16):
         q = np.zeros(cap, dtype=np.int32)

@@ -548,6 +548,17 @@ int orc_pattern_scores(orc *o, unsigned short *ptn)
   return sum;
 }
 
+/* ---- pllComputeSiteParsimony: sprparsimony.cpp:3403-3450 (the per-site row of tr->start, then zeros) ---- */
+int orc_site_scores(orc *o, int *site_pars, int nsite)
+{
+  const uint32_t *p = o->persite + (size_t)o->W * 32 * NUM(o->start);
+  int k, site = 0, sum = 0, width = 0;
+  for (k = 0; k < o->P; k++) if (o->inf[k]) width += o->wgt[k];
+  for (k = 0; k < width && site < nsite; k++) { site_pars[site] = (int)p[k]; sum += site_pars[site]; site++; }
+  for (; site < nsite; site++) site_pars[site] = 0;
+  return sum;
+}
+
 void orc_seed_ties(orc *o, int tie_mode, int seed)
 {
   o->tie_mode = tie_mode;

@@ -49,6 +49,7 @@ void orc_node_rectifier(orc *o);
 unsigned orc_evaluate(orc *o, int rec, int full);
 unsigned orc_score_tree(orc *o);             /* nodeRectifier + evaluate(start, full) */
 int orc_pattern_scores(orc *o, unsigned short *ptn /* [P] */);  /* returns sum(ptn*weight) */
+int orc_site_scores(orc *o, int *site_pars, int nsite);         /* pllComputeSiteParsimony; returns the sum */
 
 void orc_seed_ties(orc *o, int tie_mode, int seed);
 void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg);

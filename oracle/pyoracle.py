@@ -60,6 +60,8 @@ def lib():
         L.orc_score_tree.argtypes = [vp]
         L.orc_pattern_scores.restype = ci
         L.orc_pattern_scores.argtypes = [vp, vp]
+        L.orc_site_scores.restype = ci
+        L.orc_site_scores.argtypes = [vp, vp, ci]
         L.orc_seed_ties.argtypes = [vp, ci, ci]
         L.orc_set_pre_evaluate.argtypes = [vp, ci]
         L.orc_trace.argtypes = [vp, ci]
@@ -181,6 +183,11 @@ class Oracle:
     def pattern_scores(self):
         out = np.zeros(self.P, dtype=np.uint16)
         total = lib().orc_pattern_scores(self.h, _p(out))
+        return out, int(total)
+
+    def site_scores(self, nsite: int):
+        out = np.zeros(nsite, dtype=np.int32)
+        total = lib().orc_site_scores(self.h, _p(out), nsite)
         return out, int(total)
 
     def seed_ties(self, mode: int, seed: int = 1):

@@ -127,6 +127,23 @@ def test_randomized_stepwise_addition_tree_matches_oracle(mods, fx, seed, dist):
     assert (e.get_tree() == o.get_tree()).all()
 
 
+def test_site_scores_match_oracle(mods, fx):
+    """pllComputeSiteParsimony: per expanded site, zero padded"""
+    engine, po = mods[0], mods[1]
+    e = eng_of(engine, fx)
+    o = orc_of(po, fx)
+    o.enable_persite(True)
+    nsite = int(np.sum(fx["weights_np"])) + 7
+    for t in fx["trees"][:3]:
+        back = np.array(t["back"], dtype=np.int32)
+        e.set_tree(back)
+        assert o.score_tree(back) == t["score"]
+        se, te = e.site_scores(nsite)
+        so, to = o.site_scores(nsite)
+        assert te == to == t["score"]
+        assert se.tolist() == so.tolist()
+
+
 def test_pll_original_hill_climb_matches_reference_trajectory(mods, fx):
     """the PLL original's SPR hill climb (first-best rule): the reference's own accepted moves, final tree and score"""
     engine = mods[0]
