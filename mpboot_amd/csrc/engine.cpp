@@ -167,7 +167,10 @@ int Engine::pack()
       if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
       g_.Wp = wp;
       vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
-      HIPCHK(hipMalloc((void **)&d_vec_, vec_words_ * sizeof(uint32_t)));
+      // weighted mode keeps m(v) = min-plus transform of every vector next to v (second half of the allocation): a
+      // transform costs 2 S^2 operations per pattern, and each stored one is used by up to three consumers
+      g_.moff = vec_words_;
+      HIPCHK(hipMalloc((void **)&d_vec_, 2 * vec_words_ * sizeof(uint32_t)));
     }
     std::vector<uint32_t> pw((size_t)g_.Wp, 0u);
     for (int j = 0; j < ninf_; j++) pw[(size_t)j] = (uint32_t)wgt_[(size_t)inf_index_[(size_t)j]];

@@ -766,6 +766,9 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
 // nature (2*S*S add/min per transform), not MFMA-shaped (min-plus, not multiply-add).
 // Exact 32-bit arithmetic (the reference's -short_off mode).  Cost matrices must be symmetric: only then
 // is the length independent of root placement, which the directional-view formulation relies on.
+// Every vector v is stored together with m(v) (at `moff` words behind it): a parent view is m(a) + m(b), a branch
+// length min_x(a[x] + m(b)[x]), so newview needs ONE transform (of its result) instead of two, evaluate none, and an
+// SPR candidate one (of the running up-vector) instead of four.
 
 template <int S>
 struct Costs { uint32_t v[S]; };
@@ -800,23 +803,25 @@ __device__ __forceinline__ uint32_t min_of(const Costs<S> &a)
 }
 
 template <int S>
-__device__ __forceinline__ void newview_one_snk(uint32_t *__restrict__ vec, const NvOp o, const uint32_t *__restrict__ cost,
+__device__ __forceinline__ void newview_one_snk(uint32_t *__restrict__ vec, size_t moff, const NvOp o, const uint32_t *__restrict__ cost,
                                                 uint32_t *__restrict__ cntp, uint32_t nslots, int Wp, int tile, int lane)
 {
   bool valid;
   const int w0 = lane_word<1>(tile, lane, Wp, valid);
-  Costs<S> a, b, ma, mb;
-  load_costs<S>(a, vec, o.a, Wp, w0);
-  load_costs<S>(b, vec, o.b, Wp, w0);
-  mplus<S>(ma, a, cost);
-  mplus<S>(mb, b, cost);
+  Costs<S> ma, mb, c, mc;
+  load_costs<S>(ma, vec + moff, o.a, Wp, w0);
+  load_costs<S>(mb, vec + moff, o.b, Wp, w0);
   uint32_t *dst = vec + (size_t)o.dst * (size_t)(S * Wp) + w0;
   uint32_t cur = 0xFFFFFFFFu;
 #pragma unroll
   for (int z = 0; z < S; z++) {
-    const uint32_t c = ma.v[z] + mb.v[z];
-    cur = min(cur, c);
-    if (valid) dst[(size_t)z * Wp] = c;
+    c.v[z] = ma.v[z] + mb.v[z];
+    cur = min(cur, c.v[z]);
+  }
+  mplus<S>(mc, c, cost);
+  if (valid) {
+#pragma unroll
+    for (int z = 0; z < S; z++) { dst[(size_t)z * Wp] = c.v[z]; dst[moff + (size_t)z * Wp] = mc.v[z]; }
   }
   cur = valid ? cur : 0u;
   const uint32_t tot = wave_total<0>(cur);
@@ -824,7 +829,7 @@ __device__ __forceinline__ void newview_one_snk(uint32_t *__restrict__ vec, cons
 }
 
 template <int S>
-__global__ __launch_bounds__(256) void k_snk_newview(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops, int n_ops,
+__global__ __launch_bounds__(256) void k_snk_newview(uint32_t *__restrict__ vec, size_t moff, const NvOp *__restrict__ ops, int n_ops,
                                                      const uint32_t *__restrict__ cost, uint32_t *__restrict__ cntp,
                                                      uint32_t nslots, int Wp, int tiles)
 {
@@ -833,11 +838,11 @@ __global__ __launch_bounds__(256) void k_snk_newview(uint32_t *__restrict__ vec,
   gw = __builtin_amdgcn_readfirstlane(gw);
   if (gw >= n_ops * tiles) return;
   const int op = gw / tiles, tile = gw - op * tiles;
-  newview_one_snk<S>(vec, ops[op], cost, cntp, nslots, Wp, tile, lane);
+  newview_one_snk<S>(vec, moff, ops[op], cost, cntp, nslots, Wp, tile, lane);
 }
 
 template <int S>
-__global__ __launch_bounds__(1024) void k_snk_newview_wg(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+__global__ __launch_bounds__(1024) void k_snk_newview_wg(uint32_t *__restrict__ vec, size_t moff, const NvOp *__restrict__ ops,
                                                          const int32_t *__restrict__ lev_off, int n_lev,
                                                          const uint32_t *__restrict__ cost, uint32_t *__restrict__ cntp,
                                                          uint32_t nslots, int Wp)
@@ -848,14 +853,14 @@ __global__ __launch_bounds__(1024) void k_snk_newview_wg(uint32_t *__restrict__ 
   const int tile = blockIdx.x;
   for (int l = 0; l < n_lev; l++) {
     const int b = lev_off[l], e = lev_off[l + 1];
-    for (int i = b + wave; i < e; i += nw) newview_one_snk<S>(vec, ops[i], cost, cntp, nslots, Wp, tile, lane);
+    for (int i = b + wave; i < e; i += nw) newview_one_snk<S>(vec, moff, ops[i], cost, cntp, nslots, Wp, tile, lane);
     __syncthreads();
   }
 }
 
 // weighted length across branch (a, b): sum_ptn w * min_x(A[x] + m(B)[x])
 template <int S>
-__global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict__ vec, const EvOp *__restrict__ ops,
+__global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict__ vec, size_t moff, const EvOp *__restrict__ ops,
                                                       int n_ops, const uint32_t *__restrict__ cost,
                                                       const uint32_t *__restrict__ pwgt, uint32_t *__restrict__ out,
                                                       int Wp, int tiles)
@@ -868,10 +873,9 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
   const EvOp o = ops[op];
   bool valid;
   const int w0 = lane_word<1>(tile, lane, Wp, valid);
-  Costs<S> a, b, mb;
+  Costs<S> a, mb;
   load_costs<S>(a, vec, o.a, Wp, w0);
-  load_costs<S>(b, vec, o.b, Wp, w0);
-  mplus<S>(mb, b, cost);
+  load_costs<S>(mb, vec + moff, o.b, Wp, w0);
   uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
   for (int x = 0; x < S; x++) best = min(best, a.v[x] + mb.v[x]);
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
 //   JOIN  : out += sum_ptn w * min_s(m(vec[own])[s] + m(vec[sib])[s] + m(S)[s])
 // and out is the FULL length of the rearranged tree (there is no additive base in the weighted case).
 template <int S, int MAXD>
-__global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
+__global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
                                                   int n_scans, const ScanOp *__restrict__ ops,
                                                   const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
                                                   uint32_t *__restrict__ out, int Wp, int tiles)
@@ -899,10 +903,11 @@ __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ v
   bool valid;
   const int w0 = lane_word<1>(tile, lane, Wp, valid);
   const uint32_t w = valid ? pwgt[w0] : 0u;
+  const uint32_t *mvec = vec + moff;
 
-  Costs<S> ms, U[MAXD + 1], t0, t1, t2;
-  load_costs<S>(t0, vec, h.s_slot, Wp, w0);
-  mplus<S>(ms, t0, cost);
+  // MU[d] = m(U[d]): what the children of depth d and the test at depth d both need; U itself is never kept
+  Costs<S> ms, MU[MAXD + 1], t1, t2;
+  load_costs<S>(ms, mvec, h.s_slot, Wp, w0);
 
   for (uint32_t i = h.op_begin; i < h.op_end; i++) {
     const ScanOp o = ops[i];
@@ -910,28 +915,24 @@ __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ v
     const bool test = (o.meta >> 8) & 1u;
     const int kind = (int)((o.meta >> 16) & 0xFFu);
     if (kind == SCAN_ROOT) {
-      load_costs<S>(U[0], vec, o.own, Wp, w0);
+      load_costs<S>(MU[0], mvec, o.own, Wp, w0);
       continue;
     }
     uint32_t best = 0xFFFFFFFFu;
-    load_costs<S>(t0, vec, o.sib, Wp, w0);
-    mplus<S>(t1, t0, cost);                       // m(vec[sib])
+    load_costs<S>(t1, mvec, o.sib, Wp, w0);       // m(vec[sib])
     if (kind == SCAN_JOIN) {
-      load_costs<S>(t0, vec, o.own, Wp, w0);
-      mplus<S>(t2, t0, cost);
+      load_costs<S>(t2, mvec, o.own, Wp, w0);
 #pragma unroll
       for (int s = 0; s < S; s++) best = min(best, t1.v[s] + t2.v[s] + ms.v[s]);
     } else {
 #define MPF_SLEVEL(c)                                                                  \
   case c:                                                                              \
     if constexpr (c <= MAXD) {                                                         \
-      mplus<S>(t2, U[c - 1], cost);                                                    \
-      _Pragma("unroll") for (int s = 0; s < S; s++) U[c].v[s] = t1.v[s] + t2.v[s];     \
+      _Pragma("unroll") for (int s = 0; s < S; s++) t2.v[s] = t1.v[s] + MU[c - 1].v[s]; /* U[c] */ \
+      mplus<S>(MU[c], t2, cost);                                                       \
       if (test) {                                                                      \
-        load_costs<S>(t0, vec, o.own, Wp, w0);                                         \
-        mplus<S>(t1, t0, cost);                                                        \
-        mplus<S>(t2, U[c], cost);                                                      \
-        _Pragma("unroll") for (int s = 0; s < S; s++) best = min(best, t1.v[s] + t2.v[s] + ms.v[s]); \
+        load_costs<S>(t1, mvec, o.own, Wp, w0);                                        \
+        _Pragma("unroll") for (int s = 0; s < S; s++) best = min(best, t1.v[s] + MU[c].v[s] + ms.v[s]); \
       }                                                                                \
     }                                                                                  \
     break;
@@ -951,15 +952,14 @@ __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ v
 }
 
 template <int S>
-__global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict__ vec, uint32_t a_slot, uint32_t b_slot,
+__global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict__ vec, size_t moff, uint32_t a_slot, uint32_t b_slot,
                                                      const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int Wp)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= Wp) return;
-  Costs<S> a, b, mb;
+  Costs<S> a, mb;
   load_costs<S>(a, vec, a_slot, Wp, j);
-  load_costs<S>(b, vec, b_slot, Wp, j);
-  mplus<S>(mb, b, cost);
+  load_costs<S>(mb, vec + moff, b_slot, Wp, j);
   uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
   for (int x = 0; x < S; x++) best = min(best, a.v[x] + mb.v[x]);
@@ -968,22 +968,26 @@ __global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict_
 
 // compressSankoffDNA (reference sprparsimony.cpp:2636-2825): cost 0 for states in the tip's set, highest_cost otherwise
 template <int S>
-__global__ __launch_bounds__(256) void k_snk_pack(uint32_t *__restrict__ vec, const uint8_t *__restrict__ codes, int n_taxa,
+__global__ __launch_bounds__(256) void k_snk_pack(uint32_t *__restrict__ vec, size_t moff, const uint8_t *__restrict__ codes, int n_taxa,
                                                   int n_patterns, const int32_t *__restrict__ inf_index, int n_inf,
-                                                  int datatype, uint32_t highest, int Wp)
+                                                  int datatype, uint32_t highest, const uint32_t *__restrict__ cost, int Wp)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int tip = blockIdx.y;
   if (j >= Wp || tip >= n_taxa) return;
   uint32_t *dst = vec + (size_t)tip * (size_t)(S * Wp) + j;
+  Costs<S> v, mv;
   if (j >= n_inf) {
 #pragma unroll
-    for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = 0u;        // padded patterns, :2766-2775
-    return;
-  }
-  const uint32_t m = state_mask(datatype, codes[(size_t)tip * n_patterns + inf_index[j]]);
+    for (int k = 0; k < S; k++) v.v[k] = 0u;                     // padded patterns, :2766-2775
+  } else {
+    const uint32_t m = state_mask(datatype, codes[(size_t)tip * n_patterns + inf_index[j]]);
 #pragma unroll
-  for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = ((m >> k) & 1u) ? 0u : highest;
+    for (int k = 0; k < S; k++) v.v[k] = ((m >> k) & 1u) ? 0u : highest;
+  }
+  mplus<S>(mv, v, cost);
+#pragma unroll
+  for (int k = 0; k < S; k++) { dst[(size_t)k * Wp] = v.v[k]; dst[moff + (size_t)k * Wp] = mv.v[k]; }
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -1024,8 +1028,8 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (g.sankoff) {
-    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview<4>, grid, block, 0, st, vec, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
-    else hipLaunchKernelGGL(k_snk_newview<20>, grid, block, 0, st, vec, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
+    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview<4>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
+    else hipLaunchKernelGGL(k_snk_newview<20>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
     return hipGetLastError();
   }
 #define NV(S_, VW_, RED_) hipLaunchKernelGGL((k_newview<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, cntp, nslots, g.Wp, tiles)
@@ -1042,8 +1046,8 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
   if (g.sankoff) {
-    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview_wg<4>, grid, block, 0, st, vec, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
-    else hipLaunchKernelGGL(k_snk_newview_wg<20>, grid, block, 0, st, vec, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
+    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview_wg<4>, grid, block, 0, st, vec, g.moff, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
+    else hipLaunchKernelGGL(k_snk_newview_wg<20>, grid, block, 0, st, vec, g.moff, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
     return hipGetLastError();
   }
 #define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp)
@@ -1072,8 +1076,8 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (g.sankoff) {
-    if (g.S == 4) hipLaunchKernelGGL(k_snk_evaluate<4>, grid, block, 0, st, vec, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
-    else hipLaunchKernelGGL(k_snk_evaluate<20>, grid, block, 0, st, vec, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    if (g.S == 4) hipLaunchKernelGGL(k_snk_evaluate<4>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    else hipLaunchKernelGGL(k_snk_evaluate<20>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
     return hipGetLastError();
   }
 #define EV(S_, VW_, RED_) hipLaunchKernelGGL((k_evaluate<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, out, g.Wp, tiles)
@@ -1095,11 +1099,11 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
     const long waves = (long)n_scans * tiles;
     dim3 sgrid((unsigned)((waves + 3) / 4));
     if (g.S == 4) {
-      if (max_depth <= 6) hipLaunchKernelGGL((k_snk_scan<4, 6>), sgrid, block, 0, st, vec, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
-      else hipLaunchKernelGGL((k_snk_scan<4, 12>), sgrid, block, 0, st, vec, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+      if (max_depth <= 6) hipLaunchKernelGGL((k_snk_scan<4, 6>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+      else hipLaunchKernelGGL((k_snk_scan<4, 12>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
     } else {
       if (max_depth > 6) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((k_snk_scan<20, 6>), sgrid, block, 0, st, vec, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+      hipLaunchKernelGGL((k_snk_scan<20, 6>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
     }
     return hipGetLastError();
   }
@@ -1189,8 +1193,8 @@ hipError_t launch_sankoff_pattern(hipStream_t st, const Geometry &g, const uint3
                                   uint16_t *ptn_out)
 {
   dim3 grid((g.Wp + 255) / 256), block(256);
-  if (g.S == 4) hipLaunchKernelGGL(k_snk_pattern<4>, grid, block, 0, st, vec, a, b, g.cost, ptn_out, g.Wp);
-  else hipLaunchKernelGGL(k_snk_pattern<20>, grid, block, 0, st, vec, a, b, g.cost, ptn_out, g.Wp);
+  if (g.S == 4) hipLaunchKernelGGL(k_snk_pattern<4>, grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, g.Wp);
+  else hipLaunchKernelGGL(k_snk_pattern<20>, grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, g.Wp);
   return hipGetLastError();
 }
 
@@ -1199,11 +1203,11 @@ hipError_t launch_pack_tips_sankoff(hipStream_t st, const Geometry &g, uint32_t 
 {
   dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);
   if (g.S == 4)
-    hipLaunchKernelGGL(k_snk_pack<4>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
-                       g.highest_cost, g.Wp);
+    hipLaunchKernelGGL(k_snk_pack<4>, grid, block, 0, st, vec, g.moff, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
+                       g.highest_cost, g.cost, g.Wp);
   else
-    hipLaunchKernelGGL(k_snk_pack<20>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
-                       g.highest_cost, g.Wp);
+    hipLaunchKernelGGL(k_snk_pack<20>, grid, block, 0, st, vec, g.moff, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
+                       g.highest_cost, g.cost, g.Wp);
   return hipGetLastError();
 }
 

@@ -47,6 +47,7 @@ struct Geometry {
   const uint32_t *cost = nullptr;   // device, [S][S]
   const uint32_t *pwgt = nullptr;   // device, [Wp] pattern weights (0 on padding)
   uint32_t highest_cost = 0;
+  size_t moff = 0;                  // words from a vector to its min-plus transform m(v) (second half of the vector array)
 };
 
 hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
