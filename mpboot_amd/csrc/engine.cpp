@@ -163,10 +163,14 @@ int Engine::pack()
     Wref_ = (ninf_ % 16) ? ninf_ + (16 - ninf_ % 16) : ninf_;     // parsimonyLength with VECSIZE = 16 (u16, AVX)
     int wp = ((ninf_ + 31) / 32) * 32;
     if (wp == 0) wp = 32;
-    if (wp != g_.Wp || !d_vec_) {
+    // 16-bit costs, two patterns per lane (the reference's default "short" arithmetic, sprparsimony.cpp:556-641), while
+    // no intermediate can reach 2^16: a view entry is at most (tips below) x max cost, a candidate sums three terms
+    const bool want16 = snk16_opt_ != 0 && 3ull * (uint64_t)n_ * (uint64_t)g_.highest_cost < 65536ull;
+    if (wp != g_.Wp || !d_vec_ || (int)want16 != g_.snk16) {
       if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
       g_.Wp = wp;
-      vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
+      g_.snk16 = want16 ? 1 : 0;
+      vec_words_ = nslots_ * (size_t)g_.S * (size_t)(want16 ? g_.Wp / 2 : g_.Wp);
       // weighted mode keeps m(v) = min-plus transform of every vector next to v (second half of the allocation): a
       // transform costs 2 S^2 operations per pattern, and each stored one is used by up to three consumers
       g_.moff = vec_words_;
@@ -178,7 +182,12 @@ int Engine::pack()
     HIPCHK(d_cost_.reserve(cost_.size()));
     HIPCHK(d_infidx_.reserve(std::max<size_t>(inf_index_.size(), 1)));
     HIPCHK(hipMemcpyAsync(d_pwgt_.p, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
-    HIPCHK(hipMemcpyAsync(d_cost_.p, cost_.data(), cost_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+    {
+      // the device copy of the cost matrix: in the 16-bit packing every entry twice (c | c << 16)
+      cost_dev_.resize(cost_.size());
+      for (size_t i = 0; i < cost_.size(); i++) cost_dev_[i] = g_.snk16 ? (cost_[i] | (cost_[i] << 16)) : cost_[i];
+      HIPCHK(hipMemcpyAsync(d_cost_.p, cost_dev_.data(), cost_dev_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+    }
     if (!inf_index_.empty())
       HIPCHK(hipMemcpyAsync(d_infidx_.p, inf_index_.data(), inf_index_.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
     g_.cost = d_cost_.p;
@@ -1071,6 +1080,11 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
   if (key == "timing") { timing_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack
+    snk16_opt_ = v ? 1 : 0;
+    if (sankoff_) return pack();
+    return MPF_OK;
+  }
   set_error("unknown option " + key);
   return MPF_E_INVALID;
 }

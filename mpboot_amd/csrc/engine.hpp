@@ -246,7 +246,8 @@ class Engine {
   bool inf_known_ = false;                       // informative flags depend on the codes only: computed once
   // Sankoff mode
   bool sankoff_ = false;
-  std::vector<uint32_t> cost_;
+  std::vector<uint32_t> cost_, cost_dev_;
+  int snk16_opt_ = 1;                            // allow the packed 16-bit cost arithmetic when the values fit
   std::vector<int32_t> inf_index_;               // informative pattern j -> original pattern index
   DevBuf<uint32_t> d_cost_, d_pwgt_;
   DevBuf<int32_t> d_infidx_;

@@ -770,82 +770,114 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
 // length min_x(a[x] + m(b)[x]), so newview needs ONE transform (of its result) instead of two, evaluate none, and an
 // SPR candidate one (of the running up-vector) instead of four.
 
-template <int S>
-struct Costs { uint32_t v[S]; };
+// Element type: PK = false: one 32-bit cost per lane (any cost matrix); PK = true: two 16-bit costs per lane
+// (v_pk_add_u16 / v_pk_min_u16: the reference's default "short" arithmetic, usable while 2 n (max cost + 1) < 65536),
+// half the instructions and half the bytes per pattern.  `cost` is [S*S] words; in PK mode each word holds the entry
+// twice (c | c << 16) so that a uniform load IS the packed operand.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-template <int S>
-__device__ __forceinline__ void load_costs(Costs<S> &t, const uint32_t *__restrict__ vec, uint32_t slot, int Wp, int w0)
+template <bool PK> struct SnkT;
+template <> struct SnkT<false> {
+  typedef uint32_t E;
+  static __device__ __forceinline__ E add(E a, E b) { return a + b; }
+  static __device__ __forceinline__ E mn(E a, E b) { return min(a, b); }
+  static __device__ __forceinline__ E cst(uint32_t c) { return c; }
+  static __device__ __forceinline__ E inf() { return 0xFFFFFFFFu; }
+  static __device__ __forceinline__ uint32_t sum(E a) { return a; }
+  static __device__ __forceinline__ uint32_t wsum(E a, const uint32_t *__restrict__ pwgt, int e) { return a * pwgt[e]; }
+};
+template <> struct SnkT<true> {
+  typedef us2 E;
+  static __device__ __forceinline__ E add(E a, E b) { return a + b; }
+  static __device__ __forceinline__ E mn(E a, E b) { return __builtin_elementwise_min(a, b); }
+  static __device__ __forceinline__ E cst(uint32_t c) { return __builtin_bit_cast(us2, c); }
+  static __device__ __forceinline__ E inf() { return (us2){0xFFFF, 0xFFFF}; }
+  static __device__ __forceinline__ uint32_t sum(E a) { return (uint32_t)a.x + (uint32_t)a.y; }
+  static __device__ __forceinline__ uint32_t wsum(E a, const uint32_t *__restrict__ pwgt, int e)
+  {
+    return (uint32_t)a.x * pwgt[2 * e] + (uint32_t)a.y * pwgt[2 * e + 1];
+  }
+};
+
+template <int S, bool PK>
+struct Costs { typename SnkT<PK>::E v[S]; };
+
+// We = elements per state row (Wp patterns, or Wp / 2 pairs); a vector is S rows of We elements
+template <int S, bool PK>
+__device__ __forceinline__ void load_costs(Costs<S, PK> &t, const uint32_t *__restrict__ vec, uint32_t slot, int We, int e0)
 {
-  const uint32_t *p = vec + (size_t)slot * (size_t)(S * Wp) + w0;
+  const typename SnkT<PK>::E *p = reinterpret_cast<const typename SnkT<PK>::E *>(vec) + (size_t)slot * (size_t)(S * We) + e0;
 #pragma unroll
-  for (int k = 0; k < S; k++) t.v[k] = p[(size_t)k * Wp];
+  for (int k = 0; k < S; k++) t.v[k] = p[(size_t)k * We];
 }
 
-template <int S>
-__device__ __forceinline__ void mplus(Costs<S> &m, const Costs<S> &v, const uint32_t *__restrict__ cost)
+// m[z] = min_x(v[x] + cost[z][x]), four z at a time: four independent add -> min chains side by side (a dependent
+// packed-math pair costs a wait state), each reading its row of the matrix through the scalar cache.
+template <int S, bool PK>
+__device__ __forceinline__ void mplus(Costs<S, PK> &m, const Costs<S, PK> &v, const uint32_t *__restrict__ cost)
 {
+  typedef SnkT<PK> T;
+  static_assert(S % 4 == 0, "state count must be a multiple of 4");
 #pragma unroll
-  for (int z = 0; z < S; z++) {
-    uint32_t acc = v.v[0] + cost[z * S];
+  for (int z0 = 0; z0 < S; z0 += 4) {
+    typename T::E a0 = T::add(v.v[0], T::cst(cost[(z0 + 0) * S])), a1 = T::add(v.v[0], T::cst(cost[(z0 + 1) * S]));
+    typename T::E a2 = T::add(v.v[0], T::cst(cost[(z0 + 2) * S])), a3 = T::add(v.v[0], T::cst(cost[(z0 + 3) * S]));
 #pragma unroll
-    for (int x = 1; x < S; x++) acc = min(acc, v.v[x] + cost[z * S + x]);
-    m.v[z] = acc;
+    for (int x = 1; x < S; x++) {
+      const typename T::E t0 = T::add(v.v[x], T::cst(cost[(z0 + 0) * S + x])), t1 = T::add(v.v[x], T::cst(cost[(z0 + 1) * S + x]));
+      const typename T::E t2 = T::add(v.v[x], T::cst(cost[(z0 + 2) * S + x])), t3 = T::add(v.v[x], T::cst(cost[(z0 + 3) * S + x]));
+      a0 = T::mn(a0, t0); a1 = T::mn(a1, t1); a2 = T::mn(a2, t2); a3 = T::mn(a3, t3);
+    }
+    m.v[z0] = a0; m.v[z0 + 1] = a1; m.v[z0 + 2] = a2; m.v[z0 + 3] = a3;
   }
 }
 
-template <int S>
-__device__ __forceinline__ uint32_t min_of(const Costs<S> &a)
-{
-  uint32_t m = a.v[0];
-#pragma unroll
-  for (int k = 1; k < S; k++) m = min(m, a.v[k]);
-  return m;
-}
-
-template <int S>
+template <int S, bool PK>
 __device__ __forceinline__ void newview_one_snk(uint32_t *__restrict__ vec, size_t moff, const NvOp o, const uint32_t *__restrict__ cost,
-                                                uint32_t *__restrict__ cntp, uint32_t nslots, int Wp, int tile, int lane)
+                                                uint32_t *__restrict__ cntp, uint32_t nslots, int We, int tile, int lane)
 {
+  typedef SnkT<PK> T;
   bool valid;
-  const int w0 = lane_word<1>(tile, lane, Wp, valid);
-  Costs<S> ma, mb, c, mc;
-  load_costs<S>(ma, vec + moff, o.a, Wp, w0);
-  load_costs<S>(mb, vec + moff, o.b, Wp, w0);
-  uint32_t *dst = vec + (size_t)o.dst * (size_t)(S * Wp) + w0;
-  uint32_t cur = 0xFFFFFFFFu;
+  const int e0 = lane_word<1>(tile, lane, We, valid);
+  Costs<S, PK> ma, mb, c, mc;
+  load_costs<S, PK>(ma, vec + moff, o.a, We, e0);
+  load_costs<S, PK>(mb, vec + moff, o.b, We, e0);
+  typename T::E *dst = reinterpret_cast<typename T::E *>(vec) + (size_t)o.dst * (size_t)(S * We) + e0;
+  typename T::E *mdst = reinterpret_cast<typename T::E *>(vec + moff) + (size_t)o.dst * (size_t)(S * We) + e0;
+  typename T::E cur = T::inf();
 #pragma unroll
   for (int z = 0; z < S; z++) {
-    c.v[z] = ma.v[z] + mb.v[z];
-    cur = min(cur, c.v[z]);
+    c.v[z] = T::add(ma.v[z], mb.v[z]);
+    cur = T::mn(cur, c.v[z]);
   }
-  mplus<S>(mc, c, cost);
+  mplus<S, PK>(mc, c, cost);
   if (valid) {
 #pragma unroll
-    for (int z = 0; z < S; z++) { dst[(size_t)z * Wp] = c.v[z]; dst[moff + (size_t)z * Wp] = mc.v[z]; }
+    for (int z = 0; z < S; z++) { dst[(size_t)z * We] = c.v[z]; mdst[(size_t)z * We] = mc.v[z]; }
   }
-  cur = valid ? cur : 0u;
-  const uint32_t tot = wave_total<0>(cur);
+  const uint32_t cs = valid ? T::sum(cur) : 0u;
+  const uint32_t tot = wave_total<0>(cs);
   if (lane == 0) cntp[(size_t)tile * nslots + o.dst] = tot;
 }
 
-template <int S>
+template <int S, bool PK>
 __global__ __launch_bounds__(256) void k_snk_newview(uint32_t *__restrict__ vec, size_t moff, const NvOp *__restrict__ ops, int n_ops,
                                                      const uint32_t *__restrict__ cost, uint32_t *__restrict__ cntp,
-                                                     uint32_t nslots, int Wp, int tiles)
+                                                     uint32_t nslots, int We, int tiles)
 {
   const int lane = threadIdx.x & 63;
   int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   gw = __builtin_amdgcn_readfirstlane(gw);
   if (gw >= n_ops * tiles) return;
   const int op = gw / tiles, tile = gw - op * tiles;
-  newview_one_snk<S>(vec, moff, ops[op], cost, cntp, nslots, Wp, tile, lane);
+  newview_one_snk<S, PK>(vec, moff, ops[op], cost, cntp, nslots, We, tile, lane);
 }
 
-template <int S>
+template <int S, bool PK>
 __global__ __launch_bounds__(1024) void k_snk_newview_wg(uint32_t *__restrict__ vec, size_t moff, const NvOp *__restrict__ ops,
                                                          const int32_t *__restrict__ lev_off, int n_lev,
                                                          const uint32_t *__restrict__ cost, uint32_t *__restrict__ cntp,
-                                                         uint32_t nslots, int Wp)
+                                                         uint32_t nslots, int We)
 {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -853,18 +885,19 @@ __global__ __launch_bounds__(1024) void k_snk_newview_wg(uint32_t *__restrict__ 
   const int tile = blockIdx.x;
   for (int l = 0; l < n_lev; l++) {
     const int b = lev_off[l], e = lev_off[l + 1];
-    for (int i = b + wave; i < e; i += nw) newview_one_snk<S>(vec, moff, ops[i], cost, cntp, nslots, Wp, tile, lane);
+    for (int i = b + wave; i < e; i += nw) newview_one_snk<S, PK>(vec, moff, ops[i], cost, cntp, nslots, We, tile, lane);
     __syncthreads();
   }
 }
 
 // weighted length across branch (a, b): sum_ptn w * min_x(A[x] + m(B)[x])
-template <int S>
+template <int S, bool PK>
 __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict__ vec, size_t moff, const EvOp *__restrict__ ops,
                                                       int n_ops, const uint32_t *__restrict__ cost,
                                                       const uint32_t *__restrict__ pwgt, uint32_t *__restrict__ out,
-                                                      int Wp, int tiles)
+                                                      int We, int tiles)
 {
+  typedef SnkT<PK> T;
   const int lane = threadIdx.x & 63;
   int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   gw = __builtin_amdgcn_readfirstlane(gw);
@@ -872,14 +905,14 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
   const int op = gw / tiles, tile = gw - op * tiles;
   const EvOp o = ops[op];
   bool valid;
-  const int w0 = lane_word<1>(tile, lane, Wp, valid);
-  Costs<S> a, mb;
-  load_costs<S>(a, vec, o.a, Wp, w0);
-  load_costs<S>(mb, vec + moff, o.b, Wp, w0);
-  uint32_t best = 0xFFFFFFFFu;
+  const int e0 = lane_word<1>(tile, lane, We, valid);
+  Costs<S, PK> a, mb;
+  load_costs<S, PK>(a, vec, o.a, We, e0);
+  load_costs<S, PK>(mb, vec + moff, o.b, We, e0);
+  typename T::E best = T::inf();
 #pragma unroll
-  for (int x = 0; x < S; x++) best = min(best, a.v[x] + mb.v[x]);
-  const uint32_t c = valid ? best * pwgt[w0] : 0u;
+  for (int x = 0; x < S; x++) best = T::mn(best, T::add(a.v[x], mb.v[x]));
+  const uint32_t c = valid ? T::wsum(best, pwgt, e0) : 0u;
   const uint32_t tot = wave_total<0>(c);
   if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
 }
@@ -888,12 +921,13 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
 //   CHAIN : U[d] = m(U[d-1]) + m(vec[sib]);  test: out += sum_ptn w * min_s(m(U[d])[s] + m(vec[own])[s] + m(S)[s])
 //   JOIN  : out += sum_ptn w * min_s(m(vec[own])[s] + m(vec[sib])[s] + m(S)[s])
 // and out is the FULL length of the rearranged tree (there is no additive base in the weighted case).
-template <int S, int MAXD>
+template <int S, int MAXD, bool PK>
 __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
                                                   int n_scans, const ScanOp *__restrict__ ops,
                                                   const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
-                                                  uint32_t *__restrict__ out, int Wp, int tiles)
+                                                  uint32_t *__restrict__ out, int We, int tiles)
 {
+  typedef SnkT<PK> T;
   const int lane = threadIdx.x & 63;
   int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   gw = __builtin_amdgcn_readfirstlane(gw);
@@ -901,13 +935,12 @@ __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ v
   const int scan = gw / tiles, tile = gw - scan * tiles;
   const ScanHdr h = hdr[scan];
   bool valid;
-  const int w0 = lane_word<1>(tile, lane, Wp, valid);
-  const uint32_t w = valid ? pwgt[w0] : 0u;
+  const int e0 = lane_word<1>(tile, lane, We, valid);
   const uint32_t *mvec = vec + moff;
 
   // MU[d] = m(U[d]): what the children of depth d and the test at depth d both need; U itself is never kept
-  Costs<S> ms, MU[MAXD + 1], t1, t2;
-  load_costs<S>(ms, mvec, h.s_slot, Wp, w0);
+  Costs<S, PK> ms, MU[MAXD + 1], t1, t2;
+  load_costs<S, PK>(ms, mvec, h.s_slot, We, e0);
 
   for (uint32_t i = h.op_begin; i < h.op_end; i++) {
     const ScanOp o = ops[i];
@@ -915,24 +948,24 @@ __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ v
     const bool test = (o.meta >> 8) & 1u;
     const int kind = (int)((o.meta >> 16) & 0xFFu);
     if (kind == SCAN_ROOT) {
-      load_costs<S>(MU[0], mvec, o.own, Wp, w0);
+      load_costs<S, PK>(MU[0], mvec, o.own, We, e0);
       continue;
     }
-    uint32_t best = 0xFFFFFFFFu;
-    load_costs<S>(t1, mvec, o.sib, Wp, w0);       // m(vec[sib])
+    typename T::E best = T::inf();
+    load_costs<S, PK>(t1, mvec, o.sib, We, e0);       // m(vec[sib])
     if (kind == SCAN_JOIN) {
-      load_costs<S>(t2, mvec, o.own, Wp, w0);
+      load_costs<S, PK>(t2, mvec, o.own, We, e0);
 #pragma unroll
-      for (int s = 0; s < S; s++) best = min(best, t1.v[s] + t2.v[s] + ms.v[s]);
+      for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], t2.v[s]), ms.v[s]));
     } else {
 #define MPF_SLEVEL(c)                                                                  \
   case c:                                                                              \
     if constexpr (c <= MAXD) {                                                         \
-      _Pragma("unroll") for (int s = 0; s < S; s++) t2.v[s] = t1.v[s] + MU[c - 1].v[s]; /* U[c] */ \
-      mplus<S>(MU[c], t2, cost);                                                       \
+      _Pragma("unroll") for (int s = 0; s < S; s++) t2.v[s] = T::add(t1.v[s], MU[c - 1].v[s]); /* U[c] */ \
+      mplus<S, PK>(MU[c], t2, cost);                                                   \
       if (test) {                                                                      \
-        load_costs<S>(t1, mvec, o.own, Wp, w0);                                        \
-        _Pragma("unroll") for (int s = 0; s < S; s++) best = min(best, t1.v[s] + MU[c].v[s] + ms.v[s]); \
+        load_costs<S, PK>(t1, mvec, o.own, We, e0);                                    \
+        _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
       }                                                                                \
     }                                                                                  \
     break;
@@ -944,55 +977,68 @@ __global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ v
 #undef MPF_SLEVEL
     }
     if (test || kind == SCAN_JOIN) {
-      const uint32_t c = valid ? best * w : 0u;
+      const uint32_t c = valid ? T::wsum(best, pwgt, e0) : 0u;
       const uint32_t tot = wave_total<0>(c);
       if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
     }
   }
 }
 
-template <int S>
+template <int S, bool PK>
 __global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict__ vec, size_t moff, uint32_t a_slot, uint32_t b_slot,
-                                                     const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int Wp)
+                                                     const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int We)
 {
+  typedef SnkT<PK> T;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Wp) return;
-  Costs<S> a, mb;
-  load_costs<S>(a, vec, a_slot, Wp, j);
-  load_costs<S>(mb, vec + moff, b_slot, Wp, j);
-  uint32_t best = 0xFFFFFFFFu;
+  if (j >= We) return;
+  Costs<S, PK> a, mb;
+  load_costs<S, PK>(a, vec, a_slot, We, j);
+  load_costs<S, PK>(mb, vec + moff, b_slot, We, j);
+  typename T::E best = T::inf();
 #pragma unroll
-  for (int x = 0; x < S; x++) best = min(best, a.v[x] + mb.v[x]);
-  ptn[j] = (uint16_t)best;
+  for (int x = 0; x < S; x++) best = T::mn(best, T::add(a.v[x], mb.v[x]));
+  if constexpr (PK) { ptn[2 * j] = best.x; ptn[2 * j + 1] = best.y; }
+  else ptn[j] = (uint16_t)best;
 }
 
 // compressSankoffDNA (reference sprparsimony.cpp:2636-2825): cost 0 for states in the tip's set, highest_cost otherwise
-template <int S>
+template <int S, bool PK>
 __global__ __launch_bounds__(256) void k_snk_pack(uint32_t *__restrict__ vec, size_t moff, const uint8_t *__restrict__ codes, int n_taxa,
                                                   int n_patterns, const int32_t *__restrict__ inf_index, int n_inf,
-                                                  int datatype, uint32_t highest, const uint32_t *__restrict__ cost, int Wp)
+                                                  int datatype, uint32_t highest, const uint32_t *__restrict__ cost, int We)
 {
+  typedef SnkT<PK> T;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int tip = blockIdx.y;
-  if (j >= Wp || tip >= n_taxa) return;
-  uint32_t *dst = vec + (size_t)tip * (size_t)(S * Wp) + j;
-  Costs<S> v, mv;
-  if (j >= n_inf) {
+  if (j >= We || tip >= n_taxa) return;
+  Costs<S, PK> v, mv;
+  auto tip_cost = [&](int pattern, int k) -> uint32_t {
+    if (pattern >= n_inf) return 0u;                               // padded patterns, :2766-2775
+    const uint32_t m = state_mask(datatype, codes[(size_t)tip * n_patterns + inf_index[pattern]]);
+    return ((m >> k) & 1u) ? 0u : highest;
+  };
 #pragma unroll
-    for (int k = 0; k < S; k++) v.v[k] = 0u;                     // padded patterns, :2766-2775
-  } else {
-    const uint32_t m = state_mask(datatype, codes[(size_t)tip * n_patterns + inf_index[j]]);
-#pragma unroll
-    for (int k = 0; k < S; k++) v.v[k] = ((m >> k) & 1u) ? 0u : highest;
+  for (int k = 0; k < S; k++) {
+    if constexpr (PK) v.v[k] = (us2){(unsigned short)tip_cost(2 * j, k), (unsigned short)tip_cost(2 * j + 1, k)};
+    else v.v[k] = tip_cost(j, k);
   }
-  mplus<S>(mv, v, cost);
+  mplus<S, PK>(mv, v, cost);
+  typename T::E *dst = reinterpret_cast<typename T::E *>(vec) + (size_t)tip * (size_t)(S * We) + j;
+  typename T::E *mdst = reinterpret_cast<typename T::E *>(vec + moff) + (size_t)tip * (size_t)(S * We) + j;
 #pragma unroll
-  for (int k = 0; k < S; k++) { dst[(size_t)k * Wp] = v.v[k]; dst[moff + (size_t)k * Wp] = mv.v[k]; }
+  for (int k = 0; k < S; k++) { dst[(size_t)k * We] = v.v[k]; mdst[(size_t)k * We] = mv.v[k]; }
 }
 
 // ---------------------------------------------------------------- launch wrappers
 
 static inline int tiles_of(const Geometry &g) { return (g.Wp + 64 * g.vw - 1) / (64 * g.vw); }
+// weighted mode: elements per state row (patterns, or pattern pairs in the 16-bit packing)
+static inline int snk_elems(const Geometry &g) { return g.snk16 ? g.Wp / 2 : g.Wp; }
+#define MPF_DISPATCH_SNK(FN)                                                          \
+  do {                                                                                \
+    if (g.S == 4) { if (g.snk16) FN(4, true); else FN(4, false); }                    \
+    else { if (g.snk16) FN(20, true); else FN(20, false); }                           \
+  } while (0)
 
 hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
                             int n_patterns, const int32_t *site2ptn, int n_sites, int datatype,
@@ -1028,8 +1074,11 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (g.sankoff) {
-    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview<4>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
-    else hipLaunchKernelGGL(k_snk_newview<20>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, cntp, nslots, g.Wp, tiles);
+    const int We = snk_elems(g), stiles = (We + 63) / 64;
+    dim3 sgrid((unsigned)(((long)n_ops * stiles + 3) / 4));
+#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_newview<S_, PK_>), sgrid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, cntp, nslots, We, stiles)
+    MPF_DISPATCH_SNK(SNK);
+#undef SNK
     return hipGetLastError();
   }
 #define NV(S_, VW_, RED_) hipLaunchKernelGGL((k_newview<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, cntp, nslots, g.Wp, tiles)
@@ -1046,8 +1095,11 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
   if (g.sankoff) {
-    if (g.S == 4) hipLaunchKernelGGL(k_snk_newview_wg<4>, grid, block, 0, st, vec, g.moff, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
-    else hipLaunchKernelGGL(k_snk_newview_wg<20>, grid, block, 0, st, vec, g.moff, ops, lev_off, n_lev, g.cost, cntp, nslots, g.Wp);
+    const int We = snk_elems(g);
+    dim3 sgrid((unsigned)((We + 63) / 64));
+#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_newview_wg<S_, PK_>), sgrid, block, 0, st, vec, g.moff, ops, lev_off, n_lev, g.cost, cntp, nslots, We)
+    MPF_DISPATCH_SNK(SNK);
+#undef SNK
     return hipGetLastError();
   }
 #define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp)
@@ -1062,11 +1114,11 @@ hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int
                          uint32_t nslots, uint32_t *cnt)
 {
   if (n_ops <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 255) / 256), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles_of(g), cnt);
+  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 255) / 256), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles_for(g), cnt);
   return hipGetLastError();
 }
 
-int tiles_for(const Geometry &g) { return tiles_of(g); }
+int tiles_for(const Geometry &g) { return g.sankoff ? (snk_elems(g) + 63) / 64 : tiles_of(g); }
 
 hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
                            uint32_t *out)
@@ -1076,8 +1128,11 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
   const long waves = (long)n_ops * tiles;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (g.sankoff) {
-    if (g.S == 4) hipLaunchKernelGGL(k_snk_evaluate<4>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
-    else hipLaunchKernelGGL(k_snk_evaluate<20>, grid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, g.pwgt, out, g.Wp, tiles);
+    const int We = snk_elems(g), stiles = (We + 63) / 64;
+    dim3 sgrid((unsigned)(((long)n_ops * stiles + 3) / 4));
+#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_evaluate<S_, PK_>), sgrid, block, 0, st, vec, g.moff, ops, n_ops, g.cost, g.pwgt, out, We, stiles)
+    MPF_DISPATCH_SNK(SNK);
+#undef SNK
     return hipGetLastError();
   }
 #define EV(S_, VW_, RED_) hipLaunchKernelGGL((k_evaluate<S_, VW_, RED_>), grid, block, 0, st, vec, ops, n_ops, out, g.Wp, tiles)
@@ -1096,15 +1151,18 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
   dim3 block(256);
   unsigned nblocks;
   if (g.sankoff) {
-    const long waves = (long)n_scans * tiles;
+    const int We = snk_elems(g), stiles = (We + 63) / 64;
+    const long waves = (long)n_scans * stiles;
     dim3 sgrid((unsigned)((waves + 3) / 4));
+#define SNKSCAN(S_, D_) do { if (g.snk16) hipLaunchKernelGGL((k_snk_scan<S_, D_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles); \
+                             else hipLaunchKernelGGL((k_snk_scan<S_, D_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles); } while (0)
     if (g.S == 4) {
-      if (max_depth <= 6) hipLaunchKernelGGL((k_snk_scan<4, 6>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
-      else hipLaunchKernelGGL((k_snk_scan<4, 12>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+      if (max_depth <= 6) SNKSCAN(4, 6); else SNKSCAN(4, 12);
     } else {
       if (max_depth > 6) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((k_snk_scan<20, 6>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, g.Wp, tiles);
+      SNKSCAN(20, 6);
     }
+#undef SNKSCAN
     return hipGetLastError();
   }
   if (g.map == 0) {
@@ -1192,22 +1250,22 @@ size_t site_planes_words(const Geometry &g, int n_ops)
 hipError_t launch_sankoff_pattern(hipStream_t st, const Geometry &g, const uint32_t *vec, uint32_t a, uint32_t b,
                                   uint16_t *ptn_out)
 {
-  dim3 grid((g.Wp + 255) / 256), block(256);
-  if (g.S == 4) hipLaunchKernelGGL(k_snk_pattern<4>, grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, g.Wp);
-  else hipLaunchKernelGGL(k_snk_pattern<20>, grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, g.Wp);
+  const int We = snk_elems(g);
+  dim3 grid((We + 255) / 256), block(256);
+#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_pattern<S_, PK_>), grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, We)
+  MPF_DISPATCH_SNK(SNK);
+#undef SNK
   return hipGetLastError();
 }
 
 hipError_t launch_pack_tips_sankoff(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
                                     int n_patterns, const int32_t *inf_index, int n_inf, int datatype)
 {
-  dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);
-  if (g.S == 4)
-    hipLaunchKernelGGL(k_snk_pack<4>, grid, block, 0, st, vec, g.moff, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
-                       g.highest_cost, g.cost, g.Wp);
-  else
-    hipLaunchKernelGGL(k_snk_pack<20>, grid, block, 0, st, vec, g.moff, codes, n_taxa, n_patterns, inf_index, n_inf, datatype,
-                       g.highest_cost, g.cost, g.Wp);
+  const int We = snk_elems(g);
+  dim3 grid((We + 255) / 256, n_taxa), block(256);
+#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_pack<S_, PK_>), grid, block, 0, st, vec, g.moff, codes, n_taxa, n_patterns, inf_index, n_inf, datatype, g.highest_cost, g.cost, We)
+  MPF_DISPATCH_SNK(SNK);
+#undef SNK
   return hipGetLastError();
 }
 

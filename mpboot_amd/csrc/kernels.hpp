@@ -47,6 +47,7 @@ struct Geometry {
   const uint32_t *cost = nullptr;   // device, [S][S]
   const uint32_t *pwgt = nullptr;   // device, [Wp] pattern weights (0 on padding)
   uint32_t highest_cost = 0;
+  int snk16 = 0;                    // weighted mode: two 16-bit costs per lane (v_pk_add_u16 / v_pk_min_u16)
   size_t moff = 0;                  // words from a vector to its min-plus transform m(v) (second half of the vector array)
 };
 

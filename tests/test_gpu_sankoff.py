@@ -115,3 +115,37 @@ def test_asymmetric_matrix_is_refused(mods):
     with pytest.raises(engine.MpfError) as ei:
         engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=c)
     assert ei.value.code == -6
+
+
+@pytest.mark.parametrize("name", ["dna_ambig", "aa"])
+def test_packed_16_bit_and_32_bit_costs_agree(mods, name):
+    """the two arithmetic widths (reference: default short / -short_off) give the same numbers while nothing overflows;
+    large cost entries fall back to 32 bits by themselves"""
+    engine, po = mods
+    fx = load_fixture(name)
+    cost = cost_for(fx, "general")
+    start = np.array(fx["spr"]["start_back"], dtype=np.int32)
+    res = []
+    for short in (1, 0):
+        e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+        e.set_option("sankoff_short", short)
+        e.set_tree(start)
+        e.seed_ties(engine.TIE_RANDOM, 3)
+        s = e.optimize_spr(1, 6)
+        ptn, tot = e.pattern_scores()
+        q, mp, n_p = e.spr_scan(int(fx["scan"][0]["order"][0]), 1, 6)
+        res.append((s, [x.tolist() for x in e.moves()], e.get_tree().tolist(), ptn.tolist(), tot, q.tolist(), mp.tolist(), n_p))
+    assert res[0] == res[1]
+    big = cost.astype(np.uint64) * 1500                       # 3 n (max + 1) >= 2^16: must not be packed
+    big = big.astype(np.uint32)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=big)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=big)
+    for t in fx["trees"][:3]:
+        b = np.array(t["back"], dtype=np.int32)
+        assert e.score_tree(b) == o.score_tree(b)
+    e.set_tree(start)
+    o.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, 3)
+    o.seed_ties(po.TIE_RANDOM, 3)
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    assert (e.get_tree() == o.get_tree()).all()
