@@ -241,7 +241,18 @@ void mpf_reps_destroy(mpf_reps *r);
 
 int mpf_get_stats(const mpf_engine *e, mpf_stats *out);
 int mpf_reset_stats(mpf_engine *e);
-/* tuning knobs: "scan_batch" (prune nodes speculated per launch), "words_per_lane" (1|2|4) */
+/* tuning knobs (none of them changes a result):
+     "scan_batch"      prune nodes speculated per launch at the start of a climb (then adaptive)
+     "words_per_lane"  1|2|4 32-site words per lane in the Fitch kernels
+     "reduce"          0 = DPP wave reduction, 1 = ds_bpermute
+     "xcd_map"         1 = XCD-aware workgroup -> tile map of the scan kernel
+     "scan_mode"       1 = device-walked SPR scan (radius <= 8), 0 = host-planned scan programs
+     "views_mode"      1 = all dependency levels of a refresh in one launch
+     "split_below"     batches of at most this many prune nodes are cut into four scan parts each
+     "sankoff_short"   1 = two 16-bit costs per lane in the weighted kernels when no intermediate can overflow
+                       (the reference's default arithmetic), 0 = always 32-bit (its -short_off)
+     "check_counts"    1 = compare the kernel's candidate counts with the host's
+     "timing"          1 = HIP events around the kernels (mpf_stats *_kernel_ms_total) */
 int mpf_set_option(mpf_engine *e, const char *key, int64_t value);
 
 #ifdef __cplusplus
