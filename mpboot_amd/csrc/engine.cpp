@@ -221,11 +221,8 @@ int Engine::pack()
     if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
     g_.Wp = wp;
     vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
-    if (vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) {
-      // the scan kernel addresses the vector store through one raw buffer with 32-bit offsets
-      set_error("taxa x sites too large: the directional-vector store would exceed 2 GiB");
-      return MPF_E_UNSUPPORTED;
-    }
+    // below 2 GiB the scan kernel addresses the whole store through one raw buffer (32-bit offsets); above, 64-bit bases
+    g_.big = (force_big_ || vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) ? 1 : 0;
     HIPCHK(hipMalloc((void **)&d_vec_, vec_words_ * sizeof(uint32_t)));
   }
   std::vector<int32_t> s2p((size_t)std::max(nsites_, 1));
@@ -1080,6 +1077,11 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
   if (key == "timing") { timing_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "force_big") {                     // test hook: use the >= 2 GiB addressing path on any size
+    force_big_ = v ? 1 : 0;
+    if (!sankoff_) g_.big = (force_big_ || vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) ? 1 : 0;
+    return MPF_OK;
+  }
   if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack
     snk16_opt_ = v ? 1 : 0;
     if (sankoff_) return pack();

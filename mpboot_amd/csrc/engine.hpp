@@ -247,6 +247,7 @@ class Engine {
   // Sankoff mode
   bool sankoff_ = false;
   std::vector<uint32_t> cost_, cost_dev_;
+  int force_big_ = 0;
   int snk16_opt_ = 1;                            // allow the packed 16-bit cost arithmetic when the values fit
   std::vector<int32_t> inf_index_;               // informative pattern j -> original pattern index
   DevBuf<uint32_t> d_cost_, d_pwgt_;

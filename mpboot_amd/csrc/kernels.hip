@@ -553,13 +553,33 @@ __device__ __forceinline__ void load_tile_b(Tile<S, VW> &t, __amdgpu_buffer_rsrc
   }
 }
 
+// the same through a 64-bit base: for vector stores of 2 GiB and more (a raw buffer addresses 32 bits)
+template <int S, int VW>
+__device__ __forceinline__ void load_tile_g(Tile<S, VW> &t, const uint32_t *__restrict__ base, const uint32_t (&voff)[S])
+{
+  const char *b = reinterpret_cast<const char *>(base);
+#pragma unroll
+  for (int k = 0; k < S; k++) {
+    if constexpr (VW == 1) {
+      t.v[k][0] = *reinterpret_cast<const uint32_t *>(b + voff[k]);
+    } else if constexpr (VW == 2) {
+      const uint2 x = *reinterpret_cast<const uint2 *>(b + voff[k]);
+      t.v[k][0] = x.x; t.v[k][1] = x.y;
+    } else {
+      const uint4 x = *reinterpret_cast<const uint4 *>(b + voff[k]);
+      t.v[k][0] = x.x; t.v[k][1] = x.y; t.v[k][2] = x.z; t.v[k][3] = x.w;
+    }
+  }
+}
+
 // S = states held per lane.  SPLIT (protein): lanes l and l^32 share a word and hold states 0..9 / 10..19, a
 // wave covers 32 words; this keeps the protein kernel at DNA-like register counts instead of one wave per SIMD.
 // MASKS (online UFBoot, ufboot.hip): every candidate's "no common state" words go to masks[out_base + m][Wp], m
 // counting candidates in the order they are COMPUTED; info[out_base + k] = (out_base + m, scan) names the row of the
 // k-th EMITTED candidate.  The part's last slot (index out_base + count) receives the join of the pruned subtree
 // onto its home edge, fitch(vec[xa], vec[xb]).
-template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false>
+// BIG: the vector store does not fit a raw buffer's 32-bit range: plain global loads from a 64-bit base per vector.
+template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false, bool BIG = false>
 __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                    uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
@@ -623,8 +643,8 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
   for (int k = 0; k < S; k++) voff[k] = (w0 + (row0 + (uint32_t)k) * (uint32_t)Wp) * 4u;
 #define MPF_LOAD(T, cid)                                                                       \
   do {                                                                                         \
-    if constexpr (S <= 10) load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);       \
-    else load_tile_u<S, VW>(T, vec + (size_t)((uint32_t)(cid) * SW), w0, Wp);                  \
+    if constexpr (BIG) load_tile_g<S, VW>(T, vec + (size_t)(cid) * (size_t)SW, voff);            \
+    else load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);                          \
   } while (0)
 
   // sv: pruned subtree; par: U of the node being expanded; pend[d]: U of the not-yet-expanded second
@@ -1194,34 +1214,40 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;   // 8: the per-depth LDS slots of the walk are sized for it
   const bool split = g.S == 20;                                    // protein: states split over the wave halves
-  const int tiles = split ? (g.Wp + 31) / 32 : tiles_of(g);
+  const int tiles = split ? (g.Wp + 31) / 32 : (g.big ? (g.Wp + 63) / 64 : tiles_of(g));    // the 64-bit path is one word per lane
   const long waves = (long)n_scans * tiles;
   dim3 block(256);
   unsigned nblocks;
   if (g.map == 0) nblocks = (unsigned)((waves + 3) / 4);
   else { const long chunk = (waves + 7) / 8; nblocks = (unsigned)(((chunk + 3) / 4) * 8); }
   dim3 grid(nblocks);
-#define SW(S_, VW_, MAXD_, RED_, SPLIT_)                                                                                              \
+#define SWB(S_, VW_, MAXD_, RED_, SPLIT_, BIG_)                                                                                       \
   do {                                                                                                                                \
     if (masks)                                                                                                                        \
-      hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, true>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc,    \
-                         n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                       \
+      hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, true, BIG_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa,    \
+                         desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                 \
     else                                                                                                                              \
-      hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, false>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa, desc,   \
-                         n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                       \
+      hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, false, BIG_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa,   \
+                         desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                 \
   } while (0)
+#define SW(S_, VW_, MAXD_, RED_, SPLIT_) SWB(S_, VW_, MAXD_, RED_, SPLIT_, false)
 #define SW2(S_, VW_, SPLIT_)                                                                                 \
   do {                                                                                                       \
     if (max_depth <= 6) { if (g.reduce == 0) SW(S_, VW_, 6, 0, SPLIT_); else SW(S_, VW_, 6, 1, SPLIT_); }    \
     else { if (g.reduce == 0) SW(S_, VW_, 8, 0, SPLIT_); else SW(S_, VW_, 8, 1, SPLIT_); }                   \
   } while (0)
-  if (g.S == 4) {
+  if (g.big) {
+    // >= 2 GiB of vectors: one code path (one word per lane, DPP reduction), 64-bit addressing
+    if (g.S == 4) { if (max_depth <= 6) SWB(4, 1, 6, 0, false, true); else SWB(4, 1, 8, 0, false, true); }
+    else { if (max_depth <= 6) SWB(10, 1, 6, 0, true, true); else SWB(10, 1, 8, 0, true, true); }
+  } else if (g.S == 4) {
     if (g.vw == 1) SW2(4, 1, false); else SW2(4, 2, false);
   } else {
     SW2(10, 1, true);
   }
 #undef SW2
 #undef SW
+#undef SWB
   return hipGetLastError();
 }
 

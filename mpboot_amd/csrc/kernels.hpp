@@ -42,6 +42,7 @@ struct Geometry {
   int vw;       // words per lane (1 | 2 | 4)
   int reduce;   // 0 = DPP wave reduction, 1 = ds_bpermute (__shfl) reduction
   int map;      // 0 = scan-major wave mapping, 1 = tiles pinned to XCD classes
+  int big = 0;  // the vector store is 2 GiB or more: the scan kernel uses 64-bit addressing instead of one raw buffer
   // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
   int sankoff = 0;
   const uint32_t *cost = nullptr;   // device, [S][S]

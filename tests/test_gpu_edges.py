@@ -146,3 +146,31 @@ def test_engine_reuse_across_trees_and_rebuilds(mods):
         assert (e.get_tree() == o.get_tree()).all()
         assert e.make_parsimony_tree(k, 2) == o.make_tree(k, 2)[0]
         assert (e.get_tree() == o.get_tree()).all()
+
+
+@pytest.mark.parametrize("name", ["dna_ambig", "aa"])
+def test_64_bit_addressing_path_of_the_scan_kernel(name):
+    """vector stores of 2 GiB and more cannot go through one raw buffer; `force_big` runs that code path on a small input"""
+    from helpers import load_fixture
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+
+    fx = load_fixture(name)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    e.set_option("force_big", 1)
+    e.set_option("words_per_lane", 2 if name == "dna_ambig" else 1)      # ignored by the scan on this path
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    start = np.array(fx["spr"]["start_back"], dtype=np.int32)
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.set_tree(start)
+        x.seed_ties(mode, 4)
+    o.trace(True)
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    samples = np.random.default_rng(3).multinomial(len(fx["weights"]), np.ones(len(fx["weights"])) / len(fx["weights"]), size=9).astype(np.uint16)
+    for x in (e, o):
+        x.set_tree(start)
+        x.ufboot_attach(samples)
+    assert e.optimize_spr(1, 8) == o.optimize_spr(1, 8)                  # masks + deep walk on the same path
+    assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()]
