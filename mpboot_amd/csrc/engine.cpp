@@ -113,6 +113,8 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   HIPCHK(hipMemcpy(d_codes_, codes_.data(), (size_t)n_ * P_, hipMemcpyHostToDevice));
   nslots_ = (size_t)n_ + 3 * (size_t)(n_ - 1);
   HIPCHK(reserve_results(4096));
+  HIPCHK(d_done_.reserve(64));
+  HIPCHK(hipMemset(d_done_.p, 0, 64 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void **)&d_tipslots_, (size_t)n_ * sizeof(uint32_t)));
   {
     std::vector<uint32_t> ts(n_);
@@ -490,7 +492,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
   if (timing_) HIPCHK(hipEventRecord(ev2_, st_));
   if (views_mode_ == 1) {
-    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_));
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), d_done_.p));
     stats.view_launches++;
   } else {
     for (int l = 0; l < maxlev; l++) {
@@ -498,7 +500,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
       stats.view_launches++;
     }
   }
-  HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt()));
+  if (views_mode_ != 1 || sankoff_)             // the all-levels Fitch kernel folds the per-tile counts itself
+    HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt()));
   if (timing_) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;
@@ -588,7 +591,7 @@ int Engine::tree_length(uint32_t *len)
   HIPCHK(d_evops_.reserve(1));
   HIPCHK(reserve_results(1));
   HIPCHK(hipMemcpyAsync(d_evops_.p, &op, sizeof(op), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(d_out(), 0, sizeof(uint32_t), st_));
+  HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(1) * sizeof(uint32_t), st_));
   HIPCHK(launch_evaluate(st_, g_, d_vec_, d_evops_.p, 1, d_out()));
   HIPCHK(hipMemcpyAsync(h_out(), d_out(), sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   HIPCHK(hipStreamSynchronize(st_));
@@ -688,12 +691,12 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   HIPCHK(reserve_results(nout));
   HIPCHK(hipMemcpyAsync(d_scanops_.p, prog_ops_.data(), nops * sizeof(ScanOp), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(d_scanhdr_.p, prog_hdr_.data(), nh * sizeof(ScanHdr), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(d_out(), 0, nout * sizeof(uint32_t), st_));
+  HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
   HIPCHK(launch_scan(st_, g_, d_vec_, d_scanhdr_.p, (int)nh, d_scanops_.p, d_out(), prog_max_depth_));
   if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
   if (cnt_copy_pending_) {     // a refresh was enqueued just before: bring its mutation counts back in the same copy
-    HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (nslots_ + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (out_off() + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
     cnt_copy_pending_ = false;
   } else {
     HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
@@ -842,7 +845,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(h_ncand_.reserve(nd));
     HIPCHK(reserve_results(nout));
     HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_));
-    HIPCHK(hipMemsetAsync(d_out(), 0, (nout ? nout : 1) * sizeof(uint32_t), st_));
+    HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
     if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
     uint32_t *mask_ptr = nullptr;
     uint2 *info_ptr = nullptr;
@@ -857,7 +860,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
     if (cnt_copy_pending_) {
-      HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (nslots_ + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+      HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (out_off() + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
       cnt_copy_pending_ = false;
     } else if (nout) {
       HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));

@@ -266,13 +266,17 @@ class Engine {
   PinBuf<uint8_t> h_vstage_;
   bool cnt_copy_pending_ = false;
   int timing_ = 0;                               // 1 = bracket kernels with HIP events (bench / profiling)
+  // the candidate costs start on a 256-byte boundary and are cleared in whole 256-byte units: a memset of an
+  // unaligned range is split by the runtime into up to three fill kernels (5 us each, per accepted move)
+  size_t out_off() const { return (nslots_ + 63) & ~(size_t)63; }
+  static size_t clear_words(size_t nout) { return ((nout ? nout : 1) + 63) & ~(size_t)63; }
   uint32_t *d_cnt() { return d_res_.p; }
-  uint32_t *d_out() { return d_res_.p + nslots_; }
+  uint32_t *d_out() { return d_res_.p + out_off(); }
   uint32_t *h_cnt() { return h_res_.p; }
-  uint32_t *h_out() { return h_res_.p + nslots_; }
+  uint32_t *h_out() { return h_res_.p + out_off(); }
   hipError_t reserve_results(size_t nout)
   {
-    const size_t need = nslots_ + nout;
+    const size_t need = out_off() + clear_words(nout);
     if (need > d_res_.cap) {
       // grow without losing the mutation counts a pending refresh has already written to the head of the buffer
       DevBuf<uint32_t> bigger;
@@ -302,6 +306,7 @@ class Engine {
   DevBuf<ScanHdr> d_scanhdr_;
   DevBuf<uint32_t> d_ncand_;
   DevBuf<uint32_t> d_cntp_;
+  DevBuf<uint32_t> d_done_;                      // finished-workgroup counter of k_newview_wg (zero between launches)
   const uint2 *d_kids() const { return reinterpret_cast<const uint2 *>(d_vstage_.p); }
   std::vector<uint8_t> valid_;
   std::vector<int32_t> lev_, lev_epoch_;

@@ -279,11 +279,15 @@ __global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, con
 // ops, and a workgroup barrier separates levels -- sites are independent, so no other workgroup's data
 // is ever needed.  Replaces one launch per level (launch-latency-bound for the short levels of an
 // incremental refresh).
+// The per-tile mutation counts are folded by whichever workgroup finishes last (`done` counts finished workgroups and is
+// left at zero again): no separate summation kernel behind every refresh.
 template <int S, int VW, int RED>
 __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
                                                      const int32_t *__restrict__ lev_off, int n_lev,
-                                                     uint32_t *__restrict__ cntp, uint32_t nslots, int Wp)
+                                                     uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
+                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ done)
 {
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = (int)(blockDim.x >> 6);
@@ -313,6 +317,26 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
     }
     if (i < e) newview_one<S, VW, RED>(vec, ops[i], cntp, nslots, Wp, tile, lane);
     __syncthreads();
+  }
+  // ---- fold the per-tile counts: every workgroup publishes its stores (agent-scope release), takes a ticket; the
+  //      last one acquires and sums
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int n_ops = lev_off[n_lev];
+    const int tiles = (int)gridDim.x;
+    for (int i = (int)threadIdx.x; i < n_ops; i += (int)blockDim.x) {
+      const uint32_t dst = ops[i].dst;
+      uint32_t sum = 0;
+      for (int t = 0; t < tiles; t++) sum += __builtin_nontemporal_load(cntp + (size_t)t * nslots + dst);
+      cnt[dst] = sum;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1110,7 +1134,7 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
 }
 
 hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
-                                 int n_lev, uint32_t *cntp, uint32_t nslots)
+                                 int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done)
 {
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
@@ -1122,7 +1146,7 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 #undef SNK
     return hipGetLastError();
   }
-#define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp)
+#define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done)
 #define NW2(S_, VW_, dummy) do { if (g.reduce == 0) NW(S_, VW_, 0); else NW(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NW2, 0);
 #undef NW2

@@ -59,8 +59,10 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
 hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cntp,
                           uint32_t nslots);
 // every level in ONE launch (one 16-wave workgroup per tile, workgroup barrier between levels)
+// Fitch mode also folds the per-tile counts into cnt[dst] (last workgroup; `done` = a zeroed device word, left zeroed);
+// weighted mode leaves that to launch_cntsum
 hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
-                                 int n_lev, uint32_t *cntp, uint32_t nslots);
+                                 int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done);
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
                          uint32_t nslots, uint32_t *cnt);
 int tiles_for(const Geometry &g);
