@@ -95,18 +95,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
   // output row i multiplies mask row rowsel[i] (cut-off filter: only the candidates that are saved), or row i itself
   const uint32_t arow_id = rowsel ? rowsel[rb * TM + (tid % TM)] : (uint32_t)(rb * TM + (tid % TM));
   const uint32_t *arow = masks + (size_t)arow_id * Wp;
-  uint4 breg[KS][LD], areg[AL];
+  uint4 areg[AL];
 #pragma unroll
   for (int i = 0; i < AL; i++) areg[i] = make_uint4(0, 0, 0, 0);
 
-  // stage copy, written inline (constant indices only, so the stage registers stay registers).
-  // kb_ is a multiple of KS below nkb (nkb % KS == 0): blocks past kb_end are fetched but never multiplied.
-#define MPF_GLOAD(kb_)                                                                            \
+  // Stage copy.  The weights go global -> LDS directly (LDS-DMA, 16 bytes per lane: lane i of a wave lands at the wave's
+  // LDS base + 16 i, which is the tile's own linear layout), no staging registers and no ds_write; the few mask words
+  // take the register path.  kb_ is a multiple of KS below nkb (nkb % KS == 0): blocks past kb_end are fetched but
+  // never multiplied.
+  typedef __attribute__((address_space(3))) void lds_void;
+#define MPF_GLOAD(kb_, buf_)                                                                      \
   do {                                                                                            \
     const int kq_ = min((kb_), nkb - KS);                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
       const uint4 *src_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)(kq_ + s_) * wt_kstride); \
-      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) breg[s_][i_] = src_[tid + NTH * i_];      \
+      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++)                                           \
+        __builtin_amdgcn_global_load_lds(src_ + tid + NTH * i_,                                   \
+            (lds_void *)(s_b + ((size_t)(buf_) * KS + s_) * BT + (size_t)((tid & ~63) + NTH * i_) * 16), 16, 0, 0); \
     }                                                                                             \
     if (tid < TM) {                                                                               \
       _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++)                                           \
@@ -115,10 +120,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
   } while (0)
 #define MPF_LSTORE(buf_)                                                                          \
   do {                                                                                            \
-    _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
-      uint4 *dst_ = reinterpret_cast<uint4 *>(s_b + ((size_t)(buf_) * KS + s_) * BT);             \
-      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++) dst_[tid + NTH * i_] = breg[s_][i_];      \
-    }                                                                                             \
     if (tid < TM) {                                                                               \
       uint32_t *a_ = s_a + (size_t)(buf_) * (TM * kGemmAStride) + tid * kGemmAStride;             \
       _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++) {                                         \
@@ -126,13 +127,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
       }                                                                                           \
     }                                                                                             \
   } while (0)
-  MPF_GLOAD(kb_begin);
+  MPF_GLOAD(kb_begin, 0);
   MPF_LSTORE(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA pieces of this wave have landed
   __syncthreads();
 
   int buf = 0;
   for (int kb = kb_begin; kb < kb_end; kb += KS) {
-    MPF_GLOAD(kb + KS);                              // clamped: the last stage prefetches a valid block it never uses
+    MPF_GLOAD(kb + KS, buf ^ 1);                     // clamped: the last stage prefetches a valid block it never uses
     const uint8_t *sb = s_b + (size_t)buf * KS * BT;
     const uint32_t *sa = s_a + (size_t)buf * (TM * kGemmAStride);
     // every stage holds KS valid k-blocks (kb_per_split and nkb are multiples of KS): straight-line body, the
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
       }
     }
     MPF_LSTORE(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     buf ^= 1;
   }
