@@ -50,17 +50,17 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // is the same 16 sites of row r, expanded from bits to bytes in registers: nibble * 0x00204081 & 0x01010101
 // (both operands use the same (h, j) -> site map, so the sum over k is the intended one whatever order the
 // hardware assigns to the 64 k values).
-// Workgroup = 8 waves (4 x 2), tile 256 rows x 256 samples, wave tile 64 x 128 (4 x 8 MFMA tiles, 128 accumulator
-// registers): each weight byte is fetched once per 256 rows and each expanded A fragment feeds 8 MFMAs.  Two k-blocks
-// per stage, double-buffered in LDS (global -> registers -> LDS while the previous stage is multiplied).
+// Workgroup = 8 waves, tile 256 rows x 256 samples, wave tile 32 x 256 (2 x 16 MFMA tiles, 128 accumulator registers):
+// each weight byte is fetched once per 256 rows and each expanded A fragment feeds 16 MFMAs.  Four k-blocks per stage,
+// double-buffered in LDS (weights by LDS-DMA while the previous stage is multiplied).
 // blockIdx.y splits K; partial products are added with integer atomics (exact, order-independent).
-// WM x WN waves (tile = 64 WM rows x 128 WN samples), KS = k-blocks per LDS stage.
-template <int WM, int WN, int KS>
+// MT x NT MFMA tiles per wave, WM x WN waves (tile = 16 MT WM rows x 16 NT WN samples), KS = k-blocks per LDS stage.
+template <int MT, int NT, int WM, int WN, int KS>
 __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
                                                  int kb_per_split, const uint32_t *__restrict__ rowsel)
 {
-  constexpr int MT = 4, NT = 8, TM = 64 * WM, TN = 128 * WN, NTH = 64 * WM * WN;
+  constexpr int TM = 16 * MT * WM, TN = 16 * NT * WN, NTH = 64 * WM * WN;
   constexpr int kGemmAStride = 2 * KS + 1;           // words per row of the A stage tile (+1: bank spread)
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
   constexpr int LD = BT / (NTH * 16);                // 16-byte loads per thread per k-block
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
       }
 #pragma unroll
       for (int i = 0; i < MT; i++) {
-        const uint32_t word = sa[(wr * 64 + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
+        const uint32_t word = sa[(wr * 16 * MT + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
         const uint32_t bits = (word >> ((h & 1) * 16)) & 0xFFFFu;
         v4i af;
         af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
 #undef MPF_LSTORE
 
   // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
-  const int row0 = rb * TM + wr * 64, col0 = cb * TN + wc * 128;
+  const int row0 = rb * TM + wr * 16 * MT, col0 = cb * TN + wc * 16 * NT;
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
       }
     }
 }
-template <int WM, int WN, int KS>
-constexpr size_t gemm_lds() { return 2 * (size_t)KS * (128 * WN) * 64 + 2 * (size_t)(64 * WM) * (2 * KS + 1) * sizeof(uint32_t); }
+template <int MT, int NT, int WM, int WN, int KS>
+constexpr size_t gemm_lds() { return 2 * (size_t)KS * (16 * NT * WN) * 64 + 2 * (size_t)(16 * MT * WM) * (2 * KS + 1) * sizeof(uint32_t); }
 
 // R_T[b] = sum over rows of C[row][b]   (rt zeroed by the launcher; 64 rows per thread, integer atomics)
 __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
@@ -298,12 +298,12 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
   return hipGetLastError();
 }
 
-template <int WM, int WN, int KS>
+template <int MT, int NT, int WM, int WN, int KS>
 static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
                                    int mult, int accumulate, const uint32_t *rowsel)
 {
-  constexpr int TM = 64 * WM;
-  const int row_blocks = rows_padded / TM, col_blocks = Bp / (128 * WN);
+  constexpr int TM = 16 * MT * WM;
+  const int row_blocks = rows_padded / TM, col_blocks = Bp / (16 * NT * WN);
   const int nkb = Wp / 2;
   // small batches: split K so that the launch still has a few workgroups per CU
   long tiles = (long)row_blocks * col_blocks;
@@ -326,13 +326,13 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  constexpr size_t lds = gemm_lds<WM, WN, KS>();
+  constexpr size_t lds = gemm_lds<MT, NT, WM, WN, KS>();
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<WM, WN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<MT, NT, WM, WN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_bitgemm<WM, WN, KS>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
+  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
 }
 
@@ -342,8 +342,14 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   if (rows_padded <= 0) return hipSuccess;
   // 256-sample column blocks when the (padded) sample count allows, else 128-sample blocks with twice the rows per
   // workgroup (sample-sharded runs: 1000 samples over 8 GPUs = 125 per rank)
-  if (Bp % 256 == 0) return launch_bitgemm_t<4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-  return launch_bitgemm_t<8, 1, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  static int variant = -1;
+  if (variant < 0) { const char *v = std::getenv("MPF_GEMM_VARIANT"); variant = v ? std::atoi(v) : 0; }
+  if (Bp % 256 == 0) {
+    // 8 x 1 waves of 32 rows x 256 samples: an expanded A fragment feeds 16 MFMAs (0.8 vector instructions per MFMA)
+    if (variant != 1) return launch_bitgemm_t<2, 16, 8, 1, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    return launch_bitgemm_t<4, 8, 4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  }
+  return launch_bitgemm_t<4, 8, 8, 1, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
 }
 
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)
