@@ -59,6 +59,19 @@ def make_alignment(kind: str):
         for r_i, r in enumerate(rows):
             r.extend(["A", "C" if r_i == 3 else "G", "N" if r_i % 2 else "T", "-"])
         return ["".join(r) for r in rows], names, "DNA", 0
+    if kind == "dna_48":
+        # a larger case: radius-6 neighbourhoods are not clipped by the tree size, deeper chains, gaps and N
+        rng = np.random.default_rng(57)
+        L, names = synth.synth_alignment(48, 500, "DNA", 0.07, seed=12)
+        rows = [list(r) for r in synth.letters_to_text(L, "DNA")]
+        for r in rows:
+            for j in range(len(r)):
+                u = rng.random()
+                if u < 0.03:
+                    r[j] = "N" if rng.random() < 0.5 else "-"
+                elif u < 0.04:
+                    r[j] = "RYKM"[int(rng.integers(4))]
+        return ["".join(r) for r in rows], names, "DNA", 0
     if kind == "dna_dups":
         rng = np.random.default_rng(33)
         L, names = synth.synth_alignment(12, 120, "DNA", 0.12, seed=8)
@@ -187,7 +200,7 @@ def fixture(kind: str, tmp: str):
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa"):
+        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48"):
             fx = fixture(kind, tmp)
             with open(os.path.join(OUT, kind + ".json"), "w") as f:
                 json.dump(fx, f, separators=(",", ":"))

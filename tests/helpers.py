@@ -6,7 +6,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FIXTURES = ("dna_clean", "dna_ambig", "dna_dups", "aa")
+FIXTURES = ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48")
 
 
 def load_fixture(name):
