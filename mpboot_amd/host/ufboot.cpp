@@ -232,17 +232,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   const int total = 2 * n_ - 2;
   std::vector<ScanPlan> plans;
   const uint32_t *out = nullptr;
-  int batch = first_batch();
-  std::vector<UfbEvent> events;
-  std::vector<uint32_t> small, sel, crow;
-  bool have_C = false;
-  uint32_t exchange_tag = 0;
   if (u.exchange) {
     // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy
     // state instead of this engine's own history
     gap_est_ = -1.0;
     since_move_ = 0;
   }
+  int batch = first_batch();
+  std::vector<UfbEvent> events;
+  std::vector<uint32_t> small, sel, crow;
+  bool have_C = false;
+  uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
   do {
     startMP = randomMP;

@@ -250,7 +250,10 @@ if rank == 1:
     e.seed_ties(engine.TIE_RANDOM, 5)
     e.optimize_spr(1, 6)
     e.optimize_spr(1, 6)
+    e.set_option("scan_batch", 4)      # same option on both ranks below; here it only shapes this rank's history
+    e.optimize_spr(1, 6)
     e.reset_node_order()
+e.set_option("scan_batch", 4)          # small batches: several exchanges per climb
 e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
 e.seed_ties(engine.TIE_RANDOM, 19)
 e.ufboot_attach(samples, 0.5, shard=(rank, ws))
