@@ -240,7 +240,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   }
   int batch = first_batch();
   std::vector<UfbEvent> events;
-  std::vector<uint32_t> small, sel, crow;
+  std::vector<uint32_t> small, sel_rows, crow;
   bool have_C = false;
   uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
@@ -286,13 +286,13 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       uint32_t n_ev = 0;
       t0 = now_ms();
       u.t_prep += t0 - t1;
-      // with a cut-off only the saved candidates (and the home rows of their parts) are multiplied: `sel` lists their
-      // mask rows, crow maps a scan output index to its row of C
+      // with a cut-off only the saved candidates (and the home rows of their parts) are multiplied: this lists their
+      // mask rows (`sel_rows`), crow maps a scan output index to its row of C
       const uint2 *hinfo = u.h_info.p;
       const bool compact = have_cut && !none_pass;
       uint32_t n_rows = n_idx;
       if (compact) {
-        sel.clear();
+        sel_rows.clear();
         crow.assign((size_t)n_idx, 0xFFFFFFFFu);
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
@@ -303,18 +303,18 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             for (int k = 0; k < pl.part_cnt[pi]; k++) {
               const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
               if (out[idx] > lim_cost) continue;
-              crow[idx] = (uint32_t)sel.size();
-              sel.push_back(hinfo[idx].x);
+              crow[idx] = (uint32_t)sel_rows.size();
+              sel_rows.push_back(hinfo[idx].x);
               any = true;
             }
             if (any) {
               const uint32_t hidx = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
-              crow[hidx] = (uint32_t)sel.size();
-              sel.push_back(hidx);
+              crow[hidx] = (uint32_t)sel_rows.size();
+              sel_rows.push_back(hidx);
             }
           }
         }
-        n_rows = (uint32_t)sel.size();
+        n_rows = (uint32_t)sel_rows.size();
       }
       have_C = false;
       if (n_idx > 0 && !none_pass && n_rows > 0) {
@@ -333,7 +333,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = u.boot_score[(size_t)u.ids[(size_t)c2]];
         if (compact) {
           std::memcpy(small.data() + o_crow, crow.data(), (size_t)n_idx * sizeof(uint32_t));
-          std::memcpy(small.data() + o_sel, sel.data(), sel.size() * sizeof(uint32_t));      // padding rows multiply mask row 0
+          std::memcpy(small.data() + o_sel, sel_rows.data(), sel_rows.size() * sizeof(uint32_t));      // padding rows multiply mask row 0
         }
         UCHK(u.h_small.reserve(small.size() + 4));
         std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
