@@ -940,11 +940,18 @@ unsigned orc_stepwise(orc *o, long seed, unsigned *best_per_step, int *insert_pe
 unsigned orc_make_tree(orc *o, long seed, int spr_dist, int *perm_out)
 {
   int *perm = (int *)malloc(sizeof(int) * (o->n + 2));
+  /* _pllMakeParsimonyTreeFast runs with perSiteScores = 0 (sprparsimony.cpp:3126, :3185-3206): no saveCurrentTree here,
+     whatever tracker is attached */
+  const int ufb_saved = o->ufb_on, ps_saved = o->persite_on;
+  o->ufb_on = 0;
+  o->persite_on = 0;
   addition_phase(o, seed, perm, NULL, NULL);
   if (perm_out) memcpy(perm_out, perm, sizeof(int) * (o->n + 1));
   free(perm);
   orc_node_rectifier(o);
   spr_sweeps(o, 1, spr_dist, o->best);
+  o->ufb_on = ufb_saved;
+  o->persite_on = ps_saved;
   return o->best;
 }
 
