@@ -506,7 +506,16 @@ int Engine::schedule_views(const std::vector<int> *roots)
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;
   if (full) { n_invalid_ = 0; views_valid_ = true; }
-  else if (n_invalid_ > 0) { n_invalid_ -= (long)nops; if (n_invalid_ <= 0) { n_invalid_ = 0; views_valid_ = true; } }
+  else if (n_invalid_ > 0) {
+    n_invalid_ -= (long)nops;
+    if (n_invalid_ <= 0) {
+      n_invalid_ = 0;
+      views_valid_ = true;
+      if (check_counts_)                          // self-check of the bookkeeping: every vector of the tree must be valid now
+        for (size_t r = 3 * ((size_t)n_ + 1); r < back_.size(); r++)
+          if (back_[r] >= 0 && !valid_[r]) { set_error("view bookkeeping: invalid vector left behind"); return MPF_E_STATE; }
+    }
+  }
   pending_scores_ = true;
   stats.newview_ops += nops;
   stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;

@@ -229,6 +229,8 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     const int r = back_[insert_rec_];
     hookup(nx(q), insert_rec_);
     hookup(nx(nx(q)), r);
+    // the new node's three vectors have never been valid, so invalidate_node will not count them
+    if (n_invalid_ >= 0) n_invalid_ += 3;
     invalidate_node(num(q));
     invalidate_node(num(insert_rec_));
     invalidate_node(num(r));
