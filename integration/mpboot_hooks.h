@@ -1,0 +1,38 @@
+// mpboot_hooks.h -- what integration/sprparsimony_shim.cpp needs from mpboot's C++ side.
+//
+// The reference's sprparsimony.cpp reads a handful of IQTree / Params members directly (cited per field).  The shim
+// reaches them through this table instead, so that it compiles against pll.h alone (iqtree.h drags in tools.h ->
+// <iqtree_config.h>, a CMake-generated header).  A maintainer fills the table once in iqtree.cpp, e.g.
+//
+//     static double hk_random(void)                { return random_double(); }
+//     static int    hk_ratchet(IQTree *t)          { return globalParam->ratchet_iter >= 0 && (t->on_ratchet_hclimb1 || t->on_ratchet_hclimb2); }
+//     static int    hk_opt_btree(IQTree *t)        { return t && t->on_opt_btree; }
+//     static int    hk_freq(IQTree *t, int ptn)    { return t->aln->at(ptn).frequency; }
+//     static double hk_score(IQTree *t)            { return t->curScore; }
+//     static const unsigned short *hk_boot(IQTree *t, int b) { return t->boot_samples_pars[b]; }
+//     static double hk_cutoff(IQTree *t)           { return t->logl_cutoff; }
+//     ...  mpfitch_shim_install(&hooks);           // before the first parsimony call (IQTree::initializePLL)
+#pragma once
+#include "../include/mpfitch.h"
+
+class IQTree;
+
+struct mpf_mpboot_hooks {
+  double (*random_double)(void);                  // tools.cpp:3363; tie-breaks consume mpboot's own SPRNG stream
+  int (*ratchet_climb)(IQTree *);                 // sprparsimony.cpp:3249 (re-weighted climb: refresh tr->aliaswgt)
+  int (*on_opt_btree)(IQTree *);                  // sprparsimony.cpp:3253
+  int (*pattern_frequency)(IQTree *, int ptn);    // sprparsimony.cpp:3026 (_updateInternalPllOnRatchet)
+  double (*cur_score)(IQTree *);                  // sprparsimony.cpp:3279 (start-score check); NULL = no check
+  int sort_alignment;                             // globalParam->sort_alignment (sprparsimony.cpp:2462, :3383)
+  int gbo_replicates;                             // globalParam->gbo_replicates (sprparsimony.cpp:3245); 0 = no -bb
+  // -bb only (unused when gbo_replicates == 0)
+  const unsigned short *(*boot_sample)(IQTree *, int b);    // iqtree->boot_samples_pars[b], nptn entries (iqtree.cpp:213-313)
+  double ufboot_epsilon;                          // globalParam->ufboot_epsilon (iqtree.cpp:3594)
+  double (*logl_cutoff)(IQTree *);                // iqtree->logl_cutoff (iqtree.cpp:3343)
+  // called at the end of every pllOptimizeSprParsimony with the engine that holds the saveCurrentTree bookkeeping of
+  // this climb: copy treels_logl / boot_logl / boot_counts / boot_trees back with mpf_ufboot_* 
+  void (*ufboot_sync)(IQTree *, mpf_engine *);
+};
+
+void mpfitch_shim_install(const mpf_mpboot_hooks *hooks);
+mpf_engine *mpfitch_shim_engine(void);            // the engine behind the shim (NULL before the first call)

@@ -242,7 +242,9 @@ int Engine::pack()
 int Engine::set_weights(const int32_t *weights)
 {
   wgt_.assign(weights, weights + P_);
-  ufboot_detach();                               // the sample weights are laid out by site position: re-attach after re-weighting
+  // the tracker's sample weights are laid out by site position of the attach-time packing: while other weights are in
+  // force (ratchet climbs) the bookkeeping is suspended; restoring the attach-time weights resumes it with its state
+  if (ufb_) { ufb_->suspended = wgt_ != ufb_->attach_wgt; ufb_->rt_valid = false; }
   return pack();
 }
 

@@ -135,6 +135,8 @@ struct UfbState {
   PinBuf<UfbEvent> h_ev;
   PinBuf<uint32_t> h_small;                      // staging: thr | home | best | event count
   bool rt_valid = false;
+  std::vector<int32_t> attach_wgt;               // pattern weights in force at attach time
+  bool suspended = false;                        // other weights in force (mpf_set_weights): climbs run without bookkeeping
 };
 
 class Engine {

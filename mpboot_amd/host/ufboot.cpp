@@ -82,6 +82,7 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   u->boot_score.assign((size_t)n_all, UINT32_MAX);           // boot_logl = -LONG_MAX (iqtree.cpp:248)
   u->boot_counts.assign((size_t)n_all, 0);                   // :253
   u->boot_trees.assign((size_t)n_all, -1);                   // :252
+  u->attach_wgt = wgt_;
   ufb_ = std::move(u);
   return MPF_OK;
 }

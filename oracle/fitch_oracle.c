@@ -62,6 +62,7 @@ struct orc {
   /* UFBoot-MP online bookkeeping (IQTree::saveCurrentTree, iqtree.cpp:3271-3785, default options) */
   int pre_eval;               /* -1 = as the variant does (mpboot yes, PLL original no); 0 / 1 = forced */
   int ufb_on, ufb_B, ufb_bad;
+  int *ufb_w0;                       /* pattern weights at attach time */
   unsigned short *ufb_samples;    /* boot_samples_pars [B][P] */
   double ufb_eps, ufb_cutoff;     /* params->ufboot_epsilon (0.5, tools.cpp:725), logl_cutoff */
   double *ufb_logl;               /* boot_logl */
@@ -273,6 +274,12 @@ void orc_set_weights(orc *o, const int *weights)
   memcpy(o->wgt, weights, sizeof(int) * o->P);
   pack_tips(o);
   reset_flags(o);
+  /* an attached UFBoot tracker follows the attach-time weights only: other weights suspend it (the reference's
+     -no_hclimb1_bb behaviour, iqtree.cpp:3280), restoring them resumes it */
+  if (o->ufb_samples) o->ufb_on = memcmp(o->wgt, o->ufb_w0, sizeof(int) * o->P) == 0;
+  if (o->persite) { free(o->persite); o->persite = NULL; }
+  if (o->ufb_samples) o->persite_on = o->ufb_on;
+  if (o->persite_on) orc_enable_persite(o, 1);
 }
 
 void orc_enable_persite(orc *o, int on)
@@ -968,6 +975,7 @@ void orc_ufboot_detach(orc *o)
   int i;
   for (i = 0; i < o->ufb_nstore; i++) free(o->ufb_store_back[i]);
   free(o->ufb_store_back); free(o->ufb_store_idx);
+  free(o->ufb_w0); o->ufb_w0 = NULL;
   free(o->ufb_samples); free(o->ufb_logl); free(o->ufb_counts); free(o->ufb_trees); free(o->ufb_treels); free(o->ufb_ptn);
   o->ufb_store_back = NULL; o->ufb_store_idx = NULL; o->ufb_nstore = o->ufb_store_cap = 0;
   o->ufb_samples = NULL; o->ufb_logl = NULL; o->ufb_counts = NULL; o->ufb_trees = NULL; o->ufb_treels = NULL; o->ufb_ptn = NULL;
@@ -981,6 +989,8 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsi
   o->ufb_B = B;
   o->ufb_samples = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)B * o->P);
   memcpy(o->ufb_samples, samples, sizeof(unsigned short) * (size_t)B * o->P);
+  o->ufb_w0 = (int *)malloc(sizeof(int) * o->P);
+  memcpy(o->ufb_w0, o->wgt, sizeof(int) * o->P);
   o->ufb_eps = epsilon;
   o->ufb_cutoff = 0.0;                                   /* iqtree.cpp:68 */
   o->ufb_logl = (double *)malloc(sizeof(double) * B);

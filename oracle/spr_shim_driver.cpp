@@ -1,0 +1,189 @@
+/*
+ * spr_shim_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+ * Plays the part of mpboot's IQTree layer for integration/sprparsimony_shim.cpp: an ordinary PLL program (the
+ * reference's alignment parser, partitions, instance and tree code from oracle/_ref/obj, and the reference's own SPRNG
+ * generator for random_double()) that calls the mpboot-level entry points exactly as iqtree.cpp / phyloanalysis.cpp do
+ *     _pllComputeRandomizedStepwiseAdditionParsimonyTree   (phyloanalysis.cpp:1165)
+ *     pllOptimizeSprParsimony                              (iqtree.cpp:2132), plain, re-weighted (ratchet) and -bb
+ *     pllComputePatternParsimony / pllComputeSiteParsimony (iqtree.cpp:3365)
+ *     pllCalcMinParsScorePattern                           (iqtree.cpp:3827)
+ * and prints what they leave in the pllInstance.  tests/test_gpu_dropin.py replays the same calls on the CPU oracle.
+ *
+ * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B>
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+#include "pll.h"
+}
+#include "sprng/sprng.h"
+#include "../integration/mpboot_hooks.h"
+
+// the reference's declarations (sprparsimony.h:13-42)
+void resetGlobalParamOnNewAln();
+void _pllComputeRandomizedStepwiseAdditionParsimonyTree(pllInstance *tr, partitionList *partitions, int sprDist, IQTree *_iqtree);
+void _pllFreeParsimonyDataStructures(pllInstance *tr, partitionList *pr);
+int pllOptimizeSprParsimony(pllInstance *tr, partitionList *pr, int mintrav, int maxtrav, IQTree *iqtree);
+void pllComputePatternParsimony(pllInstance *tr, partitionList *pr, unsigned short *ptn_pars, int *cur_pars);
+void pllComputeSiteParsimony(pllInstance *tr, partitionList *pr, int *site_pars, int nsite, int *cur_pars);
+int pllCalcMinParsScorePattern(pllInstance *tr, int dataType, int site);
+
+// ---- the "IQTree" of this program: just the members the shim's hooks read
+struct Host {
+  int *stream = nullptr;
+  bool ratchet = false;
+  std::vector<int> freq;                       // aln->at(ptn).frequency
+  double cur_score = 0;
+  bool check_score = false;
+  int B = 0, P = 0;
+  std::vector<unsigned short> samples;         // boot_samples_pars
+  double logl_cutoff = 0;
+};
+static Host H;
+
+static double hk_random(void) { return sprng(H.stream); }
+static int hk_ratchet(IQTree *) { return H.ratchet; }
+static int hk_opt_btree(IQTree *) { return 0; }
+static int hk_freq(IQTree *, int ptn) { return H.freq[(size_t)ptn]; }
+static double hk_score(IQTree *) { return H.cur_score; }
+static const unsigned short *hk_boot(IQTree *, int b) { return &H.samples[(size_t)b * (size_t)H.P]; }
+static double hk_cutoff(IQTree *) { return H.logl_cutoff; }
+
+static void hk_sync(IQTree *, mpf_engine *e)
+{
+  int64_t nt = 0;
+  mpf_ufboot_num_trees(e, &nt);
+  std::vector<double> tl((size_t)nt), bl((size_t)H.B);
+  std::vector<int32_t> bc((size_t)H.B), bt((size_t)H.B);
+  mpf_ufboot_tree_logl(e, tl.data());
+  mpf_ufboot_get_state(e, bl.data(), bc.data(), bt.data());
+  std::printf("ufb_ntrees %lld\nufb_tree_logl", (long long)nt);
+  for (double v : tl) std::printf(" %.0f", v);
+  std::printf("\nufb_boot_logl");
+  for (double v : bl) std::printf(" %.0f", v);
+  std::printf("\nufb_boot_counts");
+  for (int v : bc) std::printf(" %d", v);
+  std::printf("\nufb_boot_trees");
+  for (int v : bt) std::printf(" %d", v);
+  std::printf("\n");
+}
+
+static unsigned long long g_lcg;
+static unsigned lcg3() { g_lcg = g_lcg * 6364136223846793005ULL + 1442695040888963407ULL; return (unsigned)((g_lcg >> 33) % 3ULL); }
+
+static int rec_of(pllInstance *tr, nodeptr p)
+{
+  if (p->number <= tr->mxtips) return 3 * p->number;
+  const long idx = (long)(p - tr->nodeBaseAddress) - tr->mxtips;
+  return 3 * p->number + (2 - (int)(idx % 3));
+}
+static void print_tree(const char *tag, pllInstance *tr)
+{
+  const int n = tr->mxtips;
+  std::printf("%s_score %u\n%s_topology", tag, tr->bestParsimony, tag);
+  for (int v = 1; v <= 2 * n - 2; v++)
+    for (int s = 0; s < (v <= n ? 1 : 3); s++) {
+      nodeptr p = v <= n ? tr->nodeBaseAddress + (v - 1) : tr->nodeBaseAddress + n + 3 * (v - n - 1) + (2 - s);
+      std::printf(" %d:%d", 3 * v + s, rec_of(tr, p->back));
+    }
+  std::printf("\n");
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 8) { std::fprintf(stderr, "usage: %s <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B>\n", argv[0]); return 2; }
+  pllInstanceAttr attr;
+  std::memset(&attr, 0, sizeof attr);
+  attr.rateHetModel = PLL_GAMMA;
+  attr.fastScaling = PLL_FALSE;
+  attr.saveMemory = PLL_FALSE;
+  attr.useRecom = PLL_FALSE;
+  attr.randomNumberSeed = 12345;
+  attr.numberOfThreads = 1;
+  pllInstance *tr = pllCreateInstance(&attr);
+  pllAlignmentData *aln = pllParseAlignmentFile(PLL_FORMAT_PHYLIP, argv[1]);
+  if (!aln) { std::fprintf(stderr, "cannot parse %s\n", argv[1]); return 2; }
+  char pstr[256];
+  std::snprintf(pstr, sizeof pstr, "%s, p1 = 1-%d\n", argv[2], aln->sequenceLength);
+  pllQueue *parts = pllPartitionParseString(pstr);
+  if (!pllPartitionsValidate(parts, aln)) return 2;
+  partitionList *pr = pllPartitionsCommit(parts, aln);
+  pllQueuePartitionsDestroy(&parts);
+  if (std::atoi(argv[3])) pllAlignmentRemoveDups(aln, pr);
+  pllTreeInitTopologyForAlignment(tr, aln);
+  if (!pllLoadAlignment(tr, aln, pr)) return 2;
+  const int maxtrav = std::atoi(argv[6]);
+  const int P = tr->originalCrunchedLength, n = tr->mxtips;
+  H.stream = init_sprng(0, 1, std::atoi(argv[4]), SPRNG_DEFAULT);      // init_random, tools.cpp:3326
+  H.B = std::atoi(argv[7]);
+  H.P = P;
+  H.freq.assign(tr->aliaswgt, tr->aliaswgt + P);
+  const std::vector<int> w0 = H.freq;
+  // boot_samples_pars stand-in: weight x {0, 1, 2}, reproducible from the seed (the test regenerates it)
+  g_lcg = 0x9E3779B97F4A7C15ULL ^ (unsigned long long)std::atoll(argv[4]);
+  H.samples.resize((size_t)H.B * (size_t)P);
+  for (int b = 0; b < H.B; b++)
+    for (int p = 0; p < P; p++) H.samples[(size_t)b * (size_t)P + (size_t)p] = (unsigned short)((unsigned)w0[(size_t)p] * lcg3());
+
+  mpf_mpboot_hooks hooks;
+  std::memset(&hooks, 0, sizeof hooks);
+  hooks.random_double = hk_random;
+  hooks.ratchet_climb = hk_ratchet;
+  hooks.on_opt_btree = hk_opt_btree;
+  hooks.pattern_frequency = hk_freq;
+  hooks.cur_score = hk_score;
+  hooks.sort_alignment = 1;
+  hooks.gbo_replicates = H.B;
+  hooks.boot_sample = hk_boot;
+  hooks.ufboot_epsilon = 0.5;
+  hooks.logl_cutoff = hk_cutoff;
+  hooks.ufboot_sync = hk_sync;
+  resetGlobalParamOnNewAln();
+  mpfitch_shim_install(&hooks);
+  IQTree *iq = nullptr;
+
+  // 1. start tree (phyloanalysis.cpp:1165: sprDist = 0 keeps it a pure stepwise addition)
+  tr->randomNumberSeed = std::atol(argv[5]);
+  _pllComputeRandomizedStepwiseAdditionParsimonyTree(tr, pr, 0, iq);
+  print_tree("ras", tr);
+
+  // 2. the SPR climb of one search iteration, with the -bb bookkeeping when B > 0 (iqtree.cpp:2132)
+  H.cur_score = -(double)tr->bestParsimony;
+  pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);
+  print_tree("spr", tr);
+  {
+    std::vector<unsigned short> pp((size_t)P + 16, 65535);
+    int cur = 0;
+    pllComputePatternParsimony(tr, pr, pp.data(), &cur);
+    std::printf("ptn_total %d\nptn_pars", cur);
+    for (int p = 0; p < P; p++) std::printf(" %u", (unsigned)pp[(size_t)p]);
+    std::printf("\n");
+    int nsite = 0;
+    for (int p = 0; p < P; p++) nsite += tr->aliaswgt[p];
+    std::vector<int> sp((size_t)nsite + 8, -1);
+    pllComputeSiteParsimony(tr, pr, sp.data(), nsite + 8, &cur);
+    std::printf("site_total %d\nsite_pars", cur);
+    for (int s = 0; s < nsite + 8; s++) std::printf(" %d", sp[(size_t)s]);
+    std::printf("\nmin_pars");
+    for (int p = 0; p < P; p++) std::printf(" %d", pllCalcMinParsScorePattern(tr, pr->partitionData[0]->dataType, p));
+    std::printf("\n");
+  }
+
+  // 3. a ratchet climb: perturbed pattern frequencies (iqtree.cpp:1706-1716), then the climb on the original weights
+  for (int p = 0; p < P; p++) H.freq[(size_t)p] = w0[(size_t)p] * (int)lcg3();
+  H.ratchet = true;
+  H.cur_score = 0;
+  hooks.cur_score = nullptr;                       // the perturbed start score is not known to this driver
+  mpfitch_shim_install(&hooks);
+  pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);
+  print_tree("ratchet", tr);
+  H.freq = w0;
+  pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);   // on_ratchet_hclimb2: original weights again, bookkeeping resumes
+  print_tree("final", tr);
+  _pllFreeParsimonyDataStructures(tr, pr);
+  resetGlobalParamOnNewAln();
+  return 0;
+}

@@ -341,7 +341,19 @@ def test_unsupported_configurations_fail_loudly(mods):
         e.optimize_spr(1, 6)
     e.set_option("scan_mode", 1)
     assert e.optimize_spr(1, 6) > 0
-    # re-weighting re-packs the sites the sample weights are laid out by: the tracker is dropped, not left stale
+    # re-weighting re-packs the sites the sample weights are laid out by: the tracker is suspended (a climb on other
+    # weights leaves its state alone), and resumes when the attach-time weights return
+    n_saved = len(e.ufboot_tree_logl())
+    other = fx["weights_np"].copy()
+    other[::2] *= 2
+    e.set_weights(other)
+    e.set_tree(np.array(fx["trees"][1]["back"], dtype=np.int32))
+    assert e.optimize_spr(1, 6) > 0
+    assert len(e.ufboot_tree_logl()) == n_saved
     e.set_weights(fx["weights_np"])
+    e.set_tree(np.array(fx["trees"][1]["back"], dtype=np.int32))
+    assert e.optimize_spr(1, 6) > 0
+    assert len(e.ufboot_tree_logl()) > n_saved
+    e.ufboot_detach()
     with pytest.raises(engine.MpfError):
         e.ufboot_state()
