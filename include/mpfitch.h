@@ -248,7 +248,8 @@ int mpf_reset_stats(mpf_engine *e);
      "reduce"          0 = DPP wave reduction, 1 = ds_bpermute
      "xcd_map"         1 = XCD-aware workgroup -> tile map of the scan kernel
      "scan_mode"       1 = device-walked SPR scan (radius <= 8), 0 = host-planned scan programs
-     "views_mode"      1 = all dependency levels of a refresh in one launch
+     "views_mode"      2 = chained refresh (stale paths run in registers, one launch; Fitch mode), 1 = all dependency
+                       levels of a refresh in one launch, 0 = one launch per level
      "split_below"     batches of at most this many prune nodes are cut into four scan parts each
      "sankoff_short"   1 = two 16-bit costs per lane in the weighted kernels when no intermediate can overflow
                        (the reference's default arithmetic), 0 = always 32-bit (its -short_off)

@@ -35,6 +35,8 @@ const std::string &last_error() { return g_err; }
 
 Engine::~Engine()
 {
+  if (std::getenv("MPF_VIEWS_PROFILE"))
+    std::fprintf(stderr, "[views] launches %llu ops %llu levels %llu\n", (unsigned long long)stats.view_launches, (unsigned long long)stats.newview_ops, (unsigned long long)dbg_levels_);
   if (d_codes_) (void)hipFree(d_codes_);
   if (d_vec_) (void)hipFree(d_vec_);
   if (d_tipslots_) (void)hipFree(d_tipslots_);
@@ -384,6 +386,101 @@ int Engine::count_visits(int q, int m)
   return v;
 }
 
+// Cut the refresh's dependency graph (ops = `order`, topologically sorted) into chains for k_newview_chain: op j continues
+// the chain of op d when d is j's ONLY stale input (its other input is valid already, so the wave can prefetch it); of the
+// up to two consumers of d the one with the longer path above it continues, the other starts a chain of the next level.
+// A chain's level is one more than the deepest chain it takes an input from; per level the chains are spread over the 16
+// waves of a workgroup, longest first.
+void Engine::build_chains(const std::vector<int> &order)
+{
+  const int N = (int)order.size();
+  if (sv_idx_.size() != back_.size()) sv_idx_.assign(back_.size(), 0);
+  for (int i = 0; i < N; i++) sv_idx_[(size_t)order[(size_t)i]] = i;
+  auto dep_of = [&](int x) { return (!tip(x) && lev_epoch_[x] == epoch_) ? sv_idx_[(size_t)x] : -1; };
+  ch_d0_.resize((size_t)N); ch_d1_.resize((size_t)N); ch_h_.assign((size_t)N, 0); ch_next_.assign((size_t)N, -1);
+  ch_chain_.resize((size_t)N);
+  for (int i = 0; i < N; i++) {
+    const int r = order[(size_t)i];
+    ch_d0_[(size_t)i] = dep_of(back_[nx(r)]);
+    ch_d1_[(size_t)i] = dep_of(back_[nx(nx(r))]);
+  }
+  for (int i = N - 1; i >= 0; i--) {
+    const int h = ch_h_[(size_t)i] + 1;
+    const int d0 = ch_d0_[(size_t)i], d1 = ch_d1_[(size_t)i];
+    if (d0 >= 0 && ch_h_[(size_t)d0] < h) ch_h_[(size_t)d0] = h;
+    if (d1 >= 0 && ch_h_[(size_t)d1] < h) ch_h_[(size_t)d1] = h;
+  }
+  auto single = [&](int j) { const int d0 = ch_d0_[(size_t)j], d1 = ch_d1_[(size_t)j]; return (d0 >= 0) != (d1 >= 0) ? (d0 >= 0 ? d0 : d1) : -1; };
+  for (int j = 0; j < N; j++) {
+    const int d = single(j);
+    if (d >= 0 && (ch_next_[(size_t)d] < 0 || ch_h_[(size_t)j] > ch_h_[(size_t)ch_next_[(size_t)d]])) ch_next_[(size_t)d] = j;
+  }
+  // chains in order of their heads; level of a chain from its head's inputs
+  ch_head_.clear(); ch_len_.clear(); ch_slev_.clear();
+  int nlev = 0;
+  for (int j = 0; j < N; j++) {
+    const int d = single(j);
+    if (d >= 0 && ch_next_[(size_t)d] == j) continue;           // a link, reached from its head
+    const int c = (int)ch_head_.size();
+    int lev = 0;
+    if (ch_d0_[(size_t)j] >= 0) lev = std::max(lev, ch_slev_[(size_t)ch_chain_[(size_t)ch_d0_[(size_t)j]]] + 1);
+    if (ch_d1_[(size_t)j] >= 0) lev = std::max(lev, ch_slev_[(size_t)ch_chain_[(size_t)ch_d1_[(size_t)j]]] + 1);
+    int len = 0;
+    for (int k = j; k >= 0; k = ch_next_[(size_t)k]) { ch_chain_[(size_t)k] = c; len++; }
+    ch_head_.push_back(j);
+    ch_len_.push_back(len);
+    ch_slev_.push_back(lev);
+    nlev = std::max(nlev, lev + 1);
+  }
+  const int C = (int)ch_head_.size();
+  // per level: chains longest first onto the least loaded wave
+  ch_lev_off_.assign((size_t)nlev + 1, 0);
+  for (int c = 0; c < C; c++) ch_lev_off_[(size_t)ch_slev_[(size_t)c] + 1]++;
+  for (int l = 0; l < nlev; l++) ch_lev_off_[(size_t)l + 1] += ch_lev_off_[(size_t)l];
+  ch_sorted_.resize((size_t)C);
+  {
+    std::vector<int> &fill = sv_fill_;
+    fill.assign(ch_lev_off_.begin(), ch_lev_off_.end() - 1);
+    for (int c = 0; c < C; c++) ch_sorted_[(size_t)fill[(size_t)ch_slev_[(size_t)c]]++] = c;
+  }
+  ch_wave_.resize((size_t)C);
+  ch_off_.assign((size_t)nlev * 16 + 1, 0);
+  for (int l = 0; l < nlev; l++) {
+    int *b = ch_sorted_.data() + ch_lev_off_[(size_t)l], *e = ch_sorted_.data() + ch_lev_off_[(size_t)l + 1];
+    if (e - b > 16) std::sort(b, e, [&](int x, int y) { return ch_len_[(size_t)x] != ch_len_[(size_t)y] ? ch_len_[(size_t)x] > ch_len_[(size_t)y] : x < y; });
+    int load[16] = {0};
+    for (int *p = b; p < e; p++) {
+      int w = 0;
+      for (int k = 1; k < 16; k++) if (load[k] < load[w]) w = k;
+      ch_wave_[(size_t)*p] = w;
+      load[w] += ch_len_[(size_t)*p];
+    }
+    for (int w = 0; w < 16; w++) ch_off_[(size_t)l * 16 + (size_t)w + 1] = load[w];
+  }
+  for (size_t i = 1; i < ch_off_.size(); i++) ch_off_[i] += ch_off_[i - 1];
+  // emit: position of every op
+  ch_ops_.resize((size_t)N);
+  {
+    std::vector<int> &fill = sv_fill_;
+    fill.assign(ch_off_.begin(), ch_off_.end() - 1);
+    for (int l = 0; l < nlev; l++)
+      for (int i = ch_lev_off_[(size_t)l]; i < ch_lev_off_[(size_t)l + 1]; i++) {
+        const int c = ch_sorted_[(size_t)i];
+        int &at = fill[(size_t)l * 16 + (size_t)ch_wave_[(size_t)c]];
+        bool first = true;
+        for (int k = ch_head_[(size_t)c]; k >= 0; k = ch_next_[(size_t)k]) {
+          const int r = order[(size_t)k];
+          ChainOp &o = ch_ops_[(size_t)at++];
+          o.rec = r;
+          // a link's memory operand is the input that is NOT the previous op
+          o.other = first ? -1 : (ch_d0_[(size_t)k] >= 0 ? back_[nx(nx(r))] : back_[nx(r)]);
+          first = false;
+        }
+      }
+  }
+  ch_levels_ = nlev;
+}
+
 int Engine::schedule_views(const std::vector<int> *roots)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
@@ -448,17 +545,36 @@ int Engine::schedule_views(const std::vector<int> *roots)
   }
   int maxlev = 0;
   for (int r : order) maxlev = std::max(maxlev, lev_[r]);
+  // chained refresh for the incremental case (few ops, deep and narrow: paths away from an edit); a refresh of most of the
+  // tree is wide, the level kernel's two-ops-in-flight loop suits it and cutting it into chains would cost the host more
+  // than it saves the device
+  const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && nops <= 512;
+  if (chains) build_chains(order);                 // -> ch_ops_ (op order), ch_off_ (per level and wave), ch_levels_
   // staging layout: [kids][ops][level offsets], one upload
   const size_t kids_bytes = nslots_ * sizeof(uint2);
   const size_t ops_off = (kids_bytes + 15) & ~(size_t)15;
   const size_t lev_off_b = ops_off + ((nops * sizeof(NvOp) + 15) & ~(size_t)15);
-  const size_t total_b = lev_off_b + ((size_t)maxlev + 2) * sizeof(int32_t);
+  const size_t n_off = chains ? ch_off_.size() : (size_t)maxlev + 2;
+  const size_t total_b = lev_off_b + n_off * sizeof(int32_t);
   HIPCHK(h_vstage_.reserve(total_b));
   HIPCHK(d_vstage_.reserve(total_b));
   std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
   NvOp *hops = reinterpret_cast<NvOp *>(h_vstage_.p + ops_off);
   int32_t *lo = reinterpret_cast<int32_t *>(h_vstage_.p + lev_off_b);   // lo[0..maxlev]: offsets of levels 1..maxlev
-  if (nops) {
+  if (chains) {
+    upd_order_.resize(nops);
+    for (size_t at = 0; at < nops; at++) {
+      const ChainOp &c = ch_ops_[at];
+      const int r = c.rec;
+      NvOp &o = hops[at];
+      o.dst = slot(r);
+      o.a = c.other < 0 ? slot(back_[nx(r)]) : 0xFFFFFFFFu;        // a link takes the previous result from registers
+      o.b = c.other < 0 ? slot(back_[nx(nx(r))]) : slot(c.other);
+      o.pad = (uint32_t)r;
+      upd_order_[at] = r;
+    }
+    std::memcpy(lo, ch_off_.data(), ch_off_.size() * sizeof(int32_t));
+  } else if (nops) {
     for (int l = 0; l <= maxlev + 1; l++) lo[l] = 0;
     for (int r : order) lo[lev_[r]]++;
     int acc = 0;
@@ -493,8 +609,14 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const int tiles = tiles_for(g_);
   HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
   if (timing_) HIPCHK(hipEventRecord(ev2_, st_));
-  if (views_mode_ == 1) {
-    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), d_done_.p));
+  // the per-tile mutation counts are folded by the refresh kernel's last workgroup when there are few ops, by a separate
+  // chip-wide launch when there are many (one workgroup would need longer than the launch costs)
+  const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;
+  if (chains) {
+    HIPCHK(launch_newview_chains(st_, g_, d_vec_, dops, dlo, ch_levels_, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr));
+    stats.view_launches++;
+  } else if (views_mode_ >= 1) {
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr));
     stats.view_launches++;
   } else {
     for (int l = 0; l < maxlev; l++) {
@@ -502,7 +624,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
       stats.view_launches++;
     }
   }
-  if (views_mode_ != 1 || sankoff_)             // the all-levels Fitch kernel folds the per-tile counts itself
+  if (!fold_inside)
     HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt()));
   if (timing_) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
@@ -520,6 +642,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   }
   pending_scores_ = true;
   stats.newview_ops += nops;
+  dbg_levels_ += (uint64_t)(chains ? ch_levels_ : maxlev);
   stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
   return MPF_OK;
 }
@@ -1087,7 +1210,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
-  if (key == "views_mode") { views_mode_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
   if (key == "timing") { timing_ = v ? 1 : 0; return MPF_OK; }

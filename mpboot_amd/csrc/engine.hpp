@@ -320,7 +320,14 @@ class Engine {
   bool pending_scores_ = false, kids_dirty_ = true, view_events_pending_ = false;
   long n_invalid_ = -1;                         // -1 = unknown/many, 0 = every vector valid
   int split_below_ = 64;                        // batches of at most this many prune nodes are cut into 4 parts per scan
-  int views_mode_ = 1;                          // 1 = all levels in one launch, 0 = one launch per level
+  int views_mode_ = 2;                          // 2 = chained refresh, 1 = all levels in one launch, 0 = one launch per level
+  struct ChainOp { int rec, other; };           // other < 0: chain head (both operands from memory)
+  void build_chains(const std::vector<int> &order);
+  std::vector<int> sv_idx_, ch_d0_, ch_d1_, ch_h_, ch_next_, ch_chain_, ch_head_, ch_len_, ch_slev_, ch_lev_off_, ch_sorted_, ch_wave_;
+  std::vector<int32_t> ch_off_;
+  std::vector<ChainOp> ch_ops_;
+  int ch_levels_ = 0;
+  uint64_t dbg_levels_ = 0;                     // MPF_VIEWS_PROFILE=1: levels summed over refreshes
   std::vector<uint2> kids_host_;
   DevBuf<WalkDesc> d_walk_;
   PinBuf<uint32_t> h_ncand_;

@@ -275,6 +275,32 @@ __global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, con
   newview_one<S, VW, RED>(vec, ops[op], cntp, nslots, Wp, tile, lane);
 }
 
+// cnt[dst] = sum over tiles of cntp[tile][dst] for the ops of a refresh: 32 lanes per op (one tile each, strided), two ops
+// per group in flight.  The partial counts were written by other workgroups (other XCDs): the caller has acquired them.
+__device__ __forceinline__ void fold_counts(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp,
+                                            uint32_t nslots, int tiles, uint32_t *__restrict__ cnt, int tid, int nthreads)
+{
+  const int l32 = tid & 31, grp = tid >> 5, ngrp = nthreads >> 5;
+  for (int i = grp; i < n_ops; i += 2 * ngrp) {
+    const int j = i + ngrp < n_ops ? i + ngrp : i;
+    const uint32_t d0 = ops[i].dst, d1 = ops[j].dst;
+    uint32_t s0 = 0, s1 = 0;
+    for (int t = l32; t < tiles; t += 32) {
+      s0 += __builtin_nontemporal_load(cntp + (size_t)t * nslots + d0);
+      s1 += __builtin_nontemporal_load(cntp + (size_t)t * nslots + d1);
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      s0 += (uint32_t)__shfl_xor((int)s0, m, 32);
+      s1 += (uint32_t)__shfl_xor((int)s1, m, 32);
+    }
+    if (l32 == 0) {
+      cnt[d0] = s0;
+      if (j != i) cnt[d1] = s1;
+    }
+  }
+}
+
 // ALL levels in one launch: one 16-wave workgroup per tile walks the levels, the waves share a level's
 // ops, and a workgroup barrier separates levels -- sites are independent, so no other workgroup's data
 // is ever needed.  Replaces one launch per level (launch-latency-bound for the short levels of an
@@ -320,6 +346,7 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
   }
   // ---- fold the per-tile counts: every workgroup publishes its stores (agent-scope release), takes a ticket; the
   //      last one acquires and sums
+  if (!done) return;                              // large refresh: launch_cntsum folds the counts with the whole chip
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -328,27 +355,110 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
   __syncthreads();
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const int n_ops = lev_off[n_lev];
-    const int tiles = (int)gridDim.x;
-    for (int i = (int)threadIdx.x; i < n_ops; i += (int)blockDim.x) {
-      const uint32_t dst = ops[i].dst;
-      uint32_t sum = 0;
-      for (int t = 0; t < tiles; t++) sum += __builtin_nontemporal_load(cntp + (size_t)t * nslots + dst);
-      cnt[dst] = sum;
-    }
+    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x);
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-__global__ void k_cntsum(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp, uint32_t nslots,
-                         int tiles, uint32_t *__restrict__ cnt)
+// Chained refresh.  After a topology edit the stale vectors form out-trees fanning away from the edited nodes: nearly
+// every stale vector has ONE stale input (the one from the edit's side) and one valid input.  The level-synchronous kernel
+// above pays a store -> barrier -> load round trip for every link of such a path; here the host cuts the dependency graph
+// into CHAINS (op k+1 takes op k's result and a vector that is already valid), a wave runs a chain with the running
+// result in registers and the valid inputs prefetched two links ahead, and barriers separate only the (few) levels of
+// the chain graph.  ops of (level l, wave w) = [wl_off[16 l + w], wl_off[16 l + w + 1]); o.a == kPrev = "previous result".
+constexpr uint32_t kPrev = 0xFFFFFFFFu;
+template <int S, int VW, int RED, int D>
+__global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+                                                        const int32_t *__restrict__ wl_off, int n_lev,
+                                                        uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
+                                                        uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, int n_ops)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tile = blockIdx.x;
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  for (int l = 0; l < n_lev; l++) {
+    const int b = wl_off[l * 16 + wave], e = wl_off[l * 16 + wave + 1];
+    if (b < e) {
+      // D register sets in rotation (no copies of in-flight registers): set d holds the operands of ops b + d, b + d + D, ...
+      // requested D ops before they are combined; the op descriptors (scalar loads) run another D ahead
+      NvOp o[D], nx[D];
+      Tile<S, VW> ta[D], tb[D], c;
+#pragma unroll
+      for (int d = 0; d < D; d++) o[d] = ops[b + d < e ? b + d : e - 1];
+#pragma unroll
+      for (int d = 0; d < D; d++) {                 // unconditional (indices are clamped): keeps the request counts static
+        if (o[d].a != kPrev) load_tile<S, VW>(ta[d], vec, o[d].a, Wp, w0);
+        load_tile<S, VW>(tb[d], vec, o[d].b, Wp, w0);
+      }
+#pragma unroll
+      for (int d = 0; d < D; d++) nx[d] = ops[b + D + d < e ? b + D + d : e - 1];
+      // one op: combine set d, write the result, request the operands of the op D further on
+#define MPF_CHAIN_STEP(d, RELOAD)                                                                        \
+  {                                                                                                      \
+    uint32_t cost;                                                                                       \
+    if (o[d].a != kPrev) {                                                                               \
+      cost = fitch<S, VW>(c, ta[d], tb[d]);                                                              \
+    } else {                                                                                             \
+      Tile<S, VW> p = c;                                                                                 \
+      cost = fitch<S, VW>(c, p, tb[d]);                                                                  \
+    }                                                                                                    \
+    if (valid) store_tile<S, VW>(c, vec, o[d].dst, Wp, w0);                                              \
+    const uint32_t tot = wave_total<RED>(valid ? cost : 0u);                                             \
+    if (lane == 0) cntp[(size_t)tile * nslots + o[d].dst] = tot;                                         \
+    o[d] = nx[d];                                                                                        \
+    if (RELOAD) {                                                                                        \
+      if (o[d].a != kPrev) load_tile<S, VW>(ta[d], vec, o[d].a, Wp, w0);                                 \
+      load_tile<S, VW>(tb[d], vec, o[d].b, Wp, w0);                                                      \
+    }                                                                                                    \
+  }
+      int k = b;
+      // steady state: every set is reloaded unconditionally, so the waits in front of a set's use can leave the younger
+      // sets' requests in flight
+      for (; k + 2 * D <= e; k += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+          MPF_CHAIN_STEP(d, true);
+          nx[d] = ops[k + d + 2 * D < e ? k + d + 2 * D : e - 1];
+        }
+      }
+      for (; k < e; k += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++)
+          if (k + d < e) MPF_CHAIN_STEP(d, k + d + D < e);
+      }
+#undef MPF_CHAIN_STEP
+    }
+    __syncthreads();
+  }
+  if (!done) return;                              // large refresh: launch_cntsum folds the counts with the whole chip
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    fold_counts(ops, n_ops, cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cntsum(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp, uint32_t nslots,
+                                                int tiles, uint32_t *__restrict__ cnt)
+{
+  const int l32 = threadIdx.x & 31;
+  const int i = (int)(blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5));      // 32 lanes per op
   if (i >= n_ops) return;
   const uint32_t dst = ops[i].dst;
   uint32_t s = 0;
-  for (int t = 0; t < tiles; t++) s += cntp[(size_t)t * nslots + dst];
-  cnt[dst] = s;
+  for (int t = l32; t < tiles; t += 32) s += cntp[(size_t)t * nslots + dst];
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m, 32);
+  if (l32 == 0) cnt[dst] = s;
 }
 
 // ---------------------------------------------------------------- K2: batched evaluate
@@ -1154,11 +1264,24 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
   return hipGetLastError();
 }
 
+hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *wl_off,
+                                 int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done)
+{
+  if (n_lev <= 0) return hipSuccess;
+  dim3 grid((unsigned)tiles_of(g)), block(1024);
+#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 8 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops)
+#define NC2(S_, VW_, dummy) do { if (g.reduce == 0) NC(S_, VW_, 0); else NC(S_, VW_, 1); } while (0)
+  MPF_DISPATCH_SV(NC2, 0);
+#undef NC2
+#undef NC
+  return hipGetLastError();
+}
+
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
                          uint32_t nslots, uint32_t *cnt)
 {
   if (n_ops <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 255) / 256), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles_for(g), cnt);
+  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 7) / 8), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles_for(g), cnt);
   return hipGetLastError();
 }
 

@@ -63,6 +63,10 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
 // weighted mode leaves that to launch_cntsum
 hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
                                  int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done);
+// the same refresh cut into chains (Fitch mode): ops laid out per (level, wave), wl_off[16 * n_lev + 1]; NvOp::a = 0xFFFFFFFF
+// takes the previous op's result from registers
+hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *wl_off,
+                                 int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done);
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
                          uint32_t nslots, uint32_t *cnt);
 int tiles_for(const Geometry &g);
