@@ -537,28 +537,45 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const size_t nops = order.size();
   const bool full = roots == &all;
   if (kids_host_.size() != nslots_) kids_host_.assign(nslots_, make_uint2(0u, 0u));
-  if (kids_dirty_) {
-    // topology for the device-walked scans: kids[cid] = the two records behind an inner record
-    for (int r : *roots)
-      if (r >= 0 && !tip(r)) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
-    for (int r : order) kids_host_[slot(r)] = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
-  }
-  int maxlev = 0;
-  for (int r : order) maxlev = std::max(maxlev, lev_[r]);
   // chained refresh for the incremental case (few ops, deep and narrow: paths away from an edit); a refresh of most of the
   // tree is wide, the level kernel's two-ops-in-flight loop suits it and cutting it into chains would cost the host more
   // than it saves the device
   const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && nops <= 512;
+  // ... and then the kernel reads its few KB of input (ops, offsets, topology updates) straight from the pinned staging
+  // buffer: no copy dispatch in front of it
+  const bool direct = chains && kids_dev_ready_ && roots->size() + nops <= 4096;
+  kid_upd_.clear();
+  if (kids_dirty_) {
+    // topology for the device-walked scans: kids[cid] = the two records behind an inner record
+    auto put = [&](int r) {
+      const uint2 k = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
+      kids_host_[slot(r)] = k;
+      if (direct) { kid_upd_.push_back(slot(r)); kid_upd_.push_back(k.x); kid_upd_.push_back(k.y); }
+    };
+    for (int r : *roots)
+      if (r >= 0 && !tip(r)) put(r);
+    for (int r : order) put(r);
+  }
+  int maxlev = 0;
+  for (int r : order) maxlev = std::max(maxlev, lev_[r]);
   if (chains) build_chains(order);                 // -> ch_ops_ (op order), ch_off_ (per level and wave), ch_levels_
   // staging layout: [kids][ops][level offsets], one upload
   const size_t kids_bytes = nslots_ * sizeof(uint2);
   const size_t ops_off = (kids_bytes + 15) & ~(size_t)15;
   const size_t lev_off_b = ops_off + ((nops * sizeof(NvOp) + 15) & ~(size_t)15);
   const size_t n_off = chains ? ch_off_.size() : (size_t)maxlev + 2;
-  const size_t total_b = lev_off_b + n_off * sizeof(int32_t);
-  HIPCHK(h_vstage_.reserve(total_b));
-  HIPCHK(d_vstage_.reserve(total_b));
-  std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
+  const size_t total_b = lev_off_b + ((n_off * sizeof(int32_t) + 15) & ~(size_t)15);
+  const size_t upd_b = (kid_upd_.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const size_t desc_b = direct ? desc_req_n_ * sizeof(WalkDesc) : 0;
+  HIPCHK(h_vstage_.reserve(total_b + upd_b + desc_b));
+  if (direct) {
+    if (!kid_upd_.empty()) std::memcpy(h_vstage_.p + total_b, kid_upd_.data(), kid_upd_.size() * sizeof(uint32_t));
+    if (desc_b) std::memcpy(h_vstage_.p + total_b + upd_b, desc_req_, desc_b);     // the scan descriptors ride along
+    HIPCHK(d_cstage_.reserve(total_b + upd_b + desc_b - ops_off));
+  } else {
+    HIPCHK(d_vstage_.reserve(total_b));            // (may move: the whole topology is uploaded again below)
+    std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
+  }
   NvOp *hops = reinterpret_cast<NvOp *>(h_vstage_.p + ops_off);
   int32_t *lo = reinterpret_cast<int32_t *>(h_vstage_.p + lev_off_b);   // lo[0..maxlev]: offsets of levels 1..maxlev
   if (chains) {
@@ -595,17 +612,23 @@ int Engine::schedule_views(const std::vector<int> *roots)
     for (int l = 1; l <= maxlev; l++) lo[l - 1] = lo[l];
     lo[maxlev] = (int32_t)nops;
   }
-  if (kids_dirty_ || nops) {
+  if (direct) {
+    // one small upload (ops, offsets, topology deltas, scan descriptors); the topology array itself stays where it is
+    HIPCHK(hipMemcpyAsync(d_cstage_.p, h_vstage_.p + ops_off, total_b + upd_b + desc_b - ops_off, hipMemcpyHostToDevice, st_));
+    if (full) kids_dirty_ = false;
+  } else if (kids_dirty_ || nops) {
     const size_t up = nops ? total_b : kids_bytes;
     HIPCHK(hipMemcpyAsync(d_vstage_.p, h_vstage_.p, up, hipMemcpyHostToDevice, st_));
+    kids_dev_ready_ = true;
     if (full) kids_dirty_ = false;
   }
   if (nops == 0) {
     if (full) { n_invalid_ = 0; views_valid_ = true; }
     return MPF_OK;
   }
-  const NvOp *dops = reinterpret_cast<const NvOp *>(d_vstage_.p + ops_off);
-  const int32_t *dlo = reinterpret_cast<const int32_t *>(d_vstage_.p + lev_off_b);
+  const uint8_t *src = direct ? d_cstage_.p - ops_off : d_vstage_.p;      // (same offsets in both layouts)
+  const NvOp *dops = reinterpret_cast<const NvOp *>(src + ops_off);
+  const int32_t *dlo = reinterpret_cast<const int32_t *>(src + lev_off_b);
   const int tiles = tiles_for(g_);
   HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
   if (timing_) HIPCHK(hipEventRecord(ev2_, st_));
@@ -613,7 +636,18 @@ int Engine::schedule_views(const std::vector<int> *roots)
   // chip-wide launch when there are many (one workgroup would need longer than the launch costs)
   const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;
   if (chains) {
-    HIPCHK(launch_newview_chains(st_, g_, d_vec_, dops, dlo, ch_levels_, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr));
+    RefreshExtra x;
+    if (direct) {
+      x.kid_upd = reinterpret_cast<const uint32_t *>(src + total_b);
+      descs_dev_ = desc_b ? reinterpret_cast<const WalkDesc *>(src + total_b + upd_b) : nullptr;
+      x.n_kid_upd = (int)(kid_upd_.size() / 3);
+      x.kids = reinterpret_cast<uint2 *>(d_vstage_.p);
+      x.zero_ptr = zero_req_ptr_;                 // the outputs of the scan that follows (scan_batch), cleared here
+      x.zero_words = (uint32_t)zero_req_words_;
+      zeroed_ptr_ = zero_req_ptr_;
+      zeroed_words_ = zero_req_words_;
+    }
+    HIPCHK(launch_newview_chains(st_, g_, d_vec_, dops, dlo, ch_levels_, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr, x));
     stats.view_launches++;
   } else if (views_mode_ >= 1) {
     HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr));
@@ -978,8 +1012,15 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(d_ncand_.reserve(nd));
     HIPCHK(h_ncand_.reserve(nd));
     HIPCHK(reserve_results(nout));
-    HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_));
-    HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
+    // a small batch's descriptors went up with the refresh's own upload and its outputs were cleared by the refresh
+    // kernel: no second copy and no memset dispatch on the critical path of a climb's batches
+    const WalkDesc *descs = descs_dev_;
+    descs_dev_ = nullptr;
+    if (!descs) { HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_)); descs = d_walk_.p; }
+    if (!(zeroed_ptr_ == d_out() && zeroed_words_ >= clear_words(nout)))
+      HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
+    zeroed_ptr_ = nullptr;
+    zeroed_words_ = 0;
     if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
     uint32_t *mask_ptr = nullptr;
     uint2 *info_ptr = nullptr;
@@ -990,7 +1031,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       info_ptr = ufb_->info.p;
       ufb_rows_ = (uint32_t)nout;
     }
-    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, d_walk_.p, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr));
+    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr));
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
     if (cnt_copy_pending_) {
@@ -1040,15 +1081,34 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
   int mt = std::min(maxtrav, ntips_ - 3);
   const bool walk = scan_mode_ == 1 && mt <= 8 && !sankoff_;
   plans.resize((size_t)count);
+  if (walk && !views_valid_ && count < n_ / 2) {
+    // small batch (the inside of a climb): plan first -- planning needs the topology only -- so that the refresh launch
+    // can clear the scan's outputs, then refresh just the vectors these scans read
+    {
+      ScopedMs timer(stats.host_plan_ms_total);
+      for (int i = 0; i < count; i++) {
+        int rc = plan_walk(recs[i], mintrav, maxtrav, plans[(size_t)i], count <= split_below_);
+        if (rc) return rc;
+      }
+    }
+    HIPCHK(reserve_results(walk_out_));
+    zero_req_ptr_ = d_out();
+    zero_req_words_ = clear_words(walk_out_);
+    desc_req_ = h_walk_.p;
+    desc_req_n_ = n_walk_;
+    sb_roots_.clear();
+    for (int i = 0; i < count; i++) collect_scan_roots(recs[i], mintrav, maxtrav, sb_roots_);
+    int rc = schedule_views(&sb_roots_);
+    zero_req_ptr_ = nullptr;
+    zero_req_words_ = 0;
+    desc_req_ = nullptr;
+    desc_req_n_ = 0;
+    if (rc) return rc;
+    return run_walks(plans, out);
+  }
   if (!views_valid_) {
     if (!walk) { int rc = update_views(); if (rc) return rc; }      // host-planned programs need the scores first
-    else if (count >= n_ / 2) { int rc = schedule_views(nullptr); if (rc) return rc; }
-    else {
-      std::vector<int> roots;
-      for (int i = 0; i < count; i++) collect_scan_roots(recs[i], mintrav, maxtrav, roots);
-      int rc = schedule_views(&roots);
-      if (rc) return rc;
-    }
+    else { int rc = schedule_views(nullptr); if (rc) return rc; }
   }
   {
     ScopedMs timer(stats.host_plan_ms_total);

@@ -327,6 +327,17 @@ class Engine {
   std::vector<int32_t> ch_off_;
   std::vector<ChainOp> ch_ops_;
   int ch_levels_ = 0;
+  // small refreshes upload only ops, offsets, topology DELTAS and the following scan's descriptors (d_cstage_); the device
+  // copy of the topology (d_vstage_) must have been uploaded whole once before
+  bool kids_dev_ready_ = false;
+  DevBuf<uint8_t> d_cstage_;
+  const WalkDesc *desc_req_ = nullptr;          // descriptors scan_batch wants uploaded with the refresh
+  size_t desc_req_n_ = 0;
+  const WalkDesc *descs_dev_ = nullptr;         // ... and where they are on the device, if the refresh took them
+  std::vector<uint32_t> kid_upd_;
+  std::vector<int> sb_roots_;
+  uint32_t *zero_req_ptr_ = nullptr, *zeroed_ptr_ = nullptr;   // scan outputs the refresh launch is asked to clear / has cleared
+  size_t zero_req_words_ = 0, zeroed_words_ = 0;
   uint64_t dbg_levels_ = 0;                     // MPF_VIEWS_PROFILE=1: levels summed over refreshes
   std::vector<uint2> kids_host_;
   DevBuf<WalkDesc> d_walk_;

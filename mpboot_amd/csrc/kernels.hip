@@ -371,7 +371,8 @@ template <int S, int VW, int RED, int D>
 __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
                                                         const int32_t *__restrict__ wl_off, int n_lev,
                                                         uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
-                                                        uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, int n_ops)
+                                                        uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, int n_ops,
+                                                        RefreshExtra x)
 {
   __shared__ int s_last;
   const int lane = threadIdx.x & 63;
@@ -379,6 +380,13 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
   const int tile = blockIdx.x;
   bool valid;
   const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  {
+    // chores for the scan launch that follows on the stream, so that it needs neither a copy nor a memset dispatch in
+    // front of it: topology updates for the device-walked scan (this kernel does not read kids) and the cleared outputs
+    const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x), gn = (int)(gridDim.x * blockDim.x);
+    for (int i = gt; i < x.n_kid_upd; i += gn) x.kids[x.kid_upd[3 * i]] = make_uint2(x.kid_upd[3 * i + 1], x.kid_upd[3 * i + 2]);
+    for (uint32_t i = (uint32_t)gt; i < x.zero_words; i += (uint32_t)gn) x.zero_ptr[i] = 0u;
+  }
   for (int l = 0; l < n_lev; l++) {
     const int b = wl_off[l * 16 + wave], e = wl_off[l * 16 + wave + 1];
     if (b < e) {
@@ -1265,11 +1273,12 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 }
 
 hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *wl_off,
-                                 int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done)
+                                 int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done,
+                                 const RefreshExtra &x)
 {
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
-#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 8 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops)
+#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 8 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, x)
 #define NC2(S_, VW_, dummy) do { if (g.reduce == 0) NC(S_, VW_, 0); else NC(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NC2, 0);
 #undef NC2
