@@ -356,28 +356,29 @@ void Engine::invalidate_node(int node)
 // the whole table in one bottom-up sweep (a full-sweep plan asks for nearly every entry anyway)
 void Engine::fill_visit_counts(int maxm)
 {
+  // dense table for ONE m (plan_walk only ever asks for m = maxtrav), built with two rolling arrays that stay in L1
   const size_t nrec = back_.size();
-  for (int m = 2; m <= maxm; m++)
-    for (size_t q = 3; q < nrec; q++) {
+  vis_a_.assign(nrec, 1);
+  vis_dense_.assign(nrec, 1);
+  std::vector<int32_t> *prev = &vis_a_, *cur = &vis_dense_;
+  for (int m = 2; m <= maxm; m++) {
+    const int32_t *pa = prev->data();
+    int32_t *pc = cur->data();
+    for (size_t q = 3 * ((size_t)n_ + 1); q < nrec; q++) {        // tips keep 1
       if (back_[q] < 0) continue;
-      const size_t key = q * 16 + (size_t)m;
-      int v = 1;
-      if (!tip((int)q)) {
-        const int a = back_[nx((int)q)], b = back_[nx(nx((int)q))];
-        if (a >= 0 && b >= 0) {
-          const int va = (m - 1 <= 1 || tip(a)) ? 1 : nvis_val_[(size_t)a * 16 + (size_t)(m - 1)];
-          const int vb = (m - 1 <= 1 || tip(b)) ? 1 : nvis_val_[(size_t)b * 16 + (size_t)(m - 1)];
-          v = 1 + va + vb;
-        }
-      }
-      nvis_val_[key] = v;
-      nvis_epoch_[key] = topo_epoch_;
+      const int a = back_[nx((int)q)], b = back_[nx(nx((int)q))];
+      pc[q] = (a >= 0 && b >= 0) ? 1 + pa[a] + pa[b] : 1;
     }
+    std::swap(prev, cur);
+  }
+  if (prev != &vis_dense_) vis_dense_.swap(vis_a_);               // prev holds the last level written
+  vis_dense_m_ = maxm;
 }
 
 int Engine::count_visits(int q, int m)
 {
   if (m <= 1 || tip(q)) return 1;
+  if (m == vis_dense_m_ && visits_filled_epoch_ == topo_epoch_) return vis_dense_[(size_t)q];
   const size_t key = (size_t)q * 16 + (size_t)m;
   if (nvis_epoch_[key] == topo_epoch_) return nvis_val_[key];
   const int v = 1 + count_visits(back_[nx(q)], m - 1) + count_visits(back_[nx(nx(q))], m - 1);
@@ -1112,7 +1113,7 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
   }
   {
     ScopedMs timer(stats.host_plan_ms_total);
-    if (walk && count >= n_ / 2 && visits_filled_epoch_ != topo_epoch_) {
+    if (walk && count >= n_ / 2 && (visits_filled_epoch_ != topo_epoch_ || vis_dense_m_ != std::min(mt, 15))) {
       fill_visit_counts(std::min(mt, 15));
       visits_filled_epoch_ = topo_epoch_;
     }

@@ -354,6 +354,8 @@ class Engine {
   int count_visits(int q, int m);
   void fill_visit_counts(int maxm);
   int32_t visits_filled_epoch_ = 0;
+  std::vector<int32_t> vis_dense_, vis_a_;      // N(q, vis_dense_m_) for every record, valid while visits_filled_epoch_ == topo_epoch_
+  int vis_dense_m_ = -1;
   int check_counts_ = 0;                         // 1 = copy the kernel's own candidate counts back and compare
 
   // staging program being built
