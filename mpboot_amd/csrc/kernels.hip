@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
 //   JOIN  : out += sum_ptn w * min_s(m(vec[own])[s] + m(vec[sib])[s] + m(S)[s])
 // and out is the FULL length of the rearranged tree (there is no additive base in the weighted case).
 template <int S, int MAXD, bool PK>
-__global__ __launch_bounds__(256) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
+__global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
                                                   int n_scans, const ScanOp *__restrict__ ops,
                                                   const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
                                                   uint32_t *__restrict__ out, int We, int tiles)
