@@ -541,7 +541,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   // chained refresh for the incremental case (few ops, deep and narrow: paths away from an edit); a refresh of most of the
   // tree is wide, the level kernel's two-ops-in-flight loop suits it and cutting it into chains would cost the host more
   // than it saves the device
-  const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && nops <= 512;
+  const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && nops <= 512 && g_.S * g_.vw <= 8;   // (wider tiles would not fit four register sets)
   // ... and then the kernel reads its few KB of input (ops, offsets, topology updates) straight from the pinned staging
   // buffer: no copy dispatch in front of it
   const bool direct = chains && kids_dev_ready_ && roots->size() + nops <= 4096;

@@ -1278,7 +1278,7 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
 {
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
-#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 8 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, x)
+#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 4 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, x)
 #define NC2(S_, VW_, dummy) do { if (g.reduce == 0) NC(S_, VW_, 0); else NC(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NC2, 0);
 #undef NC2
