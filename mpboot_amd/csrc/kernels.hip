@@ -734,7 +734,10 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
   // what it wrote: no synchronisation, no bank conflicts).  Indexed by the wave-uniform depth -- in registers the same
   // indexing costs a cascade of compares and register copies per expansion.
   // (depth 1 stays in registers: it is touched once per side, and without its slot 8 workgroups fit a CU)
-  __shared__ uint32_t s_pend[4][MAXD - 2][S * VW][64];
+  // (protein tiles -- 10 states per wave half -- keep depth 2 in registers as well: with one LDS slot fewer a fourth
+  //  workgroup fits a CU)
+  constexpr int REGP = (S * VW >= 10) ? 2 : 1;
+  __shared__ uint32_t s_pend[4][MAXD - 1 - REGP][S * VW][64];
 
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
 
   // sv: pruned subtree; par: U of the node being expanded; pend[d]: U of the not-yet-expanded second
   // child at depth d (one per depth suffices: the first child is expanded immediately)
-  Tile<S, VW> sv, par, u1, u2, d1, d2, pend1;
+  Tile<S, VW> sv, par, u1, u2, d1, d2, pend1, pend2;
   MPF_LOAD(sv, de.s_cid);
   uint32_t k = 0;                              // candidates emitted so far (scan-local index)
   uint32_t acc0 = 0;
@@ -876,11 +879,12 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
       }
       if (deeper && c2 >= n) {             // dd in [1, MAXD - 1]
         if (dd == 1u) pend1 = u2;
+        else if (REGP == 2 && dd == 2u) pend2 = u2;
         else {
 #pragma unroll
           for (int kk = 0; kk < S; kk++)
 #pragma unroll
-            for (int j = 0; j < VW; j++) s_pend[wib][dd - 2][kk * VW + j][lane] = u2.v[kk][j];
+            for (int j = 0; j < VW; j++) s_pend[wib][dd - 1 - REGP][kk * VW + j][lane] = u2.v[kk][j];
         }
       }
       if (own2) { stk[sp] = make_uint2(c2 | (dd << 24), (tot >> 16) | (r2 << 16)); sp++; }
@@ -899,11 +903,12 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
         }
         if (dq < maxtrav && q >= n) {
           if (dq == 1u) par = pend1;
+          else if (REGP == 2 && dq == 2u) par = pend2;
           else {
 #pragma unroll
             for (int kk = 0; kk < S; kk++)
 #pragma unroll
-              for (int j = 0; j < VW; j++) par.v[kk][j] = s_pend[wib][dq - 2][kk * VW + j][lane];
+              for (int j = 0; j < VW; j++) par.v[kk][j] = s_pend[wib][dq - 1 - REGP][kk * VW + j][lane];
           }
           node = q; d = dq; more = true;
           break;
