@@ -317,6 +317,7 @@ void Engine::invalidate_all()
   n_invalid_ = -1;
   views_valid_ = false;
   kids_dirty_ = true;
+  kids_list_.clear();
   topo_epoch_++;
 }
 
@@ -347,7 +348,9 @@ void Engine::invalidate_node(int node)
     }
   }
   views_valid_ = false;
-  kids_dirty_ = true;
+  // the device copy of the topology (kids[]) changes exactly at the records of edited nodes; while it is complete
+  // (no wholesale invalidation pending) a refresh sends just these
+  if (!kids_dirty_) for (int s = 0; s < 3; s++) kids_list_.push_back(3 * node + s);
   topo_epoch_++;
 }
 
@@ -544,8 +547,18 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && nops <= 512 && g_.S * g_.vw <= 8;   // (wider tiles would not fit four register sets)
   // ... and then the kernel reads its few KB of input (ops, offsets, topology updates) straight from the pinned staging
   // buffer: no copy dispatch in front of it
-  const bool direct = chains && kids_dev_ready_ && roots->size() + nops <= 4096;
+  const bool direct = chains && kids_dev_ready_ && (kids_dirty_ ? roots->size() + nops : kids_list_.size()) <= 4096;
   kid_upd_.clear();
+  if (!kids_dirty_ && !kids_list_.empty()) {
+    for (int r : kids_list_) {
+      if (back_[r] < 0) continue;
+      const uint2 k = make_uint2(slot(back_[nx(r)]), slot(back_[nx(nx(r))]));
+      kids_host_[slot(r)] = k;
+      if (direct) { kid_upd_.push_back(slot(r)); kid_upd_.push_back(k.x); kid_upd_.push_back(k.y); }
+    }
+    kids_list_.clear();
+    kids_upload_ = !direct;                        // the mirror changed: a non-direct refresh uploads it whole
+  }
   if (kids_dirty_) {
     // topology for the device-walked scans: kids[cid] = the two records behind an inner record
     auto put = [&](int r) {
@@ -617,7 +630,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
     // one small upload (ops, offsets, topology deltas, scan descriptors); the topology array itself stays where it is
     HIPCHK(hipMemcpyAsync(d_cstage_.p, h_vstage_.p + ops_off, total_b + upd_b + desc_b - ops_off, hipMemcpyHostToDevice, st_));
     if (full) kids_dirty_ = false;
-  } else if (kids_dirty_ || nops) {
+  } else if (kids_dirty_ || kids_upload_ || nops) {
+    kids_upload_ = false;
     const size_t up = nops ? total_b : kids_bytes;
     HIPCHK(hipMemcpyAsync(d_vstage_.p, h_vstage_.p, up, hipMemcpyHostToDevice, st_));
     kids_dev_ready_ = true;
