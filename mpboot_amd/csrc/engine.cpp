@@ -580,14 +580,21 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const size_t n_off = chains ? ch_off_.size() : (size_t)maxlev + 2;
   const size_t total_b = lev_off_b + ((n_off * sizeof(int32_t) + 15) & ~(size_t)15);
   const size_t upd_b = (kid_upd_.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
-  const size_t desc_b = direct ? desc_req_n_ * sizeof(WalkDesc) : 0;
-  HIPCHK(h_vstage_.reserve(total_b + upd_b + desc_b));
+  // the following scan's input rides along (Fitch refresh kernels also clear its outputs); not without a launch
+  const bool can_ride = !sankoff_ && nops > 0 && views_mode_ >= 1;
+  size_t ride_off[2] = {0, 0}, tail = total_b + upd_b;
+  for (int i = 0; i < 2; i++) {
+    ride_[i].dev = nullptr;
+    if (can_ride && ride_[i].src && ride_[i].bytes) { ride_off[i] = tail; tail += (ride_[i].bytes + 15) & ~(size_t)15; }
+  }
+  HIPCHK(h_vstage_.reserve(tail));
+  for (int i = 0; i < 2; i++)
+    if (ride_off[i]) std::memcpy(h_vstage_.p + ride_off[i], ride_[i].src, ride_[i].bytes);
   if (direct) {
     if (!kid_upd_.empty()) std::memcpy(h_vstage_.p + total_b, kid_upd_.data(), kid_upd_.size() * sizeof(uint32_t));
-    if (desc_b) std::memcpy(h_vstage_.p + total_b + upd_b, desc_req_, desc_b);     // the scan descriptors ride along
-    HIPCHK(d_cstage_.reserve(total_b + upd_b + desc_b - ops_off));
+    HIPCHK(d_cstage_.reserve(tail - ops_off));
   } else {
-    HIPCHK(d_vstage_.reserve(total_b));            // (may move: the whole topology is uploaded again below)
+    HIPCHK(d_vstage_.reserve(tail));               // (may move: the whole topology is uploaded again below)
     std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
   }
   NvOp *hops = reinterpret_cast<NvOp *>(h_vstage_.p + ops_off);
@@ -628,11 +635,11 @@ int Engine::schedule_views(const std::vector<int> *roots)
   }
   if (direct) {
     // one small upload (ops, offsets, topology deltas, scan descriptors); the topology array itself stays where it is
-    HIPCHK(hipMemcpyAsync(d_cstage_.p, h_vstage_.p + ops_off, total_b + upd_b + desc_b - ops_off, hipMemcpyHostToDevice, st_));
+    HIPCHK(hipMemcpyAsync(d_cstage_.p, h_vstage_.p + ops_off, tail - ops_off, hipMemcpyHostToDevice, st_));
     if (full) kids_dirty_ = false;
   } else if (kids_dirty_ || kids_upload_ || nops) {
     kids_upload_ = false;
-    const size_t up = nops ? total_b : kids_bytes;
+    const size_t up = nops ? tail : kids_bytes;
     HIPCHK(hipMemcpyAsync(d_vstage_.p, h_vstage_.p, up, hipMemcpyHostToDevice, st_));
     kids_dev_ready_ = true;
     if (full) kids_dirty_ = false;
@@ -650,22 +657,25 @@ int Engine::schedule_views(const std::vector<int> *roots)
   // the per-tile mutation counts are folded by the refresh kernel's last workgroup when there are few ops, by a separate
   // chip-wide launch when there are many (one workgroup would need longer than the launch costs)
   const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;
+  RefreshExtra x;
+  for (int i = 0; i < 2; i++)
+    if (ride_off[i]) ride_[i].dev = src + ride_off[i];
+  if (can_ride && zero_req_ptr_) {
+    x.zero_ptr = zero_req_ptr_;                   // the outputs of the scan that follows, cleared by the refresh launch
+    x.zero_words = (uint32_t)zero_req_words_;
+    zeroed_ptr_ = zero_req_ptr_;
+    zeroed_words_ = zero_req_words_;
+  }
   if (chains) {
-    RefreshExtra x;
     if (direct) {
       x.kid_upd = reinterpret_cast<const uint32_t *>(src + total_b);
-      descs_dev_ = desc_b ? reinterpret_cast<const WalkDesc *>(src + total_b + upd_b) : nullptr;
       x.n_kid_upd = (int)(kid_upd_.size() / 3);
       x.kids = reinterpret_cast<uint2 *>(d_vstage_.p);
-      x.zero_ptr = zero_req_ptr_;                 // the outputs of the scan that follows (scan_batch), cleared here
-      x.zero_words = (uint32_t)zero_req_words_;
-      zeroed_ptr_ = zero_req_ptr_;
-      zeroed_words_ = zero_req_words_;
     }
     HIPCHK(launch_newview_chains(st_, g_, d_vec_, dops, dlo, ch_levels_, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr, x));
     stats.view_launches++;
   } else if (views_mode_ >= 1) {
-    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr));
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr, x));
     stats.view_launches++;
   } else {
     for (int l = 0; l < maxlev; l++) {
@@ -872,11 +882,22 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   HIPCHK(d_scanops_.reserve(nops));
   HIPCHK(d_scanhdr_.reserve(nh));
   HIPCHK(reserve_results(nout));
-  HIPCHK(hipMemcpyAsync(d_scanops_.p, prog_ops_.data(), nops * sizeof(ScanOp), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemcpyAsync(d_scanhdr_.p, prog_hdr_.data(), nh * sizeof(ScanHdr), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
+  // the program may have gone up with the refresh in front (addition_phase), which then cleared the outputs as well
+  const ScanOp *dprog = static_cast<const ScanOp *>(ride_[0].dev);
+  const ScanHdr *dhdr = static_cast<const ScanHdr *>(ride_[1].dev);
+  ride_[0].dev = ride_[1].dev = nullptr;
+  if (!dprog || !dhdr) {
+    HIPCHK(hipMemcpyAsync(d_scanops_.p, prog_ops_.data(), nops * sizeof(ScanOp), hipMemcpyHostToDevice, st_));
+    HIPCHK(hipMemcpyAsync(d_scanhdr_.p, prog_hdr_.data(), nh * sizeof(ScanHdr), hipMemcpyHostToDevice, st_));
+    dprog = d_scanops_.p;
+    dhdr = d_scanhdr_.p;
+  }
+  if (!(zeroed_ptr_ == d_out() && zeroed_words_ >= clear_words(nout)))
+    HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
+  zeroed_ptr_ = nullptr;
+  zeroed_words_ = 0;
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
-  HIPCHK(launch_scan(st_, g_, d_vec_, d_scanhdr_.p, (int)nh, d_scanops_.p, d_out(), prog_max_depth_));
+  HIPCHK(launch_scan(st_, g_, d_vec_, dhdr, (int)nh, dprog, d_out(), prog_max_depth_));
   if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
   if (cnt_copy_pending_) {     // a refresh was enqueued just before: bring its mutation counts back in the same copy
     HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (out_off() + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
@@ -1029,8 +1050,8 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     HIPCHK(reserve_results(nout));
     // a small batch's descriptors went up with the refresh's own upload and its outputs were cleared by the refresh
     // kernel: no second copy and no memset dispatch on the critical path of a climb's batches
-    const WalkDesc *descs = descs_dev_;
-    descs_dev_ = nullptr;
+    const WalkDesc *descs = static_cast<const WalkDesc *>(ride_[0].dev);
+    ride_[0].dev = nullptr;
     if (!descs) { HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_)); descs = d_walk_.p; }
     if (!(zeroed_ptr_ == d_out() && zeroed_words_ >= clear_words(nout)))
       HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
@@ -1109,15 +1130,14 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
     HIPCHK(reserve_results(walk_out_));
     zero_req_ptr_ = d_out();
     zero_req_words_ = clear_words(walk_out_);
-    desc_req_ = h_walk_.p;
-    desc_req_n_ = n_walk_;
+    ride_[0].src = h_walk_.p;
+    ride_[0].bytes = n_walk_ * sizeof(WalkDesc);
     sb_roots_.clear();
     for (int i = 0; i < count; i++) collect_scan_roots(recs[i], mintrav, maxtrav, sb_roots_);
     int rc = schedule_views(&sb_roots_);
     zero_req_ptr_ = nullptr;
     zero_req_words_ = 0;
-    desc_req_ = nullptr;
-    desc_req_n_ = 0;
+    ride_[0].src = nullptr;
     if (rc) return rc;
     return run_walks(plans, out);
   }

@@ -331,9 +331,10 @@ class Engine {
   // copy of the topology (d_vstage_) must have been uploaded whole once before
   bool kids_dev_ready_ = false;
   DevBuf<uint8_t> d_cstage_;
-  const WalkDesc *desc_req_ = nullptr;          // descriptors scan_batch wants uploaded with the refresh
-  size_t desc_req_n_ = 0;
-  const WalkDesc *descs_dev_ = nullptr;         // ... and where they are on the device, if the refresh took them
+  // input of the scan launch that follows a refresh (walk descriptors, or a scan program and its headers): appended to the
+  // refresh's own upload when one happens; dev = where it landed, nullptr if the scan has to upload it itself
+  struct Ride { const void *src = nullptr; size_t bytes = 0; const void *dev = nullptr; };
+  Ride ride_[2];
   std::vector<uint32_t> kid_upd_;
   std::vector<int> kids_list_;                  // records whose kids[] entry changed since the device copy was last complete
   bool kids_upload_ = false;

@@ -311,7 +311,8 @@ template <int S, int VW, int RED>
 __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
                                                      const int32_t *__restrict__ lev_off, int n_lev,
                                                      uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
-                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ done)
+                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ done,
+                                                     RefreshExtra x)
 {
   __shared__ int s_last;
   const int lane = threadIdx.x & 63;
@@ -320,6 +321,8 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
   const int tile = blockIdx.x;
   bool valid;
   const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  // clears the outputs of the scan launch that follows on the stream (no memset dispatch in front of it)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x.zero_words; i += gridDim.x * blockDim.x) x.zero_ptr[i] = 0u;
   for (int l = 0; l < n_lev; l++) {
     const int b = lev_off[l], e = lev_off[l + 1];
     int i = b + wave;
@@ -1257,7 +1260,7 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
 }
 
 hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
-                                 int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done)
+                                 int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done, const RefreshExtra &x)
 {
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
@@ -1269,7 +1272,7 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 #undef SNK
     return hipGetLastError();
   }
-#define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done)
+#define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
 #define NW2(S_, VW_, dummy) do { if (g.reduce == 0) NW(S_, VW_, 0); else NW(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NW2, 0);
 #undef NW2

@@ -58,16 +58,17 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
 // cntp[tile][slot]: per-tile mutation counts of the recomputed vectors, folded by launch_cntsum into cnt[slot]
 hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, int n_ops, uint32_t *cntp,
                           uint32_t nslots);
+// chores a refresh launch does for the scan launch behind it on the stream: kids[kid_upd[3i]] = (kid_upd[3i+1], kid_upd[3i+2])
+// (chained kernel only) and zero_ptr[0..zero_words) = 0
+struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint2 *kids = nullptr; uint32_t *zero_ptr = nullptr; uint32_t zero_words = 0; };
 // every level in ONE launch (one 16-wave workgroup per tile, workgroup barrier between levels)
 // Fitch mode also folds the per-tile counts into cnt[dst] (last workgroup; `done` = a zeroed device word, left zeroed);
 // weighted mode leaves that to launch_cntsum
 hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
-                                 int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done);
+                                 int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done,
+                                 const RefreshExtra &x = RefreshExtra());
 // the same refresh cut into chains (Fitch mode): ops laid out per (level, wave), wl_off[16 * n_lev + 1]; NvOp::a = 0xFFFFFFFF
 // takes the previous op's result from registers
-// extra work the chained refresh does for the scan launch behind it: kids[kid_upd[3i]] = (kid_upd[3i+1], kid_upd[3i+2]),
-// zero_ptr[0..zero_words) = 0.  ops / wl_off / kid_upd may live in pinned host memory (read once, a few KB)
-struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint2 *kids = nullptr; uint32_t *zero_ptr = nullptr; uint32_t zero_words = 0; };
 hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *wl_off,
                                  int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done,
                                  const RefreshExtra &x);

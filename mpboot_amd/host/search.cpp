@@ -172,11 +172,9 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     const int q = nodep_[nextnode_++];
     back_[p] = q;
     back_[q] = p;
-    // refresh the views of the tree built so far (asynchronously), score the insertion on EVERY branch in
-    // the same submission, and apply the reference's descent cut (:3014) afterwards on the host: one
-    // synchronisation per added taxon
-    int rc = schedule_views(nullptr);
-    if (rc) return rc;
+    // score the insertion on EVERY branch and apply the reference's descent cut (:3014) afterwards on the host: the scan
+    // program (topology only) is built first and goes up with the refresh of the views of the tree built so far, the
+    // refresh launch clears the program's outputs: one upload, two launches, one copy back, one synchronisation per taxon
     stack.clear();
     stack.push_back(back_[f]);
     while (!stack.empty()) {
@@ -204,6 +202,21 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
       h.pad = 0;
       prog_hdr_.push_back(h);
     }
+    {
+      hipError_t he = reserve_results(prog_out_);
+      if (he != hipSuccess) { set_error(std::string("HIP: ") + hipGetErrorString(he)); return MPF_E_HIP; }
+    }
+    ride_[0].src = prog_ops_.data();
+    ride_[0].bytes = prog_ops_.size() * sizeof(ScanOp);
+    ride_[1].src = prog_hdr_.data();
+    ride_[1].bytes = prog_hdr_.size() * sizeof(ScanHdr);
+    zero_req_ptr_ = d_out();
+    zero_req_words_ = clear_words(prog_out_);
+    int rc = schedule_views(nullptr);
+    ride_[0].src = ride_[1].src = nullptr;
+    zero_req_ptr_ = nullptr;
+    zero_req_words_ = 0;
+    if (rc) return rc;
     rc = run_scans(plans, out);
     if (rc) return rc;
     // candidate branches in the reference's DFS order with its descent cut
