@@ -254,7 +254,8 @@ int mpf_reset_stats(mpf_engine *e);
      "sankoff_short"   1 = two 16-bit costs per lane in the weighted kernels when no intermediate can overflow
                        (the reference's default arithmetic), 0 = always 32-bit (its -short_off)
      "check_counts"    1 = compare the kernel's candidate counts with the host's
-     "timing"          1 = HIP events around the kernels (mpf_stats *_kernel_ms_total) */
+     "timing"          1 = HIP events around the scan kernels (mpf_stats scan_kernel_ms_total), 2 = around the refresh
+                       kernels too (view_kernel_ms_total); an event pair costs about 10 us on the stream */
 int mpf_set_option(mpf_engine *e, const char *key, int64_t value);
 
 #ifdef __cplusplus

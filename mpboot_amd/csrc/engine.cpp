@@ -653,7 +653,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const int32_t *dlo = reinterpret_cast<const int32_t *>(src + lev_off_b);
   const int tiles = tiles_for(g_);
   HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
-  if (timing_) HIPCHK(hipEventRecord(ev2_, st_));
+  if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));
   // the per-tile mutation counts are folded by the refresh kernel's last workgroup when there are few ops, by a separate
   // chip-wide launch when there are many (one workgroup would need longer than the launch costs)
   const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;
@@ -685,7 +685,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   }
   if (!fold_inside)
     HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt()));
-  if (timing_) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
+  if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;
   if (full) { n_invalid_ = 0; views_valid_ = true; }
@@ -1308,7 +1308,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
-  if (key == "timing") { timing_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "timing") { timing_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "force_big") {                     // test hook: use the >= 2 GiB addressing path on any size
     force_big_ = v ? 1 : 0;
     if (!sankoff_) g_.big = (force_big_ || vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) ? 1 : 0;

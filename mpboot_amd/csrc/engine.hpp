@@ -267,7 +267,7 @@ class Engine {
   DevBuf<uint8_t> d_vstage_;
   PinBuf<uint8_t> h_vstage_;
   bool cnt_copy_pending_ = false;
-  int timing_ = 0;                               // 1 = bracket kernels with HIP events (bench / profiling)
+  int timing_ = 0;                               // HIP events around kernels: 1 = scan kernels, 2 = refresh kernels too (≈5 µs per event)
   // the candidate costs start on a 256-byte boundary and are cleared in whole 256-byte units: a memset of an
   // unaligned range is split by the runtime into up to three fill kernels (5 us each, per accepted move)
   size_t out_off() const { return (nslots_ + 63) & ~(size_t)63; }

@@ -40,7 +40,7 @@ e.seed_ties(engine.TIE_RANDOM, 1)
 t0 = time.perf_counter(); s0 = e.make_parsimony_tree(4242, 0); t1 = time.perf_counter()
 back = e.get_tree()
 print(f"randomized stepwise addition: length {s0} in {t1 - t0:.1f} s")
-e.set_option("timing", 1)
+e.set_option("timing", 2)
 e.set_tree(back); e.sweep_scan(1, 6); e.reset_stats()
 t0 = time.perf_counter(); e.set_tree(back); k, best = e.sweep_scan(1, 6); dt = time.perf_counter() - t0
 st = e.stats()

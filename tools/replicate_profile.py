@@ -8,7 +8,7 @@ B = 64
 samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
 e.ufboot_attach(samples); e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1); e.optimize_spr(1, 6)
 _l, _c, bt = e.ufboot_state(); trees = [e.ufboot_tree(int(t)) for t in bt]; e.ufboot_detach()
-e.set_option("timing", 1)
+e.set_option("timing", 2)
 for b in range(3):
     e.set_weights(samples[b].astype(np.int32)); e.seed_ties(1, 5 + b); e.reset_node_order(); e.set_tree(trees[b]); e.optimize_spr(1, 6)
 tw = tc = 0.0

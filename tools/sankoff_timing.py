@@ -22,7 +22,7 @@ n, P = codes.shape
 f = engine.FitchEngine(codes, datatype=dt)
 f.seed_ties(engine.TIE_RANDOM, 1); f.make_parsimony_tree(12345, 0); back = f.get_tree(); del f
 e = engine.FitchEngine(codes, datatype=dt, cost=cost)
-e.set_option("timing", 1)
+e.set_option("timing", 2)
 e.set_tree(back); s0 = e.score_tree()
 e.sweep_scan(1, 6)
 e.reset_stats()

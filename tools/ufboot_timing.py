@@ -34,7 +34,7 @@ else:
     s0 = e.score_tree(trees.random_topology(codes.shape[0], np.random.default_rng(a.seed)))
 back0 = e.get_tree()
 # plain climb for reference
-e.set_option("timing", 1)
+e.set_option("timing", 2)
 e.reset_stats()
 t0 = time.perf_counter(); s_plain = e.optimize_spr(1, 6); t1 = time.perf_counter()
 st_plain = e.stats()
