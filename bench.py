@@ -282,6 +282,10 @@ def main():
             if n_rep > 0:
                 engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
                                    for _ in range(max(0, args.engines_per_gpu - 1))]
+                for extra in engines[1:]:
+                    for kv in args.opt:
+                        k, v = kv.split("=")
+                        extra.set_option(k, int(v))
                 bootstrap.refine_boot_trees(engines, samples[:min(n_rep, 8 * world)], boot_trees[:min(n_rep, 8 * world)], 999, args.maxtrav)  # warm-up
                 barrier()
                 tb0 = time.perf_counter()
