@@ -544,7 +544,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   // chained refresh for the incremental case (few ops, deep and narrow: paths away from an edit); a refresh of most of the
   // tree is wide, the level kernel's two-ops-in-flight loop suits it and cutting it into chains would cost the host more
   // than it saves the device
-  const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && nops <= 512 && g_.S * g_.vw <= 8;   // (wider tiles would not fit four register sets)
+  const bool chains = views_mode_ == 2 && !sankoff_ && nops > 0 && (long)nops <= chain_max_ops_ && g_.S * g_.vw <= 8;   // (wider tiles would not fit four register sets)
   // ... and then the kernel reads its few KB of input (ops, offsets, topology updates) straight from the pinned staging
   // buffer: no copy dispatch in front of it
   const bool direct = chains && kids_dev_ready_ && (kids_dirty_ ? roots->size() + nops : kids_list_.size()) <= 4096;
@@ -651,12 +651,12 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const uint8_t *src = direct ? d_cstage_.p - ops_off : d_vstage_.p;      // (same offsets in both layouts)
   const NvOp *dops = reinterpret_cast<const NvOp *>(src + ops_off);
   const int32_t *dlo = reinterpret_cast<const int32_t *>(src + lev_off_b);
-  const int tiles = tiles_for(g_);
+  const int tiles = std::max(tiles_for(g_), tiles_for_levels(g_));
   HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
   if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));
   // the per-tile mutation counts are folded by the refresh kernel's last workgroup when there are few ops, by a separate
   // chip-wide launch when there are many (one workgroup would need longer than the launch costs)
-  const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;
+  const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;   // (independent of chain_max_ops_)
   RefreshExtra x;
   for (int i = 0; i < 2; i++)
     if (ride_off[i]) ride_[i].dev = src + ride_off[i];
@@ -684,7 +684,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     }
   }
   if (!fold_inside)
-    HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt()));
+    HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), views_mode_ >= 1 ? tiles_for_levels(g_) : 0));
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;
@@ -1308,6 +1308,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "chain_max_ops") { chain_max_ops_ = v < 0 ? 0 : (long)v; return MPF_OK; }
   if (key == "timing") { timing_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "force_big") {                     // test hook: use the >= 2 GiB addressing path on any size
     force_big_ = v ? 1 : 0;

@@ -327,6 +327,7 @@ class Engine {
   std::vector<int32_t> ch_off_;
   std::vector<ChainOp> ch_ops_;
   int ch_levels_ = 0;
+  long chain_max_ops_ = 512;                    // refreshes with more ops use the level kernel
   // small refreshes upload only ops, offsets, topology DELTAS and the following scan's descriptors (d_cstage_); the device
   // copy of the topology (d_vstage_) must have been uploaded whole once before
   bool kids_dev_ready_ = false;

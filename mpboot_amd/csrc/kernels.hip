@@ -363,6 +363,53 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
   }
 }
 
+// The same with HALF a wave per op (one word per lane tiles only): a tile is 32 words, lanes 0-31 work on one op of the
+// level and lanes 32-63 on another.  Twice as many workgroups -- a refresh of most of the tree keeps only Wp/64 (25 at
+// C3) of the 256 CUs busy otherwise -- and half as many rounds per level.
+template <int S, int RED>
+__global__ __launch_bounds__(1024) void k_newview_wgh(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+                                                      const int32_t *__restrict__ lev_off, int n_lev,
+                                                      uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
+                                                      uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, RefreshExtra x)
+{
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = (int)(blockDim.x >> 6);
+  const int tile = blockIdx.x;
+  const int half = lane >> 5;
+  const int w0 = tile * 32 + (lane & 31);          // Wp is a multiple of 32: always inside the row
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x.zero_words; i += gridDim.x * blockDim.x) x.zero_ptr[i] = 0u;
+  for (int l = 0; l < n_lev; l++) {
+    const int b = lev_off[l], e = lev_off[l + 1];
+    for (int ib = b + 2 * wave; ib < e; ib += 2 * nw) {
+      const bool active = ib + half < e;
+      const NvOp o = ops[active ? ib + half : ib];
+      Tile<S, 1> ta, tb, tc;
+      load_tile<S, 1>(ta, vec, o.a, Wp, w0);
+      load_tile<S, 1>(tb, vec, o.b, Wp, w0);
+      uint32_t k = fitch<S, 1>(tc, ta, tb);
+      if (active) store_tile<S, 1>(tc, vec, o.dst, Wp, w0);
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) k += (uint32_t)__shfl_xor((int)k, m, 32);
+      if ((lane & 31) == 0 && active) cntp[(size_t)tile * nslots + o.dst] = k;
+    }
+    __syncthreads();
+  }
+  if (!done) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Chained refresh.  After a topology edit the stale vectors form out-trees fanning away from the edited nodes: nearly
 // every stale vector has ONE stale input (the one from the edit's side) and one valid input.  The level-synchronous kernel
 // above pays a store -> barrier -> load round trip for every link of such a path; here the host cuts the dependency graph
@@ -1272,6 +1319,12 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 #undef SNK
     return hipGetLastError();
   }
+  if (g.vw == 1) {                                 // half a wave per op on 32-word tiles
+    dim3 hgrid((unsigned)(g.Wp / 32));
+    if (g.S == 4) hipLaunchKernelGGL((k_newview_wgh<4, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
+    else hipLaunchKernelGGL((k_newview_wgh<20, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
+    return hipGetLastError();
+  }
 #define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
 #define NW2(S_, VW_, dummy) do { if (g.reduce == 0) NW(S_, VW_, 0); else NW(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NW2, 0);
@@ -1294,11 +1347,14 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
   return hipGetLastError();
 }
 
+int tiles_for_levels(const Geometry &g) { return (!g.sankoff && g.vw == 1) ? g.Wp / 32 : tiles_for(g); }
+
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
-                         uint32_t nslots, uint32_t *cnt)
+                         uint32_t nslots, uint32_t *cnt, int tiles)
 {
   if (n_ops <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 7) / 8), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles_for(g), cnt);
+  if (tiles <= 0) tiles = tiles_for(g);
+  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 7) / 8), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles, cnt);
   return hipGetLastError();
 }
 
