@@ -60,16 +60,28 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
         // testInsertParsimony's bookkeeping (reference :2168-2176 / fastDNAparsimony.c:1224-1229);
         // the chosen candidate is remembered by index and only named (record q) if the move is applied
         long sel = -1;
-        const size_t nc = (size_t)pl.n_total;
-        for (size_t c = 0; c < nc; c++) {
-          const uint32_t mp = pl.base + pl.cost(c, out);
+        // a candidate worse than the best so far changes nothing (no counter, no draw): that is nearly all of them, so
+        // the loop runs over the parts' output blocks with that test first
+        auto offer = [&](uint32_t mp, long c) {
+          if (mp > best_) return;
           if (tie_mode_ == MPF_TIE_RANDOM) {
             if (mp < best_) hits_ = 1;
-            else if (mp == best_) hits_++;
-            if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; sel = (long)c; }
+            else hits_++;
+            if (mp < best_ || tie_draw() <= 1.0 / (double)hits_) { best_ = mp; sel = c; }
           } else if (mp < best_) {
-            best_ = mp; sel = (long)c;
+            best_ = mp; sel = c;
           }
+        };
+        if (pl.walked) {
+          long c = 0;
+          for (int part = 0; part < pl.n_parts; part++) {
+            const uint32_t *o = out + pl.part_off[part];
+            const int cnt = pl.part_cnt[part];
+            for (int k = 0; k < cnt; k++, c++) offer(pl.base + o[k], c);
+          }
+        } else {
+          const size_t nc = (size_t)pl.n_total;
+          for (size_t c = 0; c < nc; c++) offer(pl.base + pl.cost(c, out), (long)c);
         }
         if (sel >= 0) {
           insert_rec_ = candidate_record(pl, (size_t)sel);
