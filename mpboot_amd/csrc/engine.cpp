@@ -582,6 +582,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
   const size_t upd_b = (kid_upd_.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
   // the following scan's input rides along (Fitch refresh kernels also clear its outputs); not without a launch
   const bool can_ride = !sankoff_ && nops > 0 && views_mode_ >= 1;
+  zeroed_ptr_ = nullptr;                           // (a promise from an earlier refresh that nobody collected is void)
+  zeroed_words_ = 0;
   size_t ride_off[2] = {0, 0}, tail = total_b + upd_b;
   for (int i = 0; i < 2; i++) {
     ride_[i].dev = nullptr;
