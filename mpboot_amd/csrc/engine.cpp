@@ -318,6 +318,7 @@ void Engine::invalidate_all()
   views_valid_ = false;
   kids_dirty_ = true;
   kids_list_.clear();
+  all_invalid_ = true;
   topo_epoch_++;
 }
 
@@ -500,11 +501,15 @@ int Engine::schedule_views(const std::vector<int> *roots)
     seen.assign(2 * (size_t)n_ + 1, 0);
     stack.push_back(back_[start_]);
     while (!stack.empty()) {
-      const int r = stack.back();
+      const int r = stack.back();                  // the record by which the node is entered: it faces the root (start_)
       stack.pop_back();
       if (r < 0 || tip(r) || seen[num(r)]) continue;
       seen[num(r)] = 1;
-      for (int s = 0; s < 3; s++) { all.push_back(3 * num(r) + s); stack.push_back(back_[3 * num(r) + s]); }
+      all.push_back(r);
+      all.push_back(nx(r));
+      all.push_back(nx(nx(r)));
+      stack.push_back(back_[nx(nx(r))]);
+      stack.push_back(back_[nx(r)]);
     }
     roots = &all;
   }
@@ -515,7 +520,32 @@ int Engine::schedule_views(const std::vector<int> *roots)
   order.clear();
   stack.clear();
   auto lev_of = [&](int r) { return (tip(r) || lev_epoch_[r] != epoch_) ? 0 : lev_[r]; };
+  const bool from_scratch = roots == &all && all_invalid_;
+  if (from_scratch) {
+    // nothing is valid (new topology): two sweeps over the tree rooted at start_ instead of the generic closure.
+    // `all` lists the nodes in preorder, three records each, the first one facing the root.
+    // views looking away from the root, children first: level = height
+    for (size_t i = all.size(); i >= 3; i -= 3) {
+      const int u = all[i - 3];
+      const int a = back_[nx(u)], b = back_[nx(nx(u))];
+      lev_[u] = 1 + std::max(tip(a) ? 0 : lev_[a], tip(b) ? 0 : lev_[b]);
+      lev_epoch_[u] = epoch_;
+      order.push_back(u);
+    }
+    // views looking towards the root, parents first: inputs are the parent's view towards us and the sibling's subtree
+    for (size_t i = 0; i < all.size(); i += 3) {
+      const int u = all[i], r1 = nx(u), r2 = nx(r1);
+      const int p = back_[u], c1 = back_[r1], c2 = back_[r2];
+      const int lp = tip(p) ? 0 : lev_[p];
+      lev_[r1] = 1 + std::max(lp, tip(c2) ? 0 : lev_[c2]);
+      lev_[r2] = 1 + std::max(lp, tip(c1) ? 0 : lev_[c1]);
+      lev_epoch_[r1] = lev_epoch_[r2] = epoch_;
+      order.push_back(r1);
+      order.push_back(r2);
+    }
+  }
   for (int r0 : *roots) {
+    if (from_scratch) break;
     if (r0 < 0 || tip(r0) || valid_[r0] || lev_epoch_[r0] == epoch_) continue;
     stack.emplace_back(r0, 0);
     while (!stack.empty()) {
@@ -568,7 +598,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
     };
     for (int r : *roots)
       if (r >= 0 && !tip(r)) put(r);
-    for (int r : order) put(r);
+    if (!full)                                     // (a full refresh's roots contain every op)
+      for (int r : order) put(r);
   }
   int maxlev = 0;
   for (int r : order) maxlev = std::max(maxlev, lev_[r]);
@@ -690,6 +721,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;
+  all_invalid_ = false;
   if (full) { n_invalid_ = 0; views_valid_ = true; }
   else if (n_invalid_ > 0) {
     n_invalid_ -= (long)nops;
@@ -1004,14 +1036,17 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
     walk_out_ += (uint32_t)count + (scan_masks_ ? 1u : 0u);     // masked scans: one extra slot per part (home edge)
     n_walk_++;
   };
+  // N(q, maxtrav): straight from the sweep's dense table when it is current
+  const bool dense = maxtrav >= 2 && maxtrav == vis_dense_m_ && visits_filled_epoch_ == topo_epoch_;
+  auto cv = [&](int q) { return tip(q) ? 1 : dense ? vis_dense_[(size_t)q] : count_visits(q, maxtrav); };
   auto phase = [&](int x, int mt) {
     const int xs[2] = {back_[nx(x)], back_[nx(nx(x))]};
     const int skip = mt > 1 ? 1 : 0;                  // the q side does not test the first level (mintrav2 = 2)
     int cnt[2][2] = {{0, 0}, {0, 0}};
     for (int side = 0; side < 2; side++) {
       if (tip(xs[side])) continue;
-      cnt[side][0] = count_visits(back_[nx(xs[side])], maxtrav) - skip;
-      cnt[side][1] = count_visits(back_[nx(nx(xs[side]))], maxtrav) - skip;
+      cnt[side][0] = cv(back_[nx(xs[side])]) - skip;
+      cnt[side][1] = cv(back_[nx(nx(xs[side]))]) - skip;
     }
     if (!split) { add(x, mt, 3u, 3u, cnt[0][0] + cnt[0][1] + cnt[1][0] + cnt[1][1]); return; }
     for (uint32_t side = 0; side < 2; side++) {
