@@ -1,5 +1,6 @@
 // engine.cpp -- device state, tip packing, directional views and SPR-scan programs.
 #include "engine.hpp"
+#include "../host/simd_util.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -1242,7 +1243,7 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
       for (int i = 0; i < pl.n_parts; i++) {
         const uint32_t *o = out + pl.part_off[i];
         const int cnt = pl.part_cnt[i];
-        for (int c = 0; c < cnt; c++) m = std::min(m, o[c]);
+        if (cnt > 0) m = std::min(m, min_u32(o, cnt));
       }
       if (nc) best = std::min(best, pl.base + m);
     } else {

@@ -11,6 +11,7 @@
 #include <climits>
 
 #include "../csrc/engine.hpp"
+#include "simd_util.hpp"
 
 namespace mpf {
 
@@ -77,7 +78,9 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
           for (int part = 0; part < pl.n_parts; part++) {
             const uint32_t *o = out + pl.part_off[part];
             const int cnt = pl.part_cnt[part];
-            for (int k = 0; k < cnt; k++, c++) offer(pl.base + o[k], c);
+            // (only a candidate with cost <= best_ - base matters; best_ can only fall while the block is read)
+            for (int k = 0; best_ >= pl.base && (k = first_le(o, k, cnt, best_ - pl.base)) < cnt; k++) offer(pl.base + o[k], c + k);
+            c += cnt;
           }
         } else {
           const size_t nc = (size_t)pl.n_total;
