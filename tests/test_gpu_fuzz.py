@@ -134,3 +134,47 @@ def test_random_weighted_case_matches_oracle(seed):
     assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius)
     assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
     assert (e.get_tree() == o.get_tree()).all()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_medium_climb_matches_oracle(seed):
+    """Hill climbs on 60-260 taxa from a random tree: hundreds of small scan batches, i.e. the incremental machinery of a
+    climb (chained refresh over several chain levels, topology deltas, compact uploads, adaptive batch size) at a size where
+    paths are long; moves, scores and the final tree against the oracle, then the start tree builder on the same engine."""
+    from mpboot_amd import engine, synth, trees
+    from oracle import pyoracle as po
+
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(60, 261))
+    P = int(rng.integers(200, 801))
+    letters, _names = synth.synth_alignment(n, P, "DNA", float(rng.uniform(0.05, 0.25)), seed=100 + seed)
+    codes = synth.letters_to_codes(letters, "DNA")
+    w = rng.integers(1, 3, size=P).astype(np.int32)
+    back = trees.random_topology(n, rng)
+    tie = int(rng.integers(0, 2))
+    e = engine.FitchEngine(codes, w, datatype=engine.DNA)
+    o = po.Oracle(codes, w, datatype=po.DNA)
+    opts = [{}, {"scan_batch": 4}, {"scan_batch": 1, "check_counts": 1}, {"views_mode": 1, "scan_batch": 8},
+            {"words_per_lane": 2, "scan_batch": 2}, {"chain_max_ops": 0}, {"chain_max_ops": 100000, "scan_batch": 16},
+            {"split_below": 0, "scan_batch": 64}][seed % 8]
+    for k, v in opts.items():
+        e.set_option(k, v)
+    maxtrav = int(rng.integers(3, 8))
+    for x, mode in ((e, engine.TIE_RANDOM if tie else engine.TIE_FIRST), (o, po.TIE_RANDOM if tie else po.TIE_FIRST)):
+        x.seed_ties(mode, 3 + seed)
+        x.set_tree(back)
+    if not tie:
+        o.set_pre_evaluate(1)                  # MPF_TIE_FIRST = first-best rule on exactly scored candidates
+    o.trace(True)                              # (the oracle records its moves only while tracing)
+    se, so = e.optimize_spr(1, maxtrav), o.optimize_spr(1, maxtrav)
+    assert se == so
+    assert (e.get_tree() == o.get_tree()).all()
+    me, mo = e.moves(), o.get_moves()
+    assert [x.tolist() for x in me] == [np.asarray(x).tolist() for x in mo]
+    assert len(me[0]) > 10
+    # and the start-tree builder afterwards, on the engine that has just finished a climb (state carried over)
+    e.seed_ties(engine.TIE_RANDOM, seed)
+    o.seed_ties(po.TIE_RANDOM, seed)
+    se, so = e.make_parsimony_tree(50 + seed, 2), o.make_tree(50 + seed, 2)[0]
+    assert se == so
+    assert (e.get_tree() == o.get_tree()).all()
