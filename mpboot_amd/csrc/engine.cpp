@@ -692,6 +692,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
   // chip-wide launch when there are many (one workgroup would need longer than the launch costs)
   const bool fold_inside = views_mode_ >= 1 && !sankoff_ && nops <= 512;   // (independent of chain_max_ops_)
   RefreshExtra x;
+  cnt_on_host_ = false;
+  if (fold_inside && want_host_results_) { x.cnt_host = h_cnt(); cnt_on_host_ = true; }   // small batch: counts land in the host mirror
   for (int i = 0; i < 2; i++)
     if (ride_off[i]) ride_[i].dev = src + ride_off[i];
   if (can_ride && zero_req_ptr_) {
@@ -1105,10 +1107,16 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       info_ptr = ufb_->info.p;
       ufb_rows_ = (uint32_t)nout;
     }
-    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr));
+    // small batch: the kernels write the host's copies themselves (mutation counts: the refresh's fold; candidate costs:
+    // the scan's last workgroup) -- no copy-back dispatch
+    const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && (cnt_on_host_ || !cnt_copy_pending_);
+    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr,
+                            host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8));
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
-    if (cnt_copy_pending_) {
+    if (host_direct) {
+      cnt_copy_pending_ = false;
+    } else if (cnt_copy_pending_) {
       HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (out_off() + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
       cnt_copy_pending_ = false;
     } else if (nout) {
@@ -1170,14 +1178,17 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
     zero_req_words_ = clear_words(walk_out_);
     ride_[0].src = h_walk_.p;
     ride_[0].bytes = n_walk_ * sizeof(WalkDesc);
+    want_host_results_ = true;
     sb_roots_.clear();
     for (int i = 0; i < count; i++) collect_scan_roots(recs[i], mintrav, maxtrav, sb_roots_);
     int rc = schedule_views(&sb_roots_);
     zero_req_ptr_ = nullptr;
     zero_req_words_ = 0;
     ride_[0].src = nullptr;
-    if (rc) return rc;
-    return run_walks(plans, out);
+    if (!rc) rc = run_walks(plans, out);
+    want_host_results_ = false;
+    cnt_on_host_ = false;
+    return rc;
   }
   if (!views_valid_) {
     if (!walk) { int rc = update_views(); if (rc) return rc; }      // host-planned programs need the scores first

@@ -339,6 +339,7 @@ class Engine {
   std::vector<uint32_t> kid_upd_;
   std::vector<int> kids_list_;                  // records whose kids[] entry changed since the device copy was last complete
   bool kids_upload_ = false;
+  bool want_host_results_ = false, cnt_on_host_ = false;   // small batches: kernels write the host's result buffers themselves
   bool all_invalid_ = true;                     // no vector has been valid since the last wholesale invalidation
   std::vector<int> sb_roots_;
   uint32_t *zero_req_ptr_ = nullptr, *zeroed_ptr_ = nullptr;   // scan outputs the refresh launch is asked to clear / has cleared

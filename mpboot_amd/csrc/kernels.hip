@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void k_newview(uint32_t *__restrict__ vec, con
 // cnt[dst] = sum over tiles of cntp[tile][dst] for the ops of a refresh: 32 lanes per op (one tile each, strided), two ops
 // per group in flight.  The partial counts were written by other workgroups (other XCDs): the caller has acquired them.
 __device__ __forceinline__ void fold_counts(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp,
-                                            uint32_t nslots, int tiles, uint32_t *__restrict__ cnt, int tid, int nthreads)
+                                            uint32_t nslots, int tiles, uint32_t *__restrict__ cnt, int tid, int nthreads,
+                                            uint32_t *__restrict__ cnt_host = nullptr)
 {
   const int l32 = tid & 31, grp = tid >> 5, ngrp = nthreads >> 5;
   for (int i = grp; i < n_ops; i += 2 * ngrp) {
@@ -297,6 +298,10 @@ __device__ __forceinline__ void fold_counts(const NvOp *__restrict__ ops, int n_
     if (l32 == 0) {
       cnt[d0] = s0;
       if (j != i) cnt[d1] = s1;
+      if (cnt_host) {                              // the host's copy directly (pinned memory): no copy-back dispatch
+        cnt_host[d0] = s0;
+        if (j != i) cnt_host[d1] = s1;
+      }
     }
   }
 }
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_newview_wg(uint32_t *__restrict__ vec,
   __syncthreads();
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x);
+    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(1024) void k_newview_wgh(uint32_t *__restrict__ vec
   __syncthreads();
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x);
+    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
   __syncthreads();
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    fold_counts(ops, n_ops, cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x);
+    fold_counts(ops, n_ops, cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -771,11 +776,11 @@ __device__ __forceinline__ void load_tile_g(Tile<S, VW> &t, const uint32_t *__re
 // k-th EMITTED candidate.  The part's last slot (index out_base + count) receives the join of the pruned subtree
 // onto its home edge, fitch(vec[xa], vec[xb]).
 // BIG: the vector store does not fit a raw buffer's 32-bit range: plain global loads from a 64-bit base per vector.
-template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false, bool BIG = false>
-__global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
-                                                   uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
-                                                   uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
-                                                   int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info)
+template <int S, int VW, int MAXD, int RED, bool SPLIT, bool MASKS, bool BIG>
+__device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
+                                               uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
+                                               uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
+                                               int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info)
 {
   constexpr int STK = MAXD + 2;
   constexpr bool LANEACC = MAXD <= 6;      // short walks: candidate costs gathered in a lane register, 64 per flush
@@ -972,6 +977,33 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
     if ((uint32_t)lane < (k & 63u) && acc0) atomic_add_u32(out + de.out_base + (k & ~63u) + (uint32_t)lane, acc0);
   }
   if (tile == 0 && lane == 0) ncand[scan] = k;
+}
+
+// host_out != nullptr (small batches): the workgroup that finishes last copies the n_out candidate costs to the host's
+// pinned buffer itself, so that the batch needs no copy-back dispatch behind the kernel (`done` = a zeroed device word,
+// left zeroed)
+template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false, bool BIG = false>
+__global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
+                                                   uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
+                                                   uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
+                                                   int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info,
+                                                   uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done)
+{
+  scan_walk_body<S, VW, MAXD, RED, SPLIT, MASKS, BIG>(vec, kids, n, desc, n_scans, out, ncand, Wp, tiles, map, masks, info);
+  if (!host_out) return;
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ================================================================ Sankoff (weighted parsimony) kernels
@@ -1429,7 +1461,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
 
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
-                            uint32_t *masks, uint2 *info)
+                            uint32_t *masks, uint2 *info, uint32_t *host_out, uint32_t n_out, uint32_t *done)
 {
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;   // 8: the per-depth LDS slots of the walk are sized for it
@@ -1445,10 +1477,10 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
   do {                                                                                                                                \
     if (masks)                                                                                                                        \
       hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, true, BIG_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa,    \
-                         desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                 \
+                         desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info, host_out, n_out, done);                           \
     else                                                                                                                              \
       hipLaunchKernelGGL((k_scan_walk<S_, VW_, MAXD_, RED_, SPLIT_, false, BIG_>), grid, block, 0, st, vec, kids, (uint32_t)n_taxa,   \
-                         desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info);                                                 \
+                         desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info, host_out, n_out, done);                           \
   } while (0)
 #define SW(S_, VW_, MAXD_, RED_, SPLIT_) SWB(S_, VW_, MAXD_, RED_, SPLIT_, false)
 #define SW2(S_, VW_, SPLIT_)                                                                                 \

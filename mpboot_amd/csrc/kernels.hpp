@@ -60,7 +60,8 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
                           uint32_t nslots);
 // chores a refresh launch does for the scan launch behind it on the stream: kids[kid_upd[3i]] = (kid_upd[3i+1], kid_upd[3i+2])
 // (chained kernel only) and zero_ptr[0..zero_words) = 0
-struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint2 *kids = nullptr; uint32_t *zero_ptr = nullptr; uint32_t zero_words = 0; };
+struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint2 *kids = nullptr; uint32_t *zero_ptr = nullptr; uint32_t zero_words = 0;
+                      uint32_t *cnt_host = nullptr; /* pinned host mirror of cnt[]: written by the in-kernel fold */ };
 // every level in ONE launch (one 16-wave workgroup per tile, workgroup barrier between levels)
 // Fitch mode also folds the per-tile counts into cnt[dst] (last workgroup; `done` = a zeroed device word, left zeroed);
 // weighted mode leaves that to launch_cntsum
@@ -82,7 +83,9 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
                        const ScanOp *ops, uint32_t *out, int max_depth);
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
-                            uint32_t *masks = nullptr, uint2 *info = nullptr);   // masks != nullptr: UFBoot variant (ufboot.hip)
+                            uint32_t *masks = nullptr, uint2 *info = nullptr,   // masks != nullptr: UFBoot variant (ufboot.hip)
+                            // host_out != nullptr: the last workgroup copies out[0..n_out) to pinned host memory (done: zeroed word)
+                            uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr);
 // per-pattern Fitch lengths: ops = the (a, b) joins of a rooted traversal of the current tree; `planes` is
 // scratch of site_planes_words() words; ptn_out[p] = length of pattern p (0 where first_site[p] < 0)
 hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
