@@ -34,6 +34,7 @@ struct DevBuf {
   size_t cap = 0;
   ~DevBuf() { release(); }
   void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); }
   hipError_t reserve(size_t n)
   {
     if (n <= cap) return hipSuccess;
@@ -51,6 +52,7 @@ struct PinBuf {
   size_t cap = 0;
   ~PinBuf() { release(); }
   void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
+  void swap(PinBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); }
   hipError_t reserve(size_t n)
   {
     if (n <= cap) return hipSuccess;
@@ -229,6 +231,17 @@ class Engine {
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   // online UFBoot-MP
   std::unique_ptr<UfbState> ufb_;
+  // the tracker's large scratch buffers (candidate masks, product, events: ~1 GB at C3 x 1000 samples) outlive a detach, so
+  // that re-attaching (every search iteration re-uses the engine) does not allocate inside the next climb
+  struct UfbPool {
+    DevBuf<uint32_t> masks, jmasks, sel2;
+    DevBuf<uint2> info;
+    DevBuf<int32_t> C, C2;
+    DevBuf<UfbEvent> ev;
+    PinBuf<UfbEvent> h_ev;
+    PinBuf<uint2> h_info;
+  } ufb_pool_;
+  void ufb_pool_swap(UfbState &u);
   bool scan_masks_ = false;                      // the next scan_batch also writes candidate masks (k_scan_walk<MASKS>)
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);

@@ -83,6 +83,7 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   u->boot_counts.assign((size_t)n_all, 0);                   // :253
   u->boot_trees.assign((size_t)n_all, -1);                   // :252
   u->attach_wgt = wgt_;
+  ufb_pool_swap(*u);                               // scratch buffers of an earlier tracker, if any
   ufb_ = std::move(u);
   return MPF_OK;
 }
@@ -93,7 +94,21 @@ void Engine::ufboot_detach()
     std::fprintf(stderr, "[ufboot] batches %llu events %llu stored %llu | ms: scan %.1f prep %.1f device %.1f sort %.1f replay %.1f rt %.1f (product kernels %.1f)\n",
                  (unsigned long long)ufb_->batches, (unsigned long long)ufb_->events, (unsigned long long)ufb_->stored, ufb_->t_scan,
                  ufb_->t_prep, ufb_->t_dev, ufb_->t_sort, ufb_->t_replay, ufb_->t_rt, ufb_->gemm_ms);
+  if (ufb_) ufb_pool_swap(*ufb_);                  // keep the large scratch buffers for the next attach
   ufb_.reset();
+}
+
+void Engine::ufb_pool_swap(UfbState &u)
+{
+  u.masks.swap(ufb_pool_.masks);
+  u.jmasks.swap(ufb_pool_.jmasks);
+  u.sel2.swap(ufb_pool_.sel2);
+  u.info.swap(ufb_pool_.info);
+  u.C.swap(ufb_pool_.C);
+  u.C2.swap(ufb_pool_.C2);
+  u.ev.swap(ufb_pool_.ev);
+  u.h_ev.swap(ufb_pool_.h_ev);
+  u.h_info.swap(ufb_pool_.h_info);
 }
 
 int Engine::ufboot_set_cutoff(double logl_cutoff)
