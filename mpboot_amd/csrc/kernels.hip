@@ -220,12 +220,23 @@ __global__ __launch_bounds__(256) void k_pack_tips(uint32_t *__restrict__ vec, c
   for (int k = 0; k < S; k++) val[k] = 0;
   const uint8_t *row = codes + (size_t)tip * n_patterns;
   const int site0 = tile * 64 * 32;
+  // the two dependent gathers (site -> pattern -> code) of all 32 rounds are issued together: the kernel is bound by their
+  // latency, not by the ballots
+  int ptn[32];
+  uint8_t code[32];
+#pragma unroll
   for (int c = 0; c < 32; c++) {
     const int site = site0 + 64 * c + lane;
+    ptn[c] = site < n_sites ? site2ptn[site] : -1;
+  }
+#pragma unroll
+  for (int c = 0; c < 32; c++) code[c] = ptn[c] >= 0 ? row[ptn[c]] : (uint8_t)0;
+#pragma unroll
+  for (int c = 0; c < 32; c++) {
     // expanded sites beyond the alignment are all-ones in every state row so that they
     // never count (reference sprparsimony.cpp:2947-2960)
     uint32_t m = 0xFFFFFFFFu;
-    if (site < n_sites) m = state_mask(datatype, row[site2ptn[site]]);
+    if (ptn[c] >= 0) m = state_mask(datatype, code[c]);
 #pragma unroll
     for (int k = 0; k < S; k++) {
       const unsigned long long bal = __ballot((int)((m >> k) & 1u));
