@@ -720,7 +720,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
     }
   }
   if (!fold_inside)
-    HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), views_mode_ >= 1 ? tiles_for_levels(g_) : 0));
+    HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(),
+                         (views_mode_ >= 1 && !chains) ? tiles_for_levels(g_) : 0));   // rows of cntp the refresh kernel wrote
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   for (int r : order) valid_[r] = 1;

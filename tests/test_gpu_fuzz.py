@@ -136,7 +136,7 @@ def test_random_weighted_case_matches_oracle(seed):
     assert (e.get_tree() == o.get_tree()).all()
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", list(range(48)) + [198])   # 198: a chained refresh too large for the in-kernel count fold
 def test_medium_climb_matches_oracle(seed):
     """Hill climbs on 60-260 taxa from a random tree: hundreds of small scan batches, i.e. the incremental machinery of a
     climb (chained refresh over several chain levels, topology deltas, compact uploads, adaptive batch size) at a size where
