@@ -720,6 +720,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     }
   }
   if (!fold_inside)
+    // (no host mirror here: hundreds of scattered 4-byte writes over PCIe cost more than the one copy-back they would save)
     HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(),
                          (views_mode_ >= 1 && !chains) ? tiles_for_levels(g_) : 0));   // rows of cntp the refresh kernel wrote
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
@@ -935,9 +936,13 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   zeroed_ptr_ = nullptr;
   zeroed_words_ = 0;
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
-  HIPCHK(launch_scan(st_, g_, d_vec_, dhdr, (int)nh, dprog, d_out(), prog_max_depth_));
+  const bool host_direct = want_host_results_ && !sankoff_ && nout <= 16384 && (cnt_on_host_ || !cnt_copy_pending_);
+  HIPCHK(launch_scan(st_, g_, d_vec_, dhdr, (int)nh, dprog, d_out(), prog_max_depth_, host_direct ? h_out() : nullptr, (uint32_t)nout,
+                     d_done_.p + 16));
   if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
-  if (cnt_copy_pending_) {     // a refresh was enqueued just before: bring its mutation counts back in the same copy
+  if (host_direct) {           // the kernels wrote the host's result buffers themselves
+    cnt_copy_pending_ = false;
+  } else if (cnt_copy_pending_) {     // a refresh was enqueued just before: bring its mutation counts back in the same copy
     HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (out_off() + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
     cnt_copy_pending_ = false;
   } else {

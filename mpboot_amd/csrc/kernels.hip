@@ -522,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
 }
 
 __global__ __launch_bounds__(256) void k_cntsum(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp, uint32_t nslots,
-                                                int tiles, uint32_t *__restrict__ cnt)
+                                                int tiles, uint32_t *__restrict__ cnt, uint32_t *__restrict__ cnt_host)
 {
   const int l32 = threadIdx.x & 31;
   const int i = (int)(blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5));      // 32 lanes per op
@@ -532,7 +532,10 @@ __global__ __launch_bounds__(256) void k_cntsum(const NvOp *__restrict__ ops, in
   for (int t = l32; t < tiles; t += 32) s += cntp[(size_t)t * nslots + dst];
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m, 32);
-  if (l32 == 0) cnt[dst] = s;
+  if (l32 == 0) {
+    cnt[dst] = s;
+    if (cnt_host) cnt_host[dst] = s;
+  }
 }
 
 // ---------------------------------------------------------------- K2: batched evaluate
@@ -640,9 +643,9 @@ __global__ void k_pattern_sum(const uint32_t *__restrict__ planes, int n_chunks,
 // compile-time register name.  Per candidate the wave reads two vectors and writes none.
 
 template <int S, int VW, int MAXD, int RED>
-__global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
-                                              int n_scans, const ScanOp *__restrict__ ops, uint32_t *__restrict__ out,
-                                              int Wp, int tiles, int map)
+__device__ __forceinline__ void scan_body(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
+                                          int n_scans, const ScanOp *__restrict__ ops, uint32_t *__restrict__ out,
+                                          int Wp, int tiles, int map)
 {
   const int lane = threadIdx.x & 63;
   int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -706,6 +709,31 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, 
       const uint32_t tot = wave_total<RED>(cost);
       if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
     }
+  }
+}
+
+// host_out != nullptr (stepwise addition): the last workgroup copies the n_out costs to the host's pinned buffer, as in
+// k_scan_walk
+template <int S, int VW, int MAXD, int RED>
+__global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
+                                              int n_scans, const ScanOp *__restrict__ ops, uint32_t *__restrict__ out,
+                                              int Wp, int tiles, int map, uint32_t *__restrict__ host_out, uint32_t n_out,
+                                              uint32_t *__restrict__ done)
+{
+  scan_body<S, VW, MAXD, RED>(vec, hdr, n_scans, ops, out, Wp, tiles, map);
+  if (!host_out) return;
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1393,11 +1421,11 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
 int tiles_for_levels(const Geometry &g) { return (!g.sankoff && g.vw == 1) ? g.Wp / 32 : tiles_for(g); }
 
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
-                         uint32_t nslots, uint32_t *cnt, int tiles)
+                         uint32_t nslots, uint32_t *cnt, int tiles, uint32_t *cnt_host)
 {
   if (n_ops <= 0) return hipSuccess;
   if (tiles <= 0) tiles = tiles_for(g);
-  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 7) / 8), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles, cnt);
+  hipLaunchKernelGGL(k_cntsum, dim3((n_ops + 7) / 8), dim3(256), 0, st, ops, n_ops, cntp, nslots, tiles, cnt, cnt_host);
   return hipGetLastError();
 }
 
@@ -1427,7 +1455,7 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
 }
 
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
-                       const ScanOp *ops, uint32_t *out, int max_depth)
+                       const ScanOp *ops, uint32_t *out, int max_depth, uint32_t *host_out, uint32_t n_out, uint32_t *done)
 {
   if (n_scans <= 0) return hipSuccess;
   const int tiles = tiles_of(g);
@@ -1458,7 +1486,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
   }
   dim3 grid(nblocks);
 #define SC(S_, VW_, MAXD_, RED_) \
-  hipLaunchKernelGGL((k_scan<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, hdr, n_scans, ops, out, g.Wp, tiles, g.map)
+  hipLaunchKernelGGL((k_scan<S_, VW_, MAXD_, RED_>), grid, block, 0, st, vec, hdr, n_scans, ops, out, g.Wp, tiles, g.map, host_out, n_out, done)
 #define SC2(S_, VW_, dummy)                                                          \
   do {                                                                               \
     if (max_depth <= 6) { if (g.reduce == 0) SC(S_, VW_, 6, 0); else SC(S_, VW_, 6, 1); } \

@@ -74,13 +74,15 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
                                  int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done,
                                  const RefreshExtra &x);
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
-                         uint32_t nslots, uint32_t *cnt, int tiles = 0 /* 0 = tiles_for(g) */);
+                         uint32_t nslots, uint32_t *cnt, int tiles = 0 /* 0 = tiles_for(g) */,
+                         uint32_t *cnt_host = nullptr /* pinned host mirror of cnt[] */);
 int tiles_for(const Geometry &g);
 int tiles_for_levels(const Geometry &g);      // tiles (rows of cntp) launch_newview_levels uses: 32-word tiles for one word per lane
 hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
                            uint32_t *out);
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
-                       const ScanOp *ops, uint32_t *out, int max_depth);
+                       const ScanOp *ops, uint32_t *out, int max_depth,
+                       uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr);   // as launch_scan_walk
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
                             uint32_t *masks = nullptr, uint2 *info = nullptr,   // masks != nullptr: UFBoot variant (ufboot.hip)

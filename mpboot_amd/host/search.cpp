@@ -227,12 +227,14 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
     ride_[1].bytes = prog_hdr_.size() * sizeof(ScanHdr);
     zero_req_ptr_ = d_out();
     zero_req_words_ = clear_words(prog_out_);
+    want_host_results_ = true;                     // counts and join costs land in the host's buffers: no copy-back dispatch
     int rc = schedule_views(nullptr);
     ride_[0].src = ride_[1].src = nullptr;
     zero_req_ptr_ = nullptr;
     zero_req_words_ = 0;
-    if (rc) return rc;
-    rc = run_scans(plans, out);
+    if (!rc) rc = run_scans(plans, out);
+    want_host_results_ = false;
+    cnt_on_host_ = false;
     if (rc) return rc;
     // candidate branches in the reference's DFS order with its descent cut
     stack.clear();
