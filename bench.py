@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--bootstrap-replicates", type=int, default=1000,
                     help="samples of the online phase whose trees are refined afterwards (IQTree::optimizeBootTrees), "
                          "sharded over the GPUs; capped by --ufboot-samples (0 = skip)")
+    ap.add_argument("--legs-timeout", type=int, default=600,
+                    help="multi-GPU runs: seconds after which the headline line is printed without the secondary (-bb) legs")
     ap.add_argument("--engines-per-gpu", type=int, default=4, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
@@ -240,6 +242,91 @@ def main():
     view_ms = eng.stats()["view_kernel_ms_total"] / vsteps
     eng.set_option("timing", 1)
 
+    tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_all, tests_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_all, tests_all = dt, float(tests)
+
+    core_res = None
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+        if os.path.exists(tpath) and not args.opt:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload") == args.workload:
+                traffic = tj["bytes_per_launch"]          # from the committed rocprofv3 PMC passes, not live
+        evals_per_s = tests_all / dt_all
+        W = eng.W                                          # the reference's parsimonyLength
+        bytes_per_eval = 6 * eng.S * W * 4                 # SURVEY.md §8(d): 1 chain newview + 1 three-vector join-evaluate
+        launches = max(1, st["scan_launches"])
+        scan_ms = st["scan_kernel_ms_total"] / launches
+        evals_per_launch = st["insertion_tests"] / launches
+        achieved = evals_per_launch * bytes_per_eval / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        # what the kernel itself loads per eval: ONE vector (chain in registers, siblings expanded together)
+        compulsory = evals_per_launch * 1 * eng.S * eng.Wp * 4 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        res = {
+            "metric": "Fitch site-ops/sec (taxa x patterns x SPR-evals/s)",
+            "value": n * P * evals_per_s,
+            "unit": "site-ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_all / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
+                                   "one full sweep scan per step (all prune nodes, both sides)",
+                       "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
+                       "start_tree_score": start_score, "parallelism": f"independent start trees x{world}",
+                       # SURVEY 8(d): the three rates side by side.  value = effective (n x P x evals/s, as defined);
+                       # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
+                       # running up-vector with a sibling) + one join, plus the directional-vector refresh of the step
+                       "touched_site_ops_per_s": (2.0 * tests_all + st["newview_ops"] * world) * P / dt_all},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_scan_walk", "kernel_ms_per_launch": scan_ms,
+                         "algorithmic_bytes_per_eval": bytes_per_eval,
+                         "loaded_GBps": compulsory,
+                         "note": "achieved = SURVEY §8(d) algorithmic bytes (6 vectors per eval) / HIP-event kernel time; "
+                                 "the kernel itself loads 1 vector per eval (chain in registers, sibling pairs share loads) "
+                                 "= loaded_GBps, 93 % of it L2 hits under the XCD-aware mapping (traffic = bytes that left the "
+                                 "L2s per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1): frac > 1 means the kernel beats "
+                                 "the HBM roofline of the 6-vector formulation, not that HBM delivered more than its peak; the "
+                                 "kernel is bound by VALU issue + memory latency (DESIGN.md section 5)"},
+            "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": view_ms,
+                      "launches_per_step": st["view_launches"] / args.steps},
+            "host_ms_per_step": {"plan": st["host_plan_ms_total"] / args.steps, "views": st["host_views_ms_total"] / args.steps,
+                                 "scan": st["host_scan_ms_total"] / args.steps,
+                                 "sweep_call": st["host_sweep_ms_total"] / args.steps},
+        }
+        core_res = res
+
+    # The secondary legs below exchange data between the ranks.  Should one of them stall (a rank that failed skips a
+    # collective the others wait in), the headline line still goes out: after --legs-timeout seconds rank 0 prints it
+    # without the legs and every rank leaves.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            out = dict(core_res)
+            out["bootstrap_legs_error"] = "secondary legs did not finish within %d s" % args.legs_timeout
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.legs_timeout, give_up)
+    watchdog.daemon = True
+    if args.ufboot_samples > 0 and world > 1:
+        watchdog.start()
+
     # ---- second half of BASELINE.json's metric ("bootstrap wall-clock"): the -bb flow on this alignment.
     # (1) online phase: ONE search chain, sequential by nature: every rank makes the same pllOptimizeSprParsimony call from
     #     the same start tree with IQTree::saveCurrentTree's bookkeeping after every insertion test (candidate masks ->
@@ -303,71 +390,9 @@ def main():
             legs_error = repr(exc)
             ufb = boot = None
 
-    tt = torch.tensor([dt, float(tests)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_all, tests_all = float(tmax[0]), float(tsum[1])
-    else:
-        dt_all, tests_all = dt, float(tests)
-
+    watchdog.cancel()
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
-        if os.path.exists(tpath) and not args.opt:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload") == args.workload:
-                traffic = tj["bytes_per_launch"]          # from the committed rocprofv3 PMC passes, not live
-        evals_per_s = tests_all / dt_all
-        W = eng.W                                          # the reference's parsimonyLength
-        bytes_per_eval = 6 * eng.S * W * 4                 # SURVEY.md §8(d): 1 chain newview + 1 three-vector join-evaluate
-        launches = max(1, st["scan_launches"])
-        scan_ms = st["scan_kernel_ms_total"] / launches
-        evals_per_launch = st["insertion_tests"] / launches
-        achieved = evals_per_launch * bytes_per_eval / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        # what the kernel itself loads per eval: ONE vector (chain in registers, siblings expanded together)
-        compulsory = evals_per_launch * 1 * eng.S * eng.Wp * 4 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        res = {
-            "metric": "Fitch site-ops/sec (taxa x patterns x SPR-evals/s)",
-            "value": n * P * evals_per_s,
-            "unit": "site-ops/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt_all / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
-                                   "one full sweep scan per step (all prune nodes, both sides)",
-                       "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
-                       "start_tree_score": start_score, "parallelism": f"independent start trees x{world}",
-                       # SURVEY 8(d): the three rates side by side.  value = effective (n x P x evals/s, as defined);
-                       # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
-                       # running up-vector with a sibling) + one join, plus the directional-vector refresh of the step
-                       "touched_site_ops_per_s": (2.0 * tests_all + st["newview_ops"] * world) * P / dt_all},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_scan_walk", "kernel_ms_per_launch": scan_ms,
-                         "algorithmic_bytes_per_eval": bytes_per_eval,
-                         "loaded_GBps": compulsory,
-                         "note": "achieved = SURVEY §8(d) algorithmic bytes (6 vectors per eval) / HIP-event kernel time; "
-                                 "the kernel itself loads 1 vector per eval (chain in registers, sibling pairs share loads) "
-                                 "= loaded_GBps, 93 % of it L2 hits under the XCD-aware mapping (traffic = bytes that left the "
-                                 "L2s per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1): frac > 1 means the kernel beats "
-                                 "the HBM roofline of the 6-vector formulation, not that HBM delivered more than its peak; the "
-                                 "kernel is bound by VALU issue + memory latency (DESIGN.md section 5)"},
-            "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": view_ms,
-                      "launches_per_step": st["view_launches"] / args.steps},
-            "host_ms_per_step": {"plan": st["host_plan_ms_total"] / args.steps, "views": st["host_views_ms_total"] / args.steps,
-                                 "scan": st["host_scan_ms_total"] / args.steps,
-                                 "sweep_call": st["host_sweep_ms_total"] / args.steps},
-        }
+        res = core_res
         if legs_error is not None:
             res["bootstrap_legs_error"] = legs_error
         if boot is not None:
