@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--bootstrap-replicates", type=int, default=1000,
                     help="samples of the online phase whose trees are refined afterwards (IQTree::optimizeBootTrees), "
                          "sharded over the GPUs; capped by --ufboot-samples (0 = skip)")
-    ap.add_argument("--legs-timeout", type=int, default=600,
+    ap.add_argument("--legs-timeout", type=int, default=180,
                     help="multi-GPU runs: seconds after which the headline line is printed without the secondary (-bb) legs")
     ap.add_argument("--engines-per-gpu", type=int, default=4, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
