@@ -250,10 +250,13 @@ int mpf_reset_stats(mpf_engine *e);
      "scan_mode"       1 = device-walked SPR scan (radius <= 8), 0 = host-planned scan programs
      "views_mode"      2 = chained refresh (stale paths run in registers, one launch; Fitch mode), 1 = all dependency
                        levels of a refresh in one launch, 0 = one launch per level
+     "chain_max_ops"   refreshes of up to this many vectors use the chained kernel (default 512; larger ones are wide
+                       rather than deep and take the level kernel)
      "split_below"     batches of at most this many prune nodes are cut into four scan parts each
      "sankoff_short"   1 = two 16-bit costs per lane in the weighted kernels when no intermediate can overflow
                        (the reference's default arithmetic), 0 = always 32-bit (its -short_off)
-     "check_counts"    1 = compare the kernel's candidate counts with the host's
+     "check_counts"    1 = compare the kernel's candidate counts with the host's, and check the view bookkeeping
+     "force_big"       1 = 64-bit addressing in the scan kernel even below 2 GiB of vectors (set before the first tree)
      "timing"          1 = HIP events around the scan kernels (mpf_stats scan_kernel_ms_total), 2 = around the refresh
                        kernels too (view_kernel_ms_total); an event pair costs about 10 us on the stream */
 int mpf_set_option(mpf_engine *e, const char *key, int64_t value);
