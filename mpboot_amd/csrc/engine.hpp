@@ -234,7 +234,8 @@ class Engine {
   // the tracker's large scratch buffers (candidate masks, product, events: ~1 GB at C3 x 1000 samples) outlive a detach, so
   // that re-attaching (every search iteration re-uses the engine) does not allocate inside the next climb
   struct UfbPool {
-    DevBuf<uint32_t> masks, jmasks, sel2;
+    DevBuf<uint32_t> masks, jmasks, sel2, thr, home, cmin, pre;
+    PinBuf<uint32_t> h_small;
     DevBuf<uint2> info;
     DevBuf<int32_t> C, C2;
     DevBuf<UfbEvent> ev;

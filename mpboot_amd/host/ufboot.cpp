@@ -109,6 +109,11 @@ void Engine::ufb_pool_swap(UfbState &u)
   u.ev.swap(ufb_pool_.ev);
   u.h_ev.swap(ufb_pool_.h_ev);
   u.h_info.swap(ufb_pool_.h_info);
+  u.thr.swap(ufb_pool_.thr);
+  u.home.swap(ufb_pool_.home);
+  u.cmin.swap(ufb_pool_.cmin);
+  u.pre.swap(ufb_pool_.pre);
+  u.h_small.swap(ufb_pool_.h_small);
 }
 
 int Engine::ufboot_set_cutoff(double logl_cutoff)
