@@ -166,9 +166,20 @@ def test_medium_climb_matches_oracle(seed):
     if not tie:
         o.set_pre_evaluate(1)                  # MPF_TIE_FIRST = first-best rule on exactly scored candidates
     o.trace(True)                              # (the oracle records its moves only while tracing)
+    ufb = seed % 3 == 0                        # every third case with the online UFBoot bookkeeping on top
+    if ufb:
+        samples = rng.multinomial(int(w.sum()), w / w.sum(), size=6).astype(np.uint16)
+        e.ufboot_attach(samples)
+        o.ufboot_attach(samples)
     se, so = e.optimize_spr(1, maxtrav), o.optimize_spr(1, maxtrav)
     assert se == so
     assert (e.get_tree() == o.get_tree()).all()
+    if ufb:
+        assert o.ufboot_bad() == 0
+        assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()]
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+        e.ufboot_detach()
     me, mo = e.moves(), o.get_moves()
     assert [x.tolist() for x in me] == [np.asarray(x).tolist() for x in mo]
     assert len(me[0]) > 10
