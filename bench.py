@@ -30,6 +30,42 @@ sys.path.insert(0, ROOT)
 
 I8_PEAK_TOPS = 5000.0      # dense int8 MFMA, 2 x bf16 (MI355X_MICROARCH.md, matrix cores)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12   # 32-bit integer lane-ops/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (a wave64 op issues in 4 cycles)
+
+
+def source_hash() -> str:
+    """Hash of the device code: an offline PMC figure is only quoted while it still describes this build."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("mpboot_amd/csrc/kernels.hip", "mpboot_amd/csrc/kernels.hpp", "mpboot_amd/csrc/engine.cpp", "mpboot_amd/csrc/ufboot.hip"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def offline_traffic(workload: str, kernel_prefix: str):
+    """Bytes that left the L2s per launch of the named kernel family (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    tools/profile_gpu.sh -> profiles/r2/traffic.json); None unless that file was made from exactly these sources."""
+    path = os.path.join(ROOT, "profiles", "r2", "traffic.json")
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if tj.get("workload") != workload or tj.get("source_hash") != source_hash():
+        return None
+    for k, v in tj.get("kernels", {}).items():
+        if k.startswith(kernel_prefix):
+            return v.get("bytes_per_launch")
+    return None
+
+
+def st_kernel_name(eng) -> str:
+    """Name of the scan kernel the engine's sweeps launch (mpf_get_option "scan_prog": 1 = planned program, 0 = device walk)."""
+    try:
+        return "k_scan_prog" if eng.get_option("scan_prog") else "k_scan_walk"
+    except Exception:
+        return "k_scan_walk"
 
 
 def physical_cores() -> int:
@@ -142,6 +178,55 @@ def cpu_baseline(codes, back, names, letters, alphabet, maxtrav, budget_s, all_c
                       f"({tests} insertion tests, {secs:.1f} s, 1 thread)"}
 
 
+def launch_ranks(n: int) -> int:
+    """Parent of a multi-GPU run: N child ranks through torch.distributed.run (one process per GPU, RCCL), stdout relayed.
+    The parent itself never touches the GPU (no torch import, no HIP call) and never re-executes itself."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.startswith("{"):
+            line = out
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 4
+    return rc
+
+
+def dry_run(args, rank, world, dist, torch):
+    """MPF_BENCH_DRYRUN=1 (CPU container tests of the launcher only): the ranks rendezvous, exchange their timing
+    tensors exactly as the real run does and rank 0 prints a line marked dry_run -- no engine, no measurement."""
+    backend = os.environ.get("MPF_BENCH_BACKEND", "gloo")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+    tt = torch.tensor([1.0 + rank, 100.0], dtype=torch.float64)
+    tmax, tsum = tt.clone(), tt.clone()
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "backend": backend if world > 1 else None,
+                          "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                          "max_time": float(tmax[0]), "sum_tests": float(tsum[1]), "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,13 +249,23 @@ def main():
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process (which has made NO GPU call and never imports torch)
+        # starts the N ranks as children and relays rank 0's JSON line
+        sys.exit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("MPF_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world, dist, torch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmpfitch has no CPU fallback)")
     # one process per GPU; MPF_BENCH_SHARE_GPU=1 (testing only) lets several ranks share the visible GPUs
@@ -254,27 +349,35 @@ def main():
 
     core_res = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
-        if os.path.exists(tpath) and not args.opt:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload") == args.workload:
-                traffic = tj["bytes_per_launch"]          # from the committed rocprofv3 PMC passes, not live
         evals_per_s = tests_all / dt_all
-        W = eng.W                                          # the reference's parsimonyLength
-        bytes_per_eval = 6 * eng.S * W * 4                 # 1 chain newview + 1 three-vector join-evaluate
+        W = eng.W                                          # the reference's parsimonyLength (32-site words per state row)
         launches = max(1, st["scan_launches"])
         scan_ms = st["scan_kernel_ms_total"] / launches
         evals_per_launch = st["insertion_tests"] / launches
-        achieved = evals_per_launch * bytes_per_eval / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        # what the kernel itself loads per eval: ONE vector (chain in registers, siblings expanded together)
-        compulsory = evals_per_launch * 1 * eng.S * eng.Wp * 4 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        scan_s = scan_ms * 1e-3
+        # ---- what bounds the scan kernel: VALU issue.  The directional-vector formulation loads ONE
+        # vector per insertion test and >90 % of that is served by the XCD-local L2, so HBM is nowhere near a limit; the
+        # arithmetic is.  Algorithmic 32-bit lane-operations per insertion test and 32-site word (v_bitop3 counted as one):
+        #   chain step  U' = fitch(U, sibling)          2 per state
+        #   join cost   popcount(~OR_k(fitch(U', own)_k & s_k))   3 per state + 1 popcount
+        #   wave reduction of the count                 6 DPP adds per PAIR of tests (two 16-bit counts per dword) = 3
+        ops_per_eval_word = 5 * eng.S + 1 + 3
+        lane_ops = evals_per_launch * W * ops_per_eval_word
+        achieved_valu = lane_ops / scan_s / 1e12 if scan_s > 0 else 0.0
+        # SURVEY 8(d)'s byte figure (6 vectors per test) stays as a labelled side number: the kernel does not move those bytes
+        survey_bytes_per_eval = 6 * eng.S * W * 4
+        survey_gbps = evals_per_launch * survey_bytes_per_eval / scan_s / 1e9 if scan_s > 0 else 0.0
+        loaded_gbps = evals_per_launch * eng.S * eng.Wp * 4 / scan_s / 1e9 if scan_s > 0 else 0.0   # L2-side loads: 1 vector per test
+        # bytes that MUST come from HBM per launch: every directional vector of the tree once + the candidates' costs
+        n_vec = n + 3 * (n - 2)
+        compulsory = n_vec * eng.S * eng.Wp * 4 + evals_per_launch * 4
+        traffic = offline_traffic(args.workload, "k_scan") if not args.opt else None
         res = {
             "metric": "Fitch site-ops/sec (taxa x patterns x SPR-evals/s)",
             "value": n * P * evals_per_s,
             "unit": "site-ops/s",
             "n_gpus": world,
+            "dist": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_all / args.steps * 1e3,
@@ -291,19 +394,28 @@ def main():
                        # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
                        # running up-vector with a sibling) + one join, plus the directional-vector refresh of the step
                        "touched_site_ops_per_s": (2.0 * tests_all + st["newview_ops"] * world) * P / dt_all},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_scan_walk", "kernel_ms_per_launch": scan_ms,
-                         "algorithmic_bytes_per_eval": bytes_per_eval,
-                         "loaded_GBps": compulsory,
-                         "note": "achieved = SURVEY §8(d) algorithmic bytes (6 vectors per eval) / HIP-event kernel time; "
-                                 "the kernel itself loads 1 vector per eval (chain in registers, sibling pairs share loads) "
-                                 "= loaded_GBps, 93 % of it L2 hits under the XCD-aware mapping (traffic = bytes that left the "
-                                 "L2s per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1): frac > 1 means the kernel beats "
-                                 "the HBM roofline of the 6-vector formulation, not that HBM delivered more than its peak; the "
-                                 "kernel is bound by VALU issue + memory latency (DESIGN.md section 5)"},
+            "roofline": {"bound": "valu", "achieved": achieved_valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s",
+                         "frac": achieved_valu / VALU_PEAK_TOPS, "traffic": traffic,
+                         "kernel": st_kernel_name(eng), "kernel_ms_per_launch": scan_ms, "evals_per_launch": evals_per_launch,
+                         "plan_kernel_ms_per_launch": st["plan_kernel_ms_total"] / max(1, st["plan_launches"]),
+                         "lane_ops_per_eval_word": ops_per_eval_word,
+                         "hbm": {"compulsory_bytes_per_launch": compulsory, "compulsory_GBps": compulsory / scan_s / 1e9 if scan_s > 0 else 0.0,
+                                 "frac_of_hbm_peak": compulsory / scan_s / 1e9 / HBM_PEAK_GBS if scan_s > 0 else 0.0,
+                                 "peak_GBps": HBM_PEAK_GBS, "l2_side_loaded_GBps": loaded_gbps,
+                                 "survey_6vector_GBps": survey_gbps, "survey_bytes_per_eval": survey_bytes_per_eval},
+                         "note": "bound = VALU issue: achieved = insertion tests x 32-site words x algorithmic lane-ops per test-word "
+                                 "(2 S chain + 3 S join + 1 popcount + 3 reduction) / HIP-event kernel time; peak = 256 CUs x 64 lanes x "
+                                 "2.4 GHz.  The kernel reads one vector per test, mostly from L2: HBM sees only the compulsory bytes "
+                                 "(hbm.*; traffic = rocprofv3 PMC bytes per launch, offline, only when the sources still match "
+                                 "the profiled build).  survey_6vector_GBps is SURVEY 8(d)'s 6-vectors-per-test figure / kernel "
+                                 "time: a labelled side number, not a fraction of anything the kernel moves"},
             "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": view_ms,
-                      "launches_per_step": st["view_launches"] / args.steps},
+                      "launches_per_step": st["view_launches"] / args.steps,
+                      # refresh of every directional vector: 2 vector reads + 1 write per op, HBM-bound by nature
+                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                   "achieved": (st["newview_ops"] / args.steps) * 3 * eng.S * eng.Wp * 4 / (view_ms * 1e-3) / 1e9 if view_ms > 0 else 0.0,
+                                   "frac": (st["newview_ops"] / args.steps) * 3 * eng.S * eng.Wp * 4 / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if view_ms > 0 else 0.0,
+                                   "traffic": offline_traffic(args.workload, "k_newview") if not args.opt else None}},
             "host_ms_per_step": {"plan": st["host_plan_ms_total"] / args.steps, "views": st["host_views_ms_total"] / args.steps,
                                  "scan": st["host_scan_ms_total"] / args.steps,
                                  "sweep_call": st["host_sweep_ms_total"] / args.steps},
@@ -320,7 +432,7 @@ def main():
             out = dict(core_res)
             out["bootstrap_legs_error"] = "secondary legs did not finish within %d s" % args.legs_timeout
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)                                # a stalled multi-rank leg is a failure, not a success
 
     watchdog = threading.Timer(args.legs_timeout, give_up)
     watchdog.daemon = True
@@ -459,11 +571,13 @@ def main():
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
             if "all_cores" in res["cpu_baseline"]:
                 res["gpu_over_cpu_all_cores"] = res["value"] / res["cpu_baseline"]["all_cores"]["value"]
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if legs_error is not None:
+        sys.exit(3)                                # headline printed, but a secondary leg failed
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 1
+#define MPF_ABI_VERSION 2   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option */
 
 enum {
   MPF_OK = 0,
@@ -74,6 +74,8 @@ typedef struct mpf_stats {
   double   host_views_ms_total;  /* wall time of update_views() incl. launches and sync     */
   double   host_scan_ms_total;   /* wall time of run_scans() incl. copies and sync         */
   double   host_sweep_ms_total;  /* wall time inside mpf_spr_sweep_scan                      */
+  double   plan_kernel_ms_total; /* HIP-event time of the scan-program planner (k_walk_plan)  */
+  uint64_t plan_launches;        /* scan launches that ran as planned programs (k_scan_prog)  */
 } mpf_stats;
 
 const char *mpf_last_error(void);
@@ -156,6 +158,14 @@ int mpf_spr_scan(mpf_engine *e, int32_t rec, int32_t mintrav, int32_t maxtrav, i
    the throughput primitive bench.py times.  Returns the number of insertion tests and the
    minimum mp seen. */
 int mpf_spr_sweep_scan(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint64_t *n_tests, uint32_t *min_mp);
+/* the same sweep, handing back every insertion test's tree length: prune nodes in the order pllOptimizeSprParsimony
+   visits them (nodep[1 .. 2n-2] after nodeRectifierPars, sprparsimony.cpp:3298), each node's candidates in the
+   reference's order (as mpf_spr_scan).  offsets[i] .. offsets[i+1] = candidates of the i-th prune node (offsets has
+   2n-1 entries; may be NULL).  *n_tests is always set; mp is filled only if cap >= *n_tests. */
+int mpf_spr_sweep_costs(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets,
+                        uint64_t *n_tests);
+/* tr->nodep[1 .. 2n-2] as nodeRectifierPars leaves it (sprparsimony.cpp:2046-2101): the prune records of a sweep, in order */
+int mpf_get_node_order(mpf_engine *e, int32_t *recs /* [2n-2] */);
 
 /* int pllOptimizeSprParsimony(tr, pr, mintrav, maxtrav, iqtree) (sprparsimony.cpp:3244-3319):
    SPR hill climb on the current tree until no sweep improves; the tree is modified in place
@@ -248,11 +258,17 @@ int mpf_reset_stats(mpf_engine *e);
      "reduce"          0 = DPP wave reduction, 1 = ds_bpermute
      "xcd_map"         1 = XCD-aware workgroup -> tile map of the scan kernel
      "scan_mode"       1 = device-walked SPR scan (radius <= 8), 0 = host-planned scan programs
+     "scan_prog"       device-walked mode, DNA, radius <= 6: 1 = batches of more than "prog_min_descs" scan parts are first
+                       turned into DFS programs on the device (k_walk_plan) and run with the children's vectors requested
+                       one expansion ahead (k_scan_prog); 2 = every batch; 0 = never (k_scan_walk walks the tree itself)
+     "prog_min_descs"  see "scan_prog" (default 256)
      "views_mode"      2 = chained refresh (stale paths run in registers, one launch; Fitch mode), 1 = all dependency
                        levels of a refresh in one launch, 0 = one launch per level
      "chain_max_ops"   refreshes of up to this many vectors use the chained kernel (default 512; larger ones are wide
                        rather than deep and take the level kernel)
      "split_below"     batches of at most this many prune nodes are cut into four scan parts each
+     "split_cands"     larger batches: a prune node's P or Q neighbourhood is cut into four parts only when it holds more
+                       insertion tests than this (default 64)
      "sankoff_short"   1 = two 16-bit costs per lane in the weighted kernels when no intermediate can overflow
                        (the reference's default arithmetic), 0 = always 32-bit (its -short_off)
      "check_counts"    1 = compare the kernel's candidate counts with the host's, and check the view bookkeeping
@@ -260,6 +276,12 @@ int mpf_reset_stats(mpf_engine *e);
      "timing"          1 = HIP events around the scan kernels (mpf_stats scan_kernel_ms_total), 2 = around the refresh
                        kernels too (view_kernel_ms_total); an event pair costs about 10 us on the stream */
 int mpf_set_option(mpf_engine *e, const char *key, int64_t value);
+/* diagnostic (option "scan_trace" = 1): timeline of the last planned-program scan launch, four 64-bit words per workgroup:
+   begin, end (100 MHz counter), XCC_ID << 32 | HW_ID, scan << 32 | tile << 16 | insertion tests.  *n_words is always set;
+   out is filled when cap >= *n_words. */
+int mpf_get_scan_trace(mpf_engine *e, uint64_t *out, uint64_t cap, uint64_t *n_words);
+/* current value of an option of mpf_set_option */
+int mpf_get_option(const mpf_engine *e, const char *key, int64_t *value);
 
 #ifdef __cplusplus
 }

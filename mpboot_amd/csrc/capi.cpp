@@ -185,6 +185,20 @@ int mpf_spr_sweep_scan(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint64_t
   return e->eng.sweep_scan(mintrav, maxtrav, n_tests, min_mp);
 }
 
+int mpf_spr_sweep_costs(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets, uint64_t *n_tests)
+{
+  NEED(e);
+  if (!n_tests || (cap && !mp)) { set_error("mpf_spr_sweep_costs: null output"); return MPF_E_INVALID; }
+  return e->eng.sweep_costs(mintrav, maxtrav, cap, mp, offsets, n_tests);
+}
+
+int mpf_get_node_order(mpf_engine *e, int32_t *recs)
+{
+  NEED(e);
+  if (!recs) { set_error("null output"); return MPF_E_INVALID; }
+  return e->eng.node_order(recs);
+}
+
 int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *score) { NEED(e); return e->eng.optimize_spr(mintrav, maxtrav, score); }
 
 int mpf_make_parsimony_tree(mpf_engine *e, int64_t seed, int32_t spr_dist, uint32_t *score)
@@ -269,6 +283,19 @@ int mpf_set_option(mpf_engine *e, const char *key, int64_t value)
   NEED(e);
   if (!key) { set_error("null option key"); return MPF_E_INVALID; }
   return e->eng.set_option(key, value);
+}
+int mpf_get_scan_trace(mpf_engine *e, uint64_t *out, uint64_t cap, uint64_t *n_words)
+{
+  NEED(e);
+  if (!n_words || (cap && !out)) { set_error("null output"); return MPF_E_INVALID; }
+  return e->eng.scan_trace(out, cap, n_words);
+}
+
+int mpf_get_option(const mpf_engine *e, const char *key, int64_t *value)
+{
+  NEED(e);
+  if (!key || !value) { set_error("null argument"); return MPF_E_INVALID; }
+  return e->eng.get_option(key, value);
 }
 
 }  // extern "C"

@@ -45,6 +45,7 @@ Engine::~Engine()
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (ev2_) (void)hipEventDestroy(ev2_);
   if (ev3_) (void)hipEventDestroy(ev3_);
+  if (ev4_) (void)hipEventDestroy(ev4_);
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -112,6 +113,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   HIPCHK(hipEventCreate(&ev1_));
   HIPCHK(hipEventCreate(&ev2_));
   HIPCHK(hipEventCreate(&ev3_));
+  HIPCHK(hipEventCreate(&ev4_));
   HIPCHK(hipMalloc((void **)&d_codes_, (size_t)n_ * P_));
   HIPCHK(hipMemcpy(d_codes_, codes_.data(), (size_t)n_ * P_, hipMemcpyHostToDevice));
   nslots_ = (size_t)n_ + 3 * (size_t)(n_ - 1);
@@ -1021,7 +1023,7 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
   // out back to back.  whole scan = one part; split scan (latency, small batches) = four parts
   // (gap end x first-level child)
   bool oom = false;
-  auto add = [&](int x, int mt, uint32_t side_mask, uint32_t child_mask, int count) {
+  auto add = [&](int x, int mt, uint32_t side_mask, uint32_t child_mask, int count, int count_first_end) {
     if (h_walk_.cap < n_walk_ + 1) {
       PinBuf<WalkDesc> bigger;
       if (bigger.reserve(2 * (n_walk_ + 1) + 4096) != hipSuccess) { oom = true; return; }
@@ -1036,7 +1038,8 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
     d.trav = (uint32_t)mt | ((uint32_t)maxtrav << 8) | (side_mask << 16) | (child_mask << 18);
     d.out_base = walk_out_;
     d.pad0 = (uint32_t)count;
-    d.pad1 = d.pad2 = 0;
+    d.pad1 = (uint32_t)count_first_end;            // candidates behind the first gap end: where the second end's indices start (k_walk_plan)
+    d.pad2 = 0;
     plan.part_desc[plan.n_parts] = (int)n_walk_;
     plan.part_off[plan.n_parts] = walk_out_;
     plan.part_cnt[plan.n_parts] = count;
@@ -1057,11 +1060,14 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
       cnt[side][0] = cv(back_[nx(xs[side])]) - skip;
       cnt[side][1] = cv(back_[nx(nx(xs[side]))]) - skip;
     }
-    if (!split) { add(x, mt, 3u, 3u, cnt[0][0] + cnt[0][1] + cnt[1][0] + cnt[1][1]); return; }
+    const int total = cnt[0][0] + cnt[0][1] + cnt[1][0] + cnt[1][1];
+    // throughput batches: a neighbourhood is one part unless it is long -- the waves of one launch should not differ
+    // in length by two orders of magnitude (the longest ones would run on alone at the end)
+    if (!split && (total <= split_cands_ || maxtrav > 6)) { add(x, mt, 3u, 3u, total, cnt[0][0] + cnt[0][1]); return; }
     for (uint32_t side = 0; side < 2; side++) {
       if (tip(xs[side])) continue;
-      add(x, mt, 1u << side, 1u, cnt[side][0]);
-      add(x, mt, 1u << side, 2u, cnt[side][1]);
+      add(x, mt, 1u << side, 1u, cnt[side][0], 0);
+      add(x, mt, 1u << side, 2u, cnt[side][1], 0);
     }
   };
   if (!tip(p)) {
@@ -1116,8 +1122,28 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     // small batch: the kernels write the host's copies themselves (mutation counts: the refresh's fold; candidate costs:
     // the scan's last workgroup) -- no copy-back dispatch
     const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && (cnt_on_host_ || !cnt_copy_pending_);
-    HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr,
-                            host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8));
+    // planned program (plan kernel + pipelined scan) for throughput batches; the device-walked kernel for the small,
+    // latency-bound batches inside a climb (scan_prog 2: always planned), for masks, protein and radii above 6
+    const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
+    if (prog) {
+      HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));
+      if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
+      HIPCHK(launch_walk_plan(st_, d_kids(), n_, descs, (int)nd, d_prog_.p));
+      if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }   // the scan kernel's own time starts here
+      unsigned long long *trace = nullptr;
+      if (scan_trace_) {
+        trace_words_ = scan_prog_blocks(g_, (int)nd) * 4;
+        HIPCHK(d_trace_.reserve(trace_words_));
+        HIPCHK(hipMemsetAsync(d_trace_.p, 0, trace_words_ * sizeof(unsigned long long), st_));
+        trace = d_trace_.p;
+      }
+      HIPCHK(launch_scan_prog(st_, g_, d_vec_, descs, (int)nd, d_prog_.p, d_out(), d_ncand_.p,
+                              host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8, trace));
+      stats.plan_launches++;
+    } else {
+      HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr,
+                              host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8));
+    }
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
     if (host_direct) {
@@ -1139,6 +1165,10 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
         if (h_ncand_.p[i] != h_walk_.p[i].pad0) { set_error("device/host candidate count mismatch"); return MPF_E_STATE; }
     float ms = 0;
     if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+    if (plan_event_pending_) {
+      if (hipEventElapsedTime(&ms, ev4_, ev0_) == hipSuccess) stats.plan_kernel_ms_total += ms;
+      plan_event_pending_ = false;
+    }
     stats.scan_launches++;
   }
   else if (pending_scores_) {
@@ -1273,6 +1303,39 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
   return MPF_OK;
 }
 
+int Engine::sweep_costs(int mintrav, int maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets, uint64_t *n_tests)
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  node_rectifier();
+  std::vector<ScanPlan> &plans = sweep_plans_;
+  const uint32_t *out = nullptr;
+  int rc = scan_batch(plans, nodep_.data() + 1, 2 * n_ - 2, mintrav, maxtrav, &out);
+  if (rc) return rc;
+  uint64_t tests = 0;
+  for (const ScanPlan &pl : plans) tests += pl.walked ? (uint64_t)pl.n_total : (uint64_t)pl.cands.size();
+  *n_tests = tests;
+  uint64_t at = 0;
+  size_t i = 0;
+  for (const ScanPlan &pl : plans) {
+    const size_t nc = pl.walked ? (size_t)pl.n_total : pl.cands.size();
+    if (offsets) offsets[i] = at;
+    if (cap >= tests)
+      for (size_t c = 0; c < nc; c++) mp[at + c] = pl.base + pl.cost(c, out);
+    at += nc;
+    i++;
+  }
+  if (offsets) offsets[i] = at;
+  return MPF_OK;
+}
+
+int Engine::node_order(int32_t *recs)
+{
+  if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  node_rectifier();
+  for (int i = 1; i <= 2 * n_ - 2; i++) recs[i - 1] = nodep_[(size_t)i];
+  return MPF_OK;
+}
+
 // pllComputePatternParsimony (reference sprparsimony.cpp:3363-3392) for the current tree: the joins of the
 // traversal rooted on the branch start--back[start] are counted per site on the device
 int Engine::pattern_scores(uint16_t *ptn, int32_t *total)
@@ -1362,6 +1425,10 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
+  if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
+  if (key == "scan_trace") { scan_trace_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "scan_prog") { scan_prog_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
+  if (key == "prog_min_descs") { prog_min_descs_ = v < 0 ? 0 : (int)v; return MPF_OK; }
   if (key == "check_counts") { check_counts_ = v ? 1 : 0; return MPF_OK; }
   if (key == "chain_max_ops") { chain_max_ops_ = v < 0 ? 0 : (long)v; return MPF_OK; }
   if (key == "timing") { timing_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
@@ -1377,6 +1444,37 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   set_error("unknown option " + key);
   return MPF_E_INVALID;
+}
+
+// diagnostic: the per-workgroup timeline of the last planned-program scan launch (option "scan_trace")
+int Engine::scan_trace(uint64_t *out, uint64_t cap, uint64_t *n)
+{
+  *n = trace_words_;
+  if (!trace_words_ || cap < trace_words_) return MPF_OK;
+  activate();
+  HIPCHK(hipMemcpy(out, d_trace_.p, trace_words_ * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return MPF_OK;
+}
+
+int Engine::get_option(const std::string &key, int64_t *v) const
+{
+  if (key == "scan_prog") *v = scan_prog_;
+  else if (key == "prog_min_descs") *v = prog_min_descs_;
+  else if (key == "scan_batch") *v = scan_batch_;
+  else if (key == "words_per_lane") *v = g_.vw;
+  else if (key == "reduce") *v = g_.reduce;
+  else if (key == "xcd_map") *v = g_.map;
+  else if (key == "scan_mode") *v = scan_mode_;
+  else if (key == "views_mode") *v = views_mode_;
+  else if (key == "split_below") *v = split_below_;
+  else if (key == "split_cands") *v = split_cands_;
+  else if (key == "chain_max_ops") *v = chain_max_ops_;
+  else if (key == "timing") *v = timing_;
+  else if (key == "force_big") *v = force_big_;
+  else if (key == "sankoff_short") *v = snk16_opt_;
+  else if (key == "check_counts") *v = check_counts_;
+  else { set_error("unknown option " + key); return MPF_E_INVALID; }
+  return MPF_OK;
 }
 
 }  // namespace mpf

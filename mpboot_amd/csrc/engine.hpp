@@ -190,6 +190,8 @@ class Engine {
   void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const;
   int spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p);
   int sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp);
+  int sweep_costs(int mintrav, int maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets, uint64_t *n_tests);
+  int node_order(int32_t *recs);
 
   // ---- search (host/search.cpp)
   void seed_ties(int mode, int seed) { tie_mode_ = mode; rng_.seed(seed); }
@@ -215,6 +217,8 @@ class Engine {
 
   mpf_stats stats{};
   int set_option(const std::string &key, int64_t v);
+  int get_option(const std::string &key, int64_t *v) const;
+  int scan_trace(uint64_t *out, uint64_t cap, uint64_t *n);
 
  private:
   // helpers
@@ -271,7 +275,8 @@ class Engine {
   size_t nslots_ = 0, vec_words_ = 0;
 
   hipStream_t st_ = nullptr;
-  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev2_ = nullptr, ev3_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev2_ = nullptr, ev3_ = nullptr, ev4_ = nullptr;
+  bool plan_event_pending_ = false;
   uint8_t *d_codes_ = nullptr;
   uint32_t *d_vec_ = nullptr, *d_tipslots_ = nullptr;
   // results buffer: [cnt: nslots][out: ...] so that one copy brings back both
@@ -334,6 +339,7 @@ class Engine {
   bool pending_scores_ = false, kids_dirty_ = true, view_events_pending_ = false;
   long n_invalid_ = -1;                         // -1 = unknown/many, 0 = every vector valid
   int split_below_ = 64;                        // batches of at most this many prune nodes are cut into 4 parts per scan
+  int split_cands_ = 64;                        // larger batches: only neighbourhoods with more insertion tests than this are cut
   int views_mode_ = 2;                          // 2 = chained refresh, 1 = all levels in one launch, 0 = one launch per level
   struct ChainOp { int rec, other; };           // other < 0: chain head (both operands from memory)
   void build_chains(const std::vector<int> &order);
@@ -366,6 +372,12 @@ class Engine {
   size_t n_walk_ = 0;
   uint32_t walk_out_ = 0;
   int scan_mode_ = 1;                           // 1 = device-walked scans, 0 = host-planned programs
+  // 1 = batches of more than prog_min_descs_ descriptors run as planned programs (k_walk_plan + k_scan_prog), 2 = every batch, 0 = never
+  int scan_prog_ = 1, prog_min_descs_ = 256;
+  DevBuf<uint8_t> d_prog_;
+  int scan_trace_ = 0;
+  DevBuf<unsigned long long> d_trace_;
+  size_t trace_words_ = 0;
   std::vector<uint32_t> out_scratch_;
   std::vector<ScanPlan> sweep_plans_;
   // number of records addTraverseParsimony visits below record q with m levels left (memo per topology epoch)

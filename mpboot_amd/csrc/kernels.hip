@@ -12,6 +12,7 @@
 // and leave the wave as ONE integer atomic (integer adds commute: results are exact and
 // run-to-run identical).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace mpf {
 
@@ -1045,6 +1046,289 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
   }
 }
 
+// ---------------------------------------------------------------- SPR scan, planned program (k_walk_plan + k_scan_prog)
+//
+// k_scan_walk pays, per expansion of the DFS, a DEPENDENT chain  kids[node] -> vectors of the two children -> arithmetic
+// with nothing in flight behind it: eight waves per SIMD cannot hide two memory round trips per ~220 cycles of VALU work.
+// The DFS itself is pure topology, so it is split off:
+//   k_walk_plan : one wave per (scan part, gap end).  Lane h = heap index of an expansion (root 1, children 2h / 2h+1,
+//                 depth <= 5 for radius 6): the lanes of one depth fetch kids[] together (6 dependent rounds for a whole
+//                 neighbourhood instead of one per node), subtree sizes go bottom-up and pre-order positions top-down
+//                 through ds_bpermute, and every expansion writes one 16-byte entry at its DFS position:
+//                 (children, depth, which of the two candidates exist, their indices in the REFERENCE's order, whether
+//                 the second child's up-vector must be kept, where this node's up-vector comes from).
+//   k_scan_prog : one wave per (scan part, tile) runs the entries in order.  Entries arrive through the scalar cache two
+//                 ahead, the two child vectors of entry e+1 are requested before entry e is combined (two register sets in
+//                 rotation, unconditional requests so that the waits leave the younger ones in flight), candidate costs
+//                 are dropped into lane (k & 63) of accumulator k >> 6 with v_writelane -- k = position in the reference's
+//                 order, so no frame stack is needed to delay the second child's cost -- and leave as one atomic per lane
+//                 at the end.  Counts are taken as popcount(hit) with s = 0 on lanes past the row end: no per-candidate
+//                 v_not / v_cndmask; cost = 32 * VW * (valid lanes) - sum.
+struct ProgEnt { uint32_t c1, c2, meta, k; };   // root entry (index 0): c1 = cid of the start up-vector, c2 = entries of this side
+constexpr int kProgStride = 64;                  // entries per (scan part, gap end): root + at most 63 expansions (radius <= 6)
+enum { PE_T1 = 16, PE_T2 = 32, PE_SAVE = 64, PE_PEND = 128 };
+
+__global__ __launch_bounds__(256) void k_walk_plan(const uint2 *__restrict__ kids, uint32_t n, const WalkDesc *__restrict__ desc,
+                                                   int n_scans, ProgEnt *__restrict__ prog, uint32_t cid_mask)
+{
+  const int lane = threadIdx.x & 63;
+  int item = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  item = __builtin_amdgcn_readfirstlane(item);
+  if (item >= 2 * n_scans) return;
+  const int scan = item >> 1, side = item & 1;
+  const WalkDesc de = desc[scan];
+  const int mintrav = (int)(de.trav & 0xFFu), maxtrav = (int)((de.trav >> 8) & 0xFFu);
+  const uint32_t side_mask = (de.trav >> 16) & 3u, child_mask = (de.trav >> 18) & 3u;
+  const uint32_t a = side ? de.xb_cid : de.xa_cid, other = side ? de.xa_cid : de.xb_cid;
+  ProgEnt *P = prog + (size_t)item * kProgStride;
+  if (a < n || !((side_mask >> side) & 1u) || maxtrav < 1) {          // wave-uniform: nothing behind this gap end
+    if (lane == 0) P[0] = ProgEnt{other, 0u, 0u, 0u};
+    return;
+  }
+  const int h = lane;                                   // heap index; lane 0 idles
+  const int d = h ? 31 - __builtin_clz((unsigned)h) : -1;   // depth of the node this lane expands; its children sit at d + 1
+  const int par = h >> 1, lc = (2 * h) & 63, rc = (2 * h + 1) & 63;
+  const bool has_kids = h >= 1 && h < 32;
+  uint32_t node = a;
+  int ex = h == 1;
+  uint2 kc = make_uint2(0u, 0u);
+  for (int lev = 0; lev < maxtrav; lev++) {
+    if (ex && d == lev) kc = kids[node];
+    const uint32_t pc1 = (uint32_t)__shfl((int)kc.x, par, 64), pc2 = (uint32_t)__shfl((int)kc.y, par, 64);
+    const int pex = __shfl(ex, par, 64);
+    if (d == lev + 1) {
+      node = (h & 1) ? pc2 : pc1;
+      const bool own = lev + 1 > 1 || ((child_mask >> (h & 1)) & 1u);
+      ex = pex && own && node >= n && lev + 1 < maxtrav;
+    }
+  }
+  const int dd = d + 1;
+  const bool tested = dd >= mintrav;
+  const int t1 = (ex && tested && (dd > 1 || (child_mask & 1u))) ? 1 : 0;
+  const int t2 = (ex && tested && (dd > 1 || (child_mask & 2u))) ? 1 : 0;
+  // (every shuffle below is executed by ALL lanes: ds_bpermute reads nothing from a lane that is switched off)
+  const int sx1 = __shfl(ex, lc, 64), sx2 = __shfl(ex, rc, 64);
+  const int ex1 = has_kids ? sx1 : 0, ex2 = has_kids ? sx2 : 0;
+  // candidates (T) and expansions (E) of the subtree hanging off this expansion, itself included; left child's share kept
+  int T = t1 + t2, E = ex ? 1 : 0, TL = 0, EL = 0;
+  for (int lev = maxtrav - 2; lev >= 0; lev--) {
+    const int tl = __shfl(T, lc, 64), tr = __shfl(T, rc, 64), el = __shfl(E, lc, 64), er = __shfl(E, rc, 64);
+    if (d == lev && ex && has_kids) {
+      TL = ex1 ? tl : 0;
+      EL = ex1 ? el : 0;
+      T = t1 + t2 + TL + (ex2 ? tr : 0);
+      E = 1 + EL + (ex2 ? er : 0);
+    }
+  }
+  // pre-order position of the expansion and reference index K of its first child's candidate
+  int pos = 1, K = side ? (int)de.pad1 : 0;
+  for (int lev = 0; lev + 1 < maxtrav; lev++) {
+    const int ppos = __shfl(pos, par, 64), pK = __shfl(K, par, 64), pt1 = __shfl(t1, par, 64), pt2 = __shfl(t2, par, 64);
+    const int pTL = __shfl(TL, par, 64), pEL = __shfl(EL, par, 64);
+    if (d == lev + 1 && ex) {
+      if (!(h & 1)) { pos = ppos + 1; K = pK + pt1; }
+      else { pos = ppos + 1 + pEL; K = pK + pt1 + pTL + pt2; }
+    }
+  }
+  if (ex) {
+    const uint32_t meta = (uint32_t)dd | (t1 ? PE_T1 : 0u) | (t2 ? PE_T2 : 0u) | (ex2 ? PE_SAVE : 0u) | ((h > 1 && (h & 1)) ? PE_PEND : 0u);
+    P[pos] = ProgEnt{kc.x & cid_mask, kc.y & cid_mask, meta, (uint32_t)K | ((uint32_t)(K + t1 + TL) << 16)};
+    if (h == 1) P[0] = ProgEnt{other, (uint32_t)(1 + E), 0u, (uint32_t)T};
+  }
+}
+
+// acc[lane] = val for ONE lane (v_writelane_b32: value and lane select are wave-uniform scalars).  This clang has no builtin
+// for it, so the LLVM intrinsic is declared directly (the way hip/amd_detail declares ds_bpermute); the compiler then moves
+// the lane select through M0 itself (gfx9 allows one scalar register per VALU instruction) and tracks the hazards.
+extern "C" __device__ int mpf_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t write_lane(uint32_t acc, uint32_t val, uint32_t lane)
+{
+  return (uint32_t)mpf_llvm_writelane((int)val, (int)lane, (int)acc);
+}
+
+// popcount of the sites where joining s onto fitch(u, d) finds a common state (the complement of join_cost)
+template <int S, int VW>
+__device__ __forceinline__ uint32_t join_hits(const Tile<S, VW> &u, const Tile<S, VW> &d, const Tile<S, VW> &s)
+{
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < VW; j++) {
+    uint32_t any = u.v[0][j] & d.v[0][j];
+#pragma unroll
+    for (int k = 1; k < S; k++) any = b3_andor(u.v[k][j], d.v[k][j], any);
+    uint32_t hit = b3_fitch(u.v[0][j], d.v[0][j], any) & s.v[0][j];
+#pragma unroll
+    for (int k = 1; k < S; k++) hit = b3_andor(b3_fitch(u.v[k][j], d.v[k][j], any), s.v[k][j], hit);
+    cnt += (uint32_t)__builtin_popcount(hit);
+  }
+  return cnt;
+}
+
+struct ProgEnt4 { ProgEnt e[4]; };               // four entries = one 64-byte scalar load
+
+template <int S, int VW, bool BIG>
+__global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const uint32_t *__restrict__ vec, const WalkDesc *__restrict__ desc, int n_scans,
+                                                         const ProgEnt *__restrict__ prog, uint32_t *__restrict__ out,
+                                                         uint32_t *__restrict__ ncand, int Wp, int tiles, int map,
+                                                         uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done,
+                                                         unsigned long long *__restrict__ trace)
+{
+  // up-vectors of second children that wait for their turn, depths 2..5 (depth 1 stays in registers): a lane reads back
+  // what it wrote, no synchronisation.
+  // ONE wave per workgroup: scans differ in length by two orders of magnitude (2 .. 250 insertion tests), and a
+  // multi-wave workgroup holds its LDS and its place on the CU until its longest wave is done.
+  __shared__ uint32_t s_pend[4][S * VW][64];
+  const int lane = threadIdx.x;
+  int scan = -1, tile = 0;
+  if (map == 0) {
+    const int gw = (int)blockIdx.x;
+    if (gw < n_scans * tiles) { scan = gw / tiles; tile = gw - scan * tiles; }
+  } else {
+    // XCD-aware, as k_scan_walk: the (tile, scan) items, tile-major, in 8 contiguous chunks, one per blockIdx % 8 class
+    const long total = (long)n_scans * tiles;
+    const long chunk = (total + 7) / 8;
+    const int cls = blockIdx.x & 7;
+    const long idx = (long)(blockIdx.x >> 3);
+    const long item = (long)cls * chunk + idx;
+    if (idx < chunk && item < total) { tile = (int)(item / n_scans); scan = (int)(item - (long)tile * n_scans); }
+  }
+  if (scan >= 0) {
+    // diagnostic timeline (engine option "scan_trace"): start / end of this wave on the 100 MHz clock + where it ran
+    unsigned long long t_begin = 0;
+    if (trace) t_begin = __builtin_amdgcn_s_memrealtime();
+    const WalkDesc de = desc[scan];
+    bool valid;
+    const uint32_t w0 = (uint32_t)lane_word<VW>(tile, lane, Wp, valid);
+    const uint32_t SW = (uint32_t)S * (uint32_t)Wp;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vec, 0, 0x7FFFFFFF, 0x00020000);
+    uint32_t voff[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) voff[k] = (w0 + (uint32_t)k * (uint32_t)Wp) * 4u;
+#define MPF_LOAD(T, cid)                                                                       \
+  do {                                                                                         \
+    if constexpr (BIG) load_tile_g<S, VW>(T, vec + (size_t)(cid) * (size_t)SW, voff);            \
+    else load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);                          \
+  } while (0)
+    Tile<S, VW> sv, par, pend1, ta1, ta2, tb1, tb2;
+    MPF_LOAD(sv, de.s_cid);
+    if (!valid) {                                  // lanes past the row end hold s = 0: they never hit ...
+#pragma unroll
+      for (int kk = 0; kk < S; kk++)
+#pragma unroll
+        for (int j = 0; j < VW; j++) sv.v[kk][j] = 0u;
+    }
+    const uint32_t full = 32u * (uint32_t)VW * (uint32_t)__builtin_popcountll(__ballot(valid));   // ... and are left out here
+    uint32_t *const pend_lane = &s_pend[0][0][lane];
+    uint32_t accp = 0;                             // lane e: packed hit counts of the two candidates of expansion e
+    uint32_t total = 0;
+
+    // one expansion: entry `en` (wave-uniform), children's vectors d1, d2 already requested
+    auto step = [&](const ProgEnt &en, uint32_t e, const Tile<S, VW> &d1, const Tile<S, VW> &d2) {
+      const uint32_t dd = en.meta & 15u;
+      if (en.meta & PE_PEND) {                     // this node was a second child: its up-vector was parked at its depth
+        if (dd == 2u) par = pend1;
+        else {
+          const uint32_t *p = pend_lane + ((dd - 1u) & 3u) * (uint32_t)(S * VW * 64);   // slot = depth & 3 (depths 2..5)
+#pragma unroll
+          for (int kk = 0; kk < S; kk++)
+#pragma unroll
+            for (int j = 0; j < VW; j++) par.v[kk][j] = p[(kk * VW + j) * 64];
+        }
+      }
+      Tile<S, VW> u1, u2;
+      fitch<S, VW>(u2, par, d1);
+      fitch<S, VW>(u1, par, d2);
+      if (en.meta & (PE_T1 | PE_T2)) {
+        const uint32_t c = join_hits<S, VW>(u1, d1, sv) | (join_hits<S, VW>(u2, d2, sv) << 16);
+        accp = write_lane(accp, wave_total<0>(c), e);
+      }
+      if (en.meta & PE_SAVE) {
+        if (dd == 1u) pend1 = u2;
+        else {
+          uint32_t *p = pend_lane + (dd & 3u) * (uint32_t)(S * VW * 64);
+#pragma unroll
+          for (int kk = 0; kk < S; kk++)
+#pragma unroll
+            for (int j = 0; j < VW; j++) p[(kk * VW + j) * 64] = u2.v[kk][j];
+        }
+      }
+      par = u1;
+    };
+
+    for (int side = 0; side < 2; side++) {
+      const ProgEnt *P = prog + ((size_t)scan * 2 + (size_t)side) * kProgStride;
+      const ProgEnt4 *P4 = reinterpret_cast<const ProgEnt4 *>(P);
+      // entries arrive four at a time through the scalar cache, one group ahead of their use, so that the wait in front
+      // of a group's first use (which also covers the LDS traffic of the parked up-vectors) finds them long there
+      ProgEnt4 cur = P4[0];
+      const uint32_t ne = cur.e[0].c2;             // root + expansions
+      total += cur.e[0].k;
+      if (ne < 2u) continue;
+      const uint32_t safe = cur.e[0].c1;           // any valid vector: what the clamped requests past the end fetch
+      MPF_LOAD(par, safe);
+      MPF_LOAD(ta1, cur.e[1].c1);
+      MPF_LOAD(ta2, cur.e[1].c2);
+      // STAGE(i, X, Y): entry g + i sits in set X; request entry g + i + 1 into set Y (unconditionally -- clamped past the
+      // end --, so that the wait in front of X leaves those requests in flight), then combine X
+#define MPF_STAGE(EN, NX, E, X1, X2, Y1, Y2)                                         \
+  {                                                                                  \
+    const bool more = (E) + 1u < ne;                                                 \
+    const uint32_t n1 = more ? (NX).c1 : safe, n2 = more ? (NX).c2 : safe;           \
+    MPF_LOAD(Y1, n1);                                                                \
+    MPF_LOAD(Y2, n2);                                                                \
+    step(EN, E, X1, X2);                                                             \
+    if (!more) break;                                                                \
+  }
+      uint32_t g = 0;
+      while (true) {
+        const ProgEnt4 nxt = P4[g + 4u < (uint32_t)kProgStride ? (g >> 2) + 1u : (g >> 2)];
+        if (g) MPF_STAGE(cur.e[0], cur.e[1], g, tb1, tb2, ta1, ta2)
+        MPF_STAGE(cur.e[1], cur.e[2], g + 1u, ta1, ta2, tb1, tb2)
+        MPF_STAGE(cur.e[2], cur.e[3], g + 2u, tb1, tb2, ta1, ta2)
+        MPF_STAGE(cur.e[3], nxt.e[0], g + 3u, ta1, ta2, tb1, tb2)
+        cur = nxt;
+        g += 4u;
+      }
+#undef MPF_STAGE
+      // lane e owns expansion e: its two candidates go to their places in the reference's order
+      if ((uint32_t)lane >= 1u && (uint32_t)lane < ne) {
+        const uint2 mk = *reinterpret_cast<const uint2 *>(&P[lane].meta);
+        uint32_t *o = out + de.out_base;
+        if (mk.x & PE_T1) { const uint32_t c = full - (accp & 0xFFFFu); if (c) atomic_add_u32(o + (mk.y & 0xFFFFu), c); }
+        if (mk.x & PE_T2) { const uint32_t c = full - (accp >> 16); if (c) atomic_add_u32(o + (mk.y >> 16), c); }
+      }
+    }
+#undef MPF_LOAD
+    if (tile == 0 && lane == 0) ncand[scan] = total;
+    if (trace) {
+      const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11));
+        unsigned long long *t = trace + (size_t)blockIdx.x * 4;
+        t[0] = t_begin;
+        t[1] = t_end;
+        t[2] = ((unsigned long long)xcc << 32) | hw;
+        t[3] = ((unsigned long long)(unsigned)scan << 32) | (total & 0xFFFFu) | ((unsigned)tile << 16);
+      }
+    }
+  }
+  if (!host_out) return;
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ================================================================ Sankoff (weighted parsimony) kernels
 //
 // reference: newviewSankoffParsimonyIterativeFastSIMD / evaluateSankoffParsimonyIterativeFastSIMD
@@ -1539,6 +1823,51 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 #undef SW2
 #undef SW
 #undef SWB
+  return hipGetLastError();
+}
+
+hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const WalkDesc *desc, int n_scans, void *prog)
+{
+  if (n_scans <= 0) return hipSuccess;
+  const long waves = 2L * n_scans;
+  // MPF_PROG_CID_MASK (experiments only): wrong results on purpose -- every child vector is taken from a small set, to time
+  // the scan kernel with its memory traffic confined to the nearest cache
+  static const uint32_t cid_mask = getenv("MPF_PROG_CID_MASK") ? (uint32_t)strtoul(getenv("MPF_PROG_CID_MASK"), nullptr, 0) : 0xFFFFFFFFu;
+  hipLaunchKernelGGL(k_walk_plan, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, kids, (uint32_t)n_taxa, desc, n_scans,
+                     static_cast<ProgEnt *>(prog), cid_mask);
+  return hipGetLastError();
+}
+
+size_t scan_prog_bytes(int n_scans) { return (size_t)n_scans * 2u * kProgStride * sizeof(ProgEnt); }
+
+bool scan_prog_supported(const Geometry &g, int max_depth) { return !g.sankoff && g.S == 4 && (g.vw == 1 || g.vw == 2) && max_depth <= 6; }
+
+size_t scan_prog_blocks(const Geometry &g, int n_scans)
+{
+  const int vw = g.big ? 1 : g.vw;
+  const long waves = (long)n_scans * ((g.Wp + 64 * vw - 1) / (64 * vw));
+  return g.map == 0 ? (size_t)waves : (size_t)(((waves + 7) / 8) * 8);
+}
+
+hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *vec, const WalkDesc *desc, int n_scans,
+                            const void *prog, uint32_t *out, uint32_t *ncand, uint32_t *host_out, uint32_t n_out, uint32_t *done,
+                            unsigned long long *trace)
+{
+  if (n_scans <= 0) return hipSuccess;
+  const int vw = g.big ? 1 : g.vw;
+  const int tiles = (g.Wp + 64 * vw - 1) / (64 * vw);
+  const long waves = (long)n_scans * tiles;
+  dim3 block(64);                                  // one wave per workgroup (see the kernel)
+  unsigned nblocks;
+  if (g.map == 0) nblocks = (unsigned)waves;
+  else { const long chunk = (waves + 7) / 8; nblocks = (unsigned)(chunk * 8); }
+  dim3 grid(nblocks);
+  const ProgEnt *pg = static_cast<const ProgEnt *>(prog);
+#define SP(VW_, BIG_) hipLaunchKernelGGL((k_scan_prog<4, VW_, BIG_>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace)
+  if (g.big) SP(1, true);
+  else if (vw == 1) SP(1, false);
+  else SP(2, false);
+#undef SP
   return hipGetLastError();
 }
 

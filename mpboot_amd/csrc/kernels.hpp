@@ -88,6 +88,17 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
                             uint32_t *masks = nullptr, uint2 *info = nullptr,   // masks != nullptr: UFBoot variant (ufboot.hip)
                             // host_out != nullptr: the last workgroup copies out[0..n_out) to pinned host memory (done: zeroed word)
                             uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr);
+// planned-program scan (radius <= 6, DNA): launch_walk_plan turns the descriptors into one DFS program per (scan part, gap end)
+// -- WalkDesc::pad1 must hold the number of candidates behind the FIRST gap end (xa) of the part --, launch_scan_prog runs
+// them with the children's vectors requested one expansion ahead.  Same outputs as launch_scan_walk.
+hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const WalkDesc *desc, int n_scans, void *prog);
+size_t scan_prog_bytes(int n_scans);
+bool scan_prog_supported(const Geometry &g, int max_depth);
+hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *vec, const WalkDesc *desc, int n_scans,
+                            const void *prog, uint32_t *out, uint32_t *ncand, uint32_t *host_out = nullptr, uint32_t n_out = 0,
+                            uint32_t *done = nullptr,
+                            unsigned long long *trace = nullptr /* diagnostic: 4 words per workgroup (begin, end on the 100 MHz clock, where, what) */);
+size_t scan_prog_blocks(const Geometry &g, int n_scans);
 // per-pattern Fitch lengths: ops = the (a, b) joins of a rooted traversal of the current tree; `planes` is
 // scratch of site_planes_words() words; ptn_out[p] = length of pattern p (0 where first_site[p] < 0)
 hipError_t launch_site_counts(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,

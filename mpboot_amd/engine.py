@@ -22,9 +22,9 @@ EXPORTS = [
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
     "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_site_scores", "mpf_compute_parsimony",
     "mpf_encode_iqtree_states", "mpf_seed_ties",
-    "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_optimize_spr",
+    "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
-    "mpf_set_option", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
+    "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
     "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
@@ -48,7 +48,7 @@ class Stats(C.Structure):
                 ("last_scan_kernel_ms", C.c_double), ("scan_kernel_ms_total", C.c_double),
                 ("view_kernel_ms_total", C.c_double), ("host_plan_ms_total", C.c_double),
                 ("host_views_ms_total", C.c_double), ("host_scan_ms_total", C.c_double),
-                ("host_sweep_ms_total", C.c_double)]
+                ("host_sweep_ms_total", C.c_double), ("plan_kernel_ms_total", C.c_double), ("plan_launches", C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -86,6 +86,8 @@ def load_library():
         L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
         L.mpf_spr_scan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_spr_sweep_scan.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+        L.mpf_spr_sweep_costs.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp]
+        L.mpf_get_node_order.argtypes = [vp, vp]
         L.mpf_optimize_spr.argtypes = [vp, C.c_int32, C.c_int32, vp]
         L.mpf_make_parsimony_tree.argtypes = [vp, C.c_int64, C.c_int32, vp]
         L.mpf_stepwise_addition.argtypes = [vp, C.c_int64, vp, vp, vp]
@@ -93,6 +95,8 @@ def load_library():
         L.mpf_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mpf_reset_stats.argtypes = [vp]
         L.mpf_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.mpf_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+        L.mpf_get_scan_trace.argtypes = [vp, vp, C.c_uint64, vp]
         L.mpf_reps_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp]
         L.mpf_reps_scores.argtypes = [vp, C.c_int32, vp, vp]
         L.mpf_reps_destroy.argtypes = [vp]
@@ -320,6 +324,21 @@ class FitchEngine:
         _chk(load_library().mpf_spr_sweep_scan(self.h, mintrav, maxtrav, C.byref(n), C.byref(m)))
         return n.value, m.value
 
+    def sweep_costs(self, mintrav: int = 1, maxtrav: int = 6):
+        """(n_tests, mp[n_tests], offsets[2n-1]): every insertion test of a whole sweep, prune nodes in sweep order"""
+        L = load_library()
+        n = C.c_uint64()
+        _chk(L.mpf_spr_sweep_costs(self.h, mintrav, maxtrav, 0, None, None, C.byref(n)))
+        mp = np.zeros(max(1, n.value), dtype=np.uint32)
+        off = np.zeros(2 * self.n - 1, dtype=np.uint64)
+        _chk(L.mpf_spr_sweep_costs(self.h, mintrav, maxtrav, n.value, _p(mp), _p(off), C.byref(n)))
+        return n.value, mp[:n.value], off
+
+    def node_order(self):
+        recs = np.zeros(2 * self.n - 2, dtype=np.int32)
+        _chk(load_library().mpf_get_node_order(self.h, _p(recs)))
+        return recs
+
     def optimize_spr(self, mintrav: int = 1, maxtrav: int = 6) -> int:
         s = C.c_uint32()
         _chk(load_library().mpf_optimize_spr(self.h, mintrav, maxtrav, C.byref(s)))
@@ -418,3 +437,17 @@ class FitchEngine:
 
     def set_option(self, key: str, value: int):
         _chk(load_library().mpf_set_option(self.h, key.encode(), int(value)))
+
+    def scan_trace(self):
+        """[workgroups, 4] uint64 timeline of the last planned-program scan (option scan_trace = 1)"""
+        L = load_library()
+        n = C.c_uint64()
+        _chk(L.mpf_get_scan_trace(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(4, n.value), dtype=np.uint64)
+        _chk(L.mpf_get_scan_trace(self.h, _p(out), n.value, C.byref(n)))
+        return out[:n.value].reshape(-1, 4)
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64(0)
+        _chk(load_library().mpf_get_option(self.h, key.encode(), C.byref(v)))
+        return int(v.value)

@@ -130,7 +130,9 @@ double Engine::ufboot_next_cutoff(int percent) const
   const std::vector<uint32_t> &t = ufb_->treels;
   if (t.size() <= 1000) return ufb_->logl_cutoff;
   std::vector<uint32_t> l(t);
-  const size_t k = l.size() * (size_t)percent / 100;
+  // (the reference indexes l[size * percent / 100] unclamped, iqtree.cpp:1666: one past the end at 100 %; here the
+  //  worst tree's score is the cut-off in that case)
+  const size_t k = std::min(l.size() - 1, l.size() * (size_t)percent / 100);
   std::nth_element(l.begin(), l.begin() + (long)k, l.end());   // k-th smallest length = k-th largest logl
   return -(double)l[k];
 }

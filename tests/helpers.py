@@ -15,6 +15,7 @@ def load_fixture(name):
     fx["codes_np"] = np.array(fx["codes"], dtype=np.uint8)
     fx["weights_np"] = np.array(fx["weights"], dtype=np.int32)
     fx["datatype"] = 0 if fx["pll_type"] == "DNA" else 1
+    fx["name"] = name
     return fx
 
 

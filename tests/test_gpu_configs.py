@@ -1,0 +1,282 @@
+"""Every configuration of BASELINE.json at full size on the GPU (C3 properties live in test_gpu_fullsize.py):
+
+  C2  200 taxa x 10 000 DNA patterns   -- full SPR hill climb from a random tree, move for move against the oracle
+  C5  500 taxa x 20 000 protein        -- Fitch-20: score, whole scans and a climb; weighted (-cost) 20-state scans
+  C4  1000 x 50 000, -bb               -- online UFBoot sweep at C3 size: boot_logl re-derived from per-pattern lengths,
+                                          and the sample-sharded run (two engines, events exchanged) == the unsharded one
+plus the value checks of mpf_spr_sweep_scan (the call bench.py times) against per-prune-node scans.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(name):
+    from mpboot_amd import engine, synth
+    cfg = synth.WORKLOADS[name]
+    letters, _ = synth.workload(name)
+    codes = synth.letters_to_codes(letters, cfg["alphabet"])
+    return codes, (engine.DNA if cfg["alphabet"] == "DNA" else engine.AA)
+
+
+def _oracle_scan(o, po, back, rec, maxtrav):
+    cur = o.score_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 1)
+    o.set_best(cur)
+    o.trace(True)
+    o.rearrange(int(rec), 1, maxtrav)
+    tq, tm = o.get_trace()
+    keep = tq >= 0
+    return tq[keep].tolist(), tm[keep].tolist()
+
+
+# ------------------------------------------------------------------------------------------------ C2
+
+def test_c2_full_hill_climb_matches_oracle():
+    """BASELINE config 2: full SPR hill climb, 1 GPU -- accepted moves, final topology and score == the oracle's"""
+    from mpboot_amd import engine, trees
+    from oracle import pyoracle as po
+    codes, dt = _workload("C2")
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(1))
+    for opts in (dict(), dict(scan_prog=2)):
+        e = engine.FitchEngine(codes, datatype=dt)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        o = po.Oracle(codes)
+        assert e.score_tree(back) == o.score_tree(back)
+        e.seed_ties(engine.TIE_RANDOM, 1)
+        o.seed_ties(po.TIE_RANDOM, 1)
+        o.trace(True)
+        se, so = e.optimize_spr(1, 6), o.optimize_spr(1, 6)
+        assert se == so
+        assert len(e.moves()[0]) > 300
+        assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+        assert (e.get_tree() == o.get_tree()).all()
+        if not opts:
+            st = e.stats()
+            assert st["plan_launches"] > 0                    # the climb's closing sweeps ran as planned programs
+
+
+# ------------------------------------------------------------------------------------------------ C5
+
+@pytest.fixture(scope="module")
+def c5():
+    from mpboot_amd import trees
+    codes, dt = _workload("C5")
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(9))
+    return codes, dt, back
+
+
+def test_c5_fitch20_scores_and_scans_match_oracle(c5):
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    codes, dt, back = c5
+    e = engine.FitchEngine(codes, datatype=dt)
+    o = po.Oracle(codes, datatype=po.AA)
+    assert (e.S, e.W) == (20, o.W)
+    assert e.score_tree(back) == o.score_tree(back)
+    nodep = o.nodep()
+    rng = np.random.default_rng(3)
+    for rec in nodep[1 + rng.choice(2 * codes.shape[0] - 2, size=6, replace=False)]:
+        tq, tm = _oracle_scan(o, po, back, rec, 6)
+        e.set_tree(back)
+        q, mp, _ = e.spr_scan(int(rec), 1, 6)
+        assert q.tolist() == tq and mp.tolist() == tm
+
+
+def test_c5_fitch20_climb_is_monotone_and_idempotent(c5):
+    from mpboot_amd import engine
+    codes, dt, back = c5
+    e = engine.FitchEngine(codes, datatype=dt)
+    e.set_tree(back)
+    start = e.score_tree()
+    e.seed_ties(engine.TIE_RANDOM, 5)
+    final = e.optimize_spr(1, 6)
+    sc = e.moves()[2]
+    assert len(sc) > 500 and final < start
+    assert (np.diff(sc.astype(np.int64)) <= 0).all() and int(sc[-1]) == final
+    assert e.score_tree() == final
+    tree = e.get_tree()
+    e.seed_ties(engine.TIE_FIRST, 0)
+    assert e.optimize_spr(1, 6) == final and (e.get_tree() == tree).all()
+    # per-pattern lengths of the optimum sum to its length
+    ptn, tot = e.pattern_scores()
+    assert tot == final == int(ptn.astype(np.int64).sum())
+
+
+def test_c5_weighted_20_state_scans_match_oracle(c5):
+    """the `-cost` form of config 5: Sankoff-20 tree length and every candidate of two prune nodes (about 200 insertion tests)"""
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    codes, dt, back = c5
+    rng = np.random.default_rng(5)
+    c = rng.integers(1, 6, size=(20, 20))
+    cost = (np.triu(c, 1) + np.triu(c, 1).T).astype(np.uint32)
+    e = engine.FitchEngine(codes, datatype=dt, cost=cost)
+    o = po.Oracle(codes, datatype=po.AA, cost=cost)
+    assert e.score_tree(back) == o.score_tree(back)
+    nodep = o.nodep()
+    done = 0
+    for rec in nodep[[40, 333, 700]]:
+        tq, tm = _oracle_scan(o, po, back, rec, 6)
+        e.set_tree(back)
+        q, mp, _ = e.spr_scan(int(rec), 1, 6)
+        assert q.tolist() == tq and mp.tolist() == tm
+        done += len(tq)
+    assert done > 60
+
+
+# ------------------------------------------------------------------------------------------------ sweep_scan (the timed call)
+
+@pytest.mark.parametrize("opts", [dict(), dict(scan_prog=0), dict(scan_prog=2, words_per_lane=2)])
+def test_sweep_scan_equals_per_node_scans(opts):
+    """mpf_spr_sweep_scan's unsplit whole-sweep branch: its best == the minimum over mpf_spr_scan of every prune node,
+    its test count == the sum of their candidate counts"""
+    from mpboot_amd import engine, synth, trees
+    letters, _ = synth.synth_alignment(260, 1800, "DNA", 0.07, seed=21)
+    codes = synth.letters_to_codes(letters)
+    back = trees.random_topology(260, np.random.default_rng(4))
+    e = engine.FitchEngine(codes)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    e.set_option("check_counts", 1)
+    e.set_tree(back)
+    e.score_tree()
+    ntests, best = e.sweep_scan(1, 6)
+    ref = engine.FitchEngine(codes)
+    ref.set_option("scan_prog", 0)
+    ref.set_tree(back)
+    ref.score_tree()
+    assert (e.node_order() == ref.node_order()).all()
+    ncost, costs, off = e.sweep_costs(1, 6)
+    tot, mn = 0, None
+    for i, rec in enumerate(ref.node_order()):
+        q, mp, _ = ref.spr_scan(int(rec), 1, 6)
+        assert costs[int(off[i]):int(off[i + 1])].tolist() == mp.tolist(), int(rec)     # per candidate, not just the minimum
+        tot += len(q)
+        if len(mp):
+            mn = int(mp.min()) if mn is None else min(mn, int(mp.min()))
+    assert (ntests, best) == (tot, mn) and ncost == tot
+
+
+def test_sweep_scan_candidates_at_c3_match_the_walking_kernel():
+    """C3: every candidate cost of the whole sweep, planned programs (what bench.py times) vs the device-walked kernel
+    (pinned candidate by candidate against the reference in test_gpu_parity.py)"""
+    from mpboot_amd import engine, trees
+    codes, dt = _workload("C3")
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(12))
+    res = []
+    for prog in (1, 0):
+        e = engine.FitchEngine(codes, datatype=dt)
+        e.set_option("scan_prog", prog)
+        e.set_option("check_counts", 1)
+        e.set_tree(back)
+        e.score_tree()
+        res.append(e.sweep_costs(1, 6))
+        st = e.stats()
+        assert (st["plan_launches"] > 0) == (prog == 1)
+    assert res[0][0] == res[1][0] > 50_000
+    assert (res[0][1] == res[1][1]).all()
+
+
+# ------------------------------------------------------------------------------------------------ C4 (-bb at C3 size)
+
+@pytest.fixture(scope="module")
+def c4():
+    from mpboot_amd import engine
+    codes, dt = _workload("C3")
+    e = engine.FitchEngine(codes, datatype=dt)
+    e.seed_ties(engine.TIE_RANDOM, 1)
+    e.make_parsimony_tree(12345, 0)
+    back = e.get_tree()
+    P = codes.shape[1]
+    samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=96).astype(np.uint16)
+    return codes, dt, back, samples
+
+
+def _online_phase(e, engine, back, samples, **kw):
+    e.ufboot_attach(samples, 0.5, **kw)
+    e.set_tree(back)
+    e.reset_node_order()
+    e.seed_ties(engine.TIE_RANDOM, 1)
+    return e.optimize_spr(1, 6)
+
+
+def test_c4_online_ufboot_sweep_boot_logl_rederived(c4):
+    """-bb online phase at full size: every sample's boot_logl == -<per-pattern lengths of the tree it kept, its weights>"""
+    from mpboot_amd import engine
+    codes, dt, back, samples = c4
+    e = engine.FitchEngine(codes, datatype=dt)
+    score = _online_phase(e, engine, back, samples)
+    logl, counts, tr = e.ufboot_state()
+    assert len(e.ufboot_tree_logl()) > 1000 and (counts >= 1).all()
+    final = e.get_tree()
+    for b in range(0, 96, 8):
+        e.set_tree(e.ufboot_tree(int(tr[b])))
+        ptn, _tot = e.pattern_scores()
+        assert -int((ptn.astype(np.int64) * samples[b]).sum()) == int(logl[b]), b
+    e.set_tree(final)
+    assert e.score_tree() == score
+
+
+C4_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MPF_ROOT"])
+import torch.distributed as dist
+from mpboot_amd import engine, shard, synth
+dist.init_process_group("gloo")
+rank, ws = shard.world()
+letters, _ = synth.workload("C3")
+codes = synth.letters_to_codes(letters, "DNA")
+back = np.load(os.environ["MPF_BACK"])
+P = codes.shape[1]
+samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=96).astype(np.uint16)
+e = engine.FitchEngine(codes)
+e.ufboot_attach(samples, 0.5, shard=(rank, ws))
+e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1)
+s = e.optimize_spr(1, 6)
+logl, cnt, tr = e.ufboot_state()
+res = {"s": s, "logl": logl.tolist(), "cnt": cnt.tolist(), "tr": tr.tolist(), "saved": e.ufboot_tree_logl().tolist(),
+       "final": e.get_tree().tolist(), "draws": e.ufboot_counters()["tie_draws"]}
+allr = [None] * ws
+dist.all_gather_object(allr, res)
+if rank == 0:
+    assert all(r == allr[0] for r in allr), "ranks disagree"
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+def test_c4_sample_sharded_online_phase_equals_unsharded(c4, tmp_path):
+    """BASELINE config 4's data path on this box: two ranks (sharing the one GPU, gloo rendezvous) hold every second bootstrap
+    sample each and all-gather their events per scan batch -- every rank ends with exactly the single engine's bookkeeping"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+    from mpboot_amd import engine
+    codes, dt, back, samples = c4
+    single = engine.FitchEngine(codes, datatype=dt)
+    s0 = _online_phase(single, engine, back, samples)
+    logl, cnt, tr = single.ufboot_state()
+    np.save(tmp_path / "back.npy", back)
+    script = tmp_path / "worker.py"
+    script.write_text(C4_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MPF_ROOT=ROOT, MPF_BACK=str(tmp_path / "back.npy"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert got["s"] == s0
+    assert got["logl"] == logl.tolist() and got["cnt"] == cnt.tolist() and got["tr"] == tr.tolist()
+    assert got["saved"] == single.ufboot_tree_logl().tolist()
+    assert got["final"] == single.get_tree().tolist()
+    assert got["draws"] == single.ufboot_counters()["tie_draws"]

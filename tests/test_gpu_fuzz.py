@@ -49,7 +49,8 @@ def test_random_case_matches_oracle(seed):
     # kernel / batching variants: none of them may change a result
     opts = [{}, {"words_per_lane": 2}, {"reduce": 1, "xcd_map": 0}, {"scan_batch": 3, "split_below": 0},
             {"scan_mode": 0}, {"views_mode": 0, "scan_batch": 128}, {"force_big": 1}, {"split_below": 4096, "check_counts": 1},
-            {"views_mode": 1, "scan_batch": 2}, {"views_mode": 2, "scan_batch": 1, "check_counts": 1}][seed % 10]
+            {"views_mode": 1, "scan_batch": 2}, {"views_mode": 2, "scan_batch": 1, "check_counts": 1},
+            {"scan_prog": 2, "check_counts": 1}, {"scan_prog": 2, "split_below": 0, "scan_batch": 64}][seed % 12]
     for k, v in opts.items():
         e.set_option(k, v)
     if opts.get("scan_mode") == 0 and seed % 16 == 4 and not c["aa"]:

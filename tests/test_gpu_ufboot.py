@@ -103,6 +103,10 @@ def test_cutoff_filter_and_next_cutoff(mods):
     assert_same(e, o, se, so)
     cut_e, cut_o = e.ufboot_next_cutoff(10), o.ufboot_next_cutoff(10)
     assert cut_e == cut_o and cut_e != 0.0
+    # boundary of the public ABI: 100 % indexes one past the end in the reference (iqtree.cpp:1666); the engine clamps to
+    # the worst saved tree, 0 % is the best one
+    assert e.ufboot_next_cutoff(100) == e.ufboot_tree_logl().min()
+    assert e.ufboot_next_cutoff(0) == e.ufboot_tree_logl().max()
     # second climb (as the next search iteration would) under that cut-off, from another tree
     n_before = len(o.ufboot_tree_logl())
     start2 = np.array(fx["trees"][3]["back"], dtype=np.int32)

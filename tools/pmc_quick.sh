@@ -11,8 +11,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_scan_walk" in k or "k_newview_wg" in k:
-            acc[k[:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "k_scan_walk" in k or "k_newview" in k or "k_scan_prog" in k or "k_walk_plan" in k or "k_cntsum" in k:
+            acc[k[:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k, {c: round(sum(v)/len(v)) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
 PY
