@@ -30,7 +30,11 @@ sys.path.insert(0, ROOT)
 
 I8_PEAK_TOPS = 5000.0      # dense int8 MFMA, 2 x bf16 (MI355X_MICROARCH.md, matrix cores)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
-VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12   # 32-bit integer lane-ops/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (a wave64 op issues in 4 cycles)
+# 32-bit integer lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues
+# over 2 cycles; tools/ubench/valu_rate.hip measures v_bitop3_b32 / v_and_b32 at that rate and v_bcnt / DPP / v_and_or at half of it)
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+L2_PEAK_GBS = 34500.0     # aggregate L2 -> CU bandwidth (MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s; its measured gather-from-L2
+                          # rates are 16.8-18.8 TB/s chip-wide)
 
 
 def source_hash() -> str:
@@ -178,6 +182,74 @@ def cpu_baseline(codes, back, names, letters, alphabet, maxtrav, budget_s, all_c
                       f"({tests} insertion tests, {secs:.1f} s, 1 thread)"}
 
 
+def refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, gpu_scores, maxtrav):
+    """CPU side of the bootstrap metric: the refinement of bootstrap samples (re-weight, rebuild the parsimony structures,
+    SPR hill climb from the sample's tree) on the REFERENCE's PLL code (oracle/_ref/pll_ref_driver refine), one thread for
+    sample 0 and then one sample per usable core at once; the scalar port only when the reference build did not travel."""
+    from mpboot_amd import shard, synth, trees
+    drv = os.path.join(ROOT, "oracle", "_ref", "pll_ref_driver")
+    n, P = codes.shape
+    if os.path.exists(drv) and os.access(drv, os.X_OK):
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                aln = os.path.join(tmp, "a.phy")
+                synth.write_phylip(aln, synth.letters_to_text(letters, alphabet), names)
+                ncopy = max(1, min(physical_cores(), cpu_quota(), len(boot_trees)))
+
+                def cmd(b):
+                    tf, wf = os.path.join(tmp, f"t{b}.nwk"), os.path.join(tmp, f"w{b}.txt")
+                    with open(tf, "w") as f:
+                        f.write(trees.back_to_newick(boot_trees[b], names) + "\n")
+                    with open(wf, "w") as f:
+                        f.write(" ".join(map(str, samples[b].astype(np.int64).tolist())) + "\n")
+                    return [drv, "refine", aln, "DNA" if alphabet == "DNA" else "WAG", "0", tf, str(maxtrav), wf]
+
+                def parse(text):
+                    for l in text.splitlines():
+                        t = l.split()
+                        if t and t[0] == "refined":
+                            return int(t[2]), int(t[4]), int(t[6]), float(t[10])
+                    return None
+
+                t0 = time.perf_counter()
+                one = parse(subprocess.run(cmd(0), capture_output=True, text=True, check=True, timeout=900).stdout)
+                wall1 = time.perf_counter() - t0
+                res = {"refinement_per_1000_samples_s": 1000.0 * one[3], "cores": 1, "kind": "reference",
+                       "sample": f"sample 0 on the reference's PLL AVX code (pll_ref_driver refine: re-weight + compressDNA + SPR hill "
+                                 f"climb, first-best rule): {one[2]} moves, {one[3]:.2f} s (process wall {wall1:.2f} s incl. alignment parsing)",
+                       "final_score_reference": one[1], "final_score_gpu": int(gpu_scores[0]),
+                       "note": "scores may differ by the tie rule (reference first-best vs mpboot's random ties): both are SPR-local optima"}
+                if ncopy > 1:
+                    t0 = time.perf_counter()
+                    procs = [subprocess.Popen(cmd(b), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for b in range(ncopy)]
+                    outs = []
+                    for pr in procs:
+                        try:
+                            outs.append(parse(pr.communicate(timeout=1800)[0]))
+                        except Exception:
+                            pr.kill()
+                    wall = time.perf_counter() - t0
+                    ok = [o for o in outs if o]
+                    if ok:
+                        per_sample = max(o[3] for o in ok) / len(ok)     # N samples finished within the slowest one's time
+                        res["all_cores"] = {"processes": len(ok), "physical_cores": physical_cores(), "usable_cpus": cpu_quota(),
+                                            "refinement_per_1000_samples_s": 1000.0 * per_sample, "wall_s": wall,
+                                            "sample": f"samples 0..{len(ok) - 1}, one single-threaded process each, at once"}
+                return res
+        except Exception as exc:
+            print(f"[bench] reference refine failed ({exc}); using the scalar port", file=sys.stderr)
+    from oracle import pyoracle as po
+    o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
+    tc0 = time.perf_counter()
+    o.set_weights(samples[0].astype(np.int32))
+    o.seed_ties(po.TIE_RANDOM, shard.unit_seed(7, 0))
+    o.set_tree(boot_trees[0])
+    s_cpu = o.optimize_spr(1, maxtrav)
+    tc = time.perf_counter() - tc0
+    return {"refinement_per_1000_samples_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "sample 0 on the scalar C oracle",
+            "same_score_as_gpu": bool(int(gpu_scores[0]) == int(s_cpu))}
+
+
 def launch_ranks(n: int) -> int:
     """Parent of a multi-GPU run: N child ranks through torch.distributed.run (one process per GPU, RCCL), stdout relayed.
     The parent itself never touches the GPU (no torch import, no HIP call) and never re-executes itself."""
@@ -238,6 +310,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--start-tree", default="ras", choices=["ras", "random"])
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    ap.add_argument("--tree-cache", default=None,
+                    help="file to keep rank 0's start tree in (written if absent, read if present): the counter passes of "
+                         "tools/profile_gpu.sh re-use the RAS tree of the first pass instead of rebuilding it under the profiler")
     ap.add_argument("--bootstrap-replicates", type=int, default=1000,
                     help="samples of the online phase whose trees are refined afterwards (IQTree::optimizeBootTrees), "
                          "sharded over the GPUs; capped by --ufboot-samples (0 = skip)")
@@ -294,10 +369,15 @@ def main():
         eng.set_option(k, int(v))
     # each rank scans its own start tree (independent SPR start trees shard across GPUs): the randomized
     # stepwise-addition tree the reference would hand to pllOptimizeSprParsimony (built on the GPU, untimed)
-    if args.start_tree == "ras":
+    cache = f"{args.tree_cache}.{args.workload}.{args.start_tree}.{rank}.npy" if args.tree_cache else None
+    if cache and os.path.exists(cache):
+        back = np.load(cache)
+    elif args.start_tree == "ras":
         eng.seed_ties(engine.TIE_RANDOM, 1 + rank)
         eng.make_parsimony_tree(12345 + 7919 * rank, 0)
         back = eng.get_tree()
+        if cache:
+            np.save(cache, back)
     else:
         back = trees.random_topology(n, np.random.default_rng(1000 + rank))
     eng.set_tree(back)
@@ -394,21 +474,28 @@ def main():
                        # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
                        # running up-vector with a sibling) + one join, plus the directional-vector refresh of the step
                        "touched_site_ops_per_s": (2.0 * tests_all + st["newview_ops"] * world) * P / dt_all},
-            "roofline": {"bound": "valu", "achieved": achieved_valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s",
-                         "frac": achieved_valu / VALU_PEAK_TOPS, "traffic": traffic,
+            # The scan kernel is bound by the L2 -> CU data path: one directional vector per insertion test has to reach a
+            # CU's registers, >90 % of them from the XCD's L2 (loads-only variant of the kernel: 0.93 of its time,
+            # arithmetic-only variant: 0.64 -- profiles/r2/scan_bounds.txt).  achieved = bytes the kernel loads / its time.
+            "roofline": {"bound": "l2", "achieved": loaded_gbps, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                         "frac": loaded_gbps / L2_PEAK_GBS, "traffic": traffic,
                          "kernel": st_kernel_name(eng), "kernel_ms_per_launch": scan_ms, "evals_per_launch": evals_per_launch,
                          "plan_kernel_ms_per_launch": st["plan_kernel_ms_total"] / max(1, st["plan_launches"]),
-                         "lane_ops_per_eval_word": ops_per_eval_word,
+                         "loaded_bytes_per_launch": evals_per_launch * eng.S * eng.Wp * 4,
+                         "valu": {"achieved": achieved_valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s", "frac": achieved_valu / VALU_PEAK_TOPS,
+                                  "lane_ops_per_eval_word": ops_per_eval_word},
                          "hbm": {"compulsory_bytes_per_launch": compulsory, "compulsory_GBps": compulsory / scan_s / 1e9 if scan_s > 0 else 0.0,
                                  "frac_of_hbm_peak": compulsory / scan_s / 1e9 / HBM_PEAK_GBS if scan_s > 0 else 0.0,
-                                 "peak_GBps": HBM_PEAK_GBS, "l2_side_loaded_GBps": loaded_gbps,
+                                 "peak_GBps": HBM_PEAK_GBS,
                                  "survey_6vector_GBps": survey_gbps, "survey_bytes_per_eval": survey_bytes_per_eval},
-                         "note": "bound = VALU issue: achieved = insertion tests x 32-site words x algorithmic lane-ops per test-word "
-                                 "(2 S chain + 3 S join + 1 popcount + 3 reduction) / HIP-event kernel time; peak = 256 CUs x 64 lanes x "
-                                 "2.4 GHz.  The kernel reads one vector per test, mostly from L2: HBM sees only the compulsory bytes "
-                                 "(hbm.*; traffic = rocprofv3 PMC bytes per launch, offline, only when the sources still match "
-                                 "the profiled build).  survey_6vector_GBps is SURVEY 8(d)'s 6-vectors-per-test figure / kernel "
-                                 "time: a labelled side number, not a fraction of anything the kernel moves"},
+                         "note": "bound = L2 -> CU bandwidth: achieved = insertion tests x one vector (S x Wp x 4 B, the bytes the kernel "
+                                 "actually loads per test: chain in registers, sibling pairs share loads) / HIP-event kernel time; peak = the "
+                                 "guide's aggregate L2 figure (its measured gathers from L2 reach 16.8-18.8 TB/s).  valu.* = algorithmic "
+                                 "lane-ops (2 S chain + 3 S join + 1 popcount + 3 reduction per test and 32-site word) against 256 CUs x 128 "
+                                 "lanes x 2.4 GHz.  hbm.*: what must come from HBM per launch (every vector once) -- far from a limit; "
+                                 "traffic = rocprofv3 PMC bytes that left the L2s per launch, offline, quoted only while the sources match "
+                                 "the profiled build.  survey_6vector_GBps is SURVEY 8(d)'s 6-vectors-per-test figure / kernel time: a "
+                                 "labelled side number, not a fraction of anything the kernel moves"},
             "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": view_ms,
                       "launches_per_step": st["view_launches"] / args.steps,
                       # refresh of every directional vector: 2 vector reads + 1 write per op, HBM-bound by nature
@@ -455,7 +542,8 @@ def main():
             samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
             from mpboot_amd import shard
             back_u = shard.broadcast_tree(back, 0, len(back))      # the chain starts from rank 0's tree on every rank
-            for timed in (False, True):                # first pass: allocations, code load
+            tus = []
+            for timed in (False, True, True):          # first pass: allocations, code load; then two timed passes, the faster one counts
                 eng.ufboot_attach(samples, 0.5, shard=(rank, world))   # samples rank, rank + world, ... ; events all-gathered per batch
                 eng.set_tree(back_u)
                 eng.reset_node_order()
@@ -465,9 +553,11 @@ def main():
                 tu0 = time.perf_counter()
                 us = eng.optimize_spr(1, args.maxtrav)
                 barrier()
-                tu = time.perf_counter() - tu0
+                if timed:
+                    tus.append(time.perf_counter() - tu0)
+            tu = min(tus)
             ust, ucn = eng.stats(), eng.ufboot_counters()
-            ufb = {"samples": B, "samples_local": len(range(rank, B, world)), "seconds": tu, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
+            ufb = {"samples": B, "samples_local": len(range(rank, B, world)), "seconds": tu, "seconds_each_pass": tus, "score": us, "insertion_tests": ust["insertion_tests"], "moves": ust["moves_applied"],
                    "saved_trees": len(eng.ufboot_tree_logl()), **ucn}
             n_rep = min(B, args.bootstrap_replicates)
             if n_rep > 0:
@@ -518,19 +608,8 @@ def main():
                         "sample b on rank b %% n_gpus, several engines per GPU).  seconds = online + refinement scaled to all samples"
                         % (ufb["samples"], args.maxtrav)}
         if boot is not None and not args.no_cpu and world == 1:
-            # CPU side of the refinement: the scalar C port (oracle) on sample 0, one thread
-            from oracle import pyoracle as po
-            from mpboot_amd import shard
-            o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
-            tc0 = time.perf_counter()
-            o.set_weights(samples[0].astype(np.int32))
-            o.seed_ties(po.TIE_RANDOM, shard.unit_seed(7, 0))
-            o.set_tree(boot_trees[0])
-            s_cpu = o.optimize_spr(1, args.maxtrav)
-            tc = time.perf_counter() - tc0
-            res["bootstrap_wall_clock"]["cpu_baseline"] = {
-                "refinement_per_1000_samples_s": 1000.0 * tc, "cores": 1, "kind": "port", "sample": "sample 0 on the scalar C oracle",
-                "same_score_as_gpu": bool(int(bscores[0]) == int(s_cpu))}
+            res["bootstrap_wall_clock"]["cpu_baseline"] = refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, bscores,
+                                                                             args.maxtrav)
         if ufb is not None:
             algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples_local"]
             kms = ufb["reps_kernel_ms"]
@@ -540,7 +619,7 @@ def main():
                         "for %d bootstrap samples: cut-off filter, REPS of every insertion test, per-sample update rule with the "
                         "reference's tie draws.  The search chain is sequential: every rank runs this same call on its share of the "
                         "samples (%d on rank 0) and the events are all-gathered per scan batch" % (args.maxtrav, ufb["samples"], ufb["samples_local"]),
-                "seconds": ufb["seconds"], "insertion_tests": ufb["insertion_tests"], "moves": ufb["moves"],
+                "seconds": ufb["seconds"], "seconds_each_pass": ufb["seconds_each_pass"], "insertion_tests": ufb["insertion_tests"], "moves": ufb["moves"],
                 "tests_per_s": ufb["insertion_tests"] / ufb["seconds"], "saved_trees": ufb["saved_trees"],
                 "events": ufb["events"], "tie_draws": ufb["tie_draws"], "score": ufb["score"],
                 "roofline": {"bound": "mfma", "achieved": top, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": top / I8_PEAK_TOPS,

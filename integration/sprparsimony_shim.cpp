@@ -13,8 +13,11 @@
 //   void resetGlobalParamOnNewAln()                                                                  .h:13  -> :143
 // plus the globals sprparsimony.cpp defines (:128-141): iqtree, bestTreeScoreHits, first_call, doing_stepwise_addition.
 //
-// Not provided: the Sankoff (-cost) dispatch of these functions (bind mpf_engine_create_sankoff the same way),
-// pllSaveCurrentTreeSprParsimony (the per-candidate call-back disappears: the bookkeeping runs inside
+// -cost (weighted parsimony): as in the reference, every entry point dispatches on the global pllCostMatrix
+// (sprparsimony.cpp:556-641, :967-1030): non-NULL -> the engine is created with mpf_engine_create_sankoff on that
+// matrix; initializeCostMatrix() (:159-188) and the global highest_cost (:130) are defined here.
+//
+// Not provided: pllSaveCurrentTreeSprParsimony (the per-candidate call-back disappears: the bookkeeping runs inside
 // mpf_optimize_spr, mpboot_hooks.h ufboot_sync) and the tool functions of sprparsimony.h:46-54.
 //
 // Compiled and exercised by oracle/Makefile's `ref` target (oracle/spr_shim_driver.cpp + the reference's own PLL objects)
@@ -29,7 +32,12 @@ extern "C" {
 }
 #include "mpboot_hooks.h"
 
+// globals the reference DEFINES in iqtree.cpp:35-43 and sprparsimony.cpp consumes: the cost matrix of -cost
+extern unsigned int *pllCostMatrix;        // cost[i * pllCostNstates + j] = cost of i -> j, NULL = Fitch
+extern int pllCostNstates;
+
 IQTree *iqtree = nullptr;                  // sprparsimony.cpp:128
+parsimonyNumber highest_cost = 0;          // :130, max(cost) + 1: the cost of a state a tip does not have
 unsigned long bestTreeScoreHits = 0;       // :129 (kept for link compatibility; the engine counts ties itself)
 bool first_call = true;                    // :140
 bool doing_stepwise_addition = false;      // :141
@@ -94,7 +102,11 @@ void ensure_engine(pllInstance *tr, partitionList *pr)
     cfg.n_patterns = P;
     cfg.datatype = pr->partitionData[0]->dataType == PLL_AA_DATA ? MPF_AA : MPF_DNA;
     cfg.keep_all_sites = !g_hooks.sort_alignment;
-    if (mpf_engine_create(&g_eng, &cfg, codes.data(), tr->aliaswgt)) die("mpf_engine_create");
+    if (pllCostMatrix) {
+      // the reference's dispatch on pllCostMatrix (:556-641, :967-1030): weighted engine, same entry points
+      if (pllCostNstates != (cfg.datatype == MPF_AA ? 20 : 4)) { std::fprintf(stderr, "mpfitch shim: cost matrix of %d states on %s data\n", pllCostNstates, cfg.datatype == MPF_AA ? "protein" : "DNA"); std::exit(EXIT_FAILURE); }
+      if (mpf_engine_create_sankoff(&g_eng, &cfg, codes.data(), tr->aliaswgt, pllCostMatrix)) die("mpf_engine_create_sankoff");
+    } else if (mpf_engine_create(&g_eng, &cfg, codes.data(), tr->aliaswgt)) die("mpf_engine_create");
     if (mpf_set_rand_callback(g_eng, draw, nullptr)) die("mpf_set_rand_callback");
     if (mpf_seed_ties(g_eng, MPF_TIE_RANDOM, 0)) die("mpf_seed_ties");
     g_n = n;
@@ -117,7 +129,14 @@ void ensure_engine(pllInstance *tr, partitionList *pr)
 void ensure_tracking()
 {
   if (g_hooks.gbo_replicates <= 0 || !g_hooks.boot_sample) return;
-  if (g_weights != g_first_weights) return;
+  if (g_weights != g_first_weights) {
+    if (!g_hooks.no_hclimb1_bb) {
+      std::fprintf(stderr, "mpfitch shim: -bb with ratchet climbs needs -no_hclimb1_bb: the engine books saveCurrentTree on the "
+                           "unperturbed alignment only (mpboot's default also books re-weighted climbs, iqtree.cpp:3283-3295)\n");
+      std::exit(EXIT_FAILURE);
+    }
+    return;
+  }
   if (!g_tracking) {
     const int B = g_hooks.gbo_replicates;
     std::vector<uint16_t> s((size_t)B * (size_t)g_P);
@@ -169,6 +188,17 @@ void resetGlobalParamOnNewAln()
   bestTreeScoreHits = 0;
   first_call = true;
   doing_stepwise_addition = false;
+}
+
+// initializeCostMatrix (:159-188; called from IQTree::initializePLL, iqtree.cpp:609, after pllCostMatrix is set): the
+// reference copies the matrix into its SIMD layout here; the engine takes pllCostMatrix itself at its creation, what
+// remains is highest_cost and making sure an engine built for another matrix is not reused
+void initializeCostMatrix()
+{
+  unsigned int m = 0;
+  for (int i = 0; i < pllCostNstates * pllCostNstates; i++) m = pllCostMatrix[i] > m ? pllCostMatrix[i] : m;
+  highest_cost = m + 1;
+  destroy_engine();
 }
 
 void _allocateParsimonyDataStructures(pllInstance *tr, partitionList *pr) { ensure_engine(tr, pr); }

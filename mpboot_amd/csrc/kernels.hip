@@ -1166,7 +1166,9 @@ __device__ __forceinline__ uint32_t join_hits(const Tile<S, VW> &u, const Tile<S
 
 struct ProgEnt4 { ProgEnt e[4]; };               // four entries = one 64-byte scalar load
 
-template <int S, int VW, bool BIG>
+// EXPR (experiments, MPF_PROG_EXPERIMENT): 0 = the kernel; 1 = no vector loads in the loop (children = register garbage:
+// arithmetic + control only); 2 = loads only (one AND per loaded register instead of the Fitch arithmetic)
+template <int S, int VW, bool BIG, int EXPR = 0>
 __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const uint32_t *__restrict__ vec, const WalkDesc *__restrict__ desc, int n_scans,
                                                          const ProgEnt *__restrict__ prog, uint32_t *__restrict__ out,
                                                          uint32_t *__restrict__ ncand, int Wp, int tiles, int map,
@@ -1236,11 +1238,19 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
         }
       }
       Tile<S, VW> u1, u2;
+      if constexpr (EXPR == 2) {
+#pragma unroll
+        for (int kk = 0; kk < S; kk++)
+#pragma unroll
+          for (int j = 0; j < VW; j++) { u1.v[kk][j] = par.v[kk][j] & d1.v[kk][j]; u2.v[kk][j] = par.v[kk][j] & d2.v[kk][j]; }
+        if (en.meta & (PE_T1 | PE_T2)) accp ^= u1.v[0][0] ^ u2.v[1][0];
+      } else {
       fitch<S, VW>(u2, par, d1);
       fitch<S, VW>(u1, par, d2);
       if (en.meta & (PE_T1 | PE_T2)) {
         const uint32_t c = join_hits<S, VW>(u1, d1, sv) | (join_hits<S, VW>(u2, d2, sv) << 16);
         accp = write_lane(accp, wave_total<0>(c), e);
+      }
       }
       if (en.meta & PE_SAVE) {
         if (dd == 1u) pend1 = u2;
@@ -1274,8 +1284,8 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
   {                                                                                  \
     const bool more = (E) + 1u < ne;                                                 \
     const uint32_t n1 = more ? (NX).c1 : safe, n2 = more ? (NX).c2 : safe;           \
-    MPF_LOAD(Y1, n1);                                                                \
-    MPF_LOAD(Y2, n2);                                                                \
+    if constexpr (EXPR == 1) { Y1 = X2; Y2 = X1; Y1.v[0][0] ^= n1; Y2.v[0][0] ^= n2; } \
+    else { MPF_LOAD(Y1, n1); MPF_LOAD(Y2, n2); }                                     \
     step(EN, E, X1, X2);                                                             \
     if (!more) break;                                                                \
   }
@@ -1864,6 +1874,10 @@ hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *v
   dim3 grid(nblocks);
   const ProgEnt *pg = static_cast<const ProgEnt *>(prog);
 #define SP(VW_, BIG_) hipLaunchKernelGGL((k_scan_prog<4, VW_, BIG_>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace)
+  static const int expr = getenv("MPF_PROG_EXPERIMENT") ? atoi(getenv("MPF_PROG_EXPERIMENT")) : 0;
+  if (expr == 1) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 1>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
+  else if (expr == 2) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 2>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
+  else
   if (g.big) SP(1, true);
   else if (vw == 1) SP(1, false);
   else SP(2, false);

@@ -350,6 +350,57 @@ static void cmd_spr(const char *treefile, int maxtrav)
   printf("final_check %u\n", evaluateParsimony(TR, PR, TR->start, PLL_TRUE));
 }
 
+/* ---- refine: one bootstrap-refinement replicate as IQTree::optimizeBootTrees runs it (iqtree.cpp:2515-2866 ->
+        pllOptimizeSprParsimony with on_opt_btree): the pattern weights of the replicate go into tr->aliaswgt (what
+        _updateInternalPllOnRatchet does, sprparsimony.cpp:3022-3029), the parsimony structures are rebuilt (compressDNA
+        on the new weights) and the sample's tree is hill-climbed.  Timed as a whole: bench.py's CPU side of the
+        bootstrap metric ("kind": "reference").  PLL-original first-best rule (the tie rule does not change the cost of
+        an insertion test). ---- */
+static void cmd_refine(const char *treefile, int maxtrav, const char *wfile)
+{
+  FILE *f = fopen(treefile, "r");
+  static char line[1 << 22];
+  int i, n, k, sweep = 0, moves = 0, P = TR->originalCrunchedLength;
+  unsigned int randomMP, startMP, first;
+  unsigned long long tests0;
+  double t0, t1;
+  if (!f) { perror(treefile); exit(2); }
+  if (!fgets(line, sizeof line, f)) exit(2);
+  fclose(f);
+  f = fopen(wfile, "r");
+  if (!f) { perror(wfile); exit(2); }
+  for (k = 0; k < P; k++) { int w; if (fscanf(f, "%d", &w) != 1) { fprintf(stderr, "weights: %d values expected\n", P); exit(2); } TR->aliaswgt[k] = w; }
+  fclose(f);
+  load_newick(line);
+  t0 = now_s();
+  allocateParsimonyDataStructures(TR, PR);
+  reset_orientation();
+  n = TR->mxtips;
+  TR->ntips = n;
+  nodeRectifierPars(TR);
+  TR->bestParsimony = UINT_MAX;
+  first = TR->bestParsimony = evaluateParsimony(TR, PR, TR->start, PLL_TRUE);
+  randomMP = TR->bestParsimony;
+  (void)tests0;
+  do {
+    startMP = randomMP;
+    nodeRectifierPars(TR);
+    for (i = 1; i <= 2 * n - 2; i++) {
+      rearrangeParsimony(TR, PR, TR->nodep[i], 1, maxtrav, PLL_FALSE);
+      if (TR->bestParsimony < randomMP) {
+        restoreTreeRearrangeParsimony(TR, PR);
+        randomMP = TR->bestParsimony;
+        moves++;
+      }
+    }
+    sweep++;
+  } while (randomMP < startMP);
+  t1 = now_s();
+  printf("refined start_score %u final_score %u moves %d sweeps %d seconds %.6f\n", first, randomMP, moves, sweep, t1 - t0);
+  TR->bestParsimony = UINT_MAX;
+  printf("final_check %u\n", evaluateParsimony(TR, PR, TR->start, PLL_TRUE));
+}
+
 /* ---- ras: the reference's own pllMakeParsimonyTreeFast, untouched ---- */
 static void cmd_ras(long seed, int sprDist)
 {
@@ -413,7 +464,8 @@ int main(int argc, char **argv)
   if (argc < 5) {
     fprintf(stderr,
       "usage: %s <cmd> <aln.phy> <DNA|WAG> <dedup 0|1> [args]\n"
-      "  dump | score <trees> | scan <tree> <maxtrav> | spr <tree> <maxtrav> | time <tree> <maxtrav> <seconds> | ras <seed> <sprDist> | rasx <seed>\n",
+      "  dump | score <trees> | scan <tree> <maxtrav> | spr <tree> <maxtrav> | time <tree> <maxtrav> <seconds> | ras <seed> <sprDist> | rasx <seed>\n"
+      "  refine <tree> <maxtrav> <pattern-weights file>\n",
       argv[0]);
     return 2;
   }
@@ -423,6 +475,7 @@ int main(int argc, char **argv)
   else if (!strcmp(argv[1], "scan")) cmd_scan(argv[5], atoi(argv[6]));
   else if (!strcmp(argv[1], "spr")) cmd_spr(argv[5], atoi(argv[6]));
   else if (!strcmp(argv[1], "time")) cmd_time(argv[5], atoi(argv[6]), atof(argv[7]));
+  else if (!strcmp(argv[1], "refine")) cmd_refine(argv[5], atoi(argv[6]), argv[7]);
   else if (!strcmp(argv[1], "ras")) cmd_ras(atol(argv[5]), atoi(argv[6]));
   else if (!strcmp(argv[1], "rasx")) cmd_rasx(atol(argv[5]));
   else { fprintf(stderr, "unknown command %s\n", argv[1]); return 2; }

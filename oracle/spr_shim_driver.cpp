@@ -9,7 +9,9 @@
  *     pllCalcMinParsScorePattern                           (iqtree.cpp:3827)
  * and prints what they leave in the pllInstance.  tests/test_gpu_dropin.py replays the same calls on the CPU oracle.
  *
- * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B>
+ * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B> [cost-matrix file]
+ * With a cost matrix (S x S unsigned entries, row-major) the program sets the globals IQTree::initializePLL sets for -cost
+ * (iqtree.cpp:601-615) and calls initializeCostMatrix(): the shim then dispatches to the weighted engine.
  */
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +32,11 @@ int pllOptimizeSprParsimony(pllInstance *tr, partitionList *pr, int mintrav, int
 void pllComputePatternParsimony(pllInstance *tr, partitionList *pr, unsigned short *ptn_pars, int *cur_pars);
 void pllComputeSiteParsimony(pllInstance *tr, partitionList *pr, int *site_pars, int nsite, int *cur_pars);
 int pllCalcMinParsScorePattern(pllInstance *tr, int dataType, int site);
+
+void initializeCostMatrix();
+// the globals iqtree.cpp:35-43 defines
+unsigned int *pllCostMatrix = nullptr;
+int pllCostNstates = 0;
 
 // ---- the "IQTree" of this program: just the members the shim's hooks read
 struct Host {
@@ -141,8 +148,22 @@ int main(int argc, char **argv)
   hooks.ufboot_epsilon = 0.5;
   hooks.logl_cutoff = hk_cutoff;
   hooks.ufboot_sync = hk_sync;
+  hooks.no_hclimb1_bb = 1;                         // this program plays mpboot -no_hclimb1_bb
   resetGlobalParamOnNewAln();
   mpfitch_shim_install(&hooks);
+  static std::vector<unsigned int> cost;
+  if (argc > 8) {
+    const int S = pr->partitionData[0]->states;
+    FILE *cf = std::fopen(argv[8], "r");
+    if (!cf) { std::perror(argv[8]); return 2; }
+    cost.resize((size_t)S * (size_t)S);
+    for (size_t i = 0; i < cost.size(); i++)
+      if (std::fscanf(cf, "%u", &cost[i]) != 1) { std::fprintf(stderr, "cost matrix: %d x %d entries expected\n", S, S); return 2; }
+    std::fclose(cf);
+    pllCostMatrix = cost.data();
+    pllCostNstates = S;
+    initializeCostMatrix();
+  }
   IQTree *iq = nullptr;
 
   // 1. start tree (phyloanalysis.cpp:1165: sprDist = 0 keeps it a pure stepwise addition)

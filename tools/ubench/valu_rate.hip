@@ -7,7 +7,7 @@
 
 #define REP16(X) X X X X X X X X X X X X X X X X
 template <int KIND>
-__global__ __launch_bounds__(512) void k(uint32_t *out, unsigned long long *cyc, int iters)
+__global__ __launch_bounds__(1024) void k(uint32_t *out, unsigned long long *cyc, int iters)
 {
   uint32_t a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, b0 = a0 ^ 0x55, b1 = a1 ^ 0x33, b2 = a2 ^ 0x0f, b3 = a3 ^ 0xff;
   uint32_t c0 = 1, c1 = 2, c2 = 3, c3 = 4;
@@ -47,7 +47,7 @@ void run(const char *name)
   printf("%-44s", name);
   for (int wps : {1, 2, 4, 8}) {                   // waves per SIMD: block = 256 * wps threads, one block per CU
     const int threads = 256 * wps > 1024 ? 1024 : 256 * wps;
-    const int blocks = 256 * (256 * wps / threads);
+    const int blocks = 256 * (256 * wps / threads);          // 8 waves per SIMD: two 1024-thread blocks per CU
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 10);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -55,6 +55,7 @@ void run(const char *name)
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, out, cyc, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (hipGetLastError() != hipSuccess) printf(" [launch error]");
     // instructions per SIMD = wps waves * iters * 64; at 4 cycles each and f GHz ...
     const double instr_per_simd = (double)wps * iters * 64.0;
     printf("  %dw: %.2f ns/instr/SIMD", wps, ms * 1e6 / instr_per_simd);
