@@ -1063,7 +1063,8 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
     const int total = cnt[0][0] + cnt[0][1] + cnt[1][0] + cnt[1][1];
     // throughput batches: a neighbourhood is one part unless it is long -- the waves of one launch should not differ
     // in length by two orders of magnitude (the longest ones would run on alone at the end)
-    if (!split && (total <= split_cands_ || maxtrav > 6 || scan_masks_)) {     // (masked scans: every part costs a home row of the REPS product) add(x, mt, 3u, 3u, total, cnt[0][0] + cnt[0][1]); return; }
+    // (masked scans stay whole: every part costs a home row of the REPS product)
+    if (!split && (total <= split_cands_ || maxtrav > 6 || scan_masks_)) { add(x, mt, 3u, 3u, total, cnt[0][0] + cnt[0][1]); return; }
     for (uint32_t side = 0; side < 2; side++) {
       if (tip(xs[side])) continue;
       add(x, mt, 1u << side, 1u, cnt[side][0], 0);
