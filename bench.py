@@ -250,6 +250,34 @@ def refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, gp
             "same_score_as_gpu": bool(int(gpu_scores[0]) == int(s_cpu))}
 
 
+def climb_cpu_baseline(names, letters, alphabet, back, maxtrav):
+    """A whole SPR hill climb from `back` on the reference's PLL AVX code (pll_ref_driver spr: the loop of
+    fastDNAparsimony.c:1919-1938, first-best rule), one thread."""
+    from mpboot_amd import synth, trees
+    drv = os.path.join(ROOT, "oracle", "_ref", "pll_ref_driver")
+    if not (os.path.exists(drv) and os.access(drv, os.X_OK)):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            aln, tf = os.path.join(tmp, "a.phy"), os.path.join(tmp, "t.nwk")
+            synth.write_phylip(aln, synth.letters_to_text(letters, alphabet), names)
+            with open(tf, "w") as f:
+                f.write(trees.back_to_newick(back, names) + "\n")
+            out = subprocess.run([drv, "spr", aln, "DNA" if alphabet == "DNA" else "WAG", "0", tf, str(maxtrav)], capture_output=True, text=True,
+                                 check=True, timeout=1800, env=dict(os.environ, REF_DRIVER_QUIET="1")).stdout
+        for l in out.splitlines():
+            t = l.split()
+            if t and t[0] == "climb":
+                fin = [x.split()[1] for x in out.splitlines() if x.startswith("final_score")]
+                return {"seconds": float(t[6]), "moves": int(t[2]), "sweeps": int(t[4]), "final_score": int(fin[0]) if fin else None,
+                        "cores": 1, "kind": "reference",
+                        "sample": "the whole climb from the same start tree, reference PLL AVX code, first-best rule (the GPU run draws "
+                                  "mpboot's random ties: another path to another local optimum of similar length)"}
+    except Exception as exc:
+        print(f"[bench] reference climb failed ({exc})", file=sys.stderr)
+    return None
+
+
 def launch_ranks(n: int) -> int:
     """Parent of a multi-GPU run: N child ranks through torch.distributed.run (one process per GPU, RCCL), stdout relayed.
     The parent itself never touches the GPU (no torch import, no HIP call) and never re-executes itself."""
@@ -316,6 +344,8 @@ def main():
     ap.add_argument("--bootstrap-replicates", type=int, default=1000,
                     help="samples of the online phase whose trees are refined afterwards (IQTree::optimizeBootTrees), "
                          "sharded over the GPUs; capped by --ufboot-samples (0 = skip)")
+    ap.add_argument("--random-start-leg", type=int, default=1,
+                    help="1 = also run the climb / -bb flow from a random topology (a start tree that is not already SPR-optimal)")
     ap.add_argument("--legs-timeout", type=int, default=180,
                     help="multi-GPU runs: seconds after which the headline line is printed without the secondary (-bb) legs")
     ap.add_argument("--engines-per-gpu", type=int, default=4, help="concurrent engines (host threads) per GPU in the refinement leg")
@@ -535,6 +565,8 @@ def main():
     #     rank b % n_gpus (strong scaling: the total number of samples is fixed).
     ufb = None
     boot = None
+    nondeg = None
+    back_r = None
     legs_error = None
     if args.ufboot_samples > 0:
         try:
@@ -587,10 +619,62 @@ def main():
                 tb = time.perf_counter() - tb0
                 boot = (n_rep, tb, float(np.mean(bscores)), float(np.mean(online_best)), bool((bscores <= online_best).all()))
                 eng.set_weights(np.ones(P, dtype=np.int32))
+            # ---- the same flow from a start tree that is NOT a local optimum (the RAS tree of this alignment already is one:
+            # zero moves above): a random topology, thousands of accepted moves, refinements that really climb
+            if args.random_start_leg:
+                back_r = shard.broadcast_tree(trees.random_topology(n, np.random.default_rng(2024)), 0, len(back))
+                eng.set_tree(back_r)
+                eng.reset_node_order()
+                eng.seed_ties(engine.TIE_RANDOM, 1)
+                eng.reset_stats()
+                barrier()
+                t0r = time.perf_counter()
+                s_plain = eng.optimize_spr(1, args.maxtrav)
+                barrier()
+                t_plain = time.perf_counter() - t0r
+                st_plain = eng.stats()
+                nondeg = {"start": "random topology (numpy default_rng(2024))", "start_score": eng.score_tree(back_r),
+                          "plain_climb": {"seconds": t_plain, "score": s_plain, "moves": st_plain["moves_applied"],
+                                          "insertion_tests": st_plain["insertion_tests"], "scan_launches": st_plain["scan_launches"],
+                                          "tests_per_s": st_plain["insertion_tests"] / t_plain}}
+                eng.ufboot_attach(samples, 0.5, shard=(rank, world))
+                eng.set_tree(back_r)
+                eng.reset_node_order()
+                eng.seed_ties(engine.TIE_RANDOM, 1)
+                eng.reset_stats()
+                barrier()
+                t0r = time.perf_counter()
+                s_bb = eng.optimize_spr(1, args.maxtrav)
+                barrier()
+                t_bb = time.perf_counter() - t0r
+                st_bb, cn_bb = eng.stats(), eng.ufboot_counters()
+                _l2, _c2, bt2 = eng.ufboot_state()
+                cache2, trees2 = {}, []
+                for b in range(B):
+                    t = int(bt2[b])
+                    if t not in cache2:
+                        cache2[t] = eng.ufboot_tree(t)
+                    trees2.append(cache2[t])
+                online2 = -_l2
+                eng.ufboot_detach()
+                barrier()
+                t0r = time.perf_counter()
+                if n_rep > 0:
+                    bs2, _ = bootstrap.refine_boot_trees(engines, samples[:n_rep], trees2[:n_rep], 11, args.maxtrav)
+                barrier()
+                t_ref2 = time.perf_counter() - t0r
+                eng.set_weights(np.ones(P, dtype=np.int32))
+                nondeg["bb_flow"] = {"online_phase_s": t_bb, "score": s_bb, "moves": st_bb["moves_applied"], "insertion_tests": st_bb["insertion_tests"],
+                                     "tests_per_s": st_bb["insertion_tests"] / t_bb, "events": cn_bb["events"], "tie_draws": cn_bb["tie_draws"],
+                                     "reps_kernel_ms": cn_bb["reps_kernel_ms"], "refined_samples": n_rep, "refinement_s": t_ref2,
+                                     "seconds": t_bb + t_ref2,
+                                     "mean_sample_score_online": float(np.mean(online2[:n_rep])) if n_rep else None,
+                                     "mean_sample_score_refined": float(np.mean(bs2)) if n_rep else None,
+                                     "samples_improved_by_refinement": int((bs2 < online2[:n_rep]).sum()) if n_rep else None}
             eng.set_tree(back)
         except Exception as exc:        # the headline metric above must survive a failing secondary leg
             legs_error = repr(exc)
-            ufb = boot = None
+            ufb = boot = nondeg = None
 
     watchdog.cancel()
     if rank == 0:
@@ -610,6 +694,10 @@ def main():
         if boot is not None and not args.no_cpu and world == 1:
             res["bootstrap_wall_clock"]["cpu_baseline"] = refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, bscores,
                                                                              args.maxtrav)
+        if nondeg is not None:
+            res["random_start"] = nondeg
+            if not args.no_cpu and world == 1:
+                nondeg["plain_climb"]["cpu_baseline"] = climb_cpu_baseline(names, letters, alphabet, back_r, args.maxtrav)
         if ufb is not None:
             algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples_local"]
             kms = ufb["reps_kernel_ms"]

@@ -193,6 +193,14 @@ int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t
      mpf_segment_patterns        : IQTree::doSegmenting (iqtree.cpp:3793-3820)
      mpf_remain_bounds           : IQTree::pllComputeRellRemainBound (iqtree.cpp:3842-3853) / pllRemainderLowerBounds
                                    (sprparsimony.cpp:2813-2819) for one weight vector */
+/* ParsTree::loadCostMatrixFile (parstree.cpp:31-95): `file_or_keyword` = "fitch" | "e" (unit costs for
+   n_states_alignment states) or the path of a text file "<nstates>  nstates x nstates entries"; the matrix is then closed
+   under the triangle inequality by the reference's own k-i-j loop (:74-80; *changed = 1 if that altered an entry).
+   cost has room for cap_states x cap_states entries.  The result is what mpf_engine_create_sankoff takes (the reference
+   copies it into pllCostMatrix, iqtree.cpp:601-615); that call still requires a symmetric matrix. */
+int mpf_cost_matrix_load(const char *file_or_keyword, int32_t n_states_alignment, int32_t cap_states, uint32_t *cost /* [cap*cap] */,
+                         int32_t *n_states, int32_t *changed);
+int mpf_cost_matrix_triangle_fix(int32_t n_states, uint32_t *cost /* [S*S], in place */, int32_t *changed);
 int mpf_min_pars_score_patterns(int32_t datatype, int32_t n_taxa, int32_t n_patterns, const uint8_t *codes /* [n][P] PLL tip codes */,
                                 int32_t *min_score /* [P] */);
 int mpf_mst_scores(int32_t n_states, const uint32_t *cost /* [S*S] */, int32_t n_taxa, int32_t n_patterns,

@@ -28,6 +28,7 @@ EXPORTS = [
     "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
+    "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
 ]
 
 
@@ -35,6 +36,15 @@ class MpfError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libmpfitch error {code}: {msg}")
         self.code = code
+
+
+def load_cost_matrix(file_or_keyword: str, n_states_alignment: int):
+    """ParsTree::loadCostMatrixFile: ("fitch" | "e" | path) -> (cost[S, S] uint32 after the triangle repair, repaired?)"""
+    cap = 64
+    cost = np.zeros(cap * cap, dtype=np.uint32)
+    S, ch = C.c_int32(), C.c_int32()
+    _chk(load_library().mpf_cost_matrix_load(str(file_or_keyword).encode(), n_states_alignment, cap, _p(cost), C.byref(S), C.byref(ch)))
+    return cost[:S.value * S.value].reshape(S.value, S.value).copy(), bool(ch.value)
 
 
 class Config(C.Structure):
@@ -115,6 +125,8 @@ def load_library():
         L.mpf_mst_scores.argtypes = [C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
         L.mpf_segment_patterns.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_remain_bounds.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp]
+        L.mpf_cost_matrix_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, vp]
+        L.mpf_cost_matrix_triangle_fix.argtypes = [C.c_int32, vp, vp]
         _lib = L
     return _lib
 

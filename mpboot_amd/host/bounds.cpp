@@ -7,6 +7,8 @@
 // numbers: mpboot's IQTree::doSegmenting / pllComputeRellRemainBound bookkeeping, and its reports.
 #include <climits>
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -111,4 +113,46 @@ int mpf_remain_bounds(int32_t n_units, int32_t n_segments, const int32_t *segmen
   return MPF_OK;
 }
 
+
+// ParsTree::loadCostMatrixFile (reference parstree.cpp:31-95): "fitch" / "e" = unit costs (:42-49), otherwise a text file
+// "<nstates> then nstates x nstates unsigned entries" (:50-68); then the in-place closure under the triangle inequality,
+// literally the reference's k-i-j loop over unsigned entries (:74-80) -- the repaired matrix is what every later
+// computation uses (IQTree::initializePLL copies it into pllCostMatrix, iqtree.cpp:601-615).
+int mpf_cost_matrix_triangle_fix(int32_t n_states, uint32_t *cost, int32_t *changed)
+{
+  if (!cost || n_states < 1) { set_error("mpf_cost_matrix_triangle_fix: bad argument"); return MPF_E_INVALID; }
+  bool ch = false;
+  const int S = n_states;
+  for (int k = 0; k < S; k++)
+    for (int i = 0; i < S; i++)
+      for (int j = 0; j < S; j++)
+        if (cost[i * S + j] > cost[i * S + k] + cost[k * S + j]) {
+          ch = true;
+          cost[i * S + j] = cost[i * S + k] + cost[k * S + j];
+        }
+  if (changed) *changed = ch ? 1 : 0;
+  return MPF_OK;
+}
+
+int mpf_cost_matrix_load(const char *file_or_keyword, int32_t n_states_alignment, int32_t cap_states, uint32_t *cost,
+                         int32_t *n_states, int32_t *changed)
+{
+  if (!file_or_keyword || !cost || !n_states || cap_states < 1) { set_error("mpf_cost_matrix_load: bad argument"); return MPF_E_INVALID; }
+  int S = 0;
+  if (!std::strcmp(file_or_keyword, "fitch") || !std::strcmp(file_or_keyword, "e")) {
+    S = n_states_alignment;
+    if (S < 1 || S > cap_states) { set_error("mpf_cost_matrix_load: state count does not fit the caller's buffer"); return MPF_E_INVALID; }
+    for (int i = 0; i < S; i++)
+      for (int j = 0; j < S; j++) cost[i * S + j] = i == j ? 0u : 1u;
+  } else {
+    std::FILE *f = std::fopen(file_or_keyword, "r");
+    if (!f) { set_error(std::string("cannot read cost matrix file ") + file_or_keyword); return MPF_E_INVALID; }   // outError, :54-56
+    if (std::fscanf(f, "%d", &S) != 1 || S < 1 || S > cap_states) { std::fclose(f); set_error("cost matrix file: bad state count"); return MPF_E_INVALID; }
+    for (int i = 0; i < S * S; i++)
+      if (std::fscanf(f, "%u", &cost[i]) != 1) { std::fclose(f); set_error("cost matrix file: fewer than nstates x nstates entries"); return MPF_E_INVALID; }
+    std::fclose(f);
+  }
+  *n_states = S;
+  return mpf_cost_matrix_triangle_fix(S, cost, changed);
+}
 }  // extern "C"

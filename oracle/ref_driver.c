@@ -312,11 +312,13 @@ static void cmd_spr(const char *treefile, int maxtrav)
 {
   FILE *f = fopen(treefile, "r");
   static char line[1 << 22];
-  int i, n, sweep = 0;
+  int i, n, sweep = 0, total_moves = 0;
   unsigned int randomMP, startMP;
+  double t_climb;
   if (!f) { perror(treefile); exit(2); }
   if (!fgets(line, sizeof line, f)) exit(2);
   fclose(f);
+  QUIET = getenv("REF_DRIVER_QUIET") != NULL;      /* timing runs (bench.py): no per-move lines, no topologies */
   allocateParsimonyDataStructures(TR, PR);
   load_newick(line);
   reset_orientation();
@@ -326,8 +328,9 @@ static void cmd_spr(const char *treefile, int maxtrav)
   TR->bestParsimony = UINT_MAX;
   TR->bestParsimony = evaluateParsimony(TR, PR, TR->start, PLL_TRUE);
   printf("start_score %u\n", TR->bestParsimony);
-  print_topology("start_topology");
+  if (!QUIET) print_topology("start_topology");
   randomMP = TR->bestParsimony;
+  t_climb = now_s();
   do {
     int moves = 0;
     startMP = randomMP;
@@ -335,7 +338,8 @@ static void cmd_spr(const char *treefile, int maxtrav)
     for (i = 1; i <= 2 * n - 2; i++) {
       rearrangeParsimony(TR, PR, TR->nodep[i], 1, maxtrav, PLL_FALSE);
       if (TR->bestParsimony < randomMP) {
-        printf("move %d %d %d %u\n", sweep, rec_of(TR->removeNode), rec_of(TR->insertNode), TR->bestParsimony);
+        if (!QUIET) printf("move %d %d %d %u\n", sweep, rec_of(TR->removeNode), rec_of(TR->insertNode), TR->bestParsimony);
+        total_moves++;
         restoreTreeRearrangeParsimony(TR, PR);
         randomMP = TR->bestParsimony;
         moves++;
@@ -344,8 +348,9 @@ static void cmd_spr(const char *treefile, int maxtrav)
     printf("sweep %d score %u moves %d\n", sweep, randomMP, moves);
     sweep++;
   } while (randomMP < startMP);
+  printf("climb moves %d sweeps %d seconds %.6f\n", total_moves, sweep, now_s() - t_climb);
   printf("final_score %u\n", randomMP);
-  print_topology("final_topology");
+  if (!QUIET) print_topology("final_topology");
   TR->bestParsimony = UINT_MAX;
   printf("final_check %u\n", evaluateParsimony(TR, PR, TR->start, PLL_TRUE));
 }

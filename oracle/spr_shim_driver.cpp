@@ -182,12 +182,14 @@ int main(int argc, char **argv)
     std::printf("ptn_total %d\nptn_pars", cur);
     for (int p = 0; p < P; p++) std::printf(" %u", (unsigned)pp[(size_t)p]);
     std::printf("\n");
-    int nsite = 0;
-    for (int p = 0; p < P; p++) nsite += tr->aliaswgt[p];
-    std::vector<int> sp((size_t)nsite + 8, -1);
-    pllComputeSiteParsimony(tr, pr, sp.data(), nsite + 8, &cur);
-    std::printf("site_total %d\nsite_pars", cur);
-    for (int s = 0; s < nsite + 8; s++) std::printf(" %d", sp[(size_t)s]);
+    if (!pllCostMatrix) {                          // per-site counters exist in the Fitch engine only (sprparsimony.cpp:294-376)
+      int nsite = 0;
+      for (int p = 0; p < P; p++) nsite += tr->aliaswgt[p];
+      std::vector<int> sp((size_t)nsite + 8, -1);
+      pllComputeSiteParsimony(tr, pr, sp.data(), nsite + 8, &cur);
+      std::printf("site_total %d\nsite_pars", cur);
+      for (int s = 0; s < nsite + 8; s++) std::printf(" %d", sp[(size_t)s]);
+    }
     std::printf("\nmin_pars");
     for (int p = 0; p < P; p++) std::printf(" %d", pllCalcMinParsScorePattern(tr, pr->partitionData[0]->dataType, p));
     std::printf("\n");

@@ -102,3 +102,44 @@ def test_segmenting_and_remain_bounds():
 def test_bad_arguments():
     with pytest.raises(engine.MpfError):
         engine.mst_scores(np.zeros((3, 3), dtype=np.int8), np.zeros((1, 1), dtype=np.uint32))
+
+
+def _triangle_fix_plain(c):
+    """ParsTree::loadCostMatrixFile's repair loop (parstree.cpp:74-80), transcribed for the check"""
+    c = [[int(v) for v in row] for row in c]
+    S, changed = len(c), False
+    for k in range(S):
+        for i in range(S):
+            for j in range(S):
+                if c[i][j] > c[i][k] + c[k][j]:
+                    c[i][j] = c[i][k] + c[k][j]
+                    changed = True
+    return c, changed
+
+
+def test_cost_matrix_loader_and_triangle_repair(tmp_path):
+    """mpf_cost_matrix_load: keywords, a file, and the triangle-inequality repair (symmetric and asymmetric input)"""
+    from mpboot_amd import engine
+    for kw, S in (("fitch", 4), ("e", 20)):
+        c, ch = engine.load_cost_matrix(kw, S)
+        assert c.shape == (S, S) and not ch
+        assert (c == (1 - np.eye(S, dtype=np.uint32))).all()
+    rng = np.random.default_rng(3)
+    for S, sym in ((4, True), (4, False), (20, True), (20, False)):
+        m = rng.integers(1, 30, size=(S, S))
+        if sym:
+            m = np.triu(m, 1) + np.triu(m, 1).T
+        np.fill_diagonal(m, 0)
+        f = tmp_path / f"cost_{S}_{int(sym)}.txt"
+        f.write_text(f"{S}\n" + "\n".join(" ".join(map(str, r)) for r in m.tolist()) + "\n")
+        c, ch = engine.load_cost_matrix(str(f), S)
+        exp, exp_ch = _triangle_fix_plain(m.tolist())
+        assert c.tolist() == exp and ch == exp_ch
+        if sym:
+            assert (c == c.T).all()                   # the repair keeps a symmetric matrix symmetric
+        assert all(c[i, j] <= c[i, k] + c[k, j] for i in range(S) for j in range(S) for k in range(S))
+    with pytest.raises(engine.MpfError):
+        engine.load_cost_matrix(str(tmp_path / "missing.txt"), 4)
+    (tmp_path / "short.txt").write_text("4\n0 1 1\n")
+    with pytest.raises(engine.MpfError):
+        engine.load_cost_matrix(str(tmp_path / "short.txt"), 4)
