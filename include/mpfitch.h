@@ -239,6 +239,14 @@ int mpf_ufboot_attach_sharded(mpf_engine *e, int32_t n_samples, int32_t n_local,
                               mpf_ufb_exchange_fn exchange, void *arg);
 int mpf_ufboot_detach(mpf_engine *e);
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff);            /* IQTree::logl_cutoff; 0 = none */
+/* Climbs under other pattern weights than the attach-time ones (ratchet iterations: mpf_set_weights between attach and
+   mpf_optimize_spr) are booked as the reference's default books them (iqtree.cpp:3283-3295): the length a candidate is
+   filtered and recorded with is the ORIGINAL-alignment length of the tree booked last (of the climb's start tree for
+   the first candidate) -- saveCurrentTree recomputes cur_logl from _pattern_pars before refreshing that array --, the
+   per-sample REPS are the candidate's own.  on = 0 is params->no_hclimb1_bb (iqtree.cpp:3280): such climbs run without
+   saveCurrentTree.  Takes effect at the next mpf_set_weights.  Weights that give an attach-time pattern weight 0 suspend
+   the bookkeeping in either case (mpboot's ratchet only adds copies of sites). */
+int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on);
 /* the main loop's per-iteration cut-off update, "top percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10) */
 int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff);
 int mpf_ufboot_num_trees(const mpf_engine *e, int64_t *n_trees);         /* treels_logl.size() */

@@ -29,10 +29,8 @@ struct mpf_mpboot_hooks {
   const unsigned short *(*boot_sample)(IQTree *, int b);    // iqtree->boot_samples_pars[b], nptn entries (iqtree.cpp:213-313)
   double ufboot_epsilon;                          // globalParam->ufboot_epsilon (iqtree.cpp:3594)
   double (*logl_cutoff)(IQTree *);                // iqtree->logl_cutoff (iqtree.cpp:3343)
-  // globalParam->no_hclimb1_bb (tools.cpp:795, iqtree.cpp:3280).  The engine books saveCurrentTree on the unperturbed
-  // alignment only, which is mpboot's behaviour under -no_hclimb1_bb; with the default (0) mpboot also books the
-  // candidates of ratchet climbs (iqtree.cpp:3283-3295), so under -bb the shim REFUSES a ratchet climb unless this is 1
-  // -- a run that would silently keep other boot_trees than mpboot's must not start
+  // globalParam->no_hclimb1_bb (tools.cpp:795, iqtree.cpp:3280): 1 = ratchet climbs run without saveCurrentTree; 0 (mpboot's
+  // default) = they are booked too, with the cur_logl of iqtree.cpp:3283-3295 (mpf_ufboot_set_ratchet_booking)
   int no_hclimb1_bb;
   // called at the end of every pllOptimizeSprParsimony with the engine that holds the saveCurrentTree bookkeeping of
   // this climb: copy treels_logl / boot_logl / boot_counts / boot_trees back with mpf_ufboot_* 

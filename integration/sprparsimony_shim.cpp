@@ -124,24 +124,19 @@ void ensure_engine(pllInstance *tr, partitionList *pr)
   }
 }
 
-// IQTree::saveCurrentTree's bookkeeping for the SPR path (perSiteScores = gbo_replicates > 0, :3245).  It follows the
-// unperturbed alignment; a re-weighted climb runs without it (the reference's -no_hclimb1_bb behaviour, iqtree.cpp:3280).
+// IQTree::saveCurrentTree's bookkeeping for the SPR path (perSiteScores = gbo_replicates > 0, :3245).  The tracker is
+// attached once, on the unperturbed alignment (its weights are IQTree's original_sample); re-weighted (ratchet) climbs
+// are booked by the engine as the reference books them (iqtree.cpp:3283-3295) unless -no_hclimb1_bb (:3280).
 void ensure_tracking()
 {
   if (g_hooks.gbo_replicates <= 0 || !g_hooks.boot_sample) return;
-  if (g_weights != g_first_weights) {
-    if (!g_hooks.no_hclimb1_bb) {
-      std::fprintf(stderr, "mpfitch shim: -bb with ratchet climbs needs -no_hclimb1_bb: the engine books saveCurrentTree on the "
-                           "unperturbed alignment only (mpboot's default also books re-weighted climbs, iqtree.cpp:3283-3295)\n");
-      std::exit(EXIT_FAILURE);
-    }
-    return;
-  }
   if (!g_tracking) {
+    if (g_weights != g_first_weights) return;          // (first call on perturbed weights: attach when the original ones are back)
     const int B = g_hooks.gbo_replicates;
     std::vector<uint16_t> s((size_t)B * (size_t)g_P);
     for (int b = 0; b < B; b++) std::memcpy(&s[(size_t)b * (size_t)g_P], g_hooks.boot_sample(iqtree, b), (size_t)g_P * sizeof(uint16_t));
     if (mpf_ufboot_attach(g_eng, B, s.data(), g_hooks.ufboot_epsilon)) die("mpf_ufboot_attach");
+    if (mpf_ufboot_set_ratchet_booking(g_eng, g_hooks.no_hclimb1_bb ? 0 : 1)) die("mpf_ufboot_set_ratchet_booking");
     g_tracking = true;
   }
   if (g_hooks.logl_cutoff && mpf_ufboot_set_cutoff(g_eng, g_hooks.logl_cutoff(iqtree))) die("mpf_ufboot_set_cutoff");
@@ -247,7 +242,8 @@ int pllOptimizeSprParsimony(pllInstance *tr, partitionList *pr, int mintrav, int
   if (mpf_optimize_spr(g_eng, mintrav, maxtrav, &score)) die("mpf_optimize_spr");
   pull_tree(tr);
   tr->bestParsimony = score;
-  if (g_tracking && g_weights == g_first_weights && g_hooks.ufboot_sync) g_hooks.ufboot_sync(iqtree, g_eng);
+  // (a climb that was booked: on the original weights always, on perturbed ones unless -no_hclimb1_bb)
+  if (g_tracking && (g_weights == g_first_weights || !g_hooks.no_hclimb1_bb) && g_hooks.ufboot_sync) g_hooks.ufboot_sync(iqtree, g_eng);
   return (int)score;                       // startMP of the last sweep = the final score (:3318)
 }
 

@@ -247,10 +247,23 @@ int Engine::pack()
 int Engine::set_weights(const int32_t *weights)
 {
   wgt_.assign(weights, weights + P_);
-  // the tracker's sample weights are laid out by site position of the attach-time packing: while other weights are in
-  // force (ratchet climbs) the bookkeeping is suspended; restoring the attach-time weights resumes it with its state
-  if (ufb_) { ufb_->suspended = wgt_ != ufb_->attach_wgt; ufb_->rt_valid = false; }
-  return pack();
+  // An attached tracker follows the re-weighting: its sample weights are laid out again by the sites of the new packing and
+  // climbs under other weights than the attach-time ones are booked as the reference books ratchet climbs
+  // (iqtree.cpp:3283-3295; host/ufboot.cpp).  Only weights that leave an attach-time pattern WITHOUT a site (weight 0 --
+  // mpboot's ratchet only adds copies, alignment.cpp:1915-1969) suspend the bookkeeping until other weights arrive.
+  if (ufb_) {
+    const bool other = wgt_ != ufb_->attach_wgt;
+    bool lost = false;
+    if (other)
+      for (int k = 0; k < P_ && !lost; k++) lost = ufb_->attach_wgt[(size_t)k] > 0 && wgt_[(size_t)k] <= 0;
+    ufb_->suspended = (other && lost) || (other && !ufb_->ratchet_booking);
+    ufb_->ratchet = other && !ufb_->suspended;
+    ufb_->rt_valid = false;
+  }
+  int rc = pack();
+  if (rc) return rc;
+  if (ufb_ && !ufb_->suspended) return ufb_layout_weights();
+  return MPF_OK;
 }
 
 int Engine::tip_vector(int tipno, uint32_t *out)

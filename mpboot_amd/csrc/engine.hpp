@@ -137,8 +137,20 @@ struct UfbState {
   PinBuf<UfbEvent> h_ev;
   PinBuf<uint32_t> h_small;                      // staging: thr | home | best | event count
   bool rt_valid = false;
-  std::vector<int32_t> attach_wgt;               // pattern weights in force at attach time
-  bool suspended = false;                        // other weights in force (mpf_set_weights): climbs run without bookkeeping
+  std::vector<int32_t> attach_wgt;               // pattern weights in force at attach time = IQTree's original_sample
+  bool suspended = false;                        // weights in force that leave an attach-time pattern without a site: no bookkeeping
+  // re-weighted (ratchet) climbs, reference iqtree.cpp:3283-3295: saveCurrentTree replaces cur_logl by the REPS of
+  // _pattern_pars against original_sample BEFORE that array is refreshed for the candidate -- i.e. by the original-
+  // alignment length of the tree booked last (or of the climb's start tree, which the IQ-TREE kernel left there)
+  bool ratchet = false;                          // other weights than attach_wgt in force, every attach-time pattern still packed
+  uint32_t stale_len = 0;                        // that length: what the cut-off filter sees and treels_logl records
+  uint32_t rt_orig = 0;                          // original-alignment length of the current tree (host copy of rt[orig column])
+  bool gate_closed = false;                      // a booked tree failed the cut-off: nothing else is booked in this climb
+  bool ratchet_booking = true;                   // false = params->no_hclimb1_bb (iqtree.cpp:3280): re-weighted climbs are not booked
+  DevBuf<uint16_t> d_samples;                    // [Bl + 1][P]: the local samples as given + the row of original frequencies
+  DevBuf<int32_t> d_first, d_cur;                // per pattern: first expanded site / weight of the packing in force
+  DevBuf<int32_t> d_col;                         // one column of C, contiguous
+  PinBuf<int32_t> h_col;
 };
 
 class Engine {
@@ -207,6 +219,7 @@ class Engine {
   void ufboot_detach();
   bool ufboot_attached() const { return (bool)ufb_; }
   int ufboot_set_cutoff(double logl_cutoff);
+  int ufboot_set_ratchet_booking(int on);
   double ufboot_next_cutoff(int percent) const;
   int ufboot_n_samples() const;
   int64_t ufboot_n_trees() const;
@@ -251,6 +264,7 @@ class Engine {
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);
   int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)
+  int ufb_layout_weights();                      // the product's right-hand side for the packing in force
   void ufb_store_tree(int64_t tree_index, int remove_rec, int insert_rec);
   void ufb_flush_pending(const ScanPlan &pl);
 

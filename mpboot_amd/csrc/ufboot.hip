@@ -289,6 +289,36 @@ __global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ in
   }
 }
 
+// ------------------------------------------------------------------------------------------------ weight layout
+// The product's right-hand side holds, for every 32-site word pair, the weights of the samples at the FIRST expanded
+// site of each pattern (the site pllComputePatternParsimony reads, sprparsimony.cpp:3382-3387).  The site of a pattern
+// moves whenever the alignment is re-weighted (ratchet climbs re-pack the sites), so the layout is a device pass over
+// the samples as uploaded: src[col][ptn] uint16, col = local sample (or the extra column of the original pattern
+// frequencies), first[ptn] = first expanded site of the pattern in the packing in force (-1: not packed), cur[ptn] = its
+// current weight (0: it owns no site).  Wt is zeroed by the caller.
+__global__ __launch_bounds__(256) void k_ufb_layout(const uint16_t *__restrict__ src, int n_cols, int P, const int32_t *__restrict__ first,
+                                                    const int32_t *__restrict__ cur, uint8_t *__restrict__ Wt, int Bp, int planes,
+                                                    size_t plane_bytes)
+{
+  const int ptn = blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = blockIdx.y;
+  if (ptn >= P || col >= n_cols) return;
+  const uint32_t w = src[(size_t)col * P + ptn];
+  const int site = first[ptn];
+  if (!w || site < 0 || cur[ptn] <= 0) return;
+  const int word = site >> 5, bit = site & 31;
+  const int kb = word >> 1, within = (word & 1) * 32 + bit, h = within >> 4, j = within & 15;
+  const size_t off = (size_t)kb * ((size_t)(Bp / 16) * 1024) + (size_t)h * 256 + (size_t)j + (size_t)(col >> 4) * 1024 + (size_t)(col & 15) * 16;
+  for (int pl = 0; pl < planes; pl++) Wt[(size_t)pl * plane_bytes + off] = (uint8_t)((w >> (7 * pl)) & 0x7Fu);
+}
+
+// out[i] = C[i][col]: one column of the product, contiguous (the original-frequency column of a re-weighted climb)
+__global__ __launch_bounds__(256) void k_ufb_column(const int32_t *__restrict__ C, int Bp, int col, uint32_t rows, int32_t *__restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) out[i] = C[(size_t)i * Bp + col];
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops, uint32_t *masks)
 {
@@ -378,6 +408,22 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
   hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, rt, n_idx, cmin);
   hipLaunchKernelGGL(k_ufb_prefix, dim3((Bp + 255) / 256), block, 0, st, cmin, best, Bp, nc, pre);
   hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src, int n_cols, int P, const int32_t *first, const int32_t *cur, uint8_t *Wt,
+                             int Bp, int planes, size_t plane_bytes)
+{
+  hipError_t e = hipMemsetAsync(Wt, 0, plane_bytes * (size_t)planes, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ufb_layout, dim3((P + 255) / 256, n_cols), dim3(256), 0, st, src, n_cols, P, first, cur, Wt, Bp, planes, plane_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_ufb_column(hipStream_t st, const int32_t *C, int Bp, int col, uint32_t rows, int32_t *out)
+{
+  if (!rows) return hipSuccess;
+  hipLaunchKernelGGL(k_ufb_column, dim3((rows + 255) / 256), dim3(256), 0, st, C, Bp, col, rows, out);
   return hipGetLastError();
 }
 

@@ -27,4 +27,10 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
                              const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
                              uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count);
 
+// Wt (zeroed here) <- the samples' weights at the first expanded site of every pattern of the packing in force
+hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src /* [n_cols][P] */, int n_cols, int P, const int32_t *first_site,
+                             const int32_t *cur_weight, uint8_t *Wt, int Bp, int planes, size_t plane_bytes);
+// out[i] = C[i][col], i < rows
+hipError_t launch_ufb_column(hipStream_t st, const int32_t *C, int Bp, int col, uint32_t rows, int32_t *out);
+
 }  // namespace mpf

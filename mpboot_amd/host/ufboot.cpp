@@ -50,30 +50,25 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   u->exchange = exchange;
   u->exchange_arg = exchange_arg;
   n_samples = n_local;                                     // from here on: the local weight vectors
-  u->Bp = round_up(n_samples, kUfbColTile);
+  // one extra column behind the local samples: the pattern frequencies in force now (IQTree's original_sample).  Its
+  // REPS is the length of a tree on the original alignment, which re-weighted (ratchet) climbs book instead of their own
+  u->Bp = round_up(n_samples + 1, kUfbColTile);
   u->eps = epsilon;
   uint32_t wmax = 0;
   for (size_t i = 0; i < (size_t)n_samples * (size_t)P_; i++) wmax = std::max<uint32_t>(wmax, samples[i]);
+  std::vector<uint16_t> orig((size_t)P_);
+  for (int p = 0; p < P_; p++) {
+    if (wgt_[(size_t)p] > 65535) { set_error("ufboot_attach: pattern frequency above 65535"); return MPF_E_UNSUPPORTED; }
+    orig[(size_t)p] = (uint16_t)wgt_[(size_t)p];
+    wmax = std::max<uint32_t>(wmax, orig[(size_t)p]);
+  }
   u->planes = wmax < 128 ? 1 : (wmax < 16384 ? 2 : 3);
   const int nkb = g_.Wp / 2;
   u->plane_bytes = (size_t)nkb * (size_t)u->Bp * 64;
-  std::vector<uint8_t> wt(u->plane_bytes * (size_t)u->planes, 0);
-  const size_t kstride = (size_t)(u->Bp / 16) * 1024;
-  for (int ptn = 0; ptn < P_; ptn++) {
-    const int site = first_site_[(size_t)ptn];
-    if (site < 0) continue;                                  // uninformative: its length is 0 in every tree
-    const int word = site >> 5, bit = site & 31;
-    const int kb = word >> 1, within = (word & 1) * 32 + bit, h = within >> 4, j = within & 15;
-    uint8_t *base = wt.data() + (size_t)kb * kstride + (size_t)h * 256 + (size_t)j;
-    for (int b = 0; b < n_samples; b++) {
-      const uint32_t w = samples[(size_t)b * (size_t)P_ + (size_t)ptn];
-      if (!w) continue;
-      const size_t off = (size_t)(b >> 4) * 1024 + (size_t)(b & 15) * 16;
-      for (int pl = 0; pl < u->planes; pl++) base[(size_t)pl * u->plane_bytes + off] = (uint8_t)((w >> (7 * pl)) & 0x7Fu);
-    }
-  }
-  UCHK(u->wt.reserve(wt.size()));
-  UCHK(hipMemcpyAsync(u->wt.p, wt.data(), wt.size(), hipMemcpyHostToDevice, st_));
+  UCHK(u->d_samples.reserve((size_t)(n_samples + 1) * (size_t)P_));
+  UCHK(hipMemcpyAsync(u->d_samples.p, samples, (size_t)n_samples * (size_t)P_ * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
+  UCHK(hipMemcpyAsync(u->d_samples.p + (size_t)n_samples * (size_t)P_, orig.data(), (size_t)P_ * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
+  UCHK(hipStreamSynchronize(st_));                         // (orig is a local)
   UCHK(u->rt.reserve((size_t)u->Bp));
   UCHK(u->best.reserve((size_t)u->Bp));
   UCHK(u->evcount.reserve(4));
@@ -85,6 +80,23 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   u->attach_wgt = wgt_;
   ufb_pool_swap(*u);                               // scratch buffers of an earlier tracker, if any
   ufb_ = std::move(u);
+  return ufb_layout_weights();
+}
+
+// (re)build the product's right-hand side for the packing in force: called at attach time and after every re-weighting
+int Engine::ufb_layout_weights()
+{
+  UfbState &u = *ufb_;
+  const int nkb = g_.Wp / 2;
+  u.plane_bytes = (size_t)nkb * (size_t)u.Bp * 64;          // (Wp follows the packing)
+  UCHK(u.wt.reserve(u.plane_bytes * (size_t)u.planes));
+  UCHK(u.d_first.reserve((size_t)P_));
+  UCHK(u.d_cur.reserve((size_t)P_));
+  UCHK(hipMemcpyAsync(u.d_first.p, first_site_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  UCHK(hipMemcpyAsync(u.d_cur.p, wgt_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  UCHK(launch_ufb_layout(st_, u.d_samples.p, u.Bl + 1, P_, u.d_first.p, u.d_cur.p, u.wt.p, u.Bp, u.planes, u.plane_bytes));
+  UCHK(hipStreamSynchronize(st_));
+  u.rt_valid = false;
   return MPF_OK;
 }
 
@@ -120,6 +132,15 @@ int Engine::ufboot_set_cutoff(double logl_cutoff)
 {
   if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
   ufb_->logl_cutoff = logl_cutoff;
+  return MPF_OK;
+}
+
+// params->no_hclimb1_bb (tools.cpp:795; iqtree.cpp:3280): 0 = climbs on other weights than the attach-time ones run without
+// saveCurrentTree; takes effect at the next mpf_set_weights
+int Engine::ufboot_set_ratchet_booking(int on)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  ufb_->ratchet_booking = on != 0;
   return MPF_OK;
 }
 
@@ -267,6 +288,25 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   bool have_C = false;
   uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
+  const bool ratchet = u.ratchet;
+  const int oc = u.Bl;                             // the column of the original pattern frequencies
+  auto read_rt_orig = [&]() -> int {
+    UCHK(u.h_col.reserve(4));
+    UCHK(hipMemcpyAsync(u.h_col.p, u.rt.p + oc, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+    UCHK(hipStreamSynchronize(st_));
+    u.rt_orig = (uint32_t)u.h_col.p[0];
+    return MPF_OK;
+  };
+  if (ratchet) {
+    // what the IQ-TREE kernel left in _pattern_pars before this climb: the start tree (optimizeAllBranches ->
+    // computeParsimony on the perturbed alignment, iqtree.cpp:1712-1714); its REPS against original_sample is the
+    // start tree's length on the original alignment
+    int rc = read_rt_orig();
+    if (rc) return rc;
+    u.stale_len = u.rt_orig;
+    u.gate_closed = false;
+  }
+  std::vector<int32_t> lcol;                       // ratchet: the original-frequency column of the product, per mask row
   do {
     startMP = randomMP;
     node_rectifier();
@@ -312,7 +352,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       // with a cut-off only the saved candidates (and the home rows of their parts) are multiplied: this lists their
       // mask rows (`sel_rows`), crow maps a scan output index to its row of C
       const uint2 *hinfo = u.h_info.p;
-      const bool compact = have_cut && !none_pass;
+      // (re-weighted climbs are filtered by the length booked last, not by the candidate's own: every row is multiplied,
+      //  until a booked tree fails the cut-off -- from then on nothing of this climb is booked)
+      const bool skip_product = ratchet ? (u.gate_closed || none_pass || (have_cut && u.stale_len > mp_max)) : none_pass;
+      const bool compact = have_cut && !none_pass && !ratchet;
       uint32_t n_rows = n_idx;
       if (compact) {
         sel_rows.clear();
@@ -340,7 +383,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         n_rows = (uint32_t)sel_rows.size();
       }
       have_C = false;
-      if (n_idx > 0 && !none_pass && n_rows > 0) {
+      if (n_idx > 0 && !skip_product && n_rows > 0) {
         const int rows_p = round_up((int)n_rows, kUfbRowTile);
         // staging: thr[n_parts] | home[n_parts] | best[Bp] | crow[n_idx] | sel[rows_p]
         const size_t o_crow = (size_t)2 * n_parts + (size_t)u.Bp, o_sel = o_crow + (compact ? (size_t)n_idx : 0);
@@ -349,7 +392,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           const ScanPlan &pl = plans[(size_t)j];
           for (int pi = 0; pi < pl.n_parts; pi++) {
             const uint32_t d = (uint32_t)pl.part_desc[pi];
-            small[d] = !have_cut ? UINT32_MAX : (mp_max >= pl.base ? mp_max - pl.base + 1u : 0u);   // max cost + 1
+            small[d] = (!have_cut || ratchet) ? UINT32_MAX : (mp_max >= pl.base ? mp_max - pl.base + 1u : 0u);   // max cost + 1
             small[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
           }
         }
@@ -375,6 +418,12 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         if (timing_) UCHK(hipEventRecord(ev3_, st_));
         u.gemm_rows += (uint64_t)rows_p;
         have_C = true;
+        if (ratchet) {
+          UCHK(u.d_col.reserve((size_t)rows_p));
+          UCHK(u.h_col.reserve((size_t)rows_p));
+          UCHK(launch_ufb_column(st_, u.C.p, u.Bp, oc, n_rows, u.d_col.p));
+          UCHK(hipMemcpyAsync(u.h_col.p, u.d_col.p, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost, st_));   // synchronised with the event count below
+        }
         while (true) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
@@ -398,6 +447,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         t1 = now_ms();
         u.t_dev += t1 - t0;
         events.assign(u.h_ev.p, u.h_ev.p + n_ev);
+        if (ratchet) lcol.assign(u.h_col.p, u.h_col.p + n_rows);
         for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];       // local column -> sample of the run
         if (u.exchange) {
           // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
@@ -438,9 +488,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
             const uint32_t mp = pl.base + out[idx];
             // saveCurrentTree(-mp) (reference sprparsimony.cpp:2163-2166), before the SPR tie rule
-            if (!none_pass && mp <= mp_max) {
+            bool book;
+            if (!ratchet) book = !none_pass && mp <= mp_max;
+            else {
+              // iqtree.cpp:3283-3295 then :3343: the filter sees the length booked last; a tree that fails leaves
+              // _pattern_pars as it is, so every later candidate of the climb fails too
+              book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;
+              if (!book) u.gate_closed = true;
+            }
+            if (book) {
               const int64_t tree_index = (int64_t)u.treels.size();          // iqtree.cpp:3345-3348
-              u.treels.push_back(mp);
+              u.treels.push_back(ratchet ? u.stale_len : mp);
               u.refs.push_back(0);
               while (ep < events.size() && events[ep].idx < idx) ep++;
               for (; ep < events.size() && events[ep].idx == idx; ep++) {
@@ -466,6 +524,9 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
                 }
                 if (s == bs) u.boot_counts[b]++;                              // :3728-3730
               }
+              // pllComputePatternParsimony (:3365) has now refreshed _pattern_pars for THIS candidate: its length on the
+              // original alignment is what the next call will see
+              if (ratchet) u.stale_len = (uint32_t)((int64_t)u.rt_orig - (int64_t)lcol[(size_t)home] + (int64_t)lcol[(size_t)hinfo[idx].x]);
             }
             // testInsertParsimony's tie rule (reference :2168-2176 / fastDNAparsimony.c:1224-1229)
             if (tie_mode_ == MPF_TIE_RANDOM) {
@@ -516,6 +577,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               UCHK(hipStreamSynchronize(st_));       // h_small is reused by the next batch
             }
           }
+          if (ratchet) { int rc2 = read_rt_orig(); if (rc2) return rc2; }
           moves_.push_back(Move{remove_rec_, insert_rec_, best_});
           apply_move(remove_rec_, insert_rec_);
           randomMP = best_;

@@ -62,6 +62,8 @@ struct orc {
   /* UFBoot-MP online bookkeeping (IQTree::saveCurrentTree, iqtree.cpp:3271-3785, default options) */
   int pre_eval;               /* -1 = as the variant does (mpboot yes, PLL original no); 0 / 1 = forced */
   int ufb_on, ufb_B, ufb_bad;
+  int ufb_ratchet;                   /* on_ratchet_hclimb1: other weights than the attach-time ones in force */
+  int ufb_ratchet_booking;           /* !params->no_hclimb1_bb (tools.cpp:795) */
   int *ufb_w0;                       /* pattern weights at attach time */
   unsigned short *ufb_samples;    /* boot_samples_pars [B][P] */
   double ufb_eps, ufb_cutoff;     /* params->ufboot_epsilon (0.5, tools.cpp:725), logl_cutoff */
@@ -274,9 +276,16 @@ void orc_set_weights(orc *o, const int *weights)
   memcpy(o->wgt, weights, sizeof(int) * o->P);
   pack_tips(o);
   reset_flags(o);
-  /* an attached UFBoot tracker follows the attach-time weights only: other weights suspend it (the reference's
-     -no_hclimb1_bb behaviour, iqtree.cpp:3280), restoring them resumes it */
-  if (o->ufb_samples) o->ufb_on = memcmp(o->wgt, o->ufb_w0, sizeof(int) * o->P) == 0;
+  /* an attached UFBoot tracker: under other weights than the attach-time ones (the perturbed alignment of a ratchet
+     iteration, iqtree.cpp:1694-1716) saveCurrentTree keeps running unless -no_hclimb1_bb (:3280), with the cur_logl of
+     :3283-3295.  Weights that take an attach-time pattern's last site away (weight 0; mpboot's ratchet only adds copies
+     of sites, alignment.cpp:1915-1969) are outside what the reference can produce: the tracker rests until they go. */
+  if (o->ufb_samples) {
+    int k, other = memcmp(o->wgt, o->ufb_w0, sizeof(int) * o->P) != 0, lost = 0;
+    if (other) for (k = 0; k < o->P; k++) if (o->ufb_w0[k] > 0 && o->wgt[k] <= 0) lost = 1;
+    o->ufb_on = !other || (!lost && o->ufb_ratchet_booking);
+    o->ufb_ratchet = other && o->ufb_on;
+  }
   if (o->persite) { free(o->persite); o->persite = NULL; }
   if (o->ufb_samples) o->persite_on = o->ufb_on;
   if (o->persite_on) orc_enable_persite(o, 1);
@@ -660,6 +669,14 @@ static int ufb_dot(const unsigned short *a, const unsigned short *b, int n)
 static void ufb_save_current_tree(orc *o, double cur_logl)
 {
   int tree_index, sample, test_pars;
+  if (o->ufb_ratchet) {
+    /* :3283-3295 "if on_ratchet_hclimb1, update cur_logl": REPS of _pattern_pars -- as the array stands, i.e. still
+       holding the tree of the previous call that got past the filter below (or what the IQ-TREE kernel left there for
+       the climb's start tree) -- against original_sample; the segments cover the informative patterns */
+    int k, score = 0;
+    for (k = 0; k < o->P; k++) if (o->inf[k]) score += (int)o->ufb_ptn[k] * o->ufb_w0[k];
+    cur_logl = -(double)score;
+  }
   if (o->ufb_cutoff != 0.0 && cur_logl <= o->ufb_cutoff - 1e-4) return;     /* :3343 */
   tree_index = o->ufb_ntrees;                                                /* :3345-3348 */
   if (o->ufb_ntrees == o->ufb_treels_cap) {
@@ -668,7 +685,7 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
   }
   o->ufb_treels[o->ufb_ntrees++] = cur_logl;
   test_pars = orc_pattern_scores(o, o->ufb_ptn);                             /* :3365 */
-  if (test_pars != -(int)cur_logl) o->ufb_bad++;                             /* :3366-3367 outError */
+  if (!o->ufb_ratchet && test_pars != -(int)cur_logl) o->ufb_bad++;          /* :3366-3367 outError (not on ratchet climbs) */
   for (sample = 0; sample < o->ufb_B; sample++) {                            /* :3411 */
     const unsigned short *bs = o->ufb_samples + (size_t)sample * o->P;
     int res = ufb_dot(o->ufb_ptn, bs, o->P);
@@ -851,6 +868,10 @@ unsigned orc_optimize_spr(orc *o, int mintrav, int maxtrav)
   o->best = orc_evaluate(o, o->start, 1);
   o->ntips = o->n;
   o->insert_rec = o->remove_rec = -1;
+  /* a ratchet climb starts with _pattern_pars as the IQ-TREE kernel left it: the per-pattern lengths of the tree the climb
+     starts from (optimizeAllBranches -> computeParsimony on the perturbed alignment, iqtree.cpp:1712-1714; the full
+     evaluate above has just filled the per-site counters of that tree) */
+  if (o->ufb_on && o->ufb_ratchet) (void)orc_pattern_scores(o, o->ufb_ptn);
   return spr_sweeps(o, mintrav, maxtrav, o->best);
 }
 
@@ -1001,9 +1022,12 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsi
   o->ufb_bad = 0;
   o->ufb_draws = 0;
   o->ufb_on = 1;
+  o->ufb_ratchet = 0;
+  o->ufb_ratchet_booking = 1;
   orc_enable_persite(o, 1);                              /* perSiteScores = gbo_replicates > 0, sprparsimony.cpp:3245 */
 }
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff) { o->ufb_cutoff = logl_cutoff; }
+void orc_ufboot_set_ratchet_booking(orc *o, int on) { o->ufb_ratchet_booking = on != 0; }   /* !no_hclimb1_bb; next set_weights */
 int orc_ufboot_ntrees(const orc *o) { return o->ufb_ntrees; }
 int orc_ufboot_bad(const orc *o) { return o->ufb_bad; }
 unsigned long long orc_ufboot_draws(const orc *o) { return o->ufb_draws; }

@@ -80,6 +80,7 @@ unsigned orc_stepwise(orc *o, long seed, unsigned *best_per_step, int *insert_pe
 void orc_ufboot_attach(orc *o, int B, const unsigned short *samples /* [B][P] boot_samples_pars */, double epsilon);
 void orc_ufboot_detach(orc *o);
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff);       /* 0 = none (iqtree.cpp:3343) */
+void orc_ufboot_set_ratchet_booking(orc *o, int on);          /* 0 = -no_hclimb1_bb (iqtree.cpp:3280); default 1 */
 int orc_ufboot_ntrees(const orc *o);                          /* treels_logl.size() */
 int orc_ufboot_bad(const orc *o);                             /* # candidates whose pattern-score sum != mp (:3366) */
 unsigned long long orc_ufboot_draws(const orc *o);

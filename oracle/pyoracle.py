@@ -82,6 +82,7 @@ def lib():
         L.orc_ufboot_attach.argtypes = [vp, ci, vp, C.c_double]
         L.orc_ufboot_detach.argtypes = [vp]
         L.orc_ufboot_set_cutoff.argtypes = [vp, C.c_double]
+        L.orc_ufboot_set_ratchet_booking.argtypes = [vp, ci]
         L.orc_ufboot_ntrees.restype = ci
         L.orc_ufboot_ntrees.argtypes = [vp]
         L.orc_ufboot_bad.restype = ci
@@ -247,6 +248,9 @@ class Oracle:
         assert samples.ndim == 2 and samples.shape[1] == self.P
         self.ufb_B = samples.shape[0]
         lib().orc_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon))
+
+    def ufboot_set_ratchet_booking(self, on: bool):
+        lib().orc_ufboot_set_ratchet_booking(self.h, 1 if on else 0)
 
     def ufboot_set_cutoff(self, logl_cutoff: float):
         lib().orc_ufboot_set_cutoff(self.h, float(logl_cutoff))

@@ -9,7 +9,7 @@
  *     pllCalcMinParsScorePattern                           (iqtree.cpp:3827)
  * and prints what they leave in the pllInstance.  tests/test_gpu_dropin.py replays the same calls on the CPU oracle.
  *
- * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B> [cost-matrix file]
+ * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B> [cost-matrix file | - [no_hclimb1_bb]]
  * With a cost matrix (S x S unsigned entries, row-major) the program sets the globals IQTree::initializePLL sets for -cost
  * (iqtree.cpp:601-615) and calls initializeCostMatrix(): the shim then dispatches to the weighted engine.
  */
@@ -148,11 +148,11 @@ int main(int argc, char **argv)
   hooks.ufboot_epsilon = 0.5;
   hooks.logl_cutoff = hk_cutoff;
   hooks.ufboot_sync = hk_sync;
-  hooks.no_hclimb1_bb = 1;                         // this program plays mpboot -no_hclimb1_bb
+  hooks.no_hclimb1_bb = argc > 9 ? std::atoi(argv[9]) : 0;     // mpboot's default books ratchet climbs too (iqtree.cpp:3280)
   resetGlobalParamOnNewAln();
   mpfitch_shim_install(&hooks);
   static std::vector<unsigned int> cost;
-  if (argc > 8) {
+  if (argc > 8 && std::strcmp(argv[8], "-") != 0) {
     const int S = pr->partitionData[0]->states;
     FILE *cf = std::fopen(argv[8], "r");
     if (!cf) { std::perror(argv[8]); return 2; }
@@ -196,7 +196,8 @@ int main(int argc, char **argv)
   }
 
   // 3. a ratchet climb: perturbed pattern frequencies (iqtree.cpp:1706-1716), then the climb on the original weights
-  for (int p = 0; p < P; p++) H.freq[(size_t)p] = w0[(size_t)p] * (int)lcg3();
+  // createPerturbAlignment only ADDS copies of sites (alignment.cpp:1915-1969): every frequency stays >= the original one
+  for (int p = 0; p < P; p++) H.freq[(size_t)p] = w0[(size_t)p] * (1 + (int)lcg3());
   H.ratchet = true;
   H.cur_score = 0;
   hooks.cur_score = nullptr;                       // the perturbed start score is not known to this driver
@@ -204,7 +205,7 @@ int main(int argc, char **argv)
   pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);
   print_tree("ratchet", tr);
   H.freq = w0;
-  pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);   // on_ratchet_hclimb2: original weights again, bookkeeping resumes
+  pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);   // on_ratchet_hclimb2: original weights again
   print_tree("final", tr);
   _pllFreeParsimonyDataStructures(tr, pr);
   resetGlobalParamOnNewAln();

@@ -345,11 +345,11 @@ def test_unsupported_configurations_fail_loudly(mods):
         e.optimize_spr(1, 6)
     e.set_option("scan_mode", 1)
     assert e.optimize_spr(1, 6) > 0
-    # re-weighting re-packs the sites the sample weights are laid out by: the tracker is suspended (a climb on other
-    # weights leaves its state alone), and resumes when the attach-time weights return
+    # weights that leave an attach-time pattern without a site (mpboot's ratchet never does that) rest the tracker: a climb
+    # on them leaves its state alone, and the attach-time weights resume it
     n_saved = len(e.ufboot_tree_logl())
     other = fx["weights_np"].copy()
-    other[::2] *= 2
+    other[::2] = 0
     e.set_weights(other)
     e.set_tree(np.array(fx["trees"][1]["back"], dtype=np.int32))
     assert e.optimize_spr(1, 6) > 0
@@ -358,6 +358,84 @@ def test_unsupported_configurations_fail_loudly(mods):
     e.set_tree(np.array(fx["trees"][1]["back"], dtype=np.int32))
     assert e.optimize_spr(1, 6) > 0
     assert len(e.ufboot_tree_logl()) > n_saved
-    e.ufboot_detach()
-    with pytest.raises(engine.MpfError):
-        e.ufboot_state()
+
+
+@pytest.mark.parametrize("cut", ["none", "top10", "top90", "all_fail"])
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48"])
+def test_ratchet_climbs_are_booked_like_the_reference(mods, name, cut):
+    """a search iteration on the original alignment, a ratchet iteration (pattern frequencies raised as createPerturbAlignment
+    raises them) and the climb back: saveCurrentTree's state after every climb == the oracle's literal restatement of
+    iqtree.cpp:3283-3295 (cur_logl = REPS of the not-yet-refreshed _pattern_pars against original_sample), under no
+    cut-off, a loose one, a tight one (the bookkeeping of the ratchet climb stops at the first booked tree that fails) and
+    one nothing passes"""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    samples = boot_samples(len(w0), 30, 17, fx["weights"])
+    rng = np.random.default_rng(5)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3) * rng.integers(1, 3, size=len(w0)))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"])
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"])
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 4, 6)]
+
+    def same():
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+        assert (e.get_tree() == o.get_tree()).all()
+        for ti in sorted(set(e.ufboot_state()[2].tolist())):
+            if ti >= 0:
+                assert (e.ufboot_tree(ti) == o.ufboot_tree(ti)).all()
+
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.seed_ties(mode, 23)
+        x.ufboot_attach(samples)
+        x.set_tree(t[0])
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    same()
+    n0 = len(o.ufboot_tree_logl())
+    logl = np.sort(o.ufboot_tree_logl())
+    cutoff = {"none": 0.0, "top10": float(logl[int(0.9 * len(logl))]), "top90": float(logl[int(0.1 * len(logl))]),
+              "all_fail": float(logl[-1]) + 50.0}[cut]
+    for x in (e, o):
+        x.ufboot_set_cutoff(cutoff)
+        x.set_weights(pert)                      # the ratchet iteration's alignment
+        x.set_tree(t[1])
+    tests0 = o.counters()[2]
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    same()
+    booked = len(o.ufboot_tree_logl()) - n0
+    if cut == "none":
+        assert booked == o.counters()[2] - tests0          # every insertion test of the climb is booked
+        # ... the first one with the ORIGINAL-alignment length of the tree the climb started from
+        ref = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"])
+        assert -o.ufboot_tree_logl()[n0] == ref.score_tree(t[1])
+    if cut == "all_fail":
+        assert booked == 0
+    for x in (e, o):
+        x.set_weights(w0)
+        x.set_tree(t[2])
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    same()
+    assert o.ufboot_bad() == 0
+
+
+def test_no_hclimb1_bb_leaves_ratchet_climbs_unbooked(mods):
+    engine, po = mods
+    fx = load_fixture("dna_clean")
+    w0 = fx["weights_np"]
+    samples = boot_samples(len(w0), 12, 3, fx["weights"])
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"])
+    e.ufboot_attach(samples)
+    e.ufboot_set_ratchet_booking(False)
+    e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    e.optimize_spr(1, 6)
+    n_saved = len(e.ufboot_tree_logl())
+    e.set_weights((w0 * 2).astype(np.int32))
+    e.set_tree(np.array(fx["trees"][2]["back"], dtype=np.int32))
+    e.optimize_spr(1, 6)
+    assert len(e.ufboot_tree_logl()) == n_saved
+    e.set_weights(w0)
+    e.set_tree(np.array(fx["trees"][2]["back"], dtype=np.int32))
+    e.optimize_spr(1, 6)
+    assert len(e.ufboot_tree_logl()) > n_saved

@@ -101,3 +101,40 @@ def test_draws_come_from_the_shared_stream():
     assert sa == sb
     assert [x.tolist() for x in a.ufboot_state()] == [x.tolist() for x in b.ufboot_state()]
     assert pos["i"] > a.ufboot_draws() > 0          # the callback served both kinds of draws
+
+
+def test_ratchet_booking_rule_consequences():
+    """re-weighted (ratchet) climbs, reference iqtree.cpp:3283-3295 -- consequences of the rule that can be checked without
+    the oracle's own bookkeeping: (1) with no cut-off every insertion test of the climb is booked, the first one with the
+    ORIGINAL-alignment length of the climb's start tree (scored by a second oracle instance), never with its own perturbed
+    length; (2) under a cut-off no tree passes nothing is booked; (3) -no_hclimb1_bb books nothing"""
+    fx = load_fixture("dna_48")
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(2)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=10).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    start = np.array(fx["trees"][3]["back"], dtype=np.int32)
+    ref = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"])
+    l_start = ref.score_tree(start)
+    for mode in ("none", "all_fail", "no_hclimb1_bb"):
+        o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"])
+        o.seed_ties(po.TIE_RANDOM, 4)
+        o.ufboot_attach(samples)
+        if mode == "no_hclimb1_bb":
+            o.ufboot_set_ratchet_booking(False)
+        if mode == "all_fail":
+            o.ufboot_set_cutoff(-1.0)                      # every length >= 1 fails  -len <= -1 - 1e-4
+        o.set_weights(pert)
+        o.set_tree(start)
+        t0 = o.counters()[2]
+        s_pert = o.optimize_spr(1, 6)
+        booked = o.ufboot_tree_logl()
+        if mode == "none":
+            assert len(booked) == o.counters()[2] - t0 > 100
+            assert -booked[0] == l_start
+            # original-alignment lengths, not perturbed ones: a perturbed length counts the added site copies too, so it
+            # exceeds the original-alignment length of the same tree
+            assert s_pert > ref.score_tree(o.get_tree())
+            assert (-booked).min() < s_pert
+        else:
+            assert len(booked) == 0
