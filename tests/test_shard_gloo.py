@@ -184,3 +184,25 @@ def test_event_gather_over_two_gloo_ranks(tmp_path):
             n = [5, 0, 3, 17][(rnd + rank) % 4] if rnd != 2 else 0
             want += list(map(tuple, rng.integers(0, 1000, size=(n, 3)).astype(np.uint32).tolist()))
         assert [tuple(x) for x in two[rnd]] == sorted(want)
+
+
+def test_in_process_multi_device_schedule():
+    """integration/multi_device.hpp: unit b -> device b % G, in increasing b per device, seed base + 12345 b -- the same map
+    the process-level sharding uses (shard.units_of_rank / shard.unit_seed), printed by the C++ driver (no GPU touched)"""
+    import re
+    from mpboot_amd import shard
+    drv = os.path.join(ROOT, "oracle", "_build", "multi_device_driver")
+    if not os.path.exists(drv):
+        import pytest
+        pytest.skip("oracle/_build/multi_device_driver not built")
+    for units, G in ((10, 4), (1000, 8), (3, 5)):
+        out = subprocess.run([drv, "map", str(units), str(G)], check=True, capture_output=True, text=True).stdout.splitlines()
+        assert len(out) == G
+        seen = []
+        for d, line in enumerate(out):
+            pairs = [(int(a), int(b)) for a, b in re.findall(r"(\d+)\(seed (\d+)\)", line)]
+            got = [a for a, _ in pairs]
+            assert got == shard.units_of_rank(units, d, G)
+            assert [b for _, b in pairs] == [shard.unit_seed(7, u) for u in got]
+            seen += got
+        assert sorted(seen) == list(range(units))
