@@ -1038,7 +1038,9 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
   plan.maxtrav = maxtrav;
   const int q = back_[p];
   plan.base = 0;                                   // filled in after the refresh has been synchronised
+  plan.self_idx = -1;
   if (maxtrav < mintrav) return MPF_OK;
+  if (scan_masks_) plan.self_idx = (int64_t)walk_out_++;      // the current tree's own saveCurrentTree call, :2285-2289
   if (maxtrav > 6) split = false;
   // candidate counts are known from the topology (count_visits), so the outputs of all parts are laid
   // out back to back.  whole scan = one part; split scan (latency, small batches) = four parts

@@ -83,6 +83,9 @@ struct ScanPlan {
   uint32_t part_off[8];
   int part_cnt[8];
   int mintrav_q = 2, maxtrav = 0;
+  // masked scans (online UFBoot): the output index reserved in front of this prune node's candidates for the CURRENT tree
+  // -- rearrangeParsimony books it before it starts inserting (sprparsimony.cpp:2285-2289); -1 = none
+  int64_t self_idx = -1;
   inline uint32_t cost(size_t c, const uint32_t *out) const
   {
     if (!walked) return out[cands[c].out];

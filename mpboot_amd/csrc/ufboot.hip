@@ -224,6 +224,7 @@ __device__ __forceinline__ bool ufb_score(uint32_t i, int b, const uint2 *__rest
 {
   const uint2 in = info[i];
   if (in.y == 0xFFFFFFFFu) return false;
+  if (in.y == 0xFFFFFFFEu) { s = rt; return true; }      // the current tree itself (booked once per prune node): R_T
   if (cost[i] >= thr[in.y]) return false;
   const uint32_t hi = home[in.y];
   const uint32_t rc = crow ? crow[i] : in.x, rh = crow ? crow[hi] : hi;
@@ -287,6 +288,14 @@ __global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ in
       run = (uint32_t)s;
     }
   }
+}
+
+// info[idx[i]] = (0, code): the slots reserved for the current tree in front of every prune node's candidates
+// (code 0xFFFFFFFE = takes part with score R_T, 0xFFFFFFFF = does not: the current tree fails the cut-off)
+__global__ __launch_bounds__(256) void k_ufb_self(uint2 *__restrict__ info, const uint32_t *__restrict__ idx, uint32_t n, uint32_t code)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) info[idx[i]] = make_uint2(0u, code);
 }
 
 // ------------------------------------------------------------------------------------------------ weight layout
@@ -417,6 +426,13 @@ hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src, int n_cols, in
   hipError_t e = hipMemsetAsync(Wt, 0, plane_bytes * (size_t)planes, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_ufb_layout, dim3((P + 255) / 256, n_cols), dim3(256), 0, st, src, n_cols, P, first, cur, Wt, Bp, planes, plane_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_ufb_self(hipStream_t st, uint2 *info, const uint32_t *idx, uint32_t n, uint32_t code)
+{
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_ufb_self, dim3((n + 255) / 256), dim3(256), 0, st, info, idx, n, code);
   return hipGetLastError();
 }
 

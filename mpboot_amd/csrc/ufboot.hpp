@@ -30,6 +30,8 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
 // Wt (zeroed here) <- the samples' weights at the first expanded site of every pattern of the packing in force
 hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src /* [n_cols][P] */, int n_cols, int P, const int32_t *first_site,
                              const int32_t *cur_weight, uint8_t *Wt, int Bp, int planes, size_t plane_bytes);
+// info[idx[i]] = (0, code), i < n: the current tree's slots (code 0xFFFFFFFE: scored with R_T; 0xFFFFFFFF: skipped)
+hipError_t launch_ufb_self(hipStream_t st, uint2 *info, const uint32_t *idx, uint32_t n, uint32_t code);
 // out[i] = C[i][col], i < rows
 hipError_t launch_ufb_column(hipStream_t st, const int32_t *C, int Bp, int col, uint32_t rows, int32_t *out);
 

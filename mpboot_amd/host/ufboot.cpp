@@ -246,6 +246,10 @@ void Engine::ufb_flush_pending(const ScanPlan &pl)
   UfbState &u = *ufb_;
   for (const UfbState::Pending &pe : u.pending) {
     if (u.refs[(size_t)pe.tree_index] <= 0) continue;
+    if (pe.cand == 0xFFFFFFFFu) {                    // the current tree itself (booked in front of the candidates)
+      if (!u.store.count(pe.tree_index)) { u.store.emplace(pe.tree_index, back_); u.stored++; }
+      continue;
+    }
     ufb_store_tree(pe.tree_index, pe.cand < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, (size_t)pe.cand));
   }
   u.pending.clear();
@@ -284,7 +288,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   }
   int batch = first_batch();
   std::vector<UfbEvent> events;
-  std::vector<uint32_t> small, sel_rows, crow;
+  std::vector<uint32_t> small, sel_rows, crow, self_list;
   bool have_C = false;
   uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
@@ -339,8 +343,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       const bool none_pass = have_cut && lim <= 0.0;
       // ---- device: REPS of every candidate of plans [0, jstar], then the (candidate, sample) events
       uint32_t n_idx = 0, n_parts = 0;
+      self_list.clear();
       for (int j = 0; j <= jstar; j++) {
         const ScanPlan &pl = plans[(size_t)j];
+        if (pl.self_idx >= 0) { self_list.push_back((uint32_t)pl.self_idx); n_idx = std::max(n_idx, (uint32_t)pl.self_idx + 1u); }
         for (int pi = 0; pi < pl.n_parts; pi++) {
           n_idx = std::max(n_idx, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
           n_parts = std::max(n_parts, (uint32_t)pl.part_desc[pi] + 1u);
@@ -383,11 +389,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         n_rows = (uint32_t)sel_rows.size();
       }
       have_C = false;
-      if (n_idx > 0 && !skip_product && n_rows > 0) {
-        const int rows_p = round_up((int)n_rows, kUfbRowTile);
-        // staging: thr[n_parts] | home[n_parts] | best[Bp] | crow[n_idx] | sel[rows_p]
+      bool ran_events = false;
+      // the current tree is booked in front of every prune node's candidates (sprparsimony.cpp:2285-2289) with its own
+      // length (= randomMP): it takes part unless that length fails the cut-off (ratchet climbs: decided in the replay)
+      const bool self_pass = !self_list.empty() && !skip_product && (ratchet || randomMP <= mp_max);
+      if (n_idx > 0 && !skip_product && (n_rows > 0 || self_pass)) {
+        const int rows_p = round_up((int)std::max<uint32_t>(n_rows, 1u), kUfbRowTile);
+        // staging: thr[n_parts] | home[n_parts] | best[Bp] | crow[n_idx] | sel[rows_p] | self[n_self]
         const size_t o_crow = (size_t)2 * n_parts + (size_t)u.Bp, o_sel = o_crow + (compact ? (size_t)n_idx : 0);
-        small.assign(o_sel + (compact ? (size_t)rows_p : 0), 0u);
+        const size_t o_self = o_sel + (compact ? (size_t)rows_p : 0);
+        small.assign(o_self + self_list.size(), 0u);
+        std::copy(self_list.begin(), self_list.end(), small.begin() + (long)o_self);
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
           for (int pi = 0; pi < pl.n_parts; pi++) {
@@ -412,13 +424,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
         const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
         const uint32_t *d_crow = compact ? u.thr.p + o_crow : nullptr, *d_sel = compact ? u.thr.p + o_sel : nullptr;
+        UCHK(launch_ufb_self(st_, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(), self_pass ? 0xFFFFFFFEu : 0xFFFFFFFFu));
         if (timing_) UCHK(hipEventRecord(ev2_, st_));
-        for (int pl = 0; pl < u.planes; pl++)
-          UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0, d_sel));
+        if (n_rows > 0) {
+          for (int pl = 0; pl < u.planes; pl++)
+            UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0, d_sel));
+          u.gemm_rows += (uint64_t)rows_p;
+          have_C = true;
+        }
         if (timing_) UCHK(hipEventRecord(ev3_, st_));
-        u.gemm_rows += (uint64_t)rows_p;
-        have_C = true;
-        if (ratchet) {
+        ran_events = true;
+        if (ratchet && have_C) {
           UCHK(u.d_col.reserve((size_t)rows_p));
           UCHK(u.h_col.reserve((size_t)rows_p));
           UCHK(launch_ufb_column(st_, u.C.p, u.Bp, oc, n_rows, u.d_col.p));
@@ -447,7 +463,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         t1 = now_ms();
         u.t_dev += t1 - t0;
         events.assign(u.h_ev.p, u.h_ev.p + n_ev);
-        if (ratchet) lcol.assign(u.h_col.p, u.h_col.p + n_rows);
+        if (ratchet && have_C) lcol.assign(u.h_col.p, u.h_col.p + n_rows);
         for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];       // local column -> sample of the run
         if (u.exchange) {
           // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
@@ -482,6 +498,50 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         long sel = -1;
         uint32_t sel_idx = 0, sel_home = 0;
         size_t c = 0;
+        // the update rule of one booked tree (iqtree.cpp:3684-3731) over the samples whose events name output index idx
+        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
+          while (ep < events.size() && events[ep].idx < idx) ep++;
+          for (; ep < events.size() && events[ep].idx == idx; ep++) {
+            const uint32_t b = events[ep].b, s = events[ep].s;
+            uint32_t &bs = u.boot_score[b];
+            bool accept = false;
+            if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (:3686)
+            else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
+              u.draws++;
+              accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
+            }
+            if (accept) {
+              // the tree "string" (:3689-3707): remembered as (prune node, candidate) and materialised after this
+              // prune node's scan only if some sample still points to it by then
+              if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
+              int64_t &bt = u.boot_trees[b];
+              if (bt != tree_index) {
+                if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
+                u.refs[(size_t)tree_index]++;
+                bt = tree_index;                                          // :3720
+              }
+            }
+            if (s == bs) u.boot_counts[b]++;                              // :3728-3730
+          }
+        };
+        if (pl.self_idx >= 0) {
+          // rearrangeParsimony's evaluateParsimony(p) + pllSaveCurrentTreeSprParsimony (sprparsimony.cpp:2285-2289): the
+          // current tree, length randomMP, once per prune node and before any of its insertion tests
+          bool book;
+          if (!ratchet) book = !none_pass && randomMP <= mp_max;
+          else {
+            book = !u.gate_closed && ran_events && !none_pass && u.stale_len <= mp_max;
+            if (!book) u.gate_closed = true;
+          }
+          if (book) {
+            const int64_t tree_index = (int64_t)u.treels.size();
+            u.treels.push_back(ratchet ? u.stale_len : randomMP);
+            u.refs.push_back(0);
+            replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
+            if (ratchet) u.stale_len = u.rt_orig;        // _pattern_pars now holds the current tree
+          }
+        }
         for (int pi = 0; pi < pl.n_parts; pi++) {
           const uint32_t home = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
           for (int k = 0; k < pl.part_cnt[pi]; k++, c++) {
@@ -493,37 +553,14 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             else {
               // iqtree.cpp:3283-3295 then :3343: the filter sees the length booked last; a tree that fails leaves
               // _pattern_pars as it is, so every later candidate of the climb fails too
-              book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;
+              book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;     // (have_C: a ratchet batch with candidates always has its product)
               if (!book) u.gate_closed = true;
             }
             if (book) {
               const int64_t tree_index = (int64_t)u.treels.size();          // iqtree.cpp:3345-3348
               u.treels.push_back(ratchet ? u.stale_len : mp);
               u.refs.push_back(0);
-              while (ep < events.size() && events[ep].idx < idx) ep++;
-              for (; ep < events.size() && events[ep].idx == idx; ep++) {
-                const uint32_t b = events[ep].b, s = events[ep].s;
-                uint32_t &bs = u.boot_score[b];
-                bool accept = false;
-                if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (:3686)
-                else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
-                  u.draws++;
-                  accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
-                }
-                if (accept) {
-                  // the tree "string" (:3689-3707): remembered as (prune node, candidate) and materialised after this
-                  // prune node's scan only if some sample still points to it by then
-                  if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, (uint32_t)c});
-                  if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
-                  int64_t &bt = u.boot_trees[b];
-                  if (bt != tree_index) {
-                    if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
-                    u.refs[(size_t)tree_index]++;
-                    bt = tree_index;                                          // :3720
-                  }
-                }
-                if (s == bs) u.boot_counts[b]++;                              // :3728-3730
-              }
+              replay_events(idx, tree_index, (uint32_t)c);
               // pllComputePatternParsimony (:3365) has now refreshed _pattern_pars for THIS candidate: its length on the
               // original alignment is what the next call will see
               if (ratchet) u.stale_len = (uint32_t)((int64_t)u.rt_orig - (int64_t)lcol[(size_t)home] + (int64_t)lcol[(size_t)hinfo[idx].x]);

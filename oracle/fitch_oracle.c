@@ -759,7 +759,10 @@ int orc_rearrange(orc *o, int p, int mintrav, int maxtrav)
   assert(mintrav == 1);
   if (maxtrav < mintrav) return 0;
   q = o->back[p];
-  if (o->pre_eval < 0 ? o->tie_mode == ORC_TIE_RANDOM : o->pre_eval) orc_evaluate(o, p, 0);   /* :2285, mpboot only */
+  if (o->pre_eval < 0 ? o->tie_mode == ORC_TIE_RANDOM : o->pre_eval) {
+    const unsigned mp0 = orc_evaluate(o, p, 0);       /* :2285, mpboot only */
+    if (o->ufb_on) ufb_save_current_tree(o, -(double)mp0);   /* :2286-2289: the CURRENT tree is booked once per prune node */
+  }
   trace_push(o, -1, 0);
   if (!TIP(o, p)) {
     p1 = o->back[NX(p)];

@@ -34,7 +34,10 @@ def test_bookkeeping_is_self_consistent(name):
     assert o.ufboot_bad() == 0                      # sum of per-pattern lengths == mp at every insertion test (:3366)
     logl, counts, trees = o.ufboot_state()
     saved = o.ufboot_tree_logl()
-    assert len(saved) == o.counters()[2]            # no cut-off: every insertion test is saved
+    # no cut-off: every insertion test is saved, and so is the current tree once per prune-node visit
+    # (rearrangeParsimony's own call, sprparsimony.cpp:2285-2289): a whole number of sweeps over the 2n - 2 prune nodes
+    extra = len(saved) - o.counters()[2]
+    assert extra > 0 and extra % (2 * fx["n"] - 2) == 0
     assert saved.max() == -score
     chk = fresh(fx)
     chk.enable_persite(True)
@@ -105,7 +108,8 @@ def test_draws_come_from_the_shared_stream():
 
 def test_ratchet_booking_rule_consequences():
     """re-weighted (ratchet) climbs, reference iqtree.cpp:3283-3295 -- consequences of the rule that can be checked without
-    the oracle's own bookkeeping: (1) with no cut-off every insertion test of the climb is booked, the first one with the
+    the oracle's own bookkeeping: (1) with no cut-off every insertion test of the climb (and the current tree at every
+    prune-node visit) is booked, the first entry with the
     ORIGINAL-alignment length of the climb's start tree (scored by a second oracle instance), never with its own perturbed
     length; (2) under a cut-off no tree passes nothing is booked; (3) -no_hclimb1_bb books nothing"""
     fx = load_fixture("dna_48")
@@ -130,7 +134,8 @@ def test_ratchet_booking_rule_consequences():
         s_pert = o.optimize_spr(1, 6)
         booked = o.ufboot_tree_logl()
         if mode == "none":
-            assert len(booked) == o.counters()[2] - t0 > 100
+            extra = len(booked) - (o.counters()[2] - t0)           # + the current tree, once per prune-node visit
+            assert len(booked) > 100 and extra > 0 and extra % (2 * fx["n"] - 2) == 0
             assert -booked[0] == l_start
             # original-alignment lengths, not perturbed ones: a perturbed length counts the added site copies too, so it
             # exceeds the original-alignment length of the same tree
