@@ -1,0 +1,263 @@
+"""Second, independent restatement of mpboot's SPR hill climb and of IQTree::saveCurrentTree -- TEST INFRASTRUCTURE ONLY.
+
+The C++ layer of the reference (sprparsimony.cpp, iqtree.cpp) cannot be compiled here (it includes the CMake-generated
+iqtree_config.h), so the parts of the hot path that exist only there -- mpboot's random tie rule, the sweep-level accept rule,
+saveCurrentTree's bookkeeping including its ratchet branch -- are unpinned.  This file is the second witness the first
+restatement (oracle/fitch_oracle.c) is checked against: written separately from the reference text, in another language and
+with another structure.  Nothing here is incremental: every insertion test builds the candidate topology and scores it FROM
+SCRATCH with a per-pattern numpy Fitch pass (no traversal descriptors, no orientation flags, no per-site counters), and every
+saveCurrentTree call recomputes the candidate's per-pattern lengths the same way.
+
+    pllOptimizeSprParsimony      sprparsimony.cpp:3244-3319   -> SlowSearch.optimize
+    nodeRectifierPars            sprparsimony.cpp:2046-2101   -> SlowSearch.rectify
+    rearrangeParsimony           sprparsimony.cpp:2259-2376   -> SlowSearch.rearrange   (incl. its own saveCurrentTree, :2285-2289)
+    addTraverseParsimony         sprparsimony.cpp:2208-2218   -> SlowSearch.traverse
+    testInsertParsimony          sprparsimony.cpp:2106-2188   -> SlowSearch.test_insert
+    IQTree::saveCurrentTree      iqtree.cpp:3271-3731         -> SlowSearch.save_current_tree (default options)
+
+Parity status: UNPINNED (like what it witnesses); its scorer is tied to the pinned one in tests/test_search_slow.py.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from mpboot_amd.rng import Lcg64           # SPRNG lcg64 stream, pinned against the vendored generator (tests/test_oracle_golden.py)
+
+LONG_MAX = float(2 ** 63 - 1)
+
+
+def nx(r: int) -> int:
+    v, s = divmod(r, 3)
+    return 3 * v + (s + 1) % 3
+
+
+def tip_sets(codes: np.ndarray, datatype: int) -> np.ndarray:
+    """PLL tip codes -> state sets as integers (globalVariables.h:60-78)"""
+    c = codes.astype(np.int64)
+    if datatype == 0:
+        return c
+    sets = np.where(c < 20, np.left_shift(1, np.minimum(c, 19)), 0)
+    sets = np.where(c == 20, 12, sets)
+    sets = np.where(c == 21, 96, sets)
+    return np.where(c >= 22, (1 << 20) - 1, sets)
+
+
+class SlowSearch:
+    def __init__(self, codes, weights, datatype, informative, tie_seed, samples=None, eps=0.5):
+        self.n, self.P = codes.shape
+        self.sets = tip_sets(np.asarray(codes), datatype)
+        self.w = np.asarray(weights, dtype=np.int64).copy()
+        self.inf = np.asarray(informative, dtype=bool)
+        self.rng = Lcg64(tie_seed)
+        self.draws = 0
+        self.back = None
+        self.nodep = [0] + [3 * i for i in range(1, 2 * self.n - 1)]
+        self.moves = []
+        self.tests = 0
+        sys.setrecursionlimit(max(sys.getrecursionlimit(), 8 * self.n + 200))
+        # -bb state (IQTree::setParams, iqtree.cpp:213-262)
+        self.bb = samples is not None
+        self.bb_on = self.bb
+        if self.bb:
+            self.samples = np.asarray(samples, dtype=np.int64)
+            self.orig = self.w.copy()                      # original_sample
+            B = self.samples.shape[0]
+            self.eps = eps
+            self.cutoff = 0.0
+            self.boot_logl = [-LONG_MAX] * B
+            self.boot_counts = [0] * B
+            self.boot_trees = [-1] * B
+            self.treels_logl = []
+            self.topologies = {}
+            self.ufb_draws = 0
+            self.pattern_pars = np.zeros(self.P, dtype=np.int64)     # _pattern_pars: persists between calls
+            self.ratchet = False
+            self.ratchet_booking = True                    # !params->no_hclimb1_bb
+
+    def draw(self) -> float:
+        self.draws += 1
+        return float(self.rng.doubles(1)[0])
+
+    # ---------------------------------------------------------------- scoring from scratch
+    def pattern_lengths(self, back) -> np.ndarray:
+        """per-pattern Fitch length of the (complete) tree, rooted on tip 1; 0 for patterns the PLL engine drops"""
+        n, sets, P = self.n, self.sets, self.P
+
+        def down(rec):
+            v = rec // 3
+            if v <= n:
+                return sets[v - 1], np.zeros(P, dtype=np.int64)
+            sa, ca = down(int(back[nx(rec)]))
+            sb, cb = down(int(back[nx(nx(rec))]))
+            inter = sa & sb
+            empty = inter == 0
+            return np.where(empty, sa | sb, inter), ca + cb + empty
+
+        s, c = down(int(back[3]))
+        ptn = c + ((sets[0] & s) == 0)
+        return np.where(self.inf, ptn, 0)
+
+    def length(self, back) -> int:
+        return int((self.pattern_lengths(back) * self.w).sum())
+
+    # ---------------------------------------------------------------- tree state
+    def set_tree(self, back):
+        self.back = [int(x) for x in back]
+
+    def set_weights(self, w):
+        self.w = np.asarray(w, dtype=np.int64).copy()
+        if self.bb:
+            other = bool((self.w != self.orig).any())
+            lost = bool(((self.orig > 0) & (self.w <= 0)).any())
+            self.bb_on = (not other) or (not lost and self.ratchet_booking)
+            self.ratchet = other and self.bb_on
+
+    def hookup(self, a, b):
+        self.back[a] = b
+        self.back[b] = a
+
+    def is_tip(self, r):
+        return r // 3 <= self.n
+
+    def rectify(self):
+        """nodeRectifierPars: inner entries of nodep = entry records of a preorder walk from nodep[1]->back"""
+        n = self.n
+        self.start = self.nodep[1]
+        count = 0
+
+        def reorder(p):
+            nonlocal count
+            if self.is_tip(p):
+                return
+            self.nodep[count + n + 1] = p
+            count += 1
+            reorder(self.back[nx(p)])
+            reorder(self.back[nx(nx(p))])
+
+        reorder(self.back[self.start])
+
+    # ---------------------------------------------------------------- saveCurrentTree, default options
+    def save_current_tree(self, cur_logl: float):
+        if not self.bb_on:
+            return
+        if self.ratchet:                                    # iqtree.cpp:3283-3295: from _pattern_pars AS IT STANDS
+            cur_logl = -float((self.pattern_pars * self.orig * self.inf).sum())
+        if self.cutoff != 0.0 and cur_logl <= self.cutoff - 1e-4:      # :3343
+            return
+        tree_index = len(self.treels_logl)
+        self.treels_logl.append(cur_logl)
+        self.pattern_pars = self.pattern_lengths(self.back)            # :3365 pllComputePatternParsimony
+        for b in range(self.samples.shape[0]):                         # :3411
+            rell = -float((self.pattern_pars * self.samples[b]).sum())
+            accept = rell > self.boot_logl[b] + self.eps
+            if not accept and rell > self.boot_logl[b] - self.eps:     # :3687-3688, short-circuit: the draw only on a tie
+                self.ufb_draws += 1
+                accept = self.draw() <= 1.0 / (self.boot_counts[b] + 1)
+            if accept:
+                self.topologies[tree_index] = list(self.back)
+                if rell > self.boot_logl[b]:
+                    self.boot_counts[b] = 1
+                    self.boot_logl[b] = rell
+                self.boot_trees[b] = tree_index
+            if rell == self.boot_logl[b]:
+                self.boot_counts[b] += 1
+
+    # ---------------------------------------------------------------- SPR neighbourhood
+    def test_insert(self, p, q):
+        r = self.back[q]
+        self.hookup(nx(p), q)                               # insertParsimony
+        self.hookup(nx(nx(p)), r)
+        mp = self.length(self.back)
+        self.tests += 1
+        self.save_current_tree(-float(mp))                  # :2163-2166, before the tie rule
+        if mp < self.best:
+            self.hits = 1
+        elif mp == self.best:
+            self.hits += 1
+        if mp < self.best or (mp == self.best and self.draw() <= 1.0 / self.hits):
+            self.best, self.insert_rec, self.remove_rec = mp, q, p
+        self.hookup(q, r)
+        self.back[nx(p)] = self.back[nx(nx(p))] = -1
+
+    def traverse(self, p, q, mintrav, maxtrav):
+        mintrav -= 1
+        if mintrav <= 0:
+            self.test_insert(p, q)
+        if not self.is_tip(q):
+            maxtrav -= 1
+            if maxtrav > 0:
+                self.traverse(p, self.back[nx(q)], mintrav, maxtrav)
+                self.traverse(p, self.back[nx(nx(q))], mintrav, maxtrav)
+
+    def remove_node(self, p):
+        q, r = self.back[nx(p)], self.back[nx(nx(p))]
+        self.hookup(q, r)
+        self.back[nx(p)] = self.back[nx(nx(p))] = -1
+
+    def rearrange(self, p, mintrav, maxtrav):
+        maxtrav = min(maxtrav, self.n - 3)
+        if maxtrav < mintrav:
+            return
+        q = self.back[p]
+        self.save_current_tree(-float(self.length(self.back)))        # :2285-2289
+        if not self.is_tip(p):
+            p1, p2 = self.back[nx(p)], self.back[nx(nx(p))]
+            if not self.is_tip(p1) or not self.is_tip(p2):
+                self.remove_node(p)
+                for x in (p1, p2):
+                    if not self.is_tip(x):
+                        self.traverse(p, self.back[nx(x)], mintrav, maxtrav)
+                        self.traverse(p, self.back[nx(nx(x))], mintrav, maxtrav)
+                self.hookup(nx(p), p1)
+                self.hookup(nx(nx(p)), p2)
+        if not self.is_tip(q) and maxtrav > 0:
+            q1, q2 = self.back[nx(q)], self.back[nx(nx(q))]
+
+            def deep(x):
+                return not self.is_tip(x) and (not self.is_tip(self.back[nx(x)]) or not self.is_tip(self.back[nx(nx(x))]))
+
+            if deep(q1) or deep(q2):
+                self.remove_node(q)
+                m2 = max(mintrav, 2)
+                for x in (q1, q2):
+                    if not self.is_tip(x):
+                        self.traverse(q, self.back[nx(x)], m2, maxtrav)
+                        self.traverse(q, self.back[nx(nx(x))], m2, maxtrav)
+                self.hookup(nx(q), q1)
+                self.hookup(nx(nx(q)), q2)
+
+    # ---------------------------------------------------------------- pllOptimizeSprParsimony
+    def optimize(self, mintrav=1, maxtrav=6) -> int:
+        n = self.n
+        self.moves = []
+        self.rectify()
+        self.best = self.length(self.back)
+        if self.bb and self.ratchet:
+            # what the IQ-TREE kernel left in _pattern_pars for the climb's start tree (iqtree.cpp:1712-1714)
+            self.pattern_pars = self.pattern_lengths(self.back)
+        random_mp = self.best
+        iter_hits = 1
+        while True:
+            start_mp = random_mp
+            self.rectify()
+            for i in range(1, 2 * n - 1):
+                self.insert_rec = self.remove_rec = None
+                self.hits = 1
+                self.rearrange(self.nodep[i], mintrav, maxtrav)
+                if self.best == random_mp:
+                    iter_hits += 1
+                if self.best < random_mp:
+                    iter_hits = 1
+                if (self.best < random_mp or (self.best == random_mp and self.draw() <= 1.0 / iter_hits)) and \
+                        self.remove_rec is not None and self.insert_rec is not None:
+                    self.remove_node(self.remove_rec)                       # restoreTreeRearrangeParsimony
+                    r = self.back[self.insert_rec]
+                    self.hookup(nx(self.remove_rec), self.insert_rec)
+                    self.hookup(nx(nx(self.remove_rec)), r)
+                    random_mp = self.best
+                    self.moves.append((self.remove_rec, self.insert_rec, self.best))
+            if not random_mp < start_mp:
+                break
+        return start_mp

@@ -1,0 +1,93 @@
+"""The two restatements of the unpinned part of the hot path against each other (CPU only).
+
+oracle/fitch_oracle.c (incremental: traversal descriptors, lazily oriented vectors, per-site counters -- the structure of the
+reference) and oracle/search_slow.py (every insertion test scored from scratch with a numpy per-pattern Fitch pass, every
+saveCurrentTree call recomputing per-pattern lengths) were written separately from the reference text
+(sprparsimony.cpp:2046-2376, :3244-3319; iqtree.cpp:3271-3731).  They must agree on every accepted move, the final tree, the
+number of random draws and -- with -bb -- on treels_logl, boot_logl, boot_counts, boot_trees and the stored topologies, over a
+normal climb, a ratchet climb and the climb back."""
+import numpy as np
+import pytest
+
+from helpers import load_fixture
+from oracle import pyoracle as po
+from oracle.search_slow import LONG_MAX, SlowSearch
+
+
+def both(fx, seed, samples=None):
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    o.seed_ties(po.TIE_RANDOM, seed)
+    s = SlowSearch(fx["codes_np"], fx["weights_np"], fx["datatype"], fx["informative"], seed, samples)
+    if samples is not None:
+        o.ufboot_attach(samples)
+    return o, s
+
+
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa"])
+def test_from_scratch_scorer_equals_the_reference_scores(name):
+    fx = load_fixture(name)
+    s = SlowSearch(fx["codes_np"], fx["weights_np"], fx["datatype"], fx["informative"], 1)
+    for t in fx["trees"]:
+        assert s.length(t["back"]) == t["score"]            # the reference's own evaluateParsimony (tests/golden)
+
+
+@pytest.mark.parametrize("name,seed,tree", [("dna_dups", 3, 1), ("aa", 11, 4), ("dna_ambig", 7, 2), ("dna_clean", 5, 6)])
+def test_hill_climb_with_random_ties(name, seed, tree):
+    fx = load_fixture(name)
+    start = np.array(fx["trees"][tree]["back"], dtype=np.int32)
+    o, s = both(fx, seed)
+    o.set_tree(start)
+    s.set_tree(start)
+    o.trace(True)
+    assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+    rem, ins, sc = o.get_moves()
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(rem, ins, sc)] == s.moves
+    assert len(s.moves) > 2
+    assert o.get_tree().tolist() == s.back
+    assert o.counters()[2] == s.tests
+
+
+def bb_same(o, s):
+    assert o.ufboot_tree_logl().tolist() == s.treels_logl
+    logl, counts, trees = o.ufboot_state()
+    assert [-LONG_MAX if v <= -LONG_MAX / 2 else v for v in logl.tolist()] == s.boot_logl
+    assert counts.tolist() == s.boot_counts and trees.tolist() == s.boot_trees
+    assert o.ufboot_draws() == s.ufb_draws
+    for t in set(s.boot_trees):
+        if t >= 0:
+            assert o.ufboot_tree(t).tolist() == s.topologies[t]
+    assert o.get_tree().tolist() == s.back
+
+
+@pytest.mark.parametrize("cut", ["none", "tight"])
+@pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9), ("dna_ambig", 4)])
+def test_save_current_tree_over_normal_ratchet_normal_climbs(name, seed, cut):
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(seed)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=5).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 3, 5)]
+    o, s = both(fx, seed, samples)
+    for x in (o, s):
+        x.set_tree(t[0])
+    assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+    bb_same(o, s)
+    if cut == "tight":
+        c = float(np.sort(o.ufboot_tree_logl())[int(0.3 * len(s.treels_logl))])
+        o.ufboot_set_cutoff(c)
+        s.cutoff = c
+    for x in (o, s):                                # the ratchet iteration: other weights, bookkeeping goes on (iqtree.cpp:3283-3295)
+        x.set_weights(pert)
+        x.set_tree(t[1])
+    n0 = len(s.treels_logl)
+    assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+    bb_same(o, s)
+    if cut == "none":
+        assert len(s.treels_logl) > n0              # (under a tight cut-off the ratchet climb may book nothing at all)
+    for x in (o, s):
+        x.set_weights(w0)
+        x.set_tree(t[2])
+    assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+    bb_same(o, s)
+    assert o.ufboot_bad() == 0
