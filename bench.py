@@ -156,7 +156,9 @@ def cpu_baseline(codes, back, names, letters, alphabet, maxtrav, budget_s, all_c
                                         "usable_cpus": cpu_quota(),
                                         "evals_per_s": tot_rate,
                                         "value": n * P * tot_rate,
-                                        "sample": f"{len(rates)} concurrent copies of the same single-threaded run"}
+                                        "sample": f"{len(rates)} concurrent copies of the same single-threaded run",
+                                        "note": f"this job may use {cpu_quota()} of the host's {physical_cores()} physical cores: on the whole "
+                                                f"host the CPU side would be about {physical_cores() / max(1, len(rates)):.0f}x this"}
                 return res
         except Exception as exc:  # fall through to the port
             print(f"[bench] reference driver failed ({exc}); using the scalar port", file=sys.stderr)

@@ -29,6 +29,7 @@
 
 extern "C" {
 #include "pll.h"
+double randum(long *seed);                 // pllInternal.h:34 (utils.c:335-358)
 }
 #include "mpboot_hooks.h"
 
@@ -161,7 +162,12 @@ void pull_tree(pllInstance *tr)            // record links -> pllInstance (what 
   if (mpf_get_tree(g_eng, back.data())) die("mpf_get_tree");
   for (int v = 1; v <= 2 * n - 2; v++)
     for (int s = 0; s < (v <= n ? 1 : 3); s++) ptr_of(tr, 3 * v + s)->back = ptr_of(tr, back[(size_t)(3 * v + s)]);
-  tr->start = tr->nodep[1];                // nodeRectifierPars, :2089
+  // tr->nodep[] as nodeRectifierPars leaves it (:2046-2101): tips in place, the inner entries = the records by which a
+  // preorder walk from nodep[1]->back enters the inner nodes -- callers that index nodep[] afterwards see the reference's state
+  std::vector<int32_t> order((size_t)(2 * n - 2));
+  if (mpf_get_node_order(g_eng, order.data())) die("mpf_get_node_order");
+  for (int i = 1; i <= 2 * n - 2; i++) tr->nodep[i] = ptr_of(tr, order[(size_t)(i - 1)]);
+  tr->start = tr->nodep[1];                // :2089
   tr->ntips = n;
   tr->nextnode = 2 * n - 1;
 }
@@ -210,6 +216,9 @@ void _pllComputeRandomizedStepwiseAdditionParsimonyTree(pllInstance *tr, partiti
   // perSiteScores = PLL_FALSE here (:3228): the engine's tree builder never runs the UFBoot bookkeeping
   uint32_t score = 0;
   if (mpf_make_parsimony_tree(g_eng, (int64_t)tr->randomNumberSeed, sprDist, &score)) die("mpf_make_parsimony_tree");
+  // makePermutationFast (:2221-2242) draws one randum() per taxon from tr->randomNumberSeed: leave the seed where the
+  // reference leaves it, for whoever draws from it next
+  for (int i = 1; i <= tr->mxtips; i++) (void)randum(&tr->randomNumberSeed);
   pull_tree(tr);
   tr->bestParsimony = score;
   doing_stepwise_addition = false;

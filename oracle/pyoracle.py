@@ -288,6 +288,20 @@ class Oracle:
         return a.value, b.value, c.value
 
 
+def randum_advance(seed: int, k: int) -> int:
+    """tr->randomNumberSeed after k calls of PLL's randum() (pllrepo/src/utils.c:335-358; restated in oracle/rng.h, here once
+    more in Python): what makePermutationFast leaves behind"""
+    for _ in range(k):
+        s0, s1, s2 = seed & 4095, (seed >> 12) & 4095, (seed >> 24) & 255
+        t = 1549 * s0
+        n0 = t & 4095
+        t = (t >> 12) + 1549 * s1 + 406 * s0
+        n1 = t & 4095
+        t = (t >> 12) + 1549 * s2 + 406 * s1
+        seed = ((t & 255) << 24) | (n1 << 12) | n0
+    return seed
+
+
 def lcg64_doubles(seed: int, k: int):
     """First k values of the restated SPRNG stream (oracle/rng.h) -- computed in Python ints."""
     mult = (0x27BB2EE6 << 32) | 0x87B0B0FD

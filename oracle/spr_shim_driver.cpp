@@ -170,6 +170,9 @@ int main(int argc, char **argv)
   tr->randomNumberSeed = std::atol(argv[5]);
   _pllComputeRandomizedStepwiseAdditionParsimonyTree(tr, pr, 0, iq);
   print_tree("ras", tr);
+  std::printf("ras_seed_after %ld\nras_nodep", (long)tr->randomNumberSeed);
+  for (int i = 1; i <= 2 * n - 2; i++) std::printf(" %d", rec_of(tr, tr->nodep[i]));
+  std::printf("\n");
 
   // 2. the SPR climb of one search iteration, with the -bb bookkeeping when B > 0 (iqtree.cpp:2132)
   H.cur_score = -(double)tr->bestParsimony;
