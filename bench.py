@@ -438,6 +438,23 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = eng.stats()
+    # The timed steps hand the SAME tree over again and again, so what the engine plans from the topology alone (refresh
+    # schedule, scan descriptors, device program) is planned once and reused -- as it is between bootstrap replicates that
+    # share a tree, or a re-weighting, in a real run.  A short untimed loop with that reuse switched off prices a step on a
+    # topology the engine has never seen (everything else identical); both figures go into the line.
+    eng.set_option("plan_cache", 0)
+    csteps = max(1, min(20, args.steps))
+    for _ in range(3):
+        eng.set_tree(back)
+        eng.sweep_scan(1, args.maxtrav)
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    for _ in range(csteps):
+        eng.set_tree(back)
+        eng.sweep_scan(1, args.maxtrav)
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - tc0) / csteps * 1e3
+    eng.set_option("plan_cache", 1)
     # the refresh kernels' own time comes from a short untimed pass: their event pair would cost the timed steps ~10 us each
     eng.set_option("timing", 2)
     eng.reset_stats()
@@ -493,6 +510,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_all / args.steps * 1e3,
+            "ms_per_step_new_topology": cold_ms,       # rank 0, planning from scratch every step (engine option plan_cache = 0)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -501,6 +519,10 @@ def main():
             "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
                                    "one full sweep scan per step (all prune nodes, both sides)",
                        "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
+                       "planning": "the steps re-submit one tree: refresh schedule, scan descriptors and the planned device program are "
+                                   "built at the first step and reused (they depend on the topology only); every vector is recomputed and "
+                                   "every insertion test re-scored in every step.  ms_per_step_new_topology = the same step with that "
+                                   "reuse off",
                        "start_tree_score": start_score, "parallelism": f"independent start trees x{world}",
                        # the three rates side by side.  value = effective (n x P x evals/s, as defined);
                        # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the

@@ -201,7 +201,7 @@ int Engine::pack()
     g_.pwgt = d_pwgt_.p;
     HIPCHK(launch_pack_tips_sankoff(st_, g_, d_vec_, d_codes_, n_, P_, d_infidx_.p, ninf_, datatype_));
     HIPCHK(hipStreamSynchronize(st_));
-    invalidate_all();
+    invalidate_vectors();
     return MPF_OK;
   }
   if (!inf_known_) {
@@ -240,7 +240,7 @@ int Engine::pack()
   HIPCHK(hipMemcpyAsync(d_site2ptn_.p, s2p.data(), s2p.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
   HIPCHK(launch_pack_tips(st_, g_, d_vec_, d_codes_, n_, P_, d_site2ptn_.p, nsites_, datatype_, d_tipslots_));
   HIPCHK(hipStreamSynchronize(st_));
-  invalidate_all();
+  invalidate_vectors();                      // (re-weighting changes every vector, not the tree)
   return MPF_OK;
 }
 
@@ -293,11 +293,12 @@ int Engine::set_tree(const int32_t *back)
       const int r = 3 * v + s, b = back[r];
       if (b < 3 || b >= (int)len || back[b] != r) { set_error("mpf_set_tree: inconsistent back links"); return MPF_E_INVALID; }
     }
+  const bool same = have_tree_ && ntips_ == n_ && std::equal(back + 3, back + len, back_.begin() + 3);
   std::copy(back, back + len, back_.begin());
   start_ = nodep_[1];
   ntips_ = n_;
   have_tree_ = true;
-  invalidate_all();
+  if (same) invalidate_vectors(); else invalidate_all();
   return MPF_OK;
 }
 
@@ -336,6 +337,19 @@ void Engine::invalidate_all()
   kids_list_.clear();
   all_invalid_ = true;
   topo_epoch_++;
+  sched_cache_valid_ = false;
+  sweep_cache_valid_ = false;
+}
+
+// every vector stale, topology unchanged (re-weighting, a full re-evaluation, the same tree handed over again): what
+// depends on the topology alone stays -- the device copy of kids[], the from-scratch refresh schedule, a sweep's plans
+void Engine::invalidate_vectors()
+{
+  if (!plan_cache_ || !kids_list_.empty()) { invalidate_all(); return; }
+  std::fill(valid_.begin(), valid_.end(), 0);
+  n_invalid_ = -1;
+  views_valid_ = false;
+  all_invalid_ = true;
 }
 
 // Invariant: a valid vector has valid inputs.  The vectors containing `node` are its own three and, walking
@@ -369,6 +383,8 @@ void Engine::invalidate_node(int node)
   // (no wholesale invalidation pending) a refresh sends just these
   if (!kids_dirty_) for (int s = 0; s < 3; s++) kids_list_.push_back(3 * node + s);
   topo_epoch_++;
+  sched_cache_valid_ = false;
+  sweep_cache_valid_ = false;
 }
 
 // N(q, m) = 1 + [q inner and m > 1] * (N(c1, m-1) + N(c2, m-1)): the records addTraverseParsimony visits
@@ -514,6 +530,36 @@ int Engine::schedule_views(const std::vector<int> *roots)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   ScopedMs timer(stats.host_views_ms_total);
+  if (!roots && all_invalid_ && sched_cache_valid_ && !kids_dirty_ && !sankoff_) {
+    // the same topology as when the last from-scratch schedule was built (the tree was handed over again, re-weighted or
+    // re-evaluated): its ops, level offsets and the topology array are still on the device -- launch, nothing else
+    const uint8_t *src = d_vstage_.p;
+    const NvOp *dops = reinterpret_cast<const NvOp *>(src + sc_ops_off_);
+    const int32_t *dlo = reinterpret_cast<const int32_t *>(src + sc_lev_off_b_);
+    const size_t nops = sc_nops_;
+    const int tiles = std::max(tiles_for(g_), tiles_for_levels(g_));
+    HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
+    zeroed_ptr_ = nullptr;
+    zeroed_words_ = 0;
+    for (int i = 0; i < 2; i++) ride_[i].dev = nullptr;
+    cnt_on_host_ = false;
+    if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));
+    RefreshExtra x;
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, sc_maxlev_, d_cntp_.p, (uint32_t)nslots_, d_cnt(), nullptr, x));
+    stats.view_launches++;
+    HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), tiles_for_levels(g_)));
+    if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
+    cnt_copy_pending_ = true;
+    upd_order_ = sc_order_;
+    for (int r : upd_order_) valid_[r] = 1;
+    all_invalid_ = false;
+    n_invalid_ = 0;
+    views_valid_ = true;
+    pending_scores_ = true;
+    stats.newview_ops += nops;
+    stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+    return MPF_OK;
+  }
   // scratch vectors are members: this runs once per scan batch, allocations would show
   std::vector<int> &all = sv_all_;
   all.clear();
@@ -702,6 +748,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     if (full) kids_dirty_ = false;
   }
   if (nops == 0) {
+    if (!direct) sched_cache_valid_ = false;       // (d_vstage_ may have been rewritten above)
     if (full) { n_invalid_ = 0; views_valid_ = true; }
     return MPF_OK;
   }
@@ -719,11 +766,13 @@ int Engine::schedule_views(const std::vector<int> *roots)
   if (fold_inside && want_host_results_) { x.cnt_host = h_cnt(); cnt_on_host_ = true; }   // small batch: counts land in the host mirror
   for (int i = 0; i < 2; i++)
     if (ride_off[i]) ride_[i].dev = src + ride_off[i];
+  bool can_ride_used = ride_off[0] || ride_off[1];
   if (can_ride && zero_req_ptr_) {
     x.zero_ptr = zero_req_ptr_;                   // the outputs of the scan that follows, cleared by the refresh launch
     x.zero_words = (uint32_t)zero_req_words_;
     zeroed_ptr_ = zero_req_ptr_;
     zeroed_words_ = zero_req_words_;
+    can_ride_used = true;
   }
   if (chains) {
     if (direct) {
@@ -762,6 +811,18 @@ int Engine::schedule_views(const std::vector<int> *roots)
     }
   }
   pending_scores_ = true;
+  if (!direct) {
+    // d_vstage_ was (re)written: it holds a reusable schedule only if this was the from-scratch refresh of the whole tree
+    // on the level kernel with the per-tile counts folded by the separate launch (the shape the fast path above replays)
+    sched_cache_valid_ = plan_cache_ && from_scratch && full && !chains && views_mode_ >= 1 && !fold_inside && !sankoff_ && !can_ride_used;
+    if (sched_cache_valid_) {
+      sc_nops_ = nops;
+      sc_maxlev_ = maxlev;
+      sc_ops_off_ = ops_off;
+      sc_lev_off_b_ = lev_off_b;
+      sc_order_ = upd_order_;
+    }
+  }
   stats.newview_ops += nops;
   dbg_levels_ += (uint64_t)(chains ? ch_levels_ : maxlev);
   stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
@@ -859,7 +920,7 @@ int Engine::score_tree(uint32_t *score)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   node_rectifier();
-  invalidate_all();
+  invalidate_vectors();                      // evaluateParsimony(start, PLL_TRUE): every vector again, same topology
   return tree_length(score);
 }
 
@@ -1039,6 +1100,7 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
   const int q = back_[p];
   plan.base = 0;                                   // filled in after the refresh has been synchronised
   plan.self_idx = -1;
+  if (n_walk_ == 0) walk_gen_++;                   // a new set of descriptors: whatever a cached sweep left on the device goes
   if (maxtrav < mintrav) return MPF_OK;
   if (scan_masks_) plan.self_idx = (int64_t)walk_out_++;      // the current tree's own saveCurrentTree call, :2285-2289
   if (maxtrav > 6) split = false;
@@ -1128,6 +1190,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     // kernel: no second copy and no memset dispatch on the critical path of a climb's batches
     const WalkDesc *descs = static_cast<const WalkDesc *>(ride_[0].dev);
     ride_[0].dev = nullptr;
+    if (walk_dev_reuse_) descs = d_walk_.p;        // a cached sweep: descriptors (and the planned program) are still there
     if (!descs) { HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_)); descs = d_walk_.p; }
     if (!(zeroed_ptr_ == d_out() && zeroed_words_ >= clear_words(nout)))
       HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
@@ -1151,9 +1214,11 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
     if (prog) {
       HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));
-      if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
-      HIPCHK(launch_walk_plan(st_, d_kids(), n_, descs, (int)nd, d_prog_.p));
-      if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }   // the scan kernel's own time starts here
+      if (!walk_dev_reuse_) {
+        if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
+        HIPCHK(launch_walk_plan(st_, d_kids(), n_, descs, (int)nd, d_prog_.p));
+        if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }   // the scan kernel's own time starts here
+      }
       unsigned long long *trace = nullptr;
       if (scan_trace_) {
         trace_words_ = scan_prog_blocks(g_, (int)nd) * 4;
@@ -1254,6 +1319,19 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
     if (!walk) { int rc = update_views(); if (rc) return rc; }      // host-planned programs need the scores first
     else { int rc = schedule_views(nullptr); if (rc) return rc; }
   }
+  // a whole sweep of the same topology with the same options as the last one planned into these very plans: descriptors,
+  // output layout and the device program are still in place (the topology alone determines them)
+  const int key[6] = {mintrav, maxtrav, count, split_below_, split_cands_, scan_prog_ * 16 + g_.vw * 4 + g_.map * 2 + g_.big};
+  const bool hit = walk && plan_cache_ && sweep_cache_valid_ && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2 &&
+                   sweep_cache_gen_ == walk_gen_ && std::equal(key, key + 6, sweep_cache_key_) && n_walk_ == 0 && !check_counts_;
+  if (hit) {
+    n_walk_ = sweep_cache_nwalk_;
+    walk_out_ = sweep_cache_out_;
+    walk_dev_reuse_ = true;
+    int rc = run_walks(plans, out);
+    walk_dev_reuse_ = false;
+    return rc;
+  }
   {
     ScopedMs timer(stats.host_plan_ms_total);
     if (walk && count >= n_ / 2 && (visits_filled_epoch_ != topo_epoch_ || vis_dense_m_ != std::min(mt, 15))) {
@@ -1265,6 +1343,13 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
                     : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);
       if (rc) return rc;
     }
+  }
+  if (walk && plan_cache_ && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2) {
+    sweep_cache_valid_ = true;
+    sweep_cache_gen_ = walk_gen_;
+    sweep_cache_nwalk_ = n_walk_;
+    sweep_cache_out_ = walk_out_;
+    std::copy(key, key + 6, sweep_cache_key_);
   }
   if (walk) return run_walks(plans, out);
   int rc = run_scans(plans, out_scratch_);
@@ -1447,7 +1532,8 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
-  if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
+  if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
+  if (key == "plan_cache") { plan_cache_ = v ? 1 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
   if (key == "scan_trace") { scan_trace_ = v ? 1 : 0; return MPF_OK; }
@@ -1490,6 +1576,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "xcd_map") *v = g_.map;
   else if (key == "scan_mode") *v = scan_mode_;
   else if (key == "views_mode") *v = views_mode_;
+  else if (key == "plan_cache") *v = plan_cache_;
   else if (key == "split_below") *v = split_below_;
   else if (key == "split_cands") *v = split_cands_;
   else if (key == "chain_max_ops") *v = chain_max_ops_;

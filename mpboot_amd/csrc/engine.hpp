@@ -189,6 +189,7 @@ class Engine {
   int tree_length(uint32_t *len);              // from valid views
   // validity-tracked refresh: only invalid vectors that the given roots depend on are recomputed
   void invalidate_all();
+  void invalidate_vectors();                   // vectors stale, topology (and what was planned from it) kept
   void invalidate_node(int node);              // every vector whose subtree contains `node`
   int schedule_views(const std::vector<int> *roots);   // enqueue (no sync); nullptr = every record of the tree
   void finish_views();                         // after a stream sync: subtree scores of the refreshed vectors
@@ -392,6 +393,18 @@ class Engine {
   // 1 = batches of more than prog_min_descs_ descriptors run as planned programs (k_walk_plan + k_scan_prog), 2 = every batch, 0 = never
   int scan_prog_ = 1, prog_min_descs_ = 256;
   DevBuf<uint8_t> d_prog_;
+  // what depends on the topology alone is kept while the topology stays ("plan_cache"): the schedule of a from-scratch
+  // refresh (ops by level, in d_vstage_) and the plans / descriptors / device program of a whole sweep
+  int plan_cache_ = 1;
+  bool sched_cache_valid_ = false;
+  size_t sc_nops_ = 0, sc_ops_off_ = 0, sc_lev_off_b_ = 0;
+  int sc_maxlev_ = 0;
+  std::vector<int> sc_order_;
+  bool sweep_cache_valid_ = false, walk_dev_reuse_ = false;
+  uint64_t walk_gen_ = 0, sweep_cache_gen_ = 0;
+  size_t sweep_cache_nwalk_ = 0;
+  uint32_t sweep_cache_out_ = 0;
+  int sweep_cache_key_[6] = {0, 0, 0, 0, 0, 0};
   int scan_trace_ = 0;
   DevBuf<unsigned long long> d_trace_;
   size_t trace_words_ = 0;

@@ -122,7 +122,7 @@ int Engine::optimize_spr(int mintrav, int maxtrav, uint32_t *score)
   moves_.clear();
   node_rectifier();
   uint32_t len = 0;
-  invalidate_all();
+  invalidate_vectors();                      // the full evaluate of :3277: every vector again, same topology
   int rc = tree_length(&len);
   if (rc) return rc;
   best_ = len;
