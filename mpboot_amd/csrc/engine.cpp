@@ -1,5 +1,6 @@
 // engine.cpp -- device state, tip packing, directional views and SPR-scan programs.
 #include "engine.hpp"
+#include <cstdlib>
 #include "../host/simd_util.hpp"
 
 #include <algorithm>
@@ -59,6 +60,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     set_error("mpf_engine_create: only DNA (4 states) and protein (20 states) are supported");
     return MPF_E_UNSUPPORTED;
   }
+  if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_error("no HIP device available: libmpfitch has no CPU fallback");
@@ -345,7 +347,7 @@ void Engine::invalidate_all()
 // depends on the topology alone stays -- the device copy of kids[], the from-scratch refresh schedule, a sweep's plans
 void Engine::invalidate_vectors()
 {
-  if (!plan_cache_ || !kids_list_.empty()) { invalidate_all(); return; }
+  if (!(plan_cache_ & 1) || !kids_list_.empty()) { invalidate_all(); return; }
   std::fill(valid_.begin(), valid_.end(), 0);
   n_invalid_ = -1;
   views_valid_ = false;
@@ -814,7 +816,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
   if (!direct) {
     // d_vstage_ was (re)written: it holds a reusable schedule only if this was the from-scratch refresh of the whole tree
     // on the level kernel with the per-tile counts folded by the separate launch (the shape the fast path above replays)
-    sched_cache_valid_ = plan_cache_ && from_scratch && full && !chains && views_mode_ >= 1 && !fold_inside && !sankoff_ && !can_ride_used;
+    sched_cache_valid_ = (plan_cache_ & 2) && from_scratch && full && !chains && views_mode_ >= 1 && !fold_inside && !sankoff_ && !can_ride_used;
     if (sched_cache_valid_) {
       sc_nops_ = nops;
       sc_maxlev_ = maxlev;
@@ -1322,8 +1324,9 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
   // a whole sweep of the same topology with the same options as the last one planned into these very plans: descriptors,
   // output layout and the device program are still in place (the topology alone determines them)
   const int key[6] = {mintrav, maxtrav, count, split_below_, split_cands_, scan_prog_ * 16 + g_.vw * 4 + g_.map * 2 + g_.big};
-  const bool hit = walk && plan_cache_ && sweep_cache_valid_ && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2 &&
-                   sweep_cache_gen_ == walk_gen_ && std::equal(key, key + 6, sweep_cache_key_) && n_walk_ == 0 && !check_counts_;
+  const bool hit = walk && (plan_cache_ & 4) && sweep_cache_valid_ && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2 &&
+                   sweep_cache_gen_ == walk_gen_ && std::equal(key, key + 6, sweep_cache_key_) && n_walk_ == 0 && !check_counts_ &&
+                   sweep_cache_recs_.size() == (size_t)count && std::equal(recs, recs + count, sweep_cache_recs_.begin());
   if (hit) {
     n_walk_ = sweep_cache_nwalk_;
     walk_out_ = sweep_cache_out_;
@@ -1344,12 +1347,13 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
       if (rc) return rc;
     }
   }
-  if (walk && plan_cache_ && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2) {
+  if (walk && (plan_cache_ & 4) && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2) {
     sweep_cache_valid_ = true;
     sweep_cache_gen_ = walk_gen_;
     sweep_cache_nwalk_ = n_walk_;
     sweep_cache_out_ = walk_out_;
     std::copy(key, key + 6, sweep_cache_key_);
+    sweep_cache_recs_.assign(recs, recs + count);
   }
   if (walk) return run_walks(plans, out);
   int rc = run_scans(plans, out_scratch_);
@@ -1533,7 +1537,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
-  if (key == "plan_cache") { plan_cache_ = v ? 1 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
+  if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
   if (key == "scan_trace") { scan_trace_ = v ? 1 : 0; return MPF_OK; }

@@ -395,7 +395,7 @@ class Engine {
   DevBuf<uint8_t> d_prog_;
   // what depends on the topology alone is kept while the topology stays ("plan_cache"): the schedule of a from-scratch
   // refresh (ops by level, in d_vstage_) and the plans / descriptors / device program of a whole sweep
-  int plan_cache_ = 1;
+  int plan_cache_ = 7;
   bool sched_cache_valid_ = false;
   size_t sc_nops_ = 0, sc_ops_off_ = 0, sc_lev_off_b_ = 0;
   int sc_maxlev_ = 0;
@@ -405,6 +405,7 @@ class Engine {
   size_t sweep_cache_nwalk_ = 0;
   uint32_t sweep_cache_out_ = 0;
   int sweep_cache_key_[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<int> sweep_cache_recs_;               // the prune records the cached sweep was planned for
   int scan_trace_ = 0;
   DevBuf<unsigned long long> d_trace_;
   size_t trace_words_ = 0;

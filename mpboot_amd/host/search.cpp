@@ -39,7 +39,9 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
   uint32_t startMP;
   unsigned iter_hits = 1;                         // bestIterationScoreHits
   const int total = 2 * n_ - 2;
-  std::vector<ScanPlan> plans;
+  // (the engine's own plan storage: a whole-sweep batch on a topology whose sweep is still planned -- the closing sweep of
+  //  the previous climb, the same tree under other weights -- reuses descriptors and device program, Engine::scan_batch)
+  std::vector<ScanPlan> &plans = sweep_plans_;
   const uint32_t *out = nullptr;
   int batch = first_batch();
   do {
