@@ -248,6 +248,14 @@ int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff);            /* IQTr
    the bookkeeping in either case (mpboot's ratchet only adds copies of sites). */
 int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on);
 /* the main loop's per-iteration cut-off update, "top percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10) */
+/* params->multiple_hits (-mulhits): the update rule of iqtree.cpp:3498-3540 replaces the default one (:3684-3731) -- every
+   tree whose REPS reaches a sample's best joins that sample's set (boot_trees_parsimony), a better one clears the set first;
+   trees of one topology share the index of the first of them that hit (the reference's treels string map, :3500-3514); no
+   random draws, boot_counts / boot_trees stay untouched.  Call right after the attach, before any tree is booked.
+   Not covered: -mulhits with -topboot (store_top_boot_trees, :3542-3585) and -distinct_iter_top_boot (:3587-3680). */
+int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on);
+/* boot_trees_parsimony[sample] in increasing order: *n = its size, the first min(*n, cap) entries written to out (may be NULL) */
+int mpf_ufboot_get_sample_trees(const mpf_engine *e, int32_t sample, int64_t *out, int32_t cap, int32_t *n);
 int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff);
 int mpf_ufboot_num_trees(const mpf_engine *e, int64_t *n_trees);         /* treels_logl.size() */
 int mpf_ufboot_tree_logl(const mpf_engine *e, double *out /* [n_trees] */);

@@ -32,6 +32,10 @@ struct mpf_mpboot_hooks {
   // globalParam->no_hclimb1_bb (tools.cpp:795, iqtree.cpp:3280): 1 = ratchet climbs run without saveCurrentTree; 0 (mpboot's
   // default) = they are booked too, with the cur_logl of iqtree.cpp:3283-3295 (mpf_ufboot_set_ratchet_booking)
   int no_hclimb1_bb;
+  // globalParam->multiple_hits (-mulhits, iqtree.cpp:3498-3540): 1 = every tree that reaches a sample's best REPS joins its
+  // boot_trees_parsimony set (mpf_ufboot_set_mulhits; read back with mpf_ufboot_get_sample_trees in ufboot_sync).  The
+  // -topboot / -distinct_iter_top_boot variants are not covered: leave those runs on the reference's own path.
+  int multiple_hits;
   // called at the end of every pllOptimizeSprParsimony with the engine that holds the saveCurrentTree bookkeeping of
   // this climb: copy treels_logl / boot_logl / boot_counts / boot_trees back with mpf_ufboot_* 
   void (*ufboot_sync)(IQTree *, mpf_engine *);

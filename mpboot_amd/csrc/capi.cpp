@@ -242,6 +242,15 @@ int mpf_ufboot_attach_sharded(mpf_engine *e, int32_t n_samples, int32_t n_local,
 int mpf_ufboot_detach(mpf_engine *e) { NEED(e); e->eng.ufboot_detach(); return MPF_OK; }
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff) { NEED(e); return e->eng.ufboot_set_cutoff(logl_cutoff); }
 int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_ratchet_booking(on); }
+int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_mulhits(on); }
+int mpf_ufboot_get_sample_trees(const mpf_engine *e, int32_t sample, int64_t *out, int32_t cap, int32_t *n)
+{
+  NEED(e);
+  int k = 0;
+  int rc = e->eng.ufboot_sample_trees(sample, out, cap, &k);
+  if (!rc && n) *n = k;
+  return rc;
+}
 int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff)
 {
   NEED(e);

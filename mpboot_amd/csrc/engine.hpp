@@ -15,6 +15,7 @@
 #include <map>
 #include <unordered_map>
 #include <memory>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -150,6 +151,13 @@ struct UfbState {
   uint32_t rt_orig = 0;                          // original-alignment length of the current tree (host copy of rt[orig column])
   bool gate_closed = false;                      // a booked tree failed the cut-off: nothing else is booked in this climb
   bool ratchet_booking = true;                   // false = params->no_hclimb1_bb (iqtree.cpp:3280): re-weighted climbs are not booked
+  // -mulhits (params->multiple_hits, iqtree.cpp:3498-3540): per sample the SET of trees that reach its best REPS; trees of
+  // one topology share the index of the first of them that hit (the reference's treels string map); no draws
+  bool mulhits = false;
+  std::unordered_map<std::string, int64_t> topo_index;       // canonical topology -> tree index
+  std::vector<std::set<int64_t>> hit_sets;                   // boot_trees_parsimony
+  std::string self_key;                                      // canonical form of the current tree ...
+  uint64_t self_key_epoch = ~0ull;                           // ... as of this topology epoch
   DevBuf<uint16_t> d_samples;                    // [Bl + 1][P]: the local samples as given + the row of original frequencies
   DevBuf<int32_t> d_first, d_cur;                // per pattern: first expanded site / weight of the packing in force
   DevBuf<int32_t> d_col;                         // one column of C, contiguous
@@ -221,6 +229,9 @@ class Engine {
   int ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local = -1, const int32_t *sample_ids = nullptr,
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
+  int ufboot_set_mulhits(int on);
+  int ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const;
+  void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const;
   bool ufboot_attached() const { return (bool)ufb_; }
   int ufboot_set_cutoff(double logl_cutoff);
   int ufboot_set_ratchet_booking(int on);
@@ -270,6 +281,7 @@ class Engine {
   int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)
   int ufb_layout_weights();                      // the product's right-hand side for the packing in force
   void ufb_store_tree(int64_t tree_index, int remove_rec, int insert_rec);
+  void ufb_candidate_topology(int remove_rec, int insert_rec, std::vector<int32_t> &bk) const;
   void ufb_flush_pending(const ScanPlan &pl);
 
   int addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step);

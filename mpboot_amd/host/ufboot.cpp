@@ -144,6 +144,66 @@ int Engine::ufboot_set_ratchet_booking(int on)
   return MPF_OK;
 }
 
+// params->multiple_hits (tools.cpp, -mulhits): the update rule of iqtree.cpp:3498-3540 instead of the default one.  Before
+// the first booked tree only.
+int Engine::ufboot_set_mulhits(int on)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (!ufb_->treels.empty()) { set_error("ufboot_set_mulhits: trees have been booked under the other rule already"); return MPF_E_STATE; }
+  ufb_->mulhits = on != 0;
+  ufb_->hit_sets.assign(on ? (size_t)ufb_->B : 0, std::set<int64_t>());
+  return MPF_OK;
+}
+
+int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (!ufb_->mulhits) { set_error("ufboot_sample_trees: the -mulhits rule is not in force"); return MPF_E_STATE; }
+  if (sample < 0 || sample >= ufb_->B || !n) { set_error("ufboot_sample_trees: bad argument"); return MPF_E_INVALID; }
+  const std::set<int64_t> &st = ufb_->hit_sets[(size_t)sample];
+  *n = (int)st.size();
+  int k = 0;
+  for (int64_t t : st) { if (k >= cap || !out) break; out[k++] = t; }
+  return MPF_OK;
+}
+
+// What the reference's printTree(WT_TAXON_ID | WT_SORT_TAXA) string stands for (iqtree.cpp:3508): a canonical form of the
+// unrooted topology.  Here: the tree hung from tip 1, an inner node written as -1 followed by its two subtrees, the one
+// with the smaller tip number first.
+void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key) const
+{
+  const int nrec = 3 * (2 * n_ - 1);
+  std::vector<int32_t> mins((size_t)nrec, 0), order, seq;
+  order.reserve((size_t)(2 * n_));
+  std::vector<int32_t> stack;
+  stack.push_back(bk[3]);
+  while (!stack.empty()) {                         // pre-order of the entry records, then mins bottom-up
+    const int r = stack.back();
+    stack.pop_back();
+    order.push_back(r);
+    if (r / 3 <= n_) continue;
+    stack.push_back(bk[(size_t)nx(r)]);
+    stack.push_back(bk[(size_t)nx(nx(r))]);
+  }
+  for (size_t k = order.size(); k-- > 0;) {
+    const int r = order[k];
+    mins[(size_t)r] = r / 3 <= n_ ? r / 3 : std::min(mins[(size_t)bk[(size_t)nx(r)]], mins[(size_t)bk[(size_t)nx(nx(r))]]);
+  }
+  seq.reserve(order.size());
+  stack.push_back(bk[3]);
+  while (!stack.empty()) {
+    const int r = stack.back();
+    stack.pop_back();
+    if (r / 3 <= n_) { seq.push_back(r / 3); continue; }
+    seq.push_back(-1);
+    int a = bk[(size_t)nx(r)], b = bk[(size_t)nx(nx(r))];
+    if (mins[(size_t)a] > mins[(size_t)b]) std::swap(a, b);
+    stack.push_back(b);
+    stack.push_back(a);
+  }
+  key.assign(reinterpret_cast<const char *>(seq.data()), seq.size() * sizeof(int32_t));
+}
+
 // "top cutoff_percent %" rule of the main loop (reference iqtree.cpp:1662-1676; treels_logl.size() > 1000)
 double Engine::ufboot_next_cutoff(int percent) const
 {
@@ -255,17 +315,24 @@ void Engine::ufb_flush_pending(const ScanPlan &pl)
   u.pending.clear();
 }
 
-void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
+// the tentatively inserted topology of one insertion test: subtree p re-inserted into branch q
+void Engine::ufb_candidate_topology(int p, int q, std::vector<int32_t> &bk) const
 {
-  UfbState &u = *ufb_;
-  if (u.store.count(tree_index)) return;
-  std::vector<int32_t> bk(back_);
+  bk = back_;
   auto hk = [&](int a, int b) { bk[(size_t)a] = b; bk[(size_t)b] = a; };
   const int a = bk[(size_t)nx(p)], b = bk[(size_t)nx(nx(p))];
   hk(a, b);
   const int r = bk[(size_t)q];
   hk(nx(p), q);
   hk(nx(nx(p)), r);
+}
+
+void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
+{
+  UfbState &u = *ufb_;
+  if (u.store.count(tree_index)) return;
+  std::vector<int32_t> bk;
+  ufb_candidate_topology(p, q, bk);
   u.store.emplace(tree_index, std::move(bk));
   u.stored++;
 }
@@ -289,6 +356,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   int batch = first_batch();
   std::vector<UfbEvent> events;
   std::vector<uint32_t> small, sel_rows, crow, self_list;
+  std::vector<int32_t> mh_bk;                      // -mulhits: a candidate's topology and its canonical form
+  std::string mh_key;
   bool have_C = false;
   uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
@@ -499,11 +568,39 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         uint32_t sel_idx = 0, sel_home = 0;
         size_t c = 0;
         // the update rule of one booked tree (iqtree.cpp:3684-3731) over the samples whose events name output index idx
+        // treels.find(tree_str) / treels[tree_str] = tree_index (iqtree.cpp:3500-3514, :3689-3707): a topology that some
+        // sample accepted before keeps the index of that first tree
+        auto lookup_topology = [&](int64_t tree_index, uint32_t cand_code) -> int64_t {
+          if (cand_code == 0xFFFFFFFFu) {
+            if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+            return u.topo_index.emplace(u.self_key, tree_index).first->second;
+          }
+          ufb_candidate_topology(cand_code < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, (size_t)cand_code), mh_bk);
+          canonical_topology(mh_bk, mh_key);
+          return u.topo_index.emplace(mh_key, tree_index).first->second;
+        };
         auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
           while (ep < events.size() && events[ep].idx < idx) ep++;
+          bool looked_up = false;
           for (; ep < events.size() && events[ep].idx == idx; ep++) {
             const uint32_t b = events[ep].b, s = events[ep].s;
             uint32_t &bs = u.boot_score[b];
+            if (u.mulhits) {
+              // iqtree.cpp:3498-3540: rell >= boot_logl (an event is exactly that); no draw, boot_counts untouched
+              if (s > bs) continue;
+              if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }       // :3500-3514
+              std::set<int64_t> &hs = u.hit_sets[b];
+              if (s < bs) {                                               // :3516-3519
+                for (int64_t t : hs) if (--u.refs[(size_t)t] == 0) u.store.erase(t);
+                hs.clear();
+                bs = s;
+              }
+              if (hs.insert(tree_index).second) {                         // :3530-3533
+                u.refs[(size_t)tree_index]++;
+                if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              }
+              continue;
+            }
             bool accept = false;
             if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (:3686)
             else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
@@ -511,8 +608,9 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
             }
             if (accept) {
-              // the tree "string" (:3689-3707): remembered as (prune node, candidate) and materialised after this
-              // prune node's scan only if some sample still points to it by then
+              // the tree "string" (:3689-3707): looked up once per booked tree; the topology itself is remembered as
+              // (prune node, candidate) and materialised after this prune node's scan only if some sample still points to it
+              if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }
               if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
               int64_t &bt = u.boot_trees[b];

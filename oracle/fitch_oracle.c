@@ -74,6 +74,11 @@ struct orc {
   int *ufb_store_idx, **ufb_store_back, ufb_nstore, ufb_store_cap;   /* topologies of the trees some sample accepted */
   unsigned short *ufb_ptn;
   unsigned long long ufb_draws;
+  /* -mulhits (params->multiple_hits, iqtree.cpp:3498-3540): treels (canonical topology -> tree index) and
+     boot_trees_parsimony (per sample: the set of tree indices that reach its best REPS) */
+  int ufb_mulhits;
+  int **ufb_keys, *ufb_key_idx, ufb_nkeys, ufb_keys_cap;
+  int **ufb_set, *ufb_set_n, *ufb_set_cap;
 };
 
 #define NUM(r) ((r) / 3)
@@ -624,7 +629,9 @@ static void moves_push(orc *o, int rem, int ins, unsigned score)
 }
 
 /* ---- IQTree::saveCurrentTree, maximum-parsimony branch with the default options (iqtree.cpp:3271-3785):
-        store_candidate_trees off (tools.cpp:736) => no string lookup before the cut-off test (:3343);
+        store_candidate_trees off (tools.cpp:736) => no string lookup before the cut-off test (:3343), only when a
+        sample accepts the tree (:3689-3707: treels maps the sorted tree string to the index of the first accepted
+        tree of that topology);
         pattern scores from pllComputePatternParsimony (:3365); REPS as the exact integer sum (the auto_vectorize
         loop :3418-3422; the Vec16us segment sums :3423-3449 are the same number whenever they do not wrap, and the
         remain-bound skip :3435-3445 only skips samples for which neither branch below can fire); then the DEFAULT
@@ -634,6 +641,7 @@ static void ufb_store_tree(orc *o, int tree_index)
 {
   int nrec = 3 * (2 * o->n - 1);
   if (o->ufb_nstore && o->ufb_store_idx[o->ufb_nstore - 1] == tree_index) return;
+  { int i; for (i = 0; i < o->ufb_nstore; i++) if (o->ufb_store_idx[i] == tree_index) return; }
   if (o->ufb_nstore == o->ufb_store_cap) {
     o->ufb_store_cap = o->ufb_store_cap ? 2 * o->ufb_store_cap : 64;
     o->ufb_store_idx = (int *)realloc(o->ufb_store_idx, sizeof(int) * o->ufb_store_cap);
@@ -666,9 +674,49 @@ static int ufb_dot(const unsigned short *a, const unsigned short *b, int n)
   return have ? ufb_dot_avx2(a, b, n) : ufb_dot_scalar(a, b, n);
 }
 
+/* what printTree(WT_TAXON_ID | WT_SORT_TAXA) stands for: a canonical form of the unrooted topology -- the tree hung from
+   tip 1, an inner node written as -1 followed by its two subtrees, the one holding the smaller tip number first */
+static int canon_min(const orc *o, int r, int *mins)
+{
+  int a, b;
+  if (r / 3 <= o->n) return mins[r] = r / 3;
+  a = canon_min(o, o->back[NX(r)], mins);
+  b = canon_min(o, o->back[NX(NX(r))], mins);
+  return mins[r] = a < b ? a : b;
+}
+static void canon_emit(const orc *o, int r, const int *mins, int *out, int *k)
+{
+  int a, b;
+  if (r / 3 <= o->n) { out[(*k)++] = r / 3; return; }
+  out[(*k)++] = -1;
+  a = o->back[NX(r)]; b = o->back[NX(NX(r))];
+  if (mins[a] > mins[b]) { int t = a; a = b; b = t; }
+  canon_emit(o, a, mins, out, k);
+  canon_emit(o, b, mins, out, k);
+}
+/* treels.find(tree_str) / treels[tree_str] = tree_index (iqtree.cpp:3503-3513) */
+static int ufb_lookup_topology(orc *o, int tree_index)
+{
+  int len = 2 * o->n - 2, k = 0, i;
+  int *mins = (int *)malloc(sizeof(int) * 3 * (2 * o->n - 1)), *key = (int *)malloc(sizeof(int) * len);
+  canon_min(o, o->back[3], mins);
+  canon_emit(o, o->back[3], mins, key, &k);
+  free(mins);
+  for (i = 0; i < o->ufb_nkeys; i++)
+    if (memcmp(o->ufb_keys[i], key, sizeof(int) * (size_t)k) == 0) { free(key); return o->ufb_key_idx[i]; }
+  if (o->ufb_nkeys == o->ufb_keys_cap) {
+    o->ufb_keys_cap = o->ufb_keys_cap ? 2 * o->ufb_keys_cap : 64;
+    o->ufb_keys = (int **)realloc(o->ufb_keys, sizeof(int *) * o->ufb_keys_cap);
+    o->ufb_key_idx = (int *)realloc(o->ufb_key_idx, sizeof(int) * o->ufb_keys_cap);
+  }
+  o->ufb_keys[o->ufb_nkeys] = key;
+  o->ufb_key_idx[o->ufb_nkeys++] = tree_index;
+  return tree_index;
+}
+
 static void ufb_save_current_tree(orc *o, double cur_logl)
 {
-  int tree_index, sample, test_pars;
+  int tree_index, sample, test_pars, looked_up = 0;
   if (o->ufb_ratchet) {
     /* :3283-3295 "if on_ratchet_hclimb1, update cur_logl": REPS of _pattern_pars -- as the array stands, i.e. still
        holding the tree of the previous call that got past the filter below (or what the IQ-TREE kernel left there for
@@ -690,10 +738,29 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
     const unsigned short *bs = o->ufb_samples + (size_t)sample * o->P;
     int res = ufb_dot(o->ufb_ptn, bs, o->P);
     double rell = -(double)res;
+    if (o->ufb_mulhits) {                                                    /* :3498-3540, no draw, no boot_counts */
+      if (rell >= o->ufb_logl[sample]) {
+        int i, have = 0;
+        if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }   /* :3500-3514 */
+        if (rell > o->ufb_logl[sample]) { o->ufb_set_n[sample] = 0; o->ufb_logl[sample] = rell; }      /* :3516-3519 */
+        for (i = 0; i < o->ufb_set_n[sample]; i++) if (o->ufb_set[sample][i] == tree_index) have = 1;
+        if (!have) {                                                         /* :3530-3533 */
+          if (o->ufb_set_n[sample] == o->ufb_set_cap[sample]) {
+            o->ufb_set_cap[sample] = o->ufb_set_cap[sample] ? 2 * o->ufb_set_cap[sample] : 4;
+            o->ufb_set[sample] = (int *)realloc(o->ufb_set[sample], sizeof(int) * o->ufb_set_cap[sample]);
+          }
+          o->ufb_set[sample][o->ufb_set_n[sample]++] = tree_index;
+          ufb_store_tree(o, tree_index);
+        }
+      }
+      continue;
+    }
     if (rell > o->ufb_logl[sample] + o->ufb_eps ||                           /* :3686-3688 */
         (rell > o->ufb_logl[sample] - o->ufb_eps &&
          (o->ufb_draws++, tie_draw(o)) <= 1.0 / (double)(o->ufb_counts[sample] + 1))) {
-      ufb_store_tree(o, tree_index);                                         /* :3689-3707 */
+      /* :3689-3707: the tree string, once per call; a topology that was accepted before keeps its first index */
+      if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }
+      ufb_store_tree(o, tree_index);
       if (rell > o->ufb_logl[sample]) o->ufb_counts[sample] = 1;             /* :3710-3713 */
       if (rell > o->ufb_logl[sample]) o->ufb_logl[sample] = rell;            /* :3719 max() */
       o->ufb_trees[sample] = tree_index;                                     /* :3720 */
@@ -1000,6 +1067,13 @@ void orc_ufboot_detach(orc *o)
   for (i = 0; i < o->ufb_nstore; i++) free(o->ufb_store_back[i]);
   free(o->ufb_store_back); free(o->ufb_store_idx);
   free(o->ufb_w0); o->ufb_w0 = NULL;
+  for (i = 0; i < o->ufb_nkeys; i++) free(o->ufb_keys[i]);
+  free(o->ufb_keys); free(o->ufb_key_idx);
+  o->ufb_keys = NULL; o->ufb_key_idx = NULL; o->ufb_nkeys = o->ufb_keys_cap = 0;
+  if (o->ufb_set) for (i = 0; i < o->ufb_B; i++) free(o->ufb_set[i]);
+  free(o->ufb_set); free(o->ufb_set_n); free(o->ufb_set_cap);
+  o->ufb_set = NULL; o->ufb_set_n = o->ufb_set_cap = NULL;
+  o->ufb_mulhits = 0;
   free(o->ufb_samples); free(o->ufb_logl); free(o->ufb_counts); free(o->ufb_trees); free(o->ufb_treels); free(o->ufb_ptn);
   o->ufb_store_back = NULL; o->ufb_store_idx = NULL; o->ufb_nstore = o->ufb_store_cap = 0;
   o->ufb_samples = NULL; o->ufb_logl = NULL; o->ufb_counts = NULL; o->ufb_trees = NULL; o->ufb_treels = NULL; o->ufb_ptn = NULL;
@@ -1027,10 +1101,20 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsi
   o->ufb_on = 1;
   o->ufb_ratchet = 0;
   o->ufb_ratchet_booking = 1;
+  o->ufb_set = (int **)calloc(B, sizeof(int *));
+  o->ufb_set_n = (int *)calloc(B, sizeof(int));
+  o->ufb_set_cap = (int *)calloc(B, sizeof(int));
   orc_enable_persite(o, 1);                              /* perSiteScores = gbo_replicates > 0, sprparsimony.cpp:3245 */
 }
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff) { o->ufb_cutoff = logl_cutoff; }
 void orc_ufboot_set_ratchet_booking(orc *o, int on) { o->ufb_ratchet_booking = on != 0; }   /* !no_hclimb1_bb; next set_weights */
+void orc_ufboot_set_mulhits(orc *o, int on) { o->ufb_mulhits = on != 0; }                  /* params->multiple_hits */
+int orc_ufboot_sample_trees(const orc *o, int sample, int *out, int cap)                    /* boot_trees_parsimony[sample] */
+{
+  int i, n = o->ufb_set_n[sample];
+  for (i = 0; i < n && i < cap; i++) out[i] = o->ufb_set[sample][i];
+  return n;
+}
 int orc_ufboot_ntrees(const orc *o) { return o->ufb_ntrees; }
 int orc_ufboot_bad(const orc *o) { return o->ufb_bad; }
 unsigned long long orc_ufboot_draws(const orc *o) { return o->ufb_draws; }

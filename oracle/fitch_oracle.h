@@ -81,6 +81,8 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples /* [B][P] bo
 void orc_ufboot_detach(orc *o);
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff);       /* 0 = none (iqtree.cpp:3343) */
 void orc_ufboot_set_ratchet_booking(orc *o, int on);          /* 0 = -no_hclimb1_bb (iqtree.cpp:3280); default 1 */
+void orc_ufboot_set_mulhits(orc *o, int on);                  /* 1 = -mulhits update rule (iqtree.cpp:3498-3540); right after attach */
+int orc_ufboot_sample_trees(const orc *o, int sample, int *out, int cap);   /* boot_trees_parsimony[sample] (insertion order); returns its size */
 int orc_ufboot_ntrees(const orc *o);                          /* treels_logl.size() */
 int orc_ufboot_bad(const orc *o);                             /* # candidates whose pattern-score sum != mp (:3366) */
 unsigned long long orc_ufboot_draws(const orc *o);

@@ -83,6 +83,9 @@ def lib():
         L.orc_ufboot_detach.argtypes = [vp]
         L.orc_ufboot_set_cutoff.argtypes = [vp, C.c_double]
         L.orc_ufboot_set_ratchet_booking.argtypes = [vp, ci]
+        L.orc_ufboot_set_mulhits.argtypes = [vp, ci]
+        L.orc_ufboot_sample_trees.restype = ci
+        L.orc_ufboot_sample_trees.argtypes = [vp, ci, vp, ci]
         L.orc_ufboot_ntrees.restype = ci
         L.orc_ufboot_ntrees.argtypes = [vp]
         L.orc_ufboot_bad.restype = ci
@@ -251,6 +254,16 @@ class Oracle:
 
     def ufboot_set_ratchet_booking(self, on: bool):
         lib().orc_ufboot_set_ratchet_booking(self.h, 1 if on else 0)
+
+    def ufboot_set_mulhits(self, on: bool):
+        lib().orc_ufboot_set_mulhits(self.h, 1 if on else 0)
+
+    def ufboot_sample_trees(self, sample: int):
+        """boot_trees_parsimony[sample] under -mulhits, sorted"""
+        n = lib().orc_ufboot_sample_trees(self.h, int(sample), _p(np.zeros(1, dtype=np.int32)), 0)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        lib().orc_ufboot_sample_trees(self.h, int(sample), _p(out), n)
+        return sorted(int(x) for x in out[:n])
 
     def ufboot_set_cutoff(self, logl_cutoff: float):
         lib().orc_ufboot_set_cutoff(self.h, float(logl_cutoff))

@@ -75,6 +75,10 @@ class SlowSearch:
             self.pattern_pars = np.zeros(self.P, dtype=np.int64)     # _pattern_pars: persists between calls
             self.ratchet = False
             self.ratchet_booking = True                    # !params->no_hclimb1_bb
+            self.mulhits = False                           # params->multiple_hits
+            self.treels = {}                               # topology -> tree index (only trees that hit, :3503-3513)
+            self.boot_sets = [set() for _ in range(B)]     # boot_trees_parsimony
+            self.largest_set = 0
 
     def draw(self) -> float:
         self.draws += 1
@@ -138,7 +142,22 @@ class SlowSearch:
 
         reorder(self.back[self.start])
 
-    # ---------------------------------------------------------------- saveCurrentTree, default options
+    def splits(self, back) -> frozenset:
+        """the topology as its set of bipartitions (each named by the side without tip 1): what the sorted tree string
+        of the reference identifies"""
+        n, out = self.n, set()
+
+        def down(rec):
+            if rec // 3 <= n:
+                return frozenset([rec // 3])
+            s = down(int(back[nx(rec)])) | down(int(back[nx(nx(rec))]))
+            out.add(s)
+            return s
+
+        down(int(back[3]))
+        return frozenset(out)
+
+    # ---------------------------------------------------------------- saveCurrentTree, default options (+ -mulhits)
     def save_current_tree(self, cur_logl: float):
         if not self.bb_on:
             return
@@ -149,14 +168,32 @@ class SlowSearch:
         tree_index = len(self.treels_logl)
         self.treels_logl.append(cur_logl)
         self.pattern_pars = self.pattern_lengths(self.back)            # :3365 pllComputePatternParsimony
+        looked_up = False
         for b in range(self.samples.shape[0]):                         # :3411
             rell = -float((self.pattern_pars * self.samples[b]).sum())
+            if self.mulhits:                                           # :3498-3540
+                if rell >= self.boot_logl[b]:
+                    if not looked_up:
+                        key = self.splits(self.back)
+                        tree_index = self.treels.setdefault(key, tree_index)
+                        looked_up = True
+                    if rell > self.boot_logl[b]:
+                        self.boot_sets[b].clear()
+                        self.boot_logl[b] = rell
+                    if tree_index not in self.boot_sets[b]:
+                        self.boot_sets[b].add(tree_index)
+                        self.largest_set = max(self.largest_set, len(self.boot_sets[b]))
+                        self.topologies.setdefault(tree_index, list(self.back))
+                continue
             accept = rell > self.boot_logl[b] + self.eps
             if not accept and rell > self.boot_logl[b] - self.eps:     # :3687-3688, short-circuit: the draw only on a tie
                 self.ufb_draws += 1
                 accept = self.draw() <= 1.0 / (self.boot_counts[b] + 1)
             if accept:
-                self.topologies[tree_index] = list(self.back)
+                if not looked_up:                                       # :3689-3707
+                    tree_index = self.treels.setdefault(self.splits(self.back), tree_index)
+                    looked_up = True
+                self.topologies.setdefault(tree_index, list(self.back))
                 if rell > self.boot_logl[b]:
                     self.boot_counts[b] = 1
                     self.boot_logl[b] = rell

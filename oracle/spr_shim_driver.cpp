@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 extern "C" {
@@ -48,6 +49,7 @@ struct Host {
   int B = 0, P = 0;
   std::vector<unsigned short> samples;         // boot_samples_pars
   double logl_cutoff = 0;
+  int mulhits = 0;
 };
 static Host H;
 
@@ -76,6 +78,18 @@ static void hk_sync(IQTree *, mpf_engine *e)
   std::printf("\nufb_boot_trees");
   for (int v : bt) std::printf(" %d", v);
   std::printf("\n");
+  if (H.mulhits) {                                  // boot_trees_parsimony: "sample size entries..." per sample, flattened
+    std::printf("ufb_boot_sets");
+    for (int b = 0; b < H.B; b++) {
+      int32_t k = 0;
+      mpf_ufboot_get_sample_trees(e, b, nullptr, 0, &k);
+      std::vector<int64_t> st((size_t)std::max(k, 1));
+      mpf_ufboot_get_sample_trees(e, b, st.data(), k, &k);
+      std::printf(" %d", (int)k);
+      for (int i = 0; i < k; i++) std::printf(" %lld", (long long)st[(size_t)i]);
+    }
+    std::printf("\n");
+  }
 }
 
 static unsigned long long g_lcg;
@@ -149,6 +163,7 @@ int main(int argc, char **argv)
   hooks.logl_cutoff = hk_cutoff;
   hooks.ufboot_sync = hk_sync;
   hooks.no_hclimb1_bb = argc > 9 ? std::atoi(argv[9]) : 0;     // mpboot's default books ratchet climbs too (iqtree.cpp:3280)
+  hooks.multiple_hits = H.mulhits = argc > 10 ? std::atoi(argv[10]) : 0;   // -mulhits
   resetGlobalParamOnNewAln();
   mpfitch_shim_install(&hooks);
   static std::vector<unsigned int> cost;

@@ -33,3 +33,27 @@ def trace_tokens(q, mp):
         else:
             out.append(f"{int(a)}:{int(b)}")
     return out
+
+
+def topology_splits(back, n):
+    """the unrooted topology behind a record-link array as its set of bipartitions (each named by the side without tip 1)"""
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 8 * n + 200))
+    nxt = lambda r: 3 * (r // 3) + (r % 3 + 1) % 3
+    out = set()
+
+    def down(rec):
+        if rec // 3 <= n:
+            return frozenset([rec // 3])
+        s = down(int(back[nxt(rec)])) | down(int(back[nxt(nxt(rec))]))
+        out.add(s)
+        return s
+
+    down(int(back[3]))
+    return frozenset(out)
+
+
+def same_topology(a, b, n):
+    """stored boot trees: the engine drops a tree no sample points to any more and stores the topology again (from whichever
+    candidate reaches it next) when its index is taken up again, so two stores may number the inner nodes differently"""
+    return topology_splits(a, n) == topology_splits(b, n)

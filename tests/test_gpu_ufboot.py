@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import load_fixture
+from helpers import load_fixture, same_topology
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +68,7 @@ def assert_same(e, o, se, so):
     assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
     for t in sorted(set(te.tolist())):
         if t >= 0:
-            assert (e.ufboot_tree(t) == o.ufboot_tree(t)).all()
+            assert same_topology(e.ufboot_tree(t), o.ufboot_tree(t), e.n)
 
 
 @pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa"])
@@ -239,7 +239,7 @@ import os, sys, json
 import numpy as np
 sys.path.insert(0, os.environ["MPF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MPF_ROOT"], "tests"))
 import torch.distributed as dist
-from helpers import load_fixture
+from helpers import load_fixture, same_topology
 from mpboot_amd import engine, shard
 dist.init_process_group("gloo")
 rank, ws = shard.world()
@@ -385,7 +385,7 @@ def test_ratchet_climbs_are_booked_like_the_reference(mods, name, cut):
         assert (e.get_tree() == o.get_tree()).all()
         for ti in sorted(set(e.ufboot_state()[2].tolist())):
             if ti >= 0:
-                assert (e.ufboot_tree(ti) == o.ufboot_tree(ti)).all()
+                assert same_topology(e.ufboot_tree(ti), o.ufboot_tree(ti), fx["n"])
 
     for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
         x.seed_ties(mode, 23)
@@ -440,3 +440,66 @@ def test_no_hclimb1_bb_leaves_ratchet_climbs_unbooked(mods):
     e.set_tree(np.array(fx["trees"][2]["back"], dtype=np.int32))
     e.optimize_spr(1, 6)
     assert len(e.ufboot_tree_logl()) > n_saved
+
+
+@pytest.mark.parametrize("cut", ["none", "top50"])
+@pytest.mark.parametrize("opts", [{}, {"scan_batch": 5, "split_below": 0}])
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48"])
+def test_mulhits_rule_matches_oracle(mods, name, cut, opts):
+    """-mulhits (params->multiple_hits, iqtree.cpp:3498-3540) over a normal climb, a ratchet climb and the climb back: the
+    per-sample sets of equally good trees (with the reference's one-index-per-topology rule), boot_logl, the booked list and
+    the topologies the sets name == the oracle's; no random draw is spent, so the SPR trajectory differs from the default
+    rule's and must still be the oracle's"""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    samples = boot_samples(len(w0), 24, 29, fx["weights"])
+    rng = np.random.default_rng(8)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"])
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"])
+    for k, v in opts.items():
+        e.set_option(k, v)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (2, 5, 7)]
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.seed_ties(mode, 31)
+        x.ufboot_attach(samples)
+        x.ufboot_set_mulhits(True)
+    largest = 0
+    for k, w in enumerate((w0, pert, w0)):
+        for x in (e, o):
+            x.set_weights(w)
+            x.set_tree(t[k])
+        o.trace(True)
+        assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+        assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+        assert (e.get_tree() == o.get_tree()).all()
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert e.ufboot_state()[0].tolist() == o.ufboot_state()[0].tolist()
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws() == 0
+        for b in range(len(samples)):
+            got = e.ufboot_sample_trees(b)
+            assert got == o.ufboot_sample_trees(b) and len(got) >= 1
+            largest = max(largest, len(got))
+            for ti in got:
+                assert same_topology(e.ufboot_tree(ti), o.ufboot_tree(ti), fx["n"])
+        if k == 0 and cut == "top50":
+            logl = np.sort(o.ufboot_tree_logl())
+            for x in (e, o):
+                x.ufboot_set_cutoff(float(logl[len(logl) // 2]))
+    assert o.ufboot_bad() == 0
+
+
+def test_mulhits_must_be_chosen_before_the_first_booking(mods):
+    engine, _ = mods
+    fx = load_fixture("dna_clean")
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    with pytest.raises(engine.MpfError):
+        e.ufboot_set_mulhits(True)                               # no tracker
+    e.ufboot_attach(boot_samples(len(fx["weights"]), 4, 1, fx["weights"]))
+    with pytest.raises(engine.MpfError):
+        e.ufboot_sample_trees(0)                                 # default rule in force
+    e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    e.optimize_spr(1, 3)
+    with pytest.raises(engine.MpfError):
+        e.ufboot_set_mulhits(True)                               # trees already booked under the default rule

@@ -91,3 +91,39 @@ def test_save_current_tree_over_normal_ratchet_normal_climbs(name, seed, cut):
     assert o.optimize_spr(1, 6) == s.optimize(1, 6)
     bb_same(o, s)
     assert o.ufboot_bad() == 0
+
+
+@pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9), ("dna_clean", 6)])
+def test_mulhits_rule_over_normal_ratchet_normal_climbs(name, seed):
+    """-mulhits (iqtree.cpp:3498-3540): every tree that reaches a sample's best REPS joins its set, trees of one
+    topology share the index of the first of them that hit, no random draw is spent on the bookkeeping"""
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(seed)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=6).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 3, 5)]
+    o, s = both(fx, seed, samples)
+    o.ufboot_set_mulhits(True)
+    s.mulhits = True
+    largest = 0
+    for k, w in enumerate((w0, pert, w0)):
+        for x in (o, s):
+            x.set_weights(w)
+            x.set_tree(t[k])
+        assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+        assert o.get_tree().tolist() == s.back
+        assert o.ufboot_tree_logl().tolist() == s.treels_logl
+        logl = o.ufboot_state()[0]
+        assert [-LONG_MAX if v <= -LONG_MAX / 2 else v for v in logl.tolist()] == s.boot_logl
+        for b in range(len(samples)):
+            got = o.ufboot_sample_trees(b)
+            assert got == sorted(s.boot_sets[b]) and len(got) >= 1
+            for ti in got:
+                assert o.ufboot_tree(ti).tolist() == s.topologies[ti]
+        assert o.ufboot_draws() == s.ufb_draws == 0
+        largest = max(largest, max(len(x) for x in s.boot_sets))
+    print("largest set at a checkpoint", largest, "ever", s.largest_set)
+    assert s.largest_set > 1                                 # some sample really held several equally good trees
+    # one topology met again keeps its first index: fewer distinct indices than hits
+    assert len(s.treels) < len(s.treels_logl)
