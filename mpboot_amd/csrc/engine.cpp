@@ -60,6 +60,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     set_error("mpf_engine_create: only DNA (4 states) and protein (20 states) are supported");
     return MPF_E_UNSUPPORTED;
   }
+  if (const char *hp = std::getenv("MPF_HOST_POLL")) host_poll_ = std::atoi(hp) ? 1 : 0;        // (experiments)
   if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -740,6 +741,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
   }
   if (direct) {
     // one small upload (ops, offsets, topology deltas, scan descriptors); the topology array itself stays where it is
+    // (letting the kernels read the pinned buffer itself instead costs more than this copy: 25 workgroups fetching their
+    //  descriptors over PCIe -- a C3 climb takes 0.35 s instead of 0.29 s)
     HIPCHK(hipMemcpyAsync(d_cstage_.p, h_vstage_.p + ops_off, tail - ops_off, hipMemcpyHostToDevice, st_));
     if (full) kids_dirty_ = false;
   } else if (kids_dirty_ || kids_upload_ || nops) {
@@ -997,6 +1000,17 @@ int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
   return MPF_OK;
 }
 
+// spin on a flag word a kernel raises in pinned host memory; false after ~50 ms (the caller then synchronises the stream,
+// which also surfaces a failed launch)
+static bool wait_host_flag(const uint32_t *flag)
+{
+  for (long spin = 0; spin < 20000000L; spin++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 1u) return true;
+    __builtin_ia32_pause();
+  }
+  return false;
+}
+
 int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host)
 {
   (void)plans;
@@ -1023,6 +1037,7 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   zeroed_words_ = 0;
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
   const bool host_direct = want_host_results_ && !sankoff_ && nout <= 16384 && (cnt_on_host_ || !cnt_copy_pending_);
+  if (host_direct) __atomic_store_n(h_out() + nout, 0u, __ATOMIC_RELAXED);       // the flag word behind the results
   HIPCHK(launch_scan(st_, g_, d_vec_, dhdr, (int)nh, dprog, d_out(), prog_max_depth_, host_direct ? h_out() : nullptr, (uint32_t)nout,
                      d_done_.p + 16));
   if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
@@ -1034,7 +1049,7 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   } else {
     HIPCHK(hipMemcpyAsync(h_out(), d_out(), nout * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   }
-  HIPCHK(hipStreamSynchronize(st_));
+  if (!(host_direct && host_poll_ && !timing_ && wait_host_flag(h_out() + nout))) HIPCHK(hipStreamSynchronize(st_));
   finish_views();
   float ms = 0;
   if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
@@ -1211,6 +1226,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     // small batch: the kernels write the host's copies themselves (mutation counts: the refresh's fold; candidate costs:
     // the scan's last workgroup) -- no copy-back dispatch
     const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && (cnt_on_host_ || !cnt_copy_pending_);
+    if (host_direct) __atomic_store_n(h_out() + nout, 0u, __ATOMIC_RELAXED);     // the flag word behind the results
     // planned program (plan kernel + pipelined scan) for throughput batches; the device-walked kernel for the small,
     // latency-bound batches inside a climb (scan_prog 2: always planned), for masks, protein and radii above 6
     const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
@@ -1250,7 +1266,11 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       HIPCHK(ufb_->h_info.reserve(nout));
       HIPCHK(hipMemcpyAsync(ufb_->h_info.p, ufb_->info.p, nout * sizeof(uint2), hipMemcpyDeviceToHost, st_));
     }
-    HIPCHK(hipStreamSynchronize(st_));
+    if (host_direct && host_poll_ && !timing_ && wait_host_flag(h_out() + nout)) {
+      // the scan's last workgroup has written the costs and raised the flag behind them: no need to wait for the stream
+    } else {
+      HIPCHK(hipStreamSynchronize(st_));
+    }
     if (check_counts_)
       for (size_t i = 0; i < nd; i++)
         if (h_ncand_.p[i] != h_walk_.p[i].pad0) { set_error("device/host candidate count mismatch"); return MPF_E_STATE; }
@@ -1537,6 +1557,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
+  if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }

@@ -316,11 +316,13 @@ class Engine {
   DevBuf<uint8_t> d_vstage_;
   PinBuf<uint8_t> h_vstage_;
   bool cnt_copy_pending_ = false;
+  int host_poll_ = 1;                            // wait for host-written results by polling their flag word instead of a stream synchronisation
   int timing_ = 0;                               // HIP events around kernels: 1 = scan kernels, 2 = refresh kernels too (≈5 µs per event)
   // the candidate costs start on a 256-byte boundary and are cleared in whole 256-byte units: a memset of an
   // unaligned range is split by the runtime into up to three fill kernels (5 us each, per accepted move)
   size_t out_off() const { return (nslots_ + 63) & ~(size_t)63; }
-  static size_t clear_words(size_t nout) { return ((nout ? nout : 1) + 63) & ~(size_t)63; }
+  // (+1: word nout of the host's copy is the "results are there" flag of a launch that writes them itself)
+  static size_t clear_words(size_t nout) { return ((nout ? nout : 1) + 1 + 63) & ~(size_t)63; }
   uint32_t *d_cnt() { return d_res_.p; }
   uint32_t *d_out() { return d_res_.p + out_off(); }
   uint32_t *h_cnt() { return h_res_.p; }

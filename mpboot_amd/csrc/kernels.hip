@@ -713,6 +713,19 @@ __device__ __forceinline__ void scan_body(const uint32_t *__restrict__ vec, cons
   }
 }
 
+// Tail of a launch whose last workgroup has just copied its n_out results into the host's pinned buffer: the completion
+// counter goes back to zero and host_out[n_out] = 1 tells a polling host thread that results (and the mutation counts an
+// earlier launch wrote to the host) are there -- without the wake-up latency of a stream synchronisation.
+__device__ __forceinline__ void host_results_ready(uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done)
+{
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(host_out + n_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // host_out != nullptr (stepwise addition): the last workgroup copies the n_out costs to the host's pinned buffer, as in
 // k_scan_walk
 template <int S, int VW, int MAXD, int RED>
@@ -734,7 +747,7 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t *__restrict__ vec, 
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
-    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host_results_ready(host_out, n_out, done);
   }
 }
 
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
-    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host_results_ready(host_out, n_out, done);
   }
 }
 
@@ -1335,7 +1348,7 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
-    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host_results_ready(host_out, n_out, done);
   }
 }
 
