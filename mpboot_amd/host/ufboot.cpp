@@ -337,6 +337,29 @@ void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
   u.stored++;
 }
 
+// events into replay order: by scan output index, then by sample.  The current tree, booked once per prune-node visit, ties
+// with every sample it is the best tree of -- millions of events per sweep -- so large batches take two stable counting
+// passes (sample, then index) instead of a comparison sort.
+static void sort_events(std::vector<UfbEvent> &ev, std::vector<UfbEvent> &tmp, std::vector<uint32_t> &count, uint32_t n_idx, uint32_t n_samples)
+{
+  const size_t n = ev.size();
+  if (n < 8192) {
+    std::sort(ev.begin(), ev.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
+    return;
+  }
+  tmp.resize(n);
+  auto pass = [&](const std::vector<UfbEvent> &src, std::vector<UfbEvent> &dst, uint32_t nkeys, bool by_idx) {
+    count.assign((size_t)nkeys + 1, 0u);
+    for (const UfbEvent &e : src) count[(size_t)(by_idx ? e.idx : e.b) + 1]++;
+    for (size_t k = 1; k <= nkeys; k++) count[k] += count[k - 1];
+    for (const UfbEvent &e : src) dst[count[by_idx ? e.idx : e.b]++] = e;
+  };
+  uint32_t max_idx = 0;
+  for (const UfbEvent &e : ev) max_idx = std::max(max_idx, e.idx);     // (a sharded run's merged events: other ranks' indices too)
+  pass(ev, tmp, n_samples, false);
+  pass(tmp, ev, std::max(n_idx, max_idx + 1u), true);
+}
+
 // pllOptimizeSprParsimony's sweep loop (reference sprparsimony.cpp:3295-3316) with perSiteScores = 1, i.e. with
 // saveCurrentTree after every insertion test.  Same speculative batching as Engine::spr_sweeps.
 int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
@@ -354,7 +377,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     since_move_ = 0;
   }
   int batch = first_batch();
-  std::vector<UfbEvent> events;
+  std::vector<UfbEvent> events, ev_tmp;
+  std::vector<uint32_t> ev_count;
   std::vector<uint32_t> small, sel_rows, crow, self_list;
   std::vector<int32_t> mh_bk;                      // -mulhits: a candidate's topology and its canonical form
   std::string mh_key;
@@ -531,9 +555,30 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         }
         t1 = now_ms();
         u.t_dev += t1 - t0;
-        events.assign(u.h_ev.p, u.h_ev.p + n_ev);
         if (ratchet && have_C) lcol.assign(u.h_col.p, u.h_col.p + n_rows);
-        for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];       // local column -> sample of the run
+        const bool fused_sort = !u.exchange && n_ev >= 8192;
+        if (fused_sort) {
+          // straight from the pinned copy: local column -> sample of the run, ordered by sample (first counting pass)
+          events.resize(n_ev);
+          ev_tmp.resize(n_ev);
+          ev_count.assign((size_t)u.B + 1, 0u);
+          const UfbEvent *src = u.h_ev.p;
+          for (uint32_t k = 0; k < n_ev; k++) ev_count[(size_t)u.ids[(size_t)src[k].b] + 1]++;
+          for (size_t k = 1; k <= (size_t)u.B; k++) ev_count[k] += ev_count[k - 1];
+          for (uint32_t k = 0; k < n_ev; k++) {
+            UfbEvent e = src[k];
+            e.b = (uint32_t)u.ids[(size_t)e.b];
+            ev_tmp[ev_count[e.b]++] = e;
+          }
+          // ... then by scan output index (second pass, stable)
+          ev_count.assign((size_t)n_idx + 1, 0u);
+          for (const UfbEvent &e : ev_tmp) ev_count[(size_t)e.idx + 1]++;
+          for (size_t k = 1; k <= (size_t)n_idx; k++) ev_count[k] += ev_count[k - 1];
+          for (const UfbEvent &e : ev_tmp) events[ev_count[e.idx]++] = e;
+        } else {
+          events.assign(u.h_ev.p, u.h_ev.p + n_ev);
+          for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];       // local column -> sample of the run
+        }
         if (u.exchange) {
           // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
           static_assert(sizeof(UfbEvent) == sizeof(mpf_ufb_event), "event layouts must match");
@@ -546,7 +591,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
           events.assign(pa, pa + n_all_ev);
         }
-        std::sort(events.begin(), events.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
+        if (!fused_sort) sort_events(events, ev_tmp, ev_count, n_idx, (uint32_t)u.B);
         u.events += n_ev;
         t0 = now_ms();
         u.t_sort += t0 - t1;
