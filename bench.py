@@ -350,7 +350,7 @@ def main():
                     help="1 = also run the climb / -bb flow from a random topology (a start tree that is not already SPR-optimal)")
     ap.add_argument("--legs-timeout", type=int, default=180,
                     help="multi-GPU runs: seconds after which the headline line is printed without the secondary (-bb) legs")
-    ap.add_argument("--engines-per-gpu", type=int, default=4, help="concurrent engines (host threads) per GPU in the refinement leg")
+    ap.add_argument("--engines-per-gpu", type=int, default=6, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
@@ -592,6 +592,7 @@ def main():
     nondeg = None
     back_r = None
     legs_error = None
+    n_eng = 1
     if args.ufboot_samples > 0:
         try:
             B = args.ufboot_samples
@@ -629,8 +630,14 @@ def main():
                 online_best = -_logl[:n_rep]
             eng.ufboot_detach()
             if n_rep > 0:
+                # every engine is driven by its own host thread: not more of them than this rank's share of the usable cores
+                try:
+                    cores_here = len(os.sched_getaffinity(0))
+                except AttributeError:
+                    cores_here = os.cpu_count() or 1
+                n_eng = max(1, min(args.engines_per_gpu, max(2, cores_here // max(1, world))))
                 engines = [eng] + [engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
-                                   for _ in range(max(0, args.engines_per_gpu - 1))]
+                                   for _ in range(n_eng - 1)]
                 for extra in engines[1:]:
                     for kv in args.opt:
                         k, v = kv.split("=")
@@ -709,7 +716,7 @@ def main():
             res["bootstrap_wall_clock"] = {
                 "samples": ufb["samples"], "online_phase_s": ufb["seconds"], "refined_samples": boot[0], "refinement_s": boot[1],
                 "seconds": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
-                "scaling": "strong", "engines_per_gpu": args.engines_per_gpu,
+                "scaling": "strong", "engines_per_gpu": n_eng,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
                 "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
                         "samples sharded over the ranks) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "

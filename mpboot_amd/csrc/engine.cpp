@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include "../host/simd_util.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -1007,6 +1009,7 @@ static bool wait_host_flag(const uint32_t *flag)
   for (long spin = 0; spin < 20000000L; spin++) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 1u) return true;
     __builtin_ia32_pause();
+    if ((spin & 255) == 255) sched_yield();        // several engines per GPU poll from threads that may share cores
   }
   return false;
 }
