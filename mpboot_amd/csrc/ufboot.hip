@@ -51,26 +51,36 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // (both operands use the same (h, j) -> site map, so the sum over k is the intended one whatever order the
 // hardware assigns to the 64 k values).
 // Workgroup = 8 waves, tile 256 rows x 256 samples, wave tile 32 x 256 (2 x 16 MFMA tiles, 128 accumulator registers):
-// each weight byte is fetched once per 256 rows and each expanded A fragment feeds 16 MFMAs.  Four k-blocks per stage,
-// double-buffered in LDS (weights by LDS-DMA while the previous stage is multiplied).
+// each weight byte is fetched once per 256 rows and each expanded A fragment feeds 16 MFMAs.  KS k-blocks per stage, NS
+// stages in an LDS ring; weights AND mask words arrive by LDS-DMA while older stages are multiplied (counted vmcnt waits and a
+// raw s_barrier: __syncthreads() would drain the DMA requests of the younger stages).
 // blockIdx.y splits K; partial products are added with integer atomics (exact, order-independent).
-// MT x NT MFMA tiles per wave, WM x WN waves (tile = 16 MT WM rows x 16 NT WN samples), KS = k-blocks per LDS stage.
-template <int MT, int NT, int WM, int WN, int KS>
+// MT x NT MFMA tiles per wave, WM x WN waves (tile = 16 MT WM rows x 16 NT WN samples).
+// Where the time goes (profiles/r2/gemm_bounds.txt): the C3 sweep's main launch (110 592 rows) runs at 0.63 of the nominal
+// int8 peak; with expansion, fragment reads and copies all removed the same loop reaches only 0.60 of it over the whole leg
+// (0.45 with everything in), so what is left to gain inside the loop is the global -> LDS copy's issue cost (0.45 -> 0.57
+// without it); tile shape, ring depth and k-blocks per stage all land within 0.43-0.49.
+// EXPR (measurements only, results wrong): 1 = no bit -> byte expansion of the A fragments, 2 = B fragments read from LDS once
+// per stage instead of once per k-block, 3 = no global -> LDS copies inside the loop, 4 = all three (bare MFMA stream);
+// 6 (results right) = both waves of a SIMD issue their copies at the top of the stage, as before the staggering
+template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
                                                  int kb_per_split, const uint32_t *__restrict__ rowsel)
 {
   constexpr int TM = 16 * MT * WM, TN = 16 * NT * WN, NTH = 64 * WM * WN;
-  constexpr int kGemmAStride = 2 * KS + 1;           // words per row of the A stage tile (+1: bank spread)
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
   constexpr int LD = BT / (NTH * 16);                // 16-byte loads per thread per k-block
-  constexpr int AL = KS / 2;                         // 16-byte loads per row of the A stage tile
+  constexpr int AL = KS / 2;                         // 16-byte pieces per row of the A stage tile
+  constexpr int AT = AL * TM * 16;                   // bytes of the A tile of one stage
+  static_assert(KS % 2 == 0 && TM % 64 == 0, "stage shape");
   extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
-  // [2][KS][BT] weights, then [2][TM * kGemmAStride] mask words
+  // NS stages in a ring: [NS][KS][BT] weights, then [NS][AL][TM][4] mask words -- both filled by LDS-DMA
   uint8_t *s_b = s_raw;
-  uint32_t *s_a = reinterpret_cast<uint32_t *>(s_raw + 2 * KS * BT);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint8_t *s_a = s_raw + (size_t)NS * KS * BT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
+  constexpr bool STAGGER = EXPR != 6 && KS >= 4;
   // workgroups are dealt round-robin to the 8 XCDs: the 32 concurrent workgroups of an XCD share ONE column block,
   // so its slab of Wt streams through that XCD's L2 once per round
   const int col_blocks = Bp / TN;
@@ -93,53 +103,58 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
   const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
   const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
   // output row i multiplies mask row rowsel[i] (cut-off filter: only the candidates that are saved), or row i itself
+  const bool a_wave = tid < TM;                      // wave-uniform (TM % 64 == 0): these waves also fetch the mask rows
   const uint32_t arow_id = rowsel ? rowsel[rb * TM + (tid % TM)] : (uint32_t)(rb * TM + (tid % TM));
   const uint32_t *arow = masks + (size_t)arow_id * Wp;
-  uint4 areg[AL];
-#pragma unroll
-  for (int i = 0; i < AL; i++) areg[i] = make_uint4(0, 0, 0, 0);
 
-  // Stage copy.  The weights go global -> LDS directly (LDS-DMA, 16 bytes per lane: lane i of a wave lands at the wave's
-  // LDS base + 16 i, which is the tile's own linear layout), no staging registers and no ds_write; the few mask words
-  // take the register path.  kb_ is a multiple of KS below nkb (nkb % KS == 0): blocks past kb_end are fetched but
-  // never multiplied.
+  // Stage copy, all of it global -> LDS directly (LDS-DMA, 16 bytes per lane: lane i of a wave lands at the wave's LDS base
+  // + 16 i): the weights in the tile's own linear layout, the mask words as [piece][row][4 words].  No staging registers,
+  // no ds_write.  kb_ is a multiple of KS below nkb (nkb % KS == 0): blocks past kb_end are fetched but never multiplied.
   typedef __attribute__((address_space(3))) void lds_void;
-#define MPF_GLOAD(kb_, buf_)                                                                      \
+#define MPF_GLOAD_KB(kq_, s_, st_)                                                                \
   do {                                                                                            \
-    const int kq_ = min((kb_), nkb - KS);                                                         \
-    _Pragma("unroll") for (int s_ = 0; s_ < KS; s_++) {                                           \
-      const uint4 *src_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)(kq_ + s_) * wt_kstride); \
-      _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++)                                           \
-        __builtin_amdgcn_global_load_lds(src_ + tid + NTH * i_,                                   \
-            (lds_void *)(s_b + ((size_t)(buf_) * KS + s_) * BT + (size_t)((tid & ~63) + NTH * i_) * 16), 16, 0, 0); \
-    }                                                                                             \
-    if (tid < TM) {                                                                               \
-      _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++)                                           \
-        areg[i_] = *reinterpret_cast<const uint4 *>(arow + 2 * kq_ + 4 * i_);                     \
-    }                                                                                             \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(wt_tile + (size_t)((kq_) + (s_)) * wt_kstride); \
+    _Pragma("unroll") for (int i_ = 0; i_ < LD; i_++)                                             \
+      __builtin_amdgcn_global_load_lds(src_ + tid + NTH * i_,                                     \
+          (lds_void *)(s_b + ((size_t)(st_) * KS + (s_)) * BT + (size_t)((tid & ~63) + NTH * i_) * 16), 16, 0, 0); \
+    if (((s_) & 1) == 0 && a_wave)                                                                \
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(arow + 2 * (kq_) + 2 * (s_)), \
+          (lds_void *)(s_a + (size_t)(st_) * AT + (size_t)(((s_) >> 1) * TM + (tid & ~63)) * 16), 16, 0, 0); \
   } while (0)
-#define MPF_LSTORE(buf_)                                                                          \
+#define MPF_GLOAD(kb_, st_)                                                                       \
   do {                                                                                            \
-    if (tid < TM) {                                                                               \
-      uint32_t *a_ = s_a + (size_t)(buf_) * (TM * kGemmAStride) + tid * kGemmAStride;             \
-      _Pragma("unroll") for (int i_ = 0; i_ < AL; i_++) {                                         \
-        a_[4 * i_] = areg[i_].x; a_[4 * i_ + 1] = areg[i_].y; a_[4 * i_ + 2] = areg[i_].z; a_[4 * i_ + 3] = areg[i_].w; \
-      }                                                                                           \
-    }                                                                                             \
+    const int kq0_ = min((kb_), nkb - KS);                                                        \
+    _Pragma("unroll") for (int s0_ = 0; s0_ < KS; s0_++) MPF_GLOAD_KB(kq0_, s0_, st_);            \
   } while (0)
-  MPF_GLOAD(kb_begin, 0);
-  MPF_LSTORE(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA pieces of this wave have landed
-  __syncthreads();
+  // the stage needed next has landed when at most the NS - 2 younger stages' requests of this wave are outstanding
+#define MPF_STAGE_WAIT()                                                                          \
+  do {                                                                                            \
+    if (a_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (KS * LD + AL)) : "memory");  \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (KS * LD)) : "memory");              \
+  } while (0)
+#pragma unroll
+  for (int s = 0; s < NS - 1; s++) MPF_GLOAD(kb_begin + s * KS, s);
+  MPF_STAGE_WAIT();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
-  int buf = 0;
+  int st = 0;
   for (int kb = kb_begin; kb < kb_end; kb += KS) {
-    MPF_GLOAD(kb + KS, buf ^ 1);                     // clamped: the last stage prefetches a valid block it never uses
-    const uint8_t *sb = s_b + (size_t)buf * KS * BT;
-    const uint32_t *sa = s_a + (size_t)buf * (TM * kGemmAStride);
-    // every stage holds KS valid k-blocks (kb_per_split and nkb are multiples of KS): straight-line body, the
-    // B fragments of k-block s+1 are fetched from LDS while the MFMAs of k-block s run
+    // clamped: the last stages prefetch valid blocks they never use.  The stage written is the one multiplied in the
+    // previous iteration (every wave has passed the barrier behind it)
+    // the copy's issue takes a wave off the matrix core for a good thousand cycles per stage: the two waves that share a
+    // SIMD (w and w + 4) take turns -- one issues here, the other behind the first half of the stage's MFMAs
+    const bool late = STAGGER && ((wave >> 2) & 1);
+    if constexpr (EXPR != 3 && EXPR != 4) { if (!late) MPF_GLOAD(kb + (NS - 1) * KS, st == 0 ? NS - 1 : st - 1); }
+    const uint8_t *sb = s_b + (size_t)st * KS * BT;
+    const uint32_t *sa = reinterpret_cast<const uint32_t *>(s_a + (size_t)st * AT);
+    // straight-line body: the mask words and B fragments of k-block s+1 are requested from LDS (words first: LDS answers in
+    // order, and the words are what the next k-block needs first) while the MFMAs of k-block s run
     v4i bf[2][NT];
+    uint32_t aw[2][MT];
+#define MPF_AWORD(s_, i_) sa[(((2 * (s_) + (h >> 1)) >> 2) * TM + wr * 16 * MT + 16 * (i_) + r) * 4 + ((2 * (s_) + (h >> 1)) & 3)]
+#pragma unroll
+    for (int i = 0; i < MT; i++) aw[0][i] = MPF_AWORD(0, i);
 #pragma unroll
     for (int j = 0; j < NT; j++)
       bf[0][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
@@ -147,29 +162,39 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
     for (int s = 0; s < KS; s++) {
       if (s + 1 < KS) {
 #pragma unroll
-        for (int j = 0; j < NT; j++)
-          bf[(s + 1) & 1][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(s + 1) * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+        for (int i = 0; i < MT; i++) aw[(s + 1) & 1][i] = MPF_AWORD(s + 1, i);
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          if constexpr (EXPR == 2 || EXPR == 4) bf[(s + 1) & 1][j] = bf[s & 1][j];
+          else bf[(s + 1) & 1][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(s + 1) * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+        }
       }
 #pragma unroll
       for (int i = 0; i < MT; i++) {
-        const uint32_t word = sa[(wr * 16 * MT + 16 * i + r) * kGemmAStride + 2 * s + (h >> 1)];
-        const uint32_t bits = (word >> ((h & 1) * 16)) & 0xFFFFu;
+        const uint32_t bits = (aw[s & 1][i] >> ((h & 1) * 16)) & 0xFFFFu;
         v4i af;
+        if constexpr (EXPR == 1 || EXPR == 4) { af.x = af.y = af.z = af.w = (int)aw[s & 1][i]; } else {
         af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
         af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
         af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
         af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+        }
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[s & 1][j], acc[i][j], 0, 0, 0);
       }
+      if constexpr (EXPR != 3 && EXPR != 4) { if (s == KS / 2 - 1 && late) MPF_GLOAD(kb + (NS - 1) * KS, st == 0 ? NS - 1 : st - 1); }
     }
-    MPF_LSTORE(buf ^ 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    buf ^= 1;
+#undef MPF_AWORD
+    MPF_STAGE_WAIT();
+    // a raw barrier: __syncthreads() would drain the LDS-DMA requests of the younger stages (they count as pending LDS
+    // writes on the vector-memory counter) and with them the whole point of the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st = st + 1 == NS ? 0 : st + 1;
   }
 #undef MPF_GLOAD
-#undef MPF_LSTORE
+#undef MPF_GLOAD_KB
+#undef MPF_STAGE_WAIT
 
   // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
   const int row0 = rb * TM + wr * 16 * MT, col0 = cb * TN + wc * 16 * NT;
@@ -188,8 +213,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
       }
     }
 }
-template <int MT, int NT, int WM, int WN, int KS>
-constexpr size_t gemm_lds() { return 2 * (size_t)KS * (16 * NT * WN) * 64 + 2 * (size_t)(16 * MT * WM) * (2 * KS + 1) * sizeof(uint32_t); }
+template <int MT, int NT, int WM, int WN, int KS, int NS>
+constexpr size_t gemm_lds() { return (size_t)NS * KS * (16 * NT * WN) * 64 + (size_t)NS * (KS / 2) * (16 * MT * WM) * 16; }
 
 // R_T[b] = sum over rows of C[row][b]   (rt zeroed by the launcher; 64 rows per thread, integer atomics)
 __global__ __launch_bounds__(256) void k_colsum(const int32_t *__restrict__ C, int rows, int Bp, int32_t *__restrict__ rt)
@@ -337,7 +362,7 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
   return hipGetLastError();
 }
 
-template <int MT, int NT, int WM, int WN, int KS>
+template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0>
 static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
                                    int mult, int accumulate, const uint32_t *rowsel)
 {
@@ -346,7 +371,9 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   const int nkb = Wp / 2;
   // small batches: split K so that the launch still has a few workgroups per CU
   long tiles = (long)row_blocks * col_blocks;
-  const long want = 512;
+  // (measured on the batches of a C3 climb with 1000 samples: 512 workgroups 0.50 s of product kernels per climb, 192: 0.30 s
+  //  -- every K-split multiplies the atomic adds into C, and 192 workgroups already stream the weight matrix at full rate)
+  static const long want = std::getenv("MPF_GEMM_WANT") ? std::atol(std::getenv("MPF_GEMM_WANT")) : 192;
   int ksplit = 1;
   if (tiles < want) ksplit = (int)std::min<long>((want + tiles - 1) / tiles, std::max(1, nkb / 16));
   int per = (nkb + ksplit - 1) / ksplit;
@@ -365,13 +392,13 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  constexpr size_t lds = gemm_lds<MT, NT, WM, WN, KS>();
+  constexpr size_t lds = gemm_lds<MT, NT, WM, WN, KS, NS>();
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<MT, NT, WM, WN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
+  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
 }
 
@@ -385,10 +412,24 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   if (variant < 0) { const char *v = std::getenv("MPF_GEMM_VARIANT"); variant = v ? std::atoi(v) : 0; }
   if (Bp % 256 == 0) {
     // 8 x 1 waves of 32 rows x 256 samples: an expanded A fragment feeds 16 MFMAs (0.8 vector instructions per MFMA)
-    if (variant != 1) return launch_bitgemm_t<2, 16, 8, 1, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    return launch_bitgemm_t<4, 8, 4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    // few rows (the batches inside a climb): 512-row x 128-sample tiles -- twice the column blocks, half the K-splits
+    static const int small_v = std::getenv("MPF_GEMM_SMALL") ? std::atoi(std::getenv("MPF_GEMM_SMALL")) : 1;
+    if (small_v == 1 && rows_padded <= 1024) return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    static const int expr = std::getenv("MPF_GEMM_EXPERIMENT") ? std::atoi(std::getenv("MPF_GEMM_EXPERIMENT")) : 0;
+    if (expr == 1) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 1>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (expr == 2) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (expr == 3) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 3>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (expr == 6) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 6>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (expr == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    // variants (all within 0.43-0.49 of the nominal peak, tools/gemm_bounds.sh): 0 = two k-blocks per stage, four stages in
+    // the ring; 1 / 3 = 4 x 2 waves of 64 rows x 128 samples; default = 8 x 1 waves of 32 rows x 256 samples, four k-blocks
+    // per stage, two stages
+    if (variant == 1) return launch_bitgemm_t<2, 16, 8, 1, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (variant == 2) return launch_bitgemm_t<4, 8, 4, 2, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (variant == 3) return launch_bitgemm_t<4, 8, 4, 2, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    return launch_bitgemm_t<2, 16, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
   }
-  return launch_bitgemm_t<4, 8, 8, 1, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
 }
 
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)
