@@ -24,6 +24,7 @@
 namespace mpf {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------ join masks
 // mask[op][w] = ~OR_k(vec[a]_k & vec[b]_k): the sites that mutate on the join (a, b) of a rooted traversal;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 // EXPR (measurements only, results wrong): 1 = no bit -> byte expansion of the A fragments, 2 = B fragments read from LDS once
 // per stage instead of once per k-block, 3 = no global -> LDS copies inside the loop, 4 = all three (bare MFMA stream);
 // 6 (results right) = both waves of a SIMD issue their copies at the top of the stage, as before the staggering
-template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0>
+template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0, bool M32 = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
                                                  int kb_per_split, const uint32_t *__restrict__ rowsel)
@@ -94,11 +95,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
   const int kb_begin = blockIdx.y * kb_per_split, kb_end = min(nkb, kb_begin + kb_per_split);
   if (kb_begin >= kb_end) return;
 
-  v4i acc[MT][NT];
+  // M32: the same wave tile as (MT / 2) x (NT / 2) tiles of v_mfma_i32_32x32x32_i8, two per 64-site k-block -- half the
+  // matrix instructions per product (an MFMA holds the SIMD's vector issue for 8 cycles whatever its size)
+  constexpr int MT2 = MT / 2, NT2 = NT / 2;
+  static_assert(!M32 || (MT % 2 == 0 && NT % 2 == 0), "32x32 tiles pair the 16x16 ones");
+  v4i acc[M32 ? 1 : MT][M32 ? 1 : NT];
+  v16i acc32[M32 ? MT2 : 1][M32 ? NT2 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < MT; i++)
+    for (int i = 0; i < MT2; i++)
 #pragma unroll
-    for (int j = 0; j < NT; j++) acc[i][j] = (v4i){0, 0, 0, 0};
+      for (int j = 0; j < NT2; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc32[i][j][q] = 0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc[i][j] = (v4i){0, 0, 0, 0};
+  }
+  const int c32 = lane & 31, hh = lane >> 5;       // M32: fragment row / column of the lane and its half of the 32 k-slots
 
   const uint8_t *wt_tile = Wt + (size_t)cb * (TN / 16) * 1024;
   const size_t wt_kstride = (size_t)(Bp / 16) * 1024;
@@ -150,39 +166,86 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
     const uint32_t *sa = reinterpret_cast<const uint32_t *>(s_a + (size_t)st * AT);
     // straight-line body: the mask words and B fragments of k-block s+1 are requested from LDS (words first: LDS answers in
     // order, and the words are what the next k-block needs first) while the MFMAs of k-block s run
+    if constexpr (M32) {
+      // k-block s = two MFMA k-steps (kk): k-slot (hh, j) of step kk is site 64 kblk + 16 (2 kk + hh) + j, for A and B alike.
+      // The B fragment of lane (c32, hh) sits in the 16-column group c32 / 16 of the pair, row (2 kk + hh, c32 % 16) of its 1 KiB
+      v4i bf[2][NT];
+      uint32_t aw[2][2 * MT2];
+      const uint32_t boff = (uint32_t)(((c32 >> 4) * 4 + hh) * 256 + (c32 & 15) * 16);
+#define MPF_AWORD32(s_, kk_, i_) sa[(((2 * (s_) + (kk_)) >> 2) * TM + wr * 16 * MT + 32 * (i_) + c32) * 4 + ((2 * (s_) + (kk_)) & 3)]
+#define MPF_BFRAG32(s_, kk_, j_) *reinterpret_cast<const v4i *>(sb + (size_t)(s_) * BT + (size_t)(wc * NT + 2 * (j_)) * 1024 + (kk_) * 512 + boff)
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int i = 0; i < MT2; i++) aw[0][kk * MT2 + i] = MPF_AWORD32(0, kk, i);
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int j = 0; j < NT2; j++) bf[0][kk * NT2 + j] = MPF_BFRAG32(0, kk, j);
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        if (s + 1 < KS) {
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int i = 0; i < MT2; i++) aw[(s + 1) & 1][kk * MT2 + i] = MPF_AWORD32(s + 1, kk, i);
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int j = 0; j < NT2; j++) bf[(s + 1) & 1][kk * NT2 + j] = MPF_BFRAG32(s + 1, kk, j);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+          for (int i = 0; i < MT2; i++) {
+            const uint32_t bits = (aw[s & 1][kk * MT2 + i] >> (hh * 16)) & 0xFFFFu;
+            v4i af;
+            af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
+            af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+            af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+            af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+#pragma unroll
+            for (int j = 0; j < NT2; j++) acc32[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[s & 1][kk * NT2 + j], acc32[i][j], 0, 0, 0);
+          }
+        if constexpr (EXPR != 3 && EXPR != 4) { if (s == KS / 2 - 1 && late) MPF_GLOAD(kb + (NS - 1) * KS, st == 0 ? NS - 1 : st - 1); }
+      }
+#undef MPF_AWORD32
+#undef MPF_BFRAG32
+    } else {
     v4i bf[2][NT];
-    uint32_t aw[2][MT];
-#define MPF_AWORD(s_, i_) sa[(((2 * (s_) + (h >> 1)) >> 2) * TM + wr * 16 * MT + 16 * (i_) + r) * 4 + ((2 * (s_) + (h >> 1)) & 3)]
-#pragma unroll
-    for (int i = 0; i < MT; i++) aw[0][i] = MPF_AWORD(0, i);
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-      bf[0][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
-#pragma unroll
-    for (int s = 0; s < KS; s++) {
-      if (s + 1 < KS) {
-#pragma unroll
-        for (int i = 0; i < MT; i++) aw[(s + 1) & 1][i] = MPF_AWORD(s + 1, i);
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-          if constexpr (EXPR == 2 || EXPR == 4) bf[(s + 1) & 1][j] = bf[s & 1][j];
-          else bf[(s + 1) & 1][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(s + 1) * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+      uint32_t aw[2][MT];
+  #define MPF_AWORD(s_, i_) sa[(((2 * (s_) + (h >> 1)) >> 2) * TM + wr * 16 * MT + 16 * (i_) + r) * 4 + ((2 * (s_) + (h >> 1)) & 3)]
+  #pragma unroll
+      for (int i = 0; i < MT; i++) aw[0][i] = MPF_AWORD(0, i);
+  #pragma unroll
+      for (int j = 0; j < NT; j++)
+        bf[0][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+  #pragma unroll
+      for (int s = 0; s < KS; s++) {
+        if (s + 1 < KS) {
+  #pragma unroll
+          for (int i = 0; i < MT; i++) aw[(s + 1) & 1][i] = MPF_AWORD(s + 1, i);
+  #pragma unroll
+          for (int j = 0; j < NT; j++) {
+            if constexpr (EXPR == 2 || EXPR == 4) bf[(s + 1) & 1][j] = bf[s & 1][j];
+            else bf[(s + 1) & 1][j] = *reinterpret_cast<const v4i *>(sb + (size_t)(s + 1) * BT + (size_t)(wc * NT + j) * 1024 + (size_t)lane * 16);
+          }
         }
-      }
-#pragma unroll
-      for (int i = 0; i < MT; i++) {
-        const uint32_t bits = (aw[s & 1][i] >> ((h & 1) * 16)) & 0xFFFFu;
-        v4i af;
-        if constexpr (EXPR == 1 || EXPR == 4) { af.x = af.y = af.z = af.w = (int)aw[s & 1][i]; } else {
-        af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
-        af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-        af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-        af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+  #pragma unroll
+        for (int i = 0; i < MT; i++) {
+          const uint32_t bits = (aw[s & 1][i] >> ((h & 1) * 16)) & 0xFFFFu;
+          v4i af;
+          if constexpr (EXPR == 1 || EXPR == 4) { af.x = af.y = af.z = af.w = (int)aw[s & 1][i]; } else {
+          af.x = (int)((((bits)&0xFu) * 0x00204081u) & 0x01010101u);
+          af.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+          af.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+          af.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+          }
+  #pragma unroll
+          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[s & 1][j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[s & 1][j], acc[i][j], 0, 0, 0);
+        if constexpr (EXPR != 3 && EXPR != 4) { if (s == KS / 2 - 1 && late) MPF_GLOAD(kb + (NS - 1) * KS, st == 0 ? NS - 1 : st - 1); }
       }
-      if constexpr (EXPR != 3 && EXPR != 4) { if (s == KS / 2 - 1 && late) MPF_GLOAD(kb + (NS - 1) * KS, st == 0 ? NS - 1 : st - 1); }
     }
 #undef MPF_AWORD
     MPF_STAGE_WAIT();
@@ -196,8 +259,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
 #undef MPF_GLOAD_KB
 #undef MPF_STAGE_WAIT
 
-  // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
   const int row0 = rb * TM + wr * 16 * MT, col0 = cb * TN + wc * 16 * NT;
+  if constexpr (M32) {
+    // D layout of the 32x32 forms: column = lane & 31, row = 8 (reg / 4) + 4 (lane >> 5) + reg % 4
+#pragma unroll
+    for (int i = 0; i < MT2; i++)
+#pragma unroll
+      for (int j = 0; j < NT2; j++) {
+        const int col = col0 + 32 * j + c32;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int row = row0 + 32 * i + 8 * (q >> 2) + 4 * hh + (q & 3);
+          int32_t *p = C + (size_t)row * Bp + col;
+          const int v = acc32[i][j][q] * mult;
+          if (atomic) { if (v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          else *p = v;
+        }
+      }
+    return;
+  }
+  // D layout (all 16x16 MFMA forms on gfx950): column = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -362,7 +443,7 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
   return hipGetLastError();
 }
 
-template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0>
+template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0, bool M32 = false>
 static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
                                    int mult, int accumulate, const uint32_t *rowsel)
 {
@@ -394,11 +475,11 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   (void)hipGetDevice(&dev);
   constexpr size_t lds = gemm_lds<MT, NT, WM, WN, KS, NS>();
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR, M32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
+  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR, M32>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
 }
 
@@ -424,6 +505,8 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
     // variants (all within 0.43-0.49 of the nominal peak, tools/gemm_bounds.sh): 0 = two k-blocks per stage, four stages in
     // the ring; 1 / 3 = 4 x 2 waves of 64 rows x 128 samples; default = 8 x 1 waves of 32 rows x 256 samples, four k-blocks
     // per stage, two stages
+    if (variant == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 0, true>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (variant == 5) return launch_bitgemm_t<4, 8, 4, 2, 4, 2, 0, true>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (variant == 1) return launch_bitgemm_t<2, 16, 8, 1, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (variant == 2) return launch_bitgemm_t<4, 8, 4, 2, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (variant == 3) return launch_bitgemm_t<4, 8, 4, 2, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
