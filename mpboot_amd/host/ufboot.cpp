@@ -488,6 +488,9 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       const bool self_pass = !self_list.empty() && !skip_product && (ratchet || randomMP <= mp_max);
       if (n_idx > 0 && !skip_product && (n_rows > 0 || self_pass)) {
         const int rows_p = round_up((int)std::max<uint32_t>(n_rows, 1u), kUfbRowTile);
+        // (a batch whose prune nodes have no insertion test at all -- a five-taxon tree at radius 1 -- still books the current
+        //  tree at every visit: the scan launch that normally provides the mask / info buffers was skipped)
+        { int rc2 = ufb_reserve_scan(n_idx); if (rc2) return rc2; }
         // staging: thr[n_parts] | home[n_parts] | best[Bp] | crow[n_idx] | sel[rows_p] | self[n_self]
         const size_t o_crow = (size_t)2 * n_parts + (size_t)u.Bp, o_sel = o_crow + (compact ? (size_t)n_idx : 0);
         const size_t o_self = o_sel + (compact ? (size_t)rows_p : 0);

@@ -1,15 +1,21 @@
 """Randomised engine-vs-oracle comparison: small random alignments (both alphabets, ambiguity codes, gaps, zero and
 large weights, uninformative columns), random trees, radii 1..8, both tie rules, with and without the online UFBoot
 bookkeeping.  Everything observable must match the oracle exactly."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
+# extended runs: MPF_FUZZ_OFFSET shifts the random cases (the option sets keep cycling with the test's own index)
+FUZZ_OFFSET = int(os.environ.get("MPF_FUZZ_OFFSET", "0"))
+
 
 def random_case(seed):
     from mpboot_amd import synth, trees
 
+    seed = seed + FUZZ_OFFSET
     rng = np.random.default_rng(1000 + seed)
     aa = bool(rng.integers(0, 3) == 0)
     n = int(rng.integers(5, 41))

@@ -1,0 +1,136 @@
+"""Random SEQUENCES of calls on one engine against the oracle replaying the same calls.
+
+The engine keeps state between calls that the oracle does not have -- validity of the directional vectors, the plans cached per
+topology (refresh schedule, sweep descriptors, device program), speculative batch sizes, pooled scratch buffers -- so what
+matters here is the ORDER of operations: the same tree handed over again, re-weighting between scans of one topology, sweeps
+after climbs, a tree builder in between, options that change the kernels, a tracker attached half-way.  Every observable of
+every call must equal the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_fuzz import random_case
+
+pytestmark = pytest.mark.gpu
+
+STATE_OFFSET = int(os.environ.get("MPF_FUZZ_OFFSET", "0"))
+OPTION_SETS = [{}, {"scan_batch": 3, "split_below": 0}, {"scan_prog": 2, "split_below": 0, "scan_batch": 64}, {"views_mode": 1, "scan_batch": 2},
+               {"scan_prog": 2, "check_counts": 1}, {"views_mode": 2, "scan_batch": 1}, {"plan_cache": 0}, {"words_per_lane": 2},
+               {"scan_batch": 64, "prog_min_descs": 0}]
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_call_sequences_match_oracle(seed):
+    from mpboot_amd import engine, trees
+    from oracle import pyoracle as po
+
+    c = random_case(7000 + seed + STATE_OFFSET)
+    if c["aa"] and seed % 3:
+        c = random_case(9000 + seed + STATE_OFFSET)
+    rng = np.random.default_rng(seed + STATE_OFFSET)
+    dt_e, dt_o = (engine.AA, po.AA) if c["aa"] else (engine.DNA, po.DNA)
+    e = engine.FitchEngine(c["codes"], c["w"], datatype=dt_e)
+    o = po.Oracle(c["codes"], c["w"], datatype=dt_o)
+    if o.num_informative == 0:
+        return
+    n, P = c["n"], c["P"]
+    maxtrav = min(c["maxtrav"], 8)
+    for k, v in OPTION_SETS[seed % len(OPTION_SETS)].items():
+        e.set_option(k, v)
+    known = [c["back"], trees.random_topology(n, rng)]
+    for x in (e, o):
+        x.set_tree(known[0])
+        x.seed_ties(1, seed)                    # TIE_RANDOM on both sides
+    weights = [c["w"]]
+    tracked = False
+    log = []
+    for step in range(14):
+        op = int(rng.integers(0, 9))
+        if tracked and op in (1, 2):
+            op = 3                              # (the oracle's rearrangeParsimony books every test it makes: no bare scans once tracked)
+        log.append(op)
+        if str(step) in os.environ.get("MPF_STATEFUL_SKIP", "").split(","):
+            continue
+        if os.environ.get("MPF_STATEFUL_VERBOSE"):
+            print("step", step, "op", op, "tracked", tracked, "n", n, "P", P, "aa", c["aa"], "maxtrav", maxtrav, "opts", OPTION_SETS[seed % len(OPTION_SETS)], flush=True)
+        if op == 0:                             # a tree seen before (same topology again -> cached plans) or a new one
+            t = known[int(rng.integers(0, len(known)))] if rng.random() < 0.7 else trees.random_topology(n, rng)
+            assert e.score_tree(t) == o.score_tree(t), log
+        elif op == 1:                           # one prune node's candidates
+            nodep = o.nodep()
+            rec = int(nodep[1 + int(rng.integers(0, 2 * n - 2))])
+            cur = o.score_tree()                # (both sides: the call re-orders the node table the tree builder draws from)
+            assert e.score_tree() == cur, log
+            o.set_best(cur)
+            o.trace(True)
+            saved = o.get_tree().copy()
+            o.rearrange(rec, 1, maxtrav)
+            tq, tm = o.get_trace()
+            keep = tq >= 0
+            assert (o.get_tree() == saved).all()
+            q, mp, _ = e.spr_scan(rec, 1, maxtrav)
+            assert q.tolist() == tq[keep].tolist() and mp.tolist() == tm[keep].tolist(), log
+            for x in (e, o):
+                x.seed_ties(1, seed + step)     # (the oracle's tie rule drew random numbers during that scan)
+        elif op == 2:                           # a whole sweep: the best candidate score
+            cur = o.score_tree()
+            assert e.score_tree() == cur, log
+            ntests, best = e.sweep_scan(1, maxtrav)
+            lo = None
+            for rec in o.nodep()[1:2 * n - 1]:
+                o.set_best(cur)
+                o.trace(True)
+                o.rearrange(int(rec), 1, maxtrav)
+                tq, tm = o.get_trace()
+                if (tq >= 0).any():
+                    m = int(tm[tq >= 0].min())
+                    lo = m if lo is None else min(lo, m)
+            if lo is not None:
+                assert best == lo, log
+            for x in (e, o):
+                x.seed_ties(1, seed + step)
+        elif op == 3:                           # a climb
+            o.trace(True)
+            assert e.optimize_spr(1, maxtrav) == o.optimize_spr(1, maxtrav), log
+            assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()], log
+            assert (e.get_tree() == o.get_tree()).all(), log
+            known.append(e.get_tree().copy())
+            if tracked:
+                assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()], log
+                assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist(), log
+                assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws(), log
+        elif op == 4:                           # re-weighting (between scans of one topology: the plans stay, the vectors go)
+            if rng.random() < 0.5:
+                w = weights[int(rng.integers(0, len(weights)))]
+            else:
+                w = (weights[0] * (1 + (rng.random(P) < 0.3) * rng.integers(1, 3, size=P))).astype(np.int32)
+                weights.append(w)
+            for x in (e, o):
+                x.set_weights(w)
+            assert e.score_tree() == o.score_tree(), log
+        elif op == 5:                           # a stepwise-addition tree
+            sd = int(rng.integers(1, 1000))
+            dist = int(rng.integers(0, 4))
+            assert e.make_parsimony_tree(sd, dist) == o.make_tree(sd, dist)[0], log
+            assert (e.get_tree() == o.get_tree()).all(), log
+            known.append(e.get_tree().copy())
+        elif op == 6:                           # per-pattern lengths of the current tree
+            o.enable_persite(True)
+            assert e.score_tree() == o.score_tree(), log
+            pe, te = e.pattern_scores()
+            po_, to = o.pattern_scores()
+            assert te == to and pe.tolist() == po_.tolist(), log
+        elif op == 7 and not tracked and maxtrav <= 8 and (weights[0] > 0).any():      # attach the bookkeeping half-way
+            for x in (e, o):
+                x.set_weights(weights[0])
+            samples = rng.multinomial(max(1, int(weights[0].sum())), (weights[0] + 1e-9) / (weights[0] + 1e-9).sum(), size=5).astype(np.uint16)
+            e.ufboot_attach(samples)
+            o.ufboot_attach(samples)
+            tracked = True
+        elif op == 8:                           # the same tree handed over again, explicitly
+            t = e.get_tree().copy()
+            for x in (e, o):
+                x.set_tree(t)
+            assert e.score_tree() == o.score_tree(), log
+    assert e.score_tree() == o.score_tree(), log

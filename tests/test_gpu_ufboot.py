@@ -503,3 +503,34 @@ def test_mulhits_must_be_chosen_before_the_first_booking(mods):
     e.optimize_spr(1, 3)
     with pytest.raises(engine.MpfError):
         e.ufboot_set_mulhits(True)                               # trees already booked under the default rule
+
+
+@pytest.mark.parametrize("alphabet", ["DNA", "AA"])
+def test_tiny_tree_whose_prune_nodes_have_no_insertion_test(mods, alphabet):
+    """five taxa at radius 1: no prune node has a candidate branch, yet rearrangeParsimony books the current tree at every
+    visit (sprparsimony.cpp:2285-2289) -- a batch without a scan launch (regression: the mask / info buffers of the tracker
+    were only provided by that launch)"""
+    engine, po = mods
+    from mpboot_amd import synth, trees
+
+    letters, _ = synth.synth_alignment(5, 150, alphabet, 0.25, seed=4)
+    codes = synth.letters_to_codes(letters, alphabet)
+    dt_e, dt_o = (engine.AA, po.AA) if alphabet == "AA" else (engine.DNA, po.DNA)
+    e = engine.FitchEngine(codes, datatype=dt_e)
+    o = po.Oracle(codes, datatype=dt_o)
+    if o.num_informative == 0:
+        pytest.skip("no informative pattern")
+    back = trees.random_topology(5, np.random.default_rng(2))
+    samples = boot_samples(codes.shape[1], 6, 5)
+    for x in (e, o):
+        x.set_tree(back)
+        x.seed_ties(1, 9)
+        x.ufboot_attach(samples)
+    for radius in (1, 2, 6):
+        o.trace(True)
+        assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius)
+        assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+        assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+    assert len(o.ufboot_tree_logl()) > 0

@@ -1,12 +1,5 @@
 #!/bin/bash
-mkdir -p gpurun_out/k
-for v in 0 4 5; do
-MPF_GEMM_VARIANT=$v python bench.py --random-start-leg 0 --no-cpu --steps 2 --warmup 1 --bootstrap-replicates 0 > gpurun_out/k/g$v.json 2>gpurun_out/k/g$v.err
-python - $v <<'PY'
-import json, sys
-d = json.load(open(f"gpurun_out/k/g{sys.argv[1]}.json"))
-u = d["ufboot_online"]
-print(sys.argv[1], u["roofline"]["frac"], u["roofline"]["kernel_ms_total"], u["seconds_each_pass"])
-PY
+for sk in 0 1 2 3 4 5 6 7 8 9 10 "0,1,2,3" "4,5,6" "0,1,2,3,4,5,6,7"; do
+  out=$(MPF_STATEFUL_SKIP=$sk MPF_FUZZ_OFFSET=300 timeout 120 python -m pytest tests/test_gpu_stateful.py -x -q -k "oracle[57]" 2>&1 | tail -1)
+  echo "skip $sk: $out" | cut -c1-100
 done
-MPF_GEMM_VARIANT=4 MPF_GEMM_SMALL=0 timeout 900 python -m pytest tests/test_gpu_ufboot.py -x -q 2>&1 | tail -2
