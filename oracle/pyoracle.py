@@ -252,6 +252,9 @@ class Oracle:
         self.ufb_B = samples.shape[0]
         lib().orc_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon))
 
+    def ufboot_detach(self):
+        lib().orc_ufboot_detach(self.h)
+
     def ufboot_set_ratchet_booking(self, on: bool):
         lib().orc_ufboot_set_ratchet_booking(self.h, 1 if on else 0)
 

@@ -22,31 +22,66 @@ OPTION_SETS = [{}, {"scan_batch": 3, "split_below": 0}, {"scan_prog": 2, "split_
 
 @pytest.mark.parametrize("seed", range(60))
 def test_random_call_sequences_match_oracle(seed):
-    from mpboot_amd import engine, trees
-    from oracle import pyoracle as po
-
     c = random_case(7000 + seed + STATE_OFFSET)
     if c["aa"] and seed % 3:
         c = random_case(9000 + seed + STATE_OFFSET)
+    run_sequence(c, seed, 14)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_call_sequences_on_medium_trees(seed):
+    """60-200 taxa: sweeps that are cut into several batches, split scans, the planned-program kernel, whole-tree refreshes"""
+    from mpboot_amd import synth, trees
+
+    rng = np.random.default_rng(555 + seed + STATE_OFFSET)
+    n, P = int(rng.integers(60, 201)), int(rng.integers(150, 600))
+    aa = seed % 5 == 4
+    letters, _ = synth.synth_alignment(n, P, "AA" if aa else "DNA", float(rng.uniform(0.03, 0.12)), seed=seed + STATE_OFFSET)
+    codes = synth.letters_to_codes(letters, "AA" if aa else "DNA").copy()
+    codes[rng.random(codes.shape) < 0.02] = 22 if aa else 15
+    w = rng.integers(1, 3, size=P).astype(np.int32)
+    c = dict(aa=aa, n=n, P=P, codes=codes, w=w, back=trees.random_topology(n, rng), maxtrav=int(rng.integers(2, 7)))
+    run_sequence(c, seed, 8)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_call_sequences_weighted(seed):
+    """the same on the weighted (Sankoff) engine: random symmetric cost matrices, packed 16-bit and 32-bit costs"""
+    c = random_case(11000 + seed + STATE_OFFSET)
+    rng = np.random.default_rng(77 + seed + STATE_OFFSET)
+    S = 20 if c["aa"] else 4
+    m = rng.integers(1, 6 if seed % 3 else 4000, size=(S, S))
+    cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    run_sequence(c, seed, 10, cost=cost)
+
+
+def run_sequence(c, seed, n_steps, cost=None):
+    from mpboot_amd import engine, trees
+    from oracle import pyoracle as po
+
     rng = np.random.default_rng(seed + STATE_OFFSET)
     dt_e, dt_o = (engine.AA, po.AA) if c["aa"] else (engine.DNA, po.DNA)
-    e = engine.FitchEngine(c["codes"], c["w"], datatype=dt_e)
-    o = po.Oracle(c["codes"], c["w"], datatype=dt_o)
+    if cost is not None:
+        c["w"] = np.maximum(c["w"], 0)
+    e = engine.FitchEngine(c["codes"], c["w"], datatype=dt_e, cost=cost)
+    o = po.Oracle(c["codes"], c["w"], datatype=dt_o, cost=cost)
     if o.num_informative == 0:
         return
     n, P = c["n"], c["P"]
-    maxtrav = min(c["maxtrav"], 8)
+    maxtrav = min(c["maxtrav"], 8 if cost is None else 6)
     for k, v in OPTION_SETS[seed % len(OPTION_SETS)].items():
+        if cost is not None and k == "words_per_lane":
+            continue                            # (refused in weighted mode: one pattern per lane)
         e.set_option(k, v)
     known = [c["back"], trees.random_topology(n, rng)]
     for x in (e, o):
         x.set_tree(known[0])
         x.seed_ties(1, seed)                    # TIE_RANDOM on both sides
     weights = [c["w"]]
-    tracked = False
+    tracked = mulhits = False
     log = []
-    for step in range(14):
-        op = int(rng.integers(0, 9))
+    for step in range(n_steps):
+        op = int(rng.integers(0, 12))
         if tracked and op in (1, 2):
             op = 3                              # (the oracle's rearrangeParsimony books every test it makes: no bare scans once tracked)
         log.append(op)
@@ -92,7 +127,8 @@ def test_random_call_sequences_match_oracle(seed):
                 x.seed_ties(1, seed + step)
         elif op == 3:                           # a climb
             o.trace(True)
-            assert e.optimize_spr(1, maxtrav) == o.optimize_spr(1, maxtrav), log
+            radius = int(rng.integers(1, maxtrav + 1))
+            assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius), log
             assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()], log
             assert (e.get_tree() == o.get_tree()).all(), log
             known.append(e.get_tree().copy())
@@ -100,6 +136,9 @@ def test_random_call_sequences_match_oracle(seed):
                 assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()], log
                 assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist(), log
                 assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws(), log
+                if mulhits:
+                    for b in range(5):
+                        assert e.ufboot_sample_trees(b) == o.ufboot_sample_trees(b), log
         elif op == 4:                           # re-weighting (between scans of one topology: the plans stay, the vectors go)
             if rng.random() < 0.5:
                 w = weights[int(rng.integers(0, len(weights)))]
@@ -121,13 +160,31 @@ def test_random_call_sequences_match_oracle(seed):
             pe, te = e.pattern_scores()
             po_, to = o.pattern_scores()
             assert te == to and pe.tolist() == po_.tolist(), log
-        elif op == 7 and not tracked and maxtrav <= 8 and (weights[0] > 0).any():      # attach the bookkeeping half-way
+        elif op == 7 and cost is None and not tracked and maxtrav <= 8 and (weights[0] > 0).any():      # attach the bookkeeping half-way
             for x in (e, o):
                 x.set_weights(weights[0])
             samples = rng.multinomial(max(1, int(weights[0].sum())), (weights[0] + 1e-9) / (weights[0] + 1e-9).sum(), size=5).astype(np.uint16)
             e.ufboot_attach(samples)
             o.ufboot_attach(samples)
             tracked = True
+            mulhits = bool(rng.random() < 0.3)
+            if mulhits:
+                e.ufboot_set_mulhits(True)
+                o.ufboot_set_mulhits(True)
+        elif op == 9:                           # an option that changes kernels / batching / caching, mid-way
+            k, v = [("scan_batch", int(rng.integers(1, 65))), ("split_below", int(rng.integers(0, 3)) * 2048), ("plan_cache", int(rng.integers(0, 2))),
+                    ("scan_prog", int(rng.integers(0, 3))), ("views_mode", int(rng.integers(0, 3))), ("split_cands", int(rng.integers(8, 65))),
+                    ("prog_min_descs", int(rng.integers(0, 2)) * 256), ("host_poll", int(rng.integers(0, 2)))][int(rng.integers(0, 8))]
+            e.set_option(k, v)
+        elif op == 10 and tracked and not mulhits and len(o.ufboot_tree_logl()) > 20:      # a cut-off from the trees booked so far
+            logl = np.sort(o.ufboot_tree_logl())
+            cut = float(logl[int(rng.integers(0, len(logl)))])
+            e.ufboot_set_cutoff(cut)
+            o.ufboot_set_cutoff(cut)
+        elif op == 11 and tracked and rng.random() < 0.3:
+            e.ufboot_detach()
+            o.ufboot_detach()
+            tracked = mulhits = False
         elif op == 8:                           # the same tree handed over again, explicitly
             t = e.get_tree().copy()
             for x in (e, o):
