@@ -593,6 +593,8 @@ def main():
     back_r = None
     legs_error = None
     n_eng = 1
+    tb_nocache = None
+    n_distinct_trees = None
     if args.ufboot_samples > 0:
         try:
             B = args.ufboot_samples
@@ -628,6 +630,7 @@ def main():
                         cache[t] = eng.ufboot_tree(t)
                     boot_trees.append(cache[t])
                 online_best = -_logl[:n_rep]
+                n_distinct_trees = len(cache)
             eng.ufboot_detach()
             if n_rep > 0:
                 # every engine is driven by its own host thread: not more of them than this rank's share of the usable cores
@@ -649,6 +652,19 @@ def main():
                 barrier()
                 tb = time.perf_counter() - tb0
                 boot = (n_rep, tb, float(np.mean(bscores)), float(np.mean(online_best)), bool((bscores <= online_best).all()))
+                # the samples of this workload keep ONE tree (the start tree is SPR-optimal), so every refinement after an
+                # engine's first re-uses that topology's plans; a run whose samples keep different trees plans each of them:
+                # the same leg once more with the plan cache off
+                for x in engines:
+                    x.set_option("plan_cache", 0)
+                barrier()
+                tb0 = time.perf_counter()
+                bscores_nc, _ = bootstrap.refine_boot_trees(engines, samples[:n_rep], boot_trees, 7, args.maxtrav)
+                barrier()
+                tb_nocache = time.perf_counter() - tb0
+                for x in engines:
+                    x.set_option("plan_cache", 1)
+                assert (bscores_nc == bscores).all()
                 eng.set_weights(np.ones(P, dtype=np.int32))
             # ---- the same flow from a start tree that is NOT a local optimum (the RAS tree of this alignment already is one:
             # zero moves above): a random topology, thousands of accepted moves, refinements that really climb
@@ -716,11 +732,14 @@ def main():
             res["bootstrap_wall_clock"] = {
                 "samples": ufb["samples"], "online_phase_s": ufb["seconds"], "refined_samples": boot[0], "refinement_s": boot[1],
                 "seconds": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
+                "refinement_s_plan_cache_off": tb_nocache, "distinct_boot_trees": n_distinct_trees,
                 "scaling": "strong", "engines_per_gpu": n_eng,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
                 "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
                         "samples sharded over the ranks) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "
-                        "sample b on rank b %% n_gpus, several engines per GPU).  seconds = online + refinement scaled to all samples"
+                        "sample b on rank b %% n_gpus, several engines per GPU).  seconds = online + refinement scaled to all samples.  "
+                        "distinct_boot_trees = topologies the samples kept (1 here: every refinement after an engine's first re-uses "
+                        "that topology's plans); refinement_s_plan_cache_off = the same leg planning every tree from scratch"
                         % (ufb["samples"], args.maxtrav)}
         if boot is not None and not args.no_cpu and world == 1:
             res["bootstrap_wall_clock"]["cpu_baseline"] = refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, bscores,
