@@ -1020,6 +1020,7 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   ScopedMs timer(stats.host_scan_ms_total);
   const size_t nops = prog_ops_.size(), nh = prog_hdr_.size(), nout = prog_out_;
   out_host.assign(nout, 0);
+  if (scan_vals_) vals_rows_ = (uint32_t)nout;
   if (nh == 0 || nout == 0) { prog_ops_.clear(); prog_hdr_.clear(); prog_out_ = 0; prog_max_depth_ = 0; return MPF_OK; }
   HIPCHK(d_scanops_.reserve(nops));
   HIPCHK(d_scanhdr_.reserve(nh));
@@ -1041,8 +1042,18 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
   const bool host_direct = want_host_results_ && !sankoff_ && nout <= 16384 && (cnt_on_host_ || !cnt_copy_pending_);
   if (host_direct) __atomic_store_n(h_out() + nout, 0u, __ATOMIC_RELAXED);       // the flag word behind the results
+  uint16_t *vals = nullptr;
+  uint32_t *vmax = nullptr;
+  if (scan_vals_ && ufb_) {
+    // weighted tracker: per-pattern lengths of every tentative tree, one more row for the current tree behind them
+    HIPCHK(ufb_->vals.reserve((nout + 1) * (size_t)g_.Wp));
+    HIPCHK(ufb_->vmax.reserve(4));                // (zeroed by the caller)
+    vals = ufb_->vals.p;
+    vmax = ufb_->vmax.p;
+    vals_rows_ = (uint32_t)nout;
+  }
   HIPCHK(launch_scan(st_, g_, d_vec_, dhdr, (int)nh, dprog, d_out(), prog_max_depth_, host_direct ? h_out() : nullptr, (uint32_t)nout,
-                     d_done_.p + 16));
+                     d_done_.p + 16, vals, (uint32_t)g_.Wp, vmax));
   if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
   if (host_direct) {           // the kernels wrote the host's result buffers themselves
     cnt_copy_pending_ = false;
@@ -1365,9 +1376,12 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
       visits_filled_epoch_ = topo_epoch_;
     }
     for (int i = 0; i < count; i++) {
+      int64_t self = -1;
+      if (!walk && scan_vals_) self = (int64_t)prog_out_++;      // the current tree's slot in front of this prune node's candidates
       int rc = walk ? plan_walk(recs[i], mintrav, maxtrav, plans[(size_t)i], count <= split_below_)
                     : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);
       if (rc) return rc;
+      if (!walk) plans[(size_t)i].self_idx = self;
     }
   }
   if (walk && (plan_cache_ & 4) && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2) {

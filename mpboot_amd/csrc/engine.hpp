@@ -151,6 +151,15 @@ struct UfbState {
   uint32_t rt_orig = 0;                          // original-alignment length of the current tree (host copy of rt[orig column])
   bool gate_closed = false;                      // a booked tree failed the cut-off: nothing else is booked in this climb
   bool ratchet_booking = true;                   // false = params->no_hclimb1_bb (iqtree.cpp:3280): re-weighted climbs are not booked
+  // weighted (Sankoff) engine: a tentative tree's per-pattern lengths are not 0/1 increments of a mask -- the scan writes them
+  // as 16-bit values (vals), k_vals_planes slices them into bit planes (bitp) and REPS = sum_k 2^k (plane k x weights); the
+  // current tree's own row rides along in every product (it is the "home" row of the event formula, so s = C[candidate])
+  bool snk = false;
+  int Wp_s = 0;                                  // words per plane row (a multiple of 8), patterns in engine order
+  DevBuf<uint16_t> vals;                         // [rows][npat]
+  DevBuf<uint32_t> bitp;                         // [K][rows padded][Wp_s]
+  DevBuf<uint32_t> vmax;                         // largest per-pattern length of the batch (atomic max)
+  PinBuf<uint32_t> h_vmax;
   // -mulhits (params->multiple_hits, iqtree.cpp:3498-3540): per sample the SET of trees that reach its best REPS; trees of
   // one topology share the index of the first of them that hit (the reference's treels string map); no draws
   bool mulhits = false;
@@ -261,6 +270,7 @@ class Engine {
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   // online UFBoot-MP
   std::unique_ptr<UfbState> ufb_;
   // the tracker's large scratch buffers (candidate masks, product, events: ~1 GB at C3 x 1000 samples) outlive a detach, so
@@ -391,6 +401,8 @@ class Engine {
   std::vector<uint32_t> kid_upd_;
   std::vector<int> kids_list_;                  // records whose kids[] entry changed since the device copy was last complete
   bool kids_upload_ = false;
+  bool scan_vals_ = false;                       // weighted tracker: host-planned scans also write per-pattern lengths, a slot per prune node is reserved for the current tree
+  uint32_t vals_rows_ = 0;                       // output indices of the last such batch
   bool want_host_results_ = false, cnt_on_host_ = false;   // small batches: kernels write the host's result buffers themselves
   bool all_invalid_ = true;                     // no vector has been valid since the last wholesale invalidation
   std::vector<int> sb_roots_;

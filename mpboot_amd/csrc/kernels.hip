@@ -1520,7 +1520,8 @@ template <int S, int MAXD, bool PK>
 __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
                                                   int n_scans, const ScanOp *__restrict__ ops,
                                                   const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
-                                                  uint32_t *__restrict__ out, int We, int tiles)
+                                                  uint32_t *__restrict__ out, int We, int tiles,
+                                                  uint16_t *__restrict__ vals, uint32_t npat, uint32_t *__restrict__ vmax)
 {
   typedef SnkT<PK> T;
   const int lane = threadIdx.x & 63;
@@ -1529,6 +1530,7 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
   if (gw >= n_scans * tiles) return;
   const int scan = gw / tiles, tile = gw - scan * tiles;
   const ScanHdr h = hdr[scan];
+  uint32_t lane_max = 0;                           // (vals != nullptr: largest per-pattern length written by this lane)
   bool valid;
   const int e0 = lane_word<1>(tile, lane, We, valid);
   const uint32_t *mvec = vec + moff;
@@ -1575,13 +1577,31 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
       const uint32_t c = valid ? T::wsum(best, pwgt, e0) : 0u;
       const uint32_t tot = wave_total<0>(c);
       if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+      // online UFBoot on the weighted engine: the tentative tree's per-pattern lengths (what pllComputeSankoffPatternParsimony
+      // reads after the evaluate, sprparsimony.cpp:3341-3355), row o.out of vals[][npat]
+      if (vals && valid) {
+        if constexpr (PK) {
+          *reinterpret_cast<us2 *>(vals + (size_t)o.out * npat + 2 * e0) = best;
+          lane_max = max(lane_max, max((uint32_t)best.x, (uint32_t)best.y));
+        } else {
+          vals[(size_t)o.out * npat + e0] = (uint16_t)best;
+          lane_max = max(lane_max, (uint32_t)best);
+        }
+      }
     }
+  }
+  if (vals) {
+    uint32_t m = lane_max;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sh, 64));
+    if (lane == 0 && m) atomicMax(vmax, m);
   }
 }
 
 template <int S, bool PK>
 __global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict__ vec, size_t moff, uint32_t a_slot, uint32_t b_slot,
-                                                     const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int We)
+                                                     const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int We,
+                                                     uint32_t *__restrict__ vmax)
 {
   typedef SnkT<PK> T;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1592,8 +1612,8 @@ __global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict_
   typename T::E best = T::inf();
 #pragma unroll
   for (int x = 0; x < S; x++) best = T::mn(best, T::add(a.v[x], mb.v[x]));
-  if constexpr (PK) { ptn[2 * j] = best.x; ptn[2 * j + 1] = best.y; }
-  else ptn[j] = (uint16_t)best;
+  if constexpr (PK) { ptn[2 * j] = best.x; ptn[2 * j + 1] = best.y; if (vmax) atomicMax(vmax, max((uint32_t)best.x, (uint32_t)best.y)); }
+  else { ptn[j] = (uint16_t)best; if (vmax) atomicMax(vmax, (uint32_t)best); }
 }
 
 // compressSankoffDNA (reference sprparsimony.cpp:2636-2825): cost 0 for states in the tip's set, highest_cost otherwise
@@ -1762,7 +1782,8 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
 }
 
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
-                       const ScanOp *ops, uint32_t *out, int max_depth, uint32_t *host_out, uint32_t n_out, uint32_t *done)
+                       const ScanOp *ops, uint32_t *out, int max_depth, uint32_t *host_out, uint32_t n_out, uint32_t *done,
+                       uint16_t *vals, uint32_t npat, uint32_t *vmax)
 {
   if (n_scans <= 0) return hipSuccess;
   const int tiles = tiles_of(g);
@@ -1772,8 +1793,8 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
     const int We = snk_elems(g), stiles = (We + 63) / 64;
     const long waves = (long)n_scans * stiles;
     dim3 sgrid((unsigned)((waves + 3) / 4));
-#define SNKSCAN(S_, D_) do { if (g.snk16) hipLaunchKernelGGL((k_snk_scan<S_, D_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles); \
-                             else hipLaunchKernelGGL((k_snk_scan<S_, D_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles); } while (0)
+#define SNKSCAN(S_, D_) do { if (g.snk16) hipLaunchKernelGGL((k_snk_scan<S_, D_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax); \
+                             else hipLaunchKernelGGL((k_snk_scan<S_, D_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax); } while (0)
     if (g.S == 4) {
       if (max_depth <= 6) SNKSCAN(4, 6); else SNKSCAN(4, 12);
     } else {
@@ -1921,11 +1942,11 @@ size_t site_planes_words(const Geometry &g, int n_ops)
 }
 
 hipError_t launch_sankoff_pattern(hipStream_t st, const Geometry &g, const uint32_t *vec, uint32_t a, uint32_t b,
-                                  uint16_t *ptn_out)
+                                  uint16_t *ptn_out, uint32_t *vmax)
 {
   const int We = snk_elems(g);
   dim3 grid((We + 255) / 256), block(256);
-#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_pattern<S_, PK_>), grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, We)
+#define SNK(S_, PK_) hipLaunchKernelGGL((k_snk_pattern<S_, PK_>), grid, block, 0, st, vec, g.moff, a, b, g.cost, ptn_out, We, vmax)
   MPF_DISPATCH_SNK(SNK);
 #undef SNK
   return hipGetLastError();

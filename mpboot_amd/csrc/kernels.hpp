@@ -82,7 +82,10 @@ hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *ve
                            uint32_t *out);
 hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, const ScanHdr *hdr, int n_scans,
                        const ScanOp *ops, uint32_t *out, int max_depth,
-                       uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr);   // as launch_scan_walk
+                       uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr,   // as launch_scan_walk
+                       // weighted mode, online UFBoot: vals[out index][npat] = per-pattern lengths of every tentative tree
+                       // (16 bits each), *vmax = the largest of them (atomic max)
+                       uint16_t *vals = nullptr, uint32_t npat = 0, uint32_t *vmax = nullptr);
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
                             uint32_t *masks = nullptr, uint2 *info = nullptr,   // masks != nullptr: UFBoot variant (ufboot.hip)
@@ -107,7 +110,7 @@ size_t site_planes_words(const Geometry &g, int n_ops);
 
 // Sankoff: per-pattern cost of the branch (a, b): ptn[j] = min_x(A[x] + min_y(cost[x][y] + B[y]))
 hipError_t launch_sankoff_pattern(hipStream_t st, const Geometry &g, const uint32_t *vec, uint32_t a, uint32_t b,
-                                  uint16_t *ptn_out);
+                                  uint16_t *ptn_out, uint32_t *vmax = nullptr);
 hipError_t launch_pack_tips_sankoff(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
                                     int n_patterns, const int32_t *inf_index, int n_inf, int datatype);
 

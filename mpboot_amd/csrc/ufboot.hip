@@ -434,6 +434,33 @@ __global__ __launch_bounds__(256) void k_ufb_column(const int32_t *__restrict__ 
   if (i < rows) out[i] = C[(size_t)i * Bp + col];
 }
 
+// ------------------------------------------------------------------------------------------------ weighted engine: bit planes
+// vals[row][npat] (16-bit per-pattern lengths of a tentative tree, from k_snk_scan) -> planes[j][row][Wp] with bit i of word w
+// of plane j = bit j of vals[row][32 w + i]: REPS = sum_j 2^j * (plane j x weights), one k_bitgemm per plane.
+// One wave per (row, 64 patterns); rows_p / Wp are the padded sizes of the product (the padding is zeroed by the caller).
+__global__ __launch_bounds__(256) void k_vals_planes(const uint16_t *__restrict__ vals, uint32_t rows, uint32_t npat, int K,
+                                                     uint32_t *__restrict__ planes, uint32_t rows_p, uint32_t Wp)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6), row = blockIdx.y;
+  if (row >= rows || tile * 64 >= npat) return;    // wave-uniform
+  const uint32_t j = tile * 64 + (uint32_t)lane;
+  const uint32_t v = j < npat ? vals[(size_t)row * npat + j] : 0u;
+  for (int k = 0; k < K; k++) {
+    const unsigned long long bal = __ballot((int)((v >> k) & 1u));
+    if (lane == 0)
+      *reinterpret_cast<uint2 *>(planes + ((size_t)k * rows_p + row) * Wp + 2 * tile) = make_uint2((uint32_t)bal, (uint32_t)(bal >> 32));
+  }
+}
+
+hipError_t launch_vals_planes(hipStream_t st, const uint16_t *vals, uint32_t rows, uint32_t npat, int K, uint32_t *planes, uint32_t rows_p,
+                              uint32_t Wp)
+{
+  if (!rows || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_vals_planes, dim3((npat + 255) / 256, rows), dim3(256), 0, st, vals, rows, npat, K, planes, rows_p, Wp);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops, uint32_t *masks)
 {

@@ -32,6 +32,9 @@ hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src /* [n_cols][P] 
                              const int32_t *cur_weight, uint8_t *Wt, int Bp, int planes, size_t plane_bytes);
 // info[idx[i]] = (0, code), i < n: the current tree's slots (code 0xFFFFFFFE: scored with R_T; 0xFFFFFFFF: skipped)
 hipError_t launch_ufb_self(hipStream_t st, uint2 *info, const uint32_t *idx, uint32_t n, uint32_t code);
+// weighted engine: planes[k][row][Wp] <- bit k of vals[row][npat], k < K (rows_p rows per plane; Wp >= ceil(npat / 64) * 2)
+hipError_t launch_vals_planes(hipStream_t st, const uint16_t *vals, uint32_t rows, uint32_t npat, int K, uint32_t *planes, uint32_t rows_p,
+                              uint32_t Wp);
 // out[i] = C[i][col], i < rows
 hipError_t launch_ufb_column(hipStream_t st, const int32_t *C, int Bp, int col, uint32_t rows, int32_t *out);
 

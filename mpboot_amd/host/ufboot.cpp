@@ -30,7 +30,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local, const int32_t *sample_ids,
                           mpf_ufb_exchange_fn exchange, void *exchange_arg)
 {
-  if (sankoff_) { set_error("online UFBoot: Fitch mode only (weighted per-pattern lengths are not 0/1 increments)"); return MPF_E_UNSUPPORTED; }
+  if (sankoff_ && exchange) { set_error("online UFBoot on the weighted engine: sample sharding is not supported"); return MPF_E_UNSUPPORTED; }
   if (n_samples < 1 || !samples) { set_error("ufboot_attach: bad argument"); return MPF_E_INVALID; }
   if (!(epsilon > 0.0 && epsilon < 1.0)) {
     set_error("ufboot_attach: epsilon must lie in (0, 1) -- with integer scores every such value acts like the default 0.5");
@@ -63,7 +63,9 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
     wmax = std::max<uint32_t>(wmax, orig[(size_t)p]);
   }
   u->planes = wmax < 128 ? 1 : (wmax < 16384 ? 2 : 3);
-  const int nkb = g_.Wp / 2;
+  u->snk = sankoff_;
+  u->Wp_s = sankoff_ ? round_up((g_.Wp + 31) / 32, 8) : 0;          // (weighted: g_.Wp counts patterns)
+  const int nkb = (sankoff_ ? u->Wp_s : g_.Wp) / 2;
   u->plane_bytes = (size_t)nkb * (size_t)u->Bp * 64;
   UCHK(u->d_samples.reserve((size_t)(n_samples + 1) * (size_t)P_));
   UCHK(hipMemcpyAsync(u->d_samples.p, samples, (size_t)n_samples * (size_t)P_ * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
@@ -87,13 +89,21 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
 int Engine::ufb_layout_weights()
 {
   UfbState &u = *ufb_;
-  const int nkb = g_.Wp / 2;
+  const int nkb = (u.snk ? u.Wp_s : g_.Wp) / 2;
   u.plane_bytes = (size_t)nkb * (size_t)u.Bp * 64;          // (Wp follows the packing)
   UCHK(u.wt.reserve(u.plane_bytes * (size_t)u.planes));
   UCHK(u.d_first.reserve((size_t)P_));
   UCHK(u.d_cur.reserve((size_t)P_));
-  UCHK(hipMemcpyAsync(u.d_first.p, first_site_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
-  UCHK(hipMemcpyAsync(u.d_cur.p, wgt_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  std::vector<int32_t> snk_first, snk_cur;
+  if (u.snk) {
+    // weighted engine: "site" = position of the pattern among the informative ones (the order of the cost vectors), every
+    // informative pattern takes part whatever its current weight (the weights live in pwgt, not in the packing)
+    snk_first.assign((size_t)P_, -1);
+    snk_cur.assign((size_t)P_, 0);
+    for (int j = 0; j < ninf_; j++) { snk_first[(size_t)inf_index_[(size_t)j]] = j; snk_cur[(size_t)inf_index_[(size_t)j]] = 1; }
+  }
+  UCHK(hipMemcpyAsync(u.d_first.p, u.snk ? snk_first.data() : first_site_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
+  UCHK(hipMemcpyAsync(u.d_cur.p, u.snk ? snk_cur.data() : wgt_.data(), (size_t)P_ * sizeof(int32_t), hipMemcpyHostToDevice, st_));
   UCHK(launch_ufb_layout(st_, u.d_samples.p, u.Bl + 1, P_, u.d_first.p, u.d_cur.p, u.wt.p, u.Bp, u.planes, u.plane_bytes));
   UCHK(hipStreamSynchronize(st_));
   u.rt_valid = false;
@@ -779,6 +789,301 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     uint32_t n_all_ev = 0;
     if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
   }
+  if (final_score) *final_score = randomMP;
+  return MPF_OK;
+}
+
+// The same loop on the weighted (Sankoff) engine.  pllComputePatternParsimony dispatches to
+// pllComputeSankoffPatternParsimony there (sprparsimony.cpp:3341-3355): the per-pattern lengths of the tentative tree are the
+// minima the evaluate has just taken.  The scan writes them for every insertion test (k_snk_scan, 16 bits each), k_vals_planes
+// slices them into bit planes and REPS = sum_k 2^k (plane k x weights) on the matrix cores; the current tree's own row is
+// multiplied along with every batch and serves as the "home" row of the event formula, so that a candidate's score is its own
+// product row and the current tree's slots score R_T.  Scans are host-planned (as every weighted scan), everything else --
+// cut-off filter, ratchet rule, update rules, replay order -- is the code path of spr_sweeps_ufboot.
+int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
+{
+  UfbState &u = *ufb_;
+  if (u.exchange) { set_error("online UFBoot on the weighted engine: sample sharding is not supported"); return MPF_E_UNSUPPORTED; }
+  uint32_t startMP;
+  unsigned iter_hits = 1;
+  const int total = 2 * n_ - 2;
+  const uint32_t npat = (uint32_t)g_.Wp;
+  std::vector<ScanPlan> plans;
+  const uint32_t *out = nullptr;
+  int batch = first_batch();
+  std::vector<UfbEvent> events, ev_tmp;
+  std::vector<uint32_t> ev_count, small;
+  std::vector<uint2> hinfo;
+  std::vector<int32_t> mh_bk, lcol;
+  std::string mh_key;
+  const bool ratchet = u.ratchet;
+  const int oc = u.Bl;
+  if (ratchet) u.gate_closed = false;
+  bool stale_init = false;                         // ratchet: _pattern_pars of the climb's start tree, known after the first product
+  do {
+    startMP = randomMP;
+    node_rectifier();
+    int i = 1;
+    while (i <= total) {
+      const int hi = std::min(total, i + batch - 1);
+      const int np = hi - i + 1;
+      UCHK(u.vmax.reserve(4));
+      UCHK(hipMemsetAsync(u.vmax.p, 0, sizeof(uint32_t), st_));      // (a batch without any insertion test launches no scan)
+      scan_vals_ = true;
+      int rc = scan_batch(plans, nodep_.data() + i, np, mintrav, maxtrav, &out);
+      scan_vals_ = false;
+      if (rc) return rc;
+      u.batches++;
+      const uint32_t n_idx = vals_rows_;           // output indices: a slot for the current tree in front of every prune node's candidates
+      const uint32_t R = n_idx;                    // the current tree's row of the product
+      int jstar = np - 1;
+      for (int j = 0; j < np; j++) {
+        const ScanPlan &pl = plans[(size_t)j];
+        uint32_t m = UINT32_MAX;
+        for (const Candidate &cd : pl.cands) m = std::min(m, out[cd.out]);
+        if (m < randomMP) { jstar = j; break; }
+      }
+      const bool have_cut = u.logl_cutoff != 0.0;
+      const double lim = -u.logl_cutoff + 1e-4;
+      const uint32_t mp_max = have_cut ? (lim <= 0.0 ? 0u : (uint32_t)std::ceil(lim) - 1u) : UINT32_MAX;
+      const bool none_pass = have_cut && lim <= 0.0;
+      const bool skip_product = ratchet ? (u.gate_closed || none_pass) : none_pass;
+      bool have_C = false;
+      events.clear();
+      if (!skip_product) {
+        // ---- the current tree's row, the bit planes, the product
+        UCHK(u.vals.reserve(((size_t)n_idx + 1) * npat));
+        UCHK(u.h_vmax.reserve(4));
+        UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), u.vals.p + (size_t)R * npat, u.vmax.p));
+        UCHK(hipMemcpyAsync(u.h_vmax.p, u.vmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        UCHK(hipStreamSynchronize(st_));
+        int K = 1;
+        while (K < 16 && (u.h_vmax.p[0] >> K)) K++;
+        const uint32_t rows = n_idx + 1;
+        const int rows_p = round_up((int)rows, kUfbRowTile);
+        const size_t plane_words = (size_t)rows_p * (size_t)u.Wp_s;
+        UCHK(u.bitp.reserve((size_t)K * plane_words));
+        UCHK(hipMemsetAsync(u.bitp.p, 0, (size_t)K * plane_words * sizeof(uint32_t), st_));
+        for (uint32_t r0 = 0; r0 < rows; r0 += 32768u)                  // (grid.y limit)
+          UCHK(launch_vals_planes(st_, u.vals.p + (size_t)r0 * npat, std::min(32768u, rows - r0), npat, K, u.bitp.p + (size_t)r0 * u.Wp_s, (uint32_t)rows_p,
+                                  (uint32_t)u.Wp_s));
+        UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
+        if (timing_) UCHK(hipEventRecord(ev2_, st_));
+        bool first = true;
+        for (int k = 0; k < K; k++)
+          for (int pl = 0; pl < u.planes; pl++) {
+            UCHK(launch_bitgemm(st_, u.bitp.p + (size_t)k * plane_words, rows_p, u.Wp_s, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p,
+                                (1 << k) << (7 * pl), first ? 0 : 1));
+            first = false;
+          }
+        if (timing_) UCHK(hipEventRecord(ev3_, st_));
+        u.gemm_rows += (uint64_t)rows_p * (uint64_t)K;
+        UCHK(u.rt.reserve((size_t)u.Bp));
+        UCHK(launch_colsum(st_, u.C.p + (size_t)R * u.Bp, 1, u.Bp, u.rt.p));       // R_T = the current tree's own row
+        have_C = true;
+        // ---- per output index: (row, part) for candidates of plans [0, jstar], the current tree's slots, everything else off
+        uint32_t n_parts = 0;
+        hinfo.assign((size_t)n_idx, make_uint2(0u, 0xFFFFFFFFu));
+        const bool self_pass = ratchet || randomMP <= mp_max;
+        for (int j = 0; j <= jstar; j++) {
+          const ScanPlan &pl = plans[(size_t)j];
+          if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = make_uint2(0u, self_pass ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+          for (const Candidate &cd : pl.cands) hinfo[cd.out] = make_uint2(cd.out, (uint32_t)j);
+          n_parts = (uint32_t)j + 1u;
+        }
+        // staging: thr[n_parts] | home[n_parts] | best[Bp]
+        small.assign((size_t)2 * n_parts + (size_t)u.Bp, 0u);
+        for (uint32_t d = 0; d < n_parts; d++) {
+          small[d] = (!have_cut || ratchet) ? UINT32_MAX : mp_max + 1u;            // max cost + 1 (costs are full lengths here)
+          small[n_parts + d] = R;
+        }
+        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = u.boot_score[(size_t)u.ids[(size_t)c2]];
+        UCHK(u.h_small.reserve(small.size() + 4));
+        std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
+        UCHK(u.thr.reserve(small.size() + 4));
+        UCHK(u.info.reserve((size_t)std::max<uint32_t>(n_idx, 1u)));
+        const uint32_t nch = ufb_chunks(std::max<uint32_t>(n_idx, 1u));
+        UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
+        UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
+        UCHK(u.evcount.reserve(4));
+        if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
+        UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+        if (n_idx) UCHK(hipMemcpyAsync(u.info.p, hinfo.data(), (size_t)n_idx * sizeof(uint2), hipMemcpyHostToDevice, st_));
+        const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
+        if (ratchet) {
+          UCHK(u.d_col.reserve((size_t)rows_p));
+          UCHK(u.h_col.reserve((size_t)rows_p));
+          UCHK(launch_ufb_column(st_, u.C.p, u.Bp, oc, rows, u.d_col.p));
+          UCHK(hipMemcpyAsync(u.h_col.p, u.d_col.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+        }
+        uint32_t n_ev = 0;
+        while (n_idx) {
+          UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
+          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
+                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p));
+          UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+          UCHK(hipStreamSynchronize(st_));
+          n_ev = u.h_small.p[0];
+          if (n_ev <= u.ev.cap) break;
+          UCHK(u.ev.reserve((size_t)n_ev));
+          UCHK(u.h_ev.reserve((size_t)n_ev));
+        }
+        if (!n_idx) UCHK(hipStreamSynchronize(st_));
+        if (timing_) {
+          float ms = 0;
+          if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
+        }
+        if (n_ev) {
+          UCHK(u.h_ev.reserve((size_t)n_ev));
+          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
+          UCHK(hipStreamSynchronize(st_));
+        }
+        events.assign(u.h_ev.p, u.h_ev.p + n_ev);
+        for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];
+        sort_events(events, ev_tmp, ev_count, std::max<uint32_t>(n_idx, 1u), (uint32_t)u.B);
+        u.events += n_ev;
+        if (ratchet) {
+          lcol.assign(u.h_col.p, u.h_col.p + rows);
+          u.rt_orig = (uint32_t)lcol[(size_t)R];
+          if (!stale_init) { u.stale_len = u.rt_orig; stale_init = true; }       // what the IQ-TREE kernel left for the start tree
+        }
+      }
+      // ---- host replay in the reference's order
+      size_t ep = 0;
+      bool moved = false;
+      int j = i;
+      for (; j <= hi && !moved; j++) {
+        const ScanPlan &pl = plans[(size_t)(j - i)];
+        if (tie_mode_ == MPF_TIE_RANDOM) {
+          insert_rec_ = remove_rec_ = -1;
+          hits_ = 1;
+        }
+        long sel = -1;
+        auto cand_topology_key = [&](uint32_t cand_code, int64_t tree_index) -> int64_t {
+          if (cand_code == 0xFFFFFFFFu) {
+            if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+            return u.topo_index.emplace(u.self_key, tree_index).first->second;
+          }
+          ufb_candidate_topology(cand_code < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], pl.cands[(size_t)cand_code].q, mh_bk);
+          canonical_topology(mh_bk, mh_key);
+          return u.topo_index.emplace(mh_key, tree_index).first->second;
+        };
+        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
+          while (ep < events.size() && events[ep].idx < idx) ep++;
+          bool looked_up = false;
+          for (; ep < events.size() && events[ep].idx == idx; ep++) {
+            const uint32_t b = events[ep].b, s = events[ep].s;
+            uint32_t &bs = u.boot_score[b];
+            if (u.mulhits) {
+              if (s > bs) continue;
+              if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
+              std::set<int64_t> &hs = u.hit_sets[b];
+              if (s < bs) {
+                for (int64_t t : hs) if (--u.refs[(size_t)t] == 0) u.store.erase(t);
+                hs.clear();
+                bs = s;
+              }
+              if (hs.insert(tree_index).second) {
+                u.refs[(size_t)tree_index]++;
+                if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              }
+              continue;
+            }
+            bool accept = false;
+            if (s < bs) accept = true;
+            else if (s == bs) {
+              u.draws++;
+              accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
+            }
+            if (accept) {
+              if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
+              if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              if (s < bs) { u.boot_counts[b] = 1; bs = s; }
+              int64_t &bt = u.boot_trees[b];
+              if (bt != tree_index) {
+                if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
+                u.refs[(size_t)tree_index]++;
+                bt = tree_index;
+              }
+            }
+            if (s == bs) u.boot_counts[b]++;
+          }
+        };
+        if (pl.self_idx >= 0) {
+          bool book;
+          if (!ratchet) book = !none_pass && randomMP <= mp_max;
+          else {
+            book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;
+            if (!book) u.gate_closed = true;
+          }
+          if (book) {
+            const int64_t tree_index = (int64_t)u.treels.size();
+            u.treels.push_back(ratchet ? u.stale_len : randomMP);
+            u.refs.push_back(0);
+            replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
+            if (ratchet) u.stale_len = u.rt_orig;
+          }
+        }
+        for (size_t c = 0; c < pl.cands.size(); c++) {
+          const uint32_t idx = pl.cands[c].out;
+          const uint32_t mp = out[idx];
+          bool book;
+          if (!ratchet) book = !none_pass && mp <= mp_max;
+          else {
+            book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;
+            if (!book) u.gate_closed = true;
+          }
+          if (book) {
+            const int64_t tree_index = (int64_t)u.treels.size();
+            u.treels.push_back(ratchet ? u.stale_len : mp);
+            u.refs.push_back(0);
+            replay_events(idx, tree_index, (uint32_t)c);
+            if (ratchet) u.stale_len = (uint32_t)lcol[(size_t)idx];
+          }
+          if (tie_mode_ == MPF_TIE_RANDOM) {
+            if (mp < best_) hits_ = 1;
+            else if (mp == best_) hits_++;
+            if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; sel = (long)c; }
+          } else if (mp < best_) {
+            best_ = mp; sel = (long)c;
+          }
+        }
+        if (sel >= 0) {
+          insert_rec_ = pl.cands[(size_t)sel].q;
+          remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
+        }
+        // topologies of the trees accepted during this prune node's scan that some sample still points to
+        for (const UfbState::Pending &pe : u.pending) {
+          if (u.refs[(size_t)pe.tree_index] <= 0) continue;
+          if (pe.cand == 0xFFFFFFFFu) {
+            if (!u.store.count(pe.tree_index)) { u.store.emplace(pe.tree_index, back_); u.stored++; }
+            continue;
+          }
+          ufb_store_tree(pe.tree_index, pe.cand < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], pl.cands[(size_t)pe.cand].q);
+        }
+        u.pending.clear();
+        bool accept;
+        if (tie_mode_ == MPF_TIE_RANDOM) {
+          if (best_ == randomMP) iter_hits++;
+          if (best_ < randomMP) iter_hits = 1;
+          accept = (best_ < randomMP || (best_ == randomMP && tie_draw() <= 1.0 / (double)iter_hits)) && remove_rec_ >= 0 && insert_rec_ >= 0;
+        } else {
+          accept = best_ < randomMP;
+        }
+        if (accept) {
+          if (sel < 0) { set_error("online UFBoot: accepted move without a candidate of this prune node"); return MPF_E_STATE; }
+          moves_.push_back(Move{remove_rec_, insert_rec_, best_});
+          apply_move(remove_rec_, insert_rec_);
+          randomMP = best_;
+          moved = true;
+        }
+      }
+      batch = next_batch(batch, moved, j - i, total);
+      i = j;
+    }
+  } while (randomMP < startMP);
+  climb_finished(total);
+  u.rt_valid = false;
   if (final_score) *final_score = randomMP;
   return MPF_OK;
 }

@@ -160,7 +160,7 @@ def run_sequence(c, seed, n_steps, cost=None):
             pe, te = e.pattern_scores()
             po_, to = o.pattern_scores()
             assert te == to and pe.tolist() == po_.tolist(), log
-        elif op == 7 and cost is None and not tracked and maxtrav <= 8 and (weights[0] > 0).any():      # attach the bookkeeping half-way
+        elif op == 7 and not tracked and maxtrav <= 8 and (weights[0] > 0).any():      # attach the bookkeeping half-way
             for x in (e, o):
                 x.set_weights(weights[0])
             samples = rng.multinomial(max(1, int(weights[0].sum())), (weights[0] + 1e-9) / (weights[0] + 1e-9).sum(), size=5).astype(np.uint16)

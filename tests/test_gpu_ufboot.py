@@ -333,8 +333,10 @@ def test_unsupported_configurations_fail_loudly(mods):
         e.ufboot_next_cutoff(10)
     cost = (1 - np.eye(4)).astype(np.uint32)
     s = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
-    with pytest.raises(engine.MpfError):
-        s.ufboot_attach(samples)
+    s.ufboot_attach(samples)                       # the weighted engine keeps the bookkeeping too ...
+    s.ufboot_detach()
+    with pytest.raises(engine.MpfError):           # ... but not sample-sharded
+        s.ufboot_attach(samples, shard=(0, 2))
     # the bookkeeping lives in the device-walked scan: other scan modes / longer radii refuse instead of skipping it
     e.ufboot_attach(samples)
     e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
@@ -534,3 +536,53 @@ def test_tiny_tree_whose_prune_nodes_have_no_insertion_test(mods, alphabet):
         assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
         assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
     assert len(o.ufboot_tree_logl()) > 0
+
+
+@pytest.mark.parametrize("mode", ["default", "cutoff", "mulhits"])
+@pytest.mark.parametrize("name,big", [("dna_clean", False), ("dna_ambig", True), ("aa", False), ("dna_48", False)])
+def test_weighted_engine_bookkeeping_matches_oracle(mods, name, big, mode):
+    """-cost with -bb: saveCurrentTree on the weighted (Sankoff) engine.  pllComputePatternParsimony dispatches to
+    pllComputeSankoffPatternParsimony (sprparsimony.cpp:3341-3355); here the scan writes every tentative tree's per-pattern
+    lengths, bit planes of them are multiplied with the sample weights on the matrix cores.  A normal climb, a re-weighted
+    (ratchet) climb and the climb back: every observable == the oracle's"""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    S = 4 if fx["datatype"] == 0 else 20
+    rng = np.random.default_rng(12)
+    m = rng.integers(1, 4000 if big else 6, size=(S, S))
+    cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    samples = boot_samples(len(w0), 20, 41, fx["weights"])
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 4, 6)]
+    for x in (e, o):
+        x.seed_ties(1, 17)
+        x.ufboot_attach(samples)
+        if mode == "mulhits":
+            x.ufboot_set_mulhits(True)
+    for k, w in enumerate((w0, pert, w0)):
+        for x in (e, o):
+            x.set_weights(w)
+            x.set_tree(t[k])
+        o.trace(True)
+        assert e.optimize_spr(1, 5) == o.optimize_spr(1, 5)
+        assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+        assert (e.get_tree() == o.get_tree()).all()
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+        if mode == "mulhits":
+            for b in range(len(samples)):
+                assert e.ufboot_sample_trees(b) == o.ufboot_sample_trees(b)
+        else:
+            for ti in sorted(set(e.ufboot_state()[2].tolist())):
+                if ti >= 0:
+                    assert same_topology(e.ufboot_tree(ti), o.ufboot_tree(ti), fx["n"])
+        if k == 0 and mode == "cutoff":
+            logl = np.sort(o.ufboot_tree_logl())
+            for x in (e, o):
+                x.ufboot_set_cutoff(float(logl[len(logl) // 2]))
+    assert o.ufboot_bad() == 0
+    assert len(o.ufboot_tree_logl()) > 50
