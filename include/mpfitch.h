@@ -219,8 +219,11 @@ int mpf_remain_bounds(int32_t n_units, int32_t n_segments, const int32_t *segmen
        random stream as the SPR tie-breaks (mpf_seed_ties / mpf_set_rand_callback).
    samples = boot_samples_pars (iqtree.cpp:213-313), [n_samples][n_patterns] uint16.  epsilon = params->ufboot_epsilon
    (0.5, tools.cpp:725); any value in (0, 1) is equivalent for integer scores, others are MPF_E_UNSUPPORTED.
-   Fitch mode only.  mpf_set_weights with other weights SUSPENDS the tracker (climbs then run without bookkeeping -- the
-   reference's -no_hclimb1_bb behaviour, iqtree.cpp:3280); setting the attach-time weights again resumes it with its state. */
+   Both engines: on the weighted (Sankoff, -cost) engine the per-pattern lengths are those pllComputeSankoffPatternParsimony
+   reads (sprparsimony.cpp:3341-3355); sample sharding (below) is Fitch-only.  Climbs under other weights than the attach-time
+   ones (ratchet iterations) are booked as the reference books them (iqtree.cpp:3283-3295) unless
+   mpf_ufboot_set_ratchet_booking(e, 0) (-no_hclimb1_bb, :3280); weights that take an attach-time pattern out of the
+   alignment altogether rest the tracker until the attach-time weights are back. */
 int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples, double epsilon);
 /* Multi-GPU online phase: the samples are sharded over the GPUs, the search chain is not.  Every rank runs the same
    mpf_optimize_spr calls (same tree, same tie seed) on its own engine, which holds only n_local of the n_samples weight

@@ -1069,8 +1069,11 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
   std::copy(h_out(), h_out() + nout, out_host.begin());
   stats.scan_launches++;
-  stats.insertion_tests += nout;
-  stats.algorithmic_bytes += (uint64_t)nout * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  size_t n_tests = nout;
+  if (scan_vals_)                                // (weighted tracker: the slots reserved for the current tree are not insertion tests)
+    for (const ScanPlan &pl : plans) n_tests -= pl.self_idx >= 0 ? 1u : 0u;
+  stats.insertion_tests += n_tests;
+  stats.algorithmic_bytes += (uint64_t)n_tests * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
   prog_ops_.clear();
   prog_hdr_.clear();
   prog_out_ = 0;

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="C5")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--cpu-budget", type=float, default=10.0)
+ap.add_argument("--bb", type=int, default=0, help="also time one SPR climb with the saveCurrentTree bookkeeping for this many bootstrap samples")
 a = ap.parse_args()
 cfg = synth.WORKLOADS[a.workload]
 letters, names = synth.workload(a.workload)
@@ -33,6 +34,20 @@ dt_s = (time.perf_counter() - t0) / a.steps
 st = e.stats()
 print(f"{a.workload} Sankoff ({S} states, random symmetric costs 1..5): tree length {s0}; sweep of {k} insertion tests in {dt_s*1e3:.2f} ms "
       f"= {k/dt_s:.3e} evals/s (scan kernels {st['scan_kernel_ms_total']/a.steps:.2f} ms, view kernels {st['view_kernel_ms_total']/a.steps:.2f} ms per step); best candidate {best}")
+if a.bb:
+    samples = np.random.default_rng(1).multinomial(P, np.ones(P) / P, size=a.bb).astype(np.uint16)
+    e.set_tree(back); e.seed_ties(engine.TIE_RANDOM, 1)
+    t0 = time.perf_counter(); s_plain = e.optimize_spr(1, 6); t_plain = time.perf_counter() - t0
+    mv_plain = len(e.moves()[0])
+    e.set_tree(back); e.seed_ties(engine.TIE_RANDOM, 1); e.reset_node_order()
+    e.ufboot_attach(samples)
+    e.reset_stats()
+    t0 = time.perf_counter(); s_bb = e.optimize_spr(1, 6); t_bb = time.perf_counter() - t0
+    st2, cn = e.stats(), e.ufboot_counters()
+    print(f"-bb {a.bb}: plain climb -> {s_plain} in {t_plain:.3f} s ({mv_plain} moves); with bookkeeping -> {s_bb} in {t_bb:.3f} s "
+          f"({st2['insertion_tests']} tests, {st2['moves_applied']} moves, {len(e.ufboot_tree_logl())} trees booked, product kernels {cn['reps_kernel_ms']:.1f} ms "
+          f"over {cn['reps_rows']} plane rows, {cn['events']} events, {cn['tie_draws']} draws)")
+    e.ufboot_detach()
 from oracle import pyoracle as po
 o = po.Oracle(codes, datatype=po.DNA if dt == engine.DNA else po.AA, cost=cost)
 assert o.score_tree(back) == s0
