@@ -1,5 +1,13 @@
 #!/bin/bash
-for sk in 0 1 2 3 4 5 6 7 8 9 10 "0,1,2,3" "4,5,6" "0,1,2,3,4,5,6,7"; do
-  out=$(MPF_STATEFUL_SKIP=$sk MPF_FUZZ_OFFSET=300 timeout 120 python -m pytest tests/test_gpu_stateful.py -x -q -k "oracle[57]" 2>&1 | tail -1)
-  echo "skip $sk: $out" | cut -c1-100
+for q in 4 8 16 24; do
+  echo "GPU_MAX_HW_QUEUES=$q"
+  GPU_MAX_HW_QUEUES=$q python tools/concurrent_climbs.py --engines 4,8,16 2>&1 | tail -3 | cut -c1-90
+done
+for q in 4 16; do
+GPU_MAX_HW_QUEUES=$q python bench.py --random-start-leg 0 --no-cpu --steps 2 --warmup 1 --engines-per-gpu 8 > /tmp/r$q.json 2>/dev/null
+python - $q <<'PY'
+import json, sys
+d = json.load(open(f"/tmp/r{sys.argv[1]}.json")); b = d["bootstrap_wall_clock"]
+print("queues", sys.argv[1], "refinement", b["refinement_s"], b["refinement_s_plan_cache_off"], "engines", b["engines_per_gpu"])
+PY
 done
