@@ -1269,8 +1269,27 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
                               host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8));
     }
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
-    // one copy brings back the refreshed vectors' mutation counts (if any) and the candidates' costs
-    if (host_direct) {
+    part_min_used_ = false;
+    if (want_part_min_ && !host_direct && !scan_masks_ && !check_counts_ && nout > 16384) {
+      // only the cheapest candidate of every scan part is wanted: reduce on the device, minima straight to the host
+      if (!(walk_dev_reuse_ && parts_gen_ == walk_gen_ && n_parts_dev_ > 0)) {
+        parts_host_.clear();
+        for (const ScanPlan &pl : plans)
+          for (int pi = 0; pi < pl.n_parts; pi++) parts_host_.push_back(make_uint2(pl.part_off[pi], (uint32_t)pl.part_cnt[pi]));
+        n_parts_dev_ = parts_host_.size();
+        HIPCHK(d_parts_.reserve(std::max<size_t>(n_parts_dev_, 1)));
+        HIPCHK(hipMemcpyAsync(d_parts_.p, parts_host_.data(), n_parts_dev_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
+        HIPCHK(hipStreamSynchronize(st_));          // (parts_host_ is pageable; only on a newly planned sweep)
+        parts_gen_ = walk_gen_;
+      }
+      HIPCHK(h_pmin_.reserve(std::max<size_t>(n_parts_dev_, 1)));
+      HIPCHK(launch_part_min(st_, d_out(), d_parts_.p, (int)n_parts_dev_, h_pmin_.p));
+      if (cnt_copy_pending_) {
+        HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        cnt_copy_pending_ = false;
+      }
+      part_min_used_ = true;
+    } else if (host_direct) {
       cnt_copy_pending_ = false;
     } else if (cnt_copy_pending_) {
       HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), (out_off() + nout) * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
@@ -1432,13 +1451,21 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
   node_rectifier();
   std::vector<ScanPlan> &plans = sweep_plans_;
   const uint32_t *out = nullptr;
+  want_part_min_ = true;
+  part_min_used_ = false;
   int rc = scan_batch(plans, nodep_.data() + 1, 2 * n_ - 2, mintrav, maxtrav, &out);
+  want_part_min_ = false;
   if (rc) return rc;
   uint32_t best = UINT_MAX;
   uint64_t tests = 0;
+  size_t part_at = 0;                              // part_min_used_: the parts' minima, in plan order
   for (const ScanPlan &pl : plans) {
     const size_t nc = pl.walked ? (size_t)pl.n_total : pl.cands.size();
-    if (pl.walked) {
+    if (pl.walked && part_min_used_) {
+      uint32_t m = UINT_MAX;
+      for (int i = 0; i < pl.n_parts; i++) m = std::min(m, h_pmin_.p[part_at++]);
+      if (nc) best = std::min(best, pl.base + m);
+    } else if (pl.walked) {
       uint32_t m = UINT_MAX;
       for (int i = 0; i < pl.n_parts; i++) {
         const uint32_t *o = out + pl.part_off[i];

@@ -401,6 +401,14 @@ class Engine {
   std::vector<uint32_t> kid_upd_;
   std::vector<int> kids_list_;                  // records whose kids[] entry changed since the device copy was last complete
   bool kids_upload_ = false;
+  // sweep_scan wants the best candidate per prune node only: the device reduces every scan part and writes the minima to the
+  // host (k_part_min) instead of every candidate's cost coming back
+  bool want_part_min_ = false, part_min_used_ = false;
+  DevBuf<uint2> d_parts_;
+  PinBuf<uint32_t> h_pmin_;
+  std::vector<uint2> parts_host_;
+  uint64_t parts_gen_ = ~0ull;                   // walk_gen_ the device copy of the part table belongs to
+  size_t n_parts_dev_ = 0;
   bool scan_vals_ = false;                       // weighted tracker: host-planned scans also write per-pattern lengths, a slot per prune node is reserved for the current tree
   uint32_t vals_rows_ = 0;                       // output indices of the last such batch
   bool want_host_results_ = false, cnt_on_host_ = false;   // small batches: kernels write the host's result buffers themselves

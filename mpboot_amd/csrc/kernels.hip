@@ -1884,6 +1884,27 @@ hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const
 
 size_t scan_prog_bytes(int n_scans) { return (size_t)n_scans * 2u * kProgStride * sizeof(ProgEnt); }
 
+// pmin[i] = min of out[parts[i].x .. + parts[i].y): the cheapest candidate of every scan part, for callers that only want a
+// sweep's best move per prune node -- 8 bytes per part cross the bus instead of every candidate's cost.  pmin may be pinned
+// host memory (consecutive threads write consecutive words).
+__global__ __launch_bounds__(256) void k_part_min(const uint32_t *__restrict__ out, const uint2 *__restrict__ parts, int n_parts,
+                                                  uint32_t *__restrict__ pmin)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_parts) return;
+  const uint2 pr = parts[i];
+  uint32_t m = 0xFFFFFFFFu;
+  for (uint32_t k = 0; k < pr.y; k++) m = min(m, out[pr.x + k]);
+  pmin[i] = m;
+}
+
+hipError_t launch_part_min(hipStream_t st, const uint32_t *out, const uint2 *parts, int n_parts, uint32_t *pmin)
+{
+  if (n_parts <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_part_min, dim3((n_parts + 255) / 256), dim3(256), 0, st, out, parts, n_parts, pmin);
+  return hipGetLastError();
+}
+
 bool scan_prog_supported(const Geometry &g, int max_depth) { return !g.sankoff && g.S == 4 && (g.vw == 1 || g.vw == 2) && max_depth <= 6; }
 
 size_t scan_prog_blocks(const Geometry &g, int n_scans)
