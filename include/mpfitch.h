@@ -255,8 +255,24 @@ int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on);
    tree whose REPS reaches a sample's best joins that sample's set (boot_trees_parsimony), a better one clears the set first;
    trees of one topology share the index of the first of them that hit (the reference's treels string map, :3500-3514); no
    random draws, boot_counts / boot_trees stay untouched.  Call right after the attach, before any tree is booked.
-   Not covered: -mulhits with -topboot (store_top_boot_trees, :3542-3585) and -distinct_iter_top_boot (:3587-3680). */
+   (-topboot and -distinct_iter_top_boot: below.) */
 int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on);
+/* params->store_top_boot_trees (-topboot N, together with -mulhits): the rule of iqtree.cpp:3542-3585 -- per sample the N best
+   NEW trees (a tree whose topology was booked before is never added), best first, with boot_threshold behaving as in the
+   reference (-INT_MAX until the first replacement in a full list).  After mpf_ufboot_set_mulhits(e, 1), before any tree is
+   booked; n_top = 0 switches back to plain -mulhits.  mpf_ufboot_get_sample_top: boot_trees_parsimony_top[sample] as
+   (tree index, rell) pairs, *n = its length, *threshold = boot_threshold[sample]. */
+int mpf_ufboot_set_topboot(mpf_engine *e, int32_t n_top);
+int mpf_ufboot_get_sample_top(const mpf_engine *e, int32_t sample, int64_t *trees, int32_t *rell, int32_t cap, int32_t *n, int32_t *threshold);
+/* params->distinct_iter_top_boot (-distinct_iter_top_boot k, without -mulhits): the rule of iqtree.cpp:3587-3680 -- per sample at
+   most k trees, one representative per search iteration, accepted against boot_threshold (the list's worst score) with a
+   k / boot_counts tie draw from the shared random stream; boot_trees / boot_logl / boot_counts are maintained as that rule
+   maintains them (mpf_ufboot_get_state), the list is read with mpf_ufboot_get_sample_top and the iteration each entry stands
+   for with mpf_ufboot_get_sample_iters.  Before any tree is booked.  mpf_ufboot_set_iteration: IQTree::curIt, before each
+   mpf_optimize_spr of a new search iteration. */
+int mpf_ufboot_set_distinct_iter(mpf_engine *e, int32_t k);
+int mpf_ufboot_set_iteration(mpf_engine *e, int32_t cur_it);
+int mpf_ufboot_get_sample_iters(const mpf_engine *e, int32_t sample, int32_t *iters, int32_t cap, int32_t *n);
 /* boot_trees_parsimony[sample] in increasing order: *n = its size, the first min(*n, cap) entries written to out (may be NULL) */
 int mpf_ufboot_get_sample_trees(const mpf_engine *e, int32_t sample, int64_t *out, int32_t cap, int32_t *n);
 int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff);

@@ -34,8 +34,10 @@ struct mpf_mpboot_hooks {
   int no_hclimb1_bb;
   // globalParam->multiple_hits (-mulhits, iqtree.cpp:3498-3540): 1 = every tree that reaches a sample's best REPS joins its
   // boot_trees_parsimony set (mpf_ufboot_set_mulhits; read back with mpf_ufboot_get_sample_trees in ufboot_sync).  The
-  // -topboot / -distinct_iter_top_boot variants are not covered: leave those runs on the reference's own path.
   int multiple_hits;
+  int distinct_iter_top_boot;                     // globalParam->distinct_iter_top_boot (iqtree.cpp:3587-3680; without -mulhits)
+  int (*cur_iteration)(IQTree *);                 // iqtree->curIt, read before every pllOptimizeSprParsimony (needed by that rule only)
+  int store_top_boot_trees;                       // globalParam->store_top_boot_trees (-topboot N, with -mulhits): mpf_ufboot_set_topboot
   // called at the end of every pllOptimizeSprParsimony with the engine that holds the saveCurrentTree bookkeeping of
   // this climb: copy treels_logl / boot_logl / boot_counts / boot_trees back with mpf_ufboot_* 
   void (*ufboot_sync)(IQTree *, mpf_engine *);

@@ -139,8 +139,12 @@ void ensure_tracking()
     if (mpf_ufboot_attach(g_eng, B, s.data(), g_hooks.ufboot_epsilon)) die("mpf_ufboot_attach");
     if (mpf_ufboot_set_ratchet_booking(g_eng, g_hooks.no_hclimb1_bb ? 0 : 1)) die("mpf_ufboot_set_ratchet_booking");
     if (g_hooks.multiple_hits && mpf_ufboot_set_mulhits(g_eng, 1)) die("mpf_ufboot_set_mulhits");
+    if (g_hooks.multiple_hits && g_hooks.store_top_boot_trees > 0 && mpf_ufboot_set_topboot(g_eng, g_hooks.store_top_boot_trees)) die("mpf_ufboot_set_topboot");
+    if (!g_hooks.multiple_hits && g_hooks.distinct_iter_top_boot > 0 && mpf_ufboot_set_distinct_iter(g_eng, g_hooks.distinct_iter_top_boot))
+      die("mpf_ufboot_set_distinct_iter");
     g_tracking = true;
   }
+  if (g_hooks.cur_iteration && mpf_ufboot_set_iteration(g_eng, g_hooks.cur_iteration(iqtree))) die("mpf_ufboot_set_iteration");
   if (g_hooks.logl_cutoff && mpf_ufboot_set_cutoff(g_eng, g_hooks.logl_cutoff(iqtree))) die("mpf_ufboot_set_cutoff");
 }
 

@@ -243,6 +243,25 @@ int mpf_ufboot_detach(mpf_engine *e) { NEED(e); e->eng.ufboot_detach(); return M
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff) { NEED(e); return e->eng.ufboot_set_cutoff(logl_cutoff); }
 int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_ratchet_booking(on); }
 int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_mulhits(on); }
+int mpf_ufboot_set_topboot(mpf_engine *e, int32_t n_top) { NEED(e); return e->eng.ufboot_set_topboot(n_top); }
+int mpf_ufboot_get_sample_top(const mpf_engine *e, int32_t sample, int64_t *trees, int32_t *rell, int32_t cap, int32_t *n, int32_t *threshold)
+{
+  NEED(e);
+  int k = 0;
+  int rc = e->eng.ufboot_sample_top(sample, trees, rell, cap, &k, threshold);
+  if (!rc && n) *n = k;
+  return rc;
+}
+int mpf_ufboot_set_distinct_iter(mpf_engine *e, int32_t k) { NEED(e); return e->eng.ufboot_set_distinct_iter(k); }
+int mpf_ufboot_set_iteration(mpf_engine *e, int32_t cur_it) { NEED(e); return e->eng.ufboot_set_iteration(cur_it); }
+int mpf_ufboot_get_sample_iters(const mpf_engine *e, int32_t sample, int32_t *iters, int32_t cap, int32_t *n)
+{
+  NEED(e);
+  int k = 0;
+  int rc = e->eng.ufboot_sample_iters(sample, iters, cap, &k);
+  if (!rc && n) *n = k;
+  return rc;
+}
 int mpf_ufboot_get_sample_trees(const mpf_engine *e, int32_t sample, int64_t *out, int32_t cap, int32_t *n)
 {
   NEED(e);

@@ -1249,7 +1249,10 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
     if (prog) {
       HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));
-      if (!walk_dev_reuse_) {
+      // (a cached sweep re-uses the program only if one was planned for exactly these descriptors: the sweep may have run on
+      //  the device-walked kernel when it was cached -- option prog_min_descs -- and other batches plan into the same buffer)
+      if (!walk_dev_reuse_ || prog_gen_ != walk_gen_) {
+        prog_gen_ = walk_gen_;
         if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
         HIPCHK(launch_walk_plan(st_, d_kids(), n_, descs, (int)nd, d_prog_.p));
         if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }   // the scan kernel's own time starts here

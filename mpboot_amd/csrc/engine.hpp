@@ -15,6 +15,7 @@
 #include <map>
 #include <unordered_map>
 #include <memory>
+#include <climits>
 #include <set>
 #include <string>
 #include <utility>
@@ -165,6 +166,16 @@ struct UfbState {
   bool mulhits = false;
   std::unordered_map<std::string, int64_t> topo_index;       // canonical topology -> tree index
   std::vector<std::set<int64_t>> hit_sets;                   // boot_trees_parsimony
+  // -mulhits -topboot N (params->store_top_boot_trees, iqtree.cpp:3542-3585): per sample the N best NEW trees, best first, and
+  // boot_threshold (INT_MIN + 1 until the first replacement in a full list, as in the reference)
+  int topboot = 0;
+  std::vector<std::vector<std::pair<int64_t, int32_t>>> top;
+  std::vector<int32_t> top_thr;
+  // -distinct_iter_top_boot k (params->distinct_iter_top_boot, iqtree.cpp:3587-3680; without -mulhits): the same list, at most k
+  // entries, one representative per search iteration (cur_it = IQTree::curIt), accepted against boot_threshold with a
+  // k / boot_counts tie draw
+  int distinct = 0, cur_it = 0;
+  std::vector<std::vector<int32_t>> top_iter;
   std::string self_key;                                      // canonical form of the current tree ...
   uint64_t self_key_epoch = ~0ull;                           // ... as of this topology epoch
   DevBuf<uint16_t> d_samples;                    // [Bl + 1][P]: the local samples as given + the row of original frequencies
@@ -239,6 +250,24 @@ class Engine {
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
   int ufboot_set_mulhits(int on);
+  int ufboot_set_topboot(int n_top);
+  int ufboot_set_distinct_iter(int k);
+  int ufboot_set_iteration(int cur_it);
+  int ufboot_sample_iters(int sample, int32_t *iters, int cap, int *n) const;
+  int ufboot_sample_top(int sample, int64_t *trees, int32_t *rell, int cap, int *n, int32_t *threshold) const;
+  // the -topboot block of saveCurrentTree for one (tree, sample): true if the tree went onto the sample's list
+  bool ufb_topboot_offer(uint32_t b, int32_t rell, int64_t tree_index, bool newly_added);
+  template <class Lookup> bool ufb_distinct_offer(uint32_t b, int32_t rell, int64_t &tree_index, bool &looked_up, Lookup lookup);
+  // what the device compares a (tree, sample) score with to decide whether the host must see it: the sample's best score
+  // (default rule, -mulhits: start of a running minimum), or its fixed top-list bound (-topboot)
+  uint32_t ufb_event_bound(uint32_t b) const
+  {
+    const UfbState &u = *ufb_;
+    if (u.distinct) return u.top_thr[b] == -INT_MAX ? UINT32_MAX : (uint32_t)(-(int64_t)u.top_thr[b]);      // rell >= threshold
+    if (!u.topboot) return u.boot_score[b];
+    if ((int)u.top[b].size() < u.topboot || u.top_thr[b] == -INT_MAX) return UINT32_MAX;
+    return (uint32_t)(-(int64_t)u.top_thr[b]) - 1u;              // rell > threshold  <=>  length <= -threshold - 1
+  }
   int ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const;
   void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const;
   bool ufboot_attached() const { return (bool)ufb_; }
@@ -436,6 +465,7 @@ class Engine {
   std::vector<int> sc_order_;
   bool sweep_cache_valid_ = false, walk_dev_reuse_ = false;
   uint64_t walk_gen_ = 0, sweep_cache_gen_ = 0;
+  uint64_t prog_gen_ = ~0ull;                    // walk_gen_ of the descriptors the program in d_prog_ was planned from
   size_t sweep_cache_nwalk_ = 0;
   uint32_t sweep_cache_out_ = 0;
   int sweep_cache_key_[6] = {0, 0, 0, 0, 0, 0};

@@ -377,21 +377,24 @@ __global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ in
                                                     const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
                                                     const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int B,
                                                     const int32_t *__restrict__ rt, uint32_t n_idx, const uint32_t *__restrict__ pre,
-                                                    UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count)
+                                                    UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count,
+                                                    const uint32_t *__restrict__ fixed)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t chunk = blockIdx.y;
   if (b >= B) return;
   const uint32_t i0 = chunk * kUfbChunk, i1 = min(n_idx, i0 + kUfbChunk);
   const int32_t r = rt[b];
-  uint32_t run = pre[(size_t)chunk * Bp + b];
+  // fixed (the top-N rules): the bound is the sample's threshold at the start of the batch and does not follow the scores --
+  // a list's threshold moves by the host's rule, not to the score that beat it
+  uint32_t run = fixed ? fixed[b] : pre[(size_t)chunk * Bp + b];
   for (uint32_t i = i0; i < i1; i++) {
     int32_t s;
     if (!ufb_score(i, b, info, cost, thr, home, crow, C, Bp, r, s)) continue;
     if ((uint32_t)s <= run) {
       const uint32_t at = atomicAdd(ev_count, 1u);
       if (at < ev_cap) ev[at] = UfbEvent{i, (uint32_t)b, (uint32_t)s};
-      run = (uint32_t)s;
+      if (!fixed) run = (uint32_t)s;
     }
   }
 }
@@ -560,14 +563,17 @@ uint32_t ufb_chunks(uint32_t n_idx) { return (n_idx + kUfbChunk - 1) / kUfbChunk
 
 hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
                              const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
-                             uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count)
+                             uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count, int fixed_bound)
 {
   if (n_idx == 0) return hipSuccess;
   const uint32_t nc = ufb_chunks(n_idx);
   dim3 grid((Bp + 255) / 256, nc), block(256);
-  hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, rt, n_idx, cmin);
-  hipLaunchKernelGGL(k_ufb_prefix, dim3((Bp + 255) / 256), block, 0, st, cmin, best, Bp, nc, pre);
-  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count);
+  if (!fixed_bound) {
+    hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, rt, n_idx, cmin);
+    hipLaunchKernelGGL(k_ufb_prefix, dim3((Bp + 255) / 256), block, 0, st, cmin, best, Bp, nc, pre);
+  }
+  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count,
+                     fixed_bound ? best : (const uint32_t *)nullptr);
   return hipGetLastError();
 }
 

@@ -25,7 +25,9 @@ uint32_t ufb_chunks(uint32_t n_idx);
 // crow (optional): scan output index -> row of C (compacted product)
 hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
                              const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best, uint32_t n_idx,
-                             uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count);
+                             uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
+                             // 1: best[b] is a FIXED bound (an event = score <= best[b]; the top-N rules), not the start of a running minimum
+                             int fixed_bound = 0);
 
 // Wt (zeroed here) <- the samples' weights at the first expanded site of every pattern of the packing in force
 hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src /* [n_cols][P] */, int n_cols, int P, const int32_t *first_site,

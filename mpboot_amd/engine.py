@@ -25,7 +25,7 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
-    "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_get_sample_trees", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
+    "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
@@ -118,6 +118,11 @@ def load_library():
         L.mpf_ufboot_set_ratchet_booking.argtypes = [vp, C.c_int32]
         L.mpf_ufboot_set_mulhits.argtypes = [vp, C.c_int32]
         L.mpf_ufboot_get_sample_trees.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
+        L.mpf_ufboot_set_distinct_iter.argtypes = [vp, C.c_int32]
+        L.mpf_ufboot_set_iteration.argtypes = [vp, C.c_int32]
+        L.mpf_ufboot_get_sample_iters.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
+        L.mpf_ufboot_set_topboot.argtypes = [vp, C.c_int32]
+        L.mpf_ufboot_get_sample_top.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp, vp]
         L.mpf_ufboot_next_cutoff.argtypes = [vp, C.c_int32, vp]
         L.mpf_ufboot_num_trees.argtypes = [vp, vp]
         L.mpf_ufboot_tree_logl.argtypes = [vp, vp]
@@ -418,6 +423,35 @@ class FitchEngine:
     def ufboot_set_mulhits(self, on: bool):
         """params->multiple_hits: the -mulhits update rule (iqtree.cpp:3498-3540); right after the attach"""
         _chk(load_library().mpf_ufboot_set_mulhits(self.h, 1 if on else 0))
+
+    def ufboot_set_topboot(self, n_top: int):
+        """params->store_top_boot_trees (-topboot N, with -mulhits; iqtree.cpp:3542-3585)"""
+        self.ufb_topboot = int(n_top)
+        _chk(load_library().mpf_ufboot_set_topboot(self.h, int(n_top)))
+
+    def ufboot_set_distinct_iter(self, k: int):
+        """params->distinct_iter_top_boot (iqtree.cpp:3587-3680); without -mulhits"""
+        self.ufb_topboot = int(k)
+        _chk(load_library().mpf_ufboot_set_distinct_iter(self.h, int(k)))
+
+    def ufboot_set_iteration(self, cur_it: int):
+        _chk(load_library().mpf_ufboot_set_iteration(self.h, int(cur_it)))
+
+    def ufboot_sample_iters(self, sample: int):
+        cap = max(int(getattr(self, "ufb_topboot", 0)), 1)
+        it = np.zeros(cap, dtype=np.int32)
+        n = C.c_int32(0)
+        _chk(load_library().mpf_ufboot_get_sample_iters(self.h, int(sample), _p(it), cap, C.byref(n)))
+        return [int(x) for x in it[:n.value]]
+
+    def ufboot_sample_top(self, sample: int):
+        """([(tree index, rell)...] best first, boot_threshold) of one sample under -mulhits -topboot"""
+        cap = max(int(getattr(self, "ufb_topboot", 0)), 1)
+        trees = np.zeros(cap, dtype=np.int64)
+        rell = np.zeros(cap, dtype=np.int32)
+        n, thr = C.c_int32(0), C.c_int32(0)
+        _chk(load_library().mpf_ufboot_get_sample_top(self.h, int(sample), _p(trees), _p(rell), cap, C.byref(n), C.byref(thr)))
+        return [(int(trees[i]), int(rell[i])) for i in range(n.value)], int(thr.value)
 
     def ufboot_sample_trees(self, sample: int):
         """boot_trees_parsimony[sample] under -mulhits, sorted"""

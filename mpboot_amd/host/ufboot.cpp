@@ -165,6 +165,150 @@ int Engine::ufboot_set_mulhits(int on)
   return MPF_OK;
 }
 
+// params->store_top_boot_trees (-topboot N, with -mulhits): the rule of iqtree.cpp:3542-3585.  After mpf_ufboot_set_mulhits(1),
+// before the first booked tree.
+int Engine::ufboot_set_topboot(int n_top)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (!ufb_->mulhits) { set_error("ufboot_set_topboot: the top list belongs to the -mulhits rule (set it first)"); return MPF_E_STATE; }
+  if (!ufb_->treels.empty()) { set_error("ufboot_set_topboot: trees have been booked already"); return MPF_E_STATE; }
+  if (n_top < 0 || n_top > 4096) { set_error("ufboot_set_topboot: bad list length"); return MPF_E_INVALID; }
+  ufb_->topboot = n_top;
+  ufb_->top.assign(n_top ? (size_t)ufb_->B : 0, {});
+  ufb_->top_thr.assign(n_top ? (size_t)ufb_->B : 0, -INT_MAX);            // iqtree.cpp:267
+  return MPF_OK;
+}
+
+// params->distinct_iter_top_boot (-distinct_iter_top_boot k, without -mulhits): the rule of iqtree.cpp:3587-3680.  Before the
+// first booked tree; the caller keeps mpf_ufboot_set_iteration in step with IQTree::curIt.
+int Engine::ufboot_set_distinct_iter(int k)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (ufb_->mulhits) { set_error("ufboot_set_distinct_iter: not together with -mulhits (the reference ignores it there)"); return MPF_E_STATE; }
+  if (!ufb_->treels.empty()) { set_error("ufboot_set_distinct_iter: trees have been booked already"); return MPF_E_STATE; }
+  if (k < 0 || k > 4096) { set_error("ufboot_set_distinct_iter: bad list length"); return MPF_E_INVALID; }
+  ufb_->distinct = k;
+  ufb_->top.assign(k ? (size_t)ufb_->B : 0, {});
+  ufb_->top_iter.assign(k ? (size_t)ufb_->B : 0, {});
+  ufb_->top_thr.assign(k ? (size_t)ufb_->B : 0, -INT_MAX);                // iqtree.cpp:273
+  return MPF_OK;
+}
+
+int Engine::ufboot_set_iteration(int cur_it)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  ufb_->cur_it = cur_it;
+  return MPF_OK;
+}
+
+int Engine::ufboot_sample_iters(int sample, int32_t *iters, int cap, int *n) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (!ufb_->distinct) { set_error("ufboot_sample_iters: the -distinct_iter_top_boot rule is not in force"); return MPF_E_STATE; }
+  if (sample < 0 || sample >= ufb_->B || !n) { set_error("ufboot_sample_iters: bad argument"); return MPF_E_INVALID; }
+  const auto &it = ufb_->top_iter[(size_t)sample];
+  *n = (int)it.size();
+  for (int i = 0; i < *n && i < cap && iters; i++) iters[i] = it[(size_t)i];
+  return MPF_OK;
+}
+
+int Engine::ufboot_sample_top(int sample, int64_t *trees, int32_t *rell, int cap, int *n, int32_t *threshold) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (!ufb_->topboot && !ufb_->distinct) { set_error("ufboot_sample_top: neither -topboot nor -distinct_iter_top_boot is in force"); return MPF_E_STATE; }
+  if (sample < 0 || sample >= ufb_->B || !n) { set_error("ufboot_sample_top: bad argument"); return MPF_E_INVALID; }
+  const auto &top = ufb_->top[(size_t)sample];
+  *n = (int)top.size();
+  for (int i = 0; i < *n && i < cap; i++) {
+    if (trees) trees[i] = top[(size_t)i].first;
+    if (rell) rell[i] = top[(size_t)i].second;
+  }
+  if (threshold) *threshold = ufb_->top_thr[(size_t)sample];
+  return MPF_OK;
+}
+
+bool Engine::ufb_topboot_offer(uint32_t b, int32_t rell, int64_t tree_index, bool newly_added)
+{
+  UfbState &u = *ufb_;
+  auto &top = u.top[b];
+  int32_t &thr = u.top_thr[b];
+  if (!newly_added) return false;                                          // "if newly added" (:3560)
+  const bool full = (int)top.size() == u.topboot;
+  if (full && !(rell > thr)) return false;
+  if (full) {                                                              // :3571-3578
+    const int64_t d = top.back().first;
+    top.pop_back();
+    if (--u.refs[(size_t)d] == 0) u.store.erase(d);
+  }
+  size_t pos = 0;
+  while (pos < top.size() && !(top[pos].second < rell)) pos++;            // keep the list sorted decreasingly (:3564-3569)
+  top.insert(top.begin() + (long)pos, std::make_pair(tree_index, rell));
+  if (full) thr = top[(size_t)u.topboot - 1].second;
+  else if (!(thr < rell)) thr = rell;                                      // :3570
+  u.refs[(size_t)tree_index]++;
+  return true;
+}
+
+// the -distinct_iter_top_boot block of saveCurrentTree for one (tree, sample); tree_index / looked_up: the call's tree string
+// state (resolved through `lookup` at the first acceptance); true if some list or boot_trees entry now names tree_index
+template <class Lookup>
+bool Engine::ufb_distinct_offer(uint32_t b, int32_t rell, int64_t &tree_index, bool &looked_up, Lookup lookup)
+{
+  UfbState &u = *ufb_;
+  auto &top = u.top[b];
+  auto &its = u.top_iter[b];
+  int32_t &thr = u.top_thr[b];
+  const int k = u.distinct;
+  if (rell >= thr) u.boot_counts[b]++;                                      // :3589-3591
+  bool take = rell > thr;
+  if (!take && rell == thr) {                                               // :3593-3595, the draw only on a tie
+    u.draws++;
+    take = tie_draw() <= (double)k * 1.0 / (double)u.boot_counts[b];
+  }
+  if (!take) return false;
+  uint32_t &bs = u.boot_score[b];
+  const uint32_t len = (uint32_t)(-(int64_t)rell);
+  if (len < bs) u.boot_counts[b] = 1;                                       // :3598-3600
+  if (!looked_up) { tree_index = lookup(tree_index); looked_up = true; }
+  bool named = false;
+  auto ref = [&](int64_t t) { u.refs[(size_t)t]++; named = true; };
+  auto unref = [&](int64_t t) { if (--u.refs[(size_t)t] == 0) u.store.erase(t); };
+  int64_t &bt = u.boot_trees[b];
+  if (bt != tree_index) {                                                   // :3620
+    ref(tree_index);
+    if (bt >= 0) unref(bt);
+    bt = tree_index;
+  }
+  if (len < bs) bs = len;                                                   // :3621 max()
+  const int t = std::min(k, (int)its.size());
+  for (int c = 0; c < t; c++) if (top[(size_t)c].first == tree_index) return named;      // :3627-3634 tree exists
+  int c = 0;
+  for (; c < t; c++)
+    if (its[(size_t)c] == u.cur_it) {                                       // :3637-3645 this iteration's representative
+      if (rell > top[(size_t)c].second) {
+        ref(tree_index);
+        unref(top[(size_t)c].first);
+        top[(size_t)c] = std::make_pair(tree_index, rell);
+      }
+      break;
+    }
+  if (c == t && t < k) {                                                    // :3648-3651
+    its.push_back(u.cur_it);
+    top.push_back(std::make_pair(tree_index, rell));
+    ref(tree_index);
+  } else if (c == t && t == k) {                                            // :3654-3667 replace the worst
+    int worst = 0;
+    for (int d = 1; d < t; d++) if (top[(size_t)d].second < top[(size_t)worst].second) worst = d;
+    ref(tree_index);
+    unref(top[(size_t)worst].first);
+    top[(size_t)worst] = std::make_pair(tree_index, rell);
+    its[(size_t)worst] = u.cur_it;
+  }
+  thr = top[0].second;                                                      // :3670-3675
+  for (size_t d = 1; d < top.size(); d++) thr = std::min(thr, top[d].second);
+  return named;
+}
+
 int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
 {
   if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
@@ -514,7 +658,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             small[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
           }
         }
-        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = u.boot_score[(size_t)u.ids[(size_t)c2]];
+        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
         if (compact) {
           std::memcpy(small.data() + o_crow, crow.data(), (size_t)n_idx * sizeof(uint32_t));
           std::memcpy(small.data() + o_sel, sel_rows.data(), sel_rows.size() * sizeof(uint32_t));      // padding rows multiply mask row 0
@@ -549,7 +693,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         while (true) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p));
+                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct) ? 1 : 0));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
           n_ev = u.h_small.p[0];
@@ -643,6 +787,22 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           for (; ep < events.size() && events[ep].idx == idx; ep++) {
             const uint32_t b = events[ep].b, s = events[ep].s;
             uint32_t &bs = u.boot_score[b];
+            if (u.distinct && !u.mulhits) {
+              if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return lookup_topology(ti, cand_code); }) &&
+                  (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              continue;
+            }
+            if (u.mulhits && u.topboot) {
+              // iqtree.cpp:3542-3585: the sample's list is not full yet, or the tree beats its threshold
+              const int32_t rell = -(int32_t)s;
+              if ((int)u.top[b].size() < u.topboot || rell > u.top_thr[b]) {
+                const int64_t newest = (int64_t)u.treels.size() - 1;
+                if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }
+                if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
+                    (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              }
+              continue;
+            }
             if (u.mulhits) {
               // iqtree.cpp:3498-3540: rell >= boot_logl (an event is exactly that); no draw, boot_counts untouched
               if (s > bs) continue;
@@ -897,7 +1057,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           small[d] = (!have_cut || ratchet) ? UINT32_MAX : mp_max + 1u;            // max cost + 1 (costs are full lengths here)
           small[n_parts + d] = R;
         }
-        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = u.boot_score[(size_t)u.ids[(size_t)c2]];
+        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
         UCHK(u.h_small.reserve(small.size() + 4));
         std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
         UCHK(u.thr.reserve(small.size() + 4));
@@ -920,7 +1080,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         while (n_idx) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p));
+                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct) ? 1 : 0));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
           n_ev = u.h_small.p[0];
@@ -974,6 +1134,21 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           for (; ep < events.size() && events[ep].idx == idx; ep++) {
             const uint32_t b = events[ep].b, s = events[ep].s;
             uint32_t &bs = u.boot_score[b];
+            if (u.distinct && !u.mulhits) {
+              if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return cand_topology_key(cand_code, ti); }) &&
+                  (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              continue;
+            }
+            if (u.mulhits && u.topboot) {
+              const int32_t rell = -(int32_t)s;
+              if ((int)u.top[b].size() < u.topboot || rell > u.top_thr[b]) {
+                const int64_t newest = (int64_t)u.treels.size() - 1;
+                if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
+                if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
+                    (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
+              }
+              continue;
+            }
             if (u.mulhits) {
               if (s > bs) continue;
               if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }

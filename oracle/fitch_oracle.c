@@ -77,6 +77,13 @@ struct orc {
   /* -mulhits (params->multiple_hits, iqtree.cpp:3498-3540): treels (canonical topology -> tree index) and
      boot_trees_parsimony (per sample: the set of tree indices that reach its best REPS) */
   int ufb_mulhits;
+  /* -mulhits -topboot N (params->store_top_boot_trees, iqtree.cpp:3542-3585): per sample the N best NEW trees, sorted by
+     decreasing REPS, and boot_threshold */
+  int ufb_topboot;
+  int *ufb_top_idx, *ufb_top_rell, *ufb_top_n, *ufb_thr;
+  /* -distinct_iter_top_boot k (iqtree.cpp:3587-3680, without -mulhits): the same arrays + the iteration each entry stands for */
+  int ufb_distinct, ufb_cur_it;
+  int *ufb_top_iter;
   int **ufb_keys, *ufb_key_idx, ufb_nkeys, ufb_keys_cap;
   int **ufb_set, *ufb_set_n, *ufb_set_cap;
 };
@@ -738,6 +745,63 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
     const unsigned short *bs = o->ufb_samples + (size_t)sample * o->P;
     int res = ufb_dot(o->ufb_ptn, bs, o->P);
     double rell = -(double)res;
+    if (o->ufb_distinct && !o->ufb_mulhits) {                                /* :3587-3680 */
+      const int K = o->ufb_distinct;
+      int *ti = o->ufb_top_idx + (size_t)sample * K, *tr = o->ufb_top_rell + (size_t)sample * K, *tit = o->ufb_top_iter + (size_t)sample * K;
+      int *cnt = &o->ufb_top_n[sample];
+      const double thr = (double)o->ufb_thr[sample];
+      if (rell >= thr) o->ufb_counts[sample]++;
+      if (rell > thr || (rell == thr && (o->ufb_draws++, tie_draw(o)) <= (double)K * 1.0 / (double)o->ufb_counts[sample])) {
+        int t, c, exists = 0, d;
+        if (rell > o->ufb_logl[sample]) o->ufb_counts[sample] = 1;
+        if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }
+        ufb_store_tree(o, tree_index);
+        o->ufb_trees[sample] = tree_index;
+        if (rell > o->ufb_logl[sample]) o->ufb_logl[sample] = rell;
+        t = K < *cnt ? K : *cnt;
+        for (c = 0; c < t; c++) if (ti[c] == tree_index) { exists = 1; break; }
+        if (exists) continue;
+        for (c = 0; c < t; c++)
+          if (tit[c] == o->ufb_cur_it) {
+            if (rell > (double)tr[c]) { tr[c] = (int)rell; ti[c] = tree_index; }
+            break;
+          }
+        if (c == t && t < K) { tit[*cnt] = o->ufb_cur_it; ti[*cnt] = tree_index; tr[*cnt] = (int)rell; (*cnt)++; }
+        else if (c == t && t == K) {
+          int worst = 0;
+          for (d = 1; d < t; d++) if (tr[d] < tr[worst]) worst = d;
+          ti[worst] = tree_index; tr[worst] = (int)rell; tit[worst] = o->ufb_cur_it;
+        }
+        o->ufb_thr[sample] = tr[0];
+        for (d = 1; d < *cnt; d++) if (tr[d] < o->ufb_thr[sample]) o->ufb_thr[sample] = tr[d];
+      }
+      continue;
+    }
+    if (o->ufb_mulhits && o->ufb_topboot) {                                  /* :3542-3585 */
+      const int N = o->ufb_topboot;
+      int *ti = o->ufb_top_idx + (size_t)sample * N, *tr = o->ufb_top_rell + (size_t)sample * N, *cnt = &o->ufb_top_n[sample];
+      if (*cnt < N || rell > (double)o->ufb_thr[sample]) {
+        if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }
+        if (tree_index == o->ufb_ntrees - 1) {                                /* "if newly added" */
+          int pos, i;
+          if (*cnt < N) {
+            for (pos = 0; pos < *cnt; pos++) if ((double)tr[pos] < rell) break;
+            for (i = *cnt; i > pos; i--) { ti[i] = ti[i - 1]; tr[i] = tr[i - 1]; }
+            ti[pos] = tree_index; tr[pos] = (int)rell; (*cnt)++;
+            if (!((double)o->ufb_thr[sample] < rell)) o->ufb_thr[sample] = (int)rell;
+            ufb_store_tree(o, tree_index);
+          } else if (rell > (double)o->ufb_thr[sample]) {
+            (*cnt)--;                                                         /* pop_back */
+            for (pos = 0; pos < *cnt; pos++) if ((double)tr[pos] < rell) break;
+            for (i = *cnt; i > pos; i--) { ti[i] = ti[i - 1]; tr[i] = tr[i - 1]; }
+            ti[pos] = tree_index; tr[pos] = (int)rell; (*cnt)++;
+            o->ufb_thr[sample] = tr[N - 1];
+            ufb_store_tree(o, tree_index);
+          }
+        }
+      }
+      continue;
+    }
     if (o->ufb_mulhits) {                                                    /* :3498-3540, no draw, no boot_counts */
       if (rell >= o->ufb_logl[sample]) {
         int i, have = 0;
@@ -1074,6 +1138,9 @@ void orc_ufboot_detach(orc *o)
   free(o->ufb_set); free(o->ufb_set_n); free(o->ufb_set_cap);
   o->ufb_set = NULL; o->ufb_set_n = o->ufb_set_cap = NULL;
   o->ufb_mulhits = 0;
+  free(o->ufb_top_idx); free(o->ufb_top_rell); free(o->ufb_top_n); free(o->ufb_thr); free(o->ufb_top_iter);
+  o->ufb_top_idx = o->ufb_top_rell = o->ufb_top_n = o->ufb_thr = o->ufb_top_iter = NULL;
+  o->ufb_topboot = o->ufb_distinct = o->ufb_cur_it = 0;
   free(o->ufb_samples); free(o->ufb_logl); free(o->ufb_counts); free(o->ufb_trees); free(o->ufb_treels); free(o->ufb_ptn);
   o->ufb_store_back = NULL; o->ufb_store_idx = NULL; o->ufb_nstore = o->ufb_store_cap = 0;
   o->ufb_samples = NULL; o->ufb_logl = NULL; o->ufb_counts = NULL; o->ufb_trees = NULL; o->ufb_treels = NULL; o->ufb_ptn = NULL;
@@ -1109,6 +1176,40 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsi
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff) { o->ufb_cutoff = logl_cutoff; }
 void orc_ufboot_set_ratchet_booking(orc *o, int on) { o->ufb_ratchet_booking = on != 0; }   /* !no_hclimb1_bb; next set_weights */
 void orc_ufboot_set_mulhits(orc *o, int on) { o->ufb_mulhits = on != 0; }                  /* params->multiple_hits */
+void orc_ufboot_set_topboot(orc *o, int n_top)                                              /* params->store_top_boot_trees; with -mulhits */
+{
+  int b;
+  free(o->ufb_top_idx); free(o->ufb_top_rell); free(o->ufb_top_n); free(o->ufb_thr);
+  o->ufb_topboot = n_top > 0 ? n_top : 0;
+  o->ufb_top_idx = (int *)calloc((size_t)o->ufb_B * (size_t)(n_top > 0 ? n_top : 1), sizeof(int));
+  o->ufb_top_rell = (int *)calloc((size_t)o->ufb_B * (size_t)(n_top > 0 ? n_top : 1), sizeof(int));
+  o->ufb_top_n = (int *)calloc((size_t)o->ufb_B, sizeof(int));
+  o->ufb_thr = (int *)malloc(sizeof(int) * (size_t)o->ufb_B);
+  for (b = 0; b < o->ufb_B; b++) o->ufb_thr[b] = -INT_MAX;                                   /* iqtree.cpp:267 */
+}
+void orc_ufboot_set_distinct_iter(orc *o, int k)                                            /* params->distinct_iter_top_boot; without -mulhits */
+{
+  orc_ufboot_set_topboot(o, k);                                                             /* the same arrays (iqtree.cpp:270-277) */
+  o->ufb_topboot = 0;
+  o->ufb_distinct = k > 0 ? k : 0;
+  free(o->ufb_top_iter);
+  o->ufb_top_iter = (int *)calloc((size_t)o->ufb_B * (size_t)(k > 0 ? k : 1), sizeof(int));
+}
+void orc_ufboot_set_iteration(orc *o, int cur_it) { o->ufb_cur_it = cur_it; }               /* IQTree::curIt */
+int orc_ufboot_sample_iters(const orc *o, int sample, int *iters)
+{
+  int i, n = o->ufb_top_n ? o->ufb_top_n[sample] : 0;
+  for (i = 0; i < n && o->ufb_top_iter; i++) iters[i] = o->ufb_top_iter[(size_t)sample * o->ufb_distinct + i];
+  return n;
+}
+int orc_ufboot_sample_top(const orc *o, int sample, int *idx, int *rell, int *threshold)    /* boot_trees_parsimony_top[sample] */
+{
+  const int stride = o->ufb_topboot ? o->ufb_topboot : o->ufb_distinct;
+  int i, n = o->ufb_top_n ? o->ufb_top_n[sample] : 0;
+  for (i = 0; i < n; i++) { idx[i] = o->ufb_top_idx[(size_t)sample * stride + i]; rell[i] = o->ufb_top_rell[(size_t)sample * stride + i]; }
+  if (threshold) *threshold = o->ufb_thr ? o->ufb_thr[sample] : 0;
+  return n;
+}
 int orc_ufboot_sample_trees(const orc *o, int sample, int *out, int cap)                    /* boot_trees_parsimony[sample] */
 {
   int i, n = o->ufb_set_n[sample];

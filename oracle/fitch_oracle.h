@@ -82,6 +82,11 @@ void orc_ufboot_detach(orc *o);
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff);       /* 0 = none (iqtree.cpp:3343) */
 void orc_ufboot_set_ratchet_booking(orc *o, int on);          /* 0 = -no_hclimb1_bb (iqtree.cpp:3280); default 1 */
 void orc_ufboot_set_mulhits(orc *o, int on);                  /* 1 = -mulhits update rule (iqtree.cpp:3498-3540); right after attach */
+void orc_ufboot_set_topboot(orc *o, int n_top);               /* -mulhits -topboot N (iqtree.cpp:3542-3585); after set_mulhits */
+void orc_ufboot_set_distinct_iter(orc *o, int k);             /* -distinct_iter_top_boot k (iqtree.cpp:3587-3680); without -mulhits */
+void orc_ufboot_set_iteration(orc *o, int cur_it);            /* IQTree::curIt */
+int orc_ufboot_sample_iters(const orc *o, int sample, int *iters);   /* boot_trees_parsimony_top_iter[sample] */
+int orc_ufboot_sample_top(const orc *o, int sample, int *idx, int *rell, int *threshold);   /* boot_trees_parsimony_top[sample]; returns its size */
 int orc_ufboot_sample_trees(const orc *o, int sample, int *out, int cap);   /* boot_trees_parsimony[sample] (insertion order); returns its size */
 int orc_ufboot_ntrees(const orc *o);                          /* treels_logl.size() */
 int orc_ufboot_bad(const orc *o);                             /* # candidates whose pattern-score sum != mp (:3366) */

@@ -84,6 +84,13 @@ def lib():
         L.orc_ufboot_set_cutoff.argtypes = [vp, C.c_double]
         L.orc_ufboot_set_ratchet_booking.argtypes = [vp, ci]
         L.orc_ufboot_set_mulhits.argtypes = [vp, ci]
+        L.orc_ufboot_set_topboot.argtypes = [vp, ci]
+        L.orc_ufboot_set_distinct_iter.argtypes = [vp, ci]
+        L.orc_ufboot_set_iteration.argtypes = [vp, ci]
+        L.orc_ufboot_sample_iters.restype = ci
+        L.orc_ufboot_sample_iters.argtypes = [vp, ci, vp]
+        L.orc_ufboot_sample_top.restype = ci
+        L.orc_ufboot_sample_top.argtypes = [vp, ci, vp, vp, vp]
         L.orc_ufboot_sample_trees.restype = ci
         L.orc_ufboot_sample_trees.argtypes = [vp, ci, vp, ci]
         L.orc_ufboot_ntrees.restype = ci
@@ -260,6 +267,30 @@ class Oracle:
 
     def ufboot_set_mulhits(self, on: bool):
         lib().orc_ufboot_set_mulhits(self.h, 1 if on else 0)
+
+    def ufboot_set_topboot(self, n_top: int):
+        self.ufb_topboot = int(n_top)
+        lib().orc_ufboot_set_topboot(self.h, int(n_top))
+
+    def ufboot_set_distinct_iter(self, k: int):
+        self.ufb_topboot = int(k)
+        lib().orc_ufboot_set_distinct_iter(self.h, int(k))
+
+    def ufboot_set_iteration(self, cur_it: int):
+        lib().orc_ufboot_set_iteration(self.h, int(cur_it))
+
+    def ufboot_sample_iters(self, sample: int):
+        it = np.zeros(max(self.ufb_topboot, 1), dtype=np.int32)
+        n = lib().orc_ufboot_sample_iters(self.h, int(sample), _p(it))
+        return [int(x) for x in it[:n]]
+
+    def ufboot_sample_top(self, sample: int):
+        """boot_trees_parsimony_top[sample] under -mulhits -topboot N: ([(tree index, rell)...] best first, boot_threshold)"""
+        idx = np.zeros(max(self.ufb_topboot, 1), dtype=np.int32)
+        rell = np.zeros(max(self.ufb_topboot, 1), dtype=np.int32)
+        thr = C.c_int(0)
+        n = lib().orc_ufboot_sample_top(self.h, int(sample), _p(idx), _p(rell), C.byref(thr))
+        return [(int(idx[i]), int(rell[i])) for i in range(n)], int(thr.value)
 
     def ufboot_sample_trees(self, sample: int):
         """boot_trees_parsimony[sample] under -mulhits, sorted"""

@@ -79,6 +79,12 @@ class SlowSearch:
             self.treels = {}                               # topology -> tree index (only trees that hit, :3503-3513)
             self.boot_sets = [set() for _ in range(B)]     # boot_trees_parsimony
             self.largest_set = 0
+            self.topboot = 0                               # params->store_top_boot_trees (with -mulhits)
+            self.boot_top = [[] for _ in range(B)]         # boot_trees_parsimony_top: [(tree index, rell)], best first
+            self.boot_threshold = [-(2 ** 31 - 1)] * B     # iqtree.cpp:267
+            self.distinct = 0                              # params->distinct_iter_top_boot (without -mulhits)
+            self.cur_it = 0                                # IQTree::curIt
+            self.boot_top_iter = [[] for _ in range(B)]    # boot_trees_parsimony_top_iter
 
     def draw(self) -> float:
         self.draws += 1
@@ -171,6 +177,59 @@ class SlowSearch:
         looked_up = False
         for b in range(self.samples.shape[0]):                         # :3411
             rell = -float((self.pattern_pars * self.samples[b]).sum())
+            if self.distinct and not self.mulhits:                     # :3587-3680
+                k, top, its = self.distinct, self.boot_top[b], self.boot_top_iter[b]
+                thr = self.boot_threshold[b]
+                if rell >= thr:
+                    self.boot_counts[b] += 1
+                take = rell > thr
+                if not take and rell == thr:
+                    self.ufb_draws += 1
+                    take = self.draw() <= k * 1.0 / self.boot_counts[b]
+                if take:
+                    if rell > self.boot_logl[b]:
+                        self.boot_counts[b] = 1
+                    if not looked_up:
+                        tree_index = self.treels.setdefault(self.splits(self.back), tree_index)
+                        looked_up = True
+                    self.topologies.setdefault(tree_index, list(self.back))
+                    self.boot_trees[b] = tree_index
+                    self.boot_logl[b] = max(self.boot_logl[b], rell)
+                    t = min(k, len(its))
+                    if any(top[c][0] == tree_index for c in range(t)):
+                        continue
+                    rep = next((c for c in range(t) if its[c] == self.cur_it), None)
+                    if rep is not None:
+                        if rell > top[rep][1]:
+                            top[rep] = (tree_index, int(rell))
+                    elif t < k:
+                        its.append(self.cur_it)
+                        top.append((tree_index, int(rell)))
+                    else:
+                        worst = min(range(t), key=lambda d: (top[d][1], d))
+                        top[worst] = (tree_index, int(rell))
+                        its[worst] = self.cur_it
+                    self.boot_threshold[b] = min(r for _, r in top)
+                continue
+            if self.mulhits and self.topboot:                          # :3542-3585
+                top = self.boot_top[b]
+                if len(top) < self.topboot or rell > self.boot_threshold[b]:
+                    if not looked_up:
+                        tree_index = self.treels.setdefault(self.splits(self.back), tree_index)
+                        looked_up = True
+                    if tree_index == len(self.treels_logl) - 1:        # "if newly added"
+                        full = len(top) == self.topboot
+                        if not full or rell > self.boot_threshold[b]:
+                            if full:
+                                top.pop()
+                            pos = next((i for i, (_, r) in enumerate(top) if r < rell), len(top))
+                            top.insert(pos, (tree_index, int(rell)))
+                            if full:
+                                self.boot_threshold[b] = top[self.topboot - 1][1]
+                            elif not self.boot_threshold[b] < rell:
+                                self.boot_threshold[b] = int(rell)
+                            self.topologies.setdefault(tree_index, list(self.back))
+                continue
             if self.mulhits:                                           # :3498-3540
                 if rell >= self.boot_logl[b]:
                     if not looked_up:

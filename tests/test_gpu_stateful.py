@@ -78,7 +78,8 @@ def run_sequence(c, seed, n_steps, cost=None):
         x.set_tree(known[0])
         x.seed_ties(1, seed)                    # TIE_RANDOM on both sides
     weights = [c["w"]]
-    tracked = mulhits = False
+    tracked = mulhits = toplist = False
+    iteration = 0
     log = []
     for step in range(n_steps):
         op = int(rng.integers(0, 12))
@@ -88,7 +89,7 @@ def run_sequence(c, seed, n_steps, cost=None):
         if str(step) in os.environ.get("MPF_STATEFUL_SKIP", "").split(","):
             continue
         if os.environ.get("MPF_STATEFUL_VERBOSE"):
-            print("step", step, "op", op, "tracked", tracked, "n", n, "P", P, "aa", c["aa"], "maxtrav", maxtrav, "opts", OPTION_SETS[seed % len(OPTION_SETS)], flush=True)
+            print("seed", seed, "step", step, "op", op, "tracked", tracked, "n", n, "P", P, "aa", c["aa"], "maxtrav", maxtrav, "opts", OPTION_SETS[seed % len(OPTION_SETS)], flush=True)
         if op == 0:                             # a tree seen before (same topology again -> cached plans) or a new one
             t = known[int(rng.integers(0, len(known)))] if rng.random() < 0.7 else trees.random_topology(n, rng)
             assert e.score_tree(t) == o.score_tree(t), log
@@ -127,6 +128,10 @@ def run_sequence(c, seed, n_steps, cost=None):
                 x.seed_ties(1, seed + step)
         elif op == 3:                           # a climb
             o.trace(True)
+            if tracked:
+                iteration += 1
+                for x in (e, o):
+                    x.ufboot_set_iteration(iteration)
             radius = int(rng.integers(1, maxtrav + 1))
             assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius), log
             assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()], log
@@ -136,9 +141,12 @@ def run_sequence(c, seed, n_steps, cost=None):
                 assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()], log
                 assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist(), log
                 assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws(), log
-                if mulhits:
+                if mulhits and not toplist:
                     for b in range(5):
                         assert e.ufboot_sample_trees(b) == o.ufboot_sample_trees(b), log
+                if toplist:
+                    for b in range(5):
+                        assert e.ufboot_sample_top(b) == o.ufboot_sample_top(b), log
         elif op == 4:                           # re-weighting (between scans of one topology: the plans stay, the vectors go)
             if rng.random() < 0.5:
                 w = weights[int(rng.integers(0, len(weights)))]
@@ -167,16 +175,25 @@ def run_sequence(c, seed, n_steps, cost=None):
             e.ufboot_attach(samples)
             o.ufboot_attach(samples)
             tracked = True
-            mulhits = bool(rng.random() < 0.3)
-            if mulhits:
-                e.ufboot_set_mulhits(True)
-                o.ufboot_set_mulhits(True)
+            rule = int(rng.integers(0, 6))              # 0-2 default, 3 -mulhits, 4 -mulhits -topboot, 5 -distinct_iter_top_boot
+            mulhits = rule in (3, 4)
+            toplist = rule in (4, 5)
+            for x in (e, o):
+                if mulhits:
+                    x.ufboot_set_mulhits(True)
+                if rule == 4:
+                    x.ufboot_set_topboot(3)
+                if rule == 5:
+                    x.ufboot_set_distinct_iter(2)
+            iteration = 0
         elif op == 9:                           # an option that changes kernels / batching / caching, mid-way
             k, v = [("scan_batch", int(rng.integers(1, 65))), ("split_below", int(rng.integers(0, 3)) * 2048), ("plan_cache", int(rng.integers(0, 2))),
                     ("scan_prog", int(rng.integers(0, 3))), ("views_mode", int(rng.integers(0, 3))), ("split_cands", int(rng.integers(8, 65))),
                     ("prog_min_descs", int(rng.integers(0, 2)) * 256), ("host_poll", int(rng.integers(0, 2)))][int(rng.integers(0, 8))]
+            if os.environ.get("MPF_STATEFUL_VERBOSE"):
+                print("   option", k, v, flush=True)
             e.set_option(k, v)
-        elif op == 10 and tracked and not mulhits and len(o.ufboot_tree_logl()) > 20:      # a cut-off from the trees booked so far
+        elif op == 10 and tracked and len(o.ufboot_tree_logl()) > 20:      # a cut-off from the trees booked so far
             logl = np.sort(o.ufboot_tree_logl())
             cut = float(logl[int(rng.integers(0, len(logl)))])
             e.ufboot_set_cutoff(cut)
@@ -184,7 +201,7 @@ def run_sequence(c, seed, n_steps, cost=None):
         elif op == 11 and tracked and rng.random() < 0.3:
             e.ufboot_detach()
             o.ufboot_detach()
-            tracked = mulhits = False
+            tracked = mulhits = toplist = False
         elif op == 8:                           # the same tree handed over again, explicitly
             t = e.get_tree().copy()
             for x in (e, o):

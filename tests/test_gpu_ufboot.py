@@ -586,3 +586,98 @@ def test_weighted_engine_bookkeeping_matches_oracle(mods, name, big, mode):
                 x.ufboot_set_cutoff(float(logl[len(logl) // 2]))
     assert o.ufboot_bad() == 0
     assert len(o.ufboot_tree_logl()) > 50
+
+
+@pytest.mark.parametrize("n_top", [1, 4, 10])
+@pytest.mark.parametrize("engine_kind", ["fitch", "weighted"])
+@pytest.mark.parametrize("name", ["dna_clean", "dna_dups", "aa", "dna_48"])
+def test_mulhits_topboot_rule_matches_oracle(mods, name, engine_kind, n_top):
+    """-mulhits -topboot N (params->store_top_boot_trees, iqtree.cpp:3542-3585): per sample the N best new trees, best first, and
+    boot_threshold, over a normal climb, a ratchet climb and the climb back (with a cut-off from the second climb on) -- on both
+    engines.  The device's event bound is the list's threshold at the start of the batch (fixed, not a running minimum)."""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    cost = None
+    if engine_kind == "weighted":
+        S = 4 if fx["datatype"] == 0 else 20
+        m = np.random.default_rng(3).integers(1, 6, size=(S, S))
+        cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    samples = boot_samples(len(w0), 16, 53, fx["weights"])
+    rng = np.random.default_rng(4)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (2, 5, 7)]
+    for x in (e, o):
+        x.seed_ties(1, 37)
+        x.ufboot_attach(samples)
+        x.ufboot_set_mulhits(True)
+        x.ufboot_set_topboot(n_top)
+    for k, w in enumerate((w0, pert, w0)):
+        for x in (e, o):
+            x.set_weights(w)
+            x.set_tree(t[k])
+        o.trace(True)
+        assert e.optimize_spr(1, 5) == o.optimize_spr(1, 5)
+        assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws() == 0
+        for b in range(len(samples)):
+            got, want = e.ufboot_sample_top(b), o.ufboot_sample_top(b)
+            assert got == want and len(got[0]) == n_top
+            for ti, _ in got[0]:
+                assert same_topology(e.ufboot_tree(ti), o.ufboot_tree(ti), fx["n"])
+        if k == 0:
+            logl = np.sort(o.ufboot_tree_logl())
+            for x in (e, o):
+                x.ufboot_set_cutoff(float(logl[len(logl) // 3]))
+    assert o.ufboot_bad() == 0
+
+
+@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("engine_kind", ["fitch", "weighted"])
+@pytest.mark.parametrize("name", ["dna_clean", "dna_dups", "aa", "dna_48"])
+def test_distinct_iter_top_boot_rule_matches_oracle(mods, name, engine_kind, k):
+    """-distinct_iter_top_boot k (iqtree.cpp:3587-3680) over five search iterations (a ratchet climb among them, a cut-off from
+    the third on): lists, their iterations, thresholds, boot_logl / boot_counts / boot_trees, the saved-tree list and the
+    number of tie draws == the oracle's, on both engines"""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    cost = None
+    if engine_kind == "weighted":
+        S = 4 if fx["datatype"] == 0 else 20
+        m = np.random.default_rng(3).integers(1, 6, size=(S, S))
+        cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    samples = boot_samples(len(w0), 16, 59, fx["weights"])
+    rng = np.random.default_rng(6)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    t = [np.array(fx["trees"][j]["back"], dtype=np.int32) for j in (2, 5, 7, 1, 3)]
+    for x in (e, o):
+        x.seed_ties(1, 43)
+        x.ufboot_attach(samples)
+        x.ufboot_set_distinct_iter(k)
+    for it, w in enumerate((w0, pert, w0, w0, w0)):
+        for x in (e, o):
+            x.ufboot_set_iteration(it + 1)
+            x.set_weights(w)
+            x.set_tree(t[it])
+        o.trace(True)
+        assert e.optimize_spr(1, 5) == o.optimize_spr(1, 5)
+        assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+        for b in range(len(samples)):
+            assert e.ufboot_sample_top(b) == o.ufboot_sample_top(b)
+            assert e.ufboot_sample_iters(b) == o.ufboot_sample_iters(b)
+            for ti, _ in e.ufboot_sample_top(b)[0]:
+                assert same_topology(e.ufboot_tree(ti), o.ufboot_tree(ti), fx["n"])
+        if it == 1:
+            logl = np.sort(o.ufboot_tree_logl())
+            for x in (e, o):
+                x.ufboot_set_cutoff(float(logl[len(logl) // 3]))
+    assert o.ufboot_bad() == 0 and o.ufboot_draws() > 0

@@ -127,3 +127,66 @@ def test_mulhits_rule_over_normal_ratchet_normal_climbs(name, seed):
     assert s.largest_set > 1                                 # some sample really held several equally good trees
     # one topology met again keeps its first index: fewer distinct indices than hits
     assert len(s.treels) < len(s.treels_logl)
+
+
+@pytest.mark.parametrize("n_top", [1, 3, 10])
+@pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9)])
+def test_mulhits_topboot_rule(name, seed, n_top):
+    """-mulhits -topboot N (iqtree.cpp:3542-3585): per sample the N best NEW trees in decreasing REPS order with the reference's
+    threshold quirks (it stays at -INT_MAX until the first replacement in a full list)"""
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(seed)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=5).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 3, 5)]
+    o, s = both(fx, seed, samples)
+    o.ufboot_set_mulhits(True)
+    o.ufboot_set_topboot(n_top)
+    s.mulhits, s.topboot = True, n_top
+    for k, w in enumerate((w0, pert, w0)):
+        for x in (o, s):
+            x.set_weights(w)
+            x.set_tree(t[k])
+        assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+        assert o.get_tree().tolist() == s.back
+        assert o.ufboot_tree_logl().tolist() == s.treels_logl
+        for b in range(len(samples)):
+            top, thr = o.ufboot_sample_top(b)
+            assert top == s.boot_top[b] and thr == s.boot_threshold[b]
+            assert len(top) == min(n_top, len(top)) and [r for _, r in top] == sorted((r for _, r in top), reverse=True)
+            for ti, _ in top:
+                assert o.ufboot_tree(ti).tolist() == s.topologies[ti]
+        assert o.ufboot_draws() == s.ufb_draws == 0
+    assert all(len(x) == n_top for x in s.boot_top)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5])
+@pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9), ("dna_ambig", 4)])
+def test_distinct_iter_top_boot_rule(name, seed, k):
+    """-distinct_iter_top_boot k (iqtree.cpp:3587-3680): per sample at most k trees, one representative per search iteration
+    (curIt), accepted against the list's worst score with a k / count tie draw from the shared stream"""
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(seed)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=5).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    t = [np.array(fx["trees"][j]["back"], dtype=np.int32) for j in (1, 3, 5, 2, 6)]
+    o, s = both(fx, seed, samples)
+    o.ufboot_set_distinct_iter(k)
+    s.distinct = k
+    for it, w in enumerate((w0, pert, w0, w0, w0)):
+        o.ufboot_set_iteration(it + 1)
+        s.cur_it = it + 1
+        for x in (o, s):
+            x.set_weights(w)
+            x.set_tree(t[it])
+        assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+        assert o.get_tree().tolist() == s.back
+        bb_same(o, s)
+        for b in range(len(samples)):
+            top, thr = o.ufboot_sample_top(b)
+            assert top == s.boot_top[b] and thr == s.boot_threshold[b]
+            assert o.ufboot_sample_iters(b) == s.boot_top_iter[b]
+            assert 1 <= len(top) <= k
+    assert s.ufb_draws > 0
