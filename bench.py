@@ -295,10 +295,15 @@ def launch_ranks(n: int) -> int:
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for out in proc.stdout:
-        sys.stdout.write(out)
-        sys.stdout.flush()
+        # stdout carries the ONE result line; whatever else the ranks' libraries print there (gloo's connection notes) goes to
+        # stderr
         if out.startswith("{"):
             line = out
+            sys.stdout.write(out)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(out)
+            sys.stderr.flush()
     rc = proc.wait()
     if rc == 0 and line is None:
         print("bench.py: the ranks printed no result line", file=sys.stderr)
