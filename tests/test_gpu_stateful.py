@@ -208,3 +208,27 @@ def run_sequence(c, seed, n_steps, cost=None):
                 x.set_tree(t)
             assert e.score_tree() == o.score_tree(), log
     assert e.score_tree() == o.score_tree(), log
+
+
+def test_concurrent_engines_random_sequences():
+    """several engines on one GPU, one host thread each (the shape of bootstrap.refine_boot_trees / integration/multi_device.hpp),
+    each running its own random call sequence against its own oracle at the same time: nothing in the library is shared between
+    engines but the device"""
+    import threading
+
+    errors = []
+
+    def work(k):
+        try:
+            for seed in range(40 + 8 * k, 48 + 8 * k):
+                c = random_case(13000 + seed + STATE_OFFSET)
+                run_sequence(c, seed, 10)
+        except BaseException as exc:      # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
