@@ -63,8 +63,12 @@ def run_sequence(c, seed, n_steps, cost=None):
     dt_e, dt_o = (engine.AA, po.AA) if c["aa"] else (engine.DNA, po.DNA)
     if cost is not None:
         c["w"] = np.maximum(c["w"], 0)
-    e = engine.FitchEngine(c["codes"], c["w"], datatype=dt_e, cost=cost)
-    o = po.Oracle(c["codes"], c["w"], datatype=dt_o, cost=cost)
+    keep_all = bool(c.get("keep_all", False)) and cost is None
+    tmode = int(c.get("tie", 1)) if cost is None else 1          # 0 = first-best rule (PLL original + mpboot's pre-evaluate)
+    e = engine.FitchEngine(c["codes"], c["w"], datatype=dt_e, cost=cost, keep_all=keep_all)
+    o = po.Oracle(c["codes"], c["w"], datatype=dt_o, cost=cost, keep_all=keep_all)
+    if tmode == 0:
+        o.set_pre_evaluate(1)
     if o.num_informative == 0:
         return
     n, P = c["n"], c["P"]
@@ -76,7 +80,7 @@ def run_sequence(c, seed, n_steps, cost=None):
     known = [c["back"], trees.random_topology(n, rng)]
     for x in (e, o):
         x.set_tree(known[0])
-        x.seed_ties(1, seed)                    # TIE_RANDOM on both sides
+        x.seed_ties(tmode, seed)
     weights = [c["w"]]
     tracked = mulhits = toplist = False
     iteration = 0
@@ -108,7 +112,7 @@ def run_sequence(c, seed, n_steps, cost=None):
             q, mp, _ = e.spr_scan(rec, 1, maxtrav)
             assert q.tolist() == tq[keep].tolist() and mp.tolist() == tm[keep].tolist(), log
             for x in (e, o):
-                x.seed_ties(1, seed + step)     # (the oracle's tie rule drew random numbers during that scan)
+                x.seed_ties(tmode, seed + step)     # (the oracle's tie rule drew random numbers during that scan)
         elif op == 2:                           # a whole sweep: the best candidate score
             cur = o.score_tree()
             assert e.score_tree() == cur, log
@@ -125,7 +129,7 @@ def run_sequence(c, seed, n_steps, cost=None):
             if lo is not None:
                 assert best == lo, log
             for x in (e, o):
-                x.seed_ties(1, seed + step)
+                x.seed_ties(tmode, seed + step)
         elif op == 3:                           # a climb
             o.trace(True)
             if tracked:
