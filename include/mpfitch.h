@@ -314,6 +314,11 @@ int mpf_reset_stats(mpf_engine *e);
                        insertion tests than this (default 64)
      "sankoff_short"   1 = two 16-bit costs per lane in the weighted kernels when no intermediate can overflow
                        (the reference's default arithmetic), 0 = always 32-bit (its -short_off)
+     "plan_cache"      1 (default) = what the host prepares per topology -- the whole-tree refresh schedule, a sweep's scan
+                       descriptors and its device program -- is kept while the topology stands (the same tree handed over again,
+                       re-weighted, re-evaluated); 0 = everything is planned again every time
+     "host_poll"       1 (default) = small batches: the host waits for the flag word the scan's last workgroup raises behind the
+                       results it writes to pinned memory, instead of a stream synchronisation
      "check_counts"    1 = compare the kernel's candidate counts with the host's, and check the view bookkeeping
      "force_big"       1 = 64-bit addressing in the scan kernel even below 2 GiB of vectors (set before the first tree)
      "timing"          1 = HIP events around the scan kernels (mpf_stats scan_kernel_ms_total), 2 = around the refresh
