@@ -4,15 +4,15 @@
 mkdir -p gpurun_out/bounds
 {
 echo "== bench.py --steps 20 --warmup 5 (C3 sweep; scan = HIP-event time of the scan kernel per launch, ms) =="
-bash tools/gpu_c.sh "--opt scan_prog=1"
+bash tools/bench_oneline.sh "--opt scan_prog=1"
 echo "-- MPF_PROG_EXPERIMENT=2: loads only (one AND per loaded register instead of the Fitch arithmetic; results are garbage on purpose)"
-MPF_PROG_EXPERIMENT=2 bash tools/gpu_c.sh "--opt scan_prog=1"
+MPF_PROG_EXPERIMENT=2 bash tools/bench_oneline.sh "--opt scan_prog=1"
 echo "-- MPF_PROG_EXPERIMENT=1: arithmetic + control only (no vector loads in the loop)"
-MPF_PROG_EXPERIMENT=1 bash tools/gpu_c.sh "--opt scan_prog=1"
+MPF_PROG_EXPERIMENT=1 bash tools/bench_oneline.sh "--opt scan_prog=1"
 echo "-- MPF_PROG_CID_MASK=63: the real kernel, every child vector taken from 64 hot ones"
-MPF_PROG_CID_MASK=63 bash tools/gpu_c.sh "--opt scan_prog=1"
+MPF_PROG_CID_MASK=63 bash tools/bench_oneline.sh "--opt scan_prog=1"
 echo "-- scan_prog=0: the device-walked kernel of round 1 (with long neighbourhoods cut, and as it was)"
-bash tools/gpu_c.sh "--opt scan_prog=0" "--opt scan_prog=0 --opt split_cands=100000"
+bash tools/bench_oneline.sh "--opt scan_prog=0" "--opt scan_prog=0 --opt split_cands=100000"
 echo
 echo "== tools/ubench/valu_rate: ns per wave-instruction per SIMD with 1/2/4/8 waves per SIMD =="
 tools/ubench/valu_rate
