@@ -50,6 +50,9 @@ def source_hash() -> str:
 def offline_traffic(workload: str, kernel_prefix: str):
     """Bytes that left the L2s per launch of the named kernel family (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
     tools/profile_gpu.sh -> profiles/r2/traffic.json); None unless that file was made from exactly these sources."""
+    for k, v in LIVE_TRAFFIC.items():               # measured at the start of this run
+        if k.startswith(kernel_prefix):
+            return v
     path = os.path.join(ROOT, "profiles", "r2", "traffic.json")
     try:
         with open(path) as f:
@@ -62,6 +65,62 @@ def offline_traffic(workload: str, kernel_prefix: str):
         if k.startswith(kernel_prefix):
             return v.get("bytes_per_launch")
     return None
+
+
+LIVE_TRAFFIC = {}        # kernel family -> bytes per launch, measured by live_traffic() at the start of this very run
+
+
+def live_traffic(args) -> dict:
+    """HBM traffic of the step's kernels measured NOW: two short copies of this bench under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, counters only, the program itself behind `--`), before this process touches the GPU.  Bytes per
+    launch = 2 x FETCH_SIZE (gfx950: the counter tallies 128-B requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB.
+    Returns {} when the profiler is not there or a pass fails -- the figures of profiles/r2/traffic.json (same sources) are used then."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    tmp = tempfile.mkdtemp(prefix="mpf_traffic_")
+    env = dict(os.environ)
+    env["MPF_BENCH_TRAFFIC_CHILD"] = "1"
+    env.setdefault("TMPDIR", "/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu", "--bootstrap-replicates", "0",
+             "--ufboot-samples", "0", "--random-start-leg", "0", "--workload", args.workload, "--maxtrav", str(args.maxtrav),
+             "--tree-cache", os.path.join(tmp, "tree")]
+    for kv in args.opt:
+        child += ["--opt", kv]
+    acc = {}
+    try:
+        # the start tree first, without the profiler (its ~1500 small dispatches crawl under counter collection); the passes read it
+        r0 = subprocess.run(child + ["--steps", "1", "--warmup", "0"], env=env, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+        if r0.returncode != 0:
+            return {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, env=env, cwd=tmp,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        name = row["Kernel_Name"].replace("void ", "").replace("mpf::", "")
+                        key = name.split("<")[0].split("(")[0]
+                        acc.setdefault(key, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for key, v in acc.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            fetch = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+            write = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+            out[key] = int((2.0 * fetch + write) * 1024)
+    return out
 
 
 def st_kernel_name(eng) -> str:
@@ -373,6 +432,14 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
+    traffic_source = "profiles/r2/traffic.json (rocprofv3 --pmc passes of tools/profile_gpu.sh on the same sources)"
+    if (world == 1 and os.environ.get("MPF_BENCH_DRYRUN") != "1" and os.environ.get("MPF_BENCH_TRAFFIC_CHILD") != "1"
+            and os.environ.get("MPF_BENCH_LIVE_TRAFFIC", "1") != "0"):
+        # before this process makes its first GPU call: the profiler runs are child processes
+        LIVE_TRAFFIC.update(live_traffic(args))
+        if LIVE_TRAFFIC:
+            traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command, run as child processes at the start of this run"
+
     import torch
     import torch.distributed as dist
 
@@ -505,7 +572,7 @@ def main():
         # bytes that MUST come from HBM per launch: every directional vector of the tree once + the candidates' costs
         n_vec = n + 3 * (n - 2)
         compulsory = n_vec * eng.S * eng.Wp * 4 + evals_per_launch * 4
-        traffic = offline_traffic(args.workload, "k_scan") if not args.opt else None
+        traffic = offline_traffic(args.workload, st_kernel_name(eng)) if (LIVE_TRAFFIC or not args.opt) else None
         res = {
             "metric": "Fitch site-ops/sec (taxa x patterns x SPR-evals/s)",
             "value": n * P * evals_per_s,
@@ -537,7 +604,7 @@ def main():
             # CU's registers, >90 % of them from the XCD's L2 (loads-only variant of the kernel: 0.93 of its time,
             # arithmetic-only variant: 0.64 -- profiles/r2/scan_bounds.txt).  achieved = bytes the kernel loads / its time.
             "roofline": {"bound": "l2", "achieved": loaded_gbps, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                         "frac": loaded_gbps / L2_PEAK_GBS, "traffic": traffic,
+                         "frac": loaded_gbps / L2_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
                          "kernel": st_kernel_name(eng), "kernel_ms_per_launch": scan_ms, "evals_per_launch": evals_per_launch,
                          "plan_kernel_ms_per_launch": st["plan_kernel_ms_total"] / max(1, st["plan_launches"]),
                          "loaded_bytes_per_launch": evals_per_launch * eng.S * eng.Wp * 4,
@@ -552,8 +619,8 @@ def main():
                                  "guide's aggregate L2 figure (its measured gathers from L2 reach 16.8-18.8 TB/s).  valu.* = algorithmic "
                                  "lane-ops (2 S chain + 3 S join + 1 popcount + 3 reduction per test and 32-site word) against 256 CUs x 128 "
                                  "lanes x 2.4 GHz.  hbm.*: what must come from HBM per launch (every vector once) -- far from a limit; "
-                                 "traffic = rocprofv3 PMC bytes that left the L2s per launch, offline, quoted only while the sources match "
-                                 "the profiled build.  survey_6vector_GBps is SURVEY 8(d)'s 6-vectors-per-test figure / kernel time: a "
+                                 "traffic = rocprofv3 PMC bytes that left the L2s per launch (2 x FETCH_SIZE + WRITE_SIZE, KB; see "
+                                 "traffic_source; a committed figure is quoted only while the sources match the profiled build).  survey_6vector_GBps is SURVEY 8(d)'s 6-vectors-per-test figure / kernel time: a "
                                  "labelled side number, not a fraction of anything the kernel moves"},
             "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": view_ms,
                       "launches_per_step": st["view_launches"] / args.steps,
@@ -561,7 +628,7 @@ def main():
                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                    "achieved": (st["newview_ops"] / args.steps) * 3 * eng.S * eng.Wp * 4 / (view_ms * 1e-3) / 1e9 if view_ms > 0 else 0.0,
                                    "frac": (st["newview_ops"] / args.steps) * 3 * eng.S * eng.Wp * 4 / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if view_ms > 0 else 0.0,
-                                   "traffic": offline_traffic(args.workload, "k_newview") if not args.opt else None}},
+                                   "traffic": offline_traffic(args.workload, "k_newview") if (LIVE_TRAFFIC or not args.opt) else None}},
             "host_ms_per_step": {"plan": st["host_plan_ms_total"] / args.steps, "views": st["host_views_ms_total"] / args.steps,
                                  "scan": st["host_scan_ms_total"] / args.steps,
                                  "sweep_call": st["host_sweep_ms_total"] / args.steps},
