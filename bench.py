@@ -93,13 +93,13 @@ def live_traffic(args) -> dict:
     acc = {}
     try:
         # the start tree first, without the profiler (its ~1500 small dispatches crawl under counter collection); the passes read it
-        r0 = subprocess.run(child + ["--steps", "1", "--warmup", "0"], env=env, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+        r0 = subprocess.run(child + ["--steps", "1", "--warmup", "0"], env=env, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
         if r0.returncode != 0:
             return {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, env=env, cwd=tmp,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
