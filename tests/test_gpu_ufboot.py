@@ -261,15 +261,23 @@ e.set_option("scan_batch", 4)          # small batches: several exchanges per cl
 e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
 e.seed_ties(engine.TIE_RANDOM, 19)
 e.ufboot_attach(samples, 0.5, shard=(rank, ws))
+rule = os.environ.get("MPF_RULE", "default")
+if rule == "topboot":
+    e.ufboot_set_mulhits(True); e.ufboot_set_topboot(3)
+if rule == "distinct":
+    e.ufboot_set_distinct_iter(2); e.ufboot_set_iteration(1)
 s = e.optimize_spr(1, 6)
 cut = e.ufboot_next_cutoff(10)
 e.ufboot_set_cutoff(cut)
+if rule == "distinct":
+    e.ufboot_set_iteration(2)
 e.set_tree(np.array(fx["trees"][5]["back"], dtype=np.int32))
 s2 = e.optimize_spr(1, 6)
 logl, cnt, tr = e.ufboot_state()
 res = {"s": [s, s2], "moves": [x.tolist() for x in e.moves()], "logl": logl.tolist(), "cnt": cnt.tolist(), "tr": tr.tolist(),
        "saved": e.ufboot_tree_logl().tolist(), "draws": e.ufboot_counters()["tie_draws"],
-       "trees": {str(t): e.ufboot_tree(int(t)).tolist() for t in sorted(set(tr.tolist()))}}
+       "trees": {str(t): e.ufboot_tree(int(t)).tolist() for t in sorted(set(tr.tolist())) if t >= 0},
+       "tops": [list(map(list, e.ufboot_sample_top(b)[0])) + [e.ufboot_sample_top(b)[1]] for b in range(len(samples))] if rule != "default" else []}
 allr = [None] * ws
 dist.all_gather_object(allr, res)
 if rank == 0:
@@ -279,8 +287,9 @@ dist.destroy_process_group()
 '''
 
 
+@pytest.mark.parametrize("rule", ["default", "topboot", "distinct"])
 @pytest.mark.parametrize("name", ["dna_ambig", "aa"])
-def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, name):
+def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, name, rule):
     """two ranks (sharing this GPU) hold half of the samples each and exchange their events per batch: every rank must
     end with the state of the single-engine run -- scores, moves, saved trees, boot arrays, topologies, draw count"""
     import json
@@ -298,8 +307,16 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
     e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
     e.seed_ties(engine.TIE_RANDOM, 19)
     e.ufboot_attach(samples)
+    if rule == "topboot":
+        e.ufboot_set_mulhits(True)
+        e.ufboot_set_topboot(3)
+    if rule == "distinct":
+        e.ufboot_set_distinct_iter(2)
+        e.ufboot_set_iteration(1)
     s = e.optimize_spr(1, 6)
     e.ufboot_set_cutoff(e.ufboot_next_cutoff(10))
+    if rule == "distinct":
+        e.ufboot_set_iteration(2)
     e.set_tree(np.array(fx["trees"][5]["back"], dtype=np.int32))
     s2 = e.optimize_spr(1, 6)
     logl, cnt, tr = e.ufboot_state()
@@ -308,7 +325,7 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MPF_ROOT=ROOT, MPF_FX=name)
+    env = dict(os.environ, MPF_ROOT=ROOT, MPF_FX=name, MPF_RULE=rule)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -320,6 +337,9 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
     assert got["draws"] == e.ufboot_counters()["tie_draws"]
     for t, back in got["trees"].items():
         assert back == e.ufboot_tree(int(t)).tolist()
+    if rule != "default":
+        want = [list(map(list, e.ufboot_sample_top(b)[0])) + [e.ufboot_sample_top(b)[1]] for b in range(len(samples))]
+        assert got["tops"] == want
 
 
 def test_unsupported_configurations_fail_loudly(mods):
