@@ -55,6 +55,24 @@ def test_random_call_sequences_weighted(seed):
     run_sequence(c, seed, 10, cost=cost)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_call_sequences_weighted_medium_trees(seed):
+    """the weighted engine on 50-120 taxa: host-planned scans in several batches, the tracker's bit planes over many rows"""
+    from mpboot_amd import synth, trees
+
+    rng = np.random.default_rng(888 + seed + STATE_OFFSET)
+    n, P = int(rng.integers(50, 121)), int(rng.integers(150, 400))
+    aa = seed % 2 == 1
+    letters, _ = synth.synth_alignment(n, P, "AA" if aa else "DNA", float(rng.uniform(0.04, 0.12)), seed=seed + STATE_OFFSET)
+    codes = synth.letters_to_codes(letters, "AA" if aa else "DNA").copy()
+    w = rng.integers(1, 3, size=P).astype(np.int32)
+    S = 20 if aa else 4
+    m = rng.integers(1, 6, size=(S, S))
+    cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    c = dict(aa=aa, n=n, P=P, codes=codes, w=w, back=trees.random_topology(n, rng), maxtrav=int(rng.integers(2, 5)))
+    run_sequence(c, seed, 7, cost=cost)
+
+
 def run_sequence(c, seed, n_steps, cost=None):
     from mpboot_amd import engine, trees
     from oracle import pyoracle as po
