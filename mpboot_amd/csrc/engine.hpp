@@ -182,6 +182,7 @@ struct UfbState {
   DevBuf<int32_t> d_first, d_cur;                // per pattern: first expanded site / weight of the packing in force
   DevBuf<int32_t> d_col;                         // one column of C, contiguous
   PinBuf<int32_t> h_col;
+  PinBuf<int32_t> h_rt;                          // host copy of R_T (the current tree's own bookings are walked on the host)
 };
 
 class Engine {

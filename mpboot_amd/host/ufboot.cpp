@@ -540,6 +540,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
   const bool ratchet = u.ratchet;
+  const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the events are exchanged anyway)
   const int oc = u.Bl;                             // the column of the original pattern frequencies
   auto read_rt_orig = [&]() -> int {
     UCHK(u.h_col.reserve(4));
@@ -674,7 +675,11 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
         const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
         const uint32_t *d_crow = compact ? u.thr.p + o_crow : nullptr, *d_sel = compact ? u.thr.p + o_sel : nullptr;
-        UCHK(launch_ufb_self(st_, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(), self_pass ? 0xFFFFFFFEu : 0xFFFFFFFFu));
+        UCHK(launch_ufb_self(st_, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(), (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu));
+        if (host_self && self_pass) {                  // R_T for the host's own walk over the current tree's bookings
+          UCHK(u.h_rt.reserve((size_t)u.Bp));
+          UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));   // synchronised with the event count below
+        }
         if (timing_) UCHK(hipEventRecord(ev2_, st_));
         if (n_rows > 0) {
           for (int pl = 0; pl < u.planes; pl++)
@@ -781,16 +786,15 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           canonical_topology(mh_bk, mh_key);
           return u.topo_index.emplace(mh_key, tree_index).first->second;
         };
-        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
-          while (ep < events.size() && events[ep].idx < idx) ep++;
-          bool looked_up = false;
-          for (; ep < events.size() && events[ep].idx == idx; ep++) {
-            const uint32_t b = events[ep].b, s = events[ep].s;
+        // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
+        // current tree's own bookings, which the host walks through itself
+        auto one_event = [&](const uint32_t b, const uint32_t s, int64_t &tree_index, bool &looked_up, const uint32_t cand_code) {
+            
             uint32_t &bs = u.boot_score[b];
             if (u.distinct && !u.mulhits) {
               if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return lookup_topology(ti, cand_code); }) &&
                   (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              continue;
+              return;
             }
             if (u.mulhits && u.topboot) {
               // iqtree.cpp:3542-3585: the sample's list is not full yet, or the tree beats its threshold
@@ -801,11 +805,11 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
                 if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
                     (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               }
-              continue;
+              return;
             }
             if (u.mulhits) {
               // iqtree.cpp:3498-3540: rell >= boot_logl (an event is exactly that); no draw, boot_counts untouched
-              if (s > bs) continue;
+              if (s > bs) return;
               if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }       // :3500-3514
               std::set<int64_t> &hs = u.hit_sets[b];
               if (s < bs) {                                               // :3516-3519
@@ -817,7 +821,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
                 u.refs[(size_t)tree_index]++;
                 if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               }
-              continue;
+              return;
             }
             bool accept = false;
             if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (:3686)
@@ -839,7 +843,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               }
             }
             if (s == bs) u.boot_counts[b]++;                              // :3728-3730
-          }
+          };
+        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
+          while (ep < events.size() && events[ep].idx < idx) ep++;
+          bool looked_up = false;
+          for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, looked_up, cand_code);
+        };
+        // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
+        // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
+        auto replay_self = [&](int64_t tree_index) {
+          bool looked_up = false;
+          for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
         };
         if (pl.self_idx >= 0) {
           // rearrangeParsimony's evaluateParsimony(p) + pllSaveCurrentTreeSprParsimony (sprparsimony.cpp:2285-2289): the
@@ -854,7 +868,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             const int64_t tree_index = (int64_t)u.treels.size();
             u.treels.push_back(ratchet ? u.stale_len : randomMP);
             u.refs.push_back(0);
-            replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
+            if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
             if (ratchet) u.stale_len = u.rt_orig;        // _pattern_pars now holds the current tree
           }
         }
@@ -977,6 +991,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
   std::vector<int32_t> mh_bk, lcol;
   std::string mh_key;
   const bool ratchet = u.ratchet;
+  const bool host_self = true;
   const int oc = u.Bl;
   if (ratchet) u.gate_closed = false;
   bool stale_init = false;                         // ratchet: _pattern_pars of the climb's start tree, known after the first product
@@ -1040,6 +1055,8 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         u.gemm_rows += (uint64_t)rows_p * (uint64_t)K;
         UCHK(u.rt.reserve((size_t)u.Bp));
         UCHK(launch_colsum(st_, u.C.p + (size_t)R * u.Bp, 1, u.Bp, u.rt.p));       // R_T = the current tree's own row
+        UCHK(u.h_rt.reserve((size_t)u.Bp));
+        UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));    // synchronised below
         have_C = true;
         // ---- per output index: (row, part) for candidates of plans [0, jstar], the current tree's slots, everything else off
         uint32_t n_parts = 0;
@@ -1047,7 +1064,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         const bool self_pass = ratchet || randomMP <= mp_max;
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
-          if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = make_uint2(0u, self_pass ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+          if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = make_uint2(0u, (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
           for (const Candidate &cd : pl.cands) hinfo[cd.out] = make_uint2(cd.out, (uint32_t)j);
           n_parts = (uint32_t)j + 1u;
         }
@@ -1128,16 +1145,15 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           canonical_topology(mh_bk, mh_key);
           return u.topo_index.emplace(mh_key, tree_index).first->second;
         };
-        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
-          while (ep < events.size() && events[ep].idx < idx) ep++;
-          bool looked_up = false;
-          for (; ep < events.size() && events[ep].idx == idx; ep++) {
-            const uint32_t b = events[ep].b, s = events[ep].s;
+        // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
+        // current tree's own bookings, which the host walks through itself
+        auto one_event = [&](const uint32_t b, const uint32_t s, int64_t &tree_index, bool &looked_up, const uint32_t cand_code) {
+            
             uint32_t &bs = u.boot_score[b];
             if (u.distinct && !u.mulhits) {
               if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return cand_topology_key(cand_code, ti); }) &&
                   (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              continue;
+              return;
             }
             if (u.mulhits && u.topboot) {
               const int32_t rell = -(int32_t)s;
@@ -1147,10 +1163,10 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
                 if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
                     (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               }
-              continue;
+              return;
             }
             if (u.mulhits) {
-              if (s > bs) continue;
+              if (s > bs) return;
               if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
               std::set<int64_t> &hs = u.hit_sets[b];
               if (s < bs) {
@@ -1162,7 +1178,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
                 u.refs[(size_t)tree_index]++;
                 if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               }
-              continue;
+              return;
             }
             bool accept = false;
             if (s < bs) accept = true;
@@ -1182,7 +1198,17 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
               }
             }
             if (s == bs) u.boot_counts[b]++;
-          }
+          };
+        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
+          while (ep < events.size() && events[ep].idx < idx) ep++;
+          bool looked_up = false;
+          for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, looked_up, cand_code);
+        };
+        // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
+        // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
+        auto replay_self = [&](int64_t tree_index) {
+          bool looked_up = false;
+          for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
         };
         if (pl.self_idx >= 0) {
           bool book;
@@ -1195,7 +1221,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
             const int64_t tree_index = (int64_t)u.treels.size();
             u.treels.push_back(ratchet ? u.stale_len : randomMP);
             u.refs.push_back(0);
-            replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
+            if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
             if (ratchet) u.stale_len = u.rt_orig;
           }
         }
