@@ -497,7 +497,7 @@ void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
 static void sort_events(std::vector<UfbEvent> &ev, std::vector<UfbEvent> &tmp, std::vector<uint32_t> &count, uint32_t n_idx, uint32_t n_samples)
 {
   const size_t n = ev.size();
-  if (n < 8192) {
+  if (n < 512) {
     std::sort(ev.begin(), ev.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
     return;
   }
@@ -718,7 +718,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         t1 = now_ms();
         u.t_dev += t1 - t0;
         if (ratchet && have_C) lcol.assign(u.h_col.p, u.h_col.p + n_rows);
-        const bool fused_sort = !u.exchange && n_ev >= 8192;
+        const bool fused_sort = !u.exchange && n_ev >= 512;
         if (fused_sort) {
           // straight from the pinned copy: local column -> sample of the run, ordered by sample (first counting pass)
           events.resize(n_ev);
