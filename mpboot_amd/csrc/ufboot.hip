@@ -568,11 +568,13 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
   if (n_idx == 0) return hipSuccess;
   const uint32_t nc = ufb_chunks(n_idx);
   dim3 grid((Bp + 255) / 256, nc), block(256);
-  if (!fixed_bound) {
+  // a single chunk (the small batches inside a climb): its running minimum starts at best[] itself, no prefix pass
+  const bool prefix = !fixed_bound && nc > 1;
+  if (prefix) {
     hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, rt, n_idx, cmin);
     hipLaunchKernelGGL(k_ufb_prefix, dim3((Bp + 255) / 256), block, 0, st, cmin, best, Bp, nc, pre);
   }
-  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, pre, ev, ev_cap, ev_count,
+  hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, prefix ? pre : best, ev, ev_cap, ev_count,
                      fixed_bound ? best : (const uint32_t *)nullptr);
   return hipGetLastError();
 }

@@ -600,7 +600,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           n_parts = std::max(n_parts, (uint32_t)pl.part_desc[pi] + 1u);
         }
       }
-      uint32_t n_ev = 0;
+      uint32_t n_ev = 0, n_eager = 0;
       t0 = now_ms();
       u.t_prep += t0 - t1;
       // with a cut-off only the saved candidates (and the home rows of their parts) are multiplied: this lists their
@@ -700,6 +700,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
                                  u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct) ? 1 : 0));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+          // the first few thousand events ride along with their count: the batches of a climb need no second round trip
+          n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);
+          UCHK(u.h_ev.reserve((size_t)n_eager));
+          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_eager * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
           n_ev = u.h_small.p[0];
           if (n_ev <= u.ev.cap) break;
@@ -710,9 +714,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           float ms = 0;
           if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
         }
-        if (n_ev) {
+        if (n_ev > n_eager) {
+          if (u.h_ev.cap < (size_t)n_ev) n_eager = 0;       // (a grown pinned buffer starts empty)
           UCHK(u.h_ev.reserve((size_t)n_ev));
-          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
+          UCHK(hipMemcpyAsync(u.h_ev.p + n_eager, u.ev.p + n_eager, (size_t)(n_ev - n_eager) * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
         }
         t1 = now_ms();
@@ -1093,12 +1098,15 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           UCHK(launch_ufb_column(st_, u.C.p, u.Bp, oc, rows, u.d_col.p));
           UCHK(hipMemcpyAsync(u.h_col.p, u.d_col.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
         }
-        uint32_t n_ev = 0;
+        uint32_t n_ev = 0, n_eager = 0;
         while (n_idx) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
                                  u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct) ? 1 : 0));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+          n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);     // (as in spr_sweeps_ufboot: one round trip for a small batch)
+          UCHK(u.h_ev.reserve((size_t)n_eager));
+          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_eager * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
           n_ev = u.h_small.p[0];
           if (n_ev <= u.ev.cap) break;
@@ -1110,9 +1118,10 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           float ms = 0;
           if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
         }
-        if (n_ev) {
+        if (n_ev > n_eager) {
+          if (u.h_ev.cap < (size_t)n_ev) n_eager = 0;
           UCHK(u.h_ev.reserve((size_t)n_ev));
-          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
+          UCHK(hipMemcpyAsync(u.h_ev.p + n_eager, u.ev.p + n_eager, (size_t)(n_ev - n_eager) * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
         }
         events.assign(u.h_ev.p, u.h_ev.p + n_ev);
