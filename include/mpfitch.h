@@ -257,6 +257,15 @@ int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on);
    random draws, boot_counts / boot_trees stay untouched.  Call right after the attach, before any tree is booked.
    (-topboot and -distinct_iter_top_boot: below.) */
 int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on);
+/* params->store_candidate_trees (-storetrees; off by default, tools.cpp:736): iqtree.cpp:3302-3346 -- every tree that reaches
+   saveCurrentTree is looked up by topology (printTree(WT_TAXON_ID | WT_SORT_TAXA) as the key) BEFORE the cut-off test.  One
+   met before counts as a duplicate (duplication_counter, mpf_ufboot_get_duplicates) and is skipped, unless its length
+   improved on the recorded treels_logl entry (this happens on ratchet climbs, whose lengths come from _pattern_pars as it
+   stands): then the entry is updated and the tree goes through the update rule under its OLD index, without the cut-off
+   test.  Combines with every update rule.  Costs one canonical form per insertion test on the host (the reference prints,
+   re-reads and prints the tree per test).  Call right after the attach, before any tree is booked. */
+int mpf_ufboot_set_store_trees(mpf_engine *e, int32_t on);
+int mpf_ufboot_get_duplicates(const mpf_engine *e, uint64_t *n);
 /* params->store_top_boot_trees (-topboot N, together with -mulhits): the rule of iqtree.cpp:3542-3585 -- per sample the N best
    NEW trees (a tree whose topology was booked before is never added), best first, with boot_threshold behaving as in the
    reference (-INT_MAX until the first replacement in a full list).  After mpf_ufboot_set_mulhits(e, 1), before any tree is

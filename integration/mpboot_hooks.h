@@ -35,6 +35,7 @@ struct mpf_mpboot_hooks {
   // globalParam->multiple_hits (-mulhits, iqtree.cpp:3498-3540): 1 = every tree that reaches a sample's best REPS joins its
   // boot_trees_parsimony set (mpf_ufboot_set_mulhits; read back with mpf_ufboot_get_sample_trees in ufboot_sync).  The
   int multiple_hits;
+  int store_candidate_trees;                      // globalParam->store_candidate_trees (-storetrees, iqtree.cpp:3302-3346): mpf_ufboot_set_store_trees
   int distinct_iter_top_boot;                     // globalParam->distinct_iter_top_boot (iqtree.cpp:3587-3680; without -mulhits)
   int (*cur_iteration)(IQTree *);                 // iqtree->curIt, read before every pllOptimizeSprParsimony (needed by that rule only)
   int store_top_boot_trees;                       // globalParam->store_top_boot_trees (-topboot N, with -mulhits): mpf_ufboot_set_topboot

@@ -243,6 +243,8 @@ int mpf_ufboot_detach(mpf_engine *e) { NEED(e); e->eng.ufboot_detach(); return M
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff) { NEED(e); return e->eng.ufboot_set_cutoff(logl_cutoff); }
 int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_ratchet_booking(on); }
 int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_mulhits(on); }
+int mpf_ufboot_set_store_trees(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_store_trees(on); }
+int mpf_ufboot_get_duplicates(const mpf_engine *e, uint64_t *n) { NEED(e); return e->eng.ufboot_duplicates(n); }
 int mpf_ufboot_set_topboot(mpf_engine *e, int32_t n_top) { NEED(e); return e->eng.ufboot_set_topboot(n_top); }
 int mpf_ufboot_get_sample_top(const mpf_engine *e, int32_t sample, int64_t *trees, int32_t *rell, int32_t cap, int32_t *n, int32_t *threshold)
 {

@@ -164,6 +164,10 @@ struct UfbState {
   // -mulhits (params->multiple_hits, iqtree.cpp:3498-3540): per sample the SET of trees that reach its best REPS; trees of
   // one topology share the index of the first of them that hit (the reference's treels string map); no draws
   bool mulhits = false;
+  // -storetrees (params->store_candidate_trees, iqtree.cpp:3302-3346): every tree that reaches saveCurrentTree is looked up in
+  // topo_index first; one met before is not booked again unless its length improved on treels[index]
+  bool store_trees = false;
+  uint64_t duplicates = 0;                       // duplication_counter
   std::unordered_map<std::string, int64_t> topo_index;       // canonical topology -> tree index
   std::vector<std::set<int64_t>> hit_sets;                   // boot_trees_parsimony
   // -mulhits -topboot N (params->store_top_boot_trees, iqtree.cpp:3542-3585): per sample the N best NEW trees, best first, and
@@ -251,6 +255,8 @@ class Engine {
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
   int ufboot_set_mulhits(int on);
+  int ufboot_set_store_trees(int on);
+  int ufboot_duplicates(uint64_t *n) const;
   int ufboot_set_topboot(int n_top);
   int ufboot_set_distinct_iter(int k);
   int ufboot_set_iteration(int cur_it);

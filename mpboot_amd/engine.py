@@ -25,7 +25,7 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
-    "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
+    "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
@@ -117,6 +117,8 @@ def load_library():
         L.mpf_ufboot_set_cutoff.argtypes = [vp, C.c_double]
         L.mpf_ufboot_set_ratchet_booking.argtypes = [vp, C.c_int32]
         L.mpf_ufboot_set_mulhits.argtypes = [vp, C.c_int32]
+        L.mpf_ufboot_set_store_trees.argtypes = [vp, C.c_int32]
+        L.mpf_ufboot_get_duplicates.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.mpf_ufboot_get_sample_trees.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
         L.mpf_ufboot_set_distinct_iter.argtypes = [vp, C.c_int32]
         L.mpf_ufboot_set_iteration.argtypes = [vp, C.c_int32]
@@ -419,6 +421,16 @@ class FitchEngine:
     def ufboot_set_ratchet_booking(self, on: bool):
         """False = mpboot's -no_hclimb1_bb: climbs under other weights than the attach-time ones are not booked"""
         _chk(load_library().mpf_ufboot_set_ratchet_booking(self.h, 1 if on else 0))
+
+    def ufboot_set_store_trees(self, on: bool):
+        """params->store_candidate_trees (-storetrees, iqtree.cpp:3302-3346); right after the attach"""
+        _chk(load_library().mpf_ufboot_set_store_trees(self.h, 1 if on else 0))
+
+    def ufboot_duplicates(self) -> int:
+        """duplication_counter: trees that reached saveCurrentTree with a topology booked before (-storetrees)"""
+        n = C.c_uint64()
+        _chk(load_library().mpf_ufboot_get_duplicates(self.h, C.byref(n)))
+        return int(n.value)
 
     def ufboot_set_mulhits(self, on: bool):
         """params->multiple_hits: the -mulhits update rule (iqtree.cpp:3498-3540); right after the attach"""

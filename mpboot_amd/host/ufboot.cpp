@@ -165,6 +165,21 @@ int Engine::ufboot_set_mulhits(int on)
   return MPF_OK;
 }
 
+// params->store_candidate_trees (-storetrees, iqtree.cpp:3302-3346).  Right after the attach.
+int Engine::ufboot_set_store_trees(int on)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  if (!ufb_->treels.empty()) { set_error("ufboot_set_store_trees: trees have been booked without the topology map already"); return MPF_E_STATE; }
+  ufb_->store_trees = on != 0;
+  return MPF_OK;
+}
+int Engine::ufboot_duplicates(uint64_t *n) const
+{
+  if (!ufb_) return MPF_E_STATE;
+  if (n) *n = ufb_->duplicates;
+  return MPF_OK;
+}
+
 // params->store_top_boot_trees (-topboot N, with -mulhits): the rule of iqtree.cpp:3542-3585.  After mpf_ufboot_set_mulhits(1),
 // before the first booked tree.
 int Engine::ufboot_set_topboot(int n_top)
@@ -540,6 +555,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   uint32_t exchange_tag = 0;
   if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
   const bool ratchet = u.ratchet;
+  const bool store_trees = u.store_trees;          // -storetrees (iqtree.cpp:3302-3346)
   const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the events are exchanged anyway)
   const int oc = u.Bl;                             // the column of the original pattern frequencies
   auto read_rt_orig = [&]() -> int {
@@ -608,8 +624,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       const uint2 *hinfo = u.h_info.p;
       // (re-weighted climbs are filtered by the length booked last, not by the candidate's own: every row is multiplied,
       //  until a booked tree fails the cut-off -- from then on nothing of this climb is booked)
-      const bool skip_product = ratchet ? (u.gate_closed || none_pass || (have_cut && u.stale_len > mp_max)) : none_pass;
-      const bool compact = have_cut && !none_pass && !ratchet;
+      // (-storetrees: a topology met before is booked again when its length improved, whatever the cut-off says -- every row
+      //  is multiplied and the replay decides)
+      const bool skip_product = store_trees ? false : ratchet ? (u.gate_closed || none_pass || (have_cut && u.stale_len > mp_max)) : none_pass;
+      const bool compact = have_cut && !none_pass && !ratchet && !store_trees;
       uint32_t n_rows = n_idx;
       if (compact) {
         sel_rows.clear();
@@ -640,7 +658,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       bool ran_events = false;
       // the current tree is booked in front of every prune node's candidates (sprparsimony.cpp:2285-2289) with its own
       // length (= randomMP): it takes part unless that length fails the cut-off (ratchet climbs: decided in the replay)
-      const bool self_pass = !self_list.empty() && !skip_product && (ratchet || randomMP <= mp_max);
+      const bool self_pass = !self_list.empty() && !skip_product && (ratchet || store_trees || randomMP <= mp_max);
       if (n_idx > 0 && !skip_product && (n_rows > 0 || self_pass)) {
         const int rows_p = round_up((int)std::max<uint32_t>(n_rows, 1u), kUfbRowTile);
         // (a batch whose prune nodes have no insertion test at all -- a five-taxon tree at radius 1 -- still books the current
@@ -655,7 +673,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           const ScanPlan &pl = plans[(size_t)j];
           for (int pi = 0; pi < pl.n_parts; pi++) {
             const uint32_t d = (uint32_t)pl.part_desc[pi];
-            small[d] = (!have_cut || ratchet) ? UINT32_MAX : (mp_max >= pl.base ? mp_max - pl.base + 1u : 0u);   // max cost + 1
+            small[d] = (!have_cut || ratchet || store_trees) ? UINT32_MAX : (mp_max >= pl.base ? mp_max - pl.base + 1u : 0u);   // max cost + 1
             small[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
           }
         }
@@ -698,7 +716,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         while (true) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct) ? 1 : 0));
+                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct || store_trees) ? 1 : 0));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           // the first few thousand events ride along with their count: the batches of a climb need no second round trip
           n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);
@@ -782,14 +800,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         // the update rule of one booked tree (iqtree.cpp:3684-3731) over the samples whose events name output index idx
         // treels.find(tree_str) / treels[tree_str] = tree_index (iqtree.cpp:3500-3514, :3689-3707): a topology that some
         // sample accepted before keeps the index of that first tree
-        auto lookup_topology = [&](int64_t tree_index, uint32_t cand_code) -> int64_t {
+        auto topology_key = [&](uint32_t cand_code) -> const std::string & {
           if (cand_code == 0xFFFFFFFFu) {
             if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-            return u.topo_index.emplace(u.self_key, tree_index).first->second;
+            return u.self_key;
           }
           ufb_candidate_topology(cand_code < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, (size_t)cand_code), mh_bk);
           canonical_topology(mh_bk, mh_key);
-          return u.topo_index.emplace(mh_key, tree_index).first->second;
+          return mh_key;
+        };
+        auto lookup_topology = [&](int64_t tree_index, uint32_t cand_code) -> int64_t {
+          return u.topo_index.emplace(topology_key(cand_code), tree_index).first->second;
         };
         // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
         // current tree's own bookings, which the host walks through itself
@@ -851,28 +872,47 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           };
         auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
           while (ep < events.size() && events[ep].idx < idx) ep++;
-          bool looked_up = false;
+          bool looked_up = store_trees;              // (-storetrees: tree_str is set at the top, no lookup per sample)
           for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, looked_up, cand_code);
         };
         // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
         // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
         auto replay_self = [&](int64_t tree_index) {
-          bool looked_up = false;
+          bool looked_up = store_trees;
           for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
+        };
+        // one tree arriving at saveCurrentTree with length cur_len: its index in treels_logl, or -1 when nothing is booked.
+        // Default: the cut-off test, then a new index (iqtree.cpp:3343-3348).  -storetrees: looked up by topology first
+        // (:3302-3341); one met before is skipped unless the length improved on the recorded one, and then it goes on under
+        // its old index without the cut-off test.
+        auto book_tree = [&](uint32_t cur_len, bool passes_cut, uint32_t cand_code) -> int64_t {
+          if (store_trees) {
+            const std::string &key = topology_key(cand_code);
+            auto it = u.topo_index.find(key);
+            if (it != u.topo_index.end()) {
+              u.duplicates++;
+              if (cur_len >= u.treels[(size_t)it->second]) return -1;
+              u.treels[(size_t)it->second] = cur_len;
+              return it->second;
+            }
+            if (!passes_cut) return -1;
+            u.topo_index.emplace(key, (int64_t)u.treels.size());
+          } else if (!passes_cut) return -1;
+          u.treels.push_back(cur_len);
+          u.refs.push_back(0);
+          return (int64_t)u.treels.size() - 1;
         };
         if (pl.self_idx >= 0) {
           // rearrangeParsimony's evaluateParsimony(p) + pllSaveCurrentTreeSprParsimony (sprparsimony.cpp:2285-2289): the
           // current tree, length randomMP, once per prune node and before any of its insertion tests
-          bool book;
-          if (!ratchet) book = !none_pass && randomMP <= mp_max;
+          bool pass;
+          if (!ratchet) pass = !none_pass && randomMP <= mp_max;
           else {
-            book = !u.gate_closed && ran_events && !none_pass && u.stale_len <= mp_max;
-            if (!book) u.gate_closed = true;
+            pass = (store_trees || !u.gate_closed) && ran_events && !none_pass && u.stale_len <= mp_max;
+            if (!pass) u.gate_closed = true;
           }
-          if (book) {
-            const int64_t tree_index = (int64_t)u.treels.size();
-            u.treels.push_back(ratchet ? u.stale_len : randomMP);
-            u.refs.push_back(0);
+          const int64_t tree_index = book_tree(ratchet ? u.stale_len : randomMP, pass, 0xFFFFFFFFu);
+          if (tree_index >= 0) {
             if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
             if (ratchet) u.stale_len = u.rt_orig;        // _pattern_pars now holds the current tree
           }
@@ -883,18 +923,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
             const uint32_t mp = pl.base + out[idx];
             // saveCurrentTree(-mp) (reference sprparsimony.cpp:2163-2166), before the SPR tie rule
-            bool book;
-            if (!ratchet) book = !none_pass && mp <= mp_max;
+            bool pass;
+            if (!ratchet) pass = !none_pass && mp <= mp_max;
             else {
               // iqtree.cpp:3283-3295 then :3343: the filter sees the length booked last; a tree that fails leaves
-              // _pattern_pars as it is, so every later candidate of the climb fails too
-              book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;     // (have_C: a ratchet batch with candidates always has its product)
-              if (!book) u.gate_closed = true;
+              // _pattern_pars as it is, so every later candidate of the climb fails too (-storetrees: unless a known
+              // topology gets in past the cut-off)
+              pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;     // (have_C: a ratchet batch with candidates always has its product)
+              if (!pass) u.gate_closed = true;
             }
-            if (book) {
-              const int64_t tree_index = (int64_t)u.treels.size();          // iqtree.cpp:3345-3348
-              u.treels.push_back(ratchet ? u.stale_len : mp);
-              u.refs.push_back(0);
+            const int64_t tree_index = book_tree(ratchet ? u.stale_len : mp, pass, (uint32_t)c);          // iqtree.cpp:3302-3348
+            if (tree_index >= 0) {
               replay_events(idx, tree_index, (uint32_t)c);
               // pllComputePatternParsimony (:3365) has now refreshed _pattern_pars for THIS candidate: its length on the
               // original alignment is what the next call will see
@@ -996,6 +1035,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
   std::vector<int32_t> mh_bk, lcol;
   std::string mh_key;
   const bool ratchet = u.ratchet;
+  const bool store_trees = u.store_trees;          // -storetrees (iqtree.cpp:3302-3346)
   const bool host_self = true;
   const int oc = u.Bl;
   if (ratchet) u.gate_closed = false;
@@ -1027,7 +1067,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
       const double lim = -u.logl_cutoff + 1e-4;
       const uint32_t mp_max = have_cut ? (lim <= 0.0 ? 0u : (uint32_t)std::ceil(lim) - 1u) : UINT32_MAX;
       const bool none_pass = have_cut && lim <= 0.0;
-      const bool skip_product = ratchet ? (u.gate_closed || none_pass) : none_pass;
+      const bool skip_product = store_trees ? false : ratchet ? (u.gate_closed || none_pass) : none_pass;
       bool have_C = false;
       events.clear();
       if (!skip_product) {
@@ -1066,7 +1106,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         // ---- per output index: (row, part) for candidates of plans [0, jstar], the current tree's slots, everything else off
         uint32_t n_parts = 0;
         hinfo.assign((size_t)n_idx, make_uint2(0u, 0xFFFFFFFFu));
-        const bool self_pass = ratchet || randomMP <= mp_max;
+        const bool self_pass = ratchet || store_trees || randomMP <= mp_max;
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
           if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = make_uint2(0u, (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
@@ -1076,7 +1116,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         // staging: thr[n_parts] | home[n_parts] | best[Bp]
         small.assign((size_t)2 * n_parts + (size_t)u.Bp, 0u);
         for (uint32_t d = 0; d < n_parts; d++) {
-          small[d] = (!have_cut || ratchet) ? UINT32_MAX : mp_max + 1u;            // max cost + 1 (costs are full lengths here)
+          small[d] = (!have_cut || ratchet || store_trees) ? UINT32_MAX : mp_max + 1u;            // max cost + 1 (costs are full lengths here)
           small[n_parts + d] = R;
         }
         for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
@@ -1102,7 +1142,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         while (n_idx) {
           UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct) ? 1 : 0));
+                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct || store_trees) ? 1 : 0));
           UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);     // (as in spr_sweeps_ufboot: one round trip for a small batch)
           UCHK(u.h_ev.reserve((size_t)n_eager));
@@ -1145,14 +1185,17 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           hits_ = 1;
         }
         long sel = -1;
-        auto cand_topology_key = [&](uint32_t cand_code, int64_t tree_index) -> int64_t {
+        auto topology_key = [&](uint32_t cand_code) -> const std::string & {
           if (cand_code == 0xFFFFFFFFu) {
             if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-            return u.topo_index.emplace(u.self_key, tree_index).first->second;
+            return u.self_key;
           }
           ufb_candidate_topology(cand_code < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], pl.cands[(size_t)cand_code].q, mh_bk);
           canonical_topology(mh_bk, mh_key);
-          return u.topo_index.emplace(mh_key, tree_index).first->second;
+          return mh_key;
+        };
+        auto cand_topology_key = [&](uint32_t cand_code, int64_t tree_index) -> int64_t {
+          return u.topo_index.emplace(topology_key(cand_code), tree_index).first->second;
         };
         // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
         // current tree's own bookings, which the host walks through itself
@@ -1210,26 +1253,45 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           };
         auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
           while (ep < events.size() && events[ep].idx < idx) ep++;
-          bool looked_up = false;
+          bool looked_up = store_trees;              // (-storetrees: tree_str is set at the top, no lookup per sample)
           for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, looked_up, cand_code);
         };
         // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
         // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
         auto replay_self = [&](int64_t tree_index) {
-          bool looked_up = false;
+          bool looked_up = store_trees;
           for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
         };
+        // one tree arriving at saveCurrentTree with length cur_len: its index in treels_logl, or -1 when nothing is booked.
+        // Default: the cut-off test, then a new index (iqtree.cpp:3343-3348).  -storetrees: looked up by topology first
+        // (:3302-3341); one met before is skipped unless the length improved on the recorded one, and then it goes on under
+        // its old index without the cut-off test.
+        auto book_tree = [&](uint32_t cur_len, bool passes_cut, uint32_t cand_code) -> int64_t {
+          if (store_trees) {
+            const std::string &key = topology_key(cand_code);
+            auto it = u.topo_index.find(key);
+            if (it != u.topo_index.end()) {
+              u.duplicates++;
+              if (cur_len >= u.treels[(size_t)it->second]) return -1;
+              u.treels[(size_t)it->second] = cur_len;
+              return it->second;
+            }
+            if (!passes_cut) return -1;
+            u.topo_index.emplace(key, (int64_t)u.treels.size());
+          } else if (!passes_cut) return -1;
+          u.treels.push_back(cur_len);
+          u.refs.push_back(0);
+          return (int64_t)u.treels.size() - 1;
+        };
         if (pl.self_idx >= 0) {
-          bool book;
-          if (!ratchet) book = !none_pass && randomMP <= mp_max;
+          bool pass;
+          if (!ratchet) pass = !none_pass && randomMP <= mp_max;
           else {
-            book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;
-            if (!book) u.gate_closed = true;
+            pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
+            if (!pass) u.gate_closed = true;
           }
-          if (book) {
-            const int64_t tree_index = (int64_t)u.treels.size();
-            u.treels.push_back(ratchet ? u.stale_len : randomMP);
-            u.refs.push_back(0);
+          const int64_t tree_index = book_tree(ratchet ? u.stale_len : randomMP, pass, 0xFFFFFFFFu);
+          if (tree_index >= 0) {
             if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
             if (ratchet) u.stale_len = u.rt_orig;
           }
@@ -1237,16 +1299,14 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         for (size_t c = 0; c < pl.cands.size(); c++) {
           const uint32_t idx = pl.cands[c].out;
           const uint32_t mp = out[idx];
-          bool book;
-          if (!ratchet) book = !none_pass && mp <= mp_max;
+          bool pass;
+          if (!ratchet) pass = !none_pass && mp <= mp_max;
           else {
-            book = !u.gate_closed && have_C && !none_pass && u.stale_len <= mp_max;
-            if (!book) u.gate_closed = true;
+            pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
+            if (!pass) u.gate_closed = true;
           }
-          if (book) {
-            const int64_t tree_index = (int64_t)u.treels.size();
-            u.treels.push_back(ratchet ? u.stale_len : mp);
-            u.refs.push_back(0);
+          const int64_t tree_index = book_tree(ratchet ? u.stale_len : mp, pass, (uint32_t)c);
+          if (tree_index >= 0) {
             replay_events(idx, tree_index, (uint32_t)c);
             if (ratchet) u.stale_len = (uint32_t)lcol[(size_t)idx];
           }

@@ -77,6 +77,8 @@ struct orc {
   /* -mulhits (params->multiple_hits, iqtree.cpp:3498-3540): treels (canonical topology -> tree index) and
      boot_trees_parsimony (per sample: the set of tree indices that reach its best REPS) */
   int ufb_mulhits;
+  int ufb_store_trees, ufb_dups;              /* params->store_candidate_trees, duplication_counter */
+  unsigned *ufb_key_hash;
   /* -mulhits -topboot N (params->store_top_boot_trees, iqtree.cpp:3542-3585): per sample the N best NEW trees, sorted by
      decreasing REPS, and boot_threshold */
   int ufb_topboot;
@@ -701,29 +703,56 @@ static void canon_emit(const orc *o, int r, const int *mins, int *out, int *k)
   canon_emit(o, a, mins, out, k);
   canon_emit(o, b, mins, out, k);
 }
-/* treels.find(tree_str) / treels[tree_str] = tree_index (iqtree.cpp:3503-3513) */
-static int ufb_lookup_topology(orc *o, int tree_index)
+/* treels.find(tree_str) / treels[tree_str] = tree_index (iqtree.cpp:3503-3513; with -storetrees :3302-3311, :3346) */
+static int *ufb_topology_key(const orc *o)
 {
-  int len = 2 * o->n - 2, k = 0, i;
+  int len = 2 * o->n - 2, k = 0;
   int *mins = (int *)malloc(sizeof(int) * 3 * (2 * o->n - 1)), *key = (int *)malloc(sizeof(int) * len);
   canon_min(o, o->back[3], mins);
   canon_emit(o, o->back[3], mins, key, &k);
   free(mins);
+  return key;
+}
+static unsigned ufb_key_hash(const orc *o, const int *key)
+{
+  unsigned h = 2166136261u;
+  int i;
+  for (i = 0; i < 2 * o->n - 3; i++) h = (h ^ (unsigned)key[i]) * 16777619u;     /* n - 1 tips + n - 2 inner nodes */
+  return h;
+}
+static int ufb_find_key(const orc *o, const int *key)
+{
+  const unsigned h = ufb_key_hash(o, key);
+  int i;
   for (i = 0; i < o->ufb_nkeys; i++)
-    if (memcmp(o->ufb_keys[i], key, sizeof(int) * (size_t)k) == 0) { free(key); return o->ufb_key_idx[i]; }
+    if (o->ufb_key_hash[i] == h && memcmp(o->ufb_keys[i], key, sizeof(int) * (size_t)(2 * o->n - 3)) == 0) return o->ufb_key_idx[i];
+  return -1;
+}
+static void ufb_add_key(orc *o, int *key, int tree_index)
+{
   if (o->ufb_nkeys == o->ufb_keys_cap) {
     o->ufb_keys_cap = o->ufb_keys_cap ? 2 * o->ufb_keys_cap : 64;
     o->ufb_keys = (int **)realloc(o->ufb_keys, sizeof(int *) * o->ufb_keys_cap);
     o->ufb_key_idx = (int *)realloc(o->ufb_key_idx, sizeof(int) * o->ufb_keys_cap);
+    o->ufb_key_hash = (unsigned *)realloc(o->ufb_key_hash, sizeof(unsigned) * o->ufb_keys_cap);
   }
   o->ufb_keys[o->ufb_nkeys] = key;
+  o->ufb_key_hash[o->ufb_nkeys] = ufb_key_hash(o, key);
   o->ufb_key_idx[o->ufb_nkeys++] = tree_index;
+}
+static int ufb_lookup_topology(orc *o, int tree_index)
+{
+  int *key = ufb_topology_key(o);
+  const int found = ufb_find_key(o, key);
+  if (found >= 0) { free(key); return found; }
+  ufb_add_key(o, key, tree_index);
   return tree_index;
 }
 
 static void ufb_save_current_tree(orc *o, double cur_logl)
 {
-  int tree_index, sample, test_pars, looked_up = 0;
+  int tree_index = -1, sample, test_pars, looked_up = 0;
+  int *key = NULL;
   if (o->ufb_ratchet) {
     /* :3283-3295 "if on_ratchet_hclimb1, update cur_logl": REPS of _pattern_pars -- as the array stands, i.e. still
        holding the tree of the previous call that got past the filter below (or what the IQ-TREE kernel left there for
@@ -732,13 +761,27 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
     for (k = 0; k < o->P; k++) if (o->inf[k]) score += (int)o->ufb_ptn[k] * o->ufb_w0[k];
     cur_logl = -(double)score;
   }
-  if (o->ufb_cutoff != 0.0 && cur_logl <= o->ufb_cutoff - 1e-4) return;     /* :3343 */
-  tree_index = o->ufb_ntrees;                                                /* :3345-3348 */
-  if (o->ufb_ntrees == o->ufb_treels_cap) {
-    o->ufb_treels_cap = o->ufb_treels_cap ? 2 * o->ufb_treels_cap : 1024;
-    o->ufb_treels = (double *)realloc(o->ufb_treels, sizeof(double) * o->ufb_treels_cap);
+  if (o->ufb_store_trees) {
+    /* :3302-3311 -storetrees: every tree that comes here is looked up by its topology first */
+    key = ufb_topology_key(o);
+    tree_index = ufb_find_key(o, key);
+    looked_up = 1;                                                           /* tree_str is set: no lookup further down */
   }
-  o->ufb_treels[o->ufb_ntrees++] = cur_logl;
+  if (tree_index >= 0) {                                                     /* :3313-3341 already in treels */
+    free(key);
+    o->ufb_dups++;
+    if (cur_logl <= o->ufb_treels[tree_index] + 1e-4) return;
+    o->ufb_treels[tree_index] = cur_logl;                                    /* (and on: no cut-off test on this side) */
+  } else {
+    if (o->ufb_cutoff != 0.0 && cur_logl <= o->ufb_cutoff - 1e-4) { free(key); return; }     /* :3343 */
+    tree_index = o->ufb_ntrees;                                              /* :3345-3348 */
+    if (key) ufb_add_key(o, key, tree_index);
+    if (o->ufb_ntrees == o->ufb_treels_cap) {
+      o->ufb_treels_cap = o->ufb_treels_cap ? 2 * o->ufb_treels_cap : 1024;
+      o->ufb_treels = (double *)realloc(o->ufb_treels, sizeof(double) * o->ufb_treels_cap);
+    }
+    o->ufb_treels[o->ufb_ntrees++] = cur_logl;
+  }
   test_pars = orc_pattern_scores(o, o->ufb_ptn);                             /* :3365 */
   if (!o->ufb_ratchet && test_pars != -(int)cur_logl) o->ufb_bad++;          /* :3366-3367 outError (not on ratchet climbs) */
   for (sample = 0; sample < o->ufb_B; sample++) {                            /* :3411 */
@@ -1132,8 +1175,9 @@ void orc_ufboot_detach(orc *o)
   free(o->ufb_store_back); free(o->ufb_store_idx);
   free(o->ufb_w0); o->ufb_w0 = NULL;
   for (i = 0; i < o->ufb_nkeys; i++) free(o->ufb_keys[i]);
-  free(o->ufb_keys); free(o->ufb_key_idx);
-  o->ufb_keys = NULL; o->ufb_key_idx = NULL; o->ufb_nkeys = o->ufb_keys_cap = 0;
+  free(o->ufb_keys); free(o->ufb_key_idx); free(o->ufb_key_hash);
+  o->ufb_keys = NULL; o->ufb_key_idx = NULL; o->ufb_key_hash = NULL; o->ufb_nkeys = o->ufb_keys_cap = 0;
+  o->ufb_store_trees = 0; o->ufb_dups = 0;
   if (o->ufb_set) for (i = 0; i < o->ufb_B; i++) free(o->ufb_set[i]);
   free(o->ufb_set); free(o->ufb_set_n); free(o->ufb_set_cap);
   o->ufb_set = NULL; o->ufb_set_n = o->ufb_set_cap = NULL;
@@ -1175,6 +1219,8 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsi
 }
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff) { o->ufb_cutoff = logl_cutoff; }
 void orc_ufboot_set_ratchet_booking(orc *o, int on) { o->ufb_ratchet_booking = on != 0; }   /* !no_hclimb1_bb; next set_weights */
+void orc_ufboot_set_store_trees(orc *o, int on) { o->ufb_store_trees = on != 0; }          /* params->store_candidate_trees */
+int orc_ufboot_duplicates(const orc *o) { return o->ufb_dups; }
 void orc_ufboot_set_mulhits(orc *o, int on) { o->ufb_mulhits = on != 0; }                  /* params->multiple_hits */
 void orc_ufboot_set_topboot(orc *o, int n_top)                                              /* params->store_top_boot_trees; with -mulhits */
 {

@@ -81,6 +81,8 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples /* [B][P] bo
 void orc_ufboot_detach(orc *o);
 void orc_ufboot_set_cutoff(orc *o, double logl_cutoff);       /* 0 = none (iqtree.cpp:3343) */
 void orc_ufboot_set_ratchet_booking(orc *o, int on);          /* 0 = -no_hclimb1_bb (iqtree.cpp:3280); default 1 */
+void orc_ufboot_set_store_trees(orc *o, int on);              /* 1 = -storetrees (iqtree.cpp:3302-3346): a topology met again is not booked twice */
+int orc_ufboot_duplicates(const orc *o);                      /* duplication_counter */
 void orc_ufboot_set_mulhits(orc *o, int on);                  /* 1 = -mulhits update rule (iqtree.cpp:3498-3540); right after attach */
 void orc_ufboot_set_topboot(orc *o, int n_top);               /* -mulhits -topboot N (iqtree.cpp:3542-3585); after set_mulhits */
 void orc_ufboot_set_distinct_iter(orc *o, int k);             /* -distinct_iter_top_boot k (iqtree.cpp:3587-3680); without -mulhits */

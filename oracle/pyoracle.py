@@ -84,6 +84,9 @@ def lib():
         L.orc_ufboot_set_cutoff.argtypes = [vp, C.c_double]
         L.orc_ufboot_set_ratchet_booking.argtypes = [vp, ci]
         L.orc_ufboot_set_mulhits.argtypes = [vp, ci]
+        L.orc_ufboot_set_store_trees.argtypes = [vp, ci]
+        L.orc_ufboot_duplicates.argtypes = [vp]
+        L.orc_ufboot_duplicates.restype = ci
         L.orc_ufboot_set_topboot.argtypes = [vp, ci]
         L.orc_ufboot_set_distinct_iter.argtypes = [vp, ci]
         L.orc_ufboot_set_iteration.argtypes = [vp, ci]
@@ -264,6 +267,12 @@ class Oracle:
 
     def ufboot_set_ratchet_booking(self, on: bool):
         lib().orc_ufboot_set_ratchet_booking(self.h, 1 if on else 0)
+
+    def ufboot_set_store_trees(self, on: bool):
+        lib().orc_ufboot_set_store_trees(self.h, 1 if on else 0)
+
+    def ufboot_duplicates(self) -> int:
+        return int(lib().orc_ufboot_duplicates(self.h))
 
     def ufboot_set_mulhits(self, on: bool):
         lib().orc_ufboot_set_mulhits(self.h, 1 if on else 0)

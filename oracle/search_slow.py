@@ -76,6 +76,9 @@ class SlowSearch:
             self.ratchet = False
             self.ratchet_booking = True                    # !params->no_hclimb1_bb
             self.mulhits = False                           # params->multiple_hits
+            self.store_trees = False                       # params->store_candidate_trees (-storetrees)
+            self.duplicates = 0                            # duplication_counter
+            self.rebooked = 0                              # ... of which booked again with a better length
             self.treels = {}                               # topology -> tree index (only trees that hit, :3503-3513)
             self.boot_sets = [set() for _ in range(B)]     # boot_trees_parsimony
             self.largest_set = 0
@@ -169,12 +172,27 @@ class SlowSearch:
             return
         if self.ratchet:                                    # iqtree.cpp:3283-3295: from _pattern_pars AS IT STANDS
             cur_logl = -float((self.pattern_pars * self.orig * self.inf).sum())
-        if self.cutoff != 0.0 and cur_logl <= self.cutoff - 1e-4:      # :3343
-            return
-        tree_index = len(self.treels_logl)
-        self.treels_logl.append(cur_logl)
-        self.pattern_pars = self.pattern_lengths(self.back)            # :3365 pllComputePatternParsimony
         looked_up = False
+        known = None
+        if self.store_trees:                                           # :3302-3311 -storetrees: looked up before anything else
+            key = self.splits(self.back)
+            known = self.treels.get(key)
+            looked_up = True
+        if known is not None:                                          # :3313-3341
+            self.duplicates += 1
+            if cur_logl <= self.treels_logl[known] + 1e-4:
+                return
+            self.treels_logl[known] = cur_logl
+            self.rebooked += 1
+            tree_index = known
+        else:
+            if self.cutoff != 0.0 and cur_logl <= self.cutoff - 1e-4:  # :3343
+                return
+            tree_index = len(self.treels_logl)
+            if self.store_trees:
+                self.treels[key] = tree_index                          # :3346
+            self.treels_logl.append(cur_logl)
+        self.pattern_pars = self.pattern_lengths(self.back)            # :3365 pllComputePatternParsimony
         for b in range(self.samples.shape[0]):                         # :3411
             rell = -float((self.pattern_pars * self.samples[b]).sum())
             if self.distinct and not self.mulhits:                     # :3587-3680

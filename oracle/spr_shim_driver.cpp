@@ -164,6 +164,7 @@ int main(int argc, char **argv)
   hooks.ufboot_sync = hk_sync;
   hooks.no_hclimb1_bb = argc > 9 ? std::atoi(argv[9]) : 0;     // mpboot's default books ratchet climbs too (iqtree.cpp:3280)
   hooks.multiple_hits = H.mulhits = argc > 10 ? std::atoi(argv[10]) : 0;   // -mulhits
+  hooks.store_candidate_trees = argc > 11 ? std::atoi(argv[11]) : 0;       // -storetrees
   resetGlobalParamOnNewAln();
   mpfitch_shim_install(&hooks);
   static std::vector<unsigned int> cost;

@@ -163,6 +163,7 @@ def run_sequence(c, seed, n_steps, cost=None):
                 assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()], log
                 assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist(), log
                 assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws(), log
+                assert e.ufboot_duplicates() == o.ufboot_duplicates(), log
                 if mulhits and not toplist:
                     for b in range(5):
                         assert e.ufboot_sample_trees(b) == o.ufboot_sample_trees(b), log
@@ -200,7 +201,10 @@ def run_sequence(c, seed, n_steps, cost=None):
             rule = int(rng.integers(0, 6))              # 0-2 default, 3 -mulhits, 4 -mulhits -topboot, 5 -distinct_iter_top_boot
             mulhits = rule in (3, 4)
             toplist = rule in (4, 5)
+            store = bool(rng.random() < 0.25)           # -storetrees, with any of the rules
             for x in (e, o):
+                if store:
+                    x.ufboot_set_store_trees(True)
                 if mulhits:
                     x.ufboot_set_mulhits(True)
                 if rule == 4:

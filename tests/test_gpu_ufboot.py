@@ -262,6 +262,8 @@ e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
 e.seed_ties(engine.TIE_RANDOM, 19)
 e.ufboot_attach(samples, 0.5, shard=(rank, ws))
 rule = os.environ.get("MPF_RULE", "default")
+if rule == "storetrees":
+    e.ufboot_set_store_trees(True)
 if rule == "topboot":
     e.ufboot_set_mulhits(True); e.ufboot_set_topboot(3)
 if rule == "distinct":
@@ -277,7 +279,8 @@ logl, cnt, tr = e.ufboot_state()
 res = {"s": [s, s2], "moves": [x.tolist() for x in e.moves()], "logl": logl.tolist(), "cnt": cnt.tolist(), "tr": tr.tolist(),
        "saved": e.ufboot_tree_logl().tolist(), "draws": e.ufboot_counters()["tie_draws"],
        "trees": {str(t): e.ufboot_tree(int(t)).tolist() for t in sorted(set(tr.tolist())) if t >= 0},
-       "tops": [list(map(list, e.ufboot_sample_top(b)[0])) + [e.ufboot_sample_top(b)[1]] for b in range(len(samples))] if rule != "default" else []}
+       "tops": [list(map(list, e.ufboot_sample_top(b)[0])) + [e.ufboot_sample_top(b)[1]] for b in range(len(samples))] if rule in ("topboot", "distinct") else [],
+       "dups": e.ufboot_duplicates()}
 allr = [None] * ws
 dist.all_gather_object(allr, res)
 if rank == 0:
@@ -287,7 +290,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("rule", ["default", "topboot", "distinct"])
+@pytest.mark.parametrize("rule", ["default", "topboot", "distinct", "storetrees"])
 @pytest.mark.parametrize("name", ["dna_ambig", "aa"])
 def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, name, rule):
     """two ranks (sharing this GPU) hold half of the samples each and exchange their events per batch: every rank must
@@ -307,6 +310,8 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
     e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
     e.seed_ties(engine.TIE_RANDOM, 19)
     e.ufboot_attach(samples)
+    if rule == "storetrees":
+        e.ufboot_set_store_trees(True)
     if rule == "topboot":
         e.ufboot_set_mulhits(True)
         e.ufboot_set_topboot(3)
@@ -337,7 +342,8 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
     assert got["draws"] == e.ufboot_counters()["tie_draws"]
     for t, back in got["trees"].items():
         assert back == e.ufboot_tree(int(t)).tolist()
-    if rule != "default":
+    assert got["dups"] == e.ufboot_duplicates()
+    if rule in ("topboot", "distinct"):
         want = [list(map(list, e.ufboot_sample_top(b)[0])) + [e.ufboot_sample_top(b)[1]] for b in range(len(samples))]
         assert got["tops"] == want
 
@@ -701,3 +707,82 @@ def test_distinct_iter_top_boot_rule_matches_oracle(mods, name, engine_kind, k):
             for x in (e, o):
                 x.ufboot_set_cutoff(float(logl[len(logl) // 3]))
     assert o.ufboot_bad() == 0 and o.ufboot_draws() > 0
+
+
+@pytest.mark.parametrize("rule", ["default", "mulhits", "topboot", "distinct"])
+@pytest.mark.parametrize("engine_kind,opts", [("fitch", {}), ("fitch", {"scan_batch": 5, "split_below": 0}), ("weighted", {})])
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48"])
+def test_storetrees_matches_oracle(mods, name, engine_kind, opts, rule):
+    """-storetrees (params->store_candidate_trees, iqtree.cpp:3302-3346) under every update rule, on both engines: a normal
+    climb, a ratchet climb, then two climbs under a cut-off.  A topology met again is a duplicate (same count as the
+    oracle's duplication_counter); on the ratchet climb some are booked again under their old index with an improved
+    length, past the cut-off test.  Every observable == the oracle's."""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    kw = {}
+    if engine_kind == "weighted":
+        S = 4 if fx["datatype"] == 0 else 20
+        m = np.random.default_rng(3).integers(1, 6, size=(S, S))
+        kw["cost"] = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    samples = boot_samples(len(w0), 20, 13, fx["weights"])
+    rng = np.random.default_rng(21)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"], **kw)
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"], **kw)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (2, 5, 7, 3)]
+    for x in (e, o):
+        x.seed_ties(1, 23)
+        x.ufboot_attach(samples)
+        x.ufboot_set_store_trees(True)
+        if rule in ("mulhits", "topboot"):
+            x.ufboot_set_mulhits(True)
+        if rule == "topboot":
+            x.ufboot_set_topboot(3)
+        if rule == "distinct":
+            x.ufboot_set_distinct_iter(2)
+    radius = 5 if engine_kind == "weighted" else 6
+    for it, w in enumerate((w0, pert, w0, w0)):
+        for x in (e, o):
+            if rule == "distinct":
+                x.ufboot_set_iteration(it + 1)
+            x.set_weights(w)
+            x.set_tree(t[it])
+        o.trace(True)
+        assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius)
+        assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+        assert (e.get_tree() == o.get_tree()).all()
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert e.ufboot_duplicates() == o.ufboot_duplicates()
+        assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+        for b in range(len(samples)):
+            if rule == "mulhits":
+                assert e.ufboot_sample_trees(b) == o.ufboot_sample_trees(b)
+            if rule in ("topboot", "distinct"):
+                assert e.ufboot_sample_top(b) == o.ufboot_sample_top(b)
+        if rule == "default":
+            for ti in sorted(set(e.ufboot_state()[2].tolist())):
+                if ti >= 0:
+                    assert same_topology(e.ufboot_tree(ti), o.ufboot_tree(ti), fx["n"])
+        if it == 1:
+            logl = np.sort(o.ufboot_tree_logl())
+            for x in (e, o):
+                x.ufboot_set_cutoff(float(logl[len(logl) // 2]))
+    assert o.ufboot_bad() == 0
+    assert o.ufboot_duplicates() > 0
+
+
+def test_storetrees_must_be_chosen_before_the_first_booking(mods):
+    engine, _ = mods
+    fx = load_fixture("dna_clean")
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    with pytest.raises(engine.MpfError):
+        e.ufboot_set_store_trees(True)                           # no tracker
+    e.ufboot_attach(boot_samples(len(fx["weights"]), 4, 1, fx["weights"]))
+    e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    e.optimize_spr(1, 3)
+    with pytest.raises(engine.MpfError):
+        e.ufboot_set_store_trees(True)                           # trees already booked without the map

@@ -190,3 +190,56 @@ def test_distinct_iter_top_boot_rule(name, seed, k):
             assert o.ufboot_sample_iters(b) == s.boot_top_iter[b]
             assert 1 <= len(top) <= k
     assert s.ufb_draws > 0
+
+
+@pytest.mark.parametrize("rule", ["default", "mulhits", "topboot", "distinct"])
+@pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9), ("dna_ambig", 4)])
+def test_storetrees_books_a_topology_once(name, seed, rule):
+    """-storetrees (iqtree.cpp:3302-3346): every tree that reaches saveCurrentTree is looked up by topology before the cut-off;
+    one met before is skipped unless its length improved on the recorded one (possible on ratchet climbs, whose lengths
+    come from _pattern_pars as it stands), and then it is booked again under its old index without the cut-off test"""
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(seed)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=5).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 3, 5, 2)]
+    o, s = both(fx, seed, samples)
+    o.ufboot_set_store_trees(True)
+    s.store_trees = True
+    if rule in ("mulhits", "topboot"):
+        o.ufboot_set_mulhits(True)
+        s.mulhits = True
+    if rule == "topboot":
+        o.ufboot_set_topboot(3)
+        s.topboot = 3
+    if rule == "distinct":
+        o.ufboot_set_distinct_iter(2)
+        s.distinct = 2
+    for it, w in enumerate((w0, pert, w0, w0)):
+        if rule == "distinct":
+            o.ufboot_set_iteration(it + 1)
+            s.cur_it = it + 1
+        if it == 2:
+            c = float(np.sort(o.ufboot_tree_logl())[int(0.5 * len(s.treels_logl))])
+            o.ufboot_set_cutoff(c)
+            s.cutoff = c
+        for x in (o, s):
+            x.set_weights(w)
+            x.set_tree(t[it])
+        assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+        assert o.get_tree().tolist() == s.back
+        assert o.ufboot_tree_logl().tolist() == s.treels_logl
+        assert o.ufboot_duplicates() == s.duplicates
+        logl, counts, trees = o.ufboot_state()
+        assert [-LONG_MAX if v <= -LONG_MAX / 2 else v for v in logl.tolist()] == s.boot_logl
+        if rule == "default":
+            assert counts.tolist() == s.boot_counts and trees.tolist() == s.boot_trees
+        if rule == "mulhits":
+            assert [o.ufboot_sample_trees(b) for b in range(len(samples))] == [sorted(x) for x in s.boot_sets]
+        if rule in ("topboot", "distinct"):
+            assert [o.ufboot_sample_top(b)[0] for b in range(len(samples))] == s.boot_top
+        assert o.ufboot_draws() == s.ufb_draws
+    print("duplicates", s.duplicates, "booked again", s.rebooked, "of", len(s.treels_logl), "trees")
+    assert s.duplicates > 0
+    assert len(s.treels) == len(s.treels_logl)              # one index per topology
