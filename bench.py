@@ -433,8 +433,11 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     traffic_source = "profiles/r2/traffic.json (rocprofv3 --pmc passes of tools/profile_gpu.sh on the same sources)"
+    # (under a profiler this process may hold the GPU already -- the counter tool initialises it before main() -- and must not
+    #  start programs any more: the committed figures are quoted then)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
     if (world == 1 and os.environ.get("MPF_BENCH_DRYRUN") != "1" and os.environ.get("MPF_BENCH_TRAFFIC_CHILD") != "1"
-            and os.environ.get("MPF_BENCH_LIVE_TRAFFIC", "1") != "0"):
+            and os.environ.get("MPF_BENCH_LIVE_TRAFFIC", "1") != "0" and not profiled):
         # before this process makes its first GPU call: the profiler runs are child processes
         LIVE_TRAFFIC.update(live_traffic(args))
         if LIVE_TRAFFIC:

@@ -1,4 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/k
-timeout 2400 python -m pytest tests/test_gpu_ufboot.py tests/test_gpu_stateful.py tests/test_gpu_dropin.py -x -q > gpurun_out/k/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 30 gpurun_out/k/pytest.log
-for off in 5000 6000; do MPF_FUZZ_OFFSET=$off timeout 600 python -m pytest tests/test_gpu_stateful.py -x -q 2>&1 | tail -n 2; done
+python tools/ufboot_timing.py --workload C3 --samples 1000 --verify 0 --start random --storetrees 2>&1 | cut -c1-400 | tail -5
+python tools/ufboot_timing.py --workload C2 --samples 1000 --verify 2 --start random --storetrees --check 2>&1 | cut -c1-400 | tail -5
+bash tools/profile_gpu.sh r2 > gpurun_out/k/profile.log 2>&1; tail -n 5 gpurun_out/k/profile.log
+python bench.py > gpurun_out/k/bench_default.json 2> gpurun_out/k/bench_default.err; cut -c1-600 gpurun_out/k/bench_default.json

@@ -9,6 +9,7 @@ TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export MPF_BENCH_LIVE_TRAFFIC=0     # bench.py's own counter passes are child processes: not from a process the profiler has given the GPU
 run_leg () {   # name, bench args, counter groups...
   local NAME=$1 ARGS=$2; shift 2
   local D=$OUT/$NAME

@@ -13,6 +13,7 @@ ap.add_argument("--samples", type=int, default=1000)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--start", default="ras")
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--storetrees", action="store_true", help="-storetrees: every tree looked up by topology before it is booked")
 ap.add_argument("--check", action="store_true", help="replay the first climb on the CPU oracle and compare every observable")
 ap.add_argument("--verify", type=int, default=8, help="number of samples whose kept tree is re-scored independently")
 a = ap.parse_args()
@@ -42,13 +43,16 @@ moves_plain = [x.tolist() for x in e.moves()]
 # same climb with the tracker
 e.set_tree(back0); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, a.seed)
 ta = time.perf_counter(); e.ufboot_attach(samples); tb = time.perf_counter()
+if a.storetrees:
+    e.ufboot_set_store_trees(True)
 e.reset_stats()
 t2 = time.perf_counter(); s_ufb = e.optimize_spr(1, 6); t3 = time.perf_counter()
 st = e.stats(); cn = e.ufboot_counters()
 print(f"{a.workload} B={a.samples}: start {s0}; plain climb -> {s_plain} in {t1-t0:.3f}s ({st_plain['insertion_tests']} tests, {st_plain['moves_applied']} moves); "
       f"attach {tb-ta:.2f}s; climb with online UFBoot -> {s_ufb} in {t3-t2:.3f}s ({st['insertion_tests']} tests, {st['moves_applied']} moves, "
       f"scan kernels {st['scan_kernel_ms_total']:.1f} ms, REPS product {cn['reps_kernel_ms']:.1f} ms over {cn['reps_rows']} rows, "
-      f"{cn['events']} events, {cn['tie_draws']} draws, {len(e.ufboot_tree_logl())} saved trees)")
+      f"{cn['events']} events, {cn['tie_draws']} draws, {len(e.ufboot_tree_logl())} saved trees"
+      + (f", {e.ufboot_duplicates()} duplicates" if a.storetrees else "") + ")")
 rows, W = cn["reps_rows"], e.Wp
 if cn["reps_kernel_ms"] > 0:
     ops = 2.0 * rows * (W * 32) * (-(-a.samples // 128) * 128)
@@ -68,6 +72,8 @@ if a.check:
     from oracle import pyoracle as po
     o = po.Oracle(codes, datatype=po.DNA if dt == engine.DNA else po.AA)
     o.set_tree(back0); o.seed_ties(po.TIE_RANDOM, a.seed); o.ufboot_attach(samples); o.trace(True)
+    if a.storetrees:
+        o.ufboot_set_store_trees(True)
     tc0 = time.perf_counter(); so = o.optimize_spr(1, 6); tc1 = time.perf_counter()
     lo, co, to = o.ufboot_state()
     ok = (so == s_ufb and (o.get_tree() == final).all() and lo.tolist() == logl.tolist() and co.tolist() == counts.tolist()
