@@ -174,3 +174,79 @@ def test_64_bit_addressing_path_of_the_scan_kernel(name):
         x.ufboot_attach(samples)
     assert e.optimize_spr(1, 8) == o.optimize_spr(1, 8)                  # masks + deep walk on the same path
     assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()]
+
+
+def _ladder(trees, n):
+    """unrooted ladder ((((t1,t2),t3),t4) ..., t_{n-1}, t_n): the deepest tree on n taxa"""
+    import sys
+    sys.setrecursionlimit(max(10000, 10 * n))
+    names = [f"t{i+1}" for i in range(n)]
+    inner = "(t1,t2)"
+    for i in range(3, n - 1):
+        inner = f"({inner},t{i})"
+    return trees.newick_to_back(f"({inner},t{n-1},t{n});", names)
+
+
+def _random_columns(synth, n, P, seed):
+    g = np.random.default_rng(seed)
+    L = np.repeat(g.integers(0, 4, size=P)[None, :], n, axis=0)
+    mut = g.random((n, P)) < 0.35
+    L[mut] = g.integers(0, 4, size=int(mut.sum()))
+    return synth.letters_to_codes(L.astype(np.uint8))
+
+
+def _climb_equals_oracle(engine, po, codes, back, w=None, maxtrav=6, aa=False):
+    dt_e, dt_o = (engine.AA, po.AA) if aa else (engine.DNA, po.DNA)
+    e = engine.FitchEngine(codes, w, datatype=dt_e)
+    o = po.Oracle(codes, w, datatype=dt_o)
+    assert e.score_tree(back) == o.score_tree(back)
+    e.seed_ties(engine.TIE_RANDOM, 3)
+    o.seed_ties(po.TIE_RANDOM, 3)
+    o.trace(True)
+    assert e.optimize_spr(1, maxtrav) == o.optimize_spr(1, maxtrav)
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    pe, te = e.pattern_scores()
+    o.enable_persite(True)
+    o.score_tree()
+    p_o, t_o = o.pattern_scores()
+    inf = o.informative().astype(bool)
+    assert te == t_o and (np.asarray(pe)[inf] == np.asarray(p_o)[inf]).all()
+    return len(e.moves()[0])
+
+
+@pytest.mark.parametrize("n,P,aa,maxtrav", [(300, 400, False, 6), (300, 400, False, 12), (150, 200, True, 6), (1200, 160, False, 6)])
+def test_ladder_trees(mods, n, P, aa, maxtrav):
+    """the deepest tree there is (n - 2 levels of views, prune nodes whose far side is one long chain): the whole climb away
+    from it == the oracle's, move for move"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(n, P, "AA" if aa else "DNA", 0.08, seed=n + P)
+    codes = synth.letters_to_codes(letters, "AA" if aa else "DNA")
+    assert _climb_equals_oracle(engine, po, codes, _ladder(trees, n), maxtrav=maxtrav, aa=aa) > n
+
+
+@pytest.mark.parametrize("n,P,maxtrav", [(3000, 96, 6), (6000, 40, 4)])
+def test_thousands_of_taxa_on_a_short_alignment(mods, n, P, maxtrav):
+    """three words of sites per vector, 12 000 node records: planning, batching and the refresh schedule dominate"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(n, P, "DNA", 0.03, seed=n)
+    codes = synth.letters_to_codes(letters)
+    assert _climb_equals_oracle(engine, po, codes, trees.random_topology(n, np.random.default_rng(5)), maxtrav=maxtrav) > n
+
+
+@pytest.mark.parametrize("n,P", [(6, 3_000_000), (12, 1_200_000)])
+def test_a_few_taxa_on_millions_of_patterns(mods, n, P):
+    """vectors of 10 MB, a handful of them"""
+    engine, po, synth, trees = mods
+    _climb_equals_oracle(engine, po, _random_columns(synth, n, P, P), trees.random_topology(n, np.random.default_rng(5)))
+
+
+def test_very_heavy_pattern_weights(mods):
+    """weights of 65535, 100000, 250000 next to 0, 1 and 7 (the packed form repeats a pattern weight times, sprparsimony.cpp:2922-2943)"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(40, 600, "DNA", 0.1, seed=77)
+    codes = synth.letters_to_codes(letters)
+    rng = np.random.default_rng(5)
+    w = rng.integers(0, 3, size=600).astype(np.int32)
+    w[rng.integers(0, 600, size=6)] = [65535, 40000, 100000, 1, 250000, 7]
+    assert _climb_equals_oracle(engine, po, codes, trees.random_topology(40, rng), w=w) > 10
