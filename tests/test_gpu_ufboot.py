@@ -142,6 +142,29 @@ def test_heavy_weights_use_a_second_plane(mods):
     assert_same(e, o, se, so)
 
 
+def test_weights_above_16383_use_a_third_plane(mods):
+    """a sample's pattern weights are u16 (boot_samples_pars, iqtree.cpp:230-233): 7-bit digits on the int8 matrix cores, three planes"""
+    engine, po = mods
+    fx = load_fixture("dna_ambig")
+    samples = boot_samples(len(fx["weights"]), 9, 4, fx["weights"])
+    rng = np.random.default_rng(3)
+    for b in range(len(samples)):
+        samples[b, rng.integers(0, samples.shape[1], size=3)] = [16384, 40000, 65535]
+    start = np.array(fx["trees"][4]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 6)
+    assert_same(e, o, se, so)
+
+
+@pytest.mark.parametrize("n_samples", [1, 2, 129])
+def test_sample_counts_around_the_tile_edges(mods, n_samples):
+    engine, po = mods
+    fx = load_fixture("aa")
+    samples = boot_samples(len(fx["weights"]), n_samples, 6, fx["weights"])
+    start = np.array(fx["trees"][3]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 8)
+    assert_same(e, o, se, so)
+
+
 def test_keep_all_sites_and_small_radius(mods):
     engine, po = mods
     fx = load_fixture("dna_ambig")

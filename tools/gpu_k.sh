@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out/k
-MPF_EXTREMES_FIRST=3 timeout 300 python -u tools/extremes_probe.py > gpurun_out/k/extremes.log 2>&1; echo "rc=$?"; tail -n 25 gpurun_out/k/extremes.log | cut -c1-300
+timeout 600 python -m pytest tests/test_gpu_edges.py tests/test_gpu_ufboot.py -x -q -k "ladder or thousands or millions or heavy or third_plane or tile_edges" > gpurun_out/k/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 30 gpurun_out/k/pytest.log
