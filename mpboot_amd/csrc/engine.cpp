@@ -63,6 +63,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     return MPF_E_UNSUPPORTED;
   }
   if (const char *hp = std::getenv("MPF_HOST_POLL")) host_poll_ = std::atoi(hp) ? 1 : 0;        // (experiments)
+  if (const char *vt = std::getenv("MPF_VIEWS_TILE")) { const int t = std::atoi(vt); if (t == 32 || t == 16 || t == 8) g_.nv_tile = t; }
   if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -80,6 +81,10 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   datatype_ = cfg.datatype;
   keep_all_ = cfg.keep_all_sites;
   g_.S = datatype_ == MPF_DNA ? 4 : 20;
+  // full refresh, one word per lane: DNA on 16-word tiles with the operands of the next round requested ahead (k_newview_wgq:
+  // 0.088 ms instead of 0.119 at C3); with 20 states the half-wave kernel on 32-word tiles stays ahead (0.172 vs 0.176 ms at C5)
+  g_.nv_pipe = g_.S == 4;
+  if (const char *vp = std::getenv("MPF_VIEWS_PIPE")) g_.nv_pipe = std::atoi(vp) != 0;      // (experiments: defaults of "views_pipe" / "views_tile")
   if (cost) {
     // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80), then the
     // symmetry requirement of the directional-view formulation
@@ -1606,6 +1611,13 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "views_pipe") { g_.nv_pipe = v != 0; sched_cache_valid_ = false; return MPF_OK; }
+  if (key == "views_tile") {
+    if (v != 32 && v != 16 && v != 8) { set_error("views_tile: 32, 16 or 8 words"); return MPF_E_INVALID; }
+    g_.nv_tile = (int)v;
+    sched_cache_valid_ = false;
+    return MPF_OK;
+  }
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
@@ -1651,6 +1663,8 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "xcd_map") *v = g_.map;
   else if (key == "scan_mode") *v = scan_mode_;
   else if (key == "views_mode") *v = views_mode_;
+  else if (key == "views_pipe") *v = g_.nv_pipe;
+  else if (key == "views_tile") *v = g_.nv_tile;
   else if (key == "plan_cache") *v = plan_cache_;
   else if (key == "split_below") *v = split_below_;
   else if (key == "split_cands") *v = split_cands_;

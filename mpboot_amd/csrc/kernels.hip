@@ -31,6 +31,18 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
   return v;
 }
 
+// sum over aligned groups of TW lanes (8, 16: inside a DPP row; 32: two rows), left in every lane of the group
+template <int TW>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  if constexpr (TW >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  if constexpr (TW == 32) v += (uint32_t)__shfl_xor((int)v, 16, 32);
+  return v;
+}
+
 template <int RED>
 __device__ __forceinline__ uint32_t wave_total(uint32_t v)
 {
@@ -410,6 +422,66 @@ __global__ __launch_bounds__(1024) void k_newview_wgh(uint32_t *__restrict__ vec
 #pragma unroll
       for (int m = 16; m >= 1; m >>= 1) k += (uint32_t)__shfl_xor((int)k, m, 32);
       if ((lane & 31) == 0 && active) cntp[(size_t)tile * nslots + o.dst] = k;
+    }
+    __syncthreads();
+  }
+  if (!done) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The same with TW lanes per op (TW = 32, 16, 8: tiles of TW words, 64 / TW ops of the level per wave and round) and the
+// next round's operands requested BEFORE this round's results are stored.  Finer tiles = more workgroups (a full refresh at
+// C3: 49, 98, 196 of them on 256 CUs) with no barrier between them -- a tile of sites never needs another tile's vectors.
+// The early request matters because gfx950 retires loads and stores through ONE in-order counter: a wave that asks for its
+// next operands only after its stores cannot see them before the stores are acknowledged.
+template <int S, int TW>
+__global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+                                                      const int32_t *__restrict__ lev_off, int n_lev,
+                                                      uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
+                                                      uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, RefreshExtra x)
+{
+  constexpr int OPI = 64 / TW;                     // ops per wave and round
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = (int)(blockDim.x >> 6);
+  const int tile = blockIdx.x;
+  const int sub = lane / TW;
+  const int w0 = tile * TW + (lane % TW);          // Wp is a multiple of 32: always inside the row
+  const int step = OPI * nw;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x.zero_words; i += gridDim.x * blockDim.x) x.zero_ptr[i] = 0u;
+  for (int l = 0; l < n_lev; l++) {
+    const int b = lev_off[l], e = lev_off[l + 1];
+    int ib = b + OPI * wave;
+    if (ib < e) {
+      // descriptors run two rounds ahead, operands one.  Indices are clamped into the level: surplus lanes repeat its last op on
+      // the same words as the lanes that own it and write the same values -- no lane is switched off, so every round issues
+      // the same requests (1 descriptor, 2 S operand rows, S result rows, 1 count) and the wait for the next operands can
+      // be counted past this round's stores
+      NvOp o = ops[min(ib + sub, e - 1)], o1 = ops[min(ib + step + sub, e - 1)];
+      Tile<S, 1> ta, tb;
+      load_tile<S, 1>(ta, vec, o.a, Wp, w0);
+      load_tile<S, 1>(tb, vec, o.b, Wp, w0);
+      for (; ib < e; ib += step) {
+        const NvOp o2 = ops[min(ib + 2 * step + sub, e - 1)];
+        Tile<S, 1> na, nb, tc;
+        load_tile<S, 1>(na, vec, o1.a, Wp, w0);
+        load_tile<S, 1>(nb, vec, o1.b, Wp, w0);
+        const uint32_t k = fitch<S, 1>(tc, ta, tb);
+        store_tile<S, 1>(tc, vec, o.dst, Wp, w0);
+        cntp[(size_t)tile * nslots + o.dst] = group_sum<TW>(k);
+        ta = na; tb = nb; o = o1; o1 = o2;
+      }
     }
     __syncthreads();
   }
@@ -1717,6 +1789,14 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 #undef SNK
     return hipGetLastError();
   }
+  if (g.vw == 1 && g.nv_pipe) {                    // TW lanes per op on TW-word tiles, operands requested a round ahead
+    dim3 qgrid((unsigned)(g.Wp / g.nv_tile));
+#define NQ(S_, TW_) hipLaunchKernelGGL((k_newview_wgq<S_, TW_>), qgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
+    if (g.S == 4) { if (g.nv_tile == 32) NQ(4, 32); else if (g.nv_tile == 16) NQ(4, 16); else NQ(4, 8); }
+    else { if (g.nv_tile == 32) NQ(20, 32); else if (g.nv_tile == 16) NQ(20, 16); else NQ(20, 8); }
+#undef NQ
+    return hipGetLastError();
+  }
   if (g.vw == 1) {                                 // half a wave per op on 32-word tiles
     dim3 hgrid((unsigned)(g.Wp / 32));
     if (g.S == 4) hipLaunchKernelGGL((k_newview_wgh<4, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
@@ -1745,7 +1825,7 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
   return hipGetLastError();
 }
 
-int tiles_for_levels(const Geometry &g) { return (!g.sankoff && g.vw == 1) ? g.Wp / 32 : tiles_for(g); }
+int tiles_for_levels(const Geometry &g) { return (!g.sankoff && g.vw == 1) ? g.Wp / (g.nv_pipe ? g.nv_tile : 32) : tiles_for(g); }
 
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
                          uint32_t nslots, uint32_t *cnt, int tiles, uint32_t *cnt_host)

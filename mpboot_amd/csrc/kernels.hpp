@@ -43,6 +43,8 @@ struct Geometry {
   int reduce;   // 0 = DPP wave reduction, 1 = ds_bpermute (__shfl) reduction
   int map;      // 0 = scan-major wave mapping, 1 = tiles pinned to XCD classes
   int big = 0;  // the vector store is 2 GiB or more: the scan kernel uses 64-bit addressing instead of one raw buffer
+  int nv_pipe = 1;   // level-synchronous refresh, one word per lane: 1 = k_newview_wgq (operands requested a round ahead), 0 = k_newview_wgh
+  int nv_tile = 16;  // ... on tiles of 32 | 16 | 8 words (Wp / nv_tile workgroups)
   // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
   int sankoff = 0;
   const uint32_t *cost = nullptr;   // device, [S][S]
