@@ -1278,6 +1278,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     }
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     part_min_used_ = false;
+    bool part_min_polled = false;
     if (want_part_min_ && !host_direct && !scan_masks_ && !check_counts_ && nout > 16384) {
       // only the cheapest candidate of every scan part is wanted: reduce on the device, minima straight to the host
       if (!(walk_dev_reuse_ && parts_gen_ == walk_gen_ && n_parts_dev_ > 0)) {
@@ -1290,12 +1291,14 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
         HIPCHK(hipStreamSynchronize(st_));          // (parts_host_ is pageable; only on a newly planned sweep)
         parts_gen_ = walk_gen_;
       }
-      HIPCHK(h_pmin_.reserve(std::max<size_t>(n_parts_dev_, 1)));
-      HIPCHK(launch_part_min(st_, d_out(), d_parts_.p, (int)n_parts_dev_, h_pmin_.p));
-      if (cnt_copy_pending_) {
-        HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-        cnt_copy_pending_ = false;
-      }
+      HIPCHK(h_pmin_.reserve(n_parts_dev_ + 1));
+      // the mutation counts of the refresh in front ride along, and a polling host is told through a flag word behind the minima
+      // (the scan's timing events lie in front of this launch: they are complete when the flag is up)
+      part_min_polled = host_poll_ && n_parts_dev_ > 0;
+      if (part_min_polled) __atomic_store_n(h_pmin_.p + n_parts_dev_, 0u, __ATOMIC_RELAXED);
+      HIPCHK(launch_part_min(st_, d_out(), d_parts_.p, (int)n_parts_dev_, h_pmin_.p, d_cnt(), cnt_copy_pending_ ? h_cnt() : nullptr,
+                             (uint32_t)nslots_, part_min_polled ? d_done_.p + 24 : nullptr));
+      cnt_copy_pending_ = false;
       part_min_used_ = true;
     } else if (host_direct) {
       cnt_copy_pending_ = false;
@@ -1312,6 +1315,8 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     }
     if (host_direct && host_poll_ && !timing_ && wait_host_flag(h_out() + nout)) {
       // the scan's last workgroup has written the costs and raised the flag behind them: no need to wait for the stream
+    } else if (part_min_polled && wait_host_flag(h_pmin_.p + n_parts_dev_)) {
+      // (the same behind the per-part minima)
     } else {
       HIPCHK(hipStreamSynchronize(st_));
     }

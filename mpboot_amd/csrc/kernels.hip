@@ -1965,23 +1965,52 @@ hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const
 size_t scan_prog_bytes(int n_scans) { return (size_t)n_scans * 2u * kProgStride * sizeof(ProgEnt); }
 
 // pmin[i] = min of out[parts[i].x .. + parts[i].y): the cheapest candidate of every scan part, for callers that only want a
-// sweep's best move per prune node -- 8 bytes per part cross the bus instead of every candidate's cost.  pmin may be pinned
-// host memory (consecutive threads write consecutive words).
+// sweep's best move per prune node -- 4 bytes per part cross the bus instead of every candidate's cost.  Sixteen lanes (one
+// DPP row) per part read its costs side by side; a workgroup's sixteen minima leave through consecutive lanes (pmin may be
+// pinned host memory).  The refresh's mutation counts ride along (cnt -> cnt_host, n_cnt words; nullptr: not wanted), and
+// with `done` (a zeroed device word, left zeroed) the last workgroup raises pmin[n_parts] = 1 behind everything: a polling
+// host thread then needs neither a copy dispatch nor the wake-up of a stream synchronisation.
 __global__ __launch_bounds__(256) void k_part_min(const uint32_t *__restrict__ out, const uint2 *__restrict__ parts, int n_parts,
-                                                  uint32_t *__restrict__ pmin)
+                                                  uint32_t *__restrict__ pmin, const uint32_t *__restrict__ cnt,
+                                                  uint32_t *__restrict__ cnt_host, uint32_t n_cnt, uint32_t *__restrict__ done)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_parts) return;
-  const uint2 pr = parts[i];
+  __shared__ uint32_t s_min[16];
+  __shared__ int s_last;
+  const int grp = (int)(threadIdx.x >> 4), l = (int)(threadIdx.x & 15);
+  const int i = (int)blockIdx.x * 16 + grp;
   uint32_t m = 0xFFFFFFFFu;
-  for (uint32_t k = 0; k < pr.y; k++) m = min(m, out[pr.x + k]);
-  pmin[i] = m;
+  if (i < n_parts) {
+    const uint2 pr = parts[i];
+    for (uint32_t k = (uint32_t)l; k < pr.y; k += 16u) m = min(m, out[pr.x + k]);
+  }
+  m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)m, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)m, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)m, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)m, 0x140, 0xF, 0xF, false));   // row_mirror
+  if (l == 0) s_min[grp] = m;
+  __syncthreads();
+  if (threadIdx.x < 16 && (int)blockIdx.x * 16 + (int)threadIdx.x < n_parts) pmin[blockIdx.x * 16 + threadIdx.x] = s_min[threadIdx.x];
+  if (cnt_host)
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cnt; j += gridDim.x * blockDim.x) cnt_host[j] = __builtin_nontemporal_load(cnt + j);
+  if (!done) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // this workgroup's words are in host memory before its ticket counts
+    const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1;
+    if (s_last) {
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(pmin + n_parts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
-hipError_t launch_part_min(hipStream_t st, const uint32_t *out, const uint2 *parts, int n_parts, uint32_t *pmin)
+hipError_t launch_part_min(hipStream_t st, const uint32_t *out, const uint2 *parts, int n_parts, uint32_t *pmin, const uint32_t *cnt,
+                           uint32_t *cnt_host, uint32_t n_cnt, uint32_t *done)
 {
   if (n_parts <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_part_min, dim3((n_parts + 255) / 256), dim3(256), 0, st, out, parts, n_parts, pmin);
+  hipLaunchKernelGGL(k_part_min, dim3((n_parts + 15) / 16), dim3(256), 0, st, out, parts, n_parts, pmin, cnt, cnt_host, n_cnt, done);
   return hipGetLastError();
 }
 

@@ -75,8 +75,10 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
 hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *wl_off,
                                  int n_lev, int n_ops, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done,
                                  const RefreshExtra &x);
-// pmin[i] = min(out[parts[i].x .. parts[i].x + parts[i].y)); pmin may be pinned host memory
-hipError_t launch_part_min(hipStream_t st, const uint32_t *out, const uint2 *parts, int n_parts, uint32_t *pmin);
+// pmin[i] = min(out[parts[i].x .. parts[i].x + parts[i].y)); pmin may be pinned host memory.  cnt_host != nullptr: cnt[0 .. n_cnt)
+// is copied there as well; done != nullptr (a zeroed device word, left zeroed): pmin[n_parts] = 1 once everything is written
+hipError_t launch_part_min(hipStream_t st, const uint32_t *out, const uint2 *parts, int n_parts, uint32_t *pmin,
+                           const uint32_t *cnt = nullptr, uint32_t *cnt_host = nullptr, uint32_t n_cnt = 0, uint32_t *done = nullptr);
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
                          uint32_t nslots, uint32_t *cnt, int tiles = 0 /* 0 = tiles_for(g) */,
                          uint32_t *cnt_host = nullptr /* pinned host mirror of cnt[] */);
