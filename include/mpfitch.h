@@ -316,10 +316,10 @@ int mpf_reset_stats(mpf_engine *e);
      "prog_min_descs"  see "scan_prog" (default 256)
      "views_mode"      2 = chained refresh (stale paths run in registers, one launch; Fitch mode), 1 = all dependency
                        levels of a refresh in one launch, 0 = one launch per level
-     "views_pipe"      level kernel, one word per lane: 1 = a tile of "views_tile" words per workgroup, 64 / views_tile ops per
-                       wave instruction, the next round's operands requested before this round's stores (default for DNA);
-                       0 = 32-word tiles, half a wave per op (default for protein)
-     "views_tile"      32 | 16 (default) | 8, see "views_pipe"
+     "views_pipe"      level kernel, one word per lane: 1 (default) = a tile of "views_tile" words per workgroup, 64 / tile ops
+                       per wave instruction, the next round's operands requested before this round's stores, tiles dealt
+                       to the XCDs in contiguous runs; 0 = 32-word tiles, half a wave per op
+     "views_tile"      32 | 16 | 8 | 4, or 0 (default) = the smallest of them that gives at most 256 workgroups
      "chain_max_ops"   refreshes of up to this many vectors use the chained kernel (default 512; larger ones are wide
                        rather than deep and take the level kernel)
      "split_below"     batches of at most this many prune nodes are cut into four scan parts each

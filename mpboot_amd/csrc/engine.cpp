@@ -63,7 +63,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     return MPF_E_UNSUPPORTED;
   }
   if (const char *hp = std::getenv("MPF_HOST_POLL")) host_poll_ = std::atoi(hp) ? 1 : 0;        // (experiments)
-  if (const char *vt = std::getenv("MPF_VIEWS_TILE")) { const int t = std::atoi(vt); if (t == 32 || t == 16 || t == 8) g_.nv_tile = t; }
+  if (const char *vt = std::getenv("MPF_VIEWS_TILE")) { const int t = std::atoi(vt); if (t == 32 || t == 16 || t == 8 || t == 4 || t == 0) g_.nv_tile = t; }
   if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -81,9 +81,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   datatype_ = cfg.datatype;
   keep_all_ = cfg.keep_all_sites;
   g_.S = datatype_ == MPF_DNA ? 4 : 20;
-  // full refresh, one word per lane: DNA on 16-word tiles with the operands of the next round requested ahead (k_newview_wgq:
-  // 0.088 ms instead of 0.119 at C3); with 20 states the half-wave kernel on 32-word tiles stays ahead (0.172 vs 0.176 ms at C5)
-  g_.nv_pipe = g_.S == 4;
+  // (full refresh, one word per lane: k_newview_wgq on tiles chosen from the row length, kernels.hip: newview_tile)
   if (const char *vp = std::getenv("MPF_VIEWS_PIPE")) g_.nv_pipe = std::atoi(vp) != 0;      // (experiments: defaults of "views_pipe" / "views_tile")
   if (cost) {
     // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80), then the
@@ -1618,7 +1616,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
   if (key == "views_pipe") { g_.nv_pipe = v != 0; sched_cache_valid_ = false; return MPF_OK; }
   if (key == "views_tile") {
-    if (v != 32 && v != 16 && v != 8) { set_error("views_tile: 32, 16 or 8 words"); return MPF_E_INVALID; }
+    if (v != 32 && v != 16 && v != 8 && v != 4 && v != 0) { set_error("views_tile: 32, 16, 8 or 4 words (0: chosen from the row length)"); return MPF_E_INVALID; }
     g_.nv_tile = (int)v;
     sched_cache_valid_ = false;
     return MPF_OK;

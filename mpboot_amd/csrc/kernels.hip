@@ -31,13 +31,13 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
   return v;
 }
 
-// sum over aligned groups of TW lanes (8, 16: inside a DPP row; 32: two rows), left in every lane of the group
+// sum over aligned groups of TW lanes (4, 8, 16: inside a DPP row; 32: two rows), left in every lane of the group
 template <int TW>
 __device__ __forceinline__ uint32_t group_sum(uint32_t v)
 {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  if constexpr (TW >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
   if constexpr (TW >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
   if constexpr (TW == 32) v += (uint32_t)__shfl_xor((int)v, 16, 32);
   return v;
@@ -455,7 +455,10 @@ __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = (int)(blockDim.x >> 6);
-  const int tile = blockIdx.x;
+  // workgroups go round the 8 XCDs: each XCD gets a contiguous run of tiles, so that the 64-byte segments of neighbouring
+  // tiles -- two halves of one 128-byte line -- meet in ONE L2 instead of being fetched into two
+  const int nt = (int)gridDim.x, xcd = (int)(blockIdx.x & 7u), q8 = nt >> 3, r8 = nt & 7;
+  const int tile = xcd * q8 + min(xcd, r8) + (int)(blockIdx.x >> 3);
   const int sub = lane / TW;
   const int w0 = tile * TW + (lane % TW);          // Wp is a multiple of 32: always inside the row
   const int step = OPI * nw;
@@ -1776,6 +1779,8 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
   return hipGetLastError();
 }
 
+int newview_tile(const Geometry &g);
+
 hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *vec, const NvOp *ops, const int32_t *lev_off,
                                  int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done, const RefreshExtra &x)
 {
@@ -1790,10 +1795,11 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
     return hipGetLastError();
   }
   if (g.vw == 1 && g.nv_pipe) {                    // TW lanes per op on TW-word tiles, operands requested a round ahead
-    dim3 qgrid((unsigned)(g.Wp / g.nv_tile));
+    const int tw = newview_tile(g);
+    dim3 qgrid((unsigned)(g.Wp / tw));
 #define NQ(S_, TW_) hipLaunchKernelGGL((k_newview_wgq<S_, TW_>), qgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
-    if (g.S == 4) { if (g.nv_tile == 32) NQ(4, 32); else if (g.nv_tile == 16) NQ(4, 16); else NQ(4, 8); }
-    else { if (g.nv_tile == 32) NQ(20, 32); else if (g.nv_tile == 16) NQ(20, 16); else NQ(20, 8); }
+    if (g.S == 4) { if (tw == 32) NQ(4, 32); else if (tw == 16) NQ(4, 16); else if (tw == 8) NQ(4, 8); else NQ(4, 4); }
+    else { if (tw == 32) NQ(20, 32); else if (tw == 16) NQ(20, 16); else if (tw == 8) NQ(20, 8); else NQ(20, 4); }
 #undef NQ
     return hipGetLastError();
   }
@@ -1825,7 +1831,16 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
   return hipGetLastError();
 }
 
-int tiles_for_levels(const Geometry &g) { return (!g.sankoff && g.vw == 1) ? g.Wp / (g.nv_pipe ? g.nv_tile : 32) : tiles_for(g); }
+// tile of the "views_pipe" refresh: as set, or the smallest one that keeps the workgroups within one round of the chip's 256
+// CUs (C3: 1568 words -> 8-word tiles, 196 workgroups; C5: 640 -> 4, 160; measured in profiles/r2/refresh_tile_experiments.txt)
+int newview_tile(const Geometry &g)
+{
+  if (g.nv_tile) return g.nv_tile;
+  for (int t = 4; t < 32; t *= 2)
+    if (g.Wp / t <= 256) return t;
+  return 32;
+}
+int tiles_for_levels(const Geometry &g) { return (!g.sankoff && g.vw == 1) ? g.Wp / (g.nv_pipe ? newview_tile(g) : 32) : tiles_for(g); }
 
 hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int n_ops, const uint32_t *cntp,
                          uint32_t nslots, uint32_t *cnt, int tiles, uint32_t *cnt_host)

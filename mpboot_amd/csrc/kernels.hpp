@@ -44,7 +44,7 @@ struct Geometry {
   int map;      // 0 = scan-major wave mapping, 1 = tiles pinned to XCD classes
   int big = 0;  // the vector store is 2 GiB or more: the scan kernel uses 64-bit addressing instead of one raw buffer
   int nv_pipe = 1;   // level-synchronous refresh, one word per lane: 1 = k_newview_wgq (operands requested a round ahead), 0 = k_newview_wgh
-  int nv_tile = 16;  // ... on tiles of 32 | 16 | 8 words (Wp / nv_tile workgroups)
+  int nv_tile = 0;   // ... on tiles of 32 | 16 | 8 | 4 words (Wp / tile workgroups); 0 = chosen from Wp (newview_tile)
   // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
   int sankoff = 0;
   const uint32_t *cost = nullptr;   // device, [S][S]
@@ -83,6 +83,7 @@ hipError_t launch_cntsum(hipStream_t st, const Geometry &g, const NvOp *ops, int
                          uint32_t nslots, uint32_t *cnt, int tiles = 0 /* 0 = tiles_for(g) */,
                          uint32_t *cnt_host = nullptr /* pinned host mirror of cnt[] */);
 int tiles_for(const Geometry &g);
+int newview_tile(const Geometry &g);
 int tiles_for_levels(const Geometry &g);      // tiles (rows of cntp) launch_newview_levels uses: 32-word tiles for one word per lane
 hipError_t launch_evaluate(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops,
                            uint32_t *out);

@@ -216,7 +216,7 @@ def run_sequence(c, seed, n_steps, cost=None):
             k, v = [("scan_batch", int(rng.integers(1, 65))), ("split_below", int(rng.integers(0, 3)) * 2048), ("plan_cache", int(rng.integers(0, 2))),
                     ("scan_prog", int(rng.integers(0, 3))), ("views_mode", int(rng.integers(0, 3))), ("split_cands", int(rng.integers(8, 65))),
                     ("prog_min_descs", int(rng.integers(0, 2)) * 256), ("host_poll", int(rng.integers(0, 2))),
-                    ("views_pipe", int(rng.integers(0, 2))), ("views_tile", [32, 16, 8][int(rng.integers(0, 3))])][int(rng.integers(0, 10))]
+                    ("views_pipe", int(rng.integers(0, 2))), ("views_tile", [32, 16, 8, 4, 0][int(rng.integers(0, 5))])][int(rng.integers(0, 10))]
             if os.environ.get("MPF_STATEFUL_VERBOSE"):
                 print("   option", k, v, flush=True)
             e.set_option(k, v)
