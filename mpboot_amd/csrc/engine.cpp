@@ -1280,13 +1280,15 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     if (want_part_min_ && !host_direct && !scan_masks_ && !check_counts_ && nout > 16384) {
       // only the cheapest candidate of every scan part is wanted: reduce on the device, minima straight to the host
       if (!(walk_dev_reuse_ && parts_gen_ == walk_gen_ && n_parts_dev_ > 0)) {
-        parts_host_.clear();
+        size_t np = 0;
+        for (const ScanPlan &pl : plans) np += (size_t)pl.n_parts;
+        HIPCHK(h_parts_.reserve(std::max<size_t>(np, 1)));
+        n_parts_dev_ = 0;
         for (const ScanPlan &pl : plans)
-          for (int pi = 0; pi < pl.n_parts; pi++) parts_host_.push_back(make_uint2(pl.part_off[pi], (uint32_t)pl.part_cnt[pi]));
-        n_parts_dev_ = parts_host_.size();
+          for (int pi = 0; pi < pl.n_parts; pi++) h_parts_.p[n_parts_dev_++] = make_uint2(pl.part_off[pi], (uint32_t)pl.part_cnt[pi]);
         HIPCHK(d_parts_.reserve(std::max<size_t>(n_parts_dev_, 1)));
-        HIPCHK(hipMemcpyAsync(d_parts_.p, parts_host_.data(), n_parts_dev_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
-        HIPCHK(hipStreamSynchronize(st_));          // (parts_host_ is pageable; only on a newly planned sweep)
+        // (the pinned list is rewritten only by the next newly planned sweep, i.e. after this sweep's results have come back)
+        HIPCHK(hipMemcpyAsync(d_parts_.p, h_parts_.p, n_parts_dev_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
         parts_gen_ = walk_gen_;
       }
       HIPCHK(h_pmin_.reserve(n_parts_dev_ + 1));

@@ -442,7 +442,7 @@ class Engine {
   bool want_part_min_ = false, part_min_used_ = false;
   DevBuf<uint2> d_parts_;
   PinBuf<uint32_t> h_pmin_;
-  std::vector<uint2> parts_host_;
+  PinBuf<uint2> h_parts_;                         // (pinned: uploaded without a stream synchronisation in the middle of a sweep)
   uint64_t parts_gen_ = ~0ull;                   // walk_gen_ the device copy of the part table belongs to
   size_t n_parts_dev_ = 0;
   bool scan_vals_ = false;                       // weighted tracker: host-planned scans also write per-pattern lengths, a slot per prune node is reserved for the current tree
