@@ -250,3 +250,39 @@ def test_very_heavy_pattern_weights(mods):
     w = rng.integers(0, 3, size=600).astype(np.int32)
     w[rng.integers(0, 600, size=6)] = [65535, 40000, 100000, 1, 250000, 7]
     assert _climb_equals_oracle(engine, po, codes, trees.random_topology(40, rng), w=w) > 10
+
+
+@pytest.mark.parametrize("pipe,tile", [(0, 0), (1, 32), (1, 16), (1, 8), (1, 4), (1, 0)])
+@pytest.mark.parametrize("name", ["dna_48", "aa"])
+def test_refresh_kernel_variants(mods, name, pipe, tile):
+    """options "views_pipe" / "views_tile": the level-synchronous refresh on 32-word tiles with half a wave per op, or on 32 / 16 /
+    8 / 4-word tiles with the operands requested a round ahead (0: tile chosen from the row length) -- with "views_mode" 1 every
+    refresh of the climb, partial ones included, runs on that kernel.  Scores, scans and the whole climb == the oracle's."""
+    engine, po, synth, trees = mods
+    fx = load_fixture(name)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    e.set_option("views_mode", 1)
+    e.set_option("views_pipe", pipe)
+    e.set_option("views_tile", tile)
+    assert e.get_option("views_pipe") == pipe and e.get_option("views_tile") == tile
+    for t in fx["trees"][:4]:
+        back = np.array(t["back"], dtype=np.int32)
+        assert e.score_tree(back) == o.score_tree(back) == t["score"]
+    o.seed_ties(po.TIE_RANDOM, 4)
+    cur = o.score_tree()
+    for rec in o.nodep()[1:12]:
+        o.set_best(cur)
+        o.trace(True)
+        o.rearrange(int(rec), 1, 6)
+        assert scan_tokens(e, rec, 6) == trace_tokens(*o.get_trace())
+    start = np.array(fx["trees"][5]["back"], dtype=np.int32)
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.set_tree(start)
+        x.seed_ties(mode, 6)
+    o.trace(True)
+    assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+    assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    with pytest.raises(engine.MpfError):
+        e.set_option("views_tile", 12)
