@@ -793,6 +793,7 @@ __device__ __forceinline__ void scan_body(const uint32_t *__restrict__ vec, cons
 // earlier launch wrote to the host) are there -- without the wake-up latency of a stream synchronisation.
 __device__ __forceinline__ void host_results_ready(uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done)
 {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every wave: its own words have arrived before anyone raises the flag
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2008,9 +2009,12 @@ __global__ __launch_bounds__(256) void k_part_min(const uint32_t *__restrict__ o
   if (cnt_host)
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cnt; j += gridDim.x * blockDim.x) cnt_host[j] = __builtin_nontemporal_load(cnt + j);
   if (!done) return;
+  // every wave that wrote to the host (wave 0: the minima; the first n_cnt threads of the grid: the counts): its words are in
+  // host memory before the workgroup's ticket counts
+  const uint32_t first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  if (threadIdx.x < 64u || (cnt_host && first < n_cnt)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // this workgroup's words are in host memory before its ticket counts
     const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = ticket == gridDim.x - 1;
     if (s_last) {
