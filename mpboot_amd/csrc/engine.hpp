@@ -124,6 +124,8 @@ struct UfbState {
   std::vector<Pending> pending;
   uint64_t draws = 0, events = 0, gemm_rows = 0, batches = 0, stored = 0;
   double gemm_ms = 0.0;
+  double t_lookup = 0;                           // ... of t_replay: canonical forms for the topology map
+  uint64_t lookups = 0;
   double t_scan = 0, t_prep = 0, t_dev = 0, t_sort = 0, t_replay = 0, t_rt = 0;   // host wall-clock split (ms), MPF_UFB_PROFILE=1 prints it
   // device
   DevBuf<uint8_t> wt;                            // [planes][Wp/2][Bp/16][4][16][16] signed bytes
@@ -277,6 +279,7 @@ class Engine {
   }
   int ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const;
   void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const;
+  mutable std::vector<int32_t> ct_mins_, ct_order_, ct_stack_;     // its scratch (an engine belongs to one host thread at a time)
   bool ufboot_attached() const { return (bool)ufb_; }
   int ufboot_set_cutoff(double logl_cutoff);
   int ufboot_set_ratchet_booking(int on);

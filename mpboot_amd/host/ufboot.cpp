@@ -113,9 +113,9 @@ int Engine::ufb_layout_weights()
 void Engine::ufboot_detach()
 {
   if (ufb_ && std::getenv("MPF_UFB_PROFILE"))
-    std::fprintf(stderr, "[ufboot] batches %llu events %llu stored %llu | ms: scan %.1f prep %.1f device %.1f sort %.1f replay %.1f rt %.1f (product kernels %.1f)\n",
+    std::fprintf(stderr, "[ufboot] batches %llu events %llu stored %llu | ms: scan %.1f prep %.1f device %.1f sort %.1f replay %.1f (topology lookups %llu: %.1f) rt %.1f (product kernels %.1f)\n",
                  (unsigned long long)ufb_->batches, (unsigned long long)ufb_->events, (unsigned long long)ufb_->stored, ufb_->t_scan,
-                 ufb_->t_prep, ufb_->t_dev, ufb_->t_sort, ufb_->t_replay, ufb_->t_rt, ufb_->gemm_ms);
+                 ufb_->t_prep, ufb_->t_dev, ufb_->t_sort, ufb_->t_replay, (unsigned long long)ufb_->lookups, ufb_->t_lookup, ufb_->t_rt, ufb_->gemm_ms);
   if (ufb_) ufb_pool_swap(*ufb_);                  // keep the large scratch buffers for the next attach
   ufb_.reset();
 }
@@ -341,10 +341,13 @@ int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
 // with the smaller tip number first.
 void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key) const
 {
+  // (one call per booked tree that some sample accepts -- 3e4 in a C3 climb from a random tree, every insertion test with
+  //  -storetrees: scratch arrays are members, nothing is allocated or cleared here; 16-bit entries while tip numbers fit)
   const int nrec = 3 * (2 * n_ - 1);
-  std::vector<int32_t> mins((size_t)nrec, 0), order, seq;
-  order.reserve((size_t)(2 * n_));
-  std::vector<int32_t> stack;
+  std::vector<int32_t> &mins = ct_mins_, &order = ct_order_, &stack = ct_stack_;
+  if ((int)mins.size() < nrec) mins.resize((size_t)nrec);
+  order.clear();
+  stack.clear();
   stack.push_back(bk[3]);
   while (!stack.empty()) {                         // pre-order of the entry records, then mins bottom-up
     const int r = stack.back();
@@ -358,19 +361,25 @@ void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key
     const int r = order[k];
     mins[(size_t)r] = r / 3 <= n_ ? r / 3 : std::min(mins[(size_t)bk[(size_t)nx(r)]], mins[(size_t)bk[(size_t)nx(nx(r))]]);
   }
-  seq.reserve(order.size());
+  const bool narrow = n_ < 65535;                  // tips 1 .. n, an inner node 0 (wide form: -1)
+  key.resize(order.size() * (narrow ? sizeof(uint16_t) : sizeof(int32_t)));
+  uint16_t *k16 = reinterpret_cast<uint16_t *>(&key[0]);
+  int32_t *k32 = reinterpret_cast<int32_t *>(&key[0]);
+  size_t at = 0;
   stack.push_back(bk[3]);
   while (!stack.empty()) {
     const int r = stack.back();
     stack.pop_back();
-    if (r / 3 <= n_) { seq.push_back(r / 3); continue; }
-    seq.push_back(-1);
+    if (r / 3 <= n_) {
+      if (narrow) k16[at++] = (uint16_t)(r / 3); else k32[at++] = r / 3;
+      continue;
+    }
+    if (narrow) k16[at++] = 0; else k32[at++] = -1;
     int a = bk[(size_t)nx(r)], b = bk[(size_t)nx(nx(r))];
     if (mins[(size_t)a] > mins[(size_t)b]) std::swap(a, b);
     stack.push_back(b);
     stack.push_back(a);
   }
-  key.assign(reinterpret_cast<const char *>(seq.data()), seq.size() * sizeof(int32_t));
 }
 
 // "top cutoff_percent %" rule of the main loop (reference iqtree.cpp:1662-1676; treels_logl.size() > 1000)
@@ -810,7 +819,11 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           return mh_key;
         };
         auto lookup_topology = [&](int64_t tree_index, uint32_t cand_code) -> int64_t {
-          return u.topo_index.emplace(topology_key(cand_code), tree_index).first->second;
+          const double tl = now_ms();
+          const int64_t ti = u.topo_index.emplace(topology_key(cand_code), tree_index).first->second;
+          u.t_lookup += now_ms() - tl;
+          u.lookups++;
+          return ti;
         };
         // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
         // current tree's own bookings, which the host walks through itself
