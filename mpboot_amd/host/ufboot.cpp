@@ -676,7 +676,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         // staging: thr[n_parts] | home[n_parts] | best[Bp] | crow[n_idx] | sel[rows_p] | self[n_self]
         const size_t o_crow = (size_t)2 * n_parts + (size_t)u.Bp, o_sel = o_crow + (compact ? (size_t)n_idx : 0);
         const size_t o_self = o_sel + (compact ? (size_t)rows_p : 0);
-        small.assign(o_self + self_list.size(), 0u);
+        const size_t o_cnt = o_self + self_list.size();          // the event counter: a zero word of this upload (no memset dispatch)
+        small.assign(o_cnt + 1, 0u);
         std::copy(self_list.begin(), self_list.end(), small.begin() + (long)o_self);
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
@@ -722,11 +723,12 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           UCHK(launch_ufb_column(st_, u.C.p, u.Bp, oc, n_rows, u.d_col.p));
           UCHK(hipMemcpyAsync(u.h_col.p, u.d_col.p, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost, st_));   // synchronised with the event count below
         }
-        while (true) {
-          UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
+        uint32_t *d_evcount = u.thr.p + o_cnt;
+        for (bool again = false;; again = true) {
+          if (again) UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, d_crow, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct || store_trees) ? 1 : 0));
-          UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+                                 u.ev.p, (uint32_t)u.ev.cap, d_evcount, (u.topboot || u.distinct || store_trees) ? 1 : 0));
+          UCHK(hipMemcpyAsync(u.h_small.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           // the first few thousand events ride along with their count: the batches of a climb need no second round trip
           n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);
           UCHK(u.h_ev.reserve((size_t)n_eager));
@@ -1127,7 +1129,8 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           n_parts = (uint32_t)j + 1u;
         }
         // staging: thr[n_parts] | home[n_parts] | best[Bp]
-        small.assign((size_t)2 * n_parts + (size_t)u.Bp, 0u);
+        const size_t o_cnt = (size_t)2 * n_parts + (size_t)u.Bp;   // the event counter: a zero word of this upload
+        small.assign(o_cnt + 1, 0u);
         for (uint32_t d = 0; d < n_parts; d++) {
           small[d] = (!have_cut || ratchet || store_trees) ? UINT32_MAX : mp_max + 1u;            // max cost + 1 (costs are full lengths here)
           small[n_parts + d] = R;
@@ -1152,11 +1155,12 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           UCHK(hipMemcpyAsync(u.h_col.p, u.d_col.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
         }
         uint32_t n_ev = 0, n_eager = 0;
-        while (n_idx) {
-          UCHK(hipMemsetAsync(u.evcount.p, 0, sizeof(uint32_t), st_));
+        uint32_t *d_evcount = u.thr.p + o_cnt;
+        for (bool again = false; n_idx; again = true) {
+          if (again) UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
           UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, u.evcount.p, (u.topboot || u.distinct || store_trees) ? 1 : 0));
-          UCHK(hipMemcpyAsync(u.h_small.p, u.evcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+                                 u.ev.p, (uint32_t)u.ev.cap, d_evcount, (u.topboot || u.distinct || store_trees) ? 1 : 0));
+          UCHK(hipMemcpyAsync(u.h_small.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
           n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);     // (as in spr_sweeps_ufboot: one round trip for a small batch)
           UCHK(u.h_ev.reserve((size_t)n_eager));
           UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_eager * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
