@@ -279,7 +279,7 @@ class Engine {
   }
   int ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const;
   void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const;
-  mutable std::vector<int32_t> ct_mins_, ct_order_, ct_stack_;     // its scratch (an engine belongs to one host thread at a time)
+  mutable std::vector<int32_t> ct_q_, ct_cp_, ct_mn_, ct_sz_, ct_off_;     // its scratch (an engine belongs to one host thread at a time)
   bool ufboot_attached() const { return (bool)ufb_; }
   int ufboot_set_cutoff(double logl_cutoff);
   int ufboot_set_ratchet_booking(int on);

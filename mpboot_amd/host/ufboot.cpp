@@ -341,44 +341,50 @@ int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
 // with the smaller tip number first.
 void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key) const
 {
-  // (one call per booked tree that some sample accepts -- 3e4 in a C3 climb from a random tree, every insertion test with
-  //  -storetrees: scratch arrays are members, nothing is allocated or cleared here; 16-bit entries while tip numbers fit)
-  const int nrec = 3 * (2 * n_ - 1);
-  std::vector<int32_t> &mins = ct_mins_, &order = ct_order_, &stack = ct_stack_;
-  if ((int)mins.size() < nrec) mins.resize((size_t)nrec);
-  order.clear();
-  stack.clear();
-  stack.push_back(bk[3]);
-  while (!stack.empty()) {                         // pre-order of the entry records, then mins bottom-up
-    const int r = stack.back();
-    stack.pop_back();
-    order.push_back(r);
-    if (r / 3 <= n_) continue;
-    stack.push_back(bk[(size_t)nx(r)]);
-    stack.push_back(bk[(size_t)nx(nx(r))]);
+  // One call per booked tree that some sample accepts (3e4 in a C3 climb from a random tree; every insertion test with
+  // -storetrees), so: no allocation, no stack, selects instead of branches.  Three sequential sweeps over the nodes in
+  // breadth-first order from the neighbour of tip 1 (a node's children sit side by side at cp[i], cp[i] + 1): the order itself,
+  // then min tip and sequence length of every subtree backwards, then every node's position in the sequence forwards.
+  // 16-bit entries while tip numbers fit (tips 1 .. n, an inner node 0; wide form: -1).
+  const int tipmax = 3 * n_ + 2;                   // records of tips: r <= tipmax
+  const size_t cap = 2 * (size_t)n_ + 8;
+  if (ct_q_.size() < cap) { ct_q_.resize(cap); ct_cp_.resize(cap); ct_mn_.resize(cap); ct_sz_.resize(cap); ct_off_.resize(cap); }
+  int32_t *q = ct_q_.data(), *cp = ct_cp_.data(), *mn = ct_mn_.data(), *sz = ct_sz_.data(), *off = ct_off_.data();
+  int len = 1;
+  q[0] = bk[3];
+  for (int i = 0; i < len; i++) {
+    const int r = q[i];
+    const bool inner = r > tipmax;
+    const int base = (r / 3) * 3, sl = r - base;
+    const int r1 = base + (sl == 2 ? 0 : sl + 1), r2 = base + (sl == 0 ? 2 : sl - 1);      // nx(r), nx(nx(r))
+    q[len] = bk[(size_t)r1];                       // (a tip's other records are in bounds; what is read there is overwritten)
+    q[len + 1] = bk[(size_t)r2];
+    cp[i] = inner ? len : i;                       // (a tip points at itself: the selects below stay in bounds)
+    len += inner ? 2 : 0;
   }
-  for (size_t k = order.size(); k-- > 0;) {
-    const int r = order[k];
-    mins[(size_t)r] = r / 3 <= n_ ? r / 3 : std::min(mins[(size_t)bk[(size_t)nx(r)]], mins[(size_t)bk[(size_t)nx(nx(r))]]);
+  for (int i = len - 1; i >= 0; i--) {
+    const int r = q[i], c = cp[i];
+    const bool inner = r > tipmax;
+    const int c2 = inner ? c + 1 : c;
+    mn[i] = inner ? std::min(mn[c], mn[c2]) : r / 3;
+    sz[i] = inner ? 1 + sz[c] + sz[c2] : 1;
   }
-  const bool narrow = n_ < 65535;                  // tips 1 .. n, an inner node 0 (wide form: -1)
-  key.resize(order.size() * (narrow ? sizeof(uint16_t) : sizeof(int32_t)));
+  const bool narrow = n_ < 65535;
+  key.resize((size_t)len * (narrow ? sizeof(uint16_t) : sizeof(int32_t)));
   uint16_t *k16 = reinterpret_cast<uint16_t *>(&key[0]);
   int32_t *k32 = reinterpret_cast<int32_t *>(&key[0]);
-  size_t at = 0;
-  stack.push_back(bk[3]);
-  while (!stack.empty()) {
-    const int r = stack.back();
-    stack.pop_back();
-    if (r / 3 <= n_) {
-      if (narrow) k16[at++] = (uint16_t)(r / 3); else k32[at++] = r / 3;
-      continue;
+  off[0] = 0;
+  for (int i = 0; i < len; i++) {
+    const int r = q[i], c = cp[i], o = off[i];
+    const bool inner = r > tipmax;
+    if (narrow) k16[o] = inner ? (uint16_t)0 : (uint16_t)(r / 3);
+    else k32[o] = inner ? -1 : r / 3;
+    if (inner) {                                   // the subtree with the smaller tip first
+      const bool swap = mn[c] > mn[c + 1];
+      const int first = swap ? c + 1 : c, second = swap ? c : c + 1;
+      off[first] = o + 1;
+      off[second] = o + 1 + sz[first];
     }
-    if (narrow) k16[at++] = 0; else k32[at++] = -1;
-    int a = bk[(size_t)nx(r)], b = bk[(size_t)nx(nx(r))];
-    if (mins[(size_t)a] > mins[(size_t)b]) std::swap(a, b);
-    stack.push_back(b);
-    stack.push_back(a);
   }
 }
 
