@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 2   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option */
+#define MPF_ABI_VERSION 3   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*) */
 
 enum {
   MPF_OK = 0,
@@ -76,6 +76,11 @@ typedef struct mpf_stats {
   double   host_sweep_ms_total;  /* wall time inside mpf_spr_sweep_scan                      */
   double   plan_kernel_ms_total; /* HIP-event time of the scan-program planner (k_walk_plan)  */
   uint64_t plan_launches;        /* scan launches that ran as planned programs (k_scan_prog)  */
+  uint64_t climb_launches;       /* k_climb launches (device-resident sweep segments)         */
+  uint64_t climb_steps;          /* steps (speculative batches of prune nodes) inside them    */
+  uint64_t climb_nodes;          /* prune nodes they visited                                  */
+  uint64_t climb_moves;          /* moves they accepted                                       */
+  double   climb_ms_total;       /* wall time of those launches incl. hand-over               */
 } mpf_stats;
 
 const char *mpf_last_error(void);

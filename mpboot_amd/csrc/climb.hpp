@@ -1,0 +1,73 @@
+// climb.hpp -- launch interface of the device-resident SPR hill climb (climb.hip).
+//
+// pllOptimizeSprParsimony's sweep (reference sprparsimony.cpp:3295-3316) visits one prune node after the other and
+// applies a move as soon as one is accepted, so every accepted move depends on the one before it: driven from the host
+// that is one launch chain + one synchronisation per move (~75 us).  k_climb keeps the whole loop on the GPU:
+//   * one persistent workgroup per TILE of sites (16 * VW words of every state row); a tile's directional vectors are
+//     read and written by that workgroup only, for the whole launch;
+//   * every workgroup holds the topology (back links in compact vector ids), the validity flags and the search state
+//     (best score, tie counters, the lcg64 tie stream) in LDS and runs the SAME deterministic control code: candidate
+//     enumeration in the reference's order, the closure of stale vectors, the accept / tie rules, the topology edit and
+//     its invalidation -- nothing of that is ever communicated;
+//   * the only exchange per step is the sum over tiles of the candidates' partial lengths (one 64-bit atomic add per
+//     candidate and tile carrying value + arrival count; polled until every tile has arrived).
+// The host launches one segment per sweep (nodeRectifierPars runs between sweeps, sprparsimony.cpp:3297) and replays
+// the moves the kernel reports onto its own topology mirror.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mpf {
+
+enum ClimbReason : uint32_t {
+  CLIMB_RUNNING = 0,
+  CLIMB_SWEEP_END = 1,     // every prune node of the sweep visited
+  CLIMB_IDLE = 2,          // no move for idle_limit prune nodes: the host's whole-chip batches are the better tool
+  CLIMB_MOVES_FULL = 3,    // the move list is full
+  CLIMB_ABORT = 4,         // the workgroups did not all become resident in time: nothing was changed
+  CLIMB_ERROR = 5          // an internal bound was hit (hdr.err says which); state is not to be trusted
+};
+
+// search state handed over in both directions + counters + the launch's synchronisation words
+struct ClimbHeader {
+  unsigned long long rng;          // TieRng::state
+  unsigned long long hits;         // bestTreeScoreHits
+  uint32_t best, randomMP, iter_hits, pos;   // bestParsimony, randomMP, bestIterationScoreHits, next prune index (1-based)
+  int32_t insert_cid, remove_cid;  // insertNode / removeNode as vector ids (-1: none)
+  uint32_t n_moves, reason, err, steps;
+  unsigned long long n_tests, n_ops, draws, n_scanned_nodes;
+  uint32_t arrive, abort, since_move, batch;
+  uint32_t pad[4];
+};
+
+struct ClimbParams {
+  uint32_t *vec;                   // the engine's vector store [nslots][S][Wp]
+  uint32_t n, nslots, Wp, tiles;
+  uint32_t total;                  // prune nodes per sweep (2n - 2)
+  uint32_t maxtrav;                // min(maxtrav, ntips - 3), 1..6
+  uint32_t tie_mode;               // MPF_TIE_RANDOM | MPF_TIE_FIRST
+  uint32_t idle_limit;             // 0 = never leave for idleness
+  uint32_t max_moves;
+  uint32_t batch_min, batch_max;   // prune nodes per step (speculative; doubles after a step without a move)
+  const uint16_t *order;           // [total] vector ids of nodep[1..total]
+  uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
+  uint32_t *sct;                   // [tiles][nslots] per-tile subtree scores (scratch of the launch)
+  unsigned long long *gsum;        // [3][kClimbCap] exchange ring (zeroed by the host before the launch)
+  ClimbHeader *hdr;
+  uint32_t *moves;                 // [max_moves][3] = remove cid, insert cid, score
+  uint32_t *trace;                 // optional: 8 words per visited prune node
+  uint32_t trace_cap;              // in records
+  uint32_t *beat;                  // optional, pinned host memory: progress marks of workgroup 0 (16 words)
+};
+
+constexpr uint32_t kClimbCap = 1024;      // candidates per step
+
+// states per lane group: DNA 1 (four lanes = the four states of a word), protein 5
+bool climb_supported(const Geometry &g, int n_taxa, int maxtrav);
+int climb_tiles(const Geometry &g, int vw);
+size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw);
+hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p);
+
+}  // namespace mpf

@@ -1639,6 +1639,16 @@ int Engine::set_option(const std::string &key, int64_t v)
     if (!sankoff_) g_.big = (force_big_ || vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) ? 1 : 0;
     return MPF_OK;
   }
+  if (key == "climb_device") { climb_device_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
+  if (key == "climb_tile") {
+    if (v != 1 && v != 2 && v != 4) { set_error("climb_tile: 1|2|4 words per lane group (tiles of 16, 32, 64 words)"); return MPF_E_INVALID; }
+    climb_vw_ = (int)v;
+    return MPF_OK;
+  }
+  if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
+  if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
+  if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "climb_trace") { climb_trace_ = v ? 1 : 0; cd_.h_trace.clear(); cd_.trace_records = 0; return MPF_OK; }
   if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack
     snk16_opt_ = v ? 1 : 0;
     if (sankoff_) return pack();
@@ -1651,6 +1661,13 @@ int Engine::set_option(const std::string &key, int64_t v)
 // diagnostic: the per-workgroup timeline of the last planned-program scan launch (option "scan_trace")
 int Engine::scan_trace(uint64_t *out, uint64_t cap, uint64_t *n)
 {
+  if (climb_trace_) {
+    // option "climb_trace": eight 32-bit words per prune node the device-resident climb visited (prune index, prune vector id,
+    // insertion tests, of them on the p side, cheapest, bestParsimony afterwards, chosen candidate, accepted), two per 64-bit word
+    *n = cd_.h_trace.size() / 2;
+    if (cap >= *n && *n) std::memcpy(out, cd_.h_trace.data(), cd_.h_trace.size() * sizeof(uint32_t));
+    return MPF_OK;
+  }
   *n = trace_words_;
   if (!trace_words_ || cap < trace_words_) return MPF_OK;
   activate();
@@ -1678,6 +1695,12 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "force_big") *v = force_big_;
   else if (key == "sankoff_short") *v = snk16_opt_;
   else if (key == "check_counts") *v = check_counts_;
+  else if (key == "climb_device") *v = climb_device_;
+  else if (key == "climb_tile") *v = climb_vw_;
+  else if (key == "climb_batch_min") *v = climb_batch_min_;
+  else if (key == "climb_batch_max") *v = climb_batch_max_;
+  else if (key == "climb_idle") *v = climb_idle_;
+  else if (key == "climb_trace") *v = climb_trace_;
   else { set_error("unknown option " + key); return MPF_E_INVALID; }
   return MPF_OK;
 }

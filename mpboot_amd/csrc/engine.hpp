@@ -23,6 +23,7 @@
 
 #include "../../include/mpfitch.h"
 #include "../host/rng.hpp"
+#include "climb.hpp"
 #include "kernels.hpp"
 #include "ufboot.hpp"
 
@@ -335,6 +336,25 @@ class Engine {
 
   int addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step);
   void apply_move(int remove_rec, int insert_rec);
+
+  // ---- device-resident climb (climb.hip; host/search.cpp): one k_climb launch runs the sweep loop from prune index *i on,
+  // the moves it reports are replayed onto the host's topology mirror.  The host's view bookkeeping is reset afterwards
+  // (the kernel keeps its own); whatever runs next on the host path starts with a full refresh (0.08 ms at C3).
+  struct ClimbDev {
+    DevBuf<uint16_t> bk, order;
+    DevBuf<uint32_t> sct, trace;
+    DevBuf<unsigned long long> gsum;
+    DevBuf<uint32_t> out;                        // [header | moves]
+    PinBuf<uint16_t> h_bk, h_order;
+    PinBuf<uint32_t> h_out, h_beat;
+    std::vector<uint32_t> h_trace;
+    size_t trace_records = 0;
+  } cd_;
+  int climb_device_ = 1;                         // 0 = host-driven batches only, 1 = device climb while moves are dense, 2 = always
+  int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)
+  int climb_batch_min_ = 2, climb_batch_max_ = 8, climb_idle_ = 96, climb_trace_ = 0;
+  inline int rec_of(uint32_t cid) const { return cid < (uint32_t)n_ ? 3 * ((int)cid + 1) : 3 * (n_ + 1 + (int)(cid - (uint32_t)n_) / 3) + (int)((cid - (uint32_t)n_) % 3u); }
+  int climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle, uint32_t *reason, uint32_t *n_moves);
 
   // ---- configuration / alignment
   int n_ = 0, P_ = 0, datatype_ = 0, keep_all_ = 0, dev_ = 0;

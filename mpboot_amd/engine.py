@@ -58,7 +58,9 @@ class Stats(C.Structure):
                 ("last_scan_kernel_ms", C.c_double), ("scan_kernel_ms_total", C.c_double),
                 ("view_kernel_ms_total", C.c_double), ("host_plan_ms_total", C.c_double),
                 ("host_views_ms_total", C.c_double), ("host_scan_ms_total", C.c_double),
-                ("host_sweep_ms_total", C.c_double), ("plan_kernel_ms_total", C.c_double), ("plan_launches", C.c_uint64)]
+                ("host_sweep_ms_total", C.c_double), ("plan_kernel_ms_total", C.c_double), ("plan_launches", C.c_uint64),
+                ("climb_launches", C.c_uint64), ("climb_steps", C.c_uint64), ("climb_nodes", C.c_uint64),
+                ("climb_moves", C.c_uint64), ("climb_ms_total", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

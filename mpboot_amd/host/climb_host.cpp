@@ -1,0 +1,169 @@
+// climb_host.cpp -- host side of the device-resident climb (csrc/climb.hip): hand the search state to k_climb, launch one
+// sweep segment, replay the moves it reports onto the topology mirror.
+//
+// What crosses the boundary: the tree as back links in compact vector ids, the sweep's visiting order (nodep[] after
+// nodeRectifierPars, reference sprparsimony.cpp:2046-2101, :3297), bestParsimony / randomMP / bestIterationScoreHits /
+// bestTreeScoreHits / insertNode / removeNode and the state of the lcg64 tie stream (:2168-2176, :3306-3311).  The
+// directional vectors stay where they are; the kernel treats them all as stale at launch and keeps its own per-tile
+// subtree scores, the host forgets its validity bookkeeping afterwards -- both sides only ever trust what they computed.
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#include "../csrc/engine.hpp"
+
+namespace mpf {
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" +      \
+                std::to_string(__LINE__) + ")");                                                  \
+      return MPF_E_HIP;                                                                           \
+    }                                                                                             \
+  } while (0)
+
+int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle,
+                          uint32_t *reason, uint32_t *n_moves)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  const int vw = (g_.S == 4) ? climb_vw_ : 1;
+  const int tiles = climb_tiles(g_, vw);
+  const size_t ns = nslots_;
+  const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
+  const size_t out_words = hdr_words + 3 * (size_t)total;
+  HIPCHK(cd_.bk.reserve(ns));
+  HIPCHK(cd_.order.reserve((size_t)total));
+  HIPCHK(cd_.sct.reserve((size_t)tiles * ns));
+  HIPCHK(cd_.gsum.reserve(3 * (size_t)kClimbCap));
+  HIPCHK(cd_.out.reserve(out_words));
+  HIPCHK(cd_.h_bk.reserve(ns));
+  HIPCHK(cd_.h_order.reserve((size_t)total));
+  HIPCHK(cd_.h_out.reserve(out_words));
+  for (size_t c = 0; c < ns; c++) {
+    // (the store has room for node 2n - 1, which an unrooted tree does not use: such a record points at itself)
+    const int b = back_[(size_t)rec_of((uint32_t)c)];
+    cd_.h_bk.p[c] = b < 0 ? (uint16_t)c : (uint16_t)slot(b);
+  }
+  for (int k = 1; k <= total; k++) cd_.h_order.p[k - 1] = (uint16_t)slot(nodep_[(size_t)k]);
+  ClimbHeader h;
+  std::memset(&h, 0, sizeof(h));
+  h.rng = rng_.state;
+  h.hits = hits_;
+  h.best = best_;
+  h.randomMP = *randomMP;
+  h.iter_hits = *iter_hits;
+  h.pos = (uint32_t)*i;
+  h.insert_cid = insert_rec_ >= 0 ? (int32_t)slot(insert_rec_) : -1;
+  h.remove_cid = remove_rec_ >= 0 ? (int32_t)slot(remove_rec_) : -1;
+  h.since_move = 0;
+  h.batch = 0;
+  std::memcpy(cd_.h_out.p, &h, sizeof(h));
+  ClimbParams p;
+  p.vec = d_vec_;
+  p.n = (uint32_t)n_;
+  p.nslots = (uint32_t)ns;
+  p.Wp = (uint32_t)g_.Wp;
+  p.tiles = (uint32_t)tiles;
+  p.total = (uint32_t)total;
+  p.maxtrav = (uint32_t)maxtrav_eff;
+  p.tie_mode = (uint32_t)tie_mode_;
+  p.idle_limit = may_idle ? (uint32_t)climb_idle_ : 0u;
+  p.max_moves = (uint32_t)total;
+  p.batch_min = (uint32_t)std::max(1, std::min(climb_batch_min_, 8));
+  p.batch_max = (uint32_t)std::max((int)p.batch_min, std::min(climb_batch_max_, 8));
+  p.order = cd_.order.p;
+  p.bk = cd_.bk.p;
+  p.sct = cd_.sct.p;
+  p.gsum = cd_.gsum.p;
+  p.hdr = reinterpret_cast<ClimbHeader *>(cd_.out.p);
+  p.moves = cd_.out.p + hdr_words;
+  p.trace = nullptr;
+  p.trace_cap = 0;
+  p.beat = nullptr;
+  if (climb_trace_) {
+    HIPCHK(cd_.h_beat.reserve(32));
+    std::memset(cd_.h_beat.p, 0, 32 * sizeof(uint32_t));
+    p.beat = cd_.h_beat.p;
+    const size_t cap = 1u << 16;
+    HIPCHK(cd_.trace.reserve(8 * cap));
+    p.trace = cd_.trace.p;
+    p.trace_cap = (uint32_t)cap;
+  }
+  HIPCHK(hipMemcpyAsync(cd_.bk.p, cd_.h_bk.p, ns * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemcpyAsync(cd_.order.p, cd_.h_order.p, (size_t)total * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemcpyAsync(cd_.out.p, cd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemsetAsync(cd_.gsum.p, 0, 3 * (size_t)kClimbCap * sizeof(unsigned long long), st_));
+  HIPCHK(launch_climb(st_, g_, vw, p));
+  HIPCHK(hipMemcpyAsync(cd_.h_out.p, cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  {
+    // a sweep segment takes milliseconds; a launch that is still running after many seconds will not come back (every wait
+    // inside the kernel is bounded) -- report that instead of blocking the caller for ever
+    const auto w0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    long spins = 0;
+    while ((q = hipStreamQuery(st_)) == hipErrorNotReady) {
+      if ((++spins & 63) == 0) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > (climb_trace_ ? 4.0 : 20.0)) {
+          std::string where;
+          if (p.beat) for (int k = 0; k < 32; k++) where += " " + std::to_string(cd_.h_beat.p[k]);
+          set_error("device climb: the launch did not finish within 20 s" + (where.empty() ? std::string() : " (step phase pos B ncand nops chains done err:" + where + ")"));
+          return MPF_E_STATE;
+        }
+        std::this_thread::yield();
+      }
+    }
+    if (q != hipSuccess) { set_error(std::string("device climb: ") + hipGetErrorString(q)); return MPF_E_HIP; }
+  }
+  std::memcpy(&h, cd_.h_out.p, sizeof(h));
+  *reason = h.reason;
+  *n_moves = 0;
+  stats.climb_launches++;
+  if (h.reason == CLIMB_ABORT) {
+    stats.climb_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MPF_OK;                                // nothing was changed: the caller goes on with host-driven batches
+  }
+  if (h.reason == CLIMB_ERROR || h.reason == CLIMB_RUNNING || h.n_moves > (uint32_t)total) {
+    set_error("device climb: internal error " + std::to_string(h.err) + " (reason " + std::to_string(h.reason) + ")");
+    return MPF_E_STATE;
+  }
+  if (climb_trace_) {
+    const size_t nrec = std::min<size_t>(h.pad[0], 1u << 16);
+    const size_t at = cd_.h_trace.size();
+    cd_.h_trace.resize(at + 8 * nrec);
+    if (nrec) HIPCHK(hipMemcpy(cd_.h_trace.data() + at, cd_.trace.p, 8 * nrec * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    cd_.trace_records += nrec;
+  }
+  // replay: restoreTreeRearrangeParsimony on the mirror, link by link as apply_move does
+  const uint32_t *mv = cd_.h_out.p + hdr_words;
+  for (uint32_t m = 0; m < h.n_moves; m++) {
+    const int pr = rec_of(mv[3 * m]), qr = rec_of(mv[3 * m + 1]);
+    moves_.push_back(Move{pr, qr, mv[3 * m + 2]});
+    const int a = back_[nx(pr)], b = back_[nx(nx(pr))];
+    hookup(a, b);
+    const int r = back_[qr];
+    hookup(nx(pr), qr);
+    hookup(nx(nx(pr)), r);
+    stats.moves_applied++;
+  }
+  invalidate_all();
+  rng_.state = h.rng;
+  hits_ = (unsigned long)h.hits;
+  best_ = h.best;
+  *randomMP = h.randomMP;
+  *iter_hits = h.iter_hits;
+  *i = (int)h.pos;
+  insert_rec_ = h.insert_cid >= 0 ? rec_of((uint32_t)h.insert_cid) : -1;
+  remove_rec_ = h.remove_cid >= 0 ? rec_of((uint32_t)h.remove_cid) : -1;
+  *n_moves = h.n_moves;
+  stats.insertion_tests += h.n_tests;
+  stats.algorithmic_bytes += h.n_tests * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  stats.climb_steps += h.steps;
+  stats.climb_nodes += h.n_scanned_nodes;
+  stats.climb_moves += h.n_moves;
+  stats.climb_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MPF_OK;
+}
+
+}  // namespace mpf

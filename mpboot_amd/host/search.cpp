@@ -9,6 +9,7 @@
 // the next prune node, so the trajectory is the reference's.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 
 #include "../csrc/engine.hpp"
 #include "simd_util.hpp"
@@ -44,11 +45,42 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
   std::vector<ScanPlan> &plans = sweep_plans_;
   const uint32_t *out = nullptr;
   int batch = first_batch();
+  // While accepted moves are dense every move depends on the one before it and a host-driven batch is one launch chain
+  // + one synchronisation per move: those stretches run inside ONE persistent kernel per sweep (k_climb, csrc/climb.hip),
+  // which hands back when moves get rare -- there the host's whole-chip batches are the better tool.  Same trajectory
+  // either way (the kernel follows the same rules with the same tie stream); a host-supplied random_double() callback
+  // keeps the loop on the host.
+  const int mt_eff = std::min(maxtrav, ntips_ - 3);
+  bool dev_ok = climb_device_ > 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff);
+  uint32_t sweep_moves = 0;
+  bool first_sweep = true;
   do {
     startMP = randomMP;
     node_rectifier();
     int i = 1;
+    // (auto mode: a sweep starts on the device if moves were dense lately -- an engine that has just refined nearly optimal
+    //  trees starts on the host)
+    bool dev = dev_ok && (climb_device_ >= 2 || (first_sweep ? (gap_est_ < 0 || gap_est_ < 64.0) : sweep_moves >= 16u));
+    first_sweep = false;
+    sweep_moves = 0;
     while (i <= total) {
+      if (dev) {
+        uint32_t reason = 0, nm = 0;
+        const int i0 = i;
+        int rc = climb_segment(mt_eff, total, &i, &randomMP, &iter_hits, climb_device_ < 2, &reason, &nm);
+        if (rc) return rc;
+        if (reason == CLIMB_ABORT) { dev = dev_ok = false; continue; }
+        sweep_moves += nm;
+        if (nm) {
+          const double g = (double)(i - i0) / (double)nm;
+          gap_est_ = gap_est_ < 0 ? g : std::exp(0.7 * std::log(gap_est_ + 1.0) + 0.3 * std::log(g + 1.0)) - 1.0;
+          since_move_ = 0;
+        } else {
+          since_move_ += i - i0;
+        }
+        if (reason == CLIMB_IDLE) { dev = false; batch = std::min(total, std::max(batch, 64)); }
+        continue;
+      }
       const int hi = std::min(total, i + batch - 1);
       int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
       if (rc) return rc;
@@ -106,6 +138,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
           apply_move(remove_rec_, insert_rec_);
           randomMP = best_;
           moved = true;
+          sweep_moves++;
         }
       }
       batch = next_batch(batch, moved, j - i, total);
