@@ -465,7 +465,7 @@ __device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh)
 // ---- (4) one part of a scan: addTraverseParsimony + testInsertParsimony (:2208-2218, :2106-2160) below one first-level
 // child of one gap end, both children of a node expanded together (one vector read per insertion test)
 template <int KS, int VW>
-__device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t pi, uint32_t maxtrav, uint32_t *dbg)
+__device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t pi, uint32_t maxtrav)
 {
   const uint32_t n = K.n;
   const int lane = K.lane;
@@ -486,13 +486,10 @@ __device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t 
     if (lane == 0) { K.cost[out_base + k] = cst; K.cq[out_base + k] = (uint16_t)cid; }
     k++;
   };
-#define SBEAT(v) do { if (dbg && lane == 0) __hip_atomic_store(dbg, (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
   for (uint32_t it = 0;; it++) {
     if (it > 256u) { if (lane == 0) sh.err = 6u; break; }
-    SBEAT(0x1000u | (it << 4) | 1u);
     const uint32_t r1 = nxc(node, n);
     const uint32_t c1 = rfl((uint32_t)K.bk[r1]), c2 = rfl((uint32_t)K.bk[nxc(r1, n)]);
-    SBEAT(0x1000u | (it << 4) | 2u);
     ld<KS, VW>(K, d1, c1);
     ld<KS, VW>(K, d2, c2);
     const uint32_t dd = d + 1u;
@@ -504,9 +501,7 @@ __device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t 
     if (test) {
       uint32_t cst = q_join<KS, VW>(u1, d1, sv) | (q_join<KS, VW>(u2, d2, sv) << 16);
       cst = K.cnt_lane ? cst : 0u;
-      SBEAT(0x1000u | (it << 4) | 3u);
       tot = wave_total(cst);
-      SBEAT(0x1000u | (it << 4) | 4u);
     }
     if (own2 && deeper && c2 >= n) {
 #pragma unroll
@@ -518,7 +513,6 @@ __device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t 
     if (test && own1) emit(tot & 0xFFFFu, c1);
     if (own1 && deeper && c1 >= n) { par = u1; node = c1; d = dd; continue; }
     bool more = false;
-    SBEAT(0x1000u | (it << 4) | 5u);
     while (sp > 0) {
       sp--;
       const uint2 fr = stk[sp];
@@ -536,8 +530,6 @@ __device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t 
     }
     if (!more) break;
   }
-  SBEAT(0x2000u);
-#undef SBEAT
   if (lane == 0 && k != sh.pcnt[pi]) sh.err = 100u + pi;   // the walk and the enumeration disagree: never on a consistent tree
 }
 
@@ -819,7 +811,7 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
         if (P.beat && tile == 0 && lane == 0) __hip_atomic_store(P.beat + 16 + wave, t | 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (t >= nparts) break;
         if (sh.pcnt[t] == 0u) continue;
-        scan_part<KS, VW>(K, sh, t, P.maxtrav, (P.beat && tile == 0) ? P.beat + 24 + wave : nullptr);
+        scan_part<KS, VW>(K, sh, t, P.maxtrav);
       }
       if (P.beat && tile == 0 && lane == 0) __hip_atomic_store(P.beat + 16 + wave, 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -19,6 +19,7 @@ ap.add_argument("--mode", type=int, default=2)
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--radius", type=int, default=6)
 ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--notrace", action="store_true")
 a = ap.parse_args()
 
 
@@ -46,7 +47,7 @@ def run(codes, dt, back, mode, seed, tie, radius, trace=False, opts=()):
 
 def compare(name, codes, dt, back, seed, tie, radius):
     h = run(codes, dt, back, 0, seed, tie, radius)
-    d = run(codes, dt, back, a.mode, seed, tie, radius, trace=True, opts=[(k, int(v)) for k, v in (o.split("=") for o in a.opt)])
+    d = run(codes, dt, back, a.mode, seed, tie, radius, trace=not a.notrace, opts=[(k, int(v)) for k, v in (o.split("=") for o in a.opt)])
     hm = np.stack([np.asarray(x) for x in h["moves"]], axis=1) if len(h["moves"][0]) else np.zeros((0, 3), int)
     dm = np.stack([np.asarray(x) for x in d["moves"]], axis=1) if len(d["moves"][0]) else np.zeros((0, 3), int)
     ok = h["s"] == d["s"] and hm.shape == dm.shape and (hm == dm).all() and (h["tree"] == d["tree"]).all()
