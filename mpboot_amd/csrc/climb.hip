@@ -31,13 +31,31 @@ constexpr int kNW = 8;                       // waves per workgroup
 constexpr int kThreads = kNW * 64;
 constexpr int kMaxB = 8;                     // prune nodes per step
 constexpr int kMaxUnits = 2 * kMaxB;         // (prune node, side)
-constexpr int kMaxParts = 4 * kMaxUnits;     // (prune node, side, gap end, first-level child)
+constexpr int kMaxParts = 2 * kMaxUnits;     // (prune node, side, gap end): one DFS program each
 constexpr int kDepth = 6;                    // deepest radius
+constexpr int kProgStride = 64;              // program entries per part: at most 63 expansions at radius 6
 constexpr uint32_t kNone16 = 0xFFFFu;
-// heap lanes (root 1, children 2h / 2h + 1) below the root's first / second child
-constexpr unsigned long long kSub0 = (1ull << 2) | (3ull << 4) | (0xFull << 8) | (0xFFull << 16) | (0xFFFFull << 32);
-constexpr unsigned long long kSub1 = (1ull << 3) | (3ull << 6) | (0xFull << 12) | (0xFFull << 24) | (0xFFFFull << 48);
 constexpr unsigned long long kValMask = (1ull << 40) - 1ull;
+// heap lanes (root 1, children 2h / 2h + 1) in the subtree of the root's first child
+constexpr unsigned long long kLeftSub = (1ull << 2) | (3ull << 4) | (0xFull << 8) | (0xFFull << 16) | (0xFFFFull << 32);
+// claim word of a vector: epoch << 17 | index among the step's refresh ops << 3 | stale inputs not yet recomputed
+constexpr int kEpochShift = 17;
+constexpr uint32_t kIdxMask = 0x3FFFu;
+constexpr uint32_t kEpochLimit = 32000u;     // (15 bits; a launch that gets there hands back and is started again)
+// Refresh programs: the first kLcap ops of a step's closure get descriptors (consumers, operand slots); larger closures (the
+// first step of a launch recomputes ~n vectors) run on the plain dataflow path.
+constexpr uint32_t kLcap = 256;
+constexpr uint32_t kNoSlot = 0xFFu;
+template <int KS, int VW> struct Cfg {
+  static constexpr int R = KS * VW;                                   // registers per vector tile
+  static constexpr int PF = R <= 2 ? 8 : R == 4 ? 4 : 2;              // expansions whose child vectors are requested together
+  // operand slots of the refresh (vector + per-lane subtree scores) and the parked up-vectors of the scan are never alive
+  // together: one LDS region serves both
+  static constexpr size_t kSlotBytes = (size_t)(R + 1) * 64 * 4;
+  static constexpr size_t kPendBytes = (size_t)8 * 5 * R * 64 * 4;
+  static constexpr size_t kRegion = 65536;
+  static constexpr uint32_t kSlots = kRegion / kSlotBytes < 254 ? (uint32_t)(kRegion / kSlotBytes) : 254u;
+};
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -62,17 +80,40 @@ __device__ __forceinline__ uint32_t wave_total(uint32_t v)
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// one atomic per wave whose result every lane needs: issued by ALL lanes (lane 0 adds v, the others 0) and read back from
-// lane 0.  The obvious form -- `if (lane == 0) old = atomic(...); old = readfirstlane(old);` -- is not safe here: hipcc
-// (ROCm 7.2) threads the lanes that skip the branch past it into the next loop iteration with their own constant, so that
-// they reach the readfirstlane without lane 0 (seen in the ISA of the scan's task loop: an endless loop of lanes 1..63).
+// One LDS atomic per wave whose result every lane needs (call with all lanes active).  Two obvious forms do not work here:
+//  * `if (lane == 0) old = atomic(...); old = readfirstlane(old);` -- hipcc (ROCm 7.2) threads the lanes that skip the branch
+//    past it into the next loop iteration with their own constant, so that they reach the readfirstlane without lane 0 (seen
+//    in the ISA of the scan's task loop: an endless loop of lanes 1..63);
+//  * issuing the atomic from all lanes with the value masked to lane 0 -- the atomic optimizer turns that into a loop over
+//    the 64 active lanes (~2 us per call, measured: it was half of the scan phase).
+// So the single-lane form is written out: EXEC narrowed to lane 0 around one ds instruction.
 __device__ __forceinline__ uint32_t wave_fetch_add(uint32_t *p, uint32_t v, int lane)
 {
-  return rfl(__hip_atomic_fetch_add(p, lane == 0 ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  (void)lane;
+  uint32_t old;
+  unsigned long long sv;
+  const uint32_t addr = (uint32_t)(uintptr_t)p;          // LDS offset (the low half of a flat LDS address)
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, 1\n\t"
+               "ds_add_rtn_u32 %0, %2, %3\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "s_mov_b64 exec, %1"
+               : "=&v"(old), "=&s"(sv) : "v"(addr), "v"(v) : "memory");
+  return rfl(old);
 }
 __device__ __forceinline__ uint32_t wave_fetch_sub(uint32_t *p, uint32_t v, int lane)
 {
-  return rfl(__hip_atomic_fetch_sub(p, lane == 0 ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  (void)lane;
+  uint32_t old;
+  unsigned long long sv;
+  const uint32_t addr = (uint32_t)(uintptr_t)p;
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, 1\n\t"
+               "ds_sub_rtn_u32 %0, %2, %3\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "s_mov_b64 exec, %1"
+               : "=&v"(old), "=&s"(sv) : "v"(addr), "v"(v) : "memory");
+  return rfl(old);
 }
 
 #define MPF_B3_ANDOR 0xEA   // (a & b) | c
@@ -173,10 +214,15 @@ struct Sh {
   uint32_t best, randomMP, iter_hits;
   int32_t ins, rem;
   unsigned long long rng, hits, n_tests, n_ops, draws, n_nodes;
-  uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n;
+  uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, dbg, pn_base[kMaxB];
   Unit unit[kMaxUnits];
-  uint32_t pcnt[kMaxParts], poff[kMaxParts];
+  uint32_t pcnt[kMaxParts], poff[kMaxParts], pE[kMaxParts];
   uint32_t pn_off[kMaxB], pn_cnt[kMaxB], pn_np[kMaxB], pn_p[kMaxB];
+  uint32_t ntasks;
+  uint8_t tl[2 * kMaxParts];                  // scan tasks of the step: part << 1 | half
+  unsigned long long tph[16], tlast;          // time per phase (100 MHz ticks), workgroup 0
+  uint32_t c_rounds, c_inv, c_chains, c_parts, c_inv2, c_dynops;
+  unsigned long long clk0, rt0;
 };
 
 template <int KS, int VW>
@@ -188,12 +234,20 @@ struct Kx {
   uint32_t *cost;    // per candidate: this tile's share, after the exchange the length
   uint16_t *cq;      // per candidate: the insertion branch
   uint32_t *pend;    // [wave][depth][KS * VW][64] up-vectors of second children waiting for their turn
-  uint2 *frames;     // [wave][8]
-  uint32_t *sct;     // this tile's subtree scores (global)
+  uint2 *prog;       // [part][64] DFS programs of the step's scans
+  uint32_t *stage;   // [kSlots][R + 1][64] operand slots of the refresh: vector registers + per-lane subtree scores
+  uint2 *D;          // [kLcap] refresh op: r | slot of operand a << 16 | slot of operand b << 24 ; a | b << 16
+  uint2 *CONS;       // [kLcap][2] who consumes an op's result: consumer idx | which << 8 | its stale inputs << 9 | slot of its other operand << 16 ; consumer's vector | other operand's vector << 16
+  uint32_t *NC;      // [kLcap] number of consumers registered
+  uint32_t *PEND;    // [kLcap] stale inputs not yet recomputed (joins)
+  uint16_t *OL;      // [kLcap] the first refresh ops, by index
+  uint16_t *ord;     // [total] the sweep's visiting order
+  unsigned long long pre, ancl, lsub;   // heap-index relations of this lane (enumeration)
   uint32_t n, ns, SW4;
   int lane, wave;
-  __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t voff[KS];
+  __amdgpu_buffer_rsrc_t rsrc, rsrc_s;   // the vector store; this tile's per-lane subtree scores [vector][16 word groups]
+  uint32_t voff[KS], svoff;
+  uint32_t zero;     // 0, opaque to the compiler (keeps per-lane LDS adds from being folded into a wave reduction)
   bool cnt_lane;     // this lane's popcounts count (first lane of a quad, inside the row)
   bool st_lane;      // this lane's words exist
 };
@@ -201,10 +255,18 @@ struct Kx {
 template <int KS, int VW>
 __device__ __forceinline__ void ld(const Kx<KS, VW> &K, QT<KS, VW> &t, uint32_t cid) { qload<KS, VW>(t, K.rsrc, K.voff, cid * K.SW4); }
 
+// tr->parsimonyScore[] (reference sprparsimony.cpp:874) of this tile, kept PER LANE: every lane of a quad holds the mutations
+// of its word group in the subtree, so a refresh op adds three registers and no reduction across lanes is needed until a
+// prune branch's base length is wanted
 template <int KS, int VW>
-__device__ __forceinline__ uint32_t ld_sct(const Kx<KS, VW> &K, uint32_t cid)
+__device__ __forceinline__ uint32_t ld_sl(const Kx<KS, VW> &K, uint32_t cid)
 {
-  return cid < K.n ? 0u : __hip_atomic_load(K.sct + cid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return cid < K.n ? 0u : __builtin_amdgcn_raw_buffer_load_b32(K.rsrc_s, K.svoff, cid * 64u, 0);
+}
+template <int KS, int VW>
+__device__ __forceinline__ void st_sl(const Kx<KS, VW> &K, uint32_t cid, uint32_t v)
+{
+  if (K.cnt_lane) __builtin_amdgcn_raw_buffer_store_b32(v, K.rsrc_s, K.svoff, cid * 64u, 0);
 }
 
 // a vector the scans of this step read: if it is stale, claim it for the refresh (once per step)
@@ -212,23 +274,28 @@ template <int KS, int VW>
 __device__ __forceinline__ void require(const Kx<KS, VW> &K, Sh &sh, uint32_t c, uint32_t epoch)
 {
   if (c >= K.n && !K.valid[c]) {
-    const uint32_t old = __hip_atomic_fetch_max(&K.cl[c], epoch << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if ((old >> 8) != epoch) {
+    const uint32_t old = __hip_atomic_fetch_max(&K.cl[c], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((old >> kEpochShift) != epoch) {
       const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       K.W[slot] = (uint16_t)c;
     }
   }
 }
 
-// ---- (1) one side of one prune node: which scans exist (rearrangeParsimony's tests, :2304-2310, :2330-2347), how many
-// insertion tests each part holds, which vectors they read
+// ---- (1) one side of one prune node: which scans exist (rearrangeParsimony's tests, :2304-2310, :2330-2347) and, per gap
+// end, the DFS of addTraverseParsimony (:2208-2218) as a program.  Lane h is the heap index of an expansion (root 1 = the gap
+// end itself, children 2h / 2h + 1, depth <= 5 at radius 6) and walks down from the root by the bits of h -- at most six
+// dependent LDS rounds for a whole neighbourhood.  Pre-order positions and the reference's candidate indices follow from
+// ballots and fixed heap relations: an expansion's entry goes to prog[#expansions before it in pre-order]; its first
+// candidate's index is 2 * #tested expansions before it - #tested ancestors whose LEFT subtree holds it (those have emitted
+// one candidate so far, the others two), the second one follows the left subtree's candidates.
 template <int KS, int VW>
 __device__ __forceinline__ void enum_unit(const Kx<KS, VW> &K, Sh &sh, const ClimbParams &P, uint32_t u)
 {
   const uint32_t n = K.n, epoch = sh.epoch;
   const int lane = K.lane;
   const uint32_t j = u >> 1, side = u & 1u;
-  const uint32_t p = rfl((uint32_t)P.order[sh.pos - 1u + j]);
+  const uint32_t p = rfl((uint32_t)K.ord[sh.pos - 1u + j]);
   const uint32_t q = rfl((uint32_t)K.bk[p]);
   const uint32_t x = side ? q : p, s = side ? p : q;
   const uint32_t mt = side ? 2u : 1u;                   // the q side does not test the first level (mintrav2 = 2)
@@ -246,7 +313,7 @@ __device__ __forceinline__ void enum_unit(const Kx<KS, VW> &K, Sh &sh, const Cli
       app = da || db;
     }
   }
-  uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+  uint32_t cnt[2] = {0u, 0u}, ne[2] = {0u, 0u};
   if (app) {
     const int h = lane;                                  // heap index of an expansion; lane 0 idles
     const int d = h ? 31 - __builtin_clz((unsigned)h) : -1;
@@ -271,21 +338,25 @@ __device__ __forceinline__ void enum_unit(const Kx<KS, VW> &K, Sh &sh, const Cli
         c2 = K.bk[nxc(r1, n)];
       }
       const bool tested = ex && (uint32_t)(d + 1) >= mt;
-      const unsigned long long Tm = __ballot((int)tested);
-      const uint32_t root = (uint32_t)((Tm >> 1) & 1ull);
-      const uint32_t c0n = root + 2u * (uint32_t)__builtin_popcountll(Tm & kSub0);
-      const uint32_t c1n = root + 2u * (uint32_t)__builtin_popcountll(Tm & kSub1);
-      cnt[2 * e] = c0n;
-      cnt[2 * e + 1] = c1n;
-      const bool walk0 = c0n > 0, walk1 = c1n > 0;
-      const bool need = ex && (h == 1 ? (walk0 || walk1) : (((kSub0 >> h) & 1ull) ? walk0 : walk1));
-      if (need) {
+      const unsigned long long Em = __ballot((int)ex), Tm = __ballot((int)tested);
+      const uint32_t part = 2u * u + e;
+      cnt[e] = 2u * (uint32_t)__builtin_popcountll(Tm);
+      ne[e] = cnt[e] ? (uint32_t)__builtin_popcountll(Em) | ((uint32_t)__builtin_popcountll(Em & kLeftSub) << 8) : 0u;   // expansions | of them below the root's first child
+      if (ex && cnt[e]) {
+        const uint32_t pos = (uint32_t)__builtin_popcountll(Em & K.pre);
+        const uint32_t k1 = 2u * (uint32_t)__builtin_popcountll(Tm & K.pre) - (uint32_t)__builtin_popcountll(Tm & K.ancl);
+        const uint32_t k2 = k1 + 1u + 2u * (uint32_t)__builtin_popcountll(Tm & K.lsub);
+        const uint32_t save2 = (h < 32 && ((Em >> (2 * h + 1)) & 1ull)) ? 1u : 0u;   // the second child is expanded later: keep its up-vector
+        const uint32_t fp = (h > 1 && (h & 1)) ? 1u : 0u;                            // this node IS a second child: its up-vector waits in LDS
+        K.prog[part * kProgStride + pos] =
+            make_uint2(c1 | (c2 << 16), (uint32_t)(d + 1) | (tested ? 16u : 0u) | (save2 << 5) | (fp << 6) | (k1 << 8) | (k2 << 16));
+        if (tested) { K.cq[part * 128u + k1] = (uint16_t)c1; K.cq[part * 128u + k2] = (uint16_t)c2; }   // the insertion branches by candidate index
         require<KS, VW>(K, sh, c1, epoch);
         require<KS, VW>(K, sh, c2, epoch);
       }
-      if (lane == 0 && (walk0 || walk1)) require<KS, VW>(K, sh, other, epoch);
+      if (lane == 0 && cnt[e]) require<KS, VW>(K, sh, other, epoch);
     }
-    if (lane == 0 && (cnt[0] | cnt[1] | cnt[2] | cnt[3])) {
+    if (lane == 0 && (cnt[0] | cnt[1])) {
       require<KS, VW>(K, sh, s, epoch);                  // the pruned subtree, and both ends of the prune branch for the base length
       require<KS, VW>(K, sh, x, epoch);
     }
@@ -294,8 +365,8 @@ __device__ __forceinline__ void enum_unit(const Kx<KS, VW> &K, Sh &sh, const Cli
     Unit un;
     un.x = (uint16_t)x; un.s = (uint16_t)s; un.xa = (uint16_t)xa; un.xb = (uint16_t)xb; un.mt = (uint16_t)mt; un.p = (uint16_t)p;
     sh.unit[u] = un;
-#pragma unroll
-    for (int i = 0; i < 4; i++) sh.pcnt[4u * u + (uint32_t)i] = cnt[i];
+    sh.pcnt[2u * u] = cnt[0]; sh.pcnt[2u * u + 1u] = cnt[1];
+    sh.pE[2u * u] = ne[0]; sh.pE[2u * u + 1u] = ne[1];
   }
 }
 
@@ -305,8 +376,8 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
 {
   const int lane = K.lane;
   const uint32_t n = K.n, epoch = sh.epoch, B = sh.B;
-  // candidates are laid out part after part = the reference's order (p side: first gap end, its first child's subtree, ...)
-  const uint32_t nparts = 8u * B;
+  // candidates are laid out part after part = the reference's order (p side: first gap end, second gap end; then the q side)
+  const uint32_t nparts = 4u * B;
   const uint32_t c = (uint32_t)lane < nparts ? sh.pcnt[lane] : 0u;
   uint32_t incl = c;
 #pragma unroll
@@ -315,29 +386,43 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
     if (lane >= o) incl += t;
   }
   // speculation is cut where the step's candidate buffer ends (one prune node never exceeds it)
-  const unsigned long long fits = __ballot((lane & 7) == 7 && (uint32_t)lane < nparts && incl <= kClimbCap);
+  const unsigned long long fits = __ballot((lane & 3) == 3 && (uint32_t)lane < nparts && incl <= kClimbCap);
   const uint32_t Beff = (uint32_t)__builtin_popcountll(fits);
-  const uint32_t tot_eff = (uint32_t)__shfl((int)incl, (int)(8u * Beff) - 1, 64);
+  const uint32_t tot_eff = (uint32_t)__shfl((int)incl, (int)(4u * Beff) - 1, 64);
   const uint32_t excl = incl - c;
-  const uint32_t e4 = (uint32_t)__shfl((int)incl, (lane & ~7) + 3, 64), e8 = (uint32_t)__shfl((int)incl, (lane & ~7) + 7, 64);
+  const uint32_t e2 = (uint32_t)__shfl((int)incl, (lane & ~3) + 1, 64), e4 = (uint32_t)__shfl((int)incl, (lane & ~3) + 3, 64);
   if ((uint32_t)lane < nparts) {
-    const bool live = (uint32_t)(lane >> 3) < Beff;
+    const bool live = (uint32_t)(lane >> 2) < Beff;
     sh.poff[lane] = excl;
-    if (!live) sh.pcnt[lane] = 0u;
-    if ((lane & 7) == 0 && live) {
-      const int j = lane >> 3;
+    if (!live) { sh.pcnt[lane] = 0u; sh.pE[lane] = 0u; }
+    if ((lane & 3) == 0 && live) {
+      const int j = lane >> 2;
       sh.pn_off[j] = excl;
-      sh.pn_cnt[j] = e8 - excl;
-      sh.pn_np[j] = e4 - excl;
+      sh.pn_cnt[j] = e4 - excl;
+      sh.pn_np[j] = e2 - excl;
       sh.pn_p[j] = sh.unit[2 * j].p;
     }
   }
   if (lane == 0) { sh.Beff = Beff; sh.ncand = Beff ? tot_eff : 0u; }
-  // closure: every lane follows one chain of stale inputs; forks go to the shared worklist
+  {
+    // the scan's task list: one entry per program, two for a long one (scan_part); dealt to the waves round-robin
+    const bool live = (uint32_t)lane < nparts && (uint32_t)(lane >> 2) < Beff;
+    const uint32_t E = live ? (sh.pE[lane] & 0xFFu) : 0u;
+    const uint32_t nt = E == 0u ? 0u : E >= 6u ? 2u : 1u;
+    const unsigned long long m1 = __ballot((int)(nt >= 1u)), m2 = __ballot((int)(nt == 2u));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t at = (uint32_t)__builtin_popcountll(m1 & lt) + (uint32_t)__builtin_popcountll(m2 & lt);
+    if (nt >= 1u) sh.tl[at] = (uint8_t)(lane << 1);
+    if (nt == 2u) sh.tl[at + 1u] = (uint8_t)((lane << 1) | 1);
+    if (lane == 0) sh.ntasks = (uint32_t)__builtin_popcountll(m1) + (uint32_t)__builtin_popcountll(m2);
+  }
+  // closure: every lane follows one chain of stale inputs; forks go to the shared worklist.  Every vector gets an index (the
+  // order in which the lanes take them up); the first kLcap are listed for the link pass below.
   uint32_t head = 0, tail = sh.wtail, nops = 0;
   bool have = false;
   uint32_t item = 0;
-  for (uint32_t round = 0;; round++) {
+  uint32_t round = 0;
+  for (;; round++) {
     if (round > K.ns) { if (lane == 0) sh.err = 3u; break; }
     {
       const unsigned long long need = __ballot((int)!have);
@@ -349,21 +434,24 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
     }
     const unsigned long long act = __ballot((int)have);
     if (!act) break;
-    nops += (uint32_t)__builtin_popcountll(act);
     bool push = false;
     uint32_t pv = 0;
     if (have) {
       const uint32_t r = item;
+      const uint32_t idx = nops + (uint32_t)__builtin_popcountll(act & ((1ull << lane) - 1ull));
       const uint32_t r1 = nxc(r, n);
       const uint32_t a = K.bk[r1], b = K.bk[nxc(r1, n)];
+      // (the claims go out together with the validity reads -- one LDS round trip instead of two; a claim on a vector that
+      //  turns out to be valid, or on a tip, means nothing: only stale vectors are ever looked up by their claim)
+      const uint32_t oa = __hip_atomic_fetch_max(&K.cl[a], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t ob = __hip_atomic_fetch_max(&K.cl[b], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const bool sa = a >= n && !K.valid[a], sb = b >= n && !K.valid[b];
-      bool wa = false, wb = false;
-      if (sa) wa = (__hip_atomic_fetch_max(&K.cl[a], epoch << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 8) != epoch;
-      if (sb) wb = (__hip_atomic_fetch_max(&K.cl[b], epoch << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 8) != epoch;
+      const bool wa = sa && (oa >> kEpochShift) != epoch, wb = sb && (ob >> kEpochShift) != epoch;
       const uint32_t ns = (sa ? 1u : 0u) + (sb ? 1u : 0u);
-      if (ns) {
-        K.cl[r] = (epoch << 8) | ns;                     // (r is claimed already: other lanes' fetch_max leave the word as it is)
-      } else {
+      // (r is claimed already: other lanes' fetch_max leave the word as it is)
+      K.cl[r] = (epoch << kEpochShift) | ((idx < kIdxMask ? idx : kIdxMask) << 3) | ns;
+      if (idx < kLcap) K.OL[idx] = (uint16_t)r;
+      if (!ns) {
         const uint32_t slot = __hip_atomic_fetch_add(&sh.rtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         K.R[slot] = (uint16_t)r;                         // both inputs valid: a chain starts here
       }
@@ -371,20 +459,231 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
       else if (wb) item = b;
       else have = false;
     }
+    nops += (uint32_t)__builtin_popcountll(act);
     const unsigned long long pm = __ballot((int)push);
     if (push) K.W[tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (uint16_t)pv;
     tail += (uint32_t)__builtin_popcountll(pm);
   }
-  if (lane == 0) sh.nops = nops;
+  if (lane == 0) { sh.nops = nops; sh.n_ops += nops; sh.c_rounds += round; sh.c_chains += sh.rtail; }
+  // link pass: every op of a closure that fits gets a descriptor, a slot for each operand that is valid already (staged into
+  // LDS before the chains start), and registers with its stale inputs as their consumer -- what a chain needs to go from one
+  // link to the next is then ONE entry, read a link ahead
+  const bool linkable = nops > 0 && nops <= kLcap;
+  uint32_t mode = linkable ? 1u : 0u;
+  if (linkable) {
+    uint32_t slot_base = 0, nstart = 0;
+    for (uint32_t base = 0; base < nops; base += 64u) {
+      const uint32_t i = base + (uint32_t)lane;
+      const bool act = i < nops;
+      uint32_t r = 0, a = 0, b = 0;
+      bool sa = false, sb = false;
+      if (act) {
+        r = K.OL[i];
+        const uint32_t r1 = nxc(r, n);
+        a = K.bk[r1];
+        b = K.bk[nxc(r1, n)];
+        sa = a >= n && !K.valid[a];
+        sb = b >= n && !K.valid[b];
+      }
+      const uint32_t nst = (sa ? 1u : 0u) + (sb ? 1u : 0u);
+      // an operand gets a slot if it is valid (staged from memory before the chains start) or if the op is a join of two
+      // stale inputs (whoever arrives first leaves its result there for the other one)
+      const bool wa = act && (!sa || nst == 2u), wb = act && (!sb || nst == 2u);
+      const unsigned long long ma = __ballot((int)wa), mb = __ballot((int)wb);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      uint32_t s0 = slot_base + (uint32_t)__builtin_popcountll(ma & lt) + (uint32_t)__builtin_popcountll(mb & lt);
+      uint32_t slotA = kNoSlot, slotB = kNoSlot;
+      if (wa) { slotA = s0 < Cfg<KS, VW>::kSlots ? s0 : kNoSlot; s0++; }
+      if (wb) slotB = s0 < Cfg<KS, VW>::kSlots ? s0 : kNoSlot;
+      slot_base += (uint32_t)__builtin_popcountll(ma) + (uint32_t)__builtin_popcountll(mb);
+      if (act) {
+        K.D[i] = make_uint2(r | (slotA << 16) | (slotB << 24), a | (b << 16));
+        K.PEND[i] = nst;
+        if (sa) {
+          const uint32_t ik = (K.cl[a] >> 3) & kIdxMask;
+          const uint32_t sl = __hip_atomic_fetch_add(&K.NC[ik], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (sl < 2u) K.CONS[2u * ik + sl] = make_uint2(i | (0u << 8) | (nst << 9) | (slotB << 16) | (slotA << 24), r | (b << 16));
+        }
+        if (sb) {
+          const uint32_t ik = (K.cl[b] >> 3) & kIdxMask;
+          const uint32_t sl = __hip_atomic_fetch_add(&K.NC[ik], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (sl < 2u) K.CONS[2u * ik + sl] = make_uint2(i | (1u << 8) | (nst << 9) | (slotA << 16) | (slotB << 24), r | (a << 16));
+        }
+      }
+      // chains start at the ops without a stale input
+      const unsigned long long ms = __ballot((int)(act && nst == 0u));
+      if (act && nst == 0u) K.R[nstart + (uint32_t)__builtin_popcountll(ms & lt)] = (uint16_t)i;
+      nstart += (uint32_t)__builtin_popcountll(ms);
+    }
+    if (lane == 0) sh.rtail = nstart;
+    if (slot_base > Cfg<KS, VW>::kSlots) {
+      // slots ran out: this step's refresh takes the plain path, whose chain starts are vectors, not op indices
+      for (uint32_t k = (uint32_t)lane; k < nstart; k += 64u) K.R[k] = K.OL[K.R[k]];
+      mode = 0u;
+    }
+  }
+  if (lane == 0) {
+    sh.use_static = mode;
+    if (nops) { if (mode) sh.c_parts++; else { sh.c_inv2++; sh.c_dynops += nops; } }
+  }
 }
 
-// ---- (3) dataflow refresh of the claimed vectors
+// ---- (3) refresh of the claimed vectors (newviewParsimonyIterativeFast, :554-878, on exactly the stale vectors the scans
+// read).  Closures that fit the link pass: every wave first copies the VALID operands of its share of the ops into their LDS
+// slots -- all those loads are in flight together, one memory round trip for the whole refresh instead of one per link of a
+// chain -- then the chains run: the running result and its per-lane scores stay in registers, the next link's consumer entry
+// and its other operand are requested while the current link is combined.  Where two stale inputs meet, whoever arrives
+// second goes on (the first one's result is read back from memory: joins are one op in ten).
 template <int KS, int VW>
-__device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh)
+__device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool prof)
+{
+  constexpr int R = Cfg<KS, VW>::R;
+  const uint32_t nops = sh.nops;
+  const int lane = K.lane;
+  // -- stage
+  for (uint32_t base = (uint32_t)K.wave * 4u; base < nops; base += (uint32_t)kNW * 4u) {
+    QT<KS, VW> ta[4], tb[4];
+    uint32_t la[4], lb[4], da[4], db[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const uint32_t i = base + (uint32_t)kk;
+      da[kk] = db[kk] = kNoSlot;
+      if (i < nops) {
+        const uint2 d = K.D[i];
+        const uint32_t dx = rfl(d.x), dy = rfl(d.y), join = rfl(K.PEND[i]) == 2u ? 1u : 0u;
+        da[kk] = join ? kNoSlot : (dx >> 16) & 0xFFu;
+        db[kk] = join ? kNoSlot : dx >> 24;
+        if (da[kk] != kNoSlot) { ld<KS, VW>(K, ta[kk], dy & 0xFFFFu); la[kk] = ld_sl<KS, VW>(K, dy & 0xFFFFu); }
+        if (db[kk] != kNoSlot) { ld<KS, VW>(K, tb[kk], dy >> 16); lb[kk] = ld_sl<KS, VW>(K, dy >> 16); }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      if (da[kk] != kNoSlot) {
+        uint32_t *sp = K.stage + (size_t)da[kk] * ((R + 1) * 64) + lane;
+#pragma unroll
+        for (int k = 0; k < R; k++) sp[k * 64] = ta[kk].v[k / VW][k % VW];
+        sp[R * 64] = la[kk];
+      }
+      if (db[kk] != kNoSlot) {
+        uint32_t *sp = K.stage + (size_t)db[kk] * ((R + 1) * 64) + lane;
+#pragma unroll
+        for (int k = 0; k < R; k++) sp[k * 64] = tb[kk].v[k / VW][k % VW];
+        sp[R * 64] = lb[kk];
+      }
+    }
+  }
+  __syncthreads();
+  if (prof && lane == 0) sh.tph[8] += __builtin_amdgcn_s_memrealtime() - sh.tlast;
+  // -- chains
+  auto operand = [&](QT<KS, VW> &t, uint32_t &sl, uint32_t slot, uint32_t cid) {
+    if (slot != kNoSlot) {
+      const uint32_t *sp = K.stage + (size_t)slot * ((R + 1) * 64) + lane;
+#pragma unroll
+      for (int k = 0; k < R; k++) t.v[k / VW][k % VW] = sp[k * 64];
+      sl = sp[R * 64];
+    } else {
+      // (rare: a join's other input, or no slot left.  The loads are waited for right here: left pending, the wait would be
+      //  placed behind the merge of the two paths and the usual path -- LDS only -- would sit out its own older STORES with
+      //  it: gfx950 counts loads and stores in one in-order counter)
+      ld<KS, VW>(K, t, cid);
+      sl = ld_sl<KS, VW>(K, cid);
+#pragma unroll
+      for (int k = 0; k < R; k++) asm volatile("" : "+v"(t.v[k / VW][k % VW]));
+      asm volatile("" : "+v"(sl));
+    }
+  };
+  QT<KS, VW> c, ta, tb;
+  uint32_t la = 0, lb = 0, lc = 0;
+  for (uint32_t si = (uint32_t)K.wave;; si += kNW) {       // chain starts are dealt round-robin (late ones -- rare -- land behind the list)
+    uint32_t st = kNone16, spins = 0;
+    for (;;) {
+      st = *(volatile uint16_t *)&K.R[si];                // (entries beyond the starts written so far read "none")
+      if (st != kNone16) break;
+      if (*(volatile uint32_t *)&sh.ndone >= nops) break;
+      if (++spins > (1u << 22)) { sh.err = 2u; break; }   // (bounded like every wait in this kernel)
+      __builtin_amdgcn_s_sleep(1);
+    }
+    st = rfl(st);
+    if (st == kNone16) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const unsigned long long ct0 = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t nlinks = 0;
+    uint32_t i = st, r;
+    {
+      const uint2 d = K.D[i];
+      const uint32_t dx = rfl(d.x), dy = rfl(d.y);
+      r = dx & 0xFFFFu;
+      operand(ta, la, (dx >> 16) & 0xFFu, dy & 0xFFFFu);
+      operand(tb, lb, dx >> 24, dy >> 16);
+    }
+    for (uint32_t link = 0;; link++) {
+      if (link > kLcap) { if (lane == 0) sh.err = 5u; break; }
+      // who waits for this result (read before the arithmetic, used after it)
+      const uint32_t ncv = K.NC[i];
+      const uint2 e0 = K.CONS[2u * i], e1 = K.CONS[2u * i + 1u];
+      const uint32_t cost = q_fitch<KS, VW>(c, ta, tb);
+      lc = cost + la + lb;
+      if (K.st_lane) qstore<KS, VW>(c, K.rsrc, K.voff, r * K.SW4);
+      st_sl<KS, VW>(K, r, lc);
+      if (sh.dbg & 1u) {                                  // (experiment: every store twice)
+        if (K.st_lane) qstore<KS, VW>(c, K.rsrc, K.voff, r * K.SW4);
+        st_sl<KS, VW>(K, r, lc);
+      }
+      if (lane == 0) K.valid[r] = 1;
+      const uint32_t nc = rfl(ncv);
+      uint32_t nxt = kNone16, nx_x = 0, nx_y = 0;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if ((uint32_t)u < nc) {
+          const uint32_t ex_ = rfl(u ? e1.x : e0.x), ey_ = rfl(u ? e1.y : e0.y);
+          const uint32_t j = ex_ & 0xFFu;
+          bool ready = ((ex_ >> 9) & 3u) == 1u;          // its other input is valid: go on in registers
+          if (!ready) {
+            // a join of two stale inputs: both sides leave their result in their slot and count down; whoever finds the
+            // other one's count goes on with it (LDS only: writes and the atomic of a wave arrive in order)
+            uint32_t *mp = K.stage + (size_t)(ex_ >> 24) * ((R + 1) * 64) + lane;
+#pragma unroll
+            for (int k = 0; k < R; k++) mp[k * 64] = c.v[k / VW][k % VW];
+            mp[R * 64] = lc;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t old = wave_fetch_sub(&K.PEND[j], 1u, lane);
+            ready = old == 1u;
+          }
+          if (ready) {
+            if (nxt == kNone16) { nxt = j; nx_x = ex_; nx_y = ey_; }
+            else {
+              // (a vector two ops of the step wait for: the second one becomes a chain start and reads this result from memory)
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              if (lane == 0) {
+                const uint32_t slot = __hip_atomic_fetch_add(&sh.rtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                K.R[slot] = (uint16_t)j;
+              }
+            }
+          }
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(&sh.ndone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      nlinks++;
+      if (nxt == kNone16) break;
+      // the next link: this result is one operand, the other one sits in its slot (or in memory: a join, or no slot left)
+      const uint32_t which = (nx_x >> 8) & 1u, oslot = (nx_x >> 16) & 0xFFu, ocid = nx_y >> 16;
+      i = nxt;
+      r = nx_y & 0xFFFFu;
+      if (which == 0u) { ta = c; la = lc; operand(tb, lb, oslot, ocid); }
+      else { tb = c; lb = lc; operand(ta, la, oslot, ocid); }
+    }
+    if (prof && lane == 0) { sh.tph[9] += __builtin_amdgcn_s_memrealtime() - ct0; sh.tph[10] += nlinks; sh.tph[11]++; }
+  }
+}
+
+// the plain dataflow path (closures beyond kLcap ops: the first step of a launch): operands from memory, consumers found through
+// the topology and the claim words
+template <int KS, int VW>
+__device__ __forceinline__ void refresh_dynamic(const Kx<KS, VW> &K, Sh &sh)
 {
   const uint32_t n = K.n, epoch = sh.epoch, nops = sh.nops;
   const int lane = K.lane;
-  if (nops == 0) return;
   QT<KS, VW> c, ta, tb;
   for (;;) {
     const uint32_t idx = wave_fetch_add(&sh.rhead, 1u, lane);
@@ -393,36 +692,26 @@ __device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh)
       r = *(volatile uint16_t *)&K.R[idx];
       if (r != kNone16) break;
       if (*(volatile uint32_t *)&sh.ndone >= nops) break;
-      if (++spins > (1u << 22)) { sh.err = 2u; break; }   // (bounded like every wait in this kernel)
+      if (++spins > (1u << 22)) { sh.err = 2u; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     r = rfl(r);
     if (r == kNone16) break;
     if (lane == 0) K.R[idx] = (uint16_t)kNone16;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    uint32_t prev = kNone16, sc_prev = 0;
+    uint32_t prev = kNone16, lprev = 0;
     for (uint32_t link = 0;; link++) {
       if (link > K.ns) { if (lane == 0) sh.err = 5u; break; }
       const uint32_t r1 = nxc(r, n);
       const uint32_t a = rfl((uint32_t)K.bk[r1]), b = rfl((uint32_t)K.bk[nxc(r1, n)]);
-      uint32_t sa, sb;
-      if (prev == a) {
-        ta = c; sa = sc_prev;
-        ld<KS, VW>(K, tb, b); sb = ld_sct<KS, VW>(K, b);
-      } else if (prev == b) {
-        tb = c; sb = sc_prev;
-        ld<KS, VW>(K, ta, a); sa = ld_sct<KS, VW>(K, a);
-      } else {
-        ld<KS, VW>(K, ta, a); ld<KS, VW>(K, tb, b);
-        sa = ld_sct<KS, VW>(K, a); sb = ld_sct<KS, VW>(K, b);
-      }
+      uint32_t la, lb;
+      if (prev == a) { ta = c; la = lprev; } else { ld<KS, VW>(K, ta, a); la = ld_sl<KS, VW>(K, a); }
+      if (prev == b) { tb = c; lb = lprev; } else { ld<KS, VW>(K, tb, b); lb = ld_sl<KS, VW>(K, b); }
       const uint32_t cost = q_fitch<KS, VW>(c, ta, tb);
+      const uint32_t lc = cost + la + lb;
       if (K.st_lane) qstore<KS, VW>(c, K.rsrc, K.voff, r * K.SW4);
-      const uint32_t sc = wave_total(K.cnt_lane ? cost : 0u) + rfl(sa) + rfl(sb);   // tr->parsimonyScore[p], :874 (this tile's share)
-      if (lane == 0) {
-        __hip_atomic_store(K.sct + r, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        K.valid[r] = 1;
-      }
+      st_sl<KS, VW>(K, r, lc);
+      if (lane == 0) K.valid[r] = 1;
       // the vectors that take this one as an input: the two other records of the node behind it
       const uint32_t w = rfl((uint32_t)K.bk[r]);
       uint32_t nr = 0, rdy0 = 0, rdy1 = 0;
@@ -433,15 +722,14 @@ __device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh)
           cand = nxc(cand, n);
           const uint32_t v = rfl(*(volatile uint32_t *)&K.cl[cand]);
           const uint32_t vc = rfl((uint32_t) * (volatile uint8_t *)&K.valid[cand]);
-          if ((v >> 8) == epoch && !vc) {
+          if ((v >> kEpochShift) == epoch && !vc) {
             bool ready;
-            if ((v & 0xFFu) == 1u) {
-              ready = true;                              // its other input is valid (or was finished before): go on in registers
+            if ((v & 7u) == 1u) {
+              ready = true;
             } else {
-              // a join of two stale inputs: whoever arrives second goes on, reading the first one's result from memory
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
               const uint32_t old = wave_fetch_sub(&K.cl[cand], 1u, lane);
-              ready = (old & 0xFFu) == 1u;
+              ready = (old & 7u) == 1u;
               if (ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (ready) { if (nr == 0) rdy0 = cand; else rdy1 = cand; nr++; }
@@ -457,80 +745,95 @@ __device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh)
       }
       if (lane == 0) __hip_atomic_fetch_add(&sh.ndone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (nr == 0) break;
-      prev = r; sc_prev = sc; r = rdy0;
+      prev = r; lprev = lc; r = rdy0;
     }
   }
 }
 
-// ---- (4) one part of a scan: addTraverseParsimony + testInsertParsimony (:2208-2218, :2106-2160) below one first-level
-// child of one gap end, both children of a node expanded together (one vector read per insertion test)
 template <int KS, int VW>
-__device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t pi, uint32_t maxtrav)
+__device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh, bool prof)
 {
-  const uint32_t n = K.n;
+  if (sh.nops == 0) return;
+  if (sh.use_static) refresh_static<KS, VW>(K, sh, prof);
+  else refresh_dynamic<KS, VW>(K, sh);
+}
+
+// ---- (4) one gap end of a scan: the program of (1) run front to back -- addTraverseParsimony + testInsertParsimony
+// (:2208-2218, :2106-2160), both children of a node expanded together (one vector read per insertion test).  The child
+// vectors of PF expansions are requested at once, so a part pays for one memory round trip per PF expansions; the
+// up-vector runs in registers from an expansion to its first child, second children find theirs in LDS.
+template <int KS, int VW>
+__device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t pi, uint32_t half)
+{
+  constexpr int R = Cfg<KS, VW>::R;
+  constexpr int PF = Cfg<KS, VW>::PF;
   const int lane = K.lane;
-  const Unit un = sh.unit[pi >> 2];
-  const uint32_t e = (pi >> 1) & 1u, child_mask = 1u << (pi & 1u);
-  const uint32_t a = rfl((uint32_t)(e ? un.xb : un.xa)), other = rfl((uint32_t)(e ? un.xa : un.xb));
-  const uint32_t mt = rfl((uint32_t)un.mt);
-  const uint32_t out_base = rfl(sh.poff[pi]);
-  uint2 *stk = K.frames + K.wave * 8;
-  uint32_t *pend = K.pend + (size_t)K.wave * (kDepth * KS * VW * 64);
-  QT<KS, VW> sv, par, u1, u2, d1, d2;
+  const Unit un = sh.unit[pi >> 1];
+  const uint32_t e = pi & 1u;
+  const uint32_t other = rfl((uint32_t)(e ? un.xa : un.xb));
+  const uint32_t pe = rfl(sh.pE[pi]), E = pe & 0xFFu, EL = pe >> 8;
+  // a long program is shared by two waves: both run the root entry, one goes on below its first child, the other one below
+  // the second (whose up-vector the root entry parks like any second child's)
+  const bool split = E >= 6u;
+  const uint32_t lo = !split ? 1u : half ? 1u + EL : 1u, hi = !split ? E : half ? E : 1u + EL;
+  const uint32_t root_mask = !split ? 3u : half ? 2u : 1u;       // which of the root's two candidates this wave books
+  // this lane's address of candidate 0 (quad leaders inside the row add their counts, everybody else adds nothing)
+  uint32_t *cbase = K.cost + rfl(sh.poff[pi]);
+  const uint2 *prog = K.prog + pi * kProgStride;
+  uint32_t *pend = K.pend + (size_t)K.wave * (5 * R * 64) + lane;     // slots for child depths 1..5
+  QT<KS, VW> sv, par, u1, u2, d1[PF], d2[PF];
+  uint32_t ex[PF], ey[PF];
   ld<KS, VW>(K, sv, rfl((uint32_t)un.s));
   ld<KS, VW>(K, par, other);
-  uint32_t k = 0;
-  int sp = 0;
-  uint32_t node = a, d = 0;
-  auto emit = [&](uint32_t cst, uint32_t cid) {
-    if (lane == 0) { K.cost[out_base + k] = cst; K.cq[out_base + k] = (uint16_t)cid; }
-    k++;
-  };
-  for (uint32_t it = 0;; it++) {
-    if (it > 256u) { if (lane == 0) sh.err = 6u; break; }
-    const uint32_t r1 = nxc(node, n);
-    const uint32_t c1 = rfl((uint32_t)K.bk[r1]), c2 = rfl((uint32_t)K.bk[nxc(r1, n)]);
-    ld<KS, VW>(K, d1, c1);
-    ld<KS, VW>(K, d2, c2);
-    const uint32_t dd = d + 1u;
-    const bool test = dd >= mt, deeper = dd < maxtrav;
-    q_fitch<KS, VW>(u1, par, d2);
-    q_fitch<KS, VW>(u2, par, d1);
-    const bool own1 = dd > 1u || (child_mask & 1u), own2 = dd > 1u || (child_mask & 2u);
-    uint32_t tot = 0;
-    if (test) {
-      uint32_t cst = q_join<KS, VW>(u1, d1, sv) | (q_join<KS, VW>(u2, d2, sv) << 16);
-      cst = K.cnt_lane ? cst : 0u;
-      tot = wave_total(cst);
+  // entry 0 first, then [lo, hi)
+  const uint32_t n_run = 1u + (hi - lo);
+  for (uint32_t blk = 0; blk < n_run; blk += (uint32_t)PF) {
+    uint2 en[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      uint32_t q = blk + (uint32_t)i;
+      q = q < n_run ? q : n_run - 1u;                                 // (clamped: the requests stay unconditional)
+      en[i] = prog[q == 0u ? 0u : lo + q - 1u];
     }
-    if (own2 && deeper && c2 >= n) {
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++)
-#pragma unroll
-        for (int jj = 0; jj < VW; jj++) pend[((dd - 1u) * (KS * VW) + (uint32_t)(kk * VW + jj)) * 64u + (uint32_t)lane] = u2.v[kk][jj];
+    for (int i = 0; i < PF; i++) {
+      ex[i] = rfl(en[i].x);
+      ey[i] = rfl(en[i].y);
+      ld<KS, VW>(K, d1[i], ex[i] & 0xFFFFu);
+      ld<KS, VW>(K, d2[i], ex[i] >> 16);
     }
-    if (own2) { stk[sp] = make_uint2(c2 | (dd << 24), tot >> 16); sp++; }
-    if (test && own1) emit(tot & 0xFFFFu, c1);
-    if (own1 && deeper && c1 >= n) { par = u1; node = c1; d = dd; continue; }
-    bool more = false;
-    while (sp > 0) {
-      sp--;
-      const uint2 fr = stk[sp];
-      const uint32_t fx = rfl(fr.x);
-      const uint32_t q = fx & 0xFFFFFFu, dq = fx >> 24;
-      if (dq >= mt) emit(rfl(fr.y), q);
-      if (dq < maxtrav && q >= n) {
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++)
+    for (int i = 0; i < PF; i++) {
+      const uint32_t q = blk + (uint32_t)i;
+      if (q < n_run) {
+        const uint32_t y = ey[i], dd = y & 15u;
+        if (q > 0u) {
+          if (y & 64u) {
 #pragma unroll
-          for (int jj = 0; jj < VW; jj++) par.v[kk][jj] = pend[((dq - 1u) * (KS * VW) + (uint32_t)(kk * VW + jj)) * 64u + (uint32_t)lane];
-        node = q; d = dq; more = true;
-        break;
+            for (int k = 0; k < R; k++) par.v[k / VW][k % VW] = pend[((dd - 2u) * R + (uint32_t)k) * 64u];
+          } else {
+            par = u1;
+          }
+        }
+        q_fitch<KS, VW>(u1, par, d2[i]);
+        q_fitch<KS, VW>(u2, par, d1[i]);
+        if (y & 16u) {
+          const uint32_t m = q == 0u ? root_mask : 3u;
+          // counts leave as one LDS add per candidate from the 16 quad leaders (no reduction across lanes, nothing to wait for)
+          const uint32_t j1 = (m & 1u) ? q_join<KS, VW>(u1, d1[i], sv) : 0u;      // (all lanes: the quad ORs need their neighbours)
+          const uint32_t j2 = (m & 2u) ? q_join<KS, VW>(u2, d2[i], sv) : 0u;
+          if (K.cnt_lane) {
+            if (m & 1u) __hip_atomic_fetch_add(cbase + ((y >> 8) & 0xFFu) + K.zero, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (m & 2u) __hip_atomic_fetch_add(cbase + ((y >> 16) & 0xFFu) + K.zero, j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        if (y & 32u) {
+#pragma unroll
+          for (int k = 0; k < R; k++) pend[((dd - 1u) * R + (uint32_t)k) * 64u] = u2.v[k / VW][k % VW];
+        }
       }
     }
-    if (!more) break;
   }
-  if (lane == 0 && k != sh.pcnt[pi]) sh.err = 100u + pi;   // the walk and the enumeration disagree: never on a consistent tree
 }
 
 // debugging aid (option "climb_trace"): workgroup 0 leaves where it is in pinned host memory, so that a launch that does not
@@ -592,7 +895,10 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
       }
     }
     if (sel >= 0) {
-      ins = (int32_t)K.cq[off + (uint32_t)sel];
+      // the insertion branch: named by the enumeration, per part and candidate index
+      uint32_t part = 4u * j;
+      while (part < 4u * j + 3u && off + (uint32_t)sel >= sh.poff[part] + sh.pcnt[part]) part++;
+      ins = (int32_t)K.cq[part * 128u + (off + (uint32_t)sel - sh.poff[part])];
       rem = (uint32_t)sel < np ? (int32_t)pcid : (int32_t)K.bk[pcid];
     }
     bool accept;
@@ -649,7 +955,8 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
       if (w >= n) { have = true; item = w; }
     }
     uint32_t head = 0, tail = 0;
-    for (uint32_t round = 0;; round++) {
+    uint32_t round = 0;
+    for (;; round++) {
       if (round > K.ns) { if (lane == 0) sh.err = 4u; break; }
       {
         const unsigned long long need = __ballot((int)!have);
@@ -664,8 +971,8 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
       uint32_t pv = 0;
       if (have) {
         const uint32_t o1 = nxc(item, n), o2 = nxc(o1, n);
-        const bool w1 = (__hip_atomic_fetch_max(&K.cl[o1], einv << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 8) != einv;
-        const bool w2 = (__hip_atomic_fetch_max(&K.cl[o2], einv << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 8) != einv;
+        const bool w1 = (__hip_atomic_fetch_max(&K.cl[o1], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kEpochShift) != einv;
+        const bool w2 = (__hip_atomic_fetch_max(&K.cl[o2], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kEpochShift) != einv;
         const bool v1 = w1 && K.valid[o1], v2 = w2 && K.valid[o2];
         const uint32_t u1 = K.bk[o1], u2 = K.bk[o2];
         if (v1) K.valid[o1] = 0;
@@ -679,6 +986,7 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
       if (push) K.W[tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (uint16_t)pv;
       tail += (uint32_t)__builtin_popcountll(pm);
     }
+    if (lane == 0) sh.c_inv += round;
   }
   if (lane == 0) {
     sh.best = best; sh.randomMP = randomMP; sh.iter_hits = iter_hits;
@@ -699,7 +1007,7 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     sh.B = B;
     uint32_t reason = CLIMB_RUNNING;
     if (pos > P.total) reason = CLIMB_SWEEP_END;
-    else if (n_moves >= P.max_moves) reason = CLIMB_MOVES_FULL;
+    else if (n_moves >= P.max_moves || sh.epoch > kEpochLimit) reason = CLIMB_MOVES_FULL;
     else if (P.idle_limit && since >= P.idle_limit) reason = CLIMB_IDLE;
     if (consumed == 0u || sh.steps > 4u * P.total + 16u) sh.err = sh.err ? sh.err : 7u;
     if (sh.err) reason = CLIMB_ERROR;
@@ -719,17 +1027,26 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
   size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
   Kx<KS, VW> K;
   K.cl = reinterpret_cast<uint32_t *>(smem + at); at += (((size_t)ns * 4) + 15) & ~(size_t)15;
+  K.prog = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
+  K.stage = reinterpret_cast<uint32_t *>(smem + at);
+  K.pend = reinterpret_cast<uint32_t *>(smem + at); at += Cfg<KS, VW>::kRegion;
+  K.D = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * sizeof(uint2);
+  K.CONS = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * 2 * sizeof(uint2);
+  K.NC = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
+  K.PEND = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
   K.cost = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kClimbCap * 4;
-  K.pend = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kNW * kDepth * KS * VW * 64 * 4;
-  K.frames = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kNW * 8 * sizeof(uint2);
   K.bk = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   K.W = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   K.R = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)(ns + 16) * 2) + 15) & ~(size_t)15;
-  K.cq = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kClimbCap * 2;
+  K.cq = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kMaxParts * 128 * 2;
+  K.OL = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kLcap * 2;
+  K.ord = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)P.total * 2) + 15) & ~(size_t)15;
   K.valid = reinterpret_cast<uint8_t *>(smem + at);
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
   K.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
-  K.sct = P.sct + (size_t)tile * ns;
+  K.rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)(P.sct + (size_t)tile * ns * 16), 0, (int)(ns * 64u), 0x00020000);
+  K.svoff = ((uint32_t)lane >> 2) * 4u;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(K.zero));
   K.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.vec, 0, 0x7FFFFFFF, 0x00020000);
   {
     const uint32_t w = (uint32_t)lane >> 2, g = (uint32_t)lane & 3u;
@@ -740,6 +1057,24 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
 #pragma unroll
     for (int k = 0; k < KS; k++) K.voff[k] = ((g * (uint32_t)KS + (uint32_t)k) * P.Wp + word0) * 4u;
   }
+  {
+    // heap-index relations of lane h (complete binary tree, root 1): who comes before h in pre-order, which ancestors hold h
+    // in their LEFT subtree, who sits in the subtree of h's left child
+    const uint32_t h = (uint32_t)lane;
+    unsigned long long pre = 0, ancl = 0, lsub = 0;
+    if (h >= 1u) {
+      const int dh = 31 - __builtin_clz(h);
+      const uint32_t hh = h << (5 - dh);
+      for (uint32_t g = 1; g < 64u; g++) {
+        const int dg = 31 - __builtin_clz(g);
+        const uint32_t gg = g << (5 - dg);
+        if (g != h && (gg < hh || (gg == hh && dg < dh))) pre |= 1ull << g;
+        if (dg < dh && (h >> (dh - dg)) == g && !((h >> (dh - dg - 1)) & 1u)) ancl |= 1ull << g;
+        if (dg > dh && (g >> (dg - dh - 1)) == 2u * h) lsub |= 1ull << g;
+      }
+    }
+    K.pre = pre; K.ancl = ancl; K.lsub = lsub;
+  }
   // ---- the launch's state: topology, all inner vectors stale (the kernel keeps its own per-tile subtree scores)
   for (uint32_t i = (uint32_t)tid; i < ns; i += kThreads) {
     K.bk[i] = P.bk[i];
@@ -747,14 +1082,19 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
     K.cl[i] = 0u;
   }
   for (uint32_t i = (uint32_t)tid; i < ns + 16u; i += kThreads) K.R[i] = (uint16_t)kNone16;
+  for (uint32_t i = (uint32_t)tid; i < P.total; i += kThreads) K.ord[i] = P.order[i];
   if (tid == 0) {
     const ClimbHeader h = *P.hdr;
     sh.pos = h.pos; sh.B = h.batch ? h.batch : P.batch_min; sh.epoch = 1u; sh.exit_reason = CLIMB_RUNNING;
-    sh.since_move = h.since_move; sh.steps = 0; sh.xgen = 0; sh.n_moves = 0; sh.err = 0; sh.trace_n = 0;
+    sh.since_move = h.since_move; sh.rtail = 0; sh.dbg = h.pad[0]; sh.steps = 0; sh.xgen = 0; sh.n_moves = 0; sh.err = 0; sh.trace_n = 0;
     sh.last_ncand[0] = sh.last_ncand[1] = sh.last_ncand[2] = 0;
     sh.best = h.best; sh.randomMP = h.randomMP; sh.iter_hits = h.iter_hits; sh.ins = h.insert_cid; sh.rem = h.remove_cid;
     sh.rng = h.rng; sh.hits = h.hits; sh.n_tests = 0; sh.n_ops = 0; sh.draws = 0; sh.n_nodes = 0;
     if (sh.B > (uint32_t)kMaxB) sh.B = kMaxB;
+    for (int i = 0; i < 16; i++) sh.tph[i] = 0;
+    sh.c_rounds = sh.c_inv = sh.c_chains = sh.c_parts = sh.c_inv2 = sh.c_dynops = 0;
+    sh.clk0 = __builtin_amdgcn_s_memtime(); sh.rt0 = sh.tlast;
+    sh.tlast = __builtin_amdgcn_s_memrealtime();
     // every workgroup must be resident before anyone waits for anyone: arrive, then wait for the others -- not for ever
     __hip_atomic_fetch_add(&P.hdr->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -782,6 +1122,10 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
 
   for (;;) {
     // ---- step set-up
+    for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;     // last step's chain starts
+    if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
+    for (uint32_t i = (uint32_t)tid; i < kClimbCap; i += kThreads) K.cost[i] = 0u;
+    __syncthreads();
     if (tid == 0) {
       const uint32_t left = P.total - sh.pos + 1u;
       if (sh.B > left) sh.B = left;
@@ -790,33 +1134,48 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
     __syncthreads();
     const uint32_t B = sh.B;
     beat(P, tile, tid, 0, sh.steps); beat(P, tile, tid, 2, sh.pos); beat(P, tile, tid, 3, B); beat(P, tile, tid, 1, 1);
+#define MPF_TMARK(i) do { if (tile == 0 && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); sh.tph[i] += now_ - sh.tlast; sh.tlast = now_; } } while (0)
+    MPF_TMARK(0);
     // ---- (1)
     for (uint32_t u = (uint32_t)wave; u < 2u * B; u += kNW) enum_unit<KS, VW>(K, sh, P, u);
     __syncthreads();
     beat(P, tile, tid, 1, 2);
+    MPF_TMARK(1);
     // ---- (2)
     if (wave == 0) plan_and_discover<KS, VW>(K, sh);
     __syncthreads();
     beat(P, tile, tid, 4, sh.ncand); beat(P, tile, tid, 5, sh.nops); beat(P, tile, tid, 6, sh.rtail); beat(P, tile, tid, 1, 3);
+    MPF_TMARK(2);
     // ---- (3)
-    refresh<KS, VW>(K, sh);
+    refresh<KS, VW>(K, sh, tile == 0 && wave == 0);
     __syncthreads();
     beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
+    MPF_TMARK(3);
     // ---- (4)
     const uint32_t ncand = sh.ncand;
     {
-      const uint32_t nparts = 8u * sh.Beff;
-      for (;;) {
-        const uint32_t t = wave_fetch_add(&sh.task, 1u, lane);
-        if (P.beat && tile == 0 && lane == 0) __hip_atomic_store(P.beat + 16 + wave, t | 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (t >= nparts) break;
-        if (sh.pcnt[t] == 0u) continue;
-        scan_part<KS, VW>(K, sh, t, P.maxtrav);
+      // length of the two sides of the prune branch (this tile's share): per-lane scores summed over the word groups -- wave j
+      // asks for prune node j's two score rows now and folds them after its scan tasks
+      uint32_t bv1 = 0, bv2 = 0;
+      const bool has_base = (uint32_t)wave < sh.Beff;
+      if (has_base) {
+        const uint32_t p = rfl(sh.pn_p[wave]), q = rfl((uint32_t)K.bk[p]);
+        bv1 = ld_sl<KS, VW>(K, p);
+        bv2 = ld_sl<KS, VW>(K, q);
       }
-      if (P.beat && tile == 0 && lane == 0) __hip_atomic_store(P.beat + 16 + wave, 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t ntasks = sh.ntasks;
+      for (uint32_t ti = (uint32_t)wave; ti < ntasks; ti += kNW) {
+        const uint32_t t = rfl((uint32_t)sh.tl[ti]);
+        scan_part<KS, VW>(K, sh, t >> 1, t & 1u);
+      }
+      if (has_base) {
+        const uint32_t tot = wave_total(K.cnt_lane ? bv1 + bv2 : 0u);
+        if (lane == 0) sh.pn_base[wave] = tot;
+      }
     }
     __syncthreads();
     beat(P, tile, tid, 1, 5);
+    MPF_TMARK(4);
     // ---- (5) lengths = sum over tiles of (subtree scores at both ends of the prune branch + join cost)
     if (ncand) {
       const uint32_t slot = sh.xgen % 3u;
@@ -824,8 +1183,7 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
       for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
         uint32_t j = 0;
         while (j + 1u < sh.Beff && c >= sh.pn_off[j + 1u]) j++;
-        const uint32_t p = sh.pn_p[j], q = K.bk[p];
-        const uint32_t val = K.cost[c] + ld_sct<KS, VW>(K, p) + ld_sct<KS, VW>(K, q);
+        const uint32_t val = K.cost[c] + sh.pn_base[j];
         __hip_atomic_fetch_add(gs + c, (1ull << 40) | (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
@@ -856,10 +1214,12 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
     }
     __syncthreads();
     beat(P, tile, tid, 1, 6);
+    MPF_TMARK(5);
     // ---- (6)
     if (wave == 0) decide<KS, VW>(K, sh, P, tile);
     __syncthreads();
     beat(P, tile, tid, 8, sh.err);
+    MPF_TMARK(6);
     if (sh.exit_reason != CLIMB_RUNNING) break;
   }
   beat(P, tile, tid, 1, 9);
@@ -872,7 +1232,12 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
       h->pos = sh.pos; h->insert_cid = sh.ins; h->remove_cid = sh.rem; h->n_moves = sh.n_moves; h->reason = sh.exit_reason;
       h->err = sh.err; h->steps = sh.steps; h->n_tests = sh.n_tests; h->n_ops = sh.n_ops; h->draws = sh.draws;
       h->n_scanned_nodes = sh.n_nodes; h->since_move = sh.since_move; h->batch = sh.B;
-      h->pad[0] = sh.trace_n;
+      h->pad[0] = sh.trace_n; h->pad[1] = sh.c_rounds; h->pad[2] = sh.c_inv; h->pad[3] = sh.c_chains;
+      for (int i = 0; i < 7; i++) h->tph[i] = sh.tph[i];
+      for (int i = 8; i < 16; i++) h->tph[i] = sh.tph[i];
+      h->tph[12] = sh.c_parts * 100ull;
+      // shader clock in kHz: s_memtime ticks per s_memrealtime tick (100 MHz)
+      h->tph[7] = (__builtin_amdgcn_s_memtime() - sh.clk0) * 100000ull / (__builtin_amdgcn_s_memrealtime() - sh.rt0 + 1ull);
     }
   }
 }
@@ -882,13 +1247,19 @@ size_t lds_bytes(uint32_t ns)
 {
   size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
   at += (((size_t)ns * 4) + 15) & ~(size_t)15;
+  at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
+  at += Cfg<KS, VW>::kRegion;
+  at += (size_t)kLcap * sizeof(uint2);
+  at += (size_t)kLcap * 2 * sizeof(uint2);
+  at += (size_t)kLcap * 4;
+  at += (size_t)kLcap * 4;
   at += (size_t)kClimbCap * 4;
-  at += (size_t)kNW * kDepth * KS * VW * 64 * 4;
-  at += (size_t)kNW * 8 * sizeof(uint2);
   at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   at += (((size_t)(ns + 16) * 2) + 15) & ~(size_t)15;
-  at += (size_t)kClimbCap * 2;
+  at += (size_t)kMaxParts * 128 * 2;
+  at += (size_t)kLcap * 2;
+  at += (((size_t)(ns / 2 + 1) * 2) + 15) & ~(size_t)15;      // the visiting order: 2n - 2 entries
   at += ns;
   return (at + 15) & ~(size_t)15;
 }

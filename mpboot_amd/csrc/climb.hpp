@@ -40,6 +40,7 @@ struct ClimbHeader {
   unsigned long long n_tests, n_ops, draws, n_scanned_nodes;
   uint32_t arrive, abort, since_move, batch;
   uint32_t pad[4];
+  unsigned long long tph[16];      // 100 MHz ticks workgroup 0 spent per phase: set-up, enumerate, closure, refresh, scan, exchange, decide
 };
 
 struct ClimbParams {
@@ -53,7 +54,7 @@ struct ClimbParams {
   uint32_t batch_min, batch_max;   // prune nodes per step (speculative; doubles after a step without a move)
   const uint16_t *order;           // [total] vector ids of nodep[1..total]
   uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
-  uint32_t *sct;                   // [tiles][nslots] per-tile subtree scores (scratch of the launch)
+  uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch)
   unsigned long long *gsum;        // [3][kClimbCap] exchange ring (zeroed by the host before the launch)
   ClimbHeader *hdr;
   uint32_t *moves;                 // [max_moves][3] = remove cid, insert cid, score

@@ -1648,6 +1648,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "climb_debug") { climb_debug_ = (int)v; return MPF_OK; }      // (timing experiments: results are wrong on purpose)
   if (key == "climb_trace") { climb_trace_ = v ? 1 : 0; cd_.h_trace.clear(); cd_.trace_records = 0; return MPF_OK; }
   if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack
     snk16_opt_ = v ? 1 : 0;
@@ -1701,6 +1702,9 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "climb_batch_max") *v = climb_batch_max_;
   else if (key == "climb_idle") *v = climb_idle_;
   else if (key == "climb_trace") *v = climb_trace_;
+  else if (key.rfind("climb_ctr", 0) == 0 && key.size() == 10 && key[9] >= '0' && key[9] <= '3') *v = (int64_t)climb_ctr_[key[9] - '0'];   // refresh ops, closure rounds, invalidation rounds, chains
+  else if (key.rfind("climb_phase_us", 0) == 0 && key.size() == 15 && ((key[14] >= '0' && key[14] <= '9') || (key[14] >= 'a' && key[14] <= 'f')))
+    *v = (int64_t)(climb_phase_ticks_[key[14] <= '9' ? key[14] - '0' : key[14] - 'a' + 10] / 100ull);
   else { set_error("unknown option " + key); return MPF_E_INVALID; }
   return MPF_OK;
 }

@@ -7,7 +7,9 @@
 // directional vectors stay where they are; the kernel treats them all as stale at launch and keeps its own per-tile
 // subtree scores, the host forgets its validity bookkeeping afterwards -- both sides only ever trust what they computed.
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "../csrc/engine.hpp"
@@ -24,6 +26,30 @@ namespace mpf {
     }                                                                                             \
   } while (0)
 
+// k_climb's workgroups wait for each other, so all of them must be resident at once.  Engines on several host threads of one
+// process share a device: launches are admitted only while their workgroups fit the chip together (a launch that still fails
+// to become resident -- other processes -- gives up inside the kernel after 30 ms and the caller falls back to host batches).
+namespace {
+struct ClimbGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int used = 0, cus = 0;
+};
+ClimbGate g_gate[64];
+struct GateHold {
+  ClimbGate *g = nullptr;
+  int n = 0;
+  ~GateHold() { release(); }
+  void release()
+  {
+    if (!g) return;
+    { std::lock_guard<std::mutex> lk(g->m); g->used -= n; }
+    g->cv.notify_all();
+    g = nullptr;
+  }
+};
+}  // namespace
+
 int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle,
                           uint32_t *reason, uint32_t *n_moves)
 {
@@ -35,7 +61,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   const size_t out_words = hdr_words + 3 * (size_t)total;
   HIPCHK(cd_.bk.reserve(ns));
   HIPCHK(cd_.order.reserve((size_t)total));
-  HIPCHK(cd_.sct.reserve((size_t)tiles * ns));
+  HIPCHK(cd_.sct.reserve((size_t)tiles * ns * 16));
   HIPCHK(cd_.gsum.reserve(3 * (size_t)kClimbCap));
   HIPCHK(cd_.out.reserve(out_words));
   HIPCHK(cd_.h_bk.reserve(ns));
@@ -58,6 +84,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   h.insert_cid = insert_rec_ >= 0 ? (int32_t)slot(insert_rec_) : -1;
   h.remove_cid = remove_rec_ >= 0 ? (int32_t)slot(remove_rec_) : -1;
   h.since_move = 0;
+  h.pad[0] = (uint32_t)climb_debug_;
   h.batch = 0;
   std::memcpy(cd_.h_out.p, &h, sizeof(h));
   ClimbParams p;
@@ -91,6 +118,24 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     p.trace = cd_.trace.p;
     p.trace_cap = (uint32_t)cap;
   }
+  GateHold hold;
+  {
+    ClimbGate &g = g_gate[dev_ & 63];
+    const size_t lds = climb_lds_bytes(g_, n_, vw);
+    const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
+    std::unique_lock<std::mutex> lk(g.m);
+    if (!g.cus) {
+      int c = 0;
+      if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || c <= 0) c = 256;
+      g.cus = c;
+    }
+    // (counted in CU-equivalents of this launch's footprint: tiles / per_cu CUs)
+    const int need = (tiles + per_cu - 1) / per_cu;
+    g.cv.wait(lk, [&] { return g.used == 0 || g.used + need <= g.cus; });
+    g.used += need;
+    hold.g = &g;
+    hold.n = need;
+  }
   HIPCHK(hipMemcpyAsync(cd_.bk.p, cd_.h_bk.p, ns * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(cd_.order.p, cd_.h_order.p, (size_t)total * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(cd_.out.p, cd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st_));
@@ -116,6 +161,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     }
     if (q != hipSuccess) { set_error(std::string("device climb: ") + hipGetErrorString(q)); return MPF_E_HIP; }
   }
+  hold.release();
   std::memcpy(&h, cd_.h_out.p, sizeof(h));
   *reason = h.reason;
   *n_moves = 0;
@@ -159,6 +205,10 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   *n_moves = h.n_moves;
   stats.insertion_tests += h.n_tests;
   stats.algorithmic_bytes += h.n_tests * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  for (int k = 0; k < 7; k++) climb_phase_ticks_[k] += h.tph[k];
+  for (int k = 8; k < 16; k++) climb_phase_ticks_[k] += h.tph[k];
+  climb_phase_ticks_[7] = h.tph[7] * 100ull;     // (kHz of the last launch; read back as "us" / 100)
+  climb_ctr_[0] += h.n_ops; climb_ctr_[1] += h.pad[1]; climb_ctr_[2] += h.pad[2]; climb_ctr_[3] += h.pad[3];
   stats.climb_steps += h.steps;
   stats.climb_nodes += h.n_scanned_nodes;
   stats.climb_moves += h.n_moves;

@@ -42,6 +42,10 @@ def run(codes, dt, back, mode, seed, tie, radius, trace=False, opts=()):
     dt_s = time.perf_counter() - t0
     mv = e.moves()
     tr = e.scan_trace() if trace else None
+    ph = [e.get_option(f"climb_phase_us{k}") for k in "0123456789abcdef"]
+    if mode and not trace:
+        print("   phase us (setup enum closure refresh scan exchange decide):", ph, "| refresh ops, closure rounds, invalidation rounds, chains:",
+              [e.get_option(f"climb_ctr{k}") for k in range(4)], flush=True)
     return dict(s0=s0, s=s, moves=mv, tree=e.get_tree(), secs=dt_s, stats=e.stats(), trace=tr, eng=e)
 
 

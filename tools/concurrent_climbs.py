@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="C3")
 ap.add_argument("--engines", default="1,2,4,8,12,16")
 ap.add_argument("--climbs", type=int, default=1, help="climbs per engine")
+ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
 cfg = synth.WORKLOADS[a.workload]
 letters, names = synth.workload(a.workload)
@@ -21,6 +22,8 @@ emax = max(int(x) for x in a.engines.split(","))
 engs = [engine.FitchEngine(codes, datatype=dt) for _ in range(emax)]
 for e in engs:
     e.set_option("timing", 0)
+    for kv in a.opt:
+        k, v = kv.split("="); e.set_option(k, int(v))
     e.score_tree(trees.random_topology(n, np.random.default_rng(999)))       # warm-up: buffers
     e.optimize_spr(1, 6)
 for E in (int(x) for x in a.engines.split(",")):
