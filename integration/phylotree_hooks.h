@@ -39,9 +39,16 @@ struct mpf_phylotree_hooks {
   // ParsTree: cost_matrix[i * nstates + j] (parstree.h; loaded and triangle-repaired by loadCostMatrixFile,
   // parstree.cpp:31-95); NULL = unit costs (PhyloTree, and ParsTree with "-cost fitch|e")
   const unsigned int *(*cost_matrix)(const PhyloTree *);
-  // identity of the alignment the tree currently holds: the engine (tips resident in HBM) is rebuilt when it changes
-  // (setAlignment(): ratchet, bootstrap alignments)
+  // identity of the alignment the tree currently holds (t->aln).  NOT sufficient as a cache key: optimizeBootTrees does
+  // `bootstrap_aln = new Alignment; ...; delete aln;` once per sample (iqtree.cpp:2519/2863, :2940/2977) and the allocator
+  // hands the same address back, often with the same pattern count -- so the shim compares CONTENT: every call re-reads the
+  // patterns, hashes the states and compares the frequencies (states changed -> engine rebuilt; only frequencies changed ->
+  // mpf_set_weights).  That is P hook calls and n x P bytes per computeParsimony().
   const void *(*alignment_id)(const PhyloTree *);
+  // optional (may be NULL): a number the host changes whenever the alignment's CONTENT changes (e.g. a counter bumped in
+  // Alignment's constructors / setAlignment()).  When present and unchanged, with the same alignment_id, the shim skips
+  // the re-read above.
+  unsigned long long (*alignment_stamp)(const PhyloTree *);
 };
 
 void mpfitch_phylotree_install(const mpf_phylotree_hooks *hooks);

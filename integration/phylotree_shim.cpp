@@ -34,7 +34,10 @@ bool g_installed = false;
 struct Cached {
   mpf_engine *eng = nullptr;
   const void *aln = nullptr;
+  unsigned long long stamp = 0;            // alignment_stamp at the last content check (when the hook exists)
+  unsigned long long hash = 0;             // of the pattern states the engine was built from
   int n = 0, P = 0, protein = 0;
+  std::vector<int32_t> freq;               // pattern frequencies in force in the engine
   std::vector<uint32_t> cost;              // empty = Fitch
 };
 Cached g_fitch, g_cost;                    // PhyloTree / unit-cost ParsTree, and ParsTree with a matrix
@@ -58,18 +61,35 @@ mpf_engine *engine_for(PhyloTree *t, const unsigned int *cost)
   const int S = protein ? 20 : 4;
   Cached &c = cost ? g_cost : g_fitch;
   const bool same_cost = !cost || (c.cost.size() == (size_t)S * (size_t)S && std::memcmp(c.cost.data(), cost, c.cost.size() * sizeof(uint32_t)) == 0);
-  if (c.eng && c.aln == g_h.alignment_id(t) && c.n == n && c.P == P && c.protein == protein && same_cost) return c.eng;
-  drop(c);
-  // the alignment as the IQ-TREE side holds it (patterns of convertState codes) -> PLL tip codes, weights = frequencies
+  const bool same_shape = c.eng && c.n == n && c.P == P && c.protein == protein && same_cost;
+  // the host vouches for the content: same object, same stamp
+  if (same_shape && g_h.alignment_stamp && c.aln == g_h.alignment_id(t) && c.stamp == g_h.alignment_stamp(t)) return c.eng;
+  // otherwise the content decides (a pointer is no identity: `delete aln; new Alignment` returns the same address):
+  // the alignment as the IQ-TREE side holds it (patterns of convertState codes), frequencies, and a hash of the states
   std::vector<signed char> col((size_t)n);
   std::vector<int8_t> states((size_t)n * (size_t)P);
   std::vector<int32_t> freq((size_t)P);
+  unsigned long long hash = 1469598103934665603ull;       // FNV-1a over the patterns, taxon-minor
   for (int p = 0; p < P; p++) {
     int f = 0;
     g_h.pattern(t, p, col.data(), &f);
     freq[(size_t)p] = f;
-    for (int i = 0; i < n; i++) states[(size_t)i * (size_t)P + (size_t)p] = (int8_t)col[(size_t)i];
+    for (int i = 0; i < n; i++) {
+      states[(size_t)i * (size_t)P + (size_t)p] = (int8_t)col[(size_t)i];
+      hash = (hash ^ (unsigned char)col[(size_t)i]) * 1099511628211ull;
+    }
   }
+  if (same_shape && hash == c.hash) {
+    // the same characters: at most the frequencies differ (a re-weighted copy of the alignment)
+    if (freq != c.freq) {
+      if (mpf_set_weights(c.eng, freq.data())) die("mpf_set_weights");
+      c.freq = freq;
+    }
+    c.aln = g_h.alignment_id(t);
+    c.stamp = g_h.alignment_stamp ? g_h.alignment_stamp(t) : 0;
+    return c.eng;
+  }
+  drop(c);
   std::vector<uint8_t> codes(states.size());
   if (mpf_encode_iqtree_states(protein ? MPF_AA : MPF_DNA, states.data(), (int64_t)states.size(), codes.data())) die("mpf_encode_iqtree_states");
   mpf_config cfg;
@@ -83,6 +103,9 @@ mpf_engine *engine_for(PhyloTree *t, const unsigned int *cost)
     if (mpf_engine_create_sankoff(&c.eng, &cfg, codes.data(), freq.data(), c.cost.data())) die("mpf_engine_create_sankoff");
   } else if (mpf_engine_create(&c.eng, &cfg, codes.data(), freq.data())) die("mpf_engine_create");
   c.aln = g_h.alignment_id(t);
+  c.stamp = g_h.alignment_stamp ? g_h.alignment_stamp(t) : 0;
+  c.hash = hash;
+  c.freq = freq;
   c.n = n;
   c.P = P;
   c.protein = protein;

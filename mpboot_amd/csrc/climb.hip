@@ -48,7 +48,7 @@ constexpr uint32_t kLcap = 256;
 constexpr uint32_t kNoSlot = 0xFFu;
 template <int KS, int VW> struct Cfg {
   static constexpr int R = KS * VW;                                   // registers per vector tile
-  static constexpr int PF = R <= 2 ? 8 : R == 4 ? 4 : 2;              // expansions whose child vectors are requested together
+  static constexpr int PF = R <= 2 ? 8 : 4;                           // expansions whose child vectors are requested together
   // operand slots of the refresh (vector + per-lane subtree scores) and the parked up-vectors of the scan are never alive
   // together: one LDS region serves both
   static constexpr size_t kSlotBytes = (size_t)(R + 1) * 64 * 4;
@@ -126,6 +126,14 @@ __device__ __forceinline__ uint32_t nxc(uint32_t c, uint32_t n)
 {
   const uint32_t s = (c - n) % 3u;
   return s == 2u ? c - 2u : c + 1u;
+}
+
+// the two other records of an inner record's node, in ring order
+__device__ __forceinline__ void ring2(uint32_t c, uint32_t n, uint32_t &o1, uint32_t &o2)
+{
+  const uint32_t x = c - n, s = x - 3u * ((x * 43691u) >> 17);      // x mod 3 for x < 2^16
+  o1 = s == 2u ? c - 2u : c + 1u;
+  o2 = s == 0u ? c + 2u : c - 1u;
 }
 
 template <int KS, int VW>
@@ -273,8 +281,9 @@ __device__ __forceinline__ void st_sl(const Kx<KS, VW> &K, uint32_t cid, uint32_
 template <int KS, int VW>
 __device__ __forceinline__ void require(const Kx<KS, VW> &K, Sh &sh, uint32_t c, uint32_t epoch)
 {
-  if (c >= K.n && !K.valid[c]) {
-    const uint32_t old = __hip_atomic_fetch_max(&K.cl[c], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (the claim goes out with the validity read; on a valid vector or a tip it means nothing)
+  const uint32_t old = __hip_atomic_fetch_max(&K.cl[c], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (!K.valid[c]) {
     if ((old >> kEpochShift) != epoch) {
       const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       K.W[slot] = (uint16_t)c;
@@ -378,19 +387,33 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
   const uint32_t n = K.n, epoch = sh.epoch, B = sh.B;
   // candidates are laid out part after part = the reference's order (p side: first gap end, second gap end; then the q side)
   const uint32_t nparts = 4u * B;
+  // prefix sums over the parts without LDS traffic: the four parts of a prune node are the four lanes of a DPP quad, the (at
+  // most eight) prune-node totals go through the scalar unit
   const uint32_t c = (uint32_t)lane < nparts ? sh.pcnt[lane] : 0u;
-  uint32_t incl = c;
+  const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
+  const uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x55, 0xF, 0xF, false);   // quad_perm [1,1,1,1]
+  const uint32_t q2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xAA, 0xF, 0xF, false);   // quad_perm [2,2,2,2]
+  const uint32_t q3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xFF, 0xF, 0xF, false);   // quad_perm [3,3,3,3]
+  const uint32_t qsum = q0 + q1 + q2 + q3;
+  const int lq = lane & 3;
+  const uint32_t in_quad = (lq > 0 ? q0 : 0u) + (lq > 1 ? q1 : 0u) + (lq > 2 ? q2 : 0u);
+  uint32_t pn_tot[kMaxB], pn_pre[kMaxB + 1];
+  pn_pre[0] = 0;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-    if (lane >= o) incl += t;
+  for (int j = 0; j < kMaxB; j++) {
+    pn_tot[j] = (uint32_t)__builtin_amdgcn_readlane((int)qsum, 4 * j);
+    pn_pre[j + 1] = pn_pre[j] + pn_tot[j];
   }
   // speculation is cut where the step's candidate buffer ends (one prune node never exceeds it)
-  const unsigned long long fits = __ballot((lane & 3) == 3 && (uint32_t)lane < nparts && incl <= kClimbCap);
-  const uint32_t Beff = (uint32_t)__builtin_popcountll(fits);
-  const uint32_t tot_eff = (uint32_t)__shfl((int)incl, (int)(4u * Beff) - 1, 64);
-  const uint32_t excl = incl - c;
-  const uint32_t e2 = (uint32_t)__shfl((int)incl, (lane & ~3) + 1, 64), e4 = (uint32_t)__shfl((int)incl, (lane & ~3) + 3, 64);
+  uint32_t Beff = 0, tot_eff = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxB; j++)
+    if ((uint32_t)j < B && pn_pre[j + 1] <= kClimbCap) { Beff = (uint32_t)j + 1u; tot_eff = pn_pre[j + 1]; }
+  uint32_t my_pre = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxB; j++) my_pre = (lane >> 2) == j ? pn_pre[j] : my_pre;
+  const uint32_t excl = my_pre + in_quad;
+  const uint32_t e2 = my_pre + q0 + q1, e4 = my_pre + qsum;
   if ((uint32_t)lane < nparts) {
     const bool live = (uint32_t)(lane >> 2) < Beff;
     sh.poff[lane] = excl;
@@ -418,12 +441,15 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
   }
   // closure: every lane follows one chain of stale inputs; forks go to the shared worklist.  Every vector gets an index (the
   // order in which the lanes take them up); the first kLcap are listed for the link pass below.
-  uint32_t head = 0, tail = sh.wtail, nops = 0;
+  // (a lane walks several links between two looks at the worklist: the bookkeeping of a round costs as much as a link)
+  uint32_t head = 0;
   bool have = false;
   uint32_t item = 0;
   uint32_t round = 0;
+  if (lane == 0) sh.nops = 0;
   for (;; round++) {
     if (round > K.ns) { if (lane == 0) sh.err = 3u; break; }
+    const uint32_t tail = *(volatile uint32_t *)&sh.wtail;
     {
       const unsigned long long need = __ballot((int)!have);
       const uint32_t rank = (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
@@ -432,39 +458,45 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
       const uint32_t want = (uint32_t)__builtin_popcountll(need);
       head += want < avail ? want : avail;
     }
-    const unsigned long long act = __ballot((int)have);
-    if (!act) break;
-    bool push = false;
-    uint32_t pv = 0;
-    if (have) {
-      const uint32_t r = item;
-      const uint32_t idx = nops + (uint32_t)__builtin_popcountll(act & ((1ull << lane) - 1ull));
-      const uint32_t r1 = nxc(r, n);
-      const uint32_t a = K.bk[r1], b = K.bk[nxc(r1, n)];
-      // (the claims go out together with the validity reads -- one LDS round trip instead of two; a claim on a vector that
-      //  turns out to be valid, or on a tip, means nothing: only stale vectors are ever looked up by their claim)
-      const uint32_t oa = __hip_atomic_fetch_max(&K.cl[a], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const uint32_t ob = __hip_atomic_fetch_max(&K.cl[b], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const bool sa = a >= n && !K.valid[a], sb = b >= n && !K.valid[b];
-      const bool wa = sa && (oa >> kEpochShift) != epoch, wb = sb && (ob >> kEpochShift) != epoch;
-      const uint32_t ns = (sa ? 1u : 0u) + (sb ? 1u : 0u);
-      // (r is claimed already: other lanes' fetch_max leave the word as it is)
-      K.cl[r] = (epoch << kEpochShift) | ((idx < kIdxMask ? idx : kIdxMask) << 3) | ns;
-      if (idx < kLcap) K.OL[idx] = (uint16_t)r;
-      if (!ns) {
-        const uint32_t slot = __hip_atomic_fetch_add(&sh.rtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        K.R[slot] = (uint16_t)r;                         // both inputs valid: a chain starts here
+    if (!__ballot((int)have)) break;
+#pragma unroll 1
+    for (int step = 0; step < 4; step++) {
+      if (have) {
+        const uint32_t r = item;
+        uint32_t r1, r2;
+        ring2(r, n, r1, r2);
+        // two LDS round trips per link: (1) the inputs' ids and this op's index, (2) the inputs' claims and validity -- every
+        // read unconditional (tips count as valid vectors), nothing waits in between
+        const uint32_t a = K.bk[r1], b = K.bk[r2];
+        const uint32_t idx = __hip_atomic_fetch_add(&sh.nops, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (a claim on a vector that turns out to be valid, or on a tip, means nothing: only stale vectors are ever looked up
+        //  by their claim)
+        const uint32_t oa = __hip_atomic_fetch_max(&K.cl[a], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t ob = __hip_atomic_fetch_max(&K.cl[b], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t va = K.valid[a], vb = K.valid[b];
+        const bool sa = !va, sb = !vb;
+        const bool wa = sa & ((oa >> kEpochShift) != epoch), wb = sb & ((ob >> kEpochShift) != epoch);
+        const uint32_t ns = (sa ? 1u : 0u) + (sb ? 1u : 0u);
+        // (r is claimed already: other lanes' fetch_max leave the word as it is)
+        K.cl[r] = (epoch << kEpochShift) | ((idx < kIdxMask ? idx : kIdxMask) << 3) | ns;
+        if (idx < kLcap) K.OL[idx] = (uint16_t)r;
+        if (!ns) {
+          const uint32_t slot = __hip_atomic_fetch_add(&sh.rtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          K.R[slot] = (uint16_t)r;                       // both inputs valid: a chain starts here
+        }
+        if (wa) {
+          item = a;
+          if (wb) {
+            const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            K.W[slot] = (uint16_t)b;
+          }
+        } else if (wb) item = b;
+        else have = false;
       }
-      if (wa) { item = a; if (wb) { push = true; pv = b; } }
-      else if (wb) item = b;
-      else have = false;
     }
-    nops += (uint32_t)__builtin_popcountll(act);
-    const unsigned long long pm = __ballot((int)push);
-    if (push) K.W[tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (uint16_t)pv;
-    tail += (uint32_t)__builtin_popcountll(pm);
   }
-  if (lane == 0) { sh.nops = nops; sh.n_ops += nops; sh.c_rounds += round; sh.c_chains += sh.rtail; }
+  const uint32_t nops = *(volatile uint32_t *)&sh.nops;
+  if (lane == 0) { sh.n_ops += nops; sh.c_rounds += round; sh.c_chains += sh.rtail; }
   // link pass: every op of a closure that fits gets a descriptor, a slot for each operand that is valid already (staged into
   // LDS before the chains start), and registers with its stale inputs as their consumer -- what a chain needs to go from one
   // link to the next is then ONE entry, read a link ahead
@@ -954,10 +986,12 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
       const uint32_t w = K.bk[rec];
       if (w >= n) { have = true; item = w; }
     }
-    uint32_t head = 0, tail = 0;
+    uint32_t head = 0;
     uint32_t round = 0;
+    if (lane == 0) sh.wtail = 0;
     for (;; round++) {
       if (round > K.ns) { if (lane == 0) sh.err = 4u; break; }
+      const uint32_t tail = *(volatile uint32_t *)&sh.wtail;
       {
         const unsigned long long need = __ballot((int)!have);
         const uint32_t rank = (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
@@ -967,28 +1001,35 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
         head += want < avail ? want : avail;
       }
       if (!__ballot((int)have)) break;
-      bool push = false;
-      uint32_t pv = 0;
-      if (have) {
-        const uint32_t o1 = nxc(item, n), o2 = nxc(o1, n);
-        const bool w1 = (__hip_atomic_fetch_max(&K.cl[o1], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kEpochShift) != einv;
-        const bool w2 = (__hip_atomic_fetch_max(&K.cl[o2], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kEpochShift) != einv;
-        const bool v1 = w1 && K.valid[o1], v2 = w2 && K.valid[o2];
-        const uint32_t u1 = K.bk[o1], u2 = K.bk[o2];
-        if (v1) K.valid[o1] = 0;
-        if (v2) K.valid[o2] = 0;
-        const bool g1 = v1 && u1 >= n, g2 = v2 && u2 >= n;
-        if (g1) { item = u1; if (g2) { push = true; pv = u2; } }
-        else if (g2) item = u2;
-        else have = false;
+#pragma unroll 1
+      for (int step = 0; step < 4; step++) {
+        if (have) {
+          uint32_t o1, o2;
+          ring2(item, n, o1, o2);
+          // (one LDS round trip per link: claims, validity and the records behind go out together)
+          const uint32_t c1 = __hip_atomic_fetch_max(&K.cl[o1], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t c2 = __hip_atomic_fetch_max(&K.cl[o2], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t x1 = K.valid[o1], x2 = K.valid[o2];
+          const uint32_t u1 = K.bk[o1], u2 = K.bk[o2];
+          const bool v1 = ((c1 >> kEpochShift) != einv) & (x1 != 0u), v2 = ((c2 >> kEpochShift) != einv) & (x2 != 0u);
+          if (v1) K.valid[o1] = 0;
+          if (v2) K.valid[o2] = 0;
+          const bool g1 = v1 & (u1 >= n), g2 = v2 & (u2 >= n);
+          if (g1) {
+            item = u1;
+            if (g2) {
+              const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              K.W[slot] = (uint16_t)u2;
+            }
+          } else if (g2) item = u2;
+          else have = false;
+        }
       }
-      const unsigned long long pm = __ballot((int)push);
-      if (push) K.W[tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (uint16_t)pv;
-      tail += (uint32_t)__builtin_popcountll(pm);
     }
     if (lane == 0) sh.c_inv += round;
   }
   if (lane == 0) {
+    if (sh.ncand) { sh.last_ncand[sh.xgen % 3u] = sh.ncand; sh.xgen++; }
     sh.best = best; sh.randomMP = randomMP; sh.iter_hits = iter_hits;
     sh.rng = rng; sh.hits = hits; sh.draws = draws; sh.ins = ins; sh.rem = rem;
     sh.n_tests += tests; sh.n_nodes += consumed;
@@ -1202,15 +1243,13 @@ __global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
         }
         K.cost[c] = (uint32_t)(v & kValMask);
       }
-      __syncthreads();
-      // the slot used one exchange ago has been read by everybody who got here: its turn comes again two exchanges on
+      // the slot used one exchange ago has been read by everybody who got here: its turn comes again two exchanges on (this
+      // workgroup's next adds are several barriers away)
       if (tile == sh.xgen % T) {
         const uint32_t zs = (sh.xgen + 2u) % 3u;
         unsigned long long *gz = P.gsum + (size_t)zs * kClimbCap;
         for (uint32_t c = (uint32_t)tid; c < sh.last_ncand[zs]; c += kThreads) __hip_atomic_store(gz + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __syncthreads();
-      if (tid == 0) { sh.last_ncand[slot] = ncand; sh.xgen++; }
     }
     __syncthreads();
     beat(P, tile, tid, 1, 6);

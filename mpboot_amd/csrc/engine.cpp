@@ -151,6 +151,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
 // The filter runs on the host (one pass over the codes); the bit transposition runs on the device.
 int Engine::pack()
 {
+  pack_gen_++;
   const int und = datatype_ == MPF_DNA ? 15 : 22;
   long entries = 0;
   ninf_ = 0;
@@ -1005,16 +1006,29 @@ int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
   return MPF_OK;
 }
 
-// spin on a flag word a kernel raises in pinned host memory; false after ~50 ms (the caller then synchronises the stream,
-// which also surfaces a failed launch)
+// spin on a flag word a kernel raises in pinned host memory; false after 50 ms of wall clock (the caller then synchronises
+// the stream, which also surfaces a failed launch at once instead of after a long spin)
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
 static bool wait_host_flag(const uint32_t *flag)
 {
-  for (long spin = 0; spin < 20000000L; spin++) {
+  std::chrono::steady_clock::time_point t0;
+  for (long spin = 0;; spin++) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 1u) return true;
-    __builtin_ia32_pause();
-    if ((spin & 255) == 255) sched_yield();        // several engines per GPU poll from threads that may share cores
+    cpu_relax();
+    if ((spin & 255) == 255) {
+      sched_yield();                               // several engines per GPU poll from threads that may share cores
+      const auto now = std::chrono::steady_clock::now();
+      if (spin == 255) t0 = now;
+      else if (now - t0 > std::chrono::milliseconds(50)) return false;
+    }
   }
-  return false;
 }
 
 int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_host)
@@ -1499,6 +1513,19 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
 int Engine::sweep_costs(int mintrav, int maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets, uint64_t *n_tests)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+  // a caller sizes its buffer with a first call (cap = 0) and fetches with a second one: the first call's sweep is kept, the
+  // second one copies (same tree, same packing, same radius) instead of scanning the whole tree again
+  const uint64_t key[4] = {(uint64_t)topo_epoch_, (uint64_t)mintrav, (uint64_t)maxtrav, pack_gen_};
+  if (sc_keep_valid_ && std::equal(key, key + 4, sc_keep_key_) && cap >= sc_keep_mp_.size()) {
+    *n_tests = sc_keep_mp_.size();
+    std::copy(sc_keep_mp_.begin(), sc_keep_mp_.end(), mp);
+    if (offsets) std::copy(sc_keep_off_.begin(), sc_keep_off_.end(), offsets);
+    sc_keep_valid_ = false;
+    sc_keep_mp_.clear();
+    sc_keep_mp_.shrink_to_fit();
+    return MPF_OK;
+  }
+  sc_keep_valid_ = false;
   node_rectifier();
   std::vector<ScanPlan> &plans = sweep_plans_;
   const uint32_t *out = nullptr;
@@ -1507,17 +1534,25 @@ int Engine::sweep_costs(int mintrav, int maxtrav, uint64_t cap, uint32_t *mp, ui
   uint64_t tests = 0;
   for (const ScanPlan &pl : plans) tests += pl.walked ? (uint64_t)pl.n_total : (uint64_t)pl.cands.size();
   *n_tests = tests;
+  const bool keep = cap < tests;                   // a sizing call: fill our own copy
+  if (keep) { sc_keep_mp_.resize(tests); sc_keep_off_.assign(plans.size() + 1, 0); }
+  uint32_t *dst = keep ? sc_keep_mp_.data() : mp;
+  uint64_t *doff = keep ? sc_keep_off_.data() : offsets;
   uint64_t at = 0;
   size_t i = 0;
   for (const ScanPlan &pl : plans) {
     const size_t nc = pl.walked ? (size_t)pl.n_total : pl.cands.size();
-    if (offsets) offsets[i] = at;
-    if (cap >= tests)
-      for (size_t c = 0; c < nc; c++) mp[at + c] = pl.base + pl.cost(c, out);
+    if (doff) doff[i] = at;
+    for (size_t c = 0; c < nc; c++) dst[at + c] = pl.base + pl.cost(c, out);
     at += nc;
     i++;
   }
-  if (offsets) offsets[i] = at;
+  if (doff) doff[i] = at;
+  if (keep) {
+    if (offsets) std::copy(sc_keep_off_.begin(), sc_keep_off_.end(), offsets);
+    std::copy(key, key + 4, sc_keep_key_);
+    sc_keep_valid_ = true;
+  }
   return MPF_OK;
 }
 

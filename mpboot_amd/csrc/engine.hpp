@@ -506,6 +506,11 @@ class Engine {
   size_t trace_words_ = 0;
   std::vector<uint32_t> out_scratch_;
   std::vector<ScanPlan> sweep_plans_;
+  // sweep_costs: the result of a sizing call, handed out by the fetch call behind it
+  std::vector<uint32_t> sc_keep_mp_;
+  std::vector<uint64_t> sc_keep_off_;
+  uint64_t sc_keep_key_[4] = {0, 0, 0, 0}, pack_gen_ = 0;
+  bool sc_keep_valid_ = false;
   // number of records addTraverseParsimony visits below record q with m levels left (memo per topology epoch)
   std::vector<int32_t> nvis_val_, nvis_epoch_;
   int32_t topo_epoch_ = 1;

@@ -1972,7 +1972,11 @@ hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const
   const long waves = 2L * n_scans;
   // MPF_PROG_CID_MASK (experiments only): wrong results on purpose -- every child vector is taken from a small set, to time
   // the scan kernel with its memory traffic confined to the nearest cache
+#ifdef MPF_EXPERIMENTS                     // (timing builds of tools/scan_bounds.sh only: `make EXPERIMENTS=1`)
   static const uint32_t cid_mask = getenv("MPF_PROG_CID_MASK") ? (uint32_t)strtoul(getenv("MPF_PROG_CID_MASK"), nullptr, 0) : 0xFFFFFFFFu;
+#else
+  const uint32_t cid_mask = 0xFFFFFFFFu;
+#endif
   hipLaunchKernelGGL(k_walk_plan, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, kids, (uint32_t)n_taxa, desc, n_scans,
                      static_cast<ProgEnt *>(prog), cid_mask);
   return hipGetLastError();
@@ -2057,10 +2061,12 @@ hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *v
   dim3 grid(nblocks);
   const ProgEnt *pg = static_cast<const ProgEnt *>(prog);
 #define SP(VW_, BIG_) hipLaunchKernelGGL((k_scan_prog<4, VW_, BIG_>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace)
+#ifdef MPF_EXPERIMENTS                     // (wrong results on purpose: never in the production library)
   static const int expr = getenv("MPF_PROG_EXPERIMENT") ? atoi(getenv("MPF_PROG_EXPERIMENT")) : 0;
   if (expr == 1) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 1>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else if (expr == 2) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 2>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else
+#endif
   if (g.big) SP(1, true);
   else if (vw == 1) SP(1, false);
   else SP(2, false);

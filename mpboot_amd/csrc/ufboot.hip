@@ -19,6 +19,7 @@
 #include "ufboot.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace mpf {
@@ -500,14 +501,14 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   if (col_blocks <= 8 && 8 % col_blocks == 0) { const int per_x = 8 / col_blocks; gx = (unsigned)(((row_blocks + per_x - 1) / per_x) * 8); }
   else gx = (unsigned)(row_blocks * col_blocks);
   // > 64 KiB of dynamic LDS needs the opt-in, once per device (engines of one process may sit on different GPUs)
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];                  // (engines on several host threads share a device)
   int dev = 0;
   (void)hipGetDevice(&dev);
   constexpr size_t lds = gemm_lds<MT, NT, WM, WN, KS, NS>();
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+  if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR, M32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR, M32>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
   return hipGetLastError();
@@ -526,12 +527,14 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
     // few rows (the batches inside a climb): 512-row x 128-sample tiles -- twice the column blocks, half the K-splits
     static const int small_v = std::getenv("MPF_GEMM_SMALL") ? std::atoi(std::getenv("MPF_GEMM_SMALL")) : 1;
     if (small_v == 1 && rows_padded <= 1024) return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+#ifdef MPF_EXPERIMENTS                     // (knock-out variants of tools/gemm_bounds.sh, wrong results on purpose: `make EXPERIMENTS=1` only)
     static const int expr = std::getenv("MPF_GEMM_EXPERIMENT") ? std::atoi(std::getenv("MPF_GEMM_EXPERIMENT")) : 0;
     if (expr == 1) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 1>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (expr == 2) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (expr == 3) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 3>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (expr == 6) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 6>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
     if (expr == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+#endif
     // variants (all within 0.43-0.49 of the nominal peak, tools/gemm_bounds.sh): 0 = two k-blocks per stage, four stages in
     // the ring; 1 / 3 = 4 x 2 waves of 64 rows x 128 samples; default = 8 x 1 waves of 32 rows x 256 samples, four k-blocks
     // per stage, two stages

@@ -9,7 +9,10 @@
  * _pattern_pars including its 16-entry tail.
  *
  * input (text, stdin): n P protein(0|1) ; P frequencies ; n rows of P state codes ; 2n-2 rows "k id0 [id1 id2]" ;
- *                      then "cost 0" or "cost 1" + S*S entries ; then "trees T" and T-1 further neighbour tables
+ *                      then "cost 0" or "cost 1" + S*S entries ; then "trees T" and T-1 further neighbour tables ;
+ *                      then optionally "mutate M" and M times either "freq" + P frequencies or "states" + n rows of P codes:
+ *                      the alignment object is changed IN PLACE (same address, same pattern count -- what `delete aln; new
+ *                      Alignment` of the reference's bootstrap loop looks like to a pointer-keyed cache) and the last tree scored again
  */
 #include <cstdio>
 #include <cstdlib>
@@ -89,7 +92,7 @@ int main()
   int T = 1;
   if (std::scanf("%15s %d", word, &T) != 2) return 2;
 
-  mpf_phylotree_hooks h;
+  mpf_phylotree_hooks h{};
   h.n_taxa = hk_ntaxa; h.n_patterns = hk_nptn; h.is_protein = hk_prot; h.pattern = hk_pattern; h.neighbors = hk_nei;
   h.pattern_pars = hk_ptnpars; h.cost_matrix = hk_cost; h.alignment_id = hk_alnid;
   mpfitch_phylotree_install(&h);
@@ -104,6 +107,21 @@ int main()
     std::printf("score %d\npattern_pars", score);
     for (int p = 0; p < P + 16; p++) std::printf(" %u", (unsigned)tree->_pattern_pars[p]);
     std::printf("\n");
+  }
+  int M = 0;
+  if (std::scanf("%15s %d", word, &M) == 2) {
+    for (int m = 0; m < M; m++) {
+      if (std::scanf("%15s", word) != 1) return 2;
+      if (word[0] == 'f') {
+        for (int &f : tree->freq) if (std::scanf("%d", &f) != 1) return 2;
+      } else {
+        for (auto &s : tree->states) { int v; if (std::scanf("%d", &v) != 1) return 2; s = (signed char)v; }
+      }
+      const int score = tree->computeParsimony();
+      std::printf("score %d\npattern_pars", score);
+      for (int p = 0; p < P + 16; p++) std::printf(" %u", (unsigned)tree->_pattern_pars[p]);
+      std::printf("\n");
+    }
   }
   delete tree;
   mpfitch_phylotree_release();

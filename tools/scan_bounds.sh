@@ -1,6 +1,9 @@
 #!/bin/bash
 # What bounds k_scan_prog: the kernel, its loads-only and arithmetic-only variants, the same with every
 # load confined to 64 hot vectors, the walking kernel, and the VALU issue rates of the instructions it is made of.
+# the knock-out variants exist only in an experiments build of the library (results are wrong on purpose)
+make -s -C mpboot_amd/csrc clean && make -s -j8 -C mpboot_amd/csrc EXPERIMENTS=1
+trap 'make -s -C mpboot_amd/csrc clean && make -s -j8 -C mpboot_amd/csrc' EXIT
 mkdir -p gpurun_out/bounds
 {
 echo "== bench.py --steps 20 --warmup 5 (C3 sweep; scan = HIP-event time of the scan kernel per launch, ms) =="
