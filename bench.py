@@ -27,6 +27,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# engines on several host threads launch concurrently only as far as their streams get hardware queues of their own (the
+# runtime's default is 4 per process; a persistent climb kernel holds its queue for a whole sweep: profiles/r3/concurrent_climbs.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 I8_PEAK_TOPS = 5000.0      # dense int8 MFMA, 2 x bf16 (MI355X_MICROARCH.md, matrix cores)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
@@ -415,6 +418,10 @@ def main():
     ap.add_argument("--legs-timeout", type=int, default=180,
                     help="multi-GPU runs: seconds after which the headline line is printed without the secondary (-bb) legs")
     ap.add_argument("--engines-per-gpu", type=int, default=6, help="concurrent engines (host threads) per GPU in the refinement leg")
+    ap.add_argument("--climb-engines", type=int, default=8,
+                    help="independent SPR climbs side by side on one GPU (one engine per host thread): the concurrent_climbs leg (0 = skip)")
+    ap.add_argument("--start-trees", type=int, default=100,
+                    help="randomized-stepwise-addition + SPR start trees of the start-up phase (phyloanalysis.cpp:1270-1317), sharded over the GPUs (0 = skip)")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
@@ -462,7 +469,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from mpboot_amd import engine, synth, trees
+    from mpboot_amd import engine, shard, synth, trees
 
     cfg = synth.WORKLOADS[args.workload]
     alphabet = cfg["alphabet"]
@@ -499,7 +506,13 @@ def main():
     for _ in range(8):
         eng.set_tree(back)
         eng.sweep_scan(1, args.maxtrav)
-    for _ in range(args.warmup):
+    # The timed steps hand one tree over again and again.  What the engine plans from the topology alone (refresh schedule, scan
+    # descriptors, device program) would be planned once and reused -- as it is between bootstrap replicates that share a tree, or
+    # after a re-weighting, in a real run -- but a plain search sees a NEW topology after every accepted move, so the headline is
+    # timed with that reuse switched off (engine option plan_cache = 0: every step plans from scratch, everything else identical).
+    # A short untimed loop afterwards prices the step with the reuse on; both figures go into the line.
+    eng.set_option("plan_cache", 0)
+    for _ in range(args.warmup):                 # W untimed warm-up steps, the same kind of step as the timed ones
         eng.set_tree(back)
         eng.sweep_scan(1, args.maxtrav)
     eng.reset_stats()
@@ -513,23 +526,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = eng.stats()
-    # The timed steps hand the SAME tree over again and again, so what the engine plans from the topology alone (refresh
-    # schedule, scan descriptors, device program) is planned once and reused -- as it is between bootstrap replicates that
-    # share a tree, or a re-weighting, in a real run.  A short untimed loop with that reuse switched off prices a step on a
-    # topology the engine has never seen (everything else identical); both figures go into the line.
-    eng.set_option("plan_cache", 0)
-    csteps = max(1, min(20, args.steps))
+    eng.set_option("plan_cache", 1)
+    wsteps = max(1, min(20, args.steps))
     for _ in range(3):
         eng.set_tree(back)
         eng.sweep_scan(1, args.maxtrav)
     torch.cuda.synchronize()
     tc0 = time.perf_counter()
-    for _ in range(csteps):
+    for _ in range(wsteps):
         eng.set_tree(back)
         eng.sweep_scan(1, args.maxtrav)
     torch.cuda.synchronize()
-    cold_ms = (time.perf_counter() - tc0) / csteps * 1e3
-    eng.set_option("plan_cache", 1)
+    warm_ms = (time.perf_counter() - tc0) / wsteps * 1e3
     # the refresh kernels' own time comes from a short untimed pass: their event pair would cost the timed steps ~10 us each
     eng.set_option("timing", 2)
     eng.reset_stats()
@@ -585,7 +593,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_all / args.steps * 1e3,
-            "ms_per_step_new_topology": cold_ms,       # rank 0, planning from scratch every step (engine option plan_cache = 0)
+            "ms_per_step_same_topology": warm_ms,      # rank 0, untimed side loop: plans of the topology reused (engine option plan_cache = 1)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -594,10 +602,10 @@ def main():
             "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
                                    "one full sweep scan per step (all prune nodes, both sides)",
                        "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
-                       "planning": "the steps re-submit one tree: refresh schedule, scan descriptors and the planned device program are "
-                                   "built at the first step and reused (they depend on the topology only); every vector is recomputed and "
-                                   "every insertion test re-scored in every step.  ms_per_step_new_topology = the same step with that "
-                                   "reuse off",
+                       "planning": "every step plans from scratch (refresh schedule, scan descriptors, device program: engine option "
+                                   "plan_cache = 0), recomputes every vector and re-scores every insertion test -- the step of a search that has "
+                                   "just accepted a move.  ms_per_step_same_topology = the same step on a topology the engine has planned "
+                                   "before (a re-weighted or re-evaluated tree)",
                        "start_tree_score": start_score, "parallelism": f"independent start trees x{world}",
                        # the three rates side by side.  value = effective (n x P x evals/s, as defined);
                        # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
@@ -755,10 +763,28 @@ def main():
                 barrier()
                 t_plain = time.perf_counter() - t0r
                 st_plain = eng.stats()
+                # (the same climb with the sweep loop on the host: one launch chain + synchronisation per accepted move)
+                eng.set_option("climb_device", 0)
+                eng.set_tree(back_r)
+                eng.reset_node_order()
+                eng.seed_ties(engine.TIE_RANDOM, 1)
+                barrier()
+                t0r = time.perf_counter()
+                s_plain_h = eng.optimize_spr(1, args.maxtrav)
+                barrier()
+                t_plain_h = time.perf_counter() - t0r
+                eng.set_option("climb_device", 1)
+                assert s_plain_h == s_plain
                 nondeg = {"start": "random topology (numpy default_rng(2024))", "start_score": eng.score_tree(back_r),
                           "plain_climb": {"seconds": t_plain, "score": s_plain, "moves": st_plain["moves_applied"],
                                           "insertion_tests": st_plain["insertion_tests"], "scan_launches": st_plain["scan_launches"],
-                                          "tests_per_s": st_plain["insertion_tests"] / t_plain}}
+                                          "tests_per_s": st_plain["insertion_tests"] / t_plain,
+                                          "climb_kernel": {"launches": st_plain["climb_launches"], "steps": st_plain["climb_steps"],
+                                                           "prune_nodes": st_plain["climb_nodes"], "moves": st_plain["climb_moves"],
+                                                           "ms": st_plain["climb_ms_total"]},
+                                          "seconds_host_driven_batches": t_plain_h,
+                                          "what": "pllOptimizeSprParsimony from a random tree: sweeps with dense moves run in the persistent kernel "
+                                                  "k_climb (device-resident loop), sparse ones as whole-chip host-driven batches"}}
                 eng.ufboot_attach(samples, 0.5, shard=(rank, world))
                 eng.set_tree(back_r)
                 eng.reset_node_order()
@@ -798,15 +824,129 @@ def main():
             legs_error = repr(exc)
             ufb = boot = nondeg = None
 
+    # ---- further legs: whole climbs, not sweeps
+    import threading as _th
+    mk = lambda: engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
+    conc = None
+    c2leg = None
+    startup = None
+    try:
+        pool = [eng]
+        def grow(k):
+            while len(pool) < k:
+                x = mk()
+                for kv in args.opt:
+                    kk, vv = kv.split("=")
+                    x.set_option(kk, int(vv))
+                pool.append(x)
+        def run_threads(k, fn):
+            out = [None] * k
+            def work(i):
+                out[i] = fn(i, pool[i])
+            th = [_th.Thread(target=work, args=(i,)) for i in range(k)]
+            barrier()
+            t0_ = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0_, out
+        if args.climb_engines > 0 and args.random_start_leg:
+            # independent climbs from random trees, one engine per host thread (the shape of the start trees / the refinements of
+            # a run): every climb is a chain of dependent steps, concurrent engines fill the chip
+            E = args.climb_engines
+            grow(E)
+            def climb_fn(mode, tile):
+                def f(i, x):
+                    x.set_option("climb_device", mode)
+                    x.set_option("climb_tile", tile)
+                    x.set_tree(trees.random_topology(n, np.random.default_rng(7000 + 100 * rank + i)))
+                    x.reset_node_order()
+                    x.seed_ties(engine.TIE_RANDOM, 1 + i)
+                    return x.optimize_spr(1, args.maxtrav)
+                return f
+            run_threads(E, climb_fn(2, 4))                                     # buffers, code
+            t_dev, sc_dev = run_threads(E, climb_fn(2, 4))
+            t_host, sc_host = run_threads(E, climb_fn(0, 1))
+            for x in pool:
+                x.set_option("climb_device", 1)
+                x.set_option("climb_tile", 1)
+            assert sc_dev == sc_host
+            conc = {"engines": E, "climbs_per_s": E / t_dev, "seconds_per_round": t_dev, "scores": [int(min(sc_dev)), int(max(sc_dev))],
+                    "host_driven_batches": {"climbs_per_s": E / t_host, "seconds_per_round": t_host},
+                    "what": "%d independent SPR climbs (radius %d) from random topologies side by side on one GPU, one engine per host "
+                            "thread; each climb runs in the persistent kernel k_climb (64-word tiles: %d workgroups per climb); "
+                            "host_driven_batches = the same climbs with the loop on the host (engine option climb_device = 0).  "
+                            "GPU_MAX_HW_QUEUES=%s" % (E, args.maxtrav, (eng.Wp + 63) // 64, os.environ.get("GPU_MAX_HW_QUEUES"))}
+        if args.start_trees > 0:
+            # the start-up phase of a run: numpars randomized-stepwise-addition trees, each SPR-optimised (phyloanalysis.cpp:1270-1317,
+            # tools.cpp:767); unit u on rank u % n_gpus, several engines per GPU
+            k_e = max(1, min(6, args.climb_engines if args.climb_engines > 0 else 1))
+            grow(k_e)
+            units = [u for u in range(args.start_trees) if u % world == rank]
+            def ras_fn(i, x):
+                best = None
+                for u in units[i::k_e]:
+                    sd = shard.unit_seed(31337, u)
+                    x.seed_ties(engine.TIE_RANDOM, sd)
+                    x.reset_node_order()
+                    sc = x.make_parsimony_tree(sd, args.maxtrav)
+                    best = sc if best is None else min(best, sc)
+                return best
+            t_ras, bests = run_threads(k_e, ras_fn)
+            barrier()
+            bb = [b for b in bests if b is not None]
+            startup = {"trees": args.start_trees, "seconds": t_ras, "engines_per_gpu": k_e, "best_score_rank0": int(min(bb)) if bb else None,
+                       "seconds_per_tree_per_engine": t_ras * k_e / max(1, len(units)),
+                       "what": "%d randomized stepwise-addition trees + SPR climb (radius %d) each, as the reference's start-up builds them "
+                               "(phyloanalysis.cpp:1270-1317); tree u on rank u %% n_gpus" % (args.start_trees, args.maxtrav)}
+        if world == 1 and args.workload == "C3":
+            # BASELINE config 2 (200 taxa x 10 000 patterns): a full SPR hill climb from a random tree
+            letters2, names2 = synth.workload("C2")
+            codes2 = synth.letters_to_codes(letters2, "DNA")
+            e2 = engine.FitchEngine(codes2, datatype=engine.DNA, device=device)
+            back2 = trees.random_topology(codes2.shape[0], np.random.default_rng(1))
+            tt = []
+            for _ in range(3):
+                e2.set_tree(back2)
+                e2.reset_node_order()
+                e2.seed_ties(engine.TIE_RANDOM, 1)
+                e2.reset_stats()
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                s2 = e2.optimize_spr(1, args.maxtrav)
+                tt.append(time.perf_counter() - t0_)
+            st2 = e2.stats()
+            c2leg = {"workload": "C2: 200 taxa x 10000 DNA patterns, full SPR hill climb from a random topology (numpy default_rng(1)), radius %d" % args.maxtrav,
+                     "seconds": min(tt[1:]), "seconds_each_pass": tt, "score": s2, "moves": st2["moves_applied"], "insertion_tests": st2["insertion_tests"],
+                     "climb_kernel_launches": st2["climb_launches"], "climb_kernel_steps": st2["climb_steps"]}
+            if not args.no_cpu:
+                c2leg["cpu_baseline"] = climb_cpu_baseline(names2, letters2, "DNA", back2, args.maxtrav)
+                if c2leg["cpu_baseline"]:
+                    c2leg["gpu_over_cpu"] = c2leg["cpu_baseline"]["seconds"] / c2leg["seconds"]
+            del e2
+    except Exception as exc:
+        legs_error = (legs_error or "") + " | climb legs: " + repr(exc)
+
     watchdog.cancel()
     if rank == 0:
         res = core_res
+        if conc is not None:
+            res["concurrent_climbs"] = conc
+        if startup is not None:
+            res["start_trees"] = startup
+        if c2leg is not None:
+            res["c2_climb"] = c2leg
         if legs_error is not None:
             res["bootstrap_legs_error"] = legs_error
         if boot is not None:
             res["bootstrap_wall_clock"] = {
                 "samples": ufb["samples"], "online_phase_s": ufb["seconds"], "refined_samples": boot[0], "refinement_s": boot[1],
-                "seconds": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
+                "seconds_from_ras_tree": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
+                # the flow that really searches: from a random topology (thousands of accepted moves online, refinements that climb);
+                # the RAS tree of this alignment is SPR-optimal already (zero moves: seconds_from_ras_tree is 1000 move-less sweeps)
+                "seconds": (nondeg["bb_flow"]["seconds"] if nondeg is not None and "bb_flow" in nondeg
+                            else ufb["seconds"] + boot[1] * ufb["samples"] / boot[0]),
+                "seconds_is": "random-start flow (random_start.bb_flow)" if nondeg is not None and "bb_flow" in nondeg else "flow from the RAS tree",
                 "refinement_s_plan_cache_off": tb_nocache, "distinct_boot_trees": n_distinct_trees,
                 "scaling": "strong", "engines_per_gpu": n_eng,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],

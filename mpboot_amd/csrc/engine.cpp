@@ -65,6 +65,11 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   if (const char *hp = std::getenv("MPF_HOST_POLL")) host_poll_ = std::atoi(hp) ? 1 : 0;        // (experiments)
   if (const char *vt = std::getenv("MPF_VIEWS_TILE")) { const int t = std::atoi(vt); if (t == 32 || t == 16 || t == 8 || t == 4 || t == 0) g_.nv_tile = t; }
   if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
+  // Engines on several host threads share a device through their own streams; the runtime maps streams onto 4 hardware queues
+  // per process by default, and a persistent k_climb launch holds its queue for a whole sweep (8 climbs side by side: 6 climbs/s
+  // on 4 queues, 14 on 16: profiles/r3/concurrent_climbs.txt).  Only takes effect if the HIP runtime of this process has not
+  // started yet and the variable is not set by the user.
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_error("no HIP device available: libmpfitch has no CPU fallback");
