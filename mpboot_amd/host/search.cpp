@@ -143,6 +143,8 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
       }
       batch = next_batch(batch, moved, j - i, total);
       i = j;
+      // moves have become dense again behind a quiet stretch: the rest of the sweep goes back to the kernel
+      if (moved && dev_ok && gap_est_ >= 0 && gap_est_ < 24.0 && i <= total) dev = true;
     }
   } while (randomMP < startMP);
   climb_finished(total);
