@@ -27,8 +27,6 @@ namespace mpf {
 
 namespace {
 
-constexpr int kNW = 8;                       // waves per workgroup
-constexpr int kThreads = kNW * 64;
 constexpr int kMaxB = 8;                     // prune nodes per step
 constexpr int kMaxUnits = 2 * kMaxB;         // (prune node, side)
 constexpr int kMaxParts = 2 * kMaxUnits;     // (prune node, side, gap end): one DFS program each
@@ -48,12 +46,16 @@ constexpr uint32_t kLcap = 256;
 constexpr uint32_t kNoSlot = 0xFFu;
 template <int KS, int VW> struct Cfg {
   static constexpr int R = KS * VW;                                   // registers per vector tile
+  // waves per workgroup: sixteen where the tiles are small (the scan's programs and the refresh's chains are dealt to them),
+  // eight where a wave's parked up-vectors would not fit the LDS sixteen times
+  static constexpr int NW = R <= 2 ? 16 : 8;
+  static constexpr int NT = NW * 64;
   static constexpr int PF = R <= 2 ? 8 : 4;                           // expansions whose child vectors are requested together
   // operand slots of the refresh (vector + per-lane subtree scores) and the parked up-vectors of the scan are never alive
   // together: one LDS region serves both
   static constexpr size_t kSlotBytes = (size_t)(R + 1) * 64 * 4;
-  static constexpr size_t kPendBytes = (size_t)8 * 5 * R * 64 * 4;
-  static constexpr size_t kRegion = 65536;
+  static constexpr size_t kPendBytes = (size_t)NW * 5 * R * 64 * 4;
+  static constexpr size_t kRegion = kPendBytes > 65536 ? kPendBytes : 65536;
   static constexpr uint32_t kSlots = kRegion / kSlotBytes < 254 ? (uint32_t)(kRegion / kSlotBytes) : 254u;
 };
 
@@ -573,7 +575,7 @@ __device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool
   const uint32_t nops = sh.nops;
   const int lane = K.lane;
   // -- stage
-  for (uint32_t base = (uint32_t)K.wave * 4u; base < nops; base += (uint32_t)kNW * 4u) {
+  for (uint32_t base = (uint32_t)K.wave * 4u; base < nops; base += (uint32_t)Cfg<KS, VW>::NW * 4u) {
     QT<KS, VW> ta[4], tb[4];
     uint32_t la[4], lb[4], da[4], db[4];
 #pragma unroll
@@ -627,7 +629,7 @@ __device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool
   };
   QT<KS, VW> c, ta, tb;
   uint32_t la = 0, lb = 0, lc = 0;
-  for (uint32_t si = (uint32_t)K.wave;; si += kNW) {       // chain starts are dealt round-robin (late ones -- rare -- land behind the list)
+  for (uint32_t si = (uint32_t)K.wave;; si += Cfg<KS, VW>::NW) {       // chain starts are dealt round-robin (late ones -- rare -- land behind the list)
     uint32_t st = kNone16, spins = 0;
     for (;;) {
       st = *(volatile uint16_t *)&K.R[si];                // (entries beyond the starts written so far read "none")
@@ -1057,8 +1059,9 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
 }
 
 template <int KS, int VW>
-__global__ __launch_bounds__(kThreads) void k_climb(ClimbParams P)
+__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
 {
+  constexpr uint32_t kThreads = Cfg<KS, VW>::NT, kNW = Cfg<KS, VW>::NW;
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = (int)rfl((uint32_t)(tid >> 6));
@@ -1315,7 +1318,7 @@ hipError_t launch_t(hipStream_t st, const ClimbParams &p)
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_climb<KS, VW>), dim3(p.tiles), dim3(kThreads), lds, st, p);
+  hipLaunchKernelGGL((k_climb<KS, VW>), dim3(p.tiles), dim3(Cfg<KS, VW>::NT), lds, st, p);
   return hipGetLastError();
 }
 
