@@ -46,7 +46,15 @@ enum {
   MPF_E_UNSUPPORTED = -6  /* e.g. states outside {4,20}; reference sprparsimony.cpp:575 */
 };
 
-enum { MPF_DNA = 0, MPF_AA = 1 };
+/* data types (PLL: pll.h:238-244; partition types "DNA", protein models, "BIN", "MOR" -- iqtree.cpp:515-530):
+     MPF_DNA      4 states, tip codes = 4-bit sets 1..15 (15 = undetermined)
+     MPF_AA      20 states, codes 0..19, B = 20, Z = 21, 22 = undetermined
+     MPF_BIN      2 states (PLL_BINARY_DATA), codes 1, 2, 3 = undetermined            (reference Fitch case 2, sprparsimony.cpp:679-721)
+     MPF_GENERIC 32 states (PLL_GENERIC_32), codes 0..31, 32 = undetermined           (reference `default` case, :824-869)
+   The binary alphabet runs on the 4-state kernels and multistate data on the 20-state kernels with the unused state rows
+   empty -- Fitch sets never acquire a state no tip has, so lengths, vectors and trajectories are the reference's.  A
+   multistate alignment that uses symbols beyond the 20th (K..V) is refused with MPF_E_UNSUPPORTED. */
+enum { MPF_DNA = 0, MPF_AA = 1, MPF_BIN = 2, MPF_GENERIC = 3 };
 enum { MPF_TIE_FIRST = 0, MPF_TIE_RANDOM = 1 };
 
 typedef struct mpf_engine mpf_engine;

@@ -19,6 +19,18 @@ extern "C" {
 }
 #include "../include/mpfitch.h"
 
+// PLL partition data type (pll.h:238-244) -> libmpfitch data type
+static inline int mpf_datatype_of_pll(int pll_type)
+{
+  switch (pll_type) {
+    case PLL_AA_DATA: return MPF_AA;
+    case PLL_BINARY_DATA: return MPF_BIN;          // "BIN" partitions (iqtree.cpp:526-527)
+    case PLL_GENERIC_32: return MPF_GENERIC;       // "MOR" partitions (iqtree.cpp:524-525)
+    default: return MPF_DNA;
+  }
+}
+static inline int mpf_states_of(int dt) { return dt == MPF_AA ? 20 : dt == MPF_BIN ? 2 : dt == MPF_GENERIC ? 32 : 4; }
+
 static mpf_engine *g_eng = nullptr;
 
 static void die(const char *what)
@@ -54,7 +66,7 @@ extern "C" void allocateParsimonyDataStructures(pllInstance *tr, partitionList *
   cfg.device = 0;
   cfg.n_taxa = n;
   cfg.n_patterns = P;
-  cfg.datatype = pr->partitionData[0]->dataType == PLL_AA_DATA ? MPF_AA : MPF_DNA;
+  cfg.datatype = mpf_datatype_of_pll(pr->partitionData[0]->dataType);
   cfg.keep_all_sites = 0;
   if (mpf_engine_create(&g_eng, &cfg, codes.data(), tr->aliaswgt)) die("mpf_engine_create");
   if (mpf_seed_ties(g_eng, MPF_TIE_FIRST, 0)) die("mpf_seed_ties");   // PLL original: strict '<', no random draws

@@ -33,6 +33,18 @@ double randum(long *seed);                 // pllInternal.h:34 (utils.c:335-358)
 }
 #include "mpboot_hooks.h"
 
+// PLL partition data type (pll.h:238-244) -> libmpfitch data type
+static inline int mpf_datatype_of_pll(int pll_type)
+{
+  switch (pll_type) {
+    case PLL_AA_DATA: return MPF_AA;
+    case PLL_BINARY_DATA: return MPF_BIN;          // "BIN" partitions (iqtree.cpp:526-527)
+    case PLL_GENERIC_32: return MPF_GENERIC;       // "MOR" partitions (iqtree.cpp:524-525)
+    default: return MPF_DNA;
+  }
+}
+static inline int mpf_states_of(int dt) { return dt == MPF_AA ? 20 : dt == MPF_BIN ? 2 : dt == MPF_GENERIC ? 32 : 4; }
+
 // globals the reference DEFINES in iqtree.cpp:35-43 and sprparsimony.cpp consumes: the cost matrix of -cost
 extern unsigned int *pllCostMatrix;        // cost[i * pllCostNstates + j] = cost of i -> j, NULL = Fitch
 extern int pllCostNstates;
@@ -101,11 +113,11 @@ void ensure_engine(pllInstance *tr, partitionList *pr)
     std::memset(&cfg, 0, sizeof cfg);
     cfg.n_taxa = n;
     cfg.n_patterns = P;
-    cfg.datatype = pr->partitionData[0]->dataType == PLL_AA_DATA ? MPF_AA : MPF_DNA;
+    cfg.datatype = mpf_datatype_of_pll(pr->partitionData[0]->dataType);
     cfg.keep_all_sites = !g_hooks.sort_alignment;
     if (pllCostMatrix) {
       // the reference's dispatch on pllCostMatrix (:556-641, :967-1030): weighted engine, same entry points
-      if (pllCostNstates != (cfg.datatype == MPF_AA ? 20 : 4)) { std::fprintf(stderr, "mpfitch shim: cost matrix of %d states on %s data\n", pllCostNstates, cfg.datatype == MPF_AA ? "protein" : "DNA"); std::exit(EXIT_FAILURE); }
+      if (pllCostNstates != mpf_states_of(cfg.datatype)) { std::fprintf(stderr, "mpfitch shim: cost matrix of %d states on %d-state data\n", pllCostNstates, mpf_states_of(cfg.datatype)); std::exit(EXIT_FAILURE); }
       if (mpf_engine_create_sankoff(&g_eng, &cfg, codes.data(), tr->aliaswgt, pllCostMatrix)) die("mpf_engine_create_sankoff");
     } else if (mpf_engine_create(&g_eng, &cfg, codes.data(), tr->aliaswgt)) die("mpf_engine_create");
     if (mpf_set_rand_callback(g_eng, draw, nullptr)) die("mpf_set_rand_callback");
@@ -317,6 +329,6 @@ int pllCalcMinParsScorePattern(pllInstance *tr, int dataType, int site)
   std::vector<uint8_t> col((size_t)n);
   for (int j = 1; j <= n; j++) col[(size_t)(j - 1)] = tr->yVector[j][site];
   int32_t out = 0;
-  if (mpf_min_pars_score_patterns(dataType == PLL_AA_DATA ? MPF_AA : MPF_DNA, n, 1, col.data(), &out)) die("mpf_min_pars_score_patterns");
+  if (mpf_min_pars_score_patterns(mpf_datatype_of_pll(dataType), n, 1, col.data(), &out)) die("mpf_min_pars_score_patterns");
   return out;
 }

@@ -140,11 +140,16 @@ int mpf_encode_iqtree_states(int32_t datatype, const int8_t *states, int64_t cou
       if (code == 15 && st != 18) code = -1;              // 1+2+4+8+3 is not produced by convertState
     } else if (datatype == MPF_AA) {
       if (st >= 0 && st <= 22) code = st;                 // same numbering, B = 20, Z = 21, unknown = 22
+    } else if (datatype == MPF_BIN) {
+      if (st == 0 || st == 1) code = 1 << st;             // SEQ_BINARY: '0' -> 0, '1' -> 1 (alignment.cpp:846-851)
+      else if (st == 2) code = 3;                         // STATE_UNKNOWN = num_states
+    } else if (datatype == MPF_GENERIC) {
+      if (st >= 0 && st <= 32) code = st;                 // SEQ_MORPH: symbol index, STATE_UNKNOWN = num_states <= 32 handed over as 32
     } else {
       set_error("mpf_encode_iqtree_states: unsupported data type");
       return MPF_E_UNSUPPORTED;
     }
-    if (code <= 0 && !(datatype == MPF_AA && code == 0)) { set_error("state outside the alphabet (STATE_INVALID)"); return MPF_E_INVALID; }
+    if (code <= 0 && !((datatype == MPF_AA || datatype == MPF_GENERIC) && code == 0)) { set_error("state outside the alphabet (STATE_INVALID)"); return MPF_E_INVALID; }
     codes[i] = (uint8_t)code;
   }
   return MPF_OK;

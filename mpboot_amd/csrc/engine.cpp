@@ -58,8 +58,8 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     set_error("mpf_engine_create: need n_taxa >= 4, n_patterns >= 1, codes and weights");
     return MPF_E_INVALID;
   }
-  if (cfg.datatype != MPF_DNA && cfg.datatype != MPF_AA) {
-    set_error("mpf_engine_create: only DNA (4 states) and protein (20 states) are supported");
+  if (cfg.datatype != MPF_DNA && cfg.datatype != MPF_AA && cfg.datatype != MPF_BIN && cfg.datatype != MPF_GENERIC) {
+    set_error("mpf_engine_create: data type must be MPF_DNA, MPF_AA, MPF_BIN or MPF_GENERIC");
     return MPF_E_UNSUPPORTED;
   }
   if (const char *hp = std::getenv("MPF_HOST_POLL")) host_poll_ = std::atoi(hp) ? 1 : 0;        // (experiments)
@@ -85,14 +85,57 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   P_ = cfg.n_patterns;
   datatype_ = cfg.datatype;
   keep_all_ = cfg.keep_all_sites;
-  g_.S = datatype_ == MPF_DNA ? 4 : 20;
+  // states of the reference / undetermined code (globalVariables.h pLengths) / rows the kernels work on
+  sref_ = datatype_ == MPF_DNA ? 4 : datatype_ == MPF_AA ? 20 : datatype_ == MPF_BIN ? 2 : 32;
+  und_ = datatype_ == MPF_DNA ? 15 : datatype_ == MPF_AA ? 22 : datatype_ == MPF_BIN ? 3 : 32;
+  g_.S = (datatype_ == MPF_DNA || datatype_ == MPF_BIN) ? 4 : 20;
   // (full refresh, one word per lane: k_newview_wgq on tiles chosen from the row length, kernels.hip: newview_tile)
   if (const char *vp = std::getenv("MPF_VIEWS_PIPE")) g_.nv_pipe = std::atoi(vp) != 0;      // (experiments: defaults of "views_pipe" / "views_tile")
+  const int und = und_;
+  for (size_t i = 0; i < (size_t)n_ * P_; i++) {
+    if (codes[i] > und || ((datatype_ == MPF_DNA || datatype_ == MPF_BIN) && codes[i] == 0)) {
+      set_error("mpf_engine_create: tip code outside the PLL alphabet");   // reference: assert(bitVector[nucleotide] > 0)
+      return MPF_E_INVALID;
+    }
+  }
+  codes_.assign(codes, codes + (size_t)n_ * P_);
+  if (datatype_ == MPF_GENERIC) {
+    bool used[32] = {false};
+    // Multistate data runs on the 20-state kernels: parsimony does not care what a state is called, so the symbols in use are
+    // renumbered 0, 1, 2, ... in order of their codes (row gmap_[c] of a vector is the reference's row c; unused rows do not
+    // exist).  More than 20 symbols in use would need 32-state kernels.
+    for (uint8_t c : codes_) if (c < 32) used[c] = true;
+    int k = 0;
+    for (int c = 0; c < 32; c++) gmap_[c] = used[c] ? k++ : -1;
+    if (k > 20) {
+      set_error("mpf_engine_create: multistate data with more than 20 symbols in use needs 32-state kernels, which this build does not have");
+      return MPF_E_UNSUPPORTED;
+    }
+    for (uint8_t &c : codes_) if (c < 32) c = (uint8_t)gmap_[c];
+  }
+  if (cost && datatype_ == MPF_GENERIC) {
+    // under a cost matrix a state that no tip has can still be the cheapest label of an inner node (a Steiner point of the
+    // metric), so the 32 states of the reference's matrix cannot be renumbered into 20 rows the way Fitch sets can
+    set_error("mpf_engine_create_sankoff: weighted parsimony on 32-state data needs 32-state kernels, which this build does not have");
+    return MPF_E_UNSUPPORTED;
+  }
   if (cost) {
     // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80), then the
     // symmetry requirement of the directional-view formulation
     const int S = g_.S;
-    cost_.assign(cost, cost + S * S);
+    if (sref_ == S) {
+      cost_.assign(cost, cost + S * S);
+    } else {
+      // binary in the 4-state / multistate in the 20-state kernels (the reference instantiates its Sankoff kernels for 2, 4, 20
+      // and 32 states, sprparsimony.cpp:559-639): the caller's sref x sref matrix, renumbered like the symbols; a state no tip
+      // can have costs more to enter or leave than any real change, so no minimum is ever taken through it
+      auto row_of = [&](int c) { return datatype_ == MPF_GENERIC ? gmap_[c] : (c < S ? c : -1); };
+      uint32_t hi = 0;
+      for (int i = 0; i < sref_; i++) for (int j = 0; j < sref_; j++) if (row_of(i) >= 0 && row_of(j) >= 0) hi = std::max(hi, cost[i * sref_ + j]);
+      cost_.assign((size_t)S * S, hi + 1);
+      for (int i = 0; i < S; i++) cost_[(size_t)i * S + i] = 0;
+      for (int i = 0; i < sref_; i++) for (int j = 0; j < sref_; j++) if (row_of(i) >= 0 && row_of(j) >= 0) cost_[(size_t)row_of(i) * S + row_of(j)] = cost[i * sref_ + j];
+    }
     for (int k = 0; k < S; k++)
       for (int i = 0; i < S; i++)
         for (int j = 0; j < S; j++)
@@ -111,13 +154,6 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   g_.vw = 1;
   g_.reduce = 0;
   g_.map = 1;            // XCD-aware work mapping (speed only)
-  const int und = datatype_ == MPF_DNA ? 15 : 22;
-  for (size_t i = 0; i < (size_t)n_ * P_; i++)
-    if (codes[i] > und || (datatype_ == MPF_DNA && codes[i] == 0)) {
-      set_error("mpf_engine_create: tip code outside the PLL alphabet");   // reference: assert(bitVector[nucleotide] > 0)
-      return MPF_E_INVALID;
-    }
-  codes_.assign(codes, codes + (size_t)n_ * P_);
   wgt_.assign(weights, weights + P_);
   inf_.assign(P_, 0);
   first_site_.assign(P_, -1);
@@ -157,7 +193,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
 int Engine::pack()
 {
   pack_gen_++;
-  const int und = datatype_ == MPF_DNA ? 15 : 22;
+  const int und = und_;
   long entries = 0;
   ninf_ = 0;
   if (sankoff_) {
@@ -287,9 +323,24 @@ int Engine::tip_vector(int tipno, uint32_t *out)
   std::vector<uint32_t> tmp((size_t)g_.S * g_.Wp);
   HIPCHK(hipMemcpy(tmp.data(), d_vec_ + (size_t)(tipno - 1) * g_.S * g_.Wp, tmp.size() * sizeof(uint32_t),
                    hipMemcpyDeviceToHost));
-  // hand back rows of the reference's length W (its padding words are all ones as well)
-  for (int k = 0; k < g_.S; k++)
-    for (int w = 0; w < Wref_; w++) out[(size_t)k * Wref_ + w] = w < g_.Wp ? tmp[(size_t)k * g_.Wp + w] : 0xFFFFFFFFu;
+  // hand back the reference's rows: its state count (rows the kernels do not carry -- multistate symbols beyond the 20th, never
+  // present -- are empty) and its length W; sites behind the alignment are all ones in every row (sprparsimony.cpp:2947-2960)
+  for (int k = 0; k < sref_; k++)
+    for (int w = 0; w < Wref_; w++) {
+      uint32_t v;
+      const int er = datatype_ == MPF_GENERIC ? gmap_[k] : (k < g_.S ? k : -1);      // the engine's row of the reference's state k
+      if (er >= 0) v = w < g_.Wp ? tmp[(size_t)er * g_.Wp + w] : 0xFFFFFFFFu;
+      else if (w >= g_.Wp) v = 0xFFFFFFFFu;
+      else {
+        // a symbol no taxon has: its row is set exactly where this tip is undetermined (bitVector32[32] = every state) and
+        // behind the alignment -- which is what an engine row without a symbol holds (or, with all 20 rows taken, what two
+        // rows have in common: a tip with a symbol sets one row only)
+        int used_rows = 0;
+        for (int c = 0; c < 32; c++) used_rows += gmap_[c] >= 0 ? 1 : 0;
+        v = used_rows < g_.S ? tmp[(size_t)used_rows * g_.Wp + w] : (tmp[w] & tmp[(size_t)g_.Wp + w]);
+      }
+      out[(size_t)k * Wref_ + w] = v;
+    }
   return MPF_OK;
 }
 

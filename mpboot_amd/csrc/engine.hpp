@@ -205,7 +205,7 @@ class Engine {
   void activate() const { (void)hipSetDevice(dev_); }
   int n() const { return n_; }
   int P() const { return P_; }
-  int S() const { return g_.S; }
+  int S() const { return sref_; }               // the reference's state count (the kernels' geometry may be wider: BIN in 4, GENERIC in 20)
   int Wref() const { return Wref_; }
   int Wp() const { return g_.Wp; }
   int n_informative() const { return ninf_; }
@@ -358,7 +358,8 @@ class Engine {
   int climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle, uint32_t *reason, uint32_t *n_moves);
 
   // ---- configuration / alignment
-  int n_ = 0, P_ = 0, datatype_ = 0, keep_all_ = 0, dev_ = 0;
+  int n_ = 0, P_ = 0, datatype_ = 0, keep_all_ = 0, dev_ = 0, sref_ = 4, und_ = 15;
+  int gmap_[32] = {0};                          // MPF_GENERIC: symbol code -> state row of the engine (-1: symbol not in use)
   Geometry g_{};
   int Wref_ = 0, nsites_ = 0, ninf_ = 0;
   std::vector<uint8_t> codes_;

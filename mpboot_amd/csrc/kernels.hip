@@ -206,9 +206,12 @@ __device__ __forceinline__ int lane_word(int tile, int lane, int Wp, bool &valid
 
 // state set of a PLL tip code: DNA bitVectorIdentity, protein bitVectorAA
 // (reference pllrepo/src/globalVariables.h:60-78)
+// (binary: bitVectorIdentity like DNA, codes 1..3; 32-state: bitVector32, code 32 = every state -- the engine carries the
+//  first 20 rows of such data, globalVariables.h:98-102)
 __device__ __forceinline__ uint32_t state_mask(int datatype, uint32_t code)
 {
-  if (datatype == 0) return code;
+  if (datatype == 0 || datatype == 2) return code;
+  if (datatype == 3) return code < 32u ? 1u << code : 1048575u;
   if (code < 20u) return 1u << code;
   if (code == 20u) return 12u;
   if (code == 21u) return 96u;

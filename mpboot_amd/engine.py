@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmpfitch.so")
 
-DNA, AA = 0, 1
+DNA, AA, BIN, GENERIC = 0, 1, 2, 3      # PLL_DNA_DATA, PLL_AA_DATA, PLL_BINARY_DATA (2 states), PLL_GENERIC_32 (multistate)
 TIE_FIRST, TIE_RANDOM = 0, 1
 
 EXPORTS = [

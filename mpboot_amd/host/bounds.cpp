@@ -28,8 +28,8 @@ extern "C" {
 int mpf_min_pars_score_patterns(int32_t datatype, int32_t n_taxa, int32_t n_patterns, const uint8_t *codes, int32_t *min_score)
 {
   if (!codes || !min_score || n_taxa < 1 || n_patterns < 1) { set_error("mpf_min_pars_score_patterns: bad argument"); return MPF_E_INVALID; }
-  if (datatype != MPF_DNA && datatype != MPF_AA) { set_error("mpf_min_pars_score_patterns: unsupported data type"); return MPF_E_UNSUPPORTED; }
-  const int undetermined = datatype == MPF_DNA ? 15 : 22;
+  if (datatype != MPF_DNA && datatype != MPF_AA && datatype != MPF_BIN && datatype != MPF_GENERIC) { set_error("mpf_min_pars_score_patterns: unsupported data type"); return MPF_E_UNSUPPORTED; }
+  const int undetermined = datatype == MPF_DNA ? 15 : datatype == MPF_AA ? 22 : datatype == MPF_BIN ? 3 : 32;
   for (int p = 0; p < n_patterns; p++) {
     bool seen[256] = {false};
     for (int t = 0; t < n_taxa; t++) seen[codes[(size_t)t * (size_t)n_patterns + (size_t)p]] = true;

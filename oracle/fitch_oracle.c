@@ -97,13 +97,16 @@ static inline int NX(int r) { int v = r / 3, s = r % 3; return 3 * v + (s + 1) %
 /* PLL tip code -> state set. DNA: bitVectorIdentity; AA: bitVectorAA (pllrepo/src/globalVariables.h:60-78) */
 static uint32_t state_mask(int datatype, unsigned code)
 {
-  if (datatype == ORC_DNA) return code;
+  if (datatype == ORC_DNA || datatype == ORC_BIN) return code;          /* bitVectorIdentity (binary: 1, 2, 3) */
+  if (datatype == ORC_GENERIC) return code < 32 ? 1u << code : 0xFFFFFFFFu;   /* bitVector32, globalVariables.h:98-102 */
   if (code < 20) return 1u << code;
   if (code == 20) return 12u;        /* B = N|D */
   if (code == 21) return 96u;        /* Z = Q|E */
   return 1048575u;                   /* 22: - ? * X */
 }
-static int undetermined_code(int datatype) { return datatype == ORC_DNA ? 15 : 22; } /* globalVariables.h pLengths */
+/* globalVariables.h pLengths: undetermined code per data type (binary 3, DNA 15, protein 22, 32-state 32) */
+static int undetermined_code(int datatype) { return datatype == ORC_DNA ? 15 : datatype == ORC_BIN ? 3 : datatype == ORC_GENERIC ? 32 : 22; }
+static int states_of(int datatype) { return datatype == ORC_DNA ? 4 : datatype == ORC_BIN ? 2 : datatype == ORC_GENERIC ? 32 : 20; }
 
 static double tie_draw(orc *o)
 {
@@ -211,7 +214,7 @@ orc *orc_create(int n, int P, int datatype, const unsigned char *codes, const in
   int i;
   o->n = n; o->P = P; o->datatype = datatype; o->keep_all = keep_all;
   o->pre_eval = -1;
-  o->S = datatype == ORC_DNA ? 4 : 20;
+  o->S = states_of(datatype);
   o->nrec = 3 * (2 * n - 1) + 3;
   o->codes = (unsigned char *)malloc((size_t)n * P);
   memcpy(o->codes, codes, (size_t)n * P);

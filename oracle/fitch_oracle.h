@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-enum { ORC_DNA = 0, ORC_AA = 1 };
+enum { ORC_DNA = 0, ORC_AA = 1, ORC_BIN = 2 /* PLL_BINARY_DATA, 2 states */, ORC_GENERIC = 3 /* PLL_GENERIC_32 */ };
 enum { ORC_TIE_FIRST = 0,   /* PLL original: strict '<' (pllrepo/src/fastDNAparsimony.c:1224, :1803, :1925) */
        ORC_TIE_RANDOM = 1 };/* mpboot: uniform random among ties (sprparsimony.cpp:2168-2176, :3001-3008, :3306-3311) */
 

@@ -17,13 +17,22 @@ DNA_STATE = {"A": 0, "C": 1, "G": 2, "T": 3, "U": 3, "R": 1 + 4 + 3, "Y": 2 + 8 
 PROT_SYMBOLS = "ARNDCQEGHILKMFPSTWYVX"
 
 
+MORPH_SYMBOLS = "0123456789ABCDEFGHIJKLMNOPQRSTUV"
+
+
 def convert_states(rows, alphabet="DNA"):
-    """characters -> Alignment::convertState codes, int8[n][L]"""
+    """characters -> Alignment::convertState codes, int8[n][L].  "BIN": '0' '1', anything else unknown (= 2, num_states);
+    "MOR": the symbol's index, '-' unknown (= 32); a '?' is given the reading PLL's character map gives it (symbol 22,
+    pllrepo/src/utils.c:142), so that the fixtures' PLL scores apply"""
     out = np.zeros((len(rows), len(rows[0])), dtype=np.int8)
     for i, r in enumerate(rows):
         for j, ch in enumerate(r.upper()):
             if alphabet == "DNA":
                 out[i, j] = DNA_STATE[ch]
+            elif alphabet == "BIN":
+                out[i, j] = "01".index(ch) if ch in "01" else 2
+            elif alphabet == "MOR":
+                out[i, j] = 22 if ch == "?" else (MORPH_SYMBOLS.index(ch) if ch in MORPH_SYMBOLS else 32)
             elif ch in "?-.":
                 out[i, j] = 22
             elif ch == "B":
@@ -37,12 +46,12 @@ def convert_states(rows, alphabet="DNA"):
 
 
 def _tip_sets(states, num_states):
-    unknown = 18 if num_states == 4 else 22
+    unknown = {4: 18, 20: 22}.get(num_states, num_states)       # STATE_UNKNOWN (alignment.cpp:512-518)
     s = states.astype(np.int64)
     sets = np.where(s < num_states, np.left_shift(1, np.minimum(s, num_states - 1)), 0)
     if num_states == 4:
         sets = np.where((s >= num_states) & (s != unknown), s - 3, sets)
-    else:
+    elif num_states == 20:
         sets = np.where(s == 20, 4 + 8, sets)
         sets = np.where(s == 21, 32 + 64, sets)
     sets = np.where(s == unknown, (1 << num_states) - 1, sets)

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 
-DNA, AA = 0, 1
+DNA, AA, BIN, GENERIC = 0, 1, 2, 3
 TIE_FIRST, TIE_RANDOM = 0, 1
 
 

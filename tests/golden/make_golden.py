@@ -89,6 +89,36 @@ def make_alignment(kind: str):
                 elif u < 0.05:
                     r[j] = "BZ"[int(rng.integers(2))]
         return ["".join(r) for r in rows], names, "WAG", 0
+    if kind == "bin":
+        # binary characters (PLL_BINARY_DATA, partition type "BIN": '0' '1', '-' / '?' undetermined; utils.c:78-97)
+        rng = np.random.default_rng(71)
+        L, names = synth.synth_alignment(16, 320, "DNA", 0.10, seed=14)
+        rows = [["01"[c >> 1] for c in r] for r in L]
+        for r in rows:
+            for j in range(len(r)):
+                if rng.random() < 0.04:
+                    r[j] = "-?"[int(rng.integers(2))]
+        for r_i, r in enumerate(rows):                     # constant / singleton / undetermined-only columns
+            r.extend(["0", "1" if r_i == 2 else "0", "?" if r_i % 2 else "1"])
+        return ["".join(r) for r in rows], names, "BIN", 0
+    if kind in ("morph", "morph32"):
+        # multistate characters (PLL_GENERIC_32, partition type "MOR": symbols 0-9 A-V, '-' / '?' undetermined; utils.c:138-157);
+        # "morph" uses twelve symbols plus '?', which PLL_MAP_GENERIC_32 reads as symbol 22 ('M'), not as undetermined (utils.c:142:
+        # only '-' and '*' map to 32); "morph32" uses all 32
+        sym = "0123456789ABCDEFGHIJKLMNOPQRSTUV"
+        rng = np.random.default_rng(83 if kind == "morph" else 84)
+        L, names = synth.synth_alignment(13, 220, "AA", 0.14, seed=15 if kind == "morph" else 16)
+        rows = [[sym[c % 12] if kind == "morph" else sym[c] for c in r] for r in L]
+        if kind == "morph32":
+            for r in rows:
+                for j in range(len(r)):
+                    if rng.random() < 0.25:
+                        r[j] = sym[20 + int(rng.integers(12))] if j % 3 == 0 else r[j]
+        for r in rows:
+            for j in range(len(r)):
+                if rng.random() < 0.03:
+                    r[j] = "-?"[int(rng.integers(2))]
+        return ["".join(r) for r in rows], names, "MOR", 0
     raise KeyError(kind)
 
 
@@ -200,7 +230,7 @@ def fixture(kind: str, tmp: str):
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48"):
+        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32"):
             fx = fixture(kind, tmp)
             with open(os.path.join(OUT, kind + ".json"), "w") as f:
                 json.dump(fx, f, separators=(",", ":"))

@@ -6,7 +6,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FIXTURES = ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48")
+FIXTURES = ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph")
+# + "morph32": all 32 symbols of PLL_GENERIC_32 (the engine serves multistate data that stays within 20 symbols)
+PLL_TYPES = {"DNA": 0, "WAG": 1, "BIN": 2, "MOR": 3}
 
 
 def load_fixture(name):
@@ -14,7 +16,7 @@ def load_fixture(name):
         fx = json.load(f)
     fx["codes_np"] = np.array(fx["codes"], dtype=np.uint8)
     fx["weights_np"] = np.array(fx["weights"], dtype=np.int32)
-    fx["datatype"] = 0 if fx["pll_type"] == "DNA" else 1
+    fx["datatype"] = PLL_TYPES[fx["pll_type"]]
     fx["name"] = name
     return fx
 

@@ -23,7 +23,7 @@ def fx(request):
 
 
 # moves of the PLL-original hill climb (fixture "spr", reference's own run) that an exact first-best scorer shares with it
-FIRST_BEST_PREFIX = {"dna_clean": 4, "dna_ambig": 1, "dna_dups": 1, "aa": 2, "dna_48": 3}
+FIRST_BEST_PREFIX = {"dna_clean": 4, "dna_ambig": 1, "dna_dups": 1, "aa": 2, "dna_48": 3, "bin": 4, "morph": 10}
 
 
 def eng_of(engine, fx, **kw):
@@ -284,14 +284,15 @@ def test_compute_parsimony_dropin(mods, fx):
     from oracle import iqtree_fitch
     if fx["dedup"]:
         pytest.skip("fixture columns were re-ordered by PLL's duplicate removal")
-    alpha = "DNA" if fx["datatype"] == 0 else "AA"
+    alpha = ("DNA", "AA", "BIN", "MOR")[fx["datatype"]]
     states = iqtree_fitch.convert_states(fx["rows"], alpha)
     codes = engine.encode_iqtree_states(states, fx["datatype"])
+    assert (codes == fx["codes_np"]).all()                 # the same tip codes PLL's parser produced
     e = engine.FitchEngine(codes, fx["weights_np"], datatype=fx["datatype"])
     for t in fx["trees"][:3]:
         back = np.array(t["back"], dtype=np.int32)
         score, ptn = e.compute_parsimony(back)
-        rs, rptn = iqtree_fitch.compute_parsimony(states, fx["weights"], back, 4 if alpha == "DNA" else 20)
+        rs, rptn = iqtree_fitch.compute_parsimony(states, fx["weights"], back, (4, 20, 2, 32)[fx["datatype"]])
         assert score == t["score"] == rs
         assert (ptn == rptn).all()
 
