@@ -2,8 +2,10 @@
 
   C2  200 taxa x 10 000 DNA patterns   -- full SPR hill climb from a random tree, move for move against the oracle
   C5  500 taxa x 20 000 protein        -- Fitch-20: score, whole scans and a climb; weighted (-cost) 20-state scans
-  C4  1000 x 50 000, -bb               -- online UFBoot sweep at C3 size: boot_logl re-derived from per-pattern lengths,
-                                          and the sample-sharded run (two engines, events exchanged) == the unsharded one
+  C4  1000 x 50 000, -bb 1000          -- online UFBoot phase at C3 size with 96 and with 1000 samples: boot_logl of every sample
+                                          re-derived from per-pattern lengths, and the sample-sharded run (two ranks, events
+                                          exchanged) == the unsharded one, at both sample counts
+  C3  1000 x 50 000                    -- whole scans of four prune nodes against the oracle
 plus the value checks of mpf_spr_sweep_scan (the call bench.py times) against per-prune-node scans.
 """
 import numpy as np
@@ -180,6 +182,27 @@ def test_sweep_scan_candidates_at_c3_match_the_walking_kernel():
     assert (res[0][1] == res[1][1]).all()
 
 
+def test_c3_scans_match_oracle():
+    """BASELINE config 3 at full size, directly against the oracle: tree length and every insertion test (radius 6, both sides,
+    the reference's order) of four prune nodes of a random tree"""
+    from mpboot_amd import engine, trees
+    from oracle import pyoracle as po
+    codes, dt = _workload("C3")
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(21))
+    e = engine.FitchEngine(codes, datatype=dt)
+    o = po.Oracle(codes)
+    assert e.score_tree(back) == o.score_tree(back)
+    nodep = o.nodep()
+    done = 0
+    for rec in nodep[[7, 1003, 1500, 1990]]:              # a tip and three inner nodes, start / middle / end of the sweep order
+        tq, tm = _oracle_scan(o, po, back, rec, 6)
+        e.set_tree(back)
+        q, mp, _ = e.spr_scan(int(rec), 1, 6)
+        assert q.tolist() == tq and mp.tolist() == tm
+        done += len(tq)
+    assert done > 100
+
+
 # ------------------------------------------------------------------------------------------------ C4 (-bb at C3 size)
 
 @pytest.fixture(scope="module")
@@ -220,6 +243,34 @@ def test_c4_online_ufboot_sweep_boot_logl_rederived(c4):
     assert e.score_tree() == score
 
 
+def test_c4_online_phase_with_1000_samples_boot_logl_rederived():
+    """BASELINE config 4's sample count on the C3 alignment, from a random topology (thousands of accepted moves, > 10^6 booked
+    insertion tests): boot_logl of ALL 1000 samples == -<per-pattern lengths of the tree the sample kept, the sample's weights>,
+    counts and stored trees consistent"""
+    from mpboot_amd import engine, trees
+    codes, dt = _workload("C3")
+    P = codes.shape[1]
+    samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=1000).astype(np.uint16)
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(2024))
+    e = engine.FitchEngine(codes, datatype=dt)
+    score = _online_phase(e, engine, back, samples)
+    logl, counts, tr = e.ufboot_state()
+    assert len(logl) == 1000 and (counts >= 1).all()
+    final = e.get_tree()
+    w = samples.astype(np.int64)
+    kept = {}
+    for b in range(1000):
+        kept.setdefault(int(tr[b]), []).append(b)
+    assert len(e.ufboot_tree_logl()) > 100_000             # trees that went through the bookkeeping on the way
+    for t, bs in kept.items():
+        e.set_tree(e.ufboot_tree(t))
+        ptn, _tot = e.pattern_scores()
+        got = -(w[bs] @ ptn.astype(np.int64))
+        assert got.tolist() == [int(logl[b]) for b in bs], t
+    e.set_tree(final)
+    assert e.score_tree() == score
+
+
 C4_WORKER = r'''
 import os, sys, json
 import numpy as np
@@ -232,7 +283,7 @@ letters, _ = synth.workload("C3")
 codes = synth.letters_to_codes(letters, "DNA")
 back = np.load(os.environ["MPF_BACK"])
 P = codes.shape[1]
-samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=96).astype(np.uint16)
+samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=int(os.environ.get("MPF_NSAMP", "96"))).astype(np.uint16)
 e = engine.FitchEngine(codes)
 e.ufboot_attach(samples, 0.5, shard=(rank, ws))
 e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1)
@@ -249,7 +300,8 @@ dist.destroy_process_group()
 '''
 
 
-def test_c4_sample_sharded_online_phase_equals_unsharded(c4, tmp_path):
+@pytest.mark.parametrize("n_samples", [96, 1000])
+def test_c4_sample_sharded_online_phase_equals_unsharded(c4, tmp_path, n_samples):
     """BASELINE config 4's data path on this box: two ranks (sharing the one GPU, gloo rendezvous) hold every second bootstrap
     sample each and all-gather their events per scan batch -- every rank ends with exactly the single engine's bookkeeping"""
     import json
@@ -261,6 +313,9 @@ def test_c4_sample_sharded_online_phase_equals_unsharded(c4, tmp_path):
     from helpers import ROOT
     from mpboot_amd import engine
     codes, dt, back, samples = c4
+    if n_samples != len(samples):
+        P = codes.shape[1]
+        samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=n_samples).astype(np.uint16)
     single = engine.FitchEngine(codes, datatype=dt)
     s0 = _online_phase(single, engine, back, samples)
     logl, cnt, tr = single.ufboot_state()
@@ -270,7 +325,7 @@ def test_c4_sample_sharded_online_phase_equals_unsharded(c4, tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MPF_ROOT=ROOT, MPF_BACK=str(tmp_path / "back.npy"))
+    env = dict(os.environ, MPF_ROOT=ROOT, MPF_BACK=str(tmp_path / "back.npy"), MPF_NSAMP=str(n_samples))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]

@@ -132,6 +132,18 @@ def test_more_than_128_samples_use_the_wide_column_tile(mods):
     assert_same(e, o, se, so)
 
 
+def test_a_thousand_samples_match_the_oracle(mods):
+    """-bb 1000 (the smallest count the reference accepts, tools.cpp:2106-2118): 1000 bootstrap samples on a fixture against the
+    oracle's saveCurrentTree restatement -- every array of the bookkeeping, the moves, the tie draws"""
+    engine, po = mods
+    fx = load_fixture("dna_48")
+    samples = boot_samples(len(fx["weights"]), 1000, 77, fx["weights"])
+    start = np.array(fx["trees"][1]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 13)
+    assert_same(e, o, se, so)
+    assert len(e.ufboot_state()[0]) == 1000
+
+
 def test_heavy_weights_use_a_second_plane(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
