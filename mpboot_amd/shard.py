@@ -98,32 +98,56 @@ import ctypes as _C
 EXCHANGE_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_uint32, _C.c_void_p, _C.c_uint32, _C.POINTER(_C.c_void_p), _C.POINTER(_C.c_uint32))
 
 
+# events a rank contributes per exchange in the common case: one fixed-size block [count, tag, EVENT_BLOCK triples] per rank
+# goes out in ONE all-gather (a climb's batch books a few hundred events per rank; a block is 48 KB, xGMI moves it in
+# microseconds, and a fixed shape lets RCCL reuse its buffers and plan).  A rank with more than that says so in its count and
+# everybody takes part in a second, exactly sized all-gather for the overflow.
+EVENT_BLOCK = 4096
+_ev_bufs = {}
+
+
 def gather_events(local: np.ndarray, tag: int = 0) -> np.ndarray:
     """All-gather of the (candidate index, sample, score) triples of one scan batch: [n_local, 3] uint32 in,
-    [n_all, 3] out, identical on every rank.  Two small collectives (counts + tag, then the padded triples) on the default
-    process group -- RCCL over xGMI on the GPU box ("nccl"), gloo in the CPU tests.  Ranks whose tags differ are not at
-    the same point of the run: everybody raises instead of running on."""
+    [n_all, 3] out, identical on every rank.  One fixed-size collective on the default process group -- RCCL over xGMI on the
+    GPU box ("nccl"), gloo in the CPU tests -- plus a second one only when some rank has more than EVENT_BLOCK events.  Ranks
+    whose tags differ are not at the same point of the run: everybody raises instead of running on."""
     rank, ws = world()
     if ws == 1:
         return local
     dev = _device()
-    n = torch.tensor([local.shape[0], int(tag)], dtype=torch.int64, device=dev)
-    both = torch.zeros(2 * ws, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(both, n)
-    both = both.cpu().numpy().reshape(ws, 2)
-    if (both[:, 1] != both[0, 1]).any():
-        raise RuntimeError(f"ranks out of step in the event exchange: tags {both[:, 1].tolist()}")
-    counts = both[:, 0]
-    m = int(counts.max())
-    if m == 0:
+    key = (str(dev), ws)
+    if key not in _ev_bufs:
+        _ev_bufs[key] = (torch.zeros((EVENT_BLOCK + 1, 3), dtype=torch.int32, device=dev),
+                         torch.zeros((ws, EVENT_BLOCK + 1, 3), dtype=torch.int32, device=dev))
+    blk, allb = _ev_bufs[key]
+    n_loc = int(local.shape[0])
+    head = min(n_loc, EVENT_BLOCK)
+    host = np.zeros((EVENT_BLOCK + 1, 3), dtype=np.int32)
+    host[0, 0] = n_loc
+    host[0, 1] = np.int64(int(tag) & 0x7FFFFFFF)
+    if head:
+        host[1:1 + head] = local[:head].view(np.int32)
+    blk.copy_(torch.from_numpy(host))
+    dist.all_gather_into_tensor(allb.view(ws * (EVENT_BLOCK + 1), 3), blk)
+    got = allb.cpu().numpy()
+    counts = got[:, 0, 0].astype(np.int64)
+    tags = got[:, 0, 1]
+    if (tags != tags[0]).any():
+        raise RuntimeError(f"ranks out of step in the event exchange: tags {tags.tolist()}")
+    parts = [got[r, 1:1 + min(int(counts[r]), EVENT_BLOCK)] for r in range(ws)]
+    over = int(max(0, counts.max() - EVENT_BLOCK))
+    if over:
+        # (rare: more events than a block holds -- the remainder in an all-gather of exactly the size the largest rank needs)
+        buf = torch.zeros((over, 3), dtype=torch.int32, device=dev)
+        if n_loc > EVENT_BLOCK:
+            buf[:n_loc - EVENT_BLOCK] = torch.from_numpy(np.ascontiguousarray(local[EVENT_BLOCK:]).view(np.int32)).to(dev)
+        out = torch.zeros((ws, over, 3), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(out.view(ws * over, 3), buf)
+        out = out.cpu().numpy()
+        parts = [np.concatenate([parts[r], out[r, :max(0, int(counts[r]) - EVENT_BLOCK)]], axis=0) for r in range(ws)]
+    if counts.sum() == 0:
         return local
-    buf = torch.zeros((m, 3), dtype=torch.int32, device=dev)
-    if local.shape[0]:
-        buf[:local.shape[0]] = torch.from_numpy(local.view(np.int32)).to(dev)
-    out = torch.zeros((ws, m, 3), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out.view(ws * m, 3), buf)
-    out = out.cpu().numpy().view(np.uint32)
-    return np.concatenate([out[r, :int(counts[r])] for r in range(ws)], axis=0)
+    return np.ascontiguousarray(np.concatenate(parts, axis=0)).view(np.uint32)
 
 
 def event_exchange():

@@ -155,12 +155,20 @@ if ws > 1:
     dist.init_process_group("gloo")
 rank = shard.world()[0]
 out = []
-for rnd in range(4):
+SIZES = [5, 0, 3, 17, shard.EVENT_BLOCK + 9, shard.EVENT_BLOCK]      # the last two: more than / exactly one fixed-size block
+for rnd in range(6):
     rng = np.random.default_rng(100 * rnd + rank)
-    n = [5, 0, 3, 17][(rnd + rank) % 4] if rnd != 2 else 0          # round 2: nobody has events
-    local = rng.integers(0, 1000, size=(n, 3)).astype(np.uint32)
-    merged = shard.gather_events(local)
+    n = SIZES[(rnd + rank) % 6] if rnd != 2 else 0                   # round 2: nobody has events
+    local = rng.integers(0, 2 ** 32 - 1, size=(n, 3), dtype=np.uint64).astype(np.uint32)   # full 32-bit values survive
+    merged = shard.gather_events(local, tag=1000 + rnd)
+    assert merged.dtype == np.uint32
     out.append(sorted(map(tuple, merged.tolist())))
+# ranks that are not at the same point of the run must notice
+try:
+    shard.gather_events(np.zeros((1, 3), dtype=np.uint32), tag=50 + rank)
+    out.append("no error")
+except RuntimeError as exc:
+    out.append("out of step" if "out of step" in str(exc) else str(exc))
 if rank == 0:
     print("RESULT " + json.dumps(out))
 if ws > 1:
@@ -169,7 +177,8 @@ if ws > 1:
 
 
 def test_event_gather_over_two_gloo_ranks(tmp_path):
-    """the per-batch exchange of the sample-sharded online UFBoot phase: uneven and empty contributions"""
+    """the per-batch exchange of the sample-sharded online UFBoot phase as ONE fixed-size all-gather: uneven and empty
+    contributions, a rank with more events than a block holds (second, exactly sized collective), ranks out of step"""
     global WORKER
     saved = WORKER
     try:
@@ -177,13 +186,16 @@ def test_event_gather_over_two_gloo_ranks(tmp_path):
         two = _run(2, tmp_path)
     finally:
         WORKER = saved
-    for rnd in range(4):
+    from mpboot_amd import shard
+    sizes = [5, 0, 3, 17, shard.EVENT_BLOCK + 9, shard.EVENT_BLOCK]
+    for rnd in range(6):
         want = []
         for rank in range(2):
             rng = np.random.default_rng(100 * rnd + rank)
-            n = [5, 0, 3, 17][(rnd + rank) % 4] if rnd != 2 else 0
-            want += list(map(tuple, rng.integers(0, 1000, size=(n, 3)).astype(np.uint32).tolist()))
+            n = sizes[(rnd + rank) % 6] if rnd != 2 else 0
+            want += list(map(tuple, rng.integers(0, 2 ** 32 - 1, size=(n, 3), dtype=np.uint64).astype(np.uint32).tolist()))
         assert [tuple(x) for x in two[rnd]] == sorted(want)
+    assert two[6] == "out of step"
 
 
 def test_in_process_multi_device_schedule():
