@@ -651,21 +651,46 @@ __device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool
       operand(ta, la, (dx >> 16) & 0xFFu, dy & 0xFFFFu);
       operand(tb, lb, dx >> 24, dy >> 16);
     }
+    bool pre = false;                                     // the consumer entries of op i are in flight already
+    uint32_t ncv = 0;
+    uint2 e0 = make_uint2(0u, 0u), e1 = make_uint2(0u, 0u);
     for (uint32_t link = 0;; link++) {
       if (link > kLcap) { if (lane == 0) sh.err = 5u; break; }
-      // who waits for this result (read before the arithmetic, used after it)
-      const uint32_t ncv = K.NC[i];
-      const uint2 e0 = K.CONS[2u * i], e1 = K.CONS[2u * i + 1u];
+      // who waits for this result
+      if (!pre) { ncv = K.NC[i]; e0 = K.CONS[2u * i]; e1 = K.CONS[2u * i + 1u]; }
+      const uint32_t nc = rfl(ncv), x0 = rfl(e0.x), y0 = rfl(e0.y);
+      // The usual link: ONE consumer whose other input is valid and staged.  Then the next link is known before this one is
+      // combined: its other operand and ITS consumer entries are requested now and arrive behind the arithmetic -- a chain
+      // costs one LDS round trip per link, hidden.
+      const bool fast = nc == 1u && ((x0 >> 9) & 3u) == 1u && ((x0 >> 16) & 0xFFu) != kNoSlot;
+      QT<KS, VW> pt;
+      uint32_t pl = 0, ncv2 = 0;
+      uint2 f0 = make_uint2(0u, 0u), f1 = make_uint2(0u, 0u);
+      if (fast) {
+        const uint32_t j = x0 & 0xFFu;
+        const uint32_t *sp = K.stage + (size_t)((x0 >> 16) & 0xFFu) * ((R + 1) * 64) + lane;
+#pragma unroll
+        for (int k = 0; k < R; k++) pt.v[k / VW][k % VW] = sp[k * 64];
+        pl = sp[R * 64];
+        ncv2 = K.NC[j]; f0 = K.CONS[2u * j]; f1 = K.CONS[2u * j + 1u];
+      }
       const uint32_t cost = q_fitch<KS, VW>(c, ta, tb);
       lc = cost + la + lb;
       if (K.st_lane) qstore<KS, VW>(c, K.rsrc, K.voff, r * K.SW4);
       st_sl<KS, VW>(K, r, lc);
-      if (sh.dbg & 1u) {                                  // (experiment: every store twice)
-        if (K.st_lane) qstore<KS, VW>(c, K.rsrc, K.voff, r * K.SW4);
-        st_sl<KS, VW>(K, r, lc);
-      }
       if (lane == 0) K.valid[r] = 1;
-      const uint32_t nc = rfl(ncv);
+      if (fast) {
+        if (lane == 0) __hip_atomic_fetch_add(&sh.ndone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nlinks++;
+        i = x0 & 0xFFu;
+        r = y0 & 0xFFFFu;
+        if (((x0 >> 8) & 1u) == 0u) { ta = c; la = lc; tb = pt; lb = pl; }
+        else { tb = c; lb = lc; ta = pt; la = pl; }
+        ncv = ncv2; e0 = f0; e1 = f1;
+        pre = true;
+        continue;
+      }
+      pre = false;
       uint32_t nxt = kNone16, nx_x = 0, nx_y = 0;
 #pragma unroll
       for (int u = 0; u < 2; u++) {

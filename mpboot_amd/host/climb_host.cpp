@@ -131,7 +131,10 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     }
     // (counted in CU-equivalents of this launch's footprint: tiles / per_cu CUs)
     const int need = (tiles + per_cu - 1) / per_cu;
-    g.cv.wait(lk, [&] { return g.used == 0 || g.used + need <= g.cus; });
+    // (not every CU takes a workgroup of this size at every moment -- other queues' kernels come and go -- so admission
+    //  stops at 85 % of the chip: a launch beyond that waits its turn here instead of timing out in the kernel)
+    const int cap = std::max(1, g.cus * 85 / 100);
+    g.cv.wait(lk, [&] { return g.used == 0 || g.used + need <= cap; });
     g.used += need;
     hold.g = &g;
     hold.n = need;

@@ -69,7 +69,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
         const int i0 = i;
         int rc = climb_segment(mt_eff, total, &i, &randomMP, &iter_hits, climb_device_ < 2, &reason, &nm);
         if (rc) return rc;
-        if (reason == CLIMB_ABORT) { dev = dev_ok = false; continue; }
+        if (reason == CLIMB_ABORT) { dev = false; continue; }      // (not resident in time: this sweep goes on with host batches)
         sweep_moves += nm;
         if (nm) {
           const double g = (double)(i - i0) / (double)nm;

@@ -43,5 +43,10 @@ for E in (int(x) for x in a.engines.split(",")):
     for t in th: t.start()
     for t in th: t.join()
     dt_s = time.perf_counter() - t0
+    sts = [engs[k].stats() for k in range(E)]
+    print(f"   kernel launches {sum(s_['climb_launches'] for s_ in sts)} host scan launches {sum(s_['scan_launches'] for s_ in sts)} "
+          f"kernel ms/engine {np.mean([s_['climb_ms_total'] for s_ in sts]):.0f}")
+    for k in range(E):
+        engs[k].reset_stats()
     print(f"{a.workload}: {E} engines x {a.climbs} climbs from random trees in {dt_s:.3f} s = {E * a.climbs / dt_s:.2f} climbs/s "
           f"({dt_s / a.climbs:.3f} s per round; scores {min(min(r) for r in res)}..{max(max(r) for r in res)})", flush=True)
