@@ -52,11 +52,11 @@ def source_hash() -> str:
 
 def offline_traffic(workload: str, kernel_prefix: str):
     """Bytes that left the L2s per launch of the named kernel family (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-    tools/profile_gpu.sh -> profiles/r2/traffic.json); None unless that file was made from exactly these sources."""
+    tools/profile_gpu.sh -> profiles/r3/traffic.json); None unless that file was made from exactly these sources."""
     for k, v in LIVE_TRAFFIC.items():               # measured at the start of this run
         if k.startswith(kernel_prefix):
             return v
-    path = os.path.join(ROOT, "profiles", "r2", "traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3", "traffic.json")
     try:
         with open(path) as f:
             tj = json.load(f)
@@ -77,7 +77,7 @@ def live_traffic(args) -> dict:
     """HBM traffic of the step's kernels measured NOW: two short copies of this bench under `rocprofv3 --pmc` (FETCH_SIZE, then
     WRITE_SIZE: separate passes, counters only, the program itself behind `--`), before this process touches the GPU.  Bytes per
     launch = 2 x FETCH_SIZE (gfx950: the counter tallies 128-B requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB.
-    Returns {} when the profiler is not there or a pass fails -- the figures of profiles/r2/traffic.json (same sources) are used then."""
+    Returns {} when the profiler is not there or a pass fails -- the figures of profiles/r3/traffic.json (same sources) are used then."""
     import csv
     import glob
     import shutil
@@ -420,6 +420,7 @@ def main():
     ap.add_argument("--engines-per-gpu", type=int, default=6, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--climb-engines", type=int, default=8,
                     help="independent SPR climbs side by side on one GPU (one engine per host thread): the concurrent_climbs leg (0 = skip)")
+    ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
     ap.add_argument("--start-trees", type=int, default=100,
                     help="randomized-stepwise-addition + SPR start trees of the start-up phase (phyloanalysis.cpp:1270-1317), sharded over the GPUs (0 = skip)")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
@@ -439,7 +440,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
-    traffic_source = "profiles/r2/traffic.json (rocprofv3 --pmc passes of tools/profile_gpu.sh on the same sources)"
+    traffic_source = "profiles/r3/traffic.json (rocprofv3 --pmc passes of tools/profile_gpu.sh on the same sources)"
     # (under a profiler this process may hold the GPU already -- the counter tool initialises it before main() -- and must not
     #  start programs any more: the committed figures are quoted then)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
@@ -829,6 +830,7 @@ def main():
     mk = lambda: engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
     conc = None
     c2leg = None
+    c5leg = None
     startup = None
     try:
         pool = [eng]
@@ -899,7 +901,7 @@ def main():
                        "seconds_per_tree_per_engine": t_ras * k_e / max(1, len(units)),
                        "what": "%d randomized stepwise-addition trees + SPR climb (radius %d) each, as the reference's start-up builds them "
                                "(phyloanalysis.cpp:1270-1317); tree u on rank u %% n_gpus" % (args.start_trees, args.maxtrav)}
-        if world == 1 and args.workload == "C3":
+        if world == 1 and args.workload == "C3" and args.random_start_leg:
             # BASELINE config 2 (200 taxa x 10 000 patterns): a full SPR hill climb from a random tree
             letters2, names2 = synth.workload("C2")
             codes2 = synth.letters_to_codes(letters2, "DNA")
@@ -924,6 +926,66 @@ def main():
                 if c2leg["cpu_baseline"]:
                     c2leg["gpu_over_cpu"] = c2leg["cpu_baseline"]["seconds"] / c2leg["seconds"]
             del e2
+        if world == 1 and args.workload == "C3" and args.weighted_leg:
+            # BASELINE config 5 in its `-cost` form: the weighted (Sankoff) engine on 500 taxa x 20 000 protein patterns, 20 states
+            letters5, names5 = synth.workload("C5")
+            codes5 = synth.letters_to_codes(letters5, "AA")
+            n5, P5 = codes5.shape
+            cm = np.random.default_rng(5).integers(1, 6, size=(20, 20))
+            cost5 = (np.triu(cm, 1) + np.triu(cm, 1).T).astype(np.uint32)
+            f5 = engine.FitchEngine(codes5, datatype=engine.AA, device=device)
+            f5.seed_ties(engine.TIE_RANDOM, 1)
+            f5.make_parsimony_tree(12345, 0)
+            back5 = f5.get_tree()
+            del f5
+            e5 = engine.FitchEngine(codes5, datatype=engine.AA, device=device, cost=cost5)
+            e5.set_option("timing", 2)
+            e5.set_tree(back5)
+            s5 = e5.score_tree()
+            e5.sweep_scan(1, args.maxtrav)
+            e5.reset_stats()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            k5 = 0
+            for _ in range(5):
+                e5.set_tree(back5)
+                k5, _b5 = e5.sweep_scan(1, args.maxtrav)
+            torch.cuda.synchronize()
+            t5 = (time.perf_counter() - t0_) / 5
+            st5 = e5.stats()
+            scan5 = st5["scan_kernel_ms_total"] / max(1, st5["scan_launches"])
+            # algorithmic packed-u16 operations per insertion test and pattern: one min-plus transform of the running up-vector
+            # (2 S^2 add/min; every expansion makes two tests from two transforms) + the 3 S-operation test
+            ops5 = (2 * 20 * 20 + 3 * 20) * float(e5.num_informative) * k5
+            ach5 = ops5 / (scan5 * 1e-3) / 1e12 if scan5 > 0 else 0.0
+            c5leg = {"workload": "C5 weighted: %d taxa x %d protein patterns, 20 states, symmetric random costs 1..5 (numpy default_rng(5)), one full "
+                                 "sweep scan per step from the RAS tree, radius %d" % (n5, P5, args.maxtrav),
+                     "ms_per_step": t5 * 1e3, "evals_per_step": k5, "evals_per_s": k5 / t5, "tree_length": s5,
+                     "scan_kernel_ms": scan5, "view_kernel_ms_per_step": st5["view_kernel_ms_total"] / 5,
+                     "roofline": {"bound": "valu", "achieved": ach5, "peak": 2.0 * VALU_PEAK_TOPS, "unit": "T packed-u16 op/s",
+                                  "frac": ach5 / (2.0 * VALU_PEAK_TOPS), "kernel": "k_snk_scan",
+                                  "note": "min-plus arithmetic on packed 16-bit costs (v_pk_add_u16 / v_pk_min_u16: two patterns per lane); "
+                                          "achieved = insertion tests x patterns x (2 S^2 + 3 S) / HIP-event time of the scan kernel; peak = "
+                                          "256 CUs x 4 SIMD-32 x 2.4 GHz x 2 values per lane"}}
+            if not args.no_cpu:
+                from oracle import pyoracle as po5
+                o5 = po5.Oracle(codes5, datatype=po5.AA, cost=cost5)
+                assert o5.score_tree(back5) == s5
+                o5.seed_ties(po5.TIE_RANDOM, 1)
+                o5.set_best(s5)
+                nodep5 = o5.nodep()
+                tc0 = time.perf_counter()
+                kk0, i5 = o5.counters()[2], 1
+                while time.perf_counter() - tc0 < min(args.cpu_budget, 8.0) and i5 <= 2 * n5 - 2:
+                    o5.rearrange(int(nodep5[i5]), 1, args.maxtrav)
+                    i5 += 1
+                tc = time.perf_counter() - tc0
+                kc5 = o5.counters()[2] - kk0
+                c5leg["cpu_baseline"] = {"value": kc5 / tc, "unit": "insertion tests/s", "cores": 1, "kind": "port",
+                                         "sample": "%d prune nodes (%d insertion tests) of the same sweep on the scalar C oracle (exact 32-bit; the "
+                                                   "reference's Sankoff kernels live in the unbuildable C++ layer)" % (i5 - 1, kc5)}
+                c5leg["gpu_over_cpu"] = (k5 / t5) / (kc5 / tc)
+            del e5
     except Exception as exc:
         legs_error = (legs_error or "") + " | climb legs: " + repr(exc)
 
@@ -936,6 +998,8 @@ def main():
             res["start_trees"] = startup
         if c2leg is not None:
             res["c2_climb"] = c2leg
+        if c5leg is not None:
+            res["c5_weighted_sweep"] = c5leg
         if legs_error is not None:
             res["bootstrap_legs_error"] = legs_error
         if boot is not None:

@@ -224,7 +224,7 @@ struct Sh {
   uint32_t best, randomMP, iter_hits;
   int32_t ins, rem;
   unsigned long long rng, hits, n_tests, n_ops, draws, n_nodes;
-  uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, dbg, pn_base[kMaxB];
+  uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, pn_base[kMaxB];
   Unit unit[kMaxUnits];
   uint32_t pcnt[kMaxParts], poff[kMaxParts], pE[kMaxParts];
   uint32_t pn_off[kMaxB], pn_cnt[kMaxB], pn_np[kMaxB], pn_p[kMaxB];
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
   if (tid == 0) {
     const ClimbHeader h = *P.hdr;
     sh.pos = h.pos; sh.B = h.batch ? h.batch : P.batch_min; sh.epoch = 1u; sh.exit_reason = CLIMB_RUNNING;
-    sh.since_move = h.since_move; sh.rtail = 0; sh.dbg = h.pad[0]; sh.steps = 0; sh.xgen = 0; sh.n_moves = 0; sh.err = 0; sh.trace_n = 0;
+    sh.since_move = h.since_move; sh.rtail = 0; sh.steps = 0; sh.xgen = 0; sh.n_moves = 0; sh.err = 0; sh.trace_n = 0;
     sh.last_ncand[0] = sh.last_ncand[1] = sh.last_ncand[2] = 0;
     sh.best = h.best; sh.randomMP = h.randomMP; sh.iter_hits = h.iter_hits; sh.ins = h.insert_cid; sh.rem = h.remove_cid;
     sh.rng = h.rng; sh.hits = h.hits; sh.n_tests = 0; sh.n_ops = 0; sh.draws = 0; sh.n_nodes = 0;

@@ -84,7 +84,6 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   h.insert_cid = insert_rec_ >= 0 ? (int32_t)slot(insert_rec_) : -1;
   h.remove_cid = remove_rec_ >= 0 ? (int32_t)slot(remove_rec_) : -1;
   h.since_move = 0;
-  h.pad[0] = (uint32_t)climb_debug_;
   h.batch = 0;
   std::memcpy(cd_.h_out.p, &h, sizeof(h));
   ClimbParams p;
