@@ -591,6 +591,127 @@ void Engine::build_chains(const std::vector<int> &order)
   ch_levels_ = nlev;
 }
 
+// A new topology, nothing valid, the tree complete: the schedule of the refresh can be made on the device (k_sched)
+bool Engine::dev_sched_usable() const
+{
+  return have_tree_ && all_invalid_ && dev_sched_ && !sankoff_ && ntips_ == n_ && n_ >= 4 && g_.vw == 1 && g_.nv_pipe && views_mode_ >= 1 &&
+         nslots_ <= kSchedMaxSlots;
+}
+
+// From-scratch refresh with the schedule made on the device: the host only lays out the topology array (kids[cid], 8 bytes per
+// vector) and uploads it; levels, ops in level order and level offsets come from one workgroup (k_sched) in front of the refresh
+// kernel, while the host goes on.  sweep_maxtrav > 0: a second workgroup of the same launch lays out the scan descriptors of a
+// whole sweep of that radius (nodep_ must be current) -- what plan_walk does on the host -- and tells the host how many.
+int Engine::schedule_views_dev(int sweep_maxtrav)
+{
+  ScopedMs timer(stats.host_views_ms_total);
+  const size_t nops = 3 * (size_t)(n_ - 2);
+  const size_t n_prune = sweep_maxtrav > 0 ? 2 * (size_t)n_ - 2 : 0;
+  if (kids_host_.size() != nslots_) kids_host_.assign(nslots_, make_uint2(0u, 0u));
+  for (int v = n_ + 1; v <= 2 * n_ - 2; v++) {
+    const int r0 = 3 * v;
+    const uint32_t s0 = slot(back_[r0]), s1 = slot(back_[r0 + 1]), s2 = slot(back_[r0 + 2]);
+    uint2 *k = &kids_host_[slot(r0)];            // the three records of a node sit side by side, in `next` order
+    k[0] = make_uint2(s1, s2);
+    k[1] = make_uint2(s2, s0);
+    k[2] = make_uint2(s0, s1);
+  }
+  kids_list_.clear();
+  // staging layout: [kids][prune records of the sweep][ops][level offsets][level count]; the first two go up in one copy
+  const size_t kids_bytes = nslots_ * sizeof(uint2);
+  const size_t nodep_off = (kids_bytes + 15) & ~(size_t)15;
+  const size_t ops_off = nodep_off + ((n_prune * sizeof(uint32_t) + 15) & ~(size_t)15);
+  const size_t lev_off_b = ops_off + ((nops * sizeof(NvOp) + 15) & ~(size_t)15);
+  const size_t nlev_off = lev_off_b + ((((size_t)n_ + 2) * sizeof(int32_t) + 15) & ~(size_t)15);
+  const size_t total_b = nlev_off + 64;
+  HIPCHK(h_vstage_.reserve(total_b));
+  HIPCHK(d_vstage_.reserve(total_b));
+  std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
+  uint8_t *src = d_vstage_.p;
+  SweepDescArgs sw;
+  if (n_prune) {
+    uint32_t *np = reinterpret_cast<uint32_t *>(h_vstage_.p + nodep_off);
+    for (size_t i = 0; i < n_prune; i++) np[i] = slot(nodep_[i + 1]);
+    const size_t cap = 8 * n_prune;              // a prune node has two neighbourhoods of at most four parts
+    HIPCHK(d_walk_.reserve(cap));
+    HIPCHK(d_parts_.reserve(cap));
+    HIPCHK(h_dsw_.reserve(4 + cap));
+    sw.nodep = reinterpret_cast<const uint32_t *>(src + nodep_off);
+    sw.n_prune = (uint32_t)n_prune;
+    sw.maxtrav = (uint32_t)sweep_maxtrav;
+    sw.split_cands = (uint32_t)std::max(0, split_cands_);
+    sw.desc = d_walk_.p;
+    sw.parts = d_parts_.p;
+    sw.hdr_host = h_dsw_.p;
+    sw.part_node = h_dsw_.p + 4;
+    __atomic_store_n(h_dsw_.p + 3, 0u, __ATOMIC_RELAXED);
+    walk_gen_++;                                 // whatever descriptors, program and part table were on the device are gone
+    n_walk_ = 0;
+    walk_out_ = 0;
+    sweep_cache_valid_ = false;
+  }
+  HIPCHK(hipMemcpyAsync(d_vstage_.p, h_vstage_.p, n_prune ? ops_off : kids_bytes, hipMemcpyHostToDevice, st_));
+  kids_dirty_ = false;
+  kids_upload_ = false;
+  kids_dev_ready_ = true;
+  NvOp *dops = reinterpret_cast<NvOp *>(src + ops_off);
+  int32_t *dlo = reinterpret_cast<int32_t *>(src + lev_off_b);
+  int32_t *dnl = reinterpret_cast<int32_t *>(src + nlev_off);
+  const int tiles = std::max(tiles_for(g_), tiles_for_levels(g_));
+  HIPCHK(d_cntp_.reserve((size_t)tiles * nslots_));
+  zeroed_ptr_ = nullptr;
+  zeroed_words_ = 0;
+  for (int i = 0; i < 2; i++) ride_[i].dev = nullptr;
+  cnt_on_host_ = false;
+  if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));
+  HIPCHK(launch_sched(st_, reinterpret_cast<const uint2 *>(src), (uint32_t)n_, (uint32_t)nops, dops, dlo, dnl, sw));
+  RefreshExtra x;
+  x.n_lev_ptr = dnl;
+  HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, 1, d_cntp_.p, (uint32_t)nslots_, d_cnt(), nullptr, x));
+  stats.view_launches++;
+  HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), tiles_for_levels(g_)));
+  if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
+  cnt_copy_pending_ = true;
+  // what the host still needs is a dependency order for the subtree scores (finish_views): the views looking away from
+  // start_, children first, then the ones looking towards it, parents first -- while the device works
+  std::vector<int> &all = sv_all_, &stack = sv_stack_;
+  all.clear();
+  stack.clear();
+  stack.push_back(back_[start_]);
+  while (!stack.empty()) {
+    const int r = stack.back();
+    stack.pop_back();
+    if (tip(r)) continue;
+    all.push_back(r);
+    stack.push_back(back_[nx(nx(r))]);
+    stack.push_back(back_[nx(r)]);
+  }
+  upd_order_.resize(nops);
+  size_t at = 0;
+  if (3 * all.size() != nops) { set_error("refresh schedule: the tree is not complete"); return MPF_E_STATE; }
+  for (size_t i = all.size(); i-- > 0;) upd_order_[at++] = all[i];
+  for (int u : all) { upd_order_[at++] = nx(u); upd_order_[at++] = nx(nx(u)); }
+  for (int r : upd_order_) valid_[r] = 1;
+  all_invalid_ = false;
+  n_invalid_ = 0;
+  views_valid_ = true;
+  pending_scores_ = true;
+  sched_cache_valid_ = (plan_cache_ & 2) != 0;
+  sched_gen_++;
+  if (n_prune) dsw_sched_gen_ = sched_gen_;       // the sweep descriptors belong to this schedule's topology
+  if (sched_cache_valid_) {
+    sc_nops_ = nops;
+    sc_maxlev_ = -1;
+    sc_ops_off_ = ops_off;
+    sc_lev_off_b_ = lev_off_b;
+    sc_nlev_off_ = nlev_off;
+    sc_order_ = upd_order_;
+  }
+  stats.newview_ops += nops;
+  stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  return MPF_OK;
+}
+
 int Engine::schedule_views(const std::vector<int> *roots)
 {
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
@@ -610,7 +731,8 @@ int Engine::schedule_views(const std::vector<int> *roots)
     cnt_on_host_ = false;
     if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));
     RefreshExtra x;
-    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, sc_maxlev_, d_cntp_.p, (uint32_t)nslots_, d_cnt(), nullptr, x));
+    if (sc_maxlev_ < 0) x.n_lev_ptr = reinterpret_cast<const int32_t *>(src + sc_nlev_off_);      // (made by k_sched: the count lives there)
+    HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, sc_maxlev_ < 0 ? 1 : sc_maxlev_, d_cntp_.p, (uint32_t)nslots_, d_cnt(), nullptr, x));
     stats.view_launches++;
     HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), tiles_for_levels(g_)));
     if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
@@ -625,6 +747,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     stats.algorithmic_bytes += (uint64_t)nops * 3u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
     return MPF_OK;
   }
+  if (!roots && dev_sched_usable()) return schedule_views_dev(0);
   // scratch vectors are members: this runs once per scan batch, allocations would show
   std::vector<int> &all = sv_all_;
   all.clear();
@@ -882,6 +1005,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     // d_vstage_ was (re)written: it holds a reusable schedule only if this was the from-scratch refresh of the whole tree
     // on the level kernel with the per-tile counts folded by the separate launch (the shape the fast path above replays)
     sched_cache_valid_ = (plan_cache_ & 2) && from_scratch && full && !chains && views_mode_ >= 1 && !fold_inside && !sankoff_ && !can_ride_used;
+    sched_gen_++;
     if (sched_cache_valid_) {
       sc_nops_ = nops;
       sc_maxlev_ = maxlev;
@@ -1298,9 +1422,32 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     const WalkDesc *descs = static_cast<const WalkDesc *>(ride_[0].dev);
     ride_[0].dev = nullptr;
     if (walk_dev_reuse_) descs = d_walk_.p;        // a cached sweep: descriptors (and the planned program) are still there
+    // small batch: the kernels write the host's copies themselves (mutation counts: the refresh's fold; candidate costs:
+    // the scan's last workgroup) -- no copy-back dispatch
+    const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && (cnt_on_host_ || !cnt_copy_pending_);
+    // planned program (plan kernel + pipelined scan) for throughput batches; the device-walked kernel for the small,
+    // latency-bound batches inside a climb (scan_prog 2: always planned), for masks, protein and radii above 6
+    const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
+    const bool plan_now = prog && (!walk_dev_reuse_ || prog_gen_ != walk_gen_);
+    const bool use_pmin = want_part_min_ && !host_direct && !scan_masks_ && !check_counts_ && nout > 16384;
+    const bool parts_now = use_pmin && !(walk_dev_reuse_ && parts_gen_ == walk_gen_ && n_parts_dev_ > 0);
+    if (parts_now) {
+      // the (offset, count) list of the scan parts for k_part_min goes up in front of the scan, not between it and the reduction
+      size_t np = 0;
+      for (const ScanPlan &pl : plans) np += (size_t)pl.n_parts;
+      HIPCHK(h_parts_.reserve(std::max<size_t>(np, 1)));
+      n_parts_dev_ = 0;
+      for (const ScanPlan &pl : plans)
+        for (int pi = 0; pi < pl.n_parts; pi++) h_parts_.p[n_parts_dev_++] = make_uint2(pl.part_off[pi], (uint32_t)pl.part_cnt[pi]);
+      HIPCHK(d_parts_.reserve(std::max<size_t>(n_parts_dev_, 1)));
+      // (the pinned list is rewritten only by the next newly planned sweep, i.e. after this sweep's results have come back)
+      HIPCHK(hipMemcpyAsync(d_parts_.p, h_parts_.p, n_parts_dev_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
+      parts_gen_ = walk_gen_;
+    }
     if (!descs) { HIPCHK(hipMemcpyAsync(d_walk_.p, h_walk_.p, nd * sizeof(WalkDesc), hipMemcpyHostToDevice, st_)); descs = d_walk_.p; }
-    if (!(zeroed_ptr_ == d_out() && zeroed_words_ >= clear_words(nout)))
-      HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
+    const bool zeroed = zeroed_ptr_ == d_out() && zeroed_words_ >= clear_words(nout);
+    const bool zero_in_plan = !zeroed && plan_now;           // the plan kernel clears the outputs: no memset dispatch
+    if (!zeroed && !zero_in_plan) HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
     zeroed_ptr_ = nullptr;
     zeroed_words_ = 0;
     if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
@@ -1313,21 +1460,16 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       info_ptr = ufb_->info.p;
       ufb_rows_ = (uint32_t)nout;
     }
-    // small batch: the kernels write the host's copies themselves (mutation counts: the refresh's fold; candidate costs:
-    // the scan's last workgroup) -- no copy-back dispatch
-    const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && (cnt_on_host_ || !cnt_copy_pending_);
     if (host_direct) __atomic_store_n(h_out() + nout, 0u, __ATOMIC_RELAXED);     // the flag word behind the results
-    // planned program (plan kernel + pipelined scan) for throughput batches; the device-walked kernel for the small,
-    // latency-bound batches inside a climb (scan_prog 2: always planned), for masks, protein and radii above 6
-    const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
     if (prog) {
       HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));
       // (a cached sweep re-uses the program only if one was planned for exactly these descriptors: the sweep may have run on
       //  the device-walked kernel when it was cached -- option prog_min_descs -- and other batches plan into the same buffer)
-      if (!walk_dev_reuse_ || prog_gen_ != walk_gen_) {
+      if (plan_now) {
         prog_gen_ = walk_gen_;
         if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
-        HIPCHK(launch_walk_plan(st_, d_kids(), n_, descs, (int)nd, d_prog_.p));
+        HIPCHK(launch_walk_plan(st_, d_kids(), n_, descs, (int)nd, d_prog_.p, zero_in_plan ? d_out() : nullptr,
+                                zero_in_plan ? (uint32_t)clear_words(nout) : 0u));
         if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }   // the scan kernel's own time starts here
       }
       unsigned long long *trace = nullptr;
@@ -1347,20 +1489,8 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     part_min_used_ = false;
     bool part_min_polled = false;
-    if (want_part_min_ && !host_direct && !scan_masks_ && !check_counts_ && nout > 16384) {
+    if (use_pmin) {
       // only the cheapest candidate of every scan part is wanted: reduce on the device, minima straight to the host
-      if (!(walk_dev_reuse_ && parts_gen_ == walk_gen_ && n_parts_dev_ > 0)) {
-        size_t np = 0;
-        for (const ScanPlan &pl : plans) np += (size_t)pl.n_parts;
-        HIPCHK(h_parts_.reserve(std::max<size_t>(np, 1)));
-        n_parts_dev_ = 0;
-        for (const ScanPlan &pl : plans)
-          for (int pi = 0; pi < pl.n_parts; pi++) h_parts_.p[n_parts_dev_++] = make_uint2(pl.part_off[pi], (uint32_t)pl.part_cnt[pi]);
-        HIPCHK(d_parts_.reserve(std::max<size_t>(n_parts_dev_, 1)));
-        // (the pinned list is rewritten only by the next newly planned sweep, i.e. after this sweep's results have come back)
-        HIPCHK(hipMemcpyAsync(d_parts_.p, h_parts_.p, n_parts_dev_ * sizeof(uint2), hipMemcpyHostToDevice, st_));
-        parts_gen_ = walk_gen_;
-      }
       HIPCHK(h_pmin_.reserve(n_parts_dev_ + 1));
       // the mutation counts of the refresh in front ride along, and a polling host is told through a flag word behind the minima
       // (the scan's timing events lie in front of this launch: they are complete when the flag is up)
@@ -1532,6 +1662,15 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
   if (!have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
   ScopedMs sweep_timer(stats.host_sweep_ms_total);
   node_rectifier();
+  {
+    // nothing valid (a tree just handed over or re-weighted) and the planned scan applies: schedule, descriptors and program
+    // are all made on the device
+    const int mt = std::min(maxtrav, ntips_ - 3);
+    if (dev_plan_ && mintrav == 1 && mt >= 1 && mt <= 6 && all_invalid_ && scan_mode_ == 1 && scan_prog_ > 0 && scan_prog_supported(g_, mt) &&
+        !scan_masks_ && !check_counts_ && !scan_trace_ && host_poll_ && n_ >= 8 &&
+        (dev_sched_usable() || (dsw_valid_ && sched_cache_valid_ && !kids_dirty_ && !sankoff_)))
+      return sweep_scan_dev(mt, n_tests, min_mp);
+  }
   std::vector<ScanPlan> &plans = sweep_plans_;
   const uint32_t *out = nullptr;
   want_part_min_ = true;
@@ -1562,6 +1701,88 @@ int Engine::sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *mi
     tests += nc;
   }
   if (n_tests) *n_tests = tests;
+  if (min_mp) *min_mp = best;
+  return MPF_OK;
+}
+
+// mpf_sweep_scan on a tree that has no valid vector, with nothing of it planned on the host: topology array up, then k_sched
+// (refresh schedule + scan descriptors), refresh, k_walk_plan, k_scan_prog, k_part_min; the host learns the number of scan parts
+// from a flag word (it needs it for the grids), then waits for the per-part minima and the refresh's mutation counts.
+int Engine::sweep_scan_dev(int mt, uint64_t *n_tests, uint32_t *min_mp)
+{
+  const int key[4] = {mt, split_cands_, g_.vw * 4 + g_.map * 2 + g_.big, 0};
+  // the same topology as the last device-planned sweep, nothing else planned since: descriptors, program and part table are
+  // still in place (mpf_set_tree found the links unchanged: only the vectors were invalidated)
+  const bool warm = (plan_cache_ & 4) && dsw_valid_ && dsw_walk_gen_ == walk_gen_ && prog_gen_ == walk_gen_ && parts_gen_ == walk_gen_ &&
+                    sched_cache_valid_ && dsw_sched_gen_ == sched_gen_ && !kids_dirty_ && kids_list_.empty() && std::equal(key, key + 4, dsw_key_);
+  int rc;
+  if (warm) rc = schedule_views(nullptr);          // (the cached schedule: one launch, no host work)
+  else {
+    if (!dev_sched_usable()) { dsw_valid_ = false; return sweep_scan(1, mt, n_tests, min_mp); }   // (cannot happen: the caller checked)
+    dsw_valid_ = false;
+    rc = schedule_views_dev(mt);
+  }
+  if (rc) return rc;
+  ScopedMs timer(stats.host_scan_ms_total);
+  if (!warm) {
+    if (!wait_host_flag(h_dsw_.p + 3)) HIPCHK(hipStreamSynchronize(st_));
+    dsw_parts_ = h_dsw_.p[0];
+    dsw_out_ = h_dsw_.p[1];
+    dsw_walk_gen_ = walk_gen_;
+    std::copy(key, key + 4, dsw_key_);
+    dsw_valid_ = true;
+  }
+  const size_t nd = dsw_parts_, nout = dsw_out_;
+  uint32_t best = UINT_MAX;
+  if (nd > 0) {
+    HIPCHK(d_ncand_.reserve(nd));
+    HIPCHK(reserve_results(nout));
+    HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));
+    HIPCHK(h_pmin_.reserve(nd + 1));
+    if (warm) HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
+    if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
+    if (!warm) {
+      if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
+      HIPCHK(launch_walk_plan(st_, d_kids(), n_, d_walk_.p, (int)nd, d_prog_.p, d_out(), (uint32_t)clear_words(nout)));
+      if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }
+      prog_gen_ = walk_gen_;
+      parts_gen_ = walk_gen_;
+      n_parts_dev_ = nd;
+    }
+    HIPCHK(launch_scan_prog(st_, g_, d_vec_, d_walk_.p, (int)nd, d_prog_.p, d_out(), d_ncand_.p, nullptr, (uint32_t)nout, d_done_.p + 8, nullptr));
+    stats.plan_launches++;
+    if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
+    __atomic_store_n(h_pmin_.p + nd, 0u, __ATOMIC_RELAXED);
+    HIPCHK(launch_part_min(st_, d_out(), d_parts_.p, (int)nd, h_pmin_.p, d_cnt(), cnt_copy_pending_ ? h_cnt() : nullptr, (uint32_t)nslots_,
+                           d_done_.p + 24));
+    cnt_copy_pending_ = false;
+    if (!wait_host_flag(h_pmin_.p + nd)) HIPCHK(hipStreamSynchronize(st_));
+    float ms = 0;
+    if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+    if (plan_event_pending_) {
+      if (hipEventElapsedTime(&ms, ev4_, ev0_) == hipSuccess) stats.plan_kernel_ms_total += ms;
+      plan_event_pending_ = false;
+    }
+    stats.scan_launches++;
+  } else {
+    if (cnt_copy_pending_) {
+      HIPCHK(hipMemcpyAsync(h_cnt(), d_cnt(), nslots_ * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+      cnt_copy_pending_ = false;
+    }
+    HIPCHK(hipStreamSynchronize(st_));
+  }
+  finish_views();
+  // base length of a prune node's candidates = the two subtrees either side of the cut (reference :2158-2160)
+  const uint32_t *node = h_dsw_.p + 4;
+  for (size_t i = 0; i < nd; i++) {
+    const uint32_t m = h_pmin_.p[i];
+    if (m == UINT_MAX) continue;                   // (a part without candidates)
+    const int p = nodep_[node[i] + 1], q = back_[p];
+    best = std::min(best, (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]) + m);
+  }
+  stats.insertion_tests += nout;
+  stats.algorithmic_bytes += (uint64_t)nout * 6u * (uint64_t)g_.S * (uint64_t)Wref_ * 4u;
+  if (n_tests) *n_tests = nout;
   if (min_mp) *min_mp = best;
   return MPF_OK;
 }
@@ -1704,6 +1925,8 @@ int Engine::set_option(const std::string &key, int64_t v)
     g_.vw = (int)v;
     return MPF_OK;
   }
+  if (key == "dev_sched") { dev_sched_ = v != 0; sched_cache_valid_ = false; dsw_valid_ = false; return MPF_OK; }
+  if (key == "dev_plan") { dev_plan_ = v != 0; dsw_valid_ = false; return MPF_OK; }               // scan descriptors of mpf_sweep_scan laid out on the device   // refresh schedule of a new topology made on the device (k_sched)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }
@@ -1779,6 +2002,12 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "views_pipe") *v = g_.nv_pipe;
   else if (key == "views_tile") *v = g_.nv_tile;
   else if (key == "plan_cache") *v = plan_cache_;
+  else if (key == "sched_levels" || key == "sched_ticks" || key == "sched_desc_ticks") {
+    // diagnostics of the last device-made schedule: dependency levels, duration of k_sched's two workgroups (10 ns ticks)
+    int32_t w[16] = {0};
+    if (sc_maxlev_ < 0 && sched_cache_valid_ && d_vstage_.p) { (void)hipStreamSynchronize(st_); (void)hipMemcpy(w, d_vstage_.p + sc_nlev_off_, 64, hipMemcpyDeviceToHost); }
+    *v = w[key == "sched_levels" ? 0 : key == "sched_ticks" ? 1 : 2];
+  }
   else if (key == "split_below") *v = split_below_;
   else if (key == "split_cands") *v = split_cands_;
   else if (key == "chain_max_ops") *v = chain_max_ops_;

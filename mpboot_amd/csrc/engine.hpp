@@ -228,6 +228,9 @@ class Engine {
   void invalidate_vectors();                   // vectors stale, topology (and what was planned from it) kept
   void invalidate_node(int node);              // every vector whose subtree contains `node`
   int schedule_views(const std::vector<int> *roots);   // enqueue (no sync); nullptr = every record of the tree
+  bool dev_sched_usable() const;
+  int schedule_views_dev(int sweep_maxtrav);
+  int sweep_scan_dev(int maxtrav, uint64_t *n_tests, uint32_t *min_mp);
   void finish_views();                         // after a stream sync: subtree scores of the refreshed vectors
   void collect_scan_roots(int p, int mintrav, int maxtrav, std::vector<int> &roots) const;
 
@@ -492,8 +495,16 @@ class Engine {
   // refresh (ops by level, in d_vstage_) and the plans / descriptors / device program of a whole sweep
   int plan_cache_ = 7;
   bool sched_cache_valid_ = false;
-  size_t sc_nops_ = 0, sc_ops_off_ = 0, sc_lev_off_b_ = 0;
-  int sc_maxlev_ = 0;
+  size_t sc_nops_ = 0, sc_ops_off_ = 0, sc_lev_off_b_ = 0, sc_nlev_off_ = 0;
+  int sc_maxlev_ = 0;                           // < 0: the schedule was made on the device, its level count lives at sc_nlev_off_
+  bool dev_sched_ = true;                       // option dev_sched
+  bool dev_plan_ = true;                        // option dev_plan: a whole sweep's scan descriptors laid out on the device too
+  PinBuf<uint32_t> h_dsw_;                      // {parts, candidates, -, flag}, then the prune-node index of every part (written by k_sched)
+  bool dsw_valid_ = false;                      // the descriptors on the device are k_sched's, for ...
+  uint64_t dsw_walk_gen_ = 0;                   // ... this walk_gen_, ...
+  uint64_t sched_gen_ = 0, dsw_sched_gen_ = ~0ull; // ... and the topology of this refresh schedule (counted per schedule made)
+  int dsw_key_[4] = {0, 0, 0, 0};               // ... this radius / these options
+  uint32_t dsw_parts_ = 0, dsw_out_ = 0;
   std::vector<int> sc_order_;
   bool sweep_cache_valid_ = false, walk_dev_reuse_ = false;
   uint64_t walk_gen_ = 0, sweep_cache_gen_ = 0;

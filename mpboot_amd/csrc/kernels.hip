@@ -466,6 +466,7 @@ __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec
   const int w0 = tile * TW + (lane % TW);          // Wp is a multiple of 32: always inside the row
   const int step = OPI * nw;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x.zero_words; i += gridDim.x * blockDim.x) x.zero_ptr[i] = 0u;
+  if (x.n_lev_ptr) n_lev = *x.n_lev_ptr;         // (schedule made by k_sched in front of this launch)
   for (int l = 0; l < n_lev; l++) {
     const int b = lev_off[l], e = lev_off[l + 1];
     int ib = b + OPI * wave;
@@ -598,6 +599,276 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
     fold_counts(ops, n_ops, cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// Refresh schedule of a complete tree, made on the device.  The level of a directional vector is 1 + the larger level of its two
+// inputs (tips: 0) -- a function of the topology array alone.  One workgroup: every thread owns the records tid, tid + 1024, ...
+// (their kids in registers), levels settle by in-place relaxation in LDS (a record resolves in the round after its inputs, or
+// in the same one if they were written earlier in it: the value is the same either way), one barrier per round; then a
+// counting sort by level.  Rounds <= the tree's largest level (43 for the C3 start tree), ~0.2 us each.
+static size_t sched_lds_bytes(uint32_t n, uint32_t ns, bool desc)
+{
+  const size_t a = (((size_t)ns * 2 + 15) & ~(size_t)15) + ((size_t)ns / 3 + 16) * 4;                      // levels (16 bit) + per-level counters
+  const size_t b = (((size_t)ns * 2 + 15) & ~(size_t)15) + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)ns * 4;   // N(., m) twice, tip links, kids
+  return desc ? std::max(a, b) : a;
+}
+
+// second workgroup of k_sched: scan descriptors of a sweep (Engine::plan_walk on the device).  N(c, m) = insertion tests behind
+// record c within m steps = 1 + N(kid1, m - 1) + N(kid2, m - 1), tips and m = 1: 1 -- at most 63 for radius 6, one byte each.
+__device__ void sweep_desc_block(const uint2 *__restrict__ kids_g, uint32_t n, uint32_t n_ops, const SweepDescArgs &a, uint8_t *s_mem,
+                                 uint32_t *s_w)
+{
+  const uint32_t tid = threadIdx.x, ns = n + n_ops;
+  const size_t half = (((size_t)ns * 2 + 15) & ~(size_t)15) / 2;
+  uint8_t *pa = s_mem, *pc = s_mem + half;
+  uint16_t *s_tipback = reinterpret_cast<uint16_t *>(s_mem + 2 * half);
+  uint32_t *s_k = reinterpret_cast<uint32_t *>(s_mem + 2 * half + (((size_t)n * 2 + 15) & ~(size_t)15));   // the topology array, 16 bits per kid
+  for (uint32_t c = tid; c < ns; c += 1024u) {
+    pa[c] = 1;
+    pc[c] = 1;
+    const uint2 k = c < n ? make_uint2(0u, 0u) : kids_g[c];
+    s_k[c] = k.x | (k.y << 16);
+  }
+  __syncthreads();
+  struct { const uint32_t *k; __device__ uint2 operator[](uint32_t c) const { const uint32_t v = k[c]; return make_uint2(v & 0xFFFFu, v >> 16); } } kids{s_k};
+  // the record behind record c: back(c) = first kid of the record before c in its node's ring; tips: found by their neighbour
+  auto backc = [&](uint32_t c) -> uint32_t {
+    if (c < n) return s_tipback[c];
+    const uint32_t k = c - n, b3 = n + 3u * (k / 3u), s = k % 3u;
+    return kids[b3 + (s + 2u) % 3u].x;
+  };
+  for (uint32_t c = n + tid; c < ns; c += 1024u) {
+    const uint32_t k = c - n, b3 = n + 3u * (k / 3u), s = k % 3u;
+    const uint32_t bc = kids[b3 + (s + 2u) % 3u].x;
+    if (bc < n) s_tipback[bc] = (uint16_t)c;
+  }
+  for (uint32_t m = 2; m <= a.maxtrav; m++) {
+    for (uint32_t c = n + tid; c < ns; c += 1024u) { const uint2 k = kids[c]; pc[c] = (uint8_t)(1u + pa[k.x] + pa[k.y]); }
+    __syncthreads();
+    uint8_t *t = pa; pa = pc; pc = t;
+  }
+  __syncthreads();
+  auto cv = [&](uint32_t c) -> uint32_t { return c < n ? 1u : (uint32_t)pa[c]; };
+  // the parts of prune node i, in plan_walk's order: emit(s_cid, xa, xb, mintrav of the phase, side mask, child mask, candidates,
+  // candidates behind the first gap end)
+  auto node_parts = [&](uint32_t i, auto &&emit) {
+    const uint32_t p = a.nodep[i], q = backc(p);
+    auto phase = [&](uint32_t x, uint32_t s, uint32_t mt) {
+      const uint2 xs = kids[x];
+      const uint32_t xv[2] = {xs.x, xs.y}, skip = mt > 1u ? 1u : 0u;
+      uint32_t cnt[2][2] = {{0u, 0u}, {0u, 0u}};
+      for (int side = 0; side < 2; side++) {
+        if (xv[side] < n) continue;
+        const uint2 k2 = kids[xv[side]];
+        cnt[side][0] = cv(k2.x) - skip;
+        cnt[side][1] = cv(k2.y) - skip;
+      }
+      const uint32_t total = cnt[0][0] + cnt[0][1] + cnt[1][0] + cnt[1][1];
+      if (total <= a.split_cands) { emit(s, xs.x, xs.y, mt, 3u, 3u, total, cnt[0][0] + cnt[0][1]); return; }
+      for (int side = 0; side < 2; side++) {
+        if (xv[side] < n) continue;
+        emit(s, xs.x, xs.y, mt, 1u << side, 1u, cnt[side][0], 0u);
+        emit(s, xs.x, xs.y, mt, 1u << side, 2u, cnt[side][1], 0u);
+      }
+    };
+    if (p >= n) {
+      const uint2 k = kids[p];
+      if (k.x >= n || k.y >= n) phase(p, q, 1u);
+    }
+    if (q >= n) {
+      const uint2 k = kids[q];
+      bool ok = false;
+      if (k.x >= n) { const uint2 k2 = kids[k.x]; ok = ok || k2.x >= n || k2.y >= n; }
+      if (k.y >= n) { const uint2 k2 = kids[k.y]; ok = ok || k2.x >= n || k2.y >= n; }
+      if (ok) phase(q, p, 2u);
+    }
+  };
+  // consecutive prune nodes per thread; block-wide exclusive prefix of (parts, candidates)
+  const uint32_t CH = (a.n_prune + 1023u) / 1024u;
+  const uint32_t i0 = tid * CH, i1 = min(i0 + CH, a.n_prune);
+  uint32_t np = 0, nc = 0;
+  for (uint32_t i = i0; i < i1; i++) node_parts(i, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t c, uint32_t) { np++; nc += c; });
+  uint32_t ip = np, ic = nc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t op = (uint32_t)__shfl_up((int)ip, d, 64), oc = (uint32_t)__shfl_up((int)ic, d, 64);
+    if ((int)(tid & 63u) >= d) { ip += op; ic += oc; }
+  }
+  if ((tid & 63u) == 63u) { s_w[tid >> 6] = ip; s_w[16 + (tid >> 6)] = ic; }
+  __syncthreads();
+  uint32_t bp = ip - np, bc = ic - nc, tp = 0, tc = 0;
+  for (uint32_t w = 0; w < 16u; w++) {
+    if (w < (tid >> 6)) { bp += s_w[w]; bc += s_w[16 + w]; }
+    tp += s_w[w];
+    tc += s_w[16 + w];
+  }
+  for (uint32_t i = i0; i < i1; i++)
+    node_parts(i, [&](uint32_t s, uint32_t xa, uint32_t xb, uint32_t mt, uint32_t sm, uint32_t cm, uint32_t c, uint32_t first) {
+      a.desc[bp] = WalkDesc{s, xa, xb, mt | (a.maxtrav << 8) | (sm << 16) | (cm << 18), bc, c, first, 0u};
+      a.parts[bp] = make_uint2(bc, c);
+      a.part_node[bp] = i;
+      bp++;
+      bc += c;
+    });
+  // the host polls the flag: everything this workgroup wrote to its memory lies in front of it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (tid == 0u) {
+    a.hdr_host[0] = tp;
+    a.hdr_host[1] = tc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(a.hdr_host + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Every thread owns R records (cid n + tid + 1024 j) with their inputs in registers.  Relaxation is monotone -- a record that
+// finds both inputs settled takes its final level whenever it looks -- so the waves need no barrier between passes, only the
+// test whether anything is left does: four passes per test.  A pass costs one LDS round trip: all reads first (a settled
+// record reads word 0, a broadcast), skipped per record slot when the whole wave is through with it.  39 levels at C3: 7 us
+// (21 us when every thread re-read all its records every pass, 22 us with a compacted work list in LDS: five dependent LDS
+// round trips per pass at ~200 cycles each).
+template <int R>
+__global__ __launch_bounds__(1024) void k_sched(const uint2 *__restrict__ kids, uint32_t n, uint32_t n_ops, NvOp *__restrict__ ops,
+                                                int32_t *__restrict__ lev_off, int32_t *__restrict__ n_lev_out, SweepDescArgs sw)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+  __shared__ uint32_t s_flag[3], s_max, s_wsum[32];
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();      // (100 MHz; the durations go out as diagnostics)
+  if (blockIdx.x == 1u) {
+    sweep_desc_block(kids, n, n_ops, sw, s_mem, s_wsum);
+    if (threadIdx.x == 0u) n_lev_out[2] = (int32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
+    return;
+  }
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, ns = n + n_ops;
+  uint16_t *s_lev = reinterpret_cast<uint16_t *>(s_mem);
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (((size_t)ns * 2 + 15) & ~(size_t)15));
+  const uint32_t n_cnt = ns / 3u + 16u;
+  for (uint32_t c = tid; c < n; c += 1024u) s_lev[c] = 0;
+  for (uint32_t l = tid; l < n_cnt; l += 1024u) s_cnt[l] = 0u;
+  if (tid < 3u) s_flag[tid] = 0u;
+  if (tid == 0u) s_max = 0u;
+  uint2 kk[R];
+  uint32_t mylev[R], la[R], lb[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const uint32_t c = n + tid + 1024u * (uint32_t)j;
+    kk[j] = c < ns ? kids[c] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const uint32_t c = n + tid + 1024u * (uint32_t)j;
+    // records between two tips are level 1 at once
+    mylev[j] = c >= ns ? 0u : (kk[j].x < n && kk[j].y < n) ? 1u : 0xFFFFu;
+    if (c < ns) s_lev[c] = (uint16_t)mylev[j];
+    la[j] = kk[j].x < n ? 0u : 0xFFFFu;          // (tips are level 0)
+    lb[j] = kk[j].y < n ? 0u : 0xFFFFu;
+  }
+  __syncthreads();
+  for (uint32_t round = 0; round <= ns; round++) { // (round > ns: a topology array that is not a tree -- leave, those ops stay unwritten)
+    uint32_t left = 0;
+    for (int pass = 0; pass < 4; pass++) {
+      // an input seen settled is not read again (most records wait for ONE deep input): la / lb keep what was read
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const bool wa = mylev[j] == 0xFFFFu && la[j] == 0xFFFFu, wb = mylev[j] == 0xFFFFu && lb[j] == 0xFFFFu;
+        if (__ballot(wa) != 0ull) { const uint32_t v = s_lev[wa ? kk[j].x : 0u]; la[j] = wa ? v : la[j]; }     // (wave-uniform branches;
+        if (__ballot(wb) != 0ull) { const uint32_t v = s_lev[wb ? kk[j].y : 0u]; lb[j] = wb ? v : lb[j]; }     //  settled lanes read word 0: a broadcast)
+      }
+      left = 0;
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const bool open = mylev[j] == 0xFFFFu, ready = la[j] != 0xFFFFu && lb[j] != 0xFFFFu;
+        if (open && ready) {
+          mylev[j] = 1u + (la[j] > lb[j] ? la[j] : lb[j]);
+          s_lev[n + tid + 1024u * (uint32_t)j] = (uint16_t)mylev[j];
+        }
+        left |= (open && !ready) ? 1u : 0u;
+      }
+      if (!__ballot(left != 0u)) break;             // this wave is through
+    }
+    // flags in rotation: round r raises flag r % 3; the one cleared after this barrier was read before it and is raised again
+    // only after the next
+    const uint32_t f = round % 3u;
+    if (left) s_flag[f] = 1u;
+    __syncthreads();
+    const uint32_t any = s_flag[f];
+    if (tid == 0u) s_flag[(f + 2u) % 3u] = 0u;
+    if (!any) break;
+  }
+  // histogram over levels, largest level
+  uint32_t mx = 0;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const uint32_t c = n + tid + 1024u * (uint32_t)j;
+    if (c < ns && mylev[j] != 0xFFFFu) {
+      atomicAdd(&s_cnt[mylev[j]], 1u);
+      mx = mylev[j] > mx ? mylev[j] : mx;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, m, 64); mx = o > mx ? o : mx; }
+  if (lane == 0u) atomicMax(&s_max, mx);
+  __syncthreads();
+  const uint32_t maxlev = s_max;
+  // exclusive prefix over s_cnt[1 .. maxlev]: CH consecutive levels per thread, wave scan, wave sums through LDS
+  const uint32_t CH = (maxlev + 1023u) / 1024u;
+  const uint32_t l0 = 1u + tid * CH;
+  uint32_t loc = 0;
+  for (uint32_t l = l0; l < l0 + CH && l <= maxlev; l++) loc += s_cnt[l];
+  uint32_t inc = loc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if ((int)lane >= d) inc += o; }
+  if (lane == 63u) s_wsum[tid >> 6] = inc;
+  __syncthreads();
+  uint32_t base = inc - loc;
+  for (uint32_t w = 0; w < (tid >> 6); w++) base += s_wsum[w];
+  for (uint32_t l = l0; l < l0 + CH && l <= maxlev; l++) { const uint32_t c = s_cnt[l]; s_cnt[l] = base; base += c; }
+  __syncthreads();
+  // placement: s_cnt[l] runs from the start of level l to its end (= the start of level l + 1)
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const uint32_t c = n + tid + 1024u * (uint32_t)j;
+    if (c < ns && mylev[j] != 0xFFFFu) {
+      const uint32_t pos = atomicAdd(&s_cnt[mylev[j]], 1u);
+      const uint32_t k = c - n, rec = 3u * (n + 1u + k / 3u) + k % 3u;
+      ops[pos] = NvOp{c, kk[j].x, kk[j].y, rec};
+    }
+  }
+  __syncthreads();
+  for (uint32_t l = tid; l <= maxlev; l += 1024u) lev_off[l] = l ? (int32_t)s_cnt[l] : 0;
+  if (tid == 0u) { n_lev_out[0] = (int32_t)maxlev; n_lev_out[1] = (int32_t)(__builtin_amdgcn_s_memrealtime() - t_begin); }
+}
+
+hipError_t launch_sched(hipStream_t st, const uint2 *kids, uint32_t n_taxa, uint32_t n_ops, NvOp *ops, int32_t *lev_off, int32_t *n_lev,
+                        const SweepDescArgs &sw)
+{
+  if (n_taxa + n_ops > kSchedMaxSlots) return hipErrorInvalidValue;
+  if (sw.nodep && (sw.maxtrav < 1u || sw.maxtrav > 6u)) return hipErrorInvalidValue;
+  const size_t lds = sched_lds_bytes(n_taxa, n_taxa + n_ops, sw.nodep != nullptr);
+  const uint32_t per = (n_ops + 1023u) / 1024u;
+#define MPF_SCHED(R_)                                                                                                                   \
+  do {                                                                                                                                  \
+    if (lds > 60 * 1024) {                                                                                                              \
+      static thread_local int attr_dev = -1;                                                                                            \
+      int dev = 0;                                                                                                                      \
+      (void)hipGetDevice(&dev);                                                                                                         \
+      if (attr_dev != dev) {                                                                                                            \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sched<R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (e != hipSuccess) return e;                                                                                                  \
+        attr_dev = dev;                                                                                                                 \
+      }                                                                                                                                 \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((k_sched<R_>), dim3(sw.nodep ? 2 : 1), dim3(1024), lds, st, kids, n_taxa, n_ops, ops, lev_off, n_lev, sw);       \
+  } while (0)
+  if (per <= 1u) MPF_SCHED(1);
+  else if (per <= 2u) MPF_SCHED(2);
+  else if (per <= 3u) MPF_SCHED(3);
+  else if (per <= 4u) MPF_SCHED(4);
+  else if (per <= 6u) MPF_SCHED(6);
+  else if (per <= 8u) MPF_SCHED(8);
+  else MPF_SCHED(16);
+#undef MPF_SCHED
+  return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k_cntsum(const NvOp *__restrict__ ops, int n_ops, const uint32_t *__restrict__ cntp, uint32_t nslots,
@@ -1161,8 +1432,11 @@ constexpr int kProgStride = 64;                  // entries per (scan part, gap 
 enum { PE_T1 = 16, PE_T2 = 32, PE_SAVE = 64, PE_PEND = 128 };
 
 __global__ __launch_bounds__(256) void k_walk_plan(const uint2 *__restrict__ kids, uint32_t n, const WalkDesc *__restrict__ desc,
-                                                   int n_scans, ProgEnt *__restrict__ prog, uint32_t cid_mask)
+                                                   int n_scans, ProgEnt *__restrict__ prog, uint32_t cid_mask,
+                                                   uint32_t *__restrict__ zero_ptr, uint32_t zero_words)
 {
+  // (the outputs of the scan that follows on the stream, cleared here: one memset dispatch less in front of it)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero_ptr[i] = 0u;
   const int lane = threadIdx.x & 63;
   int item = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   item = __builtin_amdgcn_readfirstlane(item);
@@ -1969,7 +2243,8 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
   return hipGetLastError();
 }
 
-hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const WalkDesc *desc, int n_scans, void *prog)
+hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const WalkDesc *desc, int n_scans, void *prog,
+                            uint32_t *zero_ptr, uint32_t zero_words)
 {
   if (n_scans <= 0) return hipSuccess;
   const long waves = 2L * n_scans;
@@ -1981,7 +2256,7 @@ hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const
   const uint32_t cid_mask = 0xFFFFFFFFu;
 #endif
   hipLaunchKernelGGL(k_walk_plan, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, kids, (uint32_t)n_taxa, desc, n_scans,
-                     static_cast<ProgEnt *>(prog), cid_mask);
+                     static_cast<ProgEnt *>(prog), cid_mask, zero_ptr, zero_words);
   return hipGetLastError();
 }
 

@@ -63,7 +63,24 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
 // chores a refresh launch does for the scan launch behind it on the stream: kids[kid_upd[3i]] = (kid_upd[3i+1], kid_upd[3i+2])
 // (chained kernel only) and zero_ptr[0..zero_words) = 0
 struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint2 *kids = nullptr; uint32_t *zero_ptr = nullptr; uint32_t zero_words = 0;
-                      uint32_t *cnt_host = nullptr; /* pinned host mirror of cnt[]: written by the in-kernel fold */ };
+                      uint32_t *cnt_host = nullptr; /* pinned host mirror of cnt[]: written by the in-kernel fold */
+                      const int32_t *n_lev_ptr = nullptr; /* the schedule was made on the device (launch_sched): level count read from here */ };
+// Refresh schedule of a COMPLETE tree made on the device from the topology array alone (kids[cid], cids n .. n + n_ops - 1 are
+// the inner records): ops in level order, lev_off[0 .. n_lev] as launch_newview_levels reads them, *n_lev.  One workgroup;
+// trees of up to kSchedMaxSlots vectors.  Order inside a level is not defined (ops of a level are independent).
+constexpr uint32_t kSchedMaxSlots = 16384;
+// ... and, by a second workgroup of the same launch, the scan descriptors of a whole sweep (what Engine::plan_walk lays out on the
+// host: per prune node the parts of its two neighbourhoods, their candidate counts N(q, maxtrav) and output offsets), radius <= 6
+struct SweepDescArgs {
+  const uint32_t *nodep = nullptr;   // cid of every prune record in sweep order; nullptr: no descriptors wanted
+  uint32_t n_prune = 0, maxtrav = 0, split_cands = 0;
+  WalkDesc *desc = nullptr;          // out: one per scan part, as launch_walk_plan / launch_scan_prog read them
+  uint2 *parts = nullptr;            // out: (output offset, candidates) per part, for launch_part_min
+  uint32_t *part_node = nullptr;     // out, pinned host memory: index of the prune node behind every part
+  uint32_t *hdr_host = nullptr;      // out, pinned host memory: {parts, candidates, 0, flag raised behind everything}
+};
+hipError_t launch_sched(hipStream_t st, const uint2 *kids, uint32_t n_taxa, uint32_t n_ops, NvOp *ops, int32_t *lev_off, int32_t *n_lev,
+                        const SweepDescArgs &sw = SweepDescArgs());
 // every level in ONE launch (one 16-wave workgroup per tile, workgroup barrier between levels)
 // Fitch mode also folds the per-tile counts into cnt[dst] (last workgroup; `done` = a zeroed device word, left zeroed);
 // weighted mode leaves that to launch_cntsum
@@ -101,7 +118,8 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 // planned-program scan (radius <= 6, DNA): launch_walk_plan turns the descriptors into one DFS program per (scan part, gap end)
 // -- WalkDesc::pad1 must hold the number of candidates behind the FIRST gap end (xa) of the part --, launch_scan_prog runs
 // them with the children's vectors requested one expansion ahead.  Same outputs as launch_scan_walk.
-hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const WalkDesc *desc, int n_scans, void *prog);
+hipError_t launch_walk_plan(hipStream_t st, const uint2 *kids, int n_taxa, const WalkDesc *desc, int n_scans, void *prog,
+                            uint32_t *zero_ptr = nullptr, uint32_t zero_words = 0);   // zero_ptr: cleared by the same launch (the scan's outputs)
 size_t scan_prog_bytes(int n_scans);
 bool scan_prog_supported(const Geometry &g, int max_depth);
 hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *vec, const WalkDesc *desc, int n_scans,
