@@ -632,10 +632,12 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   if (n_prune) {
     uint32_t *np = reinterpret_cast<uint32_t *>(h_vstage_.p + nodep_off);
     for (size_t i = 0; i < n_prune; i++) np[i] = slot(nodep_[i + 1]);
-    const size_t cap = 8 * n_prune;              // a prune node has two neighbourhoods of at most four parts
+    const size_t cap = 8 * n_prune;              // a prune node has two neighbourhoods of at most four parts ...
     HIPCHK(d_walk_.reserve(cap));
     HIPCHK(d_parts_.reserve(cap));
     HIPCHK(h_dsw_.reserve(4 + cap));
+    HIPCHK(d_prog_.reserve(scan_prog_bytes((int)cap)));
+    HIPCHK(reserve_results(cap * 63));           // ... of at most 2^6 - 1 insertion tests each (everything the launches below touch is in place now)
     sw.nodep = reinterpret_cast<const uint32_t *>(src + nodep_off);
     sw.n_prune = (uint32_t)n_prune;
     sw.maxtrav = (uint32_t)sweep_maxtrav;
@@ -644,7 +646,9 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
     sw.parts = d_parts_.p;
     sw.hdr_host = h_dsw_.p;
     sw.part_node = h_dsw_.p + 4;
+    sw.hdr_dev = reinterpret_cast<uint32_t *>(src + nlev_off) + 8;
     __atomic_store_n(h_dsw_.p + 3, 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(h_dsw_.p + 2, 0u, __ATOMIC_RELAXED);
     walk_gen_++;                                 // whatever descriptors, program and part table were on the device are gone
     n_walk_ = 0;
     walk_out_ = 0;
@@ -667,6 +671,18 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   HIPCHK(launch_sched(st_, reinterpret_cast<const uint2 *>(src), (uint32_t)n_, (uint32_t)nops, dops, dlo, dnl, sw));
   RefreshExtra x;
   x.n_lev_ptr = dnl;
+  if (n_prune && plan_ride_) {
+    // the walk plan of the sweep rides on the refresh launch (extra workgroups on the CUs the refresh leaves idle): no dispatch
+    // of its own between refresh and scan.  (The fold of the refresh's mutation counts does NOT ride on the scan launch: its
+    // 588 000 strided 4-byte reads beside the scan's first waves made the scan 60 us longer -- measured, dropped.)
+    x.wp_kids = reinterpret_cast<const uint2 *>(src);
+    x.wp_n = (uint32_t)n_;
+    x.wp_desc = d_walk_.p;
+    x.wp_hdr = sw.hdr_dev;
+    x.wp_prog = d_prog_.p;
+    x.wp_out = d_out();
+    x.wp_max_parts = (uint32_t)(8 * n_prune);
+  }
   HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, 1, d_cntp_.p, (uint32_t)nslots_, d_cnt(), nullptr, x));
   stats.view_launches++;
   HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), tiles_for_levels(g_)));
@@ -1737,14 +1753,13 @@ int Engine::sweep_scan_dev(int mt, uint64_t *n_tests, uint32_t *min_mp)
   if (nd > 0) {
     HIPCHK(d_ncand_.reserve(nd));
     HIPCHK(reserve_results(nout));
-    HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));
+    HIPCHK(d_prog_.reserve(scan_prog_bytes((int)nd)));      // (cold: all of these are in place already, schedule_views_dev saw to it)
     HIPCHK(h_pmin_.reserve(nd + 1));
     if (warm) HIPCHK(hipMemsetAsync(d_out(), 0, clear_words(nout) * sizeof(uint32_t), st_));
     if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
     if (!warm) {
-      if (timing_) HIPCHK(hipEventRecord(ev4_, st_));
-      HIPCHK(launch_walk_plan(st_, d_kids(), n_, d_walk_.p, (int)nd, d_prog_.p, d_out(), (uint32_t)clear_words(nout)));
-      if (timing_) { HIPCHK(hipEventRecord(ev0_, st_)); plan_event_pending_ = true; }
+      // (the program was planned and the outputs were cleared by the refresh launch's extra workgroups)
+      if (!plan_ride_) HIPCHK(launch_walk_plan(st_, d_kids(), n_, d_walk_.p, (int)nd, d_prog_.p, d_out(), (uint32_t)clear_words(nout)));
       prog_gen_ = walk_gen_;
       parts_gen_ = walk_gen_;
       n_parts_dev_ = nd;
@@ -1926,7 +1941,7 @@ int Engine::set_option(const std::string &key, int64_t v)
     return MPF_OK;
   }
   if (key == "dev_sched") { dev_sched_ = v != 0; sched_cache_valid_ = false; dsw_valid_ = false; return MPF_OK; }
-  if (key == "dev_plan") { dev_plan_ = v != 0; dsw_valid_ = false; return MPF_OK; }               // scan descriptors of mpf_sweep_scan laid out on the device   // refresh schedule of a new topology made on the device (k_sched)
+  if (key == "dev_plan") { dev_plan_ = v != 0; plan_ride_ = !(v & 2); dsw_valid_ = false; return MPF_OK; }   // (bit 1: the walk plan as a launch of its own)               // scan descriptors of mpf_sweep_scan laid out on the device   // refresh schedule of a new topology made on the device (k_sched)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }

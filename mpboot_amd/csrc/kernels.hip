@@ -447,6 +447,11 @@ __global__ __launch_bounds__(1024) void k_newview_wgh(uint32_t *__restrict__ vec
 // C3: 49, 98, 196 of them on 256 CUs) with no barrier between them -- a tile of sites never needs another tile's vectors.
 // The early request matters because gfx950 retires loads and stores through ONE in-order counter: a wave that asks for its
 // next operands only after its stores cannot see them before the stores are acknowledged.
+// (defined with k_walk_plan below) one wave = one (scan part, gap end) item of the walk plan
+struct ProgEnt;
+__device__ void walk_plan_item(const uint2 *__restrict__ kids, uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
+                               ProgEnt *__restrict__ prog, uint32_t cid_mask, int item, int lane);
+
 template <int S, int TW>
 __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
                                                       const int32_t *__restrict__ lev_off, int n_lev,
@@ -458,14 +463,24 @@ __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = (int)(blockDim.x >> 6);
+  const int nt = Wp / TW;                          // the refresh's own workgroups; any further ones plan the scan that follows
+  if ((int)blockIdx.x >= nt) {
+    const uint32_t n_parts = x.wp_hdr[0], n_out = x.wp_hdr[1];
+    const uint32_t xb = blockIdx.x - (uint32_t)nt, nxb = gridDim.x - (uint32_t)nt;
+    const uint32_t zw = ((n_out ? n_out : 1u) + 1u + 63u) & ~63u;      // (Engine::clear_words)
+    for (uint32_t i = xb * blockDim.x + threadIdx.x; i < zw; i += nxb * blockDim.x) x.wp_out[i] = 0u;
+    for (uint32_t item = xb * (uint32_t)nw + (uint32_t)wave; item < 2u * n_parts; item += nxb * (uint32_t)nw)
+      walk_plan_item(x.wp_kids, x.wp_n, x.wp_desc, (int)n_parts, static_cast<ProgEnt *>(x.wp_prog), 0xFFFFFFFFu, (int)item, lane);
+    return;
+  }
   // workgroups go round the 8 XCDs: each XCD gets a contiguous run of tiles, so that the 64-byte segments of neighbouring
   // tiles -- two halves of one 128-byte line -- meet in ONE L2 instead of being fetched into two
-  const int nt = (int)gridDim.x, xcd = (int)(blockIdx.x & 7u), q8 = nt >> 3, r8 = nt & 7;
+  const int xcd = (int)(blockIdx.x & 7u), q8 = nt >> 3, r8 = nt & 7;
   const int tile = xcd * q8 + min(xcd, r8) + (int)(blockIdx.x >> 3);
   const int sub = lane / TW;
   const int w0 = tile * TW + (lane % TW);          // Wp is a multiple of 32: always inside the row
   const int step = OPI * nw;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x.zero_words; i += gridDim.x * blockDim.x) x.zero_ptr[i] = 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x.zero_words; i += (uint32_t)nt * blockDim.x) x.zero_ptr[i] = 0u;
   if (x.n_lev_ptr) n_lev = *x.n_lev_ptr;         // (schedule made by k_sched in front of this launch)
   for (int l = 0; l < n_lev; l++) {
     const int b = lev_off[l], e = lev_off[l + 1];
@@ -496,12 +511,12 @@ __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const uint32_t ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = ticket == gridDim.x - 1;
+    s_last = ticket == (uint32_t)nt - 1u;
   }
   __syncthreads();
   if (s_last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    fold_counts(ops, lev_off[n_lev], cntp, nslots, (int)gridDim.x, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
+    fold_counts(ops, lev_off[n_lev], cntp, nslots, nt, cnt, (int)threadIdx.x, (int)blockDim.x, x.cnt_host);
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -714,6 +729,7 @@ __device__ void sweep_desc_block(const uint2 *__restrict__ kids_g, uint32_t n, u
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
   if (tid == 0u) {
+    if (a.hdr_dev) { a.hdr_dev[0] = tp; a.hdr_dev[1] = tc; }
     a.hdr_host[0] = tp;
     a.hdr_host[1] = tc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -1431,14 +1447,9 @@ struct ProgEnt { uint32_t c1, c2, meta, k; };   // root entry (index 0): c1 = ci
 constexpr int kProgStride = 64;                  // entries per (scan part, gap end): root + at most 63 expansions (radius <= 6)
 enum { PE_T1 = 16, PE_T2 = 32, PE_SAVE = 64, PE_PEND = 128 };
 
-__global__ __launch_bounds__(256) void k_walk_plan(const uint2 *__restrict__ kids, uint32_t n, const WalkDesc *__restrict__ desc,
-                                                   int n_scans, ProgEnt *__restrict__ prog, uint32_t cid_mask,
-                                                   uint32_t *__restrict__ zero_ptr, uint32_t zero_words)
+__device__ void walk_plan_item(const uint2 *__restrict__ kids, uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
+                               ProgEnt *__restrict__ prog, uint32_t cid_mask, int item, int lane)
 {
-  // (the outputs of the scan that follows on the stream, cleared here: one memset dispatch less in front of it)
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero_ptr[i] = 0u;
-  const int lane = threadIdx.x & 63;
-  int item = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   item = __builtin_amdgcn_readfirstlane(item);
   if (item >= 2 * n_scans) return;
   const int scan = item >> 1, side = item & 1;
@@ -1503,6 +1514,15 @@ __global__ __launch_bounds__(256) void k_walk_plan(const uint2 *__restrict__ kid
   }
 }
 
+__global__ __launch_bounds__(256) void k_walk_plan(const uint2 *__restrict__ kids, uint32_t n, const WalkDesc *__restrict__ desc,
+                                                   int n_scans, ProgEnt *__restrict__ prog, uint32_t cid_mask,
+                                                   uint32_t *__restrict__ zero_ptr, uint32_t zero_words)
+{
+  // (the outputs of the scan that follows on the stream, cleared here: one memset dispatch less in front of it)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero_ptr[i] = 0u;
+  walk_plan_item(kids, n, desc, n_scans, prog, cid_mask, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), (int)(threadIdx.x & 63));
+}
+
 // acc[lane] = val for ONE lane (v_writelane_b32: value and lane select are wave-uniform scalars).  This clang has no builtin
 // for it, so the LLVM intrinsic is declared directly (the way hip/amd_detail declares ds_bpermute); the compiler then moves
 // the lane select through M0 itself (gfx9 allows one scalar register per VALU instruction) and tracks the hazards.
@@ -1541,6 +1561,7 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
                                                          uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done,
                                                          unsigned long long *__restrict__ trace)
 {
+  const unsigned bid = blockIdx.x;
   // up-vectors of second children that wait for their turn, depths 2..5 (depth 1 stays in registers): a lane reads back
   // what it wrote, no synchronisation.
   // ONE wave per workgroup: scans differ in length by two orders of magnitude (2 .. 250 insertion tests), and a
@@ -1549,14 +1570,14 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
   const int lane = threadIdx.x;
   int scan = -1, tile = 0;
   if (map == 0) {
-    const int gw = (int)blockIdx.x;
+    const int gw = (int)bid;
     if (gw < n_scans * tiles) { scan = gw / tiles; tile = gw - scan * tiles; }
   } else {
     // XCD-aware, as k_scan_walk: the (tile, scan) items, tile-major, in 8 contiguous chunks, one per blockIdx % 8 class
     const long total = (long)n_scans * tiles;
     const long chunk = (total + 7) / 8;
-    const int cls = blockIdx.x & 7;
-    const long idx = (long)(blockIdx.x >> 3);
+    const int cls = bid & 7;
+    const long idx = (long)(bid >> 3);
     const long item = (long)cls * chunk + idx;
     if (idx < chunk && item < total) { tile = (int)(item / n_scans); scan = (int)(item - (long)tile * n_scans); }
   }
@@ -1681,7 +1702,7 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
       if (lane == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11));
-        unsigned long long *t = trace + (size_t)blockIdx.x * 4;
+        unsigned long long *t = trace + (size_t)bid * 4;
         t[0] = t_begin;
         t[1] = t_end;
         t[2] = ((unsigned long long)xcc << 32) | hw;
@@ -2074,7 +2095,9 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
   }
   if (g.vw == 1 && g.nv_pipe) {                    // TW lanes per op on TW-word tiles, operands requested a round ahead
     const int tw = newview_tile(g);
-    dim3 qgrid((unsigned)(g.Wp / tw));
+    // (a device-planned sweep: one extra 16-wave workgroup per 64 possible walk-plan items, at most as many as fit beside the refresh)
+    const unsigned extra = x.wp_desc ? std::min(512u, (2u * x.wp_max_parts + 63u) / 64u) : 0u;
+    dim3 qgrid((unsigned)(g.Wp / tw) + extra);
 #define NQ(S_, TW_) hipLaunchKernelGGL((k_newview_wgq<S_, TW_>), qgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
     if (g.S == 4) { if (tw == 32) NQ(4, 32); else if (tw == 16) NQ(4, 16); else if (tw == 8) NQ(4, 8); else NQ(4, 4); }
     else { if (tw == 32) NQ(20, 32); else if (tw == 16) NQ(20, 16); else if (tw == 8) NQ(20, 8); else NQ(20, 4); }

@@ -64,7 +64,12 @@ hipError_t launch_newview(hipStream_t st, const Geometry &g, uint32_t *vec, cons
 // (chained kernel only) and zero_ptr[0..zero_words) = 0
 struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint2 *kids = nullptr; uint32_t *zero_ptr = nullptr; uint32_t zero_words = 0;
                       uint32_t *cnt_host = nullptr; /* pinned host mirror of cnt[]: written by the in-kernel fold */
-                      const int32_t *n_lev_ptr = nullptr; /* the schedule was made on the device (launch_sched): level count read from here */ };
+                      const int32_t *n_lev_ptr = nullptr; /* the schedule was made on the device (launch_sched): level count read from here */
+                      // a device-planned sweep (launch_sched's descriptors): the DFS programs of its scan parts are written by EXTRA
+                      // workgroups of the refresh launch (launch_newview_levels adds them; they also clear the scan's outputs), on CUs
+                      // the refresh leaves idle -- no plan kernel on the critical path
+                      const uint2 *wp_kids = nullptr; uint32_t wp_n = 0; const WalkDesc *wp_desc = nullptr; const uint32_t *wp_hdr = nullptr /* {parts, candidates} */;
+                      void *wp_prog = nullptr; uint32_t *wp_out = nullptr; uint32_t wp_max_parts = 0; };
 // Refresh schedule of a COMPLETE tree made on the device from the topology array alone (kids[cid], cids n .. n + n_ops - 1 are
 // the inner records): ops in level order, lev_off[0 .. n_lev] as launch_newview_levels reads them, *n_lev.  One workgroup;
 // trees of up to kSchedMaxSlots vectors.  Order inside a level is not defined (ops of a level are independent).
@@ -78,6 +83,7 @@ struct SweepDescArgs {
   uint2 *parts = nullptr;            // out: (output offset, candidates) per part, for launch_part_min
   uint32_t *part_node = nullptr;     // out, pinned host memory: index of the prune node behind every part
   uint32_t *hdr_host = nullptr;      // out, pinned host memory: {parts, candidates, 0, flag raised behind everything}
+  uint32_t *hdr_dev = nullptr;       // out, device memory: {parts, candidates} for the kernels that follow
 };
 hipError_t launch_sched(hipStream_t st, const uint2 *kids, uint32_t n_taxa, uint32_t n_ops, NvOp *ops, int32_t *lev_off, int32_t *n_lev,
                         const SweepDescArgs &sw = SweepDescArgs());
