@@ -526,6 +526,7 @@ def main():
         tests += k
     barrier()
     dt = time.perf_counter() - t0
+    sched_us = (eng.get_option("sched_ticks") / 100.0, eng.get_option("sched_desc_ticks") / 100.0, eng.get_option("sched_levels"))
     st = eng.stats()
     eng.set_option("plan_cache", 1)
     wsteps = max(1, min(20, args.steps))
@@ -603,9 +604,10 @@ def main():
             "config": {"workload": f"{args.workload}: {n} taxa x {P} {alphabet} patterns, SPR radius {args.maxtrav}, "
                                    "one full sweep scan per step (all prune nodes, both sides)",
                        "evals_per_step": tests_all / args.steps / world, "evals_per_s": evals_per_s,
-                       "planning": "every step plans from scratch (refresh schedule, scan descriptors, device program: engine option "
-                                   "plan_cache = 0), recomputes every vector and re-scores every insertion test -- the step of a search that has "
-                                   "just accepted a move.  ms_per_step_same_topology = the same step on a topology the engine has planned "
+                       "planning": "every step plans from scratch (engine option plan_cache = 0): the host uploads the topology array, the "
+                                   "device makes the refresh schedule, the scan descriptors and the DFS programs (k_sched; the walk plan rides on "
+                                   "the refresh launch), recomputes every vector and re-scores every insertion test -- the step of a search that "
+                                   "has just accepted a move.  ms_per_step_same_topology = the same step on a topology the engine has planned "
                                    "before (a re-weighted or re-evaluated tree)",
                        "start_tree_score": start_score, "parallelism": f"independent start trees x{world}",
                        # the three rates side by side.  value = effective (n x P x evals/s, as defined);
@@ -635,6 +637,11 @@ def main():
                                  "traffic_source; a committed figure is quoted only while the sources match the profiled build).  survey_6vector_GBps is SURVEY 8(d)'s 6-vectors-per-test figure / kernel time: a "
                                  "labelled side number, not a fraction of anything the kernel moves"},
             "views": {"newview_ops": st["newview_ops"] / args.steps, "kernel_ms_per_step": view_ms,
+                      "schedule_kernel": {"kernel": "k_sched", "schedule_workgroup_us": sched_us[0], "descriptor_workgroup_us": sched_us[1],
+                                          "dependency_levels": sched_us[2],
+                                          "what": "one launch in front of the refresh of a NEW topology: refresh schedule (levels, ops in level "
+                                                  "order) and the sweep's scan descriptors from the topology array, one workgroup each; durations "
+                                                  "measured in the kernel (s_memrealtime)"},
                       "launches_per_step": st["view_launches"] / args.steps,
                       # refresh of every directional vector: 2 vector reads + 1 write per op, HBM-bound by nature
                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -964,6 +971,9 @@ def main():
                      "scan_kernel_ms": scan5, "view_kernel_ms_per_step": st5["view_kernel_ms_total"] / 5,
                      "roofline": {"bound": "valu", "achieved": ach5, "peak": 2.0 * VALU_PEAK_TOPS, "unit": "T packed-u16 op/s",
                                   "frac": ach5 / (2.0 * VALU_PEAK_TOPS), "kernel": "k_snk_scan",
+                                  # v_pk_add_u16 / v_pk_min_u16 issue once per 1.76 ns per SIMD (tools/ubench/valu_rate, profiles/r3/valu_rate.txt)
+                                  "measured_issue_ceiling": 1024 * 128 / 1.76e-9 / 1e12,
+                                  "frac_of_measured_issue_ceiling": ach5 / (1024 * 128 / 1.76e-9 / 1e12),
                                   "note": "min-plus arithmetic on packed 16-bit costs (v_pk_add_u16 / v_pk_min_u16: two patterns per lane); "
                                           "achieved = insertion tests x patterns x (2 S^2 + 3 S) / HIP-event time of the scan kernel; peak = "
                                           "256 CUs x 4 SIMD-32 x 2.4 GHz x 2 values per lane"}}

@@ -667,8 +667,8 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   zeroed_words_ = 0;
   for (int i = 0; i < 2; i++) ride_[i].dev = nullptr;
   cnt_on_host_ = false;
-  if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));
   HIPCHK(launch_sched(st_, reinterpret_cast<const uint2 *>(src), (uint32_t)n_, (uint32_t)nops, dops, dlo, dnl, sw));
+  if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));   // (view kernel time = the refresh proper; k_sched reports its own: option sched_ticks)
   RefreshExtra x;
   x.n_lev_ptr = dnl;
   if (n_prune && plan_ride_) {
@@ -715,12 +715,13 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   sched_cache_valid_ = (plan_cache_ & 2) != 0;
   sched_gen_++;
   if (n_prune) dsw_sched_gen_ = sched_gen_;       // the sweep descriptors belong to this schedule's topology
+  sc_nlev_off_ = nlev_off;                         // (also where the diagnostics of the last k_sched launch are read from)
+  sched_on_dev_ = true;
   if (sched_cache_valid_) {
     sc_nops_ = nops;
     sc_maxlev_ = -1;
     sc_ops_off_ = ops_off;
     sc_lev_off_b_ = lev_off_b;
-    sc_nlev_off_ = nlev_off;
     sc_order_ = upd_order_;
   }
   stats.newview_ops += nops;
@@ -1022,6 +1023,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     // on the level kernel with the per-tile counts folded by the separate launch (the shape the fast path above replays)
     sched_cache_valid_ = (plan_cache_ & 2) && from_scratch && full && !chains && views_mode_ >= 1 && !fold_inside && !sankoff_ && !can_ride_used;
     sched_gen_++;
+    sched_on_dev_ = false;                         // (d_vstage_ was rewritten by the host's schedule)
     if (sched_cache_valid_) {
       sc_nops_ = nops;
       sc_maxlev_ = maxlev;
@@ -2020,7 +2022,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "sched_levels" || key == "sched_ticks" || key == "sched_desc_ticks") {
     // diagnostics of the last device-made schedule: dependency levels, duration of k_sched's two workgroups (10 ns ticks)
     int32_t w[16] = {0};
-    if (sc_maxlev_ < 0 && sched_cache_valid_ && d_vstage_.p) { (void)hipStreamSynchronize(st_); (void)hipMemcpy(w, d_vstage_.p + sc_nlev_off_, 64, hipMemcpyDeviceToHost); }
+    if (sched_on_dev_ && d_vstage_.p) { (void)hipStreamSynchronize(st_); (void)hipMemcpy(w, d_vstage_.p + sc_nlev_off_, 64, hipMemcpyDeviceToHost); }
     *v = w[key == "sched_levels" ? 0 : key == "sched_ticks" ? 1 : 2];
   }
   else if (key == "split_below") *v = split_below_;

@@ -31,6 +31,18 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, unsigned long long *cyc
       REP16(asm volatile("v_bitop3_b32 v40, v44, v49, v40 bitop3:0xea\n v_bitop3_b32 v41, v45, v50, v41 bitop3:0xea\n v_bitop3_b32 v42, v46, v51, v42 bitop3:0xea\n v_bitop3_b32 v43, v47, v48, v43 bitop3:0xea" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51");)
     } else if constexpr (KIND == 8) { // bitop3 with all three sources in the same bank (v40, v44, v48)
       REP16(asm volatile("v_bitop3_b32 v40, v44, v48, v40 bitop3:0xea\n v_bitop3_b32 v41, v45, v49, v41 bitop3:0xea\n v_bitop3_b32 v42, v46, v50, v42 bitop3:0xea\n v_bitop3_b32 v43, v47, v51, v43 bitop3:0xea" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51");)
+    } else if constexpr (KIND == 9) { // v_pk_add_u16, VGPR sources (the weighted engine's min-plus arithmetic)
+      REP16(asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %5\n v_pk_add_u16 %2, %2, %6\n v_pk_add_u16 %3, %3, %7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));)
+    } else if constexpr (KIND == 10) { // v_pk_min_u16
+      REP16(asm volatile("v_pk_min_u16 %0, %0, %4\n v_pk_min_u16 %1, %1, %5\n v_pk_min_u16 %2, %2, %6\n v_pk_min_u16 %3, %3, %7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));)
+    } else if constexpr (KIND == 11) { // v_pk_add_u16 with a scalar source (a cost from the scalar cache)
+      REP16(asm volatile("v_pk_add_u16 %0, %4, s20\n v_pk_add_u16 %1, %5, s21\n v_pk_add_u16 %2, %6, s22\n v_pk_add_u16 %3, %7, s23" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23");)
+    } else if constexpr (KIND == 12) { // the pair as the kernel issues it: t = a + cost (scalar); m = min(m, t)
+      REP16(asm volatile("v_pk_add_u16 %4, %8, s20\n v_pk_min_u16 %0, %0, %4\n v_pk_add_u16 %5, %9, s21\n v_pk_min_u16 %1, %1, %5\n v_pk_add_u16 %6, %10, s22\n v_pk_min_u16 %2, %2, %6\n v_pk_add_u16 %7, %11, s23\n v_pk_min_u16 %3, %3, %7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23");)
+    } else if constexpr (KIND == 13) { // 32-bit: v_add_u32 + v_min_u32
+      REP16(asm volatile("v_add_u32 %4, %8, s20\n v_min_u32 %0, %0, %4\n v_add_u32 %5, %9, s21\n v_min_u32 %1, %1, %5\n v_add_u32 %6, %10, s22\n v_min_u32 %2, %2, %6\n v_add_u32 %7, %11, s23\n v_min_u32 %3, %3, %7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23");)
+    } else if constexpr (KIND == 14) { // v_min3_u32
+      REP16(asm volatile("v_min3_u32 %0, %0, %4, %8\n v_min3_u32 %1, %1, %5, %9\n v_min3_u32 %2, %2, %6, %10\n v_min3_u32 %3, %3, %7, %11" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));)
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -57,7 +69,7 @@ void run(const char *name)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (hipGetLastError() != hipSuccess) printf(" [launch error]");
     // instructions per SIMD = wps waves * iters * 64; at 4 cycles each and f GHz ...
-    const double instr_per_simd = (double)wps * iters * 64.0;
+    const double instr_per_simd = (double)wps * iters * 64.0 * ((KIND == 12 || KIND == 13) ? 2.0 : 1.0);
     printf("  %dw: %.2f ns/instr/SIMD", wps, ms * 1e6 / instr_per_simd);
   }
   printf("\n");
@@ -75,6 +87,12 @@ int main()
   run<6>("v_or3_b32 3 VGPR srcs");
   run<7>("v_bitop3_b32 srcs in 3 different banks");
   run<8>("v_bitop3_b32 srcs in the same bank");
+  run<9>("v_pk_add_u16 VGPR srcs");
+  run<10>("v_pk_min_u16 VGPR srcs");
+  run<11>("v_pk_add_u16 VGPR + SGPR src");
+  run<12>("v_pk_add_u16 (SGPR) + v_pk_min_u16 pairs (per instr)");
+  run<13>("v_add_u32 (SGPR) + v_min_u32 pairs (per instr)");
+  run<14>("v_min3_u32 3 VGPR srcs");
   printf("(4 cycles at 2.4 GHz = 1.67 ns)\n");
   return 0;
 }
