@@ -66,8 +66,8 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   if (const char *vt = std::getenv("MPF_VIEWS_TILE")) { const int t = std::atoi(vt); if (t == 32 || t == 16 || t == 8 || t == 4 || t == 0) g_.nv_tile = t; }
   if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
   // Engines on several host threads share a device through their own streams; the runtime maps streams onto 4 hardware queues
-  // per process by default, and a persistent k_climb launch holds its queue for a whole sweep (8 climbs side by side: 6 climbs/s
-  // on 4 queues, 14 on 16: profiles/r3/concurrent_climbs.txt).  Only takes effect if the HIP runtime of this process has not
+  // per process by default, and a persistent k_climb launch holds its queue for a whole sweep (8 climbs side by side: 8.7 climbs/s
+  // on 4 queues, 19.8 on 16: profiles/r3/concurrent_climbs.txt).  Only takes effect if the HIP runtime of this process has not
   // started yet and the variable is not set by the user.
   setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int ndev = 0;
@@ -280,8 +280,11 @@ int Engine::pack()
     vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
     // below 2 GiB the scan kernel addresses the whole store through one raw buffer (32-bit offsets); above, 64-bit bases
     g_.big = (force_big_ || vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) ? 1 : 0;
-    HIPCHK(hipMalloc((void **)&d_vec_, vec_words_ * sizeof(uint32_t)));
+    // DNA below 2 GiB: room for the word-major copy the planned scan reads (Geometry::shoff)
+    g_.shoff = (g_.S == 4 && vec_words_ * sizeof(uint32_t) < ((size_t)1 << 31)) ? vec_words_ : 0;
+    HIPCHK(hipMalloc((void **)&d_vec_, (vec_words_ + (g_.shoff ? vec_words_ : 0)) * sizeof(uint32_t)));
   }
+  shadow_ok_ = false;                          // (the tips' copies are rewritten below; the inner vectors' with the next full refresh)
   std::vector<int32_t> s2p((size_t)std::max(nsites_, 1));
   for (int s = 0; s < P_; s++)
     if (inf_[s])
@@ -708,6 +711,7 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   for (size_t i = all.size(); i-- > 0;) upd_order_[at++] = all[i];
   for (int u : all) { upd_order_[at++] = nx(u); upd_order_[at++] = nx(nx(u)); }
   for (int r : upd_order_) valid_[r] = 1;
+  shadow_ok_ = g_.shoff != 0;                      // (dev_sched_usable: the refresh was k_newview_wgq's)
   all_invalid_ = false;
   n_invalid_ = 0;
   views_valid_ = true;
@@ -754,6 +758,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), tiles_for_levels(g_)));
     if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
     cnt_copy_pending_ = true;
+    shadow_ok_ = g_.shoff != 0 && g_.vw == 1 && g_.nv_pipe;      // (every vector of the tree rewritten by k_newview_wgq, both layouts)
     upd_order_ = sc_order_;
     for (int r : upd_order_) valid_[r] = 1;
     all_invalid_ = false;
@@ -1004,6 +1009,13 @@ int Engine::schedule_views(const std::vector<int> *roots)
                          (views_mode_ >= 1 && !chains) ? tiles_for_levels(g_) : 0));   // rows of cntp the refresh kernel wrote
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
+  {
+    // the word-major copy follows only k_newview_wgq: any other refresh kernel leaves it behind, a full from-scratch pass
+    // of that kernel makes it whole again, a partial one keeps it as it was
+    const bool wgq = !chains && views_mode_ >= 1 && !sankoff_ && g_.vw == 1 && g_.nv_pipe && g_.shoff != 0;
+    if (!wgq) shadow_ok_ = false;
+    else if (from_scratch && full) shadow_ok_ = true;
+  }
   for (int r : order) valid_[r] = 1;
   all_invalid_ = false;
   if (full) { n_invalid_ = 0; views_valid_ = true; }
@@ -1498,7 +1510,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
         trace = d_trace_.p;
       }
       HIPCHK(launch_scan_prog(st_, g_, d_vec_, descs, (int)nd, d_prog_.p, d_out(), d_ncand_.p,
-                              host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8, trace));
+                              host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8, trace, shadow_ok_ && scan_shadow_));
       stats.plan_launches++;
     } else {
       HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr,
@@ -1766,7 +1778,8 @@ int Engine::sweep_scan_dev(int mt, uint64_t *n_tests, uint32_t *min_mp)
       parts_gen_ = walk_gen_;
       n_parts_dev_ = nd;
     }
-    HIPCHK(launch_scan_prog(st_, g_, d_vec_, d_walk_.p, (int)nd, d_prog_.p, d_out(), d_ncand_.p, nullptr, (uint32_t)nout, d_done_.p + 8, nullptr));
+    HIPCHK(launch_scan_prog(st_, g_, d_vec_, d_walk_.p, (int)nd, d_prog_.p, d_out(), d_ncand_.p, nullptr, (uint32_t)nout, d_done_.p + 8, nullptr,
+                            shadow_ok_ && scan_shadow_));
     stats.plan_launches++;
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     __atomic_store_n(h_pmin_.p + nd, 0u, __ATOMIC_RELAXED);
@@ -1944,6 +1957,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   if (key == "dev_sched") { dev_sched_ = v != 0; sched_cache_valid_ = false; dsw_valid_ = false; return MPF_OK; }
   if (key == "dev_plan") { dev_plan_ = v != 0; plan_ride_ = !(v & 2); dsw_valid_ = false; return MPF_OK; }   // (bit 1: the walk plan as a launch of its own)               // scan descriptors of mpf_sweep_scan laid out on the device   // refresh schedule of a new topology made on the device (k_sched)
+  if (key == "scan_shadow") { scan_shadow_ = v != 0; return MPF_OK; }        // planned scan reads the word-major copy when it is current (A/B switch)
   if (key == "reduce") { g_.reduce = v ? 1 : 0; return MPF_OK; }
   if (key == "xcd_map") { g_.map = v ? 1 : 0; return MPF_OK; }
   if (key == "scan_mode") { scan_mode_ = v ? 1 : 0; return MPF_OK; }

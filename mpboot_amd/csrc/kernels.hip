@@ -225,7 +225,7 @@ template <int S>
 __global__ __launch_bounds__(256) void k_pack_tips(uint32_t *__restrict__ vec, const uint8_t *__restrict__ codes,
                                                    int n_taxa, int n_patterns, const int32_t *__restrict__ site2ptn,
                                                    int n_sites, int datatype, const uint32_t *__restrict__ tip_slots,
-                                                   int Wp)
+                                                   int Wp, uint32_t *__restrict__ shadow)
 {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256) void k_pack_tips(uint32_t *__restrict__ vec, c
     uint32_t *dst = vec + (size_t)tip_slots[tip] * (size_t)(S * Wp) + w;
 #pragma unroll
     for (int k = 0; k < S; k++) dst[(size_t)k * Wp] = val[k];
+    if constexpr (S == 4)
+      if (shadow) *reinterpret_cast<uint4 *>(shadow + ((size_t)tip_slots[tip] * (size_t)Wp + (size_t)w) * 4) = make_uint4(val[0], val[1], val[2], val[3]);
   }
 }
 
@@ -501,6 +503,8 @@ __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec
         load_tile<S, 1>(nb, vec, o1.b, Wp, w0);
         const uint32_t k = fitch<S, 1>(tc, ta, tb);
         store_tile<S, 1>(tc, vec, o.dst, Wp, w0);
+        if constexpr (S == 4)
+          if (x.shadow) *reinterpret_cast<uint4 *>(x.shadow + ((size_t)o.dst * (size_t)Wp + (size_t)w0) * 4) = make_uint4(tc.v[0][0], tc.v[1][0], tc.v[2][0], tc.v[3][0]);
         cntp[(size_t)tile * nslots + o.dst] = group_sum<TW>(k);
         ta = na; tb = nb; o = o1; o1 = o2;
       }
@@ -1554,7 +1558,7 @@ struct ProgEnt4 { ProgEnt e[4]; };               // four entries = one 64-byte s
 
 // EXPR (experiments, MPF_PROG_EXPERIMENT): 0 = the kernel; 1 = no vector loads in the loop (children = register garbage:
 // arithmetic + control only); 2 = loads only (one AND per loaded register instead of the Fitch arithmetic)
-template <int S, int VW, bool BIG, int EXPR = 0>
+template <int S, int VW, bool BIG, int EXPR = 0, bool WM = false>
 __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const uint32_t *__restrict__ vec, const WalkDesc *__restrict__ desc, int n_scans,
                                                          const ProgEnt *__restrict__ prog, uint32_t *__restrict__ out,
                                                          uint32_t *__restrict__ ncand, int Wp, int tiles, int map,
@@ -1593,11 +1597,16 @@ __global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const u
     uint32_t voff[S];
 #pragma unroll
     for (int k = 0; k < S; k++) voff[k] = (w0 + (uint32_t)k * (uint32_t)Wp) * 4u;
+    // WM: `vec` is the word-major copy (the four state words of a site word side by side): one 16-byte load per lane and vector
 #define MPF_LOAD(T, cid)                                                                       \
   do {                                                                                         \
-    if constexpr (BIG) load_tile_g<S, VW>(T, vec + (size_t)(cid) * (size_t)SW, voff);            \
+    if constexpr (WM) {                                                                        \
+      const auto x4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, w0 * 16u, (uint32_t)(cid) * SW * 4u, 0); \
+      T.v[0][0] = x4[0]; T.v[1][0] = x4[1]; T.v[2][0] = x4[2]; T.v[3][0] = x4[3];              \
+    } else if constexpr (BIG) load_tile_g<S, VW>(T, vec + (size_t)(cid) * (size_t)SW, voff);   \
     else load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);                          \
   } while (0)
+    static_assert(!WM || (S == 4 && VW == 1 && !BIG), "word-major copy: DNA, one word per lane, below 2 GiB");
     Tile<S, VW> sv, par, pend1, ta1, ta2, tb1, tb2;
     MPF_LOAD(sv, de.s_cid);
     if (!valid) {                                  // lanes past the row end hold s = 0: they never hit ...
@@ -2036,10 +2045,10 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
   dim3 grid((g.Wp + 255) / 256, n_taxa), block(256);          // 4 waves x 64 words per block
   if (g.S == 4)
     hipLaunchKernelGGL(k_pack_tips<4>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
-                       tip_slots, g.Wp);
+                       tip_slots, g.Wp, g.shoff ? vec + g.shoff : nullptr);
   else
     hipLaunchKernelGGL(k_pack_tips<20>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
-                       tip_slots, g.Wp);
+                       tip_slots, g.Wp, nullptr);
   return hipGetLastError();
 }
 
@@ -2094,11 +2103,13 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
     return hipGetLastError();
   }
   if (g.vw == 1 && g.nv_pipe) {                    // TW lanes per op on TW-word tiles, operands requested a round ahead
+    RefreshExtra xs = x;
+    if (g.shoff && g.S == 4) xs.shadow = vec + g.shoff;
     const int tw = newview_tile(g);
     // (a device-planned sweep: one extra 16-wave workgroup per 64 possible walk-plan items, at most as many as fit beside the refresh)
     const unsigned extra = x.wp_desc ? std::min(512u, (2u * x.wp_max_parts + 63u) / 64u) : 0u;
     dim3 qgrid((unsigned)(g.Wp / tw) + extra);
-#define NQ(S_, TW_) hipLaunchKernelGGL((k_newview_wgq<S_, TW_>), qgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
+#define NQ(S_, TW_) hipLaunchKernelGGL((k_newview_wgq<S_, TW_>), qgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, xs)
     if (g.S == 4) { if (tw == 32) NQ(4, 32); else if (tw == 16) NQ(4, 16); else if (tw == 8) NQ(4, 8); else NQ(4, 4); }
     else { if (tw == 32) NQ(20, 32); else if (tw == 16) NQ(20, 16); else if (tw == 8) NQ(20, 8); else NQ(20, 4); }
 #undef NQ
@@ -2349,7 +2360,7 @@ size_t scan_prog_blocks(const Geometry &g, int n_scans)
 
 hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *vec, const WalkDesc *desc, int n_scans,
                             const void *prog, uint32_t *out, uint32_t *ncand, uint32_t *host_out, uint32_t n_out, uint32_t *done,
-                            unsigned long long *trace)
+                            unsigned long long *trace, bool word_major)
 {
   if (n_scans <= 0) return hipSuccess;
   const int vw = g.big ? 1 : g.vw;
@@ -2369,6 +2380,8 @@ hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *v
   else
 #endif
   if (g.big) SP(1, true);
+  else if (vw == 1 && word_major && g.shoff)
+    hipLaunchKernelGGL((k_scan_prog<4, 1, false, 0, true>), grid, block, 0, st, vec + g.shoff, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else if (vw == 1) SP(1, false);
   else SP(2, false);
 #undef SP

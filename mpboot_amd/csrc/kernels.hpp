@@ -44,6 +44,11 @@ struct Geometry {
   int map;      // 0 = scan-major wave mapping, 1 = tiles pinned to XCD classes
   int big = 0;  // the vector store is 2 GiB or more: the scan kernel uses 64-bit addressing instead of one raw buffer
   int nv_pipe = 1;   // level-synchronous refresh, one word per lane: 1 = k_newview_wgq (operands requested a round ahead), 0 = k_newview_wgh
+  // DNA, below 2 GiB: a second copy of every vector in WORD-major order (the four state words of a 32-site word side by side, 16 B)
+  // `shoff` words behind the row-major store.  A CU loads 1 KB of it with ONE buffer_load_dwordx4 per wave at 124-146 GB/s, against
+  // 75 GB/s for the four 256-byte row loads (tools/ubench/l1_rate: the load path inside the CU is what bounds the planned scan).
+  // Written by k_pack_tips and k_newview_wgq, read by k_scan_prog while Engine::shadow_ok_ holds.
+  size_t shoff = 0;
   int nv_tile = 0;   // ... on tiles of 32 | 16 | 8 | 4 words (Wp / tile workgroups); 0 = chosen from Wp (newview_tile)
   // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
   int sankoff = 0;
@@ -69,7 +74,8 @@ struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint
                       // workgroups of the refresh launch (launch_newview_levels adds them; they also clear the scan's outputs), on CUs
                       // the refresh leaves idle -- no plan kernel on the critical path
                       const uint2 *wp_kids = nullptr; uint32_t wp_n = 0; const WalkDesc *wp_desc = nullptr; const uint32_t *wp_hdr = nullptr /* {parts, candidates} */;
-                      void *wp_prog = nullptr; uint32_t *wp_out = nullptr; uint32_t wp_max_parts = 0; };
+                      void *wp_prog = nullptr; uint32_t *wp_out = nullptr; uint32_t wp_max_parts = 0;
+                      uint32_t *shadow = nullptr; /* k_newview_wgq: the word-major copy of every vector written (Geometry::shoff) */ };
 // Refresh schedule of a COMPLETE tree made on the device from the topology array alone (kids[cid], cids n .. n + n_ops - 1 are
 // the inner records): ops in level order, lev_off[0 .. n_lev] as launch_newview_levels reads them, *n_lev.  One workgroup;
 // trees of up to kSchedMaxSlots vectors.  Order inside a level is not defined (ops of a level are independent).
@@ -131,7 +137,8 @@ bool scan_prog_supported(const Geometry &g, int max_depth);
 hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *vec, const WalkDesc *desc, int n_scans,
                             const void *prog, uint32_t *out, uint32_t *ncand, uint32_t *host_out = nullptr, uint32_t n_out = 0,
                             uint32_t *done = nullptr,
-                            unsigned long long *trace = nullptr /* diagnostic: 4 words per workgroup (begin, end on the 100 MHz clock, where, what) */);
+                            unsigned long long *trace = nullptr /* diagnostic: 4 words per workgroup (begin, end on the 100 MHz clock, where, what) */,
+                            bool word_major = false /* read the vectors from the word-major copy (Geometry::shoff; the caller knows it is current) */);
 size_t scan_prog_blocks(const Geometry &g, int n_scans);
 // per-pattern Fitch lengths: ops = the (a, b) joins of a rooted traversal of the current tree; `planes` is
 // scratch of site_planes_words() words; ptn_out[p] = length of pattern p (0 where first_site[p] < 0)

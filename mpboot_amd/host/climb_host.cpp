@@ -142,6 +142,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   HIPCHK(hipMemcpyAsync(cd_.order.p, cd_.h_order.p, (size_t)total * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(cd_.out.p, cd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemsetAsync(cd_.gsum.p, 0, 3 * (size_t)kClimbCap * sizeof(unsigned long long), st_));
+  shadow_ok_ = false;                              // (k_climb rewrites vectors in the row-major store only)
   HIPCHK(launch_climb(st_, g_, vw, p));
   HIPCHK(hipMemcpyAsync(cd_.h_out.p, cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   {
