@@ -1010,10 +1010,10 @@ int Engine::schedule_views(const std::vector<int> *roots)
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   {
-    // the word-major copy follows only k_newview_wgq: any other refresh kernel leaves it behind, a full from-scratch pass
-    // of that kernel makes it whole again, a partial one keeps it as it was
-    const bool wgq = !chains && views_mode_ >= 1 && !sankoff_ && g_.vw == 1 && g_.nv_pipe && g_.shoff != 0;
-    if (!wgq) shadow_ok_ = false;
+    // the word-major copy follows k_newview_wgq and k_newview_chain only: any other refresh kernel leaves it behind, a full
+    // from-scratch pass makes it whole again, a partial one keeps it as it was
+    const bool both = views_mode_ >= 1 && !sankoff_ && g_.vw == 1 && g_.shoff != 0 && (chains || g_.nv_pipe);   // (k_newview_wgq and k_newview_chain write both)
+    if (!both) shadow_ok_ = false;
     else if (from_scratch && full) shadow_ok_ = true;
   }
   for (int r : order) valid_[r] = 1;

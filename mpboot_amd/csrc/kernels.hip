@@ -579,6 +579,9 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
       cost = fitch<S, VW>(c, p, tb[d]);                                                                  \
     }                                                                                                    \
     if (valid) store_tile<S, VW>(c, vec, o[d].dst, Wp, w0);                                              \
+    if constexpr (S == 4 && VW == 1)                                                                     \
+      if (valid && x.shadow)  /* the word-major copy the planned scan reads (Geometry::shoff) */         \
+        *reinterpret_cast<uint4 *>(x.shadow + ((size_t)o[d].dst * (size_t)Wp + (size_t)w0) * 4) = make_uint4(c.v[0][0], c.v[1][0], c.v[2][0], c.v[3][0]); \
     const uint32_t tot = wave_total<RED>(valid ? cost : 0u);                                             \
     if (lane == 0) cntp[(size_t)tile * nslots + o[d].dst] = tot;                                         \
     o[d] = nx[d];                                                                                        \
@@ -2135,7 +2138,9 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
 {
   if (n_lev <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles_of(g)), block(1024);
-#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 4 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, x)
+  RefreshExtra xs = x;
+  if (g.shoff && g.S == 4 && g.vw == 1) xs.shadow = vec + g.shoff;
+#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 4 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, xs)
 #define NC2(S_, VW_, dummy) do { if (g.reduce == 0) NC(S_, VW_, 0); else NC(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NC2, 0);
 #undef NC2

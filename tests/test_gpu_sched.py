@@ -161,3 +161,51 @@ def test_device_planned_sweep_equals_host_planned_sweep(mods, n, P, cache):
         k, best = e.sweep_scan(1, 6)              # vectors valid now: the host-planned path
         assert (int(k), int(best)) == want
     assert e1.score_tree() == ref.score_tree()
+
+
+@pytest.mark.parametrize("n,P", [(40, 900), (130, 2500)])
+def test_word_major_copy_follows_every_refresh(mods, n, P):
+    """the planned scan (k_scan_prog) reads a word-major copy of the vectors (one 16-byte load per lane and vector) that
+    k_pack_tips, k_newview_wgq and k_newview_chain write beside the row-major store: a climb on host-driven batches with every
+    scan planned (scan_prog 2) -- chained refreshes between the scans, re-weighting in the middle, a device climb in between
+    (k_climb writes the row-major store only: the copy must be left alone until the next full refresh) -- gives the oracle's
+    moves with the copy in use (scan_shadow 1, the default) and without"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(n, P, "DNA", 0.06, seed=n + 1)
+    codes = synth.letters_to_codes(letters, "DNA")
+    back = trees.random_topology(n, np.random.default_rng(n))
+    back2 = trees.random_topology(n, np.random.default_rng(n + 7))
+    w = np.random.default_rng(5).integers(0, 3, size=codes.shape[1]).astype(np.int32)
+    o = po.Oracle(codes)
+    o.set_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 3)
+    want = [o.optimize_spr(1, 6)]
+    want.append(o.get_tree().tolist())
+    o.set_weights(w)
+    o.set_tree(back2)
+    want.append(o.optimize_spr(1, 6))
+    want.append(o.get_tree().tolist())
+    o.set_tree(back)
+    want.append(o.optimize_spr(1, 6))
+    want.append(o.get_tree().tolist())
+    for shadow in (1, 0):
+        for split in (1000, 0):
+            e = engine.FitchEngine(codes)
+            e.set_option("scan_shadow", shadow)
+            e.set_option("scan_prog", 2)
+            e.set_option("split_below", split)
+            e.set_option("climb_device", 0)
+            e.set_tree(back)
+            e.seed_ties(engine.TIE_RANDOM, 3)
+            got = [e.optimize_spr(1, 6), e.get_tree().tolist()]
+            e.set_weights(w)
+            e.set_tree(back2)
+            e.set_option("climb_device", 2)          # the kernel edits vectors behind the copy's back ...
+            got.append(e.optimize_spr(1, 6))
+            got.append(e.get_tree().tolist())
+            e.set_option("climb_device", 0)          # ... and the host-driven batches that follow must not read it stale
+            e.set_tree(back)
+            got.append(e.optimize_spr(1, 6))
+            got.append(e.get_tree().tolist())
+            assert got == want, (shadow, split)
+            assert e.score_tree() == want[4]
