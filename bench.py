@@ -614,9 +614,10 @@ def main():
                        # touched = node-vector operations actually performed x P: per eval one chain step (fitch of the
                        # running up-vector with a sibling) + one join, plus the directional-vector refresh of the step
                        "touched_site_ops_per_s": (2.0 * tests_all + st["newview_ops"] * world) * P / dt_all},
-            # The scan kernel is bound by the L2 -> CU data path: one directional vector per insertion test has to reach a
-            # CU's registers, >90 % of them from the XCD's L2 (loads-only variant of the kernel: 0.93 of its time,
-            # arithmetic-only variant: 0.64 -- profiles/r2/scan_bounds.txt).  achieved = bytes the kernel loads / its time.
+            # One directional vector per insertion test has to reach a CU's registers, >90 % of them from the XCD's L2.  Round 2's
+            # kernel (four 256-byte row loads per vector) sat on the CU's load path: 75 GB/s per CU whatever the cache level.  Round 3
+            # reads a word-major copy (one buffer_load_dwordx4 per vector and lane: 124-146 GB/s per CU, tools/ubench/l1_rate) and
+            # is now close to its arithmetic + control side (profiles/r3/scan_bounds.txt).  achieved = bytes the kernel loads / its time.
             "roofline": {"bound": "l2", "achieved": loaded_gbps, "peak": L2_PEAK_GBS, "unit": "GB/s",
                          "frac": loaded_gbps / L2_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
                          "kernel": st_kernel_name(eng), "kernel_ms_per_launch": scan_ms, "evals_per_launch": evals_per_launch,
@@ -629,8 +630,10 @@ def main():
                                  "peak_GBps": HBM_PEAK_GBS,
                                  "survey_6vector_GBps": survey_gbps, "survey_bytes_per_eval": survey_bytes_per_eval},
                          "note": "bound = L2 -> CU bandwidth: achieved = insertion tests x one vector (S x Wp x 4 B, the bytes the kernel "
-                                 "actually loads per test: chain in registers, sibling pairs share loads) / HIP-event kernel time; peak = the "
-                                 "guide's aggregate L2 figure (its measured gathers from L2 reach 16.8-18.8 TB/s).  valu.* = algorithmic "
+                                 "actually loads per test: chain in registers, sibling pairs share loads; read from the word-major copy, 16 B "
+                                 "per lane and vector) / HIP-event kernel time; peak = the guide's aggregate L2 figure (its measured gathers "
+                                 "from L2 reach 16.8-18.8 TB/s; this box: 124 GB/s per CU = 31.7 TB/s for 1-KB dwordx4 gathers from L2, "
+                                 "tools/ubench/l1_rate).  valu.* = algorithmic "
                                  "lane-ops (2 S chain + 3 S join + 1 popcount + 3 reduction per test and 32-site word) against 256 CUs x 128 "
                                  "lanes x 2.4 GHz.  hbm.*: what must come from HBM per launch (every vector once) -- far from a limit; "
                                  "traffic = rocprofv3 PMC bytes that left the L2s per launch (2 x FETCH_SIZE + WRITE_SIZE, KB; see "

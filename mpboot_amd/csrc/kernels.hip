@@ -2380,7 +2380,9 @@ hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *v
 #define SP(VW_, BIG_) hipLaunchKernelGGL((k_scan_prog<4, VW_, BIG_>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace)
 #ifdef MPF_EXPERIMENTS                     // (wrong results on purpose: never in the production library)
   static const int expr = getenv("MPF_PROG_EXPERIMENT") ? atoi(getenv("MPF_PROG_EXPERIMENT")) : 0;
+  const bool wm = word_major && g.shoff && !g.big && vw == 1;
   if (expr == 1) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 1>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
+  else if (expr == 2 && wm) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 2, true>), grid, block, 0, st, vec + g.shoff, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else if (expr == 2) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 2>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else
 #endif
