@@ -284,7 +284,7 @@ int Engine::pack()
     g_.shoff = (g_.S == 4 && vec_words_ * sizeof(uint32_t) < ((size_t)1 << 31)) ? vec_words_ : 0;
     HIPCHK(hipMalloc((void **)&d_vec_, (vec_words_ + (g_.shoff ? vec_words_ : 0)) * sizeof(uint32_t)));
   }
-  shadow_ok_ = false;                          // (the tips' copies are rewritten below; the inner vectors' with the next full refresh)
+  shadow_ok_ = false;                          // (until the tips' copies are rewritten below: invalidate_vectors sets it again)
   std::vector<int32_t> s2p((size_t)std::max(nsites_, 1));
   for (int s = 0; s < P_; s++)
     if (inf_[s])
@@ -407,6 +407,7 @@ void Engine::invalidate_all()
   topo_epoch_++;
   sched_cache_valid_ = false;
   sweep_cache_valid_ = false;
+  shadow_ok_ = g_.shoff != 0;                      // (no valid inner vector left that the word-major copy could disagree with)
 }
 
 // every vector stale, topology unchanged (re-weighting, a full re-evaluation, the same tree handed over again): what
@@ -418,6 +419,7 @@ void Engine::invalidate_vectors()
   n_invalid_ = -1;
   views_valid_ = false;
   all_invalid_ = true;
+  shadow_ok_ = g_.shoff != 0;
 }
 
 // Invariant: a valid vector has valid inputs.  The vectors containing `node` are its own three and, walking
@@ -711,7 +713,6 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   for (size_t i = all.size(); i-- > 0;) upd_order_[at++] = all[i];
   for (int u : all) { upd_order_[at++] = nx(u); upd_order_[at++] = nx(nx(u)); }
   for (int r : upd_order_) valid_[r] = 1;
-  shadow_ok_ = g_.shoff != 0;                      // (dev_sched_usable: the refresh was k_newview_wgq's)
   all_invalid_ = false;
   n_invalid_ = 0;
   views_valid_ = true;
@@ -758,7 +759,7 @@ int Engine::schedule_views(const std::vector<int> *roots)
     HIPCHK(launch_cntsum(st_, g_, dops, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), tiles_for_levels(g_)));
     if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
     cnt_copy_pending_ = true;
-    shadow_ok_ = g_.shoff != 0 && g_.vw == 1 && g_.nv_pipe;      // (every vector of the tree rewritten by k_newview_wgq, both layouts)
+    if (!(g_.vw == 1 && g_.nv_pipe)) shadow_ok_ = false;          // (another refresh kernel than k_newview_wgq: row-major store only)
     upd_order_ = sc_order_;
     for (int r : upd_order_) valid_[r] = 1;
     all_invalid_ = false;
@@ -1010,11 +1011,10 @@ int Engine::schedule_views(const std::vector<int> *roots)
   if (timing_ >= 2) { HIPCHK(hipEventRecord(ev3_, st_)); view_events_pending_ = true; }
   cnt_copy_pending_ = true;                 // copied back together with the scan results (or by update_views)
   {
-    // the word-major copy follows k_newview_wgq and k_newview_chain only: any other refresh kernel leaves it behind, a full
-    // from-scratch pass makes it whole again, a partial one keeps it as it was
-    const bool both = views_mode_ >= 1 && !sankoff_ && g_.vw == 1 && g_.shoff != 0 && (chains || g_.nv_pipe);   // (k_newview_wgq and k_newview_chain write both)
+    // shadow_ok_ = "every valid vector has its word-major copy": true whenever nothing is valid (invalidate_all / _vectors),
+    // kept by k_newview_wgq and k_newview_chain, which write both layouts, lost when any other kernel writes vectors
+    const bool both = views_mode_ >= 1 && !sankoff_ && g_.vw == 1 && g_.shoff != 0 && (chains || g_.nv_pipe);
     if (!both) shadow_ok_ = false;
-    else if (from_scratch && full) shadow_ok_ = true;
   }
   for (int r : order) valid_[r] = 1;
   all_invalid_ = false;
@@ -1514,7 +1514,7 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       stats.plan_launches++;
     } else {
       HIPCHK(launch_scan_walk(st_, g_, d_vec_, d_kids(), n_, descs, (int)nd, d_out(), d_ncand_.p, maxd, mask_ptr, info_ptr,
-                              host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8));
+                              host_direct ? h_out() : nullptr, (uint32_t)nout, d_done_.p + 8, shadow_ok_ && scan_shadow_));
     }
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     part_min_used_ = false;

@@ -506,7 +506,7 @@ class Engine {
   int dsw_key_[4] = {0, 0, 0, 0};               // ... this radius / these options
   uint32_t dsw_parts_ = 0, dsw_out_ = 0;
   bool sched_on_dev_ = false;                   // d_vstage_ holds a k_sched-made schedule (diagnostics: options sched_levels / sched_ticks / sched_desc_ticks)
-  bool shadow_ok_ = false;                      // the word-major copy (Geometry::shoff) matches the row-major vectors of the whole tree
+  bool shadow_ok_ = false;                      // every VALID vector has its word-major copy (Geometry::shoff) in place
   bool scan_shadow_ = true;                     // option scan_shadow
   bool plan_ride_ = true;                       // the walk plan of a device-planned sweep rides on the refresh launch
   std::vector<int> sc_order_;

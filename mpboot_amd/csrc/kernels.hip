@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void load_tile_g(Tile<S, VW> &t, const uint32_t *__re
 // k-th EMITTED candidate.  The part's last slot (index out_base + count) receives the join of the pruned subtree
 // onto its home edge, fitch(vec[xa], vec[xb]).
 // BIG: the vector store does not fit a raw buffer's 32-bit range: plain global loads from a 64-bit base per vector.
-template <int S, int VW, int MAXD, int RED, bool SPLIT, bool MASKS, bool BIG>
+template <int S, int VW, int MAXD, int RED, bool SPLIT, bool MASKS, bool BIG, bool WM = false>
 __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
@@ -1267,9 +1267,14 @@ __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec,
   uint32_t voff[S];
 #pragma unroll
   for (int k = 0; k < S; k++) voff[k] = (w0 + (row0 + (uint32_t)k) * (uint32_t)Wp) * 4u;
+  // WM: `vec` is the word-major copy (Geometry::shoff): the four state words of a site word in one 16-byte load
+  static_assert(!WM || (S == 4 && VW == 1 && !SPLIT && !BIG), "word-major copy: DNA, one word per lane, below 2 GiB");
 #define MPF_LOAD(T, cid)                                                                       \
   do {                                                                                         \
-    if constexpr (BIG) load_tile_g<S, VW>(T, vec + (size_t)(cid) * (size_t)SW, voff);            \
+    if constexpr (WM) {                                                                        \
+      const auto x4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, w0 * 16u, (uint32_t)(cid) * SW * 4u, 0); \
+      T.v[0][0] = x4[0]; T.v[1][0] = x4[1]; T.v[2][0] = x4[2]; T.v[3][0] = x4[3];              \
+    } else if constexpr (BIG) load_tile_g<S, VW>(T, vec + (size_t)(cid) * (size_t)SW, voff);   \
     else load_tile_b<S, VW>(T, rsrc, voff, (uint32_t)(cid) * SW * 4u);                          \
   } while (0)
 
@@ -1408,14 +1413,14 @@ __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec,
 // host_out != nullptr (small batches): the workgroup that finishes last copies the n_out candidate costs to the host's
 // pinned buffer itself, so that the batch needs no copy-back dispatch behind the kernel (`done` = a zeroed device word,
 // left zeroed)
-template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false, bool BIG = false>
+template <int S, int VW, int MAXD, int RED, bool SPLIT = false, bool MASKS = false, bool BIG = false, bool WM = false>
 __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8 : 1) void k_scan_walk(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                    uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
                                                    int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info,
                                                    uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done)
 {
-  scan_walk_body<S, VW, MAXD, RED, SPLIT, MASKS, BIG>(vec, kids, n, desc, n_scans, out, ncand, Wp, tiles, map, masks, info);
+  scan_walk_body<S, VW, MAXD, RED, SPLIT, MASKS, BIG, WM>(vec, kids, n, desc, n_scans, out, ncand, Wp, tiles, map, masks, info);
   if (!host_out) return;
   __shared__ int s_last;
   __syncthreads();
@@ -2240,7 +2245,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
 
 hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *vec, const uint2 *kids, int n_taxa,
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
-                            uint32_t *masks, uint2 *info, uint32_t *host_out, uint32_t n_out, uint32_t *done)
+                            uint32_t *masks, uint2 *info, uint32_t *host_out, uint32_t n_out, uint32_t *done, bool word_major)
 {
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;   // 8: the per-depth LDS slots of the walk are sized for it
@@ -2271,6 +2276,20 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
     // >= 2 GiB of vectors: one code path (one word per lane, DPP reduction), 64-bit addressing
     if (g.S == 4) { if (max_depth <= 6) SWB(4, 1, 6, 0, false, true); else SWB(4, 1, 8, 0, false, true); }
     else { if (max_depth <= 6) SWB(10, 1, 6, 0, true, true); else SWB(10, 1, 8, 0, true, true); }
+  } else if (g.S == 4 && g.vw == 1 && word_major && g.shoff) {
+    // the vectors from the word-major copy (the caller knows it is current): one 16-byte load per lane and vector
+#define SWM(MAXD_, RED_)                                                                                                              \
+  do {                                                                                                                                \
+    if (masks)                                                                                                                        \
+      hipLaunchKernelGGL((k_scan_walk<4, 1, MAXD_, RED_, false, true, false, true>), grid, block, 0, st, vec + g.shoff, kids,         \
+                         (uint32_t)n_taxa, desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info, host_out, n_out, done);         \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((k_scan_walk<4, 1, MAXD_, RED_, false, false, false, true>), grid, block, 0, st, vec + g.shoff, kids,        \
+                         (uint32_t)n_taxa, desc, n_scans, out, ncand, g.Wp, tiles, g.map, masks, info, host_out, n_out, done);         \
+  } while (0)
+    if (max_depth <= 6) { if (g.reduce == 0) SWM(6, 0); else SWM(6, 1); }
+    else { if (g.reduce == 0) SWM(8, 0); else SWM(8, 1); }
+#undef SWM
   } else if (g.S == 4) {
     if (g.vw == 1) SW2(4, 1, false); else SW2(4, 2, false);
   } else {

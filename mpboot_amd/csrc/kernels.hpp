@@ -126,7 +126,8 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
                             const WalkDesc *desc, int n_scans, uint32_t *out, uint32_t *ncand, int max_depth,
                             uint32_t *masks = nullptr, uint2 *info = nullptr,   // masks != nullptr: UFBoot variant (ufboot.hip)
                             // host_out != nullptr: the last workgroup copies out[0..n_out) to pinned host memory (done: zeroed word)
-                            uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr);
+                            uint32_t *host_out = nullptr, uint32_t n_out = 0, uint32_t *done = nullptr,
+                            bool word_major = false /* read the vectors from the word-major copy (Geometry::shoff): the caller knows it is current */);
 // planned-program scan (radius <= 6, DNA): launch_walk_plan turns the descriptors into one DFS program per (scan part, gap end)
 // -- WalkDesc::pad1 must hold the number of candidates behind the FIRST gap end (xa) of the part --, launch_scan_prog runs
 // them with the children's vectors requested one expansion ahead.  Same outputs as launch_scan_walk.
