@@ -209,3 +209,21 @@ def test_word_major_copy_follows_every_refresh(mods, n, P):
             got.append(e.get_tree().tolist())
             assert got == want, (shadow, split)
             assert e.score_tree() == want[4]
+
+
+def test_trees_beyond_the_device_scheduler_take_the_host_path(mods):
+    """k_sched keeps the topology of up to 16 384 vectors in the LDS of one workgroup (4 096 taxa); a larger tree is scheduled and
+    planned on the host as before -- same results, no error"""
+    engine, po, synth, trees = mods
+    n = 4200
+    letters, _ = synth.synth_alignment(n, 96, "DNA", 0.05, seed=2)
+    codes = synth.letters_to_codes(letters, "DNA")
+    back = trees.random_topology(n, np.random.default_rng(4))
+    e = engine.FitchEngine(codes)
+    o = po.Oracle(codes)
+    assert e.score_tree(back) == o.score_tree(back)
+    e.set_tree(back)
+    k, best = e.sweep_scan(1, 6)
+    k2, mp, _ = e.sweep_costs(1, 6)
+    assert (int(k), int(best)) == (int(k2), int(mp.min()))
+    assert e.get_option("sched_levels") == 0           # (no device-made schedule on record)
