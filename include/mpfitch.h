@@ -103,8 +103,12 @@ int mpf_engine_create(mpf_engine **out, const mpf_config *cfg, const uint8_t *co
    the triangle inequality as ParsTree::loadCostMatrixFile does, parstree.cpp:31-95; initializeCostMatrix
    sprparsimony.cpp:159-188).  Kernels: newviewSankoffParsimonyIterativeFastSIMD / evaluateSankoff... (:477-551,
    :880-961), tips as compressSankoffDNA (:2636-2825).  Arithmetic is exact 32-bit (the reference's -short_off
-   mode).  The matrix must be symmetric (MPF_E_UNSUPPORTED otherwise): only then is the length independent of
-   root placement.  Serves ParsTree::computeParsimony (parstree.cpp:101-116) through mpf_compute_parsimony. */
+   mode).  A matrix that is not symmetric (the loader accepts any, parstree.cpp:31-95) makes the length of a tree depend
+   on where it is rooted: every evaluation is then rooted as the reference roots it -- mpf_score_tree at the start tip's
+   edge with the tip as the child, an SPR insertion test at the new node's edge towards the near side of the tested branch
+   (testInsertParsimony evaluates p->next->next, :2158), a stepwise-addition test at the new tip's edge (:2993-2997) --, so
+   the numbers are the reference's own; mpf_ufboot_attach refuses such an engine.  Serves ParsTree::computeParsimony
+   (parstree.cpp:101-116) through mpf_compute_parsimony (symmetric matrices only: IQ-TREE's own Sankoff kernel roots elsewhere). */
 int mpf_engine_create_sankoff(mpf_engine **out, const mpf_config *cfg, const uint8_t *codes, const int32_t *weights,
                               const uint32_t *cost /* [S*S] */);
 /* _pllFreeParsimonyDataStructures (sprparsimony.cpp:3062-3104) */
@@ -210,7 +214,7 @@ int mpf_get_moves(const mpf_engine *e, int32_t cap, int32_t *remove_rec, int32_t
    n_states_alignment states) or the path of a text file "<nstates>  nstates x nstates entries"; the matrix is then closed
    under the triangle inequality by the reference's own k-i-j loop (:74-80; *changed = 1 if that altered an entry).
    cost has room for cap_states x cap_states entries.  The result is what mpf_engine_create_sankoff takes (the reference
-   copies it into pllCostMatrix, iqtree.cpp:601-615); that call still requires a symmetric matrix. */
+   copies it into pllCostMatrix, iqtree.cpp:601-615). */
 int mpf_cost_matrix_load(const char *file_or_keyword, int32_t n_states_alignment, int32_t cap_states, uint32_t *cost /* [cap*cap] */,
                          int32_t *n_states, int32_t *changed);
 int mpf_cost_matrix_triangle_fix(int32_t n_states, uint32_t *cost /* [S*S], in place */, int32_t *changed);

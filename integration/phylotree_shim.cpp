@@ -181,6 +181,12 @@ int _ZN8ParsTree16computeParsimonyEv(PhyloTree *self)
       for (int j = 0; j < S; j++)
         if (cost[i * S + j] != (i == j ? 0u : 1u)) { unit = false; break; }
     if (unit) cost = nullptr;
+    // (IQ-TREE's own Sankoff kernel roots the tree at its `root` leaf with its own parent / child convention; only for a
+    //  symmetric matrix is the length independent of that, and only then is the engine's number known to be IQ-TREE's)
+    if (cost)
+      for (int i = 0; i < S; i++)
+        for (int j = 0; j < i; j++)
+          if (cost[i * S + j] != cost[j * S + i]) die("ParsTree::computeParsimony: asymmetric cost matrix");
   }
   return compute(self, cost);
 }

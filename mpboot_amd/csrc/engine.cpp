@@ -120,8 +120,9 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     return MPF_E_UNSUPPORTED;
   }
   if (cost) {
-    // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80), then the
-    // symmetry requirement of the directional-view formulation
+    // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80).  A matrix that is not
+    // symmetric afterwards makes the length of a tree depend on where it is rooted; the reference roots every evaluation
+    // at the edge it is handed, and so do the kernels (asym_: the root side of a test goes through the transposed matrix)
     const int S = g_.S;
     if (sref_ == S) {
       cost_.assign(cost, cost + S * S);
@@ -143,7 +144,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
     uint32_t hi = 0;
     for (int i = 0; i < S; i++)
       for (int j = 0; j < S; j++) {
-        if (cost_[i * S + j] != cost_[j * S + i]) { set_error("Sankoff cost matrix must be symmetric"); return MPF_E_UNSUPPORTED; }
+        if (cost_[i * S + j] != cost_[j * S + i]) asym_ = true;
         hi = std::max(hi, cost_[i * S + j]);
       }
     if (hi >= 65535u) { set_error("Sankoff costs too large"); return MPF_E_UNSUPPORTED; }
@@ -244,6 +245,16 @@ int Engine::pack()
       cost_dev_.resize(cost_.size());
       for (size_t i = 0; i < cost_.size(); i++) cost_dev_[i] = g_.snk16 ? (cost_[i] | (cost_[i] << 16)) : cost_[i];
       HIPCHK(hipMemcpyAsync(d_cost_.p, cost_dev_.data(), cost_dev_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+      g_.costT = nullptr;
+      if (asym_) {
+        const int S = g_.S;
+        costT_dev_.resize(cost_.size());
+        for (int i = 0; i < S; i++)
+          for (int j = 0; j < S; j++) costT_dev_[(size_t)i * S + j] = cost_dev_[(size_t)j * S + i];
+        HIPCHK(d_costT_.reserve(costT_dev_.size()));
+        HIPCHK(hipMemcpyAsync(d_costT_.p, costT_dev_.data(), costT_dev_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+        g_.costT = d_costT_.p;
+      }
     }
     if (!inf_index_.empty())
       HIPCHK(hipMemcpyAsync(d_infidx_.p, inf_index_.data(), inf_index_.size() * sizeof(int32_t), hipMemcpyHostToDevice, st_));
@@ -1123,7 +1134,9 @@ void Engine::collect_scan_roots(int p, int mintrav, int maxtrav, std::vector<int
 int Engine::tree_length(uint32_t *len)
 {
   if (!views_valid_) { int rc = update_views(); if (rc) return rc; }
-  const int a = start_, b = back_[start_];
+  // weighted mode: evaluateParsimony(tr->start) = min_x(left[x] + m(right)[x]) with left = the far end of the edge, right = the
+  // record handed over (reference :880-961) -- the order matters when the matrix is not symmetric
+  const int a = sankoff_ ? back_[start_] : start_, b = sankoff_ ? start_ : back_[start_];
   EvOp op{slot(a), slot(b), 0, 0};
   HIPCHK(d_evops_.reserve(1));
   HIPCHK(reserve_results(1));
@@ -1882,7 +1895,7 @@ int Engine::pattern_scores(uint16_t *ptn, int32_t *total)
     DevBuf<uint16_t> d_p;
     std::vector<uint16_t> hp((size_t)g_.Wp);
     HIPCHK(d_p.reserve((size_t)g_.Wp));
-    HIPCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), d_p.p));
+    HIPCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(back_[start_]), slot(start_), d_p.p));      // (left = far end, right = start: as tree_length)
     HIPCHK(hipMemcpyAsync(hp.data(), d_p.p, hp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, st_));
     HIPCHK(hipStreamSynchronize(st_));
     long sum = 0;

@@ -370,11 +370,12 @@ class Engine {
   bool inf_known_ = false;                       // informative flags depend on the codes only: computed once
   // Sankoff mode
   bool sankoff_ = false;
-  std::vector<uint32_t> cost_, cost_dev_;
+  std::vector<uint32_t> cost_, cost_dev_, costT_dev_;
+  bool asym_ = false;                            // the (repaired) cost matrix is not symmetric: evaluations are rooted as the reference roots them
   int force_big_ = 0;
   int snk16_opt_ = 1;                            // allow the packed 16-bit cost arithmetic when the values fit
   std::vector<int32_t> inf_index_;               // informative pattern j -> original pattern index
-  DevBuf<uint32_t> d_cost_, d_pwgt_;
+  DevBuf<uint32_t> d_cost_, d_costT_, d_pwgt_;
   DevBuf<int32_t> d_infidx_;
   size_t nslots_ = 0, vec_words_ = 0;
 

@@ -1907,12 +1907,23 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
 //   CHAIN : U[d] = m(U[d-1]) + m(vec[sib]);  test: out += sum_ptn w * min_s(m(U[d])[s] + m(vec[own])[s] + m(S)[s])
 //   JOIN  : out += sum_ptn w * min_s(m(vec[own])[s] + m(vec[sib])[s] + m(S)[s])
 // and out is the FULL length of the rearranged tree (there is no additive base in the weighted case).
-template <int S, int MAXD, bool PK>
+// ASYM (a cost matrix that is not symmetric): the reference scores a rearranged tree rooted at the edge it evaluates, parent
+// state = row of the matrix (newview :477-551, evaluate :880-961: min_x(left[x] + min_y(cost[x][y] + right[y])), left = the
+// far end of the edge handed to evaluateParsimony).  The stored transforms m(v)[z] = min_x(v[x] + cost[z][x]) have that
+// orientation already (the viewer is the parent); what differs is the ROOT side of each test, which enters through the
+// transposed matrix, mT(v)[y] = min_x(v[x] + cost[x][y]):
+//   SPR test (testInsertParsimony evaluates p->next->next, whose back is r = q->back, the NEAR side):
+//       min_y( m(S)[y] + m(vec[own])[y] + mT(U)[y] )        U = the near side's vector, computed along the chain
+//   stepwise addition (evaluates the new inner node against p->back, the NEW TIP):
+//       min_y( m(vec[own])[y] + m(vec[sib])[y] + mT(S)[y] )
+// With a symmetric matrix mT = m and both collapse to the form below.  costT == nullptr selects ASYM = false.
+template <int S, int MAXD, bool PK, bool ASYM = false>
 __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
                                                   int n_scans, const ScanOp *__restrict__ ops,
                                                   const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
                                                   uint32_t *__restrict__ out, int We, int tiles,
-                                                  uint16_t *__restrict__ vals, uint32_t npat, uint32_t *__restrict__ vmax)
+                                                  uint16_t *__restrict__ vals, uint32_t npat, uint32_t *__restrict__ vmax,
+                                                  const uint32_t *__restrict__ costT)
 {
   typedef SnkT<PK> T;
   const int lane = threadIdx.x & 63;
@@ -1928,7 +1939,10 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
 
   // MU[d] = m(U[d]): what the children of depth d and the test at depth d both need; U itself is never kept
   Costs<S, PK> ms, MU[MAXD + 1], t1, t2;
-  load_costs<S, PK>(ms, mvec, h.s_slot, We, e0);
+  if (ASYM && (h.pad & 1u)) {                       // stepwise addition: the new tip is the root side
+    load_costs<S, PK>(t2, vec, h.s_slot, We, e0);
+    mplus<S, PK>(ms, t2, costT);
+  } else load_costs<S, PK>(ms, mvec, h.s_slot, We, e0);
 
   for (uint32_t i = h.op_begin; i < h.op_end; i++) {
     const ScanOp o = ops[i];
@@ -1950,8 +1964,13 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
   case c:                                                                              \
     if constexpr (c <= MAXD) {                                                         \
       _Pragma("unroll") for (int s = 0; s < S; s++) t2.v[s] = T::add(t1.v[s], MU[c - 1].v[s]); /* U[c] */ \
+      if (ASYM && test) {   /* the near side is the root side of the test: mT(U) first, in MU[c]'s registers */ \
+        mplus<S, PK>(MU[c], t2, costT);                                                \
+        load_costs<S, PK>(t1, mvec, o.own, We, e0);                                    \
+        _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
+      }                                                                                \
       mplus<S, PK>(MU[c], t2, cost);                                                   \
-      if (test) {                                                                      \
+      if (!ASYM && test) {                                                             \
         load_costs<S, PK>(t1, mvec, o.own, We, e0);                                    \
         _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
       }                                                                                \
@@ -2210,8 +2229,9 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
     const int We = snk_elems(g), stiles = (We + 63) / 64;
     const long waves = (long)n_scans * stiles;
     dim3 sgrid((unsigned)((waves + 3) / 4));
-#define SNKSCAN(S_, D_) do { if (g.snk16) hipLaunchKernelGGL((k_snk_scan<S_, D_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax); \
-                             else hipLaunchKernelGGL((k_snk_scan<S_, D_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax); } while (0)
+#define SNKSCAN2(S_, D_, PK_) do { if (g.costT) hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); \
+                                   else hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); } while (0)
+#define SNKSCAN(S_, D_) do { if (g.snk16) SNKSCAN2(S_, D_, true); else SNKSCAN2(S_, D_, false); } while (0)
     if (g.S == 4) {
       if (max_depth <= 6) SNKSCAN(4, 6); else SNKSCAN(4, 12);
     } else {
@@ -2219,6 +2239,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
       SNKSCAN(20, 6);
     }
 #undef SNKSCAN
+#undef SNKSCAN2
     return hipGetLastError();
   }
   if (g.map == 0) {

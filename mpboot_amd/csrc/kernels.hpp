@@ -22,7 +22,7 @@ struct EvOp { uint32_t a, b, out, pad; };
 //   kind 1  ROOT  : U[0] = vec[own]
 //   kind 2  JOIN  : out[out] += cost(fitch(vec[own], vec[sib]), S)            (stepwise addition)
 struct ScanOp { uint32_t own, sib, meta, out; };   // meta = depth | test<<8 | kind<<16
-struct ScanHdr { uint32_t op_begin, op_end, s_slot, pad; };
+struct ScanHdr { uint32_t op_begin, op_end, s_slot, pad /* bit 0: stepwise-addition program (the subtree s is the root side of every test) */; };
 
 enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2 };
 
@@ -53,6 +53,7 @@ struct Geometry {
   // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
   int sankoff = 0;
   const uint32_t *cost = nullptr;   // device, [S][S]
+  const uint32_t *costT = nullptr;  // device, the transposed matrix; nullptr: the matrix is symmetric (see k_snk_scan)
   const uint32_t *pwgt = nullptr;   // device, [Wp] pattern weights (0 on padding)
   uint32_t highest_cost = 0;
   int snk16 = 0;                    // weighted mode: two 16-bit costs per lane (v_pk_add_u16 / v_pk_min_u16)

@@ -252,7 +252,7 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
       h.op_begin = (uint32_t)b;
       h.op_end = (uint32_t)std::min(prog_ops_.size(), b + 4);
       h.s_slot = slot(p);
-      h.pad = 0;
+      h.pad = 1;                                   // stepwise addition: the new tip is the root side of every test (k_snk_scan, ASYM)
       prog_hdr_.push_back(h);
     }
     {

@@ -31,6 +31,9 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
                           mpf_ufb_exchange_fn exchange, void *exchange_arg)
 {
   if (sankoff_ && exchange) { set_error("online UFBoot on the weighted engine: sample sharding is not supported"); return MPF_E_UNSUPPORTED; }
+  // (an asymmetric matrix gives the CURRENT tree another length at every prune node's visit -- it is evaluated at that node's
+  //  edge --, which the tracker's one row for the current tree does not model)
+  if (sankoff_ && asym_) { set_error("online UFBoot on the weighted engine: the cost matrix must be symmetric"); return MPF_E_UNSUPPORTED; }
   if (n_samples < 1 || !samples) { set_error("ufboot_attach: bad argument"); return MPF_E_INVALID; }
   if (!(epsilon > 0.0 && epsilon < 1.0)) {
     set_error("ufboot_attach: epsilon must lie in (0, 1) -- with integer scores every such value acts like the default 0.5");

@@ -113,7 +113,8 @@ def test_random_case_matches_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_random_weighted_case_matches_oracle(seed):
-    """the same for the weighted (Sankoff) engine: random symmetric cost matrices, small (packed 16-bit) and large (32-bit)"""
+    """the same for the weighted (Sankoff) engine: random cost matrices, small (packed 16-bit) and large (32-bit), symmetric and
+    -- every fourth case -- not (then every length is the one of the edge the reference roots it at)"""
     from mpboot_amd import engine
     from oracle import pyoracle as po
 
@@ -123,6 +124,9 @@ def test_random_weighted_case_matches_oracle(seed):
     hi = 6 if seed % 3 else 4000
     m = rng.integers(1, hi, size=(S, S))
     cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    if seed % 4 == 1:
+        cost = m.astype(np.uint32)
+        np.fill_diagonal(cost, 0)
     dt_e, dt_o = (engine.AA, po.AA) if c["aa"] else (engine.DNA, po.DNA)
     w = np.maximum(c["w"], 0)
     e = engine.FitchEngine(c["codes"], w, datatype=dt_e, cost=cost)
@@ -140,6 +144,10 @@ def test_random_weighted_case_matches_oracle(seed):
     o.trace(True)
     assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius)
     assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    for x, tmode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.seed_ties(tmode, seed + 2)
+    assert e.make_parsimony_tree(31 + seed, min(radius, 3)) == o.make_tree(31 + seed, min(radius, 3))[0]
     assert (e.get_tree() == o.get_tree()).all()
 
 

@@ -27,10 +27,22 @@ def random_metric(S, seed):
     return c
 
 
+def random_asymmetric(S, seed):
+    """step-matrix style costs: i -> j and j -> i differ (gains dearer than losses, plus noise); the loader's triangle repair
+    is applied by engine and oracle alike (reference parstree.cpp:74-80) and leaves it asymmetric"""
+    rng = np.random.default_rng(seed)
+    c = rng.integers(1, 7, size=(S, S)).astype(np.uint32)
+    c[np.triu_indices(S, 1)] += 2
+    np.fill_diagonal(c, 0)
+    return c
+
+
 def cost_for(fx, kind):
     S = fx["S"]
     if kind == "unit":
         return unit_cost(S)
+    if kind == "asym":
+        return random_asymmetric(S, 11)
     return tstv_cost() if S == 4 else random_metric(S, 4)      # protein 20 x 20, binary 2 x 2, multistate 32 x 32
 
 
@@ -56,8 +68,11 @@ def test_weighted_multistate_is_refused(mods):
     assert ei.value.code == -6 and "32-state" in str(ei.value)
 
 
-@pytest.mark.parametrize("kind", ["unit", "general"])
+@pytest.mark.parametrize("kind", ["unit", "general", "asym"])
 def test_scores_patterns_and_scans(mods, fx, kind):
+    """kind asym: a matrix that is not symmetric -- the length of a tree depends on the edge it is rooted at, and every number
+    must be the one the reference's rooted kernels give there (evaluate: left = far end of the edge, :880-961; insertion test:
+    rooted at the new node's edge towards the near side of the branch, :2158)"""
     engine, po = mods
     cost = cost_for(fx, kind)
     e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
@@ -89,7 +104,7 @@ def test_scores_patterns_and_scans(mods, fx, kind):
         assert mine == toks, rec
 
 
-@pytest.mark.parametrize("kind", ["unit", "general"])
+@pytest.mark.parametrize("kind", ["unit", "general", "asym"])
 def test_hill_climb_and_ras_trajectories(mods, fx, kind):
     engine, po = mods
     cost = cost_for(fx, kind)
@@ -117,13 +132,26 @@ def test_hill_climb_and_ras_trajectories(mods, fx, kind):
         assert (f.get_tree() == e2.get_tree()).all()     # `-cost e` == Fitch trajectory
 
 
-def test_asymmetric_matrix_is_refused(mods):
-    engine = mods[0]
-    fx = load_fixture("dna_clean")
-    c = tstv_cost()
-    c[0, 1] = 3
+def test_asymmetric_matrix_roots_like_the_reference(mods):
+    """an asymmetric matrix is accepted (ParsTree::loadCostMatrixFile takes any, parstree.cpp:31-95): the same tree has
+    different lengths at different root edges, the engine's are the oracle's at each of them -- the start edge (score_tree), the
+    candidates of single prune nodes -- and differ from the transposed matrix's; online UFBoot refuses such an engine"""
+    engine, po = mods
+    fx = load_fixture("dna_ambig")
+    c = random_asymmetric(4, 3)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=c)
+    et = engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=c.T.copy())
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], cost=c)
+    differ = 0
+    for t in fx["trees"]:
+        b = np.array(t["back"], dtype=np.int32)
+        s = e.score_tree(b)
+        assert s == o.score_tree(b)
+        differ += s != et.score_tree(b)
+    assert differ > 0
+    samples = np.random.default_rng(5).multinomial(fx["codes_np"].shape[1], np.ones(fx["codes_np"].shape[1]) / fx["codes_np"].shape[1], size=8).astype(np.uint16)
     with pytest.raises(engine.MpfError) as ei:
-        engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=c)
+        e.ufboot_attach(samples)
     assert ei.value.code == -6
 
 
