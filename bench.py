@@ -129,7 +129,8 @@ def live_traffic(args) -> dict:
 def st_kernel_name(eng) -> str:
     """Name of the scan kernel the engine's sweeps launch (mpf_get_option "scan_prog": 1 = planned program, 0 = device walk)."""
     try:
-        return "k_scan_prog" if eng.get_option("scan_prog") else "k_scan_walk"
+        # (the planned program exists for the 4-row kernels: DNA and binary data; protein sweeps run the device walk)
+        return "k_scan_prog" if eng.get_option("scan_prog") and eng.S == 4 else "k_scan_walk"
     except Exception:
         return "k_scan_walk"
 
