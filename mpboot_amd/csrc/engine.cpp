@@ -640,13 +640,16 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   const size_t lev_off_b = ops_off + ((nops * sizeof(NvOp) + 15) & ~(size_t)15);
   const size_t nlev_off = lev_off_b + ((((size_t)n_ + 2) * sizeof(int32_t) + 15) & ~(size_t)15);
   const size_t total_b = nlev_off + 64;
-  HIPCHK(h_vstage_.reserve(total_b));
+  // the topology array and the prune records stay in pinned host memory of their own (k_sched reads them over the bus: 40 KB,
+  // no copy dispatch in front of the launch; nothing else writes this buffer, and a result of the launch is waited for before
+  // the next one is prepared)
+  HIPCHK(h_kstage_.reserve(ops_off));
   HIPCHK(d_vstage_.reserve(total_b));
-  std::memcpy(h_vstage_.p, kids_host_.data(), kids_bytes);
+  std::memcpy(h_kstage_.p, kids_host_.data(), kids_bytes);
   uint8_t *src = d_vstage_.p;
   SweepDescArgs sw;
   if (n_prune) {
-    uint32_t *np = reinterpret_cast<uint32_t *>(h_vstage_.p + nodep_off);
+    uint32_t *np = reinterpret_cast<uint32_t *>(h_kstage_.p + nodep_off);
     for (size_t i = 0; i < n_prune; i++) np[i] = slot(nodep_[i + 1]);
     const size_t cap = 8 * n_prune;              // a prune node has two neighbourhoods of at most four parts ...
     HIPCHK(d_walk_.reserve(cap));
@@ -654,7 +657,7 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
     HIPCHK(h_dsw_.reserve(4 + cap));
     HIPCHK(d_prog_.reserve(scan_prog_bytes((int)cap)));
     HIPCHK(reserve_results(cap * 63));           // ... of at most 2^6 - 1 insertion tests each (everything the launches below touch is in place now)
-    sw.nodep = reinterpret_cast<const uint32_t *>(src + nodep_off);
+    sw.nodep = reinterpret_cast<const uint32_t *>(h_kstage_.p + nodep_off);
     sw.n_prune = (uint32_t)n_prune;
     sw.maxtrav = (uint32_t)sweep_maxtrav;
     sw.split_cands = (uint32_t)std::max(0, split_cands_);
@@ -670,7 +673,6 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
     walk_out_ = 0;
     sweep_cache_valid_ = false;
   }
-  HIPCHK(hipMemcpyAsync(d_vstage_.p, h_vstage_.p, n_prune ? ops_off : kids_bytes, hipMemcpyHostToDevice, st_));
   kids_dirty_ = false;
   kids_upload_ = false;
   kids_dev_ready_ = true;
@@ -683,7 +685,8 @@ int Engine::schedule_views_dev(int sweep_maxtrav)
   zeroed_words_ = 0;
   for (int i = 0; i < 2; i++) ride_[i].dev = nullptr;
   cnt_on_host_ = false;
-  HIPCHK(launch_sched(st_, reinterpret_cast<const uint2 *>(src), (uint32_t)n_, (uint32_t)nops, dops, dlo, dnl, sw));
+  HIPCHK(launch_sched(st_, reinterpret_cast<const uint2 *>(h_kstage_.p), (uint32_t)n_, (uint32_t)nops, dops, dlo, dnl, sw,
+                      reinterpret_cast<uint2 *>(src)));
   if (timing_ >= 2) HIPCHK(hipEventRecord(ev2_, st_));   // (view kernel time = the refresh proper; k_sched reports its own: option sched_ticks)
   RefreshExtra x;
   x.n_lev_ptr = dnl;

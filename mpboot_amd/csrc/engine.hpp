@@ -500,6 +500,7 @@ class Engine {
   int sc_maxlev_ = 0;                           // < 0: the schedule was made on the device, its level count lives at sc_nlev_off_
   bool dev_sched_ = true;                       // option dev_sched
   bool dev_plan_ = true;                        // option dev_plan: a whole sweep's scan descriptors laid out on the device too
+  PinBuf<uint8_t> h_kstage_;                    // topology array + prune records of a device-scheduled refresh (read by k_sched from host memory)
   PinBuf<uint32_t> h_dsw_;                      // {parts, candidates, -, flag}, then the prune-node index of every part (written by k_sched)
   bool dsw_valid_ = false;                      // the descriptors on the device are k_sched's, for ...
   uint64_t dsw_walk_gen_ = 0;                   // ... this walk_gen_, ...

@@ -752,7 +752,8 @@ __device__ void sweep_desc_block(const uint2 *__restrict__ kids_g, uint32_t n, u
 // round trips per pass at ~200 cycles each).
 template <int R>
 __global__ __launch_bounds__(1024) void k_sched(const uint2 *__restrict__ kids, uint32_t n, uint32_t n_ops, NvOp *__restrict__ ops,
-                                                int32_t *__restrict__ lev_off, int32_t *__restrict__ n_lev_out, SweepDescArgs sw)
+                                                int32_t *__restrict__ lev_off, int32_t *__restrict__ n_lev_out, SweepDescArgs sw,
+                                                uint2 *__restrict__ kids_copy)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
   __shared__ uint32_t s_flag[3], s_max, s_wsum[32];
@@ -776,6 +777,7 @@ __global__ __launch_bounds__(1024) void k_sched(const uint2 *__restrict__ kids, 
   for (int j = 0; j < R; j++) {
     const uint32_t c = n + tid + 1024u * (uint32_t)j;
     kk[j] = c < ns ? kids[c] : make_uint2(0u, 0u);
+    if (kids_copy && c < ns) kids_copy[c] = kk[j];         // (kids came from pinned host memory: the device copy for the kernels behind)
   }
 #pragma unroll
   for (int j = 0; j < R; j++) {
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(1024) void k_sched(const uint2 *__restrict__ kids, 
 }
 
 hipError_t launch_sched(hipStream_t st, const uint2 *kids, uint32_t n_taxa, uint32_t n_ops, NvOp *ops, int32_t *lev_off, int32_t *n_lev,
-                        const SweepDescArgs &sw)
+                        const SweepDescArgs &sw, uint2 *kids_copy)
 {
   if (n_taxa + n_ops > kSchedMaxSlots) return hipErrorInvalidValue;
   if (sw.nodep && (sw.maxtrav < 1u || sw.maxtrav > 6u)) return hipErrorInvalidValue;
@@ -881,7 +883,7 @@ hipError_t launch_sched(hipStream_t st, const uint2 *kids, uint32_t n_taxa, uint
         attr_dev = dev;                                                                                                                 \
       }                                                                                                                                 \
     }                                                                                                                                   \
-    hipLaunchKernelGGL((k_sched<R_>), dim3(sw.nodep ? 2 : 1), dim3(1024), lds, st, kids, n_taxa, n_ops, ops, lev_off, n_lev, sw);       \
+    hipLaunchKernelGGL((k_sched<R_>), dim3(sw.nodep ? 2 : 1), dim3(1024), lds, st, kids, n_taxa, n_ops, ops, lev_off, n_lev, sw, kids_copy);       \
   } while (0)
   if (per <= 1u) MPF_SCHED(1);
   else if (per <= 2u) MPF_SCHED(2);

@@ -92,8 +92,11 @@ struct SweepDescArgs {
   uint32_t *hdr_host = nullptr;      // out, pinned host memory: {parts, candidates, 0, flag raised behind everything}
   uint32_t *hdr_dev = nullptr;       // out, device memory: {parts, candidates} for the kernels that follow
 };
+// kids (and sw.nodep) may be PINNED HOST memory: the two workgroups read the 8 bytes per vector over the bus themselves (no copy
+// dispatch in front of the launch); kids_copy != nullptr: the schedule workgroup leaves a copy in device memory for the kernels
+// that follow
 hipError_t launch_sched(hipStream_t st, const uint2 *kids, uint32_t n_taxa, uint32_t n_ops, NvOp *ops, int32_t *lev_off, int32_t *n_lev,
-                        const SweepDescArgs &sw = SweepDescArgs());
+                        const SweepDescArgs &sw = SweepDescArgs(), uint2 *kids_copy = nullptr);
 // every level in ONE launch (one 16-wave workgroup per tile, workgroup barrier between levels)
 // Fitch mode also folds the per-tile counts into cnt[dst] (last workgroup; `done` = a zeroed device word, left zeroed);
 // weighted mode leaves that to launch_cntsum
