@@ -389,7 +389,8 @@ void Engine::node_rectifier()
 {
   start_ = nodep_[1];
   int count = 0;
-  std::vector<int> stack;
+  std::vector<int> &stack = sv_stack_;             // (a member: this runs once per sweep, an allocation would show)
+  stack.clear();
   stack.push_back(back_[start_]);
   while (!stack.empty()) {
     const int p = stack.back();
