@@ -56,17 +56,18 @@ def offline_traffic(workload: str, kernel_prefix: str):
     for k, v in LIVE_TRAFFIC.items():               # measured at the start of this run
         if k.startswith(kernel_prefix):
             return v
-    path = os.path.join(ROOT, "profiles", "r3", "traffic.json")
-    try:
-        with open(path) as f:
-            tj = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if tj.get("workload") != workload or tj.get("source_hash") != source_hash():
-        return None
-    for k, v in tj.get("kernels", {}).items():
-        if k.startswith(kernel_prefix):
-            return v.get("bytes_per_launch")
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):      # newest round first
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if tj.get("workload") != workload or tj.get("source_hash") != source_hash():
+            continue
+        for k, v in tj.get("kernels", {}).items():
+            if k.startswith(kernel_prefix):
+                return v.get("bytes_per_launch")
     return None
 
 
@@ -89,8 +90,8 @@ def live_traffic(args) -> dict:
     env["MPF_BENCH_TRAFFIC_CHILD"] = "1"
     env.setdefault("TMPDIR", "/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu", "--bootstrap-replicates", "0",
-             "--ufboot-samples", "0", "--random-start-leg", "0", "--workload", args.workload, "--maxtrav", str(args.maxtrav),
-             "--tree-cache", os.path.join(tmp, "tree")]
+             "--ufboot-samples", "0", "--random-start-leg", "0", "--weighted-leg", "0", "--start-trees", "0", "--climb-engines", "0",
+             "--workload", args.workload, "--maxtrav", str(args.maxtrav), "--tree-cache", os.path.join(tmp, "tree")]
     for kv in args.opt:
         child += ["--opt", kv]
     acc = {}
@@ -112,17 +113,23 @@ def live_traffic(args) -> dict:
                             continue
                         name = row["Kernel_Name"].replace("void ", "").replace("mpf::", "")
                         key = name.split("<")[0].split("(")[0]
-                        acc.setdefault(key, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+                        acc.setdefault(key, {}).setdefault(counter, []).append((int(row.get("Grid_Size") or 0), float(row["Counter_Value"])))
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    def sweep_mean(rows):
+        # only the dispatches of the timed sweep: the child runs nothing but sweep steps (every secondary leg is off), and of those
+        # only the launches with the kernel's most frequent grid count (a start-tree build that was not cached would add small ones)
+        grids = [g for g, _ in rows]
+        mode = max(set(grids), key=grids.count)
+        vals = [x for g, x in rows if g == mode]
+        return sum(vals) / len(vals)
+
     out = {}
     for key, v in acc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            fetch = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
-            write = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-            out[key] = int((2.0 * fetch + write) * 1024)
+            out[key] = int((2.0 * sweep_mean(v["FETCH_SIZE"]) + sweep_mean(v["WRITE_SIZE"])) * 1024)
     return out
 
 
@@ -441,7 +448,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
-    traffic_source = "profiles/r3/traffic.json (rocprofv3 --pmc passes of tools/profile_gpu.sh on the same sources)"
+    traffic_source = "profiles/r*/traffic.json (rocprofv3 --pmc passes of tools/profile_gpu.sh on the same sources)"
     # (under a profiler this process may hold the GPU already -- the counter tool initialises it before main() -- and must not
     #  start programs any more: the committed figures are quoted then)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
