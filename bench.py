@@ -350,6 +350,54 @@ def climb_cpu_baseline(names, letters, alphabet, back, maxtrav):
     return None
 
 
+def shim_climb_leg(eng, names, letters, alphabet, back, maxtrav, reps=3):
+    """pllOptimizeSprParsimony THROUGH the reference-side binding: oracle/_ref/spr_shim_driver is the reference's own PLL program
+    (alignment parser, pllInstance, Newick reader, SPRNG generator -- compiled from the reference's sources) linked with
+    integration/sprparsimony_shim.cpp instead of sprparsimony.cpp; its `time` mode puts the start tree into the pllInstance and times
+    the call itself (topology marshalled in and out, the SPRNG state handed over and taken back).  The same call is then replayed on
+    this process's engine from the topology the driver printed: score, number of moves and the generator's final state must agree."""
+    from mpboot_amd import engine, synth, trees
+    drv = os.path.join(ROOT, "oracle", "_ref", "spr_shim_driver")
+    if not (os.path.exists(drv) and os.access(drv, os.X_OK)):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            aln, tf = os.path.join(tmp, "a.phy"), os.path.join(tmp, "t.nwk")
+            synth.write_phylip(aln, synth.letters_to_text(letters, alphabet), names)
+            with open(tf, "w") as f:
+                f.write(trees.back_to_newick(back, names) + "\n")
+            out = subprocess.run([drv, "time", aln, "DNA" if alphabet == "DNA" else "WAG", "1", str(maxtrav), tf, str(reps), "1"],
+                                 capture_output=True, text=True, check=True, timeout=900).stdout
+        runs, start = [], None
+        for l in out.splitlines():
+            t = l.split()
+            if t and t[0] == "time_start_topology":
+                start = np.full(len(back), -1, dtype=np.int32)
+                for tok in t[1:]:
+                    a, b = tok.split(":")
+                    start[int(a)] = int(b)
+            elif t and t[0] == "time_climb":
+                runs.append({t[i]: (float(t[i + 1]) if t[i] == "seconds" else int(t[i + 1])) for i in range(1, len(t) - 1, 2)})
+        if not runs or start is None:
+            return None
+        eng.set_tree(start)
+        eng.reset_node_order()
+        eng.seed_ties(engine.TIE_RANDOM, 1)
+        eng.reset_stats()
+        sc = eng.optimize_spr(1, maxtrav)
+        same = all(r["score"] == sc and r["moves"] == eng.stats()["moves_applied"] and r["rng_state"] == eng.tie_state() for r in runs)
+        later = [r["seconds"] for r in runs[1:]] or [runs[0]["seconds"]]
+        return {"seconds": min(later), "seconds_each_call": [r["seconds"] for r in runs], "score": runs[-1]["score"], "moves": runs[-1]["moves"],
+                "climb_launches": runs[-1]["climb_launches"], "insertion_tests": runs[-1]["insertion_tests"],
+                "same_as_in_process_engine": bool(same),
+                "what": "the same climb through integration/sprparsimony_shim.cpp on the reference's pllInstance (oracle/_ref/spr_shim_driver time): "
+                        "wall clock around pllOptimizeSprParsimony itself, SPRNG stream handed over by state (mpf_set_tie_state) so the sweep "
+                        "loop runs in k_climb; the first call also creates the engine (tips packed, buffers allocated)"}
+    except Exception as exc:
+        print(f"[bench] shim climb leg failed ({exc})", file=sys.stderr)
+    return None
+
+
 def launch_ranks(n: int) -> int:
     """Parent of a multi-GPU run: N child ranks through torch.distributed.run (one process per GPU, RCCL), stdout relayed.
     The parent itself never touches the GPU (no torch import, no HIP call) and never re-executes itself."""
@@ -1051,6 +1099,7 @@ def main():
             res["random_start"] = nondeg
             if not args.no_cpu and world == 1:
                 nondeg["plain_climb"]["cpu_baseline"] = climb_cpu_baseline(names, letters, alphabet, back_r, args.maxtrav)
+                nondeg["plain_climb"]["through_reference_binding"] = shim_climb_leg(eng, names, letters, alphabet, back_r, args.maxtrav)
         if ufb is not None:
             algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples_local"]
             kms = ufb["reps_kernel_ms"]

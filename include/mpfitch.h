@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 3   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*) */
+#define MPF_ABI_VERSION 4   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
+                               4: mpf_set_tie_state / mpf_get_tie_state */
 
 enum {
   MPF_OK = 0,
@@ -163,6 +164,18 @@ int mpf_encode_iqtree_states(int32_t datatype, const int8_t *states, int64_t cou
    wants to share ITS stream passes a callback (drop-in inside mpboot: random_double). */
 int mpf_seed_ties(mpf_engine *e, int32_t tie_mode, int32_t seed);
 int mpf_set_rand_callback(mpf_engine *e, double (*fn)(void *), void *arg);
+/* Hand-over of the tie stream itself (ABI 4).  random_double() is SPRNG's 64-bit LCG with prime addend
+   (sprng/lcg64.c:220, :268: state = state * multiplier + prime, value = state * 2^-64); mpboot creates stream 0 of 1 with
+   the default parameter (tools.cpp:3326), i.e. MPF_LCG64_MULTIPLIER / MPF_LCG64_ADDEND (lcg64.c:63, :197;
+   primes-lcg64.c:64-68).  A host whose stream has exactly these two constants passes the generator's 64-bit state in
+   before a call and takes it back afterwards: the engine then consumes the host's stream draw for draw (ties of
+   testInsertParsimony sprparsimony.cpp:2171-2172, of the sweep :3309-3310, of saveCurrentTree iqtree.cpp:3594) WITHOUT a
+   call-back per draw -- which is what lets the whole sweep loop run on the device (a call-back keeps it on the host).
+   mpf_set_tie_state also removes an installed call-back. */
+#define MPF_LCG64_MULTIPLIER 0x27bb2ee687b0b0fdULL
+#define MPF_LCG64_ADDEND 3037000493ULL
+int mpf_set_tie_state(mpf_engine *e, uint64_t state);
+int mpf_get_tie_state(const mpf_engine *e, uint64_t *state);
 
 /* rearrangeParsimony(tr, pr, p, mintrav, maxtrav) candidates (sprparsimony.cpp:2259-2376):
    every insertion test of prune record `rec`, in the reference's DFS order (p side, then q

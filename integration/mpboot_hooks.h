@@ -19,6 +19,23 @@ class IQTree;
 
 struct mpf_mpboot_hooks {
   double (*random_double)(void);                  // tools.cpp:3363; tie-breaks consume mpboot's own SPRNG stream
+  // Hand-over of that stream (optional, both or neither).  With these two hooks the shim passes the generator's 64-bit state
+  // to the engine before every call and writes it back afterwards (mpf_set_tie_state / mpf_get_tie_state) instead of
+  // installing random_double as a per-draw call-back -- the whole sweep loop of pllOptimizeSprParsimony can then run on the
+  // device (k_climb).  rng_get_state returns 1 and fills the three words if randstream is SPRNG's lcg64 (RAN_TYPE ==
+  // RAN_SPRNG, tools.cpp:3320-3331), 0 otherwise (the shim then falls back to the call-back).  mpboot side, with SPRNG's public
+  // pack_sprng / unpack_sprng / free_sprng (sprng/sprng.h:61-62; layout lcg64.c:486-497: gentype string, seven 4-byte big-endian
+  // integers -- the last one the prime addend --, then state and multiplier as 8-byte big-endian words):
+  //     static int hk_rng_get(uint64_t *st, uint64_t *mul, uint64_t *add) {
+  //       char *b; if (pack_sprng(randstream, &b) <= 0) return 0;
+  //       const unsigned char *p = (const unsigned char *)b + strlen(b) + 1;
+  //       *add = be(p + 24, 4); *st = be(p + 28, 8); *mul = be(p + 36, 8); free(b); return 1; }
+  //     static void hk_rng_set(uint64_t st) {
+  //       char *b; pack_sprng(randstream, &b); put_be((unsigned char *)b + strlen(b) + 1 + 28, st, 8);
+  //       free_sprng(randstream); randstream = unpack_sprng(b); free(b); }
+  // (oracle/spr_shim_driver.cpp has exactly this code running against the reference's own SPRNG objects.)
+  int (*rng_get_state)(uint64_t *state, uint64_t *multiplier, uint64_t *addend);
+  void (*rng_set_state)(uint64_t state);
   int (*ratchet_climb)(IQTree *);                 // sprparsimony.cpp:3249 (re-weighted climb: refresh tr->aliaswgt)
   int (*on_opt_btree)(IQTree *);                  // sprparsimony.cpp:3253
   int (*pattern_frequency)(IQTree *, int ptn);    // sprparsimony.cpp:3026 (_updateInternalPllOnRatchet)

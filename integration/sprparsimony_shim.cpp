@@ -75,6 +75,31 @@ bool g_tracking = false;                   // online UFBoot bookkeeping attached
 
 double draw(void *) { return g_hooks.random_double(); }
 
+// The tie stream for the duration of one engine call.  mpboot draws every tie-break of the parsimony search from ONE
+// random_double() stream (tools.cpp:3363-3368; sprparsimony.cpp:2171-2172, :3004, :3309-3310; iqtree.cpp:3594).  When the host
+// can name the generator's state (hooks rng_get_state / rng_set_state) and it is the lcg64 the engine implements, the state
+// travels with the call: in before, out after -- nothing on the mpboot side draws while the engine runs (saveCurrentTree's
+// draws are made by the engine itself; ufboot_sync is called after the state is back).  Otherwise every draw is a call-back
+// and the sweep loop stays on the host.
+bool g_stream_lent = false;
+void lend_stream()
+{
+  uint64_t st = 0, mul = 0, add = 0;
+  g_stream_lent = g_hooks.rng_get_state && g_hooks.rng_set_state && g_hooks.rng_get_state(&st, &mul, &add) &&
+                  mul == MPF_LCG64_MULTIPLIER && add == MPF_LCG64_ADDEND;
+  if (g_stream_lent) {
+    if (mpf_set_tie_state(g_eng, st)) die("mpf_set_tie_state");
+  } else if (mpf_set_rand_callback(g_eng, draw, nullptr)) die("mpf_set_rand_callback");
+}
+void return_stream()
+{
+  if (!g_stream_lent) return;
+  uint64_t st = 0;
+  if (mpf_get_tie_state(g_eng, &st)) die("mpf_get_tie_state");
+  g_hooks.rng_set_state(st);
+  g_stream_lent = false;
+}
+
 // record id = 3 * number + slot; slot = position in the `next` ring counted from the record nodep[number] pointed to when
 // the instance was created (the three records of an inner node are contiguous, pllrepo/src/utils.c:2019-2044)
 int rec_of(pllInstance *tr, nodeptr p)
@@ -120,8 +145,7 @@ void ensure_engine(pllInstance *tr, partitionList *pr)
       if (pllCostNstates != mpf_states_of(cfg.datatype)) { std::fprintf(stderr, "mpfitch shim: cost matrix of %d states on %d-state data\n", pllCostNstates, mpf_states_of(cfg.datatype)); std::exit(EXIT_FAILURE); }
       if (mpf_engine_create_sankoff(&g_eng, &cfg, codes.data(), tr->aliaswgt, pllCostMatrix)) die("mpf_engine_create_sankoff");
     } else if (mpf_engine_create(&g_eng, &cfg, codes.data(), tr->aliaswgt)) die("mpf_engine_create");
-    if (mpf_set_rand_callback(g_eng, draw, nullptr)) die("mpf_set_rand_callback");
-    if (mpf_seed_ties(g_eng, MPF_TIE_RANDOM, 0)) die("mpf_seed_ties");
+    if (mpf_seed_ties(g_eng, MPF_TIE_RANDOM, 0)) die("mpf_seed_ties");     // (the stream itself: lend_stream() before every call)
     g_n = n;
     g_P = P;
     g_weights.assign(tr->aliaswgt, tr->aliaswgt + P);
@@ -233,7 +257,9 @@ void _pllComputeRandomizedStepwiseAdditionParsimonyTree(pllInstance *tr, partiti
   ensure_engine(tr, pr);
   // perSiteScores = PLL_FALSE here (:3228): the engine's tree builder never runs the UFBoot bookkeeping
   uint32_t score = 0;
+  lend_stream();
   if (mpf_make_parsimony_tree(g_eng, (int64_t)tr->randomNumberSeed, sprDist, &score)) die("mpf_make_parsimony_tree");
+  return_stream();
   // makePermutationFast (:2221-2242) draws one randum() per taxon from tr->randomNumberSeed: leave the seed where the
   // reference leaves it, for whoever draws from it next
   for (int i = 1; i <= tr->mxtips; i++) (void)randum(&tr->randomNumberSeed);
@@ -266,7 +292,9 @@ int pllOptimizeSprParsimony(pllInstance *tr, partitionList *pr, int mintrav, int
     }
   }
   uint32_t score = 0;
+  lend_stream();
   if (mpf_optimize_spr(g_eng, mintrav, maxtrav, &score)) die("mpf_optimize_spr");
+  return_stream();
   pull_tree(tr);
   tr->bestParsimony = score;
   // (a climb that was booked: on the original weights always, on perturbed ones unless -no_hclimb1_bb)

@@ -165,6 +165,22 @@ int mpf_seed_ties(mpf_engine *e, int32_t tie_mode, int32_t seed)
 
 int mpf_set_rand_callback(mpf_engine *e, double (*fn)(void *), void *arg) { NEED(e); e->eng.set_rand(fn, arg); return MPF_OK; }
 
+int mpf_set_tie_state(mpf_engine *e, uint64_t state)
+{
+  NEED(e);
+  e->eng.set_rand(nullptr, nullptr);
+  e->eng.set_tie_state(state);
+  return MPF_OK;
+}
+
+int mpf_get_tie_state(const mpf_engine *e, uint64_t *state)
+{
+  NEED(e);
+  if (!state) { set_error("null argument"); return MPF_E_INVALID; }
+  *state = e->eng.tie_state();
+  return MPF_OK;
+}
+
 int mpf_spr_scan(mpf_engine *e, int32_t rec, int32_t mintrav, int32_t maxtrav, int32_t cap, int32_t *q_recs,
                  uint32_t *mp, int32_t *n_p, int32_t *n_total)
 {

@@ -251,6 +251,8 @@ class Engine {
   // ---- search (host/search.cpp)
   void seed_ties(int mode, int seed) { tie_mode_ = mode; rng_.seed(seed); }
   void set_rand(double (*fn)(void *), void *arg) { rand_fn_ = fn; rand_arg_ = arg; }
+  void set_tie_state(uint64_t s) { rng_.state = s; }
+  uint64_t tie_state() const { return rng_.state; }
   int optimize_spr(int mintrav, int maxtrav, uint32_t *score);
   int make_parsimony_tree(int64_t seed, int spr_dist, uint32_t *score);
   int stepwise_addition(int64_t seed, uint32_t *best_per_step, int32_t *insert_per_step, uint32_t *score);

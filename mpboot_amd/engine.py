@@ -21,7 +21,7 @@ EXPORTS = [
     "mpf_set_weights",
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
     "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_site_scores", "mpf_compute_parsimony",
-    "mpf_encode_iqtree_states", "mpf_seed_ties",
+    "mpf_encode_iqtree_states", "mpf_seed_ties", "mpf_set_tie_state", "mpf_get_tie_state",
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
@@ -96,6 +96,8 @@ def load_library():
         L.mpf_compute_parsimony.argtypes = [vp, vp, vp, vp]
         L.mpf_encode_iqtree_states.argtypes = [C.c_int32, vp, C.c_int64, vp]
         L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
+        L.mpf_set_tie_state.argtypes = [vp, C.c_uint64]
+        L.mpf_get_tie_state.argtypes = [vp, vp]
         L.mpf_spr_scan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_spr_sweep_scan.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
         L.mpf_spr_sweep_costs.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp]
@@ -327,6 +329,15 @@ class FitchEngine:
 
     def seed_ties(self, mode: int, seed: int = 1):
         _chk(load_library().mpf_seed_ties(self.h, mode, seed))
+
+    def set_tie_state(self, state: int):
+        """Hand the 64-bit state of the host's SPRNG lcg64 stream over (mpf_set_tie_state)."""
+        _chk(load_library().mpf_set_tie_state(self.h, state & ((1 << 64) - 1)))
+
+    def tie_state(self) -> int:
+        s = C.c_uint64()
+        _chk(load_library().mpf_get_tie_state(self.h, C.byref(s)))
+        return int(s.value)
 
     def site_scores(self, n_sites: int):
         """pllComputeSiteParsimony: lengths per expanded (weight-replicated) site of the kept patterns."""

@@ -597,6 +597,8 @@ void orc_seed_ties(orc *o, int tie_mode, int seed)
   o->tie_mode = tie_mode;
   orc_lcg64_init(&o->rng, seed);
 }
+void orc_set_tie_state(orc *o, unsigned long long state) { o->rng.state = state; }
+unsigned long long orc_get_tie_state(const orc *o) { return o->rng.state; }
 void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg) { o->rand_fn = fn; o->rand_arg = arg; }
 void orc_set_pre_evaluate(orc *o, int mode) { o->pre_eval = mode; }
 

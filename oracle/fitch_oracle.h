@@ -52,6 +52,9 @@ int orc_pattern_scores(orc *o, unsigned short *ptn /* [P] */);  /* returns sum(p
 int orc_site_scores(orc *o, int *site_pars, int nsite);         /* pllComputeSiteParsimony; returns the sum */
 
 void orc_seed_ties(orc *o, int tie_mode, int seed);
+/* the 64-bit state of the restated lcg64 tie stream (rng.h), for hand-over tests */
+void orc_set_tie_state(orc *o, unsigned long long state);
+unsigned long long orc_get_tie_state(const orc *o);
 void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg);
 /* the evaluateParsimony(p) at the top of rearrangeParsimony (sprparsimony.cpp:2285; absent from the PLL original):
    -1 = as the tie mode's variant has it, 0 = off, 1 = on */

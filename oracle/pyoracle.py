@@ -63,6 +63,9 @@ def lib():
         L.orc_site_scores.restype = ci
         L.orc_site_scores.argtypes = [vp, vp, ci]
         L.orc_seed_ties.argtypes = [vp, ci, ci]
+        L.orc_set_tie_state.argtypes = [vp, C.c_ulonglong]
+        L.orc_get_tie_state.restype = C.c_ulonglong
+        L.orc_get_tie_state.argtypes = [vp]
         L.orc_set_pre_evaluate.argtypes = [vp, ci]
         L.orc_trace.argtypes = [vp, ci]
         L.orc_trace_get.argtypes = [vp, vp, vp]
@@ -206,6 +209,12 @@ class Oracle:
 
     def seed_ties(self, mode: int, seed: int = 1):
         lib().orc_seed_ties(self.h, mode, seed)
+
+    def set_tie_state(self, state: int):
+        lib().orc_set_tie_state(self.h, state & ((1 << 64) - 1))
+
+    def tie_state(self) -> int:
+        return int(lib().orc_get_tie_state(self.h))
 
     def set_pre_evaluate(self, mode: int):
         lib().orc_set_pre_evaluate(self.h, int(mode))

@@ -9,7 +9,8 @@
  *     pllCalcMinParsScorePattern                           (iqtree.cpp:3827)
  * and prints what they leave in the pllInstance.  tests/test_gpu_dropin.py replays the same calls on the CPU oracle.
  *
- * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B> [cost-matrix file | - [no_hclimb1_bb]]
+ * usage: spr_shim_driver <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B> [cost-matrix file | - [no_hclimb1_bb
+ *                         [mulhits [storetrees [stream hand-over: 1 (default) = rng_get_state / rng_set_state hooks, 0 = per-draw call-back only]]]]]
  * With a cost matrix (S x S unsigned entries, row-major) the program sets the globals IQTree::initializePLL sets for -cost
  * (iqtree.cpp:601-615) and calls initializeCostMatrix(): the shim then dispatches to the weighted engine.
  */
@@ -54,6 +55,45 @@ struct Host {
 static Host H;
 
 static double hk_random(void) { return sprng(H.stream); }
+// the stream's state through SPRNG's public pack / unpack interface (sprng/sprng.h:61-62; layout sprng/lcg64.c:486-497)
+static uint64_t be_load(const unsigned char *p, int nbytes)
+{
+  uint64_t v = 0;
+  for (int i = 0; i < nbytes; i++) v = (v << 8) | p[i];
+  return v;
+}
+static int hk_rng_get(uint64_t *st, uint64_t *mul, uint64_t *add)
+{
+  char *b = nullptr;
+  if (pack_sprng(H.stream, &b) <= 0 || !b) return 0;
+  const unsigned char *p = (const unsigned char *)b + std::strlen(b) + 1;
+  *add = be_load(p + 24, 4);
+  *st = be_load(p + 28, 8);
+  *mul = be_load(p + 36, 8);
+  std::free(b);
+  return 1;
+}
+static void hk_rng_set(uint64_t st)
+{
+  char *b = nullptr;
+  if (pack_sprng(H.stream, &b) <= 0 || !b) { std::fprintf(stderr, "pack_sprng failed\n"); std::exit(2); }
+  unsigned char *p = (unsigned char *)b + std::strlen(b) + 1 + 28;
+  for (int i = 0; i < 8; i++) p[i] = (unsigned char)(st >> (8 * (7 - i)));
+  free_sprng(H.stream);
+  H.stream = unpack_sprng(b);
+  std::free(b);
+}
+// what the host's stream and the engine look like after a call: the generator's state (the NEXT random_double() follows from
+// it) and how many persistent climb kernels the engine has launched so far
+static void print_stream(const char *tag)
+{
+  uint64_t st = 0, mul = 0, add = 0;
+  hk_rng_get(&st, &mul, &add);
+  mpf_stats ms;
+  std::memset(&ms, 0, sizeof ms);
+  if (mpfitch_shim_engine()) mpf_get_stats(mpfitch_shim_engine(), &ms);
+  std::printf("%s_rng_state %llu\n%s_climb_launches %llu\n", tag, (unsigned long long)st, tag, (unsigned long long)ms.climb_launches);
+}
 static int hk_ratchet(IQTree *) { return H.ratchet; }
 static int hk_opt_btree(IQTree *) { return 0; }
 static int hk_freq(IQTree *, int ptn) { return H.freq[(size_t)ptn]; }
@@ -113,9 +153,11 @@ static void print_tree(const char *tag, pllInstance *tr)
   std::printf("\n");
 }
 
-int main(int argc, char **argv)
+static pllInstance *tr = nullptr;
+static partitionList *pr = nullptr;
+
+static void load(const char *file, const char *model, int dedup)
 {
-  if (argc < 8) { std::fprintf(stderr, "usage: %s <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B>\n", argv[0]); return 2; }
   pllInstanceAttr attr;
   std::memset(&attr, 0, sizeof attr);
   attr.rateHetModel = PLL_GAMMA;
@@ -124,18 +166,89 @@ int main(int argc, char **argv)
   attr.useRecom = PLL_FALSE;
   attr.randomNumberSeed = 12345;
   attr.numberOfThreads = 1;
-  pllInstance *tr = pllCreateInstance(&attr);
-  pllAlignmentData *aln = pllParseAlignmentFile(PLL_FORMAT_PHYLIP, argv[1]);
-  if (!aln) { std::fprintf(stderr, "cannot parse %s\n", argv[1]); return 2; }
+  tr = pllCreateInstance(&attr);
+  pllAlignmentData *aln = pllParseAlignmentFile(PLL_FORMAT_PHYLIP, file);
+  if (!aln) { std::fprintf(stderr, "cannot parse %s\n", file); std::exit(2); }
   char pstr[256];
-  std::snprintf(pstr, sizeof pstr, "%s, p1 = 1-%d\n", argv[2], aln->sequenceLength);
+  std::snprintf(pstr, sizeof pstr, "%s, p1 = 1-%d\n", model, aln->sequenceLength);
   pllQueue *parts = pllPartitionParseString(pstr);
-  if (!pllPartitionsValidate(parts, aln)) return 2;
-  partitionList *pr = pllPartitionsCommit(parts, aln);
+  if (!pllPartitionsValidate(parts, aln)) std::exit(2);
+  pr = pllPartitionsCommit(parts, aln);
   pllQueuePartitionsDestroy(&parts);
-  if (std::atoi(argv[3])) pllAlignmentRemoveDups(aln, pr);
+  if (dedup) pllAlignmentRemoveDups(aln, pr);
   pllTreeInitTopologyForAlignment(tr, aln);
-  if (!pllLoadAlignment(tr, aln, pr)) return 2;
+  if (!pllLoadAlignment(tr, aln, pr)) std::exit(2);
+}
+
+// spr_shim_driver time <aln.phy> <DNA|WAG> <sprng seed> <maxtrav> <newick file> <repetitions> [stream hand-over 1|0]
+// bench.py's leg "through the reference-side binding": pllOptimizeSprParsimony (iqtree.cpp:2132) on a pllInstance that holds the
+// tree of the Newick file, timed around the call itself -- marshalling of the topology in and out included -- once per
+// repetition from the same start tree and the same SPRNG seed (the first one also creates the engine: tips packed, buffers made).
+#include <chrono>
+static int time_main(int argc, char **argv)
+{
+  if (argc < 8) { std::fprintf(stderr, "usage: %s time <aln.phy> <DNA|WAG> <sprng seed> <maxtrav> <newick file> <repetitions> [hand-over]\n", argv[0]); return 2; }
+  load(argv[2], argv[3], 0);
+  const int seed = std::atoi(argv[4]), maxtrav = std::atoi(argv[5]), reps = std::atoi(argv[7]);
+  const bool handover = argc <= 8 || std::atoi(argv[8]);
+  FILE *f = std::fopen(argv[6], "r");
+  if (!f) { std::perror(argv[6]); return 2; }
+  static char line[1 << 22];
+  if (!std::fgets(line, sizeof line, f)) return 2;
+  std::fclose(f);
+  H.P = tr->originalCrunchedLength;
+  H.freq.assign(tr->aliaswgt, tr->aliaswgt + H.P);
+  mpf_mpboot_hooks hooks;
+  std::memset(&hooks, 0, sizeof hooks);
+  hooks.random_double = hk_random;
+  if (handover) { hooks.rng_get_state = hk_rng_get; hooks.rng_set_state = hk_rng_set; }
+  hooks.ratchet_climb = hk_ratchet;
+  hooks.on_opt_btree = hk_opt_btree;
+  hooks.pattern_frequency = hk_freq;
+  hooks.sort_alignment = 1;
+  resetGlobalParamOnNewAln();
+  mpfitch_shim_install(&hooks);
+  const int n = tr->mxtips;
+  for (int rep = 0; rep < reps; rep++) {
+    pllNewickTree *t = pllNewickParseString(line);
+    if (!t) { std::fprintf(stderr, "bad newick\n"); return 2; }
+    if (!pllValidateNewick(t)) pllNewickUnroot(t);
+    pllTreeInitTopologyNewick(tr, t, PLL_FALSE);
+    pllNewickParseDestroy(&t);
+    if (H.stream) free_sprng(H.stream);
+    H.stream = init_sprng(0, 1, seed, SPRNG_DEFAULT);
+    if (rep == 0) {                                  // the start tree as record links, for whoever wants to replay the call
+      std::printf("time_start_topology");
+      for (int v = 1; v <= 2 * n - 2; v++)
+        for (int s = 0; s < (v <= n ? 1 : 3); s++) {
+          nodeptr p = v <= n ? tr->nodeBaseAddress + (v - 1) : tr->nodeBaseAddress + n + 3 * (v - n - 1) + (2 - s);
+          std::printf(" %d:%d", 3 * v + s, rec_of(tr, p->back));
+        }
+      std::printf("\n");
+    }
+    mpf_stats m0, m1;
+    std::memset(&m0, 0, sizeof m0);
+    std::memset(&m1, 0, sizeof m1);
+    if (mpfitch_shim_engine()) mpf_get_stats(mpfitch_shim_engine(), &m0);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int score = pllOptimizeSprParsimony(tr, pr, 1, maxtrav, nullptr);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    mpf_get_stats(mpfitch_shim_engine(), &m1);
+    uint64_t st = 0, mul = 0, add = 0;
+    hk_rng_get(&st, &mul, &add);
+    std::printf("time_climb rep %d seconds %.6f score %d moves %llu climb_launches %llu insertion_tests %llu rng_state %llu\n", rep, dt, score,
+                (unsigned long long)(m1.moves_applied - m0.moves_applied), (unsigned long long)(m1.climb_launches - m0.climb_launches),
+                (unsigned long long)(m1.insertion_tests - m0.insertion_tests), (unsigned long long)st);
+  }
+  resetGlobalParamOnNewAln();
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc > 1 && !std::strcmp(argv[1], "time")) return time_main(argc, argv);
+  if (argc < 8) { std::fprintf(stderr, "usage: %s <aln.phy> <DNA|WAG> <dedup> <sprng seed> <pll seed> <maxtrav> <B>\n", argv[0]); return 2; }
+  load(argv[1], argv[2], std::atoi(argv[3]));
   const int maxtrav = std::atoi(argv[6]);
   const int P = tr->originalCrunchedLength, n = tr->mxtips;
   H.stream = init_sprng(0, 1, std::atoi(argv[4]), SPRNG_DEFAULT);      // init_random, tools.cpp:3326
@@ -152,6 +265,10 @@ int main(int argc, char **argv)
   mpf_mpboot_hooks hooks;
   std::memset(&hooks, 0, sizeof hooks);
   hooks.random_double = hk_random;
+  if (argc <= 12 || std::atoi(argv[12])) {
+    hooks.rng_get_state = hk_rng_get;
+    hooks.rng_set_state = hk_rng_set;
+  }
   hooks.ratchet_climb = hk_ratchet;
   hooks.on_opt_btree = hk_opt_btree;
   hooks.pattern_frequency = hk_freq;
@@ -186,6 +303,7 @@ int main(int argc, char **argv)
   tr->randomNumberSeed = std::atol(argv[5]);
   _pllComputeRandomizedStepwiseAdditionParsimonyTree(tr, pr, 0, iq);
   print_tree("ras", tr);
+  print_stream("ras");
   std::printf("ras_seed_after %ld\nras_nodep", (long)tr->randomNumberSeed);
   for (int i = 1; i <= 2 * n - 2; i++) std::printf(" %d", rec_of(tr, tr->nodep[i]));
   std::printf("\n");
@@ -194,6 +312,7 @@ int main(int argc, char **argv)
   H.cur_score = -(double)tr->bestParsimony;
   pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);
   print_tree("spr", tr);
+  print_stream("spr");
   {
     std::vector<unsigned short> pp((size_t)P + 16, 65535);
     int cur = 0;
@@ -223,9 +342,11 @@ int main(int argc, char **argv)
   mpfitch_shim_install(&hooks);
   pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);
   print_tree("ratchet", tr);
+  print_stream("ratchet");
   H.freq = w0;
   pllOptimizeSprParsimony(tr, pr, 1, maxtrav, iq);   // on_ratchet_hclimb2: original weights again
   print_tree("final", tr);
+  print_stream("final");
   _pllFreeParsimonyDataStructures(tr, pr);
   resetGlobalParamOnNewAln();
   return 0;
