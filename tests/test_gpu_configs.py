@@ -335,3 +335,94 @@ def test_c4_sample_sharded_online_phase_equals_unsharded(c4, tmp_path, n_samples
     assert got["saved"] == single.ufboot_tree_logl().tolist()
     assert got["final"] == single.get_tree().tolist()
     assert got["draws"] == single.ufboot_counters()["tie_draws"]
+
+
+# ------------------------------------------------------------------------------------------------ C3: the climbs bench.py times
+
+def _climb(codes, dt, back, mode, tile, seed=1):
+    from mpboot_amd import engine
+    e = engine.FitchEngine(codes, datatype=dt)
+    e.set_option("climb_device", mode)
+    e.set_option("climb_tile", tile)
+    e.set_tree(back)
+    e.reset_node_order()
+    e.seed_ties(engine.TIE_RANDOM, seed)
+    s = e.optimize_spr(1, 6)
+    return e, s, [x.tolist() for x in e.moves()]
+
+
+@pytest.fixture(scope="module")
+def c3_climb():
+    """BASELINE config 3's alignment, the random start tree of bench.py's random_start leg, and the climb from it with the sweep
+    loop on the host (host-driven whole-chip batches: the path pinned move for move against the oracle on the fixtures and at C2)"""
+    from mpboot_amd import trees
+    codes, dt = _workload("C3")
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(2024))
+    e, s, moves = _climb(codes, dt, back, 0, 1)
+    assert e.stats()["climb_launches"] == 0 and len(moves[0]) > 3000
+    return codes, dt, back, s, moves, e.get_tree().tolist(), e.tie_state()
+
+
+@pytest.mark.parametrize("tile", [1, 4])
+def test_c3_device_climb_equals_host_batches(c3_climb, tile):
+    """random_start.plain_climb of bench.py at full size: the persistent kernel (98 co-resident workgroups at VW = 1, 25 at VW = 4,
+    candidate lengths exchanged through the three-generation 64-bit atomic ring across the XCDs) accepts exactly the moves the
+    host-driven loop accepts -- the whole list, the final topology and the state the tie stream is left in."""
+    codes, dt, back, s, moves, final, rng = c3_climb
+    for mode in (1, 2):                               # auto (hands sparse sweeps back to the host) and always-in-kernel
+        e, sd, md = _climb(codes, dt, back, mode, tile)
+        st = e.stats()
+        assert st["climb_launches"] >= 1 and st["climb_moves"] > 3000
+        assert sd == s
+        assert md == moves
+        assert e.get_tree().tolist() == final
+        assert e.tie_state() == rng
+
+
+def test_c3_eight_concurrent_device_climbs_equal_their_solo_runs(c3_climb):
+    """bench.py's concurrent_climbs leg: eight engines on eight host threads, 64-word tiles (25 workgroups per climb, the launches
+    admitted together and polling each other's exchange rings on one chip) -- every engine's moves are those of its solo run."""
+    import threading
+    from mpboot_amd import engine, trees
+    codes, dt, back0, _s, _m, _f, _r = c3_climb
+    n = codes.shape[0]
+    K = 8
+    backs = [back0] + [trees.random_topology(n, np.random.default_rng(3000 + k)) for k in range(1, K)]
+    engines = []
+    for k in range(K):
+        e = engine.FitchEngine(codes, datatype=dt)
+        e.set_option("climb_device", 1)
+        e.set_option("climb_tile", 4)
+        engines.append(e)
+    solo = []
+    for k in range(K):
+        e = engines[k]
+        e.set_tree(backs[k]); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 10 + k)
+        s = e.optimize_spr(1, 6)
+        solo.append((s, [x.tolist() for x in e.moves()], e.get_tree().tolist()))
+    if True:
+        # the first tree twice: solo with tile 4 == the host-driven reference of the fixture (seed 1)
+        e = engines[0]
+        e.set_tree(backs[0]); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1)
+        assert e.optimize_spr(1, 6) == _s and [x.tolist() for x in e.moves()] == _m
+    got, errs = [None] * K, []
+
+    def work(k):
+        try:
+            e = engines[k]
+            e.set_tree(backs[k]); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 10 + k)
+            e.reset_stats()
+            s = e.optimize_spr(1, 6)
+            got[k] = (s, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.stats()["climb_launches"])
+        except Exception as exc:                      # noqa: BLE001
+            errs.append((k, repr(exc)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(K):
+        assert got[k][3] >= 1
+        assert got[k][:3] == solo[k], f"engine {k} diverged from its solo run"

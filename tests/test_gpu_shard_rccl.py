@@ -43,3 +43,101 @@ def test_shard_collectives_on_rccl_single_rank():
     assert res["empty"] == []
     assert res["best"][0] == 5 and res["best"][2] == 9 and res["best"][1] > 2 ** 62
     assert res["tree"] == list(range(12))
+
+
+# ---- two real RCCL ranks (one GPU each).  The pool's boxes have ONE GPU, so this skips there; it runs the first time the suite
+# meets a node with two or more -- the driver's multi-GPU box -- and covers what the gloo tests cannot: device tensors through
+# RCCL over xGMI in the event exchange, the best-score all-reduce, the tree broadcast, and BASELINE config 4's sample-sharded
+# online phase with one engine per GPU.
+RCCL2_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MPF_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+rank, ws = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+lr = int(os.environ.get("LOCAL_RANK", rank))
+torch.cuda.set_device(lr)
+dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+from mpboot_amd import engine, shard, synth, trees
+out = {}
+SIZES = [5, 0, 3, 17, shard.EVENT_BLOCK + 9, shard.EVENT_BLOCK]
+g = []
+for rnd in range(6):
+    rng = np.random.default_rng(100 * rnd + rank)
+    n = SIZES[(rnd + rank) % 6] if rnd != 2 else 0
+    local = rng.integers(0, 2 ** 32 - 1, size=(n, 3), dtype=np.uint64).astype(np.uint32)
+    g.append(sorted(map(tuple, shard.gather_events(local, tag=1000 + rnd).tolist())))
+out["gather"] = g
+out["best"] = [int(x) for x in shard.reduce_best({rank: 100 + rank, 2: 7 if rank == 1 else 9}, 3)[0]]
+out["tree"] = shard.broadcast_tree(np.arange(12, dtype=np.int32) * (1 if rank == 0 else -1), 0, 12).tolist()
+# the sample-sharded online UFBoot phase: one engine per GPU, every second sample each
+letters, _ = synth.synth_alignment(40, 2000, "DNA", 0.08, seed=21)
+codes = synth.letters_to_codes(letters, "DNA")
+P = codes.shape[1]
+samples = np.random.default_rng(7).multinomial(P, np.ones(P) / P, size=64).astype(np.uint16)
+back = trees.random_topology(40, np.random.default_rng(5))
+e = engine.FitchEngine(codes, device=lr)
+e.ufboot_attach(samples, 0.5, shard=(rank, ws))
+e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1)
+s = e.optimize_spr(1, 6)
+logl, cnt, tr = e.ufboot_state()
+res = {"s": s, "logl": logl.tolist(), "cnt": cnt.tolist(), "tr": tr.tolist(), "final": e.get_tree().tolist(),
+       "draws": e.ufboot_counters()["tie_draws"]}
+allr = [None] * ws
+dist.all_gather_object(allr, res)
+out["ranks_agree"] = all(r == allr[0] for r in allr)
+out["ufb"] = res
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+if rank == 0:
+    print("RESULT " + json.dumps(out))
+'''
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()                  # (counting does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_exchange_and_sample_sharded_online_phase(tmp_path):
+    import json
+    import socket
+
+    import numpy as np
+    from mpboot_amd import engine, shard, synth, trees
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL2_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MPF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    sizes = [5, 0, 3, 17, shard.EVENT_BLOCK + 9, shard.EVENT_BLOCK]
+    for rnd in range(6):
+        want = []
+        for rank in range(2):
+            rng = np.random.default_rng(100 * rnd + rank)
+            n = sizes[(rnd + rank) % 6] if rnd != 2 else 0
+            want += list(map(tuple, rng.integers(0, 2 ** 32 - 1, size=(n, 3), dtype=np.uint64).astype(np.uint32).tolist()))
+        assert [tuple(x) for x in got["gather"][rnd]] == sorted(want)
+    assert got["best"] == [100, 101, 7]
+    assert got["tree"] == list(range(12))
+    assert got["ranks_agree"]
+    # == the unsharded engine on this process's GPU
+    letters, _ = synth.synth_alignment(40, 2000, "DNA", 0.08, seed=21)
+    codes = synth.letters_to_codes(letters, "DNA")
+    P = codes.shape[1]
+    samples = np.random.default_rng(7).multinomial(P, np.ones(P) / P, size=64).astype(np.uint16)
+    back = trees.random_topology(40, np.random.default_rng(5))
+    e = engine.FitchEngine(codes)
+    e.ufboot_attach(samples, 0.5)
+    e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1)
+    s = e.optimize_spr(1, 6)
+    logl, cnt, tr = e.ufboot_state()
+    u = got["ufb"]
+    assert (u["s"], u["logl"], u["cnt"], u["tr"], u["final"]) == (s, logl.tolist(), cnt.tolist(), tr.tolist(), e.get_tree().tolist())
+    assert u["draws"] == e.ufboot_counters()["tie_draws"]
