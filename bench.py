@@ -747,6 +747,7 @@ def main():
     legs_error = None
     n_eng = 1
     tb_nocache = None
+    tb_persample = None
     n_distinct_trees = None
     if args.ufboot_samples > 0:
         try:
@@ -818,6 +819,13 @@ def main():
                 for x in engines:
                     x.set_option("plan_cache", 1)
                 assert (bscores_nc == bscores).all()
+                # ... and as the reference's loop has it: one re-weighting + one climb per sample (what the batched first sweep replaces)
+                barrier()
+                tb0 = time.perf_counter()
+                bscores_ps, _ = bootstrap.refine_boot_trees(engines, samples[:n_rep], boot_trees, 7, args.maxtrav, batched=False)
+                barrier()
+                tb_persample = time.perf_counter() - tb0
+                assert (bscores_ps == bscores).all()
                 eng.set_weights(np.ones(P, dtype=np.int32))
             # ---- the same flow from a start tree that is NOT a local optimum (the RAS tree of this alignment already is one:
             # zero moves above): a random topology, thousands of accepted moves, refinements that really climb
@@ -1083,14 +1091,17 @@ def main():
                 "seconds": (nondeg["bb_flow"]["seconds"] if nondeg is not None and "bb_flow" in nondeg
                             else ufb["seconds"] + boot[1] * ufb["samples"] / boot[0]),
                 "seconds_is": "random-start flow (random_start.bb_flow)" if nondeg is not None and "bb_flow" in nondeg else "flow from the RAS tree",
-                "refinement_s_plan_cache_off": tb_nocache, "distinct_boot_trees": n_distinct_trees,
+                "refinement_s_plan_cache_off": tb_nocache, "refinement_s_per_sample_climbs": tb_persample, "distinct_boot_trees": n_distinct_trees,
                 "scaling": "strong", "engines_per_gpu": n_eng,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
                 "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
-                        "samples sharded over the ranks) + refinement of every sample's tree (re-weight, re-pack, one SPR climb, radius %d; "
-                        "sample b on rank b %% n_gpus, several engines per GPU).  seconds = online + refinement scaled to all samples.  "
-                        "distinct_boot_trees = topologies the samples kept (1 here: every refinement after an engine's first re-uses "
-                        "that topology's plans); refinement_s_plan_cache_off = the same leg planning every tree from scratch"
+                        "samples sharded over the ranks) + refinement of every sample's tree (one SPR climb under the sample's weights, radius %d; "
+                        "sample b on rank b %% n_gpus).  Refinement: the first sweep of all climbs that start from one topology is computed at "
+                        "once (mpf_ufboot_refine_sweep: masked scan + mask x weight product on the matrix cores + per-sample replay of the tie "
+                        "rules; the samples' weights are uploaded and laid out inside the timed region); samples whose sweep accepts a move "
+                        "climb alone (re-weight, re-pack, SPR climb; several engines per GPU).  refinement_s_per_sample_climbs = the "
+                        "reference's loop, one re-weighting + one climb per sample; seconds = online + refinement scaled to all samples.  "
+                        "distinct_boot_trees = topologies the samples kept; refinement_s_plan_cache_off = the same leg planning every tree from scratch"
                         % (ufb["samples"], args.maxtrav)}
         if boot is not None and not args.no_cpu and world == 1:
             res["bootstrap_wall_clock"]["cpu_baseline"] = refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, bscores,

@@ -34,8 +34,8 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 4   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
-                               4: mpf_set_tie_state / mpf_get_tie_state */
+#define MPF_ABI_VERSION 5   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
+                               4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep */
 
 enum {
   MPF_OK = 0,
@@ -255,6 +255,22 @@ int mpf_remain_bounds(int32_t n_units, int32_t n_segments, const int32_t *segmen
    mpf_ufboot_set_ratchet_booking(e, 0) (-no_hclimb1_bb, :3280); weights that take an attach-time pattern out of the
    alignment altogether rest the tracker until the attach-time weights are back. */
 int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples, double epsilon);
+/* Batched bootstrap refinement -- IQTree::optimizeBootTrees' default branch (iqtree.cpp:2797-2862: per sample modifyPatternFreq
+   :2520, the parsimony structures rebuilt, ONE pllOptimizeSprParsimony from the sample's tree :2837) for every attached sample
+   whose tree is the engine's CURRENT tree, at once.  Fitch state sets do not depend on pattern weights, only the counts do: the
+   first sweep of all those climbs is one masked scan + one mask x weight product on the matrix cores; every sample's sweep
+   (testInsertParsimony's tie rule sprparsimony.cpp:2168-2176, the sweep's accept rule :3306-3311) is then replayed from the few
+   (insertion test, sample) pairs that reach the sample's running best, with the sample's own tie stream (seeded like
+   mpf_seed_ties(e, MPF_TIE_RANDOM, tie_seeds[b]); NULL: seed b).
+     scores[b]  = length of the current tree under sample b's weights (what the climb starts from)
+     stable[b]  = 1: that sweep accepts no move -- mpf_set_weights(sample b) + mpf_optimize_spr from this tree would return
+                  scores[b] and leave the tree as it is; 0: it accepts one (first_move_visit[b] = 1-based position in the sweep's
+                  visiting order, mpf_get_node_order) -- the caller runs that sample's climb alone
+   All three arrays have n_samples entries of the attach call (a sample-sharded tracker fills the entries of its own samples);
+   any may be NULL.  Needs the attach-time weights in force, the random tie rule, the Fitch engine and maxtrav <= 8.  The
+   tracker's saveCurrentTree bookkeeping is not touched.  (ABI 5) */
+int mpf_ufboot_refine_sweep(mpf_engine *e, int32_t maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable,
+                            int32_t *first_move_visit);
 /* Multi-GPU online phase: the samples are sharded over the GPUs, the search chain is not.  Every rank runs the same
    mpf_optimize_spr calls (same tree, same tie seed) on its own engine, which holds only n_local of the n_samples weight
    vectors (sample_ids[c] = run-wide index of local vector c) and so does 1/n_gpus of the REPS work.  After each scan batch

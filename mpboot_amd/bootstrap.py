@@ -69,7 +69,7 @@ def run_replicates(eng, weights, n_rep: int, base_seed: int, radius: int = 6, st
     return scores, trees
 
 
-def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6):
+def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6, batched=None, attached: bool = False):
     """The refinement step of UFBoot-MP, IQTree::optimizeBootTrees default branch (iqtree.cpp:2797-2862): for every
     bootstrap sample b the alignment is re-weighted with boot_samples_pars[b] (modifyPatternFreq :2520), the sample's
     tree from the online phase (boot_trees[b]) is read back and ONE SPR hill climb is run from it (:2837); the result
@@ -77,12 +77,23 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6)
 
     samples: [B][P] weights; boot_trees: [B][nrec] topologies (mpf_ufboot_get_tree per sample).  Sample b is refined on
     rank b % world (and on engine k of that rank's list); every replicate draws its ties from its own stream so the
-    result does not depend on the sharding.  Returns (scores[B] after the all-reduce, {b: refined tree} of this rank)."""
+    result does not depend on the sharding.
+
+    batched (default: whenever the engine offers it): the samples of this rank are grouped by start topology and the FIRST sweep
+    of every group's climbs is computed at once on engine 0 (mpf_ufboot_refine_sweep: one masked scan + one mask x weight product
+    per topology); a sample whose sweep accepts no move is done -- its climb would return the tree unchanged --, the others run
+    their climb alone as before.  Same results either way.  Engine 0 must hold the weights the samples were drawn from.
+    attached = True: the tracker of the online phase is still attached to engine 0 with exactly these samples and this sharding
+    (no second upload of the weights); it is released before any per-sample climb runs on engine 0.
+
+    Returns (scores[B] after the all-reduce, {b: refined tree} of this rank)."""
     samples = np.asarray(samples)
     B = samples.shape[0]
     rank, ws = shard.world()
     units = shard.units_of_rank(B, rank, ws)
     engines = eng if isinstance(eng, (list, tuple)) else [eng]
+    if batched is None:
+        batched = hasattr(engines[0], "ufboot_refine_sweep")
 
     def one(e, b):
         e.set_weights(samples[b].astype(np.int32))
@@ -92,14 +103,38 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6)
         return e.optimize_spr(1, radius), e.get_tree()
 
     local, trees = {}, {}
-    if len(engines) == 1:
+    todo = units
+    if batched and units:
+        e0 = engines[0]
+        if not attached:
+            e0.ufboot_attach(samples, 0.5, shard=(rank, ws))
+        e0.seed_ties(1, 0)
+        seeds = np.array([shard.unit_seed(base_seed, b) for b in range(B)], dtype=np.int64).astype(np.int32)
+        groups = {}
         for b in units:
+            groups.setdefault(np.asarray(boot_trees[b], dtype=np.int32).tobytes(), []).append(b)
+        todo = []
+        for key, members in groups.items():
+            t = np.frombuffer(key, dtype=np.int32).copy()
+            e0.reset_node_order()
+            e0.set_tree(t)
+            sc, stable, _first = e0.ufboot_refine_sweep(radius, seeds)
+            for b in members:
+                if stable[b]:
+                    local[b], trees[b] = int(sc[b]), t
+                else:
+                    todo.append(b)
+        if not attached or todo:
+            e0.ufboot_detach()                       # (a climb under an attached tracker would be booked like a search iteration)
+        todo.sort()
+    if len(engines) == 1:
+        for b in todo:
             local[b], trees[b] = one(engines[0], b)
-    else:
+    elif todo:
         from concurrent.futures import ThreadPoolExecutor
 
         def work(k):
-            return {b: one(engines[k], b) for b in units[k::len(engines)]}
+            return {b: one(engines[k], b) for b in todo[k::len(engines)]}
 
         with ThreadPoolExecutor(len(engines)) as ex:
             for part in ex.map(work, range(len(engines))):

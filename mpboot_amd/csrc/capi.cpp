@@ -321,6 +321,12 @@ int mpf_ufboot_get_tree(const mpf_engine *e, int64_t tree_index, int32_t *back)
   if (!back) { set_error("null output"); return MPF_E_INVALID; }
   return e->eng.ufboot_tree(tree_index, back);
 }
+int mpf_ufboot_refine_sweep(mpf_engine *e, int32_t maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit)
+{
+  NEED(e);
+  return e->eng.ufboot_refine_sweep(maxtrav, tie_seeds, scores, stable, first_move_visit);
+}
+
 int mpf_ufboot_get_counters(const mpf_engine *e, uint64_t *tie_draws, uint64_t *events, uint64_t *reps_rows, double *reps_kernel_ms)
 {
   NEED(e);

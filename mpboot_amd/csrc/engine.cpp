@@ -2010,6 +2010,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "refine_chunk") { refine_chunk_ = v < 1 ? 1 : (int)std::min<int64_t>(v, 1 << 30); return MPF_OK; }
   if (key == "climb_trace") { climb_trace_ = v ? 1 : 0; cd_.h_trace.clear(); cd_.trace_records = 0; return MPF_OK; }
   if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack
     snk16_opt_ = v ? 1 : 0;
@@ -2068,6 +2069,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "climb_batch_min") *v = climb_batch_min_;
   else if (key == "climb_batch_max") *v = climb_batch_max_;
   else if (key == "climb_idle") *v = climb_idle_;
+  else if (key == "refine_chunk") *v = refine_chunk_;
   else if (key == "climb_trace") *v = climb_trace_;
   else if (key.rfind("climb_ctr", 0) == 0 && key.size() == 10 && key[9] >= '0' && key[9] <= '3') *v = (int64_t)climb_ctr_[key[9] - '0'];   // refresh ops, closure rounds, invalidation rounds, chains
   else if (key.rfind("climb_phase_us", 0) == 0 && key.size() == 15 && ((key[14] >= '0' && key[14] <= '9') || (key[14] >= 'a' && key[14] <= 'f')))

@@ -262,6 +262,8 @@ class Engine {
   int ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local = -1, const int32_t *sample_ids = nullptr,
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
+  // the first sweep of pllOptimizeSprParsimony from the current tree under every attached sample's weights at once
+  int ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit);
   int ufboot_set_mulhits(int on);
   int ufboot_set_store_trees(int on);
   int ufboot_duplicates(uint64_t *n) const;
@@ -315,6 +317,7 @@ class Engine {
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int refine_chunk_ = 1 << 30;                   // prune nodes per masked scan + product of the refine sweep (option "refine_chunk")
   int spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   // online UFBoot-MP
   std::unique_ptr<UfbState> ufb_;

@@ -25,7 +25,7 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
-    "mpf_ufboot_attach", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
+    "mpf_ufboot_attach", "mpf_ufboot_refine_sweep", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
@@ -116,6 +116,7 @@ def load_library():
         L.mpf_reps_destroy.argtypes = [vp]
         L.mpf_reps_destroy.restype = None
         L.mpf_ufboot_attach.argtypes = [vp, C.c_int32, vp, C.c_double]
+        L.mpf_ufboot_refine_sweep.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
         L.mpf_ufboot_attach_sharded.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp]
         L.mpf_ufboot_detach.argtypes = [vp]
         L.mpf_ufboot_set_cutoff.argtypes = [vp, C.c_double]
@@ -424,6 +425,19 @@ class FitchEngine:
         self._ufb_exchange = exchange            # keep the ctypes callback alive as long as the tracker
         _chk(load_library().mpf_ufboot_attach_sharded(self.h, self.ufb_B, len(ids), _p(ids), _p(local), float(epsilon),
                                                       C.cast(exchange, C.c_void_p), None))
+
+    def ufboot_refine_sweep(self, maxtrav: int, tie_seeds=None):
+        """Batched bootstrap refinement (mpf_ufboot_refine_sweep): the first sweep of the SPR climb from the CURRENT tree under
+        every attached sample's weights at once -> (scores[B], stable[B] bool, first_move_visit[B])."""
+        B = self.ufb_B
+        seeds = None if tie_seeds is None else np.ascontiguousarray(tie_seeds, dtype=np.int32)
+        if seeds is not None and len(seeds) != B:
+            raise ValueError("one tie seed per attached sample")
+        scores = np.zeros(B, dtype=np.uint32)
+        stable = np.zeros(B, dtype=np.uint8)
+        first = np.zeros(B, dtype=np.int32)
+        _chk(load_library().mpf_ufboot_refine_sweep(self.h, maxtrav, None if seeds is None else _p(seeds), _p(scores), _p(stable), _p(first)))
+        return scores, stable.astype(bool), first
 
     def ufboot_detach(self):
         _chk(load_library().mpf_ufboot_detach(self.h))

@@ -1,0 +1,114 @@
+"""Batched bootstrap refinement (mpf_ufboot_refine_sweep): the first sweep of pllOptimizeSprParsimony from ONE tree under many
+samples' weights at once -- masked scan + mask x weight product + per-sample replay -- against the calls it stands for:
+mpf_set_weights(sample b) + mpf_optimize_spr per sample on the engine, and the same on the CPU oracle (reference flow:
+IQTree::optimizeBootTrees, iqtree.cpp:2797-2862)."""
+import numpy as np
+import pytest
+
+from helpers import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(w0, B, rng):
+    nsite = int(w0.sum())
+    site_pattern = np.repeat(np.arange(len(w0)), w0)
+    out = np.zeros((B, len(w0)), dtype=np.uint16)
+    for b in range(B):
+        out[b] = np.bincount(site_pattern[rng.integers(0, nsite, size=nsite)], minlength=len(w0))
+    return out
+
+
+def _check(codes, w0, dt_e, dt_o, back, samples, seeds, radius, chunk=None):
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    B = len(samples)
+    e = engine.FitchEngine(codes, w0, datatype=dt_e)
+    if chunk:
+        e.set_option("refine_chunk", chunk)
+    e.seed_ties(engine.TIE_RANDOM, 0)
+    e.ufboot_attach(samples, 0.5)
+    e.reset_node_order()
+    e.set_tree(back)
+    order = e.node_order()
+    scores, stable, first = e.ufboot_refine_sweep(radius, seeds)
+    e.ufboot_detach()
+    solo = engine.FitchEngine(codes, w0, datatype=dt_e)
+    o = po.Oracle(codes, w0, datatype=dt_o)
+    n_stable = 0
+    for b in range(B):
+        w = samples[b].astype(np.int32)
+        solo.set_weights(w)
+        solo.seed_ties(engine.TIE_RANDOM, int(seeds[b]))
+        solo.reset_node_order()
+        solo.set_tree(back)
+        s0 = solo.score_tree()
+        s1 = solo.optimize_spr(1, radius)
+        mv = solo.moves()
+        o.set_weights(w)
+        o.seed_ties(po.TIE_RANDOM, int(seeds[b]))
+        o.reset_nodep()
+        assert o.score_tree(back) == s0 == scores[b]
+        o.trace(True)
+        so = o.optimize_spr(1, radius)
+        assert so == s1 and [x.tolist() for x in o.get_moves()] == [x.tolist() for x in mv]
+        assert bool(stable[b]) == (len(mv[0]) == 0), (b, stable[b], len(mv[0]))
+        if stable[b]:
+            n_stable += 1
+            assert s1 == scores[b] and (solo.get_tree() == back).all() and first[b] == 0
+        else:
+            # the first accepted move prunes at the visit the replay names (p side: that record, q side: the one behind it)
+            rec = int(order[first[b] - 1])
+            assert int(mv[0][0]) in (rec, int(back[rec]))
+    return n_stable
+
+
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48"])
+def test_refine_sweep_equals_per_sample_climbs_on_fixtures(name):
+    from mpboot_amd import engine, trees
+    from oracle import pyoracle as po
+    fx = load_fixture(name)
+    codes, w0 = fx["codes_np"], fx["weights_np"]
+    dt_e = engine.AA if fx["datatype"] == po.AA else engine.DNA
+    rng = np.random.default_rng(17)
+    samples = _samples(w0, 24, rng)
+    seeds = rng.integers(1, 10 ** 6, size=24)
+    # an SPR-optimal tree (most samples leave it alone or move sideways) and a random one (every sample moves)
+    e = engine.FitchEngine(codes, w0, datatype=dt_e)
+    start = trees.random_topology(fx["n"], np.random.default_rng(3))
+    e.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, 5)
+    e.optimize_spr(1, 6)
+    opt = e.get_tree()
+    for back, radius, chunk in ((opt, 6, None), (opt, 3, 5), (start, 6, 7)):
+        _check(codes, w0, dt_e, fx["datatype"], back, samples, seeds, radius, chunk)
+
+
+def test_refine_sweep_on_a_decisive_alignment_and_through_the_driver():
+    """120 taxa x 6000 patterns: long alignments leave nearly every sample on the online phase's tree; refine_boot_trees with the
+    batched first sweep == the per-sample loop"""
+    from mpboot_amd import bootstrap, engine, synth, trees
+    from oracle import pyoracle as po
+    letters, _ = synth.synth_alignment(120, 6000, "DNA", 0.05, seed=8)
+    codes = synth.letters_to_codes(letters, "DNA")
+    n, P = codes.shape
+    w0 = np.ones(P, dtype=np.int32)
+    e = engine.FitchEngine(codes)
+    e.set_tree(trees.random_topology(n, np.random.default_rng(1)))
+    e.seed_ties(engine.TIE_RANDOM, 2)
+    e.optimize_spr(1, 6)
+    opt = e.get_tree()
+    rng = np.random.default_rng(23)
+    samples = _samples(w0, 40, rng)
+    seeds = np.array([9 + 12345 * b for b in range(40)])
+    n_stable = _check(codes, w0, engine.DNA, po.DNA, opt, samples, seeds, 6)
+    assert n_stable >= 20
+    # the driver: two start topologies among the samples
+    other = trees.random_topology(n, np.random.default_rng(4))
+    boot_trees = [opt if b % 5 else other for b in range(40)]
+    e2 = engine.FitchEngine(codes)
+    sc_b, tr_b = bootstrap.refine_boot_trees(e2, samples, boot_trees, 9, 6, batched=True)
+    e3 = engine.FitchEngine(codes)
+    sc_s, tr_s = bootstrap.refine_boot_trees(e3, samples, boot_trees, 9, 6, batched=False)
+    assert sc_b.tolist() == sc_s.tolist()
+    assert all((tr_b[b] == tr_s[b]).all() for b in range(40))
