@@ -387,7 +387,8 @@ int mpf_set_option(mpf_engine *e, const char *key, int64_t value);
    begin, end (100 MHz counter), XCC_ID << 32 | HW_ID, scan << 32 | tile << 16 | insertion tests.  *n_words is always set;
    out is filled when cap >= *n_words. */
 int mpf_get_scan_trace(mpf_engine *e, uint64_t *out, uint64_t cap, uint64_t *n_words);
-/* current value of an option of mpf_set_option */
+/* current value of an option of mpf_set_option; read-only: "kernel_states" = state rows the kernels carry (4: DNA and binary,
+   20: protein and multistate data with at most 20 symbols in use, 32: multistate data beyond that or under a cost matrix) */
 int mpf_get_option(const mpf_engine *e, const char *key, int64_t *value);
 
 #ifdef __cplusplus

@@ -12,7 +12,12 @@ struct mpf_engine {
 
 using mpf::set_error;
 
-#define NEED(e) do { if (!(e)) { set_error("null engine handle"); return MPF_E_INVALID; } (e)->eng.activate(); } while (0)
+#define NEED(e)                                                                                                        \
+  do {                                                                                                                 \
+    if (!(e)) { set_error("null engine handle"); return MPF_E_INVALID; }                                               \
+    if ((e)->eng.broken()) { set_error("engine unusable: a device launch did not come back (destroy it)"); return MPF_E_STATE; } \
+    (e)->eng.activate();                                                                                               \
+  } while (0)
 
 extern "C" {
 

@@ -1357,13 +1357,14 @@ size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw)
 {
   const uint32_t ns = slots_of(n_taxa);
   if (g.S == 4) return vw == 1 ? lds_bytes<1, 1>(ns) : vw == 2 ? lds_bytes<1, 2>(ns) : lds_bytes<1, 4>(ns);
+  if (g.S == 32) return lds_bytes<8, 1>(ns);
   return lds_bytes<5, 1>(ns);
 }
 
 bool climb_supported(const Geometry &g, int n_taxa, int maxtrav)
 {
   if (g.sankoff || g.big) return false;
-  if (g.S != 4 && g.S != 20) return false;
+  if (g.S != 4 && g.S != 20 && g.S != 32) return false;
   if (maxtrav < 1 || maxtrav > kDepth) return false;
   if (slots_of(n_taxa) + 16u >= 0xFFFFu) return false;
   if (climb_tiles(g, 1) >= (1 << 20)) return false;
@@ -1377,6 +1378,7 @@ hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbPa
     if (vw == 2) return launch_t<1, 2>(st, p);
     return launch_t<1, 4>(st, p);
   }
+  if (g.S == 32) return launch_t<8, 1>(st, p);           // 32-state data: eight states per lane
   return launch_t<5, 1>(st, p);
 }
 

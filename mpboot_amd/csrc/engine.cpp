@@ -65,11 +65,10 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   if (const char *hp = std::getenv("MPF_HOST_POLL")) host_poll_ = std::atoi(hp) ? 1 : 0;        // (experiments)
   if (const char *vt = std::getenv("MPF_VIEWS_TILE")) { const int t = std::atoi(vt); if (t == 32 || t == 16 || t == 8 || t == 4 || t == 0) g_.nv_tile = t; }
   if (const char *pc = std::getenv("MPF_PLAN_CACHE")) plan_cache_ = std::atoi(pc);     // (debugging: default of option "plan_cache"; bits: 1 keep topology state, 2 refresh schedule, 4 sweep plans)
-  // Engines on several host threads share a device through their own streams; the runtime maps streams onto 4 hardware queues
-  // per process by default, and a persistent k_climb launch holds its queue for a whole sweep (8 climbs side by side: 8.7 climbs/s
-  // on 4 queues, 19.8 on 16: profiles/r3/concurrent_climbs.txt).  Only takes effect if the HIP runtime of this process has not
-  // started yet and the variable is not set by the user.
-  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // (Engines on several host threads share a device through their own streams; the runtime maps streams onto 4 hardware queues
+  //  per process unless GPU_MAX_HW_QUEUES says otherwise, and a persistent k_climb launch holds its queue for a whole sweep --
+  //  8 climbs side by side: 8.7 climbs/s on 4 queues, 19.8 on 16, profiles/r3/concurrent_climbs.txt.  The variable belongs to
+  //  whoever starts the process -- INTEGRATION.md, mpboot_amd/engine.py --: a library does not edit its host's environment.)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_error("no HIP device available: libmpfitch has no CPU fallback");
@@ -101,23 +100,21 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   codes_.assign(codes, codes + (size_t)n_ * P_);
   if (datatype_ == MPF_GENERIC) {
     bool used[32] = {false};
-    // Multistate data runs on the 20-state kernels: parsimony does not care what a state is called, so the symbols in use are
-    // renumbered 0, 1, 2, ... in order of their codes (row gmap_[c] of a vector is the reference's row c; unused rows do not
-    // exist).  More than 20 symbols in use would need 32-state kernels.
+    // Multistate data with at most 20 symbols in use runs on the 20-state kernels: parsimony does not care what a state is
+    // called, so the symbols in use are renumbered 0, 1, 2, ... in order of their codes (row gmap_[c] of a vector is the
+    // reference's row c; unused rows do not exist).  More symbols -- or a cost matrix, under which a state that no tip has can
+    // still be the cheapest label of an inner node (a Steiner point of the metric), so that the matrix's 32 states cannot be
+    // renumbered -- take the 32-state kernels with the reference's own numbering (its `default:` / `case 32` branches,
+    // sprparsimony.cpp:824-869, :1164-1203, :571-573).
     for (uint8_t c : codes_) if (c < 32) used[c] = true;
     int k = 0;
     for (int c = 0; c < 32; c++) gmap_[c] = used[c] ? k++ : -1;
-    if (k > 20) {
-      set_error("mpf_engine_create: multistate data with more than 20 symbols in use needs 32-state kernels, which this build does not have");
-      return MPF_E_UNSUPPORTED;
+    if (k > 20 || cost) {
+      g_.S = 32;
+      for (int c = 0; c < 32; c++) gmap_[c] = c;
+    } else {
+      for (uint8_t &c : codes_) if (c < 32) c = (uint8_t)gmap_[c];
     }
-    for (uint8_t &c : codes_) if (c < 32) c = (uint8_t)gmap_[c];
-  }
-  if (cost && datatype_ == MPF_GENERIC) {
-    // under a cost matrix a state that no tip has can still be the cheapest label of an inner node (a Steiner point of the
-    // metric), so the 32 states of the reference's matrix cannot be renumbered into 20 rows the way Fitch sets can
-    set_error("mpf_engine_create_sankoff: weighted parsimony on 32-state data needs 32-state kernels, which this build does not have");
-    return MPF_E_UNSUPPORTED;
   }
   if (cost) {
     // ParsTree::loadCostMatrixFile's triangle-inequality closure (reference parstree.cpp:74-80).  A matrix that is not
@@ -1969,6 +1966,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "words_per_lane") {
     if (sankoff_ && v != 1) { set_error("words_per_lane: weighted mode uses one pattern per lane"); return MPF_E_INVALID; }
     if (!(v == 1 || v == 2 || v == 4) || (g_.S == 20 && v == 4)) { set_error("words_per_lane: 1|2|4 (protein: 1|2)"); return MPF_E_INVALID; }
+    if (g_.S == 32) return MPF_OK;                 // (32 state rows fill a lane's registers with one word: the knob rests)
     g_.vw = (int)v;
     return MPF_OK;
   }
@@ -2044,6 +2042,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "prog_min_descs") *v = prog_min_descs_;
   else if (key == "scan_batch") *v = scan_batch_;
   else if (key == "words_per_lane") *v = g_.vw;
+  else if (key == "kernel_states") *v = g_.S;            // state rows the kernels carry: 4 (DNA, binary), 20 (protein, multistate <= 20 symbols), 32
   else if (key == "reduce") *v = g_.reduce;
   else if (key == "xcd_map") *v = g_.map;
   else if (key == "scan_mode") *v = scan_mode_;

@@ -203,6 +203,7 @@ class Engine {
   int tip_vector(int tip, uint32_t *out);
   // HIP's current device is per host thread: every entry point re-selects the engine's device first
   void activate() const { (void)hipSetDevice(dev_); }
+  bool broken() const { return broken_; }
   int n() const { return n_; }
   int P() const { return P_; }
   int S() const { return sref_; }               // the reference's state count (the kernels' geometry may be wider: BIN in 4, GENERIC in 20)
@@ -263,6 +264,7 @@ class Engine {
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
   // the first sweep of pllOptimizeSprParsimony from the current tree under every attached sample's weights at once
+  int climb_fit_vw();                            // tile width k_climb will run with on this device (0: does not fit)
   int ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit);
   int ufboot_set_mulhits(int on);
   int ufboot_set_store_trees(int on);
@@ -317,6 +319,8 @@ class Engine {
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int climb_cus_ = 0;                            // CUs of the device (admission of persistent launches)
+  bool broken_ = false;                          // a device launch did not come back: every further call fails
   int refine_chunk_ = 1 << 30;                   // prune nodes per masked scan + product of the refine sweep (option "refine_chunk")
   int spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   // online UFBoot-MP

@@ -211,7 +211,7 @@ __device__ __forceinline__ int lane_word(int tile, int lane, int Wp, bool &valid
 __device__ __forceinline__ uint32_t state_mask(int datatype, uint32_t code)
 {
   if (datatype == 0 || datatype == 2) return code;
-  if (datatype == 3) return code < 32u ? 1u << code : 1048575u;
+  if (datatype == 3) return code < 32u ? 1u << code : 0xFFFFFFFFu;      // (20-row packing: the rows that exist)
   if (code < 20u) return 1u << code;
   if (code == 20u) return 12u;
   if (code == 21u) return 96u;
@@ -2064,7 +2064,8 @@ static inline int snk_elems(const Geometry &g) { return g.snk16 ? g.Wp / 2 : g.W
 #define MPF_DISPATCH_SNK(FN)                                                          \
   do {                                                                                \
     if (g.S == 4) { if (g.snk16) FN(4, true); else FN(4, false); }                    \
-    else { if (g.snk16) FN(20, true); else FN(20, false); }                           \
+    else if (g.S == 20) { if (g.snk16) FN(20, true); else FN(20, false); }            \
+    else { if (g.snk16) FN(32, true); else FN(32, false); }                           \
   } while (0)
 
 hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, const uint8_t *codes, int n_taxa,
@@ -2075,8 +2076,11 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
   if (g.S == 4)
     hipLaunchKernelGGL(k_pack_tips<4>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
                        tip_slots, g.Wp, g.shoff ? vec + g.shoff : nullptr);
-  else
+  else if (g.S == 20)
     hipLaunchKernelGGL(k_pack_tips<20>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
+                       tip_slots, g.Wp, nullptr);
+  else
+    hipLaunchKernelGGL(k_pack_tips<32>, grid, block, 0, st, vec, codes, n_taxa, n_patterns, site2ptn, n_sites, datatype,
                        tip_slots, g.Wp, nullptr);
   return hipGetLastError();
 }
@@ -2087,9 +2091,11 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
       if (g.vw == 1) { FN(4, 1, __VA_ARGS__); }                                    \
       else if (g.vw == 2) { FN(4, 2, __VA_ARGS__); }                               \
       else { FN(4, 4, __VA_ARGS__); }                                              \
-    } else {                                                                       \
+    } else if (g.S == 20) {                                                        \
       if (g.vw == 1) { FN(20, 1, __VA_ARGS__); }                                   \
       else { FN(20, 2, __VA_ARGS__); }                                             \
+    } else {                                                                       \
+      FN(32, 1, __VA_ARGS__);      /* 32 states: one word per lane */              \
     }                                                                              \
   } while (0)
 
@@ -2140,14 +2146,16 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
     dim3 qgrid((unsigned)(g.Wp / tw) + extra);
 #define NQ(S_, TW_) hipLaunchKernelGGL((k_newview_wgq<S_, TW_>), qgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, xs)
     if (g.S == 4) { if (tw == 32) NQ(4, 32); else if (tw == 16) NQ(4, 16); else if (tw == 8) NQ(4, 8); else NQ(4, 4); }
-    else { if (tw == 32) NQ(20, 32); else if (tw == 16) NQ(20, 16); else if (tw == 8) NQ(20, 8); else NQ(20, 4); }
+    else if (g.S == 20) { if (tw == 32) NQ(20, 32); else if (tw == 16) NQ(20, 16); else if (tw == 8) NQ(20, 8); else NQ(20, 4); }
+    else { if (tw == 32) NQ(32, 32); else if (tw == 16) NQ(32, 16); else if (tw == 8) NQ(32, 8); else NQ(32, 4); }
 #undef NQ
     return hipGetLastError();
   }
   if (g.vw == 1) {                                 // half a wave per op on 32-word tiles
     dim3 hgrid((unsigned)(g.Wp / 32));
     if (g.S == 4) hipLaunchKernelGGL((k_newview_wgh<4, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
-    else hipLaunchKernelGGL((k_newview_wgh<20, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
+    else if (g.S == 20) hipLaunchKernelGGL((k_newview_wgh<20, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
+    else hipLaunchKernelGGL((k_newview_wgh<32, 0>), hgrid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x);
     return hipGetLastError();
   }
 #define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
@@ -2238,7 +2246,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
       if (max_depth <= 6) SNKSCAN(4, 6); else SNKSCAN(4, 12);
     } else {
       if (max_depth > 6) return hipErrorInvalidValue;
-      SNKSCAN(20, 6);
+      if (g.S == 20) SNKSCAN(20, 6); else SNKSCAN(32, 6);
     }
 #undef SNKSCAN
 #undef SNKSCAN2
@@ -2272,7 +2280,7 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 {
   if (n_scans <= 0) return hipSuccess;
   if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;   // 8: the per-depth LDS slots of the walk are sized for it
-  const bool split = g.S == 20;                                    // protein: states split over the wave halves
+  const bool split = g.S >= 20;                                    // protein / 32-state data: states split over the wave halves
   const int tiles = split ? (g.Wp + 31) / 32 : (g.big ? (g.Wp + 63) / 64 : tiles_of(g));    // the 64-bit path is one word per lane
   const long waves = (long)n_scans * tiles;
   dim3 block(256);
@@ -2298,7 +2306,8 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
   if (g.big) {
     // >= 2 GiB of vectors: one code path (one word per lane, DPP reduction), 64-bit addressing
     if (g.S == 4) { if (max_depth <= 6) SWB(4, 1, 6, 0, false, true); else SWB(4, 1, 8, 0, false, true); }
-    else { if (max_depth <= 6) SWB(10, 1, 6, 0, true, true); else SWB(10, 1, 8, 0, true, true); }
+    else if (g.S == 20) { if (max_depth <= 6) SWB(10, 1, 6, 0, true, true); else SWB(10, 1, 8, 0, true, true); }
+    else { if (max_depth <= 6) SWB(16, 1, 6, 0, true, true); else SWB(16, 1, 8, 0, true, true); }
   } else if (g.S == 4 && g.vw == 1 && word_major && g.shoff) {
     // the vectors from the word-major copy (the caller knows it is current): one 16-byte load per lane and vector
 #define SWM(MAXD_, RED_)                                                                                                              \
@@ -2315,8 +2324,10 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
 #undef SWM
   } else if (g.S == 4) {
     if (g.vw == 1) SW2(4, 1, false); else SW2(4, 2, false);
-  } else {
+  } else if (g.S == 20) {
     SW2(10, 1, true);
+  } else {
+    SW2(16, 1, true);
   }
 #undef SW2
 #undef SW

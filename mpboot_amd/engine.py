@@ -11,7 +11,12 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmpfitch.so")
+# (MPF_LIB_PATH: a differently built library, e.g. the experiments build of tools/scan_bounds.sh -- never the default)
+LIB_PATH = os.environ.get("MPF_LIB_PATH") or os.path.join(HERE, "libmpfitch.so")
+# Engines on several host threads launch side by side only as far as their streams get hardware queues of their own; the HIP
+# runtime's default is 4 per process and a persistent climb kernel holds its queue for a whole sweep.  The setting belongs to
+# the process, not to the library: this module is the host side and sets it before the runtime starts, unless the user did.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 DNA, AA, BIN, GENERIC = 0, 1, 2, 3      # PLL_DNA_DATA, PLL_AA_DATA, PLL_BINARY_DATA (2 states), PLL_GENERIC_32 (multistate)
 TIE_FIRST, TIE_RANDOM = 0, 1

@@ -50,11 +50,32 @@ struct GateHold {
 };
 }  // namespace
 
+// k_climb's workgroups wait for each other: a launch whose tiles cannot all be resident would spin until its start barrier times
+// out, every time.  The tile width the launch will use: option "climb_tile", widened (DNA: 2, 4 words per lane group) until the
+// workgroups fit 85 % of the CUs (several per CU where the control state is small); 0 = this alignment is too long for the kernel.
+int Engine::climb_fit_vw()
+{
+  if (climb_cus_ <= 0) {
+    int c = 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || c <= 0) c = 256;
+    climb_cus_ = c;
+  }
+  const int cap = std::max(1, climb_cus_ * 85 / 100);
+  for (int vw = (g_.S == 4) ? std::max(1, climb_vw_) : 1; vw <= ((g_.S == 4) ? 4 : 1); vw *= 2) {
+    const size_t lds = climb_lds_bytes(g_, n_, vw);
+    if (lds > 160 * 1024) continue;
+    const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
+    if ((climb_tiles(g_, vw) + per_cu - 1) / per_cu <= cap) return vw;
+  }
+  return 0;
+}
+
 int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle,
                           uint32_t *reason, uint32_t *n_moves)
 {
   const auto t0 = std::chrono::steady_clock::now();
-  const int vw = (g_.S == 4) ? climb_vw_ : 1;
+  const int vw = climb_fit_vw();
+  if (vw <= 0) { set_error("device climb: the alignment's tiles do not fit the chip"); return MPF_E_STATE; }
   const int tiles = climb_tiles(g_, vw);
   const size_t ns = nslots_;
   const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
@@ -157,12 +178,15 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
           std::string where;
           if (p.beat) for (int k = 0; k < 32; k++) where += " " + std::to_string(cd_.h_beat.p[k]);
           set_error("device climb: the launch did not finish within 20 s" + (where.empty() ? std::string() : " (step phase pos B ncand nops chains done err:" + where + ")"));
+          // (the kernel may still be writing vectors: nothing this engine holds can be trusted any more)
+          invalidate_all();
+          broken_ = true;
           return MPF_E_STATE;
         }
         std::this_thread::yield();
       }
     }
-    if (q != hipSuccess) { set_error(std::string("device climb: ") + hipGetErrorString(q)); return MPF_E_HIP; }
+    if (q != hipSuccess) { invalidate_all(); set_error(std::string("device climb: ") + hipGetErrorString(q)); return MPF_E_HIP; }
   }
   hold.release();
   std::memcpy(&h, cd_.h_out.p, sizeof(h));
@@ -174,6 +198,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     return MPF_OK;                                // nothing was changed: the caller goes on with host-driven batches
   }
   if (h.reason == CLIMB_ERROR || h.reason == CLIMB_RUNNING || h.n_moves > (uint32_t)total) {
+    invalidate_all();                             // (the kernel has rewritten vectors for topologies the mirror never saw)
     set_error("device climb: internal error " + std::to_string(h.err) + " (reason " + std::to_string(h.reason) + ")");
     return MPF_E_STATE;
   }

@@ -51,7 +51,9 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
   // either way (the kernel follows the same rules with the same tie stream); a host-supplied random_double() callback
   // keeps the loop on the host.
   const int mt_eff = std::min(maxtrav, ntips_ - 3);
-  bool dev_ok = climb_device_ > 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff);
+  // (... and only where all of the kernel's workgroups fit the chip together, if need be on wider tiles: climb_fit_vw)
+  bool dev_ok = climb_device_ > 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff) &&
+                climb_fit_vw() > 0;
   uint32_t sweep_moves = 0;
   bool first_sweep = true;
   do {
@@ -69,7 +71,9 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
         const int i0 = i;
         int rc = climb_segment(mt_eff, total, &i, &randomMP, &iter_hits, climb_device_ < 2, &reason, &nm);
         if (rc) return rc;
-        if (reason == CLIMB_ABORT) { dev = false; continue; }      // (not resident in time: this sweep goes on with host batches)
+        // (not resident in time -- somebody else holds the chip: the rest of this climb runs as host-driven batches; trying again
+        //  behind every move would cost a 30 ms time-out each)
+        if (reason == CLIMB_ABORT) { dev = false; dev_ok = false; continue; }
         sweep_moves += nm;
         if (nm) {
           const double g = (double)(i - i0) / (double)nm;

@@ -53,19 +53,23 @@ def mods():
     return engine, po
 
 
-# (multistate data under a cost matrix would need 32-state kernels -- a state no tip has can be an inner node's cheapest
-#  label -- and is refused: test_weighted_multistate_is_refused)
-@pytest.fixture(scope="module", params=[f for f in FIXTURES if f != "morph"])
+# (multistate data under a cost matrix always runs on the 32-state kernels, the reference's `case 32`, sprparsimony.cpp:571-573:
+#  a state no tip has can be an inner node's cheapest label, so the matrix's states are not renumbered)
+@pytest.fixture(scope="module", params=list(FIXTURES))
 def fx(request):
     return load_fixture(request.param)
 
 
-def test_weighted_multistate_is_refused(mods):
+def test_weighted_multistate_runs_on_32_state_kernels(mods):
     engine, po = mods
+    for name in ("morph", "morph32"):
+        fx = load_fixture(name)
+        e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=random_metric(32, 4))
+        assert e.S == 32 and e.get_option("kernel_states") == 32
     fx = load_fixture("morph")
-    with pytest.raises(engine.MpfError) as ei:
-        engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=random_metric(32, 4))
-    assert ei.value.code == -6 and "32-state" in str(ei.value)
+    assert engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"]).get_option("kernel_states") == 20
+    fx = load_fixture("morph32")
+    assert engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"]).get_option("kernel_states") == 32
 
 
 @pytest.mark.parametrize("kind", ["unit", "general", "asym"])

@@ -14,7 +14,7 @@ from helpers import FIXTURES, GOLDEN, hex_words, load_fixture, trace_tokens
 from oracle import pyoracle as po
 
 
-@pytest.fixture(scope="module", params=FIXTURES + ("morph32",))
+@pytest.fixture(scope="module", params=FIXTURES)
 def fx(request):
     return load_fixture(request.param)
 

@@ -3,9 +3,12 @@
 # store (four row loads per vector) and with every load confined to two hot vectors, the walking kernel, the VALU issue rates of
 # the instructions it is made of and the load rate of a CU by access shape.
 # the knock-out variants exist only in an experiments build of the library (results are wrong on purpose)
-make -s -C mpboot_amd/csrc clean && make -s -j8 -C mpboot_amd/csrc EXPERIMENTS=1
-trap 'make -s -C mpboot_amd/csrc clean && make -s -j8 -C mpboot_amd/csrc' EXIT
+# (a library of its own beside the production one, selected through MPF_LIB_PATH: the shipped libmpfitch.so is never replaced)
+EXP=$PWD/mpboot_amd/libmpfitch_exp.so
+make -s -j8 -C mpboot_amd/csrc EXPERIMENTS=1 OUT=$EXP OBJDIR=$PWD/mpboot_amd/csrc/_obj_exp
+export MPF_LIB_PATH=$EXP
 mkdir -p gpurun_out/bounds
+for u in valu_rate l1_rate; do hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip; done
 {
 echo "== bench.py --steps 20 --warmup 5 (C3 sweep; scan = HIP-event time of the scan kernel per launch, ms) =="
 echo "-- the kernel as shipped: child vectors from the word-major copy, one buffer_load_dwordx4 per vector and lane"
