@@ -350,6 +350,51 @@ def climb_cpu_baseline(names, letters, alphabet, back, maxtrav):
     return None
 
 
+def start_trees_cpu_baseline(names, letters, alphabet, maxtrav, n_trees):
+    """The reference's start-up tree (randomized stepwise addition + the SPR sweeps behind it, pllMakeParsimonyTreeFast,
+    fastDNAparsimony.c:1857 -- the PLL twin of _pllComputeRandomizedStepwiseAdditionParsimonyTree) on the box's host cores:
+    one tree on one thread, then one tree per usable core side by side (oracle/_ref/pll_ref_driver ras)."""
+    from mpboot_amd import synth
+    drv = os.path.join(ROOT, "oracle", "_ref", "pll_ref_driver")
+    if not (os.path.exists(drv) and os.access(drv, os.X_OK)):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            aln = os.path.join(tmp, "a.phy")
+            synth.write_phylip(aln, synth.letters_to_text(letters, alphabet), names)
+            env = dict(os.environ, REF_DRIVER_QUIET="1")
+
+            def cmd(u):
+                return [drv, "ras", aln, "DNA" if alphabet == "DNA" else "WAG", "0", str(31337 + 12345 * u), str(maxtrav)]
+
+            def secs(text):
+                for l in text.splitlines():
+                    if l.startswith("ras_seconds"):
+                        return float(l.split()[1])
+                return None
+
+            one = secs(subprocess.run(cmd(0), capture_output=True, text=True, check=True, timeout=900, env=env).stdout)
+            k = max(1, min(cpu_quota(), 16))
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen(cmd(u), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for u in range(k)]
+            each = [secs(pr.communicate(timeout=1800)[0]) for pr in procs]
+            wall = time.perf_counter() - t0
+        each = [x for x in each if x is not None]
+        if one is None or not each:
+            return None
+        per_tree_all = max(each) / len(each)             # k trees finish in max(each) seconds of build time
+        return {"seconds_per_tree_one_core": one, "cores": 1, "kind": "reference",
+                "all_cores": {"cores": len(each), "seconds_per_tree_each": each, "wall_s_incl_parsing": wall,
+                              "seconds_for_%d_trees" % n_trees: per_tree_all * n_trees},
+                "seconds_for_%d_trees_one_core" % n_trees: one * n_trees,
+                "sample": "one start tree (compressDNA + randomized stepwise addition + SPR sweeps, radius %d) by the reference's PLL AVX "
+                          "code on one thread, then %d such trees side by side (one process per usable core); scaled to %d trees"
+                          % (maxtrav, len(each), n_trees)}
+    except Exception as exc:
+        print(f"[bench] reference start trees failed ({exc})", file=sys.stderr)
+    return None
+
+
 def shim_climb_leg(eng, names, letters, alphabet, back, maxtrav, reps=3):
     """pllOptimizeSprParsimony THROUGH the reference-side binding: oracle/_ref/spr_shim_driver is the reference's own PLL program
     (alignment parser, pllInstance, Newick reader, SPRNG generator -- compiled from the reference's sources) linked with
@@ -476,6 +521,7 @@ def main():
     ap.add_argument("--engines-per-gpu", type=int, default=6, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--climb-engines", type=int, default=8,
                     help="independent SPR climbs side by side on one GPU (one engine per host thread): the concurrent_climbs leg (0 = skip)")
+    ap.add_argument("--start-engines", type=int, default=6, help="concurrent engines (host threads) per GPU in the start-trees leg")
     ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
     ap.add_argument("--start-trees", type=int, default=100,
                     help="randomized-stepwise-addition + SPR start trees of the start-up phase (phyloanalysis.cpp:1270-1317), sharded over the GPUs (0 = skip)")
@@ -959,7 +1005,7 @@ def main():
         if args.start_trees > 0:
             # the start-up phase of a run: numpars randomized-stepwise-addition trees, each SPR-optimised (phyloanalysis.cpp:1270-1317,
             # tools.cpp:767); unit u on rank u % n_gpus, several engines per GPU
-            k_e = max(1, min(6, args.climb_engines if args.climb_engines > 0 else 1))
+            k_e = max(1, args.start_engines)
             grow(k_e)
             units = [u for u in range(args.start_trees) if u % world == rank]
             def ras_fn(i, x):
@@ -1076,6 +1122,12 @@ def main():
             res["concurrent_climbs"] = conc
         if startup is not None:
             res["start_trees"] = startup
+            if not args.no_cpu and world == 1:
+                startup["cpu_baseline"] = start_trees_cpu_baseline(names, letters, alphabet, args.maxtrav, startup["trees"])
+                cb = startup["cpu_baseline"]
+                if cb:
+                    startup["gpu_over_cpu_one_core"] = cb["seconds_for_%d_trees_one_core" % startup["trees"]] / startup["seconds"]
+                    startup["gpu_over_cpu_all_cores"] = cb["all_cores"]["seconds_for_%d_trees" % startup["trees"]] / startup["seconds"]
         if c2leg is not None:
             res["c2_climb"] = c2leg
         if c5leg is not None:

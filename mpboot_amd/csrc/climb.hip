@@ -225,6 +225,7 @@ struct Sh {
   int32_t ins, rem;
   unsigned long long rng, hits, n_tests, n_ops, draws, n_nodes;
   uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, pn_base[kMaxB];
+  uint32_t xcc, xm;                          // this workgroup's XCD and how many of the launch's workgroups share it
   Unit unit[kMaxUnits];
   uint32_t pcnt[kMaxParts], poff[kMaxParts], pE[kMaxParts];
   uint32_t pn_off[kMaxB], pn_cnt[kMaxB], pn_np[kMaxB], pn_p[kMaxB];
@@ -1165,7 +1166,10 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     sh.clk0 = __builtin_amdgcn_s_memtime(); sh.rt0 = sh.tlast;
     sh.tlast = __builtin_amdgcn_s_memrealtime();
     // every workgroup must be resident before anyone waits for anyone: arrive, then wait for the others -- not for ever
-    __hip_atomic_fetch_add(&P.hdr->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (counted per XCD first: the release order of the two adds makes the per-XCD counts final once everybody has arrived)
+    sh.xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 7u;
+    __hip_atomic_fetch_add(&P.xcnt[sh.xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&P.hdr->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t ok = 1;
     for (;;) {
@@ -1182,6 +1186,7 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     if (ok && __hip_atomic_load(&P.hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
         __hip_atomic_load(&P.hdr->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T) ok = 0;
     sh.ok = ok;
+    sh.xm = ok ? __hip_atomic_load(&P.xcnt[sh.xcc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
   __syncthreads();
   if (!sh.ok) {
@@ -1249,11 +1254,27 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     if (ncand) {
       const uint32_t slot = sh.xgen % 3u;
       unsigned long long *gs = P.gsum + (size_t)slot * kClimbCap;
+      // level 1: this XCD's own words.  Every address below is touched by the workgroups of ONE XCD only, so these atomics are
+      // issued at workgroup scope -- they execute in that XCD's L2 and never cross the fabric; the returned count tells the last
+      // workgroup of the XCD that the total is complete.  Level 2: that one forwards it with a device-scope add (count = the XCD's
+      // workgroups) and clears the level-1 word for its next turn, three exchanges on.
+      unsigned long long *xs = P.xsum + ((size_t)sh.xcc * 3u + slot) * kClimbCap;
+      const uint32_t xm = sh.xm;
       for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
         uint32_t j = 0;
         while (j + 1u < sh.Beff && c >= sh.pn_off[j + 1u]) j++;
         const uint32_t val = K.cost[c] + sh.pn_base[j];
-        __hip_atomic_fetch_add(gs + c, (1ull << 40) | (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (xm == 1u) {
+          __hip_atomic_fetch_add(gs + c, (1ull << 40) | (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const unsigned long long mine = (1ull << 40) | (unsigned long long)val;
+          const unsigned long long old = __hip_atomic_fetch_add(xs + c, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((uint32_t)(old >> 40) + 1u == xm) {
+            const unsigned long long tot = old + mine;
+            __hip_atomic_fetch_add(gs + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_sub(xs + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
       }
       for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
         unsigned long long v;

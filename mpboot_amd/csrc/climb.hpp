@@ -56,6 +56,10 @@ struct ClimbParams {
   uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
   uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch)
   unsigned long long *gsum;        // [3][kClimbCap] exchange ring (zeroed by the host before the launch)
+  // two-level exchange: the workgroups of one XCD first add their shares into that XCD's own words (atomics that stay in its L2),
+  // the last one to arrive forwards the XCD's total -- 8 device-scope adds per candidate instead of one per workgroup
+  unsigned long long *xsum;        // [8][3][kClimbCap], zeroed like gsum
+  uint32_t *xcnt;                  // [8] workgroups of the launch per XCD (zeroed; counted at the start barrier)
   ClimbHeader *hdr;
   uint32_t *moves;                 // [max_moves][3] = remove cid, insert cid, score
   uint32_t *trace;                 // optional: 8 words per visited prune node

@@ -83,7 +83,9 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   HIPCHK(cd_.bk.reserve(ns));
   HIPCHK(cd_.order.reserve((size_t)total));
   HIPCHK(cd_.sct.reserve((size_t)tiles * ns * 16));
-  HIPCHK(cd_.gsum.reserve(3 * (size_t)kClimbCap));
+  // exchange ring | per-XCD level-1 words | per-XCD workgroup counts
+  const size_t gsum_words = 3 * (size_t)kClimbCap + 8 * 3 * (size_t)kClimbCap + 8;
+  HIPCHK(cd_.gsum.reserve(gsum_words));
   HIPCHK(cd_.out.reserve(out_words));
   HIPCHK(cd_.h_bk.reserve(ns));
   HIPCHK(cd_.h_order.reserve((size_t)total));
@@ -124,6 +126,8 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   p.bk = cd_.bk.p;
   p.sct = cd_.sct.p;
   p.gsum = cd_.gsum.p;
+  p.xsum = cd_.gsum.p + 3 * (size_t)kClimbCap;
+  p.xcnt = reinterpret_cast<uint32_t *>(cd_.gsum.p + 27 * (size_t)kClimbCap);
   p.hdr = reinterpret_cast<ClimbHeader *>(cd_.out.p);
   p.moves = cd_.out.p + hdr_words;
   p.trace = nullptr;
@@ -162,7 +166,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   HIPCHK(hipMemcpyAsync(cd_.bk.p, cd_.h_bk.p, ns * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(cd_.order.p, cd_.h_order.p, (size_t)total * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
   HIPCHK(hipMemcpyAsync(cd_.out.p, cd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(cd_.gsum.p, 0, 3 * (size_t)kClimbCap * sizeof(unsigned long long), st_));
+  HIPCHK(hipMemsetAsync(cd_.gsum.p, 0, gsum_words * sizeof(unsigned long long), st_));
   shadow_ok_ = false;                              // (k_climb rewrites vectors in the row-major store only)
   HIPCHK(launch_climb(st_, g_, vw, p));
   HIPCHK(hipMemcpyAsync(cd_.h_out.p, cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));

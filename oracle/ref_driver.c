@@ -414,15 +414,22 @@ static void cmd_ras(long seed, int sprDist)
   long s2 = seed;
   /* the permutation the call below will draw (same generator, same seed) */
   { long save = TR->randomNumberSeed; TR->randomNumberSeed = s2; makePermutationFast(perm, n, TR); TR->randomNumberSeed = save; }
-  printf("perm");
-  for (i = 1; i <= n; i++) printf(" %d", perm[i]);
-  printf("\n");
+  if (!getenv("REF_DRIVER_QUIET")) {
+    printf("perm");
+    for (i = 1; i <= n; i++) printf(" %d", perm[i]);
+    printf("\n");
+  }
   free(perm);
   TR->randomNumberSeed = seed;
-  allocateParsimonyDataStructures(TR, PR);
-  pllMakeParsimonyTreeFast(TR, PR, sprDist);
+  QUIET = getenv("REF_DRIVER_QUIET") != NULL;      /* timing runs (bench.py): no topology */
+  {
+    double t0 = now_s();
+    allocateParsimonyDataStructures(TR, PR);
+    pllMakeParsimonyTreeFast(TR, PR, sprDist);
+    printf("ras_seconds %.6f\n", now_s() - t0);    /* compressDNA + randomized stepwise addition + the SPR sweeps behind it */
+  }
   printf("ras_score %u\n", TR->bestParsimony);
-  print_topology("ras_topology");
+  if (!QUIET) print_topology("ras_topology");
   printf("start %d\n", rec_of(TR->start));
   TR->bestParsimony = UINT_MAX;
   printf("ras_check %u\n", evaluateParsimony(TR, PR, TR->start, PLL_TRUE));

@@ -112,3 +112,60 @@ def test_refine_sweep_on_a_decisive_alignment_and_through_the_driver():
     sc_s, tr_s = bootstrap.refine_boot_trees(e3, samples, boot_trees, 9, 6, batched=False)
     assert sc_b.tolist() == sc_s.tolist()
     assert all((tr_b[b] == tr_s[b]).all() for b in range(40))
+
+
+REFINE_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MPF_ROOT"])
+import torch.distributed as dist
+from mpboot_amd import bootstrap, engine, shard, synth, trees
+dist.init_process_group("gloo")
+rank, ws = shard.world()
+letters, _ = synth.synth_alignment(60, 3000, "DNA", 0.06, seed=12)
+codes = synth.letters_to_codes(letters, "DNA")
+n, P = codes.shape
+e = engine.FitchEngine(codes)
+e.set_tree(trees.random_topology(n, np.random.default_rng(1)))
+e.seed_ties(engine.TIE_RANDOM, 2)
+e.optimize_spr(1, 6)
+opt = e.get_tree()
+other = trees.random_topology(n, np.random.default_rng(4))
+samples = np.random.default_rng(23).multinomial(P, np.ones(P) / P, size=30).astype(np.uint16)
+boot_trees = [opt if b % 4 else other for b in range(30)]
+scores, local = bootstrap.refine_boot_trees(e, samples, boot_trees, 9, 6, batched=os.environ["MPF_BATCHED"] == "1")
+mine = {int(b): t.tolist() for b, t in local.items()}
+allt = [None] * ws
+dist.all_gather_object(allt, mine)
+if rank == 0:
+    merged = {}
+    for d in allt:
+        merged.update(d)
+    print("RESULT " + json.dumps({"scores": scores.tolist(), "trees": [merged[b] for b in range(30)]}))
+dist.destroy_process_group()
+'''
+
+
+def test_batched_refinement_sharded_over_two_ranks_equals_per_sample_loop(tmp_path):
+    """bootstrap.refine_boot_trees as bench.py --gpus N runs it: sample b on rank b % N (two gloo ranks sharing this box's GPU), the
+    batched first sweep on each rank's share of the samples (sample-sharded tracker) -- same scores and trees as the per-sample loop"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+    script = tmp_path / "worker.py"
+    script.write_text(REFINE_WORKER)
+    res = {}
+    for batched in ("1", "0"):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MPF_ROOT=ROOT, MPF_BATCHED=batched)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res[batched] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["1"] == res["0"]
