@@ -476,7 +476,7 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
 
 template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0, bool M32 = false>
 static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                                   int mult, int accumulate, const uint32_t *rowsel)
+                                   int mult, int accumulate, const uint32_t *rowsel, long want_default = 192)
 {
   constexpr int TM = 16 * MT * WM;
   const int row_blocks = rows_padded / TM, col_blocks = Bp / (16 * NT * WN);
@@ -485,7 +485,9 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
   long tiles = (long)row_blocks * col_blocks;
   // (measured on the batches of a C3 climb with 1000 samples: 512 workgroups 0.50 s of product kernels per climb, 192: 0.30 s
   //  -- every K-split multiplies the atomic adds into C, and 192 workgroups already stream the weight matrix at full rate)
-  static const long want = std::getenv("MPF_GEMM_WANT") ? std::atol(std::getenv("MPF_GEMM_WANT")) : 192;
+  // (128-row tiles, the batches inside a climb: 256 workgroups 0.234 s, 192: 0.261 s, 512: 0.233 s)
+  static const long want_env = std::getenv("MPF_GEMM_WANT") ? std::atol(std::getenv("MPF_GEMM_WANT")) : 0;
+  const long want = want_env > 0 ? want_env : want_default;
   int ksplit = 1;
   if (tiles < want) ksplit = (int)std::min<long>((want + tiles - 1) / tiles, std::max(1, nkb / 16));
   int per = (nkb + ksplit - 1) / ksplit;
@@ -525,8 +527,13 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   if (Bp % 256 == 0) {
     // 8 x 1 waves of 32 rows x 256 samples: an expanded A fragment feeds 16 MFMAs (0.8 vector instructions per MFMA)
     // few rows (the batches inside a climb): 512-row x 128-sample tiles -- twice the column blocks, half the K-splits
-    static const int small_v = std::getenv("MPF_GEMM_SMALL") ? std::atoi(std::getenv("MPF_GEMM_SMALL")) : 1;
+    // (C3 climb from a random tree, 1000 samples, product kernels in total: 512 x 128 tiles 0.298 s, 256 x 128 0.253 s, 128 x 128
+    //  0.234 s, 128 x 256 0.264 s -- fewer K-splits per output element, i.e. fewer atomic adds into C, and all CUs busy)
+    static const int small_v = std::getenv("MPF_GEMM_SMALL") ? std::atoi(std::getenv("MPF_GEMM_SMALL")) : 2;
     if (small_v == 1 && rows_padded <= 1024) return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (small_v == 2 && rows_padded <= 2048) return launch_bitgemm_t<1, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, 256);
+    if (small_v == 3 && rows_padded <= 2048) return launch_bitgemm_t<2, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (small_v == 4 && rows_padded <= 2048) return launch_bitgemm_t<1, 16, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
 #ifdef MPF_EXPERIMENTS                     // (knock-out variants of tools/gemm_bounds.sh, wrong results on purpose: `make EXPERIMENTS=1` only)
     static const int expr = std::getenv("MPF_GEMM_EXPERIMENT") ? std::atoi(std::getenv("MPF_GEMM_EXPERIMENT")) : 0;
     if (expr == 1) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 1>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
