@@ -34,8 +34,8 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 5   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
-                               4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep */
+#define MPF_ABI_VERSION 6   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
+                               4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep; 6: mpf_compute_parsimony_at */
 
 enum {
   MPF_OK = 0,
@@ -152,6 +152,13 @@ int mpf_site_scores(mpf_engine *e, int32_t *site_pars, int32_t n_sites, int32_t 
    tree from scratch plus the per-pattern lengths the reference leaves in _pattern_pars
    (phylotree.cpp:956-957, :986-987).  `back` may be NULL to use the current tree. */
 int mpf_compute_parsimony(mpf_engine *e, const int32_t *back, uint32_t *score, uint16_t *pattern_pars /* [P] or NULL */);
+/* The same, evaluated at the edge of leaf `root_taxon` (1-based; 0 = the engine's own start leaf, taxon 1).  Only matters for
+   the weighted engine with an ASYMMETRIC cost matrix, where the length of a tree depends on the edge it is rooted at:
+   ParsTree::computeParsimony() (parstree.cpp:101-116) roots at IQ-TREE's `root` leaf -- computeParsimonyBranch(root->neighbors[0],
+   root), :439-541: min_i( rest[i] + min_j( leaf[j] + cost[i][j] ) ), the rest of the tree as the parent side (rows of the matrix)
+   -- which is the orientation of this evaluation (and of evaluateSankoffParsimonyIterativeFastSIMD, sprparsimony.cpp:880-961).
+   (ABI 6) */
+int mpf_compute_parsimony_at(mpf_engine *e, const int32_t *back, int32_t root_taxon, uint32_t *score, uint16_t *pattern_pars);
 
 /* The IQ-TREE side of the reference stores Alignment::convertState codes (alignment.cpp:839-916):
    DNA 0..3, ambiguity = 4-bit mask + 3, STATE_UNKNOWN 18; protein 0..19, B 20, Z 21, STATE_UNKNOWN 22.

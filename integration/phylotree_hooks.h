@@ -39,6 +39,9 @@ struct mpf_phylotree_hooks {
   // ParsTree: cost_matrix[i * nstates + j] (parstree.h; loaded and triangle-repaired by loadCostMatrixFile,
   // parstree.cpp:31-95); NULL = unit costs (PhyloTree, and ParsTree with "-cost fitch|e")
   const unsigned int *(*cost_matrix)(const PhyloTree *);
+  // optional (may be NULL = taxon 0): t->root->id, the leaf ParsTree::computeParsimony() roots the tree at (parstree.cpp:101-116).
+  // Only an ASYMMETRIC cost matrix makes the length depend on it.
+  int (*root_id)(const PhyloTree *);
   // identity of the alignment the tree currently holds (t->aln).  NOT sufficient as a cache key: optimizeBootTrees does
   // `bootstrap_aln = new Alignment; ...; delete aln;` once per sample (iqtree.cpp:2519/2863, :2940/2977) and the allocator
   // hands the same address back, often with the same pattern count -- so the shim compares CONTENT: every call re-reads the

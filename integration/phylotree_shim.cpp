@@ -145,7 +145,11 @@ int compute(PhyloTree *t, const unsigned int *cost)
   unsigned short *pp = g_h.pattern_pars(t, P + kVcsizeUshort);           // phylotree.cpp:1056-1057
   std::memset(pp, 0, sizeof(unsigned short) * (size_t)(P + kVcsizeUshort));   // :957
   uint32_t score = 0;
-  if (mpf_compute_parsimony(e, back.data(), &score, pp)) die("mpf_compute_parsimony");
+  // ParsTree::computeParsimony() = computeParsimonyBranch(root->neighbors[0], root) (parstree.cpp:101-116): evaluated at the
+  // root leaf's edge, the rest of the tree as the parent side -- the engine's evaluation at that leaf (node number = id + 1)
+  const int root = (cost && g_h.root_id) ? g_h.root_id(t) : 0;
+  if (root < 0 || root >= n) { std::fprintf(stderr, "mpfitch phylotree shim: root %d is not a leaf id\n", root); std::exit(EXIT_FAILURE); }
+  if (mpf_compute_parsimony_at(e, back.data(), root + 1, &score, pp)) die("mpf_compute_parsimony_at");
   return (int)score;
 }
 
@@ -181,12 +185,7 @@ int _ZN8ParsTree16computeParsimonyEv(PhyloTree *self)
       for (int j = 0; j < S; j++)
         if (cost[i * S + j] != (i == j ? 0u : 1u)) { unit = false; break; }
     if (unit) cost = nullptr;
-    // (IQ-TREE's own Sankoff kernel roots the tree at its `root` leaf with its own parent / child convention; only for a
-    //  symmetric matrix is the length independent of that, and only then is the engine's number known to be IQ-TREE's)
-    if (cost)
-      for (int i = 0; i < S; i++)
-        for (int j = 0; j < i; j++)
-          if (cost[i * S + j] != cost[j * S + i]) die("ParsTree::computeParsimony: asymmetric cost matrix");
+    // (an asymmetric matrix makes the length depend on the rooting: compute() evaluates where ParsTree does, hook root_id)
   }
   return compute(self, cost);
 }

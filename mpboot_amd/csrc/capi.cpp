@@ -117,10 +117,20 @@ int mpf_site_scores(mpf_engine *e, int32_t *site_pars, int32_t n_sites, int32_t 
 
 int mpf_compute_parsimony(mpf_engine *e, const int32_t *back, uint32_t *score, uint16_t *pattern_pars)
 {
+  return mpf_compute_parsimony_at(e, back, 0, score, pattern_pars);
+}
+
+int mpf_compute_parsimony_at(mpf_engine *e, const int32_t *back, int32_t root_taxon, uint32_t *score, uint16_t *pattern_pars)
+{
   NEED(e);
   if (back) { int rc = e->eng.set_tree(back); if (rc) return rc; }
+  if (root_taxon < 0 || root_taxon > e->eng.n()) { set_error("mpf_compute_parsimony_at: root taxon out of range"); return MPF_E_INVALID; }
+  // (the tree is evaluated at the edge of the leaf in start_; 0 keeps the engine's own -- tr->start = taxon 1)
   uint32_t s = 0;
-  int rc = e->eng.score_tree(&s);
+  int rc = e->eng.score_tree(&s);            // (nodeRectifierPars puts start_ back on taxon 1: the guard goes behind it)
+  if (rc) return rc;
+  mpf::Engine::StartGuard guard(e->eng, root_taxon);
+  if (root_taxon > 1) rc = e->eng.tree_length_at_start(&s);
   if (rc) return rc;
   if (score) *score = s;
   if (pattern_pars) {

@@ -204,6 +204,15 @@ class Engine {
   // HIP's current device is per host thread: every entry point re-selects the engine's device first
   void activate() const { (void)hipSetDevice(dev_); }
   bool broken() const { return broken_; }
+  int tree_length_at_start(uint32_t *len) { return tree_length(len); }      // evaluateParsimony at start_'s edge, views as they are
+  // evaluate (score_tree / pattern_scores) at another leaf's edge for the life of the guard: with an asymmetric cost matrix the
+  // length of a tree depends on the edge it is rooted at (ParsTree::computeParsimony roots at IQ-TREE's `root` leaf)
+  struct StartGuard {
+    Engine &e;
+    int saved;
+    StartGuard(Engine &eng, int taxon) : e(eng), saved(eng.start_) { if (taxon >= 1) e.start_ = 3 * taxon; }
+    ~StartGuard() { e.start_ = saved; }
+  };
   int n() const { return n_; }
   int P() const { return P_; }
   int S() const { return sref_; }               // the reference's state count (the kernels' geometry may be wider: BIN in 4, GENERIC in 20)

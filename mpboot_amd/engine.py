@@ -25,7 +25,7 @@ EXPORTS = [
     "mpf_last_error", "mpf_abi_version", "mpf_engine_create", "mpf_engine_create_sankoff", "mpf_engine_destroy",
     "mpf_set_weights",
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
-    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_site_scores", "mpf_compute_parsimony",
+    "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_site_scores", "mpf_compute_parsimony", "mpf_compute_parsimony_at",
     "mpf_encode_iqtree_states", "mpf_seed_ties", "mpf_set_tie_state", "mpf_get_tie_state",
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
@@ -99,6 +99,7 @@ def load_library():
         L.mpf_pattern_scores.argtypes = [vp, vp, vp]
         L.mpf_site_scores.argtypes = [vp, vp, C.c_int32, vp]
         L.mpf_compute_parsimony.argtypes = [vp, vp, vp, vp]
+        L.mpf_compute_parsimony_at.argtypes = [vp, vp, C.c_int32, vp, vp]
         L.mpf_encode_iqtree_states.argtypes = [C.c_int32, vp, C.c_int64, vp]
         L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
         L.mpf_set_tie_state.argtypes = [vp, C.c_uint64]

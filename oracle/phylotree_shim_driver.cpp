@@ -59,6 +59,8 @@ static unsigned short *hk_ptnpars(PhyloTree *t, int len)
 }
 static const unsigned int *hk_cost(const PhyloTree *t) { return t->cost_matrix.empty() ? nullptr : t->cost_matrix.data(); }
 static const void *hk_alnid(const PhyloTree *t) { return t->states.data(); }
+static int g_root = 0;
+static int hk_root(const PhyloTree *) { return g_root; }
 
 static void read_tree(PhyloTree *t)
 {
@@ -91,10 +93,15 @@ int main()
   if (have_cost) { cost.resize((size_t)S * (size_t)S); for (auto &c : cost) if (std::scanf("%u", &c) != 1) return 2; }
   int T = 1;
   if (std::scanf("%15s %d", word, &T) != 2) return 2;
+  if (word[0] == 'r') {                                  // "root <leaf id>" in front of "trees T": IQ-TREE's root leaf
+    g_root = T;
+    if (std::scanf("%15s %d", word, &T) != 2) return 2;
+  }
 
   mpf_phylotree_hooks h{};
   h.n_taxa = hk_ntaxa; h.n_patterns = hk_nptn; h.is_protein = hk_prot; h.pattern = hk_pattern; h.neighbors = hk_nei;
   h.pattern_pars = hk_ptnpars; h.cost_matrix = hk_cost; h.alignment_id = hk_alnid;
+  h.root_id = hk_root;
   mpfitch_phylotree_install(&h);
 
   // mpboot holds its tree as IQTree (a PhyloTree) or, under -cost, as ParsTree; every caller goes through the base pointer

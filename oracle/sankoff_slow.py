@@ -33,8 +33,9 @@ def close_triangle(cost):
     return c
 
 
-def tree_cost(codes, weights, back, cost, datatype=0):
-    """-> (weighted tree cost, per-pattern costs) rooted on the branch of tip 1."""
+def tree_cost(codes, weights, back, cost, datatype=0, root_tip=1):
+    """-> (weighted tree cost, per-pattern costs) rooted on the branch of tip `root_tip`: min_i(rest[i] + min_j(leaf[j] + cost[i][j])),
+    the rest of the tree as the parent side (ParsTree::computeParsimonyBranch, parstree.cpp:439-541, from computeParsimony :101-116)."""
     n, P = codes.shape
     S = 4 if datatype == 0 else 20
     cost = close_triangle(cost)
@@ -61,9 +62,9 @@ def tree_cost(codes, weights, back, cost, datatype=0):
             return tipvec(v)
         return mplus(down(int(back[nx(rec)]))) + mplus(down(int(back[nx(nx(rec))])))
 
-    a = tipvec(1)
-    b = down(int(back[3]))
-    ptn = np.min(a + mplus(b), axis=0)
+    a = tipvec(root_tip)
+    b = down(int(back[3 * root_tip]))
+    ptn = np.min(b + mplus(a), axis=0)
     return int((ptn * np.asarray(weights, dtype=np.int64)).sum()), ptn
 
 
