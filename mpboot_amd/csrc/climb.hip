@@ -226,6 +226,8 @@ struct Sh {
   unsigned long long rng, hits, n_tests, n_ops, draws, n_nodes;
   uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, pn_base[kMaxB];
   uint32_t xcc, xm;                          // this workgroup's XCD and how many of the launch's workgroups share it
+  uint32_t qtail;                            // vectors the step's scans read, listed by the enumeration (validity looked at later)
+  uint32_t moved, einv, inv5[5];             // the move decide_select applied: stamp and touched nodes for the invalidation walk
   Unit unit[kMaxUnits];
   uint32_t pcnt[kMaxParts], poff[kMaxParts], pE[kMaxParts];
   uint32_t pn_off[kMaxB], pn_cnt[kMaxB], pn_np[kMaxB], pn_p[kMaxB];
@@ -253,6 +255,7 @@ struct Kx {
   uint32_t *PEND;    // [kLcap] stale inputs not yet recomputed (joins)
   uint16_t *OL;      // [kLcap] the first refresh ops, by index
   uint16_t *ord;     // [total] the sweep's visiting order
+  uint16_t *Q;       // [ns] what the enumeration lists (lives in the stage / pend region, idle between decide and refresh)
   unsigned long long pre, ancl, lsub;   // heap-index relations of this lane (enumeration)
   uint32_t n, ns, SW4;
   int lane, wave;
@@ -280,16 +283,34 @@ __device__ __forceinline__ void st_sl(const Kx<KS, VW> &K, uint32_t cid, uint32_
   if (K.cnt_lane) __builtin_amdgcn_raw_buffer_store_b32(v, K.rsrc_s, K.svoff, cid * 64u, 0);
 }
 
-// a vector the scans of this step read: if it is stale, claim it for the refresh (once per step)
+// a vector the scans of this step read: listed once per step (the claim word's epoch de-duplicates).  Whether it is stale is
+// looked at AFTER the enumeration (filter_required): the enumeration of a step runs beside the invalidation walk of the move
+// before it, which is still clearing validity flags.
 template <int KS, int VW>
 __device__ __forceinline__ void require(const Kx<KS, VW> &K, Sh &sh, uint32_t c, uint32_t epoch)
 {
-  // (the claim goes out with the validity read; on a valid vector or a tip it means nothing)
+  if (c < K.n) return;                                   // tips are never stale
   const uint32_t old = __hip_atomic_fetch_max(&K.cl[c], epoch << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if (!K.valid[c]) {
-    if ((old >> kEpochShift) != epoch) {
-      const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      K.W[slot] = (uint16_t)c;
+  if ((old >> kEpochShift) != epoch) {
+    const uint32_t slot = __hip_atomic_fetch_add(&sh.qtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    K.Q[slot] = (uint16_t)c;
+  }
+}
+
+// the stale ones among the listed vectors become the closure's work list (all waves; order is free: every workgroup decides
+// from the exchanged sums only, never from the order in which it refreshed its own tile)
+template <int KS, int VW>
+__device__ __forceinline__ void filter_required(const Kx<KS, VW> &K, Sh &sh, int tid, int nthreads)
+{
+  const uint32_t nq = sh.qtail;
+  for (uint32_t base = 0; base < nq; base += (uint32_t)nthreads) {
+    const uint32_t i = base + (uint32_t)tid;
+    const uint32_t c = i < nq ? (uint32_t)K.Q[i] : 0u;
+    const bool stale = i < nq && !K.valid[c];
+    const unsigned long long m = __ballot((int)stale);
+    if (m) {
+      const uint32_t at = wave_fetch_add(&sh.wtail, (uint32_t)__builtin_popcountll(m), K.lane);
+      if (stale) K.W[at + (uint32_t)__builtin_popcountll(m & ((1ull << K.lane) - 1ull))] = (uint16_t)c;
     }
   }
 }
@@ -998,65 +1019,12 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
       K.bk[p1] = (uint16_t)q; K.bk[q] = (uint16_t)p1;
       K.bk[p2] = (uint16_t)r; K.bk[r] = (uint16_t)p2;
     }
-    // every vector whose subtree contains an edited node is stale: the three of each edited node and, walking outwards, the
-    // two outward-looking ones of every node reached, as far as they were valid
-    const uint32_t einv = sh.epoch + 1u;
-    uint32_t five = a;
-    five = lane / 3 == 1 ? b : five;
-    five = lane / 3 == 2 ? p : five;
-    five = lane / 3 == 3 ? q : five;
-    five = lane / 3 == 4 ? r : five;
-    bool have = false;
-    uint32_t item = 0;
-    if (lane < 15 && five >= n) {
-      const uint32_t rec = five - (five - n) % 3u + (uint32_t)(lane % 3);
-      K.valid[rec] = 0;
-      const uint32_t w = K.bk[rec];
-      if (w >= n) { have = true; item = w; }
-    }
-    uint32_t head = 0;
-    uint32_t round = 0;
-    if (lane == 0) sh.wtail = 0;
-    for (;; round++) {
-      if (round > K.ns) { if (lane == 0) sh.err = 4u; break; }
-      const uint32_t tail = *(volatile uint32_t *)&sh.wtail;
-      {
-        const unsigned long long need = __ballot((int)!have);
-        const uint32_t rank = (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-        const uint32_t avail = tail - head;
-        if (!have && rank < avail) { item = K.W[head + rank]; have = true; }
-        const uint32_t want = (uint32_t)__builtin_popcountll(need);
-        head += want < avail ? want : avail;
-      }
-      if (!__ballot((int)have)) break;
-#pragma unroll 1
-      for (int step = 0; step < 4; step++) {
-        if (have) {
-          uint32_t o1, o2;
-          ring2(item, n, o1, o2);
-          // (one LDS round trip per link: claims, validity and the records behind go out together)
-          const uint32_t c1 = __hip_atomic_fetch_max(&K.cl[o1], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const uint32_t c2 = __hip_atomic_fetch_max(&K.cl[o2], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const uint32_t x1 = K.valid[o1], x2 = K.valid[o2];
-          const uint32_t u1 = K.bk[o1], u2 = K.bk[o2];
-          const bool v1 = ((c1 >> kEpochShift) != einv) & (x1 != 0u), v2 = ((c2 >> kEpochShift) != einv) & (x2 != 0u);
-          if (v1) K.valid[o1] = 0;
-          if (v2) K.valid[o2] = 0;
-          const bool g1 = v1 & (u1 >= n), g2 = v2 & (u2 >= n);
-          if (g1) {
-            item = u1;
-            if (g2) {
-              const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              K.W[slot] = (uint16_t)u2;
-            }
-          } else if (g2) item = u2;
-          else have = false;
-        }
-      }
-    }
-    if (lane == 0) sh.c_inv += round;
+    // (the invalidation this edit causes is walked after the barrier behind this function, beside the next step's enumeration:
+    //  invalidate_walk)
+    if (lane == 0) { sh.inv5[0] = a; sh.inv5[1] = b; sh.inv5[2] = p; sh.inv5[3] = q; sh.inv5[4] = r; sh.einv = sh.epoch + 1u; }
   }
   if (lane == 0) {
+    sh.moved = moved ? 1u : 0u;
     if (sh.ncand) { sh.last_ncand[sh.xgen % 3u] = sh.ncand; sh.xgen++; }
     sh.best = best; sh.randomMP = randomMP; sh.iter_hits = iter_hits;
     sh.rng = rng; sh.hits = hits; sh.draws = draws; sh.ins = ins; sh.rem = rem;
@@ -1073,7 +1041,10 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     uint32_t B = moved ? P.batch_min : sh.B * 2u;
     B = B > P.batch_max ? P.batch_max : B;
     B = B < 1u ? 1u : B;
+    if (pos <= P.total && B > P.total - pos + 1u) B = P.total - pos + 1u;      // (not beyond the end of the sweep)
     sh.B = B;
+    // the next step's counters (its enumeration starts right behind the barrier that follows)
+    sh.rtail = 0; sh.rhead = 0; sh.ndone = 0; sh.nops = 0; sh.task = 0; sh.qtail = 0;
     uint32_t reason = CLIMB_RUNNING;
     if (pos > P.total) reason = CLIMB_SWEEP_END;
     else if (n_moves >= P.max_moves || sh.epoch > kEpochLimit) reason = CLIMB_MOVES_FULL;
@@ -1082,6 +1053,71 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     if (sh.err) reason = CLIMB_ERROR;
     sh.exit_reason = reason;
   }
+}
+
+// ---- (6b) wave 0, beside the next step's enumeration: every vector whose subtree contains an edited node is stale -- the three
+// of each edited node and, walking outwards, the two outward-looking ones of every node reached, as far as they were valid.
+// (The enumeration stamps claim words with the NEXT epoch meanwhile; the stamp of this walk only saves second visits, validity
+//  decides.)
+template <int KS, int VW>
+__device__ __forceinline__ void invalidate_walk(const Kx<KS, VW> &K, Sh &sh)
+{
+  const int lane = K.lane;
+  const uint32_t n = K.n, einv = sh.einv;
+  uint32_t five = sh.inv5[0];
+  five = lane / 3 == 1 ? sh.inv5[1] : five;
+  five = lane / 3 == 2 ? sh.inv5[2] : five;
+  five = lane / 3 == 3 ? sh.inv5[3] : five;
+  five = lane / 3 == 4 ? sh.inv5[4] : five;
+  bool have = false;
+  uint32_t item = 0;
+  if (lane < 15 && five >= n) {
+    const uint32_t rec = five - (five - n) % 3u + (uint32_t)(lane % 3);
+    K.valid[rec] = 0;
+    const uint32_t w = K.bk[rec];
+    if (w >= n) { have = true; item = w; }
+  }
+  uint32_t head = 0;
+  uint32_t round = 0;
+  if (lane == 0) sh.wtail = 0;
+  for (;; round++) {
+    if (round > K.ns) { if (lane == 0) sh.err = 4u; break; }
+    const uint32_t tail = *(volatile uint32_t *)&sh.wtail;
+    {
+      const unsigned long long need = __ballot((int)!have);
+      const uint32_t rank = (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+      const uint32_t avail = tail - head;
+      if (!have && rank < avail) { item = K.W[head + rank]; have = true; }
+      const uint32_t want = (uint32_t)__builtin_popcountll(need);
+      head += want < avail ? want : avail;
+    }
+    if (!__ballot((int)have)) break;
+#pragma unroll 1
+    for (int step = 0; step < 4; step++) {
+      if (have) {
+        uint32_t o1, o2;
+        ring2(item, n, o1, o2);
+        // (one LDS round trip per link: claims, validity and the records behind go out together)
+        const uint32_t c1 = __hip_atomic_fetch_max(&K.cl[o1], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t c2 = __hip_atomic_fetch_max(&K.cl[o2], einv << kEpochShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t x1 = K.valid[o1], x2 = K.valid[o2];
+        const uint32_t u1 = K.bk[o1], u2 = K.bk[o2];
+        const bool v1 = ((c1 >> kEpochShift) != einv) & (x1 != 0u), v2 = ((c2 >> kEpochShift) != einv) & (x2 != 0u);
+        if (v1) K.valid[o1] = 0;
+        if (v2) K.valid[o2] = 0;
+        const bool g1 = v1 & (u1 >= n), g2 = v2 & (u2 >= n);
+        if (g1) {
+          item = u1;
+          if (g2) {
+            const uint32_t slot = __hip_atomic_fetch_add(&sh.wtail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            K.W[slot] = (uint16_t)u2;
+          }
+        } else if (g2) item = u2;
+        else have = false;
+      }
+    }
+  }
+  if (lane == 0) sh.c_inv += round;
 }
 
 template <int KS, int VW>
@@ -1099,7 +1135,8 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
   K.cl = reinterpret_cast<uint32_t *>(smem + at); at += (((size_t)ns * 4) + 15) & ~(size_t)15;
   K.prog = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
   K.stage = reinterpret_cast<uint32_t *>(smem + at);
-  K.pend = reinterpret_cast<uint32_t *>(smem + at); at += Cfg<KS, VW>::kRegion;
+  K.pend = reinterpret_cast<uint32_t *>(smem + at);
+  K.Q = reinterpret_cast<uint16_t *>(smem + at); at += Cfg<KS, VW>::kRegion;       // (ns entries of 2 bytes: fits the region for every ns the other arrays allow)
   K.D = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * sizeof(uint2);
   K.CONS = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * 2 * sizeof(uint2);
   K.NC = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
@@ -1161,6 +1198,8 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     sh.best = h.best; sh.randomMP = h.randomMP; sh.iter_hits = h.iter_hits; sh.ins = h.insert_cid; sh.rem = h.remove_cid;
     sh.rng = h.rng; sh.hits = h.hits; sh.n_tests = 0; sh.n_ops = 0; sh.draws = 0; sh.n_nodes = 0;
     if (sh.B > (uint32_t)kMaxB) sh.B = kMaxB;
+    if (sh.pos <= P.total && sh.B > P.total - sh.pos + 1u) sh.B = P.total - sh.pos + 1u;
+    sh.wtail = 0; sh.rhead = 0; sh.ndone = 0; sh.nops = 0; sh.task = 0; sh.qtail = 0; sh.moved = 0; sh.einv = 0;
     for (int i = 0; i < 16; i++) sh.tph[i] = 0;
     sh.c_rounds = sh.c_inv = sh.c_chains = sh.c_parts = sh.c_inv2 = sh.c_dynops = 0;
     sh.clk0 = __builtin_amdgcn_s_memtime(); sh.rt0 = sh.tlast;
@@ -1194,27 +1233,26 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     return;
   }
 
+#define MPF_TMARK(i) do { if (tile == 0 && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); sh.tph[i] += now_ - sh.tlast; sh.tlast = now_; } } while (0)
+  bool first = true;
   for (;;) {
-    // ---- step set-up
-    for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;     // last step's chain starts
-    if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
-    for (uint32_t i = (uint32_t)tid; i < kClimbCap; i += kThreads) K.cost[i] = 0u;
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t left = P.total - sh.pos + 1u;
-      if (sh.B > left) sh.B = left;
-      sh.wtail = 0; sh.rtail = 0; sh.rhead = 0; sh.ndone = 0; sh.nops = 0; sh.task = 0;
+    // ---- (1) the step's enumeration.  First step of the launch: all waves, right here.  Later steps: it ran behind decide_select
+    // of the step before (bottom of the loop), on waves 1.. beside wave 0's invalidation walk.
+    if (first) {
+      if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
+      for (uint32_t i = (uint32_t)tid; i < kClimbCap; i += kThreads) K.cost[i] = 0u;
+      for (uint32_t u = (uint32_t)wave; u < 2u * sh.B; u += kNW) enum_unit<KS, VW>(K, sh, P, u);
+      first = false;
     }
     __syncthreads();
     const uint32_t B = sh.B;
     beat(P, tile, tid, 0, sh.steps); beat(P, tile, tid, 2, sh.pos); beat(P, tile, tid, 3, B); beat(P, tile, tid, 1, 1);
-#define MPF_TMARK(i) do { if (tile == 0 && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); sh.tph[i] += now_ - sh.tlast; sh.tlast = now_; } } while (0)
-    MPF_TMARK(0);
-    // ---- (1)
-    for (uint32_t u = (uint32_t)wave; u < 2u * B; u += kNW) enum_unit<KS, VW>(K, sh, P, u);
+    MPF_TMARK(1);
+    // the stale ones among the vectors the scans read: the closure's work list (validity is final now: the walk is over)
+    filter_required<KS, VW>(K, sh, tid, (int)kThreads);
     __syncthreads();
     beat(P, tile, tid, 1, 2);
-    MPF_TMARK(1);
+    MPF_TMARK(0);
     // ---- (2)
     if (wave == 0) plan_and_discover<KS, VW>(K, sh);
     __syncthreads();
@@ -1225,6 +1263,10 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     __syncthreads();
     beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
     MPF_TMARK(3);
+    // (the refresh's lists are done with: chain starts back to "none", consumer counts to zero -- nothing reads them before the
+    //  next closure, which runs several barriers on)
+    for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
+    if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
     // ---- (4)
     const uint32_t ncand = sh.ncand;
     {
@@ -1303,12 +1345,21 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     __syncthreads();
     beat(P, tile, tid, 1, 6);
     MPF_TMARK(5);
-    // ---- (6)
+    // ---- (6a) the reference's bookkeeping over the step's prune nodes; an accepted move is applied to the topology
     if (wave == 0) decide<KS, VW>(K, sh, P, tile);
     __syncthreads();
     beat(P, tile, tid, 8, sh.err);
     MPF_TMARK(6);
     if (sh.exit_reason != CLIMB_RUNNING) break;
+    // ---- (6b) side by side: wave 0 walks the invalidation the move causes, the other waves clear the candidate sums and enumerate
+    // the NEXT step on the edited topology (pure topology work; what it lists is looked at for validity behind the barrier)
+    if (wave == 0) {
+      if (sh.moved) invalidate_walk<KS, VW>(K, sh);
+      if (lane == 0) sh.wtail = 0;                       // (the walk's work list is done with: the filter fills it anew)
+    } else {
+      for (uint32_t i = (uint32_t)tid - 64u; i < kClimbCap; i += kThreads - 64u) K.cost[i] = 0u;
+      for (uint32_t u = (uint32_t)wave - 1u; u < 2u * sh.B; u += kNW - 1u) enum_unit<KS, VW>(K, sh, P, u);
+    }
   }
   beat(P, tile, tid, 1, 9);
   // ---- hand the state back
