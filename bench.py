@@ -521,6 +521,7 @@ def main():
     ap.add_argument("--engines-per-gpu", type=int, default=6, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--climb-engines", type=int, default=8,
                     help="independent SPR climbs side by side on one GPU (one engine per host thread): the concurrent_climbs leg (0 = skip)")
+    ap.add_argument("--c2-engines", type=int, default=16, help="concurrent engines (host threads) in the C2 concurrent-climbs leg")
     ap.add_argument("--start-engines", type=int, default=6, help="concurrent engines (host threads) per GPU in the start-trees leg")
     ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
     ap.add_argument("--start-trees", type=int, default=100,
@@ -1049,6 +1050,47 @@ def main():
                 if c2leg["cpu_baseline"]:
                     c2leg["gpu_over_cpu"] = c2leg["cpu_baseline"]["seconds"] / c2leg["seconds"]
             del e2
+            # ... and many such climbs side by side (independent start trees: what the start-up phase and the bootstrap
+            # refinement of a small alignment look like): one engine per host thread, 64-word tiles = 5 workgroups per climb
+            try:
+                ncore = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncore = os.cpu_count() or 1
+            k2 = max(1, min(args.c2_engines, ncore))
+            es = []
+            for _ in range(k2):
+                x = engine.FitchEngine(codes2, datatype=engine.DNA, device=device)
+                x.set_option("climb_tile", 4)
+                es.append(x)
+            per = 6
+            starts2 = [[trees.random_topology(codes2.shape[0], np.random.default_rng(7000 + 97 * i + j)) for j in range(per)] for i in range(k2)]
+            sc2 = [None] * k2
+
+            def c2_work(i):
+                x, out = es[i], []
+                for j in range(per):
+                    x.set_tree(starts2[i][j])
+                    x.reset_node_order()
+                    x.seed_ties(engine.TIE_RANDOM, 100 + i * per + j)
+                    out.append(x.optimize_spr(1, args.maxtrav))
+                sc2[i] = out
+
+            for rep in range(2):                          # (the first round allocates the climb buffers)
+                th2 = [_th.Thread(target=c2_work, args=(i,)) for i in range(k2)]
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for t in th2:
+                    t.start()
+                for t in th2:
+                    t.join()
+                t_c2 = time.perf_counter() - t0_
+            cb2 = c2leg.get("cpu_baseline")
+            c2leg["concurrent"] = {"engines": k2, "climbs": k2 * per, "seconds": t_c2, "climbs_per_s": k2 * per / t_c2,
+                                   "climb_launches_engine0": es[0].stats()["climb_launches"],
+                                   "reference_climbs_per_s_one_core": (1.0 / cb2["seconds"]) if cb2 else None,
+                                   "what": "%d engines on host threads, %d climbs each from different random topologies, k_climb with 64-word tiles "
+                                           "(5 workgroups per climb)" % (k2, per)}
+            del es
         if world == 1 and args.workload == "C3" and args.weighted_leg:
             # BASELINE config 5 in its `-cost` form: the weighted (Sankoff) engine on 500 taxa x 20 000 protein patterns, 20 states
             letters5, names5 = synth.workload("C5")
