@@ -521,6 +521,7 @@ def main():
     ap.add_argument("--engines-per-gpu", type=int, default=6, help="concurrent engines (host threads) per GPU in the refinement leg")
     ap.add_argument("--climb-engines", type=int, default=8,
                     help="independent SPR climbs side by side on one GPU (one engine per host thread): the concurrent_climbs leg (0 = skip)")
+    ap.add_argument("--climb-tile", type=int, default=4, help="words per lane group of k_climb in the concurrent-climbs leg (4: 25, 8: 13 workgroups per C3 climb)")
     ap.add_argument("--c2-engines", type=int, default=16, help="concurrent engines (host threads) in the C2 concurrent-climbs leg")
     ap.add_argument("--start-engines", type=int, default=6, help="concurrent engines (host threads) per GPU in the start-trees leg")
     ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
@@ -990,8 +991,8 @@ def main():
                     x.seed_ties(engine.TIE_RANDOM, 1 + i)
                     return x.optimize_spr(1, args.maxtrav)
                 return f
-            run_threads(E, climb_fn(2, 4))                                     # buffers, code
-            t_dev, sc_dev = run_threads(E, climb_fn(2, 4))
+            run_threads(E, climb_fn(2, args.climb_tile))                       # buffers, code
+            t_dev, sc_dev = run_threads(E, climb_fn(2, args.climb_tile))
             t_host, sc_host = run_threads(E, climb_fn(0, 1))
             for x in pool:
                 x.set_option("climb_device", 1)
@@ -1000,9 +1001,9 @@ def main():
             conc = {"engines": E, "climbs_per_s": E / t_dev, "seconds_per_round": t_dev, "scores": [int(min(sc_dev)), int(max(sc_dev))],
                     "host_driven_batches": {"climbs_per_s": E / t_host, "seconds_per_round": t_host},
                     "what": "%d independent SPR climbs (radius %d) from random topologies side by side on one GPU, one engine per host "
-                            "thread; each climb runs in the persistent kernel k_climb (64-word tiles: %d workgroups per climb); "
+                            "thread; each climb runs in the persistent kernel k_climb (%d-word tiles: %d workgroups per climb); "
                             "host_driven_batches = the same climbs with the loop on the host (engine option climb_device = 0).  "
-                            "GPU_MAX_HW_QUEUES=%s" % (E, args.maxtrav, (eng.Wp + 63) // 64, os.environ.get("GPU_MAX_HW_QUEUES"))}
+                            "GPU_MAX_HW_QUEUES=%s" % (E, args.maxtrav, 16 * args.climb_tile, (eng.Wp + 16 * args.climb_tile - 1) // (16 * args.climb_tile), os.environ.get("GPU_MAX_HW_QUEUES"))}
         if args.start_trees > 0:
             # the start-up phase of a run: numpars randomized-stepwise-addition trees, each SPR-optimised (phyloanalysis.cpp:1270-1317,
             # tools.cpp:767); unit u on rank u % n_gpus, several engines per GPU

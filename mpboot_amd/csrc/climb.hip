@@ -48,7 +48,9 @@ template <int KS, int VW> struct Cfg {
   static constexpr int R = KS * VW;                                   // registers per vector tile
   // waves per workgroup: sixteen where the tiles are small (the scan's programs and the refresh's chains are dealt to them),
   // eight where a wave's parked up-vectors would not fit the LDS sixteen times
-  static constexpr int NW = R <= 2 ? 16 : 8;
+  // (DNA on 128-word tiles -- many climbs side by side on one chip, 13 workgroups each at C3 --: four, or the parked up-vectors
+  //  would not fit beside the control state)
+  static constexpr int NW = R <= 2 ? 16 : (KS == 1 && VW == 8) ? 4 : 8;
   static constexpr int NT = NW * 64;
   static constexpr int PF = R <= 2 ? 8 : 4;                           // expansions whose child vectors are requested together
   // operand slots of the refresh (vector + per-lane subtree scores) and the parked up-vectors of the scan are never alive
@@ -152,8 +154,11 @@ __device__ __forceinline__ void qload(QT<KS, VW> &t, __amdgpu_buffer_rsrc_t rsrc
       const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[k], soff, 0);
       t.v[k][0] = x[0]; t.v[k][1] = x[1];
     } else {
-      const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], soff, 0);
-      t.v[k][0] = x[0]; t.v[k][1] = x[1]; t.v[k][2] = x[2]; t.v[k][3] = x[3];
+#pragma unroll
+      for (int h = 0; h < VW / 4; h++) {
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k] + 16u * (uint32_t)h, soff, 0);
+        t.v[k][4 * h] = x[0]; t.v[k][4 * h + 1] = x[1]; t.v[k][4 * h + 2] = x[2]; t.v[k][4 * h + 3] = x[3];
+      }
     }
   }
 }
@@ -169,8 +174,11 @@ __device__ __forceinline__ void qstore(const QT<KS, VW> &t, __amdgpu_buffer_rsrc
       v2u x; x[0] = t.v[k][0]; x[1] = t.v[k][1];
       __builtin_amdgcn_raw_buffer_store_b64(x, rsrc, voff[k], soff, 0);
     } else {
-      v4u x; x[0] = t.v[k][0]; x[1] = t.v[k][1]; x[2] = t.v[k][2]; x[3] = t.v[k][3];
-      __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, voff[k], soff, 0);
+#pragma unroll
+      for (int h = 0; h < VW / 4; h++) {
+        v4u x; x[0] = t.v[k][4 * h]; x[1] = t.v[k][4 * h + 1]; x[2] = t.v[k][4 * h + 2]; x[3] = t.v[k][4 * h + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, voff[k] + 16u * (uint32_t)h, soff, 0);
+      }
     }
   }
 }
@@ -1272,21 +1280,30 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     {
       // length of the two sides of the prune branch (this tile's share): per-lane scores summed over the word groups -- wave j
       // asks for prune node j's two score rows now and folds them after its scan tasks
-      uint32_t bv1 = 0, bv2 = 0;
-      const bool has_base = (uint32_t)wave < sh.Beff;
-      if (has_base) {
-        const uint32_t p = rfl(sh.pn_p[wave]), q = rfl((uint32_t)K.bk[p]);
-        bv1 = ld_sl<KS, VW>(K, p);
-        bv2 = ld_sl<KS, VW>(K, q);
+      // (workgroups of fewer than kMaxB waves: a wave takes prune nodes wave, wave + kNW)
+      constexpr int kBaseRounds = (kMaxB + (int)kNW - 1) / (int)kNW;
+      uint32_t bv[kBaseRounds];
+#pragma unroll
+      for (int rr = 0; rr < kBaseRounds; rr++) {
+        const uint32_t j = (uint32_t)wave + (uint32_t)rr * kNW;
+        bv[rr] = 0;
+        if (j < sh.Beff) {
+          const uint32_t p = rfl(sh.pn_p[j]), q = rfl((uint32_t)K.bk[p]);
+          bv[rr] = ld_sl<KS, VW>(K, p) + ld_sl<KS, VW>(K, q);
+        }
       }
       const uint32_t ntasks = sh.ntasks;
       for (uint32_t ti = (uint32_t)wave; ti < ntasks; ti += kNW) {
         const uint32_t t = rfl((uint32_t)sh.tl[ti]);
         scan_part<KS, VW>(K, sh, t >> 1, t & 1u);
       }
-      if (has_base) {
-        const uint32_t tot = wave_total(K.cnt_lane ? bv1 + bv2 : 0u);
-        if (lane == 0) sh.pn_base[wave] = tot;
+#pragma unroll
+      for (int rr = 0; rr < kBaseRounds; rr++) {
+        const uint32_t j = (uint32_t)wave + (uint32_t)rr * kNW;
+        if (j < sh.Beff) {
+          const uint32_t tot = wave_total(K.cnt_lane ? bv[rr] : 0u);
+          if (lane == 0) sh.pn_base[j] = tot;
+        }
       }
     }
     __syncthreads();
@@ -1428,7 +1445,7 @@ int climb_tiles(const Geometry &g, int vw) { return (g.Wp + 16 * vw - 1) / (16 *
 size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw)
 {
   const uint32_t ns = slots_of(n_taxa);
-  if (g.S == 4) return vw == 1 ? lds_bytes<1, 1>(ns) : vw == 2 ? lds_bytes<1, 2>(ns) : lds_bytes<1, 4>(ns);
+  if (g.S == 4) return vw == 1 ? lds_bytes<1, 1>(ns) : vw == 2 ? lds_bytes<1, 2>(ns) : vw == 4 ? lds_bytes<1, 4>(ns) : lds_bytes<1, 8>(ns);
   if (g.S == 32) return lds_bytes<8, 1>(ns);
   return lds_bytes<5, 1>(ns);
 }
@@ -1448,6 +1465,7 @@ hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbPa
   if (g.S == 4) {
     if (vw == 1) return launch_t<1, 1>(st, p);
     if (vw == 2) return launch_t<1, 2>(st, p);
+    if (vw == 8) return launch_t<1, 8>(st, p);
     return launch_t<1, 4>(st, p);
   }
   if (g.S == 32) return launch_t<8, 1>(st, p);           // 32-state data: eight states per lane

@@ -2001,7 +2001,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   if (key == "climb_device") { climb_device_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; return MPF_OK; }
   if (key == "climb_tile") {
-    if (v != 1 && v != 2 && v != 4) { set_error("climb_tile: 1|2|4 words per lane group (tiles of 16, 32, 64 words)"); return MPF_E_INVALID; }
+    if (v != 1 && v != 2 && v != 4 && v != 8) { set_error("climb_tile: 1|2|4|8 words per lane group (tiles of 16, 32, 64, 128 words)"); return MPF_E_INVALID; }
     climb_vw_ = (int)v;
     return MPF_OK;
   }

@@ -51,7 +51,7 @@ struct GateHold {
 }  // namespace
 
 // k_climb's workgroups wait for each other: a launch whose tiles cannot all be resident would spin until its start barrier times
-// out, every time.  The tile width the launch will use: option "climb_tile", widened (DNA: 2, 4 words per lane group) until the
+// out, every time.  The tile width the launch will use: option "climb_tile", widened (DNA: 2, 4, 8 words per lane group) until the
 // workgroups fit 85 % of the CUs (several per CU where the control state is small); 0 = this alignment is too long for the kernel.
 int Engine::climb_fit_vw()
 {
@@ -61,7 +61,7 @@ int Engine::climb_fit_vw()
     climb_cus_ = c;
   }
   const int cap = std::max(1, climb_cus_ * 85 / 100);
-  for (int vw = (g_.S == 4) ? std::max(1, climb_vw_) : 1; vw <= ((g_.S == 4) ? 4 : 1); vw *= 2) {
+  for (int vw = (g_.S == 4) ? std::max(1, climb_vw_) : 1; vw <= ((g_.S == 4) ? 8 : 1); vw *= 2) {
     const size_t lds = climb_lds_bytes(g_, n_, vw);
     if (lds > 160 * 1024) continue;
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));

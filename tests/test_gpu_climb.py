@@ -71,7 +71,7 @@ def test_device_climb_matches_oracle_on_fixtures(mods, name, tie, radius):
 @pytest.mark.parametrize("alpha,n,P", [("DNA", 60, 1500), ("DNA", 150, 4000), ("AA", 40, 900)])
 def test_device_climb_equals_host_batches(mods, alpha, n, P):
     """the same engine code path with the loop on the host (climb_device 0), on the device while moves are dense (1, the
-    default) and always on the device (2): identical moves; tiles of 16, 32 and 64 words; every speculative batch size"""
+    default) and always on the device (2): identical moves; tiles of 16, 32, 64 and 128 words; every speculative batch size"""
     engine, po, synth, trees = mods
     letters, _ = synth.synth_alignment(n, P, alpha, 0.06, seed=n)
     codes = synth.letters_to_codes(letters, alpha)
@@ -81,7 +81,7 @@ def test_device_climb_equals_host_batches(mods, alpha, n, P):
     variants = [dict(mode=0), dict(mode=1), dict(mode=2), dict(mode=2, climb_batch_min=1, climb_batch_max=1),
                 dict(mode=2, climb_batch_min=8, climb_batch_max=8), dict(mode=1, climb_idle=8)]
     if alpha == "DNA":
-        variants += [dict(mode=2, climb_tile=2), dict(mode=2, climb_tile=4)]
+        variants += [dict(mode=2, climb_tile=2), dict(mode=2, climb_tile=4), dict(mode=2, climb_tile=8)]
     for v in variants:
         v = dict(v)
         mode = v.pop("mode")
