@@ -1213,27 +1213,33 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     sh.clk0 = __builtin_amdgcn_s_memtime(); sh.rt0 = sh.tlast;
     sh.tlast = __builtin_amdgcn_s_memrealtime();
     // every workgroup must be resident before anyone waits for anyone: arrive, then wait for the others -- not for ever
-    // (counted per XCD first: the release order of the two adds makes the per-XCD counts final once everybody has arrived)
-    sh.xcc = (uint32_t)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 7u;
-    __hip_atomic_fetch_add(&P.xcnt[sh.xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (exchange groups: workgroup b belongs to group b % 8 -- the workgroups the dispatcher deals to one XCD, so a group's
+    //  level-1 words normally live in one L2; membership is by NUMBER, not by where a workgroup happens to run: a preempted
+    //  workgroup may come back on another XCD, and the protocol must not care)
+    sh.xcc = tile & 7u;
     __hip_atomic_fetch_add(&P.hdr->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t ok = 1;
+    // go or abort is ONE word decided by ONE compare-and-swap: whoever sees everybody arrived proposes "go", whoever runs out of
+    // time proposes "abort", the first proposal stands and everybody -- also a workgroup that only becomes resident later --
+    // follows it (round 3 let a time-out and the last arrival race: some tiles left, the others waited for them in the exchange)
+    uint32_t gate = 0;
     for (;;) {
-      if (__hip_atomic_load(&P.hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
-      if (__hip_atomic_load(&P.hdr->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= T) break;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 30ull * 100000ull) {      // 30 ms of the 100 MHz clock
-        __hip_atomic_store(&P.hdr->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
+      gate = __hip_atomic_load(&P.hdr->start_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gate) break;
+      uint32_t want = 0;
+      if (P.fault == 0xFFFFFFFFu) want = 2u;
+      else if (__hip_atomic_load(&P.hdr->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= T) want = 1u;
+      else if (__builtin_amdgcn_s_memrealtime() - t0 > 30ull * 100000ull) want = 2u;      // 30 ms of the 100 MHz clock
+      if (want) {
+        uint32_t expect = 0;
+        __hip_atomic_compare_exchange_strong(&P.hdr->start_gate, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
       }
       __builtin_amdgcn_s_sleep(8);
     }
-    // (a workgroup that saw everybody arrive may still be overtaken by another one's time-out: look once more)
-    if (ok && __hip_atomic_load(&P.hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
-        __hip_atomic_load(&P.hdr->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T) ok = 0;
+    const uint32_t ok = gate == 1u ? 1u : 0u;
     sh.ok = ok;
-    sh.xm = ok ? __hip_atomic_load(&P.xcnt[sh.xcc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    sh.xm = (T >> 3) + ((tile & 7u) < (T & 7u) ? 1u : 0u);          // workgroups b < T with b % 8 == tile % 8
   }
   __syncthreads();
   if (!sh.ok) {
@@ -1313,13 +1319,14 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     if (ncand) {
       const uint32_t slot = sh.xgen % 3u;
       unsigned long long *gs = P.gsum + (size_t)slot * kClimbCap;
-      // level 1: this XCD's own words.  Every address below is touched by the workgroups of ONE XCD only, so these atomics are
-      // issued at workgroup scope -- they execute in that XCD's L2 and never cross the fabric; the returned count tells the last
-      // workgroup of the XCD that the total is complete.  Level 2: that one forwards it with a device-scope add (count = the XCD's
-      // workgroups) and clears the level-1 word for its next turn, three exchanges on.
+      // level 1: the words of this workgroup's group (every eighth workgroup: 12-13 adds per word instead of 98 -- same-address
+      // atomics are served one after the other); the returned count tells the group's last workgroup that the total is complete.
+      // Level 2: that one forwards it with one more add (count = the group's workgroups) and clears the level-1 word for its next
+      // turn, three exchanges on.  All device scope: correctness does not depend on where a workgroup runs.
       unsigned long long *xs = P.xsum + ((size_t)sh.xcc * 3u + slot) * kClimbCap;
       const uint32_t xm = sh.xm;
-      for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
+      const bool withhold = P.fault && P.fault != 0xFFFFFFFFu && sh.steps + 1u == P.fault && tile + 1u == T && T > 1u;
+      for (uint32_t c = (uint32_t)tid; c < ncand && !withhold; c += kThreads) {
         uint32_t j = 0;
         while (j + 1u < sh.Beff && c >= sh.pn_off[j + 1u]) j++;
         const uint32_t val = K.cost[c] + sh.pn_base[j];
@@ -1327,25 +1334,38 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
           __hip_atomic_fetch_add(gs + c, (1ull << 40) | (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
           const unsigned long long mine = (1ull << 40) | (unsigned long long)val;
-          const unsigned long long old = __hip_atomic_fetch_add(xs + c, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const unsigned long long old = __hip_atomic_fetch_add(xs + c, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(old >> 40) + 1u == xm) {
             const unsigned long long tot = old + mine;
             __hip_atomic_fetch_add(gs + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_sub(xs + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_sub(xs + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
       for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
-        unsigned long long v;
+        unsigned long long v, wait0 = 0ull;
         uint32_t spins = 0;
         for (;;) {
           v = __hip_atomic_load(gs + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(v >> 40) >= T) break;
-          if ((++spins & 1023u) == 0u) {
-            // a tile that never arrives (it cannot happen once every workgroup is resident) must not hang the GPU: whoever
-            // notices first tells everybody through the header, and the launch ends with CLIMB_ERROR
+          if ((++spins & 255u) == 0u) {
+            // a tile that does not arrive: with every workgroup resident that cannot happen -- but a chip shared with OTHER
+            // processes' persistent kernels can take some of this launch's workgroups off their CUs (queue time-slicing) and not
+            // bring them all back while the others spin.  Nobody waits for ever: after 100 ms of wall clock whoever notices first
+            // tells everybody through the header, the launch ends with CLIMB_ERROR / err 1, and the host -- whose own state is
+            // untouched until a launch comes back clean -- runs the segment as host-driven batches instead.
             if (__hip_atomic_load(&P.hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh.err = 1u; break; }
-            if (spins > (1u << 20)) { __hip_atomic_store(&P.hdr->abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sh.err = 1u; break; }
+            if (wait0 == 0ull) wait0 = __builtin_amdgcn_s_memrealtime();
+            else if (__builtin_amdgcn_s_memrealtime() - wait0 > 100ull * 100000ull) {
+              uint32_t expect = 0;
+              if (__hip_atomic_compare_exchange_strong(&P.hdr->pad2[0], &expect, 0x80000000u | tile, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                P.hdr->pad2[1] = c | (ncand << 16);
+                P.hdr->pad2[2] = (uint32_t)(v >> 40) | (sh.xgen << 16);
+              }
+              __hip_atomic_store(&P.hdr->abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              sh.err = 1u;
+              break;
+            }
           }
           __builtin_amdgcn_s_sleep(2);
         }

@@ -40,6 +40,7 @@ struct ClimbHeader {
   unsigned long long n_tests, n_ops, draws, n_scanned_nodes;
   uint32_t arrive, abort, since_move, batch;
   uint32_t pad[4];
+  uint32_t start_gate, pad2[3];    // 0 = undecided, 1 = every workgroup has arrived: go, 2 = somebody timed out: nobody starts (ONE compare-and-swap decides)
   unsigned long long tph[16];      // 100 MHz ticks workgroup 0 spent per phase: set-up, enumerate, closure, refresh, scan, exchange, decide
 };
 
@@ -56,15 +57,18 @@ struct ClimbParams {
   uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
   uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch)
   unsigned long long *gsum;        // [3][kClimbCap] exchange ring (zeroed by the host before the launch)
-  // two-level exchange: the workgroups of one XCD first add their shares into that XCD's own words (atomics that stay in its L2),
-  // the last one to arrive forwards the XCD's total -- 8 device-scope adds per candidate instead of one per workgroup
+  // two-level exchange: every eighth workgroup forms a group that first sums into words of its own, the group's last arrival
+  // forwards the total -- same-address atomics are served one after the other: 12-13 + 8 deep instead of 98
   unsigned long long *xsum;        // [8][3][kClimbCap], zeroed like gsum
-  uint32_t *xcnt;                  // [8] workgroups of the launch per XCD (zeroed; counted at the start barrier)
+  uint32_t *xcnt;                  // (unused: group sizes follow from the workgroup count)
   ClimbHeader *hdr;
   uint32_t *moves;                 // [max_moves][3] = remove cid, insert cid, score
   uint32_t *trace;                 // optional: 8 words per visited prune node
   uint32_t trace_cap;              // in records
   uint32_t *beat;                  // optional, pinned host memory: progress marks of workgroup 0 (16 words)
+  // tests only (engine option "climb_fault"): 0 = none; 0xFFFFFFFF = the start barrier decides "abort"; k = in the exchange of
+  // step k the last workgroup withholds its sums, so that the others run into their time-out (recovery paths of climb_host.cpp)
+  uint32_t fault;
 };
 
 constexpr uint32_t kClimbCap = 1024;      // candidates per step

@@ -2008,6 +2008,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "climb_fault") { climb_fault_ = v; return MPF_OK; }          // (tests of the recovery paths: climb.hpp)
   if (key == "refine_chunk") { refine_chunk_ = v < 1 ? 1 : (int)std::min<int64_t>(v, 1 << 30); return MPF_OK; }
   if (key == "climb_trace") { climb_trace_ = v ? 1 : 0; cd_.h_trace.clear(); cd_.trace_records = 0; return MPF_OK; }
   if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack

@@ -133,6 +133,8 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   p.trace = nullptr;
   p.trace_cap = 0;
   p.beat = nullptr;
+  p.fault = (uint32_t)climb_fault_;
+  climb_fault_ = 0;                                  // (one launch)
   if (climb_trace_) {
     HIPCHK(cd_.h_beat.reserve(32));
     std::memset(cd_.h_beat.p, 0, 32 * sizeof(uint32_t));
@@ -201,9 +203,21 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     stats.climb_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MPF_OK;                                // nothing was changed: the caller goes on with host-driven batches
   }
+  if (h.reason == CLIMB_ERROR && h.err == 1u) {
+    // the launch's workgroups lost each other (a chip shared with other processes' persistent kernels: climb.hip, exchange): the
+    // moves it may have made were never taken over -- topology mirror, tie stream and counters are as they were before the
+    // launch --, only the vectors in HBM were rewritten.  Forget those, and let the caller run the segment as host-driven batches.
+    invalidate_all();
+    stats.climb_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *reason = CLIMB_ABORT;
+    return MPF_OK;
+  }
   if (h.reason == CLIMB_ERROR || h.reason == CLIMB_RUNNING || h.n_moves > (uint32_t)total) {
     invalidate_all();                             // (the kernel has rewritten vectors for topologies the mirror never saw)
-    set_error("device climb: internal error " + std::to_string(h.err) + " (reason " + std::to_string(h.reason) + ")");
+    set_error("device climb: internal error " + std::to_string(h.err) + " (reason " + std::to_string(h.reason) + "; waiter " +
+              std::to_string(h.pad2[0] & 0x7FFFFFFFu) + " of " + std::to_string(tiles) + " tiles, candidate " + std::to_string(h.pad2[1] & 0xFFFFu) + " of " +
+              std::to_string(h.pad2[1] >> 16) + ", arrivals seen " + std::to_string(h.pad2[2] & 0xFFFFu) + ", exchange " + std::to_string(h.pad2[2] >> 16) +
+              ", steps " + std::to_string(h.steps) + ")");
     return MPF_E_STATE;
   }
   if (climb_trace_) {

@@ -176,3 +176,37 @@ def test_c2_device_climb_full_size(mods):
     o.seed_ties(po.TIE_RANDOM, 1)
     assert o.optimize_spr(1, 6) == s2
     assert (o.get_tree() == e2.get_tree()).all()
+
+
+@pytest.mark.parametrize("fault", [0xFFFFFFFF, 1, 7])
+def test_a_lost_launch_falls_back_to_the_host_path_with_the_same_trajectory(mods, fault):
+    """the recovery paths of the persistent kernel (engine option climb_fault, tests only): the start barrier decides "abort"
+    (a chip on which the workgroups do not all become resident), or one workgroup withholds its sums in the exchange of step k
+    (workgroups that lost each other: the others time out after 100 ms).  Either way the host has taken nothing over from that
+    launch; the climb goes on as host-driven batches and ends with the moves of an undisturbed run."""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(150, 4000, "DNA", 0.06, seed=150)
+    codes = synth.letters_to_codes(letters, "DNA")
+    back = trees.random_topology(150, np.random.default_rng(3))
+    ref_e, ref_s, ref_mv = climb(engine, codes, engine.DNA, back, 2, engine.TIE_RANDOM, 7, 6)
+    e = engine.FitchEngine(codes)
+    e.set_option("climb_device", 2)
+    e.set_option("climb_fault", fault)
+    e.set_tree(back)
+    e.reset_node_order()
+    e.seed_ties(engine.TIE_RANDOM, 7)
+    s = e.optimize_spr(1, 6)
+    assert s == ref_s
+    assert [list(map(int, m)) for m in zip(*e.moves())] == ref_mv
+    assert (e.get_tree() == ref_e.get_tree()).all()
+    st = e.stats()
+    assert st["climb_launches"] >= 1 and st["climb_moves"] < len(ref_mv)          # the faulted launch contributed nothing
+    # and the engine is whole afterwards: another climb from another tree, in the kernel again
+    back2 = trees.random_topology(150, np.random.default_rng(4))
+    ref2 = climb(engine, codes, engine.DNA, back2, 2, engine.TIE_RANDOM, 9, 6)
+    e.set_tree(back2)
+    e.reset_node_order()
+    e.seed_ties(engine.TIE_RANDOM, 9)
+    e.reset_stats()
+    assert e.optimize_spr(1, 6) == ref2[1] and [list(map(int, m)) for m in zip(*e.moves())] == ref2[2]
+    assert e.stats()["climb_moves"] == len(ref2[2])

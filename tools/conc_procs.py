@@ -33,7 +33,9 @@ def _reap():                                   # never leave workers behind: per
     for p in ps:                               # admission gate can starve each other at their start barriers
         if p.poll() is None:
             p.kill()
-threading.Timer(120.0, _reap).start()
+_timer = threading.Timer(120.0, _reap)
+_timer.daemon = True
+_timer.start()
 for p in ps:
     assert p.stdout.readline().startswith("READY")
 open(go, "w").close()
@@ -43,6 +45,7 @@ for p in ps:
     ts.append((float(l[1]), float(l[2])))
     p.wait()
 os.remove(go)
+_timer.cancel()
 _reap()
 wall = max(t[1] for t in ts) - min(t[0] for t in ts)
 print(f"{K} processes x 3 climbs (tile {tile}): {wall:.3f} s -> {3 * K / wall:.1f} climbs/s; per climb {sum(t[1]-t[0] for t in ts)/(3*K):.3f} s")
