@@ -400,6 +400,36 @@ __global__ __launch_bounds__(256) void k_ufb_events(const uint2 *__restrict__ in
   }
 }
 
+// The batches inside a climb (a few hundred output indices: two to four chunks): the same events in ONE launch -- every chunk's
+// threads first run the minimum over the chunks in front of theirs themselves (at most three chunks of re-reads from L2) instead
+// of waiting for two more dispatches (chunk minima, prefix), each of which costs more than the re-reads.
+__global__ __launch_bounds__(256) void k_ufb_events_fused(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
+                                                          const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
+                                                          const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int B,
+                                                          const int32_t *__restrict__ rt, uint32_t n_idx, const uint32_t *__restrict__ best,
+                                                          UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.y;
+  if (b >= B) return;
+  const uint32_t i0 = chunk * kUfbChunk, i1 = min(n_idx, i0 + kUfbChunk);
+  const int32_t r = rt[b];
+  uint32_t run = best[b];
+  for (uint32_t i = 0; i < i0; i++) {
+    int32_t s;
+    if (ufb_score(i, b, info, cost, thr, home, crow, C, Bp, r, s)) run = min(run, (uint32_t)s);
+  }
+  for (uint32_t i = i0; i < i1; i++) {
+    int32_t s;
+    if (!ufb_score(i, b, info, cost, thr, home, crow, C, Bp, r, s)) continue;
+    if ((uint32_t)s <= run) {
+      const uint32_t at = atomicAdd(ev_count, 1u);
+      if (at < ev_cap) ev[at] = UfbEvent{i, (uint32_t)b, (uint32_t)s};
+      run = (uint32_t)s;
+    }
+  }
+}
+
 // info[idx[i]] = (0, code): the slots reserved for the current tree in front of every prune node's candidates
 // (code 0xFFFFFFFE = takes part with score R_T, 0xFFFFFFFF = does not: the current tree fails the cut-off)
 __global__ __launch_bounds__(256) void k_ufb_self(uint2 *__restrict__ info, const uint32_t *__restrict__ idx, uint32_t n, uint32_t code)
@@ -578,7 +608,11 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
   if (n_idx == 0) return hipSuccess;
   const uint32_t nc = ufb_chunks(n_idx);
   dim3 grid((Bp + 255) / 256, nc), block(256);
-  // a single chunk (the small batches inside a climb): its running minimum starts at best[] itself, no prefix pass
+  if (!fixed_bound && nc > 1 && nc <= 4) {
+    hipLaunchKernelGGL(k_ufb_events_fused, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count);
+    return hipGetLastError();
+  }
+  // a single chunk: its running minimum starts at best[] itself, no prefix pass
   const bool prefix = !fixed_bound && nc > 1;
   if (prefix) {
     hipLaunchKernelGGL(k_ufb_chunkmin, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, rt, n_idx, cmin);
