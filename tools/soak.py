@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised soak of this round's device paths against the host-driven paths of the same engine (both pinned against the oracle
+by the test-suite on fixed cases):
+  * k_climb (every tile width, both tie rules, radii 1..6, batch sizes) == host-driven batches: moves, tree, tie-stream state
+  * mpf_ufboot_refine_sweep == mpf_set_weights + mpf_optimize_spr per sample: stable <=> no move, scores
+     python tools/soak.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpboot_amd import engine, synth, trees
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+n_climb = n_ref = n_samples = 0
+while time.time() < t_end:
+    alpha = "AA" if rng.random() < 0.25 else "DNA"
+    n = int(rng.integers(5, 90))
+    P = int(rng.integers(40, 2500 if n >= 10 else 120))      # (the generator tops up to P DISTINCT variable columns: few taxa, few patterns)
+    letters, _ = synth.synth_alignment(n, P, alpha, float(rng.uniform(0.02, 0.3)), seed=int(rng.integers(1 << 30)))
+    codes = synth.letters_to_codes(letters, alpha)
+    dt = engine.DNA if alpha == "DNA" else engine.AA
+    w = rng.integers(1, 4, size=codes.shape[1]).astype(np.int32) if rng.random() < 0.3 else None
+    back = trees.random_topology(n, np.random.default_rng(int(rng.integers(1 << 30))))
+    tie = engine.TIE_RANDOM if rng.random() < 0.8 else engine.TIE_FIRST
+    radius = int(rng.integers(1, 7))
+    seed = int(rng.integers(1, 1 << 20))
+    if os.environ.get("SOAK_VERBOSE"):
+        print(f"case {n_climb}: {alpha} n={n} P={P} tie={tie} radius={radius} seed={seed} weighted={w is not None} t={time.time() - (t_end - budget):.1f}", flush=True)
+    # ---- climb: host loop vs kernel
+    res = []
+    for mode, opts in ((0, {}), (2, {"climb_tile": int(rng.choice([1, 2, 4, 8])) if alpha == "DNA" else 1,
+                                     "climb_batch_min": int(rng.integers(1, 9)), "climb_batch_max": 8})):
+        e = engine.FitchEngine(codes, w, datatype=dt)
+        e.set_option("climb_device", mode)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_tree(back); e.reset_node_order(); e.seed_ties(tie, seed)
+        if os.environ.get("SOAK_VERBOSE") == "2":
+            print("  climb mode", mode, opts, flush=True)
+        s = e.optimize_spr(1, radius)
+        res.append((s, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.tie_state()))
+        opt_tree = e.get_tree()
+    assert res[0] == res[1], ("climb mismatch", alpha, n, P, tie, radius, seed, opts)
+    n_climb += 1
+    # ---- refine sweep vs per-sample climbs (random tie rule only)
+    if n >= 6:
+        B = int(rng.integers(3, 20))
+        w0 = w if w is not None else np.ones(codes.shape[1], dtype=np.int32)
+        nsite = int(w0.sum())
+        sp = np.repeat(np.arange(len(w0)), w0)
+        samples = np.stack([np.bincount(sp[rng.integers(0, nsite, size=nsite)], minlength=len(w0)) for _ in range(B)]).astype(np.uint16)
+        seeds = rng.integers(1, 1 << 20, size=B)
+        start = opt_tree if rng.random() < 0.7 else back
+        r2 = int(rng.integers(1, 7))
+        e = engine.FitchEngine(codes, w, datatype=dt)
+        if rng.random() < 0.5:
+            e.set_option("refine_chunk", int(rng.integers(1, 40)))
+        e.seed_ties(engine.TIE_RANDOM, 0)
+        e.ufboot_attach(samples, 0.5)
+        e.reset_node_order(); e.set_tree(start)
+        if os.environ.get("SOAK_VERBOSE") == "2":
+            print("  refine B", B, "r2", r2, "chunk", e.get_option("refine_chunk"), "start is opt", start is opt_tree, flush=True)
+        sc, stable, first = e.ufboot_refine_sweep(r2, seeds)
+        if os.environ.get("SOAK_VERBOSE") == "2":
+            print("  refine done", flush=True)
+        e.ufboot_detach()
+        solo = engine.FitchEngine(codes, w, datatype=dt)
+        for b in range(B):
+            if os.environ.get("SOAK_DUMP"):
+                np.savez(os.environ["SOAK_DUMP"], codes=codes, samples=samples, w0=w0, start=start, seeds=seeds, r2=r2, dt=dt, b=b, weighted=w is not None)
+            solo.set_weights(samples[b].astype(np.int32))
+            solo.seed_ties(engine.TIE_RANDOM, int(seeds[b])); solo.reset_node_order(); solo.set_tree(start)
+            s0 = solo.score_tree()
+            solo.optimize_spr(1, r2)
+            moved = len(solo.moves()[0]) > 0
+            assert s0 == sc[b] and bool(stable[b]) == (not moved), ("refine mismatch", alpha, n, P, b, r2, int(seeds[b]), s0, int(sc[b]), bool(stable[b]), moved)
+            n_samples += 1
+        n_ref += 1
+print(f"soak ok: {n_climb} climbs (kernel == host loop), {n_ref} refine sweeps / {n_samples} samples (== per-sample climbs)")
