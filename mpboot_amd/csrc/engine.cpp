@@ -1008,6 +1008,14 @@ int Engine::schedule_views(const std::vector<int> *roots)
     HIPCHK(launch_newview_chains(st_, g_, d_vec_, dops, dlo, ch_levels_, (int)nops, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr, x));
     stats.view_launches++;
   } else if (views_mode_ >= 1) {
+    // narrow levels (the partial trees of the addition phase, small refreshes): fewer waves per workgroup -- a wave of the
+    // one-word-per-lane kernel takes 64 / tile ops per round, so 2 x (ops per level) x tile / 64 waves cover a level in two rounds
+    if (nv_waves_ > 0) x.waves_hint = nv_waves_;
+    else if (nv_waves_ == 0 && maxlev > 0 && g_.vw == 1 && g_.nv_pipe && !sankoff_) {
+      const long per_level = ((long)nops + maxlev - 1) / maxlev;
+      const long need = (2 * per_level * newview_tile(g_) + 63) / 64;
+      x.waves_hint = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+    }
     HIPCHK(launch_newview_levels(st_, g_, d_vec_, dops, dlo, maxlev, d_cntp_.p, (uint32_t)nslots_, d_cnt(), fold_inside ? d_done_.p : nullptr, x));
     stats.view_launches++;
   } else {
@@ -2009,6 +2017,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
   if (key == "climb_fault") { climb_fault_ = v; return MPF_OK; }          // (tests of the recovery paths: climb.hpp)
+  if (key == "views_waves") { nv_waves_ = (int)v; return MPF_OK; }         // waves per refresh workgroup: 0 = by level width, -1 = always sixteen, 2 .. 16
   if (key == "refine_chunk") { refine_chunk_ = v < 1 ? 1 : (int)std::min<int64_t>(v, 1 << 30); return MPF_OK; }
   if (key == "climb_trace") { climb_trace_ = v ? 1 : 0; cd_.h_trace.clear(); cd_.trace_records = 0; return MPF_OK; }
   if (key == "sankoff_short") {                 // 0 = always 32-bit costs (the reference's -short_off); takes effect at the next re-pack
@@ -2070,6 +2079,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "climb_batch_max") *v = climb_batch_max_;
   else if (key == "climb_idle") *v = climb_idle_;
   else if (key == "refine_chunk") *v = refine_chunk_;
+  else if (key == "views_waves") *v = nv_waves_;
   else if (key == "climb_trace") *v = climb_trace_;
   else if (key.rfind("climb_ctr", 0) == 0 && key.size() == 10 && key[9] >= '0' && key[9] <= '3') *v = (int64_t)climb_ctr_[key[9] - '0'];   // refresh ops, closure rounds, invalidation rounds, chains
   else if (key.rfind("climb_phase_us", 0) == 0 && key.size() == 15 && ((key[14] >= '0' && key[14] <= '9') || (key[14] >= 'a' && key[14] <= 'f')))

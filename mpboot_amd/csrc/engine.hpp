@@ -328,6 +328,7 @@ class Engine {
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int nv_waves_ = -1;                            // option "views_waves" (see Engine::set_option)
   int64_t climb_fault_ = 0;                      // tests: fault injected into the next k_climb launch (ClimbParams::fault)
   int climb_cus_ = 0;                            // CUs of the device (admission of persistent launches)
   bool broken_ = false;                          // a device launch did not come back: every further call fails

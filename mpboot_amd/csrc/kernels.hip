@@ -2128,7 +2128,10 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
                                  int n_lev, uint32_t *cntp, uint32_t nslots, uint32_t *cnt, uint32_t *done, const RefreshExtra &x)
 {
   if (n_lev <= 0) return hipSuccess;
-  dim3 grid((unsigned)tiles_of(g)), block(1024);
+  // waves per workgroup: sixteen, or fewer where the levels are narrow (x.waves_hint: a partial tree in the addition phase has a
+  // few ops per level -- sixteen waves per tile then only hold wave slots that other engines' launches could use)
+  const unsigned nthreads = (x.waves_hint >= 1 && x.waves_hint < 16) ? 64u * (unsigned)x.waves_hint : 1024u;
+  dim3 grid((unsigned)tiles_of(g)), block(nthreads);
   if (g.sankoff) {
     const int We = snk_elems(g);
     dim3 sgrid((unsigned)((We + 63) / 64));

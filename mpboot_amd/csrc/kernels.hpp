@@ -76,7 +76,8 @@ struct RefreshExtra { const uint32_t *kid_upd = nullptr; int n_kid_upd = 0; uint
                       // the refresh leaves idle -- no plan kernel on the critical path
                       const uint2 *wp_kids = nullptr; uint32_t wp_n = 0; const WalkDesc *wp_desc = nullptr; const uint32_t *wp_hdr = nullptr /* {parts, candidates} */;
                       void *wp_prog = nullptr; uint32_t *wp_out = nullptr; uint32_t wp_max_parts = 0;
-                      uint32_t *shadow = nullptr; /* k_newview_wgq: the word-major copy of every vector written (Geometry::shoff) */ };
+                      uint32_t *shadow = nullptr; /* k_newview_wgq: the word-major copy of every vector written (Geometry::shoff) */
+                      int waves_hint = 0; /* launch_newview_levels: waves per workgroup (0 = sixteen); narrow levels need fewer */ };
 // Refresh schedule of a COMPLETE tree made on the device from the topology array alone (kids[cid], cids n .. n + n_ops - 1 are
 // the inner records): ops in level order, lev_off[0 .. n_lev] as launch_newview_levels reads them, *n_lev.  One workgroup;
 // trees of up to kSchedMaxSlots vectors.  Order inside a level is not defined (ops of a level are independent).
