@@ -183,6 +183,9 @@ int mpf_set_rand_callback(mpf_engine *e, double (*fn)(void *), void *arg);
 #define MPF_LCG64_ADDEND 3037000493ULL
 int mpf_set_tie_state(mpf_engine *e, uint64_t state);
 int mpf_get_tie_state(const mpf_engine *e, uint64_t *state);
+/* the state of that stream n_draws random_double() calls on, in O(log n_draws) (no engine, no device: pure arithmetic) -- what the
+   batched refinement uses to pass over prune-node visits in which nothing but the visit's own accept draw happens */
+uint64_t mpf_tie_state_after(uint64_t state, uint64_t n_draws);
 
 /* rearrangeParsimony(tr, pr, p, mintrav, maxtrav) candidates (sprparsimony.cpp:2259-2376):
    every insertion test of prune record `rec`, in the reference's DFS order (p side, then q

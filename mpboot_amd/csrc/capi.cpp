@@ -188,6 +188,8 @@ int mpf_set_tie_state(mpf_engine *e, uint64_t state)
   return MPF_OK;
 }
 
+uint64_t mpf_tie_state_after(uint64_t state, uint64_t n_draws) { return mpf::lcg64_skip(state, n_draws); }
+
 int mpf_get_tie_state(const mpf_engine *e, uint64_t *state)
 {
   NEED(e);

@@ -102,6 +102,8 @@ struct ScanPlan {
 
 struct Move { int32_t remove_rec, insert_rec; uint32_t score; };
 
+uint64_t lcg64_skip(uint64_t state, uint64_t k);      // the tie stream k draws on (host/ufboot.cpp)
+
 // online UFBoot-MP: the arrays IQTree keeps per bootstrap sample (iqtree.cpp:213-262) plus the device buffers of
 // the masked scan, the REPS product and the event extraction (ufboot.hip)
 struct UfbState {

@@ -26,7 +26,7 @@ EXPORTS = [
     "mpf_set_weights",
     "mpf_get_geometry", "mpf_get_informative", "mpf_get_tip_vector", "mpf_set_tree", "mpf_get_tree",
     "mpf_reset_node_order", "mpf_score_tree", "mpf_score_trees", "mpf_pattern_scores", "mpf_site_scores", "mpf_compute_parsimony", "mpf_compute_parsimony_at",
-    "mpf_encode_iqtree_states", "mpf_seed_ties", "mpf_set_tie_state", "mpf_get_tie_state",
+    "mpf_encode_iqtree_states", "mpf_seed_ties", "mpf_set_tie_state", "mpf_get_tie_state", "mpf_tie_state_after",
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
@@ -104,6 +104,8 @@ def load_library():
         L.mpf_seed_ties.argtypes = [vp, C.c_int32, C.c_int32]
         L.mpf_set_tie_state.argtypes = [vp, C.c_uint64]
         L.mpf_get_tie_state.argtypes = [vp, vp]
+        L.mpf_tie_state_after.argtypes = [C.c_uint64, C.c_uint64]
+        L.mpf_tie_state_after.restype = C.c_uint64
         L.mpf_spr_scan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_spr_sweep_scan.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
         L.mpf_spr_sweep_costs.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp]

@@ -1050,9 +1050,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
 // better, skipped ahead in closed form over visits without events).  stable[b] = the sweep accepts no move: the climb's result
 // is the current tree with length scores[b], exactly what the solo call returns.  A sample whose sweep does accept a move
 // (an improvement, or a drawn move to an equally long tree) is NOT advanced here: the caller runs its climb alone.
-namespace {
 // state * A^k + c * (A^k - 1) / (A - 1) mod 2^64 by doubling: k draws of the tie stream at once
-inline uint64_t lcg64_skip(uint64_t state, uint64_t k)
+uint64_t lcg64_skip(uint64_t state, uint64_t k)
 {
   uint64_t a = 0x27bb2ee687b0b0fdULL, c = 3037000493ULL, acc_a = 1, acc_c = 0;
   while (k) {
@@ -1063,7 +1062,6 @@ inline uint64_t lcg64_skip(uint64_t state, uint64_t k)
   }
   return acc_a * state + acc_c;
 }
-}  // namespace
 
 int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit)
 {

@@ -127,3 +127,26 @@ def test_bootstrap_weights_resample_sites():
     for d in g.doubles(int(w.sum())):
         exp[site_pattern[int(np.floor(d * w.sum()))]] += 1
     assert b.tolist() == exp.tolist()
+
+
+def test_tie_stream_skip_ahead_equals_drawing_one_by_one():
+    """mpf_tie_state_after (pure host arithmetic in libmpfitch.so: the k-step jump of the lcg64 tie stream the batched refinement
+    uses) against the oracle's restated generator stepped draw by draw, which is pinned against SPRNG's own output"""
+    import ctypes
+    import numpy as np
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    lib = engine.load_library()
+    o = po.Oracle(np.array([[1, 2], [2, 1], [1, 1], [2, 2]], dtype=np.uint8))
+    for seed in (0, 1, 77, 2 ** 31 - 1):
+        o.seed_ties(po.TIE_RANDOM, seed)
+        s0 = o.tie_state()
+        state, drawn = s0, 0
+        for k in (0, 1, 2, 3, 63, 64, 1000, 12345):
+            # the restated stream, k more draws: state = state * A + c, k times (oracle/rng.h)
+            for _ in range(k):
+                state = (state * 0x27bb2ee687b0b0fd + 3037000493) & (2 ** 64 - 1)
+            drawn += k
+            assert lib.mpf_tie_state_after(ctypes.c_uint64(s0), ctypes.c_uint64(drawn)) == state
+        assert lib.mpf_tie_state_after(ctypes.c_uint64(s0), ctypes.c_uint64(2 ** 40)) == \
+            lib.mpf_tie_state_after(ctypes.c_uint64(lib.mpf_tie_state_after(ctypes.c_uint64(s0), ctypes.c_uint64(2 ** 39))), ctypes.c_uint64(2 ** 39))
