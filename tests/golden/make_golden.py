@@ -101,6 +101,20 @@ def make_alignment(kind: str):
         for r_i, r in enumerate(rows):                     # constant / singleton / undetermined-only columns
             r.extend(["0", "1" if r_i == 2 else "0", "?" if r_i % 2 else "1"])
         return ["".join(r) for r in rows], names, "BIN", 0
+    if kind == "morph32_40":
+        # all 32 symbols again, on 40 taxa: radius-6 neighbourhoods that the tree does not clip, deeper refresh chains and longer
+        # climbs for the 32-row kernels (the engine's S = 32 instantiations; "morph32" has 13 taxa)
+        sym = "0123456789ABCDEFGHIJKLMNOPQRSTUV"
+        rng = np.random.default_rng(91)
+        L, names = synth.synth_alignment(40, 360, "AA", 0.10, seed=19)
+        rows = [[sym[c] for c in r] for r in L]
+        for r in rows:
+            for j in range(len(r)):
+                if j % 2 == 0 and rng.random() < 0.3:
+                    r[j] = sym[20 + int(rng.integers(12))]
+                if rng.random() < 0.03:
+                    r[j] = "-?"[int(rng.integers(2))]
+        return ["".join(r) for r in rows], names, "MOR", 0
     if kind in ("morph", "morph32"):
         # multistate characters (PLL_GENERIC_32, partition type "MOR": symbols 0-9 A-V, '-' / '?' undetermined; utils.c:138-157);
         # "morph" uses twelve symbols plus '?', which PLL_MAP_GENERIC_32 reads as symbol 22 ('M'), not as undetermined (utils.c:142:
@@ -230,7 +244,7 @@ def fixture(kind: str, tmp: str):
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32"):
+        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32", "morph32_40"):
             fx = fixture(kind, tmp)
             with open(os.path.join(OUT, kind + ".json"), "w") as f:
                 json.dump(fx, f, separators=(",", ":"))
