@@ -101,6 +101,19 @@ def make_alignment(kind: str):
         for r_i, r in enumerate(rows):                     # constant / singleton / undetermined-only columns
             r.extend(["0", "1" if r_i == 2 else "0", "?" if r_i % 2 else "1"])
         return ["".join(r) for r in rows], names, "BIN", 0
+    if kind == "aa_40":
+        # protein on 40 taxa (the 20-row kernels beyond the 11 taxa of "aa"): B / Z / X and gaps, neighbourhoods the tree does not clip
+        rng = np.random.default_rng(45)
+        L, names = synth.synth_alignment(40, 380, "AA", 0.09, seed=23)
+        rows = [list(r) for r in synth.letters_to_text(L, "AA")]
+        for r in rows:
+            for j in range(len(r)):
+                u = rng.random()
+                if u < 0.03:
+                    r[j] = "X-?"[int(rng.integers(3))]
+                elif u < 0.045:
+                    r[j] = "BZ"[int(rng.integers(2))]
+        return ["".join(r) for r in rows], names, "WAG", 0
     if kind == "morph32_40":
         # all 32 symbols again, on 40 taxa: radius-6 neighbourhoods that the tree does not clip, deeper refresh chains and longer
         # climbs for the 32-row kernels (the engine's S = 32 instantiations; "morph32" has 13 taxa)
@@ -244,7 +257,7 @@ def fixture(kind: str, tmp: str):
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32", "morph32_40"):
+        for kind in ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32", "morph32_40", "aa_40"):
             fx = fixture(kind, tmp)
             with open(os.path.join(OUT, kind + ".json"), "w") as f:
                 json.dump(fx, f, separators=(",", ":"))

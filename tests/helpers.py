@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # "morph": PLL_GENERIC_32 data with fewer than 20 symbols in use (20-row kernels, symbols renumbered); "morph32": all 32 symbols
 # (32-row kernels, the reference's `default:` branches sprparsimony.cpp:824-869, :1164-1203)
-# "morph32_40": all 32 symbols on 40 taxa (neighbourhoods the tree does not clip, a 73-move reference climb)
-FIXTURES = ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32", "morph32_40")
+# "morph32_40" / "aa_40": all 32 symbols / protein on 40 taxa (neighbourhoods the tree does not clip, long reference climbs)
+FIXTURES = ("dna_clean", "dna_ambig", "dna_dups", "aa", "dna_48", "bin", "morph", "morph32", "morph32_40", "aa_40")
 PLL_TYPES = {"DNA": 0, "WAG": 1, "BIN": 2, "MOR": 3}
 
 

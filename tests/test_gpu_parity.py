@@ -23,7 +23,7 @@ def fx(request):
 
 
 # moves of the PLL-original hill climb (fixture "spr", reference's own run) that an exact first-best scorer shares with it
-FIRST_BEST_PREFIX = {"dna_clean": 4, "dna_ambig": 1, "dna_dups": 1, "aa": 2, "dna_48": 3, "bin": 4, "morph": 10, "morph32": 4, "morph32_40": 2}
+FIRST_BEST_PREFIX = {"dna_clean": 4, "dna_ambig": 1, "dna_dups": 1, "aa": 2, "dna_48": 3, "bin": 4, "morph": 10, "morph32": 4, "morph32_40": 2, "aa_40": 2}
 
 
 def eng_of(engine, fx, **kw):
