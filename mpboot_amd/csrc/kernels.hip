@@ -1799,6 +1799,19 @@ __device__ __forceinline__ void load_costs(Costs<S, PK> &t, const uint32_t *__re
   for (int k = 0; k < S; k++) t.v[k] = p[(size_t)k * We];
 }
 
+// The same through a raw buffer: the slot's base and the row stride are uniform, so every row's address is the lane's own byte
+// offset (voff, constant for the whole kernel) plus a SCALAR offset -- no 64-bit vector address arithmetic per row (the scan
+// kernel spent a quarter of its vector instructions on that: profiles/r4/snk_scan_isa.txt).  The store may exceed 2 GiB: the scalar
+// offset is 32-bit unsigned (a weighted C5 store with its transform copy is 1.6 + 1.6 GB, each half behind its own descriptor).
+template <int S, bool PK>
+__device__ __forceinline__ void load_costs_b(Costs<S, PK> &t, __amdgpu_buffer_rsrc_t rsrc, uint32_t slot, uint32_t row_bytes, uint32_t voff)
+{
+  const uint32_t base = slot * (uint32_t)S * row_bytes;
+#pragma unroll
+  for (int k = 0; k < S; k++)
+    t.v[k] = __builtin_bit_cast(typename SnkT<PK>::E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, base + (uint32_t)k * row_bytes, 0));
+}
+
 // m[z] = min_x(v[x] + cost[z][x]), four z at a time: four independent add -> min chains side by side (a dependent
 // packed-math pair costs a wait state), each reading its row of the matrix through the scalar cache.
 template <int S, bool PK>
@@ -1919,7 +1932,7 @@ __global__ __launch_bounds__(256) void k_snk_evaluate(const uint32_t *__restrict
 //   stepwise addition (evaluates the new inner node against p->back, the NEW TIP):
 //       min_y( m(vec[own])[y] + m(vec[sib])[y] + mT(S)[y] )
 // With a symmetric matrix mT = m and both collapse to the form below.  costT == nullptr selects ASYM = false.
-template <int S, int MAXD, bool PK, bool ASYM = false>
+template <int S, int MAXD, bool PK, bool ASYM = false, bool BUF = true>
 __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_scan(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
                                                   int n_scans, const ScanOp *__restrict__ ops,
                                                   const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
@@ -1938,13 +1951,21 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
   bool valid;
   const int e0 = lane_word<1>(tile, lane, We, valid);
   const uint32_t *mvec = vec + moff;
+  // (descriptors over the two halves of the store: the vectors and their min-plus transforms; a half stays below 4 GiB or the
+  //  launcher takes the 64-bit-pointer variant)
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)vec, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)mvec, 0, -1, 0x00020000);
+  const uint32_t row_bytes = (uint32_t)We * 4u, voff = (uint32_t)e0 * 4u;
+  // (BUF = false: a half of the store beyond 4 GiB -- 64-bit pointers per row as before)
+  auto ldv = [&](Costs<S, PK> &t, uint32_t slot) { if constexpr (BUF) load_costs_b<S, PK>(t, rs_v, slot, row_bytes, voff); else load_costs<S, PK>(t, vec, slot, We, e0); };
+  auto ldm = [&](Costs<S, PK> &t, uint32_t slot) { if constexpr (BUF) load_costs_b<S, PK>(t, rs_m, slot, row_bytes, voff); else load_costs<S, PK>(t, mvec, slot, We, e0); };
 
   // MU[d] = m(U[d]): what the children of depth d and the test at depth d both need; U itself is never kept
   Costs<S, PK> ms, MU[MAXD + 1], t1, t2;
   if (ASYM && (h.pad & 1u)) {                       // stepwise addition: the new tip is the root side
-    load_costs<S, PK>(t2, vec, h.s_slot, We, e0);
+    ldv(t2, h.s_slot);
     mplus<S, PK>(ms, t2, costT);
-  } else load_costs<S, PK>(ms, mvec, h.s_slot, We, e0);
+  } else ldm(ms, h.s_slot);
 
   for (uint32_t i = h.op_begin; i < h.op_end; i++) {
     const ScanOp o = ops[i];
@@ -1952,13 +1973,13 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
     const bool test = (o.meta >> 8) & 1u;
     const int kind = (int)((o.meta >> 16) & 0xFFu);
     if (kind == SCAN_ROOT) {
-      load_costs<S, PK>(MU[0], mvec, o.own, We, e0);
+      ldm(MU[0], o.own);
       continue;
     }
     typename T::E best = T::inf();
-    load_costs<S, PK>(t1, mvec, o.sib, We, e0);       // m(vec[sib])
+    ldm(t1, o.sib);       // m(vec[sib])
     if (kind == SCAN_JOIN) {
-      load_costs<S, PK>(t2, mvec, o.own, We, e0);
+      ldm(t2, o.own);
 #pragma unroll
       for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], t2.v[s]), ms.v[s]));
     } else {
@@ -1968,12 +1989,12 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
       _Pragma("unroll") for (int s = 0; s < S; s++) t2.v[s] = T::add(t1.v[s], MU[c - 1].v[s]); /* U[c] */ \
       if (ASYM && test) {   /* the near side is the root side of the test: mT(U) first, in MU[c]'s registers */ \
         mplus<S, PK>(MU[c], t2, costT);                                                \
-        load_costs<S, PK>(t1, mvec, o.own, We, e0);                                    \
+        ldm(t1, o.own);                                    \
         _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
       }                                                                                \
       mplus<S, PK>(MU[c], t2, cost);                                                   \
       if (!ASYM && test) {                                                             \
-        load_costs<S, PK>(t1, mvec, o.own, We, e0);                                    \
+        ldm(t1, o.own);                                    \
         _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
       }                                                                                \
     }                                                                                  \
@@ -2242,8 +2263,10 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
     const int We = snk_elems(g), stiles = (We + 63) / 64;
     const long waves = (long)n_scans * stiles;
     dim3 sgrid((unsigned)((waves + 3) / 4));
-#define SNKSCAN2(S_, D_, PK_) do { if (g.costT) hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); \
-                                   else hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); } while (0)
+    const bool buf_ok = (unsigned long long)g.moff * 4ull < (1ull << 32);      // each half of the store behind one 32-bit-offset descriptor
+#define SNKSCAN3(S_, D_, PK_, A_) do { if (buf_ok) hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, A_, true>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); \
+                                       else hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, A_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); } while (0)
+#define SNKSCAN2(S_, D_, PK_) do { if (g.costT) SNKSCAN3(S_, D_, PK_, true); else SNKSCAN3(S_, D_, PK_, false); } while (0)
 #define SNKSCAN(S_, D_) do { if (g.snk16) SNKSCAN2(S_, D_, true); else SNKSCAN2(S_, D_, false); } while (0)
     if (g.S == 4) {
       if (max_depth <= 6) SNKSCAN(4, 6); else SNKSCAN(4, 12);
@@ -2253,6 +2276,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
     }
 #undef SNKSCAN
 #undef SNKSCAN2
+#undef SNKSCAN3
     return hipGetLastError();
   }
   if (g.map == 0) {
