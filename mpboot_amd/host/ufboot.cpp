@@ -1173,9 +1173,7 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
         const uint32_t j = (uint32_t)(std::upper_bound(ends.begin(), ends.end(), e.idx) - ends.begin());
         all.push_back(Ev{e.b, (uint32_t)(i - 1) + j, e.idx, e.s});
       }
-      u.events += n_ev;
     }
-    u.batches++;
   }
   // ---- every sample's sweep, replayed from its own events
   std::sort(all.begin(), all.end(), [](const Ev &x, const Ev &y) { return x.col != y.col ? x.col < y.col : x.visit != y.visit ? x.visit < y.visit : x.ord < y.ord; });
@@ -1196,7 +1194,6 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
       const uint64_t k = (uint64_t)(v - done_visits);
       rng.state = lcg64_skip(rng.state, k);
       iter_hits += k;
-      u.draws += k;
       // this visit: testInsertParsimony's rule over its events (:2168-2176), bestTreeScoreHits = 1 at its start
       uint64_t hits = 1;
       bool sel = false;
@@ -1206,13 +1203,12 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
         if (mp < best) hits = 1;
         else hits++;
         bool take = mp < best;
-        if (!take) { u.draws++; take = rng.next() <= 1.0 / (double)hits; }
+        if (!take) take = rng.next() <= 1.0 / (double)hits;
         if (take) { best = mp; sel = true; }
       }
       bool accept = best < randomMP;
       if (!accept) {                                      // best == randomMP
         iter_hits++;
-        u.draws++;
         accept = rng.next() <= 1.0 / (double)iter_hits;
       }
       if (accept && sel) { moved = true; move_visit = v; }

@@ -101,10 +101,11 @@ def run_sequence(c, seed, n_steps, cost=None):
         x.seed_ties(tmode, seed)
     weights = [c["w"]]
     tracked = mulhits = toplist = False
+    samples_cur = None
     iteration = 0
     log = []
     for step in range(n_steps):
-        op = int(rng.integers(0, 12))
+        op = int(rng.integers(0, 14))
         if tracked and op in (1, 2):
             op = 3                              # (the oracle's rearrangeParsimony books every test it makes: no bare scans once tracked)
         log.append(op)
@@ -198,6 +199,7 @@ def run_sequence(c, seed, n_steps, cost=None):
             e.ufboot_attach(samples)
             o.ufboot_attach(samples)
             tracked = True
+            samples_cur = samples
             rule = int(rng.integers(0, 6))              # 0-2 default, 3 -mulhits, 4 -mulhits -topboot, 5 -distinct_iter_top_boot
             mulhits = rule in (3, 4)
             toplist = rule in (4, 5)
@@ -229,6 +231,34 @@ def run_sequence(c, seed, n_steps, cost=None):
             e.ufboot_detach()
             o.ufboot_detach()
             tracked = mulhits = toplist = False
+        elif op == 12:                          # the tie stream by state (what the reference-side binding does around every call)
+            if cost is None:
+                assert e.tie_state() == o.tie_state(), log
+            st = int(rng.integers(0, 2 ** 63))
+            for x in (e, o):
+                x.set_tie_state(st)
+        elif op == 13 and tracked and cost is None and tmode == 1:
+            # the batched refinement sweep on the attached samples, in the middle of everything else: == one re-weighted climb per
+            # sample on a second oracle; and it must leave the tracker, the plans and the tie stream of THIS engine alone (the
+            # calls after it are still compared with the oracle, which never saw it)
+            for x in (e, o):
+                x.set_weights(weights[0])
+            cur = e.get_tree().copy()
+            r = int(rng.integers(1, maxtrav + 1))
+            seeds = rng.integers(1, 1 << 20, size=len(samples_cur))
+            st_before = e.tie_state()
+            sc, stable, _first = e.ufboot_refine_sweep(r, seeds)
+            assert e.tie_state() == st_before, log
+            o2 = po.Oracle(c["codes"], weights[0], datatype=dt_o, keep_all=keep_all)
+            for b in range(len(samples_cur)):
+                o2.set_weights(samples_cur[b].astype(np.int32))
+                o2.seed_ties(po.TIE_RANDOM, int(seeds[b]))
+                o2.reset_nodep()
+                assert o2.score_tree(cur) == sc[b], log
+                o2.trace(True)
+                o2.optimize_spr(1, r)
+                assert bool(stable[b]) == (len(o2.get_moves()[0]) == 0), (log, b)
+            assert e.score_tree() == o.score_tree(), log      # (and both node tables in the same order again)
         elif op == 8:                           # the same tree handed over again, explicitly
             t = e.get_tree().copy()
             for x in (e, o):
