@@ -1084,7 +1084,6 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
   // ---- the whole sweep's insertion tests, with masks (chunks of prune nodes bound the mask and product buffers)
   std::vector<ScanPlan> plans;
   const uint32_t *out = nullptr;
-  std::vector<UfbEvent> events;                        // idx made sweep-wide: visit << 32 would not fit -> (visit, order) below
   struct Ev { uint32_t col, visit, ord, s; };
   std::vector<Ev> all;
   std::vector<uint32_t> small;
