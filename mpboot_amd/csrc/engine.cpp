@@ -1248,7 +1248,7 @@ static inline void cpu_relax()
   asm volatile("yield");
 #endif
 }
-static bool wait_host_flag(const uint32_t *flag)
+bool Engine::wait_host_flag(const uint32_t *flag)
 {
   std::chrono::steady_clock::time_point t0;
   for (long spin = 0;; spin++) {
@@ -1540,6 +1540,12 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     }
     if (timing_) HIPCHK(hipEventRecord(ev1_, st_));
     part_min_used_ = false;
+    if (ufb_async_ && scan_masks_ && !check_counts_) {
+      walk_async_ = true;
+      walk_async_nd_ = nd;
+      walk_async_nout_ = nout;
+      return MPF_OK;
+    }
     bool part_min_polled = false;
     if (use_pmin) {
       // only the cheapest candidate of every scan part is wanted: reduce on the device, minima straight to the host
@@ -1575,13 +1581,6 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     if (check_counts_)
       for (size_t i = 0; i < nd; i++)
         if (h_ncand_.p[i] != h_walk_.p[i].pad0) { set_error("device/host candidate count mismatch"); return MPF_E_STATE; }
-    float ms = 0;
-    if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
-    if (plan_event_pending_) {
-      if (hipEventElapsedTime(&ms, ev4_, ev0_) == hipSuccess) stats.plan_kernel_ms_total += ms;
-      plan_event_pending_ = false;
-    }
-    stats.scan_launches++;
   }
   else if (pending_scores_) {
     if (cnt_copy_pending_) {
@@ -1589,6 +1588,22 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
       cnt_copy_pending_ = false;
     }
     HIPCHK(hipStreamSynchronize(st_));
+  }
+  return run_walks_finish(plans, out_host);
+}
+
+int Engine::run_walks_finish(std::vector<ScanPlan> &plans, const uint32_t **out_host)
+{
+  const size_t nd = n_walk_;
+  walk_async_ = false;
+  if (nd > 0) {
+    float ms = 0;
+    if (timing_ && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { stats.last_scan_kernel_ms = ms; stats.scan_kernel_ms_total += ms; }
+    if (plan_event_pending_) {
+      if (hipEventElapsedTime(&ms, ev4_, ev0_) == hipSuccess) stats.plan_kernel_ms_total += ms;
+      plan_event_pending_ = false;
+    }
+    stats.scan_launches++;
   }
   finish_views();
   uint64_t tests = 0;
@@ -1993,6 +2008,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
@@ -2070,6 +2086,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "split_cands") *v = split_cands_;
   else if (key == "chain_max_ops") *v = chain_max_ops_;
   else if (key == "timing") *v = timing_;
+  else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "force_big") *v = force_big_;
   else if (key == "sankoff_short") *v = snk16_opt_;
   else if (key == "check_counts") *v = check_counts_;

@@ -146,6 +146,7 @@ struct UfbState {
   DevBuf<UfbEvent> ev;
   PinBuf<UfbEvent> h_ev;
   PinBuf<uint32_t> h_small;                      // staging: thr | home | best | event count
+  PinBuf<uint32_t> h_flag;                       // [0] event count, [1] flag: written by the extraction kernel's last workgroup
   bool rt_valid = false;
   std::vector<int32_t> attach_wgt;               // pattern weights in force at attach time = IQTree's original_sample
   bool suspended = false;                        // weights in force that leave an attach-time pattern without a site: no bookkeeping
@@ -252,6 +253,11 @@ class Engine {
   // device-walked variant: the kernel enumerates the neighbourhood itself (k_scan_walk)
   int plan_walk(int rec, int mintrav, int maxtrav, ScanPlan &plan, bool split);
   int run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host);
+  // ufb_async_ (the online tracker's climb batches): run_walks returns right behind the scan launch -- no copy-back, no
+  // synchronisation -- with walk_async_ set; the caller enqueues the bookkeeping behind it, waits once for everything and then
+  // calls run_walks_finish (scores of the refresh, base lengths, statistics)
+  int run_walks_finish(std::vector<ScanPlan> &plans, const uint32_t **out_host);
+  static bool wait_host_flag(const uint32_t *flag);
   int scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out);
   int candidate_record(const ScanPlan &plan, size_t c);               // q of the c-th insertion test
   void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const;
@@ -351,6 +357,9 @@ class Engine {
   } ufb_pool_;
   void ufb_pool_swap(UfbState &u);
   bool scan_masks_ = false;                      // the next scan_batch also writes candidate masks (k_scan_walk<MASKS>)
+  bool ufb_async_ = false, walk_async_ = false;  // see run_walks_finish
+  size_t walk_async_nd_ = 0, walk_async_nout_ = 0;
+  int ufb_fast_ = 1;                             // option "ufb_fast": one dispatch chain and one wait per batch of the tracker's climbs
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);
   int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)

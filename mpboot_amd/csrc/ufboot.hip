@@ -430,6 +430,139 @@ __global__ __launch_bounds__(256) void k_ufb_events_fused(const uint2 *__restric
   }
 }
 
+// ---- the batches inside a climb: ONE extraction launch that also hands the results to the host --------------------------------
+// k_ufb_events gives every sample one thread that walks a chunk of 256 indices alone: four to eight workgroups, each thread a
+// chain of 256 dependent-looking iterations and one same-address atomic per event -- 34-82 us for the few hundred candidates of a
+// climb's batch, more than the product in front of it.  Here a workgroup owns 64 samples (one per lane: the rows of C are read
+// as 256-byte runs) and its 16 waves share the indices: a wave scores kUfbSlice consecutive indices into registers, the
+// slices' minima meet in LDS, every wave takes the running minimum of the slices in front of its own from there and emits its
+// events with ONE atomic per wave (the order of events in the buffer is free: the host sorts them).
+// The workgroup that finishes last publishes to the host's pinned buffers without a copy dispatch: the first h_ev_cap events,
+// up to three word ranges (the scan's costs and the refresh's mutation counts, info, R_T), the event count and a flag word.
+constexpr int kUfbSlice = 16;
+struct UfbPublish {
+  const uint32_t *src[3];
+  uint32_t *dst[3];
+  uint32_t words[3];
+  UfbEvent *h_ev;
+  uint32_t h_ev_cap;
+  uint32_t *h_flag;                                // [0] = number of events, [1] = 1 when everything above has arrived
+  uint32_t *done;                                  // zeroed device word, left zeroed
+};
+
+__device__ __forceinline__ void ufb_publish(const UfbPublish &pb, const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count)
+{
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t ticket = __hip_atomic_fetch_add(pb.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x * gridDim.y - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const uint32_t n_ev = __hip_atomic_load(ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t n_copy = min(n_ev, pb.h_ev_cap) * 3u;
+  const uint32_t *evw = reinterpret_cast<const uint32_t *>(ev);
+  uint32_t *hw = reinterpret_cast<uint32_t *>(pb.h_ev);
+  for (uint32_t i = threadIdx.x; i < n_copy; i += blockDim.x) hw[i] = __builtin_nontemporal_load(evw + i);
+  for (int k = 0; k < 3; k++)
+    for (uint32_t i = threadIdx.x; i < pb.words[k]; i += blockDim.x) pb.dst[k][i] = __builtin_nontemporal_load(pb.src[k] + i);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(pb.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pb.h_flag[0] = n_ev;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(pb.h_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <bool FIXED>
+__global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ info, const uint32_t *__restrict__ cost,
+                                                      const uint32_t *__restrict__ thr, const uint32_t *__restrict__ home,
+                                                      const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int B,
+                                                      const int32_t *__restrict__ rt, uint32_t n_idx, const uint32_t *__restrict__ best,
+                                                      UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count,
+                                                      UfbPublish pb)
+{
+  __shared__ uint32_t wmin[16][64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int bb = min(b, Bp - 1);
+  const int32_t r = rt[bb];
+  uint32_t run0 = best[bb];
+  for (uint32_t base = 0; base < n_idx; base += 16u * kUfbSlice) {
+    const uint32_t i0 = base + (uint32_t)w * kUfbSlice;
+    uint32_t sc[kUfbSlice];
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < kUfbSlice; k++) {
+      const uint32_t i = i0 + (uint32_t)k;
+      sc[k] = 0xFFFFFFFFu;
+      int32_t s;
+      if (i < n_idx && ufb_score(i, bb, info, cost, thr, home, crow, C, Bp, r, s)) sc[k] = (uint32_t)s;
+      m = min(m, sc[k]);
+    }
+    wmin[w][lane] = m;
+    __syncthreads();
+    uint32_t run = run0, tot = run0;
+    for (int w2 = 0; w2 < 16; w2++) {
+      const uint32_t v = wmin[w2][lane];
+      if (!FIXED && w2 < w) run = min(run, v);
+      tot = min(tot, v);
+    }
+    // this lane's events of the slice (a fixed bound does not follow the scores)
+    uint32_t hit = 0, cur = run;
+#pragma unroll
+    for (int k = 0; k < kUfbSlice; k++)
+      if (live && sc[k] != 0xFFFFFFFFu && sc[k] <= cur) { hit |= 1u << k; if (!FIXED) cur = sc[k]; }
+    const uint32_t n_mine = (uint32_t)__popc(hit);
+    // exclusive prefix over the wave, one reservation per wave
+    uint32_t incl = n_mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t at0 = 0;
+    if (wave_total) {
+      if (lane == 63) at0 = atomicAdd(ev_count, wave_total);
+      at0 = (uint32_t)__shfl((int)at0, 63, 64);
+    }
+    uint32_t at = at0 + incl - n_mine;
+#pragma unroll
+    for (int k = 0; k < kUfbSlice; k++)
+      if (hit & (1u << k)) {
+        if (at < ev_cap) ev[at] = UfbEvent{i0 + (uint32_t)k, (uint32_t)b, sc[k]};
+        at++;
+      }
+    if (!FIXED) run0 = tot;
+    __syncthreads();
+  }
+  if (pb.h_flag) ufb_publish(pb, ev, ev_count);
+}
+
+// the publishing tail alone, behind the chunked kernels of a large batch
+__global__ __launch_bounds__(1024) void k_ufb_publish(const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count, UfbPublish pb)
+{
+  ufb_publish(pb, ev, ev_count);
+}
+
+// in front of the product of a climb's batch, one launch: C <- 0 (the K-split product adds into it), the event counter <- 0,
+// and the current tree's slots info[idx[i]] = (0, code) as k_ufb_self writes them
+__global__ __launch_bounds__(256) void k_ufb_prep(uint4 *__restrict__ C4, uint32_t n4, uint2 *__restrict__ info, const uint32_t *__restrict__ idx,
+                                                  uint32_t n_self, uint32_t code, uint32_t *__restrict__ ev_count)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) C4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < n_self) info[idx[i]] = make_uint2(0u, code);
+  if (i == 0) *ev_count = 0u;
+}
+
 // info[idx[i]] = (0, code): the slots reserved for the current tree in front of every prune node's candidates
 // (code 0xFFFFFFFE = takes part with score R_T, 0xFFFFFFFF = does not: the current tree fails the cut-off)
 __global__ __launch_bounds__(256) void k_ufb_self(uint2 *__restrict__ info, const uint32_t *__restrict__ idx, uint32_t n, uint32_t code)
@@ -585,6 +718,13 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
   return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
 }
 
+int ufb_row_padding(int rows, int Bp)
+{
+  static const int small_v = std::getenv("MPF_GEMM_SMALL") ? std::atoi(std::getenv("MPF_GEMM_SMALL")) : 2;
+  const int r128 = (std::max(rows, 1) + 127) / 128 * 128;
+  return (Bp % 256 == 0 && small_v == 2 && r128 <= 2048) ? 128 : kUfbRowTile;     // (launch_bitgemm's 128-row variant)
+}
+
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt)
 {
   hipError_t e = hipMemsetAsync(rt, 0, (size_t)Bp * sizeof(int32_t), st);
@@ -620,6 +760,38 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
   }
   hipLaunchKernelGGL(k_ufb_events, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, prefix ? pre : best, ev, ev_cap, ev_count,
                      fixed_bound ? best : (const uint32_t *)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_ufb_prep(hipStream_t st, int32_t *C, size_t c_words, uint2 *info, const uint32_t *self_idx, uint32_t n_self, uint32_t code,
+                           uint32_t *ev_count)
+{
+  const uint32_t n4 = (uint32_t)((c_words + 3) / 4);                     // (C is reserved in whole row tiles: a multiple of four words)
+  const uint32_t n = std::max(std::max(n4, n_self), 1u);
+  hipLaunchKernelGGL(k_ufb_prep, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4 *>(C), n4, info, self_idx, n_self, code, ev_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
+                                     const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best,
+                                     uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
+                                     int fixed_bound, const UfbPublishArgs &a)
+{
+  UfbPublish pb;
+  for (int k = 0; k < 3; k++) { pb.src[k] = a.src[k]; pb.dst[k] = a.dst[k]; pb.words[k] = a.words[k]; }
+  pb.h_ev = a.h_ev;
+  pb.h_ev_cap = a.h_ev_cap;
+  pb.h_flag = a.h_flag;
+  pb.done = a.done;
+  if (n_idx > 0 && n_idx <= kUfbEvents2Max) {
+    dim3 grid((unsigned)((B + 63) / 64)), block(1024);
+    if (fixed_bound) hipLaunchKernelGGL(k_ufb_events2<true>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb);
+    else hipLaunchKernelGGL(k_ufb_events2<false>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb);
+    return hipGetLastError();
+  }
+  hipError_t e = launch_ufb_events(st, info, cost, thr, home, crow, C, Bp, B, rt, best, n_idx, cmin, pre, ev, ev_cap, ev_count, fixed_bound);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ufb_publish, dim3(1), dim3(1024), 0, st, ev, ev_count, pb);
   return hipGetLastError();
 }
 

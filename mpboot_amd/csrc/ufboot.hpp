@@ -29,6 +29,30 @@ hipError_t launch_ufb_events(hipStream_t st, const uint2 *info, const uint32_t *
                              // 1: best[b] is a FIXED bound (an event = score <= best[b]; the top-N rules), not the start of a running minimum
                              int fixed_bound = 0);
 
+// ---- the batches inside a climb: the extraction kernel's last workgroup writes the results into the host's pinned
+// buffers itself and raises a flag the host polls -- no copy dispatches, no stream synchronisation
+constexpr uint32_t kUfbEvents2Max = 4096;    // scan output indices up to which the one-launch extraction (k_ufb_events2) is used
+struct UfbPublishArgs {
+  const uint32_t *src[3] = {nullptr, nullptr, nullptr};   // device word ranges copied to ...
+  uint32_t *dst[3] = {nullptr, nullptr, nullptr};         // ... pinned host memory
+  uint32_t words[3] = {0, 0, 0};
+  UfbEvent *h_ev = nullptr;                  // pinned: the first h_ev_cap events
+  uint32_t h_ev_cap = 0;
+  uint32_t *h_flag = nullptr;                // pinned: [0] = event count, [1] = 1 once everything has arrived (zeroed by the host before)
+  uint32_t *done = nullptr;                  // device: zeroed word (left zeroed)
+};
+// C[0, c_words) <- 0, *ev_count <- 0, info[self_idx[i]] = (0, code) for i < n_self
+hipError_t launch_ufb_prep(hipStream_t st, int32_t *C, size_t c_words, uint2 *info, const uint32_t *self_idx, uint32_t n_self, uint32_t code,
+                           uint32_t *ev_count);
+// launch_ufb_events + the publication of its results (one launch for n_idx <= kUfbEvents2Max, else the chunked kernels + a
+// publishing launch); ev_count must be zero
+hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
+                                     const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best,
+                                     uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
+                                     int fixed_bound, const UfbPublishArgs &a);
+// the row padding launch_bitgemm needs for this many rows (small products run on 128-row tiles)
+int ufb_row_padding(int rows, int Bp);
+
 // Wt (zeroed here) <- the samples' weights at the first expanded site of every pattern of the packing in force
 hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src /* [n_cols][P] */, int n_cols, int P, const int32_t *first_site,
                              const int32_t *cur_weight, uint8_t *Wt, int Bp, int planes, size_t plane_bytes);

@@ -600,10 +600,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     while (i <= total) {
       const int hi = std::min(total, i + batch - 1);
       double t0 = now_ms();
+      // cut-off filter (reference iqtree.cpp:3343): a candidate is saved iff  -mp > logl_cutoff - 1e-4
+      const bool have_cut = u.logl_cutoff != 0.0;
+      // one dispatch chain per batch: without a cut-off nothing the host would read from the scan decides what is
+      // multiplied, so the product and the extraction are enqueued right behind the scan and the host waits ONCE
       scan_masks_ = true;
+      ufb_async_ = ufb_fast_ && !have_cut && !ratchet && !store_trees;
       int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
       scan_masks_ = false;
+      ufb_async_ = false;
       if (rc) return rc;
+      const bool chained = walk_async_;            // the scan is in flight, `out` is not there yet
       double t1 = now_ms();
       u.t_scan += t1 - t0;
       u.batches++;
@@ -611,15 +618,13 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       // ---- the first prune node with a strictly better candidate ends the batch for certain: nothing behind it
       //      needs REPS (a tie may end it earlier; then the tail of the product is simply not used)
       int jstar = np - 1;
-      for (int j = 0; j < np; j++) {
+      for (int j = 0; j < np && !chained; j++) {
         const ScanPlan &pl = plans[(size_t)j];
         uint32_t m = UINT32_MAX;
         for (int pi = 0; pi < pl.n_parts; pi++)
           for (int k = 0; k < pl.part_cnt[pi]; k++) m = std::min(m, out[pl.part_off[pi] + (uint32_t)k]);
         if (m != UINT32_MAX && pl.base + m < randomMP) { jstar = j; break; }
       }
-      // cut-off filter (reference iqtree.cpp:3343): a candidate is saved iff  -mp > logl_cutoff - 1e-4
-      const bool have_cut = u.logl_cutoff != 0.0;
       const double lim = -u.logl_cutoff + 1e-4;
       const uint32_t mp_max = have_cut ? (lim <= 0.0 ? 0u : (uint32_t)std::ceil(lim) - 1u) : UINT32_MAX;
       const bool none_pass = have_cut && lim <= 0.0;
@@ -639,7 +644,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       u.t_prep += t0 - t1;
       // with a cut-off only the saved candidates (and the home rows of their parts) are multiplied: this lists their
       // mask rows (`sel_rows`), crow maps a scan output index to its row of C
-      const uint2 *hinfo = u.h_info.p;
+      const uint2 *hinfo = u.h_info.p;             // (a chained batch fills it -- and may move it -- later)
       // (re-weighted climbs are filtered by the length booked last, not by the candidate's own: every row is multiplied,
       //  until a booked tree fails the cut-off -- from then on nothing of this climb is booked)
       // (-storetrees: a topology met before is booked again when its length improved, whatever the cut-off says -- every row
@@ -677,8 +682,9 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       // the current tree is booked in front of every prune node's candidates (sprparsimony.cpp:2285-2289) with its own
       // length (= randomMP): it takes part unless that length fails the cut-off (ratchet climbs: decided in the replay)
       const bool self_pass = !self_list.empty() && !skip_product && (ratchet || store_trees || randomMP <= mp_max);
+      if (chained && !(n_idx > 0 && !skip_product && !compact)) { set_error("online UFBoot: chained batch without a product"); return MPF_E_STATE; }
       if (n_idx > 0 && !skip_product && (n_rows > 0 || self_pass)) {
-        const int rows_p = round_up((int)std::max<uint32_t>(n_rows, 1u), kUfbRowTile);
+        const int rows_p = round_up((int)std::max<uint32_t>(n_rows, 1u), chained ? ufb_row_padding((int)n_rows, u.Bp) : kUfbRowTile);
         // (a batch whose prune nodes have no insertion test at all -- a five-taxon tree at radius 1 -- still books the current
         //  tree at every visit: the scan launch that normally provides the mask / info buffers was skipped)
         { int rc2 = ufb_reserve_scan(n_idx); if (rc2) return rc2; }
@@ -712,6 +718,70 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
         const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
         const uint32_t *d_crow = compact ? u.thr.p + o_crow : nullptr, *d_sel = compact ? u.thr.p + o_sel : nullptr;
+        if (chained) {
+          // ---- prep (C <- 0, counter <- 0, the current tree's slots) -> product -> extraction, whose last workgroup writes the
+          //      events, the scan's costs (with the refresh's mutation counts), info and R_T into the host's pinned buffers
+          uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32;
+          UCHK(launch_ufb_prep(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(),
+                               (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu, d_evcount));
+          if (timing_) UCHK(hipEventRecord(ev2_, st_));
+          for (int pl = 0; pl < u.planes; pl++)
+            UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), 1));
+          u.gemm_rows += (uint64_t)rows_p;
+          have_C = true;
+          ran_events = true;
+          if (timing_) UCHK(hipEventRecord(ev3_, st_));
+          n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);
+          UCHK(u.h_ev.reserve((size_t)n_eager));
+          UCHK(u.h_flag.reserve(4));
+          UCHK(u.h_info.reserve(walk_async_nout_));
+          UfbPublishArgs pa;
+          if (cnt_copy_pending_) { pa.src[0] = d_cnt(); pa.dst[0] = h_cnt(); pa.words[0] = (uint32_t)(out_off() + walk_async_nout_); }
+          else { pa.src[0] = d_out(); pa.dst[0] = h_out(); pa.words[0] = (uint32_t)walk_async_nout_; }
+          cnt_copy_pending_ = false;
+          pa.src[1] = reinterpret_cast<const uint32_t *>(u.info.p);
+          pa.dst[1] = reinterpret_cast<uint32_t *>(u.h_info.p);
+          pa.words[1] = (uint32_t)(2 * walk_async_nout_);
+          if (host_self && self_pass) {                // R_T for the host's own walk over the current tree's bookings
+            UCHK(u.h_rt.reserve((size_t)u.Bp));
+            pa.src[2] = reinterpret_cast<const uint32_t *>(u.rt.p);
+            pa.dst[2] = reinterpret_cast<uint32_t *>(u.h_rt.p);
+            pa.words[2] = (uint32_t)u.Bl;
+          }
+          pa.h_ev = u.h_ev.p;
+          pa.h_ev_cap = n_eager;
+          pa.h_flag = u.h_flag.p;
+          pa.done = d_fin;
+          __atomic_store_n(u.h_flag.p + 1, 0u, __ATOMIC_RELAXED);
+          UCHK(launch_ufb_events_publish(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
+                                         u.ev.p, (uint32_t)u.ev.cap, d_evcount, (u.topboot || u.distinct) ? 1 : 0, pa));
+          if (!(host_poll_ && !timing_ && wait_host_flag(u.h_flag.p + 1))) {
+            UCHK(hipStreamSynchronize(st_));
+            if (__atomic_load_n(u.h_flag.p + 1, __ATOMIC_ACQUIRE) != 1u) { set_error("online UFBoot: the extraction kernel did not publish its results"); return MPF_E_STATE; }
+          }
+          n_ev = u.h_flag.p[0];
+          { int rc2 = run_walks_finish(plans, &out); if (rc2) return rc2; }
+          hinfo = u.h_info.p;
+          if (timing_) {
+            UCHK(hipStreamSynchronize(st_));
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
+          }
+          if (n_ev > u.ev.cap) {
+            // more events than room: grow and extract again (the product is still there)
+            UCHK(u.ev.reserve((size_t)n_ev));
+            UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
+            UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
+                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, (u.topboot || u.distinct) ? 1 : 0));
+            n_eager = 0;
+          }
+          if (n_ev > n_eager) {
+            if (u.h_ev.cap < (size_t)n_ev) n_eager = 0;       // (a grown pinned buffer starts empty)
+            UCHK(u.h_ev.reserve((size_t)n_ev));
+            UCHK(hipMemcpyAsync(u.h_ev.p + n_eager, u.ev.p + n_eager, (size_t)(n_ev - n_eager) * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
+            UCHK(hipStreamSynchronize(st_));
+          }
+        } else {
         UCHK(launch_ufb_self(st_, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(), (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu));
         if (host_self && self_pass) {                  // R_T for the host's own walk over the current tree's bookings
           UCHK(u.h_rt.reserve((size_t)u.Bp));
@@ -757,6 +827,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           UCHK(u.h_ev.reserve((size_t)n_ev));
           UCHK(hipMemcpyAsync(u.h_ev.p + n_eager, u.ev.p + n_eager, (size_t)(n_ev - n_eager) * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
           UCHK(hipStreamSynchronize(st_));
+        }
         }
         t1 = now_ms();
         u.t_dev += t1 - t0;
