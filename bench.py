@@ -915,12 +915,14 @@ def main():
                 eng.set_tree(back_r)
                 eng.reset_node_order()
                 eng.seed_ties(engine.TIE_RANDOM, 1)
+                eng.set_option("timing", 0)            # (HIP events around the product would cost every batch a synchronisation)
                 eng.reset_stats()
                 barrier()
                 t0r = time.perf_counter()
                 s_bb = eng.optimize_spr(1, args.maxtrav)
                 barrier()
                 t_bb = time.perf_counter() - t0r
+                eng.set_option("timing", 1)
                 st_bb, cn_bb = eng.stats(), eng.ufboot_counters()
                 _l2, _c2, bt2 = eng.ufboot_state()
                 cache2, trees2 = {}, []
@@ -940,7 +942,7 @@ def main():
                 eng.set_weights(np.ones(P, dtype=np.int32))
                 nondeg["bb_flow"] = {"online_phase_s": t_bb, "score": s_bb, "moves": st_bb["moves_applied"], "insertion_tests": st_bb["insertion_tests"],
                                      "tests_per_s": st_bb["insertion_tests"] / t_bb, "events": cn_bb["events"], "tie_draws": cn_bb["tie_draws"],
-                                     "reps_kernel_ms": cn_bb["reps_kernel_ms"], "refined_samples": n_rep, "refinement_s": t_ref2,
+                                     "reps_kernel_ms": cn_bb["reps_kernel_ms"] or None, "refined_samples": n_rep, "refinement_s": t_ref2,
                                      "seconds": t_bb + t_ref2,
                                      "mean_sample_score_online": float(np.mean(online2[:n_rep])) if n_rep else None,
                                      "mean_sample_score_refined": float(np.mean(bs2)) if n_rep else None,

@@ -125,6 +125,17 @@ struct UfbState {
   std::vector<int32_t> refs;                     // per saved tree: number of samples whose boot_trees entry names it
   struct Pending { int64_t tree_index; uint32_t cand; };      // accepted during the current prune node, not yet materialised
   std::vector<Pending> pending;
+  // deferred part of the default update rule (host/ufboot.cpp, ufb_drain_log): which tree a sample points to, the topology map
+  // and the stored topologies never feed back into a draw or into the search -- the replay only logs the acceptances (and the end
+  // of every prune node's scan) and the log is worked off while the device runs the next batch
+  struct LogEntry { uint32_t b, cand; int64_t tree; int32_t plan; };      // b = 0xFFFFFFFF: end of the scan of prune node `plan`
+  std::vector<LogEntry> log;
+  std::vector<int32_t> log_back;                 // the topology the log's candidates refer to
+  int32_t log_epoch = 0;
+  std::vector<int32_t> log_bk;
+  std::string log_key;
+  double t_defer = 0;
+  const std::vector<ScanPlan> *log_plans = nullptr;
   uint64_t draws = 0, events = 0, gemm_rows = 0, batches = 0, stored = 0;
   double gemm_ms = 0.0;
   double t_lookup = 0;                           // ... of t_replay: canonical forms for the topology map
@@ -362,6 +373,7 @@ class Engine {
   int ufb_fast_ = 1;                             // option "ufb_fast": one dispatch chain and one wait per batch of the tracker's climbs
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);
+  void ufb_drain_log();
   int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)
   int ufb_layout_weights();                      // the product's right-hand side for the packing in force
   void ufb_store_tree(int64_t tree_index, int remove_rec, int insert_rec);

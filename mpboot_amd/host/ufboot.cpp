@@ -116,9 +116,9 @@ int Engine::ufb_layout_weights()
 void Engine::ufboot_detach()
 {
   if (ufb_ && std::getenv("MPF_UFB_PROFILE"))
-    std::fprintf(stderr, "[ufboot] batches %llu events %llu stored %llu | ms: scan %.1f prep %.1f device %.1f sort %.1f replay %.1f (topology lookups %llu: %.1f) rt %.1f (product kernels %.1f)\n",
+    std::fprintf(stderr, "[ufboot] batches %llu events %llu stored %llu | ms: scan %.1f prep %.1f device %.1f (of which deferred bookkeeping beside the device %.1f) sort %.1f replay %.1f (topology lookups %llu: %.1f) rt %.1f (product kernels %.1f)\n",
                  (unsigned long long)ufb_->batches, (unsigned long long)ufb_->events, (unsigned long long)ufb_->stored, ufb_->t_scan,
-                 ufb_->t_prep, ufb_->t_dev, ufb_->t_sort, ufb_->t_replay, (unsigned long long)ufb_->lookups, ufb_->t_lookup, ufb_->t_rt, ufb_->gemm_ms);
+                 ufb_->t_prep, ufb_->t_dev, ufb_->t_defer, ufb_->t_sort, ufb_->t_replay, (unsigned long long)ufb_->lookups, ufb_->t_lookup, ufb_->t_rt, ufb_->gemm_ms);
   if (ufb_) ufb_pool_swap(*ufb_);                  // keep the large scratch buffers for the next attach
   ufb_.reset();
 }
@@ -524,6 +524,47 @@ void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
   u.stored++;
 }
 
+// The deferred half of the default update rule (iqtree.cpp:3689-3707, :3720): the tree "string" of a booked tree -- looked up
+// once, at its first acceptance --, boot_trees[b], the reference counts and the topologies to keep.  Runs against the topology
+// the log was written under (the climb may have moved on by one move since).
+void Engine::ufb_drain_log()
+{
+  UfbState &u = *ufb_;
+  if (u.log.empty()) return;
+  back_.swap(u.log_back);
+  std::swap(topo_epoch_, u.log_epoch);
+  int64_t raw = -1, resolved = -1;
+  for (const UfbState::LogEntry &le : u.log) {
+    const ScanPlan &pl = (*u.log_plans)[(size_t)le.plan];
+    if (le.b == 0xFFFFFFFFu) { ufb_flush_pending(pl); continue; }
+    if (le.tree != raw) {
+      raw = le.tree;
+      const double tl = now_ms();
+      const std::string *key = &u.self_key;
+      if (le.cand == 0xFFFFFFFFu) {
+        if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+      } else {
+        ufb_candidate_topology(le.cand < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, (size_t)le.cand), u.log_bk);
+        canonical_topology(u.log_bk, u.log_key);
+        key = &u.log_key;
+      }
+      resolved = u.topo_index.emplace(*key, raw).first->second;
+      u.t_lookup += now_ms() - tl;
+      u.lookups++;
+    }
+    if (u.pending.empty() || u.pending.back().tree_index != resolved) u.pending.push_back(UfbState::Pending{resolved, le.cand});
+    int64_t &bt = u.boot_trees[le.b];
+    if (bt != resolved) {
+      if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
+      u.refs[(size_t)resolved]++;
+      bt = resolved;
+    }
+  }
+  u.log.clear();
+  back_.swap(u.log_back);
+  std::swap(topo_epoch_, u.log_epoch);
+}
+
 // events into replay order: by scan output index, then by sample.  The current tree, booked once per prune-node visit, ties
 // with every sample it is the best tree of -- millions of events per sweep -- so large batches take two stable counting
 // passes (sample, then index) instead of a comparison sort.
@@ -555,7 +596,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   uint32_t startMP;
   unsigned iter_hits = 1;
   const int total = 2 * n_ - 2;
-  std::vector<ScanPlan> plans;
+  std::vector<ScanPlan> plans_buf[2];                // (the deferred log of a batch names its plans while the next batch is planned)
+  int plans_cur = 0;
   const uint32_t *out = nullptr;
   if (u.exchange) {
     // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy
@@ -575,6 +617,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   const bool ratchet = u.ratchet;
   const bool store_trees = u.store_trees;          // -storetrees (iqtree.cpp:3302-3346)
   const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the events are exchanged anyway)
+  // default update rule: the part of an acceptance that no draw and no search decision depends on is logged and worked off
+  // beside the next batch's device work (ufb_drain_log)
+  const bool defer = ufb_fast_ && !ratchet && !store_trees && !u.mulhits && !u.distinct && !u.topboot;
+  bool log_open = false;                           // acceptances logged since the last end-of-prune-node mark
   const int oc = u.Bl;                             // the column of the original pattern frequencies
   auto read_rt_orig = [&]() -> int {
     UCHK(u.h_col.reserve(4));
@@ -600,6 +646,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     while (i <= total) {
       const int hi = std::min(total, i + batch - 1);
       double t0 = now_ms();
+      plans_cur ^= 1;
+      std::vector<ScanPlan> &plans = plans_buf[plans_cur];
       // cut-off filter (reference iqtree.cpp:3343): a candidate is saved iff  -mp > logl_cutoff - 1e-4
       const bool have_cut = u.logl_cutoff != 0.0;
       // one dispatch chain per batch: without a cut-off nothing the host would read from the scan decides what is
@@ -611,6 +659,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       ufb_async_ = false;
       if (rc) return rc;
       const bool chained = walk_async_;            // the scan is in flight, `out` is not there yet
+      if (!chained) ufb_drain_log();               // (a chained batch works the log off while the device runs)
       double t1 = now_ms();
       u.t_scan += t1 - t0;
       u.batches++;
@@ -755,6 +804,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           __atomic_store_n(u.h_flag.p + 1, 0u, __ATOMIC_RELAXED);
           UCHK(launch_ufb_events_publish(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
                                          u.ev.p, (uint32_t)u.ev.cap, d_evcount, (u.topboot || u.distinct) ? 1 : 0, pa));
+          { const double td = now_ms(); ufb_drain_log(); u.t_defer += now_ms() - td; }
           if (!(host_poll_ && !timing_ && wait_host_flag(u.h_flag.p + 1))) {
             UCHK(hipStreamSynchronize(st_));
             if (__atomic_load_n(u.h_flag.p + 1, __ATOMIC_ACQUIRE) != 1u) { set_error("online UFBoot: the extraction kernel did not publish its results"); return MPF_E_STATE; }
@@ -832,28 +882,59 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         t1 = now_ms();
         u.t_dev += t1 - t0;
         if (ratchet && have_C) lcol.assign(u.h_col.p, u.h_col.p + n_rows);
+        // a chained batch was multiplied and extracted as a whole: what lies behind the first prune node with a strictly better
+        // candidate is never replayed (the batch ends there at the latest) -- dropped before the sort
+        uint32_t idx_cut = n_idx;
+        if (chained) {
+          int js = np - 1;
+          for (int j = 0; j < np; j++) {
+            const ScanPlan &pl = plans[(size_t)j];
+            uint32_t m = UINT32_MAX;
+            for (int pi = 0; pi < pl.n_parts; pi++)
+              for (int k = 0; k < pl.part_cnt[pi]; k++) m = std::min(m, out[pl.part_off[pi] + (uint32_t)k]);
+            if (m != UINT32_MAX && pl.base + m < randomMP) { js = j; break; }
+          }
+          if (js < np - 1) {
+            idx_cut = 0;
+            for (int j = 0; j <= js; j++) {
+              const ScanPlan &pl = plans[(size_t)j];
+              if (pl.self_idx >= 0) idx_cut = std::max(idx_cut, (uint32_t)pl.self_idx + 1u);
+              for (int pi = 0; pi < pl.n_parts; pi++) idx_cut = std::max(idx_cut, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
+            }
+          }
+        }
         const bool fused_sort = !u.exchange && n_ev >= 512;
         if (fused_sort) {
           // straight from the pinned copy: local column -> sample of the run, ordered by sample (first counting pass)
-          events.resize(n_ev);
-          ev_tmp.resize(n_ev);
           ev_count.assign((size_t)u.B + 1, 0u);
           const UfbEvent *src = u.h_ev.p;
-          for (uint32_t k = 0; k < n_ev; k++) ev_count[(size_t)u.ids[(size_t)src[k].b] + 1]++;
+          uint32_t kept = 0;
+          for (uint32_t k = 0; k < n_ev; k++)
+            if (src[k].idx < idx_cut) { ev_count[(size_t)u.ids[(size_t)src[k].b] + 1]++; kept++; }
+          events.resize(kept);
+          ev_tmp.resize(kept);
           for (size_t k = 1; k <= (size_t)u.B; k++) ev_count[k] += ev_count[k - 1];
           for (uint32_t k = 0; k < n_ev; k++) {
             UfbEvent e = src[k];
+            if (e.idx >= idx_cut) continue;
             e.b = (uint32_t)u.ids[(size_t)e.b];
             ev_tmp[ev_count[e.b]++] = e;
           }
+          n_ev = kept;
           // ... then by scan output index (second pass, stable)
           ev_count.assign((size_t)n_idx + 1, 0u);
           for (const UfbEvent &e : ev_tmp) ev_count[(size_t)e.idx + 1]++;
           for (size_t k = 1; k <= (size_t)n_idx; k++) ev_count[k] += ev_count[k - 1];
           for (const UfbEvent &e : ev_tmp) events[ev_count[e.idx]++] = e;
         } else {
-          events.assign(u.h_ev.p, u.h_ev.p + n_ev);
-          for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];       // local column -> sample of the run
+          events.clear();
+          for (uint32_t k = 0; k < n_ev; k++) {
+            UfbEvent ev = u.h_ev.p[k];
+            if (ev.idx >= idx_cut) continue;
+            ev.b = (uint32_t)u.ids[(size_t)ev.b];                                  // local column -> sample of the run
+            events.push_back(ev);
+          }
+          n_ev = (uint32_t)events.size();
         }
         if (u.exchange) {
           // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
@@ -881,6 +962,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       int j = i;
       for (; j <= hi && !moved; j++) {
         const ScanPlan &pl = plans[(size_t)(j - i)];
+        const int32_t cur_plan = (int32_t)(j - i);
         if (tie_mode_ == MPF_TIE_RANDOM) {
           insert_rec_ = remove_rec_ = -1;
           hits_ = 1;
@@ -950,7 +1032,11 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               u.draws++;
               accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
             }
-            if (accept) {
+            if (accept && defer) {
+              u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
+              log_open = true;
+              if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
+            } else if (accept) {
               // the tree "string" (:3689-3707): looked up once per booked tree; the topology itself is remembered as
               // (prune node, candidate) and materialised after this prune node's scan only if some sample still points to it
               if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }
@@ -1048,7 +1134,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           insert_rec_ = candidate_record(pl, (size_t)sel);
           remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
         }
-        ufb_flush_pending(pl);
+        if (!defer) ufb_flush_pending(pl);
+        else if (log_open) { u.log.push_back(UfbState::LogEntry{0xFFFFFFFFu, 0u, 0, cur_plan}); log_open = false; }
         bool accept;
         if (tie_mode_ == MPF_TIE_RANDOM) {
           if (best_ == randomMP) iter_hits++;
@@ -1085,16 +1172,19 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
           }
           if (ratchet) { int rc2 = read_rt_orig(); if (rc2) return rc2; }
           moves_.push_back(Move{remove_rec_, insert_rec_, best_});
+          if (!u.log.empty()) { u.log_back = back_; u.log_epoch = topo_epoch_; u.log_plans = &plans; }   // the tree the log speaks of
           apply_move(remove_rec_, insert_rec_);
           randomMP = best_;
           moved = true;
         }
       }
+      if (!moved && !u.log.empty()) { u.log_back = back_; u.log_epoch = topo_epoch_; u.log_plans = &plans; }
       batch = next_batch(batch, moved, j - i, total);
       i = j;
       u.t_replay += now_ms() - t0;
     }
   } while (randomMP < startMP);
+  ufb_drain_log();
   climb_finished(total);
   if (u.exchange) {
     // closing handshake: a rank that took another path would be in the middle of a batch here

@@ -15,6 +15,7 @@ ap.add_argument("--start", default="ras")
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--storetrees", action="store_true", help="-storetrees: every tree looked up by topology before it is booked")
 ap.add_argument("--check", action="store_true", help="replay the first climb on the CPU oracle and compare every observable")
+ap.add_argument("--timing", type=int, default=0, help="engine option timing during the tracked climb (events around kernels cost the batches a synchronisation each)")
 ap.add_argument("--verify", type=int, default=8, help="number of samples whose kept tree is re-scored independently")
 a = ap.parse_args()
 cfg = synth.WORKLOADS[a.workload]
@@ -45,6 +46,7 @@ e.set_tree(back0); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, a.seed)
 ta = time.perf_counter(); e.ufboot_attach(samples); tb = time.perf_counter()
 if a.storetrees:
     e.ufboot_set_store_trees(True)
+e.set_option("timing", a.timing)
 e.reset_stats()
 t2 = time.perf_counter(); s_ufb = e.optimize_spr(1, 6); t3 = time.perf_counter()
 st = e.stats(); cn = e.ufboot_counters()
