@@ -1623,6 +1623,7 @@ int Engine::run_walks_finish(std::vector<ScanPlan> &plans, const uint32_t **out_
 // plan + run the scans of `count` prune records in the configured mode
 int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out)
 {
+  if (ufb_) { ufb_->st_valid = false; ufb_->st_dev = nullptr; }
   int mt = std::min(maxtrav, ntips_ - 3);
   const bool walk = scan_mode_ == 1 && mt <= 8 && !sankoff_;
   plans.resize((size_t)count);
@@ -1641,6 +1642,13 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
     zero_req_words_ = clear_words(walk_out_);
     ride_[0].src = h_walk_.p;
     ride_[0].bytes = n_walk_ * sizeof(WalkDesc);
+    const bool stage = ufb_async_ && scan_masks_ && ufb_;
+    if (stage) {                                   // the tracker's staging block of this batch goes up with the same copy
+      int rc = ufb_stage_small(plans, count);
+      if (rc) return rc;
+      ride_[1].src = ufb_->h_small.p;
+      ride_[1].bytes = (size_t)ufb_->st_words * sizeof(uint32_t);
+    }
     want_host_results_ = true;
     sb_roots_.clear();
     for (int i = 0; i < count; i++) collect_scan_roots(recs[i], mintrav, maxtrav, sb_roots_);
@@ -1648,6 +1656,11 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
     zero_req_ptr_ = nullptr;
     zero_req_words_ = 0;
     ride_[0].src = nullptr;
+    if (stage) {
+      ufb_->st_dev = static_cast<const uint32_t *>(ride_[1].dev);
+      ride_[1].src = nullptr;
+      ride_[1].dev = nullptr;
+    }
     if (!rc) rc = run_walks(plans, out);
     want_host_results_ = false;
     cnt_on_host_ = false;

@@ -157,6 +157,10 @@ struct UfbState {
   DevBuf<UfbEvent> ev;
   PinBuf<UfbEvent> h_ev;
   PinBuf<uint32_t> h_small;                      // staging: thr | home | best | event count
+  // the staged block of a chained batch: words, layout and where it lies on the device (nullptr: not uploaded yet)
+  bool st_valid = false;
+  uint32_t st_n_idx = 0, st_n_parts = 0, st_n_self = 0, st_o_self = 0, st_words = 0;
+  const uint32_t *st_dev = nullptr;
   PinBuf<uint32_t> h_flag;                       // [0] event count, [1] flag: written by the extraction kernel's last workgroup
   bool rt_valid = false;
   std::vector<int32_t> attach_wgt;               // pattern weights in force at attach time = IQTree's original_sample
@@ -374,6 +378,9 @@ class Engine {
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);
   void ufb_drain_log();
+  // chained batches: thr | home | best | self list of the batch's plans into UfbState::h_small (the staging block the extraction
+  // kernel reads), so that it can go up with the refresh's own upload
+  int ufb_stage_small(const std::vector<ScanPlan> &plans, int count);
   int ufb_current_tree_reps();                   // R_T of the current tree (join masks x weights, column sums)
   int ufb_layout_weights();                      // the product's right-hand side for the packing in force
   void ufb_store_tree(int64_t tree_index, int remove_rec, int insert_rec);

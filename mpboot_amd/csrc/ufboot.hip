@@ -450,12 +450,24 @@ struct UfbPublish {
   uint32_t *done;                                  // zeroed device word, left zeroed
 };
 
+// (one workgroup copying 70 KB with a load -> store loop of a dozen dependent iterations took 19 us: the ranges are copied by ALL
+//  workgroups, a slice each, in front of the ticket; k_ufb_events2 writes its events to the host as it emits them)
+__device__ __forceinline__ void ufb_publish_ranges(const UfbPublish &pb, uint32_t part, uint32_t n_parts)
+{
+  for (int k = 0; k < 3; k++) {
+    const uint32_t n = pb.words[k], per = (n + n_parts - 1) / n_parts;
+    const uint32_t lo = min(n, part * per), hi = min(n, lo + per);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) pb.dst[k][i] = __builtin_nontemporal_load(pb.src[k] + i);
+  }
+}
+
+template <bool COPY_EVENTS>
 __device__ __forceinline__ void ufb_publish(const UfbPublish &pb, const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count)
 {
   __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every wave: its own words (device and host) have arrived
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const uint32_t ticket = __hip_atomic_fetch_add(pb.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = ticket == gridDim.x * gridDim.y - 1;
   }
@@ -463,14 +475,14 @@ __device__ __forceinline__ void ufb_publish(const UfbPublish &pb, const UfbEvent
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const uint32_t n_ev = __hip_atomic_load(ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint32_t n_copy = min(n_ev, pb.h_ev_cap) * 3u;
-  const uint32_t *evw = reinterpret_cast<const uint32_t *>(ev);
-  uint32_t *hw = reinterpret_cast<uint32_t *>(pb.h_ev);
-  for (uint32_t i = threadIdx.x; i < n_copy; i += blockDim.x) hw[i] = __builtin_nontemporal_load(evw + i);
-  for (int k = 0; k < 3; k++)
-    for (uint32_t i = threadIdx.x; i < pb.words[k]; i += blockDim.x) pb.dst[k][i] = __builtin_nontemporal_load(pb.src[k] + i);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  __syncthreads();
+  if (COPY_EVENTS) {
+    const uint32_t n_copy = min(n_ev, pb.h_ev_cap) * 3u;
+    const uint32_t *evw = reinterpret_cast<const uint32_t *>(ev);
+    uint32_t *hw = reinterpret_cast<uint32_t *>(pb.h_ev);
+    for (uint32_t i = threadIdx.x; i < n_copy; i += blockDim.x) hw[i] = __builtin_nontemporal_load(evw + i);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     __hip_atomic_store(pb.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pb.h_flag[0] = n_ev;
@@ -488,22 +500,47 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
                                                       UfbPublish pb)
 {
   __shared__ uint32_t wmin[16][64];
+  __shared__ uint32_t wtot[16];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int b = blockIdx.x * 64 + lane;
   const bool live = b < B;
   const int bb = min(b, Bp - 1);
   const int32_t r = rt[bb];
   uint32_t run0 = best[bb];
+  if (pb.h_flag) ufb_publish_ranges(pb, blockIdx.x, gridDim.x);
   for (uint32_t base = 0; base < n_idx; base += 16u * kUfbSlice) {
     const uint32_t i0 = base + (uint32_t)w * kUfbSlice;
+    // the slice's metadata by lanes 0..15 (info -> thr / home -> rows: three dependent round trips per pass, not per index),
+    // then the 2 x 16 reads of C go out together -- taking an index one at a time behind its own tests made a pass 10 us long
+    uint32_t my_rc = 0, my_rh = 0, my_mode = 0;    // mode: 0 = takes no part, 1 = the current tree (score R_T), 2 = candidate
+    {
+      const uint32_t mi = i0 + (uint32_t)(lane & (kUfbSlice - 1));
+      if (mi < n_idx) {
+        const uint2 in = info[mi];
+        if (in.y == 0xFFFFFFFEu) my_mode = 1;
+        else if (in.y != 0xFFFFFFFFu) {
+          const uint32_t hm = home[in.y];
+          if (cost[mi] < thr[in.y]) {
+            my_mode = 2;
+            my_rc = crow ? crow[mi] : in.x;
+            my_rh = crow ? crow[hm] : hm;
+          }
+        }
+      }
+    }
     uint32_t sc[kUfbSlice];
+    int32_t ch[kUfbSlice], cc[kUfbSlice];
+#pragma unroll
+    for (int k = 0; k < kUfbSlice; k++) {
+      const uint32_t rh = (uint32_t)__builtin_amdgcn_readlane((int)my_rh, k), rc = (uint32_t)__builtin_amdgcn_readlane((int)my_rc, k);
+      ch[k] = C[(size_t)rh * Bp + bb];
+      cc[k] = C[(size_t)rc * Bp + bb];
+    }
     uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < kUfbSlice; k++) {
-      const uint32_t i = i0 + (uint32_t)k;
-      sc[k] = 0xFFFFFFFFu;
-      int32_t s;
-      if (i < n_idx && ufb_score(i, bb, info, cost, thr, home, crow, C, Bp, r, s)) sc[k] = (uint32_t)s;
+      const uint32_t mode = (uint32_t)__builtin_amdgcn_readlane((int)my_mode, k);
+      sc[k] = mode == 0 ? 0xFFFFFFFFu : mode == 1 ? (uint32_t)r : (uint32_t)(r - ch[k] + cc[k]);
       m = min(m, sc[k]);
     }
     wmin[w][lane] = m;
@@ -519,37 +556,53 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
 #pragma unroll
     for (int k = 0; k < kUfbSlice; k++)
       if (live && sc[k] != 0xFFFFFFFFu && sc[k] <= cur) { hit |= 1u << k; if (!FIXED) cur = sc[k]; }
-    const uint32_t n_mine = (uint32_t)__popc(hit);
-    // exclusive prefix over the wave, one reservation per wave
-    uint32_t incl = n_mine;
+    // one reservation per WORKGROUP and pass (same-address atomics are served one after the other, ~70 ns each: one per wave
+    // made this kernel 25 us long): the waves' totals meet in LDS, wave 0 reserves, every wave starts behind the waves in front
+    // of it.  Inside a wave the events lie in (index, sample) order -- ballots, no lane scan.
+    uint32_t wave_total = 0;
+    uint32_t pos[kUfbSlice];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-      if (lane >= d) incl += up;
+    for (int k = 0; k < kUfbSlice; k++) {
+      const unsigned long long bal = __ballot((hit >> k) & 1u);
+      pos[k] = wave_total + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      wave_total += (uint32_t)__popcll(bal);
     }
-    const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
-    uint32_t at0 = 0;
-    if (wave_total) {
-      if (lane == 63) at0 = atomicAdd(ev_count, wave_total);
-      at0 = (uint32_t)__shfl((int)at0, 63, 64);
+    if (lane == 0) wtot[w] = wave_total;
+    __syncthreads();
+    if (w == 0) {
+      uint32_t t = lane < 16 ? wtot[lane] : 0u, incl = t;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      const uint32_t all = (uint32_t)__shfl((int)incl, 15, 64);
+      uint32_t base0 = 0;
+      if (lane == 0 && all) base0 = atomicAdd(ev_count, all);
+      base0 = (uint32_t)__shfl((int)base0, 0, 64);
+      if (lane < 16) wtot[lane] = base0 + incl - t;
     }
-    uint32_t at = at0 + incl - n_mine;
+    __syncthreads();
+    const uint32_t at0 = wtot[w];
 #pragma unroll
     for (int k = 0; k < kUfbSlice; k++)
       if (hit & (1u << k)) {
-        if (at < ev_cap) ev[at] = UfbEvent{i0 + (uint32_t)k, (uint32_t)b, sc[k]};
-        at++;
+        const uint32_t at = at0 + pos[k];
+        const UfbEvent e{i0 + (uint32_t)k, (uint32_t)b, sc[k]};
+        if (at < ev_cap) ev[at] = e;
+        if (at < pb.h_ev_cap) pb.h_ev[at] = e;       // (h_ev_cap = 0 without a host to publish to)
       }
     if (!FIXED) run0 = tot;
     __syncthreads();
   }
-  if (pb.h_flag) ufb_publish(pb, ev, ev_count);
+  if (pb.h_flag) ufb_publish<false>(pb, ev, ev_count);
 }
 
 // the publishing tail alone, behind the chunked kernels of a large batch
 __global__ __launch_bounds__(1024) void k_ufb_publish(const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count, UfbPublish pb)
 {
-  ufb_publish(pb, ev, ev_count);
+  ufb_publish_ranges(pb, 0u, 1u);
+  ufb_publish<true>(pb, ev, ev_count);
 }
 
 // in front of the product of a climb's batch, one launch: C <- 0 (the K-split product adds into it), the event counter <- 0,

@@ -524,6 +524,39 @@ void Engine::ufb_store_tree(int64_t tree_index, int p, int q)
   u.stored++;
 }
 
+int Engine::ufb_stage_small(const std::vector<ScanPlan> &plans, int count)
+{
+  UfbState &u = *ufb_;
+  uint32_t n_idx = 0, n_parts = 0, n_self = 0;
+  for (int j = 0; j < count; j++) {
+    const ScanPlan &pl = plans[(size_t)j];
+    if (pl.self_idx >= 0) { n_self++; n_idx = std::max(n_idx, (uint32_t)pl.self_idx + 1u); }
+    for (int pi = 0; pi < pl.n_parts; pi++) {
+      n_idx = std::max(n_idx, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
+      n_parts = std::max(n_parts, (uint32_t)pl.part_desc[pi] + 1u);
+    }
+  }
+  const size_t o_self = (size_t)2 * n_parts + (size_t)u.Bp, words = o_self + n_self;
+  UCHK(u.h_small.reserve(words + 4));
+  uint32_t *sm = u.h_small.p;
+  std::memset(sm, 0, words * sizeof(uint32_t));                 // (padding columns of best: 0 -> never an event)
+  uint32_t at = (uint32_t)o_self;
+  for (int j = 0; j < count; j++) {
+    const ScanPlan &pl = plans[(size_t)j];
+    if (pl.self_idx >= 0) sm[at++] = (uint32_t)pl.self_idx;
+    for (int pi = 0; pi < pl.n_parts; pi++) {
+      const uint32_t d = (uint32_t)pl.part_desc[pi];
+      sm[d] = UINT32_MAX;                                        // no cut-off in force: every candidate takes part
+      sm[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
+    }
+  }
+  for (int c2 = 0; c2 < u.Bl; c2++) sm[(size_t)2 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
+  u.st_n_idx = n_idx; u.st_n_parts = n_parts; u.st_n_self = n_self; u.st_o_self = (uint32_t)o_self; u.st_words = (uint32_t)words;
+  u.st_valid = true;
+  u.st_dev = nullptr;
+  return MPF_OK;
+}
+
 // The deferred half of the default update rule (iqtree.cpp:3689-3707, :3720): the tree "string" of a booked tree -- looked up
 // once, at its first acceptance --, boot_trees[b], the reference counts and the topologies to keep.  Runs against the topology
 // the log was written under (the climb may have moved on by one move since).
@@ -741,6 +774,24 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         const size_t o_crow = (size_t)2 * n_parts + (size_t)u.Bp, o_sel = o_crow + (compact ? (size_t)n_idx : 0);
         const size_t o_self = o_sel + (compact ? (size_t)rows_p : 0);
         const size_t o_cnt = o_self + self_list.size();          // the event counter: a zero word of this upload (no memset dispatch)
+        UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
+        const uint32_t nch = ufb_chunks(n_idx);
+        UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
+        UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
+        if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
+        const uint32_t *d_thr = nullptr, *d_home = nullptr, *d_best = nullptr, *d_crow = nullptr, *d_sel = nullptr, *d_self = nullptr;
+        if (chained) {
+          // the staging block normally went up with the refresh's own upload (Engine::scan_batch); a batch on valid views has none
+          if (!u.st_valid) { int rc2 = ufb_stage_small(plans, np); if (rc2) return rc2; }
+          if (u.st_n_idx != n_idx || u.st_n_parts != n_parts || u.st_n_self != self_list.size()) { set_error("online UFBoot: staged block out of step with the batch"); return MPF_E_STATE; }
+          const uint32_t *dsm = u.st_dev;
+          if (!dsm) {
+            UCHK(u.thr.reserve((size_t)u.st_words + 4));
+            UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, (size_t)u.st_words * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+            dsm = u.thr.p;
+          }
+          d_thr = dsm; d_home = dsm + n_parts; d_best = dsm + 2 * n_parts; d_self = dsm + u.st_o_self;
+        } else {
         small.assign(o_cnt + 1, 0u);
         std::copy(self_list.begin(), self_list.end(), small.begin() + (long)o_self);
         for (int j = 0; j <= jstar; j++) {
@@ -759,19 +810,16 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         UCHK(u.h_small.reserve(small.size() + 4));
         std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
         UCHK(u.thr.reserve(small.size() + 4));
-        UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
-        const uint32_t nch = ufb_chunks(n_idx);
-        UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
-        UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
-        if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
         UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
-        const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
-        const uint32_t *d_crow = compact ? u.thr.p + o_crow : nullptr, *d_sel = compact ? u.thr.p + o_sel : nullptr;
+        d_thr = u.thr.p; d_home = u.thr.p + n_parts; d_best = u.thr.p + 2 * n_parts;
+        d_crow = compact ? u.thr.p + o_crow : nullptr; d_sel = compact ? u.thr.p + o_sel : nullptr;
+        d_self = u.thr.p + o_self;
+        }
         if (chained) {
           // ---- prep (C <- 0, counter <- 0, the current tree's slots) -> product -> extraction, whose last workgroup writes the
           //      events, the scan's costs (with the refresh's mutation counts), info and R_T into the host's pinned buffers
           uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32;
-          UCHK(launch_ufb_prep(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(),
+          UCHK(launch_ufb_prep(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, d_self, (uint32_t)self_list.size(),
                                (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu, d_evcount));
           if (timing_) UCHK(hipEventRecord(ev2_, st_));
           for (int pl = 0; pl < u.planes; pl++)
@@ -832,7 +880,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             UCHK(hipStreamSynchronize(st_));
           }
         } else {
-        UCHK(launch_ufb_self(st_, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(), (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu));
+        UCHK(launch_ufb_self(st_, u.info.p, d_self, (uint32_t)self_list.size(), (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu));
         if (host_self && self_pass) {                  // R_T for the host's own walk over the current tree's bookings
           UCHK(u.h_rt.reserve((size_t)u.Bp));
           UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));   // synchronised with the event count below
