@@ -2022,6 +2022,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
   if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
@@ -2100,6 +2101,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "chain_max_ops") *v = chain_max_ops_;
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
+  else if (key == "ufb_pipe") *v = ufb_pipe_;
   else if (key == "force_big") *v = force_big_;
   else if (key == "sankoff_short") *v = snk16_opt_;
   else if (key == "check_counts") *v = check_counts_;

@@ -161,6 +161,9 @@ struct UfbState {
   bool st_valid = false;
   uint32_t st_n_idx = 0, st_n_parts = 0, st_n_self = 0, st_o_self = 0, st_words = 0;
   const uint32_t *st_dev = nullptr;
+  PinBuf<uint32_t> p_flag_s[2], p_flag_e[2];     // pipelined climb: flags of the scan results / of the events, by batch parity
+  PinBuf<int32_t> p_rt[2];
+  PinBuf<UfbEvent> p_ev[2];
   PinBuf<uint32_t> h_flag;                       // [0] event count, [1] flag: written by the extraction kernel's last workgroup
   bool rt_valid = false;
   std::vector<int32_t> attach_wgt;               // pattern weights in force at attach time = IQTree's original_sample
@@ -351,6 +354,7 @@ class Engine {
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  int spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int nv_waves_ = -1;                            // option "views_waves" (see Engine::set_option)
   int64_t climb_fault_ = 0;                      // tests: fault injected into the next k_climb launch (ClimbParams::fault)
   int climb_cus_ = 0;                            // CUs of the device (admission of persistent launches)
@@ -374,6 +378,7 @@ class Engine {
   bool scan_masks_ = false;                      // the next scan_batch also writes candidate masks (k_scan_walk<MASKS>)
   bool ufb_async_ = false, walk_async_ = false;  // see run_walks_finish
   size_t walk_async_nd_ = 0, walk_async_nout_ = 0;
+  int ufb_pipe_ = 1;                             // option "ufb_pipe": the search's decision from the costs alone where they settle it, the next batch launched beside the bookkeeping of this one
   int ufb_fast_ = 1;                             // option "ufb_fast": one dispatch chain and one wait per batch of the tracker's climbs
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);

@@ -462,14 +462,15 @@ __device__ __forceinline__ void ufb_publish_ranges(const UfbPublish &pb, uint32_
 }
 
 template <bool COPY_EVENTS>
-__device__ __forceinline__ void ufb_publish(const UfbPublish &pb, const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count)
+__device__ __forceinline__ void ufb_publish(const UfbPublish &pb, const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count,
+                                            uint32_t n_tickets)
 {
   __shared__ int s_last;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every wave: its own words (device and host) have arrived
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t ticket = __hip_atomic_fetch_add(pb.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = ticket == gridDim.x * gridDim.y - 1;
+    s_last = ticket == n_tickets - 1;
   }
   __syncthreads();
   if (!s_last) return;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
                                                       const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int B,
                                                       const int32_t *__restrict__ rt, uint32_t n_idx, const uint32_t *__restrict__ best,
                                                       UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count,
-                                                      UfbPublish pb)
+                                                      UfbPublish pb, int clamp_rt)
 {
   __shared__ uint32_t wmin[16][64];
   __shared__ uint32_t wtot[16];
@@ -507,6 +508,10 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
   const int bb = min(b, Bp - 1);
   const int32_t r = rt[bb];
   uint32_t run0 = best[bb];
+  // clamp_rt (a batch launched before the replay of the one in front): best[] is one batch old -- but the current tree
+  // was offered to every sample when it was accepted, so no sample's best is worse than R_T, and a bound that is too high only
+  // costs events the host ignores
+  if (clamp_rt) run0 = min(run0, (uint32_t)r);
   if (pb.h_flag) ufb_publish_ranges(pb, blockIdx.x, gridDim.x);
   for (uint32_t base = 0; base < n_idx; base += 16u * kUfbSlice) {
     const uint32_t i0 = base + (uint32_t)w * kUfbSlice;
@@ -595,14 +600,30 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
     if (!FIXED) run0 = tot;
     __syncthreads();
   }
-  if (pb.h_flag) ufb_publish<false>(pb, ev, ev_count);
+  if (pb.h_flag) ufb_publish<false>(pb, ev, ev_count, gridDim.x);
 }
 
 // the publishing tail alone, behind the chunked kernels of a large batch
 __global__ __launch_bounds__(1024) void k_ufb_publish(const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count, UfbPublish pb)
 {
   ufb_publish_ranges(pb, 0u, 1u);
-  ufb_publish<true>(pb, ev, ev_count);
+  ufb_publish<true>(pb, ev, ev_count, 1u);
+}
+
+// k_ufb_prep + the publication of the SCAN's results (costs with the refresh's mutation counts, info) behind a flag of their own:
+// the host can take the search's decision from the costs while the product and the extraction are still running
+__global__ __launch_bounds__(256) void k_ufb_mid(uint4 *__restrict__ C4, uint32_t n4, uint2 *__restrict__ info, const uint32_t *__restrict__ idx,
+                                                 uint32_t n_self, uint32_t code, uint32_t *__restrict__ ev_count, UfbPublish pb)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) C4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < n_self) info[idx[i]] = make_uint2(0u, code);
+  if (i == 0) *ev_count = 0u;
+  const uint32_t pub = min(gridDim.x, 16u);        // publishing workgroups (a ticket per workgroup of a 400-workgroup launch would take longer than the copy)
+  if (blockIdx.x < pub) {
+    ufb_publish_ranges(pb, blockIdx.x, pub);
+    ufb_publish<false>(pb, nullptr, ev_count, pub);
+  }
 }
 
 // in front of the product of a climb's batch, one launch: C <- 0 (the K-split product adds into it), the event counter <- 0,
@@ -825,10 +846,7 @@ hipError_t launch_ufb_prep(hipStream_t st, int32_t *C, size_t c_words, uint2 *in
   return hipGetLastError();
 }
 
-hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
-                                     const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best,
-                                     uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
-                                     int fixed_bound, const UfbPublishArgs &a)
+static UfbPublish publish_of(const UfbPublishArgs &a)
 {
   UfbPublish pb;
   for (int k = 0; k < 3; k++) { pb.src[k] = a.src[k]; pb.dst[k] = a.dst[k]; pb.words[k] = a.words[k]; }
@@ -836,10 +854,28 @@ hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const ui
   pb.h_ev_cap = a.h_ev_cap;
   pb.h_flag = a.h_flag;
   pb.done = a.done;
+  return pb;
+}
+
+hipError_t launch_ufb_mid(hipStream_t st, int32_t *C, size_t c_words, uint2 *info, const uint32_t *self_idx, uint32_t n_self, uint32_t code,
+                          uint32_t *ev_count, const UfbPublishArgs &a)
+{
+  const uint32_t n4 = (uint32_t)((c_words + 3) / 4);
+  const uint32_t n = std::max(std::max(n4, n_self), 1u);
+  hipLaunchKernelGGL(k_ufb_mid, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4 *>(C), n4, info, self_idx, n_self, code, ev_count, publish_of(a));
+  return hipGetLastError();
+}
+
+hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
+                                     const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best,
+                                     uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
+                                     int fixed_bound, const UfbPublishArgs &a, int clamp_rt)
+{
+  const UfbPublish pb = publish_of(a);
   if (n_idx > 0 && n_idx <= kUfbEvents2Max) {
     dim3 grid((unsigned)((B + 63) / 64)), block(1024);
-    if (fixed_bound) hipLaunchKernelGGL(k_ufb_events2<true>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb);
-    else hipLaunchKernelGGL(k_ufb_events2<false>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb);
+    if (fixed_bound) hipLaunchKernelGGL(k_ufb_events2<true>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb, 0);
+    else hipLaunchKernelGGL(k_ufb_events2<false>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb, clamp_rt);
     return hipGetLastError();
   }
   hipError_t e = launch_ufb_events(st, info, cost, thr, home, crow, C, Bp, B, rt, best, n_idx, cmin, pre, ev, ev_cap, ev_count, fixed_bound);

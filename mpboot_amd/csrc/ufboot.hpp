@@ -49,7 +49,12 @@ hipError_t launch_ufb_prep(hipStream_t st, int32_t *C, size_t c_words, uint2 *in
 hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
                                      const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best,
                                      uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
-                                     int fixed_bound, const UfbPublishArgs &a);
+                                     int fixed_bound, const UfbPublishArgs &a,
+                                     // 1: start every sample's running minimum at min(best[b], rt[b]) (see k_ufb_events2); only with n_idx <= kUfbEvents2Max
+                                     int clamp_rt = 0);
+// launch_ufb_prep + publication of a.src/dst ranges behind a.h_flag[1] (the scan's results, in front of the product)
+hipError_t launch_ufb_mid(hipStream_t st, int32_t *C, size_t c_words, uint2 *info, const uint32_t *self_idx, uint32_t n_self, uint32_t code,
+                          uint32_t *ev_count, const UfbPublishArgs &a);
 // the row padding launch_bitgemm needs for this many rows (small products run on 128-row tiles)
 int ufb_row_padding(int rows, int Bp);
 
