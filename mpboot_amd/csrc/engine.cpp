@@ -2102,6 +2102,8 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "ufb_pipe") *v = ufb_pipe_;
+  else if (key == "ufb_batches") *v = ufb_stat_batches_;
+  else if (key == "ufb_early_batches") *v = ufb_stat_early_;
   else if (key == "force_big") *v = force_big_;
   else if (key == "sankoff_short") *v = snk16_opt_;
   else if (key == "check_counts") *v = check_counts_;

@@ -378,6 +378,7 @@ class Engine {
   bool scan_masks_ = false;                      // the next scan_batch also writes candidate masks (k_scan_walk<MASKS>)
   bool ufb_async_ = false, walk_async_ = false;  // see run_walks_finish
   size_t walk_async_nd_ = 0, walk_async_nout_ = 0;
+  int64_t ufb_stat_batches_ = 0, ufb_stat_early_ = 0;   // read-only options ufb_batches / ufb_early_batches: batches of the tracker's climbs since the engine was made, and how many of them were decided from the costs
   int ufb_pipe_ = 1;                             // option "ufb_pipe": the search's decision from the costs alone where they settle it, the next batch launched beside the bookkeeping of this one
   int ufb_fast_ = 1;                             // option "ufb_fast": one dispatch chain and one wait per batch of the tracker's climbs
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan

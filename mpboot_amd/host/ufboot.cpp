@@ -626,7 +626,7 @@ static void sort_events(std::vector<UfbEvent> &ev, std::vector<UfbEvent> &tmp, s
 int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
 {
   UfbState &u = *ufb_;
-  if (ufb_fast_ && ufb_pipe_ && !u.exchange && !u.ratchet && !u.store_trees && !u.mulhits && !u.distinct && !u.topboot && u.logl_cutoff == 0.0 &&
+  if (ufb_fast_ && ufb_pipe_ && !u.ratchet && !u.store_trees && !u.mulhits && !u.distinct && !u.topboot && u.logl_cutoff == 0.0 &&
       host_poll_ && !timing_ && !check_counts_)
     return spr_sweeps_ufboot_pipe(mintrav, maxtrav, randomMP, final_score);
   uint32_t startMP;
@@ -682,6 +682,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     while (i <= total) {
       const int hi = std::min(total, i + batch - 1);
       double t0 = now_ms();
+      ufb_stat_batches_++;
       plans_cur ^= 1;
       std::vector<ScanPlan> &plans = plans_buf[plans_cur];
       // cut-off filter (reference iqtree.cpp:3343): a candidate is saved iff  -mp > logl_cutoff - 1e-4
@@ -1248,7 +1249,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
 }
 
 // ---- the tracker's climb as a two-stage pipeline ----------------------------------------------------------------
-// Default update rule, no cut-off in force (the first climb of a run -- where the time goes), one engine holding all samples.
+// Default update rule, no cut-off in force (the first climb of a run -- where the time goes).
 // The bookkeeping needs the product and the event extraction of a batch; the SEARCH mostly does not: whenever the costs alone
 // settle what the sweep does next -- every prune node of the batch strictly worse than the current tree, or the first one that
 // is better has ONE cheapest candidate (draws among dearer ties are overridden by it, sprparsimony.cpp:2168-2176, and a strictly
@@ -1276,6 +1277,13 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   int cur = 0;
   bool prelaunched = false;
   bool moved_once = false;
+  if (u.exchange) {
+    // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy state
+    gap_est_ = -1.0;
+    since_move_ = 0;
+  }
+  const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the events are exchanged anyway)
+  uint32_t exchange_tag = 0;
   int batch = first_batch();
   std::vector<UfbEvent> events, ev_tmp;
   std::vector<uint32_t> ev_count;
@@ -1346,7 +1354,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     ps.h_flag = u.p_flag_s[B.par].p;
     ps.done = d_fin;
     __atomic_store_n(u.p_flag_s[B.par].p + 1, 0u, __ATOMIC_RELAXED);
-    UCHK(launch_ufb_mid(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, d_self, B.n_self, 0xFFFFFFFFu, d_evcount, ps));
+    UCHK(launch_ufb_mid(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, d_self, B.n_self, host_self ? 0xFFFFFFFFu : 0xFFFFFFFEu, d_evcount, ps));
     for (int pl = 0; pl < u.planes; pl++)
       UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), 1));
     u.gemm_rows += (uint64_t)rows_p;
@@ -1432,7 +1440,9 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       int next_i = i, next_batch_size = batch;
       const bool overflow_safe = (uint64_t)B.n_idx * (uint64_t)u.Bl <= (uint64_t)u.ev.cap;     // (no second extraction after C has been reused)
       bool early = ufb_pipe_ && d.certain && overflow_safe;
+      ufb_stat_batches_++;
       if (early) {
+        ufb_stat_early_++;
         if (d.moved) {
           const ScanPlan &pl = B.plans[(size_t)d.j];
           d.ins = candidate_record(pl, (size_t)d.sel);
@@ -1508,7 +1518,34 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       }
       {
         const UfbEvent *src = u.p_ev[B.par].p;
-        if (n_ev >= 512) {
+        if (u.exchange) {
+          // every rank replays the events of all ranks (one all-gather per batch; the cut is the same everywhere: same costs)
+          events.clear();
+          for (uint32_t k = 0; k < n_ev; k++) {
+            UfbEvent e = src[k];
+            if (e.idx >= idx_cut) continue;
+            e.b = (uint32_t)u.ids[(size_t)e.b];
+            events.push_back(e);
+          }
+          if (!B.device)                             // nothing was scanned: the current tree's own bookings, from R_T on the host
+            for (int jj = 0; jj < B.np; jj++)
+              if (B.plans[(size_t)jj].self_idx >= 0)
+                for (int c2 = 0; c2 < u.Bl; c2++)
+                  if ((uint32_t)u.p_rt[B.par].p[c2] <= u.boot_score[(size_t)u.ids[(size_t)c2]])
+                    events.push_back(UfbEvent{(uint32_t)B.plans[(size_t)jj].self_idx, (uint32_t)u.ids[(size_t)c2], (uint32_t)u.p_rt[B.par].p[c2]});
+          n_ev = (uint32_t)events.size();
+          const mpf_ufb_event *all = nullptr;
+          uint32_t n_all_ev = 0;
+          if (u.exchange(u.exchange_arg, exchange_tag++, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
+            set_error("online UFBoot: event exchange failed (ranks out of step?)");
+            return MPF_E_STATE;
+          }
+          const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
+          events.assign(pa, pa + n_all_ev);
+          uint32_t n_keys = B.n_idx;
+          for (int jj = 0; jj < B.np; jj++) n_keys = std::max(n_keys, (uint32_t)(B.plans[(size_t)jj].self_idx + 1));
+          sort_events(events, ev_tmp, ev_count, n_keys, (uint32_t)u.B);
+        } else if (n_ev >= 512) {
           ev_count.assign((size_t)u.B + 1, 0u);
           uint32_t kept = 0;
           for (uint32_t k = 0; k < n_ev; k++)
@@ -1580,7 +1617,13 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         if (pl.self_idx >= 0) {
           // the current tree, once per prune node and before its insertion tests (sprparsimony.cpp:2285-2289)
           const int64_t tree_index = book(randomMP);
-          for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)h_rt[c2], tree_index, 0xFFFFFFFFu);
+          if (host_self) {
+            for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)h_rt[c2], tree_index, 0xFFFFFFFFu);
+          } else {
+            const uint32_t idx = (uint32_t)pl.self_idx;
+            while (ep < events.size() && events[ep].idx < idx) ep++;
+            for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, 0xFFFFFFFFu);
+          }
         }
         for (int pi = 0; pi < pl.n_parts; pi++) {
           const uint32_t home = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
@@ -1650,6 +1693,12 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   } while (randomMP < startMP);
   ufb_drain_log();
   climb_finished(total);
+  if (u.exchange) {
+    // closing handshake: a rank that took another path would be in the middle of a batch here
+    const mpf_ufb_event *all = nullptr;
+    uint32_t n_all_ev = 0;
+    if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
+  }
   if (final_score) *final_score = randomMP;
   return MPF_OK;
 }

@@ -94,6 +94,53 @@ def test_batching_and_kernel_options_do_not_change_the_result(mods, opts):
     assert_same(e, o, se, so)
 
 
+def _observables(e, rule):
+    logl, cnt, tr = e.ufboot_state()
+    obs = {"moves": [x.tolist() for x in e.moves()], "tree": e.get_tree().tolist(), "saved": e.ufboot_tree_logl().tolist(),
+           "logl": logl.tolist(), "cnt": cnt.tolist(), "tr": tr.tolist(), "draws": e.ufboot_counters()["tie_draws"],
+           "trees": {int(t): e.ufboot_tree(int(t)).tolist() for t in sorted(set(tr.tolist())) if t >= 0}}
+    if rule in ("topboot", "distinct"):
+        obs["tops"] = [list(map(list, e.ufboot_sample_top(b)[0])) + [e.ufboot_sample_top(b)[1]] for b in range(len(logl))]
+    return obs
+
+
+@pytest.mark.parametrize("tie", ["random", "first"])
+@pytest.mark.parametrize("rule", ["default", "mulhits", "topboot", "distinct"])
+@pytest.mark.parametrize("name", ["dna_48", "aa_40"])
+def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
+    """ufb_fast = 0: scan, wait, product + extraction (chunked kernels), wait, replay.  ufb_pipe = 0: one dispatch chain and one
+    wait per batch (k_ufb_events2, deferred log).  Default: the pipeline that takes the search's decision from the costs where
+    they settle it.  Every observable must be the same -- and the default must really have decided batches early.  (The
+    fixed-bound extraction of the top-N rules runs through both kernels here with batches of several hundred candidates.)"""
+    engine, po = mods
+    fx = load_fixture(name)
+    w = np.asarray(fx["weights"], dtype=np.float64)
+    samples = np.random.default_rng(77).multinomial(int(w.sum()), w / w.sum(), size=150).astype(np.uint16)
+    start = np.array(fx["trees"][1]["back"], dtype=np.int32)
+    got = []
+    for opts in ({"ufb_fast": 0}, {"ufb_pipe": 0}, {}):
+        e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_tree(start)
+        e.seed_ties(engine.TIE_RANDOM if tie == "random" else engine.TIE_FIRST, 5)
+        e.ufboot_attach(samples)
+        if rule in ("mulhits", "topboot"):
+            e.ufboot_set_mulhits(True)
+        if rule == "topboot":
+            e.ufboot_set_topboot(3)
+        if rule == "distinct":
+            e.ufboot_set_distinct_iter(2)
+            e.ufboot_set_iteration(1)
+        s = e.optimize_spr(1, 6)
+        got.append((s, _observables(e, rule), e.get_option("ufb_early_batches"), e.get_option("ufb_batches")))
+    assert got[0][:2] == got[1][:2]
+    assert got[0][:2] == got[2][:2]
+    assert got[0][2] == 0 and got[1][2] == 0
+    if rule == "default":
+        assert got[2][2] > 0 and got[2][2] <= got[2][3]
+
+
 def test_cutoff_filter_and_next_cutoff(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
