@@ -3,6 +3,8 @@
 by the test-suite on fixed cases):
   * k_climb (every tile width, both tie rules, radii 1..6, batch sizes) == host-driven batches: moves, tree, tie-stream state
   * mpf_ufboot_refine_sweep == mpf_set_weights + mpf_optimize_spr per sample: stable <=> no move, scores
+  * the tracked climb (-bb bookkeeping) as a pipeline (ufb_pipe, decisions taken from the costs) == one chain per batch (ufb_pipe 0)
+    == scan / wait / product / wait / replay (ufb_fast 0): moves, tree, saved trees, boot arrays, kept topologies, draws, tie state
      python tools/soak.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
@@ -13,7 +15,7 @@ from mpboot_amd import engine, synth, trees
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-n_climb = n_ref = n_samples = 0
+n_climb = n_ref = n_samples = n_trk = n_early = 0
 while time.time() < t_end:
     alpha = "AA" if rng.random() < 0.25 else "DNA"
     n = int(rng.integers(5, 90))
@@ -78,4 +80,30 @@ while time.time() < t_end:
             assert s0 == sc[b] and bool(stable[b]) == (not moved), ("refine mismatch", alpha, n, P, b, r2, int(seeds[b]), s0, int(sc[b]), bool(stable[b]), moved)
             n_samples += 1
         n_ref += 1
-print(f"soak ok: {n_climb} climbs (kernel == host loop), {n_ref} refine sweeps / {n_samples} samples (== per-sample climbs)")
+    # ---- tracked climb: the three ways through it
+    if n >= 6:
+        B = int(rng.integers(2, 70))
+        w0 = w if w is not None else np.ones(codes.shape[1], dtype=np.int32)
+        nsite = int(w0.sum())
+        sp = np.repeat(np.arange(len(w0)), w0)
+        samples = np.stack([np.bincount(sp[rng.integers(0, nsite, size=nsite)], minlength=len(w0)) for _ in range(B)]).astype(np.uint16)
+        sb = int(rng.choice([1, 2, 4, 16, 64]))
+        got = []
+        for opts in ({"ufb_fast": 0}, {"ufb_pipe": 0}, {}):
+            e = engine.FitchEngine(codes, w, datatype=dt)
+            e.set_option("scan_batch", sb)
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_tree(back); e.reset_node_order(); e.seed_ties(tie, seed)
+            e.ufboot_attach(samples, 0.5)
+            s1 = e.optimize_spr(1, radius)
+            logl, cnt, tr = e.ufboot_state()
+            got.append((s1, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.ufboot_tree_logl().tolist(), logl.tolist(), cnt.tolist(),
+                        tr.tolist(), e.ufboot_counters()["tie_draws"], e.tie_state(),
+                        [e.ufboot_tree(int(t)).tolist() for t in sorted(set(tr.tolist())) if t >= 0]))
+            if not opts:
+                n_early += e.get_option("ufb_early_batches")
+        assert got[0] == got[1] and got[0] == got[2], ("tracked climb mismatch", alpha, n, P, tie, radius, seed, B, sb)
+        n_trk += 1
+print(f"soak ok: {n_climb} climbs (kernel == host loop), {n_ref} refine sweeps / {n_samples} samples (== per-sample climbs), "
+      f"{n_trk} tracked climbs three ways ({n_early} batches decided from the costs)")

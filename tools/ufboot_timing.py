@@ -54,7 +54,8 @@ print(f"{a.workload} B={a.samples}: start {s0}; plain climb -> {s_plain} in {t1-
       f"attach {tb-ta:.2f}s; climb with online UFBoot -> {s_ufb} in {t3-t2:.3f}s ({st['insertion_tests']} tests, {st['moves_applied']} moves, "
       f"scan kernels {st['scan_kernel_ms_total']:.1f} ms, REPS product {cn['reps_kernel_ms']:.1f} ms over {cn['reps_rows']} rows, "
       f"{cn['events']} events, {cn['tie_draws']} draws, {len(e.ufboot_tree_logl())} saved trees"
-      + (f", {e.ufboot_duplicates()} duplicates" if a.storetrees else "") + ")")
+      + (f", {e.ufboot_duplicates()} duplicates" if a.storetrees else "") + ")"
+      + f"; batches of the tracked climb {e.get_option('ufb_batches')}, decided from the costs {e.get_option('ufb_early_batches')}")
 rows, W = cn["reps_rows"], e.Wp
 if cn["reps_kernel_ms"] > 0:
     ops = 2.0 * rows * (W * 32) * (-(-a.samples // 128) * 128)
