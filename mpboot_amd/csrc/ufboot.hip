@@ -606,8 +606,8 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
 // the publishing tail alone, behind the chunked kernels of a large batch
 __global__ __launch_bounds__(1024) void k_ufb_publish(const UfbEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count, UfbPublish pb)
 {
-  ufb_publish_ranges(pb, 0u, 1u);
-  ufb_publish<true>(pb, ev, ev_count, 1u);
+  ufb_publish_ranges(pb, blockIdx.x, gridDim.x);
+  ufb_publish<true>(pb, ev, ev_count, gridDim.x);
 }
 
 // k_ufb_prep + the publication of the SCAN's results (costs with the refresh's mutation counts, info) behind a flag of their own:
@@ -880,7 +880,7 @@ hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const ui
   }
   hipError_t e = launch_ufb_events(st, info, cost, thr, home, crow, C, Bp, B, rt, best, n_idx, cmin, pre, ev, ev_cap, ev_count, fixed_bound);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_ufb_publish, dim3(1), dim3(1024), 0, st, ev, ev_count, pb);
+  hipLaunchKernelGGL(k_ufb_publish, dim3(16), dim3(1024), 0, st, ev, ev_count, pb);      // (whole sweeps: 1e5 costs, 2e5 info words)
   return hipGetLastError();
 }
 
