@@ -1333,23 +1333,23 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
 
 // ---- device-walked scans -------------------------------------------------------------------
 // the same enumeration as add_traverse, host side, only to NAME a candidate (needed when a move is accepted)
-void Engine::enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const
+void Engine::enumerate_side(const std::vector<int32_t> &bk, int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const
 {
   struct Fr { int q, d; };
-  std::vector<Fr> st;
-  const int x1 = back_[nx(x)], x2 = back_[nx(nx(x))];
+  Fr st[160];                                      // (one entry more per level of the walk; radii stay far below 128)
+  int sp = 0;
+  const int x1 = bk[(size_t)nx(x)], x2 = bk[(size_t)nx(nx(x))];
   for (int side = 0; side < 2; side++) {
     const int a = side ? x2 : x1;
     if (tip(a)) continue;
-    st.push_back(Fr{back_[nx(nx(a))], 1});
-    st.push_back(Fr{back_[nx(a)], 1});
-    while (!st.empty()) {
-      const Fr f = st.back();
-      st.pop_back();
+    st[sp++] = Fr{bk[(size_t)nx(nx(a))], 1};
+    st[sp++] = Fr{bk[(size_t)nx(a)], 1};
+    while (sp) {
+      const Fr f = st[--sp];
       if (f.d >= mintrav) q.push_back(f.q);
       if (!tip(f.q) && f.d < maxtrav) {
-        st.push_back(Fr{back_[nx(nx(f.q))], f.d + 1});
-        st.push_back(Fr{back_[nx(f.q)], f.d + 1});
+        st[sp++] = Fr{bk[(size_t)nx(nx(f.q))], f.d + 1};
+        st[sp++] = Fr{bk[(size_t)nx(f.q)], f.d + 1};
       }
     }
   }
@@ -2023,6 +2023,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_thread") { ufb_thread_ = v ? 1 : 0; return MPF_OK; }
   if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
@@ -2102,6 +2103,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "ufb_pipe") *v = ufb_pipe_;
+  else if (key == "ufb_thread") *v = ufb_thread_;
   else if (key == "ufb_batches") *v = ufb_stat_batches_;
   else if (key == "ufb_early_batches") *v = ufb_stat_early_;
   else if (key == "force_big") *v = force_big_;

@@ -278,7 +278,8 @@ class Engine {
   static bool wait_host_flag(const uint32_t *flag);
   int scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out);
   int candidate_record(const ScanPlan &plan, size_t c);               // q of the c-th insertion test
-  void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const;
+  void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const { enumerate_side(back_, x, mintrav, maxtrav, q); }
+  void enumerate_side(const std::vector<int32_t> &bk, int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const;   // (on any topology; reads n_ only)
   int spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p);
   int sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp);
   int sweep_costs(int mintrav, int maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets, uint64_t *n_tests);
@@ -323,8 +324,10 @@ class Engine {
     return (uint32_t)(-(int64_t)u.top_thr[b]) - 1u;              // rell > threshold  <=>  length <= -threshold - 1
   }
   int ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const;
-  void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const;
-  mutable std::vector<int32_t> ct_q_, ct_cp_, ct_mn_, ct_sz_, ct_off_;     // its scratch (an engine belongs to one host thread at a time)
+  struct CanonScratch { std::vector<int32_t> q, cp, mn, sz, off; };
+  void canonical_topology(const std::vector<int32_t> &bk, std::string &key, CanonScratch &sc) const;
+  void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const { canonical_topology(bk, key, ct_); }
+  mutable CanonScratch ct_;                      // the calling thread's scratch (the tracker's log worker brings its own)
   bool ufboot_attached() const { return (bool)ufb_; }
   int ufboot_set_cutoff(double logl_cutoff);
   int ufboot_set_ratchet_booking(int on);
@@ -384,6 +387,24 @@ class Engine {
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);
   void ufb_drain_log();
+  // the log of one batch against an explicit topology: touches nothing of the engine but n_ and the tracker's deferred state
+  // (topology map, boot_trees, reference counts, stored topologies), so that it can run on the worker thread of a pipelined climb
+  struct DrainScratch {
+    CanonScratch canon;
+    std::vector<int32_t> bk, q_p, q_q;
+    std::string key, self_key;                   // (the current tree's canonical form, valid for topology epoch self_epoch)
+    int64_t self_epoch = -1;
+    int q_plan = -1;
+    std::vector<UfbState::Pending> pending;      // accepted during the current prune node, not yet materialised
+    // counters of the calling thread, added to the tracker's by whoever owns the scratch (the tracker's own words share cache
+    // lines with what the replay counts on the other thread)
+    uint64_t lookups = 0, stored = 0;
+    double t_lookup = 0;
+  };
+  void ufb_drain(const std::vector<UfbState::LogEntry> &log, const std::vector<int32_t> &bk, int32_t epoch, const std::vector<ScanPlan> &plans,
+                 DrainScratch &sc);
+  DrainScratch drain_scratch_;
+  int ufb_thread_ = 1;                           // option "ufb_thread": the pipelined climb works its log off on a second host thread
   // chained batches: thr | home | best | self list of the batch's plans into UfbState::h_small (the staging block the extraction
   // kernel reads), so that it can go up with the refresh's own upload
   int ufb_stage_small(const std::vector<ScanPlan> &plans, int count);

@@ -13,6 +13,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <pthread.h>
+#include <sched.h>
 
 #include "../csrc/engine.hpp"
 
@@ -342,7 +349,7 @@ int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
 // What the reference's printTree(WT_TAXON_ID | WT_SORT_TAXA) string stands for (iqtree.cpp:3508): a canonical form of the
 // unrooted topology.  Here: the tree hung from tip 1, an inner node written as -1 followed by its two subtrees, the one
 // with the smaller tip number first.
-void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key) const
+void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key, CanonScratch &sc) const
 {
   // One call per booked tree that some sample accepts (3e4 in a C3 climb from a random tree; every insertion test with
   // -storetrees), so: no allocation, no stack, selects instead of branches.  Three sequential sweeps over the nodes in
@@ -351,8 +358,8 @@ void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key
   // 16-bit entries while tip numbers fit (tips 1 .. n, an inner node 0; wide form: -1).
   const int tipmax = 3 * n_ + 2;                   // records of tips: r <= tipmax
   const size_t cap = 2 * (size_t)n_ + 8;
-  if (ct_q_.size() < cap) { ct_q_.resize(cap); ct_cp_.resize(cap); ct_mn_.resize(cap); ct_sz_.resize(cap); ct_off_.resize(cap); }
-  int32_t *q = ct_q_.data(), *cp = ct_cp_.data(), *mn = ct_mn_.data(), *sz = ct_sz_.data(), *off = ct_off_.data();
+  if (sc.q.size() < cap) { sc.q.resize(cap); sc.cp.resize(cap); sc.mn.resize(cap); sc.sz.resize(cap); sc.off.resize(cap); }
+  int32_t *q = sc.q.data(), *cp = sc.cp.data(), *mn = sc.mn.data(), *sz = sc.sz.data(), *off = sc.off.data();
   int len = 1;
   q[0] = bk[3];
   for (int i = 0; i < len; i++) {
@@ -564,28 +571,76 @@ void Engine::ufb_drain_log()
 {
   UfbState &u = *ufb_;
   if (u.log.empty()) return;
-  back_.swap(u.log_back);
-  std::swap(topo_epoch_, u.log_epoch);
+  DrainScratch &sc = drain_scratch_;
+  ufb_drain(u.log, u.log_back, u.log_epoch, *u.log_plans, sc);
+  u.lookups += sc.lookups; u.stored += sc.stored; u.t_lookup += sc.t_lookup;
+  sc.lookups = sc.stored = 0;
+  sc.t_lookup = 0;
+  u.log.clear();
+}
+
+void Engine::ufb_drain(const std::vector<UfbState::LogEntry> &log, const std::vector<int32_t> &bk, int32_t epoch, const std::vector<ScanPlan> &plans,
+                       DrainScratch &sc)
+{
+  UfbState &u = *ufb_;
+  sc.q_plan = -1;
+  // q of the c-th insertion test of plan j on THIS topology (Engine::candidate_record on back_): both sides enumerated once per plan
+  auto record_of = [&](int j, const ScanPlan &pl, size_t c) -> int {
+    if (!pl.walked) return pl.cands[c].q;
+    if (sc.q_plan != j) {
+      sc.q_p.clear();
+      sc.q_q.clear();
+      if (pl.n_p > 0) enumerate_side(bk, pl.rec, 1, pl.maxtrav, sc.q_p);
+      if (pl.n_total > pl.n_p) enumerate_side(bk, bk[(size_t)pl.rec], pl.mintrav_q, pl.maxtrav, sc.q_q);
+      sc.q_plan = j;
+    }
+    return (int)c < pl.n_p ? sc.q_p[c] : sc.q_q[c - (size_t)pl.n_p];
+  };
+  auto topology_of = [&](const ScanPlan &pl, int ins, uint32_t cand, std::vector<int32_t> &out) {       // Engine::ufb_candidate_topology on bk
+    const int p = cand < (uint32_t)pl.n_p ? pl.rec : bk[(size_t)pl.rec];
+    out = bk;
+    auto hk = [&](int a, int b2) { out[(size_t)a] = b2; out[(size_t)b2] = a; };
+    const int a = out[(size_t)nx(p)], b2 = out[(size_t)nx(nx(p))];
+    hk(a, b2);
+    const int r = out[(size_t)ins];
+    hk(nx(p), ins);
+    hk(nx(nx(p)), r);
+  };
+  auto need_ref = [&](int64_t t) { if (u.refs.size() <= (size_t)t) u.refs.resize((size_t)t + 1 + u.refs.size() / 2, 0); };
   int64_t raw = -1, resolved = -1;
-  for (const UfbState::LogEntry &le : u.log) {
-    const ScanPlan &pl = (*u.log_plans)[(size_t)le.plan];
-    if (le.b == 0xFFFFFFFFu) { ufb_flush_pending(pl); continue; }
+  for (const UfbState::LogEntry &le : log) {
+    const ScanPlan &pl = plans[(size_t)le.plan];
+    if (le.b == 0xFFFFFFFFu) {
+      // end of this prune node's scan: the topologies accepted during it that some sample still points to (ufb_flush_pending)
+      for (const UfbState::Pending &pe : sc.pending) {
+        if (u.refs[(size_t)pe.tree_index] <= 0 || u.store.count(pe.tree_index)) continue;
+        if (pe.cand == 0xFFFFFFFFu) u.store.emplace(pe.tree_index, bk);
+        else {
+          topology_of(pl, record_of(le.plan, pl, (size_t)pe.cand), pe.cand, sc.bk);
+          u.store.emplace(pe.tree_index, sc.bk);
+        }
+        sc.stored++;
+      }
+      sc.pending.clear();
+      continue;
+    }
     if (le.tree != raw) {
       raw = le.tree;
       const double tl = now_ms();
-      const std::string *key = &u.self_key;
+      const std::string *key = &sc.self_key;
       if (le.cand == 0xFFFFFFFFu) {
-        if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+        if (sc.self_epoch != (int64_t)epoch) { canonical_topology(bk, sc.self_key, sc.canon); sc.self_epoch = (int64_t)epoch; }
       } else {
-        ufb_candidate_topology(le.cand < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], candidate_record(pl, (size_t)le.cand), u.log_bk);
-        canonical_topology(u.log_bk, u.log_key);
-        key = &u.log_key;
+        topology_of(pl, record_of(le.plan, pl, (size_t)le.cand), le.cand, sc.bk);
+        canonical_topology(sc.bk, sc.key, sc.canon);
+        key = &sc.key;
       }
       resolved = u.topo_index.emplace(*key, raw).first->second;
-      u.t_lookup += now_ms() - tl;
-      u.lookups++;
+      sc.t_lookup += now_ms() - tl;
+      sc.lookups++;
     }
-    if (u.pending.empty() || u.pending.back().tree_index != resolved) u.pending.push_back(UfbState::Pending{resolved, le.cand});
+    need_ref(resolved);
+    if (sc.pending.empty() || sc.pending.back().tree_index != resolved) sc.pending.push_back(UfbState::Pending{resolved, le.cand});
     int64_t &bt = u.boot_trees[le.b];
     if (bt != resolved) {
       if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
@@ -593,9 +648,6 @@ void Engine::ufb_drain_log()
       bt = resolved;
     }
   }
-  u.log.clear();
-  back_.swap(u.log_back);
-  std::swap(topo_epoch_, u.log_epoch);
 }
 
 // events into replay order: by scan output index, then by sample.  The current tree, booked once per prune-node visit, ties
@@ -1301,6 +1353,101 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
   uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32;
   bool log_open = false;
+  // the deferred log of every batch goes to a second host thread (option ufb_thread): it owns the tracker's deferred state
+  // (topology map, boot_trees, reference counts, stored topologies) for the length of this climb and works on copies of the
+  // topology and the plans, this thread never looks at that state before the worker has been joined
+  struct Job { std::vector<UfbState::LogEntry> log; std::vector<int32_t> back; int32_t epoch = 0; std::vector<ScanPlan> plans; };
+  struct Worker {
+    Engine *e = nullptr;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job *> q;
+    std::vector<Job *> spare;
+    std::vector<std::unique_ptr<Job>> all;
+    size_t inflight = 0;
+    bool stop = false, started = false;
+    DrainScratch sc;
+    void run()
+    {
+      for (;;) {
+        Job *j = nullptr;
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return stop || !q.empty(); });
+          if (q.empty()) return;
+          j = q.front();
+          q.pop_front();
+        }
+        e->ufb_drain(j->log, j->back, j->epoch, j->plans, sc);
+        j->log.clear();
+        {
+          std::lock_guard<std::mutex> lk(m);
+          spare.push_back(j);
+          inflight--;
+        }
+        cv.notify_all();
+      }
+    }
+    Job *get()
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return inflight < 256; });
+      if (spare.empty()) { all.emplace_back(new Job()); return all.back().get(); }
+      Job *j = spare.back();
+      spare.pop_back();
+      return j;
+    }
+    void submit(Job *j)
+    {
+      if (!started) {
+        started = true;
+        th = std::thread([this] { run(); });
+        // keep the worker on the cores that share this thread's last-level cache (best effort): the log, the plans and the
+        // topology copies change hands every batch, and on a two-socket host a worker on the other socket made the replay --
+        // which then writes into lines the worker owns -- 2.4 times slower than it is alone
+        const int cpu = sched_getcpu();
+        if (cpu >= 0) {
+          char path[128];
+          std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+          if (FILE *fp = std::fopen(path, "r")) {
+            char buf[256] = {0};
+            if (std::fgets(buf, sizeof buf, fp)) {
+              cpu_set_t set;
+              CPU_ZERO(&set);
+              int n_set = 0;
+              for (char *p = buf; *p && *p != '\n';) {
+                char *end = nullptr;
+                const long a = std::strtol(p, &end, 10);
+                if (end == p) break;
+                long b = a;
+                p = end;
+                if (*p == '-') { b = std::strtol(p + 1, &end, 10); p = end; }
+                for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c != cpu) { CPU_SET((int)c, &set); n_set++; }
+                if (*p == ',') p++;
+              }
+              if (n_set > 0) (void)pthread_setaffinity_np(th.native_handle(), sizeof set, &set);
+            }
+            std::fclose(fp);
+          }
+        }
+      }
+      { std::lock_guard<std::mutex> lk(m); q.push_back(j); inflight++; }
+      cv.notify_all();
+    }
+    void finish()
+    {
+      if (!started) return;
+      { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return inflight == 0; }); stop = true; }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+      started = false;
+    }
+    ~Worker() { finish(); }
+  } worker;
+  worker.e = this;
+  const bool use_worker = ufb_thread_ != 0;
+  uint64_t n_draws = 0;                            // (added to the tracker's counter at the end: its word shares a cache line with the worker's)
 
   // plan + enqueue the whole chain of the batch [i, i + b): refresh, masked scan, mid (C <- 0, self slots, scan results to the host),
   // product, extraction (events and R_T to the host)
@@ -1599,7 +1746,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           bool accept = false;
           if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (iqtree.cpp:3686)
           else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
-            u.draws++;
+            n_draws++;
             accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
           }
           if (accept) {
@@ -1611,7 +1758,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         };
         auto book = [&](uint32_t len) -> int64_t {                      // iqtree.cpp:3343-3348 without a cut-off
           u.treels.push_back(len);
-          u.refs.push_back(0);
+          if (!use_worker) u.refs.push_back(0);                         // (the worker sizes the reference counts itself)
           return (int64_t)u.treels.size() - 1;
         };
         if (pl.self_idx >= 0) {
@@ -1680,7 +1827,15 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       }
       if (early && !d.moved && moved) { set_error("online UFBoot: a move where the costs said none is possible"); return MPF_E_STATE; }
       // the log of this batch speaks of the tree in front of its move
-      if (!u.log.empty()) {
+      if (!u.log.empty() && use_worker) {
+        Job *jb = worker.get();
+        jb->log.swap(u.log);
+        u.log.clear();
+        if (moved) { jb->back.swap(snap_back); jb->epoch = snap_epoch; }
+        else { jb->back = back_; jb->epoch = topo_epoch_; }
+        jb->plans = B.plans;
+        worker.submit(jb);
+      } else if (!u.log.empty()) {
         if (moved) { u.log_back.swap(snap_back); u.log_epoch = snap_epoch; }
         else { u.log_back = back_; u.log_epoch = topo_epoch_; }
         u.log_plans = &B.plans;
@@ -1692,6 +1847,10 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     }
   } while (randomMP < startMP);
   ufb_drain_log();
+  worker.finish();
+  u.lookups += worker.sc.lookups; u.stored += worker.sc.stored; u.t_lookup += worker.sc.t_lookup;
+  u.draws += n_draws;
+  if (u.refs.size() < u.treels.size()) u.refs.resize(u.treels.size(), 0);
   climb_finished(total);
   if (u.exchange) {
     // closing handshake: a rank that took another path would be in the middle of a batch here
