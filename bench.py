@@ -524,6 +524,9 @@ def main():
     ap.add_argument("--climb-tile", type=int, default=4, help="words per lane group of k_climb in the concurrent-climbs leg (4: 25, 8: 13 workgroups per C3 climb)")
     ap.add_argument("--c2-engines", type=int, default=16, help="concurrent engines (host threads) in the C2 concurrent-climbs leg")
     ap.add_argument("--start-engines", type=int, default=6, help="concurrent engines (host threads) per GPU in the start-trees leg")
+    ap.add_argument("--shard-online", default="auto", choices=["auto", "0", "1"],
+                    help="online UFBoot phase on several GPUs: 1 = samples sharded, events all-gathered per scan batch; 0 = every rank keeps all samples "
+                         "(replicas); auto = sharded from shard.ONLINE_SHARD_MIN_SAMPLES samples on (below, the exchange costs the pipelined climb more than the share saves)")
     ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
     ap.add_argument("--start-trees", type=int, default=100,
                     help="randomized-stepwise-addition + SPR start trees of the start-up phase (phyloanalysis.cpp:1270-1317), sharded over the GPUs (0 = skip)")
@@ -805,7 +808,7 @@ def main():
             back_u = shard.broadcast_tree(back, 0, len(back))      # the chain starts from rank 0's tree on every rank
             tus = []
             for timed in (False, True, True):          # first pass: allocations, code load; then two timed passes, the faster one counts
-                eng.ufboot_attach(samples, 0.5, shard=(rank, world))   # samples rank, rank + world, ... ; events all-gathered per batch
+                eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online))   # sharded: samples rank, rank + world, ... ; events all-gathered per batch
                 eng.set_tree(back_u)
                 eng.reset_node_order()
                 eng.seed_ties(engine.TIE_RANDOM, 1)
@@ -911,7 +914,7 @@ def main():
                                           "seconds_host_driven_batches": t_plain_h,
                                           "what": "pllOptimizeSprParsimony from a random tree: sweeps with dense moves run in the persistent kernel "
                                                   "k_climb (device-resident loop), sparse ones as whole-chip host-driven batches"}}
-                eng.ufboot_attach(samples, 0.5, shard=(rank, world))
+                eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online))
                 eng.set_tree(back_r)
                 eng.reset_node_order()
                 eng.seed_ties(engine.TIE_RANDOM, 1)
@@ -1190,9 +1193,10 @@ def main():
                 "seconds_is": "random-start flow (random_start.bb_flow)" if nondeg is not None and "bb_flow" in nondeg else "flow from the RAS tree",
                 "refinement_s_plan_cache_off": tb_nocache, "refinement_s_per_sample_climbs": tb_persample, "distinct_boot_trees": n_distinct_trees,
                 "scaling": "strong", "engines_per_gpu": n_eng,
+                "online_phase_sharded": shard.online_shard(ufb["samples"], rank, world, args.shard_online) is not None,
                 "mean_sample_score_online": boot[3], "mean_sample_score_refined": boot[2], "refinement_never_worse": boot[4],
                 "what": "-bb %d on this alignment from one start tree: online phase (one SPR climb with saveCurrentTree bookkeeping, "
-                        "samples sharded over the ranks) + refinement of every sample's tree (one SPR climb under the sample's weights, radius %d; "
+                        "samples sharded over the ranks from shard.ONLINE_SHARD_MIN_SAMPLES samples on, every rank with all samples below) + refinement of every sample's tree (one SPR climb under the sample's weights, radius %d; "
                         "sample b on rank b %% n_gpus).  Refinement: the first sweep of all climbs that start from one topology is computed at "
                         "once (mpf_ufboot_refine_sweep: masked scan + mask x weight product on the matrix cores + per-sample replay of the tie "
                         "rules; the samples' weights are uploaded and laid out inside the timed region); samples whose sweep accepts a move "

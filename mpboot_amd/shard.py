@@ -106,6 +106,24 @@ EVENT_BLOCK = 4096
 _ev_bufs = {}
 
 
+ONLINE_SHARD_MIN_SAMPLES = 4096
+
+
+def online_shard(n_samples: int, rank: int, world_size: int, mode: str = "auto"):
+    """The `shard` argument of FitchEngine.ufboot_attach for the ONLINE phase of a run on `world_size` GPUs, or None = every rank
+    keeps all samples and makes the same calls (replicas: identical results by construction, no exchange).
+    Sharding divides the REPS product and the event extraction of every scan batch (C3: 26 + 14 us per batch and 1000 samples
+    on one GPU) and costs one all-gather of the batch's events on the HOST's side of the pipelined climb (the host
+    has 35 us to spare per batch; the exchange -- two copies, the collective, Python -- is priced at 100-150 us).  Per batch:
+    65 + 40 * B / 1000 us unsharded against max(65 + 40 * B / 1000 / W, 220) us sharded, so sharding pays from about 4000
+    samples on, whatever W.  mode: "auto" (that rule), "1" (always), "0" (never)."""
+    if world_size <= 1 or mode == "0":
+        return None
+    if mode == "1" or n_samples >= ONLINE_SHARD_MIN_SAMPLES:
+        return (rank, world_size)
+    return None
+
+
 def gather_events(local: np.ndarray, tag: int = 0) -> np.ndarray:
     """All-gather of the (candidate index, sample, score) triples of one scan batch: [n_local, 3] uint32 in,
     [n_all, 3] out, identical on every rank.  One fixed-size collective on the default process group -- RCCL over xGMI on the

@@ -218,3 +218,14 @@ def test_in_process_multi_device_schedule():
             assert [b for _, b in pairs] == [shard.unit_seed(7, u) for u in got]
             seen += got
         assert sorted(seen) == list(range(units))
+
+
+def test_online_phase_sharding_policy():
+    """below ONLINE_SHARD_MIN_SAMPLES every rank keeps all samples (the pipelined climb leaves the per-batch exchange no room,
+    DESIGN 9); the explicit modes override"""
+    from mpboot_amd import shard
+    assert shard.online_shard(1000, 3, 8) is None
+    assert shard.online_shard(shard.ONLINE_SHARD_MIN_SAMPLES, 3, 8) == (3, 8)
+    assert shard.online_shard(10 ** 6, 0, 1) is None
+    assert shard.online_shard(1000, 1, 2, "1") == (1, 2)
+    assert shard.online_shard(10 ** 6, 1, 2, "0") is None
