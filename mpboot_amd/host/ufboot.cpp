@@ -1447,6 +1447,24 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   } worker;
   worker.e = this;
   const bool use_worker = ufb_thread_ != 0;
+  // any return but the last one leaves launches in flight and a batch half consumed: wait for the device, forget what the
+  // engine believes about the views and the pending scan, so that the next call starts from the topology alone
+  struct Abort {
+    Engine *e;
+    bool ok = false;
+    ~Abort()
+    {
+      if (ok) return;
+      (void)hipStreamSynchronize(e->st_);
+      e->walk_async_ = false;
+      e->n_walk_ = 0;
+      e->walk_out_ = 0;
+      e->cnt_copy_pending_ = false;
+      e->pending_scores_ = false;
+      e->invalidate_all();
+      if (e->ufb_) { e->ufb_->log.clear(); e->ufb_->rt_valid = false; }
+    }
+  } abort_guard{this};
   uint64_t n_draws = 0;                            // (added to the tracker's counter at the end: its word shares a cache line with the worker's)
 
   // plan + enqueue the whole chain of the batch [i, i + b): refresh, masked scan, mid (C <- 0, self slots, scan results to the host),
@@ -1859,6 +1877,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
   }
   if (final_score) *final_score = randomMP;
+  abort_guard.ok = true;
   return MPF_OK;
 }
 

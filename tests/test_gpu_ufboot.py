@@ -142,6 +142,50 @@ def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
             assert g[2] > 0 and g[2] <= g[3]
 
 
+def test_a_failing_exchange_in_mid_climb_leaves_a_usable_engine(mods):
+    """the pipelined climb returns from the middle of a batch when the event exchange fails -- with the next batch possibly in
+    flight on the device.  The call must fail loudly and the engine must afterwards behave like a new one."""
+    import ctypes as C
+
+    from mpboot_amd import shard
+    engine, po = mods
+    fx = load_fixture("dna_48")
+    w = np.asarray(fx["weights"], dtype=np.float64)
+    samples = np.random.default_rng(5).multinomial(int(w.sum()), w / w.sum(), size=40).astype(np.uint16)
+    start = np.array(fx["trees"][0]["back"], dtype=np.int32)
+    calls = {"n": 0}
+    keep = {}
+
+    def fn(_arg, tag, local_ptr, n_local, all_ptr, n_all_ptr):
+        calls["n"] += 1
+        if calls["n"] > 6:
+            return 1
+        buf = np.ctypeslib.as_array(C.cast(local_ptr, C.POINTER(C.c_uint32)), shape=(n_local, 3)).copy() if n_local else np.zeros((0, 3), dtype=np.uint32)
+        keep["buf"] = buf
+        all_ptr[0] = buf.ctypes.data if n_local else None
+        n_all_ptr[0] = n_local
+        return 0
+
+    cb = shard.EXCHANGE_FN(fn)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    e.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, 3)
+    e.ufboot_attach(samples, 0.5, shard=(0, 2), exchange=cb)
+    with pytest.raises(Exception):
+        e.optimize_spr(1, 6)
+    assert calls["n"] == 7
+    e.ufboot_detach()
+    f = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    for x in (e, f):
+        x.set_tree(start)
+        x.reset_node_order()
+        x.seed_ties(engine.TIE_RANDOM, 3)
+    assert e.score_tree(start) == f.score_tree(start)
+    se, sf = e.optimize_spr(1, 6), f.optimize_spr(1, 6)
+    assert se == sf and (e.get_tree() == f.get_tree()).all()
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in f.moves()]
+
+
 def test_cutoff_filter_and_next_cutoff(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
