@@ -684,6 +684,23 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   uint32_t startMP;
   unsigned iter_hits = 1;
   const int total = 2 * n_ - 2;
+  // (an early return may leave a chained batch in flight: wait for it and start over from the topology, as the pipelined climb does)
+  struct Abort {
+    Engine *e;
+    bool ok = false;
+    ~Abort()
+    {
+      if (ok) return;
+      (void)hipStreamSynchronize(e->st_);
+      e->walk_async_ = false;
+      e->n_walk_ = 0;
+      e->walk_out_ = 0;
+      e->cnt_copy_pending_ = false;
+      e->pending_scores_ = false;
+      e->invalidate_all();
+      if (e->ufb_) { e->ufb_->log.clear(); e->ufb_->rt_valid = false; }
+    }
+  } abort_guard{this};
   std::vector<ScanPlan> plans_buf[2];                // (the deferred log of a batch names its plans while the next batch is planned)
   int plans_cur = 0;
   const uint32_t *out = nullptr;
@@ -1297,6 +1314,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
   }
   if (final_score) *final_score = randomMP;
+  abort_guard.ok = true;
   return MPF_OK;
 }
 

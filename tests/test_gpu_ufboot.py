@@ -142,7 +142,8 @@ def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
             assert g[2] > 0 and g[2] <= g[3]
 
 
-def test_a_failing_exchange_in_mid_climb_leaves_a_usable_engine(mods):
+@pytest.mark.parametrize("opts", [{}, {"ufb_pipe": 0}, {"ufb_fast": 0}])
+def test_a_failing_exchange_in_mid_climb_leaves_a_usable_engine(mods, opts):
     """the pipelined climb returns from the middle of a batch when the event exchange fails -- with the next batch possibly in
     flight on the device.  The call must fail loudly and the engine must afterwards behave like a new one."""
     import ctypes as C
@@ -168,6 +169,8 @@ def test_a_failing_exchange_in_mid_climb_leaves_a_usable_engine(mods):
 
     cb = shard.EXCHANGE_FN(fn)
     e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    for k, v in opts.items():
+        e.set_option(k, v)
     e.set_tree(start)
     e.seed_ties(engine.TIE_RANDOM, 3)
     e.ufboot_attach(samples, 0.5, shard=(0, 2), exchange=cb)
