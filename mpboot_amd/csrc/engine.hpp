@@ -133,6 +133,7 @@ struct UfbState {
   std::vector<int32_t> log_back;                 // the topology the log's candidates refer to
   int32_t log_epoch = 0;
   std::vector<int32_t> log_bk;
+  std::vector<double> inv;                       // inv[k] = 1.0 / (double)k, grown on demand (the very quotient the rule compares a draw with)
   std::string log_key;
   double t_defer = 0;
   const std::vector<ScanPlan> *log_plans = nullptr;
@@ -387,6 +388,9 @@ class Engine {
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);
   void ufb_drain_log();
+  // the current tree offered to every local sample under the default update rule with the deferred log (iqtree.cpp:3684-3731 for
+  // 1000 samples x every prune-node visit: 2e6 bookings per move-less C3 sweep) -- one tight loop, the reciprocals from a table
+  void ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws);
   // the log of one batch against an explicit topology: touches nothing of the engine but n_ and the tracker's deferred state
   // (topology map, boot_trees, reference counts, stored topologies), so that it can run on the worker thread of a pipelined climb
   struct DrainScratch {

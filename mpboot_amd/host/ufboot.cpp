@@ -564,6 +564,40 @@ int Engine::ufb_stage_small(const std::vector<ScanPlan> &plans, int count)
   return MPF_OK;
 }
 
+void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws)
+{
+  UfbState &u = *ufb_;
+  uint32_t *bsv = u.boot_score.data();
+  int32_t *cnt = u.boot_counts.data();
+  const int32_t *ids = u.ids.data();
+  std::vector<double> &inv = u.inv;
+  if (inv.size() < 2) { inv.assign(2, 0.0); inv[1] = 1.0; }
+  const bool callback = rand_fn_ != nullptr;
+  uint64_t st = rng_.state, draws = 0;
+  for (int c2 = 0; c2 < u.Bl; c2++) {
+    const uint32_t b = (uint32_t)ids[c2], s = (uint32_t)rt[c2], bs = bsv[b];
+    if (s > bs) continue;
+    bool accept = true;                                                 // rell > boot_logl + epsilon (:3686)
+    if (s == bs) {                                                      // a tie: one draw against 1 / (boot_counts + 1) (:3687-3688)
+      draws++;
+      const size_t k = (size_t)cnt[b] + 1;
+      if (k >= inv.size()) { const size_t from = inv.size(); inv.resize(std::max(k + 1, 2 * from)); for (size_t i = from; i < inv.size(); i++) inv[i] = 1.0 / (double)i; }
+      double r;
+      if (callback) r = rand_fn_(rand_arg_);
+      else { st = st * 0x27bb2ee687b0b0fdULL + 3037000493ULL; r = (double)st * 5.4210108624275222e-20; }     // (TieRng::next)
+      accept = r <= inv[k];
+    }
+    if (accept) {
+      u.log.push_back(UfbState::LogEntry{b, 0xFFFFFFFFu, tree_index, cur_plan});
+      log_open = true;
+      if (s < bs) { cnt[b] = 1; bsv[b] = s; }                           // :3710-3719
+    }
+    cnt[b]++;                                                           // :3728-3730 (s equals the sample's best here in either case)
+  }
+  if (!callback) rng_.state = st;
+  n_draws += draws;
+}
+
 // The deferred half of the default update rule (iqtree.cpp:3689-3707, :3720): the tree "string" of a booked tree -- looked up
 // once, at its first acceptance --, boot_trees[b], the reference counts and the topologies to keep.  Runs against the topology
 // the log was written under (the climb may have moved on by one move since).
@@ -1180,6 +1214,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
         // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
         auto replay_self = [&](int64_t tree_index) {
+          if (defer) { ufb_self_default(u.h_rt.p, tree_index, cur_plan, log_open, u.draws); return; }
           bool looked_up = store_trees;
           for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
         };
@@ -1801,7 +1836,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           // the current tree, once per prune node and before its insertion tests (sprparsimony.cpp:2285-2289)
           const int64_t tree_index = book(randomMP);
           if (host_self) {
-            for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)h_rt[c2], tree_index, 0xFFFFFFFFu);
+            ufb_self_default(h_rt, tree_index, cur_plan, log_open, n_draws);
           } else {
             const uint32_t idx = (uint32_t)pl.self_idx;
             while (ep < events.size() && events[ep].idx < idx) ep++;
