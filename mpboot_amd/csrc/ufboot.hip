@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_join_masks(const uint32_t *__restrict__
 template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0, bool M32 = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__restrict__ masks, int Wp, const uint8_t *__restrict__ Wt,
                                                  int Bp, int32_t *__restrict__ C, int mult, int atomic, int row_blocks,
-                                                 int kb_per_split, const uint32_t *__restrict__ rowsel)
+                                                 int kb_per_split, const uint32_t *__restrict__ rowsel, const uint32_t *__restrict__ row_limit)
 {
   constexpr int TM = 16 * MT * WM, TN = 16 * NT * WN, NTH = 64 * WM * WN;
   constexpr int BT = TN * 64;                        // bytes of one k-block of the B tile (16 KiB)
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bitgemm(const uint32_t *__rest
   if (col_blocks <= 8 && (8 % col_blocks) == 0) { cb = xcd % col_blocks; rb = grp * (8 / col_blocks) + xcd / col_blocks; }
   else { cb = (int)(blockIdx.x % (unsigned)col_blocks); rb = (int)(blockIdx.x / (unsigned)col_blocks); }
   if (rb >= row_blocks) return;
+  // row_limit (a climb's batch): rows from *row_limit on lie behind the batch's certain end -- nobody reads their products
+  if (row_limit && (uint32_t)(rb * TM) >= __builtin_nontemporal_load(row_limit)) return;
   const int r = lane & 15, h = lane >> 4;
   const int nkb = Wp >> 1;
   const int kb_begin = blockIdx.y * kb_per_split, kb_end = min(nkb, kb_begin + kb_per_split);
@@ -498,8 +500,9 @@ __global__ __launch_bounds__(1024) void k_ufb_events2(const uint2 *__restrict__ 
                                                       const uint32_t *__restrict__ crow, const int32_t *__restrict__ C, int Bp, int B,
                                                       const int32_t *__restrict__ rt, uint32_t n_idx, const uint32_t *__restrict__ best,
                                                       UfbEvent *__restrict__ ev, uint32_t ev_cap, uint32_t *__restrict__ ev_count,
-                                                      UfbPublish pb, int clamp_rt)
+                                                      UfbPublish pb, int clamp_rt, const uint32_t *__restrict__ cut)
 {
+  if (cut) n_idx = min(n_idx, __builtin_nontemporal_load(cut));       // (the batch's certain end, k_ufb_mid)
   __shared__ uint32_t wmin[16][64];
   __shared__ uint32_t wtot[16];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -613,12 +616,31 @@ __global__ __launch_bounds__(1024) void k_ufb_publish(const UfbEvent *__restrict
 // k_ufb_prep + the publication of the SCAN's results (costs with the refresh's mutation counts, info) behind a flag of their own:
 // the host can take the search's decision from the costs while the product and the extraction are still running
 __global__ __launch_bounds__(256) void k_ufb_mid(uint4 *__restrict__ C4, uint32_t n4, uint2 *__restrict__ info, const uint32_t *__restrict__ idx,
-                                                 uint32_t n_self, uint32_t code, uint32_t *__restrict__ ev_count, UfbPublish pb)
+                                                 uint32_t n_self, uint32_t code, uint32_t *__restrict__ ev_count, UfbPublish pb,
+                                                 const uint32_t *__restrict__ cost, const uint32_t *__restrict__ home,
+                                                 const uint32_t *__restrict__ plan_end, uint32_t n_idx, uint32_t *__restrict__ cut)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) C4[i] = make_uint4(0u, 0u, 0u, 0u);
-  if (i < n_self) info[idx[i]] = make_uint2(0u, code);
   if (i == 0) *ev_count = 0u;
+  if (blockIdx.x == 0) {
+    // the current tree's slots first (what an earlier batch left in them must not be taken for a candidate below)
+    for (uint32_t k = threadIdx.x; k < n_self; k += blockDim.x) info[idx[k]] = make_uint2(0u, code);
+    // the batch's certain end: a candidate is strictly better than the current tree <=> its cost is below the cost of its part's
+    // home edge (both are the join onto an edge of the tree without the pruned subtree; the rest of the length is common), and
+    // the first prune node that has one ends the batch at the latest.  cut = end of that prune node's index range: the
+    // product's row blocks and the extraction stop there.
+    __shared__ uint32_t s_cut;
+    if (threadIdx.x == 0) s_cut = n_idx;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_idx; k += blockDim.x) {
+      const uint2 in = info[k];
+      if (in.y >= 0xFFFFFFFEu) continue;
+      if (cost[k] < cost[home[in.y]]) atomicMin(&s_cut, plan_end[in.y]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { *cut = s_cut; pb.h_flag[2] = s_cut; }
+  }
   const uint32_t pub = min(gridDim.x, 16u);        // publishing workgroups (a ticket per workgroup of a 400-workgroup launch would take longer than the copy)
   if (blockIdx.x < pub) {
     ufb_publish_ranges(pb, blockIdx.x, pub);
@@ -713,7 +735,7 @@ hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *
 
 template <int MT, int NT, int WM, int WN, int KS, int NS, int EXPR = 0, bool M32 = false>
 static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                                   int mult, int accumulate, const uint32_t *rowsel, long want_default = 192)
+                                   int mult, int accumulate, const uint32_t *rowsel, const uint32_t *row_limit, long want_default = 192)
 {
   constexpr int TM = 16 * MT * WM;
   const int row_blocks = rows_padded / TM, col_blocks = Bp / (16 * NT * WN);
@@ -749,12 +771,12 @@ static hipError_t launch_bitgemm_t(hipStream_t st, const uint32_t *masks, int ro
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR, M32>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel);
+  hipLaunchKernelGGL((k_bitgemm<MT, NT, WM, WN, KS, NS, EXPR, M32>), dim3(gx, (unsigned)ksplit), dim3(64 * WM * WN), lds, st, masks, Wp, Wt, Bp, C, mult, atomic, row_blocks, per, rowsel, row_limit);
   return hipGetLastError();
 }
 
 hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                          int mult, int accumulate, const uint32_t *rowsel)
+                          int mult, int accumulate, const uint32_t *rowsel, const uint32_t *row_limit)
 {
   if (rows_padded <= 0) return hipSuccess;
   // 256-sample column blocks when the (padded) sample count allows, else 128-sample blocks with twice the rows per
@@ -767,29 +789,29 @@ hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded
     // (C3 climb from a random tree, 1000 samples, product kernels in total: 512 x 128 tiles 0.298 s, 256 x 128 0.253 s, 128 x 128
     //  0.234 s, 128 x 256 0.264 s -- fewer K-splits per output element, i.e. fewer atomic adds into C, and all CUs busy)
     static const int small_v = std::getenv("MPF_GEMM_SMALL") ? std::atoi(std::getenv("MPF_GEMM_SMALL")) : 2;
-    if (small_v == 1 && rows_padded <= 1024) return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (small_v == 2 && rows_padded <= 2048) return launch_bitgemm_t<1, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, 256);
-    if (small_v == 3 && rows_padded <= 2048) return launch_bitgemm_t<2, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (small_v == 4 && rows_padded <= 2048) return launch_bitgemm_t<1, 16, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (small_v == 1 && rows_padded <= 1024) return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (small_v == 2 && rows_padded <= 2048) return launch_bitgemm_t<1, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit, 256);
+    if (small_v == 3 && rows_padded <= 2048) return launch_bitgemm_t<2, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (small_v == 4 && rows_padded <= 2048) return launch_bitgemm_t<1, 16, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
 #ifdef MPF_EXPERIMENTS                     // (knock-out variants of tools/gemm_bounds.sh, wrong results on purpose: `make EXPERIMENTS=1` only)
     static const int expr = std::getenv("MPF_GEMM_EXPERIMENT") ? std::atoi(std::getenv("MPF_GEMM_EXPERIMENT")) : 0;
-    if (expr == 1) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 1>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (expr == 2) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (expr == 3) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 3>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (expr == 6) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 6>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (expr == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (expr == 1) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 1>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (expr == 2) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (expr == 3) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 3>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (expr == 6) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 6>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (expr == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
 #endif
     // variants (all within 0.43-0.49 of the nominal peak, tools/gemm_bounds.sh): 0 = two k-blocks per stage, four stages in
     // the ring; 1 / 3 = 4 x 2 waves of 64 rows x 128 samples; default = 8 x 1 waves of 32 rows x 256 samples, four k-blocks
     // per stage, two stages
-    if (variant == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 0, true>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (variant == 5) return launch_bitgemm_t<4, 8, 4, 2, 4, 2, 0, true>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (variant == 1) return launch_bitgemm_t<2, 16, 8, 1, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (variant == 2) return launch_bitgemm_t<4, 8, 4, 2, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    if (variant == 3) return launch_bitgemm_t<4, 8, 4, 2, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
-    return launch_bitgemm_t<2, 16, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+    if (variant == 4) return launch_bitgemm_t<2, 16, 8, 1, 4, 2, 0, true>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (variant == 5) return launch_bitgemm_t<4, 8, 4, 2, 4, 2, 0, true>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (variant == 1) return launch_bitgemm_t<2, 16, 8, 1, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (variant == 2) return launch_bitgemm_t<4, 8, 4, 2, 2, 4>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    if (variant == 3) return launch_bitgemm_t<4, 8, 4, 2, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
+    return launch_bitgemm_t<2, 16, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
   }
-  return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel);
+  return launch_bitgemm_t<4, 8, 8, 1, 4, 2>(st, masks, rows_padded, Wp, Wt, Bp, C, mult, accumulate, rowsel, row_limit);
 }
 
 int ufb_row_padding(int rows, int Bp)
@@ -858,24 +880,26 @@ static UfbPublish publish_of(const UfbPublishArgs &a)
 }
 
 hipError_t launch_ufb_mid(hipStream_t st, int32_t *C, size_t c_words, uint2 *info, const uint32_t *self_idx, uint32_t n_self, uint32_t code,
-                          uint32_t *ev_count, const UfbPublishArgs &a)
+                          uint32_t *ev_count, const UfbPublishArgs &a, const uint32_t *cost, const uint32_t *home, const uint32_t *plan_end,
+                          uint32_t n_idx, uint32_t *cut)
 {
   const uint32_t n4 = (uint32_t)((c_words + 3) / 4);
-  const uint32_t n = std::max(std::max(n4, n_self), 1u);
-  hipLaunchKernelGGL(k_ufb_mid, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4 *>(C), n4, info, self_idx, n_self, code, ev_count, publish_of(a));
+  const uint32_t n = std::max(n4, 1u);
+  hipLaunchKernelGGL(k_ufb_mid, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4 *>(C), n4, info, self_idx, n_self, code, ev_count, publish_of(a),
+                     cost, home, plan_end, n_idx, cut);
   return hipGetLastError();
 }
 
 hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const uint32_t *cost, const uint32_t *thr, const uint32_t *home,
                                      const uint32_t *crow, const int32_t *C, int Bp, int B, const int32_t *rt, const uint32_t *best,
                                      uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
-                                     int fixed_bound, const UfbPublishArgs &a, int clamp_rt)
+                                     int fixed_bound, const UfbPublishArgs &a, int clamp_rt, const uint32_t *cut)
 {
   const UfbPublish pb = publish_of(a);
   if (n_idx > 0 && n_idx <= kUfbEvents2Max) {
     dim3 grid((unsigned)((B + 63) / 64)), block(1024);
-    if (fixed_bound) hipLaunchKernelGGL(k_ufb_events2<true>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb, 0);
-    else hipLaunchKernelGGL(k_ufb_events2<false>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb, clamp_rt);
+    if (fixed_bound) hipLaunchKernelGGL(k_ufb_events2<true>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb, 0, cut);
+    else hipLaunchKernelGGL(k_ufb_events2<false>, grid, block, 0, st, info, cost, thr, home, crow, C, Bp, B, rt, n_idx, best, ev, ev_cap, ev_count, pb, clamp_rt, cut);
     return hipGetLastError();
   }
   hipError_t e = launch_ufb_events(st, info, cost, thr, home, crow, C, Bp, B, rt, best, n_idx, cmin, pre, ev, ev_cap, ev_count, fixed_bound);

@@ -15,8 +15,9 @@ constexpr int kUfbRowTile = 512, kUfbColTile = 128;   // padding units of k_bitg
 hipError_t launch_join_masks(hipStream_t st, const Geometry &g, const uint32_t *vec, const EvOp *ops, int n_ops, uint32_t *masks);
 // C[rows_padded][Bp] = (accumulate ? C : 0) + mult * masks x Wt; rows_padded % kUfbRowTile == 0, Bp % kUfbColTile == 0
 // rowsel (optional, rows_padded entries): output row i multiplies mask row rowsel[i]
+// row_limit (optional, device word): row blocks that start at or behind *row_limit are skipped (their part of C is left as it is)
 hipError_t launch_bitgemm(hipStream_t st, const uint32_t *masks, int rows_padded, int Wp, const uint8_t *Wt, int Bp, int32_t *C,
-                          int mult, int accumulate, const uint32_t *rowsel = nullptr);
+                          int mult, int accumulate, const uint32_t *rowsel = nullptr, const uint32_t *row_limit = nullptr);
 hipError_t launch_colsum(hipStream_t st, const int32_t *C, int rows, int Bp, int32_t *rt);
 // rt += C[row] - C[home]
 hipError_t launch_rt_update(hipStream_t st, int32_t *rt, const int32_t *C, int Bp, uint32_t row, uint32_t home);
@@ -51,10 +52,14 @@ hipError_t launch_ufb_events_publish(hipStream_t st, const uint2 *info, const ui
                                      uint32_t n_idx, uint32_t *cmin, uint32_t *pre, UfbEvent *ev, uint32_t ev_cap, uint32_t *ev_count,
                                      int fixed_bound, const UfbPublishArgs &a,
                                      // 1: start every sample's running minimum at min(best[b], rt[b]) (see k_ufb_events2); only with n_idx <= kUfbEvents2Max
-                                     int clamp_rt = 0);
+                                     int clamp_rt = 0,
+                                     // device word: indices from *cut on are not looked at (only with n_idx <= kUfbEvents2Max)
+                                     const uint32_t *cut = nullptr);
 // launch_ufb_prep + publication of a.src/dst ranges behind a.h_flag[1] (the scan's results, in front of the product)
+// ... and *cut = the batch's certain end (see k_ufb_mid; also written to a.h_flag[2]): cost = the scan's output, home / plan_end per part
 hipError_t launch_ufb_mid(hipStream_t st, int32_t *C, size_t c_words, uint2 *info, const uint32_t *self_idx, uint32_t n_self, uint32_t code,
-                          uint32_t *ev_count, const UfbPublishArgs &a);
+                          uint32_t *ev_count, const UfbPublishArgs &a, const uint32_t *cost, const uint32_t *home, const uint32_t *plan_end,
+                          uint32_t n_idx, uint32_t *cut);
 // the row padding launch_bitgemm needs for this many rows (small products run on 128-row tiles)
 int ufb_row_padding(int rows, int Bp);
 

@@ -543,7 +543,8 @@ int Engine::ufb_stage_small(const std::vector<ScanPlan> &plans, int count)
       n_parts = std::max(n_parts, (uint32_t)pl.part_desc[pi] + 1u);
     }
   }
-  const size_t o_self = (size_t)2 * n_parts + (size_t)u.Bp, words = o_self + n_self;
+  // layout: thr[n_parts] | home[n_parts] | plan_end[n_parts] | best[Bp] | self[n_self]
+  const size_t o_self = (size_t)3 * n_parts + (size_t)u.Bp, words = o_self + n_self;
   UCHK(u.h_small.reserve(words + 4));
   uint32_t *sm = u.h_small.p;
   std::memset(sm, 0, words * sizeof(uint32_t));                 // (padding columns of best: 0 -> never an event)
@@ -551,13 +552,16 @@ int Engine::ufb_stage_small(const std::vector<ScanPlan> &plans, int count)
   for (int j = 0; j < count; j++) {
     const ScanPlan &pl = plans[(size_t)j];
     if (pl.self_idx >= 0) sm[at++] = (uint32_t)pl.self_idx;
+    uint32_t end = pl.self_idx >= 0 ? (uint32_t)pl.self_idx + 1u : 0u;     // end of this prune node's index range
+    for (int pi = 0; pi < pl.n_parts; pi++) end = std::max(end, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
     for (int pi = 0; pi < pl.n_parts; pi++) {
       const uint32_t d = (uint32_t)pl.part_desc[pi];
       sm[d] = UINT32_MAX;                                        // no cut-off in force: every candidate takes part
       sm[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
+      sm[2 * n_parts + d] = end;
     }
   }
-  for (int c2 = 0; c2 < u.Bl; c2++) sm[(size_t)2 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
+  for (int c2 = 0; c2 < u.Bl; c2++) sm[(size_t)3 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
   u.st_n_idx = n_idx; u.st_n_parts = n_parts; u.st_n_self = n_self; u.st_o_self = (uint32_t)o_self; u.st_words = (uint32_t)words;
   u.st_valid = true;
   u.st_dev = nullptr;
@@ -897,7 +901,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, (size_t)u.st_words * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
             dsm = u.thr.p;
           }
-          d_thr = dsm; d_home = dsm + n_parts; d_best = dsm + 2 * n_parts; d_self = dsm + u.st_o_self;
+          d_thr = dsm; d_home = dsm + n_parts; d_best = dsm + 3 * n_parts; d_self = dsm + u.st_o_self;      // (dsm + 2 n_parts: the parts' prune-node ends)
         } else {
         small.assign(o_cnt + 1, 0u);
         std::copy(self_list.begin(), self_list.end(), small.begin() + (long)o_self);
@@ -1404,7 +1408,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   // extraction kernel writes as it emits (a copy of "the rest" would queue up behind the next batch, which reuses the device buffer)
   if (u.ev.cap < (1u << 20)) UCHK(u.ev.reserve(1u << 20));
   for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
-  uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32;
+  uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32, *d_cut = d_done_.p + 56;
   bool log_open = false;
   // the deferred log of every batch goes to a second host thread (option ufb_thread): it owns the tracker's deferred state
   // (topology map, boot_trees, reference counts, stored topologies) for the length of this climb and works on copies of the
@@ -1560,7 +1564,8 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, (size_t)u.st_words * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
       dsm = u.thr.p;
     }
-    const uint32_t *d_thr = dsm, *d_home = dsm + B.n_parts, *d_best = dsm + 2 * B.n_parts, *d_self = dsm + u.st_o_self;
+    const uint32_t *d_thr = dsm, *d_home = dsm + B.n_parts, *d_pend = dsm + 2 * B.n_parts, *d_best = dsm + 3 * B.n_parts, *d_self = dsm + u.st_o_self;
+    const bool small_batch = B.n_idx <= kUfbEvents2Max;   // (the chunked kernels of a larger batch do not take the cut)
     UCHK(u.h_info.reserve(walk_async_nout_));
     UfbPublishArgs ps;                             // the scan's results
     if (cnt_copy_pending_) { ps.src[0] = d_cnt(); ps.dst[0] = h_cnt(); ps.words[0] = (uint32_t)(out_off() + walk_async_nout_); }
@@ -1572,9 +1577,10 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     ps.h_flag = u.p_flag_s[B.par].p;
     ps.done = d_fin;
     __atomic_store_n(u.p_flag_s[B.par].p + 1, 0u, __ATOMIC_RELAXED);
-    UCHK(launch_ufb_mid(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, d_self, B.n_self, host_self ? 0xFFFFFFFFu : 0xFFFFFFFEu, d_evcount, ps));
+    UCHK(launch_ufb_mid(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, d_self, B.n_self, host_self ? 0xFFFFFFFFu : 0xFFFFFFFEu, d_evcount, ps,
+                        d_out(), d_home, d_pend, B.n_idx, d_cut));
     for (int pl = 0; pl < u.planes; pl++)
-      UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), 1));
+      UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), 1, nullptr, small_batch ? d_cut : nullptr));
     u.gemm_rows += (uint64_t)rows_p;
     B.n_eager = (uint32_t)std::min<size_t>(u.p_ev[B.par].cap, 0xFFFFFFFFu);
     UfbPublishArgs pe;                             // the bookkeeping's inputs
@@ -1587,7 +1593,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     pe.done = d_fin;
     __atomic_store_n(u.p_flag_e[B.par].p + 1, 0u, __ATOMIC_RELAXED);
     UCHK(launch_ufb_events_publish(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, B.n_idx, u.cmin.p, u.pre.p,
-                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0, pe, (early && moved_once) ? 1 : 0));
+                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0, pe, (early && moved_once) ? 1 : 0, small_batch ? d_cut : nullptr));
     u.t_scan += now_ms() - t0;
     return MPF_OK;
   };
@@ -1734,6 +1740,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           }
         }
       }
+      if (B.device && u.p_flag_s[B.par].p[2] != idx_cut) { set_error("online UFBoot: the device's end of the batch differs from the host's"); return MPF_E_STATE; }
       {
         const UfbEvent *src = u.p_ev[B.par].p;
         if (u.exchange) {
