@@ -1455,11 +1455,11 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       spare.pop_back();
       return j;
     }
-    void submit(Job *j)
+    bool submit(Job *j)                            // false: no second thread to be had -- the caller works the job off itself
     {
       if (!started) {
+        try { th = std::thread([this] { run(); }); } catch (...) { return false; }
         started = true;
-        th = std::thread([this] { run(); });
         // keep the worker on the cores that share this thread's last-level cache (best effort): the log, the plans and the
         // topology copies change hands every batch, and on a two-socket host a worker on the other socket made the replay --
         // which then writes into lines the worker owns -- 2.4 times slower than it is alone
@@ -1491,6 +1491,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       }
       { std::lock_guard<std::mutex> lk(m); q.push_back(j); inflight++; }
       cv.notify_all();
+      return true;
     }
     void finish()
     {
@@ -1912,7 +1913,11 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         if (moved) { jb->back.swap(snap_back); jb->epoch = snap_epoch; }
         else { jb->back = back_; jb->epoch = topo_epoch_; }
         jb->plans = B.plans;
-        worker.submit(jb);
+        if (!worker.submit(jb)) {
+          ufb_drain(jb->log, jb->back, jb->epoch, jb->plans, worker.sc);
+          jb->log.clear();
+          worker.spare.push_back(jb);
+        }
       } else if (!u.log.empty()) {
         if (moved) { u.log_back.swap(snap_back); u.log_epoch = snap_epoch; }
         else { u.log_back = back_; u.log_epoch = topo_epoch_; }

@@ -9,5 +9,6 @@ rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/raw -- 
 tail -5 $OUT/out.txt
 python3 tools/batch_timeline.py $OUT/raw 0.5 70 > $OUT/timeline.txt 2>&1
 python3 tools/batch_timeline.py $OUT/raw 0.9 70 > $OUT/timeline_late.txt 2>&1
+python3 tools/batch_timeline.py $OUT/raw 0.985 70 > $OUT/timeline_end.txt 2>&1
 rm -rf $OUT/raw
 head -120 $OUT/timeline.txt
