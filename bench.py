@@ -935,6 +935,34 @@ def main():
                         cache2[t] = eng.ufboot_tree(t)
                     trees2.append(cache2[t])
                 online2 = -_l2
+                # a LATER search iteration, as a run repeats it hundreds of times: cut-off from the saved trees (top 10 %, iqtree.cpp:1662-1676),
+                # the best tree perturbed by 30 random SPR moves, one more climb with the bookkeeping (measured behind the captured state:
+                # the refinement below does not see it).  Every rank perturbs with the same generator.
+                it_leg = None
+                try:
+                    final_bb = eng.get_tree()
+                    cut_bb = eng.ufboot_next_cutoff(10)
+                    eng.ufboot_set_cutoff(cut_bb)
+                    pert = trees.random_spr_moves(eng, final_bb, np.random.default_rng(77), 30)
+                    eng.set_tree(pert)
+                    eng.reset_node_order()
+                    s_pert = eng.score_tree()
+                    eng.set_option("timing", 0)
+                    eng.reset_stats()
+                    barrier()
+                    t0i = time.perf_counter()
+                    s_it = eng.optimize_spr(1, args.maxtrav)
+                    barrier()
+                    t_it = time.perf_counter() - t0i
+                    eng.set_option("timing", 1)
+                    st_it = eng.stats()
+                    it_leg = {"seconds": t_it, "cutoff_length": -cut_bb, "perturbed_score": s_pert, "score": s_it, "moves": st_it["moves_applied"],
+                              "insertion_tests": st_it["insertion_tests"],
+                              "what": "one later search iteration of the same run: logl_cutoff = top 10 % of the saved trees, best tree perturbed by 30 "
+                                      "random SPR moves, SPR climb with saveCurrentTree bookkeeping under the cut-off (the two-wait path: with a cut-off "
+                                      "the product is compacted on the host between scan and product)"}
+                except Exception as exc:
+                    it_leg = {"error": repr(exc)}
                 eng.ufboot_detach()
                 barrier()
                 t0r = time.perf_counter()
@@ -946,7 +974,7 @@ def main():
                 nondeg["bb_flow"] = {"online_phase_s": t_bb, "score": s_bb, "moves": st_bb["moves_applied"], "insertion_tests": st_bb["insertion_tests"],
                                      "tests_per_s": st_bb["insertion_tests"] / t_bb, "events": cn_bb["events"], "tie_draws": cn_bb["tie_draws"],
                                      "reps_kernel_ms": cn_bb["reps_kernel_ms"] or None, "refined_samples": n_rep, "refinement_s": t_ref2,
-                                     "seconds": t_bb + t_ref2,
+                                     "seconds": t_bb + t_ref2, "later_iteration": it_leg,
                                      "mean_sample_score_online": float(np.mean(online2[:n_rep])) if n_rep else None,
                                      "mean_sample_score_refined": float(np.mean(bs2)) if n_rep else None,
                                      "samples_improved_by_refinement": int((bs2 < online2[:n_rep]).sum()) if n_rep else None}
