@@ -133,7 +133,18 @@ def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
             e.ufboot_set_distinct_iter(2)
             e.ufboot_set_iteration(1)
         s = e.optimize_spr(1, 6)
-        got.append((s, _observables(e, rule), e.get_option("ufb_early_batches"), e.get_option("ufb_batches")))
+        early1 = e.get_option("ufb_early_batches")
+        obs1 = _observables(e, rule)
+        # a later iteration: cut-off from the saved trees, another start tree (every way takes the two-wait loop there: the product
+        # is compacted on the host)
+        cut = e.ufboot_next_cutoff(10)
+        e.ufboot_set_cutoff(cut)
+        if rule == "distinct":
+            e.ufboot_set_iteration(2)
+        e.set_tree(np.array(fx["trees"][5]["back"], dtype=np.int32))
+        s2 = e.optimize_spr(1, 6)
+        got.append(((s, s2, cut), (obs1, _observables(e, rule)), early1, e.get_option("ufb_batches"), e.get_option("ufb_early_batches")))
+    assert got[0][0][2] != 0.0                      # (a cut-off was in force in the second climb)
     for g in got[1:]:
         assert got[0][:2] == g[:2]
     assert got[0][2] == 0 and got[1][2] == 0
