@@ -200,6 +200,46 @@ def test_a_failing_exchange_in_mid_climb_leaves_a_usable_engine(mods, opts):
     assert [x.tolist() for x in e.moves()] == [x.tolist() for x in f.moves()]
 
 
+def test_tracked_climb_with_the_hosts_own_random_stream(mods):
+    """mpf_set_rand_callback (a host whose stream cannot be handed over by state): every draw of the pipelined tracked climb --
+    the bookings' and the search's -- comes through the callback, in the reference's order.  A callback that runs the lcg64 of
+    the seeded engine must leave every observable as the seeded engine's, and be called exactly once per draw."""
+    import ctypes as C
+
+    from mpboot_amd.engine import load_library
+    engine, po = mods
+    fx = load_fixture("dna_48")
+    w = np.asarray(fx["weights"], dtype=np.float64)
+    samples = np.random.default_rng(9).multinomial(int(w.sum()), w / w.sum(), size=60).astype(np.uint16)
+    start = np.array(fx["trees"][2]["back"], dtype=np.int32)
+    a = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    a.set_tree(start)
+    a.seed_ties(engine.TIE_RANDOM, 41)
+    state0 = a.tie_state()
+    a.ufboot_attach(samples)
+    sa = a.optimize_spr(1, 6)
+    st = {"s": state0, "n": 0}
+
+    def draw(_arg):
+        st["s"] = (st["s"] * 0x27BB2EE687B0B0FD + 3037000493) & 0xFFFFFFFFFFFFFFFF
+        st["n"] += 1
+        return float(st["s"]) * 5.4210108624275222e-20
+
+    cb = C.CFUNCTYPE(C.c_double, C.c_void_p)(draw)
+    b = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    b.set_tree(start)
+    b.seed_ties(engine.TIE_RANDOM, 1)                # (the rule; its own stream is not used)
+    L = load_library()
+    L.mpf_set_rand_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.mpf_set_rand_callback(b.h, C.cast(cb, C.c_void_p), None) == 0
+    b.ufboot_attach(samples)
+    sb = b.optimize_spr(1, 6)
+    assert sa == sb
+    assert _observables(a, "default") == _observables(b, "default")
+    assert st["s"] == a.tie_state()                  # the callback's stream stands where the seeded engine's does
+    assert b.get_option("ufb_early_batches") > 0
+
+
 def test_cutoff_filter_and_next_cutoff(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
