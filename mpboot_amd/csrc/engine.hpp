@@ -134,6 +134,7 @@ struct UfbState {
   int32_t log_epoch = 0;
   std::vector<int32_t> log_bk;
   std::vector<double> inv;                       // inv[k] = 1.0 / (double)k, grown on demand (the very quotient the rule compares a draw with)
+  bool ids_identity = true;                      // local column c is sample c (an unsharded tracker): the bookings of eight samples at a time
   std::string log_key;
   double t_defer = 0;
   const std::vector<ScanPlan> *log_plans = nullptr;

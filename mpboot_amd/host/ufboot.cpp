@@ -22,6 +22,7 @@
 #include <sched.h>
 
 #include "../csrc/engine.hpp"
+#include "lcg_block.hpp"
 
 namespace mpf {
 
@@ -53,8 +54,10 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   if (n_local < 0) n_local = n_all;                        // unsharded: every sample is local, ids = identity
   u->Bl = n_local;
   u->ids.resize((size_t)n_local);
+  u->ids_identity = n_local == n_all;
   for (int c = 0; c < n_local; c++) {
     u->ids[(size_t)c] = sample_ids ? sample_ids[c] : c;
+    if (u->ids[(size_t)c] != c) u->ids_identity = false;
     if (u->ids[(size_t)c] < 0 || u->ids[(size_t)c] >= n_all) { set_error("ufboot_attach: sample id out of range"); return MPF_E_INVALID; }
   }
   u->exchange = exchange;
@@ -568,6 +571,26 @@ int Engine::ufb_stage_small(const std::vector<ScanPlan> &plans, int count)
   return MPF_OK;
 }
 
+// eight consecutive samples that ALL tie with the current tree (the rule of a move-less sweep: 2e6 such bookings at C3): their
+// draws in one vector step (lcg_block.hpp), thresholds gathered from the reciprocal table, counts + 1.  Returns the mask of the
+// accepted ones, or -1 with nothing touched when the eight are not all ties (or the table is too short): the caller takes them
+// one by one.
+__attribute__((target("avx512f,avx512dq,avx512vl,avx2"))) static int self_tie8(const int32_t *rt, const uint32_t *bs, int32_t *cnt, const double *inv,
+                                                                              size_t inv_n, uint64_t &state, const Lcg64Jump8 &jump)
+{
+  const __m256i r = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(rt));
+  const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(bs));
+  if (_mm256_cmpeq_epi32_mask(r, b) != 0xFF) return -1;
+  const __m256i k = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(cnt)), _mm256_set1_epi32(1));
+  if (inv_n > 0x7FFFFFFFu || _mm256_cmpgt_epi32_mask(k, _mm256_set1_epi32((int)inv_n - 1)) || _mm256_cmplt_epi32_mask(k, _mm256_set1_epi32(1))) return -1;
+  const __m512d thr = _mm512_i32gather_pd(k, inv, 8);
+  __m512d v;
+  state = lcg64_draw8(state, jump, &v);
+  const int acc = (int)_mm512_cmp_pd_mask(v, thr, _CMP_LE_OQ);
+  _mm256_storeu_si256(reinterpret_cast<__m256i *>(cnt), k);
+  return acc;
+}
+
 void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws)
 {
   UfbState &u = *ufb_;
@@ -578,7 +601,21 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
   if (inv.size() < 2) { inv.assign(2, 0.0); inv[1] = 1.0; }
   const bool callback = rand_fn_ != nullptr;
   uint64_t st = rng_.state, draws = 0;
+  static const Lcg64Jump8 jump;
+  const bool by_eight = !callback && u.ids_identity && lcg64_have_avx512();
   for (int c2 = 0; c2 < u.Bl; c2++) {
+    if (by_eight && c2 + 8 <= u.Bl) {
+      int acc = self_tie8(rt + c2, bsv + c2, cnt + c2, inv.data(), inv.size(), st, jump);
+      if (acc >= 0) {
+        draws += 8;
+        for (; acc; acc &= acc - 1) {
+          u.log.push_back(UfbState::LogEntry{(uint32_t)(c2 + __builtin_ctz((unsigned)acc)), 0xFFFFFFFFu, tree_index, cur_plan});
+          log_open = true;
+        }
+        c2 += 7;
+        continue;
+      }
+    }
     const uint32_t b = (uint32_t)ids[c2], s = (uint32_t)rt[c2], bs = bsv[b];
     if (s > bs) continue;
     bool accept = true;                                                 // rell > boot_logl + epsilon (:3686)
