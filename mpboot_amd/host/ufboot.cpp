@@ -1564,7 +1564,9 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
 
   // plan + enqueue the whole chain of the batch [i, i + b): refresh, masked scan, mid (C <- 0, self slots, scan results to the host),
   // product, extraction (events and R_T to the host)
-  auto launch = [&](Batch &B, int i, int b, bool early) -> int {
+  // (clamp: the current tree has been offered to every sample -- true once a move of this climb has been accepted --, so the
+  //  extraction may start every sample's bound at R_T when the bounds it was given are one replay old)
+  auto launch = [&](Batch &B, int i, int b, bool early, bool clamp) -> int {
     const double t0 = now_ms();
     B.i = i;
     B.hi = std::min(total, i + b - 1);
@@ -1631,7 +1633,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     pe.done = d_fin;
     __atomic_store_n(u.p_flag_e[B.par].p + 1, 0u, __ATOMIC_RELAXED);
     UCHK(launch_ufb_events_publish(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, B.n_idx, u.cmin.p, u.pre.p,
-                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0, pe, (early && moved_once) ? 1 : 0, small_batch ? d_cut : nullptr));
+                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0, pe, (early && clamp) ? 1 : 0, small_batch ? d_cut : nullptr));
     u.t_scan += now_ms() - t0;
     return MPF_OK;
   };
@@ -1685,7 +1687,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     int i = 1;
     while (i <= total) {
       Batch &B = ring[cur];
-      if (!prelaunched) { B.par = cur & 1; int rc = launch(B, i, batch, false); if (rc) return rc; }
+      if (!prelaunched) { B.par = cur & 1; int rc = launch(B, i, batch, false, false); if (rc) return rc; }
       prelaunched = false;
       double t0 = now_ms();
       const uint32_t *out = nullptr;
@@ -1723,10 +1725,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         if (next_i <= total) {
           const int nxt = (cur + 1) % 3;
           ring[nxt].par = B.par ^ 1;
-          const bool mo = moved_once;
-          if (d.moved) moved_once = true;
-          int rc = launch(ring[nxt], next_i, next_batch_size, true);
-          moved_once = mo;
+          int rc = launch(ring[nxt], next_i, next_batch_size, true, moved_once || d.moved);
           if (rc) return rc;
           prelaunched = true;
         }
