@@ -13,12 +13,13 @@ sys.path.insert(0, ROOT)
 from mpboot_amd import engine, synth, trees
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+BIG = os.environ.get("SOAK_BIG") == "1"       # 120-319 taxa, 100-399 samples: whole-sweep batches of tens of thousands of indices (the chunked extraction, the overflow rule)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 n_climb = n_ref = n_samples = n_trk = n_early = 0
 while time.time() < t_end:
     alpha = "AA" if rng.random() < 0.25 else "DNA"
-    n = int(rng.integers(5, 90))
+    n = int(rng.integers(5, 90)) if not BIG else int(rng.integers(120, 320))
     P = int(rng.integers(40, 2500 if n >= 10 else 120))      # (the generator tops up to P DISTINCT variable columns: few taxa, few patterns)
     letters, _ = synth.synth_alignment(n, P, alpha, float(rng.uniform(0.02, 0.3)), seed=int(rng.integers(1 << 30)))
     codes = synth.letters_to_codes(letters, alpha)
@@ -82,7 +83,7 @@ while time.time() < t_end:
         n_ref += 1
     # ---- tracked climb: the three ways through it
     if n >= 6:
-        B = int(rng.integers(2, 70))
+        B = int(rng.integers(2, 70)) if not BIG else int(rng.integers(100, 400))
         w0 = w if w is not None else np.ones(codes.shape[1], dtype=np.int32)
         nsite = int(w0.sum())
         sp = np.repeat(np.arange(len(w0)), w0)
