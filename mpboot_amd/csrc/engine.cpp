@@ -2024,6 +2024,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_thread") { ufb_thread_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_event_cap") { if (v < 16 || v > (1ll << 28)) { set_error("ufb_event_cap: 16 .. 2^28"); return MPF_E_INVALID; } ufb_event_cap_ = v; return MPF_OK; }
   if (key == "plan_cache") { plan_cache_ = v ? 7 : 0; sched_cache_valid_ = false; sweep_cache_valid_ = false; return MPF_OK; }
   if (key == "split_below") { split_below_ = (int)v; return MPF_OK; }
   if (key == "split_cands") { split_cands_ = v < 0 ? 0 : (int)v; return MPF_OK; }
@@ -2104,6 +2105,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "ufb_pipe") *v = ufb_pipe_;
   else if (key == "ufb_thread") *v = ufb_thread_;
+  else if (key == "ufb_event_cap") *v = ufb_event_cap_;
   else if (key == "ufb_batches") *v = ufb_stat_batches_;
   else if (key == "ufb_early_batches") *v = ufb_stat_early_;
   else if (key == "force_big") *v = force_big_;

@@ -409,6 +409,7 @@ class Engine {
   void ufb_drain(const std::vector<UfbState::LogEntry> &log, const std::vector<int32_t> &bk, int32_t epoch, const std::vector<ScanPlan> &plans,
                  DrainScratch &sc);
   DrainScratch drain_scratch_;
+  int64_t ufb_event_cap_ = 1 << 20;              // option "ufb_event_cap" (tests): first size of the event buffers -- small values exercise the overflow paths
   int ufb_thread_ = 1;                           // option "ufb_thread": the pipelined climb works its log off on a second host thread
   // chained batches: thr | home | best | self list of the batch's plans into UfbState::h_small (the staging block the extraction
   // kernel reads), so that it can go up with the refresh's own upload

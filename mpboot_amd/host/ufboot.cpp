@@ -926,7 +926,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         const uint32_t nch = ufb_chunks(n_idx);
         UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
         UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
-        if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
+        if (u.ev.cap == 0) { const size_t c0 = (size_t)std::min<int64_t>(ufb_event_cap_, 1 << 18); UCHK(u.ev.reserve(c0)); UCHK(u.h_ev.reserve(c0)); }
         const uint32_t *d_thr = nullptr, *d_home = nullptr, *d_best = nullptr, *d_crow = nullptr, *d_sel = nullptr, *d_self = nullptr;
         if (chained) {
           // the staging block normally went up with the refresh's own upload (Engine::scan_batch); a batch on valid views has none
@@ -1443,7 +1443,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   }
   // every event a batch can produce while the next one may already be in flight fits the device buffer AND the pinned one the
   // extraction kernel writes as it emits (a copy of "the rest" would queue up behind the next batch, which reuses the device buffer)
-  if (u.ev.cap < (1u << 20)) UCHK(u.ev.reserve(1u << 20));
+  if (u.ev.cap < (size_t)ufb_event_cap_) UCHK(u.ev.reserve((size_t)ufb_event_cap_));
   for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
   uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32, *d_cut = d_done_.p + 56;
   bool log_open = false;
@@ -1743,9 +1743,12 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           UCHK(u.ev.reserve((size_t)n_ev));
           const uint32_t *dsm = u.st_dev ? u.st_dev : u.thr.p;
           UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
-          UCHK(launch_ufb_events(st_, u.info.p, d_out(), dsm, dsm + B.n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, dsm + 2 * B.n_parts, B.n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));
+          UCHK(launch_ufb_events(st_, u.info.p, d_out(), dsm, dsm + B.n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, dsm + 3 * B.n_parts, B.n_idx, u.cmin.p, u.pre.p,
+                                 u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));      // (staging: thr | home | prune-node ends | best)
           B.n_eager = 0;
+          // (nothing else is in flight: both pinned buffers follow the device buffer, which the overflow rule is stated in)
+          UCHK(hipStreamSynchronize(st_));
+          for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
         }
         if (n_ev > B.n_eager) {
           if (prelaunched) { set_error("online UFBoot: events beyond the pinned buffer behind a batch launched early"); return MPF_E_STATE; }

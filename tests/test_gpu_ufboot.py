@@ -240,6 +240,31 @@ def test_tracked_climb_with_the_hosts_own_random_stream(mods):
     assert b.get_option("ufb_early_batches") > 0
 
 
+@pytest.mark.parametrize("opts", [{}, {"ufb_pipe": 0}])
+def test_event_buffers_that_overflow_are_grown_and_extracted_again(mods, opts):
+    """option ufb_event_cap (tests): event buffers that start at 16 entries -- every batch overflows until they have grown, the
+    pipelined climb may not launch a successor early behind a batch that could overflow, and the second extraction must find
+    the staging block where the first one did.  Same observables as with the default buffers."""
+    engine, po = mods
+    fx = load_fixture("dna_48")
+    w = np.asarray(fx["weights"], dtype=np.float64)
+    samples = np.random.default_rng(3).multinomial(int(w.sum()), w / w.sum(), size=90).astype(np.uint16)
+    start = np.array(fx["trees"][4]["back"], dtype=np.int32)
+    got = []
+    for cap in (16, None):
+        e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+        for k, v in opts.items():
+            e.set_option(k, v)
+        if cap:
+            e.set_option("ufb_event_cap", cap)
+        e.set_tree(start)
+        e.seed_ties(engine.TIE_RANDOM, 13)
+        e.ufboot_attach(samples)
+        s = e.optimize_spr(1, 6)
+        got.append((s, _observables(e, "default")))
+    assert got[0] == got[1]
+
+
 def test_cutoff_filter_and_next_cutoff(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
