@@ -265,6 +265,44 @@ def test_event_buffers_that_overflow_are_grown_and_extracted_again(mods, opts):
     assert got[0] == got[1]
 
 
+@pytest.mark.parametrize("n,radius", [(5, 1), (5, 6), (6, 1), (9, 2)])
+def test_tiny_trees_on_a_sharded_tracker_take_the_same_books_every_way(mods, n, radius):
+    """trees so small that whole batches have no insertion test at all (five taxa at radius 1): the current tree is still booked
+    at every prune-node visit, and on a sharded tracker those bookings travel as events.  One rank of two with the other one
+    silent (an exchange that returns what it was given): the pipelined climb, the one-chain loop and the two-wait loop must
+    keep the same books."""
+    import ctypes as C
+
+    from mpboot_amd import shard, synth, trees
+    engine, po = mods
+    letters, _ = synth.synth_alignment(n, 80, "DNA", 0.25, seed=100 + n)
+    codes = synth.letters_to_codes(letters, "DNA")
+    P = codes.shape[1]
+    samples = np.random.default_rng(n).multinomial(P, np.ones(P) / P, size=11).astype(np.uint16)
+    start = trees.random_topology(n, np.random.default_rng(7))
+    got = []
+    for opts in ({"ufb_fast": 0}, {"ufb_pipe": 0}, {}):
+        keep = {}
+
+        def fn(_arg, tag, local_ptr, n_local, all_ptr, n_all_ptr):
+            buf = np.ctypeslib.as_array(C.cast(local_ptr, C.POINTER(C.c_uint32)), shape=(n_local, 3)).copy() if n_local else np.zeros((0, 3), dtype=np.uint32)
+            keep["buf"] = buf
+            all_ptr[0] = buf.ctypes.data if n_local else None
+            n_all_ptr[0] = n_local
+            return 0
+
+        cb = shard.EXCHANGE_FN(fn)
+        e = engine.FitchEngine(codes, datatype=engine.DNA)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_tree(start)
+        e.seed_ties(engine.TIE_RANDOM, 5)
+        e.ufboot_attach(samples, 0.5, shard=(0, 2), exchange=cb)
+        s = e.optimize_spr(1, radius)
+        got.append((s, _observables(e, "default")))
+    assert got[0] == got[1] and got[0] == got[2]
+
+
 def test_cutoff_filter_and_next_cutoff(mods):
     engine, po = mods
     fx = load_fixture("dna_clean")
