@@ -104,8 +104,16 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
 
     local, trees = {}, {}
     todo = units
+    # every engine is handed back under the weights it came with: one() leaves an engine on the last sample it climbed for, and
+    # the batched block multiplies the samples against the packing in force on engine 0 -- a pattern at weight 0 there would
+    # silently drop out of every sample's product
+    held = [e.weights() if hasattr(e, "weights") else None for e in engines]
+    touched = set()
     if batched and units:
         e0 = engines[0]
+        if held[0] is not None and ((held[0] == 0) & (samples[units].max(axis=0) > 0)).any():
+            raise ValueError("refine_boot_trees: engine 0 holds weights that leave a pattern some sample counts without a site -- "
+                             "it must hold the weights the samples were drawn from (set_weights(original) first)")
         if not attached:
             e0.ufboot_attach(samples, 0.5, shard=(rank, ws))
         e0.seed_ties(1, 0)
@@ -129,16 +137,22 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
         todo.sort()
     if len(engines) == 1:
         for b in todo:
+            touched.add(0)
             local[b], trees[b] = one(engines[0], b)
     elif todo:
         from concurrent.futures import ThreadPoolExecutor
 
         def work(k):
+            if todo[k::len(engines)]:
+                touched.add(k)
             return {b: one(engines[k], b) for b in todo[k::len(engines)]}
 
         with ThreadPoolExecutor(len(engines)) as ex:
             for part in ex.map(work, range(len(engines))):
                 for b, (sc, t) in part.items():
                     local[b], trees[b] = sc, t
+    for k in sorted(touched):
+        if held[k] is not None:
+            engines[k].set_weights(held[k])
     scores, _best, _owner = shard.reduce_best(local, B)
     return scores, trees

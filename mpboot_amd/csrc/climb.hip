@@ -949,10 +949,20 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
   int32_t ins = sh.ins, rem = sh.rem;
   const bool rnd = P.tie_mode == (uint32_t)MPF_TIE_RANDOM;
   const uint32_t Beff = sh.Beff;
-  bool moved = false;
+  bool moved = false, cut = false;
+  const uint32_t stop_len = P.stop_len;
   uint32_t j = 0;
   for (; j < Beff && !moved; j++) {
     const uint32_t off = sh.pn_off[j], nt = sh.pn_cnt[j], np = sh.pn_np[j], pcid = sh.pn_p[j];
+    if (stop_len) {
+      // a tree the tracker would have to book: hand back in front of this prune node, nothing of it consumed
+      unsigned long long any = 0ull;
+      for (uint32_t base = 0; base < nt; base += 64u) {
+        const uint32_t ci = base + (uint32_t)lane;
+        any |= __ballot((int)((ci < nt ? K.cost[off + ci] : 0xFFFFFFFFu) <= stop_len));
+      }
+      if (any) { cut = true; break; }
+    }
     tests += nt;
     if (rnd) { ins = rem = -1; hits = 1; }
     int32_t sel = -1;
@@ -1057,7 +1067,8 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     if (pos > P.total) reason = CLIMB_SWEEP_END;
     else if (n_moves >= P.max_moves || sh.epoch > kEpochLimit) reason = CLIMB_MOVES_FULL;
     else if (P.idle_limit && since >= P.idle_limit) reason = CLIMB_IDLE;
-    if (consumed == 0u || sh.steps > 4u * P.total + 16u) sh.err = sh.err ? sh.err : 7u;
+    if (cut) reason = CLIMB_CUTOFF;
+    if ((consumed == 0u && !cut) || sh.steps > 4u * P.total + 16u) sh.err = sh.err ? sh.err : 7u;
     if (sh.err) reason = CLIMB_ERROR;
     sh.exit_reason = reason;
   }

@@ -27,7 +27,8 @@ enum ClimbReason : uint32_t {
   CLIMB_IDLE = 2,          // no move for idle_limit prune nodes: the host's whole-chip batches are the better tool
   CLIMB_MOVES_FULL = 3,    // the move list is full
   CLIMB_ABORT = 4,         // the workgroups did not all become resident in time: nothing was changed
-  CLIMB_ERROR = 5          // an internal bound was hit (hdr.err says which); state is not to be trusted
+  CLIMB_ERROR = 5,         // an internal bound was hit (hdr.err says which); state is not to be trusted
+  CLIMB_CUTOFF = 6         // stop_len: the prune node at hdr.pos has an insertion test no longer than that -- not visited, no draw taken for it
 };
 
 // search state handed over in both directions + counters + the launch's synchronisation words
@@ -69,6 +70,10 @@ struct ClimbParams {
   // tests only (engine option "climb_fault"): 0 = none; 0xFFFFFFFF = the start barrier decides "abort"; k = in the exchange of
   // step k the last workgroup withholds its sums, so that the others run into their time-out (recovery paths of climb_host.cpp)
   uint32_t fault;
+  // 0 = none.  Otherwise the launch ends IN FRONT of the first prune node one of whose insertion tests gives a tree of at most
+  // this length (CLIMB_CUTOFF): with -bb and a logl_cutoff in force such a tree is the first one IQTree::saveCurrentTree would
+  // book (iqtree.cpp:3343) -- up to there the climb is the plain one, from there on the host's tracked path takes over
+  uint32_t stop_len;
 };
 
 constexpr uint32_t kClimbCap = 1024;      // candidates per step

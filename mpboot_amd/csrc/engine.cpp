@@ -2022,6 +2022,8 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "views_mode") { views_mode_ = v < 0 ? 0 : v > 2 ? 2 : (int)v; sched_cache_valid_ = false; return MPF_OK; }
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_quiet") { ufb_quiet_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_cut_batch") { ufb_cut_batch_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 20)); return MPF_OK; }
   if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_thread") { ufb_thread_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_event_cap") { if (v < 16 || v > (1ll << 28)) { set_error("ufb_event_cap: 16 .. 2^28"); return MPF_E_INVALID; } ufb_event_cap_ = v; return MPF_OK; }
@@ -2103,6 +2105,9 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "chain_max_ops") *v = chain_max_ops_;
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
+  else if (key == "ufb_quiet") *v = ufb_quiet_;
+  else if (key == "ufb_cut_batch") *v = ufb_cut_batch_;
+  else if (key == "ufb_quiet_climbs") *v = ufb_stat_quiet_;
   else if (key == "ufb_pipe") *v = ufb_pipe_;
   else if (key == "ufb_thread") *v = ufb_thread_;
   else if (key == "ufb_event_cap") *v = ufb_event_cap_;

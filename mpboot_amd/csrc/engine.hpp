@@ -358,6 +358,11 @@ class Engine {
   int pack();                                   // compressDNA on the device
   void add_traverse(int q, int sib, int depth, int mintrav, int maxtrav, ScanPlan &plan);
   int spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
+  // where a sweep loop stands: handed from the plain loop to the tracked one when a climb under a logl_cutoff reaches the trees the
+  // tracker books (host/search.cpp: spr_sweeps_run)
+  struct SweepCursor { uint32_t startMP = 0, randomMP = 0; unsigned iter_hits = 1; int i = 1; bool stopped = false; };
+  int spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t stop_len);
+  uint32_t climb_stop_len_ = 0;                  // ClimbParams::stop_len of the next k_climb launch
   int spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score);
   int nv_waves_ = -1;                            // option "views_waves" (see Engine::set_option)
@@ -385,6 +390,9 @@ class Engine {
   size_t walk_async_nd_ = 0, walk_async_nout_ = 0;
   int64_t ufb_stat_batches_ = 0, ufb_stat_early_ = 0;   // read-only options ufb_batches / ufb_early_batches: batches of the tracker's climbs since the engine was made, and how many of them were decided from the costs
   int ufb_pipe_ = 1;                             // option "ufb_pipe": the search's decision from the costs alone where they settle it, the next batch launched beside the bookkeeping of this one
+  int ufb_cut_batch_ = 128;                      // option "ufb_cut_batch": smallest batch (prune nodes) of a tracked climb under a logl_cutoff
+  int ufb_quiet_ = 1;                            // option "ufb_quiet": a climb under a logl_cutoff runs as the plain one until it reaches the trees the tracker books
+  int64_t ufb_stat_quiet_ = 0;                   // read-only option ufb_quiet_climbs: tracked climbs that began with a quiet stretch
   int ufb_fast_ = 1;                             // option "ufb_fast": one dispatch chain and one wait per batch of the tracker's climbs
   uint32_t ufb_rows_ = 0;                        // rows (scan output indices) of the last masked scan
   int ufb_reserve_scan(size_t n_idx);

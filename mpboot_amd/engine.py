@@ -249,6 +249,7 @@ class FitchEngine:
         if weights is None:
             weights = np.ones(self.P, dtype=np.int32)
         weights = np.ascontiguousarray(weights, dtype=np.int32)
+        self._weights = weights.copy()           # the pattern weights in force (mpf_set_weights keeps it in step)
         cfg = Config(device, self.n, self.P, datatype, int(keep_all))
         h = C.c_void_p()
         if cost is None:
@@ -281,7 +282,12 @@ class FitchEngine:
     def set_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.int32)
         _chk(load_library().mpf_set_weights(self.h, _p(w)))
+        self._weights = w.copy()
         self._refresh_geometry()
+
+    def weights(self):
+        """The pattern weights in force (a copy)."""
+        return self._weights.copy()
 
     def informative(self):
         f = np.zeros(self.P, dtype=np.int32)

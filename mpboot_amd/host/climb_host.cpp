@@ -135,6 +135,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   p.beat = nullptr;
   p.fault = (uint32_t)climb_fault_;
   climb_fault_ = 0;                                  // (one launch)
+  p.stop_len = climb_stop_len_;
   if (climb_trace_) {
     HIPCHK(cd_.h_beat.reserve(32));
     std::memset(cd_.h_beat.p, 0, 32 * sizeof(uint32_t));

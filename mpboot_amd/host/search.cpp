@@ -37,8 +37,28 @@ void Engine::apply_move(int p, int q)
 // _pllMakeParsimonyTreeFast (:3185-3206); MPF_TIE_FIRST follows pllrepo/src/fastDNAparsimony.c:1919-1938
 int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
 {
-  uint32_t startMP;
+  SweepCursor c;
+  c.randomMP = randomMP;
+  int rc = spr_sweeps_run(mintrav, maxtrav, c, 0u);
+  if (rc) return rc;
+  if (final_score) *final_score = c.randomMP;
+  return MPF_OK;
+}
+
+// The same loop with a way out (stop_len != 0): it returns IN FRONT of the first prune-node visit that would test a tree of at
+// most stop_len -- or at once when the current tree is that short --, nothing of that visit consumed (c.stopped, c.i = its index
+// in the sweep under way, c.startMP / c.iter_hits the sweep's state).  With -bb and a logl_cutoff in force, trees above the
+// cut-off never reach IQTree::saveCurrentTree's bookkeeping (iqtree.cpp:3343): up to that visit the tracked climb IS the plain one
+// (Engine::spr_sweeps_ufboot takes over from there).
+int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t stop_len)
+{
+  uint32_t startMP, randomMP = cur.randomMP;
   unsigned iter_hits = 1;                         // bestIterationScoreHits
+  cur.stopped = false;
+  auto stop_at = [&](int i, uint32_t start_mp) {
+    cur.stopped = true; cur.i = i; cur.startMP = start_mp; cur.randomMP = randomMP; cur.iter_hits = iter_hits;
+    return MPF_OK;
+  };
   const int total = 2 * n_ - 2;
   // (the engine's own plan storage: a whole-sweep batch on a topology whose sweep is still planned -- the closing sweep of
   //  the previous climb, the same tree under other weights -- reuses descriptors and device program, Engine::scan_batch)
@@ -66,10 +86,13 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
     first_sweep = false;
     sweep_moves = 0;
     while (i <= total) {
+      if (stop_len && randomMP <= stop_len) return stop_at(i, startMP);     // the current tree itself is booked from here on
       if (dev) {
         uint32_t reason = 0, nm = 0;
         const int i0 = i;
+        climb_stop_len_ = stop_len;
         int rc = climb_segment(mt_eff, total, &i, &randomMP, &iter_hits, climb_device_ < 2, &reason, &nm);
+        climb_stop_len_ = 0;
         if (rc) return rc;
         // (not resident in time -- somebody else holds the chip: the rest of this climb runs as host-driven batches; trying again
         //  behind every move would cost a 30 ms time-out each)
@@ -83,6 +106,7 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
           since_move_ += i - i0;
         }
         if (reason == CLIMB_IDLE) { dev = false; batch = std::min(total, std::max(batch, 64)); }
+        if (reason == CLIMB_CUTOFF) return stop_at(i, startMP);
         continue;
       }
       const int hi = std::min(total, i + batch - 1);
@@ -90,8 +114,19 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
       if (rc) return rc;
       bool moved = false;
       int j = i;
+      bool cut = false;
       for (; j <= hi && !moved; j++) {
         const ScanPlan &pl = plans[(size_t)(j - i)];
+        if (stop_len && stop_len >= pl.base) {
+          // (a visit with an insertion test the tracker would book: hand back in front of it)
+          if (pl.walked) {
+            for (int part = 0; part < pl.n_parts && !cut; part++)
+              cut = first_le(out + pl.part_off[part], 0, pl.part_cnt[part], stop_len - pl.base) < pl.part_cnt[part];
+          } else {
+            for (size_t c = 0; c < (size_t)pl.n_total && !cut; c++) cut = pl.base + pl.cost(c, out) <= stop_len;
+          }
+          if (cut) break;
+        }
         if (tie_mode_ == MPF_TIE_RANDOM) {
           insert_rec_ = remove_rec_ = -1;
           hits_ = 1;
@@ -147,12 +182,14 @@ int Engine::spr_sweeps(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *fi
       }
       batch = next_batch(batch, moved, j - i, total);
       i = j;
+      if (cut) return stop_at(i, startMP);
       // moves have become dense again behind a quiet stretch: the rest of the sweep goes back to the kernel
       if (moved && dev_ok && gap_est_ >= 0 && gap_est_ < 24.0 && i <= total) dev = true;
     }
   } while (randomMP < startMP);
   climb_finished(total);
-  if (final_score) *final_score = randomMP;
+  cur.randomMP = randomMP;
+  cur.iter_hits = iter_hits;
   return MPF_OK;
 }
 

@@ -33,6 +33,7 @@ namespace mpf {
   } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static bool ufb_trace_env() { static const bool on = std::getenv("MPF_UFB_TRACE") != nullptr; return on; }
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local, const int32_t *sample_ids,
@@ -756,9 +757,54 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   if (ufb_fast_ && ufb_pipe_ && !u.ratchet && !u.store_trees && !u.mulhits && !u.distinct && !u.topboot && u.logl_cutoff == 0.0 &&
       host_poll_ && !timing_ && !check_counts_)
     return spr_sweeps_ufboot_pipe(mintrav, maxtrav, randomMP, final_score);
-  uint32_t startMP;
+  uint32_t startMP = randomMP;
   unsigned iter_hits = 1;
   const int total = 2 * n_ - 2;
+  // ---- the quiet stretch of a climb under a cut-off.  Nothing above the cut-off reaches the bookkeeping (iqtree.cpp:3343: the
+  // filter sits in front of everything saveCurrentTree does, and without -storetrees nothing else looks at such a tree), so as
+  // long as neither the current tree nor any insertion test of the visit at hand gives a tree of at most the largest admissible
+  // length, the tracked climb IS the plain one -- same draws, same moves -- and runs as one: in k_climb while moves are dense,
+  // as whole-chip cost-only batches otherwise (Engine::spr_sweeps_run).  That is most of a later search iteration: the
+  // perturbed tree starts far above the cut-off (top 10 % of the saved trees) and climbs back towards it.  The first visit
+  // with an admissible insertion test moves to that tree for certain (it is strictly shorter than the current one), and from
+  // there on every visit books the current tree: one hand-over per climb, in front of that visit.
+  // Re-weighted (ratchet) climbs are filtered by the length booked LAST (iqtree.cpp:3283-3295): if the start tree's length on the
+  // original alignment fails the cut-off, the first booking closes the gate and nothing of the climb is booked at all.
+  int resume_i = 0;                                // > 0: the sweep under way continues at this visit (startMP, iter_hits as handed over)
+  if (ufb_quiet_ && u.logl_cutoff != 0.0 && !u.store_trees && !u.snk) {
+    const double lim0 = -u.logl_cutoff + 1e-4;
+    const uint32_t mp_max0 = lim0 <= 0.0 ? 0u : (uint32_t)std::ceil(lim0) - 1u;
+    bool whole = lim0 <= 0.0;                      // nothing can pass
+    if (u.ratchet && !whole) {
+      if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
+      UCHK(u.h_col.reserve(4));
+      UCHK(hipMemcpyAsync(u.h_col.p, u.rt.p + u.Bl, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+      UCHK(hipStreamSynchronize(st_));
+      u.rt_orig = (uint32_t)u.h_col.p[0];
+      whole = u.rt_orig > mp_max0;
+    }
+    if (whole || !u.ratchet) {
+      SweepCursor c;
+      c.randomMP = randomMP;
+      // (the batch policy remembers the move-less sweeps the climb before ended with; this one starts from a perturbed tree, far
+      //  above the cut-off: moves are dense again -- start as an engine without a history does, in the persistent kernel)
+      gap_est_ = -1.0;
+      since_move_ = 0;
+      int rc = spr_sweeps_run(mintrav, maxtrav, c, whole ? 0u : mp_max0);
+      if (rc) return rc;
+      u.rt_valid = false;                          // (R_T is not carried through the stretch: made from scratch at the hand-over)
+      ufb_stat_quiet_++;
+      if (u.ratchet) { u.stale_len = u.rt_orig; u.gate_closed = true; }
+      if (!c.stopped) {
+        if (final_score) *final_score = c.randomMP;
+        return MPF_OK;
+      }
+      randomMP = c.randomMP;
+      startMP = c.startMP;
+      iter_hits = c.iter_hits;
+      resume_i = c.i;
+    }
+  }
   // (an early return may leave a chained batch in flight: wait for it and start over from the topology, as the pipelined climb does)
   struct Abort {
     Engine *e;
@@ -785,7 +831,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     gap_est_ = -1.0;
     since_move_ = 0;
   }
-  int batch = first_batch();
+  // (under a cut-off every batch is two waits -- the product is compacted between them -- and the moves that are left lie hundreds of
+  //  prune nodes apart: a batch that restarts at a handful of prune nodes behind every move pays the waits six times over)
+  const int batch_floor = (u.logl_cutoff != 0.0 && !u.exchange) ? std::min(total, ufb_cut_batch_) : 1;
+  int batch = std::max(first_batch(), batch_floor);
   std::vector<UfbEvent> events, ev_tmp;
   std::vector<uint32_t> ev_count;
   std::vector<uint32_t> small, sel_rows, crow, self_list;
@@ -820,12 +869,13 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   }
   std::vector<int32_t> lcol;                       // ratchet: the original-frequency column of the product, per mask row
   do {
-    startMP = randomMP;
-    node_rectifier();
     int i = 1;
+    if (resume_i > 0) { i = resume_i; resume_i = 0; }          // (the sweep the quiet stretch handed over: order and startMP stand)
+    else { startMP = randomMP; node_rectifier(); }
     while (i <= total) {
       const int hi = std::min(total, i + batch - 1);
       double t0 = now_ms();
+      const double tr_scan0 = u.t_scan, tr_dev0 = u.t_dev;      // (MPF_UFB_TRACE=1: one line per batch)
       ufb_stat_batches_++;
       plans_cur ^= 1;
       std::vector<ScanPlan> &plans = plans_buf[plans_cur];
@@ -1152,6 +1202,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         events.clear();
       }
       t0 = now_ms();
+      const double tr_t0 = t0;
       // ---- host replay in the reference's order
       size_t ep = 0;
       bool moved = false;
@@ -1376,7 +1427,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         }
       }
       if (!moved && !u.log.empty()) { u.log_back = back_; u.log_epoch = topo_epoch_; u.log_plans = &plans; }
-      batch = next_batch(batch, moved, j - i, total);
+      if (ufb_trace_env())
+        std::fprintf(stderr, "[ufb-batch] i %d np %d used %d n_idx %u rows %u events %u moved %d len %u mp_max %u | last scan %.3f dev %.3f replay %.3f ms\n", i, np, j - i, n_idx,
+                     n_rows, n_ev, (int)moved, randomMP, mp_max, u.t_scan - tr_scan0, u.t_dev - tr_dev0, now_ms() - tr_t0);
+      batch = std::max(next_batch(batch, moved, j - i, total), batch_floor);
       i = j;
       u.t_replay += now_ms() - t0;
     }

@@ -1,0 +1,90 @@
+"""A -bb run as the search repeats it (iqtree.cpp:1631-1965): one tracked climb, then later iterations under the percentile cut-off
+(:1662-1676) from perturbed trees, every other one a ratchet iteration (climb on the re-weighted alignment, then on the original
+one) -- engine against the oracle on every observable after every climb.  The later climbs begin far above the cut-off, where
+nothing reaches saveCurrentTree's bookkeeping (:3343): the engine runs that stretch as the plain climb (k_climb / cost-only
+batches, Engine::spr_sweeps_run) and hands over to the tracked loop in front of the first admissible insertion test."""
+import numpy as np
+import pytest
+
+from helpers import same_topology
+
+pytestmark = pytest.mark.gpu
+
+
+def _perturb(trees, eng, back, rng, k, maxtrav):
+    return trees.random_spr_moves(eng, back, rng, k, maxtrav)
+
+
+def _same(e, o):
+    em, om = [x.tolist() for x in e.moves()], [x.tolist() for x in o.get_moves()]
+    assert em == [x[len(x) - len(em[0]):] for x in om]           # (the oracle's trace runs on over its climbs)
+    assert (e.get_tree() == o.get_tree()).all()
+    assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+    le, ce, te = e.ufboot_state()
+    lo, co, to = o.ufboot_state()
+    assert le.tolist() == lo.tolist() and ce.tolist() == co.tolist() and te.tolist() == to.tolist()
+    assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+    assert e.tie_state() == o.tie_state()
+    assert o.ufboot_bad() == 0
+    for t in sorted(set(te.tolist())):
+        if t >= 0:
+            assert same_topology(e.ufboot_tree(t), o.ufboot_tree(t), e.n)
+
+
+@pytest.mark.parametrize("rule", ["default", "mulhits"])
+@pytest.mark.parametrize("n,P,alphabet,maxtrav", [(40, 1500, "DNA", 6), (64, 2500, "DNA", 4), (30, 600, "AA", 6)])
+def test_later_iterations_under_the_cutoff_match_the_oracle(n, P, alphabet, maxtrav, rule):
+    from mpboot_amd import engine, synth, trees
+    from oracle import pyoracle as po
+    letters, _ = synth.synth_alignment(n, P, alphabet, 0.07, seed=n + P)
+    codes = synth.letters_to_codes(letters, alphabet)
+    dt_e, dt_o = (engine.DNA, po.DNA) if alphabet == "DNA" else (engine.AA, po.AA)
+    e = engine.FitchEngine(codes, datatype=dt_e)
+    o = po.Oracle(codes, datatype=dt_o)
+    rng = np.random.default_rng(3)
+    samples = rng.multinomial(P, np.ones(P) / P, size=60).astype(np.uint16)
+    start = trees.random_topology(n, np.random.default_rng(8))
+    w0 = np.ones(P, dtype=np.int32)
+    o.trace(True)
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.set_tree(start)
+        x.seed_ties(mode, 21)
+        x.ufboot_attach(samples)
+        if rule == "mulhits":
+            x.ufboot_set_mulhits(True)
+    best_s = e.optimize_spr(1, maxtrav)
+    assert o.optimize_spr(1, maxtrav) == best_s
+    _same(e, o)
+    best = e.get_tree()
+    scratch = engine.FitchEngine(codes, datatype=dt_e)          # (the perturbation's own scans must not touch the tracked engine)
+    quiet_before = e.get_option("ufb_quiet_climbs")
+    launches_before = e.stats()["climb_launches"]
+    for it in range(7):
+        cut = e.ufboot_next_cutoff(10)
+        assert cut == o.ufboot_next_cutoff(10)
+        e.ufboot_set_cutoff(cut)
+        o.ufboot_set_cutoff(cut)
+        pert = _perturb(trees, scratch, best, rng, 8 if it % 3 else 2, maxtrav)
+        if it % 2 == 1:
+            # ratchet iteration (createPerturbAlignment, alignment.cpp:1915-1969): a climb on re-weighted patterns first
+            w = w0.copy()
+            w[rng.random(P) < 0.5] += 1
+            for x in (e, o):
+                x.set_weights(w)
+                x.set_tree(pert)
+            s1 = e.optimize_spr(1, maxtrav)
+            assert o.optimize_spr(1, maxtrav) == s1
+            _same(e, o)
+            pert = e.get_tree()
+            for x in (e, o):
+                x.set_weights(w0)
+        for x in (e, o):
+            x.set_tree(pert)
+        s = e.optimize_spr(1, maxtrav)
+        assert o.optimize_spr(1, maxtrav) == s
+        _same(e, o)
+        if s <= best_s:
+            best_s, best = s, e.get_tree()
+    # the later climbs began as plain ones, and the dense stretches ran in the persistent kernel
+    assert e.get_option("ufb_quiet_climbs") - quiet_before >= 7
+    assert e.stats()["climb_launches"] > launches_before

@@ -112,6 +112,18 @@ def test_refine_sweep_on_a_decisive_alignment_and_through_the_driver():
     sc_s, tr_s = bootstrap.refine_boot_trees(e3, samples, boot_trees, 9, 6, batched=False)
     assert sc_b.tolist() == sc_s.tolist()
     assert all((tr_b[b] == tr_s[b]).all() for b in range(40))
+    # called again on the SAME engine (bench.py does, four times in a row): samples on `other` are not stable, so engine 0 has
+    # climbed under sample weights in the first call -- it must have been handed back under the weights it came with
+    assert (e2.weights() == w0).all()
+    sc_b2, tr_b2 = bootstrap.refine_boot_trees(e2, samples, boot_trees, 9, 6, batched=True)
+    assert sc_b2.tolist() == sc_s.tolist()
+    assert all((tr_b2[b] == tr_s[b]).all() for b in range(40))
+    # ... and an engine that holds weights which drop a pattern the samples count is refused, not silently mis-scored
+    w_bad = w0.copy()
+    w_bad[int(np.argmax(samples.max(axis=0) > 0))] = 0
+    e2.set_weights(w_bad)
+    with pytest.raises(ValueError):
+        bootstrap.refine_boot_trees(e2, samples, boot_trees, 9, 6, batched=True)
 
 
 REFINE_WORKER = r'''

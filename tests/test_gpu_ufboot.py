@@ -118,7 +118,7 @@ def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
     samples = np.random.default_rng(77).multinomial(int(w.sum()), w / w.sum(), size=150).astype(np.uint16)
     start = np.array(fx["trees"][1]["back"], dtype=np.int32)
     got = []
-    for opts in ({"ufb_fast": 0}, {"ufb_pipe": 0}, {"ufb_thread": 0}, {}):
+    for opts in ({"ufb_fast": 0, "ufb_quiet": 0}, {"ufb_pipe": 0}, {"ufb_thread": 0}, {}, {"ufb_quiet": 0}):
         e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
         for k, v in opts.items():
             e.set_option(k, v)
@@ -143,14 +143,18 @@ def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
             e.ufboot_set_iteration(2)
         e.set_tree(np.array(fx["trees"][5]["back"], dtype=np.int32))
         s2 = e.optimize_spr(1, 6)
-        got.append(((s, s2, cut), (obs1, _observables(e, rule)), early1, e.get_option("ufb_batches"), e.get_option("ufb_early_batches")))
+        got.append(((s, s2, cut), (obs1, _observables(e, rule)), early1, e.get_option("ufb_batches"), e.get_option("ufb_early_batches"),
+                    e.get_option("ufb_quiet_climbs"), e.tie_state()))
     assert got[0][0][2] != 0.0                      # (a cut-off was in force in the second climb)
     for g in got[1:]:
         assert got[0][:2] == g[:2]
+        assert got[0][6] == g[6]                    # (the tie stream stands where it stood)
     assert got[0][2] == 0 and got[1][2] == 0
     if rule == "default":
         for g in got[2:]:
             assert g[2] > 0 and g[2] <= g[3]
+    # the climb under the cut-off began as the plain one (ufb_quiet) -- except where that is switched off
+    assert got[0][5] == 0 and got[4][5] == 0 and got[3][5] == 1
 
 
 @pytest.mark.parametrize("opts", [{}, {"ufb_pipe": 0}, {"ufb_fast": 0}])
