@@ -322,6 +322,45 @@ def refine_cpu_baseline(codes, names, letters, alphabet, samples, boot_trees, gp
             "same_score_as_gpu": bool(int(gpu_scores[0]) == int(s_cpu))}
 
 
+def bb_run_cpu_baseline(codes, alphabet, samples, back, maxtrav, budget_s, plain_evals_per_s, run, refine_cb):
+    """CPU time of the same -bb run, extrapolated: the trees that reach saveCurrentTree's bookkeeping (run["trees_booked"]) at the rate
+    of the C port with its AVX2 REPS loop, timed here on a prefix of the first climb's first sweep (kind "port": IQTree::saveCurrentTree
+    lives in the unbuildable C++ layer); every other insertion test at the reference's own plain rate (PLL AVX testInsertParsimony,
+    the headline's cpu_baseline); the refinement at the reference's per-sample time where that leg measured it."""
+    import time
+    from oracle import pyoracle as po
+    if not plain_evals_per_s:
+        return None
+    o = po.Oracle(codes, datatype=po.DNA if alphabet == "DNA" else po.AA)
+    o.seed_ties(po.TIE_RANDOM, 1)
+    o.ufboot_attach(samples)
+    o.set_best(o.score_tree(back))
+    nodep = o.nodep()
+    n = codes.shape[0]
+    t0 = time.perf_counter()
+    k0, i = o.counters()[2], 1
+    while time.perf_counter() - t0 < budget_s and i <= 2 * n - 2:
+        o.rearrange(int(nodep[i]), 1, maxtrav)
+        i += 1
+    dt = time.perf_counter() - t0
+    booked_rate = (o.counters()[2] - k0) / dt
+    booked = run["trees_booked"]
+    plain = max(0, run["insertion_tests"] - booked)
+    online_s = booked / booked_rate + plain / plain_evals_per_s
+    refine_s = None
+    if isinstance(refine_cb, dict):
+        per1000 = refine_cb.get("refinement_per_1000_samples_s")
+        if per1000:
+            refine_s = per1000 * samples.shape[0] / 1000.0
+    total = online_s + (refine_s or 0.0)
+    return {"value": total, "unit": "s (one core, extrapolated)", "cores": 1, "kind": "port",
+            "booked_trees_per_s": booked_rate, "plain_tests_per_s": plain_evals_per_s, "online_s": online_s, "refinement_s": refine_s,
+            "sample": "%d prune nodes (%d insertion tests with REPS for %d samples) of the first sweep on the C port; extrapolated to %d booked "
+                      "trees + %d unbooked insertion tests at the reference's plain rate%s"
+                      % (i - 1, o.counters()[2] - k0, samples.shape[0], booked, plain,
+                         " + the refinement at the reference's per-sample time" if refine_s else " (refinement not included)")}
+
+
 def climb_cpu_baseline(names, letters, alphabet, back, maxtrav):
     """A whole SPR hill climb from `back` on the reference's PLL AVX code (pll_ref_driver spr: the loop of
     fastDNAparsimony.c:1919-1938, first-best rule), one thread."""
@@ -530,6 +569,9 @@ def main():
     ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
     ap.add_argument("--start-trees", type=int, default=100,
                     help="randomized-stepwise-addition + SPR start trees of the start-up phase (phyloanalysis.cpp:1270-1317), sharded over the GPUs (0 = skip)")
+    ap.add_argument("--bb-iterations", type=int, default=50,
+                    help="later search iterations of the -bb run leg (bootstrap_wall_clock.seconds): perturb the best tree, climb under the "
+                         "updated logl_cutoff with the bookkeeping (0 = skip the leg)")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
@@ -978,6 +1020,38 @@ def main():
                                      "mean_sample_score_online": float(np.mean(online2[:n_rep])) if n_rep else None,
                                      "mean_sample_score_refined": float(np.mean(bs2)) if n_rep else None,
                                      "samples_improved_by_refinement": int((bs2 < online2[:n_rep]).sum()) if n_rep else None}
+                # ---- the -bb RUN: what the search really repeats.  One tracked climb from the random tree, then --bb-iterations later
+                # iterations (cut-off = top 10 % of the saved trees, iqtree.cpp:1662-1676; best tree perturbed by 30 random SPR moves;
+                # tracked climb under the cut-off), then the refinement of all samples.  Every rank makes the same calls (the online
+                # part is one sequential chain, replicated below shard.ONLINE_SHARD_MIN_SAMPLES samples); the refinement shards.
+                if args.bb_iterations > 0 and n_rep > 0:
+                    from mpboot_amd import bootstrap as _bs
+                    eng.set_option("timing", 0)
+                    _bs.bb_search(eng, samples, back_r, min(3, args.bb_iterations), 30, args.maxtrav, 1, engines=engines)      # allocations
+                    barrier()
+                    t0r = time.perf_counter()
+                    rr = _bs.bb_search(eng, samples, back_r, args.bb_iterations, 30, args.maxtrav, 1, engines=engines)
+                    barrier()
+                    t_run = time.perf_counter() - t0r
+                    eng.set_option("timing", 1)
+                    its_ = np.array(rr["iter_s"])
+                    tests_run = int(rr["first_stats"]["insertion_tests"] + sum(x[1] for x in rr["iter_stats"]))
+                    nondeg["bb_run"] = {
+                        "seconds": rr["first_s"] + float(its_.sum()) + rr["refine_s"], "seconds_with_perturbation_scans": t_run,
+                        "first_climb_s": rr["first_s"], "iterations": int(len(its_)), "iterations_s": float(its_.sum()),
+                        "iteration_ms_mean": float(its_.mean() * 1e3), "iteration_ms_median": float(np.median(its_) * 1e3),
+                        "iteration_ms_max": float(its_.max() * 1e3), "refinement_s": rr["refine_s"],
+                        "insertion_tests": tests_run, "trees_booked": int(rr["saved_trees"]), "trees_booked_first_climb": int(rr["saved_first"]),
+                        "moves_per_iteration": float(np.mean([x[0] for x in rr["iter_stats"]])),
+                        "tests_per_iteration": float(np.mean([x[1] for x in rr["iter_stats"]])),
+                        "best_score": rr["best_score"], "distinct_boot_trees": rr["distinct_boot_trees"], "state_sha16": rr["state_hash"],
+                        "what": "-bb %d as a run: 1 tracked climb from a random tree + %d later iterations (logl_cutoff = top 10 %% of the saved "
+                                "trees, best tree perturbed by 30 random SPR moves, tracked climb under the cut-off) + refinement of every sample's "
+                                "tree.  A later climb starts far above the cut-off, where nothing reaches saveCurrentTree's bookkeeping "
+                                "(iqtree.cpp:3343): that stretch runs as the plain climb (k_climb / cost-only batches) and hands over to the "
+                                "tracked loop in front of the first admissible insertion test; seconds = climbs + refinement (the perturbation's "
+                                "own scans stand in for doRandomNNIs and are left out; seconds_with_perturbation_scans has them)"
+                                % (B, len(its_))}
             eng.set_tree(back)
         except Exception as exc:        # the headline metric above must survive a failing secondary leg
             legs_error = repr(exc)
@@ -1216,9 +1290,13 @@ def main():
                 "seconds_from_ras_tree": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
                 # the flow that really searches: from a random topology (thousands of accepted moves online, refinements that climb);
                 # the RAS tree of this alignment is SPR-optimal already (zero moves: seconds_from_ras_tree is 1000 move-less sweeps)
-                "seconds": (nondeg["bb_flow"]["seconds"] if nondeg is not None and "bb_flow" in nondeg
+                "seconds": (nondeg["bb_run"]["seconds"] if nondeg is not None and "bb_run" in nondeg
+                            else nondeg["bb_flow"]["seconds"] if nondeg is not None and "bb_flow" in nondeg
                             else ufb["seconds"] + boot[1] * ufb["samples"] / boot[0]),
-                "seconds_is": "random-start flow (random_start.bb_flow)" if nondeg is not None and "bb_flow" in nondeg else "flow from the RAS tree",
+                "seconds_is": ("the -bb run from a random tree: first climb + %d later iterations under the cut-off + refinement (random_start.bb_run)"
+                               % nondeg["bb_run"]["iterations"] if nondeg is not None and "bb_run" in nondeg
+                               else "random-start flow, ONE climb + refinement (random_start.bb_flow)" if nondeg is not None and "bb_flow" in nondeg
+                               else "flow from the RAS tree"),
                 "refinement_s_plan_cache_off": tb_nocache, "refinement_s_per_sample_climbs": tb_persample, "distinct_boot_trees": n_distinct_trees,
                 "scaling": "strong", "engines_per_gpu": n_eng,
                 "online_phase_sharded": shard.online_shard(ufb["samples"], rank, world, args.shard_online) is not None,
@@ -1280,6 +1358,16 @@ def main():
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
             if "all_cores" in res["cpu_baseline"]:
                 res["gpu_over_cpu_all_cores"] = res["value"] / res["cpu_baseline"]["all_cores"]["value"]
+            if nondeg is not None and "bb_run" in nondeg:
+                try:
+                    nondeg["bb_run"]["cpu_baseline"] = bb_run_cpu_baseline(codes, alphabet, samples, back_r, args.maxtrav, min(args.cpu_budget, 10.0),
+                                                                           res["cpu_baseline"].get("evals_per_s"), nondeg["bb_run"],
+                                                                           res.get("bootstrap_wall_clock", {}).get("cpu_baseline"))
+                    cbr = nondeg["bb_run"]["cpu_baseline"]
+                    if cbr:
+                        nondeg["bb_run"]["gpu_over_cpu_one_core"] = cbr["value"] / nondeg["bb_run"]["seconds"]
+                except Exception as exc:
+                    nondeg["bb_run"]["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -2023,6 +2023,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_quiet") { ufb_quiet_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_moot") { ufb_moot_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_cut_batch") { ufb_cut_batch_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 20)); return MPF_OK; }
   if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_thread") { ufb_thread_ = v ? 1 : 0; return MPF_OK; }
@@ -2106,6 +2107,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "ufb_quiet") *v = ufb_quiet_;
+  else if (key == "ufb_moot") *v = ufb_moot_;
   else if (key == "ufb_cut_batch") *v = ufb_cut_batch_;
   else if (key == "ufb_quiet_climbs") *v = ufb_stat_quiet_;
   else if (key == "ufb_pipe") *v = ufb_pipe_;

@@ -399,7 +399,10 @@ class Engine {
   void ufb_drain_log();
   // the current tree offered to every local sample under the default update rule with the deferred log (iqtree.cpp:3684-3731 for
   // 1000 samples x every prune-node visit: 2e6 bookings per move-less C3 sweep) -- one tight loop, the reciprocals from a table
-  void ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws);
+  // samples for which an acceptance of the current tree would change nothing (see ufb_self_default)
+  struct SelfMoot { std::vector<uint8_t> flag; int n_set = 0, n_le = -1, jump_n = -1; uint64_t jump_a = 1, jump_c = 0; };
+  void ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws, SelfMoot *moot = nullptr);
+  int ufb_moot_ = 1;                             // option "ufb_moot"
   // the log of one batch against an explicit topology: touches nothing of the engine but n_ and the tracker's deferred state
   // (topology map, boot_trees, reference counts, stored topologies), so that it can run on the worker thread of a pipelined climb
   struct DrainScratch {

@@ -9,12 +9,18 @@
 // the next prune node, so the trajectory is the reference's.
 #include <algorithm>
 #include <climits>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../csrc/engine.hpp"
 #include "simd_util.hpp"
 
 namespace mpf {
+
+static bool sweep_trace_env() { static const bool on = std::getenv("MPF_UFB_TRACE") != nullptr; return on; }
+static double sw_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // restoreTreeRearrangeParsimony (reference sprparsimony.cpp:2379-2384, :2191-2205)
 void Engine::apply_move(int p, int q)
@@ -91,9 +97,11 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
         uint32_t reason = 0, nm = 0;
         const int i0 = i;
         climb_stop_len_ = stop_len;
+        const double tr0 = sweep_trace_env() ? sw_now_ms() : 0.0;
         int rc = climb_segment(mt_eff, total, &i, &randomMP, &iter_hits, climb_device_ < 2, &reason, &nm);
         climb_stop_len_ = 0;
         if (rc) return rc;
+        if (sweep_trace_env()) std::fprintf(stderr, "[sweep] k_climb i %d -> %d moves %u reason %u len %u | %.3f ms\n", i0, i, nm, reason, randomMP, sw_now_ms() - tr0);
         // (not resident in time -- somebody else holds the chip: the rest of this climb runs as host-driven batches; trying again
         //  behind every move would cost a 30 ms time-out each)
         if (reason == CLIMB_ABORT) { dev = false; dev_ok = false; continue; }
@@ -109,9 +117,18 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
         if (reason == CLIMB_CUTOFF) return stop_at(i, startMP);
         continue;
       }
+      // what a batch costs is a step function of its size: up to 32 prune nodes (neighbourhoods cut into short parts, chained refresh,
+      // the device-walked kernel, results polled) 45-110 us; anything larger pays the long parts' dependent chains and the level
+      // refresh -- 0.25-0.4 ms for 64 .. 256 prune nodes, 0.22 ms for the whole rest of a sweep on the planned path.  So: small, or
+      // all that is left of the sweep; and where moves have been lying dozens of prune nodes apart, 32 at once rather than 4, 8, 16
+      if (batch > 32) batch = total;
+      else if (gap_est_ >= 32.0) batch = 32;
       const int hi = std::min(total, i + batch - 1);
+      const double tr0 = sweep_trace_env() ? sw_now_ms() : 0.0;
+      const double tp0 = stats.host_plan_ms_total, tv0 = stats.host_views_ms_total, ts0 = stats.host_scan_ms_total;
       int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
       if (rc) return rc;
+      const double tr1 = sweep_trace_env() ? sw_now_ms() : 0.0;
       bool moved = false;
       int j = i;
       bool cut = false;
@@ -180,6 +197,8 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
           sweep_moves++;
         }
       }
+      if (sweep_trace_env()) std::fprintf(stderr, "[sweep] host batch i %d np %d used %d moved %d cut %d len %u | scan %.3f (plan %.3f views %.3f scan %.3f) select %.3f ms\n", i, hi - i + 1, j - i, (int)moved, (int)cut, randomMP, tr1 - tr0,
+                                         stats.host_plan_ms_total - tp0, stats.host_views_ms_total - tv0, stats.host_scan_ms_total - ts0, sw_now_ms() - tr1);
       batch = next_batch(batch, moved, j - i, total);
       i = j;
       if (cut) return stop_at(i, startMP);

@@ -23,6 +23,7 @@
 
 #include "../csrc/engine.hpp"
 #include "lcg_block.hpp"
+#include "simd_util.hpp"
 
 namespace mpf {
 
@@ -592,7 +593,7 @@ __attribute__((target("avx512f,avx512dq,avx512vl,avx2"))) static int self_tie8(c
   return acc;
 }
 
-void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws)
+void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws, SelfMoot *moot)
 {
   UfbState &u = *ufb_;
   uint32_t *bsv = u.boot_score.data();
@@ -604,14 +605,45 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
   uint64_t st = rng_.state, draws = 0;
   static const Lcg64Jump8 jump;
   const bool by_eight = !callback && u.ids_identity && lcg64_have_avx512();
+  // Samples whose tree ALREADY is the current topology and whose best score the current tree ties (SelfMoot): the draw is taken --
+  // the stream moves on, boot_counts rises -- but its outcome decides nothing (an acceptance would point the sample at the tree it
+  // points at).  A move-less sweep of the tree every sample holds is 2n - 2 visits of nothing else: one jump of the generator.
+  uint8_t *mf = (moot && !callback && u.ids_identity) ? moot->flag.data() : nullptr;
+  if (mf && moot->n_le < 0) {
+    // how many samples the current tree reaches at all (its REPS <= their best): while it is none -- the visits of a tree well
+    // above every sample's best -- a booking touches nothing (recounted whenever a best score has fallen)
+    int k = 0;
+    for (int c2 = 0; c2 < u.Bl; c2++) k += (uint32_t)rt[c2] <= bsv[c2];
+    moot->n_le = k;
+  }
+  if (mf && moot->n_le == 0) return;
+  if (mf && moot->n_set == u.Bl) {
+    for (int c2 = 0; c2 < u.Bl; c2++) cnt[c2]++;
+    rng_.state = st * moot->jump_a + moot->jump_c;
+    n_draws += (uint64_t)u.Bl;
+    return;
+  }
   for (int c2 = 0; c2 < u.Bl; c2++) {
+    if (mf && c2 + 8 <= u.Bl) {
+      uint64_t f8;
+      std::memcpy(&f8, mf + c2, 8);
+      if (f8 == 0x0101010101010101ULL) {
+        for (int k = 0; k < 8; k++) cnt[c2 + k]++;
+        st = st * jump.a[7] + jump.c[7];
+        draws += 8;
+        c2 += 7;
+        continue;
+      }
+    }
     if (by_eight && c2 + 8 <= u.Bl) {
       int acc = self_tie8(rt + c2, bsv + c2, cnt + c2, inv.data(), inv.size(), st, jump);
       if (acc >= 0) {
         draws += 8;
         for (; acc; acc &= acc - 1) {
-          u.log.push_back(UfbState::LogEntry{(uint32_t)(c2 + __builtin_ctz((unsigned)acc)), 0xFFFFFFFFu, tree_index, cur_plan});
+          const int b8 = c2 + __builtin_ctz((unsigned)acc);
+          u.log.push_back(UfbState::LogEntry{(uint32_t)b8, 0xFFFFFFFFu, tree_index, cur_plan});
           log_open = true;
+          if (mf && !mf[b8]) { mf[b8] = 1; moot->n_set++; }              // (it ties and now points at the current tree)
         }
         c2 += 7;
         continue;
@@ -627,12 +659,13 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
       double r;
       if (callback) r = rand_fn_(rand_arg_);
       else { st = st * 0x27bb2ee687b0b0fdULL + 3037000493ULL; r = (double)st * 5.4210108624275222e-20; }     // (TieRng::next)
-      accept = r <= inv[k];
+      accept = (mf && mf[c2]) ? false : r <= inv[k];                    // (moot: the acceptance would change nothing -- not logged)
     }
     if (accept) {
       u.log.push_back(UfbState::LogEntry{b, 0xFFFFFFFFu, tree_index, cur_plan});
       log_open = true;
       if (s < bs) { cnt[b] = 1; bsv[b] = s; }                           // :3710-3719
+      if (mf && !mf[c2]) { mf[c2] = 1; moot->n_set++; }
     }
     cnt[b]++;                                                           // :3728-3730 (s equals the sample's best here in either case)
   }
@@ -867,6 +900,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     u.stale_len = u.rt_orig;
     u.gate_closed = false;
   }
+  SelfMoot moot;
+  bool moot_on = false;
   std::vector<int32_t> lcol;                       // ratchet: the original-frequency column of the product, per mask row
   do {
     int i = 1;
@@ -1203,6 +1238,27 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       }
       t0 = now_ms();
       const double tr_t0 = t0;
+      // (SelfMoot, see ufb_self_default: which samples hold the current topology already and tie with it -- boot_trees is this
+      //  thread's here, and the log of the batch before has been worked off)
+      moot_on = false;
+      if (defer && host_self && self_pass && ran_events && u.ids_identity && !rand_fn_ && ufb_moot_ && u.log.empty()) {
+        if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+        const auto it = u.topo_index.find(u.self_key);
+        moot.flag.assign((size_t)u.Bl + 8, 0);
+        moot.n_set = 0;
+        moot.n_le = -1;
+        if (it != u.topo_index.end()) {
+          const int64_t cur_res = it->second;
+          for (int c2 = 0; c2 < u.Bl; c2++)
+            if (u.boot_trees[(size_t)c2] == cur_res && (uint32_t)u.h_rt.p[c2] == u.boot_score[(size_t)c2]) { moot.flag[(size_t)c2] = 1; moot.n_set++; }
+        }
+        if (moot.jump_n != u.Bl) {
+          moot.jump_n = u.Bl;
+          moot.jump_a = lcg64_skip(1, (uint64_t)u.Bl) - lcg64_skip(0, (uint64_t)u.Bl);     // A^Bl
+          moot.jump_c = lcg64_skip(0, (uint64_t)u.Bl);
+        }
+        moot_on = true;
+      }
       // ---- host replay in the reference's order
       size_t ep = 0;
       bool moved = false;
@@ -1282,6 +1338,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             if (accept && defer) {
               u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
               log_open = true;
+              if (moot_on && cand_code != 0xFFFFFFFFu && moot.flag[b]) { moot.flag[b] = 0; moot.n_set--; }   // (it points elsewhere now)
+              if (moot_on && s < bs) moot.n_le = -1;
               if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
             } else if (accept) {
               // the tree "string" (:3689-3707): looked up once per booked tree; the topology itself is remembered as
@@ -1306,7 +1364,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
         // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
         auto replay_self = [&](int64_t tree_index) {
-          if (defer) { ufb_self_default(u.h_rt.p, tree_index, cur_plan, log_open, u.draws); return; }
+          if (defer) { ufb_self_default(u.h_rt.p, tree_index, cur_plan, log_open, u.draws, moot_on ? &moot : nullptr); return; }
           bool looked_up = store_trees;
           for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
         };
@@ -1349,6 +1407,15 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         for (int pi = 0; pi < pl.n_parts; pi++) {
           const uint32_t home = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
           for (int k = 0; k < pl.part_cnt[pi]; k++, c++) {
+            if (have_cut && !ratchet && !store_trees) {
+              // under a cut-off most insertion tests change nothing: not booked (above the cut-off) and longer than the best tree so
+              // far (no counter, no draw) -- on to the next one that is either (best_ only falls while the block is read)
+              const uint32_t lim_len = std::max(none_pass ? 0u : mp_max, best_);
+              const int k2 = lim_len >= pl.base ? first_le(out + pl.part_off[pi], k, pl.part_cnt[pi], lim_len - pl.base) : pl.part_cnt[pi];
+              c += (size_t)(k2 - k);
+              k = k2;
+              if (k >= pl.part_cnt[pi]) break;
+            }
             const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
             const uint32_t mp = pl.base + out[idx];
             // saveCurrentTree(-mp) (reference sprparsimony.cpp:2163-2166), before the SPR tie rule
