@@ -1627,7 +1627,7 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
   int mt = std::min(maxtrav, ntips_ - 3);
   const bool walk = scan_mode_ == 1 && mt <= 8 && !sankoff_;
   plans.resize((size_t)count);
-  if (walk && !views_valid_ && count < n_ / 2) {
+  if (walk && !views_valid_ && count < n_ / 2 && count <= small_batch_max_) {
     // small batch (the inside of a climb): plan first -- planning needs the topology only -- so that the refresh launch
     // can clear the scan's outputs, then refresh just the vectors these scans read
     {
@@ -2023,6 +2023,8 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_quiet") { ufb_quiet_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "max_visits") { max_visits_ = std::max<int64_t>(0, v); return MPF_OK; }
+  if (key == "small_batch_max") { small_batch_max_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 30)); return MPF_OK; }
   if (key == "ufb_moot") { ufb_moot_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_cut_batch") { ufb_cut_batch_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 20)); return MPF_OK; }
   if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
@@ -2107,6 +2109,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "ufb_quiet") *v = ufb_quiet_;
+  else if (key == "max_visits") *v = max_visits_;
   else if (key == "ufb_moot") *v = ufb_moot_;
   else if (key == "ufb_cut_batch") *v = ufb_cut_batch_;
   else if (key == "ufb_quiet_climbs") *v = ufb_stat_quiet_;

@@ -391,6 +391,12 @@ class Engine {
   int64_t ufb_stat_batches_ = 0, ufb_stat_early_ = 0;   // read-only options ufb_batches / ufb_early_batches: batches of the tracker's climbs since the engine was made, and how many of them were decided from the costs
   int ufb_pipe_ = 1;                             // option "ufb_pipe": the search's decision from the costs alone where they settle it, the next batch launched beside the bookkeeping of this one
   int ufb_cut_batch_ = 128;                      // option "ufb_cut_batch": smallest batch (prune nodes) of a tracked climb under a logl_cutoff
+  int small_batch_max_ = 1 << 30;                // option "small_batch_max": batches above this many prune nodes take the whole-sweep path of scan_batch (all stale vectors refreshed, no closure on the host)
+  // test aid (option "max_visits"): a climb returns behind this many prune-node visits, its state as that visit left it (0 = no
+  // limit).  The persistent kernel is not used then; the pipelined tracked climb stops with its look-ahead batch discarded.
+  int64_t max_visits_ = 0, visits_done_ = 0;
+  bool visits_out() const { return max_visits_ > 0 && visits_done_ >= max_visits_; }
+  int visits_cap(int i, int hi) const { return max_visits_ > 0 ? (int)std::min<int64_t>(hi, (int64_t)i + (max_visits_ - visits_done_) - 1) : hi; }
   int ufb_quiet_ = 1;                            // option "ufb_quiet": a climb under a logl_cutoff runs as the plain one until it reaches the trees the tracker books
   int64_t ufb_stat_quiet_ = 0;                   // read-only option ufb_quiet_climbs: tracked climbs that began with a quiet stretch
   int ufb_fast_ = 1;                             // option "ufb_fast": one dispatch chain and one wait per batch of the tracker's climbs

@@ -66,6 +66,10 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
     return MPF_OK;
   };
   const int total = 2 * n_ - 2;
+  // (batches of a few hundred prune nodes -- what is left of a sweep -- are cheaper on the whole-sweep path of scan_batch: every stale
+  //  vector refreshed by the level kernel, no closure of the batch's roots on the host)
+  struct SmallMax { int &ref; int saved; ~SmallMax() { ref = saved; } } small_guard{small_batch_max_, small_batch_max_};
+  small_batch_max_ = std::min(small_batch_max_, 128);
   // (the engine's own plan storage: a whole-sweep batch on a topology whose sweep is still planned -- the closing sweep of
   //  the previous climb, the same tree under other weights -- reuses descriptors and device program, Engine::scan_batch)
   std::vector<ScanPlan> &plans = sweep_plans_;
@@ -78,7 +82,7 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
   // keeps the loop on the host.
   const int mt_eff = std::min(maxtrav, ntips_ - 3);
   // (... and only where all of the kernel's workgroups fit the chip together, if need be on wider tiles: climb_fit_vw)
-  bool dev_ok = climb_device_ > 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff) &&
+  bool dev_ok = climb_device_ > 0 && max_visits_ == 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff) &&
                 climb_fit_vw() > 0;
   uint32_t sweep_moves = 0;
   bool first_sweep = true;
@@ -92,6 +96,7 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
     first_sweep = false;
     sweep_moves = 0;
     while (i <= total) {
+      if (visits_out()) { cur.randomMP = randomMP; cur.iter_hits = iter_hits; return MPF_OK; }
       if (stop_len && randomMP <= stop_len) return stop_at(i, startMP);     // the current tree itself is booked from here on
       if (dev) {
         uint32_t reason = 0, nm = 0;
@@ -123,7 +128,7 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
       // all that is left of the sweep; and where moves have been lying dozens of prune nodes apart, 32 at once rather than 4, 8, 16
       if (batch > 32) batch = total;
       else if (gap_est_ >= 32.0) batch = 32;
-      const int hi = std::min(total, i + batch - 1);
+      const int hi = visits_cap(i, std::min(total, i + batch - 1));
       const double tr0 = sweep_trace_env() ? sw_now_ms() : 0.0;
       const double tp0 = stats.host_plan_ms_total, tv0 = stats.host_views_ms_total, ts0 = stats.host_scan_ms_total;
       int rc = scan_batch(plans, nodep_.data() + i, hi - i + 1, mintrav, maxtrav, &out);
@@ -200,12 +205,13 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
       if (sweep_trace_env()) std::fprintf(stderr, "[sweep] host batch i %d np %d used %d moved %d cut %d len %u | scan %.3f (plan %.3f views %.3f scan %.3f) select %.3f ms\n", i, hi - i + 1, j - i, (int)moved, (int)cut, randomMP, tr1 - tr0,
                                          stats.host_plan_ms_total - tp0, stats.host_views_ms_total - tv0, stats.host_scan_ms_total - ts0, sw_now_ms() - tr1);
       batch = next_batch(batch, moved, j - i, total);
+      visits_done_ += j - i;
       i = j;
       if (cut) return stop_at(i, startMP);
       // moves have become dense again behind a quiet stretch: the rest of the sweep goes back to the kernel
       if (moved && dev_ok && gap_est_ >= 0 && gap_est_ < 24.0 && i <= total) dev = true;
     }
-  } while (randomMP < startMP);
+  } while (randomMP < startMP && !visits_out());
   climb_finished(total);
   cur.randomMP = randomMP;
   cur.iter_hits = iter_hits;
@@ -225,6 +231,7 @@ int Engine::optimize_spr(int mintrav, int maxtrav, uint32_t *score)
   best_ = len;
   ntips_ = n_;
   insert_rec_ = remove_rec_ = -1;
+  visits_done_ = 0;
   if (ufb_ && !ufb_->suspended && ufb_->snk) return spr_sweeps_ufboot_snk(mintrav, maxtrav, best_, score);
   if (ufb_ && !ufb_->suspended) {                 // perSiteScores = gbo_replicates > 0 (reference :3245)
     if (scan_mode_ != 1 || std::min(maxtrav, ntips_ - 3) > 8) { set_error("online UFBoot needs the device-walked scan (maxtrav <= 8)"); return MPF_E_UNSUPPORTED; }

@@ -907,8 +907,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     int i = 1;
     if (resume_i > 0) { i = resume_i; resume_i = 0; }          // (the sweep the quiet stretch handed over: order and startMP stand)
     else { startMP = randomMP; node_rectifier(); }
-    while (i <= total) {
-      const int hi = std::min(total, i + batch - 1);
+    while (i <= total && !visits_out()) {
+      const int hi = visits_cap(i, std::min(total, i + batch - 1));
       double t0 = now_ms();
       const double tr_scan0 = u.t_scan, tr_dev0 = u.t_dev;      // (MPF_UFB_TRACE=1: one line per batch)
       ufb_stat_batches_++;
@@ -1498,10 +1498,11 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         std::fprintf(stderr, "[ufb-batch] i %d np %d used %d n_idx %u rows %u events %u moved %d len %u mp_max %u | last scan %.3f dev %.3f replay %.3f ms\n", i, np, j - i, n_idx,
                      n_rows, n_ev, (int)moved, randomMP, mp_max, u.t_scan - tr_scan0, u.t_dev - tr_dev0, now_ms() - tr_t0);
       batch = std::max(next_batch(batch, moved, j - i, total), batch_floor);
+      visits_done_ += j - i;
       i = j;
       u.t_replay += now_ms() - t0;
     }
-  } while (randomMP < startMP);
+  } while (randomMP < startMP && !visits_out());
   ufb_drain_log();
   climb_finished(total);
   if (u.exchange) {
@@ -1544,6 +1545,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   int cur = 0;
   bool prelaunched = false;
   bool moved_once = false;
+  int pipe_ahead = 0;
   if (u.exchange) {
     // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy state
     gap_est_ = -1.0;
@@ -1691,6 +1693,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     const double t0 = now_ms();
     B.i = i;
     B.hi = std::min(total, i + b - 1);
+    if (max_visits_ > 0) B.hi = std::max(i, (int)std::min<int64_t>(B.hi, (int64_t)i + (max_visits_ - visits_done_ - (early ? pipe_ahead : 0)) - 1));
     B.np = B.hi - i + 1;
     B.early_bounds = early;
     const uint32_t *out_unused = nullptr;
@@ -1806,7 +1809,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     startMP = randomMP;
     node_rectifier();
     int i = 1;
-    while (i <= total) {
+    while (i <= total && !visits_out()) {
       Batch &B = ring[cur];
       if (!prelaunched) { B.par = cur & 1; int rc = launch(B, i, batch, false, false); if (rc) return rc; }
       prelaunched = false;
@@ -1843,7 +1846,8 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           next_i = B.hi + 1;
           next_batch_size = next_batch(batch, false, B.np, total);
         }
-        if (next_i <= total) {
+        pipe_ahead = next_i - i;                   // (visits of this batch that count before the look-ahead batch starts)
+        if (next_i <= total && !(max_visits_ > 0 && visits_done_ + pipe_ahead >= max_visits_)) {
           const int nxt = (cur + 1) % 3;
           ring[nxt].par = B.par ^ 1;
           int rc = launch(ring[nxt], next_i, next_batch_size, true, moved_once || d.moved);
@@ -2083,12 +2087,13 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         else { u.log_back = back_; u.log_epoch = topo_epoch_; }
         u.log_plans = &B.plans;
       }
+      visits_done_ += j - i;
       if (early) { batch = next_batch_size; i = next_i; }
       else { batch = next_batch(batch, moved, j - i, total); i = j; }
       cur = (cur + 1) % 3;
       u.t_replay += now_ms() - t0;
     }
-  } while (randomMP < startMP);
+  } while (randomMP < startMP && !visits_out());
   ufb_drain_log();
   worker.finish();
   u.lookups += worker.sc.lookups; u.stored += worker.sc.stored; u.t_lookup += worker.sc.t_lookup;

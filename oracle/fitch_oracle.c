@@ -61,6 +61,7 @@ struct orc {
   unsigned long long c_newview, c_eval, c_test;
   /* UFBoot-MP online bookkeeping (IQTree::saveCurrentTree, iqtree.cpp:3271-3785, default options) */
   int pre_eval;               /* -1 = as the variant does (mpboot yes, PLL original no); 0 / 1 = forced */
+  long max_visits;            /* test aid: orc_optimize_spr returns after this many prune-node visits (0 = no limit) */
   int ufb_on, ufb_B, ufb_bad;
   int ufb_ratchet;                   /* on_ratchet_hclimb1: other weights than the attach-time ones in force */
   int ufb_ratchet_booking;           /* !params->no_hclimb1_bb (tools.cpp:795) */
@@ -601,6 +602,7 @@ void orc_set_tie_state(orc *o, unsigned long long state) { o->rng.state = state;
 unsigned long long orc_get_tie_state(const orc *o) { return o->rng.state; }
 void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg) { o->rand_fn = fn; o->rand_arg = arg; }
 void orc_set_pre_evaluate(orc *o, int mode) { o->pre_eval = mode; }
+void orc_set_max_visits(orc *o, long k) { o->max_visits = k; }
 
 /* ---- traces ---- */
 void orc_trace(orc *o, int on) { o->trace_on = on; o->trace_len = 0; o->moves_len = 0; }
@@ -1013,10 +1015,13 @@ static unsigned spr_sweeps(orc *o, int mintrav, int maxtrav, unsigned randomMP)
   unsigned startMP;
   unsigned iter_hits = 1;
   int i;
+  long visits = 0;
   do {
     startMP = randomMP;
     orc_node_rectifier(o);
     for (i = 1; i <= 2 * o->n - 2; i++) {
+      /* (test aid: the climb is cut short behind a given number of visits -- the state stays as that visit left it) */
+      if (o->max_visits > 0 && visits++ >= o->max_visits) return randomMP;
       if (o->tie_mode == ORC_TIE_RANDOM) {
         o->insert_rec = o->remove_rec = -1;
         o->hits = 1;

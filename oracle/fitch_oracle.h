@@ -59,6 +59,7 @@ void orc_set_rand_callback(orc *o, double (*fn)(void *), void *arg);
 /* the evaluateParsimony(p) at the top of rearrangeParsimony (sprparsimony.cpp:2285; absent from the PLL original):
    -1 = as the tie mode's variant has it, 0 = off, 1 = on */
 void orc_set_pre_evaluate(orc *o, int mode);
+void orc_set_max_visits(orc *o, long k);   /* test aid: orc_optimize_spr stops behind k prune-node visits (0 = no limit) */
 
 /* trace of the insertion tests performed by the calls below: (q rec, mp), -1/-2 separators */
 void orc_trace(orc *o, int on);

@@ -67,6 +67,7 @@ def lib():
         L.orc_get_tie_state.restype = C.c_ulonglong
         L.orc_get_tie_state.argtypes = [vp]
         L.orc_set_pre_evaluate.argtypes = [vp, ci]
+        L.orc_set_max_visits.argtypes = [vp, C.c_long]
         L.orc_trace.argtypes = [vp, ci]
         L.orc_trace_get.argtypes = [vp, vp, vp]
         L.orc_moves_get.argtypes = [vp, vp, vp, vp]
@@ -218,6 +219,10 @@ class Oracle:
 
     def set_pre_evaluate(self, mode: int):
         lib().orc_set_pre_evaluate(self.h, int(mode))
+
+    def set_max_visits(self, k: int):
+        """test aid: optimize_spr returns behind k prune-node visits (0 = no limit)"""
+        lib().orc_set_max_visits(self.h, int(k))
 
     def trace(self, on=True):
         lib().orc_trace(self.h, int(on))

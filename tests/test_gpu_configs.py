@@ -363,6 +363,66 @@ def c3_climb():
     return codes, dt, back, s, moves, e.get_tree().tolist(), e.tie_state()
 
 
+def test_c3_benchmarked_climb_equals_the_oracle(c3_climb):
+    """bench.py's random_start.plain_climb (C3, random topology 2024, tie seed 1) against the ORACLE at full size: every accepted
+    move with its length, the final topology and the state the tie stream is left in.  (The fixture is the host-driven loop; the
+    tests below hold the persistent kernel, 98 and 25 workgroups, and eight concurrent climbs to the same list.)"""
+    from oracle import pyoracle as po
+    codes, dt, back, s, moves, final, rng = c3_climb
+    o = po.Oracle(codes)
+    o.set_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 1)
+    o.trace(True)
+    assert o.optimize_spr(1, 6) == s
+    assert [x.tolist() for x in o.get_moves()] == moves
+    assert o.get_tree().tolist() == final
+    assert o.tie_state() == rng
+
+
+@pytest.mark.parametrize("opts", [{}, {"ufb_pipe": 0}, {"ufb_fast": 0}])
+def test_c4_tracked_climb_first_visits_equal_the_oracle(opts):
+    """-bb at full size against the ORACLE: the tracked climb of bench.py's bb_flow (C3 alignment, random topology 2024, tie seed 1)
+    with 16 samples, cut short behind 240 prune-node visits (option max_visits / orc_set_max_visits; ~50 accepted moves, ~7 000
+    booked trees) -- every book: accepted moves, topology, treels_logl, boot_logl / boot_counts / boot_trees and the trees
+    themselves, the number of draws and the state of the tie stream.  All three ways through the loop."""
+    from helpers import same_topology
+    from mpboot_amd import engine, trees
+    from oracle import pyoracle as po
+    codes, dt = _workload("C3")
+    P = codes.shape[1]
+    samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=1000).astype(np.uint16)[:16]
+    back = trees.random_topology(codes.shape[0], np.random.default_rng(2024))
+    K = 240
+    e = engine.FitchEngine(codes, datatype=dt)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    e.set_option("max_visits", K)
+    o = po.Oracle(codes)
+    o.set_max_visits(K)
+    o.trace(True)
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.ufboot_attach(samples)
+        x.set_tree(back)
+        x.seed_ties(mode, 1)
+    e.reset_node_order()
+    se, so = e.optimize_spr(1, 6), o.optimize_spr(1, 6)
+    assert se == so
+    em = [x.tolist() for x in e.moves()]
+    assert len(em[0]) > 20 and em == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    assert e.tie_state() == o.tie_state()
+    assert len(e.ufboot_tree_logl()) > 3000 and e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+    le, ce, te = e.ufboot_state()
+    lo, co, to = o.ufboot_state()
+    assert le.tolist() == lo.tolist() and ce.tolist() == co.tolist() and te.tolist() == to.tolist()
+    assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws() and o.ufboot_bad() == 0
+    for t in sorted(set(te.tolist())):
+        if t >= 0:
+            assert same_topology(e.ufboot_tree(t), o.ufboot_tree(t), e.n)
+    if not opts:
+        assert e.get_option("ufb_early_batches") > 0          # (the default really took decisions from the costs)
+
+
 @pytest.mark.parametrize("tile", [1, 4])
 def test_c3_device_climb_equals_host_batches(c3_climb, tile):
     """random_start.plain_climb of bench.py at full size: the persistent kernel (98 co-resident workgroups at VW = 1, 25 at VW = 4,
