@@ -1272,7 +1272,7 @@ def main():
             res["concurrent_climbs"] = conc
         if startup is not None:
             res["start_trees"] = startup
-            if not args.no_cpu and world == 1:
+            if not args.no_cpu and world == 1 and not profiled:
                 startup["cpu_baseline"] = start_trees_cpu_baseline(names, letters, alphabet, args.maxtrav, startup["trees"])
                 cb = startup["cpu_baseline"]
                 if cb:
@@ -1317,7 +1317,9 @@ def main():
             res["random_start"] = nondeg
             if not args.no_cpu and world == 1:
                 nondeg["plain_climb"]["cpu_baseline"] = climb_cpu_baseline(names, letters, alphabet, back_r, args.maxtrav)
-                nondeg["plain_climb"]["through_reference_binding"] = shim_climb_leg(eng, names, letters, alphabet, back_r, args.maxtrav)
+                # (spr_shim_driver is a GPU program: not started from a process a profiler has handed the GPU to)
+                if not profiled:
+                    nondeg["plain_climb"]["through_reference_binding"] = shim_climb_leg(eng, names, letters, alphabet, back_r, args.maxtrav)
         if ufb is not None:
             algo_ops = 2.0 * ufb["insertion_tests"] * (eng.W * 32) * ufb["samples_local"]
             kms = ufb["reps_kernel_ms"]

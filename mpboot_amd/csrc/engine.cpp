@@ -2023,6 +2023,9 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_quiet") { ufb_quiet_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "grow_device") { grow_device_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "grow_tile") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) { set_error("grow_tile: 0 (fitted), 1, 2, 4 or 8"); return MPF_E_INVALID; } grow_vw_ = (int)v; return MPF_OK; }
+  if (key == "grow_fault") { grow_fault_ = v; return MPF_OK; }
   if (key == "max_visits") { max_visits_ = std::max<int64_t>(0, v); return MPF_OK; }
   if (key == "small_batch_max") { small_batch_max_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 30)); return MPF_OK; }
   if (key == "ufb_moot") { ufb_moot_ = v ? 1 : 0; return MPF_OK; }
@@ -2109,6 +2112,13 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "timing") *v = timing_;
   else if (key == "ufb_fast") *v = ufb_fast_;
   else if (key == "ufb_quiet") *v = ufb_quiet_;
+  else if (key == "grow_device") *v = grow_device_;
+  else if (key == "grow_tile") *v = grow_vw_;
+  else if (key == "grow_launches") *v = (int64_t)grow_launches_;
+  else if (key == "grow_steps") *v = (int64_t)grow_steps_;
+  else if (key == "grow_us") *v = (int64_t)(grow_ms_total_ * 1000.0);
+  else if (key == "grow_last_err") *v = grow_last_err_;
+  else if (key.rfind("grow_ticks_", 0) == 0 && key.size() == 12 && key[11] >= '0' && key[11] <= '6') *v = (int64_t)grow_phase_ticks_[key[11] - '0'];
   else if (key == "max_visits") *v = max_visits_;
   else if (key == "ufb_moot") *v = ufb_moot_;
   else if (key == "ufb_cut_batch") *v = ufb_cut_batch_;

@@ -460,6 +460,24 @@ class Engine {
   inline int rec_of(uint32_t cid) const { return cid < (uint32_t)n_ ? 3 * ((int)cid + 1) : 3 * (n_ + 1 + (int)(cid - (uint32_t)n_) / 3) + (int)((cid - (uint32_t)n_) % 3u); }
   int climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle, uint32_t *reason, uint32_t *n_moves);
 
+  // ---- device-resident stepwise addition (grow.hip; host/climb_host.cpp): one k_grow launch adds every taxon behind the start
+  // tree, the insertions it reports are replayed onto the host's topology mirror
+  struct GrowDev {
+    DevBuf<uint16_t> init;
+    DevBuf<uint32_t> xrow, park, ucp, out;
+    PinBuf<uint16_t> h_init;
+    PinBuf<uint32_t> h_out;
+  } gd_;
+  int grow_device_ = 1;                          // option "grow_device": 0 = the host's loop (one refresh + one scan + one round trip per taxon)
+  int grow_vw_ = 0;                              // option "grow_tile": words per lane group of k_grow (0 = fitted: at most 32 workgroups)
+  int64_t grow_fault_ = 0;                       // tests: fault injected into the next k_grow launch
+  uint64_t grow_launches_ = 0, grow_steps_ = 0;
+  double grow_ms_total_ = 0;
+  int grow_last_err_ = 0;                        // reason * 100 + err of the last launch that did not come back clean
+  unsigned long long grow_phase_ticks_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int grow_fit_vw() const;
+  int grow_segment(const std::vector<int> &perm, uint32_t len0, uint32_t *best_per_step, int32_t *insert_per_step, bool *done);
+
   // ---- configuration / alignment
   int n_ = 0, P_ = 0, datatype_ = 0, keep_all_ = 0, dev_ = 0, sref_ = 4, und_ = 15;
   int gmap_[32] = {0};                          // MPF_GENERIC: symbol code -> state row of the engine (-1: symbol not in use)

@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "../csrc/engine.hpp"
+#include "../csrc/grow.hpp"
 
 namespace mpf {
 
@@ -260,6 +261,178 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   stats.climb_nodes += h.n_scanned_nodes;
   stats.climb_moves += h.n_moves;
   stats.climb_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MPF_OK;
+}
+
+// ---- device-resident stepwise addition (csrc/grow.hip) ---------------------------------------------------------------------
+// The tree built so far goes down as a ROOTED tree hung from the start tip: per node its parent, its two children in the order
+// stepwiseAddition visits them (q->next->back, then q->next->next->back, reference sprparsimony.cpp:3015-3016), pre-order position,
+// subtree size, depth and the vector id of its "down" record.  The kernel adds the taxa perm[ntips_ + 1 ..] and reports, per
+// step, the branch it chose and the length of the tree; the insertions are replayed here on the topology mirror exactly as
+// Engine::addition_phase applies them (:3158-3171).  *done = false: the kernel could not be used or did not come back clean --
+// nothing of the engine's state has been touched except the vectors, the caller's own loop builds the tree.
+int Engine::grow_fit_vw() const
+{
+  if (g_.S != 4) return 1;
+  if (grow_vw_ > 0) return grow_vw_;
+  for (int vw = 1; vw <= 8; vw *= 2)
+    if (grow_tiles(g_, vw) <= 32) return vw;
+  return 8;
+}
+
+int Engine::grow_segment(const std::vector<int> &perm, uint32_t len0, uint32_t *best_per_step, int32_t *insert_per_step, bool *done)
+{
+  *done = false;
+  const int n = n_;
+  const int steps = n - ntips_;
+  if (steps <= 0) return MPF_OK;
+  const int vw = grow_fit_vw();
+  const int tiles = grow_tiles(g_, vw), waves = grow_waves(g_, vw);
+  const size_t N2 = 2 * (size_t)n;
+  const auto t0 = std::chrono::steady_clock::now();
+  // ---- the rooted start tree
+  std::vector<uint16_t> init(8 * N2, (uint16_t)kGrowNone);
+  uint16_t *par = init.data(), *ch1 = par + N2, *ch2 = ch1 + N2, *pos = ch2 + N2, *sz = pos + N2, *dep = sz + N2, *dc = dep + N2, *ord = dc + N2;
+  auto node_of = [&](int r) -> uint32_t { const int v = num(r); return v <= n ? (uint32_t)(v - 1) : (uint32_t)(n + (v - n - 1)); };
+  const int f = start_;
+  uint32_t m0 = 0;
+  {
+    struct Fr { int rec; uint32_t parent; uint32_t depth; };
+    std::vector<Fr> st;
+    st.push_back(Fr{back_[f], kGrowNone, 0u});
+    while (!st.empty()) {
+      const Fr fr = st.back();
+      st.pop_back();
+      const int c = fr.rec;
+      const uint32_t u = node_of(c);
+      par[u] = (uint16_t)fr.parent; dep[u] = (uint16_t)fr.depth; pos[u] = (uint16_t)m0; ord[m0++] = (uint16_t)u;
+      dc[u] = (uint16_t)slot(c);
+      sz[u] = 1;
+      if (!tip(c)) {
+        const int c1 = back_[nx(c)], c2 = back_[nx(nx(c))];
+        ch1[u] = (uint16_t)node_of(c1); ch2[u] = (uint16_t)node_of(c2);
+        st.push_back(Fr{c2, u, fr.depth + 1u});
+        st.push_back(Fr{c1, u, fr.depth + 1u});
+      }
+    }
+    for (int i = (int)m0 - 1; i >= 0; i--) {
+      const uint32_t u = ord[i];
+      if (ch1[u] != kGrowNone) sz[u] = (uint16_t)(1u + sz[ch1[u]] + sz[ch2[u]]);
+    }
+  }
+  if (m0 != (uint32_t)(2 * ntips_ - 3)) { set_error("device addition: the start tree is not a binary tree below the start tip"); return MPF_E_STATE; }
+  // per step: the tip, and the inner node the reference takes for it -- tr->nodep[nextnode++], whichever node and record that
+  // is after earlier nodeRectifierPars calls; q->next->next becomes its down record
+  std::vector<uint16_t> tips(3 * (size_t)steps);
+  for (int s = 0; s < steps; s++) {
+    tips[(size_t)s] = (uint16_t)slot(nodep_[(size_t)perm[(size_t)(ntips_ + 1 + s)]]);
+    const int q = nodep_[(size_t)(nextnode_ + s)];
+    if (tip(q)) { set_error("device addition: nodep names a tip where an inner node is due"); return MPF_E_STATE; }
+    tips[(size_t)steps + (size_t)s] = (uint16_t)node_of(q);
+    tips[2 * (size_t)steps + (size_t)s] = (uint16_t)slot(nx(nx(q)));
+  }
+  // ---- buffers
+  const size_t hdr_words = (sizeof(GrowHeader) + 3) / 4, out_words = hdr_words + 2 * (size_t)steps;
+  const size_t xstride = (size_t)n + N2 / 32 + 8;
+  const size_t slot_words = grow_vec_words(g_, vw);
+  HIPCHK(gd_.init.reserve(8 * N2 + 3 * (size_t)steps));
+  HIPCHK(gd_.xrow.reserve(2 * (size_t)tiles * xstride));
+  HIPCHK(gd_.park.reserve((size_t)tiles * ((size_t)waves * kGrowParkPart + kGrowParkSkel) * slot_words));
+  HIPCHK(gd_.ucp.reserve((size_t)tiles * kGrowMaxParts * slot_words));
+  HIPCHK(gd_.out.reserve(out_words));
+  HIPCHK(gd_.h_init.reserve(8 * N2 + 3 * (size_t)steps));
+  HIPCHK(gd_.h_out.reserve(out_words));
+  std::memcpy(gd_.h_init.p, init.data(), 8 * N2 * sizeof(uint16_t));
+  std::memcpy(gd_.h_init.p + 8 * N2, tips.data(), 3 * (size_t)steps * sizeof(uint16_t));
+  GrowHeader h;
+  std::memset(&h, 0, sizeof(h));
+  h.rng = rng_.state;
+  std::memcpy(gd_.h_out.p, &h, sizeof(h));
+  GrowParams p;
+  p.vec = d_vec_;
+  p.n = (uint32_t)n; p.nslots = (uint32_t)nslots_; p.Wp = (uint32_t)g_.Wp; p.tiles = (uint32_t)tiles;
+  p.m0 = m0; p.steps = (uint32_t)steps; p.tie_mode = (uint32_t)tie_mode_; p.len0 = len0;
+  p.root_cid = slot(f); p.root_node = node_of(back_[f]);
+  p.init = gd_.init.p; p.tips = gd_.init.p + 8 * N2; p.xnode = p.tips + steps; p.xdcid = p.tips + 2 * (size_t)steps;
+  p.xrow = gd_.xrow.p; p.xstride = (uint32_t)xstride;
+  p.park = gd_.park.p; p.ucp = gd_.ucp.p;
+  p.hdr = reinterpret_cast<GrowHeader *>(gd_.out.p);
+  p.out = gd_.out.p + hdr_words;
+  p.fault = (uint32_t)grow_fault_;
+  grow_fault_ = 0;
+  GateHold hold;
+  {
+    ClimbGate &g = g_gate[dev_ & 63];
+    const size_t lds = grow_lds_bytes(g_, n, vw);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / std::max<size_t>(lds, 1)));
+    std::unique_lock<std::mutex> lk(g.m);
+    if (!g.cus) {
+      int c = 0;
+      if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || c <= 0) c = 256;
+      g.cus = c;
+    }
+    const int need = (tiles + per_cu - 1) / per_cu;
+    const int cap = std::max(1, g.cus * 85 / 100);
+    g.cv.wait(lk, [&] { return g.used == 0 || g.used + need <= cap; });
+    g.used += need;
+    hold.g = &g;
+    hold.n = need;
+  }
+  HIPCHK(hipMemcpyAsync(gd_.init.p, gd_.h_init.p, (8 * N2 + 3 * (size_t)steps) * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
+  HIPCHK(hipMemcpyAsync(gd_.out.p, gd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st_));
+  shadow_ok_ = false;                              // (k_grow writes vectors in the row-major store only)
+  HIPCHK(launch_grow(st_, g_, vw, p));
+  HIPCHK(hipMemcpyAsync(gd_.h_out.p, gd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    long spins = 0;
+    while ((q = hipStreamQuery(st_)) == hipErrorNotReady) {
+      if ((++spins & 63) == 0) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 30.0) {
+          set_error("device addition: the launch did not finish within 30 s");
+          invalidate_all();
+          broken_ = true;
+          return MPF_E_STATE;
+        }
+        std::this_thread::yield();
+      }
+    }
+    if (q != hipSuccess) { invalidate_all(); set_error(std::string("device addition: ") + hipGetErrorString(q)); return MPF_E_HIP; }
+  }
+  hold.release();
+  std::memcpy(&h, gd_.h_out.p, sizeof(h));
+  grow_launches_++;
+  grow_ms_total_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  invalidate_all();                                // (whatever the kernel did, only it knows which vectors are whose)
+  if (h.reason != GROW_DONE || h.steps_done != (uint32_t)steps) {
+    grow_last_err_ = (int)(h.reason * 100u + h.err);
+    return MPF_OK;                                 // the caller's own loop builds the tree (same seed, same draws: nothing was taken over)
+  }
+  // ---- replay the insertions on the mirror (buildNewTip + the hookups of :3158-3171)
+  const uint32_t *out = gd_.h_out.p + hdr_words;
+  for (int s = 0; s < steps; s++) {
+    const int nextsp = ++ntips_;
+    const int pr = nodep_[(size_t)perm[(size_t)nextsp]];
+    const int q = nodep_[(size_t)nextnode_++];
+    back_[(size_t)pr] = q;
+    back_[(size_t)q] = pr;
+    const int ins = rec_of(out[2 * s]);
+    const int r = back_[(size_t)ins];
+    hookup(nx(q), ins);
+    hookup(nx(nx(q)), r);
+    best_ = out[2 * s + 1];
+    insert_rec_ = ins;
+    if (best_per_step) best_per_step[nextsp] = best_;
+    if (insert_per_step) insert_per_step[nextsp] = ins;
+    stats.insertion_tests += (uint64_t)(2 * (nextsp - 1) - 3);
+  }
+  rng_.state = h.rng;
+  topo_epoch_++;
+  kids_dirty_ = true;
+  for (int k = 0; k < 7; k++) grow_phase_ticks_[k] += h.tph[k];
+  grow_steps_ += (uint64_t)steps;
+  *done = true;
   return MPF_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "../csrc/engine.hpp"
+#include "../csrc/grow.hpp"
 #include "simd_util.hpp"
 
 namespace mpf {
@@ -284,6 +285,13 @@ int Engine::addition_phase(int64_t seed, uint32_t *best_per_step, int32_t *inser
   {
     int rc = tree_length(&len);
     if (rc) return rc;
+  }
+  // the whole loop below as ONE persistent kernel (k_grow, csrc/grow.hip) where it applies: same insertions, same draws
+  if (grow_device_ && !rand_fn_ && !sankoff_ && grow_supported(g_, n_)) {
+    bool done = false;
+    int rc = grow_segment(perm, len, best_per_step, insert_per_step, &done);
+    if (rc) return rc;
+    if (done) return MPF_OK;
   }
   while (ntips_ < n) {
     best_ = (uint32_t)INT_MAX;

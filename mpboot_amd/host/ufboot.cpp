@@ -1669,6 +1669,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   // engine believes about the views and the pending scan, so that the next call starts from the topology alone
   struct Abort {
     Engine *e;
+    Worker *w;
     bool ok = false;
     ~Abort()
     {
@@ -1680,9 +1681,20 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       e->cnt_copy_pending_ = false;
       e->pending_scores_ = false;
       e->invalidate_all();
-      if (e->ufb_) { e->ufb_->log.clear(); e->ufb_->rt_valid = false; }
+      // (the log worker booked trees without growing the reference counts: they follow treels on EVERY way out, or a later
+      //  climb on the other paths -- which push both in lockstep -- would index past their end)
+      w->finish();
+      if (e->ufb_) {
+        UfbState &u = *e->ufb_;
+        u.log.clear();
+        u.rt_valid = false;
+        u.lookups += w->sc.lookups; u.stored += w->sc.stored; u.t_lookup += w->sc.t_lookup;
+        w->sc.lookups = w->sc.stored = 0;
+        w->sc.t_lookup = 0;
+        if (u.refs.size() < u.treels.size()) u.refs.resize(u.treels.size(), 0);
+      }
     }
-  } abort_guard{this};
+  } abort_guard{this, &worker};
   uint64_t n_draws = 0;                            // (added to the tracker's counter at the end: its word shares a cache line with the worker's)
 
   // plan + enqueue the whole chain of the batch [i, i + b): refresh, masked scan, mid (C <- 0, self slots, scan results to the host),
@@ -1865,14 +1877,22 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         n_ev = u.p_flag_e[B.par].p[0];
         if (n_ev > u.ev.cap) {
           if (prelaunched) { set_error("online UFBoot: event buffer overflow behind a batch launched early"); return MPF_E_STATE; }
-          UCHK(u.ev.reserve((size_t)n_ev));
           const uint32_t *dsm = u.st_dev ? u.st_dev : u.thr.p;
-          UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
-          UCHK(launch_ufb_events(st_, u.info.p, d_out(), dsm, dsm + B.n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, dsm + 3 * B.n_parts, B.n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));      // (staging: thr | home | prune-node ends | best)
+          // (the first extraction ran under the device's cut -- rows behind the batch's certain end were not multiplied --, this one
+          //  does not and may find more: extract until the count it reports fits the buffer it wrote to)
+          for (;;) {
+            UCHK(u.ev.reserve((size_t)n_ev));
+            UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
+            UCHK(launch_ufb_events(st_, u.info.p, d_out(), dsm, dsm + B.n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, dsm + 3 * B.n_parts, B.n_idx, u.cmin.p, u.pre.p,
+                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));      // (staging: thr | home | prune-node ends | best)
+            UCHK(u.h_col.reserve(4));
+            UCHK(hipMemcpyAsync(u.h_col.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+            // (nothing else is in flight: both pinned buffers follow the device buffer, which the overflow rule is stated in)
+            UCHK(hipStreamSynchronize(st_));
+            n_ev = (uint32_t)u.h_col.p[0];
+            if (n_ev <= u.ev.cap) break;
+          }
           B.n_eager = 0;
-          // (nothing else is in flight: both pinned buffers follow the device buffer, which the overflow rule is stated in)
-          UCHK(hipStreamSynchronize(st_));
           for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
         }
         if (n_ev > B.n_eager) {

@@ -22,3 +22,5 @@ for rep in range(3):
     t0 = time.perf_counter()
     s = e.make_parsimony_tree(1234, 0)
     print(f"{wl} {' '.join(sys.argv[2:])}: {time.perf_counter() - t0:.4f} s, score {s}")
+print("k_grow: launches", e.get_option("grow_launches"), "steps", e.get_option("grow_steps"), "us", e.get_option("grow_us"), "last_err", e.get_option("grow_last_err"),
+      "| phase us of the launches (plan, skeleton, parts, exchange, decide, insert, path):", [e.get_option("grow_ticks_%d" % k) / 100.0 for k in range(7)])
