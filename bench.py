@@ -562,7 +562,8 @@ def main():
                     help="independent SPR climbs side by side on one GPU (one engine per host thread): the concurrent_climbs leg (0 = skip)")
     ap.add_argument("--climb-tile", type=int, default=4, help="words per lane group of k_climb in the concurrent-climbs leg (4: 25, 8: 13 workgroups per C3 climb)")
     ap.add_argument("--c2-engines", type=int, default=16, help="concurrent engines (host threads) in the C2 concurrent-climbs leg")
-    ap.add_argument("--start-engines", type=int, default=6, help="concurrent engines (host threads) per GPU in the start-trees leg")
+    ap.add_argument("--start-engines", type=int, default=12,
+                    help="concurrent engines (host threads) per GPU in the start-trees leg (k_grow: 25 workgroups per C3 tree, two trees per CU)")
     ap.add_argument("--shard-online", default="auto", choices=["auto", "0", "1"],
                     help="online UFBoot phase on several GPUs: 1 = samples sharded, events all-gathered per scan batch; 0 = every rank keeps all samples "
                          "(replicas); auto = sharded from shard.ONLINE_SHARD_MIN_SAMPLES samples on (below, the exchange costs the pipelined climb more than the share saves)")
@@ -1126,13 +1127,24 @@ def main():
                     sc = x.make_parsimony_tree(sd, args.maxtrav)
                     best = sc if best is None else min(best, sc)
                 return best
+            def ras_warm(i, x):                     # (an engine's first tree allocates the kernel's scratch: not a step of the phase)
+                x.seed_ties(engine.TIE_RANDOM, 1)
+                x.make_parsimony_tree(1, args.maxtrav)
+                return None
+            run_threads(k_e, ras_warm)
+            g0 = sum(x.get_option("grow_launches") for x in pool[:k_e])
+            barrier()
             t_ras, bests = run_threads(k_e, ras_fn)
             barrier()
+            g1 = sum(x.get_option("grow_launches") for x in pool[:k_e])
             bb = [b for b in bests if b is not None]
             startup = {"trees": args.start_trees, "seconds": t_ras, "engines_per_gpu": k_e, "best_score_rank0": int(min(bb)) if bb else None,
                        "seconds_per_tree_per_engine": t_ras * k_e / max(1, len(units)),
+                       "trees_grown_in_k_grow": int(g1 - g0),
                        "what": "%d randomized stepwise-addition trees + SPR climb (radius %d) each, as the reference's start-up builds them "
-                               "(phyloanalysis.cpp:1270-1317); tree u on rank u %% n_gpus" % (args.start_trees, args.maxtrav)}
+                               "(phyloanalysis.cpp:1270-1317); tree u on rank u %% n_gpus.  The addition loop of a tree is ONE persistent kernel "
+                               "launch (k_grow: the rooted tree in LDS, one vector load per branch and added taxon, the insertions replayed on "
+                               "the host's mirror); trees_grown_in_k_grow counts the launches that came back clean" % (args.start_trees, args.maxtrav)}
         if world == 1 and args.workload == "C3" and args.random_start_leg:
             # BASELINE config 2 (200 taxa x 10 000 patterns): a full SPR hill climb from a random tree
             letters2, names2 = synth.workload("C2")

@@ -28,12 +28,12 @@ template <int KS, int VW> struct GCfg {
   static constexpr int R = KS * VW;                                   // registers per vector tile
   static constexpr int NW = R <= 2 ? 16 : 8;
   static constexpr int NT = NW * 64;
-  static constexpr int PF = R <= 4 ? 4 : 2;                           // expansions whose child vectors are requested together
+  static constexpr int PF = R <= 2 ? 4 : 2;                           // expansions whose child vectors are requested together (two sets in rotation)
 };
 
 struct GSh {
   uint32_t m, step, ok, err, exit_reason, root, len, S;
-  uint32_t nskel, nparts, part_next, nzero, path_n, ins_pos, best, pad0;
+  uint32_t nskel, nparts, part_next, nzero, path_n, ins_pos, best, npub, skel_done, pad0[3];
   uint32_t wcnt[16];
   unsigned long long rng, draws;
   unsigned long long tph[8], tlast;
@@ -79,9 +79,13 @@ __device__ __forceinline__ double g_tie_draw(unsigned long long &st)
   return (double)st * 5.4210108624275222e-20;            // :268
 }
 
-// the walk of the skeleton (SKEL: wave 0, expansions = sh.nskel nodes of G.skl) or of one part (root r, at most 64 nodes).
+__device__ __forceinline__ void publish_parts(GSh &sh, uint32_t np, int lane);
+
+// the walk of the skeleton (SKEL: wave 0, expansions = sh.nskel nodes of G.skl) or of one part (root r, at most 128 nodes).
 // Ur = U(r).  Books the candidate costs of every expanded node's two children; U of the first child stays in registers, U of a
-// second child that is expanded later waits in `park` at the level of its parent.
+// second child that is expanded later waits in `park` at the level of its parent.  The children's vectors of the next PF
+// expansions are requested before the current PF are worked on (two register sets in rotation): the skeleton's walk is one
+// wave on its own, there is nobody else to hide its memory round trips.
 template <int KS, int VW, bool SKEL>
 __device__ __forceinline__ void walk(const Gx<KS, VW> &G, GSh &sh, uint32_t r, const QT<KS, VW> &Ur, const QT<KS, VW> &T, uint32_t *park,
                                      uint32_t *ucp)
@@ -91,47 +95,54 @@ __device__ __forceinline__ void walk(const Gx<KS, VW> &G, GSh &sh, uint32_t r, c
   const uint32_t S = sh.S;
   const uint32_t depr = rfl((uint32_t)G.dep[r]);
   uint32_t E, base = 0;
-  unsigned long long todo = 0ull;
+  unsigned long long todo0 = 0ull, todo1 = 0ull;
   if constexpr (SKEL) {
     E = sh.nskel;
   } else {
     base = rfl((uint32_t)G.pos[r]);
     const uint32_t cnt = rfl((uint32_t)G.sz[r]);
-    bool inner = false;
-    if ((uint32_t)lane < cnt) inner = G.sz[G.ord[base + (uint32_t)lane]] > 1u;
-    todo = __ballot((int)inner);
-    E = (uint32_t)__builtin_popcountll(todo);
+    bool in0 = false, in1 = false;
+    if ((uint32_t)lane < cnt) in0 = G.sz[G.ord[base + (uint32_t)lane]] > 1u;
+    if (64u + (uint32_t)lane < cnt) in1 = G.sz[G.ord[base + 64u + (uint32_t)lane]] > 1u;
+    todo0 = __ballot((int)in0);
+    todo1 = __ballot((int)in1);
+    E = (uint32_t)__builtin_popcountll(todo0) + (uint32_t)__builtin_popcountll(todo1);
   }
-  uint32_t np = SKEL ? sh.nparts : 0u;
-  QT<KS, VW> u1, u2, par, d1[PF], d2[PF];
-  uint32_t en[PF], ea[PF], eb[PF];
-  for (uint32_t blk = 0; blk < E; blk += (uint32_t)PF) {
+  uint32_t np = SKEL ? sh.nparts : 0u, np_pub = np;
+  (void)np_pub;
+  QT<KS, VW> u1, u2, par;
+  struct Set { QT<KS, VW> d1[PF], d2[PF]; uint32_t en[PF], ea[PF], eb[PF]; } A, B;
+  uint32_t last_e = r;
+  // requests of the expansions [blk, blk + PF) into one register set (clamped past the end: the requests stay unconditional)
+  auto issue = [&](Set &X, uint32_t blk) {
 #pragma unroll
     for (int i = 0; i < PF; i++) {
       const uint32_t q = blk + (uint32_t)i;
-      uint32_t e;
+      uint32_t e = last_e;
       if (q < E) {
         if constexpr (SKEL) {
           e = rfl((uint32_t)G.skl[q]);
         } else {
-          const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
-          todo &= todo - 1ull;
+          uint32_t bit;
+          if (todo0) { bit = (uint32_t)__builtin_ctzll(todo0); todo0 &= todo0 - 1ull; }
+          else { bit = 64u + (uint32_t)__builtin_ctzll(todo1); todo1 &= todo1 - 1ull; }
           e = rfl((uint32_t)G.ord[base + bit]);
         }
-      } else {
-        e = en[i > 0 ? i - 1 : 0];                                    // (clamped: the requests stay unconditional)
+        last_e = e;
       }
-      en[i] = e;
-      ea[i] = rfl((uint32_t)G.ch1[e]);
-      eb[i] = rfl((uint32_t)G.ch2[e]);
-      g_ld<KS, VW>(G, d1[i], rfl((uint32_t)G.dcid[ea[i]]));
-      g_ld<KS, VW>(G, d2[i], rfl((uint32_t)G.dcid[eb[i]]));
+      X.en[i] = e;
+      X.ea[i] = rfl((uint32_t)G.ch1[e]);
+      X.eb[i] = rfl((uint32_t)G.ch2[e]);
+      g_ld<KS, VW>(G, X.d1[i], rfl((uint32_t)G.dcid[X.ea[i]]));
+      g_ld<KS, VW>(G, X.d2[i], rfl((uint32_t)G.dcid[X.eb[i]]));
     }
+  };
+  auto work = [&](Set &X, uint32_t blk) {
 #pragma unroll
     for (int i = 0; i < PF; i++) {
       const uint32_t q = blk + (uint32_t)i;
       if (q < E) {
-        const uint32_t e = en[i], a = ea[i], b = eb[i];
+        const uint32_t e = X.en[i], a = X.ea[i], b = X.eb[i];
         const uint32_t lev = rfl((uint32_t)G.dep[e]) - depr;
         if (e == r) {
           par = Ur;
@@ -140,10 +151,10 @@ __device__ __forceinline__ void walk(const Gx<KS, VW> &G, GSh &sh, uint32_t r, c
           if (rfl((uint32_t)G.ch1[pe]) == e) par = u1;                // first child: its parent was the expansion just before
           else s_ld<KS, VW>(park, lev - 1u, par, lane);
         }
-        q_fitch<KS, VW>(u1, par, d2[i]);                              // U(a) = fitch(U(e), D(b))
-        q_fitch<KS, VW>(u2, par, d1[i]);
-        const uint32_t j1 = q_join<KS, VW>(u1, d1[i], T);
-        const uint32_t j2 = q_join<KS, VW>(u2, d2[i], T);
+        q_fitch<KS, VW>(u1, par, X.d2[i]);                            // U(a) = fitch(U(e), D(b))
+        q_fitch<KS, VW>(u2, par, X.d1[i]);
+        const uint32_t j1 = q_join<KS, VW>(u1, X.d1[i], T);
+        const uint32_t j2 = q_join<KS, VW>(u2, X.d2[i], T);
         if (G.cnt_lane) {
           __hip_atomic_fetch_add(G.cost + rfl((uint32_t)G.pos[a]) + G.zero, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(G.cost + rfl((uint32_t)G.pos[b]) + G.zero, j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -166,12 +177,29 @@ __device__ __forceinline__ void walk(const Gx<KS, VW> &G, GSh &sh, uint32_t r, c
         }
       }
     }
+  };
+  if (E > 0u) issue(A, 0u);
+  for (uint32_t blk = 0; blk < E; blk += 2u * (uint32_t)PF) {
+    issue(B, blk + (uint32_t)PF);
+    work(A, blk);
+    issue(A, blk + 2u * (uint32_t)PF);
+    work(B, blk + (uint32_t)PF);
+    // (the parts left so far: published with the stores in front of the count; waiting for them also waits for the requests that
+    //  are out, so not more often than every other block)
+    if constexpr (SKEL) { if (np != np_pub) { publish_parts(sh, np, lane); np_pub = np; } }
   }
   if constexpr (SKEL) { if (lane == 0) sh.nparts = np; }
 }
 
+// the parts the skeleton's walk has left so far become visible to the waiting waves: their roots' U (HBM) first, then the count
+__device__ __forceinline__ void publish_parts(GSh &sh, uint32_t np, int lane)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&sh.npub, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int KS, int VW>
-__global__ __launch_bounds__((GCfg<KS, VW>::NT)) void k_grow(GrowParams P)
+__device__ __forceinline__ void grow_body(const GrowParams &P)
 {
   constexpr uint32_t kThreads = GCfg<KS, VW>::NT, kNW = GCfg<KS, VW>::NW;
   constexpr int PF = GCfg<KS, VW>::PF;
@@ -281,7 +309,7 @@ __global__ __launch_bounds__((GCfg<KS, VW>::NT)) void k_grow(GrowParams P)
     if (tid == 0) {
       uint32_t S = m / (3u * kNW);
       S = S < 8u ? 8u : S > 64u ? 64u : S;
-      sh.S = S; sh.nparts = 0; sh.part_next = 0; sh.nskel = 0;
+      sh.S = S; sh.nparts = 0; sh.part_next = 0; sh.nskel = 0; sh.npub = 0; sh.skel_done = 0;
     }
     for (uint32_t i = (uint32_t)tid; i < m; i += kThreads) G.cost[i] = 0u;
     __syncthreads();
@@ -306,7 +334,8 @@ __global__ __launch_bounds__((GCfg<KS, VW>::NT)) void k_grow(GrowParams P)
     }
     __syncthreads();
     MPF_GMARK(0);
-    // ---- (2) skeleton: the root's child first (its U is the start tip's vector)
+    // ---- (2) skeleton: the root's child first (its U is the start tip's vector).  The other waves do not wait for the walk to end:
+    // they take the parts it leaves as it goes (3).
     if (wave == 0) {
       const uint32_t c0 = sh.root;
       QT<KS, VW> U0, D0;
@@ -323,19 +352,26 @@ __global__ __launch_bounds__((GCfg<KS, VW>::NT)) void k_grow(GrowParams P)
           if (lane == 0) { G.parts[0] = (uint16_t)c0; sh.nparts = 1u; }
         }
       }
+      publish_parts(sh, rfl(*(volatile uint32_t *)&sh.nparts), lane);
+      if (lane == 0) __hip_atomic_store(&sh.skel_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      MPF_GMARK(1);
     }
-    __syncthreads();
-    MPF_GMARK(1);
-    // ---- (3) parts
-    {
-      const uint32_t np = sh.nparts;
+    // ---- (3) parts: a wave claims the next index and waits until the skeleton's walk has got that far (or is over)
+    for (;;) {
+      const uint32_t pi = wave_fetch_add(&sh.part_next, 1u, lane);
+      bool have = false;
       for (;;) {
-        const uint32_t pi = wave_fetch_add(&sh.part_next, 1u, lane);
-        if (pi >= np) break;
-        QT<KS, VW> Ur;
-        s_ld<KS, VW>(ucp, pi, Ur, lane);
-        walk<KS, VW, false>(G, sh, rfl((uint32_t)G.parts[pi]), Ur, Tv, park_w, ucp);
+        const uint32_t done = rfl(__hip_atomic_load(&sh.skel_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const uint32_t pub = rfl(__hip_atomic_load(&sh.npub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (pi < pub) { have = true; break; }
+        if (done) break;                                     // (npub was read behind the flag: it is final)
+        __builtin_amdgcn_s_sleep(1);
       }
+      if (!have) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      QT<KS, VW> Ur;
+      s_ld<KS, VW>(ucp, pi, Ur, lane);
+      walk<KS, VW, false>(G, sh, rfl((uint32_t)G.parts[pi]), Ur, Tv, park_w, ucp);
     }
     __syncthreads();
     MPF_GMARK(2);
@@ -578,6 +614,13 @@ __global__ __launch_bounds__((GCfg<KS, VW>::NT)) void k_grow(GrowParams P)
 }
 
 template <int KS, int VW>
+__global__ __launch_bounds__((GCfg<KS, VW>::NT)) void k_grow(GrowParams P) { grow_body<KS, VW>(P); }
+// DNA tiles: held to 128 registers, so that TWO workgroups (two trees) share a CU -- one tree's waves alone leave its SIMDs idle
+// half of the time (one wave walks the skeleton, the parts wait for memory)
+template <int KS, int VW>
+__global__ __launch_bounds__((GCfg<KS, VW>::NT)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_grow_tight(GrowParams P) { grow_body<KS, VW>(P); }
+
+template <int KS, int VW>
 size_t g_lds_bytes(uint32_t n)
 {
   const size_t N2 = 2 * (size_t)n;
@@ -591,6 +634,12 @@ size_t g_lds_bytes(uint32_t n)
 }
 
 template <int KS, int VW>
+constexpr bool g_tight() { return KS == 1 && VW <= 4; }
+
+template <int KS, int VW>
+const void *g_kernel() { return g_tight<KS, VW>() ? reinterpret_cast<const void *>(&k_grow_tight<KS, VW>) : reinterpret_cast<const void *>(&k_grow<KS, VW>); }
+
+template <int KS, int VW>
 hipError_t g_launch(hipStream_t st, const GrowParams &p)
 {
   const size_t lds = g_lds_bytes<KS, VW>(p.n);
@@ -598,12 +647,22 @@ hipError_t g_launch(hipStream_t st, const GrowParams &p)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (lds > 64 * 1024 || attr_dev != dev) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grow<KS, VW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(g_kernel<KS, VW>(), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_grow<KS, VW>), dim3(p.tiles), dim3(GCfg<KS, VW>::NT), lds, st, p);
+  if constexpr (g_tight<KS, VW>()) hipLaunchKernelGGL((k_grow_tight<KS, VW>), dim3(p.tiles), dim3(GCfg<KS, VW>::NT), lds, st, p);
+  else hipLaunchKernelGGL((k_grow<KS, VW>), dim3(p.tiles), dim3(GCfg<KS, VW>::NT), lds, st, p);
   return hipGetLastError();
+}
+
+// workgroups of this launch shape that fit one CU together (registers, LDS): what the admission gate counts in
+template <int KS, int VW>
+int g_blocks_per_cu(uint32_t n)
+{
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g_kernel<KS, VW>(), GCfg<KS, VW>::NT, g_lds_bytes<KS, VW>(n)) != hipSuccess || nb < 1) nb = 1;
+  return nb;
 }
 
 }  // namespace
@@ -631,6 +690,14 @@ bool grow_supported(const Geometry &g, int n_taxa)
   if (n_taxa < 4 || 2 * (size_t)n_taxa > 8 * 512) return false;       // (the insertion moves at most 8 entries per thread)
   if ((uint32_t)n_taxa + 3u * (uint32_t)(n_taxa - 1) + 16u >= 0xFFFFu) return false;
   return grow_lds_bytes(g, n_taxa, 1) <= 150 * 1024;
+}
+
+int grow_blocks_per_cu(const Geometry &g, int n_taxa, int vw)
+{
+  if (g.S == 4) return vw == 1 ? g_blocks_per_cu<1, 1>((uint32_t)n_taxa) : vw == 2 ? g_blocks_per_cu<1, 2>((uint32_t)n_taxa)
+                       : vw == 8 ? g_blocks_per_cu<1, 8>((uint32_t)n_taxa) : g_blocks_per_cu<1, 4>((uint32_t)n_taxa);
+  if (g.S == 32) return g_blocks_per_cu<8, 1>((uint32_t)n_taxa);
+  return g_blocks_per_cu<5, 1>((uint32_t)n_taxa);
 }
 
 hipError_t launch_grow(hipStream_t st, const Geometry &g, int vw, const GrowParams &p)

@@ -64,7 +64,7 @@ struct GrowParams {
 };
 
 constexpr uint32_t kGrowNone = 0xFFFFu;
-constexpr uint32_t kGrowParkPart = 64;     // levels a part's walk can park (a part has at most 64 nodes)
+constexpr uint32_t kGrowParkPart = 128;    // levels a part's walk can park = the largest part (nodes): two ballots give its walk
 constexpr uint32_t kGrowParkSkel = 512;    // levels of the skeleton's walk (deeper: GROW_ERROR 3, the host's loop takes over)
 constexpr uint32_t kGrowMaxParts = 1024;
 
@@ -72,6 +72,7 @@ bool grow_supported(const Geometry &g, int n_taxa);
 int grow_tiles(const Geometry &g, int vw);
 int grow_waves(const Geometry &g, int vw);
 size_t grow_lds_bytes(const Geometry &g, int n_taxa, int vw);
+int grow_blocks_per_cu(const Geometry &g, int n_taxa, int vw);      // workgroups of the launch that fit one CU together (registers, LDS)
 size_t grow_vec_words(const Geometry &g, int vw);      // 32-bit words of one tile of a vector (R * 64)
 hipError_t launch_grow(hipStream_t st, const Geometry &g, int vw, const GrowParams &p);
 

@@ -363,8 +363,7 @@ int Engine::grow_segment(const std::vector<int> &perm, uint32_t len0, uint32_t *
   GateHold hold;
   {
     ClimbGate &g = g_gate[dev_ & 63];
-    const size_t lds = grow_lds_bytes(g_, n, vw);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / std::max<size_t>(lds, 1)));
+    const int per_cu = std::max(1, grow_blocks_per_cu(g_, n, vw));
     std::unique_lock<std::mutex> lk(g.m);
     if (!g.cus) {
       int c = 0;
