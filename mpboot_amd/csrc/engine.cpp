@@ -2024,7 +2024,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_quiet") { ufb_quiet_ = v ? 1 : 0; return MPF_OK; }
   if (key == "grow_device") { grow_device_ = v ? 1 : 0; return MPF_OK; }
-  if (key == "grow_tile") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) { set_error("grow_tile: 0 (fitted), 1, 2, 4 or 8"); return MPF_E_INVALID; } grow_vw_ = (int)v; return MPF_OK; }
+  if (key == "grow_tile") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != -1) { set_error("grow_tile: 0 (word-major copy where there is one, else fitted), -1 (fitted quad tiles), 1, 2, 4 or 8"); return MPF_E_INVALID; } grow_vw_ = (int)v; return MPF_OK; }
   if (key == "grow_fault") { grow_fault_ = v; return MPF_OK; }
   if (key == "max_visits") { max_visits_ = std::max<int64_t>(0, v); return MPF_OK; }
   if (key == "small_batch_max") { small_batch_max_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 30)); return MPF_OK; }

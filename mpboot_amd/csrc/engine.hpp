@@ -469,7 +469,7 @@ class Engine {
     PinBuf<uint32_t> h_out;
   } gd_;
   int grow_device_ = 1;                          // option "grow_device": 0 = the host's loop (one refresh + one scan + one round trip per taxon)
-  int grow_vw_ = 0;                              // option "grow_tile": words per lane group of k_grow (0 = fitted: at most 32 workgroups)
+  int grow_vw_ = -1;                             // option "grow_tile": words per lane group of k_grow's quad tiles (-1 = fitted: at most 32 workgroups; 0 = the word-major DNA layout)
   int64_t grow_fault_ = 0;                       // tests: fault injected into the next k_grow launch
   uint64_t grow_launches_ = 0, grow_steps_ = 0;
   double grow_ms_total_ = 0;

@@ -43,6 +43,7 @@ template <int KS, int VW>
 struct Gx {
   uint16_t *par, *ch1, *ch2, *pos, *sz, *dep, *dcid, *ord, *skl, *parts, *path, *psib;
   uint32_t *cost, *gflag;
+  uint4 *prog;       // [waves][64] the walks' programs
   uint8_t *nz, *pflag;
   uint32_t n, N2, SW4;
   int lane, wave;
@@ -52,10 +53,59 @@ struct Gx {
   bool cnt_lane, st_lane;
 };
 
+// KS == 4 is the WORD-MAJOR DNA layout: the kernel works on the engine's word-major copy of the vectors (Geometry::shoff: the four
+// state words of a 32-site word side by side), a lane holds ALL FOUR states of ONE word.  A vector tile is then one contiguous
+// kilobyte -- one buffer_load_dwordx4 per wave instead of four 256-byte row segments -- and Fitch's cross-state OR stays inside
+// the lane: half the vector instructions of the quad layout and four times longer bursts (the addition loop reads every down
+// vector once per added taxon: at a dozen trees side by side it is bound by what HBM delivers for such gathers).
 template <int KS, int VW>
-__device__ __forceinline__ void g_ld(const Gx<KS, VW> &G, QT<KS, VW> &t, uint32_t cid) { qload<KS, VW>(t, G.rsrc, G.voff, cid * G.SW4); }
+__device__ __forceinline__ void g_ld(const Gx<KS, VW> &G, QT<KS, VW> &t, uint32_t cid)
+{
+  if constexpr (KS == 4) {
+    const v4u x = __builtin_amdgcn_raw_buffer_load_b128(G.rsrc, G.voff[0], cid * G.SW4, 0);
+    t.v[0][0] = x[0]; t.v[1][0] = x[1]; t.v[2][0] = x[2]; t.v[3][0] = x[3];
+  } else {
+    qload<KS, VW>(t, G.rsrc, G.voff, cid * G.SW4);
+  }
+}
 template <int KS, int VW>
-__device__ __forceinline__ void g_st(const Gx<KS, VW> &G, const QT<KS, VW> &t, uint32_t cid) { if (G.st_lane) qstore<KS, VW>(t, G.rsrc, G.voff, cid * G.SW4); }
+__device__ __forceinline__ void g_st(const Gx<KS, VW> &G, const QT<KS, VW> &t, uint32_t cid)
+{
+  if (!G.st_lane) return;
+  if constexpr (KS == 4) {
+    v4u x; x[0] = t.v[0][0]; x[1] = t.v[1][0]; x[2] = t.v[2][0]; x[3] = t.v[3][0];
+    __builtin_amdgcn_raw_buffer_store_b128(x, G.rsrc, G.voff[0], cid * G.SW4, 0);
+  } else {
+    qstore<KS, VW>(t, G.rsrc, G.voff, cid * G.SW4);
+  }
+}
+// c = fitch(a, b); returns this lane's count of sites with an empty intersection (quad layout: the same number in the four lanes
+// of a quad, counted by the first; word-major: every lane its own word)
+template <int KS, int VW>
+__device__ __forceinline__ uint32_t v_fitch(QT<KS, VW> &c, const QT<KS, VW> &a, const QT<KS, VW> &b)
+{
+  if constexpr (KS == 4) {
+    const uint32_t any = b3_andor(a.v[3][0], b.v[3][0], b3_andor(a.v[2][0], b.v[2][0], b3_andor(a.v[1][0], b.v[1][0], a.v[0][0] & b.v[0][0])));
+#pragma unroll
+    for (int k = 0; k < 4; k++) c.v[k][0] = b3_fitch(a.v[k][0], b.v[k][0], any);
+    return (uint32_t)__builtin_popcount(~any);
+  } else {
+    return q_fitch<KS, VW>(c, a, b);
+  }
+}
+template <int KS, int VW>
+__device__ __forceinline__ uint32_t v_join(const QT<KS, VW> &u, const QT<KS, VW> &d, const QT<KS, VW> &s)
+{
+  if constexpr (KS == 4) {
+    const uint32_t any = b3_andor(u.v[3][0], d.v[3][0], b3_andor(u.v[2][0], d.v[2][0], b3_andor(u.v[1][0], d.v[1][0], u.v[0][0] & d.v[0][0])));
+    uint32_t hit = b3_fitch(u.v[0][0], d.v[0][0], any) & s.v[0][0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) hit = b3_andor(b3_fitch(u.v[k][0], d.v[k][0], any), s.v[k][0], hit);
+    return (uint32_t)__builtin_popcount(~hit);
+  } else {
+    return q_join<KS, VW>(u, d, s);
+  }
+}
 
 // a vector tile in a scratch slot (parked up-vectors, the parts' roots): [slot][R][64] words, lane-major
 template <int KS, int VW>
@@ -81,11 +131,14 @@ __device__ __forceinline__ double g_tie_draw(unsigned long long &st)
 
 __device__ __forceinline__ void publish_parts(GSh &sh, uint32_t np, int lane);
 
-// the walk of the skeleton (SKEL: wave 0, expansions = sh.nskel nodes of G.skl) or of one part (root r, at most 128 nodes).
+// the walk of the skeleton (SKEL: wave 0, expansions = sh.nskel nodes of G.skl) or of one part (root r, at most 64 nodes).
 // Ur = U(r).  Books the candidate costs of every expanded node's two children; U of the first child stays in registers, U of a
-// second child that is expanded later waits in `park` at the level of its parent.  The children's vectors of the next PF
-// expansions are requested before the current PF are worked on (two register sets in rotation): the skeleton's walk is one
-// wave on its own, there is nobody else to hide its memory round trips.
+// second child that is expanded later waits in `park` at the level of its parent.
+// What an expansion needs to know about the tree -- its children's vectors and pre-order positions, where its own U comes from,
+// what becomes of the children -- is worked out for 64 expansions at a time, a lane each, into a 16-byte entry of this wave's
+// program buffer: the walk itself then costs ONE broadcast LDS read per expansion (the first version asked the tree arrays a
+// dozen dependent questions per expansion, each a round trip to LDS through readfirstlane: 0.7 us of the 0.9 us an expansion took).
+// The children's vectors of the next PF expansions are requested before the current PF are worked on (two register sets in rotation).
 template <int KS, int VW, bool SKEL>
 __device__ __forceinline__ void walk(const Gx<KS, VW> &G, GSh &sh, uint32_t r, const QT<KS, VW> &Ur, const QT<KS, VW> &T, uint32_t *park,
                                      uint32_t *ucp)
@@ -94,99 +147,117 @@ __device__ __forceinline__ void walk(const Gx<KS, VW> &G, GSh &sh, uint32_t r, c
   const int lane = G.lane;
   const uint32_t S = sh.S;
   const uint32_t depr = rfl((uint32_t)G.dep[r]);
+  uint4 *prog = G.prog + (size_t)G.wave * 64;
   uint32_t E, base = 0;
-  unsigned long long todo0 = 0ull, todo1 = 0ull;
+  unsigned long long todo = 0ull;
   if constexpr (SKEL) {
     E = sh.nskel;
   } else {
     base = rfl((uint32_t)G.pos[r]);
     const uint32_t cnt = rfl((uint32_t)G.sz[r]);
-    bool in0 = false, in1 = false;
-    if ((uint32_t)lane < cnt) in0 = G.sz[G.ord[base + (uint32_t)lane]] > 1u;
-    if (64u + (uint32_t)lane < cnt) in1 = G.sz[G.ord[base + 64u + (uint32_t)lane]] > 1u;
-    todo0 = __ballot((int)in0);
-    todo1 = __ballot((int)in1);
-    E = (uint32_t)__builtin_popcountll(todo0) + (uint32_t)__builtin_popcountll(todo1);
+    bool inner = false;
+    if ((uint32_t)lane < cnt) inner = G.sz[G.ord[base + (uint32_t)lane]] > 1u;
+    todo = __ballot((int)inner);
+    E = (uint32_t)__builtin_popcountll(todo);
   }
   uint32_t np = SKEL ? sh.nparts : 0u, np_pub = np;
   (void)np_pub;
   QT<KS, VW> u1, u2, par;
-  struct Set { QT<KS, VW> d1[PF], d2[PF]; uint32_t en[PF], ea[PF], eb[PF]; } A, B;
-  uint32_t last_e = r;
-  // requests of the expansions [blk, blk + PF) into one register set (clamped past the end: the requests stay unconditional)
-  auto issue = [&](Set &X, uint32_t blk) {
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-      const uint32_t q = blk + (uint32_t)i;
-      uint32_t e = last_e;
-      if (q < E) {
-        if constexpr (SKEL) {
-          e = rfl((uint32_t)G.skl[q]);
-        } else {
-          uint32_t bit;
-          if (todo0) { bit = (uint32_t)__builtin_ctzll(todo0); todo0 &= todo0 - 1ull; }
-          else { bit = 64u + (uint32_t)__builtin_ctzll(todo1); todo1 &= todo1 - 1ull; }
-          e = rfl((uint32_t)G.ord[base + bit]);
-        }
-        last_e = e;
+  struct Set { QT<KS, VW> d1[PF], d2[PF]; } A, B;
+  for (uint32_t q0 = 0; q0 < E; q0 += 64u) {
+    const uint32_t EC = E - q0 < 64u ? E - q0 : 64u;                  // expansions of this chunk
+    // ---- the chunk's program, a lane per expansion
+    {
+      uint32_t e = 0, slot = 0;
+      bool mine;
+      if constexpr (SKEL) {
+        mine = (uint32_t)lane < EC;
+        if (mine) e = G.skl[q0 + (uint32_t)lane];
+        slot = (uint32_t)lane;
+      } else {
+        mine = ((todo >> lane) & 1ull) != 0ull;                        // (a part is one chunk: E <= 64)
+        if (mine) e = G.ord[base + (uint32_t)lane];
+        slot = (uint32_t)__builtin_popcountll(todo & ((1ull << lane) - 1ull));
       }
-      X.en[i] = e;
-      X.ea[i] = rfl((uint32_t)G.ch1[e]);
-      X.eb[i] = rfl((uint32_t)G.ch2[e]);
-      g_ld<KS, VW>(G, X.d1[i], rfl((uint32_t)G.dcid[X.ea[i]]));
-      g_ld<KS, VW>(G, X.d2[i], rfl((uint32_t)G.dcid[X.eb[i]]));
-    }
-  };
-  auto work = [&](Set &X, uint32_t blk) {
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-      const uint32_t q = blk + (uint32_t)i;
-      if (q < E) {
-        const uint32_t e = X.en[i], a = X.ea[i], b = X.eb[i];
-        const uint32_t lev = rfl((uint32_t)G.dep[e]) - depr;
+      if (mine) {
+        const uint32_t a = G.ch1[e], b = G.ch2[e];
+        const uint32_t sza = G.sz[a], szb = G.sz[b];
+        uint32_t z = (G.dep[e] - depr) << 8;
+        const bool walk_a = sza > 1u && (!SKEL || sza > S);
         if (e == r) {
-          par = Ur;
+          z |= 2u;
         } else {
-          const uint32_t pe = rfl((uint32_t)G.par[e]);
-          if (rfl((uint32_t)G.ch1[pe]) == e) par = u1;                // first child: its parent was the expansion just before
+          const uint32_t pe = G.par[e], sib = G.ch1[pe];
+          if (sib == e) z |= 1u;                                       // first child: its parent was the expansion just before
+          else if (!(G.sz[sib] > 1u && (!SKEL || G.sz[sib] > S))) z |= 32u;   // second child of a parent whose first child is not walked: the parent was the expansion just before, U is still in its second register set
+        }
+        if (szb > 1u && (!SKEL || szb > S) && walk_a) z |= 4u;         // both children are walked: the second one's U waits in HBM
+        if (SKEL && sza > 1u && sza <= S) z |= 8u;                     // a cut-off subtree's root: its U goes on the part list
+        if (SKEL && szb > 1u && szb <= S) z |= 16u;
+        prog[slot] = make_uint4((uint32_t)G.dcid[a] | ((uint32_t)G.dcid[b] << 16), (uint32_t)G.pos[a] | ((uint32_t)G.pos[b] << 16), z, e);
+      }
+    }
+    // requests of the expansions [blk, blk + PF) of the chunk into one register set (clamped: the requests stay unconditional)
+    auto issue = [&](Set &X, uint32_t blk) {
+#pragma unroll
+      for (int i = 0; i < PF; i++) {
+        uint32_t q = blk + (uint32_t)i;
+        q = q < EC ? q : EC - 1u;
+        const uint32_t x = rfl(prog[q].x);
+        g_ld<KS, VW>(G, X.d1[i], x & 0xFFFFu);
+        g_ld<KS, VW>(G, X.d2[i], x >> 16);
+      }
+    };
+    auto work = [&](Set &X, uint32_t blk) {
+#pragma unroll
+      for (int i = 0; i < PF; i++) {
+        const uint32_t q = blk + (uint32_t)i;
+        if (q < EC) {
+          const uint4 en = prog[q];
+          const uint32_t y = rfl(en.y), z = rfl(en.z);
+          const uint32_t lev = z >> 8;
+          if (z & 2u) par = Ur;
+          else if (z & 1u) par = u1;
+          else if (z & 32u) par = u2;
           else s_ld<KS, VW>(park, lev - 1u, par, lane);
-        }
-        q_fitch<KS, VW>(u1, par, X.d2[i]);                            // U(a) = fitch(U(e), D(b))
-        q_fitch<KS, VW>(u2, par, X.d1[i]);
-        const uint32_t j1 = q_join<KS, VW>(u1, X.d1[i], T);
-        const uint32_t j2 = q_join<KS, VW>(u2, X.d2[i], T);
-        if (G.cnt_lane) {
-          __hip_atomic_fetch_add(G.cost + rfl((uint32_t)G.pos[a]) + G.zero, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(G.cost + rfl((uint32_t)G.pos[b]) + G.zero, j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        const uint32_t sza = rfl((uint32_t)G.sz[a]), szb = rfl((uint32_t)G.sz[b]);
-        const bool walk_b = szb > 1u && (!SKEL || szb > S);
-        if (walk_b) {
-          if (lev >= (SKEL ? kGrowParkSkel : kGrowParkPart)) { if (lane == 0) sh.err = 3u; }
-          else s_st<KS, VW>(park, lev, u2, lane);
-        }
-        if constexpr (SKEL) {
-          if (sza > 1u && sza <= S) {
-            if (np < kGrowMaxParts) { s_st<KS, VW>(ucp, np, u1, lane); if (lane == 0) G.parts[np] = (uint16_t)a; np++; }
-            else if (lane == 0) sh.err = 4u;
+          v_fitch<KS, VW>(u1, par, X.d2[i]);                          // U(a) = fitch(U(e), D(b))
+          v_fitch<KS, VW>(u2, par, X.d1[i]);
+          const uint32_t j1 = v_join<KS, VW>(u1, X.d1[i], T);
+          const uint32_t j2 = v_join<KS, VW>(u2, X.d2[i], T);
+          if (G.cnt_lane) {
+            __hip_atomic_fetch_add(G.cost + (y & 0xFFFFu) + G.zero, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(G.cost + (y >> 16) + G.zero, j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
-          if (szb > 1u && szb <= S) {
-            if (np < kGrowMaxParts) { s_st<KS, VW>(ucp, np, u2, lane); if (lane == 0) G.parts[np] = (uint16_t)b; np++; }
-            else if (lane == 0) sh.err = 4u;
+          if (z & 4u) {
+            if (lev >= (SKEL ? kGrowParkSkel : kGrowParkPart)) { if (lane == 0) sh.err = 3u; }
+            else s_st<KS, VW>(park, lev, u2, lane);
+          }
+          if constexpr (SKEL) {
+            if (z & 24u) {
+              const uint32_t e = rfl(en.w);
+              if (z & 8u) {
+                if (np < kGrowMaxParts) { s_st<KS, VW>(ucp, np, u1, lane); if (lane == 0) G.parts[np] = G.ch1[e]; np++; }
+                else if (lane == 0) sh.err = 4u;
+              }
+              if (z & 16u) {
+                if (np < kGrowMaxParts) { s_st<KS, VW>(ucp, np, u2, lane); if (lane == 0) G.parts[np] = G.ch2[e]; np++; }
+                else if (lane == 0) sh.err = 4u;
+              }
+            }
           }
         }
       }
+    };
+    issue(A, 0u);
+    for (uint32_t blk = 0; blk < EC; blk += 2u * (uint32_t)PF) {
+      issue(B, blk + (uint32_t)PF);
+      work(A, blk);
+      // (the parts left so far: published with the stores in front of the count.  The release waits for every request that is out --
+      //  here those of set B, which the next lines wait for anyway)
+      if constexpr (SKEL) { if (np != np_pub) { publish_parts(sh, np, lane); np_pub = np; } }
+      issue(A, blk + 2u * (uint32_t)PF);
+      work(B, blk + (uint32_t)PF);
     }
-  };
-  if (E > 0u) issue(A, 0u);
-  for (uint32_t blk = 0; blk < E; blk += 2u * (uint32_t)PF) {
-    issue(B, blk + (uint32_t)PF);
-    work(A, blk);
-    issue(A, blk + 2u * (uint32_t)PF);
-    work(B, blk + (uint32_t)PF);
-    // (the parts left so far: published with the stores in front of the count; waiting for them also waits for the requests that
-    //  are out, so not more often than every other block)
-    if constexpr (SKEL) { if (np != np_pub) { publish_parts(sh, np, lane); np_pub = np; } }
   }
   if constexpr (SKEL) { if (lane == 0) sh.nparts = np; }
 }
@@ -217,12 +288,22 @@ __device__ __forceinline__ void grow_body(const GrowParams &P)
   G.cost = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)N2 * 4;
   G.gflag = reinterpret_cast<uint32_t *>(smem + at); at += (((size_t)(N2 / 32 + 2) * 4) + 15) & ~(size_t)15;
   G.nz = reinterpret_cast<uint8_t *>(smem + at); at += ((size_t)N2 + 15) & ~(size_t)15;
-  G.pflag = reinterpret_cast<uint8_t *>(smem + at);
+  G.pflag = reinterpret_cast<uint8_t *>(smem + at); at += ((size_t)N2 + 15) & ~(size_t)15;
+  G.prog = reinterpret_cast<uint4 *>(smem + at);
   G.n = n; G.N2 = N2; G.lane = lane; G.wave = wave;
-  G.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
   asm volatile("v_mov_b32 %0, 0" : "=v"(G.zero));
   G.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.vec, 0, 0x7FFFFFFF, 0x00020000);
-  {
+  if constexpr (KS == 4) {
+    // word-major copy (P.vec points at it): vector = Wp x 16 bytes, this lane's word at 16 bytes x word
+    G.SW4 = P.Wp * 16u;
+    uint32_t word0 = tile * 64u + (uint32_t)lane;
+    G.st_lane = word0 < P.Wp;
+    if (!G.st_lane) word0 = P.Wp - 1u;
+    G.cnt_lane = G.st_lane;
+    G.voff[0] = word0 * 16u;
+    G.voff[1] = G.voff[2] = G.voff[3] = 0;
+  } else {
+    G.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
     const uint32_t w = (uint32_t)lane >> 2, g = (uint32_t)lane & 3u;
     uint32_t word0 = (tile * 16u + w) * (uint32_t)VW;
     G.st_lane = word0 < P.Wp;
@@ -290,7 +371,7 @@ __device__ __forceinline__ void grow_body(const GrowParams &P)
       QT<KS, VW> a, b, d;
       g_ld<KS, VW>(G, a, rfl((uint32_t)G.dcid[rfl((uint32_t)G.ch1[c])]));
       g_ld<KS, VW>(G, b, rfl((uint32_t)G.dcid[rfl((uint32_t)G.ch2[c])]));
-      const uint32_t cnt = q_fitch<KS, VW>(d, a, b);
+      const uint32_t cnt = v_fitch<KS, VW>(d, a, b);
       g_st<KS, VW>(G, d, rfl((uint32_t)G.dcid[c]));
       const bool any = __ballot((int)(G.cnt_lane && cnt > 0u)) != 0ull;
       if (lane == 0) { G.path[k] = (uint16_t)c; G.psib[k] = (uint16_t)kGrowNone; G.pflag[k] = any ? 1 : 0; }
@@ -308,7 +389,7 @@ __device__ __forceinline__ void grow_body(const GrowParams &P)
     // ---- (1) plan
     if (tid == 0) {
       uint32_t S = m / (3u * kNW);
-      S = S < 8u ? 8u : S > 64u ? 64u : S;
+      S = S < 8u ? 8u : S > kGrowParkPart ? kGrowParkPart : S;
       sh.S = S; sh.nparts = 0; sh.part_next = 0; sh.nskel = 0; sh.npub = 0; sh.skel_done = 0;
     }
     for (uint32_t i = (uint32_t)tid; i < m; i += kThreads) G.cost[i] = 0u;
@@ -341,7 +422,7 @@ __device__ __forceinline__ void grow_body(const GrowParams &P)
       QT<KS, VW> U0, D0;
       g_ld<KS, VW>(G, U0, P.root_cid);
       g_ld<KS, VW>(G, D0, rfl((uint32_t)G.dcid[c0]));
-      const uint32_t j0 = q_join<KS, VW>(U0, D0, Tv);
+      const uint32_t j0 = v_join<KS, VW>(U0, D0, Tv);
       if (G.cnt_lane) __hip_atomic_fetch_add(G.cost + G.zero, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const uint32_t s0 = rfl((uint32_t)G.sz[c0]);
       if (s0 > 1u) {
@@ -566,7 +647,7 @@ __device__ __forceinline__ void grow_body(const GrowParams &P)
       {
         QT<KS, VW> dc;
         g_ld<KS, VW>(G, dc, rfl((uint32_t)G.dcid[cs]));
-        const uint32_t cnt = q_fitch<KS, VW>(cur, Tv, dc);
+        const uint32_t cnt = v_fitch<KS, VW>(cur, Tv, dc);
         g_st<KS, VW>(G, cur, rfl((uint32_t)G.dcid[xnode]));
         const bool any = __ballot((int)(G.cnt_lane && cnt > 0u)) != 0ull;
         if (lane == 0) { G.path[0] = (uint16_t)xnode; G.psib[0] = (uint16_t)cs; G.pflag[0] = any ? 1 : 0; }
@@ -590,7 +671,7 @@ __device__ __forceinline__ void grow_body(const GrowParams &P)
         for (int i = 0; i < PF; i++) {
           const uint32_t q = blk + (uint32_t)i;
           if (q < k) {
-            const uint32_t cnt = q_fitch<KS, VW>(nw, cur, sib[i]);
+            const uint32_t cnt = v_fitch<KS, VW>(nw, cur, sib[i]);
             g_st<KS, VW>(G, nw, rfl((uint32_t)G.dcid[rfl((uint32_t)G.path[q])]));
             const bool any = __ballot((int)(G.cnt_lane && cnt > 0u)) != 0ull;
             if (lane == 0) G.pflag[q] = any ? 1 : 0;
@@ -630,11 +711,12 @@ size_t g_lds_bytes(uint32_t n)
   at += (((N2 / 32 + 2) * 4) + 15) & ~(size_t)15;
   at += (N2 + 15) & ~(size_t)15;
   at += (N2 + 15) & ~(size_t)15;
+  at += (size_t)GCfg<KS, VW>::NW * 64 * sizeof(uint4);
   return (at + 15) & ~(size_t)15;
 }
 
 template <int KS, int VW>
-constexpr bool g_tight() { return KS == 1 && VW <= 4; }
+constexpr bool g_tight() { return (KS == 1 && VW <= 4) || KS == 4; }
 
 template <int KS, int VW>
 const void *g_kernel() { return g_tight<KS, VW>() ? reinterpret_cast<const void *>(&k_grow_tight<KS, VW>) : reinterpret_cast<const void *>(&k_grow<KS, VW>); }
@@ -667,15 +749,17 @@ int g_blocks_per_cu(uint32_t n)
 
 }  // namespace
 
-int grow_tiles(const Geometry &g, int vw) { return (g.Wp + 16 * vw - 1) / (16 * vw); }
+// vw = 0: the word-major DNA layout (64 words per tile, a lane = one word with its four states)
+int grow_tiles(const Geometry &g, int vw) { return vw == 0 ? (g.Wp + 63) / 64 : (g.Wp + 16 * vw - 1) / (16 * vw); }
 
 int grow_waves(const Geometry &g, int vw)
 {
+  if (vw == 0) return 8;
   const int r = (g.S == 4 ? 1 : g.S == 32 ? 8 : 5) * vw;
   return r <= 2 ? 16 : 8;
 }
 
-size_t grow_vec_words(const Geometry &g, int vw) { return (size_t)(g.S == 4 ? 1 : g.S == 32 ? 8 : 5) * (size_t)vw * 64; }
+size_t grow_vec_words(const Geometry &g, int vw) { return vw == 0 ? 256 : (size_t)(g.S == 4 ? 1 : g.S == 32 ? 8 : 5) * (size_t)vw * 64; }
 
 size_t grow_lds_bytes(const Geometry &g, int n_taxa, int vw)
 {
@@ -694,6 +778,7 @@ bool grow_supported(const Geometry &g, int n_taxa)
 
 int grow_blocks_per_cu(const Geometry &g, int n_taxa, int vw)
 {
+  if (g.S == 4 && vw == 0) return g_blocks_per_cu<4, 1>((uint32_t)n_taxa);
   if (g.S == 4) return vw == 1 ? g_blocks_per_cu<1, 1>((uint32_t)n_taxa) : vw == 2 ? g_blocks_per_cu<1, 2>((uint32_t)n_taxa)
                        : vw == 8 ? g_blocks_per_cu<1, 8>((uint32_t)n_taxa) : g_blocks_per_cu<1, 4>((uint32_t)n_taxa);
   if (g.S == 32) return g_blocks_per_cu<8, 1>((uint32_t)n_taxa);
@@ -703,6 +788,7 @@ int grow_blocks_per_cu(const Geometry &g, int n_taxa, int vw)
 hipError_t launch_grow(hipStream_t st, const Geometry &g, int vw, const GrowParams &p)
 {
   if (g.S == 4) {
+    if (vw == 0) return g_launch<4, 1>(st, p);        // (p.vec = the word-major copy)
     if (vw == 1) return g_launch<1, 1>(st, p);
     if (vw == 2) return g_launch<1, 2>(st, p);
     if (vw == 8) return g_launch<1, 8>(st, p);

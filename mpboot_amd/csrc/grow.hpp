@@ -64,7 +64,7 @@ struct GrowParams {
 };
 
 constexpr uint32_t kGrowNone = 0xFFFFu;
-constexpr uint32_t kGrowParkPart = 128;    // levels a part's walk can park = the largest part (nodes): two ballots give its walk
+constexpr uint32_t kGrowParkPart = 64;     // levels a part's walk can park = the largest part (nodes): one ballot gives its walk
 constexpr uint32_t kGrowParkSkel = 512;    // levels of the skeleton's walk (deeper: GROW_ERROR 3, the host's loop takes over)
 constexpr uint32_t kGrowMaxParts = 1024;
 

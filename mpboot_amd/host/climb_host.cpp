@@ -275,6 +275,9 @@ int Engine::grow_fit_vw() const
 {
   if (g_.S != 4) return 1;
   if (grow_vw_ > 0) return grow_vw_;
+  // (option grow_tile 0: the word-major copy, DNA below 2 GiB -- 64-word tiles, a lane = one word with its four states: half the
+  //  vector instructions and contiguous kilobytes, but measured slower than the 64-word quad tiles at C3: 45 against 56 trees/s)
+  if (g_.shoff && grow_vw_ == 0) return 0;
   for (int vw = 1; vw <= 8; vw *= 2)
     if (grow_tiles(g_, vw) <= 32) return vw;
   return 8;
@@ -349,7 +352,7 @@ int Engine::grow_segment(const std::vector<int> &perm, uint32_t len0, uint32_t *
   h.rng = rng_.state;
   std::memcpy(gd_.h_out.p, &h, sizeof(h));
   GrowParams p;
-  p.vec = d_vec_;
+  p.vec = vw == 0 ? d_vec_ + g_.shoff : d_vec_;
   p.n = (uint32_t)n; p.nslots = (uint32_t)nslots_; p.Wp = (uint32_t)g_.Wp; p.tiles = (uint32_t)tiles;
   p.m0 = m0; p.steps = (uint32_t)steps; p.tie_mode = (uint32_t)tie_mode_; p.len0 = len0;
   p.root_cid = slot(f); p.root_node = node_of(back_[f]);

@@ -45,11 +45,12 @@ def test_fixture_trees_equal_the_host_loop_and_the_oracle(name, tie):
         assert ob.tolist() == d[0] and o.tie_state() == d[4]
 
 
-@pytest.mark.parametrize("n,P,alphabet,opts", [(30, 600, "DNA", {}), (200, 10000, "DNA", {}), (200, 10000, "DNA", {"grow_tile": 4}),
+@pytest.mark.parametrize("n,P,alphabet,opts", [(30, 600, "DNA", {}), (200, 10000, "DNA", {}), (200, 10000, "DNA", {"grow_tile": 4}), (200, 10000, "DNA", {"grow_tile": 0}), (700, 1500, "DNA", {"grow_tile": 0}),
                                                (300, 3000, "DNA", {"grow_tile": 2}), (90, 9000, "DNA", {"grow_tile": 8}), (120, 3000, "AA", {}),
                                                (700, 1500, "DNA", {})])
 def test_synthetic_trees_equal_the_host_loop(n, P, alphabet, opts):
-    """larger trees (the skeleton + parts split, several workgroups exchanging rows) and every tile width"""
+    """larger trees (the skeleton + parts split, several workgroups exchanging rows) and every tile shape: quad tiles of 16 x 1 / 2 / 4 / 8 words (default: fitted) and
+    the word-major DNA layout (grow_tile 0: a lane = one word with its four states, read from the engine's word-major copy)"""
     from mpboot_amd import engine, synth
     letters, _ = synth.synth_alignment(n, P, alphabet, 0.07, seed=n + P)
     codes = synth.letters_to_codes(letters, alphabet)
