@@ -1118,9 +1118,14 @@ def main():
             k_e = max(1, args.start_engines)
             grow(k_e)
             units = [u for u in range(args.start_trees) if u % world == rank]
+            unit_q, unit_lock = iter(units), _th.Lock()          # (the engines take the next tree when they are done with theirs)
             def ras_fn(i, x):
                 best = None
-                for u in units[i::k_e]:
+                while True:
+                    with unit_lock:
+                        u = next(unit_q, None)
+                    if u is None:
+                        break
                     sd = shard.unit_seed(31337, u)
                     x.seed_ties(engine.TIE_RANDOM, sd)
                     x.reset_node_order()

@@ -95,21 +95,16 @@ if rank == 0:
 
 
 def _gpu_count():
-    """GPUs this process may use, from sysfs / the visibility variables -- no HIP call, no torch import at collection time (a
-    runtime started here would be running before mpboot_amd.engine exports GPU_MAX_HW_QUEUES)"""
-    import glob
-    n = 0
-    for node in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-        try:
-            props = dict(l.split()[:2] for l in open(node) if len(l.split()) >= 2)
-            n += int(props.get("simd_count", "0")) > 0
-        except OSError:
-            pass
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
-    return n
+    """GPUs a process started from here can use, asked of a CHILD process: no HIP call and no torch import in the pytest process
+    (a runtime started here at collection time would be running before mpboot_amd.engine exports GPU_MAX_HW_QUEUES; sysfs lists
+    the host's GPUs, not the ones this container was given)"""
+    probe = ("import torch\nok = 0\nfor i in range(torch.cuda.device_count()):\n    try:\n        torch.cuda.set_device(i); torch.zeros(1, device='cuda'); ok += 1\n"
+             "    except Exception:\n        break\nprint(ok)")       # (device_count() can name GPUs of the host this container cannot open)
+    out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
 
 
 def test_two_rccl_ranks_exchange_and_sample_sharded_online_phase(tmp_path):

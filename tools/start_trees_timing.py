@@ -25,8 +25,14 @@ for K in Ks:
     while len(pool) < K:
         pool.append(mk())
     scores = [None] * ntrees
+    nxt = iter(range(ntrees))
+    lock = threading.Lock()
     def work(k):
-        for u in range(k, ntrees, K):
+        while True:
+            with lock:
+                u = next(nxt, None)
+            if u is None:
+                return
             e = pool[k]
             e.seed_ties(engine.TIE_RANDOM, 100 + u)
             scores[u] = e.make_parsimony_tree(5000 + u, 6)
