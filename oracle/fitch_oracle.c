@@ -70,6 +70,8 @@ struct orc {
   double ufb_eps, ufb_cutoff;     /* params->ufboot_epsilon (0.5, tools.cpp:725), logl_cutoff */
   double *ufb_logl;               /* boot_logl */
   int *ufb_counts, *ufb_trees;    /* boot_counts, boot_trees */
+  int *ufb_orig;                  /* boot_tree_orig_logl (iqtree.h:766; -cutoff_from_btrees): the logl under which each sample's tree was booked */
+  int ufb_cut_btrees;             /* params->cutoff_from_btrees (tools.cpp:2442) */
   double *ufb_treels;             /* treels_logl */
   int ufb_ntrees, ufb_treels_cap;
   int *ufb_store_idx, **ufb_store_back, ufb_nstore, ufb_store_cap;   /* topologies of the trees some sample accepted */
@@ -806,6 +808,7 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
         if (rell > o->ufb_logl[sample]) o->ufb_counts[sample] = 1;
         if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }
         ufb_store_tree(o, tree_index);
+        if (o->ufb_cut_btrees) o->ufb_orig[sample] = (int)cur_logl;          /* :3617-3619 */
         o->ufb_trees[sample] = tree_index;
         if (rell > o->ufb_logl[sample]) o->ufb_logl[sample] = rell;
         t = K < *cnt ? K : *cnt;
@@ -857,6 +860,7 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
         int i, have = 0;
         if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }   /* :3500-3514 */
         if (rell > o->ufb_logl[sample]) { o->ufb_set_n[sample] = 0; o->ufb_logl[sample] = rell; }      /* :3516-3519 */
+        if (o->ufb_cut_btrees && (int)cur_logl > o->ufb_orig[sample]) o->ufb_orig[sample] = (int)cur_logl;   /* :3523-3527 (the array starts at 0: lengths being negative logls, this never fires -- the reference's own quirk) */
         for (i = 0; i < o->ufb_set_n[sample]; i++) if (o->ufb_set[sample][i] == tree_index) have = 1;
         if (!have) {                                                         /* :3530-3533 */
           if (o->ufb_set_n[sample] == o->ufb_set_cap[sample]) {
@@ -876,6 +880,7 @@ static void ufb_save_current_tree(orc *o, double cur_logl)
       if (!looked_up) { tree_index = ufb_lookup_topology(o, o->ufb_ntrees - 1); looked_up = 1; }
       ufb_store_tree(o, tree_index);
       if (rell > o->ufb_logl[sample]) o->ufb_counts[sample] = 1;             /* :3710-3713 */
+      if (o->ufb_cut_btrees) o->ufb_orig[sample] = (int)cur_logl;            /* :3716-3718 */
       if (rell > o->ufb_logl[sample]) o->ufb_logl[sample] = rell;            /* :3719 max() */
       o->ufb_trees[sample] = tree_index;                                     /* :3720 */
     }
@@ -1192,12 +1197,13 @@ void orc_ufboot_detach(orc *o)
   free(o->ufb_set); free(o->ufb_set_n); free(o->ufb_set_cap);
   o->ufb_set = NULL; o->ufb_set_n = o->ufb_set_cap = NULL;
   o->ufb_mulhits = 0;
+  o->ufb_cut_btrees = 0;
   free(o->ufb_top_idx); free(o->ufb_top_rell); free(o->ufb_top_n); free(o->ufb_thr); free(o->ufb_top_iter);
   o->ufb_top_idx = o->ufb_top_rell = o->ufb_top_n = o->ufb_thr = o->ufb_top_iter = NULL;
   o->ufb_topboot = o->ufb_distinct = o->ufb_cur_it = 0;
-  free(o->ufb_samples); free(o->ufb_logl); free(o->ufb_counts); free(o->ufb_trees); free(o->ufb_treels); free(o->ufb_ptn);
+  free(o->ufb_samples); free(o->ufb_logl); free(o->ufb_counts); free(o->ufb_orig); free(o->ufb_trees); free(o->ufb_treels); free(o->ufb_ptn);
   o->ufb_store_back = NULL; o->ufb_store_idx = NULL; o->ufb_nstore = o->ufb_store_cap = 0;
-  o->ufb_samples = NULL; o->ufb_logl = NULL; o->ufb_counts = NULL; o->ufb_trees = NULL; o->ufb_treels = NULL; o->ufb_ptn = NULL;
+  o->ufb_samples = NULL; o->ufb_logl = NULL; o->ufb_counts = NULL; o->ufb_orig = NULL; o->ufb_trees = NULL; o->ufb_treels = NULL; o->ufb_ptn = NULL;
   o->ufb_ntrees = o->ufb_treels_cap = 0;
   o->ufb_on = 0;
 }
@@ -1214,6 +1220,7 @@ void orc_ufboot_attach(orc *o, int B, const unsigned short *samples, double epsi
   o->ufb_cutoff = 0.0;                                   /* iqtree.cpp:68 */
   o->ufb_logl = (double *)malloc(sizeof(double) * B);
   o->ufb_counts = (int *)calloc(B, sizeof(int));
+  o->ufb_orig = (int *)calloc(B, sizeof(int));                 /* iqtree.cpp:254: resize(gbo_replicates, 0) */
   o->ufb_trees = (int *)malloc(sizeof(int) * B);
   for (b = 0; b < B; b++) { o->ufb_logl[b] = -(double)LONG_MAX; o->ufb_trees[b] = -1; }   /* :248-253 */
   o->ufb_ptn = (unsigned short *)calloc((size_t)o->P + 16, sizeof(unsigned short));
@@ -1291,9 +1298,17 @@ int orc_ufboot_tree(const orc *o, int tree_index, int *back)
 }
 /* the per-iteration cut-off update, "top cutoff_percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10 tools.cpp:793) */
 static int cmp_desc(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return x < y ? 1 : x > y ? -1 : 0; }
+void orc_ufboot_set_cutoff_from_btrees(orc *o, int on) { o->ufb_cut_btrees = on != 0; }
+void orc_ufboot_orig_logl(const orc *o, int *out) { memcpy(out, o->ufb_orig, sizeof(int) * (size_t)o->ufb_B); }
+
 double orc_ufboot_next_cutoff(const orc *o, int percent)
 {
   double *l, c;
+  if (o->ufb_cut_btrees) {                               /* :1657-1660: logl_cutoff = min(boot_tree_orig_logl) */
+    int b, mn = o->ufb_orig[0];
+    for (b = 1; b < o->ufb_B; b++) if (o->ufb_orig[b] < mn) mn = o->ufb_orig[b];
+    return (double)mn;
+  }
   if (o->ufb_ntrees <= 1000) return o->ufb_cutoff;
   l = (double *)malloc(sizeof(double) * o->ufb_ntrees);
   memcpy(l, o->ufb_treels, sizeof(double) * o->ufb_ntrees);

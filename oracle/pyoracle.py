@@ -112,6 +112,8 @@ def lib():
         L.orc_ufboot_tree.argtypes = [vp, ci, vp]
         L.orc_ufboot_next_cutoff.restype = C.c_double
         L.orc_ufboot_next_cutoff.argtypes = [vp, ci]
+        L.orc_ufboot_set_cutoff_from_btrees.argtypes = [vp, ci]
+        L.orc_ufboot_orig_logl.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -348,6 +350,14 @@ class Oracle:
 
     def ufboot_draws(self):
         return int(lib().orc_ufboot_draws(self.h))
+
+    def ufboot_set_cutoff_from_btrees(self, on: bool):
+        lib().orc_ufboot_set_cutoff_from_btrees(self.h, 1 if on else 0)
+
+    def ufboot_orig_logl(self):
+        out = np.zeros(self.ufb_B, dtype=np.int32)
+        lib().orc_ufboot_orig_logl(self.h, _p(out))
+        return out
 
     def ufboot_next_cutoff(self, percent: int = 10):
         return float(lib().orc_ufboot_next_cutoff(self.h, percent))

@@ -76,6 +76,8 @@ class SlowSearch:
             self.ratchet = False
             self.ratchet_booking = True                    # !params->no_hclimb1_bb
             self.mulhits = False                           # params->multiple_hits
+            self.cutoff_from_btrees = False                # params->cutoff_from_btrees (tools.cpp:2442)
+            self.boot_tree_orig_logl = [0] * B             # iqtree.cpp:254
             self.store_trees = False                       # params->store_candidate_trees (-storetrees)
             self.duplicates = 0                            # duplication_counter
             self.rebooked = 0                              # ... of which booked again with a better length
@@ -211,6 +213,8 @@ class SlowSearch:
                         tree_index = self.treels.setdefault(self.splits(self.back), tree_index)
                         looked_up = True
                     self.topologies.setdefault(tree_index, list(self.back))
+                    if self.cutoff_from_btrees:                        # :3617-3619
+                        self.boot_tree_orig_logl[b] = int(cur_logl)
                     self.boot_trees[b] = tree_index
                     self.boot_logl[b] = max(self.boot_logl[b], rell)
                     t = min(k, len(its))
@@ -257,6 +261,8 @@ class SlowSearch:
                     if rell > self.boot_logl[b]:
                         self.boot_sets[b].clear()
                         self.boot_logl[b] = rell
+                    if self.cutoff_from_btrees and cur_logl > self.boot_tree_orig_logl[b]:      # :3523-3527
+                        self.boot_tree_orig_logl[b] = int(cur_logl)
                     if tree_index not in self.boot_sets[b]:
                         self.boot_sets[b].add(tree_index)
                         self.largest_set = max(self.largest_set, len(self.boot_sets[b]))
@@ -274,6 +280,8 @@ class SlowSearch:
                 if rell > self.boot_logl[b]:
                     self.boot_counts[b] = 1
                     self.boot_logl[b] = rell
+                if self.cutoff_from_btrees:                             # :3716-3718
+                    self.boot_tree_orig_logl[b] = int(cur_logl)
                 self.boot_trees[b] = tree_index
             if rell == self.boot_logl[b]:
                 self.boot_counts[b] += 1

@@ -93,6 +93,48 @@ def test_save_current_tree_over_normal_ratchet_normal_climbs(name, seed, cut):
     assert o.ufboot_bad() == 0
 
 
+@pytest.mark.parametrize("rule", ["default", "mulhits", "distinct"])
+@pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9)])
+def test_cutoff_from_btrees_over_normal_ratchet_normal_climbs(name, seed, rule):
+    """-cutoff_from_btrees (tools.cpp:2442): boot_tree_orig_logl[b] = the logl under which sample b's tree was booked
+    (iqtree.cpp:3523-3527 / :3617-3619 / :3716-3718 -- on ratchet climbs the value saveCurrentTree replaced it by), and the next
+    iteration's cut-off is the smallest of them (:1657-1660).  With -mulhits the reference only ever RAISES the entries from their
+    initial 0, which negative logls never do: the cut-off stays 0 there (restated as it stands)."""
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(seed)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=6).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 3, 5)]
+    o, s = both(fx, seed, samples)
+    o.ufboot_set_cutoff_from_btrees(True)
+    s.cutoff_from_btrees = True
+    if rule == "mulhits":
+        o.ufboot_set_mulhits(True)
+        s.mulhits = True
+    if rule == "distinct":
+        o.ufboot_set_distinct_iter(2)
+        o.ufboot_set_iteration(1)
+        s.distinct = 2
+        s.cur_it = 1
+    for k, (wgt, tree) in enumerate(((w0, t[0]), (pert, t[1]), (w0, t[2]))):
+        for x in (o, s):
+            x.set_weights(wgt)
+            x.set_tree(tree)
+        assert o.optimize_spr(1, 6) == s.optimize(1, 6)
+        assert o.ufboot_orig_logl().tolist() == s.boot_tree_orig_logl
+        cut = o.ufboot_next_cutoff(10)
+        assert cut == float(min(s.boot_tree_orig_logl))
+        if rule == "mulhits":
+            assert cut == 0.0
+        else:
+            assert cut < 0.0
+        o.ufboot_set_cutoff(cut)
+        s.cutoff = cut
+    assert o.ufboot_tree_logl().tolist() == s.treels_logl
+    assert o.ufboot_bad() == 0
+
+
 @pytest.mark.parametrize("name,seed", [("dna_dups", 2), ("aa", 9), ("dna_clean", 6)])
 def test_mulhits_rule_over_normal_ratchet_normal_climbs(name, seed):
     """-mulhits (iqtree.cpp:3498-3540): every tree that reaches a sample's best REPS joins its set, trees of one
