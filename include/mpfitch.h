@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 6   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
+#define MPF_ABI_VERSION 7   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
                                4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep; 6: mpf_compute_parsimony_at */
 
 enum {
@@ -341,6 +341,13 @@ int mpf_ufboot_get_sample_iters(const mpf_engine *e, int32_t sample, int32_t *it
 /* boot_trees_parsimony[sample] in increasing order: *n = its size, the first min(*n, cap) entries written to out (may be NULL) */
 int mpf_ufboot_get_sample_trees(const mpf_engine *e, int32_t sample, int64_t *out, int32_t cap, int32_t *n);
 int mpf_ufboot_next_cutoff(const mpf_engine *e, int32_t percent, double *logl_cutoff);
+/* -cutoff_from_btrees (params->cutoff_from_btrees, tools.cpp:2442; ABI 7): boot_tree_orig_logl[b] (iqtree.h:766) = the logl under which
+   sample b's tree was booked -- set at every acceptance of the default and the -distinct_iter_top_boot rule (iqtree.cpp:3716-3718,
+   :3617-3619), only ever raised from its initial 0 by -mulhits (:3523-3527: with negative logls, never) --, and
+   mpf_ufboot_next_cutoff returns their minimum (:1657-1660) instead of the percentile of the saved trees.  Any time after the
+   attach; the array is kept whether or not the switch is on. */
+int mpf_ufboot_set_cutoff_from_btrees(mpf_engine *e, int32_t on);
+int mpf_ufboot_get_orig_logl(const mpf_engine *e, int32_t *out /* [n_samples] */);
 int mpf_ufboot_num_trees(const mpf_engine *e, int64_t *n_trees);         /* treels_logl.size() */
 int mpf_ufboot_tree_logl(const mpf_engine *e, double *out /* [n_trees] */);
 /* boot_logl / boot_counts / boot_trees (any may be NULL) */

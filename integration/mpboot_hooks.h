@@ -56,6 +56,9 @@ struct mpf_mpboot_hooks {
   int distinct_iter_top_boot;                     // globalParam->distinct_iter_top_boot (iqtree.cpp:3587-3680; without -mulhits)
   int (*cur_iteration)(IQTree *);                 // iqtree->curIt, read before every pllOptimizeSprParsimony (needed by that rule only)
   int store_top_boot_trees;                       // globalParam->store_top_boot_trees (-topboot N, with -mulhits): mpf_ufboot_set_topboot
+  // globalParam->cutoff_from_btrees (tools.cpp:2442): boot_tree_orig_logl is read back in ufboot_sync (mpf_ufboot_get_orig_logl) --
+  // the main loop then takes its minimum as logl_cutoff itself (iqtree.cpp:1657-1660), or asks mpf_ufboot_next_cutoff
+  int cutoff_from_btrees;
   // called at the end of every pllOptimizeSprParsimony with the engine that holds the saveCurrentTree bookkeeping of
   // this climb: copy treels_logl / boot_logl / boot_counts / boot_trees back with mpf_ufboot_* 
   void (*ufboot_sync)(IQTree *, mpf_engine *);

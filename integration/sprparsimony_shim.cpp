@@ -176,6 +176,7 @@ void ensure_tracking()
     if (mpf_ufboot_set_ratchet_booking(g_eng, g_hooks.no_hclimb1_bb ? 0 : 1)) die("mpf_ufboot_set_ratchet_booking");
     if (g_hooks.store_candidate_trees && mpf_ufboot_set_store_trees(g_eng, 1)) die("mpf_ufboot_set_store_trees");
     if (g_hooks.multiple_hits && mpf_ufboot_set_mulhits(g_eng, 1)) die("mpf_ufboot_set_mulhits");
+    if (g_hooks.cutoff_from_btrees && mpf_ufboot_set_cutoff_from_btrees(g_eng, 1)) die("mpf_ufboot_set_cutoff_from_btrees");
     if (g_hooks.multiple_hits && g_hooks.store_top_boot_trees > 0 && mpf_ufboot_set_topboot(g_eng, g_hooks.store_top_boot_trees)) die("mpf_ufboot_set_topboot");
     if (!g_hooks.multiple_hits && g_hooks.distinct_iter_top_boot > 0 && mpf_ufboot_set_distinct_iter(g_eng, g_hooks.distinct_iter_top_boot))
       die("mpf_ufboot_set_distinct_iter");

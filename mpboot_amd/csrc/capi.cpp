@@ -281,6 +281,13 @@ int mpf_ufboot_detach(mpf_engine *e) { NEED(e); e->eng.ufboot_detach(); return M
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff) { NEED(e); return e->eng.ufboot_set_cutoff(logl_cutoff); }
 int mpf_ufboot_set_ratchet_booking(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_ratchet_booking(on); }
 int mpf_ufboot_set_mulhits(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_mulhits(on); }
+int mpf_ufboot_set_cutoff_from_btrees(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_cutoff_from_btrees(on); }
+int mpf_ufboot_get_orig_logl(const mpf_engine *e, int32_t *out)
+{
+  if (!e || !out) { set_error("mpf_ufboot_get_orig_logl: bad argument"); return MPF_E_INVALID; }
+  e->eng.activate();
+  return e->eng.ufboot_orig_logl(out);
+}
 int mpf_ufboot_set_store_trees(mpf_engine *e, int32_t on) { NEED(e); return e->eng.ufboot_set_store_trees(on); }
 int mpf_ufboot_get_duplicates(const mpf_engine *e, uint64_t *n) { NEED(e); return e->eng.ufboot_duplicates(n); }
 int mpf_ufboot_set_topboot(mpf_engine *e, int32_t n_top) { NEED(e); return e->eng.ufboot_set_topboot(n_top); }

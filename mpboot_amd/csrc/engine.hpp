@@ -119,6 +119,11 @@ struct UfbState {
   // host bookkeeping (scores are parsimony lengths, i.e. -boot_logl; UINT32_MAX = "-LONG_MAX")
   std::vector<uint32_t> boot_score;
   std::vector<int32_t> boot_counts;
+  // boot_tree_orig_logl (iqtree.h:766, -cutoff_from_btrees): the logl under which each sample's tree was booked; cur_logl_now = that
+  // of the tree the replay has in hand (on ratchet climbs the value saveCurrentTree replaced it by)
+  std::vector<int32_t> boot_orig;
+  int32_t cur_logl_now = 0;
+  bool cut_btrees = false;                       // params->cutoff_from_btrees: mpf_ufboot_next_cutoff = min(boot_orig)
   std::vector<int64_t> boot_trees;
   std::vector<uint32_t> treels;                  // treels_logl as lengths
   std::unordered_map<int64_t, std::vector<int32_t>> store;   // topologies of the trees some sample currently points to
@@ -305,6 +310,8 @@ class Engine {
   int climb_fit_vw();                            // tile width k_climb will run with on this device (0: does not fit)
   int ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit);
   int ufboot_set_mulhits(int on);
+  int ufboot_set_cutoff_from_btrees(int on);
+  int ufboot_orig_logl(int32_t *out) const;
   int ufboot_set_store_trees(int on);
   int ufboot_duplicates(uint64_t *n) const;
   int ufboot_set_topboot(int n_top);

@@ -30,7 +30,7 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
-    "mpf_ufboot_attach", "mpf_ufboot_refine_sweep", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_num_trees",
+    "mpf_ufboot_attach", "mpf_ufboot_refine_sweep", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_set_cutoff_from_btrees", "mpf_ufboot_get_orig_logl", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
@@ -139,6 +139,8 @@ def load_library():
         L.mpf_ufboot_set_topboot.argtypes = [vp, C.c_int32]
         L.mpf_ufboot_get_sample_top.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp, vp]
         L.mpf_ufboot_next_cutoff.argtypes = [vp, C.c_int32, vp]
+        L.mpf_ufboot_set_cutoff_from_btrees.argtypes = [vp, C.c_int32]
+        L.mpf_ufboot_get_orig_logl.argtypes = [vp, vp]
         L.mpf_ufboot_num_trees.argtypes = [vp, vp]
         L.mpf_ufboot_tree_logl.argtypes = [vp, vp]
         L.mpf_ufboot_get_state.argtypes = [vp, vp, vp, vp]
@@ -514,6 +516,16 @@ class FitchEngine:
         out = np.zeros(max(n.value, 1), dtype=np.int64)
         _chk(L.mpf_ufboot_get_sample_trees(self.h, int(sample), _p(out), n.value, C.byref(n)))
         return [int(x) for x in out[:n.value]]
+
+    def ufboot_set_cutoff_from_btrees(self, on: bool):
+        """-cutoff_from_btrees: ufboot_next_cutoff = min over the samples of the logl their tree was booked under"""
+        _chk(load_library().mpf_ufboot_set_cutoff_from_btrees(self.h, 1 if on else 0))
+
+    def ufboot_orig_logl(self):
+        """boot_tree_orig_logl [n_samples]"""
+        out = np.zeros(self.ufb_B, dtype=np.int32)
+        _chk(load_library().mpf_ufboot_get_orig_logl(self.h, _p(out)))
+        return out
 
     def ufboot_next_cutoff(self, percent: int = 10) -> float:
         c = C.c_double()

@@ -93,6 +93,7 @@ int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon
   UCHK(hipStreamSynchronize(st_));
   u->boot_score.assign((size_t)n_all, UINT32_MAX);           // boot_logl = -LONG_MAX (iqtree.cpp:248)
   u->boot_counts.assign((size_t)n_all, 0);                   // :253
+  u->boot_orig.assign((size_t)n_all, 0);                     // :254
   u->boot_trees.assign((size_t)n_all, -1);                   // :252
   u->attach_wgt = wgt_;
   ufb_pool_swap(*u);                               // scratch buffers of an earlier tracker, if any
@@ -166,6 +167,20 @@ int Engine::ufboot_set_ratchet_booking(int on)
 {
   if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
   ufb_->ratchet_booking = on != 0;
+  return MPF_OK;
+}
+
+// params->cutoff_from_btrees (tools.cpp:2442): the next cut-off is the smallest boot_tree_orig_logl (iqtree.cpp:1657-1660)
+int Engine::ufboot_set_cutoff_from_btrees(int on)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  ufb_->cut_btrees = on != 0;
+  return MPF_OK;
+}
+int Engine::ufboot_orig_logl(int32_t *out) const
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  std::copy(ufb_->boot_orig.begin(), ufb_->boot_orig.end(), out);
   return MPF_OK;
 }
 
@@ -299,6 +314,7 @@ bool Engine::ufb_distinct_offer(uint32_t b, int32_t rell, int64_t &tree_index, b
   uint32_t &bs = u.boot_score[b];
   const uint32_t len = (uint32_t)(-(int64_t)rell);
   if (len < bs) u.boot_counts[b] = 1;                                       // :3598-3600
+  u.boot_orig[b] = u.cur_logl_now;                                          // :3617-3619
   if (!looked_up) { tree_index = lookup(tree_index); looked_up = true; }
   bool named = false;
   auto ref = [&](int64_t t) { u.refs[(size_t)t]++; named = true; };
@@ -407,6 +423,7 @@ void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key
 double Engine::ufboot_next_cutoff(int percent) const
 {
   if (!ufb_) return 0.0;
+  if (ufb_->cut_btrees) return (double)*std::min_element(ufb_->boot_orig.begin(), ufb_->boot_orig.end());     // :1657-1660
   const std::vector<uint32_t> &t = ufb_->treels;
   if (t.size() <= 1000) return ufb_->logl_cutoff;
   std::vector<uint32_t> l(t);
@@ -643,6 +660,7 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
           const int b8 = c2 + __builtin_ctz((unsigned)acc);
           u.log.push_back(UfbState::LogEntry{(uint32_t)b8, 0xFFFFFFFFu, tree_index, cur_plan});
           log_open = true;
+          u.boot_orig[(size_t)b8] = u.cur_logl_now;                         // :3716-3718
           if (mf && !mf[b8]) { mf[b8] = 1; moot->n_set++; }              // (it ties and now points at the current tree)
         }
         c2 += 7;
@@ -664,6 +682,7 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
     if (accept) {
       u.log.push_back(UfbState::LogEntry{b, 0xFFFFFFFFu, tree_index, cur_plan});
       log_open = true;
+      u.boot_orig[b] = u.cur_logl_now;                                  // :3716-3718
       if (s < bs) { cnt[b] = 1; bsv[b] = s; }                           // :3710-3719
       if (mf && !mf[c2]) { mf[c2] = 1; moot->n_set++; }
     }
@@ -1241,7 +1260,9 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       // (SelfMoot, see ufb_self_default: which samples hold the current topology already and tie with it -- boot_trees is this
       //  thread's here, and the log of the batch before has been worked off)
       moot_on = false;
-      if (defer && host_self && self_pass && ran_events && u.ids_identity && !rand_fn_ && ufb_moot_ && u.log.empty()) {
+      if (defer && host_self && self_pass && ran_events && u.ids_identity && !rand_fn_ && ufb_moot_ && u.log.empty() && !u.cut_btrees) {
+        // (a sample may have taken the current topology during a ratchet climb, under another logl than the tree's own: an acceptance
+        //  now would change boot_tree_orig_logl -- no shortcut while that array matters)
         if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
         const auto it = u.topo_index.find(u.self_key);
         moot.flag.assign((size_t)u.Bl + 8, 0);
@@ -1323,6 +1344,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
                 hs.clear();
                 bs = s;
               }
+              if (u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
               if (hs.insert(tree_index).second) {                         // :3530-3533
                 u.refs[(size_t)tree_index]++;
                 if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
@@ -1335,6 +1357,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               u.draws++;
               accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
             }
+            if (accept) u.boot_orig[b] = u.cur_logl_now;                  // :3716-3718
             if (accept && defer) {
               u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
               log_open = true;
@@ -1398,6 +1421,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
             pass = (store_trees || !u.gate_closed) && ran_events && !none_pass && u.stale_len <= mp_max;
             if (!pass) u.gate_closed = true;
           }
+          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : randomMP);
           const int64_t tree_index = book_tree(ratchet ? u.stale_len : randomMP, pass, 0xFFFFFFFFu);
           if (tree_index >= 0) {
             if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
@@ -1428,6 +1452,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;     // (have_C: a ratchet batch with candidates always has its product)
               if (!pass) u.gate_closed = true;
             }
+            u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : mp);
             const int64_t tree_index = book_tree(ratchet ? u.stale_len : mp, pass, (uint32_t)c);          // iqtree.cpp:3302-3348
             if (tree_index >= 0) {
               replay_events(idx, tree_index, (uint32_t)c);
@@ -2015,6 +2040,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           if (accept) {
             u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
             log_open = true;
+            u.boot_orig[b] = u.cur_logl_now;                          // :3716-3718
             if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
           }
           if (s == bs) u.boot_counts[b]++;                              // :3728-3730
@@ -2026,6 +2052,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         };
         if (pl.self_idx >= 0) {
           // the current tree, once per prune node and before its insertion tests (sprparsimony.cpp:2285-2289)
+          u.cur_logl_now = -(int32_t)randomMP;
           const int64_t tree_index = book(randomMP);
           if (host_self) {
             ufb_self_default(h_rt, tree_index, cur_plan, log_open, n_draws);
@@ -2040,6 +2067,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           for (int k = 0; k < pl.part_cnt[pi]; k++, c++) {
             const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
             const uint32_t mp = pl.base + out[idx];
+            u.cur_logl_now = -(int32_t)mp;
             const int64_t tree_index = book(mp);                        // saveCurrentTree(-mp), sprparsimony.cpp:2163-2166
             while (ep < events.size() && events[ep].idx < idx) ep++;
             for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, (uint32_t)c);
@@ -2535,6 +2563,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
                 hs.clear();
                 bs = s;
               }
+              if (u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
               if (hs.insert(tree_index).second) {
                 u.refs[(size_t)tree_index]++;
                 if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
@@ -2548,6 +2577,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
               accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
             }
             if (accept) {
+              u.boot_orig[b] = u.cur_logl_now;                            // :3716-3718
               if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
               if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               if (s < bs) { u.boot_counts[b] = 1; bs = s; }
@@ -2599,6 +2629,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
             pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
             if (!pass) u.gate_closed = true;
           }
+          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : randomMP);
           const int64_t tree_index = book_tree(ratchet ? u.stale_len : randomMP, pass, 0xFFFFFFFFu);
           if (tree_index >= 0) {
             if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
@@ -2614,6 +2645,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
             pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
             if (!pass) u.gate_closed = true;
           }
+          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : mp);
           const int64_t tree_index = book_tree(ratchet ? u.stale_len : mp, pass, (uint32_t)c);
           if (tree_index >= 0) {
             replay_events(idx, tree_index, (uint32_t)c);

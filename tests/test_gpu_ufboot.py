@@ -1034,3 +1034,60 @@ def test_storetrees_must_be_chosen_before_the_first_booking(mods):
     e.optimize_spr(1, 3)
     with pytest.raises(engine.MpfError):
         e.ufboot_set_store_trees(True)                           # trees already booked without the map
+
+
+@pytest.mark.parametrize("opts", [{}, {"ufb_pipe": 0}, {"ufb_fast": 0}])
+@pytest.mark.parametrize("rule,engine_kind", [("default", "fitch"), ("mulhits", "fitch"), ("distinct", "fitch"), ("storetrees", "fitch"), ("default", "weighted")])
+@pytest.mark.parametrize("name", ["dna_dups", "aa", "dna_48"])
+def test_cutoff_from_btrees_matches_oracle(mods, name, rule, engine_kind, opts):
+    """-cutoff_from_btrees (tools.cpp:2442): boot_tree_orig_logl -- the logl under which every sample's tree was booked
+    (iqtree.cpp:3523-3527 / :3617-3619 / :3716-3718; on ratchet climbs the value saveCurrentTree replaced cur_logl by) -- over
+    normal / ratchet / normal climbs, and the next iteration's cut-off = its minimum (:1657-1660), fed back like the main loop
+    does.  Every update rule, the weighted tracker, all ways through the tracked loop."""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    rng = np.random.default_rng(11)
+    samples = rng.multinomial(int(w0.sum()), w0 / w0.sum(), size=40).astype(np.uint16)
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    cost = None
+    if engine_kind == "weighted":
+        S = 20 if fx["datatype"] == engine.AA else 4
+        c = np.random.default_rng(2).integers(1, 4, size=(S, S))
+        cost = (np.triu(c, 1) + np.triu(c, 1).T).astype(np.uint32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    trees_ = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 3, 5)]
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.set_tree(trees_[0])
+        x.seed_ties(mode, 13)
+        x.ufboot_attach(samples)
+        x.ufboot_set_cutoff_from_btrees(True)
+        if rule == "mulhits":
+            x.ufboot_set_mulhits(True)
+        if rule == "distinct":
+            x.ufboot_set_distinct_iter(2)
+            x.ufboot_set_iteration(1)
+        if rule == "storetrees":
+            x.ufboot_set_store_trees(True)
+    for k, (wgt, tree) in enumerate(((w0, trees_[0]), (pert, trees_[1]), (w0, trees_[2]))):
+        for x in (e, o):
+            x.set_weights(wgt)
+            x.set_tree(tree)
+            if rule == "distinct":
+                x.ufboot_set_iteration(1 + k)
+        assert e.optimize_spr(1, 6) == o.optimize_spr(1, 6)
+        assert e.ufboot_orig_logl().tolist() == o.ufboot_orig_logl().tolist()
+        ce, co = e.ufboot_next_cutoff(10), o.ufboot_next_cutoff(10)
+        assert ce == co
+        assert (ce == 0.0) == (rule == "mulhits")
+        le, cne, te = e.ufboot_state()
+        lo, cno, to = o.ufboot_state()
+        assert le.tolist() == lo.tolist() and cne.tolist() == cno.tolist() and te.tolist() == to.tolist()
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert e.tie_state() == o.tie_state()
+        e.ufboot_set_cutoff(ce)
+        o.ufboot_set_cutoff(co)
+    assert o.ufboot_bad() == 0
