@@ -1196,7 +1196,9 @@ int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
   plan.n_p = plan.n_total = 0;
   if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
   if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
-  if (maxtrav > kMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
+  // (Fitch: any radius -- beyond kMaxDepth levels the up-vectors live in HBM, k_scan_deep; the weighted kernels keep theirs in
+  //  registers: 12 levels for DNA, 6 otherwise)
+  if (maxtrav > (sankoff_ ? (g_.S == 4 ? kMaxDepth : 6) : 255)) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
   const int q = back_[p];
   plan.base = sankoff_ ? 0u : (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);   // weighted: the kernel returns full lengths
   if (maxtrav < mintrav) return MPF_OK;
@@ -1289,7 +1291,14 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   zeroed_ptr_ = nullptr;
   zeroed_words_ = 0;
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
-  const bool host_direct = want_host_results_ && !sankoff_ && nout <= 16384 && (cnt_on_host_ || !cnt_copy_pending_);
+  const bool deep = !sankoff_ && prog_max_depth_ > kMaxDepth;
+  if (deep && !g_.deep_scratch) {
+    // per-level up-vectors of the scans' waves: 256 MB, the launches are cut to fit (launch_scan)
+    HIPCHK(d_deep_.reserve(deep_scratch_words_));
+    g_.deep_scratch = d_deep_.p;
+    g_.deep_scratch_words = deep_scratch_words_;
+  }
+  const bool host_direct = want_host_results_ && !sankoff_ && !deep && nout <= 16384 && (cnt_on_host_ || !cnt_copy_pending_);
   if (host_direct) __atomic_store_n(h_out() + nout, 0u, __ATOMIC_RELAXED);       // the flag word behind the results
   uint16_t *vals = nullptr;
   uint32_t *vmax = nullptr;
@@ -2023,6 +2032,11 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "host_poll") { host_poll_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_fast") { ufb_fast_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_quiet") { ufb_quiet_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "deep_scratch_kwords") {             // (tests: a small scratch cuts a deep scan into many launches)
+    if (v < 1 || v > (1 << 22)) { set_error("deep_scratch_kwords: 1 .. 4194304"); return MPF_E_INVALID; }
+    deep_scratch_words_ = (size_t)v << 10; d_deep_.release(); g_.deep_scratch = nullptr; g_.deep_scratch_words = 0;
+    return MPF_OK;
+  }
   if (key == "grow_device") { grow_device_ = v ? 1 : 0; return MPF_OK; }
   if (key == "grow_tile") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != -1) { set_error("grow_tile: 0 (word-major copy where there is one, else fitted), -1 (fitted quad tiles), 1, 2, 4 or 8"); return MPF_E_INVALID; } grow_vw_ = (int)v; return MPF_OK; }
   if (key == "grow_fault") { grow_fault_ = v; return MPF_OK; }

@@ -554,6 +554,8 @@ class Engine {
     return hipSuccess;
   }
   DevBuf<int32_t> d_site2ptn_;
+  size_t deep_scratch_words_ = (size_t)1 << 26;   // option "deep_scratch_kwords" (256 MB)
+  DevBuf<uint32_t> d_deep_;                      // k_scan_deep's scratch (Geometry::deep_scratch), allocated by the first scan above kMaxDepth levels
   DevBuf<EvOp> d_evops_;
   DevBuf<ScanOp> d_scanops_;
   DevBuf<ScanHdr> d_scanhdr_;

@@ -1087,6 +1087,70 @@ __device__ __forceinline__ void scan_body(const uint32_t *__restrict__ vec, cons
   }
 }
 
+// The same programs at ANY radius (rearrangeParsimony takes whatever -spr_rad gives it, sprparsimony.cpp:2259-2376): the up-vectors
+// of the levels do not fit registers beyond MAXD = 12, so here they live in a scratch area of the wave in HBM (one tile per
+// level).  The vector of the level just computed stays in registers -- a DFS mostly goes on one level down --, a step back up
+// re-reads its parent level.  Rarely used (mpboot's default radius is 6): one store per step, sometimes a load; the launches are
+// cut so that the scratch stays bounded (launch_scan).
+template <int S, int VW, int RED>
+__global__ __launch_bounds__(256) void k_scan_deep(const uint32_t *__restrict__ vec, const ScanHdr *__restrict__ hdr,
+                                                   int n_scans, const ScanOp *__restrict__ ops, uint32_t *__restrict__ out,
+                                                   int Wp, int tiles, uint32_t *__restrict__ scratch, int levels)
+{
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_scans * tiles) return;
+  const int scan = gw / tiles, tile = gw - scan * tiles;
+  const ScanHdr h = hdr[scan];
+  bool valid;
+  const int w0 = lane_word<VW>(tile, lane, Wp, valid);
+  uint32_t *mine = scratch + (size_t)gw * (size_t)levels * (size_t)(S * VW * 64) + lane;
+  auto put = [&](int lev, const Tile<S, VW> &t) {
+    uint32_t *q = mine + (size_t)lev * (size_t)(S * VW * 64);
+#pragma unroll
+    for (int k = 0; k < S * VW; k++) q[k * 64] = t.v[k / VW][k % VW];
+  };
+  auto get = [&](int lev, Tile<S, VW> &t) {
+    const uint32_t *q = mine + (size_t)lev * (size_t)(S * VW * 64);
+#pragma unroll
+    for (int k = 0; k < S * VW; k++) t.v[k / VW][k % VW] = q[k * 64];
+  };
+  Tile<S, VW> sv, last, par, dsib, down;
+  int ld = -1;                                       // level of `last`
+  load_tile<S, VW>(sv, vec, h.s_slot, Wp, w0);
+  for (uint32_t i = h.op_begin; i < h.op_end; i++) {
+    const ScanOp o = ops[i];
+    const int d = (int)(o.meta & 0xFFu);
+    const bool test = (o.meta >> 8) & 1u;
+    const int kind = (int)((o.meta >> 16) & 0xFFu);
+    if (kind == SCAN_ROOT) {
+      load_tile<S, VW>(last, vec, o.own, Wp, w0);
+      put(0, last);
+      ld = 0;
+      continue;
+    }
+    load_tile<S, VW>(dsib, vec, o.sib, Wp, w0);
+    uint32_t cost = 0;
+    if (kind == SCAN_JOIN) {
+      load_tile<S, VW>(down, vec, o.own, Wp, w0);
+      cost = join_cost<S, VW>(dsib, down, sv);
+    } else {
+      if (test) load_tile<S, VW>(down, vec, o.own, Wp, w0);
+      if (d - 1 == ld) par = last; else get(d - 1, par);
+      fitch<S, VW>(last, par, dsib);
+      ld = d;
+      if (d + 1 < levels) put(d, last);              // (the deepest level has no children)
+      if (test) cost = join_cost<S, VW>(last, down, sv);
+    }
+    if (test || kind == SCAN_JOIN) {
+      cost = valid ? cost : 0u;
+      const uint32_t tot = wave_total<RED>(cost);
+      if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+    }
+  }
+}
+
 // Tail of a launch whose last workgroup has just copied its n_out results into the host's pinned buffer: the completion
 // counter goes back to zero and host_out[n_out] = 1 tells a polling host thread that results (and the mutation counts an
 // earlier launch wrote to the host) are there -- without the wake-up latency of a stream synchronisation.
@@ -2278,6 +2342,29 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
 #undef SNKSCAN2
 #undef SNKSCAN3
     return hipGetLastError();
+  }
+  if (max_depth > kMaxDepth) {
+    // beyond the levels that fit registers: k_scan_deep, cut into launches whose waves' scratch (levels x one tile each) stays
+    // within scan_deep_scratch_words
+    if (host_out || !g.deep_scratch) return hipErrorInvalidValue;
+    const int levels = max_depth + 1;
+    const size_t per_wave = (size_t)levels * (size_t)(g.S * g.vw * 64);
+    long per_launch = (long)(g.deep_scratch_words / per_wave) / tiles;
+    if (per_launch < 1) return hipErrorOutOfMemory;
+    for (long s0 = 0; s0 < n_scans; s0 += per_launch) {
+      const int ns = (int)std::min<long>(per_launch, n_scans - s0);
+      dim3 dgrid((unsigned)(((long)ns * tiles + 3) / 4));
+#define SD(S_, VW_, dummy)                                                                                                     \
+      do {                                                                                                                     \
+        if (g.reduce == 0) hipLaunchKernelGGL((k_scan_deep<S_, VW_, 0>), dgrid, block, 0, st, vec, hdr + s0, ns, ops, out, g.Wp, tiles, g.deep_scratch, levels); \
+        else hipLaunchKernelGGL((k_scan_deep<S_, VW_, 1>), dgrid, block, 0, st, vec, hdr + s0, ns, ops, out, g.Wp, tiles, g.deep_scratch, levels);              \
+      } while (0)
+      MPF_DISPATCH_SV(SD, 0);
+#undef SD
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
   }
   if (g.map == 0) {
     const long waves = (long)n_scans * tiles;

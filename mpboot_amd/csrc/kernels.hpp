@@ -49,6 +49,9 @@ struct Geometry {
   // 75 GB/s for the four 256-byte row loads (tools/ubench/l1_rate: the load path inside the CU is what bounds the planned scan).
   // Written by k_pack_tips and k_newview_wgq, read by k_scan_prog while Engine::shadow_ok_ holds.
   size_t shoff = 0;
+  // radii above kMaxDepth (k_scan_deep): the scans' per-level up-vectors live in this scratch area (allocated on first use)
+  uint32_t *deep_scratch = nullptr;
+  size_t deep_scratch_words = 0;
   int nv_tile = 0;   // ... on tiles of 32 | 16 | 8 | 4 words (Wp / tile workgroups); 0 = chosen from Wp (newview_tile)
   // Sankoff (weighted parsimony) mode: vectors hold one 32-bit cost per state and pattern
   int sankoff = 0;

@@ -50,9 +50,11 @@ def test_tiny_trees(mods, n):
     assert (e3.get_tree() == o3.get_tree()).all()
 
 
-@pytest.mark.parametrize("maxtrav,mode", [(1, 1), (2, 1), (7, 1), (8, 1), (9, 1), (12, 0), (10, 0)])
+@pytest.mark.parametrize("maxtrav,mode", [(1, 1), (2, 1), (7, 1), (8, 1), (9, 1), (12, 0), (10, 0), (13, 1), (20, 0), (37, 1), (99, 1)])
 def test_radii(mods, maxtrav, mode):
-    """radius 7-8 uses the deep device-walked kernel, 9-12 the host-planned one"""
+    """radius 7-8 uses the deep device-walked kernel, 9-12 the host-planned one, anything above (rearrangeParsimony takes whatever
+    -spr_rad gives it: 37 = the whole 40-taxon tree, 99 is clipped to it) the host-planned programs with the levels' up-vectors in
+    HBM (k_scan_deep)"""
     engine, po, synth, trees = mods
     letters, _ = synth.synth_alignment(40, 500, "DNA", 0.1, seed=31)
     codes = synth.letters_to_codes(letters)
@@ -75,6 +77,27 @@ def test_radii(mods, maxtrav, mode):
     o2.seed_ties(po.TIE_RANDOM, 2)
     assert e.optimize_spr(1, maxtrav) == o2.optimize_spr(1, maxtrav)
     assert (e.get_tree() == o2.get_tree()).all()
+
+
+@pytest.mark.parametrize("alphabet,n,P,maxtrav,kwords", [("AA", 30, 300, 16, 64), ("DNA", 60, 2500, 25, 16), ("DNA", 60, 2500, 14, 1 << 16)])
+def test_radii_above_twelve_in_cut_launches(mods, alphabet, n, P, maxtrav, kwords):
+    """k_scan_deep with a scratch so small that a batch of scans is cut into many launches (option deep_scratch_kwords), protein and
+    DNA on several tiles: whole climbs against the oracle"""
+    engine, po, synth, trees = mods
+    letters, _ = synth.synth_alignment(n, P, alphabet, 0.09, seed=n + maxtrav)
+    codes = synth.letters_to_codes(letters, alphabet)
+    dt_e, dt_o = (engine.DNA, po.DNA) if alphabet == "DNA" else (engine.AA, po.AA)
+    back = trees.random_topology(n, np.random.default_rng(9))
+    e = engine.FitchEngine(codes, datatype=dt_e)
+    e.set_option("deep_scratch_kwords", kwords)
+    o = po.Oracle(codes, datatype=dt_o)
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.set_tree(back)
+        x.seed_ties(mode, 4)
+    o.trace(True)
+    assert e.optimize_spr(1, maxtrav) == o.optimize_spr(1, maxtrav)
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all() and e.tie_state() == o.tie_state()
 
 
 def test_keep_all_sites_and_zero_weights(mods):
@@ -126,8 +149,13 @@ def test_error_behaviour(mods):
     with pytest.raises(engine.MpfError):
         engine.FitchEngine(fx["codes_np"], -np.ones(fx["codes_np"].shape[1], dtype=np.int32))
     e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    q13, mp13, _ = e.spr_scan(6, 1, 13)                  # any radius on the Fitch engine (k_scan_deep above 12 levels) ...
+    q99, mp99, _ = e.spr_scan(6, 1, 99)                  # ... clipped to the tree like rearrangeParsimony clips it
+    assert len(q13) > 0 and len(q99) >= len(q13)
+    sk = engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=(1 - np.eye(4)).astype(np.uint32))
+    sk.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
     with pytest.raises(engine.MpfError):
-        e.spr_scan(6, 1, 13)                             # beyond the supported radius
+        sk.spr_scan(6, 1, 13)                            # the weighted kernels keep their levels in registers: 12 for DNA
 
 
 def test_engine_reuse_across_trees_and_rebuilds(mods):
