@@ -297,6 +297,22 @@ int mpf_ufboot_attach_sharded(mpf_engine *e, int32_t n_samples, int32_t n_local,
                               const uint16_t *samples_local /* [n_local][n_patterns] */, double epsilon,
                               mpf_ufb_exchange_fn exchange, void *arg);
 int mpf_ufboot_detach(mpf_engine *e);
+/* The exchanges of the multi-GPU path, native (ABI 7; mpboot_amd/host/rccl_exchange.cpp): RCCL over xGMI from inside the library,
+   librccl opened at run time.  One communicator per process / GPU: rank 0 makes the id (mpf_rccl_unique_id, 128 bytes) and hands
+   it to the others by whatever the host has; everybody calls mpf_rccl_create.  mpf_rccl_exchange IS an mpf_ufb_exchange_fn --
+   pass it with the communicator as `arg` to mpf_ufboot_attach_sharded: one all-gather of fixed-size event blocks per scan
+   batch on a stream of its own, a second one only when some rank has more than 4096 events.  mpf_rccl_allreduce_min: the
+   "single all-reduce of best scores per round" of independent units (start trees, replicates).  The reference has nothing
+   distributed: these replace what a multi-GPU mpboot host would otherwise write with MPI. */
+typedef struct mpf_rccl mpf_rccl;
+int mpf_rccl_available(void);
+int mpf_rccl_unique_id(uint8_t *out /* [128] */);
+int mpf_rccl_create(mpf_rccl **out, const uint8_t *id /* [128] */, int32_t rank, int32_t world, int32_t device);
+void mpf_rccl_destroy(mpf_rccl *c);
+int mpf_rccl_exchange(void *arg /* mpf_rccl* */, uint32_t tag, const mpf_ufb_event *local, uint32_t n_local,
+                      const mpf_ufb_event **all, uint32_t *n_all);
+int mpf_rccl_allreduce_min(mpf_rccl *c, uint32_t *vals, int32_t n);
+int mpf_rccl_counters(const mpf_rccl *c, uint64_t *exchanges, uint64_t *overflows);
 int mpf_ufboot_set_cutoff(mpf_engine *e, double logl_cutoff);            /* IQTree::logl_cutoff; 0 = none */
 /* Climbs under other pattern weights than the attach-time ones (ratchet iterations: mpf_set_weights between attach and
    mpf_optimize_spr) are booked as the reference's default books them (iqtree.cpp:3283-3295): the length a candidate is

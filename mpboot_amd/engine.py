@@ -30,7 +30,7 @@ EXPORTS = [
     "mpf_set_rand_callback", "mpf_spr_scan", "mpf_spr_sweep_scan", "mpf_spr_sweep_costs", "mpf_get_node_order", "mpf_optimize_spr",
     "mpf_make_parsimony_tree", "mpf_stepwise_addition", "mpf_get_moves", "mpf_get_stats", "mpf_reset_stats",
     "mpf_set_option", "mpf_get_option", "mpf_get_scan_trace", "mpf_reps_create", "mpf_reps_scores", "mpf_reps_destroy",
-    "mpf_ufboot_attach", "mpf_ufboot_refine_sweep", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_set_cutoff_from_btrees", "mpf_ufboot_get_orig_logl", "mpf_ufboot_num_trees",
+    "mpf_ufboot_attach", "mpf_ufboot_refine_sweep", "mpf_ufboot_attach_sharded", "mpf_ufboot_detach", "mpf_ufboot_set_cutoff", "mpf_ufboot_set_ratchet_booking", "mpf_ufboot_set_mulhits", "mpf_ufboot_set_store_trees", "mpf_ufboot_get_duplicates", "mpf_ufboot_get_sample_trees", "mpf_ufboot_set_topboot", "mpf_ufboot_get_sample_top", "mpf_ufboot_set_distinct_iter", "mpf_ufboot_set_iteration", "mpf_ufboot_get_sample_iters", "mpf_ufboot_next_cutoff", "mpf_ufboot_set_cutoff_from_btrees", "mpf_ufboot_get_orig_logl", "mpf_rccl_available", "mpf_rccl_unique_id", "mpf_rccl_create", "mpf_rccl_destroy", "mpf_rccl_exchange", "mpf_rccl_allreduce_min", "mpf_rccl_counters", "mpf_ufboot_num_trees",
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
@@ -140,6 +140,12 @@ def load_library():
         L.mpf_ufboot_get_sample_top.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp, vp]
         L.mpf_ufboot_next_cutoff.argtypes = [vp, C.c_int32, vp]
         L.mpf_ufboot_set_cutoff_from_btrees.argtypes = [vp, C.c_int32]
+        L.mpf_rccl_unique_id.argtypes = [vp]
+        L.mpf_rccl_create.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
+        L.mpf_rccl_destroy.argtypes = [vp]
+        L.mpf_rccl_destroy.restype = None
+        L.mpf_rccl_allreduce_min.argtypes = [vp, vp, C.c_int32]
+        L.mpf_rccl_counters.argtypes = [vp, vp, vp]
         L.mpf_ufboot_get_orig_logl.argtypes = [vp, vp]
         L.mpf_ufboot_num_trees.argtypes = [vp, vp]
         L.mpf_ufboot_tree_logl.argtypes = [vp, vp]
@@ -230,6 +236,50 @@ class Reps:
     def close(self):
         if getattr(self, "h", None):
             load_library().mpf_reps_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RcclComm:
+    """The library's own RCCL communicator (include/mpfitch.h: mpf_rccl_*): event exchange of a sample-sharded online phase and the
+    all-reduce of best scores, native -- no torch in the data path.  `uid`: 128 bytes from RcclComm.unique_id() on rank 0, carried
+    to the other ranks by the caller (mpboot_amd.shard.native_comm does it over torch.distributed's store)."""
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int = 0):
+        L = load_library()
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _chk(L.mpf_rccl_create(C.byref(self.h), buf, rank, world, device))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def available() -> bool:
+        return bool(load_library().mpf_rccl_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _chk(load_library().mpf_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def allreduce_min(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        _chk(load_library().mpf_rccl_allreduce_min(self.h, _p(v), len(v)))
+        return v
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(load_library().mpf_rccl_counters(self.h, C.byref(a), C.byref(b)))
+        return {"exchanges": a.value, "overflows": b.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mpf_rccl_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -438,7 +488,11 @@ class FitchEngine:
         if exchange is None:
             from . import shard as _shard
             exchange = _shard.event_exchange()
-        self._ufb_exchange = exchange            # keep the ctypes callback alive as long as the tracker
+        self._ufb_exchange = exchange            # keep the ctypes callback (or the native communicator) alive as long as the tracker
+        if isinstance(exchange, RcclComm):       # the library's own exchange: mpf_rccl_exchange with the communicator as its argument
+            fn = C.cast(load_library().mpf_rccl_exchange, C.c_void_p)
+            _chk(load_library().mpf_ufboot_attach_sharded(self.h, self.ufb_B, len(ids), _p(ids), _p(local), float(epsilon), fn, exchange.h))
+            return
         _chk(load_library().mpf_ufboot_attach_sharded(self.h, self.ufb_B, len(ids), _p(ids), _p(local), float(epsilon),
                                                       C.cast(exchange, C.c_void_p), None))
 

@@ -168,6 +168,19 @@ def gather_events(local: np.ndarray, tag: int = 0) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate(parts, axis=0)).view(np.uint32)
 
 
+def native_comm(device: int = 0):
+    """The library's own RCCL communicator for this process's rank (engine.RcclComm), its id carried from rank 0 over
+    torch.distributed (any backend: 128 bytes, once): pass it as `exchange` to FitchEngine.ufboot_attach for an event exchange
+    that never leaves the library.  None where librccl is not available or the run has one rank."""
+    from . import engine as _engine
+    rank, ws = world()
+    if ws == 1 or not _engine.RcclComm.available():
+        return None
+    box = [_engine.RcclComm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return _engine.RcclComm(box[0], rank, ws, device)
+
+
 def event_exchange():
     """The callback mpf_ufboot_attach_sharded takes (include/mpfitch.h: mpf_ufb_exchange_fn)."""
     keep = {}

@@ -86,6 +86,16 @@ allr = [None] * ws
 dist.all_gather_object(allr, res)
 out["ranks_agree"] = all(r == allr[0] for r in allr)
 out["ufb"] = res
+# the same phase once more with the library's OWN exchange (mpf_rccl_exchange: ncclAllGather from inside libmpfitch.so)
+comm = shard.native_comm(lr)
+e2 = engine.FitchEngine(codes, device=lr)
+e2.ufboot_attach(samples, 0.5, shard=(rank, ws), exchange=comm)
+e2.set_tree(back); e2.reset_node_order(); e2.seed_ties(engine.TIE_RANDOM, 1)
+s2 = e2.optimize_spr(1, 6)
+l2, c2, t2 = e2.ufboot_state()
+out["native_same"] = (s2, l2.tolist(), c2.tolist(), t2.tolist(), e2.get_tree().tolist()) == (s, logl.tolist(), cnt.tolist(), tr.tolist(), e.get_tree().tolist())
+out["native_exchanges"] = comm.counters()["exchanges"]
+out["native_min"] = comm.allreduce_min([100 + rank, 50 - rank, 7]).tolist()
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()
@@ -108,6 +118,8 @@ def _gpu_count():
 
 
 def test_two_rccl_ranks_exchange_and_sample_sharded_online_phase(tmp_path):
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
     import json
     import socket
 
@@ -134,6 +146,7 @@ def test_two_rccl_ranks_exchange_and_sample_sharded_online_phase(tmp_path):
     assert got["best"] == [100, 101, 7]
     assert got["tree"] == list(range(12))
     assert got["ranks_agree"]
+    assert got["native_same"] and got["native_exchanges"] > 0 and got["native_min"] == [100, 49, 7]
     # == the unsharded engine on this process's GPU
     letters, _ = synth.synth_alignment(40, 2000, "DNA", 0.08, seed=21)
     codes = synth.letters_to_codes(letters, "DNA")
@@ -148,3 +161,48 @@ def test_two_rccl_ranks_exchange_and_sample_sharded_online_phase(tmp_path):
     u = got["ufb"]
     assert (u["s"], u["logl"], u["cnt"], u["tr"], u["final"]) == (s, logl.tolist(), cnt.tolist(), tr.tolist(), e.get_tree().tolist())
     assert u["draws"] == e.ufboot_counters()["tie_draws"]
+
+
+def test_native_rccl_exchange_on_one_rank():
+    """mpf_rccl_* (mpboot_amd/host/rccl_exchange.cpp): the library's own communicator -- ncclCommInitRank, the fixed-block
+    ncclAllGather of a batch's events incl. the overflow gather, ncclAllReduce(min) -- on the one GPU this box has, as a
+    communicator of ONE rank: a sample-"sharded" tracker whose shard is every sample goes through the exchange at every batch
+    and must reproduce the unsharded run.  (Two real ranks: the test above, wherever two GPUs are visible.)"""
+    import ctypes as C
+
+    import numpy as np
+    from mpboot_amd import engine, synth, trees
+    if not engine.RcclComm.available():
+        pytest.skip("librccl.so not found")
+    comm = engine.RcclComm(engine.RcclComm.unique_id(), 0, 1, 0)
+    assert comm.allreduce_min([9, 3, 2 ** 32 - 1]).tolist() == [9, 3, 2 ** 32 - 1]
+    letters, _ = synth.synth_alignment(40, 2000, "DNA", 0.08, seed=21)
+    codes = synth.letters_to_codes(letters, "DNA")
+    P = codes.shape[1]
+    back = trees.random_topology(40, np.random.default_rng(5))
+    for B in (64, 700):                                   # 700 samples: batches with more than 4096 events (the second gather)
+        samples = np.random.default_rng(7).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
+        ref = engine.FitchEngine(codes)
+        ref.ufboot_attach(samples, 0.5)
+        ref.set_tree(back); ref.reset_node_order(); ref.seed_ties(engine.TIE_RANDOM, 1)
+        s = ref.optimize_spr(1, 6)
+        e = engine.FitchEngine(codes)
+        L = engine.load_library()
+        ids = np.arange(B, dtype=np.int32)
+        e.ufb_B = B
+        rc = L.mpf_ufboot_attach_sharded(e.h, B, B, ids.ctypes.data_as(C.c_void_p), samples.ctypes.data_as(C.c_void_p), C.c_double(0.5),
+                                         C.cast(L.mpf_rccl_exchange, C.c_void_p), comm.h)
+        assert rc == 0, L.mpf_last_error()
+        e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1)
+        before = comm.counters()
+        assert e.optimize_spr(1, 6) == s
+        after = comm.counters()
+        assert after["exchanges"] > before["exchanges"]
+        if B == 700:
+            assert after["overflows"] > before["overflows"]
+        for a, b in zip(e.ufboot_state(), ref.ufboot_state()):
+            assert a.tolist() == b.tolist()
+        assert (e.get_tree() == ref.get_tree()).all() and e.tie_state() == ref.tie_state()
+        assert e.ufboot_counters()["tie_draws"] == ref.ufboot_counters()["tie_draws"]
+        assert e.ufboot_tree_logl().tolist() == ref.ufboot_tree_logl().tolist()
+    comm.close()
