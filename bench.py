@@ -849,9 +849,17 @@ def main():
             samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
             from mpboot_amd import shard
             back_u = shard.broadcast_tree(back, 0, len(back))      # the chain starts from rank 0's tree on every rank
+            # a sample-sharded online phase exchanges its events through the library's own RCCL communicator (mpf_rccl_exchange:
+            # ncclAllGather from inside libmpfitch.so) where that is to be had; torch.distributed otherwise (gloo in the CPU tests)
+            native_x = None
+            if world > 1 and backend == "nccl" and shard.online_shard(B, rank, world, args.shard_online) is not None:
+                try:
+                    native_x = shard.native_comm(device)
+                except Exception:
+                    native_x = None
             tus = []
             for timed in (False, True, True):          # first pass: allocations, code load; then two timed passes, the faster one counts
-                eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online))   # sharded: samples rank, rank + world, ... ; events all-gathered per batch
+                eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online), exchange=native_x)   # sharded: samples rank, rank + world, ... ; events all-gathered per batch
                 eng.set_tree(back_u)
                 eng.reset_node_order()
                 eng.seed_ties(engine.TIE_RANDOM, 1)
@@ -957,7 +965,7 @@ def main():
                                           "seconds_host_driven_batches": t_plain_h,
                                           "what": "pllOptimizeSprParsimony from a random tree: sweeps with dense moves run in the persistent kernel "
                                                   "k_climb (device-resident loop), sparse ones as whole-chip host-driven batches"}}
-                eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online))
+                eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online), exchange=native_x)
                 eng.set_tree(back_r)
                 eng.reset_node_order()
                 eng.seed_ties(engine.TIE_RANDOM, 1)
@@ -1002,8 +1010,9 @@ def main():
                     it_leg = {"seconds": t_it, "cutoff_length": -cut_bb, "perturbed_score": s_pert, "score": s_it, "moves": st_it["moves_applied"],
                               "insertion_tests": st_it["insertion_tests"],
                               "what": "one later search iteration of the same run: logl_cutoff = top 10 % of the saved trees, best tree perturbed by 30 "
-                                      "random SPR moves, SPR climb with saveCurrentTree bookkeeping under the cut-off (the two-wait path: with a cut-off "
-                                      "the product is compacted on the host between scan and product)"}
+                                      "random SPR moves, SPR climb with saveCurrentTree bookkeeping under the cut-off: the stretch in which nothing "
+                                      "reaches the bookkeeping runs as the plain climb (k_climb with a hand-back condition, cost-only batches), the "
+                                      "rest on the tracker's two-wait loop (product compacted on the host); random_start.bb_run times 50 of them"}
                 except Exception as exc:
                     it_leg = {"error": repr(exc)}
                 eng.ufboot_detach()
