@@ -40,7 +40,6 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local, const int32_t *sample_ids,
                           mpf_ufb_exchange_fn exchange, void *exchange_arg)
 {
-  if (sankoff_ && exchange) { set_error("online UFBoot on the weighted engine: sample sharding is not supported"); return MPF_E_UNSUPPORTED; }
   // (an asymmetric matrix gives the CURRENT tree another length at every prune node's visit -- it is evaluated at that node's
   //  edge --, which the tracker's one row for the current tree does not model)
   if (sankoff_ && asym_) { set_error("online UFBoot on the weighted engine: the cost matrix must be symmetric"); return MPF_E_UNSUPPORTED; }
@@ -2356,7 +2355,12 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
 int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
 {
   UfbState &u = *ufb_;
-  if (u.exchange) { set_error("online UFBoot on the weighted engine: sample sharding is not supported"); return MPF_E_UNSUPPORTED; }
+  if (u.exchange) {
+    // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy state
+    gap_est_ = -1.0;
+    since_move_ = 0;
+  }
+  uint32_t exchange_tag = 0;
   uint32_t startMP;
   unsigned iter_hits = 1;
   const int total = 2 * n_ - 2;
@@ -2371,7 +2375,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
   std::string mh_key;
   const bool ratchet = u.ratchet;
   const bool store_trees = u.store_trees;          // -storetrees (iqtree.cpp:3302-3346)
-  const bool host_self = true;
+  const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the current tree's bookings come as device events)
   const int oc = u.Bl;
   if (ratchet) u.gate_closed = false;
   bool stale_init = false;                         // ratchet: _pattern_pars of the climb's start tree, known after the first product
@@ -2503,6 +2507,17 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         }
         events.assign(u.h_ev.p, u.h_ev.p + n_ev);
         for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];
+        if (u.exchange) {
+          // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
+          const mpf_ufb_event *all = nullptr;
+          uint32_t n_all_ev = 0;
+          if (u.exchange(u.exchange_arg, exchange_tag++, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
+            set_error("online UFBoot: event exchange failed (ranks out of step?)");
+            return MPF_E_STATE;
+          }
+          const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
+          events.assign(pa, pa + n_all_ev);
+        }
         sort_events(events, ev_tmp, ev_count, std::max<uint32_t>(n_idx, 1u), (uint32_t)u.B);
         u.events += n_ev;
         if (ratchet) {
@@ -2695,6 +2710,12 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
   } while (randomMP < startMP);
   climb_finished(total);
   u.rt_valid = false;
+  if (u.exchange) {
+    // closing handshake: a rank that took another path would be in the middle of a batch here
+    const mpf_ufb_event *all = nullptr;
+    uint32_t n_all_ev = 0;
+    if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
+  }
   if (final_score) *final_score = randomMP;
   return MPF_OK;
 }

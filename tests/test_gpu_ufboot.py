@@ -495,7 +495,13 @@ fx = load_fixture(os.environ["MPF_FX"])
 P = len(fx["weights"])
 w = np.asarray(fx["weights"], dtype=np.float64)
 samples = np.random.default_rng(31).multinomial(int(w.sum()), w / w.sum(), size=23).astype(np.uint16)
-e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+rule = os.environ.get("MPF_RULE", "default")
+cost = None
+if rule.startswith("weighted"):
+    S = 20 if os.environ["MPF_FX"] == "aa" else 4
+    c = np.random.default_rng(2).integers(1, 4, size=(S, S))
+    cost = (np.triu(c, 1) + np.triu(c, 1).T).astype(np.uint32)
+e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
 if rank == 1:
     # a different past on this engine (its batch-size estimate, node order ...) must not change how it cuts the climb
     e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
@@ -509,7 +515,8 @@ e.set_option("scan_batch", 4)          # small batches: several exchanges per cl
 e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
 e.seed_ties(engine.TIE_RANDOM, 19)
 e.ufboot_attach(samples, 0.5, shard=(rank, ws))
-rule = os.environ.get("MPF_RULE", "default")
+if rule == "weighted_mulhits":
+    e.ufboot_set_mulhits(True)
 if rule == "storetrees":
     e.ufboot_set_store_trees(True)
 if rule == "topboot":
@@ -538,7 +545,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("rule", ["default", "topboot", "distinct", "storetrees"])
+@pytest.mark.parametrize("rule", ["default", "topboot", "distinct", "storetrees", "weighted", "weighted_mulhits"])
 @pytest.mark.parametrize("name", ["dna_ambig", "aa"])
 def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, name, rule):
     """two ranks (sharing this GPU) hold half of the samples each and exchange their events per batch: every rank must
@@ -554,10 +561,17 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
     fx = load_fixture(name)
     w = np.asarray(fx["weights"], dtype=np.float64)
     samples = np.random.default_rng(31).multinomial(int(w.sum()), w / w.sum(), size=23).astype(np.uint16)
-    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    cost = None
+    if rule.startswith("weighted"):                  # the weighted (-cost) tracker, sample-sharded as well (round 5)
+        S = 20 if name == "aa" else 4
+        c = np.random.default_rng(2).integers(1, 4, size=(S, S))
+        cost = (np.triu(c, 1) + np.triu(c, 1).T).astype(np.uint32)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
     e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
     e.seed_ties(engine.TIE_RANDOM, 19)
     e.ufboot_attach(samples)
+    if rule == "weighted_mulhits":
+        e.ufboot_set_mulhits(True)
     if rule == "storetrees":
         e.ufboot_set_store_trees(True)
     if rule == "topboot":
@@ -607,10 +621,13 @@ def test_unsupported_configurations_fail_loudly(mods):
         e.ufboot_next_cutoff(10)
     cost = (1 - np.eye(4)).astype(np.uint32)
     s = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
-    s.ufboot_attach(samples)                       # the weighted engine keeps the bookkeeping too ...
-    s.ufboot_detach()
-    with pytest.raises(engine.MpfError):           # ... but not sample-sharded
-        s.ufboot_attach(samples, shard=(0, 2))
+    s.ufboot_attach(samples)                       # the weighted engine keeps the bookkeeping too (sample-sharded as well: see
+    s.ufboot_detach()                              # test_sample_sharded_online_phase_equals_the_unsharded_run) ...
+    asym = cost.copy()
+    asym[0, 1] = 2                                 # ... but not under an asymmetric matrix (the current tree's length depends on the visit's edge)
+    a = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=asym)
+    with pytest.raises(engine.MpfError):
+        a.ufboot_attach(samples)
     # the bookkeeping lives in the device-walked scan: other scan modes / longer radii refuse instead of skipping it
     e.ufboot_attach(samples)
     e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
