@@ -302,6 +302,7 @@ class FitchEngine:
             weights = np.ones(self.P, dtype=np.int32)
         weights = np.ascontiguousarray(weights, dtype=np.int32)
         self._weights = weights.copy()           # the pattern weights in force (mpf_set_weights keeps it in step)
+        self.weighted = cost is not None         # the Sankoff (-cost) engine
         cfg = Config(device, self.n, self.P, datatype, int(keep_all))
         h = C.c_void_p()
         if cost is None:
