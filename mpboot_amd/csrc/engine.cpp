@@ -2043,6 +2043,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "max_visits") { max_visits_ = std::max<int64_t>(0, v); return MPF_OK; }
   if (key == "small_batch_max") { small_batch_max_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 30)); return MPF_OK; }
   if (key == "ufb_moot") { ufb_moot_ = v ? 1 : 0; return MPF_OK; }
+  if (key == "ufb_memo") { ufb_memo_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_cut_batch") { ufb_cut_batch_ = (int)std::max<int64_t>(1, std::min<int64_t>(v, 1 << 20)); return MPF_OK; }
   if (key == "ufb_pipe") { ufb_pipe_ = v ? 1 : 0; return MPF_OK; }
   if (key == "ufb_thread") { ufb_thread_ = v ? 1 : 0; return MPF_OK; }
@@ -2135,6 +2136,8 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key.rfind("grow_ticks_", 0) == 0 && key.size() == 12 && key[11] >= '0' && key[11] <= '6') *v = (int64_t)grow_phase_ticks_[key[11] - '0'];
   else if (key == "max_visits") *v = max_visits_;
   else if (key == "ufb_moot") *v = ufb_moot_;
+  else if (key == "ufb_memo") *v = ufb_memo_;
+  else if (key == "ufb_memo_batches") *v = ufb_ ? (int64_t)ufb_->memo_batches : 0;
   else if (key == "ufb_cut_batch") *v = ufb_cut_batch_;
   else if (key == "ufb_quiet_climbs") *v = ufb_stat_quiet_;
   else if (key == "ufb_pipe") *v = ufb_pipe_;

@@ -119,6 +119,10 @@ struct UfbState {
   // host bookkeeping (scores are parsimony lengths, i.e. -boot_logl; UINT32_MAX = "-LONG_MAX")
   std::vector<uint32_t> boot_score;
   std::vector<int32_t> boot_counts;
+  // topologies whose complete move-less sweep produced no candidate event, with the widest cut-off (largest admissible length)
+  // that held under: nothing to multiply when the search comes back to one (host/ufboot.cpp, `memo`)
+  std::unordered_map<std::string, uint32_t> quiet_topo;
+  uint64_t memo_batches = 0;
   // boot_tree_orig_logl (iqtree.h:766, -cutoff_from_btrees): the logl under which each sample's tree was booked; cur_logl_now = that
   // of the tree the replay has in hand (on ratchet climbs the value saveCurrentTree replaced it by)
   std::vector<int32_t> boot_orig;
@@ -416,6 +420,7 @@ class Engine {
   struct SelfMoot { std::vector<uint8_t> flag; int n_set = 0, n_le = -1, jump_n = -1; uint64_t jump_a = 1, jump_c = 0; };
   void ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws, SelfMoot *moot = nullptr);
   int ufb_moot_ = 1;                             // option "ufb_moot"
+  int ufb_memo_ = 1;                             // option "ufb_memo": no product for the batches of a topology known to be event-free (UfbState::quiet_topo)
   // the log of one batch against an explicit topology: touches nothing of the engine but n_ and the tracker's deferred state
   // (topology map, boot_trees, reference counts, stored topologies), so that it can run on the worker thread of a pipelined climb
   struct DrainScratch {

@@ -921,10 +921,14 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   SelfMoot moot;
   bool moot_on = false;
   std::vector<int32_t> lcol;                       // ratchet: the original-frequency column of the product, per mask row
+  uint32_t sw_mp_max = 0;
   do {
     int i = 1;
     if (resume_i > 0) { i = resume_i; resume_i = 0; }          // (the sweep the quiet stretch handed over: order and startMP stand)
     else { startMP = randomMP; node_rectifier(); }
+    // (for UfbState::quiet_topo: is this a COMPLETE sweep of one topology without a single candidate event?)
+    bool sw_full = i == 1, sw_moved = false;
+    uint64_t sw_events = 0;
     while (i <= total && !visits_out()) {
       const int hi = visits_cap(i, std::min(total, i + batch - 1));
       double t0 = now_ms();
@@ -985,7 +989,18 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       const bool skip_product = store_trees ? false : ratchet ? (u.gate_closed || none_pass || (have_cut && u.stale_len > mp_max)) : none_pass;
       const bool compact = have_cut && !none_pass && !ratchet && !store_trees;
       uint32_t n_rows = n_idx;
-      if (compact) {
+      // A topology whose complete move-less sweep has produced NO candidate event before, under a cut-off at least as wide: the
+      // samples' best scores only ever fall and the admissible set only shrinks, so none of its insertion tests can reach any
+      // sample now either -- nothing to multiply, nothing to extract (UfbState::quiet_topo; the bookings themselves -- treels,
+      // the current tree's visits, every draw -- go on as ever).  Searches return to their local optima again and again.
+      bool memo = false;
+      if (compact && defer && host_self && ufb_memo_ && !u.quiet_topo.empty()) {
+        if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+        const auto it = u.quiet_topo.find(u.self_key);
+        memo = it != u.quiet_topo.end() && mp_max <= it->second;
+      }
+      if (memo) { n_rows = 0; u.memo_batches++; }
+      if (compact && !memo) {
         sel_rows.clear();
         crow.assign((size_t)n_idx, 0xFFFFFFFFu);
         for (int j = 0; j <= jstar; j++) {
@@ -1016,7 +1031,17 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       // length (= randomMP): it takes part unless that length fails the cut-off (ratchet climbs: decided in the replay)
       const bool self_pass = !self_list.empty() && !skip_product && (ratchet || store_trees || randomMP <= mp_max);
       if (chained && !(n_idx > 0 && !skip_product && !compact)) { set_error("online UFBoot: chained batch without a product"); return MPF_E_STATE; }
-      if (n_idx > 0 && !skip_product && (n_rows > 0 || self_pass)) {
+      if (memo) {
+        if (self_pass) {                               // R_T for the host's walk over the current tree's bookings
+          UCHK(u.h_rt.reserve((size_t)u.Bp));
+          UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+          UCHK(hipStreamSynchronize(st_));
+        }
+        ran_events = true;
+        events.clear();
+        t1 = now_ms();
+        u.t_dev += t1 - t0;
+      } else if (n_idx > 0 && !skip_product && (n_rows > 0 || self_pass)) {
         const int rows_p = round_up((int)std::max<uint32_t>(n_rows, 1u), chained ? ufb_row_padding((int)n_rows, u.Bp) : kUfbRowTile);
         // (a batch whose prune nodes have no insertion test at all -- a five-taxon tree at radius 1 -- still books the current
         //  tree at every visit: the scan launch that normally provides the mask / info buffers was skipped)
@@ -1524,7 +1549,15 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       batch = std::max(next_batch(batch, moved, j - i, total), batch_floor);
       visits_done_ += j - i;
       i = j;
+      sw_events += n_ev;
+      sw_moved = sw_moved || moved;
+      sw_mp_max = mp_max;
       u.t_replay += now_ms() - t0;
+    }
+    if (sw_full && !sw_moved && sw_events == 0 && i > total && defer && host_self && ufb_memo_) {
+      if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+      uint32_t &v = u.quiet_topo[u.self_key];
+      v = std::max(v, sw_mp_max);
     }
   } while (randomMP < startMP && !visits_out());
   ufb_drain_log();
@@ -1845,6 +1878,8 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     startMP = randomMP;
     node_rectifier();
     int i = 1;
+    bool sw_moved = false;                         // (UfbState::quiet_topo: a complete sweep of one topology without a candidate event)
+    uint64_t sw_events = 0;
     while (i <= total && !visits_out()) {
       Batch &B = ring[cur];
       if (!prelaunched) { B.par = cur & 1; int rc = launch(B, i, batch, false, false); if (rc) return rc; }
@@ -2138,7 +2173,13 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
       if (early) { batch = next_batch_size; i = next_i; }
       else { batch = next_batch(batch, moved, j - i, total); i = j; }
       cur = (cur + 1) % 3;
+      sw_events += n_ev;
+      sw_moved = sw_moved || moved;
       u.t_replay += now_ms() - t0;
+    }
+    if (!sw_moved && sw_events == 0 && i > total && host_self && ufb_memo_) {       // (no cut-off in force here: every insertion test was multiplied)
+      if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
+      u.quiet_topo[u.self_key] = UINT32_MAX;
     }
   } while (randomMP < startMP && !visits_out());
   ufb_drain_log();

@@ -88,3 +88,13 @@ def test_later_iterations_under_the_cutoff_match_the_oracle(n, P, alphabet, maxt
     # the later climbs began as plain ones, and the dense stretches ran in the persistent kernel
     assert e.get_option("ufb_quiet_climbs") - quiet_before >= 7
     assert e.stats()["climb_launches"] > launches_before
+    memo_batches.append(e.get_option("ufb_memo_batches"))
+
+
+memo_batches = []
+
+
+def test_the_search_came_back_to_known_optima_without_multiplying():
+    """(behind the runs above) batches of a topology whose complete move-less sweep had produced no candidate event before are
+    booked without a product (UfbState::quiet_topo) -- and the oracle comparison above held with them"""
+    assert memo_batches and max(memo_batches) > 0

@@ -118,7 +118,7 @@ def test_the_three_ways_through_a_tracked_climb_agree(mods, name, rule, tie):
     samples = np.random.default_rng(77).multinomial(int(w.sum()), w / w.sum(), size=150).astype(np.uint16)
     start = np.array(fx["trees"][1]["back"], dtype=np.int32)
     got = []
-    for opts in ({"ufb_fast": 0, "ufb_quiet": 0}, {"ufb_pipe": 0}, {"ufb_thread": 0}, {}, {"ufb_quiet": 0, "ufb_moot": 0}):
+    for opts in ({"ufb_fast": 0, "ufb_quiet": 0}, {"ufb_pipe": 0}, {"ufb_thread": 0}, {}, {"ufb_quiet": 0, "ufb_moot": 0, "ufb_memo": 0}):
         e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
         for k, v in opts.items():
             e.set_option(k, v)
