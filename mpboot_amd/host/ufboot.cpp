@@ -313,7 +313,7 @@ bool Engine::ufb_distinct_offer(uint32_t b, int32_t rell, int64_t &tree_index, b
   uint32_t &bs = u.boot_score[b];
   const uint32_t len = (uint32_t)(-(int64_t)rell);
   if (len < bs) u.boot_counts[b] = 1;                                       // :3598-3600
-  u.boot_orig[b] = u.cur_logl_now;                                          // :3617-3619
+  if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                                          // :3617-3619
   if (!looked_up) { tree_index = lookup(tree_index); looked_up = true; }
   bool named = false;
   auto ref = [&](int64_t t) { u.refs[(size_t)t]++; named = true; };
@@ -659,7 +659,7 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
           const int b8 = c2 + __builtin_ctz((unsigned)acc);
           u.log.push_back(UfbState::LogEntry{(uint32_t)b8, 0xFFFFFFFFu, tree_index, cur_plan});
           log_open = true;
-          u.boot_orig[(size_t)b8] = u.cur_logl_now;                         // :3716-3718
+          if (u.cut_btrees) u.boot_orig[(size_t)b8] = u.cur_logl_now;                         // :3716-3718
           if (mf && !mf[b8]) { mf[b8] = 1; moot->n_set++; }              // (it ties and now points at the current tree)
         }
         c2 += 7;
@@ -681,7 +681,7 @@ void Engine::ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur
     if (accept) {
       u.log.push_back(UfbState::LogEntry{b, 0xFFFFFFFFu, tree_index, cur_plan});
       log_open = true;
-      u.boot_orig[b] = u.cur_logl_now;                                  // :3716-3718
+      if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                                  // :3716-3718
       if (s < bs) { cnt[b] = 1; bsv[b] = s; }                           // :3710-3719
       if (mf && !mf[c2]) { mf[c2] = 1; moot->n_set++; }
     }
@@ -1286,7 +1286,8 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       moot_on = false;
       if (defer && host_self && self_pass && ran_events && u.ids_identity && !rand_fn_ && ufb_moot_ && u.log.empty() && !u.cut_btrees) {
         // (a sample may have taken the current topology during a ratchet climb, under another logl than the tree's own: an acceptance
-        //  now would change boot_tree_orig_logl -- no shortcut while that array matters)
+        //  now would change boot_tree_orig_logl -- no shortcut while that array is kept, i.e. under -cutoff_from_btrees; without the
+        //  option the reference does not keep it (iqtree.cpp:3717) and neither does this tracker)
         if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
         const auto it = u.topo_index.find(u.self_key);
         moot.flag.assign((size_t)u.Bl + 8, 0);
@@ -1368,7 +1369,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
                 hs.clear();
                 bs = s;
               }
-              if (u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
+              if (u.cut_btrees && u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
               if (hs.insert(tree_index).second) {                         // :3530-3533
                 u.refs[(size_t)tree_index]++;
                 if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
@@ -1381,7 +1382,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
               u.draws++;
               accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
             }
-            if (accept) u.boot_orig[b] = u.cur_logl_now;                  // :3716-3718
+            if (accept && u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                  // :3716-3718
             if (accept && defer) {
               u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
               log_open = true;
@@ -2074,7 +2075,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
           if (accept) {
             u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
             log_open = true;
-            u.boot_orig[b] = u.cur_logl_now;                          // :3716-3718
+            if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                          // :3716-3718
             if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
           }
           if (s == bs) u.boot_counts[b]++;                              // :3728-3730
@@ -2619,7 +2620,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
                 hs.clear();
                 bs = s;
               }
-              if (u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
+              if (u.cut_btrees && u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
               if (hs.insert(tree_index).second) {
                 u.refs[(size_t)tree_index]++;
                 if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
@@ -2633,7 +2634,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
               accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
             }
             if (accept) {
-              u.boot_orig[b] = u.cur_logl_now;                            // :3716-3718
+              if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                            // :3716-3718
               if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
               if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
               if (s < bs) { u.boot_counts[b] = 1; bs = s; }

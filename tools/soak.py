@@ -3,6 +3,9 @@
 by the test-suite on fixed cases):
   * k_climb (every tile width, both tie rules, radii 1..6, batch sizes) == host-driven batches: moves, tree, tie-stream state
   * mpf_ufboot_refine_sweep == mpf_set_weights + mpf_optimize_spr per sample: stable <=> no move, scores
+  * k_grow (one launch per start tree, every tile shape) == the host-driven addition loop: per-step lengths and insertion branches, tree, tie-stream state
+  * later search iterations of a -bb run (percentile or -cutoff_from_btrees cut-off, perturbed trees, every other one a ratchet iteration):
+    the quiet stretch in k_climb / moot bookings / known optima without a product == every batch through the tracker's two-wait loop
   * the tracked climb (-bb bookkeeping) as a pipeline (ufb_pipe, decisions taken from the costs; its log on a second host thread or,
     ufb_thread 0, on the same one) == one chain per batch (ufb_pipe 0) == scan / wait / product / wait / replay (ufb_fast 0): moves, tree, saved trees, boot arrays, kept topologies, draws, tie state
      python tools/soak.py [seconds] [seed]"""
@@ -10,13 +13,15 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from mpboot_amd import engine, synth, trees
+import soak_lib
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 BIG = os.environ.get("SOAK_BIG") == "1"       # 120-319 taxa, 100-399 samples: whole-sweep batches of tens of thousands of indices (the chunked extraction, the overflow rule)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-n_climb = n_ref = n_samples = n_trk = n_early = 0
+n_climb = n_ref = n_samples = n_trk = n_early = n_grow = n_iter = n_quiet = n_memo = n_fail = 0
 while time.time() < t_end:
     alpha = "AA" if rng.random() < 0.25 else "DNA"
     n = int(rng.integers(5, 90)) if not BIG else int(rng.integers(120, 320))
@@ -47,6 +52,21 @@ while time.time() < t_end:
         opt_tree = e.get_tree()
     assert res[0] == res[1], ("climb mismatch", alpha, n, P, tie, radius, seed, opts)
     n_climb += 1
+    # ---- start tree: k_grow vs the host-driven addition loop
+    if n >= 6:
+        gres = []
+        gseed = int(rng.integers(1, 1 << 20))
+        for dev, tile in ((0, -1), (1, int(rng.choice([-1, 0, 1, 2, 4, 8])) if alpha == "DNA" else -1)):
+            e = engine.FitchEngine(codes, w, datatype=dt)
+            e.set_option("grow_device", dev)
+            e.set_option("grow_tile", tile)
+            e.seed_ties(tie, seed)
+            sc_, best_, ins_ = e.stepwise_addition(gseed)
+            gres.append((sc_, best_.tolist(), ins_.tolist(), e.get_tree().tolist(), e.tie_state()))
+            if dev:
+                assert e.get_option("grow_launches") == 1 and e.get_option("grow_last_err") == 0, ("k_grow did not build the tree", alpha, n, P, tile)
+        assert gres[0] == gres[1], ("k_grow mismatch", alpha, n, P, tie, seed, gseed, tile)
+        n_grow += 1
     # ---- refine sweep vs per-sample climbs (random tie rule only)
     if n >= 6:
         B = int(rng.integers(3, 20))
@@ -106,5 +126,47 @@ while time.time() < t_end:
                 n_early += e.get_option("ufb_early_batches")
         assert all(g == got[0] for g in got[1:]), ("tracked climb mismatch", alpha, n, P, tie, radius, seed, B, sb)
         n_trk += 1
-print(f"soak ok: {n_climb} climbs (kernel == host loop), {n_ref} refine sweeps / {n_samples} samples (== per-sample climbs), "
+    # ---- later iterations of a -bb run: the round-5 shortcuts against the plain two-wait loop
+    if n >= 8 and rng.random() < 0.6:
+        B = int(rng.integers(2, 50))
+        w0 = w if w is not None else np.ones(codes.shape[1], dtype=np.int32)
+        nsite = int(w0.sum())
+        sp = np.repeat(np.arange(len(w0)), w0)
+        samples = np.stack([np.bincount(sp[rng.integers(0, nsite, size=nsite)], minlength=len(w0)) for _ in range(B)]).astype(np.uint16)
+        btrees = rng.random() < 0.3
+        iters = int(rng.integers(2, 6))
+        it_seed = int(rng.integers(1 << 30))
+        case = {"codes": codes, "weighted": w is not None, "alpha": alpha, "back": back, "samples": samples, "w0": w0.astype(np.int32), "tie": tie, "seed": seed, "radius": radius,
+                "btrees": btrees, "iters": iters, "it_seed": it_seed}
+        got = []
+        variants = ({"ufb_quiet": 0, "ufb_moot": 0, "ufb_memo": 0, "ufb_pipe": 0}, {})
+        for opts in variants:
+            e = engine.FitchEngine(codes, w, datatype=dt)
+            for k, v in opts.items():
+                e.set_option(k, v)
+            got.append(soak_lib.later_iterations(e, engine.FitchEngine(codes, w, datatype=dt), trees, case, tie))
+            if not opts:
+                n_quiet += e.get_option("ufb_quiet_climbs")
+                n_memo += e.get_option("ufb_memo_batches")
+        diff = soak_lib.first_difference(got[0], got[1])
+        if diff is not None:
+            # which shortcut? each one alone against the plain loop
+            blame = []
+            for alone in ({"ufb_moot": 0, "ufb_memo": 0}, {"ufb_quiet": 0, "ufb_memo": 0}, {"ufb_quiet": 0, "ufb_moot": 0}, {"ufb_quiet": 0, "ufb_moot": 0, "ufb_memo": 0}):
+                e = engine.FitchEngine(codes, w, datatype=dt)
+                for k, v in alone.items():
+                    e.set_option(k, v)
+                d = soak_lib.first_difference(got[0], soak_lib.later_iterations(e, engine.FitchEngine(codes, w, datatype=dt), trees, case, tie))
+                blame.append((alone, d))
+            n_fail += 1
+            out = os.path.join(ROOT, "gpurun_out", f"soak_fail_{int(sys.argv[2]) if len(sys.argv) > 2 else 1}_{n_fail}.npz")
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            np.savez_compressed(out, **case)
+            print("LATER ITERATIONS MISMATCH", alpha, n, P, "tie", tie, "radius", radius, "B", B, "btrees", btrees, "iters", iters, "->", diff, "| alone:", blame, "| case in", out, flush=True)
+            if n_fail >= 4:
+                break
+        n_iter += iters
+if n_fail:
+    sys.exit(f"soak FAILED: {n_fail} later-iteration cases differ")
+print(f"soak ok: {n_grow} start trees (k_grow == host loop), {n_iter} later -bb iterations two ways ({n_quiet} climbs began as plain ones, {n_memo} batches booked without a product); {n_climb} climbs (kernel == host loop), {n_ref} refine sweeps / {n_samples} samples (== per-sample climbs), "
       f"{n_trk} tracked climbs four ways ({n_early} batches decided from the costs)")
