@@ -27,7 +27,10 @@ namespace mpf {
 
 namespace {
 
-constexpr int kMaxB = 8;                     // prune nodes per step
+#ifndef MPF_CLIMB_MAXB
+#define MPF_CLIMB_MAXB 16
+#endif
+constexpr int kMaxB = MPF_CLIMB_MAXB;                    // prune nodes per step (their 4 x 16 parts are the lanes of one wave in plan_and_discover)
 constexpr int kMaxUnits = 2 * kMaxB;         // (prune node, side)
 constexpr int kMaxParts = 2 * kMaxUnits;     // (prune node, side, gap end): one DFS program each
 constexpr int kDepth = 6;                    // deepest radius
@@ -57,9 +60,11 @@ template <int KS, int VW> struct Cfg {
   // together: one LDS region serves both
   static constexpr size_t kSlotBytes = (size_t)(R + 1) * 64 * 4;
   static constexpr size_t kPendBytes = (size_t)NW * 5 * R * 64 * 4;
-  static constexpr size_t kRegion = kPendBytes > 65536 ? kPendBytes : 65536;
-  static constexpr uint32_t kSlots = kRegion / kSlotBytes < 254 ? (uint32_t)(kRegion / kSlotBytes) : 254u;
+  // (64 KB where the control state leaves them, down to 40 KB -- or the parked vectors' size -- at a thousand taxa: region_bytes)
+  static constexpr size_t kRegionMax = kPendBytes > 65536 ? kPendBytes : 65536;
+  static constexpr size_t kRegionMin = kPendBytes > 40960 ? kPendBytes : 40960;
 };
+constexpr size_t kLdsBudget = 150 * 1024;
 
 #include "quadtile.hpp"
 
@@ -96,7 +101,7 @@ struct Kx {
   uint16_t *cq;      // per candidate: the insertion branch
   uint32_t *pend;    // [wave][depth][KS * VW][64] up-vectors of second children waiting for their turn
   uint2 *prog;       // [part][64] DFS programs of the step's scans
-  uint32_t *stage;   // [kSlots][R + 1][64] operand slots of the refresh: vector registers + per-lane subtree scores
+  uint32_t *stage;   // [slots][R + 1][64] operand slots of the refresh: vector registers + per-lane subtree scores
   uint2 *D;          // [kLcap] refresh op: r | slot of operand a << 16 | slot of operand b << 24 ; a | b << 16
   uint2 *CONS;       // [kLcap][2] who consumes an op's result: consumer idx | which << 8 | its stale inputs << 9 | slot of its other operand << 16 ; consumer's vector | other operand's vector << 16
   uint32_t *NC;      // [kLcap] number of consumers registered
@@ -106,6 +111,7 @@ struct Kx {
   uint16_t *Q;       // [ns] what the enumeration lists (lives in the stage / pend region, idle between decide and refresh)
   unsigned long long pre, ancl, lsub;   // heap-index relations of this lane (enumeration)
   uint32_t n, ns, SW4;
+  uint32_t slots;    // operand slots the region holds
   int lane, wave;
   __amdgpu_buffer_rsrc_t rsrc, rsrc_s;   // the vector store; this tile's per-lane subtree scores [vector][16 word groups]
   uint32_t voff[KS], svoff;
@@ -397,8 +403,8 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
       const unsigned long long lt = (1ull << lane) - 1ull;
       uint32_t s0 = slot_base + (uint32_t)__builtin_popcountll(ma & lt) + (uint32_t)__builtin_popcountll(mb & lt);
       uint32_t slotA = kNoSlot, slotB = kNoSlot;
-      if (wa) { slotA = s0 < Cfg<KS, VW>::kSlots ? s0 : kNoSlot; s0++; }
-      if (wb) slotB = s0 < Cfg<KS, VW>::kSlots ? s0 : kNoSlot;
+      if (wa) { slotA = s0 < K.slots ? s0 : kNoSlot; s0++; }
+      if (wb) slotB = s0 < K.slots ? s0 : kNoSlot;
       slot_base += (uint32_t)__builtin_popcountll(ma) + (uint32_t)__builtin_popcountll(mb);
       if (act) {
         K.D[i] = make_uint2(r | (slotA << 16) | (slotB << 24), a | (b << 16));
@@ -420,7 +426,7 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
       nstart += (uint32_t)__builtin_popcountll(ms);
     }
     if (lane == 0) sh.rtail = nstart;
-    if (slot_base > Cfg<KS, VW>::kSlots) {
+    if (slot_base > K.slots) {
       // slots ran out: this step's refresh takes the plain path, whose chain starts are vectors, not op indices
       for (uint32_t k = (uint32_t)lane; k < nstart; k += 64u) K.R[k] = K.OL[K.R[k]];
       mode = 0u;
@@ -895,8 +901,11 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     sh.epoch += 2u;
     const uint32_t since = moved ? 0u : sh.since_move + consumed;
     sh.since_move = since;
-    // a batch is wasted behind the first accepted move; after a step without one the next looks twice as far ahead
-    uint32_t B = moved ? P.batch_min : sh.B * 2u;
+    // a batch is wasted behind the first accepted move; after a step without one the next looks twice as far ahead -- and after a
+    // move that was sixteen or more prune nodes away half as far as that (moves come in stretches of similar density: a sweep near an
+    // optimum does not start from two prune nodes again after each of its rare moves)
+    const uint32_t gap = sh.since_move + consumed;
+    uint32_t B = moved ? (gap >= 16u ? gap / 2u : P.batch_min) : sh.B * 2u;
     B = B > P.batch_max ? P.batch_max : B;
     B = B < 1u ? 1u : B;
     if (pos <= P.total && B > P.total - pos + 1u) B = P.total - pos + 1u;      // (not beyond the end of the sweep)
@@ -979,6 +988,39 @@ __device__ __forceinline__ void invalidate_walk(const Kx<KS, VW> &K, Sh &sh)
   if (lane == 0) sh.c_inv += round;
 }
 
+// everything in a workgroup's LDS but the stage / pend region (the kernel carves in this order)
+__host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns)
+{
+  size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
+  at += (((size_t)ns * 4) + 15) & ~(size_t)15;
+  at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
+  at += (size_t)kLcap * sizeof(uint2);
+  at += (size_t)kLcap * 2 * sizeof(uint2);
+  at += (size_t)kLcap * 4;
+  at += (size_t)kLcap * 4;
+  at += (size_t)kClimbCap * 4;
+  at += (((size_t)ns * 2) + 15) & ~(size_t)15;
+  at += (((size_t)ns * 2) + 15) & ~(size_t)15;
+  at += (((size_t)(ns + 16) * 2) + 15) & ~(size_t)15;
+  at += (size_t)kMaxParts * 128 * 2;
+  at += (size_t)kLcap * 2;
+  at += (((size_t)(ns / 2 + 1) * 2) + 15) & ~(size_t)15;      // the visiting order: 2n - 2 entries
+  at += ns;
+  return (at + 15) & ~(size_t)15;
+}
+
+// the stage / pend region of a launch: what the budget leaves, between the configuration's bounds (host and kernel agree by
+// computing it from the same number of vector slots)
+template <int KS, int VW>
+__host__ __device__ inline size_t region_bytes(uint32_t ns)
+{
+  const size_t fixed = lds_fixed_bytes(ns);
+  size_t r = kLdsBudget > fixed ? (kLdsBudget - fixed) & ~(size_t)15 : 0;
+  r = r > Cfg<KS, VW>::kRegionMax ? Cfg<KS, VW>::kRegionMax : r;
+  r = r < Cfg<KS, VW>::kRegionMin ? Cfg<KS, VW>::kRegionMin : r;
+  return r;
+}
+
 template <int KS, int VW>
 __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
 {
@@ -995,7 +1037,7 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
   K.prog = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
   K.stage = reinterpret_cast<uint32_t *>(smem + at);
   K.pend = reinterpret_cast<uint32_t *>(smem + at);
-  K.Q = reinterpret_cast<uint16_t *>(smem + at); at += Cfg<KS, VW>::kRegion;       // (ns entries of 2 bytes: fits the region for every ns the other arrays allow)
+  K.Q = reinterpret_cast<uint16_t *>(smem + at); at += region_bytes<KS, VW>(ns);       // (ns entries of 2 bytes: fits the region for every ns the other arrays allow)
   K.D = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * sizeof(uint2);
   K.CONS = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * 2 * sizeof(uint2);
   K.NC = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
@@ -1009,6 +1051,7 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
   K.ord = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)P.total * 2) + 15) & ~(size_t)15;
   K.valid = reinterpret_cast<uint8_t *>(smem + at);
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
+  { const size_t sl = region_bytes<KS, VW>(ns) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
   K.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
   K.rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)(P.sct + (size_t)tile * ns * 16), 0, (int)(ns * 64u), 0x00020000);
   K.svoff = ((uint32_t)lane >> 2) * 4u;
@@ -1272,23 +1315,7 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
 template <int KS, int VW>
 size_t lds_bytes(uint32_t ns)
 {
-  size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
-  at += (((size_t)ns * 4) + 15) & ~(size_t)15;
-  at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
-  at += Cfg<KS, VW>::kRegion;
-  at += (size_t)kLcap * sizeof(uint2);
-  at += (size_t)kLcap * 2 * sizeof(uint2);
-  at += (size_t)kLcap * 4;
-  at += (size_t)kLcap * 4;
-  at += (size_t)kClimbCap * 4;
-  at += (((size_t)ns * 2) + 15) & ~(size_t)15;
-  at += (((size_t)ns * 2) + 15) & ~(size_t)15;
-  at += (((size_t)(ns + 16) * 2) + 15) & ~(size_t)15;
-  at += (size_t)kMaxParts * 128 * 2;
-  at += (size_t)kLcap * 2;
-  at += (((size_t)(ns / 2 + 1) * 2) + 15) & ~(size_t)15;      // the visiting order: 2n - 2 entries
-  at += ns;
-  return (at + 15) & ~(size_t)15;
+  return lds_fixed_bytes(ns) + region_bytes<KS, VW>(ns);
 }
 
 template <int KS, int VW>

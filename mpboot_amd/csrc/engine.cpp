@@ -175,6 +175,7 @@ int Engine::init(const mpf_config &cfg, const uint8_t *codes, const int32_t *wei
   }
   back_.assign(3 * (size_t)(2 * n_ - 1) + 3, -1);
   nodep_.assign(2 * (size_t)n_, 0);
+  reset_node_order();                              // (nodep[i] = node i's first record, as the reference's tree set-up leaves it: a caller need not ask for it)
   sc_.assign(back_.size(), 0);
   valid_.assign(back_.size(), 0);
   lev_.assign(back_.size(), 0);
@@ -2068,8 +2069,8 @@ int Engine::set_option(const std::string &key, int64_t v)
     climb_vw_ = (int)v;
     return MPF_OK;
   }
-  if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
-  if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 8 ? 8 : (int)v; return MPF_OK; }
+  if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
+  if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
   if (key == "climb_fault") { climb_fault_ = v; return MPF_OK; }          // (tests of the recovery paths: climb.hpp)
   if (key == "views_waves") { nv_waves_ = (int)v; return MPF_OK; }         // waves per refresh workgroup: 0 = by level width, -1 = always sixteen, 2 .. 16

@@ -79,7 +79,8 @@ def test_device_climb_equals_host_batches(mods, alpha, n, P):
     back = trees.random_topology(n, np.random.default_rng(3))
     ref = None
     variants = [dict(mode=0), dict(mode=1), dict(mode=2), dict(mode=2, climb_batch_min=1, climb_batch_max=1),
-                dict(mode=2, climb_batch_min=8, climb_batch_max=8), dict(mode=1, climb_idle=8)]
+                dict(mode=2, climb_batch_min=8, climb_batch_max=8), dict(mode=2, climb_batch_min=3, climb_batch_max=16),
+                dict(mode=2, climb_batch_min=16, climb_batch_max=16), dict(mode=1, climb_idle=8)]
     if alpha == "DNA":
         variants += [dict(mode=2, climb_tile=2), dict(mode=2, climb_tile=4), dict(mode=2, climb_tile=8)]
     for v in variants:

@@ -132,6 +132,30 @@ def test_all_patterns_uninformative(mods):
     assert e.optimize_spr(1, 6) == 0
 
 
+def test_a_new_engine_needs_no_call_but_set_tree(mods):
+    """mpf_set_tree + mpf_optimize_spr on an engine nothing else was asked of (no mpf_reset_node_order, no start tree made by it):
+    nodep[] is the identity order from creation on, as the reference's tree set-up leaves it -- found by a probe that crashed at
+    1000 taxa in round 5; score_tree in front of it, and the kernel path as well as the host loop"""
+    engine, po = mods[0], mods[1]
+    from mpboot_amd import synth, trees
+    letters, _ = synth.synth_alignment(300, 3000, "DNA", 0.05, seed=12)
+    codes = synth.letters_to_codes(letters, "DNA")
+    back = trees.random_topology(300, np.random.default_rng(4))
+    o = po.Oracle(codes)
+    o.set_tree(back); o.seed_ties(po.TIE_RANDOM, 5)
+    want = o.optimize_spr(1, 6)
+    for dev in (0, 2):
+        for score_first in (False, True):
+            e = engine.FitchEngine(codes)
+            e.set_option("climb_device", dev)
+            if score_first:
+                e.score_tree(back)
+            e.set_tree(back)
+            e.seed_ties(engine.TIE_RANDOM, 5)
+            assert e.optimize_spr(1, 6) == want
+            assert (e.get_tree() == o.get_tree()).all() and e.tie_state() == o.tie_state()
+
+
 def test_error_behaviour(mods):
     engine = mods[0]
     fx = load_fixture("dna_clean")
