@@ -1197,9 +1197,9 @@ int Engine::plan_scan(int p, int mintrav, int maxtrav, ScanPlan &plan)
   plan.n_p = plan.n_total = 0;
   if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
   if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
-  // (Fitch: any radius -- beyond kMaxDepth levels the up-vectors live in HBM, k_scan_deep; the weighted kernels keep theirs in
-  //  registers: 12 levels for DNA, 6 otherwise)
-  if (maxtrav > (sankoff_ ? (g_.S == 4 ? kMaxDepth : 6) : 255)) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
+  // (any radius: beyond the levels the kernels keep in registers -- Fitch 12, weighted 12 for DNA and 6 otherwise -- the levels'
+  //  vectors live in HBM scratch, k_scan_deep / k_snk_scan_deep)
+  if (maxtrav > 255) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
   const int q = back_[p];
   plan.base = sankoff_ ? 0u : (tip(p) ? 0u : sc_[p]) + (tip(q) ? 0u : sc_[q]);   // weighted: the kernel returns full lengths
   if (maxtrav < mintrav) return MPF_OK;
@@ -1292,7 +1292,7 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   zeroed_ptr_ = nullptr;
   zeroed_words_ = 0;
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
-  const bool deep = !sankoff_ && prog_max_depth_ > kMaxDepth;
+  const bool deep = prog_max_depth_ > (sankoff_ && g_.S != 4 ? 6 : kMaxDepth);
   if (deep && !g_.deep_scratch) {
     // per-level up-vectors of the scans' waves: 256 MB, the launches are cut to fit (launch_scan)
     HIPCHK(d_deep_.reserve(deep_scratch_words_));
@@ -1388,7 +1388,7 @@ int Engine::plan_walk(int p, int mintrav, int maxtrav, ScanPlan &plan, bool spli
   plan.n_parts = plan.n_parts_p = 0;
   if (maxtrav > ntips_ - 3) maxtrav = ntips_ - 3;
   if (mintrav != 1) { set_error("mintrav must be 1 (reference asserts it, sprparsimony.cpp:2280)"); return MPF_E_INVALID; }
-  if (maxtrav > kWalkMaxDepth) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
+  if (maxtrav > 255) { set_error("maxtrav above the supported chain depth"); return MPF_E_UNSUPPORTED; }
   plan.maxtrav = maxtrav;
   const int q = back_[p];
   plan.base = 0;                                   // filled in after the refresh has been synchronised
@@ -1486,7 +1486,13 @@ int Engine::run_walks(std::vector<ScanPlan> &plans, const uint32_t **out_host)
     if (walk_dev_reuse_) descs = d_walk_.p;        // a cached sweep: descriptors (and the planned program) are still there
     // small batch: the kernels write the host's copies themselves (mutation counts: the refresh's fold; candidate costs:
     // the scan's last workgroup) -- no copy-back dispatch
-    const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && (cnt_on_host_ || !cnt_copy_pending_);
+    const bool host_direct = want_host_results_ && nout <= 16384 && !scan_masks_ && !check_counts_ && maxd <= kWalkMaxDepth && (cnt_on_host_ || !cnt_copy_pending_);
+    if (maxd > kWalkMaxDepth && !g_.deep_scratch) {
+      // parked up-vectors of the deep walks' waves: the launches are cut to fit (launch_scan_walk)
+      HIPCHK(d_deep_.reserve(deep_scratch_words_));
+      g_.deep_scratch = d_deep_.p;
+      g_.deep_scratch_words = deep_scratch_words_;
+    }
     // planned program (plan kernel + pipelined scan) for throughput batches; the device-walked kernel for the small,
     // latency-bound batches inside a climb (scan_prog 2: always planned), for masks, protein and radii above 6
     const bool prog = scan_prog_ > 0 && !scan_masks_ && scan_prog_supported(g_, maxd) && (scan_prog_ >= 2 || nd > (size_t)prog_min_descs_);
@@ -1635,7 +1641,9 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
 {
   if (ufb_) { ufb_->st_valid = false; ufb_->st_dev = nullptr; }
   int mt = std::min(maxtrav, ntips_ - 3);
-  const bool walk = scan_mode_ == 1 && mt <= 8 && !sankoff_;
+  // (above 8 levels the plain scans are host-planned programs; the tracker's masks exist in the device-walked kernel only, which
+  //  parks its up-vectors in HBM scratch there: k_scan_walk_deep)
+  const bool walk = scan_mode_ == 1 && (mt <= kWalkMaxDepth || scan_masks_) && !sankoff_;
   plans.resize((size_t)count);
   if (walk && !views_valid_ && count < n_ / 2 && count <= small_batch_max_) {
     // small batch (the inside of a climb): plan first -- planning needs the topology only -- so that the refresh launch

@@ -1268,11 +1268,15 @@ __device__ __forceinline__ void load_tile_g(Tile<S, VW> &t, const uint32_t *__re
 // k-th EMITTED candidate.  The part's last slot (index out_base + count) receives the join of the pruned subtree
 // onto its home edge, fitch(vec[xa], vec[xb]).
 // BIG: the vector store does not fit a raw buffer's 32-bit range: plain global loads from a 64-bit base per vector.
-template <int S, int VW, int MAXD, int RED, bool SPLIT, bool MASKS, bool BIG, bool WM = false>
+// DEEP (any radius above kWalkMaxDepth, MAXD = 255): the parked up-vectors live in a scratch area of the wave in HBM (pend_g:
+// [wave of the launch][level][state, word][lane]) instead of the LDS; the launches are cut so that it stays bounded
+// (launch_scan_walk), scan_base = index of the launch's first scan among the batch's (what info[] names).
+template <int S, int VW, int MAXD, int RED, bool SPLIT, bool MASKS, bool BIG, bool WM = false, bool DEEP = false>
 __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids,
                                                uint32_t n, const WalkDesc *__restrict__ desc, int n_scans,
                                                uint32_t *__restrict__ out, uint32_t *__restrict__ ncand, int Wp,
-                                               int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info)
+                                               int tiles, int map, uint32_t *__restrict__ masks, uint2 *__restrict__ info,
+                                               uint32_t *__restrict__ pend_g = nullptr, int levels = 0, uint32_t scan_base = 0)
 {
   constexpr int STK = MAXD + 2;
   constexpr bool LANEACC = MAXD <= 6;      // short walks: candidate costs gathered in a lane register, 64 per flush
@@ -1284,17 +1288,19 @@ __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec,
   // (protein tiles -- 10 states per wave half -- keep depth 2 in registers as well: with one LDS slot fewer a fourth
   //  workgroup fits a CU)
   constexpr int REGP = (S * VW >= 10) ? 2 : 1;
-  __shared__ uint32_t s_pend[4][MAXD - 1 - REGP][S * VW][64];
+  __shared__ uint32_t s_pend[4][DEEP ? 1 : MAXD - 1 - REGP][DEEP ? 1 : S * VW][DEEP ? 1 : 64];
+  uint32_t *my_pend = nullptr;                 // DEEP: this wave's levels in HBM
 
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   int scan, tile;
-  if (map == 0) {
+  if (map == 0 || DEEP) {
     int gw = blockIdx.x * (blockDim.x >> 6) + wib;
     gw = __builtin_amdgcn_readfirstlane(gw);
     if (gw >= n_scans * tiles) return;
     scan = gw / tiles;
     tile = gw - scan * tiles;
+    if constexpr (DEEP) my_pend = pend_g + (size_t)gw * (size_t)levels * (size_t)(S * VW * 64) + lane;
   } else {
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the groups that
     // share an L2).  The (tile, scan) items, tile-major, are cut into 8 equal contiguous chunks, one per
@@ -1379,7 +1385,7 @@ __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec,
   }
   auto emit = [&](uint32_t c, uint32_t row) {
     if constexpr (MASKS) {
-      if (tile == 0 && lane == 0) info[de.out_base + k] = make_uint2(de.out_base + row, (uint32_t)scan);
+      if (tile == 0 && lane == 0) info[de.out_base + k] = make_uint2(de.out_base + row, scan_base + (uint32_t)scan);
     }
     if constexpr (LANEACC) {
       // candidate k is kept by lane k & 63 (a lane select instead of a memory atomic per candidate); every 64
@@ -1432,7 +1438,13 @@ __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec,
       if (deeper && c2 >= n) {             // dd in [1, MAXD - 1]
         if (dd == 1u) pend1 = u2;
         else if (REGP == 2 && dd == 2u) pend2 = u2;
-        else {
+        else if constexpr (DEEP) {
+          uint32_t *q = my_pend + (size_t)(dd - 1 - REGP) * (size_t)(S * VW * 64);
+#pragma unroll
+          for (int kk = 0; kk < S; kk++)
+#pragma unroll
+            for (int j = 0; j < VW; j++) q[(kk * VW + j) * 64] = u2.v[kk][j];
+        } else {
 #pragma unroll
           for (int kk = 0; kk < S; kk++)
 #pragma unroll
@@ -1456,7 +1468,13 @@ __device__ __forceinline__ void scan_walk_body(const uint32_t *__restrict__ vec,
         if (dq < maxtrav && q >= n) {
           if (dq == 1u) par = pend1;
           else if (REGP == 2 && dq == 2u) par = pend2;
-          else {
+          else if constexpr (DEEP) {
+            const uint32_t *q = my_pend + (size_t)(dq - 1 - REGP) * (size_t)(S * VW * 64);
+#pragma unroll
+            for (int kk = 0; kk < S; kk++)
+#pragma unroll
+              for (int j = 0; j < VW; j++) par.v[kk][j] = q[(kk * VW + j) * 64];
+          } else {
 #pragma unroll
             for (int kk = 0; kk < S; kk++)
 #pragma unroll
@@ -1501,6 +1519,16 @@ __global__ __launch_bounds__(256, (S == 4 && VW == 1 && MAXD <= 6 && !MASKS) ? 8
     for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) host_out[i] = __builtin_nontemporal_load(out + i);
     host_results_ready(host_out, n_out, done);
   }
+}
+
+// the device-walked scan at any radius (DEEP, above): with or without the candidates' masks
+template <int S, int VW, int RED, bool SPLIT, bool MASKS, bool BIG>
+__global__ __launch_bounds__(256) void k_scan_walk_deep(const uint32_t *__restrict__ vec, const uint2 *__restrict__ kids, uint32_t n,
+                                                        const WalkDesc *__restrict__ desc, int n_scans, uint32_t *__restrict__ out,
+                                                        uint32_t *__restrict__ ncand, int Wp, int tiles, uint32_t *__restrict__ masks,
+                                                        uint2 *__restrict__ info, uint32_t *__restrict__ pend_g, int levels, uint32_t scan_base)
+{
+  scan_walk_body<S, VW, 255, RED, SPLIT, MASKS, BIG, false, true>(vec, kids, n, desc, n_scans, out, ncand, Wp, tiles, 0, masks, info, pend_g, levels, scan_base);
 }
 
 // ---------------------------------------------------------------- SPR scan, planned program (k_walk_plan + k_scan_prog)
@@ -2095,6 +2123,110 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
   }
 }
 
+// The weighted scan at ANY radius (k_snk_scan keeps m(U) of every level in registers: 12 levels for DNA, 6 otherwise): here the
+// levels' transforms live in a scratch area of the wave in HBM, the one just computed stays in registers (a DFS mostly goes on one
+// level down), a step back up re-reads its parent level -- the layout of k_scan_deep.  Launches are cut to the scratch (launch_scan).
+template <int S, bool PK, bool ASYM, bool BUF>
+__global__ __launch_bounds__(256) void k_snk_scan_deep(const uint32_t *__restrict__ vec, size_t moff, const ScanHdr *__restrict__ hdr,
+                                                       int n_scans, const ScanOp *__restrict__ ops,
+                                                       const uint32_t *__restrict__ cost, const uint32_t *__restrict__ pwgt,
+                                                       uint32_t *__restrict__ out, int We, int tiles,
+                                                       uint16_t *__restrict__ vals, uint32_t npat, uint32_t *__restrict__ vmax,
+                                                       const uint32_t *__restrict__ costT, uint32_t *__restrict__ scratch, int levels)
+{
+  typedef SnkT<PK> T;
+  typedef typename T::E E;
+  const int lane = threadIdx.x & 63;
+  int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  gw = __builtin_amdgcn_readfirstlane(gw);
+  if (gw >= n_scans * tiles) return;
+  const int scan = gw / tiles, tile = gw - scan * tiles;
+  const ScanHdr h = hdr[scan];
+  uint32_t lane_max = 0;
+  bool valid;
+  const int e0 = lane_word<1>(tile, lane, We, valid);
+  const uint32_t *mvec = vec + moff;
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)vec, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)mvec, 0, -1, 0x00020000);
+  const uint32_t row_bytes = (uint32_t)We * 4u, voff = (uint32_t)e0 * 4u;
+  auto ldv = [&](Costs<S, PK> &t, uint32_t slot) { if constexpr (BUF) load_costs_b<S, PK>(t, rs_v, slot, row_bytes, voff); else load_costs<S, PK>(t, vec, slot, We, e0); };
+  auto ldm = [&](Costs<S, PK> &t, uint32_t slot) { if constexpr (BUF) load_costs_b<S, PK>(t, rs_m, slot, row_bytes, voff); else load_costs<S, PK>(t, mvec, slot, We, e0); };
+  uint32_t *mine = scratch + (size_t)gw * (size_t)levels * (size_t)(S * 64) + lane;
+  auto put = [&](int lev, const Costs<S, PK> &t) {
+    uint32_t *q = mine + (size_t)lev * (size_t)(S * 64);
+#pragma unroll
+    for (int k = 0; k < S; k++) q[k * 64] = __builtin_bit_cast(uint32_t, t.v[k]);
+  };
+  auto get = [&](int lev, Costs<S, PK> &t) {
+    const uint32_t *q = mine + (size_t)lev * (size_t)(S * 64);
+#pragma unroll
+    for (int k = 0; k < S; k++) t.v[k] = __builtin_bit_cast(E, q[k * 64]);
+  };
+  Costs<S, PK> ms, last, t1, t2;                   // last = m(U[ld])
+  int ld = -1;
+  if (ASYM && (h.pad & 1u)) {
+    ldv(t2, h.s_slot);
+    mplus<S, PK>(ms, t2, costT);
+  } else ldm(ms, h.s_slot);
+  for (uint32_t i = h.op_begin; i < h.op_end; i++) {
+    const ScanOp o = ops[i];
+    const int d = (int)(o.meta & 0xFFu);
+    const bool test = (o.meta >> 8) & 1u;
+    const int kind = (int)((o.meta >> 16) & 0xFFu);
+    if (kind == SCAN_ROOT) {
+      ldm(last, o.own);
+      put(0, last);
+      ld = 0;
+      continue;
+    }
+    E best = T::inf();
+    ldm(t1, o.sib);
+    if (kind == SCAN_JOIN) {
+      ldm(t2, o.own);
+#pragma unroll
+      for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], t2.v[s]), ms.v[s]));
+    } else {
+      if (d - 1 != ld) get(d - 1, last);
+#pragma unroll
+      for (int s = 0; s < S; s++) t2.v[s] = T::add(t1.v[s], last.v[s]);      // U[d]
+      if (ASYM && test) {
+        mplus<S, PK>(last, t2, costT);
+        ldm(t1, o.own);
+#pragma unroll
+        for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], last.v[s]), ms.v[s]));
+      }
+      mplus<S, PK>(last, t2, cost);
+      ld = d;
+      if (d + 1 < levels) put(d, last);
+      if (!ASYM && test) {
+        ldm(t1, o.own);
+#pragma unroll
+        for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], last.v[s]), ms.v[s]));
+      }
+    }
+    if (test || kind == SCAN_JOIN) {
+      const uint32_t c = valid ? T::wsum(best, pwgt, e0) : 0u;
+      const uint32_t tot = wave_total<0>(c);
+      if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
+      if (vals && valid) {
+        if constexpr (PK) {
+          *reinterpret_cast<us2 *>(vals + (size_t)o.out * npat + 2 * e0) = best;
+          lane_max = max(lane_max, max((uint32_t)best.x, (uint32_t)best.y));
+        } else {
+          vals[(size_t)o.out * npat + e0] = (uint16_t)best;
+          lane_max = max(lane_max, (uint32_t)best);
+        }
+      }
+    }
+  }
+  if (vals) {
+    uint32_t m = lane_max;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sh, 64));
+    if (lane == 0 && m) atomicMax(vmax, m);
+  }
+}
+
 template <int S, bool PK>
 __global__ __launch_bounds__(256) void k_snk_pattern(const uint32_t *__restrict__ vec, size_t moff, uint32_t a_slot, uint32_t b_slot,
                                                      const uint32_t *__restrict__ cost, uint16_t *__restrict__ ptn, int We,
@@ -2332,10 +2464,32 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
                                        else hipLaunchKernelGGL((k_snk_scan<S_, D_, PK_, A_, false>), sgrid, block, 0, st, vec, g.moff, hdr, n_scans, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT); } while (0)
 #define SNKSCAN2(S_, D_, PK_) do { if (g.costT) SNKSCAN3(S_, D_, PK_, true); else SNKSCAN3(S_, D_, PK_, false); } while (0)
 #define SNKSCAN(S_, D_) do { if (g.snk16) SNKSCAN2(S_, D_, true); else SNKSCAN2(S_, D_, false); } while (0)
+    if (max_depth > (g.S == 4 ? kMaxDepth : 6)) {
+      // beyond the levels that fit registers: k_snk_scan_deep, cut into launches whose waves' scratch stays within the area
+      if (!g.deep_scratch) return hipErrorInvalidValue;
+      const int levels = max_depth + 1;
+      const size_t per_wave = (size_t)levels * (size_t)(g.S * 64);
+      long per_launch = (long)(g.deep_scratch_words / per_wave) / stiles;
+      if (per_launch < 1) return hipErrorOutOfMemory;
+      for (long s0 = 0; s0 < n_scans; s0 += per_launch) {
+        const int ns = (int)std::min<long>(per_launch, n_scans - s0);
+        dim3 dgrid((unsigned)(((long)ns * stiles + 3) / 4));
+#define SNKD3(S_, PK_, A_) do { if (buf_ok) hipLaunchKernelGGL((k_snk_scan_deep<S_, PK_, A_, true>), dgrid, block, 0, st, vec, g.moff, hdr + s0, ns, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT, g.deep_scratch, levels); \
+                                else hipLaunchKernelGGL((k_snk_scan_deep<S_, PK_, A_, false>), dgrid, block, 0, st, vec, g.moff, hdr + s0, ns, ops, g.cost, g.pwgt, out, We, stiles, vals, npat, vmax, g.costT, g.deep_scratch, levels); } while (0)
+#define SNKD2(S_, PK_) do { if (g.costT) SNKD3(S_, PK_, true); else SNKD3(S_, PK_, false); } while (0)
+#define SNKD(S_) do { if (g.snk16) SNKD2(S_, true); else SNKD2(S_, false); } while (0)
+        if (g.S == 4) SNKD(4); else if (g.S == 20) SNKD(20); else SNKD(32);
+#undef SNKD
+#undef SNKD2
+#undef SNKD3
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
     if (g.S == 4) {
       if (max_depth <= 6) SNKSCAN(4, 6); else SNKSCAN(4, 12);
     } else {
-      if (max_depth > 6) return hipErrorInvalidValue;
       if (g.S == 20) SNKSCAN(20, 6); else SNKSCAN(32, 6);
     }
 #undef SNKSCAN
@@ -2393,9 +2547,43 @@ hipError_t launch_scan_walk(hipStream_t st, const Geometry &g, const uint32_t *v
                             uint32_t *masks, uint2 *info, uint32_t *host_out, uint32_t n_out, uint32_t *done, bool word_major)
 {
   if (n_scans <= 0) return hipSuccess;
-  if (max_depth > kWalkMaxDepth) return hipErrorInvalidValue;   // 8: the per-depth LDS slots of the walk are sized for it
   const bool split = g.S >= 20;                                    // protein / 32-state data: states split over the wave halves
   const int tiles = split ? (g.Wp + 31) / 32 : (g.big ? (g.Wp + 63) / 64 : tiles_of(g));    // the 64-bit path is one word per lane
+  if (max_depth > kWalkMaxDepth) {
+    // 8: the per-depth LDS slots of the walk are sized for it.  Beyond: k_scan_walk_deep, the parked up-vectors in HBM scratch, cut
+    // into launches whose waves' levels fit it (the batch's scans are laid out independently: out_base per scan)
+    if (host_out || !g.deep_scratch) return hipErrorInvalidValue;
+    const int levels = max_depth;                                  // (slots for depths 1 + REGP .. max_depth - 1)
+    const int rows = split ? (g.S / 2) : g.S * (g.big ? 1 : g.vw);
+    const size_t per_wave = (size_t)levels * (size_t)(rows * 64);
+    long per_launch = (long)(g.deep_scratch_words / per_wave) / tiles;
+    if (per_launch < 1) return hipErrorOutOfMemory;
+    for (long s0 = 0; s0 < n_scans; s0 += per_launch) {
+      const int ns = (int)std::min<long>(per_launch, n_scans - s0);
+      dim3 dgrid((unsigned)(((long)ns * tiles + 3) / 4)), dblock(256);
+#define SWD(S_, VW_, SPLIT_, BIG_)                                                                                                          \
+      do {                                                                                                                                  \
+        if (masks) {                                                                                                                        \
+          if (g.reduce == 0) hipLaunchKernelGGL((k_scan_walk_deep<S_, VW_, 0, SPLIT_, true, BIG_>), dgrid, dblock, 0, st, vec, kids, (uint32_t)n_taxa, desc + s0, ns, out, ncand + s0, g.Wp, tiles, masks, info, g.deep_scratch, levels, (uint32_t)s0); \
+          else hipLaunchKernelGGL((k_scan_walk_deep<S_, VW_, 1, SPLIT_, true, BIG_>), dgrid, dblock, 0, st, vec, kids, (uint32_t)n_taxa, desc + s0, ns, out, ncand + s0, g.Wp, tiles, masks, info, g.deep_scratch, levels, (uint32_t)s0); \
+        } else {                                                                                                                            \
+          if (g.reduce == 0) hipLaunchKernelGGL((k_scan_walk_deep<S_, VW_, 0, SPLIT_, false, BIG_>), dgrid, dblock, 0, st, vec, kids, (uint32_t)n_taxa, desc + s0, ns, out, ncand + s0, g.Wp, tiles, masks, info, g.deep_scratch, levels, (uint32_t)s0); \
+          else hipLaunchKernelGGL((k_scan_walk_deep<S_, VW_, 1, SPLIT_, false, BIG_>), dgrid, dblock, 0, st, vec, kids, (uint32_t)n_taxa, desc + s0, ns, out, ncand + s0, g.Wp, tiles, masks, info, g.deep_scratch, levels, (uint32_t)s0); \
+        }                                                                                                                                   \
+      } while (0)
+      if (g.big) {
+        if (g.S == 4) SWD(4, 1, false, true); else if (g.S == 20) SWD(10, 1, true, true); else SWD(16, 1, true, true);
+      } else if (g.S == 4) {
+        if (g.vw == 1) SWD(4, 1, false, false); else SWD(4, 2, false, false);
+      } else if (g.S == 20) SWD(10, 1, true, false);
+      else if (g.S == 32) SWD(16, 1, true, false);
+      else return hipErrorInvalidValue;
+#undef SWD
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
   const long waves = (long)n_scans * tiles;
   dim3 block(256);
   unsigned nblocks;

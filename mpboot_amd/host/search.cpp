@@ -235,7 +235,7 @@ int Engine::optimize_spr(int mintrav, int maxtrav, uint32_t *score)
   visits_done_ = 0;
   if (ufb_ && !ufb_->suspended && ufb_->snk) return spr_sweeps_ufboot_snk(mintrav, maxtrav, best_, score);
   if (ufb_ && !ufb_->suspended) {                 // perSiteScores = gbo_replicates > 0 (reference :3245)
-    if (scan_mode_ != 1 || std::min(maxtrav, ntips_ - 3) > 8) { set_error("online UFBoot needs the device-walked scan (maxtrav <= 8)"); return MPF_E_UNSUPPORTED; }
+    if (scan_mode_ != 1) { set_error("online UFBoot needs the device-walked scan (option scan_mode 1)"); return MPF_E_UNSUPPORTED; }
     ufb_->rt_valid = false;
     return spr_sweeps_ufboot(mintrav, maxtrav, best_, score);
   }

@@ -2236,8 +2236,7 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
   if (u.snk || sankoff_) { set_error("refine sweep: Fitch engine only"); return MPF_E_UNSUPPORTED; }
   if (u.suspended || u.ratchet) { set_error("refine sweep: the attach-time weights must be in force"); return MPF_E_STATE; }
   if (tie_mode_ != MPF_TIE_RANDOM) { set_error("refine sweep: mpboot's random tie rule only (MPF_TIE_RANDOM)"); return MPF_E_UNSUPPORTED; }
-  const int mt = std::min(maxtrav, ntips_ - 3);
-  if (scan_mode_ != 1 || mt > 8) { set_error("refine sweep needs the device-walked scan (maxtrav <= 8)"); return MPF_E_UNSUPPORTED; }
+  if (scan_mode_ != 1) { set_error("refine sweep needs the device-walked scan (option scan_mode 1)"); return MPF_E_UNSUPPORTED; }
   const int total = 2 * n_ - 2;
   node_rectifier();
   { int rc = ufb_current_tree_reps(); if (rc) return rc; }          // R_T[b]: what the evaluate of sprparsimony.cpp:3277 returns under sample b

@@ -178,8 +178,10 @@ def test_error_behaviour(mods):
     assert len(q13) > 0 and len(q99) >= len(q13)
     sk = engine.FitchEngine(fx["codes_np"], fx["weights_np"], cost=(1 - np.eye(4)).astype(np.uint32))
     sk.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
+    k13, _m, _ = sk.spr_scan(6, 1, 13)                   # ... and on the weighted one (k_snk_scan_deep; tests/test_gpu_sankoff.py)
+    assert k13.tolist() == q13.tolist()
     with pytest.raises(engine.MpfError):
-        sk.spr_scan(6, 1, 13)                            # the weighted kernels keep their levels in registers: 12 for DNA
+        sk.spr_scan(6, 1, 300)                           # (a radius is one byte of a descriptor)
 
 
 def test_engine_reuse_across_trees_and_rebuilds(mods):

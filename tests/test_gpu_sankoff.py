@@ -136,6 +136,46 @@ def test_hill_climb_and_ras_trajectories(mods, fx, kind):
         assert (f.get_tree() == e2.get_tree()).all()     # `-cost e` == Fitch trajectory
 
 
+@pytest.mark.parametrize("name,kind,maxtrav,kwords", [("dna_ambig", "general", 13, 0), ("dna_clean", "asym", 30, 16), ("aa", "general", 7, 0), ("aa", "asym", 12, 64),
+                                                      ("morph32_40", "general", 9, 0), ("bin", "unit", 8, 0)])
+def test_weighted_engine_at_any_radius(mods, name, kind, maxtrav, kwords):
+    """-spr_rad above the levels the weighted scan keeps in registers (12 for DNA, 6 otherwise): k_snk_scan_deep parks the levels'
+    transforms in HBM scratch (a small scratch cuts the batch into several launches) -- insertion tests in the reference's order
+    and whole climbs equal the oracle's"""
+    engine, po = mods
+    fx = load_fixture(name)
+    cost = cost_for(fx, kind)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    if kwords:
+        e.set_option("deep_scratch_kwords", kwords)
+    sc = fx["scan"][0]
+    back = np.array(sc["back"], dtype=np.int32)
+    e.set_tree(back)
+    cur = e.score_tree()
+    o.reset_nodep()
+    o.set_tree(back)
+    assert o.score_tree() == cur
+    o.seed_ties(po.TIE_RANDOM, 1)
+    for rec in sc["order"][:12]:
+        o.set_best(cur)
+        o.trace(True)
+        o.rearrange(rec, 1, maxtrav)
+        toks = trace_tokens(*o.get_trace())
+        q, mp, n_p = e.spr_scan(rec, 1, maxtrav)
+        mine = ["P"] + [f"{a}:{b}" for a, b in zip(q[:n_p], mp[:n_p])] + ["Q"] + [f"{a}:{b}" for a, b in zip(q[n_p:], mp[n_p:])]
+        assert mine == toks, rec
+    start = np.array(fx["spr"]["start_back"], dtype=np.int32)
+    e.set_tree(start)
+    o.set_tree(start)
+    e.seed_ties(engine.TIE_RANDOM, 9)
+    o.seed_ties(po.TIE_RANDOM, 9)
+    o.trace(True)
+    assert e.optimize_spr(1, maxtrav) == o.optimize_spr(1, maxtrav)
+    assert [x.tolist() for x in e.moves()] == [x.tolist() for x in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+
+
 def test_asymmetric_matrix_roots_like_the_reference(mods):
     """an asymmetric matrix is accepted (ParsTree::loadCostMatrixFile takes any, parstree.cpp:31-95): the same tree has
     different lengths at different root edges, the engine's are the oracle's at each of them -- the start edge (score_tree), the

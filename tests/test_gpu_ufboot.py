@@ -409,6 +409,60 @@ def test_radius_above_six_uses_the_deep_walk_kernel(mods, name, maxtrav):
     assert_same(e, o, se, so)
 
 
+@pytest.mark.parametrize("name,maxtrav,opts", [("dna_clean", 9, {}), ("dna_clean", 13, {"deep_scratch_kwords": 64}), ("dna_ambig", 200, {"ufb_pipe": 0}),
+                                               ("aa", 9, {}), ("aa", 40, {"deep_scratch_kwords": 256}), ("dna_dups", 11, {"ufb_fast": 0})])
+def test_any_radius_under_the_tracker(mods, name, maxtrav, opts):
+    """-spr_rad above 8 with -bb (rearrangeParsimony takes any radius, sprparsimony.cpp:2259-2376): the masked scans come from
+    k_scan_walk_deep, which parks the up-vectors of its levels in HBM scratch -- also where a small scratch cuts a batch into
+    several launches -- and every book equals the oracle's"""
+    engine, po = mods
+    fx = load_fixture(name)
+    samples = boot_samples(len(fx["weights"]), 12, 5, fx["weights"])
+    start = np.array(fx["trees"][4]["back"], dtype=np.int32)
+    e, o, se, so = run_both(engine, po, fx, start, samples, 17, maxtrav=maxtrav, opts=opts)
+    assert_same(e, o, se, so)
+    # a later iteration under a cut-off, same radius
+    cut = e.ufboot_next_cutoff(10)
+    assert cut == o.ufboot_next_cutoff(10)
+    back2 = np.array(fx["trees"][6]["back"], dtype=np.int32)
+    for x in (e, o):
+        x.ufboot_set_cutoff(cut)
+        x.set_tree(back2)
+    assert e.optimize_spr(1, maxtrav) == o.optimize_spr(1, maxtrav)
+    assert (e.get_tree() == o.get_tree()).all() and e.tie_state() == o.tie_state()
+    assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+    assert [a.tolist() for a in e.ufboot_state()] == [a.tolist() for a in o.ufboot_state()]
+
+
+def test_batched_refinement_at_a_long_radius(mods):
+    """mpf_ufboot_refine_sweep above 8 levels == set_weights + optimize_spr per sample (stable <=> no move)"""
+    engine, po = mods
+    fx = load_fixture("dna_ambig")
+    B = 7
+    samples = boot_samples(len(fx["weights"]), B, 3, fx["weights"])
+    start = np.array(fx["trees"][3]["back"], dtype=np.int32)
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    e.seed_ties(engine.TIE_RANDOM, 0)
+    e.ufboot_attach(samples, 0.5)
+    e.set_tree(start)
+    seeds = np.arange(1, B + 1)
+    sc, stable, first = e.ufboot_refine_sweep(12, seeds)
+    e.ufboot_detach()
+    solo = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"])
+    for b in range(B):
+        for x, mode in ((solo, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+            x.set_weights(samples[b].astype(np.int32))
+            x.seed_ties(mode, int(seeds[b]))
+            x.set_tree(start)
+        solo.reset_node_order(); o.reset_nodep()
+        s0 = solo.score_tree()
+        assert s0 == sc[b] == o.score_tree()
+        o.trace(True)
+        assert solo.optimize_spr(1, 12) == o.optimize_spr(1, 12)
+        assert bool(stable[b]) == (len(solo.moves()[0]) == 0)
+
+
 def test_first_best_tie_rule(mods):
     """PLL-original tie rule for the SPR part (MPF_TIE_FIRST): the bookkeeping still draws its own ties"""
     engine, po = mods
@@ -628,11 +682,10 @@ def test_unsupported_configurations_fail_loudly(mods):
     a = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=asym)
     with pytest.raises(engine.MpfError):
         a.ufboot_attach(samples)
-    # the bookkeeping lives in the device-walked scan: other scan modes / longer radii refuse instead of skipping it
+    # the bookkeeping lives in the device-walked scan: the other scan mode refuses instead of skipping it (any radius is served:
+    # test_any_radius_under_the_tracker)
     e.ufboot_attach(samples)
     e.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
-    with pytest.raises(engine.MpfError):
-        e.optimize_spr(1, 9)
     e.set_option("scan_mode", 0)
     with pytest.raises(engine.MpfError):
         e.optimize_spr(1, 6)
@@ -827,6 +880,31 @@ def test_tiny_tree_whose_prune_nodes_have_no_insertion_test(mods, alphabet):
         assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
         assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
     assert len(o.ufboot_tree_logl()) > 0
+
+
+@pytest.mark.parametrize("name,radius", [("dna_clean", 14), ("aa", 8)])
+def test_weighted_tracker_at_a_long_radius(mods, name, radius):
+    """-cost with -bb above the levels the weighted scan keeps in registers: the per-pattern lengths come from k_snk_scan_deep"""
+    engine, po = mods
+    fx = load_fixture(name)
+    S = 4 if fx["datatype"] == 0 else 20
+    m = np.random.default_rng(3).integers(1, 6, size=(S, S))
+    cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    samples = boot_samples(len(fx["weights"]), 11, 4, fx["weights"])
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    e.set_option("deep_scratch_kwords", 128)
+    for x in (e, o):
+        x.seed_ties(1, 5)
+        x.ufboot_attach(samples)
+        x.set_tree(np.array(fx["trees"][2]["back"], dtype=np.int32))
+    o.trace(True)
+    assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius)
+    assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+    assert (e.get_tree() == o.get_tree()).all()
+    assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+    assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+    assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
 
 
 @pytest.mark.parametrize("mode", ["default", "cutoff", "mulhits"])

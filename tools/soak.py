@@ -32,7 +32,7 @@ while time.time() < t_end:
     w = rng.integers(1, 4, size=codes.shape[1]).astype(np.int32) if rng.random() < 0.3 else None
     back = trees.random_topology(n, np.random.default_rng(int(rng.integers(1 << 30))))
     tie = engine.TIE_RANDOM if rng.random() < 0.8 else engine.TIE_FIRST
-    radius = int(rng.integers(1, 7))
+    radius = int(rng.integers(1, 7)) if rng.random() < 0.85 else int(rng.integers(7, 16))      # (above 6: host loops; above 8: the deep kernels)
     seed = int(rng.integers(1, 1 << 20))
     if os.environ.get("SOAK_VERBOSE"):
         print(f"case {n_climb}: {alpha} n={n} P={P} tie={tie} radius={radius} seed={seed} weighted={w is not None} t={time.time() - (t_end - budget):.1f}", flush=True)
