@@ -61,6 +61,8 @@ def test_random_case_matches_oracle(seed):
         e.set_option(k, v)
     if opts.get("scan_mode") == 0 and seed % 16 == 4 and not c["aa"]:
         c["maxtrav"] = 10                       # host-planned scans reach radius 12
+    if seed % 16 == 10:
+        c["maxtrav"] = 9 + seed % 7             # ... and the deep kernels any radius, under the tracker too
     assert (e.W, e.num_informative) == (o.W, o.num_informative)
     if o.num_informative == 0:
         return
@@ -89,7 +91,7 @@ def test_random_case_matches_oracle(seed):
         x.seed_ties(tmode, seed + 3)
     if c["tie"] == 0:
         o.set_pre_evaluate(1)                  # MPF_TIE_FIRST = first-best rule on exactly scored candidates
-    ufb = seed % 2 == 0 and opts.get("scan_mode", 1) == 1 and c["maxtrav"] <= 8
+    ufb = seed % 2 == 0 and opts.get("scan_mode", 1) == 1
     if ufb:
         samples = np.random.default_rng(seed).multinomial(max(1, int(c["w"].sum())), (c["w"] + 1e-9) / (c["w"] + 1e-9).sum(), size=7).astype(np.uint16)
         e.ufboot_attach(samples)

@@ -41,6 +41,8 @@ def test_random_call_sequences_on_medium_trees(seed):
     codes[rng.random(codes.shape) < 0.02] = 22 if aa else 15
     w = rng.integers(1, 3, size=P).astype(np.int32)
     c = dict(aa=aa, n=n, P=P, codes=codes, w=w, back=trees.random_topology(n, rng), maxtrav=int(rng.integers(2, 7)))
+    if seed % 4 == 3:
+        c["maxtrav"] = 9 + seed % 6               # long radii: host-planned programs, the deep kernels under the tracker
     run_sequence(c, seed, 8)
 
 
@@ -70,6 +72,8 @@ def test_random_call_sequences_weighted_medium_trees(seed):
     m = rng.integers(1, 6, size=(S, S))
     cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
     c = dict(aa=aa, n=n, P=P, codes=codes, w=w, back=trees.random_topology(n, rng), maxtrav=int(rng.integers(2, 5)))
+    if seed >= 2:
+        c["maxtrav"] = 7 + 3 * seed               # 13 (DNA), 16 (protein): k_snk_scan_deep, also under the tracker
     run_sequence(c, seed, 7, cost=cost)
 
 
@@ -90,7 +94,7 @@ def run_sequence(c, seed, n_steps, cost=None):
     if o.num_informative == 0:
         return
     n, P = c["n"], c["P"]
-    maxtrav = min(c["maxtrav"], 8 if cost is None else 6)
+    maxtrav = c["maxtrav"]                        # (any radius on both engines since round 5: the deep kernels above 8 / 12 / 6 levels)
     for k, v in OPTION_SETS[seed % len(OPTION_SETS)].items():
         if cost is not None and k == "words_per_lane":
             continue                            # (refused in weighted mode: one pattern per lane)
@@ -192,7 +196,7 @@ def run_sequence(c, seed, n_steps, cost=None):
             pe, te = e.pattern_scores()
             po_, to = o.pattern_scores()
             assert te == to and pe.tolist() == po_.tolist(), log
-        elif op == 7 and not tracked and maxtrav <= 8 and (weights[0] > 0).any():      # attach the bookkeeping half-way
+        elif op == 7 and not tracked and (weights[0] > 0).any():      # attach the bookkeeping half-way
             for x in (e, o):
                 x.set_weights(weights[0])
             samples = rng.multinomial(max(1, int(weights[0].sum())), (weights[0] + 1e-9) / (weights[0] + 1e-9).sum(), size=5).astype(np.uint16)
