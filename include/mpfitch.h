@@ -260,7 +260,8 @@ int mpf_remain_bounds(int32_t n_units, int32_t n_segments, const int32_t *segmen
    samples = boot_samples_pars (iqtree.cpp:213-313), [n_samples][n_patterns] uint16.  epsilon = params->ufboot_epsilon
    (0.5, tools.cpp:725); any value in (0, 1) is equivalent for integer scores, others are MPF_E_UNSUPPORTED.
    Both engines: on the weighted (Sankoff, -cost) engine the per-pattern lengths are those pllComputeSankoffPatternParsimony
-   reads (sprparsimony.cpp:3341-3355; a symmetric matrix only), sample sharding (below) included.  Climbs under other weights than the attach-time
+   reads (sprparsimony.cpp:3341-3355) -- with a matrix that is not symmetric the current tree is booked at every prune node's
+   visit with the length and the per-pattern lengths it has at that node's edge (:2285) --, sample sharding (below) included.  Climbs under other weights than the attach-time
    ones (ratchet iterations) are booked as the reference books them (iqtree.cpp:3283-3295) unless
    mpf_ufboot_set_ratchet_booking(e, 0) (-no_hclimb1_bb, :3280); weights that take an attach-time pattern out of the
    alignment altogether rest the tracker until the attach-time weights are back. */

@@ -1715,6 +1715,23 @@ int Engine::scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count,
                     : plan_scan(recs[i], mintrav, maxtrav, plans[(size_t)i]);
       if (rc) return rc;
       if (!walk) plans[(size_t)i].self_idx = self;
+      if (self >= 0 && sankoff_ && asym_) {
+        // an asymmetric matrix: the current tree has another length, and other per-pattern lengths, at every prune node's visit
+        // -- the reference evaluates it at that node's edge (evaluateParsimony(p), :2285).  One more program of one op writes the
+        // row and the length to the visit's slot: min_x(vec[q][x] + m(vec[p])[x]), vec[q] = m(x1) + m(x2) of q's children.
+        const int pr = recs[i], q = back_[pr];
+        ScanHdr h;
+        h.op_begin = (uint32_t)prog_ops_.size();
+        h.s_slot = slot(pr);
+        h.pad = 0;
+        ScanOp o;
+        if (!tip(q)) { o.own = slot(back_[nx(q)]); o.sib = slot(back_[nx(nx(q))]); o.meta = ((uint32_t)SCAN_JOIN << 16) | (1u << 8); }
+        else { o.own = 0; o.sib = slot(q); o.meta = ((uint32_t)SCAN_EVAL << 16) | (1u << 8); }
+        o.out = (uint32_t)self;
+        prog_ops_.push_back(o);
+        h.op_end = (uint32_t)prog_ops_.size();
+        prog_hdr_.push_back(h);
+      }
     }
   }
   if (walk && (plan_cache_ & 4) && !scan_masks_ && &plans == &sweep_plans_ && count >= n_ / 2) {

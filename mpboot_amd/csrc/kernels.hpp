@@ -24,7 +24,7 @@ struct EvOp { uint32_t a, b, out, pad; };
 struct ScanOp { uint32_t own, sib, meta, out; };   // meta = depth | test<<8 | kind<<16
 struct ScanHdr { uint32_t op_begin, op_end, s_slot, pad /* bit 0: stepwise-addition program (the subtree s is the root side of every test) */; };
 
-enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2 };
+enum { SCAN_CHAIN = 0, SCAN_ROOT = 1, SCAN_JOIN = 2, SCAN_EVAL = 3 };   // EVAL (weighted kernels only): min_x(vec[sib][x] + m(S)[x]), the evaluate at a tip's edge
 
 // device-walked scan: the kernel enumerates the neighbourhood of prune record x itself from the
 // topology (back links) resident in HBM; candidate i of the scan lands in out[out_base + i] in the

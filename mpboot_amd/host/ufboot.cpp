@@ -40,9 +40,6 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local, const int32_t *sample_ids,
                           mpf_ufb_exchange_fn exchange, void *exchange_arg)
 {
-  // (an asymmetric matrix gives the CURRENT tree another length at every prune node's visit -- it is evaluated at that node's
-  //  edge --, which the tracker's one row for the current tree does not model)
-  if (sankoff_ && asym_) { set_error("online UFBoot on the weighted engine: the cost matrix must be symmetric"); return MPF_E_UNSUPPORTED; }
   if (n_samples < 1 || !samples) { set_error("ufboot_attach: bad argument"); return MPF_E_INVALID; }
   if (!(epsilon > 0.0 && epsilon < 1.0)) {
     set_error("ufboot_attach: epsilon must lie in (0, 1) -- with integer scores every such value acts like the default 0.5");
@@ -2416,7 +2413,10 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
   std::string mh_key;
   const bool ratchet = u.ratchet;
   const bool store_trees = u.store_trees;          // -storetrees (iqtree.cpp:3302-3346)
-  const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the current tree's bookings come as device events)
+  // (an asymmetric matrix gives the CURRENT tree another length and another row at every prune node's visit -- it is evaluated at
+  //  that node's edge, evaluateParsimony(p) of :2285 --: the scan writes both to the visit's slot, scan_batch)
+  const bool asym = asym_;
+  const bool host_self = !u.exchange && !asym;     // (sample-sharded: R_T lives in pieces on the ranks, the current tree's bookings come as device events)
   const int oc = u.Bl;
   if (ratchet) u.gate_closed = false;
   bool stale_init = false;                         // ratchet: _pattern_pars of the climb's start tree, known after the first product
@@ -2454,7 +2454,8 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         // ---- the current tree's row, the bit planes, the product
         UCHK(u.vals.reserve(((size_t)n_idx + 1) * npat));
         UCHK(u.h_vmax.reserve(4));
-        UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), u.vals.p + (size_t)R * npat, u.vmax.p));
+        if (asym) UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(back_[start_]), slot(start_), u.vals.p + (size_t)R * npat, u.vmax.p));     // (left = far end, as tree_length)
+        else UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), u.vals.p + (size_t)R * npat, u.vmax.p));
         UCHK(hipMemcpyAsync(u.h_vmax.p, u.vmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
         UCHK(hipStreamSynchronize(st_));
         int K = 1;
@@ -2489,7 +2490,9 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         const bool self_pass = ratchet || store_trees || randomMP <= mp_max;
         for (int j = 0; j <= jstar; j++) {
           const ScanPlan &pl = plans[(size_t)j];
-          if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = make_uint2(0u, (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+          // (asym: the visit's slot is a row of its own -- it takes part like a candidate, its cost the length at that edge)
+          if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = asym ? make_uint2((uint32_t)pl.self_idx, (uint32_t)j)
+                                                                   : make_uint2(0u, (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
           for (const Candidate &cd : pl.cands) hinfo[cd.out] = make_uint2(cd.out, (uint32_t)j);
           n_parts = (uint32_t)j + 1u;
         }
@@ -2679,17 +2682,18 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
           return (int64_t)u.treels.size() - 1;
         };
         if (pl.self_idx >= 0) {
+          const uint32_t self_len = asym ? out[(size_t)pl.self_idx] : randomMP;       // (:2285: mp of evaluateParsimony(p))
           bool pass;
-          if (!ratchet) pass = !none_pass && randomMP <= mp_max;
+          if (!ratchet) pass = !none_pass && self_len <= mp_max;
           else {
             pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
             if (!pass) u.gate_closed = true;
           }
-          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : randomMP);
-          const int64_t tree_index = book_tree(ratchet ? u.stale_len : randomMP, pass, 0xFFFFFFFFu);
+          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : self_len);
+          const int64_t tree_index = book_tree(ratchet ? u.stale_len : self_len, pass, 0xFFFFFFFFu);
           if (tree_index >= 0) {
             if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
-            if (ratchet) u.stale_len = u.rt_orig;
+            if (ratchet) u.stale_len = asym ? (uint32_t)lcol[(size_t)pl.self_idx] : u.rt_orig;
           }
         }
         for (size_t c = 0; c < pl.cands.size(); c++) {

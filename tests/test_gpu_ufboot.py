@@ -555,6 +555,8 @@ if rule.startswith("weighted"):
     S = 20 if os.environ["MPF_FX"] == "aa" else 4
     c = np.random.default_rng(2).integers(1, 4, size=(S, S))
     cost = (np.triu(c, 1) + np.triu(c, 1).T).astype(np.uint32)
+    if rule == "weighted_asym":
+        cost[np.triu_indices(S, 1)] += 2
 e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
 if rank == 1:
     # a different past on this engine (its batch-size estimate, node order ...) must not change how it cuts the climb
@@ -599,7 +601,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("rule", ["default", "topboot", "distinct", "storetrees", "weighted", "weighted_mulhits"])
+@pytest.mark.parametrize("rule", ["default", "topboot", "distinct", "storetrees", "weighted", "weighted_mulhits", "weighted_asym"])
 @pytest.mark.parametrize("name", ["dna_ambig", "aa"])
 def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, name, rule):
     """two ranks (sharing this GPU) hold half of the samples each and exchange their events per batch: every rank must
@@ -620,6 +622,8 @@ def test_sample_sharded_online_phase_equals_the_unsharded_run(mods, tmp_path, na
         S = 20 if name == "aa" else 4
         c = np.random.default_rng(2).integers(1, 4, size=(S, S))
         cost = (np.triu(c, 1) + np.triu(c, 1).T).astype(np.uint32)
+        if rule == "weighted_asym":                  # (every visit's own row and length: device events on every rank)
+            cost[np.triu_indices(S, 1)] += 2
     e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
     e.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32))
     e.seed_ties(engine.TIE_RANDOM, 19)
@@ -678,10 +682,10 @@ def test_unsupported_configurations_fail_loudly(mods):
     s.ufboot_attach(samples)                       # the weighted engine keeps the bookkeeping too (sample-sharded as well: see
     s.ufboot_detach()                              # test_sample_sharded_online_phase_equals_the_unsharded_run) ...
     asym = cost.copy()
-    asym[0, 1] = 2                                 # ... but not under an asymmetric matrix (the current tree's length depends on the visit's edge)
+    asym[0, 1] = 2                                 # ... also under an asymmetric matrix (test_weighted_tracker_under_an_asymmetric_matrix)
     a = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=asym)
-    with pytest.raises(engine.MpfError):
-        a.ufboot_attach(samples)
+    a.ufboot_attach(samples)
+    a.ufboot_detach()
     # the bookkeeping lives in the device-walked scan: the other scan mode refuses instead of skipping it (any radius is served:
     # test_any_radius_under_the_tracker)
     e.ufboot_attach(samples)
@@ -905,6 +909,54 @@ def test_weighted_tracker_at_a_long_radius(mods, name, radius):
     assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
     assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
     assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+
+
+@pytest.mark.parametrize("mode", ["default", "cutoff", "mulhits", "storetrees"])
+@pytest.mark.parametrize("name", ["dna_clean", "dna_ambig", "aa", "dna_48"])
+def test_weighted_tracker_under_an_asymmetric_matrix(mods, name, mode):
+    """-cost with a matrix that is not symmetric, under -bb: the current tree has another length and other per-pattern lengths at
+    every prune node's visit (evaluateParsimony(p) roots it at that node's edge, sprparsimony.cpp:2285) -- the scan writes both
+    into the visit's slot.  A normal climb, a ratchet climb, the climb back: every observable == the oracle's"""
+    engine, po = mods
+    fx = load_fixture(name)
+    w0 = fx["weights_np"]
+    S = 4 if fx["datatype"] == 0 else 20
+    rng = np.random.default_rng(21)
+    cost = rng.integers(1, 7, size=(S, S)).astype(np.uint32)
+    cost[np.triu_indices(S, 1)] += 2
+    np.fill_diagonal(cost, 0)
+    samples = boot_samples(len(w0), 14, 9, fx["weights"])
+    pert = (w0 * (1 + (rng.random(len(w0)) < 0.3))).astype(np.int32)
+    e = engine.FitchEngine(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], w0, datatype=fx["datatype"], cost=cost)
+    t = [np.array(fx["trees"][k]["back"], dtype=np.int32) for k in (1, 4, 6)]
+    for x in (e, o):
+        x.seed_ties(1, 17)
+        x.ufboot_attach(samples)
+        if mode == "mulhits":
+            x.ufboot_set_mulhits(True)
+        if mode == "storetrees":
+            x.ufboot_set_store_trees(True)
+    for k, w in enumerate((w0, pert, w0)):
+        for x in (e, o):
+            x.set_weights(w)
+            x.set_tree(t[k])
+        o.trace(True)
+        assert e.optimize_spr(1, 5) == o.optimize_spr(1, 5)
+        assert [a.tolist() for a in e.moves()] == [a.tolist() for a in o.get_moves()]
+        assert (e.get_tree() == o.get_tree()).all()
+        assert e.ufboot_tree_logl().tolist() == o.ufboot_tree_logl().tolist()
+        assert [x.tolist() for x in e.ufboot_state()] == [x.tolist() for x in o.ufboot_state()]
+        assert e.ufboot_counters()["tie_draws"] == o.ufboot_draws()
+        if mode == "mulhits":
+            for b in range(len(samples)):
+                assert e.ufboot_sample_trees(b) == o.ufboot_sample_trees(b)
+        if k == 0 and mode == "cutoff":
+            logl = np.sort(o.ufboot_tree_logl())
+            for x in (e, o):
+                x.ufboot_set_cutoff(float(logl[len(logl) // 2]))
+    assert len(set(o.ufboot_tree_logl().tolist())) > 10
+    assert len(o.ufboot_tree_logl()) > 50
 
 
 @pytest.mark.parametrize("mode", ["default", "cutoff", "mulhits"])
