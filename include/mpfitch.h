@@ -278,7 +278,7 @@ int mpf_ufboot_attach(mpf_engine *e, int32_t n_samples, const uint16_t *samples,
                   scores[b] and leave the tree as it is; 0: it accepts one (first_move_visit[b] = 1-based position in the sweep's
                   visiting order, mpf_get_node_order) -- the caller runs that sample's climb alone
    All three arrays have n_samples entries of the attach call (a sample-sharded tracker fills the entries of its own samples);
-   any may be NULL.  Needs the attach-time weights in force, the random tie rule and the Fitch engine (any maxtrav).  The
+   any may be NULL.  Needs the attach-time weights in force, the random tie rule (any maxtrav, both engines).  The
    tracker's saveCurrentTree bookkeeping is not touched.  (ABI 5) */
 int mpf_ufboot_refine_sweep(mpf_engine *e, int32_t maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable,
                             int32_t *first_move_visit);

@@ -93,9 +93,9 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     units = shard.units_of_rank(B, rank, ws)
     engines = eng if isinstance(eng, (list, tuple)) else [eng]
     if batched is None:
-        # (the batched first sweep is the Fitch engine's: state sets that do not depend on the weights; the weighted engine's vectors
-        #  ARE costs under the weights -- its samples climb one by one)
-        batched = hasattr(engines[0], "ufboot_refine_sweep") and not getattr(engines[0], "weighted", False)
+        # (both engines: Fitch state sets and the weighted engine's per-pattern cost vectors alike do not depend on the pattern
+        #  weights -- those enter in the product with the samples)
+        batched = hasattr(engines[0], "ufboot_refine_sweep")
 
     def one(e, b):
         e.set_weights(samples[b].astype(np.int32))

@@ -48,8 +48,24 @@ Api &api()
   static Api a;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime THIS library runs on: a process that has imported torch holds a second ROCm stack
+    // (torch/lib/libamdhip64.so + librccl.so, other sonames), and a plain dlopen("librccl.so") would hand back that one -- whose
+    // runtime knows nothing of this library's device buffers and streams.  So: the librccl next to the libamdhip64 our own HIP
+    // calls resolve to, by path; the plain names only where that fails.
+    std::vector<std::string> names;
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+      std::string dir(di.dli_fname);
+      const size_t cut = dir.find_last_of('/');
+      if (cut != std::string::npos) {
+        dir.resize(cut);
+        names.push_back(dir + "/librccl.so.1");
+        names.push_back(dir + "/librccl.so");
+      }
+    }
+    for (const char *name : {"/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"}) names.push_back(name);
+    for (const std::string &name : names) {
+      a.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (a.lib) break;
     }
     if (!a.lib) return;

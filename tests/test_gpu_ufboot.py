@@ -463,6 +463,54 @@ def test_batched_refinement_at_a_long_radius(mods):
         assert bool(stable[b]) == (len(solo.moves()[0]) == 0)
 
 
+@pytest.mark.parametrize("name,kind,radius,chunk", [("dna_ambig", "sym", 6, 0), ("dna_48", "sym", 6, 7), ("aa", "sym", 5, 0), ("dna_clean", "asym", 6, 3), ("aa", "asym", 9, 0),
+                                                    ("dna_dups", "big", 4, 0)])
+def test_batched_refinement_on_the_weighted_engine(mods, name, kind, radius, chunk):
+    """mpf_ufboot_refine_sweep on the weighted (-cost) engine: the first sweep of every sample's climb from one topology out of ONE
+    scan with per-pattern lengths + bit-plane products == set_weights + optimize_spr per sample (score of the start tree under
+    the sample, stable <=> the climb makes no move, the first move's visit), also under an asymmetric matrix and 32-bit costs"""
+    engine, po = mods
+    fx = load_fixture(name)
+    S = 4 if fx["datatype"] == 0 else 20
+    rng = np.random.default_rng(8)
+    m = rng.integers(1, 4000 if kind == "big" else 6, size=(S, S))
+    cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+    if kind == "asym":
+        cost[np.triu_indices(S, 1)] += 2
+    B = 9
+    samples = boot_samples(len(fx["weights"]), B, 3, fx["weights"])
+    e = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    if chunk:
+        e.set_option("refine_chunk", chunk)
+    e.seed_ties(engine.TIE_RANDOM, 0)
+    e.ufboot_attach(samples, 0.5)
+    seeds = np.arange(11, 11 + B)
+    solo = engine.FitchEngine(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    o = po.Oracle(fx["codes_np"], fx["weights_np"], datatype=fx["datatype"], cost=cost)
+    n_stable = 0
+    for start in (np.array(fx["trees"][3]["back"], dtype=np.int32), None):
+        if start is None:                               # ... and from a local optimum: most samples stable
+            solo.set_weights(fx["weights_np"]); solo.set_tree(np.array(fx["trees"][3]["back"], dtype=np.int32)); solo.seed_ties(engine.TIE_RANDOM, 2)
+            solo.optimize_spr(1, radius)
+            start = solo.get_tree()
+        e.reset_node_order()
+        e.set_tree(start)
+        sc, stable, first = e.ufboot_refine_sweep(radius, seeds)
+        for b in range(B):
+            for x, mode in ((solo, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+                x.set_weights(samples[b].astype(np.int32))
+                x.seed_ties(mode, int(seeds[b]))
+                x.set_tree(start)
+            solo.reset_node_order(); o.reset_nodep()
+            assert solo.score_tree() == sc[b] == o.score_tree()
+            o.trace(True)
+            assert solo.optimize_spr(1, radius) == o.optimize_spr(1, radius)
+            moved = len(solo.moves()[0]) > 0
+            assert bool(stable[b]) == (not moved), (b, int(first[b]))
+            n_stable += bool(stable[b])
+    assert n_stable > 0 or kind == "asym"          # (under an asymmetric matrix a tree keeps moving: its length depends on the edge)
+
+
 def test_first_best_tie_rule(mods):
     """PLL-original tie rule for the SPR part (MPF_TIE_FIRST): the bookkeeping still draws its own ties"""
     engine, po = mods
