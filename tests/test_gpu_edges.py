@@ -180,8 +180,8 @@ def test_error_behaviour(mods):
     sk.set_tree(np.array(fx["trees"][0]["back"], dtype=np.int32))
     k13, _m, _ = sk.spr_scan(6, 1, 13)                   # ... and on the weighted one (k_snk_scan_deep; tests/test_gpu_sankoff.py)
     assert k13.tolist() == q13.tolist()
-    with pytest.raises(engine.MpfError):
-        sk.spr_scan(6, 1, 300)                           # (a radius is one byte of a descriptor)
+    k300, _m, _ = sk.spr_scan(6, 1, 300)                 # (clipped to ntips - 3 first)
+    assert k300.tolist() == q99.tolist()
 
 
 def test_engine_reuse_across_trees_and_rebuilds(mods):
