@@ -6,6 +6,9 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <ctime>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -1251,14 +1254,53 @@ static inline void cpu_relax()
   asm volatile("yield");
 #endif
 }
+// How many host threads of this process are waiting for the device right now, against the CPU time the process may use (the
+// cgroup's quota: a container that is granted 16 of 256 cores is THROTTLED as a whole once its spinning threads have burnt the
+// period's quota -- 32 engines polling at full speed stall each other and the HIP runtime's own threads).  Crowded = more
+// waiters than the budget: they sleep between looks instead of spinning.
+namespace {
+std::atomic<int> g_waiters{0};
+int cpu_budget()
+{
+  static const int budget = [] {
+    int b = (int)std::thread::hardware_concurrency();
+    if (b <= 0) b = 1;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
+      char q[32] = {0};
+      long period = 0;
+      if (std::fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) b = std::min(b, (int)std::max(1L, std::atol(q) / period));
+      std::fclose(f);
+    } else {
+      long quota = -1, period = 0;                                                  // cgroup v1
+      if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%ld", &quota) != 1) quota = -1; std::fclose(g); }
+      if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%ld", &period) != 1) period = 0; std::fclose(g); }
+      if (quota > 0 && period > 0) b = std::min(b, (int)std::max(1L, quota / period));
+    }
+    return b;
+  }();
+  return budget;
+}
+}  // namespace
+Engine::WaitScope::WaitScope() { g_waiters.fetch_add(1, std::memory_order_relaxed); }
+Engine::WaitScope::~WaitScope() { g_waiters.fetch_sub(1, std::memory_order_relaxed); }
+void Engine::wait_pause()
+{
+  if (g_waiters.load(std::memory_order_relaxed) > cpu_budget()) {
+    struct timespec ts = {0, 20000};               // (20 us + the timer slack: the core goes to somebody who has work)
+    nanosleep(&ts, nullptr);
+  } else {
+    sched_yield();                                 // several engines per GPU poll from threads that may share cores
+  }
+}
 bool Engine::wait_host_flag(const uint32_t *flag)
 {
   std::chrono::steady_clock::time_point t0;
+  WaitScope waiting;
   for (long spin = 0;; spin++) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 1u) return true;
     cpu_relax();
     if ((spin & 255) == 255) {
-      sched_yield();                               // several engines per GPU poll from threads that may share cores
+      wait_pause();
       const auto now = std::chrono::steady_clock::now();
       if (spin == 255) t0 = now;
       else if (now - t0 > std::chrono::milliseconds(50)) return false;

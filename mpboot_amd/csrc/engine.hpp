@@ -287,6 +287,8 @@ class Engine {
   // calls run_walks_finish (scores of the refresh, base lengths, statistics)
   int run_walks_finish(std::vector<ScanPlan> &plans, const uint32_t **out_host);
   static bool wait_host_flag(const uint32_t *flag);
+  struct WaitScope { WaitScope(); ~WaitScope(); };   // a host thread waiting for the device (counted: see wait_pause)
+  static void wait_pause();                          // between two looks of a polling loop: yield, or sleep when the process is crowded
   int scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out);
   int candidate_record(const ScanPlan &plan, size_t c);               // q of the c-th insertion test
   void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const { enumerate_side(back_, x, mintrav, maxtrav, q); }

@@ -180,8 +180,12 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     const auto w0 = std::chrono::steady_clock::now();
     hipError_t q;
     long spins = 0;
+    WaitScope waiting;
     while ((q = hipStreamQuery(st_)) == hipErrorNotReady) {
-      if ((++spins & 63) == 0) {
+      // (a launch runs for milliseconds: the waiting thread sleeps between its looks -- a core per waiting engine is what a
+      //  container's CPU quota cannot afford when many engines share the GPU, and the HIP runtime's own threads need theirs)
+      { struct timespec ts = {0, 30000}; nanosleep(&ts, nullptr); }
+      if ((++spins & 15) == 0) {
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > (climb_trace_ ? 4.0 : 20.0)) {
           std::string where;
           if (p.beat) for (int k = 0; k < 32; k++) where += " " + std::to_string(cd_.h_beat.p[k]);
@@ -191,7 +195,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
           broken_ = true;
           return MPF_E_STATE;
         }
-        std::this_thread::yield();
+        wait_pause();
       }
     }
     if (q != hipSuccess) { invalidate_all(); set_error(std::string("device climb: ") + hipGetErrorString(q)); return MPF_E_HIP; }
@@ -389,15 +393,17 @@ int Engine::grow_segment(const std::vector<int> &perm, uint32_t len0, uint32_t *
     const auto w0 = std::chrono::steady_clock::now();
     hipError_t q;
     long spins = 0;
+    WaitScope waiting;
     while ((q = hipStreamQuery(st_)) == hipErrorNotReady) {
-      if ((++spins & 63) == 0) {
+      { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }      // (a tree takes tens of milliseconds: sleep between looks, as climb_segment)
+      if ((++spins & 15) == 0) {
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 30.0) {
           set_error("device addition: the launch did not finish within 30 s");
           invalidate_all();
           broken_ = true;
           return MPF_E_STATE;
         }
-        std::this_thread::yield();
+        wait_pause();
       }
     }
     if (q != hipSuccess) { invalidate_all(); set_error(std::string("device addition: ") + hipGetErrorString(q)); return MPF_E_HIP; }

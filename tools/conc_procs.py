@@ -8,8 +8,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
     import numpy as np
     from mpboot_amd import engine, synth, trees
     i, tile, go = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    letters, _ = synth.workload("C3")
-    codes = synth.letters_to_codes(letters, "DNA")
+    WL = os.environ.get("MPF_WL", "C3")
+    letters, _ = synth.workload(WL)
+    codes = synth.letters_to_codes(letters, synth.WORKLOADS[WL]["alphabet"])
     e = engine.FitchEngine(codes)
     e.set_option("climb_device", 2); e.set_option("climb_tile", tile)
     n = codes.shape[0]
@@ -21,7 +22,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
     while not os.path.exists(go):
         time.sleep(0.001)
     t0 = time.time()
-    for r in range(3):
+    R = int(os.environ.get("MPF_ROUNDS", "3"))
+    for r in range(R):
         run(i + 100 * r)
     print("DONE", t0, time.time(), flush=True)
     sys.exit(0)
@@ -47,5 +49,6 @@ for p in ps:
 os.remove(go)
 _timer.cancel()
 _reap()
+R = int(os.environ.get("MPF_ROUNDS", "3"))
 wall = max(t[1] for t in ts) - min(t[0] for t in ts)
-print(f"{K} processes x 3 climbs (tile {tile}): {wall:.3f} s -> {3 * K / wall:.1f} climbs/s; per climb {sum(t[1]-t[0] for t in ts)/(3*K):.3f} s")
+print(f"{K} processes x {R} climbs (tile {tile}): {wall:.3f} s -> {R * K / wall:.1f} climbs/s; per climb {sum(t[1]-t[0] for t in ts)/(R*K):.3f} s")

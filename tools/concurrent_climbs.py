@@ -29,13 +29,16 @@ for e in engs:
 for E in (int(x) for x in a.engines.split(",")):
     starts = [[trees.random_topology(n, np.random.default_rng(100 * k + c)) for c in range(a.climbs)] for k in range(E)]
     res = [None] * E
+    busy = [0.0] * emax
 
     def work(k):
         e = engs[k]
         out = []
         for c in range(a.climbs):
             e.set_tree(starts[k][c]); e.seed_ties(engine.TIE_RANDOM, k + 1); e.reset_node_order()
+            t_ = time.perf_counter()
             out.append(e.optimize_spr(1, 6))
+            busy[k] += time.perf_counter() - t_
         res[k] = out
 
     th = [threading.Thread(target=work, args=(k,)) for k in range(E)]
@@ -45,7 +48,8 @@ for E in (int(x) for x in a.engines.split(",")):
     dt_s = time.perf_counter() - t0
     sts = [engs[k].stats() for k in range(E)]
     print(f"   kernel launches {sum(s_['climb_launches'] for s_ in sts)} host scan launches {sum(s_['scan_launches'] for s_ in sts)} "
-          f"kernel ms/engine {np.mean([s_['climb_ms_total'] for s_ in sts]):.0f}")
+          f"kernel ms/engine {np.mean([s_['climb_ms_total'] for s_ in sts]):.0f} | host ms/engine: views {np.mean([s_['host_views_ms_total'] for s_ in sts]):.0f} "
+          f"plan {np.mean([s_['host_plan_ms_total'] for s_ in sts]):.0f} scan {np.mean([s_['host_scan_ms_total'] for s_ in sts]):.0f} | busy per engine {np.mean(busy[:E]) * 1e3:.0f} ms")
     for k in range(E):
         engs[k].reset_stats()
     print(f"{a.workload}: {E} engines x {a.climbs} climbs from random trees in {dt_s:.3f} s = {E * a.climbs / dt_s:.2f} climbs/s "
