@@ -2069,13 +2069,15 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
       continue;
     }
     typename T::E best = T::inf();
-    if (kind == SCAN_EVAL) {       // the current tree at the edge of a TIP q: min_x(vec[q][x] + m(S)[x]) (evaluate, :880-961)
+    bool eval_op = false;           // (SCAN_EVAL exists in programs under an asymmetric matrix only: no code for it in the other variant)
+    if constexpr (ASYM) eval_op = kind == SCAN_EVAL;
+    if (eval_op) {                  // the current tree at the edge of a TIP q: min_x(vec[q][x] + m(S)[x]) (evaluate, :880-961)
       ldv(t1, o.sib);
 #pragma unroll
       for (int s = 0; s < S; s++) best = T::mn(best, T::add(t1.v[s], ms.v[s]));
     } else
     ldm(t1, o.sib);       // m(vec[sib])
-    if (kind == SCAN_EVAL) {
+    if (eval_op) {
     } else if (kind == SCAN_JOIN) {
       ldm(t2, o.own);
 #pragma unroll
@@ -2104,7 +2106,7 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
       }
 #undef MPF_SLEVEL
     }
-    if (test || kind == SCAN_JOIN || kind == SCAN_EVAL) {
+    if (test || kind == SCAN_JOIN) {       // (a SCAN_EVAL op carries the test bit)
       const uint32_t c = valid ? T::wsum(best, pwgt, e0) : 0u;
       const uint32_t tot = wave_total<0>(c);
       if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
@@ -2186,13 +2188,15 @@ __global__ __launch_bounds__(256) void k_snk_scan_deep(const uint32_t *__restric
       continue;
     }
     E best = T::inf();
-    if (kind == SCAN_EVAL) {
+    bool eval_op = false;
+    if constexpr (ASYM) eval_op = kind == SCAN_EVAL;
+    if (eval_op) {
       ldv(t1, o.sib);
 #pragma unroll
       for (int s = 0; s < S; s++) best = T::mn(best, T::add(t1.v[s], ms.v[s]));
     } else
     ldm(t1, o.sib);
-    if (kind == SCAN_EVAL) {
+    if (eval_op) {
     } else if (kind == SCAN_JOIN) {
       ldm(t2, o.own);
 #pragma unroll
@@ -2216,7 +2220,7 @@ __global__ __launch_bounds__(256) void k_snk_scan_deep(const uint32_t *__restric
         for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], last.v[s]), ms.v[s]));
       }
     }
-    if (test || kind == SCAN_JOIN || kind == SCAN_EVAL) {
+    if (test || kind == SCAN_JOIN) {
       const uint32_t c = valid ? T::wsum(best, pwgt, e0) : 0u;
       const uint32_t tot = wave_total<0>(c);
       if (lane == 0 && tot) atomic_add_u32(out + o.out, tot);
