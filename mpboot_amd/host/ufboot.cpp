@@ -2292,7 +2292,9 @@ int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t 
     const uint32_t *out = nullptr;
     std::vector<uint2> hinfo;
     std::vector<uint32_t> small;
-    const int chunk = std::max(1, refine_chunk_);
+    // (a row is one tentative tree's per-pattern lengths, 2 bytes per pattern, ~60 rows per prune node at radius 6: chunks of
+    //  at most ~2 GB of rows -- plus their bit planes -- whatever the option says)
+    const int chunk = std::max(1, std::min(refine_chunk_, (int)std::max<uint64_t>(1, 2000000000ull / ((uint64_t)npat * 2ull * 64ull))));
     bool have_rt = false;
     for (int i = 1; i <= total; i += chunk) {
       const int hi = std::min(total, i + chunk - 1), np = hi - i + 1;
