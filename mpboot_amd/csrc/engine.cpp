@@ -1385,28 +1385,6 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
 
 // ---- device-walked scans -------------------------------------------------------------------
 // the same enumeration as add_traverse, host side, only to NAME a candidate (needed when a move is accepted)
-void Engine::enumerate_side(const std::vector<int32_t> &bk, int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const
-{
-  struct Fr { int q, d; };
-  Fr st[160];                                      // (one entry more per level of the walk; radii stay far below 128)
-  int sp = 0;
-  const int x1 = bk[(size_t)nx(x)], x2 = bk[(size_t)nx(nx(x))];
-  for (int side = 0; side < 2; side++) {
-    const int a = side ? x2 : x1;
-    if (tip(a)) continue;
-    st[sp++] = Fr{bk[(size_t)nx(nx(a))], 1};
-    st[sp++] = Fr{bk[(size_t)nx(a)], 1};
-    while (sp) {
-      const Fr f = st[--sp];
-      if (f.d >= mintrav) q.push_back(f.q);
-      if (!tip(f.q) && f.d < maxtrav) {
-        st[sp++] = Fr{bk[(size_t)nx(nx(f.q))], f.d + 1};
-        st[sp++] = Fr{bk[(size_t)nx(f.q)], f.d + 1};
-      }
-    }
-  }
-}
-
 int Engine::candidate_record(const ScanPlan &plan, size_t c)
 {
   if (!plan.walked) return plan.cands[c].q;

@@ -23,6 +23,7 @@
 
 #include "../../include/mpfitch.h"
 #include "../host/rng.hpp"
+#include "../host/ufb_books.hpp"
 #include "climb.hpp"
 #include "kernels.hpp"
 #include "ufboot.hpp"
@@ -106,7 +107,7 @@ uint64_t lcg64_skip(uint64_t state, uint64_t k);      // the tie stream k draws 
 
 // online UFBoot-MP: the arrays IQTree keeps per bootstrap sample (iqtree.cpp:213-262) plus the device buffers of
 // the masked scan, the REPS product and the event extraction (ufboot.hip)
-struct UfbState {
+struct UfbState : books::Deferred {      // (boot_trees, store, refs, topo_index: the deferred state, host/ufb_books.hpp)
   int B = 0, Bp = 0, planes = 1;                 // B = all samples of the run (host arrays); Bp = padded LOCAL columns
   // sample sharding (multi-GPU online phase): this engine multiplies only its own samples, ids[c] = global sample of
   // local column c; every rank replays the merged events of all ranks, so the search chain stays identical everywhere
@@ -128,16 +129,13 @@ struct UfbState {
   std::vector<int32_t> boot_orig;
   int32_t cur_logl_now = 0;
   bool cut_btrees = false;                       // params->cutoff_from_btrees: mpf_ufboot_next_cutoff = min(boot_orig)
-  std::vector<int64_t> boot_trees;
   std::vector<uint32_t> treels;                  // treels_logl as lengths
-  std::unordered_map<int64_t, std::vector<int32_t>> store;   // topologies of the trees some sample currently points to
-  std::vector<int32_t> refs;                     // per saved tree: number of samples whose boot_trees entry names it
-  struct Pending { int64_t tree_index; uint32_t cand; };      // accepted during the current prune node, not yet materialised
+  using Pending = books::Pending;                // accepted during the current prune node, not yet materialised
   std::vector<Pending> pending;
   // deferred part of the default update rule (host/ufboot.cpp, ufb_drain_log): which tree a sample points to, the topology map
   // and the stored topologies never feed back into a draw or into the search -- the replay only logs the acceptances (and the end
   // of every prune node's scan) and the log is worked off while the device runs the next batch
-  struct LogEntry { uint32_t b, cand; int64_t tree; int32_t plan; };      // b = 0xFFFFFFFF: end of the scan of prune node `plan`
+  using LogEntry = books::LogEntry;              // b = 0xFFFFFFFF: end of the scan of prune node `plan`
   std::vector<LogEntry> log;
   std::vector<int32_t> log_back;                 // the topology the log's candidates refer to
   int32_t log_epoch = 0;
@@ -203,7 +201,6 @@ struct UfbState {
   // topo_index first; one met before is not booked again unless its length improved on treels[index]
   bool store_trees = false;
   uint64_t duplicates = 0;                       // duplication_counter
-  std::unordered_map<std::string, int64_t> topo_index;       // canonical topology -> tree index
   std::vector<std::set<int64_t>> hit_sets;                   // boot_trees_parsimony
   // -mulhits -topboot N (params->store_top_boot_trees, iqtree.cpp:3542-3585): per sample the N best NEW trees, best first, and
   // boot_threshold (INT_MIN + 1 until the first replacement in a full list, as in the reference)
@@ -292,7 +289,7 @@ class Engine {
   int scan_batch(std::vector<ScanPlan> &plans, const int *recs, int count, int mintrav, int maxtrav, const uint32_t **out);
   int candidate_record(const ScanPlan &plan, size_t c);               // q of the c-th insertion test
   void enumerate_side(int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const { enumerate_side(back_, x, mintrav, maxtrav, q); }
-  void enumerate_side(const std::vector<int32_t> &bk, int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const;   // (on any topology; reads n_ only)
+  void enumerate_side(const std::vector<int32_t> &bk, int x, int mintrav, int maxtrav, std::vector<int32_t> &q) const { books::enumerate_side(n_, bk, x, mintrav, maxtrav, q); }   // (on any topology)
   int spr_scan(int rec, int mintrav, int maxtrav, std::vector<int32_t> &q, std::vector<uint32_t> &mp, int &n_p);
   int sweep_scan(int mintrav, int maxtrav, uint64_t *n_tests, uint32_t *min_mp);
   int sweep_costs(int mintrav, int maxtrav, uint64_t cap, uint32_t *mp, uint64_t *offsets, uint64_t *n_tests);
@@ -339,8 +336,8 @@ class Engine {
     return (uint32_t)(-(int64_t)u.top_thr[b]) - 1u;              // rell > threshold  <=>  length <= -threshold - 1
   }
   int ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const;
-  struct CanonScratch { std::vector<int32_t> q, cp, mn, sz, off; };
-  void canonical_topology(const std::vector<int32_t> &bk, std::string &key, CanonScratch &sc) const;
+  using CanonScratch = books::CanonScratch;
+  void canonical_topology(const std::vector<int32_t> &bk, std::string &key, CanonScratch &sc) const { books::canonical_topology(n_, bk, key, sc); }
   void canonical_topology(const std::vector<int32_t> &bk, std::string &key) const { canonical_topology(bk, key, ct_); }
   mutable CanonScratch ct_;                      // the calling thread's scratch (the tracker's log worker brings its own)
   bool ufboot_attached() const { return (bool)ufb_; }
@@ -425,20 +422,9 @@ class Engine {
   int ufb_memo_ = 1;                             // option "ufb_memo": no product for the batches of a topology known to be event-free (UfbState::quiet_topo)
   // the log of one batch against an explicit topology: touches nothing of the engine but n_ and the tracker's deferred state
   // (topology map, boot_trees, reference counts, stored topologies), so that it can run on the worker thread of a pipelined climb
-  struct DrainScratch {
-    CanonScratch canon;
-    std::vector<int32_t> bk, q_p, q_q;
-    std::string key, self_key;                   // (the current tree's canonical form, valid for topology epoch self_epoch)
-    int64_t self_epoch = -1;
-    int q_plan = -1;
-    std::vector<UfbState::Pending> pending;      // accepted during the current prune node, not yet materialised
-    // counters of the calling thread, added to the tracker's by whoever owns the scratch (the tracker's own words share cache
-    // lines with what the replay counts on the other thread)
-    uint64_t lookups = 0, stored = 0;
-    double t_lookup = 0;
-  };
+  using DrainScratch = books::DrainScratch;
   void ufb_drain(const std::vector<UfbState::LogEntry> &log, const std::vector<int32_t> &bk, int32_t epoch, const std::vector<ScanPlan> &plans,
-                 DrainScratch &sc);
+                 DrainScratch &sc) { books::drain<ScanPlan>(n_, *ufb_, log, bk, epoch, plans, sc); }
   DrainScratch drain_scratch_;
   int64_t ufb_event_cap_ = 1 << 20;              // option "ufb_event_cap" (tests): first size of the event buffers -- small values exercise the overflow paths
   int ufb_thread_ = 1;                           // option "ufb_thread": the pipelined climb works its log off on a second host thread

@@ -366,55 +366,6 @@ int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
 // What the reference's printTree(WT_TAXON_ID | WT_SORT_TAXA) string stands for (iqtree.cpp:3508): a canonical form of the
 // unrooted topology.  Here: the tree hung from tip 1, an inner node written as -1 followed by its two subtrees, the one
 // with the smaller tip number first.
-void Engine::canonical_topology(const std::vector<int32_t> &bk, std::string &key, CanonScratch &sc) const
-{
-  // One call per booked tree that some sample accepts (3e4 in a C3 climb from a random tree; every insertion test with
-  // -storetrees), so: no allocation, no stack, selects instead of branches.  Three sequential sweeps over the nodes in
-  // breadth-first order from the neighbour of tip 1 (a node's children sit side by side at cp[i], cp[i] + 1): the order itself,
-  // then min tip and sequence length of every subtree backwards, then every node's position in the sequence forwards.
-  // 16-bit entries while tip numbers fit (tips 1 .. n, an inner node 0; wide form: -1).
-  const int tipmax = 3 * n_ + 2;                   // records of tips: r <= tipmax
-  const size_t cap = 2 * (size_t)n_ + 8;
-  if (sc.q.size() < cap) { sc.q.resize(cap); sc.cp.resize(cap); sc.mn.resize(cap); sc.sz.resize(cap); sc.off.resize(cap); }
-  int32_t *q = sc.q.data(), *cp = sc.cp.data(), *mn = sc.mn.data(), *sz = sc.sz.data(), *off = sc.off.data();
-  int len = 1;
-  q[0] = bk[3];
-  for (int i = 0; i < len; i++) {
-    const int r = q[i];
-    const bool inner = r > tipmax;
-    const int base = (r / 3) * 3, sl = r - base;
-    const int r1 = base + (sl == 2 ? 0 : sl + 1), r2 = base + (sl == 0 ? 2 : sl - 1);      // nx(r), nx(nx(r))
-    q[len] = bk[(size_t)r1];                       // (a tip's other records are in bounds; what is read there is overwritten)
-    q[len + 1] = bk[(size_t)r2];
-    cp[i] = inner ? len : i;                       // (a tip points at itself: the selects below stay in bounds)
-    len += inner ? 2 : 0;
-  }
-  for (int i = len - 1; i >= 0; i--) {
-    const int r = q[i], c = cp[i];
-    const bool inner = r > tipmax;
-    const int c2 = inner ? c + 1 : c;
-    mn[i] = inner ? std::min(mn[c], mn[c2]) : r / 3;
-    sz[i] = inner ? 1 + sz[c] + sz[c2] : 1;
-  }
-  const bool narrow = n_ < 65535;
-  key.resize((size_t)len * (narrow ? sizeof(uint16_t) : sizeof(int32_t)));
-  uint16_t *k16 = reinterpret_cast<uint16_t *>(&key[0]);
-  int32_t *k32 = reinterpret_cast<int32_t *>(&key[0]);
-  off[0] = 0;
-  for (int i = 0; i < len; i++) {
-    const int r = q[i], c = cp[i], o = off[i];
-    const bool inner = r > tipmax;
-    if (narrow) k16[o] = inner ? (uint16_t)0 : (uint16_t)(r / 3);
-    else k32[o] = inner ? -1 : r / 3;
-    if (inner) {                                   // the subtree with the smaller tip first
-      const bool swap = mn[c] > mn[c + 1];
-      const int first = swap ? c + 1 : c, second = swap ? c : c + 1;
-      off[first] = o + 1;
-      off[second] = o + 1 + sz[first];
-    }
-  }
-}
-
 // "top cutoff_percent %" rule of the main loop (reference iqtree.cpp:1662-1676; treels_logl.size() > 1000)
 double Engine::ufboot_next_cutoff(int percent) const
 {
@@ -701,77 +652,6 @@ void Engine::ufb_drain_log()
   sc.lookups = sc.stored = 0;
   sc.t_lookup = 0;
   u.log.clear();
-}
-
-void Engine::ufb_drain(const std::vector<UfbState::LogEntry> &log, const std::vector<int32_t> &bk, int32_t epoch, const std::vector<ScanPlan> &plans,
-                       DrainScratch &sc)
-{
-  UfbState &u = *ufb_;
-  sc.q_plan = -1;
-  // q of the c-th insertion test of plan j on THIS topology (Engine::candidate_record on back_): both sides enumerated once per plan
-  auto record_of = [&](int j, const ScanPlan &pl, size_t c) -> int {
-    if (!pl.walked) return pl.cands[c].q;
-    if (sc.q_plan != j) {
-      sc.q_p.clear();
-      sc.q_q.clear();
-      if (pl.n_p > 0) enumerate_side(bk, pl.rec, 1, pl.maxtrav, sc.q_p);
-      if (pl.n_total > pl.n_p) enumerate_side(bk, bk[(size_t)pl.rec], pl.mintrav_q, pl.maxtrav, sc.q_q);
-      sc.q_plan = j;
-    }
-    return (int)c < pl.n_p ? sc.q_p[c] : sc.q_q[c - (size_t)pl.n_p];
-  };
-  auto topology_of = [&](const ScanPlan &pl, int ins, uint32_t cand, std::vector<int32_t> &out) {       // Engine::ufb_candidate_topology on bk
-    const int p = cand < (uint32_t)pl.n_p ? pl.rec : bk[(size_t)pl.rec];
-    out = bk;
-    auto hk = [&](int a, int b2) { out[(size_t)a] = b2; out[(size_t)b2] = a; };
-    const int a = out[(size_t)nx(p)], b2 = out[(size_t)nx(nx(p))];
-    hk(a, b2);
-    const int r = out[(size_t)ins];
-    hk(nx(p), ins);
-    hk(nx(nx(p)), r);
-  };
-  auto need_ref = [&](int64_t t) { if (u.refs.size() <= (size_t)t) u.refs.resize((size_t)t + 1 + u.refs.size() / 2, 0); };
-  int64_t raw = -1, resolved = -1;
-  for (const UfbState::LogEntry &le : log) {
-    const ScanPlan &pl = plans[(size_t)le.plan];
-    if (le.b == 0xFFFFFFFFu) {
-      // end of this prune node's scan: the topologies accepted during it that some sample still points to (ufb_flush_pending)
-      for (const UfbState::Pending &pe : sc.pending) {
-        if (u.refs[(size_t)pe.tree_index] <= 0 || u.store.count(pe.tree_index)) continue;
-        if (pe.cand == 0xFFFFFFFFu) u.store.emplace(pe.tree_index, bk);
-        else {
-          topology_of(pl, record_of(le.plan, pl, (size_t)pe.cand), pe.cand, sc.bk);
-          u.store.emplace(pe.tree_index, sc.bk);
-        }
-        sc.stored++;
-      }
-      sc.pending.clear();
-      continue;
-    }
-    if (le.tree != raw) {
-      raw = le.tree;
-      const double tl = now_ms();
-      const std::string *key = &sc.self_key;
-      if (le.cand == 0xFFFFFFFFu) {
-        if (sc.self_epoch != (int64_t)epoch) { canonical_topology(bk, sc.self_key, sc.canon); sc.self_epoch = (int64_t)epoch; }
-      } else {
-        topology_of(pl, record_of(le.plan, pl, (size_t)le.cand), le.cand, sc.bk);
-        canonical_topology(sc.bk, sc.key, sc.canon);
-        key = &sc.key;
-      }
-      resolved = u.topo_index.emplace(*key, raw).first->second;
-      sc.t_lookup += now_ms() - tl;
-      sc.lookups++;
-    }
-    need_ref(resolved);
-    if (sc.pending.empty() || sc.pending.back().tree_index != resolved) sc.pending.push_back(UfbState::Pending{resolved, le.cand});
-    int64_t &bt = u.boot_trees[le.b];
-    if (bt != resolved) {
-      if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
-      u.refs[(size_t)resolved]++;
-      bt = resolved;
-    }
-  }
 }
 
 // events into replay order: by scan output index, then by sample.  The current tree, booked once per prune-node visit, ties
@@ -1628,98 +1508,28 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   // the deferred log of every batch goes to a second host thread (option ufb_thread): it owns the tracker's deferred state
   // (topology map, boot_trees, reference counts, stored topologies) for the length of this climb and works on copies of the
   // topology and the plans, this thread never looks at that state before the worker has been joined
-  struct Job { std::vector<UfbState::LogEntry> log; std::vector<int32_t> back; int32_t epoch = 0; std::vector<ScanPlan> plans; };
-  struct Worker {
-    Engine *e = nullptr;
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<Job *> q;
-    std::vector<Job *> spare;
-    std::vector<std::unique_ptr<Job>> all;
-    size_t inflight = 0;
-    bool stop = false, started = false;
-    DrainScratch sc;
-    void run()
-    {
-      for (;;) {
-        Job *j = nullptr;
-        {
-          std::unique_lock<std::mutex> lk(m);
-          cv.wait(lk, [&] { return stop || !q.empty(); });
-          if (q.empty()) return;
-          j = q.front();
-          q.pop_front();
-        }
-        e->ufb_drain(j->log, j->back, j->epoch, j->plans, sc);
-        j->log.clear();
-        {
-          std::lock_guard<std::mutex> lk(m);
-          spare.push_back(j);
-          inflight--;
-        }
-        cv.notify_all();
-      }
-    }
-    Job *get()
-    {
-      std::unique_lock<std::mutex> lk(m);
-      cv.wait(lk, [&] { return inflight < 256; });
-      if (spare.empty()) { all.emplace_back(new Job()); return all.back().get(); }
-      Job *j = spare.back();
-      spare.pop_back();
-      return j;
-    }
-    bool submit(Job *j)                            // false: no second thread to be had -- the caller works the job off itself
-    {
-      if (!started) {
-        try { th = std::thread([this] { run(); }); } catch (...) { return false; }
-        started = true;
-        // keep the worker on the cores that share this thread's last-level cache (best effort): the log, the plans and the
-        // topology copies change hands every batch, and on a two-socket host a worker on the other socket made the replay --
-        // which then writes into lines the worker owns -- 2.4 times slower than it is alone
-        const int cpu = sched_getcpu();
-        if (cpu >= 0) {
-          char path[128];
-          std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-          if (FILE *fp = std::fopen(path, "r")) {
-            char buf[256] = {0};
-            if (std::fgets(buf, sizeof buf, fp)) {
-              cpu_set_t set;
-              CPU_ZERO(&set);
-              int n_set = 0;
-              for (char *p = buf; *p && *p != '\n';) {
-                char *end = nullptr;
-                const long a = std::strtol(p, &end, 10);
-                if (end == p) break;
-                long b = a;
-                p = end;
-                if (*p == '-') { b = std::strtol(p + 1, &end, 10); p = end; }
-                for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c != cpu) { CPU_SET((int)c, &set); n_set++; }
-                if (*p == ',') p++;
-              }
-              if (n_set > 0) (void)pthread_setaffinity_np(th.native_handle(), sizeof set, &set);
-            }
-            std::fclose(fp);
-          }
-        }
-      }
-      { std::lock_guard<std::mutex> lk(m); q.push_back(j); inflight++; }
-      cv.notify_all();
-      return true;
-    }
-    void finish()
-    {
-      if (!started) return;
-      { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return inflight == 0; }); stop = true; }
-      cv.notify_all();
-      if (th.joinable()) th.join();
-      started = false;
-    }
-    ~Worker() { finish(); }
-  } worker;
-  worker.e = this;
+  using Worker = books::LogWorker<ScanPlan>;     // (host/ufb_books.hpp: the same code tests/cpu/ufb_books_test.cpp runs under the thread sanitizer)
+  using Job = Worker::Job;
+  Worker worker;
+  worker.n_taxa = n_;
+  worker.d = &u;
   const bool use_worker = ufb_thread_ != 0;
+  // MPF_UFB_RECORD=<path>: what this climb hands its worker goes to a file as well (appended: one climb after the other), with
+  // the deferred state in front of and behind it -- the stream tests/cpu/ufb_books_test.cpp replays without a GPU
+  struct Recording {
+    std::FILE *f = nullptr;
+    ~Recording() { if (f) std::fclose(f); }
+  } recording;
+  if (const char *path = use_worker ? std::getenv("MPF_UFB_RECORD") : nullptr) {
+    std::FILE *probe = std::fopen(path, "rb");
+    const bool fresh = probe == nullptr;
+    if (probe) std::fclose(probe);
+    recording.f = std::fopen(path, "ab");
+    if (recording.f) {
+      if (fresh) { books::rec::put(recording.f, "UFBREC3", 8); books::rec::put1<int32_t>(recording.f, n_); }
+      books::rec::write_state(recording.f, 'D', u, u.treels.size());
+    }
+  }
   // any return but the last one leaves launches in flight and a batch half consumed: wait for the device, forget what the
   // engine believes about the views and the pending scan, so that the next call starts from the topology alone
   struct Abort {
@@ -2157,6 +1967,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
         if (moved) { jb->back.swap(snap_back); jb->epoch = snap_epoch; }
         else { jb->back = back_; jb->epoch = topo_epoch_; }
         jb->plans = B.plans;
+        if (recording.f) books::rec::write_job<ScanPlan>(recording.f, jb->log, jb->back, jb->epoch, jb->plans);
         if (!worker.submit(jb)) {
           ufb_drain(jb->log, jb->back, jb->epoch, jb->plans, worker.sc);
           jb->log.clear();
@@ -2185,6 +1996,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
   u.lookups += worker.sc.lookups; u.stored += worker.sc.stored; u.t_lookup += worker.sc.t_lookup;
   u.draws += n_draws;
   if (u.refs.size() < u.treels.size()) u.refs.resize(u.treels.size(), 0);
+  if (recording.f) books::rec::write_state(recording.f, 'E', u, u.treels.size());
   climb_finished(total);
   if (u.exchange) {
     // closing handshake: a rank that took another path would be in the middle of a batch here
