@@ -6,36 +6,11 @@
 // the same stream as the SPR tie-breaks).  Here the arithmetic runs on the device for a whole batch of scans
 // (ufboot.hip) and the host replays only the order-dependent part: the candidates in scan order, and for each of
 // them the few (sample) events where its score reaches that sample's running best.
-#include <algorithm>
-#include <climits>
-#include <cmath>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <condition_variable>
-#include <deque>
-#include <memory>
-#include <mutex>
-#include <thread>
-#include <pthread.h>
-#include <sched.h>
 
-#include "../csrc/engine.hpp"
-#include "lcg_block.hpp"
-#include "simd_util.hpp"
+
+#include "ufboot_common.hpp"
 
 namespace mpf {
-
-#define UCHK(expr)                                                                                   \
-  do {                                                                                               \
-    hipError_t e__ = (expr);                                                                         \
-    if (e__ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e__)); return MPF_E_HIP; } \
-  } while (0)
-
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-static bool ufb_trace_env() { static const bool on = std::getenv("MPF_UFB_TRACE") != nullptr; return on; }
-static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int Engine::ufboot_attach(int n_samples, const uint16_t *samples, double epsilon, int n_local, const int32_t *sample_ids,
                           mpf_ufb_exchange_fn exchange, void *exchange_arg)
@@ -288,67 +263,6 @@ bool Engine::ufb_topboot_offer(uint32_t b, int32_t rell, int64_t tree_index, boo
   else if (!(thr < rell)) thr = rell;                                      // :3570
   u.refs[(size_t)tree_index]++;
   return true;
-}
-
-// the -distinct_iter_top_boot block of saveCurrentTree for one (tree, sample); tree_index / looked_up: the call's tree string
-// state (resolved through `lookup` at the first acceptance); true if some list or boot_trees entry now names tree_index
-template <class Lookup>
-bool Engine::ufb_distinct_offer(uint32_t b, int32_t rell, int64_t &tree_index, bool &looked_up, Lookup lookup)
-{
-  UfbState &u = *ufb_;
-  auto &top = u.top[b];
-  auto &its = u.top_iter[b];
-  int32_t &thr = u.top_thr[b];
-  const int k = u.distinct;
-  if (rell >= thr) u.boot_counts[b]++;                                      // :3589-3591
-  bool take = rell > thr;
-  if (!take && rell == thr) {                                               // :3593-3595, the draw only on a tie
-    u.draws++;
-    take = tie_draw() <= (double)k * 1.0 / (double)u.boot_counts[b];
-  }
-  if (!take) return false;
-  uint32_t &bs = u.boot_score[b];
-  const uint32_t len = (uint32_t)(-(int64_t)rell);
-  if (len < bs) u.boot_counts[b] = 1;                                       // :3598-3600
-  if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                                          // :3617-3619
-  if (!looked_up) { tree_index = lookup(tree_index); looked_up = true; }
-  bool named = false;
-  auto ref = [&](int64_t t) { u.refs[(size_t)t]++; named = true; };
-  auto unref = [&](int64_t t) { if (--u.refs[(size_t)t] == 0) u.store.erase(t); };
-  int64_t &bt = u.boot_trees[b];
-  if (bt != tree_index) {                                                   // :3620
-    ref(tree_index);
-    if (bt >= 0) unref(bt);
-    bt = tree_index;
-  }
-  if (len < bs) bs = len;                                                   // :3621 max()
-  const int t = std::min(k, (int)its.size());
-  for (int c = 0; c < t; c++) if (top[(size_t)c].first == tree_index) return named;      // :3627-3634 tree exists
-  int c = 0;
-  for (; c < t; c++)
-    if (its[(size_t)c] == u.cur_it) {                                       // :3637-3645 this iteration's representative
-      if (rell > top[(size_t)c].second) {
-        ref(tree_index);
-        unref(top[(size_t)c].first);
-        top[(size_t)c] = std::make_pair(tree_index, rell);
-      }
-      break;
-    }
-  if (c == t && t < k) {                                                    // :3648-3651
-    its.push_back(u.cur_it);
-    top.push_back(std::make_pair(tree_index, rell));
-    ref(tree_index);
-  } else if (c == t && t == k) {                                            // :3654-3667 replace the worst
-    int worst = 0;
-    for (int d = 1; d < t; d++) if (top[(size_t)d].second < top[(size_t)worst].second) worst = d;
-    ref(tree_index);
-    unref(top[(size_t)worst].first);
-    top[(size_t)worst] = std::make_pair(tree_index, rell);
-    its[(size_t)worst] = u.cur_it;
-  }
-  thr = top[0].second;                                                      // :3670-3675
-  for (size_t d = 1; d < top.size(); d++) thr = std::min(thr, top[d].second);
-  return named;
 }
 
 int Engine::ufboot_sample_trees(int sample, int64_t *out, int cap, int *n) const
@@ -652,29 +566,6 @@ void Engine::ufb_drain_log()
   sc.lookups = sc.stored = 0;
   sc.t_lookup = 0;
   u.log.clear();
-}
-
-// events into replay order: by scan output index, then by sample.  The current tree, booked once per prune-node visit, ties
-// with every sample it is the best tree of -- millions of events per sweep -- so large batches take two stable counting
-// passes (sample, then index) instead of a comparison sort.
-static void sort_events(std::vector<UfbEvent> &ev, std::vector<UfbEvent> &tmp, std::vector<uint32_t> &count, uint32_t n_idx, uint32_t n_samples)
-{
-  const size_t n = ev.size();
-  if (n < 512) {
-    std::sort(ev.begin(), ev.end(), [](const UfbEvent &x, const UfbEvent &y) { return x.idx != y.idx ? x.idx < y.idx : x.b < y.b; });
-    return;
-  }
-  tmp.resize(n);
-  auto pass = [&](const std::vector<UfbEvent> &src, std::vector<UfbEvent> &dst, uint32_t nkeys, bool by_idx) {
-    count.assign((size_t)nkeys + 1, 0u);
-    for (const UfbEvent &e : src) count[(size_t)(by_idx ? e.idx : e.b) + 1]++;
-    for (size_t k = 1; k <= nkeys; k++) count[k] += count[k - 1];
-    for (const UfbEvent &e : src) dst[count[by_idx ? e.idx : e.b]++] = e;
-  };
-  uint32_t max_idx = 0;
-  for (const UfbEvent &e : ev) max_idx = std::max(max_idx, e.idx);     // (a sharded run's merged events: other ranks' indices too)
-  pass(ev, tmp, n_samples, false);
-  pass(tmp, ev, std::max(n_idx, max_idx + 1u), true);
 }
 
 // pllOptimizeSprParsimony's sweep loop (reference sprparsimony.cpp:3295-3316) with perSiteScores = 1, i.e. with
@@ -1448,1244 +1339,6 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
   }
   if (final_score) *final_score = randomMP;
   abort_guard.ok = true;
-  return MPF_OK;
-}
-
-// ---- the tracker's climb as a two-stage pipeline ----------------------------------------------------------------
-// Default update rule, no cut-off in force (the first climb of a run -- where the time goes).
-// The bookkeeping needs the product and the event extraction of a batch; the SEARCH mostly does not: whenever the costs alone
-// settle what the sweep does next -- every prune node of the batch strictly worse than the current tree, or the first one that
-// is better has ONE cheapest candidate (draws among dearer ties are overridden by it, sprparsimony.cpp:2168-2176, and a strictly
-// better tree is accepted without a draw, :3306-3311) -- the move is applied and the next batch planned and launched as soon as
-// the scan's results are on the host, while the device still multiplies and extracts the batch in front.  The replay of that
-// batch (all draws in the reference's order, one stream) then runs beside the next batch's device work and must arrive at the
-// very decision taken early (checked).  Where a draw decides (ties with the current tree, two cheapest candidates) the batch is
-// taken as before: replay first, then move.
-int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
-{
-  UfbState &u = *ufb_;
-  uint32_t startMP;
-  unsigned iter_hits = 1;
-  const int total = 2 * n_ - 2;
-  struct Batch {
-    int i = 0, hi = 0, np = 0, par = 0;
-    std::vector<ScanPlan> plans;
-    uint32_t n_idx = 0, n_parts = 0, n_self = 0, n_eager = 0;
-    bool device = false;                           // false: nothing to scan (no insertion test in the whole batch)
-    bool early_bounds = false;                     // launched before the replay of the batch in front
-    std::vector<uint32_t> out;                     // the scan's costs and info, taken off the shared pinned buffers
-    std::vector<uint2> info;
-  } ring[3];
-  struct Decision { bool certain = false, moved = false; int j = 0; long sel = -1; uint32_t score = 0, sel_idx = 0, sel_home = 0; int ins = -1, rem = -1; };
-  int cur = 0;
-  bool prelaunched = false;
-  bool moved_once = false;
-  int pipe_ahead = 0;
-  if (u.exchange) {
-    // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy state
-    gap_est_ = -1.0;
-    since_move_ = 0;
-  }
-  const bool host_self = !u.exchange;              // (sample-sharded: R_T lives in pieces on the ranks, the events are exchanged anyway)
-  uint32_t exchange_tag = 0;
-  int batch = first_batch();
-  std::vector<UfbEvent> events, ev_tmp;
-  std::vector<uint32_t> ev_count;
-  std::vector<int32_t> snap_back;
-  int32_t snap_epoch = 0;
-  if (!u.rt_valid) { int rc = ufb_current_tree_reps(); if (rc) return rc; }
-  for (int k = 0; k < 2; k++) {
-    UCHK(u.p_flag_s[k].reserve(4));
-    UCHK(u.p_flag_e[k].reserve(4));
-    UCHK(u.p_rt[k].reserve((size_t)u.Bp));
-  }
-  // every event a batch can produce while the next one may already be in flight fits the device buffer AND the pinned one the
-  // extraction kernel writes as it emits (a copy of "the rest" would queue up behind the next batch, which reuses the device buffer)
-  if (u.ev.cap < (size_t)ufb_event_cap_) UCHK(u.ev.reserve((size_t)ufb_event_cap_));
-  for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
-  uint32_t *d_evcount = d_done_.p + 48, *d_fin = d_done_.p + 32, *d_cut = d_done_.p + 56;
-  bool log_open = false;
-  // the deferred log of every batch goes to a second host thread (option ufb_thread): it owns the tracker's deferred state
-  // (topology map, boot_trees, reference counts, stored topologies) for the length of this climb and works on copies of the
-  // topology and the plans, this thread never looks at that state before the worker has been joined
-  using Worker = books::LogWorker<ScanPlan>;     // (host/ufb_books.hpp: the same code tests/cpu/ufb_books_test.cpp runs under the thread sanitizer)
-  using Job = Worker::Job;
-  Worker worker;
-  worker.n_taxa = n_;
-  worker.d = &u;
-  const bool use_worker = ufb_thread_ != 0;
-  // MPF_UFB_RECORD=<path>: what this climb hands its worker goes to a file as well (appended: one climb after the other), with
-  // the deferred state in front of and behind it -- the stream tests/cpu/ufb_books_test.cpp replays without a GPU
-  struct Recording {
-    std::FILE *f = nullptr;
-    ~Recording() { if (f) std::fclose(f); }
-  } recording;
-  if (const char *path = use_worker ? std::getenv("MPF_UFB_RECORD") : nullptr) {
-    std::FILE *probe = std::fopen(path, "rb");
-    const bool fresh = probe == nullptr;
-    if (probe) std::fclose(probe);
-    recording.f = std::fopen(path, "ab");
-    if (recording.f) {
-      if (fresh) { books::rec::put(recording.f, "UFBREC3", 8); books::rec::put1<int32_t>(recording.f, n_); }
-      books::rec::write_state(recording.f, 'D', u, u.treels.size());
-    }
-  }
-  // any return but the last one leaves launches in flight and a batch half consumed: wait for the device, forget what the
-  // engine believes about the views and the pending scan, so that the next call starts from the topology alone
-  struct Abort {
-    Engine *e;
-    Worker *w;
-    bool ok = false;
-    ~Abort()
-    {
-      if (ok) return;
-      (void)hipStreamSynchronize(e->st_);
-      e->walk_async_ = false;
-      e->n_walk_ = 0;
-      e->walk_out_ = 0;
-      e->cnt_copy_pending_ = false;
-      e->pending_scores_ = false;
-      e->invalidate_all();
-      // (the log worker booked trees without growing the reference counts: they follow treels on EVERY way out, or a later
-      //  climb on the other paths -- which push both in lockstep -- would index past their end)
-      w->finish();
-      if (e->ufb_) {
-        UfbState &u = *e->ufb_;
-        u.log.clear();
-        u.rt_valid = false;
-        u.lookups += w->sc.lookups; u.stored += w->sc.stored; u.t_lookup += w->sc.t_lookup;
-        w->sc.lookups = w->sc.stored = 0;
-        w->sc.t_lookup = 0;
-        if (u.refs.size() < u.treels.size()) u.refs.resize(u.treels.size(), 0);
-      }
-    }
-  } abort_guard{this, &worker};
-  uint64_t n_draws = 0;                            // (added to the tracker's counter at the end: its word shares a cache line with the worker's)
-
-  // plan + enqueue the whole chain of the batch [i, i + b): refresh, masked scan, mid (C <- 0, self slots, scan results to the host),
-  // product, extraction (events and R_T to the host)
-  // (clamp: the current tree has been offered to every sample -- true once a move of this climb has been accepted --, so the
-  //  extraction may start every sample's bound at R_T when the bounds it was given are one replay old)
-  auto launch = [&](Batch &B, int i, int b, bool early, bool clamp) -> int {
-    const double t0 = now_ms();
-    B.i = i;
-    B.hi = std::min(total, i + b - 1);
-    if (max_visits_ > 0) B.hi = std::max(i, (int)std::min<int64_t>(B.hi, (int64_t)i + (max_visits_ - visits_done_ - (early ? pipe_ahead : 0)) - 1));
-    B.np = B.hi - i + 1;
-    B.early_bounds = early;
-    const uint32_t *out_unused = nullptr;
-    scan_masks_ = true;
-    ufb_async_ = true;
-    int rc = scan_batch(B.plans, nodep_.data() + i, B.np, mintrav, maxtrav, &out_unused);
-    scan_masks_ = false;
-    ufb_async_ = false;
-    if (rc) return rc;
-    B.device = walk_async_;
-    u.batches++;
-    if (!B.device) {                               // run_walks has finished the (empty) scan itself
-      B.n_idx = B.n_parts = 0;
-      B.out.clear();
-      B.info.clear();
-      UCHK(hipMemcpyAsync(u.p_rt[B.par].p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
-      UCHK(hipStreamSynchronize(st_));
-      u.t_scan += now_ms() - t0;
-      return MPF_OK;
-    }
-    if (!u.st_valid) { int rc2 = ufb_stage_small(B.plans, B.np); if (rc2) return rc2; }
-    B.n_idx = u.st_n_idx; B.n_parts = u.st_n_parts; B.n_self = u.st_n_self;
-    if (B.n_idx != (uint32_t)walk_async_nout_) { set_error("online UFBoot: staged block out of step with the scan"); return MPF_E_STATE; }
-    const int rows_p = round_up((int)std::max<uint32_t>(B.n_idx, 1u), ufb_row_padding((int)B.n_idx, u.Bp));
-    UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
-    const uint32_t nch = ufb_chunks(B.n_idx);
-    UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
-    UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
-    const uint32_t *dsm = u.st_dev;
-    if (!dsm) {
-      UCHK(u.thr.reserve((size_t)u.st_words + 4));
-      UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, (size_t)u.st_words * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
-      dsm = u.thr.p;
-    }
-    const uint32_t *d_thr = dsm, *d_home = dsm + B.n_parts, *d_pend = dsm + 2 * B.n_parts, *d_best = dsm + 3 * B.n_parts, *d_self = dsm + u.st_o_self;
-    const bool small_batch = B.n_idx <= kUfbEvents2Max;   // (the chunked kernels of a larger batch do not take the cut)
-    UCHK(u.h_info.reserve(walk_async_nout_));
-    UfbPublishArgs ps;                             // the scan's results
-    if (cnt_copy_pending_) { ps.src[0] = d_cnt(); ps.dst[0] = h_cnt(); ps.words[0] = (uint32_t)(out_off() + walk_async_nout_); }
-    else { ps.src[0] = d_out(); ps.dst[0] = h_out(); ps.words[0] = (uint32_t)walk_async_nout_; }
-    cnt_copy_pending_ = false;
-    ps.src[1] = reinterpret_cast<const uint32_t *>(u.info.p);
-    ps.dst[1] = reinterpret_cast<uint32_t *>(u.h_info.p);
-    ps.words[1] = (uint32_t)(2 * walk_async_nout_);
-    ps.h_flag = u.p_flag_s[B.par].p;
-    ps.done = d_fin;
-    __atomic_store_n(u.p_flag_s[B.par].p + 1, 0u, __ATOMIC_RELAXED);
-    UCHK(launch_ufb_mid(st_, u.C.p, (size_t)rows_p * (size_t)u.Bp, u.info.p, d_self, B.n_self, host_self ? 0xFFFFFFFFu : 0xFFFFFFFEu, d_evcount, ps,
-                        d_out(), d_home, d_pend, B.n_idx, d_cut));
-    for (int pl = 0; pl < u.planes; pl++)
-      UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), 1, nullptr, small_batch ? d_cut : nullptr));
-    u.gemm_rows += (uint64_t)rows_p;
-    B.n_eager = (uint32_t)std::min<size_t>(u.p_ev[B.par].cap, 0xFFFFFFFFu);
-    UfbPublishArgs pe;                             // the bookkeeping's inputs
-    pe.src[0] = reinterpret_cast<const uint32_t *>(u.rt.p);
-    pe.dst[0] = reinterpret_cast<uint32_t *>(u.p_rt[B.par].p);
-    pe.words[0] = (uint32_t)u.Bl;
-    pe.h_ev = u.p_ev[B.par].p;
-    pe.h_ev_cap = B.n_eager;
-    pe.h_flag = u.p_flag_e[B.par].p;
-    pe.done = d_fin;
-    __atomic_store_n(u.p_flag_e[B.par].p + 1, 0u, __ATOMIC_RELAXED);
-    UCHK(launch_ufb_events_publish(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, B.n_idx, u.cmin.p, u.pre.p,
-                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0, pe, (early && clamp) ? 1 : 0, small_batch ? d_cut : nullptr));
-    u.t_scan += now_ms() - t0;
-    return MPF_OK;
-  };
-  auto wait_flag = [&](const uint32_t *flag) -> int {
-    if (!wait_host_flag(flag)) {
-      UCHK(hipStreamSynchronize(st_));
-      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != 1u) { set_error("online UFBoot: a batch's results were not published"); return MPF_E_STATE; }
-    }
-    return MPF_OK;
-  };
-  // what the sweep does with this batch as far as the costs alone say it (no draw taken, no state touched)
-  auto decide = [&](const Batch &B) -> Decision {
-    Decision d;
-    uint32_t best = best_;
-    for (int j = 0; j < B.np; j++) {
-      const ScanPlan &pl = B.plans[(size_t)j];
-      uint32_t m = UINT32_MAX, m_cnt = 0, m_idx = 0, m_home = 0;
-      long m_c = -1, c = 0;
-      for (int pi = 0; pi < pl.n_parts; pi++) {
-        const uint32_t home = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
-        for (int k = 0; k < pl.part_cnt[pi]; k++, c++) {
-          const uint32_t idx = pl.part_off[pi] + (uint32_t)k, mp = pl.base + B.out[idx];
-          if (mp < m) { m = mp; m_cnt = 1; m_c = c; m_idx = idx; m_home = home; }
-          else if (mp == m) m_cnt++;
-        }
-      }
-      if (m_c < 0 || m > best) {                   // nothing reaches the best length: no candidate is selected, whatever is drawn
-        if (best > randomMP) return d;             // (never: the best length is at most the current tree's)
-        continue;
-      }
-      if (m == best) {
-        if (tie_mode_ == MPF_TIE_RANDOM) return d; // a draw picks among the ties, another accepts the move or not
-        if (best < randomMP) return d;             // (never, see above)
-        continue;                                  // first-best rule: an equally long tree is not a candidate
-      }
-      if (!(m < randomMP)) return d;
-      if (tie_mode_ == MPF_TIE_RANDOM && m_cnt > 1) return d;    // which of the cheapest candidates: a draw
-      d.certain = d.moved = true;                  // (first-best rule: m_c is the first of the cheapest, as the rule takes it)
-      d.j = j; d.sel = m_c; d.score = m; d.sel_idx = m_idx; d.sel_home = m_home;
-      return d;
-    }
-    d.certain = true;
-    d.moved = false;
-    d.j = B.np;
-    return d;
-  };
-
-  do {
-    startMP = randomMP;
-    node_rectifier();
-    int i = 1;
-    bool sw_moved = false;                         // (UfbState::quiet_topo: a complete sweep of one topology without a candidate event)
-    uint64_t sw_events = 0;
-    while (i <= total && !visits_out()) {
-      Batch &B = ring[cur];
-      if (!prelaunched) { B.par = cur & 1; int rc = launch(B, i, batch, false, false); if (rc) return rc; }
-      prelaunched = false;
-      double t0 = now_ms();
-      const uint32_t *out = nullptr;
-      if (B.device) {
-        { int rc = wait_flag(u.p_flag_s[B.par].p + 1); if (rc) return rc; }
-        { int rc = run_walks_finish(B.plans, &out); if (rc) return rc; }
-        B.out.assign(out, out + B.n_idx);
-        B.info.assign(u.h_info.p, u.h_info.p + B.n_idx);
-      }
-      out = B.out.data();
-      const uint2 *hinfo = B.info.data();
-      // ---- the search's decision from the costs, and the next batch on its way
-      Decision d = decide(B);
-      int next_i = i, next_batch_size = batch;
-      const bool overflow_safe = (uint64_t)B.n_idx * (uint64_t)u.Bl <= (uint64_t)u.ev.cap;     // (no second extraction after C has been reused)
-      bool early = ufb_pipe_ && d.certain && overflow_safe;
-      ufb_stat_batches_++;
-      if (early) {
-        ufb_stat_early_++;
-        if (d.moved) {
-          const ScanPlan &pl = B.plans[(size_t)d.j];
-          d.ins = candidate_record(pl, (size_t)d.sel);
-          d.rem = d.sel < pl.n_p ? pl.rec : back_[pl.rec];
-          if (B.device) UCHK(launch_rt_update(st_, u.rt.p, u.C.p, u.Bp, hinfo[d.sel_idx].x, d.sel_home));
-          snap_back = back_;
-          snap_epoch = topo_epoch_;
-          moves_.push_back(Move{d.rem, d.ins, d.score});
-          apply_move(d.rem, d.ins);
-          next_i = i + d.j + 1;
-          next_batch_size = next_batch(batch, true, d.j + 1, total);
-        } else {
-          next_i = B.hi + 1;
-          next_batch_size = next_batch(batch, false, B.np, total);
-        }
-        pipe_ahead = next_i - i;                   // (visits of this batch that count before the look-ahead batch starts)
-        if (next_i <= total && !(max_visits_ > 0 && visits_done_ + pipe_ahead >= max_visits_)) {
-          const int nxt = (cur + 1) % 3;
-          ring[nxt].par = B.par ^ 1;
-          int rc = launch(ring[nxt], next_i, next_batch_size, true, moved_once || d.moved);
-          if (rc) return rc;
-          prelaunched = true;
-        }
-      }
-      u.t_prep += now_ms() - t0;
-      // ---- the bookkeeping of this batch: the log of the one before (beside the device), then events -> order -> replay
-      { const double td = now_ms(); ufb_drain_log(); u.t_defer += now_ms() - td; }
-      t0 = now_ms();
-      uint32_t n_ev = 0;
-      if (B.device) {
-        { int rc = wait_flag(u.p_flag_e[B.par].p + 1); if (rc) return rc; }
-        n_ev = u.p_flag_e[B.par].p[0];
-        if (n_ev > u.ev.cap) {
-          if (prelaunched) { set_error("online UFBoot: event buffer overflow behind a batch launched early"); return MPF_E_STATE; }
-          const uint32_t *dsm = u.st_dev ? u.st_dev : u.thr.p;
-          // (the first extraction ran under the device's cut -- rows behind the batch's certain end were not multiplied --, this one
-          //  does not and may find more: extract until the count it reports fits the buffer it wrote to)
-          for (;;) {
-            UCHK(u.ev.reserve((size_t)n_ev));
-            UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
-            UCHK(launch_ufb_events(st_, u.info.p, d_out(), dsm, dsm + B.n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, dsm + 3 * B.n_parts, B.n_idx, u.cmin.p, u.pre.p,
-                                   u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));      // (staging: thr | home | prune-node ends | best)
-            UCHK(u.h_col.reserve(4));
-            UCHK(hipMemcpyAsync(u.h_col.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-            // (nothing else is in flight: both pinned buffers follow the device buffer, which the overflow rule is stated in)
-            UCHK(hipStreamSynchronize(st_));
-            n_ev = (uint32_t)u.h_col.p[0];
-            if (n_ev <= u.ev.cap) break;
-          }
-          B.n_eager = 0;
-          for (int k = 0; k < 2; k++) UCHK(u.p_ev[k].reserve(u.ev.cap));
-        }
-        if (n_ev > B.n_eager) {
-          if (prelaunched) { set_error("online UFBoot: events beyond the pinned buffer behind a batch launched early"); return MPF_E_STATE; }
-          if (u.p_ev[B.par].cap < (size_t)n_ev) B.n_eager = 0;
-          UCHK(u.p_ev[B.par].reserve((size_t)n_ev));
-          UCHK(hipMemcpyAsync(u.p_ev[B.par].p + B.n_eager, u.ev.p + B.n_eager, (size_t)(n_ev - B.n_eager) * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
-          UCHK(hipStreamSynchronize(st_));
-        }
-      }
-      double t1 = now_ms();
-      u.t_dev += t1 - t0;
-      // what lies behind the batch's certain end is never replayed: dropped before the sort
-      uint32_t idx_cut = B.n_idx;
-      {
-        int js = B.np - 1;
-        for (int j = 0; j < B.np; j++) {
-          const ScanPlan &pl = B.plans[(size_t)j];
-          uint32_t m = UINT32_MAX;
-          for (int pi = 0; pi < pl.n_parts; pi++)
-            for (int k = 0; k < pl.part_cnt[pi]; k++) m = std::min(m, out[pl.part_off[pi] + (uint32_t)k]);
-          if (m != UINT32_MAX && pl.base + m < randomMP) { js = j; break; }
-        }
-        if (js < B.np - 1) {
-          idx_cut = 0;
-          for (int j = 0; j <= js; j++) {
-            const ScanPlan &pl = B.plans[(size_t)j];
-            if (pl.self_idx >= 0) idx_cut = std::max(idx_cut, (uint32_t)pl.self_idx + 1u);
-            for (int pi = 0; pi < pl.n_parts; pi++) idx_cut = std::max(idx_cut, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
-          }
-        }
-      }
-      if (B.device && u.p_flag_s[B.par].p[2] != idx_cut) { set_error("online UFBoot: the device's end of the batch differs from the host's"); return MPF_E_STATE; }
-      {
-        const UfbEvent *src = u.p_ev[B.par].p;
-        if (u.exchange) {
-          // every rank replays the events of all ranks (one all-gather per batch; the cut is the same everywhere: same costs)
-          events.clear();
-          for (uint32_t k = 0; k < n_ev; k++) {
-            UfbEvent e = src[k];
-            if (e.idx >= idx_cut) continue;
-            e.b = (uint32_t)u.ids[(size_t)e.b];
-            events.push_back(e);
-          }
-          if (!B.device)                             // nothing was scanned: the current tree's own bookings, from R_T on the host
-            for (int jj = 0; jj < B.np; jj++)
-              if (B.plans[(size_t)jj].self_idx >= 0)
-                for (int c2 = 0; c2 < u.Bl; c2++)
-                  if ((uint32_t)u.p_rt[B.par].p[c2] <= u.boot_score[(size_t)u.ids[(size_t)c2]])
-                    events.push_back(UfbEvent{(uint32_t)B.plans[(size_t)jj].self_idx, (uint32_t)u.ids[(size_t)c2], (uint32_t)u.p_rt[B.par].p[c2]});
-          n_ev = (uint32_t)events.size();
-          const mpf_ufb_event *all = nullptr;
-          uint32_t n_all_ev = 0;
-          if (u.exchange(u.exchange_arg, exchange_tag++, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
-            set_error("online UFBoot: event exchange failed (ranks out of step?)");
-            return MPF_E_STATE;
-          }
-          const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
-          events.assign(pa, pa + n_all_ev);
-          uint32_t n_keys = B.n_idx;
-          for (int jj = 0; jj < B.np; jj++) n_keys = std::max(n_keys, (uint32_t)(B.plans[(size_t)jj].self_idx + 1));
-          sort_events(events, ev_tmp, ev_count, n_keys, (uint32_t)u.B);
-        } else if (n_ev >= 512) {
-          ev_count.assign((size_t)u.B + 1, 0u);
-          uint32_t kept = 0;
-          for (uint32_t k = 0; k < n_ev; k++)
-            if (src[k].idx < idx_cut) { ev_count[(size_t)u.ids[(size_t)src[k].b] + 1]++; kept++; }
-          events.resize(kept);
-          ev_tmp.resize(kept);
-          for (size_t k = 1; k <= (size_t)u.B; k++) ev_count[k] += ev_count[k - 1];
-          for (uint32_t k = 0; k < n_ev; k++) {
-            UfbEvent e = src[k];
-            if (e.idx >= idx_cut) continue;
-            e.b = (uint32_t)u.ids[(size_t)e.b];
-            ev_tmp[ev_count[e.b]++] = e;
-          }
-          ev_count.assign((size_t)B.n_idx + 1, 0u);
-          for (const UfbEvent &e : ev_tmp) ev_count[(size_t)e.idx + 1]++;
-          for (size_t k = 1; k <= (size_t)B.n_idx; k++) ev_count[k] += ev_count[k - 1];
-          for (const UfbEvent &e : ev_tmp) events[ev_count[e.idx]++] = e;
-          n_ev = kept;
-        } else {
-          events.clear();
-          for (uint32_t k = 0; k < n_ev; k++) {
-            UfbEvent e = src[k];
-            if (e.idx >= idx_cut) continue;
-            e.b = (uint32_t)u.ids[(size_t)e.b];
-            events.push_back(e);
-          }
-          n_ev = (uint32_t)events.size();
-          sort_events(events, ev_tmp, ev_count, B.n_idx, (uint32_t)u.B);
-        }
-        u.events += n_ev;
-      }
-      t0 = now_ms();
-      u.t_sort += t0 - t1;
-      // ---- replay in the reference's order (Engine::spr_sweeps_ufboot's, reduced to the default rule without a cut-off)
-      const int32_t *h_rt = u.p_rt[B.par].p;
-      size_t ep = 0;
-      bool moved = false;
-      int j = i;
-      for (; j <= B.hi && !moved; j++) {
-        const ScanPlan &pl = B.plans[(size_t)(j - i)];
-        const int32_t cur_plan = (int32_t)(j - i);
-        if (tie_mode_ == MPF_TIE_RANDOM) {
-          insert_rec_ = remove_rec_ = -1;
-          hits_ = 1;
-        }
-        long sel = -1;
-        uint32_t sel_idx = 0, sel_home = 0;
-        size_t c = 0;
-        auto one_event = [&](const uint32_t b, const uint32_t s, const int64_t tree_index, const uint32_t cand_code) {
-          uint32_t &bs = u.boot_score[b];
-          bool accept = false;
-          if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (iqtree.cpp:3686)
-          else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
-            n_draws++;
-            accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
-          }
-          if (accept) {
-            u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
-            log_open = true;
-            if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                          // :3716-3718
-            if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
-          }
-          if (s == bs) u.boot_counts[b]++;                              // :3728-3730
-        };
-        auto book = [&](uint32_t len) -> int64_t {                      // iqtree.cpp:3343-3348 without a cut-off
-          u.treels.push_back(len);
-          if (!use_worker) u.refs.push_back(0);                         // (the worker sizes the reference counts itself)
-          return (int64_t)u.treels.size() - 1;
-        };
-        if (pl.self_idx >= 0) {
-          // the current tree, once per prune node and before its insertion tests (sprparsimony.cpp:2285-2289)
-          u.cur_logl_now = -(int32_t)randomMP;
-          const int64_t tree_index = book(randomMP);
-          if (host_self) {
-            ufb_self_default(h_rt, tree_index, cur_plan, log_open, n_draws);
-          } else {
-            const uint32_t idx = (uint32_t)pl.self_idx;
-            while (ep < events.size() && events[ep].idx < idx) ep++;
-            for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, 0xFFFFFFFFu);
-          }
-        }
-        for (int pi = 0; pi < pl.n_parts; pi++) {
-          const uint32_t home = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
-          for (int k = 0; k < pl.part_cnt[pi]; k++, c++) {
-            const uint32_t idx = pl.part_off[pi] + (uint32_t)k;
-            const uint32_t mp = pl.base + out[idx];
-            u.cur_logl_now = -(int32_t)mp;
-            const int64_t tree_index = book(mp);                        // saveCurrentTree(-mp), sprparsimony.cpp:2163-2166
-            while (ep < events.size() && events[ep].idx < idx) ep++;
-            for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, (uint32_t)c);
-            if (tie_mode_ == MPF_TIE_RANDOM) {                          // testInsertParsimony's tie rule (:2168-2176)
-              if (mp < best_) hits_ = 1;
-              else if (mp == best_) hits_++;
-              if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; sel = (long)c; sel_idx = idx; sel_home = home; }
-            } else if (mp < best_) {
-              best_ = mp; sel = (long)c; sel_idx = idx; sel_home = home;
-            }
-          }
-        }
-        const bool early_here = early && d.moved && (j - i) == d.j;
-        if (sel >= 0) {
-          if (early_here) { insert_rec_ = d.ins; remove_rec_ = d.rem; }          // (named before the move was applied)
-          else if (early) { set_error("online UFBoot: the replay selects a candidate where the costs said none is"); return MPF_E_STATE; }
-          else {
-            insert_rec_ = candidate_record(pl, (size_t)sel);
-            remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
-          }
-        }
-        if (log_open) { u.log.push_back(UfbState::LogEntry{0xFFFFFFFFu, 0u, 0, cur_plan}); log_open = false; }
-        bool accept;
-        if (tie_mode_ == MPF_TIE_RANDOM) {                              // :3306-3311
-          if (best_ == randomMP) iter_hits++;
-          if (best_ < randomMP) iter_hits = 1;
-          accept = (best_ < randomMP || (best_ == randomMP && tie_draw() <= 1.0 / (double)iter_hits)) &&
-                   remove_rec_ >= 0 && insert_rec_ >= 0;
-        } else {
-          accept = best_ < randomMP;
-        }
-        if (early && accept != early_here) { set_error("online UFBoot: the replay's decision differs from the one taken from the costs"); return MPF_E_STATE; }
-        if (accept) {
-          if (sel < 0) { set_error("online UFBoot: accepted move without a candidate of this prune node"); return MPF_E_STATE; }
-          if (early) {
-            if (sel != d.sel || best_ != d.score) { set_error("online UFBoot: the replay's move differs from the one taken from the costs"); return MPF_E_STATE; }
-          } else {
-            if (B.device) UCHK(launch_rt_update(st_, u.rt.p, u.C.p, u.Bp, hinfo[sel_idx].x, sel_home));
-            snap_back = back_;
-            snap_epoch = topo_epoch_;
-            moves_.push_back(Move{remove_rec_, insert_rec_, best_});
-            apply_move(remove_rec_, insert_rec_);
-          }
-          randomMP = best_;
-          moved = true;
-          moved_once = true;
-        }
-      }
-      if (early && !d.moved && moved) { set_error("online UFBoot: a move where the costs said none is possible"); return MPF_E_STATE; }
-      // the log of this batch speaks of the tree in front of its move
-      if (!u.log.empty() && use_worker) {
-        Job *jb = worker.get();
-        jb->log.swap(u.log);
-        u.log.clear();
-        if (moved) { jb->back.swap(snap_back); jb->epoch = snap_epoch; }
-        else { jb->back = back_; jb->epoch = topo_epoch_; }
-        jb->plans = B.plans;
-        if (recording.f) books::rec::write_job<ScanPlan>(recording.f, jb->log, jb->back, jb->epoch, jb->plans);
-        if (!worker.submit(jb)) {
-          ufb_drain(jb->log, jb->back, jb->epoch, jb->plans, worker.sc);
-          jb->log.clear();
-          worker.spare.push_back(jb);
-        }
-      } else if (!u.log.empty()) {
-        if (moved) { u.log_back.swap(snap_back); u.log_epoch = snap_epoch; }
-        else { u.log_back = back_; u.log_epoch = topo_epoch_; }
-        u.log_plans = &B.plans;
-      }
-      visits_done_ += j - i;
-      if (early) { batch = next_batch_size; i = next_i; }
-      else { batch = next_batch(batch, moved, j - i, total); i = j; }
-      cur = (cur + 1) % 3;
-      sw_events += n_ev;
-      sw_moved = sw_moved || moved;
-      u.t_replay += now_ms() - t0;
-    }
-    if (!sw_moved && sw_events == 0 && i > total && host_self && ufb_memo_) {       // (no cut-off in force here: every insertion test was multiplied)
-      if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-      u.quiet_topo[u.self_key] = UINT32_MAX;
-    }
-  } while (randomMP < startMP && !visits_out());
-  ufb_drain_log();
-  worker.finish();
-  u.lookups += worker.sc.lookups; u.stored += worker.sc.stored; u.t_lookup += worker.sc.t_lookup;
-  u.draws += n_draws;
-  if (u.refs.size() < u.treels.size()) u.refs.resize(u.treels.size(), 0);
-  if (recording.f) books::rec::write_state(recording.f, 'E', u, u.treels.size());
-  climb_finished(total);
-  if (u.exchange) {
-    // closing handshake: a rank that took another path would be in the middle of a batch here
-    const mpf_ufb_event *all = nullptr;
-    uint32_t n_all_ev = 0;
-    if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
-  }
-  if (final_score) *final_score = randomMP;
-  abort_guard.ok = true;
-  return MPF_OK;
-}
-
-// ---- batched bootstrap refinement ------------------------------------------------------------------------------------------
-// IQTree::optimizeBootTrees' default branch (iqtree.cpp:2797-2862) takes the samples one at a time: re-weight the alignment with
-// boot_samples_pars[b] (modifyPatternFreq :2520), rebuild the parsimony structures (on_opt_btree, sprparsimony.cpp:3253), read the
-// sample's tree and run ONE pllOptimizeSprParsimony from it (:2837).  The online phase leaves most samples on few distinct trees
-// (one, where the data are decisive), and a tree that is already SPR-optimal under a sample's weights comes back unchanged after
-// one sweep without an accepted move.  Fitch state sets do not depend on the weights -- only the counts do -- so that first sweep
-// is computed for ALL samples that share the current tree at once: one masked scan (the 1-bit "no common state" mask of every
-// insertion test), one binary x int8 product against the samples' weights on the matrix cores (length of candidate c under
-// sample b = R_T[b] - C[home][b] + C[c][b]), and the extraction of the (candidate, sample) pairs whose length reaches the
-// sample's running best (k_ufb_events with the bound R_T[b]) -- the only pairs testInsertParsimony's rule (:2168-2176) can act on.
-// Each sample's sweep is then replayed on the host from ITS events with ITS tie stream: hits / draws inside a prune node, the
-// sweep's accept rule with bestIterationScoreHits behind every prune node (:3306-3311; one draw per visit while nothing is
-// better, skipped ahead in closed form over visits without events).  stable[b] = the sweep accepts no move: the climb's result
-// is the current tree with length scores[b], exactly what the solo call returns.  A sample whose sweep does accept a move
-// (an improvement, or a drawn move to an equally long tree) is NOT advanced here: the caller runs its climb alone.
-// state * A^k + c * (A^k - 1) / (A - 1) mod 2^64 by doubling: k draws of the tie stream at once
-uint64_t lcg64_skip(uint64_t state, uint64_t k)
-{
-  uint64_t a = 0x27bb2ee687b0b0fdULL, c = 3037000493ULL, acc_a = 1, acc_c = 0;
-  while (k) {
-    if (k & 1) { acc_a *= a; acc_c = acc_c * a + c; }
-    c = (a + 1) * c;
-    a *= a;
-    k >>= 1;
-  }
-  return acc_a * state + acc_c;
-}
-
-int Engine::ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit)
-{
-  if (!ufb_) { set_error("refine sweep: no samples attached (mpf_ufboot_attach)"); return MPF_E_STATE; }
-  UfbState &u = *ufb_;
-  if (!have_tree_ || ntips_ != n_) { set_error("refine sweep: no complete tree set"); return MPF_E_STATE; }
-  if (u.suspended || u.ratchet) { set_error("refine sweep: the attach-time weights must be in force"); return MPF_E_STATE; }
-  if (tie_mode_ != MPF_TIE_RANDOM) { set_error("refine sweep: mpboot's random tie rule only (MPF_TIE_RANDOM)"); return MPF_E_UNSUPPORTED; }
-  const int total = 2 * n_ - 2;
-  struct Ev { uint32_t col, visit, ord, s; };
-  std::vector<Ev> all;
-  std::vector<uint32_t> rt((size_t)u.Bl);
-  // every sample's sweep, replayed from its own events (both engines)
-  auto replay = [&]() {
-    std::sort(all.begin(), all.end(), [](const Ev &x, const Ev &y) { return x.col != y.col ? x.col < y.col : x.visit != y.visit ? x.visit < y.visit : x.ord < y.ord; });
-    size_t ep = 0;
-    for (int c = 0; c < u.Bl; c++) {
-      const int b = u.ids[(size_t)c];
-      const uint32_t randomMP = rt[(size_t)c];
-      uint32_t best = randomMP;
-      TieRng rng;
-      rng.seed(tie_seeds ? tie_seeds[b] : b);
-      uint64_t iter_hits = 1;
-      uint32_t done_visits = 0;                             // visits [0, done_visits) of the sweep are behind us
-      bool moved = false;
-      uint32_t move_visit = 0;
-      while (ep < all.size() && all[ep].col == (uint32_t)c && !moved) {
-        const uint32_t v = all[ep].visit;
-        // visits without an event: bestParsimony == randomMP, one draw each, nothing selected (:3306-3311)
-        const uint64_t k = (uint64_t)(v - done_visits);
-        rng.state = lcg64_skip(rng.state, k);
-        iter_hits += k;
-        // this visit: testInsertParsimony's rule over its events (:2168-2176), bestTreeScoreHits = 1 at its start
-        uint64_t hits = 1;
-        bool sel = false;
-        for (; ep < all.size() && all[ep].col == (uint32_t)c && all[ep].visit == v; ep++) {
-          const uint32_t mp = all[ep].s;
-          if (mp > best) continue;
-          if (mp < best) hits = 1;
-          else hits++;
-          bool take = mp < best;
-          if (!take) take = rng.next() <= 1.0 / (double)hits;
-          if (take) { best = mp; sel = true; }
-        }
-        bool accept = best < randomMP;
-        if (!accept) {                                      // best == randomMP
-          iter_hits++;
-          accept = rng.next() <= 1.0 / (double)iter_hits;
-        }
-        if (accept && sel) { moved = true; move_visit = v; }
-        done_visits = v + 1u;
-      }
-      while (ep < all.size() && all[ep].col == (uint32_t)c) ep++;
-      if (scores) scores[b] = randomMP;
-      if (stable) stable[b] = moved ? 0 : 1;
-      if (first_move_visit) first_move_visit[b] = moved ? (int32_t)move_visit + 1 : 0;     // 1-based index into nodep[], 0 = none
-    }
-  };
-  if (u.snk) {
-    // ---- the weighted (-cost) engine: the scans write every tentative tree's per-pattern lengths (k_snk_scan), bit planes of them
-    // times the sample weights on the matrix cores = every sample's length of every tentative tree; the current tree's row is
-    // multiplied along and is the samples' bound (the evaluate of :3277 under sample b)
-    node_rectifier();
-    const uint32_t npat = (uint32_t)g_.Wp;
-    std::vector<ScanPlan> plans;
-    const uint32_t *out = nullptr;
-    std::vector<uint2> hinfo;
-    std::vector<uint32_t> small;
-    // (a row is one tentative tree's per-pattern lengths, 2 bytes per pattern, ~60 rows per prune node at radius 6: chunks of
-    //  at most ~2 GB of rows -- plus their bit planes -- whatever the option says)
-    const int chunk = std::max(1, std::min(refine_chunk_, (int)std::max<uint64_t>(1, 2000000000ull / ((uint64_t)npat * 2ull * 64ull))));
-    bool have_rt = false;
-    for (int i = 1; i <= total; i += chunk) {
-      const int hi = std::min(total, i + chunk - 1), np = hi - i + 1;
-      UCHK(u.vmax.reserve(4));
-      UCHK(hipMemsetAsync(u.vmax.p, 0, sizeof(uint32_t), st_));
-      scan_vals_ = true;
-      int rc = scan_batch(plans, nodep_.data() + i, np, 1, maxtrav, &out);
-      scan_vals_ = false;
-      if (rc) return rc;
-      const uint32_t n_idx = vals_rows_, R = n_idx;
-      UCHK(u.vals.reserve(((size_t)n_idx + 1) * npat));
-      UCHK(u.h_vmax.reserve(4));
-      if (asym_) UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(back_[start_]), slot(start_), u.vals.p + (size_t)R * npat, u.vmax.p));
-      else UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), u.vals.p + (size_t)R * npat, u.vmax.p));
-      UCHK(hipMemcpyAsync(u.h_vmax.p, u.vmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-      UCHK(hipStreamSynchronize(st_));
-      int K = 1;
-      while (K < 16 && (u.h_vmax.p[0] >> K)) K++;
-      const uint32_t rows = n_idx + 1;
-      const int rows_p = round_up((int)rows, kUfbRowTile);
-      const size_t plane_words = (size_t)rows_p * (size_t)u.Wp_s;
-      UCHK(u.bitp.reserve((size_t)K * plane_words));
-      UCHK(hipMemsetAsync(u.bitp.p, 0, (size_t)K * plane_words * sizeof(uint32_t), st_));
-      for (uint32_t r0 = 0; r0 < rows; r0 += 32768u)
-        UCHK(launch_vals_planes(st_, u.vals.p + (size_t)r0 * npat, std::min(32768u, rows - r0), npat, K, u.bitp.p + (size_t)r0 * u.Wp_s, (uint32_t)rows_p,
-                                (uint32_t)u.Wp_s));
-      UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
-      bool first = true;
-      for (int k = 0; k < K; k++)
-        for (int pl = 0; pl < u.planes; pl++) {
-          UCHK(launch_bitgemm(st_, u.bitp.p + (size_t)k * plane_words, rows_p, u.Wp_s, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p,
-                              (1 << k) << (7 * pl), first ? 0 : 1));
-          first = false;
-        }
-      u.gemm_rows += (uint64_t)rows_p * (uint64_t)K;
-      UCHK(u.rt.reserve((size_t)u.Bp));
-      UCHK(launch_colsum(st_, u.C.p + (size_t)R * u.Bp, 1, u.Bp, u.rt.p));
-      if (!have_rt) {
-        UCHK(u.h_rt.reserve((size_t)u.Bp));
-        UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
-        UCHK(hipStreamSynchronize(st_));
-        for (int c = 0; c < u.Bl; c++) rt[(size_t)c] = (uint32_t)u.h_rt.p[c];
-        have_rt = true;
-      }
-      if (n_idx == 0) continue;
-      // per output index: (row, prune node of the chunk) for the candidates; the current tree's slots take no part
-      hinfo.assign((size_t)n_idx, make_uint2(0u, 0xFFFFFFFFu));
-      std::vector<uint32_t> ends((size_t)np);
-      uint32_t run = 0;
-      for (int j = 0; j < np; j++) {
-        const ScanPlan &pl = plans[(size_t)j];
-        if (pl.self_idx >= 0) run = std::max(run, (uint32_t)pl.self_idx + 1u);
-        for (const Candidate &cd : pl.cands) { hinfo[cd.out] = make_uint2(cd.out, (uint32_t)j); run = std::max(run, cd.out + 1u); }
-        ends[(size_t)j] = run;
-      }
-      const uint32_t n_parts = (uint32_t)np;
-      const size_t o_cnt = (size_t)2 * n_parts;
-      small.assign(o_cnt + 1, 0u);
-      for (uint32_t d = 0; d < n_parts; d++) { small[d] = UINT32_MAX; small[n_parts + d] = R; }
-      UCHK(u.h_small.reserve(small.size() + 4));
-      std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
-      UCHK(u.thr.reserve(small.size() + 4));
-      UCHK(u.info.reserve((size_t)n_idx));
-      const uint32_t nch = ufb_chunks(n_idx);
-      UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
-      UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
-      if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
-      UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
-      UCHK(hipMemcpyAsync(u.info.p, hinfo.data(), (size_t)n_idx * sizeof(uint2), hipMemcpyHostToDevice, st_));
-      uint32_t *d_evcount = u.thr.p + o_cnt;
-      uint32_t n_ev = 0;
-      for (bool again = false;; again = true) {
-        if (again) UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
-        UCHK(launch_ufb_events(st_, u.info.p, d_out(), u.thr.p, u.thr.p + n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p,
-                               reinterpret_cast<const uint32_t *>(u.rt.p), n_idx, u.cmin.p, u.pre.p, u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));
-        UCHK(hipMemcpyAsync(u.h_small.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-        UCHK(hipStreamSynchronize(st_));
-        n_ev = u.h_small.p[0];
-        if (n_ev <= u.ev.cap) break;
-        UCHK(u.ev.reserve((size_t)n_ev));
-        UCHK(u.h_ev.reserve((size_t)n_ev));
-      }
-      if (n_ev) {
-        UCHK(u.h_ev.reserve((size_t)n_ev));
-        UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
-        UCHK(hipStreamSynchronize(st_));
-        for (uint32_t k = 0; k < n_ev; k++) {
-          const UfbEvent &e = u.h_ev.p[k];
-          const uint32_t j = (uint32_t)(std::upper_bound(ends.begin(), ends.end(), e.idx) - ends.begin());
-          all.push_back(Ev{e.b, (uint32_t)(i - 1) + j, e.idx, e.s});
-        }
-      }
-    }
-    replay();
-    u.rt_valid = false;
-    return MPF_OK;
-  }
-  if (scan_mode_ != 1) { set_error("refine sweep needs the device-walked scan (option scan_mode 1)"); return MPF_E_UNSUPPORTED; }
-  node_rectifier();
-  { int rc = ufb_current_tree_reps(); if (rc) return rc; }          // R_T[b]: what the evaluate of sprparsimony.cpp:3277 returns under sample b
-  UCHK(u.h_rt.reserve((size_t)u.Bp));
-  UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
-  UCHK(hipStreamSynchronize(st_));
-  for (int c = 0; c < u.Bl; c++) rt[(size_t)c] = (uint32_t)u.h_rt.p[c];
-  // ---- the whole sweep's insertion tests, with masks (chunks of prune nodes bound the mask and product buffers)
-  std::vector<ScanPlan> plans;
-  const uint32_t *out = nullptr;
-  std::vector<uint32_t> small;
-  const int chunk = std::max(1, refine_chunk_);
-  for (int i = 1; i <= total; i += chunk) {
-    const int hi = std::min(total, i + chunk - 1), np = hi - i + 1;
-    scan_masks_ = true;
-    int rc = scan_batch(plans, nodep_.data() + i, np, 1, maxtrav, &out);
-    scan_masks_ = false;
-    if (rc) return rc;
-    uint32_t n_idx = 0, n_parts = 0;
-    std::vector<uint32_t> self_list;
-    for (int j = 0; j < np; j++) {
-      const ScanPlan &pl = plans[(size_t)j];
-      if (pl.self_idx >= 0) { self_list.push_back((uint32_t)pl.self_idx); n_idx = std::max(n_idx, (uint32_t)pl.self_idx + 1u); }
-      for (int pi = 0; pi < pl.n_parts; pi++) {
-        n_idx = std::max(n_idx, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
-        n_parts = std::max(n_parts, (uint32_t)pl.part_desc[pi] + 1u);
-      }
-    }
-    if (n_parts == 0) continue;                         // (no insertion test in this chunk)
-    const int rows_p = round_up((int)std::max<uint32_t>(n_idx, 1u), kUfbRowTile);
-    { int rc2 = ufb_reserve_scan(n_idx); if (rc2) return rc2; }
-    // staging: thr[n_parts] | home[n_parts] | self[n_self] | event count
-    const size_t o_self = (size_t)2 * n_parts, o_cnt = o_self + self_list.size();
-    small.assign(o_cnt + 1, 0u);
-    std::copy(self_list.begin(), self_list.end(), small.begin() + (long)o_self);
-    for (int j = 0; j < np; j++) {
-      const ScanPlan &pl = plans[(size_t)j];
-      for (int pi = 0; pi < pl.n_parts; pi++) {
-        const uint32_t d = (uint32_t)pl.part_desc[pi];
-        small[d] = UINT32_MAX;                          // no cut-off: every insertion test counts
-        small[n_parts + d] = pl.part_off[pi] + (uint32_t)pl.part_cnt[pi];
-      }
-    }
-    UCHK(u.h_small.reserve(small.size() + 4));
-    std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
-    UCHK(u.thr.reserve(small.size() + 4));
-    UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
-    const uint32_t nch = ufb_chunks(n_idx);
-    UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
-    UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
-    if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
-    UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
-    // (the current tree's own slots take no part: its length under sample b IS the bound)
-    UCHK(launch_ufb_self(st_, u.info.p, u.thr.p + o_self, (uint32_t)self_list.size(), 0xFFFFFFFFu));
-    if (timing_) UCHK(hipEventRecord(ev2_, st_));
-    for (int pl = 0; pl < u.planes; pl++)
-      UCHK(launch_bitgemm(st_, u.masks.p, rows_p, g_.Wp, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p, 1 << (7 * pl), pl > 0, nullptr));
-    u.gemm_rows += (uint64_t)rows_p;
-    if (timing_) UCHK(hipEventRecord(ev3_, st_));
-    uint32_t *d_evcount = u.thr.p + o_cnt;
-    uint32_t n_ev = 0;
-    for (bool again = false;; again = true) {
-      if (again) UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
-      // the bound of sample b: the current tree's length under its weights, R_T[b] -- a running minimum from there on
-      UCHK(launch_ufb_events(st_, u.info.p, d_out(), u.thr.p, u.thr.p + n_parts, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p,
-                             reinterpret_cast<const uint32_t *>(u.rt.p), n_idx, u.cmin.p, u.pre.p, u.ev.p, (uint32_t)u.ev.cap, d_evcount, 0));
-      UCHK(hipMemcpyAsync(u.h_small.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-      UCHK(hipStreamSynchronize(st_));
-      n_ev = u.h_small.p[0];
-      if (n_ev <= u.ev.cap) break;
-      UCHK(u.ev.reserve((size_t)n_ev));
-      UCHK(u.h_ev.reserve((size_t)n_ev));
-    }
-    if (timing_) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
-    }
-    if (n_ev) {
-      UCHK(u.h_ev.reserve((size_t)n_ev));
-      UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_ev * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
-      UCHK(hipStreamSynchronize(st_));
-      // output index -> (visit of the sweep, order inside the visit): the indices of one prune node's parts rise in the
-      // reference's candidate order
-      std::vector<uint32_t> ends((size_t)np);            // end (exclusive) of prune node j's index range
-      uint32_t run = 0;
-      for (int j = 0; j < np; j++) {
-        const ScanPlan &pl = plans[(size_t)j];
-        if (pl.self_idx >= 0) run = std::max(run, (uint32_t)pl.self_idx + 1u);
-        for (int pi = 0; pi < pl.n_parts; pi++) run = std::max(run, pl.part_off[pi] + (uint32_t)pl.part_cnt[pi] + 1u);
-        ends[(size_t)j] = run;
-      }
-      for (uint32_t k = 0; k < n_ev; k++) {
-        const UfbEvent &e = u.h_ev.p[k];
-        const uint32_t j = (uint32_t)(std::upper_bound(ends.begin(), ends.end(), e.idx) - ends.begin());
-        all.push_back(Ev{e.b, (uint32_t)(i - 1) + j, e.idx, e.s});
-      }
-    }
-  }
-  replay();
-  u.rt_valid = true;
-  return MPF_OK;
-}
-
-// The same loop on the weighted (Sankoff) engine.  pllComputePatternParsimony dispatches to
-// pllComputeSankoffPatternParsimony there (sprparsimony.cpp:3341-3355): the per-pattern lengths of the tentative tree are the
-// minima the evaluate has just taken.  The scan writes them for every insertion test (k_snk_scan, 16 bits each), k_vals_planes
-// slices them into bit planes and REPS = sum_k 2^k (plane k x weights) on the matrix cores; the current tree's own row is
-// multiplied along with every batch and serves as the "home" row of the event formula, so that a candidate's score is its own
-// product row and the current tree's slots score R_T.  Scans are host-planned (as every weighted scan), everything else --
-// cut-off filter, ratchet rule, update rules, replay order -- is the code path of spr_sweeps_ufboot.
-int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, uint32_t *final_score)
-{
-  UfbState &u = *ufb_;
-  if (u.exchange) {
-    // sample-sharded run: every rank must cut the climb into the same batches -- start from a fixed batch policy state
-    gap_est_ = -1.0;
-    since_move_ = 0;
-  }
-  uint32_t exchange_tag = 0;
-  uint32_t startMP;
-  unsigned iter_hits = 1;
-  const int total = 2 * n_ - 2;
-  const uint32_t npat = (uint32_t)g_.Wp;
-  std::vector<ScanPlan> plans;
-  const uint32_t *out = nullptr;
-  int batch = first_batch();
-  std::vector<UfbEvent> events, ev_tmp;
-  std::vector<uint32_t> ev_count, small;
-  std::vector<uint2> hinfo;
-  std::vector<int32_t> mh_bk, lcol;
-  std::string mh_key;
-  const bool ratchet = u.ratchet;
-  const bool store_trees = u.store_trees;          // -storetrees (iqtree.cpp:3302-3346)
-  // (an asymmetric matrix gives the CURRENT tree another length and another row at every prune node's visit -- it is evaluated at
-  //  that node's edge, evaluateParsimony(p) of :2285 --: the scan writes both to the visit's slot, scan_batch)
-  const bool asym = asym_;
-  const bool host_self = !u.exchange && !asym;     // (sample-sharded: R_T lives in pieces on the ranks, the current tree's bookings come as device events)
-  const int oc = u.Bl;
-  if (ratchet) u.gate_closed = false;
-  bool stale_init = false;                         // ratchet: _pattern_pars of the climb's start tree, known after the first product
-  do {
-    startMP = randomMP;
-    node_rectifier();
-    int i = 1;
-    while (i <= total) {
-      const int hi = std::min(total, i + batch - 1);
-      const int np = hi - i + 1;
-      UCHK(u.vmax.reserve(4));
-      UCHK(hipMemsetAsync(u.vmax.p, 0, sizeof(uint32_t), st_));      // (a batch without any insertion test launches no scan)
-      scan_vals_ = true;
-      int rc = scan_batch(plans, nodep_.data() + i, np, mintrav, maxtrav, &out);
-      scan_vals_ = false;
-      if (rc) return rc;
-      u.batches++;
-      const uint32_t n_idx = vals_rows_;           // output indices: a slot for the current tree in front of every prune node's candidates
-      const uint32_t R = n_idx;                    // the current tree's row of the product
-      int jstar = np - 1;
-      for (int j = 0; j < np; j++) {
-        const ScanPlan &pl = plans[(size_t)j];
-        uint32_t m = UINT32_MAX;
-        for (const Candidate &cd : pl.cands) m = std::min(m, out[cd.out]);
-        if (m < randomMP) { jstar = j; break; }
-      }
-      const bool have_cut = u.logl_cutoff != 0.0;
-      const double lim = -u.logl_cutoff + 1e-4;
-      const uint32_t mp_max = have_cut ? (lim <= 0.0 ? 0u : (uint32_t)std::ceil(lim) - 1u) : UINT32_MAX;
-      const bool none_pass = have_cut && lim <= 0.0;
-      const bool skip_product = store_trees ? false : ratchet ? (u.gate_closed || none_pass) : none_pass;
-      bool have_C = false;
-      events.clear();
-      if (!skip_product) {
-        // ---- the current tree's row, the bit planes, the product
-        UCHK(u.vals.reserve(((size_t)n_idx + 1) * npat));
-        UCHK(u.h_vmax.reserve(4));
-        if (asym) UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(back_[start_]), slot(start_), u.vals.p + (size_t)R * npat, u.vmax.p));     // (left = far end, as tree_length)
-        else UCHK(launch_sankoff_pattern(st_, g_, d_vec_, slot(start_), slot(back_[start_]), u.vals.p + (size_t)R * npat, u.vmax.p));
-        UCHK(hipMemcpyAsync(u.h_vmax.p, u.vmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-        UCHK(hipStreamSynchronize(st_));
-        int K = 1;
-        while (K < 16 && (u.h_vmax.p[0] >> K)) K++;
-        const uint32_t rows = n_idx + 1;
-        const int rows_p = round_up((int)rows, kUfbRowTile);
-        const size_t plane_words = (size_t)rows_p * (size_t)u.Wp_s;
-        UCHK(u.bitp.reserve((size_t)K * plane_words));
-        UCHK(hipMemsetAsync(u.bitp.p, 0, (size_t)K * plane_words * sizeof(uint32_t), st_));
-        for (uint32_t r0 = 0; r0 < rows; r0 += 32768u)                  // (grid.y limit)
-          UCHK(launch_vals_planes(st_, u.vals.p + (size_t)r0 * npat, std::min(32768u, rows - r0), npat, K, u.bitp.p + (size_t)r0 * u.Wp_s, (uint32_t)rows_p,
-                                  (uint32_t)u.Wp_s));
-        UCHK(u.C.reserve((size_t)rows_p * (size_t)u.Bp));
-        if (timing_) UCHK(hipEventRecord(ev2_, st_));
-        bool first = true;
-        for (int k = 0; k < K; k++)
-          for (int pl = 0; pl < u.planes; pl++) {
-            UCHK(launch_bitgemm(st_, u.bitp.p + (size_t)k * plane_words, rows_p, u.Wp_s, u.wt.p + (size_t)pl * u.plane_bytes, u.Bp, u.C.p,
-                                (1 << k) << (7 * pl), first ? 0 : 1));
-            first = false;
-          }
-        if (timing_) UCHK(hipEventRecord(ev3_, st_));
-        u.gemm_rows += (uint64_t)rows_p * (uint64_t)K;
-        UCHK(u.rt.reserve((size_t)u.Bp));
-        UCHK(launch_colsum(st_, u.C.p + (size_t)R * u.Bp, 1, u.Bp, u.rt.p));       // R_T = the current tree's own row
-        UCHK(u.h_rt.reserve((size_t)u.Bp));
-        UCHK(hipMemcpyAsync(u.h_rt.p, u.rt.p, (size_t)u.Bl * sizeof(int32_t), hipMemcpyDeviceToHost, st_));    // synchronised below
-        have_C = true;
-        // ---- per output index: (row, part) for candidates of plans [0, jstar], the current tree's slots, everything else off
-        uint32_t n_parts = 0;
-        hinfo.assign((size_t)n_idx, make_uint2(0u, 0xFFFFFFFFu));
-        const bool self_pass = ratchet || store_trees || randomMP <= mp_max;
-        for (int j = 0; j <= jstar; j++) {
-          const ScanPlan &pl = plans[(size_t)j];
-          // (asym: the visit's slot is a row of its own -- it takes part like a candidate, its cost the length at that edge)
-          if (pl.self_idx >= 0) hinfo[(size_t)pl.self_idx] = asym ? make_uint2((uint32_t)pl.self_idx, (uint32_t)j)
-                                                                   : make_uint2(0u, (self_pass && !host_self) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
-          for (const Candidate &cd : pl.cands) hinfo[cd.out] = make_uint2(cd.out, (uint32_t)j);
-          n_parts = (uint32_t)j + 1u;
-        }
-        // staging: thr[n_parts] | home[n_parts] | best[Bp]
-        const size_t o_cnt = (size_t)2 * n_parts + (size_t)u.Bp;   // the event counter: a zero word of this upload
-        small.assign(o_cnt + 1, 0u);
-        for (uint32_t d = 0; d < n_parts; d++) {
-          small[d] = (!have_cut || ratchet || store_trees) ? UINT32_MAX : mp_max + 1u;            // max cost + 1 (costs are full lengths here)
-          small[n_parts + d] = R;
-        }
-        for (int c2 = 0; c2 < u.Bl; c2++) small[(size_t)2 * n_parts + (size_t)c2] = ufb_event_bound((uint32_t)u.ids[(size_t)c2]);
-        UCHK(u.h_small.reserve(small.size() + 4));
-        std::memcpy(u.h_small.p, small.data(), small.size() * sizeof(uint32_t));
-        UCHK(u.thr.reserve(small.size() + 4));
-        UCHK(u.info.reserve((size_t)std::max<uint32_t>(n_idx, 1u)));
-        const uint32_t nch = ufb_chunks(std::max<uint32_t>(n_idx, 1u));
-        UCHK(u.cmin.reserve((size_t)nch * (size_t)u.Bp));
-        UCHK(u.pre.reserve((size_t)nch * (size_t)u.Bp));
-        UCHK(u.evcount.reserve(4));
-        if (u.ev.cap == 0) { UCHK(u.ev.reserve(1u << 18)); UCHK(u.h_ev.reserve(1u << 18)); }
-        UCHK(hipMemcpyAsync(u.thr.p, u.h_small.p, small.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
-        if (n_idx) UCHK(hipMemcpyAsync(u.info.p, hinfo.data(), (size_t)n_idx * sizeof(uint2), hipMemcpyHostToDevice, st_));
-        const uint32_t *d_thr = u.thr.p, *d_home = u.thr.p + n_parts, *d_best = u.thr.p + 2 * n_parts;
-        if (ratchet) {
-          UCHK(u.d_col.reserve((size_t)rows_p));
-          UCHK(u.h_col.reserve((size_t)rows_p));
-          UCHK(launch_ufb_column(st_, u.C.p, u.Bp, oc, rows, u.d_col.p));
-          UCHK(hipMemcpyAsync(u.h_col.p, u.d_col.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st_));
-        }
-        uint32_t n_ev = 0, n_eager = 0;
-        uint32_t *d_evcount = u.thr.p + o_cnt;
-        for (bool again = false; n_idx; again = true) {
-          if (again) UCHK(hipMemsetAsync(d_evcount, 0, sizeof(uint32_t), st_));
-          UCHK(launch_ufb_events(st_, u.info.p, d_out(), d_thr, d_home, nullptr, u.C.p, u.Bp, u.Bl, u.rt.p, d_best, n_idx, u.cmin.p, u.pre.p,
-                                 u.ev.p, (uint32_t)u.ev.cap, d_evcount, (u.topboot || u.distinct || store_trees) ? 1 : 0));
-          UCHK(hipMemcpyAsync(u.h_small.p, d_evcount, sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-          n_eager = (uint32_t)std::min<size_t>(u.ev.cap, 4096);     // (as in spr_sweeps_ufboot: one round trip for a small batch)
-          UCHK(u.h_ev.reserve((size_t)n_eager));
-          UCHK(hipMemcpyAsync(u.h_ev.p, u.ev.p, (size_t)n_eager * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
-          UCHK(hipStreamSynchronize(st_));
-          n_ev = u.h_small.p[0];
-          if (n_ev <= u.ev.cap) break;
-          UCHK(u.ev.reserve((size_t)n_ev));
-          UCHK(u.h_ev.reserve((size_t)n_ev));
-        }
-        if (!n_idx) UCHK(hipStreamSynchronize(st_));
-        if (timing_) {
-          float ms = 0;
-          if (hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) u.gemm_ms += ms;
-        }
-        if (n_ev > n_eager) {
-          if (u.h_ev.cap < (size_t)n_ev) n_eager = 0;
-          UCHK(u.h_ev.reserve((size_t)n_ev));
-          UCHK(hipMemcpyAsync(u.h_ev.p + n_eager, u.ev.p + n_eager, (size_t)(n_ev - n_eager) * sizeof(UfbEvent), hipMemcpyDeviceToHost, st_));
-          UCHK(hipStreamSynchronize(st_));
-        }
-        events.assign(u.h_ev.p, u.h_ev.p + n_ev);
-        for (UfbEvent &ev : events) ev.b = (uint32_t)u.ids[(size_t)ev.b];
-        if (u.exchange) {
-          // sample-sharded run: every rank replays the events of all ranks (one all-gather per batch)
-          const mpf_ufb_event *all = nullptr;
-          uint32_t n_all_ev = 0;
-          if (u.exchange(u.exchange_arg, exchange_tag++, reinterpret_cast<const mpf_ufb_event *>(events.data()), (uint32_t)events.size(), &all, &n_all_ev) != 0) {
-            set_error("online UFBoot: event exchange failed (ranks out of step?)");
-            return MPF_E_STATE;
-          }
-          const UfbEvent *pa = reinterpret_cast<const UfbEvent *>(all);
-          events.assign(pa, pa + n_all_ev);
-        }
-        sort_events(events, ev_tmp, ev_count, std::max<uint32_t>(n_idx, 1u), (uint32_t)u.B);
-        u.events += n_ev;
-        if (ratchet) {
-          lcol.assign(u.h_col.p, u.h_col.p + rows);
-          u.rt_orig = (uint32_t)lcol[(size_t)R];
-          if (!stale_init) { u.stale_len = u.rt_orig; stale_init = true; }       // what the IQ-TREE kernel left for the start tree
-        }
-      }
-      // ---- host replay in the reference's order
-      size_t ep = 0;
-      bool moved = false;
-      int j = i;
-      for (; j <= hi && !moved; j++) {
-        const ScanPlan &pl = plans[(size_t)(j - i)];
-        if (tie_mode_ == MPF_TIE_RANDOM) {
-          insert_rec_ = remove_rec_ = -1;
-          hits_ = 1;
-        }
-        long sel = -1;
-        auto topology_key = [&](uint32_t cand_code) -> const std::string & {
-          if (cand_code == 0xFFFFFFFFu) {
-            if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-            return u.self_key;
-          }
-          ufb_candidate_topology(cand_code < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], pl.cands[(size_t)cand_code].q, mh_bk);
-          canonical_topology(mh_bk, mh_key);
-          return mh_key;
-        };
-        auto cand_topology_key = [&](uint32_t cand_code, int64_t tree_index) -> int64_t {
-          return u.topo_index.emplace(topology_key(cand_code), tree_index).first->second;
-        };
-        // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
-        // current tree's own bookings, which the host walks through itself
-        auto one_event = [&](const uint32_t b, const uint32_t s, int64_t &tree_index, bool &looked_up, const uint32_t cand_code) {
-            
-            uint32_t &bs = u.boot_score[b];
-            if (u.distinct && !u.mulhits) {
-              if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return cand_topology_key(cand_code, ti); }) &&
-                  (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              return;
-            }
-            if (u.mulhits && u.topboot) {
-              const int32_t rell = -(int32_t)s;
-              if ((int)u.top[b].size() < u.topboot || rell > u.top_thr[b]) {
-                const int64_t newest = (int64_t)u.treels.size() - 1;
-                if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
-                if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
-                    (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              }
-              return;
-            }
-            if (u.mulhits) {
-              if (s > bs) return;
-              if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
-              std::set<int64_t> &hs = u.hit_sets[b];
-              if (s < bs) {
-                for (int64_t t : hs) if (--u.refs[(size_t)t] == 0) u.store.erase(t);
-                hs.clear();
-                bs = s;
-              }
-              if (u.cut_btrees && u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
-              if (hs.insert(tree_index).second) {
-                u.refs[(size_t)tree_index]++;
-                if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              }
-              return;
-            }
-            bool accept = false;
-            if (s < bs) accept = true;
-            else if (s == bs) {
-              u.draws++;
-              accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
-            }
-            if (accept) {
-              if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                            // :3716-3718
-              if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
-              if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              if (s < bs) { u.boot_counts[b] = 1; bs = s; }
-              int64_t &bt = u.boot_trees[b];
-              if (bt != tree_index) {
-                if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
-                u.refs[(size_t)tree_index]++;
-                bt = tree_index;
-              }
-            }
-            if (s == bs) u.boot_counts[b]++;
-          };
-        auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
-          while (ep < events.size() && events[ep].idx < idx) ep++;
-          bool looked_up = store_trees;              // (-storetrees: tree_str is set at the top, no lookup per sample)
-          for (; ep < events.size() && events[ep].idx == idx; ep++) one_event(events[ep].b, events[ep].s, tree_index, looked_up, cand_code);
-        };
-        // the current tree scores R_T[b] for every sample: no device events for its slots (they would be B per prune-node visit,
-        // 2.0e6 per move-less C3 sweep, all to be copied and ordered) -- the host has R_T and offers it to every sample in order
-        auto replay_self = [&](int64_t tree_index) {
-          bool looked_up = store_trees;
-          for (int c2 = 0; c2 < u.Bl; c2++) one_event((uint32_t)u.ids[(size_t)c2], (uint32_t)u.h_rt.p[c2], tree_index, looked_up, 0xFFFFFFFFu);
-        };
-        // one tree arriving at saveCurrentTree with length cur_len: its index in treels_logl, or -1 when nothing is booked.
-        // Default: the cut-off test, then a new index (iqtree.cpp:3343-3348).  -storetrees: looked up by topology first
-        // (:3302-3341); one met before is skipped unless the length improved on the recorded one, and then it goes on under
-        // its old index without the cut-off test.
-        auto book_tree = [&](uint32_t cur_len, bool passes_cut, uint32_t cand_code) -> int64_t {
-          if (store_trees) {
-            const std::string &key = topology_key(cand_code);
-            auto it = u.topo_index.find(key);
-            if (it != u.topo_index.end()) {
-              u.duplicates++;
-              if (cur_len >= u.treels[(size_t)it->second]) return -1;
-              u.treels[(size_t)it->second] = cur_len;
-              return it->second;
-            }
-            if (!passes_cut) return -1;
-            u.topo_index.emplace(key, (int64_t)u.treels.size());
-          } else if (!passes_cut) return -1;
-          u.treels.push_back(cur_len);
-          u.refs.push_back(0);
-          return (int64_t)u.treels.size() - 1;
-        };
-        if (pl.self_idx >= 0) {
-          const uint32_t self_len = asym ? out[(size_t)pl.self_idx] : randomMP;       // (:2285: mp of evaluateParsimony(p))
-          bool pass;
-          if (!ratchet) pass = !none_pass && self_len <= mp_max;
-          else {
-            pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
-            if (!pass) u.gate_closed = true;
-          }
-          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : self_len);
-          const int64_t tree_index = book_tree(ratchet ? u.stale_len : self_len, pass, 0xFFFFFFFFu);
-          if (tree_index >= 0) {
-            if (host_self) replay_self(tree_index); else replay_events((uint32_t)pl.self_idx, tree_index, 0xFFFFFFFFu);
-            if (ratchet) u.stale_len = asym ? (uint32_t)lcol[(size_t)pl.self_idx] : u.rt_orig;
-          }
-        }
-        for (size_t c = 0; c < pl.cands.size(); c++) {
-          const uint32_t idx = pl.cands[c].out;
-          const uint32_t mp = out[idx];
-          bool pass;
-          if (!ratchet) pass = !none_pass && mp <= mp_max;
-          else {
-            pass = (store_trees || !u.gate_closed) && have_C && !none_pass && u.stale_len <= mp_max;
-            if (!pass) u.gate_closed = true;
-          }
-          u.cur_logl_now = -(int32_t)(ratchet ? u.stale_len : mp);
-          const int64_t tree_index = book_tree(ratchet ? u.stale_len : mp, pass, (uint32_t)c);
-          if (tree_index >= 0) {
-            replay_events(idx, tree_index, (uint32_t)c);
-            if (ratchet) u.stale_len = (uint32_t)lcol[(size_t)idx];
-          }
-          if (tie_mode_ == MPF_TIE_RANDOM) {
-            if (mp < best_) hits_ = 1;
-            else if (mp == best_) hits_++;
-            if (mp < best_ || (mp == best_ && tie_draw() <= 1.0 / (double)hits_)) { best_ = mp; sel = (long)c; }
-          } else if (mp < best_) {
-            best_ = mp; sel = (long)c;
-          }
-        }
-        if (sel >= 0) {
-          insert_rec_ = pl.cands[(size_t)sel].q;
-          remove_rec_ = sel < pl.n_p ? pl.rec : back_[pl.rec];
-        }
-        // topologies of the trees accepted during this prune node's scan that some sample still points to
-        for (const UfbState::Pending &pe : u.pending) {
-          if (u.refs[(size_t)pe.tree_index] <= 0) continue;
-          if (pe.cand == 0xFFFFFFFFu) {
-            if (!u.store.count(pe.tree_index)) { u.store.emplace(pe.tree_index, back_); u.stored++; }
-            continue;
-          }
-          ufb_store_tree(pe.tree_index, pe.cand < (uint32_t)pl.n_p ? pl.rec : back_[pl.rec], pl.cands[(size_t)pe.cand].q);
-        }
-        u.pending.clear();
-        bool accept;
-        if (tie_mode_ == MPF_TIE_RANDOM) {
-          if (best_ == randomMP) iter_hits++;
-          if (best_ < randomMP) iter_hits = 1;
-          accept = (best_ < randomMP || (best_ == randomMP && tie_draw() <= 1.0 / (double)iter_hits)) && remove_rec_ >= 0 && insert_rec_ >= 0;
-        } else {
-          accept = best_ < randomMP;
-        }
-        if (accept) {
-          if (sel < 0) { set_error("online UFBoot: accepted move without a candidate of this prune node"); return MPF_E_STATE; }
-          moves_.push_back(Move{remove_rec_, insert_rec_, best_});
-          apply_move(remove_rec_, insert_rec_);
-          randomMP = best_;
-          moved = true;
-        }
-      }
-      batch = next_batch(batch, moved, j - i, total);
-      i = j;
-    }
-  } while (randomMP < startMP);
-  climb_finished(total);
-  u.rt_valid = false;
-  if (u.exchange) {
-    // closing handshake: a rank that took another path would be in the middle of a batch here
-    const mpf_ufb_event *all = nullptr;
-    uint32_t n_all_ev = 0;
-    if (u.exchange(u.exchange_arg, 0xFFFFFFFFu, nullptr, 0, &all, &n_all_ev) != 0) { set_error("online UFBoot: ranks out of step at the end of the climb"); return MPF_E_STATE; }
-  }
-  if (final_score) *final_score = randomMP;
   return MPF_OK;
 }
 
