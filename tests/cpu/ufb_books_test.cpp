@@ -199,10 +199,77 @@ static int random_streams(uint64_t seed, int n_batches)
   return ok ? 0 : 1;
 }
 
+// ---- canonical form: the same unrooted topology under any numbering of its inner nodes and any rotation of their records
+// gives the same key; another topology (checked by its set of bipartitions) gives another
+static std::vector<int32_t> relabel(int n, const std::vector<int32_t> &bk, std::mt19937_64 &g)
+{
+  const int first = n + 1, last = 2 * n - 2;
+  std::vector<int> perm((size_t)(last - first + 1));
+  for (size_t i = 0; i < perm.size(); i++) perm[i] = first + (int)i;
+  std::shuffle(perm.begin(), perm.end(), g);
+  std::vector<int> rot(perm.size());
+  for (int &r : rot) r = (int)(g() % 3);
+  auto map = [&](int rec) {
+    const int v = rec / 3, s = rec % 3;
+    if (v <= n) return rec;
+    return 3 * perm[(size_t)(v - first)] + (s + rot[(size_t)(v - first)]) % 3;
+  };
+  std::vector<int32_t> out(bk.size(), -1);
+  for (int v = 1; v <= last; v++)
+    for (int sl = 0; sl < (v <= n ? 1 : 3); sl++) {
+      const int r = 3 * v + sl;
+      out[(size_t)map(r)] = map(bk[(size_t)r]);
+    }
+  return out;
+}
+static void splits_of(int n, const std::vector<int32_t> &bk, int rec, std::vector<std::vector<int>> &out, std::vector<int> &tips)
+{
+  // tips behind record `rec` (looking away from bk[rec])
+  if (is_tip(rec, n)) { tips.push_back(rec / 3); return; }
+  std::vector<int> mine;
+  splits_of(n, bk, bk[(size_t)nx(rec)], out, mine);
+  splits_of(n, bk, bk[(size_t)nx(nx(rec))], out, mine);
+  std::sort(mine.begin(), mine.end());
+  if (mine.size() > 1 && (int)mine.size() < n - 1) out.push_back(mine);
+  tips.insert(tips.end(), mine.begin(), mine.end());
+}
+static std::vector<std::vector<int>> bipartitions(int n, const std::vector<int32_t> &bk)
+{
+  std::vector<std::vector<int>> out;
+  std::vector<int> tips;
+  splits_of(n, bk, bk[3], out, tips);              // everything behind tip 1's neighbour: sides not containing tip 1
+  std::sort(out.begin(), out.end());
+  return out;
+}
+static int canon_check(uint64_t seed, int rounds)
+{
+  std::mt19937_64 g(seed);
+  CanonScratch sc;
+  std::string k0, k1;
+  int same_seen = 0, differ_seen = 0;
+  for (int r = 0; r < rounds; r++) {
+    const int n = 4 + (int)(g() % 60);
+    const std::vector<int32_t> a = random_tree(n, g);
+    canonical_topology(n, a, k0, sc);
+    const std::vector<int32_t> b = relabel(n, a, g);
+    canonical_topology(n, b, k1, sc);
+    if (k0 != k1 || bipartitions(n, a) != bipartitions(n, b)) { std::fprintf(stderr, "round %d: a relabelled tree got another key\n", r); return 1; }
+    same_seen++;
+    const std::vector<int32_t> c = random_tree(n, g);
+    canonical_topology(n, c, k1, sc);
+    const bool same_topology = bipartitions(n, a) == bipartitions(n, c);
+    if ((k0 == k1) != same_topology) { std::fprintf(stderr, "round %d: keys %s, topologies %s\n", r, k0 == k1 ? "equal" : "differ", same_topology ? "equal" : "differ"); return 1; }
+    differ_seen += !same_topology;
+  }
+  std::printf("canonical form: %d relabelled pairs equal, %d different topologies told apart\n", same_seen, differ_seen);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
+  if (argc >= 4 && !std::strcmp(argv[1], "canon")) return canon_check(std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]));
   if (argc >= 3 && !std::strcmp(argv[1], "replay")) return replay_file(argv[2]);
   if (argc >= 4 && !std::strcmp(argv[1], "random")) return random_streams(std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]));
-  std::fprintf(stderr, "usage: ufb_books_test replay <file> | random <seed> <batches>\n");
+  std::fprintf(stderr, "usage: ufb_books_test replay <file> | random <seed> <batches> | canon <seed> <rounds>\n");
   return 2;
 }

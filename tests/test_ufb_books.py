@@ -56,3 +56,10 @@ def test_recorded_stream_replays_to_the_recorded_state(prog):
 def test_random_streams_inline_equal_worker(prog, seed):
     out = _run(prog, "random", str(seed), "300")
     assert "equal" in out and "DIFFERENT" not in out
+
+
+def test_canonical_form_names_topologies_not_numberings(prog):
+    """books::canonical_topology (the key of the topology map, treels' tree "string" of iqtree.cpp:3689-3707): equal under any
+    numbering of the inner nodes and rotation of their records, different for different sets of bipartitions"""
+    out = _run(prog, "canon", "11", "3000")
+    assert "3000 relabelled pairs equal" in out
