@@ -2116,6 +2116,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
+  if (key == "climb_batch_max_sparse") { climb_batch_max_sparse_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
   if (key == "climb_fault") { climb_fault_ = v; return MPF_OK; }          // (tests of the recovery paths: climb.hpp)
   if (key == "views_waves") { nv_waves_ = (int)v; return MPF_OK; }         // waves per refresh workgroup: 0 = by level width, -1 = always sixteen, 2 .. 16
@@ -2198,6 +2199,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "climb_tile") *v = climb_vw_;
   else if (key == "climb_batch_min") *v = climb_batch_min_;
   else if (key == "climb_batch_max") *v = climb_batch_max_;
+  else if (key == "climb_batch_max_sparse") *v = climb_batch_max_sparse_;
   else if (key == "climb_idle") *v = climb_idle_;
   else if (key == "refine_chunk") *v = refine_chunk_;
   else if (key == "views_waves") *v = nv_waves_;

@@ -456,6 +456,7 @@ class Engine {
   unsigned long long climb_phase_ticks_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, climb_ctr_[4] = {0, 0, 0, 0};
   int climb_device_ = 1;                         // 0 = host-driven batches only, 1 = device climb while moves are dense, 2 = always
   int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)
+  int climb_batch_max_sparse_ = 16;              // option climb_batch_max_sparse: prune nodes per step of the quiet stretch of a tracked climb
   int climb_batch_min_ = 2, climb_batch_max_ = 8, climb_idle_ = 96, climb_trace_ = 0;
   inline int rec_of(uint32_t cid) const { return cid < (uint32_t)n_ ? 3 * ((int)cid + 1) : 3 * (n_ + 1 + (int)(cid - (uint32_t)n_) / 3) + (int)((cid - (uint32_t)n_) % 3u); }
   int climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle, uint32_t *reason, uint32_t *n_moves);

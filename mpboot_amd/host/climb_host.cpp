@@ -122,7 +122,9 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   p.idle_limit = may_idle ? (uint32_t)climb_idle_ : 0u;
   p.max_moves = (uint32_t)total;
   p.batch_min = (uint32_t)std::max(1, std::min(climb_batch_min_, 16));
-  p.batch_max = (uint32_t)std::max((int)p.batch_min, std::min(climb_batch_max_, 16));
+  // (a climb under a stop length is a later iteration of a -bb search: it starts near an optimum, its moves are some 25-45 prune
+  //  nodes apart -- sixteen prune nodes per step there)
+  p.batch_max = (uint32_t)std::max((int)p.batch_min, std::min(climb_stop_len_ ? climb_batch_max_sparse_ : climb_batch_max_, 16));
   p.order = cd_.order.p;
   p.bk = cd_.bk.p;
   p.sct = cd_.sct.p;
