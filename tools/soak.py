@@ -8,6 +8,8 @@ by the test-suite on fixed cases):
     the quiet stretch in k_climb / moot bookings / known optima without a product == every batch through the tracker's two-wait loop
   * the tracked climb (-bb bookkeeping) as a pipeline (ufb_pipe, decisions taken from the costs; its log on a second host thread or,
     ufb_thread 0, on the same one) == one chain per batch (ufb_pipe 0) == scan / wait / product / wait / replay (ufb_fast 0): moves, tree, saved trees, boot arrays, kept topologies, draws, tie state
+  * the same tracked climb with the current tree's bookings extracted on the device (the exchange path of a sample-sharded run, one
+    rank of one) == the host's walk over R_T; every fourth of these on the weighted engine (symmetric / asymmetric costs)
      python tools/soak.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
@@ -21,7 +23,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 BIG = os.environ.get("SOAK_BIG") == "1"       # 120-319 taxa, 100-399 samples: whole-sweep batches of tens of thousands of indices (the chunked extraction, the overflow rule)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-n_climb = n_ref = n_samples = n_trk = n_early = n_grow = n_iter = n_quiet = n_memo = n_fail = 0
+n_climb = n_ref = n_samples = n_trk = n_early = n_grow = n_iter = n_quiet = n_memo = n_fail = n_echo = n_echo_w = 0
 while time.time() < t_end:
     alpha = "AA" if rng.random() < 0.25 else "DNA"
     n = int(rng.integers(5, 90)) if not BIG else int(rng.integers(120, 320))
@@ -126,6 +128,45 @@ while time.time() < t_end:
                 n_early += e.get_option("ufb_early_batches")
         assert all(g == got[0] for g in got[1:]), ("tracked climb mismatch", alpha, n, P, tie, radius, seed, B, sb)
         n_trk += 1
+        # ---- the same climb with the current tree's bookings as DEVICE events (what a sample-sharded run does: one rank of one,
+        # an exchange that hands back what it was given), on the Fitch engine and -- every fourth case -- the weighted engine
+        # (symmetric or asymmetric random costs): == the host's own walk over R_T
+        if not BIG and rng.random() < 0.5:
+            import ctypes as C
+            from mpboot_amd import shard
+            S = 4 if alpha == "DNA" else 20
+            cost = None
+            if rng.random() < 0.25 and n <= 40 and P <= 900:
+                m = rng.integers(1, 6, size=(S, S))
+                cost = (np.triu(m, 1) + np.triu(m, 1).T).astype(np.uint32)
+                if rng.random() < 0.5:
+                    cost[np.triu_indices(S, 1)] += 2
+            two = []
+            for echo in (False, True):
+                keep = {}
+
+                def fn(_arg, tag, local_ptr, n_local, all_ptr, n_all_ptr):
+                    buf = np.ctypeslib.as_array(C.cast(local_ptr, C.POINTER(C.c_uint32)), shape=(n_local, 3)).copy() if n_local else np.zeros((0, 3), dtype=np.uint32)
+                    keep["buf"] = buf
+                    all_ptr[0] = buf.ctypes.data if n_local else None
+                    n_all_ptr[0] = n_local
+                    return 0
+
+                cb = shard.EXCHANGE_FN(fn)
+                e = engine.FitchEngine(codes, w, datatype=dt, cost=cost)
+                e.set_option("scan_batch", sb)
+                e.set_tree(back); e.reset_node_order(); e.seed_ties(tie, seed)
+                if echo:
+                    e.ufboot_attach(samples, 0.5, shard=(0, 1), exchange=cb)
+                else:
+                    e.ufboot_attach(samples, 0.5)
+                s1 = e.optimize_spr(1, min(radius, 6))
+                logl, cnt, tr = e.ufboot_state()
+                two.append((s1, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.ufboot_tree_logl().tolist(), logl.tolist(), cnt.tolist(), tr.tolist(),
+                            e.ufboot_counters()["tie_draws"], e.tie_state()))
+            assert two[0] == two[1], ("exchange-path mismatch", alpha, n, P, tie, radius, seed, B, sb, cost is not None)
+            n_echo += 1
+            n_echo_w += cost is not None
     # ---- later iterations of a -bb run: the round-5 shortcuts against the plain two-wait loop
     if n >= 8 and rng.random() < 0.6:
         B = int(rng.integers(2, 50))
@@ -169,4 +210,4 @@ while time.time() < t_end:
 if n_fail:
     sys.exit(f"soak FAILED: {n_fail} later-iteration cases differ")
 print(f"soak ok: {n_grow} start trees (k_grow == host loop), {n_iter} later -bb iterations two ways ({n_quiet} climbs began as plain ones, {n_memo} batches booked without a product); {n_climb} climbs (kernel == host loop), {n_ref} refine sweeps / {n_samples} samples (== per-sample climbs), "
-      f"{n_trk} tracked climbs four ways ({n_early} batches decided from the costs)")
+      f"{n_trk} tracked climbs four ways ({n_early} batches decided from the costs), {n_echo} of them also with the current tree's bookings as device events ({n_echo_w} on the weighted engine)")
