@@ -418,6 +418,11 @@ class Engine {
   // samples for which an acceptance of the current tree would change nothing (see ufb_self_default)
   struct SelfMoot { std::vector<uint8_t> flag; int n_set = 0, n_le = -1, jump_n = -1; uint64_t jump_a = 1, jump_c = 0; };
   void ufb_self_default(const int32_t *rt, int64_t tree_index, int32_t cur_plan, bool &log_open, uint64_t &n_draws, SelfMoot *moot = nullptr);
+  // the update rule of ONE booked tree for ONE sample and the booking of a tree itself, shared by the two-wait loop and the
+  // weighted loop (host/ufboot_common.hpp); dc.on = the deferred mode of the default rule (acceptances go to the log)
+  struct UfbDeferCtx { bool on = false; int32_t cur_plan = 0; bool *log_open = nullptr; SelfMoot *moot = nullptr; };
+  template <class Lookup> void ufb_one_event(uint32_t b, uint32_t s, int64_t &tree_index, bool &looked_up, uint32_t cand_code, Lookup lookup, const UfbDeferCtx &dc);
+  template <class KeyFn> int64_t ufb_book_tree(uint32_t cur_len, bool passes_cut, uint32_t cand_code, bool store_trees, KeyFn key);
   int ufb_moot_ = 1;                             // option "ufb_moot"
   int ufb_memo_ = 1;                             // option "ufb_memo": no product for the batches of a topology known to be event-free (UfbState::quiet_topo)
   // the log of one batch against an explicit topology: touches nothing of the engine but n_ and the tracker's deferred state

@@ -1108,70 +1108,10 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         };
         // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
         // current tree's own bookings, which the host walks through itself
+        const UfbDeferCtx dctx{defer, cur_plan, &log_open, moot_on ? &moot : nullptr};
         auto one_event = [&](const uint32_t b, const uint32_t s, int64_t &tree_index, bool &looked_up, const uint32_t cand_code) {
-            
-            uint32_t &bs = u.boot_score[b];
-            if (u.distinct && !u.mulhits) {
-              if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return lookup_topology(ti, cand_code); }) &&
-                  (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              return;
-            }
-            if (u.mulhits && u.topboot) {
-              // iqtree.cpp:3542-3585: the sample's list is not full yet, or the tree beats its threshold
-              const int32_t rell = -(int32_t)s;
-              if ((int)u.top[b].size() < u.topboot || rell > u.top_thr[b]) {
-                const int64_t newest = (int64_t)u.treels.size() - 1;
-                if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }
-                if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
-                    (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              }
-              return;
-            }
-            if (u.mulhits) {
-              // iqtree.cpp:3498-3540: rell >= boot_logl (an event is exactly that); no draw, boot_counts untouched
-              if (s > bs) return;
-              if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }       // :3500-3514
-              std::set<int64_t> &hs = u.hit_sets[b];
-              if (s < bs) {                                               // :3516-3519
-                for (int64_t t : hs) if (--u.refs[(size_t)t] == 0) u.store.erase(t);
-                hs.clear();
-                bs = s;
-              }
-              if (u.cut_btrees && u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
-              if (hs.insert(tree_index).second) {                         // :3530-3533
-                u.refs[(size_t)tree_index]++;
-                if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              }
-              return;
-            }
-            bool accept = false;
-            if (s < bs) accept = true;                                    // rell > boot_logl + epsilon (:3686)
-            else if (s == bs) {                                           // rell > boot_logl - epsilon: tie, draw (:3687-3688)
-              u.draws++;
-              accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
-            }
-            if (accept && u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                  // :3716-3718
-            if (accept && defer) {
-              u.log.push_back(UfbState::LogEntry{b, cand_code, tree_index, cur_plan});
-              log_open = true;
-              if (moot_on && cand_code != 0xFFFFFFFFu && moot.flag[b]) { moot.flag[b] = 0; moot.n_set--; }   // (it points elsewhere now)
-              if (moot_on && s < bs) moot.n_le = -1;
-              if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
-            } else if (accept) {
-              // the tree "string" (:3689-3707): looked up once per booked tree; the topology itself is remembered as
-              // (prune node, candidate) and materialised after this prune node's scan only if some sample still points to it
-              if (!looked_up) { tree_index = lookup_topology(tree_index, cand_code); looked_up = true; }
-              if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              if (s < bs) { u.boot_counts[b] = 1; bs = s; }              // :3710-3719
-              int64_t &bt = u.boot_trees[b];
-              if (bt != tree_index) {
-                if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
-                u.refs[(size_t)tree_index]++;
-                bt = tree_index;                                          // :3720
-              }
-            }
-            if (s == bs) u.boot_counts[b]++;                              // :3728-3730
-          };
+          ufb_one_event(b, s, tree_index, looked_up, cand_code, lookup_topology, dctx);      // (host/ufboot_common.hpp)
+        };
         auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
           while (ep < events.size() && events[ep].idx < idx) ep++;
           bool looked_up = store_trees;              // (-storetrees: tree_str is set at the top, no lookup per sample)
@@ -1189,21 +1129,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
         // (:3302-3341); one met before is skipped unless the length improved on the recorded one, and then it goes on under
         // its old index without the cut-off test.
         auto book_tree = [&](uint32_t cur_len, bool passes_cut, uint32_t cand_code) -> int64_t {
-          if (store_trees) {
-            const std::string &key = topology_key(cand_code);
-            auto it = u.topo_index.find(key);
-            if (it != u.topo_index.end()) {
-              u.duplicates++;
-              if (cur_len >= u.treels[(size_t)it->second]) return -1;
-              u.treels[(size_t)it->second] = cur_len;
-              return it->second;
-            }
-            if (!passes_cut) return -1;
-            u.topo_index.emplace(key, (int64_t)u.treels.size());
-          } else if (!passes_cut) return -1;
-          u.treels.push_back(cur_len);
-          u.refs.push_back(0);
-          return (int64_t)u.treels.size() - 1;
+          return ufb_book_tree(cur_len, passes_cut, cand_code, store_trees, topology_key);
         };
         if (pl.self_idx >= 0) {
           // rearrangeParsimony's evaluateParsimony(p) + pllSaveCurrentTreeSprParsimony (sprparsimony.cpp:2285-2289): the

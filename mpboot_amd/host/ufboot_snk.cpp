@@ -215,60 +215,10 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         };
         // the update rule of one booked tree for one sample (b, score s): shared by the events the device extracted and by the
         // current tree's own bookings, which the host walks through itself
+        const UfbDeferCtx dctx{};                   // (no deferred mode on this engine)
         auto one_event = [&](const uint32_t b, const uint32_t s, int64_t &tree_index, bool &looked_up, const uint32_t cand_code) {
-            
-            uint32_t &bs = u.boot_score[b];
-            if (u.distinct && !u.mulhits) {
-              if (ufb_distinct_offer(b, -(int32_t)s, tree_index, looked_up, [&](int64_t ti) { return cand_topology_key(cand_code, ti); }) &&
-                  (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              return;
-            }
-            if (u.mulhits && u.topboot) {
-              const int32_t rell = -(int32_t)s;
-              if ((int)u.top[b].size() < u.topboot || rell > u.top_thr[b]) {
-                const int64_t newest = (int64_t)u.treels.size() - 1;
-                if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
-                if (ufb_topboot_offer(b, rell, tree_index, tree_index == newest) &&
-                    (u.pending.empty() || u.pending.back().tree_index != tree_index)) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              }
-              return;
-            }
-            if (u.mulhits) {
-              if (s > bs) return;
-              if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
-              std::set<int64_t> &hs = u.hit_sets[b];
-              if (s < bs) {
-                for (int64_t t : hs) if (--u.refs[(size_t)t] == 0) u.store.erase(t);
-                hs.clear();
-                bs = s;
-              }
-              if (u.cut_btrees && u.cur_logl_now > u.boot_orig[b]) u.boot_orig[b] = u.cur_logl_now;     // :3523-3527
-              if (hs.insert(tree_index).second) {
-                u.refs[(size_t)tree_index]++;
-                if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              }
-              return;
-            }
-            bool accept = false;
-            if (s < bs) accept = true;
-            else if (s == bs) {
-              u.draws++;
-              accept = tie_draw() <= 1.0 / (double)(u.boot_counts[b] + 1);
-            }
-            if (accept) {
-              if (u.cut_btrees) u.boot_orig[b] = u.cur_logl_now;                            // :3716-3718
-              if (!looked_up) { tree_index = cand_topology_key(cand_code, tree_index); looked_up = true; }
-              if (u.pending.empty() || u.pending.back().tree_index != tree_index) u.pending.push_back(UfbState::Pending{tree_index, cand_code});
-              if (s < bs) { u.boot_counts[b] = 1; bs = s; }
-              int64_t &bt = u.boot_trees[b];
-              if (bt != tree_index) {
-                if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
-                u.refs[(size_t)tree_index]++;
-                bt = tree_index;
-              }
-            }
-            if (s == bs) u.boot_counts[b]++;
-          };
+          ufb_one_event(b, s, tree_index, looked_up, cand_code, [&](int64_t ti, uint32_t cc) { return cand_topology_key(cc, ti); }, dctx);
+        };
         auto replay_events = [&](uint32_t idx, int64_t tree_index, uint32_t cand_code) {
           while (ep < events.size() && events[ep].idx < idx) ep++;
           bool looked_up = store_trees;              // (-storetrees: tree_str is set at the top, no lookup per sample)
@@ -285,21 +235,7 @@ int Engine::spr_sweeps_ufboot_snk(int mintrav, int maxtrav, uint32_t randomMP, u
         // (:3302-3341); one met before is skipped unless the length improved on the recorded one, and then it goes on under
         // its old index without the cut-off test.
         auto book_tree = [&](uint32_t cur_len, bool passes_cut, uint32_t cand_code) -> int64_t {
-          if (store_trees) {
-            const std::string &key = topology_key(cand_code);
-            auto it = u.topo_index.find(key);
-            if (it != u.topo_index.end()) {
-              u.duplicates++;
-              if (cur_len >= u.treels[(size_t)it->second]) return -1;
-              u.treels[(size_t)it->second] = cur_len;
-              return it->second;
-            }
-            if (!passes_cut) return -1;
-            u.topo_index.emplace(key, (int64_t)u.treels.size());
-          } else if (!passes_cut) return -1;
-          u.treels.push_back(cur_len);
-          u.refs.push_back(0);
-          return (int64_t)u.treels.size() - 1;
+          return ufb_book_tree(cur_len, passes_cut, cand_code, store_trees, topology_key);
         };
         if (pl.self_idx >= 0) {
           const uint32_t self_len = asym ? out[(size_t)pl.self_idx] : randomMP;       // (:2285: mp of evaluateParsimony(p))
