@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define MPF_ABI_VERSION 7   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
-                               4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep; 6: mpf_compute_parsimony_at */
+#define MPF_ABI_VERSION 8   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
+                               4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep; 6: mpf_compute_parsimony_at;
+                               8: mpf_iq_* (the search loop's own steps between two climbs), mpf_ufboot_merge_* */
 
 enum {
   MPF_OK = 0,
@@ -381,6 +382,25 @@ typedef struct mpf_reps mpf_reps;
 int mpf_reps_create(mpf_reps **out, int32_t device, int32_t n_samples, int32_t n_patterns, const uint16_t *boot /* [B][P] */);
 int mpf_reps_scores(mpf_reps *r, int32_t n_trees, const uint16_t *pattern_pars /* [M][P] */, int32_t *rell /* [M][B] */);
 void mpf_reps_destroy(mpf_reps *r);
+
+/* ---- The steps of IQTree::doTreeSearch BETWEEN two climbs (iqtree.cpp:1631-1965), device-free, on `back` records: for hosts
+   without IQ-TREE's tree classes (bench.py, tests, a C++ driver) that want to run the flow the reference runs -- candidate tree ->
+   floor(0.5 (n - 3)) random NNIs, or every second iteration a re-weighted alignment -> climb.  All draws come from the host's
+   random_double() stream, handed over by state like the climb's own (mpf_set_tie_state / mpf_get_tie_state).  mpboot keeps its own
+   code for these steps; the engine never calls them.  (mpboot_amd/host/iqflow.cpp; second witness oracle/iqflow_slow.py.)
+
+   mpf_iq_random_nnis      IQTree::doRandomNNIs(numNNI) (iqtree.cpp:1083-1106) + PhyloTree::doOneRandomNNI (phylotree.cpp:3665-3711):
+                           per NNI one random_int(n - 3) for the branch and two random_int(1) (always 0: the first neighbour at each
+                           end); a branch that touches a node already used re-lists the branches and takes the same index (:1096-1103).
+                           The listing order and which neighbour is "first" are this library's (ring order from tip 1).
+   mpf_iq_perturb_weights  Alignment::createPerturbAlignment (alignment.cpp:1915-1969; -ratchet_percent 50, -ratchet_wgt 1,
+                           tools.cpp:778-780): n_informative_sites * percent / 100 distinct sites of informative patterns, `add` more
+                           copies of each one's pattern.  out[n_patterns].
+   mpf_iq_topology_key     128-bit digest of the canonical unrooted topology: the key of CandidateSet::topologies (candidateset.cpp:110-150). */
+int mpf_iq_random_nnis(int32_t n_taxa, int32_t *back, int32_t num_nni, uint64_t *tie_state, int32_t *n_relists);
+int mpf_iq_perturb_weights(int32_t n_patterns, const int32_t *weights, const uint8_t *informative, int32_t percent, int32_t add,
+                           uint64_t *tie_state, int32_t *out);
+int mpf_iq_topology_key(int32_t n_taxa, const int32_t *back, uint64_t key[2]);
 
 int mpf_get_stats(const mpf_engine *e, mpf_stats *out);
 int mpf_reset_stats(mpf_engine *e);

@@ -111,53 +111,116 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     # silently drop out of every sample's product
     held = [e.weights() if hasattr(e, "weights") else None for e in engines]
     touched = set()
-    if batched and units:
-        e0 = engines[0]
-        if held[0] is not None and ((held[0] == 0) & (samples[units].max(axis=0) > 0)).any():
-            raise ValueError("refine_boot_trees: engine 0 holds weights that leave a pattern some sample counts without a site -- "
-                             "it must hold the weights the samples were drawn from (set_weights(original) first)")
-        if not attached:
-            e0.ufboot_attach(samples, 0.5, shard=(rank, ws))
-        e0.seed_ties(1, 0)
-        seeds = np.array([shard.unit_seed(base_seed, b) for b in range(B)], dtype=np.int64).astype(np.int32)
-        groups = {}
-        for b in units:
-            groups.setdefault(np.asarray(boot_trees[b], dtype=np.int32).tobytes(), []).append(b)
-        todo = []
-        for key, members in groups.items():
-            t = np.frombuffer(key, dtype=np.int32).copy()
-            e0.reset_node_order()
-            e0.set_tree(t)
-            sc, stable, _first = e0.ufboot_refine_sweep(radius, seeds)
-            for b in members:
-                if stable[b]:
-                    local[b], trees[b] = int(sc[b]), t
-                else:
-                    todo.append(b)
-        if not attached or todo:
-            e0.ufboot_detach()                       # (a climb under an attached tracker would be booked like a search iteration)
-        todo.sort()
-    if len(engines) == 1:
-        for b in todo:
-            touched.add(0)
-            local[b], trees[b] = one(engines[0], b)
-    elif todo:
-        from concurrent.futures import ThreadPoolExecutor
+    try:
+        if batched and units:
+            e0 = engines[0]
+            if held[0] is not None and ((held[0] == 0) & (samples[units].max(axis=0) > 0)).any():
+                raise ValueError("refine_boot_trees: engine 0 holds weights that leave a pattern some sample counts without a site -- "
+                                 "it must hold the weights the samples were drawn from (set_weights(original) first)")
+            if not attached:
+                e0.ufboot_attach(samples, 0.5, shard=(rank, ws))
+            e0.seed_ties(1, 0)
+            seeds = np.array([shard.unit_seed(base_seed, b) for b in range(B)], dtype=np.int64).astype(np.int32)
+            groups = {}
+            for b in units:
+                groups.setdefault(np.asarray(boot_trees[b], dtype=np.int32).tobytes(), []).append(b)
+            todo = []
+            for key, members in groups.items():
+                t = np.frombuffer(key, dtype=np.int32).copy()
+                e0.reset_node_order()
+                e0.set_tree(t)
+                sc, stable, _first = e0.ufboot_refine_sweep(radius, seeds)
+                for b in members:
+                    if stable[b]:
+                        local[b], trees[b] = int(sc[b]), t
+                    else:
+                        todo.append(b)
+            if not attached or todo:
+                e0.ufboot_detach()                       # (a climb under an attached tracker would be booked like a search iteration)
+            todo.sort()
+        if len(engines) == 1:
+            for b in todo:
+                touched.add(0)
+                local[b], trees[b] = one(engines[0], b)
+        elif todo:
+            from concurrent.futures import ThreadPoolExecutor
 
-        def work(k):
-            if todo[k::len(engines)]:
-                touched.add(k)
-            return {b: one(engines[k], b) for b in todo[k::len(engines)]}
+            def work(k):
+                if todo[k::len(engines)]:
+                    touched.add(k)
+                return {b: one(engines[k], b) for b in todo[k::len(engines)]}
 
-        with ThreadPoolExecutor(len(engines)) as ex:
-            for part in ex.map(work, range(len(engines))):
-                for b, (sc, t) in part.items():
-                    local[b], trees[b] = sc, t
-    for k in sorted(touched):
-        if held[k] is not None:
-            engines[k].set_weights(held[k])
+            with ThreadPoolExecutor(len(engines)) as ex:
+                for part in ex.map(work, range(len(engines))):
+                    for b, (sc, t) in part.items():
+                        local[b], trees[b] = sc, t
+    finally:
+        # (also when a climb raises: an engine left on some sample's weights is the silent-drop state the guard above looks for)
+        for k in sorted(touched):
+            if held[k] is not None:
+                engines[k].set_weights(held[k])
     scores, _best, _owner = shard.reduce_best(local, B)
     return scores, trees
+
+
+def bb_run(eng, samples, start_trees, iters, maxtrav=6, seed=1, engines=None, verbose=False, refine=True, search_kw=None):
+    """`-bb` as the reference runs it: the start trees enter the candidate set (phyloanalysis.cpp:1300-1313; they are
+    not booked -- the start-tree phase runs without per-site scores, sprparsimony.cpp:3228), then IQTree::doTreeSearch's iterations
+    (mpboot_amd.search.MpSearch: a random one of the 5 best candidate trees perturbed by floor(0.5 (n - 3)) random NNIs, every second
+    iteration the ratchet's two climbs instead, cut-off = top 10 % of the saved trees) with saveCurrentTree behind every insertion test,
+    then the refinement of every sample's tree (optimizeBootTrees).
+
+    start_trees: [(back, length)].  iters: iterations to run (the reference runs until unsuccess_iterations(n) in a row bring no better
+    tree, iqtree.cpp:129-130: the caller extrapolates).  -> dict; per-iteration dicts in ["log"].  Deterministic for a given seed."""
+    import hashlib
+    import time
+
+    from . import engine, search
+    eng.ufboot_attach(samples, 0.5)
+    eng.seed_ties(engine.TIE_RANDOM, seed)
+    S = search.MpSearch(eng, maxtrav=maxtrav, tracked=True, **(search_kw or {}))
+    for t, length in start_trees:
+        S.add_candidate(t, length)
+    start_best = -S.best_score
+    log = []
+    t_all = time.perf_counter()
+    for _ in range(iters):
+        eng.reset_stats()
+        c0 = eng.ufboot_counters()
+        n0 = len(eng.ufboot_tree_logl()) if verbose else 0
+        info = S.iterate()
+        st = eng.stats()
+        c1 = eng.ufboot_counters()
+        info.update(moves=st["moves_applied"], insertion_tests=st["insertion_tests"], events=c1["events"] - c0["events"],
+                    tie_draws=c1["tie_draws"] - c0["tie_draws"], climb_launches=st["climb_launches"], climb_steps=st["climb_steps"],
+                    climb_nodes=st["climb_nodes"], climb_ms=st["climb_ms_total"], scan_launches=st["scan_launches"])
+        log.append(info)
+        if verbose:
+            print(f"  it {info['iteration']} {'ratchet' if info['ratchet'] else 'nni    '} -> {info['score']} in {info['seconds'] * 1e3:.1f} ms "
+                  f"(perturb {info['perturb_s'] * 1e3:.2f}, after {info['after_s'] * 1e3:.2f}; {info['moves']} moves, {info['insertion_tests']} tests, "
+                  f"{info['events']} events; k_climb {info['climb_launches']} launches {info['climb_steps']} steps {info['climb_ms']:.1f} ms; "
+                  f"scan launches {info['scan_launches']}; booked +{len(eng.ufboot_tree_logl()) - n0})", flush=True)
+    t_iters = time.perf_counter() - t_all
+    logl, counts, bt = eng.ufboot_state()
+    n_saved = len(eng.ufboot_tree_logl())
+    cache, bts = {}, []
+    for b in range(samples.shape[0]):
+        t = int(bt[b])
+        if t not in cache:
+            cache[t] = eng.ufboot_tree(t) if t >= 0 else S.best_tree
+        bts.append(cache[t])
+    state_hash = hashlib.sha256(logl.tobytes() + counts.tobytes() + bt.tobytes() + str(eng.tie_state()).encode()).hexdigest()[:16]
+    eng.ufboot_detach()
+    out = {"iterations_s": t_iters, "log": log, "best_score": int(-S.best_score), "start_best_score": int(start_best), "saved_trees": n_saved,
+           "distinct_boot_trees": len(cache), "state_hash": state_hash, "iterations_left_by_stop_rule": S.iterations_left(),
+           "unsuccess_iterations": S.unsuccess, "last_improved_iteration": S.last_improved, "online_scores": (-logl).astype(np.int64)}
+    if refine:
+        t0 = time.perf_counter()
+        sc, _ = refine_boot_trees(engines or [eng], samples, bts, 11, maxtrav)
+        out["refine_s"] = time.perf_counter() - t0
+        out["mean_refined"] = float(np.mean(sc))
+        out["samples_improved_by_refinement"] = int((np.asarray(sc) < out["online_scores"]).sum())
+    return out
 
 
 def bb_search(eng, samples, start, iters, perturb, maxtrav, seed, ratchet_every=0, verbose=False, engines=None):

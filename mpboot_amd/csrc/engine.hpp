@@ -122,7 +122,16 @@ struct UfbState : books::Deferred {      // (boot_trees, store, refs, topo_index
   std::vector<int32_t> boot_counts;
   // topologies whose complete move-less sweep produced no candidate event, with the widest cut-off (largest admissible length)
   // that held under: nothing to multiply when the search comes back to one (host/ufboot.cpp, `memo`)
+  // The entry speaks of the insertion tests of ONE neighbourhood shape: the key carries the radii the event-free sweep ran under
+  // (a later climb at a larger radius on the same topology has tests the memo never saw -- ADVICE r5).
   std::unordered_map<std::string, uint32_t> quiet_topo;
+  std::string quiet_key(int mintrav, int maxtrav, int n_taxa) const
+  {
+    std::string k = self_key;
+    const int hi = maxtrav < n_taxa - 3 ? maxtrav : n_taxa - 3;        // (no neighbourhood reaches further than the tree does)
+    k.push_back((char)(mintrav & 0xFF)); k.push_back((char)(hi & 0xFF)); k.push_back((char)((hi >> 8) & 0xFF));
+    return k;
+  }
   uint64_t memo_batches = 0;
   // boot_tree_orig_logl (iqtree.h:766, -cutoff_from_btrees): the logl under which each sample's tree was booked; cur_logl_now = that
   // of the tree the replay has in hand (on ratchet climbs the value saveCurrentTree replaced it by)

@@ -158,6 +158,9 @@ def load_library():
         L.mpf_remain_bounds.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_cost_matrix_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, vp]
         L.mpf_cost_matrix_triangle_fix.argtypes = [C.c_int32, vp, vp]
+        L.mpf_iq_random_nnis.argtypes = [C.c_int32, vp, C.c_int32, vp, vp]
+        L.mpf_iq_perturb_weights.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
+        L.mpf_iq_topology_key.argtypes = [C.c_int32, vp, vp]
         _lib = L
     return _lib
 
@@ -208,6 +211,35 @@ def remain_bounds(segment_upper, min_unit_pars, weight) -> np.ndarray:
     return out[:len(up) - 1]
 
 
+def iq_random_nnis(back: np.ndarray, num_nni: int, tie_state: int):
+    """IQTree::doRandomNNIs (iqtree.cpp:1083-1106) on a copy of `back` -> (perturbed back, stream state behind the draws, re-listings)."""
+    b = np.ascontiguousarray(back, dtype=np.int32).copy()
+    n = (len(b) // 3 + 1) // 2
+    st = C.c_uint64(tie_state & ((1 << 64) - 1))
+    rl = C.c_int32()
+    _chk(load_library().mpf_iq_random_nnis(n, _p(b), int(num_nni), C.byref(st), C.byref(rl)))
+    return b, int(st.value), int(rl.value)
+
+
+def iq_perturb_weights(weights, informative, percent: int, add: int, tie_state: int):
+    """Alignment::createPerturbAlignment (alignment.cpp:1915-1969) as pattern weights -> (weights, stream state behind the draws)."""
+    w = np.ascontiguousarray(weights, dtype=np.int32)
+    inf = np.ascontiguousarray(informative, dtype=np.uint8)
+    out = np.zeros_like(w)
+    st = C.c_uint64(tie_state & ((1 << 64) - 1))
+    _chk(load_library().mpf_iq_perturb_weights(len(w), _p(w), _p(inf), int(percent), int(add), C.byref(st), _p(out)))
+    return out, int(st.value)
+
+
+def iq_topology_key(back: np.ndarray) -> bytes:
+    """16-byte digest of the canonical unrooted topology (the key CandidateSet::topologies looks trees up by)."""
+    b = np.ascontiguousarray(back, dtype=np.int32)
+    n = (len(b) // 3 + 1) // 2
+    key = np.zeros(2, dtype=np.uint64)
+    _chk(load_library().mpf_iq_topology_key(n, _p(b), _p(key)))
+    return key.tobytes()
+
+
 def encode_iqtree_states(states: np.ndarray, datatype: int = DNA) -> np.ndarray:
     """Alignment::convertState codes -> PLL tip codes (host only, no GPU needed)."""
     states = np.ascontiguousarray(states, dtype=np.int8)
@@ -256,6 +288,7 @@ class RcclComm:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         _chk(L.mpf_rccl_create(C.byref(self.h), buf, rank, world, device))
         self.rank, self.world = rank, world
+        self._users = 0                          # engines whose tracker holds self.h as its exchange argument
 
     @staticmethod
     def available() -> bool:
@@ -278,7 +311,12 @@ class RcclComm:
         return {"exchanges": a.value, "overflows": b.value}
 
     def close(self):
+        """Frees the native communicator.  Refused while an engine's tracker still has it registered as its exchange
+        (mpf_ufboot_attach_sharded stored the raw handle: a later climb or the closing handshake would call into freed memory);
+        detach or close those engines first."""
         if getattr(self, "h", None):
+            if getattr(self, "_users", 0) > 0:
+                raise MpfError(-1, "RcclComm.close(): %d engine(s) still attached through this communicator -- ufboot_detach() them first" % self._users)
             load_library().mpf_rccl_destroy(self.h)
             self.h = None
 
@@ -316,10 +354,17 @@ class FitchEngine:
         _chk(L.mpf_get_geometry(self.h, C.byref(s), C.byref(w), C.byref(ni), C.byref(wp)))
         self.S, self.W, self.num_informative, self.Wp = s.value, w.value, ni.value, wp.value
 
+    def _drop_exchange(self):
+        ex = getattr(self, "_ufb_exchange", None)
+        if isinstance(ex, RcclComm):
+            ex._users -= 1
+        self._ufb_exchange = None
+
     def close(self):
         if getattr(self, "h", None):
             load_library().mpf_engine_destroy(self.h)
             self.h = None
+            self._drop_exchange()
 
     def __del__(self):
         try:
@@ -482,6 +527,7 @@ class FitchEngine:
         self.ufb_B = samples.shape[0]
         if shard is None or shard[1] == 1:
             _chk(load_library().mpf_ufboot_attach(self.h, self.ufb_B, _p(samples), float(epsilon)))
+            self._drop_exchange()
             return
         rank, world = shard
         ids = np.arange(rank, self.ufb_B, world, dtype=np.int32)
@@ -489,11 +535,14 @@ class FitchEngine:
         if exchange is None:
             from . import shard as _shard
             exchange = _shard.event_exchange()
-        self._ufb_exchange = exchange            # keep the ctypes callback (or the native communicator) alive as long as the tracker
+        self._drop_exchange()
         if isinstance(exchange, RcclComm):       # the library's own exchange: mpf_rccl_exchange with the communicator as its argument
             fn = C.cast(load_library().mpf_rccl_exchange, C.c_void_p)
             _chk(load_library().mpf_ufboot_attach_sharded(self.h, self.ufb_B, len(ids), _p(ids), _p(local), float(epsilon), fn, exchange.h))
+            self._ufb_exchange = exchange
+            exchange._users += 1                 # (RcclComm.close() refuses while a tracker holds the raw handle)
             return
+        self._ufb_exchange = exchange            # keep the ctypes callback alive as long as the tracker
         _chk(load_library().mpf_ufboot_attach_sharded(self.h, self.ufb_B, len(ids), _p(ids), _p(local), float(epsilon),
                                                       C.cast(exchange, C.c_void_p), None))
 
@@ -512,6 +561,7 @@ class FitchEngine:
 
     def ufboot_detach(self):
         _chk(load_library().mpf_ufboot_detach(self.h))
+        self._drop_exchange()
 
     def ufboot_set_cutoff(self, logl_cutoff: float):
         _chk(load_library().mpf_ufboot_set_cutoff(self.h, float(logl_cutoff)))

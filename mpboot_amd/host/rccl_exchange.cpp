@@ -41,7 +41,7 @@ struct Api {
   const char *(*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
-constexpr int kNcclUint32 = 3, kNcclMin = 3;       // ncclDataType_t / ncclRedOp_t (rccl.h:451, :462)
+constexpr int kNcclUint32 = 3, kNcclMax = 2, kNcclMin = 3;      // ncclDataType_t / ncclRedOp_t (rccl.h:451, :462)
 
 Api &api()
 {
@@ -188,15 +188,31 @@ int mpf_rccl_exchange(void *arg, uint32_t tag, const mpf_ufb_event *local, uint3
     // (rare: more events than a block holds -- the remainder in an all-gather of exactly the size the largest rank needs)
     c->n_overflows++;
     if (over > c->over_cap) {
+      // Every rank sees the same `over` and keeps the same over_cap, so all of them come here together.  An allocation that fails
+      // on ONE rank must not leave the others waiting in the gather below: the ranks agree on the outcome first (one all-reduce of
+      // a status word; this path runs once per growth of the buffers) and return non-zero together.
       if (c->d_over_s) (void)hipFree(c->d_over_s);
       if (c->d_over_r) (void)hipFree(c->d_over_r);
       if (c->h_over_r) (void)hipHostFree(c->h_over_r);
       c->d_over_s = c->d_over_r = c->h_over_r = nullptr;
       c->over_cap = 0;
       const size_t cap = (size_t)over + over / 2 + 64;
-      if (hipMalloc((void **)&c->d_over_s, cap * 12) != hipSuccess) return 1;
-      if (hipMalloc((void **)&c->d_over_r, cap * 12 * (size_t)c->world) != hipSuccess) return 1;
-      if (hipHostMalloc((void **)&c->h_over_r, cap * 12 * (size_t)c->world, hipHostMallocDefault) != hipSuccess) return 1;
+      uint32_t bad = 0;
+      if (hipMalloc((void **)&c->d_over_s, cap * 12) != hipSuccess) bad = 1;
+      if (!bad && hipMalloc((void **)&c->d_over_r, cap * 12 * (size_t)c->world) != hipSuccess) bad = 1;
+      if (!bad && hipHostMalloc((void **)&c->h_over_r, cap * 12 * (size_t)c->world, hipHostMallocDefault) != hipSuccess) bad = 1;
+      c->h_send[0] = bad;
+      if (hipMemcpyAsync(c->d_send, c->h_send, 4, hipMemcpyHostToDevice, c->st) != hipSuccess) return 1;
+      if (api().AllReduce(c->d_send, c->d_send, 1, kNcclUint32, kNcclMax, c->comm, c->st)) return 1;
+      if (hipMemcpyAsync(c->h_send, c->d_send, 4, hipMemcpyDeviceToHost, c->st) != hipSuccess) return 1;
+      if (hipStreamSynchronize(c->st) != hipSuccess) return 1;
+      if (c->h_send[0]) {
+        if (c->d_over_s) (void)hipFree(c->d_over_s);
+        if (c->d_over_r) (void)hipFree(c->d_over_r);
+        if (c->h_over_r) (void)hipHostFree(c->h_over_r);
+        c->d_over_s = c->d_over_r = c->h_over_r = nullptr;
+        return 3;                                  // some rank is out of memory: every rank leaves here
+      }
       c->over_cap = cap;
     }
     if (n_local > kEventBlock &&

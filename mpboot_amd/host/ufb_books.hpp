@@ -271,8 +271,12 @@ struct LogWorker {
         if (FILE *fp = std::fopen(path, "r")) {
           char buf[256] = {0};
           if (std::fgets(buf, sizeof buf, fp)) {
-            cpu_set_t set;
+            cpu_set_t set, allowed;
             CPU_ZERO(&set);
+            CPU_ZERO(&allowed);
+            // only CPUs the caller itself may run on (taskset / numactl / a launcher's per-rank binding): the worker never leaves the
+            // mask its process was given; no such sibling -> no pinning
+            const bool have_mask = sched_getaffinity(0, sizeof allowed, &allowed) == 0;
             int n_set = 0;
             for (char *p = buf; *p && *p != '\n';) {
               char *end = nullptr;
@@ -281,7 +285,8 @@ struct LogWorker {
               long b = a;
               p = end;
               if (*p == '-') { b = std::strtol(p + 1, &end, 10); p = end; }
-              for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c != cpu) { CPU_SET((int)c, &set); n_set++; }
+              for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+                if (c != cpu && (!have_mask || CPU_ISSET((int)c, &allowed))) { CPU_SET((int)c, &set); n_set++; }
               if (*p == ',') p++;
             }
             if (n_set > 0) (void)pthread_setaffinity_np(th.native_handle(), sizeof set, &set);

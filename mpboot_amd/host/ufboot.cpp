@@ -764,7 +764,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
       bool memo = false;
       if (compact && defer && host_self && ufb_memo_ && !u.quiet_topo.empty()) {
         if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-        const auto it = u.quiet_topo.find(u.self_key);
+        const auto it = u.quiet_topo.find(u.quiet_key(mintrav, maxtrav, n_));
         memo = it != u.quiet_topo.end() && mp_max <= it->second;
       }
       if (memo) { n_rows = 0; u.memo_batches++; }
@@ -1251,7 +1251,7 @@ int Engine::spr_sweeps_ufboot(int mintrav, int maxtrav, uint32_t randomMP, uint3
     }
     if (sw_full && !sw_moved && sw_events == 0 && i > total && defer && host_self && ufb_memo_) {
       if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-      uint32_t &v = u.quiet_topo[u.self_key];
+      uint32_t &v = u.quiet_topo[u.quiet_key(mintrav, maxtrav, n_)];
       v = std::max(v, sw_mp_max);
     }
   } while (randomMP < startMP && !visits_out());

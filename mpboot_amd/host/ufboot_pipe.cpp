@@ -540,7 +540,7 @@ int Engine::spr_sweeps_ufboot_pipe(int mintrav, int maxtrav, uint32_t randomMP, 
     }
     if (!sw_moved && sw_events == 0 && i > total && host_self && ufb_memo_) {       // (no cut-off in force here: every insertion test was multiplied)
       if (u.self_key_epoch != (uint64_t)topo_epoch_) { canonical_topology(back_, u.self_key); u.self_key_epoch = (uint64_t)topo_epoch_; }
-      u.quiet_topo[u.self_key] = UINT32_MAX;
+      u.quiet_topo[u.quiet_key(mintrav, maxtrav, n_)] = UINT32_MAX;
     }
   } while (randomMP < startMP && !visits_out());
   ufb_drain_log();

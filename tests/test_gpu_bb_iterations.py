@@ -98,3 +98,78 @@ def test_the_search_came_back_to_known_optima_without_multiplying():
     """(behind the runs above) batches of a topology whose complete move-less sweep had produced no candidate event before are
     booked without a product (UfbState::quiet_topo) -- and the oracle comparison above held with them"""
     assert memo_batches and max(memo_batches) > 0
+
+
+@pytest.mark.parametrize("n,P,alphabet,maxtrav,rate", [(40, 1500, "DNA", 6, 0.07), (64, 2500, "DNA", 4, 0.12), (30, 600, "AA", 6, 0.1)])
+def test_the_reference_search_flow_matches_the_oracle(n, P, alphabet, maxtrav, rate):
+    """IQTree::doTreeSearch as mpboot runs it (mpboot_amd.search.MpSearch; iqtree.cpp:1631-1965): a random one of the best candidate
+    trees, floor(0.5 (n - 3)) random NNIs with doRandomNNIs' used-node rule (:1083-1106) -- every second iteration the ratchet's
+    re-weighted climb + the climb on the original alignment instead (:1694-1716, :1819-1851) --, cut-off = top 10 % of the saved
+    trees, all draws (candidate, NNIs, re-weighted sites, ties, bookkeeping) from ONE stream.  The same loop drives the engine and
+    the oracle; after every iteration every observable of the two must agree."""
+    from mpboot_amd import engine, search, synth, trees
+    from oracle import pyoracle as po
+    letters, _ = synth.synth_alignment(n, P, alphabet, rate, seed=n + P + 1)
+    codes = synth.letters_to_codes(letters, alphabet)
+    dt_e, dt_o = (engine.DNA, po.DNA) if alphabet == "DNA" else (engine.AA, po.AA)
+    e = engine.FitchEngine(codes, datatype=dt_e)
+    o = po.Oracle(codes, datatype=dt_o)
+    samples = np.random.default_rng(3).multinomial(P, np.ones(P) / P, size=60).astype(np.uint16)
+    # start trees (phyloanalysis.cpp:1270-1317: not booked), the same ones for both
+    starts = []
+    for k in range(4):
+        e.seed_ties(engine.TIE_RANDOM, 1 + k)
+        e.make_parsimony_tree(1 + (k + 1) * 12345, maxtrav)
+        t = e.get_tree()
+        starts.append((t, e.score_tree()))
+        assert o.score_tree(t) == starts[-1][1]
+    o.trace(True)
+    S = []
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.ufboot_attach(samples)
+        x.seed_ties(mode, 21)
+        s = search.MpSearch(x, maxtrav=maxtrav, tracked=True, weights=np.ones(P, dtype=np.int32), unsuccess=10)
+        for t, length in starts:
+            s.add_candidate(t, length)
+        S.append(s)
+    kinds = []
+    for _ in range(10):
+        ie, io = S[0].iterate(), S[1].iterate()
+        assert (ie["ratchet"], ie["score"], ie.get("better")) == (io["ratchet"], io["score"], io.get("better"))
+        assert ie.get("perturbed_score") == io.get("perturbed_score")
+        _same(e, o)
+        assert S[0].cands._scores == S[1].cands._scores and [k for k, _t in S[0].cands._items] == [k for k, _t in S[1].cands._items]
+        assert S[0].last_improved == S[1].last_improved and S[0].stop() == S[1].stop()
+        kinds.append(ie["ratchet"])
+    assert kinds == [False, True] * 5                            # ratchet_iter = 1: every second iteration (tools.cpp:778)
+    assert e.stats()["climb_launches"] > 0                       # the dense stretches of these climbs ran in the persistent kernel
+
+
+def test_a_larger_radius_on_a_known_optimum_is_not_taken_for_known():
+    """UfbState::quiet_topo remembers topologies whose complete move-less sweep produced no candidate event -- for the
+    neighbourhoods of THAT sweep.  A later climb at a larger radius on the same topology tests insertions the memo never saw
+    (ADVICE r5): the entry is keyed on the radii, and the books must follow the oracle."""
+    from mpboot_amd import engine, synth, trees
+    from oracle import pyoracle as po
+    n, P = 48, 1800
+    letters, _ = synth.synth_alignment(n, P, "DNA", 0.09, seed=77)
+    codes = synth.letters_to_codes(letters, "DNA")
+    e, o = engine.FitchEngine(codes), po.Oracle(codes)
+    samples = np.random.default_rng(4).multinomial(P, np.ones(P) / P, size=80).astype(np.uint16)
+    start = trees.random_topology(n, np.random.default_rng(2))
+    o.trace(True)
+    for x, mode in ((e, engine.TIE_RANDOM), (o, po.TIE_RANDOM)):
+        x.set_tree(start)
+        x.seed_ties(mode, 5)
+        x.ufboot_attach(samples)
+    for radius, cut in ((2, False), (2, True), (6, True), (3, True), (7, True)):
+        if cut:
+            c = e.ufboot_next_cutoff(10)
+            c = c if c != 0.0 else -float(e.score_tree() + 3)   # (few trees booked yet: a cut-off just above the optimum)
+            e.ufboot_set_cutoff(c)
+            o.ufboot_set_cutoff(c)
+        t = e.get_tree()
+        for x in (e, o):
+            x.set_tree(t)
+        assert e.optimize_spr(1, radius) == o.optimize_spr(1, radius)
+        _same(e, o)

@@ -205,4 +205,11 @@ def test_native_rccl_exchange_on_one_rank():
         assert (e.get_tree() == ref.get_tree()).all() and e.tie_state() == ref.tie_state()
         assert e.ufboot_counters()["tie_draws"] == ref.ufboot_counters()["tie_draws"]
         assert e.ufboot_tree_logl().tolist() == ref.ufboot_tree_logl().tolist()
+        e.ufboot_detach()                                 # (the tracker holds comm.h as its exchange argument: release it before the communicator goes)
+    # the Python face counts the engines attached through a communicator and refuses to free it under them
+    e2 = engine.FitchEngine(codes)
+    e2.ufboot_attach(samples, 0.5, shard=(0, 2), exchange=comm)
+    with pytest.raises(engine.MpfError):
+        comm.close()
+    e2.ufboot_detach()
     comm.close()
