@@ -36,7 +36,7 @@ extern "C" {
 
 #define MPF_ABI_VERSION 8   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
                                4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep; 6: mpf_compute_parsimony_at;
-                               8: mpf_iq_* (the search loop's own steps between two climbs), mpf_ufboot_merge_* */
+                               8: mpf_iq_* (the search loop's own steps between two climbs), mpf_ufboot_adopt */
 
 enum {
   MPF_OK = 0,
@@ -372,6 +372,13 @@ int mpf_ufboot_tree_logl(const mpf_engine *e, double *out /* [n_trees] */);
 int mpf_ufboot_get_state(const mpf_engine *e, double *boot_logl, int32_t *boot_counts, int32_t *boot_trees);
 /* topology of a tree some sample currently points to (boot_trees[b]), as back[] */
 int mpf_ufboot_get_tree(const mpf_engine *e, int64_t tree_index, int32_t *back);
+/* Iteration-parallel -bb (the reference's parallel form distributes the ITERATIONS of doTreeSearch over processes that meet from time
+   to time, README.md:71-78): books another chain of the same run keeps.  Update k offers sample[k] the tree tree_of[k] (one of
+   n_trees topologies, backs[n_trees][3 (2n - 1)], lengths[] = their lengths on the original alignment) at REPS length score[k]; a
+   sample takes it when it is STRICTLY shorter than what it holds (the strict branch of saveCurrentTree's rule, iqtree.cpp:3686,
+   :3710-3720; equal lengths keep the holder, no draw).  Default update rule, unsharded tracker, between two climbs. */
+int mpf_ufboot_adopt(mpf_engine *e, int32_t n_updates, const int32_t *sample, const uint32_t *score, const int32_t *tree_of, int32_t n_trees,
+                     const int32_t *backs, const uint32_t *lengths, int32_t *n_taken);
 int mpf_ufboot_get_counters(const mpf_engine *e, uint64_t *tie_draws, uint64_t *events, uint64_t *reps_rows, double *reps_kernel_ms);
 
 /* REPS -- resampling parsimony scores of candidate trees under B bootstrap weight vectors, the inner loop of

@@ -345,6 +345,12 @@ int mpf_ufboot_get_tree(const mpf_engine *e, int64_t tree_index, int32_t *back)
   if (!back) { set_error("null output"); return MPF_E_INVALID; }
   return e->eng.ufboot_tree(tree_index, back);
 }
+int mpf_ufboot_adopt(mpf_engine *e, int32_t n_updates, const int32_t *sample, const uint32_t *score, const int32_t *tree_of, int32_t n_trees,
+                     const int32_t *backs, const uint32_t *lengths, int32_t *n_taken)
+{
+  NEED(e);
+  return e->eng.ufboot_adopt(n_updates, sample, score, tree_of, n_trees, backs, lengths, n_taken);
+}
 int mpf_ufboot_refine_sweep(mpf_engine *e, int32_t maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit)
 {
   NEED(e);

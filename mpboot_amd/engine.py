@@ -158,6 +158,7 @@ def load_library():
         L.mpf_remain_bounds.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_cost_matrix_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, vp]
         L.mpf_cost_matrix_triangle_fix.argtypes = [C.c_int32, vp, vp]
+        L.mpf_ufboot_adopt.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.mpf_iq_random_nnis.argtypes = [C.c_int32, vp, C.c_int32, vp, vp]
         L.mpf_iq_perturb_weights.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
         L.mpf_iq_topology_key.argtypes = [C.c_int32, vp, vp]
@@ -657,6 +658,19 @@ class FitchEngine:
         back = np.empty(self.nrec, dtype=np.int32)
         _chk(load_library().mpf_ufboot_get_tree(self.h, int(tree_index), _p(back)))
         return back
+
+    def ufboot_adopt(self, samples, scores, tree_of, trees, lengths) -> int:
+        """mpf_ufboot_adopt: books of another search chain of the same run -- sample samples[k] is offered trees[tree_of[k]] at REPS
+        length scores[k] and takes it when that is strictly shorter than what it holds.  -> number of samples that took one."""
+        sm = np.ascontiguousarray(samples, dtype=np.int32)
+        sc = np.ascontiguousarray(scores, dtype=np.uint32)
+        to = np.ascontiguousarray(tree_of, dtype=np.int32)
+        tr = np.ascontiguousarray(trees, dtype=np.int32).reshape(-1, 3 * (2 * self.n - 1)) if len(trees) else np.zeros((0, 3 * (2 * self.n - 1)), dtype=np.int32)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        assert len(sm) == len(sc) == len(to) and len(tr) == len(ln)
+        k = C.c_int32()
+        _chk(load_library().mpf_ufboot_adopt(self.h, len(sm), _p(sm), _p(sc), _p(to), len(tr), _p(tr), _p(ln), C.byref(k)))
+        return int(k.value)
 
     def ufboot_counters(self) -> dict:
         d, e, r, ms = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()

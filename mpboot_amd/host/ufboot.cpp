@@ -325,6 +325,64 @@ int Engine::ufboot_tree(int64_t tree_index, int32_t *back) const
   return MPF_OK;
 }
 
+// Books that another search chain of the SAME run keeps (iteration-parallel -bb: several engines / ranks run different iterations
+// of IQTree::doTreeSearch and meet every few iterations, as the reference's MPI branches do, README.md:71-78): a sample for which
+// the other chain holds a strictly shorter tree takes that tree over -- the rule saveCurrentTree applies to a strictly better
+// tree (iqtree.cpp:3686, :3710-3720: boot_logl, boot_counts = 1 then counted once, boot_trees), with the tree entering
+// treels_logl under its length on the original alignment like any booked tree.  Equal lengths keep the holder (no draw: the
+// chains' streams are their own).  Default update rule, unsharded tracker, between two climbs.
+int Engine::ufboot_adopt(int n_upd, const int32_t *sample, const uint32_t *score, const int32_t *tree_of, int n_trees, const int32_t *backs,
+                         const uint32_t *lengths, int32_t *n_taken)
+{
+  if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }
+  UfbState &u = *ufb_;
+  if (u.mulhits || u.topboot || u.distinct || u.store_trees || u.exchange || !u.ids_identity) {
+    set_error("mpf_ufboot_adopt: default update rule on an unsharded tracker only");
+    return MPF_E_UNSUPPORTED;
+  }
+  if (n_upd < 0 || n_trees < 0 || (n_upd && (!sample || !score || !tree_of)) || (n_trees && (!backs || !lengths))) { set_error("mpf_ufboot_adopt: bad argument"); return MPF_E_INVALID; }
+  ufb_drain_log();
+  const size_t nrec = 3 * (size_t)(2 * n_ - 1);
+  std::vector<int64_t> idx((size_t)n_trees, -1);
+  std::vector<int32_t> bk(nrec);
+  std::string key;
+  int taken = 0;
+  for (int k = 0; k < n_upd; k++) {
+    const int b = sample[k], t = tree_of[k];
+    if (b < 0 || b >= u.B || t < 0 || t >= n_trees) { set_error("mpf_ufboot_adopt: index out of range"); return MPF_E_INVALID; }
+    if (score[k] >= u.boot_score[(size_t)b]) continue;
+    if (idx[(size_t)t] < 0) {
+      std::memcpy(bk.data(), backs + (size_t)t * nrec, nrec * sizeof(int32_t));
+      for (int v = 1; v <= 2 * n_ - 2; v++)
+        for (int sl = 0; sl < (v <= n_ ? 1 : 3); sl++) {
+          const int r = 3 * v + sl, bb = bk[(size_t)r];
+          if (bb < 3 || bb >= (int)nrec || bk[(size_t)bb] != r) { set_error("mpf_ufboot_adopt: inconsistent back links"); return MPF_E_INVALID; }
+        }
+      canonical_topology(bk, key);
+      auto ins = u.topo_index.emplace(key, (int64_t)u.treels.size());
+      if (ins.second) { u.treels.push_back(lengths[t]); }
+      idx[(size_t)t] = ins.first->second;
+      if (u.refs.size() <= (size_t)idx[(size_t)t]) u.refs.resize((size_t)idx[(size_t)t] + 1 + u.refs.size() / 2, 0);
+      if (!u.store.count(idx[(size_t)t])) u.store.emplace(idx[(size_t)t], bk);
+    }
+    const int64_t ti = idx[(size_t)t];
+    u.boot_score[(size_t)b] = score[k];
+    u.boot_counts[(size_t)b] = 2;                              // = 1 on the strict improvement, counted once more as an equal (:3710, :3728-3730)
+    if (u.cut_btrees) u.boot_orig[(size_t)b] = -(int32_t)lengths[t];
+    int64_t &bt = u.boot_trees[(size_t)b];
+    if (bt != ti) {
+      u.refs[(size_t)ti]++;
+      if (bt >= 0 && --u.refs[(size_t)bt] == 0) u.store.erase(bt);
+      bt = ti;
+    }
+    taken++;
+  }
+  for (int t = 0; t < n_trees; t++)                            // (a topology stored for nothing: no sample took it)
+    if (idx[(size_t)t] >= 0 && u.refs[(size_t)idx[(size_t)t]] == 0) u.store.erase(idx[(size_t)t]);
+  if (n_taken) *n_taken = taken;
+  return MPF_OK;
+}
+
 int Engine::ufboot_counters(uint64_t *draws, uint64_t *events, uint64_t *gemm_rows, double *gemm_ms) const
 {
   if (!ufb_) { set_error("no UFBoot tracker attached"); return MPF_E_STATE; }

@@ -197,9 +197,23 @@ class MpSearch:
             info["better"] = True
         self.cands.update(tree.copy(), cur)
         self.cur_it += 1
+        self._last_tree = tree.copy()
+        info["_tree"] = self._last_tree
         info.update(score=s, seconds=time.perf_counter() - t0, after_s=time.perf_counter() - t3)
         self.log.append(info)
         return info
+
+    def log_tree(self, info) -> bytes:
+        """the tree an iteration ended on, as bytes (for the exchange of an iteration-parallel run)"""
+        return np.ascontiguousarray(info["_tree"], dtype=np.int32).tobytes()
+
+    def absorb(self, tree, length: int):
+        """the result of ANOTHER chain's iteration: into the candidate set, and the best tree if it is one (iteration-parallel runs)"""
+        tree = np.asarray(tree, dtype=np.int32).copy()
+        cur = -float(length)
+        if cur > self.best_score:
+            self.best_score, self.best_tree, self.best_key = cur, tree, _engine.iq_topology_key(tree)
+        self.cands.update(tree, cur)
 
     def iterations_left(self) -> int:
         return max(0, self.last_improved + self.unsuccess - self.cur_it + 1)

@@ -1296,6 +1296,46 @@ int orc_ufboot_tree(const orc *o, int tree_index, int *back)
     if (o->ufb_store_idx[i] == tree_index) { memcpy(back, o->ufb_store_back[i], sizeof(int) * 3 * (2 * o->n - 1)); return 1; }
   return 0;
 }
+/* Books of another search chain of the same run (iteration-parallel -bb; the engine's mpf_ufboot_adopt): sample[k] is offered tree
+   tree_of[k] at REPS length score[k] and takes it when strictly better -- the strict branch of the default update rule
+   (iqtree.cpp:3686, :3710-3720: rell > boot_logl + epsilon -> boot_logl, boot_counts = 1 and counted once more at :3728-3730,
+   boot_trees through the tree-string map :3689-3707); the tree enters treels_logl under its length on the original alignment. */
+int orc_ufboot_adopt(orc *o, int n_upd, const int *sample, const unsigned *score, const int *tree_of, int n_trees, const int *backs,
+                     const unsigned *lengths)
+{
+  const int nrec = 3 * (2 * o->n - 1);
+  int *save = (int *)malloc(sizeof(int) * nrec), *idx = (int *)malloc(sizeof(int) * (n_trees > 0 ? n_trees : 1));
+  int k, taken = 0;
+  memcpy(save, o->back, sizeof(int) * nrec);
+  for (k = 0; k < n_trees; k++) idx[k] = -1;
+  for (k = 0; k < n_upd; k++) {
+    const int b = sample[k], t = tree_of[k];
+    const double rell = -(double)score[k];
+    if (!(rell > o->ufb_logl[b] + o->ufb_eps)) continue;
+    if (idx[t] < 0) {
+      int ti;
+      memcpy(o->back, backs + (size_t)t * nrec, sizeof(int) * nrec);
+      ti = ufb_lookup_topology(o, o->ufb_ntrees);
+      if (ti == o->ufb_ntrees) {
+        if (o->ufb_ntrees == o->ufb_treels_cap) {
+          o->ufb_treels_cap = o->ufb_treels_cap ? 2 * o->ufb_treels_cap : 1024;
+          o->ufb_treels = (double *)realloc(o->ufb_treels, sizeof(double) * o->ufb_treels_cap);
+        }
+        o->ufb_treels[o->ufb_ntrees++] = -(double)lengths[t];
+      }
+      ufb_store_tree(o, ti);
+      idx[t] = ti;
+    }
+    o->ufb_logl[b] = rell;
+    o->ufb_counts[b] = 2;
+    o->ufb_trees[b] = idx[t];
+    if (o->ufb_cut_btrees) o->ufb_orig[b] = -(int)lengths[t];
+    taken++;
+  }
+  memcpy(o->back, save, sizeof(int) * nrec);
+  free(save); free(idx);
+  return taken;
+}
 /* the per-iteration cut-off update, "top cutoff_percent %" rule (iqtree.cpp:1662-1676, cutoff_percent = 10 tools.cpp:793) */
 static int cmp_desc(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return x < y ? 1 : x > y ? -1 : 0; }
 void orc_ufboot_set_cutoff_from_btrees(orc *o, int on) { o->ufb_cut_btrees = on != 0; }

@@ -100,6 +100,9 @@ unsigned long long orc_ufboot_draws(const orc *o);
 void orc_ufboot_tree_logl(const orc *o, double *out);
 void orc_ufboot_state(const orc *o, double *boot_logl, int *boot_counts, int *boot_trees);
 int orc_ufboot_tree(const orc *o, int tree_index, int *back); /* 1 if that tree was accepted by some sample */
+/* books of another search chain of the same run: strictly better (sample, tree) offers are taken (iqtree.cpp:3686, :3710-3720) */
+int orc_ufboot_adopt(orc *o, int n_upd, const int *sample, const unsigned *score, const int *tree_of, int n_trees, const int *backs,
+                     const unsigned *lengths);
 double orc_ufboot_next_cutoff(const orc *o, int percent);     /* iqtree.cpp:1662-1676; with -cutoff_from_btrees :1657-1660 */
 void orc_ufboot_set_cutoff_from_btrees(orc *o, int on);       /* params->cutoff_from_btrees (tools.cpp:2442): boot_tree_orig_logl kept at every acceptance */
 void orc_ufboot_orig_logl(const orc *o, int *out);            /* boot_tree_orig_logl [B] */

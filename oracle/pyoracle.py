@@ -108,6 +108,8 @@ def lib():
         L.orc_ufboot_draws.argtypes = [vp]
         L.orc_ufboot_tree_logl.argtypes = [vp, vp]
         L.orc_ufboot_state.argtypes = [vp, vp, vp, vp]
+        L.orc_ufboot_adopt.restype = ci
+        L.orc_ufboot_adopt.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp]
         L.orc_ufboot_tree.restype = ci
         L.orc_ufboot_tree.argtypes = [vp, ci, vp]
         L.orc_ufboot_next_cutoff.restype = C.c_double
@@ -131,6 +133,7 @@ class Oracle:
         if weights is None:
             weights = np.ones(self.P, dtype=np.int32)
         weights = np.ascontiguousarray(weights, dtype=np.int32)
+        self._w = weights.copy()
         if cost is None:
             self.h = lib().orc_create(self.n, self.P, datatype, _p(codes), _p(weights), int(keep_all))
         else:
@@ -166,6 +169,7 @@ class Oracle:
 
     def set_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.int32)
+        self._w = w.copy()
         lib().orc_set_weights(self.h, _p(w))
 
     def enable_persite(self, on=True):
@@ -344,6 +348,20 @@ class Oracle:
         back = np.empty(self.nrec, dtype=np.int32)
         ok = lib().orc_ufboot_tree(self.h, int(tree_index), _p(back))
         return back if ok else None
+
+    def ufboot_adopt(self, samples, scores, tree_of, trees, lengths) -> int:
+        sm = np.ascontiguousarray(samples, dtype=np.int32)
+        sc = np.ascontiguousarray(scores, dtype=np.uint32)
+        to = np.ascontiguousarray(tree_of, dtype=np.int32)
+        tr = np.ascontiguousarray(trees, dtype=np.int32).reshape(-1, self.nrec) if len(trees) else np.zeros((0, self.nrec), dtype=np.int32)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        return int(lib().orc_ufboot_adopt(self.h, len(sm), _p(sm), _p(sc), _p(to), len(tr), _p(tr), _p(ln)))
+
+    def weights(self):
+        return self._w.copy()
+
+    def reset_node_order(self):
+        self.reset_nodep()
 
     def ufboot_bad(self):
         return lib().orc_ufboot_bad(self.h)
