@@ -570,13 +570,21 @@ def main():
     ap.add_argument("--weighted-leg", type=int, default=1, help="1 = also time the weighted (Sankoff, -cost) sweep of config 5")
     ap.add_argument("--start-trees", type=int, default=100,
                     help="randomized-stepwise-addition + SPR start trees of the start-up phase (phyloanalysis.cpp:1270-1317), sharded over the GPUs (0 = skip)")
-    ap.add_argument("--bb-iterations", type=int, default=50,
-                    help="later search iterations of the -bb run leg (bootstrap_wall_clock.seconds): perturb the best tree, climb under the "
-                         "updated logl_cutoff with the bookkeeping (0 = skip the leg)")
+    ap.add_argument("--bb-iterations", type=int, default=200,
+                    help="bb_reference_run leg, ONE chain: doTreeSearch iterations timed (random NNIs / ratchet alternating, tracked climbs "
+                         "under the cut-off); the stop rule's horizon is extrapolated from them (0 = skip)")
+    ap.add_argument("--bb-workers", type=int, default=8, help="bb_reference_run leg, iteration-parallel form: chains (engines on host threads) per GPU")
+    ap.add_argument("--bb-rounds", type=int, default=6, help="... rounds timed (a round = --bb-sync iterations on every chain, then one exchange; 0 = skip)")
+    ap.add_argument("--bb-sync", type=int, default=8, help="... iterations between two exchanges")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated secondary legs to run (default all): concurrent_climbs, start_trees, bb_reference_run, c2_climb, "
+                         "c5_weighted_sweep, c5_fitch, noisy_bootstrap; the headline step, its roofline and cpu_baseline always run")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
     args = ap.parse_args()
+    legs_wanted = set(x.strip() for x in args.legs.split(","))
+    leg_on = lambda name: "all" in legs_wanted or name in legs_wanted
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process (which has made NO GPU call and never imports torch)
@@ -839,6 +847,7 @@ def main():
     nondeg = None
     back_r = None
     legs_error = None
+    samples = None
     n_eng = 1
     tb_nocache = None
     tb_persample = None
@@ -1012,7 +1021,7 @@ def main():
                               "what": "one later search iteration of the same run: logl_cutoff = top 10 % of the saved trees, best tree perturbed by 30 "
                                       "random SPR moves, SPR climb with saveCurrentTree bookkeeping under the cut-off: the stretch in which nothing "
                                       "reaches the bookkeeping runs as the plain climb (k_climb with a hand-back condition, cost-only batches), the "
-                                      "rest on the tracker's two-wait loop (product compacted on the host); random_start.bb_run times 50 of them"}
+                                      "rest on the tracker's two-wait loop (product compacted on the host); the bb_reference_run leg times the reference's own iteration flow"}
                 except Exception as exc:
                     it_leg = {"error": repr(exc)}
                 eng.ufboot_detach()
@@ -1030,38 +1039,6 @@ def main():
                                      "mean_sample_score_online": float(np.mean(online2[:n_rep])) if n_rep else None,
                                      "mean_sample_score_refined": float(np.mean(bs2)) if n_rep else None,
                                      "samples_improved_by_refinement": int((bs2 < online2[:n_rep]).sum()) if n_rep else None}
-                # ---- the -bb RUN: what the search really repeats.  One tracked climb from the random tree, then --bb-iterations later
-                # iterations (cut-off = top 10 % of the saved trees, iqtree.cpp:1662-1676; best tree perturbed by 30 random SPR moves;
-                # tracked climb under the cut-off), then the refinement of all samples.  Every rank makes the same calls (the online
-                # part is one sequential chain, replicated below shard.ONLINE_SHARD_MIN_SAMPLES samples); the refinement shards.
-                if args.bb_iterations > 0 and n_rep > 0:
-                    from mpboot_amd import bootstrap as _bs
-                    eng.set_option("timing", 0)
-                    _bs.bb_search(eng, samples, back_r, min(3, args.bb_iterations), 30, args.maxtrav, 1, engines=engines)      # allocations
-                    barrier()
-                    t0r = time.perf_counter()
-                    rr = _bs.bb_search(eng, samples, back_r, args.bb_iterations, 30, args.maxtrav, 1, engines=engines)
-                    barrier()
-                    t_run = time.perf_counter() - t0r
-                    eng.set_option("timing", 1)
-                    its_ = np.array(rr["iter_s"])
-                    tests_run = int(rr["first_stats"]["insertion_tests"] + sum(x[1] for x in rr["iter_stats"]))
-                    nondeg["bb_run"] = {
-                        "seconds": rr["first_s"] + float(its_.sum()) + rr["refine_s"], "seconds_with_perturbation_scans": t_run,
-                        "first_climb_s": rr["first_s"], "iterations": int(len(its_)), "iterations_s": float(its_.sum()),
-                        "iteration_ms_mean": float(its_.mean() * 1e3), "iteration_ms_median": float(np.median(its_) * 1e3),
-                        "iteration_ms_max": float(its_.max() * 1e3), "refinement_s": rr["refine_s"],
-                        "insertion_tests": tests_run, "trees_booked": int(rr["saved_trees"]), "trees_booked_first_climb": int(rr["saved_first"]),
-                        "moves_per_iteration": float(np.mean([x[0] for x in rr["iter_stats"]])),
-                        "tests_per_iteration": float(np.mean([x[1] for x in rr["iter_stats"]])),
-                        "best_score": rr["best_score"], "distinct_boot_trees": rr["distinct_boot_trees"], "state_sha16": rr["state_hash"],
-                        "what": "-bb %d as a run: 1 tracked climb from a random tree + %d later iterations (logl_cutoff = top 10 %% of the saved "
-                                "trees, best tree perturbed by 30 random SPR moves, tracked climb under the cut-off) + refinement of every sample's "
-                                "tree.  A later climb starts far above the cut-off, where nothing reaches saveCurrentTree's bookkeeping "
-                                "(iqtree.cpp:3343): that stretch runs as the plain climb (k_climb / cost-only batches) and hands over to the "
-                                "tracked loop in front of the first admissible insertion test; seconds = climbs + refinement (the perturbation's "
-                                "own scans stand in for doRandomNNIs and are left out; seconds_with_perturbation_scans has them)"
-                                % (B, len(its_))}
             eng.set_tree(back)
         except Exception as exc:        # the headline metric above must survive a failing secondary leg
             legs_error = repr(exc)
@@ -1071,6 +1048,7 @@ def main():
     import threading as _th
     mk = lambda: engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
     conc = None
+    bbref = None
     c2leg = None
     c5leg = None
     startup = None
@@ -1094,7 +1072,7 @@ def main():
             for t in th: t.join()
             torch.cuda.synchronize()
             return time.perf_counter() - t0_, out
-        if args.climb_engines > 0 and args.random_start_leg:
+        if args.climb_engines > 0 and args.random_start_leg and leg_on("concurrent_climbs"):
             # independent climbs from random trees, one engine per host thread (the shape of the start trees / the refinements of
             # a run): every climb is a chain of dependent steps, concurrent engines fill the chip
             E = args.climb_engines
@@ -1121,13 +1099,14 @@ def main():
                             "thread; each climb runs in the persistent kernel k_climb (%d-word tiles: %d workgroups per climb); "
                             "host_driven_batches = the same climbs with the loop on the host (engine option climb_device = 0).  "
                             "GPU_MAX_HW_QUEUES=%s" % (E, args.maxtrav, 16 * args.climb_tile, (eng.Wp + 16 * args.climb_tile - 1) // (16 * args.climb_tile), os.environ.get("GPU_MAX_HW_QUEUES"))}
-        if args.start_trees > 0:
+        if args.start_trees > 0 and (leg_on("start_trees") or leg_on("bb_reference_run")):
             # the start-up phase of a run: numpars randomized-stepwise-addition trees, each SPR-optimised (phyloanalysis.cpp:1270-1317,
             # tools.cpp:767); unit u on rank u % n_gpus, several engines per GPU
             k_e = max(1, args.start_engines)
             grow(k_e)
             units = [u for u in range(args.start_trees) if u % world == rank]
             unit_q, unit_lock = iter(units), _th.Lock()          # (the engines take the next tree when they are done with theirs)
+            start_trees_built = []
             def ras_fn(i, x):
                 best = None
                 while True:
@@ -1139,6 +1118,8 @@ def main():
                     x.seed_ties(engine.TIE_RANDOM, sd)
                     x.reset_node_order()
                     sc = x.make_parsimony_tree(sd, args.maxtrav)
+                    with unit_lock:
+                        start_trees_built.append((u, x.get_tree(), int(sc)))
                     best = sc if best is None else min(best, sc)
                 return best
             def ras_warm(i, x):                     # (an engine's first tree allocates the kernel's scratch: not a step of the phase)
@@ -1159,7 +1140,25 @@ def main():
                                "(phyloanalysis.cpp:1270-1317); tree u on rank u %% n_gpus.  The addition loop of a tree is ONE persistent kernel "
                                "launch (k_grow: the rooted tree in LDS, one vector load per branch and added taxon, the insertions replayed on "
                                "the host's mirror); trees_grown_in_k_grow counts the launches that came back clean" % (args.start_trees, args.maxtrav)}
-        if world == 1 and args.workload == "C3" and args.random_start_leg:
+        if startup is not None and samples is not None and (args.bb_iterations > 0 or args.bb_rounds > 0) and leg_on("bb_reference_run"):
+            # ---- BASELINE config 4: -bb 1000 as the reference runs it (benchlegs/bb_run.py).  The start trees of all ranks are the
+            # candidate set of every chain.
+            from benchlegs import bb_run as _bbleg
+            mine = sorted(start_trees_built)
+            if world > 1:
+                box = [None] * world
+                dist.all_gather_object(box, [(u, t.tobytes(), sc) for u, t, sc in mine])
+                mine = sorted((u, np.frombuffer(t, dtype=np.int32), sc) for part in box for u, t, sc in part)
+            starts_bb = [(t, sc) for _u, t, sc in mine]
+            grow(max(1, args.bb_workers))
+            try:
+                bbref = _bbleg.run(pool, samples, starts_bb, args.maxtrav, rank, world, barrier, args.bb_iterations, args.bb_workers, args.bb_rounds,
+                                   args.bb_sync, startup["seconds"], pool[:max(1, min(len(pool), args.engines_per_gpu))])
+            except Exception as exc:
+                bbref = {"error": repr(exc)}
+            eng.set_option("timing", 1)
+            eng.set_weights(np.ones(P, dtype=np.int32))
+        if world == 1 and args.workload == "C3" and args.random_start_leg and leg_on("c2_climb"):
             # BASELINE config 2 (200 taxa x 10 000 patterns): a full SPR hill climb from a random tree
             letters2, names2 = synth.workload("C2")
             codes2 = synth.letters_to_codes(letters2, "DNA")
@@ -1225,7 +1224,7 @@ def main():
                                    "what": "%d engines on host threads, %d climbs each from different random topologies, k_climb with 64-word tiles "
                                            "(5 workgroups per climb)" % (k2, per)}
             del es
-        if world == 1 and args.workload == "C3" and args.weighted_leg:
+        if world == 1 and args.workload == "C3" and args.weighted_leg and leg_on("c5_weighted_sweep"):
             # BASELINE config 5 in its `-cost` form: the weighted (Sankoff) engine on 500 taxa x 20 000 protein patterns, 20 states
             letters5, names5 = synth.workload("C5")
             codes5 = synth.letters_to_codes(letters5, "AA")
@@ -1304,6 +1303,8 @@ def main():
                 if cb:
                     startup["gpu_over_cpu_one_core"] = cb["seconds_for_%d_trees_one_core" % startup["trees"]] / startup["seconds"]
                     startup["gpu_over_cpu_all_cores"] = cb["all_cores"]["seconds_for_%d_trees" % startup["trees"]] / startup["seconds"]
+        if bbref is not None:
+            res["bb_reference_run"] = bbref
         if c2leg is not None:
             res["c2_climb"] = c2leg
         if c5leg is not None:
@@ -1316,13 +1317,19 @@ def main():
                 "seconds_from_ras_tree": ufb["seconds"] + boot[1] * ufb["samples"] / boot[0],
                 # the flow that really searches: from a random topology (thousands of accepted moves online, refinements that climb);
                 # the RAS tree of this alignment is SPR-optimal already (zero moves: seconds_from_ras_tree is 1000 move-less sweeps)
-                "seconds": (nondeg["bb_run"]["seconds"] if nondeg is not None and "bb_run" in nondeg
+                # the run the reference performs (bb_reference_run leg: start trees + doTreeSearch iterations + refinement); where that leg
+                # did not run, the older one-climb flow from a random tree
+                "seconds": (bbref["seconds_measured_one_chain"] if bbref and "seconds_measured_one_chain" in bbref
                             else nondeg["bb_flow"]["seconds"] if nondeg is not None and "bb_flow" in nondeg
                             else ufb["seconds"] + boot[1] * ufb["samples"] / boot[0]),
-                "seconds_is": ("the -bb run from a random tree: first climb + %d later iterations under the cut-off + refinement (random_start.bb_run)"
-                               % nondeg["bb_run"]["iterations"] if nondeg is not None and "bb_run" in nondeg
+                "seconds_is": ("bb_reference_run: %d start trees + %d doTreeSearch iterations of ONE chain (random NNIs / ratchet alternating) + refinement, "
+                               "as measured; the stop rule needs >= %d iterations: see seconds_extrapolated_to_stop_rule"
+                               % (bbref["start_trees"], bbref["sequential"]["iterations"], bbref["stop_rule_unsuccessful_iterations"])
+                               if bbref and "seconds_measured_one_chain" in bbref
                                else "random-start flow, ONE climb + refinement (random_start.bb_flow)" if nondeg is not None and "bb_flow" in nondeg
                                else "flow from the RAS tree"),
+                "seconds_extrapolated_to_stop_rule": bbref.get("seconds_extrapolated_to_stop_rule_one_chain") if bbref else None,
+                "seconds_extrapolated_to_stop_rule_iteration_parallel": bbref.get("seconds_extrapolated_to_stop_rule_parallel") if bbref else None,
                 "refinement_s_plan_cache_off": tb_nocache, "refinement_s_per_sample_climbs": tb_persample, "distinct_boot_trees": n_distinct_trees,
                 "scaling": "strong", "engines_per_gpu": n_eng,
                 "online_phase_sharded": shard.online_shard(ufb["samples"], rank, world, args.shard_online) is not None,
@@ -1386,16 +1393,19 @@ def main():
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
             if "all_cores" in res["cpu_baseline"]:
                 res["gpu_over_cpu_all_cores"] = res["value"] / res["cpu_baseline"]["all_cores"]["value"]
-            if nondeg is not None and "bb_run" in nondeg:
+            if bbref and "sequential" in bbref:
                 try:
-                    nondeg["bb_run"]["cpu_baseline"] = bb_run_cpu_baseline(codes, alphabet, samples, back_r, args.maxtrav, min(args.cpu_budget, 10.0),
-                                                                           res["cpu_baseline"].get("evals_per_s"), nondeg["bb_run"],
-                                                                           res.get("bootstrap_wall_clock", {}).get("cpu_baseline"))
-                    cbr = nondeg["bb_run"]["cpu_baseline"]
+                    sq = bbref["sequential"]
+                    run_counts = {"trees_booked": sq["trees_booked"], "insertion_tests": sq["insertion_tests"]}
+                    cbr = bb_run_cpu_baseline(codes, alphabet, samples, back, args.maxtrav, min(args.cpu_budget, 10.0),
+                                              res["cpu_baseline"].get("evals_per_s"), run_counts, res.get("bootstrap_wall_clock", {}).get("cpu_baseline"))
                     if cbr:
-                        nondeg["bb_run"]["gpu_over_cpu_one_core"] = cbr["value"] / nondeg["bb_run"]["seconds"]
+                        # (the timed iterations only: start trees have a reference baseline of their own in the start_trees leg)
+                        cbr["sample"] += "; covers the %d timed iterations + the refinement, not the start trees" % sq["iterations"]
+                        bbref["cpu_baseline"] = cbr
+                        bbref["gpu_over_cpu_one_core"] = cbr["value"] / (sq["iterations_s"] + (bbref.get("parallel") or {}).get("refinement_s", 0.0))
                 except Exception as exc:
-                    nondeg["bb_run"]["cpu_baseline"] = {"error": repr(exc)}
+                    bbref["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -221,78 +221,3 @@ def bb_run(eng, samples, start_trees, iters, maxtrav=6, seed=1, engines=None, ve
         out["mean_refined"] = float(np.mean(sc))
         out["samples_improved_by_refinement"] = int((np.asarray(sc) < out["online_scores"]).sum())
     return out
-
-
-def bb_search(eng, samples, start, iters, perturb, maxtrav, seed, ratchet_every=0, verbose=False, engines=None):
-    """The -bb search as a run repeats it (IQTree::doTreeSearch, iqtree.cpp:1631-1965): ONE tracked climb from `start`, then `iters` later
-    iterations -- logl_cutoff from the saved trees (top 10 %, :1662-1676), the best tree perturbed by `perturb` random SPR moves (a
-    stand-in for doRandomNNIs, :1742-1747), one more tracked climb under the cut-off (:2132; every `ratchet_every`-th iteration first
-    climbs on a re-weighted alignment, createPerturbAlignment) -- and the refinement of every sample's tree behind them
-    (optimizeBootTrees).  -> dict(first_s, iter_s[list], refine_s, best_score, ...).  Deterministic for a given seed; every rank of
-    a multi-GPU run makes the same calls (the refinement shards the samples)."""
-    import hashlib
-    import time
-
-    from . import engine, trees
-    n = eng.n
-    eng.ufboot_attach(samples, 0.5)
-    eng.reset_stats()
-    eng.set_tree(start)
-    eng.reset_node_order()
-    eng.seed_ties(engine.TIE_RANDOM, seed)
-    t0 = time.perf_counter()
-    best_score = eng.optimize_spr(1, maxtrav)
-    t_first = time.perf_counter() - t0
-    first_stats = eng.stats()
-    saved_first = len(eng.ufboot_tree_logl())
-    best = eng.get_tree()
-    rng = np.random.default_rng(seed + 77)
-    its, stats = [], []
-    P = samples.shape[1]
-    w0 = eng.weights()
-    for it in range(iters):
-        cut = eng.ufboot_next_cutoff(10)
-        eng.ufboot_set_cutoff(cut)
-        pert = trees.random_spr_moves(eng, best, rng, perturb, maxtrav)
-        eng.reset_stats()
-        c0 = eng.ufboot_counters()
-        t0 = time.perf_counter()
-        if ratchet_every and it % ratchet_every == ratchet_every - 1:
-            # createPerturbAlignment (alignment.cpp:1915-1969): half of the patterns up-weighted by one, climb there, then on the original
-            w = w0.copy()
-            w[rng.random(P) < 0.5] += 1
-            eng.set_weights(w)
-            eng.set_tree(pert)
-            eng.reset_node_order()
-            eng.optimize_spr(1, maxtrav)
-            pert = eng.get_tree()
-            eng.set_weights(w0)
-        eng.set_tree(pert)
-        eng.reset_node_order()
-        s = eng.optimize_spr(1, maxtrav)
-        dt = time.perf_counter() - t0
-        st = eng.stats()
-        c1 = eng.ufboot_counters()
-        its.append(dt)
-        stats.append((st["moves_applied"], st["insertion_tests"], c1["events"] - c0["events"], c1["tie_draws"] - c0["tie_draws"]))
-        if verbose:
-            print(f"  iteration {it}: cut-off {-cut:.0f}, climb -> {s} in {dt * 1e3:.1f} ms ({st['moves_applied']} moves, {st['insertion_tests']} tests, "
-                  f"{c1['events'] - c0['events']} events, {c1['tie_draws'] - c0['tie_draws']} draws; k_climb: {st['climb_launches']} launches, {st['climb_steps']} steps, "
-                  f"{st['climb_nodes']} prune nodes, {st['climb_moves']} moves, {st['climb_ms_total']:.2f} ms; scan launches {st['scan_launches']})", flush=True)
-        if s < best_score or (s == best_score and rng.random() < 0.5):
-            best_score, best = s, eng.get_tree()
-    logl, counts, bt = eng.ufboot_state()
-    n_saved = len(eng.ufboot_tree_logl())
-    cache, bts = {}, []
-    for b in range(samples.shape[0]):
-        t = int(bt[b])
-        if t not in cache:
-            cache[t] = eng.ufboot_tree(t)
-        bts.append(cache[t])
-    state_hash = hashlib.sha256(logl.tobytes() + counts.tobytes() + bt.tobytes() + str(eng.tie_state()).encode()).hexdigest()[:16]
-    eng.ufboot_detach()
-    t0 = time.perf_counter()
-    sc, _ = refine_boot_trees(engines or [eng], samples, bts, 11, maxtrav)
-    t_ref = time.perf_counter() - t0
-    return {"first_s": t_first, "first_stats": first_stats, "saved_first": saved_first, "iter_s": its, "iter_stats": stats, "refine_s": t_ref, "best_score": int(best_score), "saved_trees": n_saved,
-            "distinct_boot_trees": len(cache), "mean_refined": float(np.mean(sc)), "state_hash": state_hash}
