@@ -1049,6 +1049,7 @@ def main():
     mk = lambda: engine.FitchEngine(codes, datatype=engine.DNA if alphabet == "DNA" else engine.AA, device=device)
     conc = None
     bbref = None
+    noisy_leg = None
     c2leg = None
     c5leg = None
     startup = None
@@ -1158,6 +1159,12 @@ def main():
                 bbref = {"error": repr(exc)}
             eng.set_option("timing", 1)
             eng.set_weights(np.ones(P, dtype=np.int32))
+        if world == 1 and args.workload == "C3" and leg_on("noisy_bootstrap"):
+            try:
+                from benchlegs import noisy as _noisy
+                noisy_leg = _noisy.run(device, args.maxtrav, 12, 40, args.engines_per_gpu, barrier, B=max(1, args.ufboot_samples))
+            except Exception as exc:
+                noisy_leg = {"error": repr(exc)}
         if world == 1 and args.workload == "C3" and args.random_start_leg and leg_on("c2_climb"):
             # BASELINE config 2 (200 taxa x 10 000 patterns): a full SPR hill climb from a random tree
             letters2, names2 = synth.workload("C2")
@@ -1305,6 +1312,8 @@ def main():
                     startup["gpu_over_cpu_all_cores"] = cb["all_cores"]["seconds_for_%d_trees" % startup["trees"]] / startup["seconds"]
         if bbref is not None:
             res["bb_reference_run"] = bbref
+        if noisy_leg is not None:
+            res["noisy_bootstrap"] = noisy_leg
         if c2leg is not None:
             res["c2_climb"] = c2leg
         if c5leg is not None:

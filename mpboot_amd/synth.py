@@ -12,6 +12,7 @@ The named workloads of BASELINE.json:
     C2  200 taxa x 10 000 patterns, DNA, r=0.05, seed 11
     C3  1000 taxa x 50 000 patterns, DNA, r=0.04, seed 3     (headline)
     C5  500 taxa x 20 000 patterns, protein, r=0.08, seed 9
+    C4N 1000 taxa x 2 000 patterns, DNA, r=0.3, seed 17      (noisy: bootstrap samples that disagree)
 """
 from __future__ import annotations
 
@@ -31,6 +32,10 @@ WORKLOADS = {
     "C2": dict(n_taxa=200, n_patterns=10_000, alphabet="DNA", r=0.05, seed=11),
     "C3": dict(n_taxa=1000, n_patterns=50_000, alphabet="DNA", r=0.04, seed=3),
     "C5": dict(n_taxa=500, n_patterns=20_000, alphabet="AA", r=0.08, seed=9),
+    # a bootstrap workload whose samples DISAGREE: C3's taxa, 2 000 columns, 30 % substitutions per branch -- the
+    # samples of a -bb 1000 run keep some 230 distinct trees and nearly every refinement climbs (tools/noisy_probe.py tried
+    # 1 500 x 0.1, 1 000 x 0.05, 5 000 x 0.15: one to three trees)
+    "C4N": dict(n_taxa=1000, n_patterns=2_000, alphabet="DNA", r=0.3, seed=17),
 }
 
 

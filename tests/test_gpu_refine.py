@@ -181,3 +181,45 @@ def test_batched_refinement_sharded_over_two_ranks_equals_per_sample_loop(tmp_pa
         assert out.returncode == 0, out.stderr[-3000:]
         res[batched] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["1"] == res["0"]
+
+
+def test_batched_refinement_from_many_distinct_trees_equals_per_sample_oracle_climbs():
+    """A noisy alignment (as synth C4N is at full size): the samples of the online phase keep MANY different trees and nearly every
+    refinement climbs.  refine_boot_trees (one masked sweep + one product per distinct topology, then the unstable samples' own
+    climbs) against IQTree::optimizeBootTrees' loop on the oracle: per sample re-weight, seed, one SPR climb from its tree
+    (iqtree.cpp:2797-2862)."""
+    from mpboot_amd import bootstrap, engine, shard, synth, trees
+    from oracle import pyoracle as po
+    n, P, B, radius = 40, 300, 96, 4
+    letters, _ = synth.synth_alignment(n, P, "DNA", 0.4, seed=31)
+    codes = synth.letters_to_codes(letters, "DNA")
+    w0 = np.ones(P, dtype=np.int32)
+    samples = _samples(w0, B, np.random.default_rng(5))
+    # the online phase's result, stood in for: every sample's tree = an SPR-optimal tree of ANOTHER sample's alignment
+    e = engine.FitchEngine(codes)
+    boot_trees = []
+    for b in range(B):
+        e.set_weights(samples[(b * 7 + 3) % B].astype(np.int32))
+        e.seed_ties(engine.TIE_RANDOM, 100 + b)
+        e.reset_node_order()
+        e.set_tree(trees.random_topology(n, np.random.default_rng(b % 60)))
+        e.optimize_spr(1, radius)
+        boot_trees.append(e.get_tree())
+    e.set_weights(w0)
+    distinct = len({engine.iq_topology_key(t) for t in boot_trees})
+    assert distinct >= 50
+    pool = [e, engine.FitchEngine(codes), engine.FitchEngine(codes)]
+    sc_b, tr_b = bootstrap.refine_boot_trees(pool, samples, boot_trees, 9, radius, batched=True)
+    o = po.Oracle(codes)
+    moved = 0
+    for b in range(B):
+        o.set_weights(samples[b].astype(np.int32))
+        o.seed_ties(po.TIE_RANDOM, shard.unit_seed(9, b))
+        o.reset_nodep()
+        o.set_tree(boot_trees[b])
+        s = o.optimize_spr(1, radius)
+        assert s == sc_b[b], b
+        assert (o.get_tree() == tr_b[b]).all(), b
+        moved += int(not (o.get_tree() == boot_trees[b]).all())
+    assert moved >= B // 2                      # the refinements really climb here
+    assert (e.weights() == w0).all()
