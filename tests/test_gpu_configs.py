@@ -486,3 +486,110 @@ def test_c3_eight_concurrent_device_climbs_equal_their_solo_runs(c3_climb):
     for k in range(K):
         assert got[k][3] >= 1
         assert got[k][:3] == solo[k], f"engine {k} diverged from its solo run"
+
+
+# ------------------------------------------------------------------------------------------------ full-size pins of two benchmarked legs
+
+@pytest.mark.parametrize("tie", ["random", "first"])
+def test_c3_start_tree_equals_the_oracle_insertion_by_insertion(tie):
+    """bench.py's start_trees leg at ITS size: the addition loop of one C3 start tree (1000 taxa x 50 000 patterns; k_grow: skeleton +
+    parts, several workgroups exchanging rows) against the ORACLE's stepwiseAddition loop (sprparsimony.cpp:2977-3019, :3107-3181)
+    -- the length after every insertion, every insertion branch, the finished tree and the state the tie stream is left in, under
+    mpboot's random tie rule and under the PLL original's first-best rule."""
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    codes, dt = _workload("C3")
+    seed = 31337 + 12345 * 3                                  # (a unit of the bench's start_trees leg)
+    e = engine.FitchEngine(codes, datatype=dt)
+    e.seed_ties(engine.TIE_RANDOM if tie == "random" else engine.TIE_FIRST, 7)
+    s, best, ins = e.stepwise_addition(seed)
+    assert e.get_option("grow_launches") == 1 and e.get_option("grow_last_err") == 0      # the kernel built it, and came back clean
+    o = po.Oracle(codes)
+    o.seed_ties(po.TIE_RANDOM if tie == "random" else po.TIE_FIRST, 7)
+    so, ob, oi = o.stepwise(seed)
+    assert so == s
+    assert ob.tolist() == best.tolist()
+    assert oi.tolist() == ins.tolist()
+    assert (o.get_tree() == e.get_tree()).all()
+    assert o.tie_state() == e.tie_state()
+
+
+def test_c3_start_tree_equals_the_reference_first_best():
+    """... and against the REFERENCE itself: oracle/_ref/pll_ref_driver rasx = PLL's own makePermutationFast + buildSimpleTree +
+    stepwiseAddition loop (fastDNAparsimony.c, compiled from the reference's sources), one checkpoint per added taxon."""
+    import os
+    import subprocess
+    import tempfile
+
+    from helpers import ROOT
+    from mpboot_amd import engine, synth, trees
+    drv = os.path.join(ROOT, "oracle", "_ref", "pll_ref_driver")
+    if not (os.path.exists(drv) and os.access(drv, os.X_OK)):
+        pytest.skip("oracle/_ref/pll_ref_driver not built (needs /root/reference at build time)")
+    letters, names = synth.workload("C3")
+    codes = synth.letters_to_codes(letters, "DNA")
+    n = codes.shape[0]
+    seed = 424242
+    with tempfile.TemporaryDirectory() as tmp:
+        aln = os.path.join(tmp, "a.phy")
+        synth.write_phylip(aln, synth.letters_to_text(letters, "DNA"), names)
+        out = subprocess.run([drv, "rasx", aln, "DNA", "0", str(seed)], capture_output=True, text=True, check=True, timeout=1200).stdout
+    adds, back, check = [], None, None
+    for l in out.splitlines():
+        t = l.split()
+        if t and t[0] == "add":
+            adds.append((int(t[1]), int(t[3]), int(t[5]), int(t[7])))
+        elif t and t[0] == "rasx_topology":
+            back = trees.parse_topology_line(t[1:], n)
+        elif t and t[0] == "rasx_check":
+            check = int(t[1])
+    assert len(adds) == n - 3 and back is not None
+    e = engine.FitchEngine(codes)
+    e.seed_ties(engine.TIE_FIRST, 0)
+    s, best, ins = e.stepwise_addition(seed)
+    assert e.get_option("grow_launches") == 1 and e.get_option("grow_last_err") == 0
+    for step, _tip, b, i in adds:
+        assert (int(best[step]), int(ins[step])) == (b, i), step
+    assert e.get_tree().tolist() == back.tolist()
+    assert s == check == e.score_tree()
+
+
+def test_c5_fitch20_climb_first_visits_equal_the_oracle(c5):
+    """BASELINE config 5 in its Fitch form at full size (500 taxa x 20 000 protein patterns, 20-state kernels): the SPR climb from a
+    random tree against the ORACLE over its first 260 prune-node visits (orc_set_max_visits) -- every accepted move with its length
+    --, and the WHOLE climb in the persistent kernel (k_climb, five states per lane) against the host-driven loop: moves, final
+    topology and the state of the tie stream.  (A visit limit keeps a climb out of the kernel, so the kernel is held to the oracle
+    through the host loop's list.)"""
+    from mpboot_amd import engine
+    from oracle import pyoracle as po
+    codes, dt, back = c5
+    K = 260
+    o = po.Oracle(codes, datatype=po.AA)
+    o.set_max_visits(K)
+    o.set_tree(back)
+    o.seed_ties(po.TIE_RANDOM, 5)
+    o.trace(True)
+    so = o.optimize_spr(1, 6)
+    om = [x.tolist() for x in o.get_moves()]
+    assert len(om[0]) >= 40
+    runs = {}
+    for mode in (0, 2):
+        e = engine.FitchEngine(codes, datatype=dt)
+        e.set_option("climb_device", mode)
+        e.set_tree(back)
+        e.reset_node_order()
+        e.seed_ties(engine.TIE_RANDOM, 5)
+        s = e.optimize_spr(1, 6)
+        runs[mode] = (s, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.tie_state(), e.stats()["climb_launches"])
+    assert runs[0][4] == 0 and runs[2][4] >= 1
+    assert runs[0][:4] == runs[2][:4]
+    k = len(om[0])
+    assert [x[:k] for x in runs[0][1]] == om and om[2][-1] == so
+    # the host loop cut at the same visit ends where the oracle ends
+    e = engine.FitchEngine(codes, datatype=dt)
+    e.set_option("max_visits", K)
+    e.set_tree(back)
+    e.reset_node_order()
+    e.seed_ties(engine.TIE_RANDOM, 5)
+    assert e.optimize_spr(1, 6) == so
+    assert (e.get_tree() == o.get_tree()).all() and e.tie_state() == o.tie_state()
