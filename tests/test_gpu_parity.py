@@ -37,7 +37,7 @@ def orc_of(po, fx, **kw):
 def test_native_library_is_loaded(mods):
     engine = mods[0]
     lib = engine.load_library()
-    assert lib.mpf_abi_version() == 7
+    assert lib.mpf_abi_version() == 8
     with open("/proc/self/maps") as f:
         assert "libmpfitch.so" in f.read()
 

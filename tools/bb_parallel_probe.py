@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--trees", type=int, default=6)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--switch", type=float, default=1e-4)
     args = ap.parse_args()
     from mpboot_amd import bootstrap, engine, synth
     from mpboot_amd.rng import Lcg64
@@ -50,6 +51,7 @@ def main():
             out = [None] * W
             def work(i):
                 out[i] = bootstrap.bb_run(pool[i], samples, starts, args.iters if rep else 4, 6, 1 + 977 * i, refine=False)
+            sys.setswitchinterval(args.switch)
             th = [threading.Thread(target=work, args=(i,)) for i in range(W)]
             t0 = time.perf_counter()
             for t in th: t.start()

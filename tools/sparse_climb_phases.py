@@ -12,6 +12,7 @@ ap.add_argument("--workload", default="C3")
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--climbs", type=int, default=6)
 ap.add_argument("--device", type=int, default=2)
+ap.add_argument("--nni", type=int, default=0, help="perturb with this many random NNIs (doRandomNNIs: floor(0.5 (n - 3)) = 498 at C3) instead of 30 random SPR moves")
 a = ap.parse_args()
 cfg = synth.WORKLOADS[a.workload]
 letters, _ = synth.workload(a.workload)
@@ -29,7 +30,7 @@ rng = np.random.default_rng(5)
 names = "setup enum closure refresh scan exchange decide".split()
 tot = np.zeros(7); wall = 0.0; steps = nodes = moves = launches = 0
 for c in range(a.climbs + 1):
-    pert = trees.random_spr_moves(scratch, best, rng, 30, 6)
+    pert = engine.iq_random_nnis(best, a.nni, 1000 + c)[0] if a.nni else trees.random_spr_moves(scratch, best, rng, 30, 6)
     e.set_tree(pert); e.reset_node_order(); e.reset_stats()
     p0 = np.array([e.get_option(f"climb_phase_us{k}") for k in "0123456"], dtype=float)
     t0 = time.perf_counter()
