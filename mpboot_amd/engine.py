@@ -34,6 +34,7 @@ EXPORTS = [
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
+    "mpf_iq_random_nnis", "mpf_iq_perturb_weights", "mpf_iq_topology_key", "mpf_ufboot_adopt",
 ]
 
 

@@ -16,7 +16,7 @@ All random choices -- candidate tree, NNIs, re-weighted sites -- come from the o
 draw from; the engine takes and returns that stream by state (set_tie_state / tie_state), so the host draws between two climbs.
 The perturbation steps themselves are device-free C++ in the library (mpboot_amd/host/iqflow.cpp: mpf_iq_*).
 
-`eng` is anything with the engine's face (mpboot_amd.engine.FitchEngine; the tests drive oracle.pyoracle.Oracle through the same
+`eng` is anything with the engine's face (mpboot_amd.engine.FitchEngine; the tests drive the CPU oracle through the same
 loop and compare the two after every climb).  The 100 start trees (phyloanalysis.cpp:1261-1317) are the caller's: add_candidate().
 """
 from __future__ import annotations

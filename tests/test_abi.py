@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     lib.mpf_abi_version.restype = ctypes.c_int
-    assert lib.mpf_abi_version() == 7
+    assert lib.mpf_abi_version() == 8
 
 
 def test_python_binding_lists_the_same_symbols():
