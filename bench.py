@@ -1050,6 +1050,7 @@ def main():
     conc = None
     bbref = None
     noisy_leg = None
+    c5f_sweep = c5f_climb = None
     c2leg = None
     c5leg = None
     startup = None
@@ -1159,6 +1160,13 @@ def main():
                 bbref = {"error": repr(exc)}
             eng.set_option("timing", 1)
             eng.set_weights(np.ones(P, dtype=np.int32))
+        if world == 1 and args.workload == "C3" and leg_on("c5_fitch"):
+            try:
+                from benchlegs import c5_fitch as _c5f
+                c5f_sweep, c5f_climb = _c5f.run(device, args.maxtrav, 20, 5, barrier, None if args.no_cpu else cpu_baseline,
+                                                None if args.no_cpu else climb_cpu_baseline, min(args.cpu_budget, 10.0))
+            except Exception as exc:
+                c5f_sweep, c5f_climb = {"error": repr(exc)}, None
         if world == 1 and args.workload == "C3" and leg_on("noisy_bootstrap"):
             try:
                 from benchlegs import noisy as _noisy
@@ -1314,6 +1322,10 @@ def main():
             res["bb_reference_run"] = bbref
         if noisy_leg is not None:
             res["noisy_bootstrap"] = noisy_leg
+        if c5f_sweep is not None:
+            res["c5_fitch_sweep"] = c5f_sweep
+        if c5f_climb is not None:
+            res["c5_fitch_climb"] = c5f_climb
         if c2leg is not None:
             res["c2_climb"] = c2leg
         if c5leg is not None:

@@ -1334,7 +1334,7 @@ int Engine::run_scans(std::vector<ScanPlan> &plans, std::vector<uint32_t> &out_h
   zeroed_ptr_ = nullptr;
   zeroed_words_ = 0;
   if (timing_) HIPCHK(hipEventRecord(ev0_, st_));
-  const bool deep = prog_max_depth_ > (sankoff_ && g_.S != 4 ? 6 : kMaxDepth);
+  const bool deep = prog_max_depth_ > scan_reg_depth(g_.S, sankoff_);
   if (deep && !g_.deep_scratch) {
     // per-level up-vectors of the scans' waves: 256 MB, the launches are cut to fit (launch_scan)
     HIPCHK(d_deep_.reserve(deep_scratch_words_));
@@ -2057,7 +2057,10 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "words_per_lane") {
     if (sankoff_ && v != 1) { set_error("words_per_lane: weighted mode uses one pattern per lane"); return MPF_E_INVALID; }
     if (!(v == 1 || v == 2 || v == 4) || (g_.S == 20 && v == 4)) { set_error("words_per_lane: 1|2|4 (protein: 1|2)"); return MPF_E_INVALID; }
-    if (g_.S == 32) return MPF_OK;                 // (32 state rows fill a lane's registers with one word: the knob rests)
+    // (20 or 32 state rows fill a lane's registers with ONE word: two words per lane put 40-register tiles in every kernel and all of
+    //  them spilled to scratch -- k_newview_wg<20, 2> 352-408 bytes, k_scan<20, 2, 12> 500, k_newview_chain<20, 2> 1 KiB per lane,
+    //  round 5's disassembly --; the knob rests for these alphabets since round 6 and the instantiations are gone)
+    if (g_.S >= 20) return MPF_OK;
     g_.vw = (int)v;
     return MPF_OK;
   }

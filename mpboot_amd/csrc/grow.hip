@@ -719,7 +719,12 @@ template <int KS, int VW>
 constexpr bool g_tight() { return (KS == 1 && VW <= 4) || KS == 4; }
 
 template <int KS, int VW>
-const void *g_kernel() { return g_tight<KS, VW>() ? reinterpret_cast<const void *>(&k_grow_tight<KS, VW>) : reinterpret_cast<const void *>(&k_grow<KS, VW>); }
+const void *g_kernel()
+{
+  // (one of the two per shape: the other would be compiled for nothing -- and the tight form of the wide shapes spills)
+  if constexpr (g_tight<KS, VW>()) return reinterpret_cast<const void *>(&k_grow_tight<KS, VW>);
+  else return reinterpret_cast<const void *>(&k_grow<KS, VW>);
+}
 
 template <int KS, int VW>
 hipError_t g_launch(hipStream_t st, const GrowParams &p)

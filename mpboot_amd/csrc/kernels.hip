@@ -532,8 +532,12 @@ __global__ __launch_bounds__(1024) void k_newview_wgq(uint32_t *__restrict__ vec
 // result in registers and the valid inputs prefetched two links ahead, and barriers separate only the (few) levels of
 // the chain graph.  ops of (level l, wave w) = [wl_off[16 l + w], wl_off[16 l + w + 1]); o.a == kPrev = "previous result".
 constexpr uint32_t kPrev = 0xFFFFFFFFu;
+// Wide state sets (protein, 32-symbol data) keep D + 2 tiles of S registers each: at sixteen waves per workgroup (128 registers a
+// lane) those spilled to scratch (round 5: 560-1300 bytes per lane).  They run EIGHT waves -- 256 registers --, each wave taking
+// two of the sixteen chain slots of a level one after the other.
+template <int S, int VW> constexpr int chain_waves() { return S * VW >= 16 ? 8 : 16; }
 template <int S, int VW, int RED, int D>
-__global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
+__global__ __launch_bounds__((chain_waves<S, VW>() * 64)) void k_newview_chain(uint32_t *__restrict__ vec, const NvOp *__restrict__ ops,
                                                         const int32_t *__restrict__ wl_off, int n_lev,
                                                         uint32_t *__restrict__ cntp, uint32_t nslots, int Wp,
                                                         uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, int n_ops,
@@ -553,17 +557,22 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
     for (uint32_t i = (uint32_t)gt; i < x.zero_words; i += (uint32_t)gn) x.zero_ptr[i] = 0u;
   }
   for (int l = 0; l < n_lev; l++) {
-    const int b = wl_off[l * 16 + wave], e = wl_off[l * 16 + wave + 1];
+   for (int ws = wave; ws < 16; ws += chain_waves<S, VW>()) {
+    const int b = wl_off[l * 16 + ws], e = wl_off[l * 16 + ws + 1];
     if (b < e) {
       // D register sets in rotation (no copies of in-flight registers): set d holds the operands of ops b + d, b + d + D, ...
       // requested D ops before they are combined; the op descriptors (scalar loads) run another D ahead
+      // Wide state sets: only the operand nearly every op has -- the valid vector b -- rotates through D sets; the first operand of
+      // a chain's HEAD (the one op per chain that does not continue the running result) is fetched when it is needed.  With a[D]
+      // as well the 20-row kernel kept 52-76 bytes per lane in scratch even at 256 registers, the 32-row one 700.
+      constexpr bool TA1 = S * VW >= 16;
       NvOp o[D], nx[D];
-      Tile<S, VW> ta[D], tb[D], c;
+      Tile<S, VW> ta[TA1 ? 1 : D], tb[D], c;
 #pragma unroll
       for (int d = 0; d < D; d++) o[d] = ops[b + d < e ? b + d : e - 1];
 #pragma unroll
       for (int d = 0; d < D; d++) {                 // unconditional (indices are clamped): keeps the request counts static
-        if (o[d].a != kPrev) load_tile<S, VW>(ta[d], vec, o[d].a, Wp, w0);
+        if constexpr (!TA1) { if (o[d].a != kPrev) load_tile<S, VW>(ta[d], vec, o[d].a, Wp, w0); }
         load_tile<S, VW>(tb[d], vec, o[d].b, Wp, w0);
       }
 #pragma unroll
@@ -573,7 +582,8 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
   {                                                                                                      \
     uint32_t cost;                                                                                       \
     if (o[d].a != kPrev) {                                                                               \
-      cost = fitch<S, VW>(c, ta[d], tb[d]);                                                              \
+      if constexpr (TA1) load_tile<S, VW>(ta[0], vec, o[d].a, Wp, w0);                                   \
+      cost = fitch<S, VW>(c, ta[TA1 ? 0 : d], tb[d]);                                                    \
     } else {                                                                                             \
       Tile<S, VW> p = c;                                                                                 \
       cost = fitch<S, VW>(c, p, tb[d]);                                                                  \
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
     if (lane == 0) cntp[(size_t)tile * nslots + o[d].dst] = tot;                                         \
     o[d] = nx[d];                                                                                        \
     if (RELOAD) {                                                                                        \
-      if (o[d].a != kPrev) load_tile<S, VW>(ta[d], vec, o[d].a, Wp, w0);                                 \
+      if constexpr (!TA1) { if (o[d].a != kPrev) load_tile<S, VW>(ta[d], vec, o[d].a, Wp, w0); }         \
       load_tile<S, VW>(tb[d], vec, o[d].b, Wp, w0);                                                      \
     }                                                                                                    \
   }
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(1024) void k_newview_chain(uint32_t *__restrict__ v
       }
 #undef MPF_CHAIN_STEP
     }
+   }
     __syncthreads();
   }
   if (!done) return;                              // large refresh: launch_cntsum folds the counts with the whole chip
@@ -1661,7 +1672,7 @@ struct ProgEnt4 { ProgEnt e[4]; };               // four entries = one 64-byte s
 // EXPR (experiments, MPF_PROG_EXPERIMENT): 0 = the kernel; 1 = no vector loads in the loop (children = register garbage:
 // arithmetic + control only); 2 = loads only (one AND per loaded register instead of the Fitch arithmetic)
 template <int S, int VW, bool BIG, int EXPR = 0, bool WM = false>
-__global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : 4) void k_scan_prog(const uint32_t *__restrict__ vec, const WalkDesc *__restrict__ desc, int n_scans,
+__global__ __launch_bounds__(64, (S * VW <= 4) ? 8 : (S * VW <= 8) ? 4 : 2) void k_scan_prog(const uint32_t *__restrict__ vec, const WalkDesc *__restrict__ desc, int n_scans,
                                                          const ProgEnt *__restrict__ prog, uint32_t *__restrict__ out,
                                                          uint32_t *__restrict__ ncand, int Wp, int tiles, int map,
                                                          uint32_t *__restrict__ host_out, uint32_t n_out, uint32_t *__restrict__ done,
@@ -2325,8 +2336,7 @@ hipError_t launch_pack_tips(hipStream_t st, const Geometry &g, uint32_t *vec, co
       else if (g.vw == 2) { FN(4, 2, __VA_ARGS__); }                               \
       else { FN(4, 4, __VA_ARGS__); }                                              \
     } else if (g.S == 20) {                                                        \
-      if (g.vw == 1) { FN(20, 1, __VA_ARGS__); }                                   \
-      else { FN(20, 2, __VA_ARGS__); }                                             \
+      FN(20, 1, __VA_ARGS__);      /* 20 states: one word per lane (engine.cpp, "words_per_lane") */ \
     } else {                                                                       \
       FN(32, 1, __VA_ARGS__);      /* 32 states: one word per lane */              \
     }                                                                              \
@@ -2396,7 +2406,9 @@ hipError_t launch_newview_levels(hipStream_t st, const Geometry &g, uint32_t *ve
   }
 #define NW(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_wg<S_, VW_, RED_>), grid, block, 0, st, vec, ops, lev_off, n_lev, cntp, nslots, g.Wp, cnt, done, x)
 #define NW2(S_, VW_, dummy) do { if (g.reduce == 0) NW(S_, VW_, 0); else NW(S_, VW_, 1); } while (0)
-  MPF_DISPATCH_SV(NW2, 0);
+  // (several words per lane: DNA only -- wider alphabets run one word per lane and took the branches above)
+  if (g.S != 4) return hipErrorInvalidValue;
+  if (g.vw == 2) NW2(4, 2, 0); else NW2(4, 4, 0);
 #undef NW2
 #undef NW
   return hipGetLastError();
@@ -2407,10 +2419,10 @@ hipError_t launch_newview_chains(hipStream_t st, const Geometry &g, uint32_t *ve
                                  const RefreshExtra &x)
 {
   if (n_lev <= 0) return hipSuccess;
-  dim3 grid((unsigned)tiles_of(g)), block(1024);
+  dim3 grid((unsigned)tiles_of(g));
   RefreshExtra xs = x;
   if (g.shoff && g.S == 4 && g.vw == 1) xs.shadow = vec + g.shoff;
-#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 4 ? 4 : 2)>), grid, block, 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, xs)
+#define NC(S_, VW_, RED_) hipLaunchKernelGGL((k_newview_chain<S_, VW_, RED_, (S_ * VW_ <= 4 ? 4 : 2)>), grid, dim3(chain_waves<S_, VW_>() * 64), 0, st, vec, ops, wl_off, n_lev, cntp, nslots, g.Wp, cnt, done, n_ops, xs)
 #define NC2(S_, VW_, dummy) do { if (g.reduce == 0) NC(S_, VW_, 0); else NC(S_, VW_, 1); } while (0)
   MPF_DISPATCH_SV(NC2, 0);
 #undef NC2
@@ -2513,7 +2525,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
 #undef SNKSCAN3
     return hipGetLastError();
   }
-  if (max_depth > kMaxDepth) {
+  if (max_depth > scan_reg_depth(g.S, false)) {
     // beyond the levels that fit registers: k_scan_deep, cut into launches whose waves' scratch (levels x one tile each) stays
     // within scan_deep_scratch_words
     if (host_out || !g.deep_scratch) return hipErrorInvalidValue;
@@ -2550,7 +2562,7 @@ hipError_t launch_scan(hipStream_t st, const Geometry &g, const uint32_t *vec, c
 #define SC2(S_, VW_, dummy)                                                          \
   do {                                                                               \
     if (max_depth <= 6) { if (g.reduce == 0) SC(S_, VW_, 6, 0); else SC(S_, VW_, 6, 1); } \
-    else { if (g.reduce == 0) SC(S_, VW_, 12, 0); else SC(S_, VW_, 12, 1); }         \
+    else if constexpr (scan_reg_depth(S_, false) > 6) { if (g.reduce == 0) SC(S_, VW_, 12, 0); else SC(S_, VW_, 12, 1); } \
   } while (0)
   MPF_DISPATCH_SV(SC2, 0);
 #undef SC2
@@ -2725,7 +2737,12 @@ hipError_t launch_part_min(hipStream_t st, const uint32_t *out, const uint2 *par
   return hipGetLastError();
 }
 
-bool scan_prog_supported(const Geometry &g, int max_depth) { return !g.sankoff && g.S == 4 && (g.vw == 1 || g.vw == 2) && max_depth <= 6; }
+// DNA (one or two words per lane) and, since round 6, the 20-row alphabets (one word per lane, row-major loads: C5's Fitch sweep ran on the
+// device-walked kernel before, every wave chasing kids[] itself)
+bool scan_prog_supported(const Geometry &g, int max_depth)
+{
+  return !g.sankoff && max_depth <= 6 && ((g.S == 4 && (g.vw == 1 || g.vw == 2)) || (g.S == 20 && g.vw == 1 && !g.big));
+}
 
 size_t scan_prog_blocks(const Geometry &g, int n_scans)
 {
@@ -2757,7 +2774,8 @@ hipError_t launch_scan_prog(hipStream_t st, const Geometry &g, const uint32_t *v
   else if (expr == 2) hipLaunchKernelGGL((k_scan_prog<4, 1, false, 2>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else
 #endif
-  if (g.big) SP(1, true);
+  if (g.S == 20) hipLaunchKernelGGL((k_scan_prog<20, 1, false>), grid, block, 0, st, vec, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
+  else if (g.big) SP(1, true);
   else if (vw == 1 && word_major && g.shoff)
     hipLaunchKernelGGL((k_scan_prog<4, 1, false, 0, true>), grid, block, 0, st, vec + g.shoff, desc, n_scans, pg, out, ncand, g.Wp, tiles, g.map, host_out, n_out, done, trace);
   else if (vw == 1) SP(1, false);

@@ -35,6 +35,9 @@ struct WalkDesc { uint32_t s_cid, xa_cid, xb_cid, trav /* mintrav | maxtrav<<8 |
                   out_base, pad0, pad1, pad2; };
 constexpr int kWalkMaxDepth = 8;    // deepest device-walked scan (k_scan_walk); longer radii use the host-planned k_scan
 constexpr int kMaxDepth = 12;   // deepest chain the register-resident scan kernel supports
+// ... for 4- and 20-row tiles.  32-row tiles: 6 (thirteen of them do not fit a lane's 512 registers: k_scan<32, 1, 12> spilled);
+// longer radii there take the HBM-scratch kernel like everything above kMaxDepth
+constexpr int scan_reg_depth(int S, bool sankoff) { return sankoff ? (S != 4 ? 6 : kMaxDepth) : (S >= 32 ? 6 : kMaxDepth); }
 
 struct Geometry {
   int S;        // states (4 | 20)
