@@ -1280,9 +1280,19 @@ def main():
                                   # v_pk_add_u16 / v_pk_min_u16 issue once per 1.76 ns per SIMD (tools/ubench/valu_rate, profiles/r3/valu_rate.txt)
                                   "measured_issue_ceiling": 1024 * 128 / 1.76e-9 / 1e12,
                                   "frac_of_measured_issue_ceiling": ach5 / (1024 * 128 / 1.76e-9 / 1e12),
+                                  # the kernel's other bound (profiles/r6/snk_scan_pmc.txt: FETCH_SIZE x 2 per launch of this sweep,
+                                  # SQ_INSTS_VALU per launch; counters of the committed build, not of this run)
+                                  "hbm": {"traffic_per_launch_bytes": 73.9e9, "achieved": 73.9 / scan5 if scan5 > 0 else None, "peak": 8000.0,
+                                          "unit": "GB/s", "frac": 73.9 / scan5 / 8000.0 if scan5 > 0 else None,
+                                          "source": "profiles/r6/snk_scan_pmc.txt (rocprofv3 --pmc FETCH_SIZE, gfx950 correction x 2)"},
+                                  "valu_issue": {"wave_instructions_per_launch": 9.37e9, "ns_per_instruction_and_simd_two_waves": 1.95,
+                                                 "issue_ms": 9.37e9 * 1.95e-9 / 1024 * 1e3,
+                                                 "frac_of_kernel_time": 9.37e9 * 1.95e-9 / 1024 * 1e3 / scan5 if scan5 > 0 else None},
                                   "note": "min-plus arithmetic on packed 16-bit costs (v_pk_add_u16 / v_pk_min_u16: two patterns per lane); "
                                           "achieved = insertion tests x patterns x (2 S^2 + 3 S) / HIP-event time of the scan kernel; peak = "
-                                          "256 CUs x 4 SIMD-32 x 2.4 GHz x 2 values per lane"}}
+                                          "256 CUs x 4 SIMD-32 x 2.4 GHz x 2 values per lane.  The kernel also moves 74 GB per launch from HBM "
+                                          "(two 800 KB vectors per test, nothing re-used within an L2's reach): hbm.*; valu_issue = what its "
+                                          "9.4e9 wave-instructions cost at the rate two resident waves per SIMD reach"}}
             if not args.no_cpu:
                 from oracle import pyoracle as po5
                 o5 = po5.Oracle(codes5, datatype=po5.AA, cost=cost5)

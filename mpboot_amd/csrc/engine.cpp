@@ -243,15 +243,26 @@ int Engine::pack()
     HIPCHK(hipMemcpyAsync(d_pwgt_.p, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
     {
       // the device copy of the cost matrix: in the 16-bit packing every entry twice (c | c << 16)
-      cost_dev_.resize(cost_.size());
-      for (size_t i = 0; i < cost_.size(); i++) cost_dev_[i] = g_.snk16 ? (cost_[i] | (cost_[i] << 16)) : cost_[i];
+      // ... and, behind the S x S entries, the pair-packed rows the scan kernel's 16-bit transform reads (c[z][2j] | c[z][2j + 1] << 16:
+      // kernels.hip, mplus on a pair-packed matrix)
+      const size_t SS = cost_.size(), S_ = (size_t)g_.S;
+      auto with_pairs = [&](std::vector<uint32_t> &dev, auto entry) {
+        dev.assign(SS + SS / 2, 0u);
+        for (size_t z = 0; z < S_; z++)
+          for (size_t x = 0; x < S_; x++) {
+            const uint32_t c = entry(z, x);
+            dev[z * S_ + x] = g_.snk16 ? (c | (c << 16)) : c;
+            if (g_.snk16) dev[SS + z * (S_ / 2) + x / 2] |= (c & 0xFFFFu) << (16 * (x & 1));
+          }
+      };
+      with_pairs(cost_dev_, [&](size_t z, size_t x) { return cost_[z * S_ + x]; });
+      HIPCHK(d_cost_.reserve(cost_dev_.size()));
       HIPCHK(hipMemcpyAsync(d_cost_.p, cost_dev_.data(), cost_dev_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
       g_.costT = nullptr;
       if (asym_) {
         const int S = g_.S;
-        costT_dev_.resize(cost_.size());
-        for (int i = 0; i < S; i++)
-          for (int j = 0; j < S; j++) costT_dev_[(size_t)i * S + j] = cost_dev_[(size_t)j * S + i];
+        (void)S;
+        with_pairs(costT_dev_, [&](size_t z, size_t x) { return cost_[x * S_ + z]; });
         HIPCHK(d_costT_.reserve(costT_dev_.size()));
         HIPCHK(hipMemcpyAsync(d_costT_.p, costT_dev_.data(), costT_dev_.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
         g_.costT = d_costT_.p;

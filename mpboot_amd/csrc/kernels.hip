@@ -1936,6 +1936,46 @@ __device__ __forceinline__ void mplus(Costs<S, PK> &m, const Costs<S, PK> &v, co
   }
 }
 
+// The 16-bit form of the transform on a PAIR-PACKED matrix (round 6): the device copy of the cost matrix carries, behind its S x S
+// replicated entries (c | c << 16), S x S / 2 words holding two neighbouring entries of a row each (c[z][2j] | c[z][2j + 1] << 16);
+// VOP3P's op_sel picks which half of the scalar operand feeds BOTH halves of the packed add, so a group of four rows needs 40
+// scalar registers instead of 80 -- the matrix operand of the next group can be on its way while this one is combined (with 80 of
+// the ~100 scalar registers tied up per group the loads could not run ahead: the transform waited on the scalar cache for about
+// as long as its 780 packed operations took, profiles/r3/valu_rate.txt).
+// (written as shuffles of the scalar word: the instruction selector folds them into the packed add's op_sel / op_sel_hi bits --
+//  inline asm for the same instruction kept the compiler from scheduling around it and cost 1.2 KB of scratch per lane)
+__device__ __forceinline__ us2 pk_add_lo(us2 v, uint32_t c2) { const us2 p = __builtin_bit_cast(us2, c2); return v + __builtin_shufflevector(p, p, 0, 0); }
+__device__ __forceinline__ us2 pk_add_hi(us2 v, uint32_t c2) { const us2 p = __builtin_bit_cast(us2, c2); return v + __builtin_shufflevector(p, p, 1, 1); }
+template <int S>
+__device__ __forceinline__ void mplus(Costs<S, true> &m, const Costs<S, true> &v, const uint32_t *__restrict__ cost, int /* pair-packed */)
+{
+  typedef SnkT<true> T;
+  static_assert(S % 4 == 0, "state count must be a multiple of 4");
+  const uint32_t *__restrict__ c2 = cost + S * S;
+  constexpr int H = S / 2;
+#pragma unroll
+  for (int z0 = 0; z0 < S; z0 += 4) {
+    us2 a0, a1, a2, a3;
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+      const uint32_t w0 = c2[(z0 + 0) * H + j], w1 = c2[(z0 + 1) * H + j], w2 = c2[(z0 + 2) * H + j], w3 = c2[(z0 + 3) * H + j];
+      const us2 t0 = pk_add_lo(v.v[2 * j], w0), t1 = pk_add_lo(v.v[2 * j], w1), t2 = pk_add_lo(v.v[2 * j], w2), t3 = pk_add_lo(v.v[2 * j], w3);
+      if (j == 0) { a0 = t0; a1 = t1; a2 = t2; a3 = t3; }
+      else { a0 = T::mn(a0, t0); a1 = T::mn(a1, t1); a2 = T::mn(a2, t2); a3 = T::mn(a3, t3); }
+      const us2 u0 = pk_add_hi(v.v[2 * j + 1], w0), u1 = pk_add_hi(v.v[2 * j + 1], w1), u2 = pk_add_hi(v.v[2 * j + 1], w2), u3 = pk_add_hi(v.v[2 * j + 1], w3);
+      a0 = T::mn(a0, u0); a1 = T::mn(a1, u1); a2 = T::mn(a2, u2); a3 = T::mn(a3, u3);
+    }
+    m.v[z0] = a0; m.v[z0 + 1] = a1; m.v[z0 + 2] = a2; m.v[z0 + 3] = a3;
+  }
+}
+// (the scan kernels' call: pair-packed for the 16-bit form, the plain matrix otherwise)
+template <int S, bool PK>
+__device__ __forceinline__ void mplus_fast(Costs<S, PK> &m, const Costs<S, PK> &v, const uint32_t *__restrict__ cost)
+{
+  if constexpr (PK) mplus<S>(m, v, cost, 0);
+  else mplus<S, PK>(m, v, cost);
+}
+
 template <int S, bool PK>
 __device__ __forceinline__ void newview_one_snk(uint32_t *__restrict__ vec, size_t moff, const NvOp o, const uint32_t *__restrict__ cost,
                                                 uint32_t *__restrict__ cntp, uint32_t nslots, int We, int tile, int lane)
@@ -2045,6 +2085,10 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
 {
   typedef SnkT<PK> T;
   const int lane = threadIdx.x & 63;
+  // Work items = (scan, tile of 64 elements), scan-major: the 157 tile-waves of a C5 scan read WHOLE rows of its vectors between
+  // them (a row is 40 KB of consecutive bytes).  Round 6 tried the Fitch kernels' XCD classes with a tile-major order inside a class
+  // (an XCD's waves = neighbouring scans of one tile, for L2 reuse): 31.0 ms against 24.8 -- 256-byte pieces of 20 rows of many
+  // vectors are a worse stream for the memory system than whole rows, and 4 MB of L2 hold 40 of these vectors' pieces anyway.
   int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   gw = __builtin_amdgcn_readfirstlane(gw);
   if (gw >= n_scans * tiles) return;
@@ -2067,7 +2111,7 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
   Costs<S, PK> ms, MU[MAXD + 1], t1, t2;
   if (ASYM && (h.pad & 1u)) {                       // stepwise addition: the new tip is the root side
     ldv(t2, h.s_slot);
-    mplus<S, PK>(ms, t2, costT);
+    mplus_fast<S, PK>(ms, t2, costT);
   } else ldm(ms, h.s_slot);
 
   for (uint32_t i = h.op_begin; i < h.op_end; i++) {
@@ -2099,11 +2143,11 @@ __global__ __launch_bounds__(256, (S == 20 && MAXD <= 6) ? 2 : 1) void k_snk_sca
     if constexpr (c <= MAXD) {                                                         \
       _Pragma("unroll") for (int s = 0; s < S; s++) t2.v[s] = T::add(t1.v[s], MU[c - 1].v[s]); /* U[c] */ \
       if (ASYM && test) {   /* the near side is the root side of the test: mT(U) first, in MU[c]'s registers */ \
-        mplus<S, PK>(MU[c], t2, costT);                                                \
+        mplus_fast<S, PK>(MU[c], t2, costT);                                                \
         ldm(t1, o.own);                                    \
         _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
       }                                                                                \
-      mplus<S, PK>(MU[c], t2, cost);                                                   \
+      mplus_fast<S, PK>(MU[c], t2, cost);                                                   \
       if (!ASYM && test) {                                                             \
         ldm(t1, o.own);                                    \
         _Pragma("unroll") for (int s = 0; s < S; s++) best = T::mn(best, T::add(T::add(t1.v[s], MU[c].v[s]), ms.v[s])); \
