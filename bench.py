@@ -964,6 +964,34 @@ def main():
                 t_plain_h = time.perf_counter() - t0r
                 eng.set_option("climb_device", 1)
                 assert s_plain_h == s_plain
+                # ... and with every sweep in the persistent kernel (climb_device 2): k_climb's own data rate and where a step's time goes
+                eng.set_option("climb_device", 2)
+                eng.set_tree(back_r)
+                eng.reset_node_order()
+                eng.seed_ties(engine.TIE_RANDOM, 1)
+                eng.reset_stats()
+                ph0 = np.array([eng.get_option("climb_phase_us%d" % k_) for k_ in range(7)], dtype=np.float64)
+                barrier()
+                t0r = time.perf_counter()
+                s_plain_k = eng.optimize_spr(1, args.maxtrav)
+                barrier()
+                t_plain_k = time.perf_counter() - t0r
+                ph1 = np.array([eng.get_option("climb_phase_us%d" % k_) for k_ in range(7)], dtype=np.float64)
+                st_k = eng.stats()
+                eng.set_option("climb_device", 1)
+                assert s_plain_k == s_plain
+                vec_b = int(eng.S) * int(eng.Wp) * 4
+                k_ms = st_k["climb_ms_total"]
+                k_ach = st_k["insertion_tests"] * vec_b / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+                climb_roof = {"bound": "l2", "achieved": k_ach, "peak": 34500.0, "unit": "GB/s", "frac": k_ach / 34500.0, "traffic": None,
+                              "kernel": "k_climb", "launches": st_k["climb_launches"], "steps": st_k["climb_steps"], "kernel_ms": k_ms,
+                              "seconds_all_in_kernel": t_plain_k, "insertion_tests": st_k["insertion_tests"], "bytes_per_test": vec_b,
+                              "us_per_step": k_ms * 1e3 / max(1, st_k["climb_steps"]),
+                              "phase_us_per_step": dict(zip(["filter", "enumerate_and_walk", "closure", "refresh", "scan", "exchange", "decide"],
+                                                            ((ph1 - ph0) / max(1, st_k["climb_steps"])).round(2).tolist())),
+                              "note": "the whole climb in the persistent kernel: insertion tests x one vector (the bytes a test needs, as the headline "
+                                      "prices k_scan_prog) / the kernel's own time, against the aggregate L2 -> CU rate.  A step is a chain of "
+                                      "dependent phases on ~100 candidates per workgroup: the kernel is bound by their latencies, not by this rate"}
                 nondeg = {"start": "random topology (numpy default_rng(2024))", "start_score": eng.score_tree(back_r),
                           "plain_climb": {"seconds": t_plain, "score": s_plain, "moves": st_plain["moves_applied"],
                                           "insertion_tests": st_plain["insertion_tests"], "scan_launches": st_plain["scan_launches"],
@@ -971,7 +999,7 @@ def main():
                                           "climb_kernel": {"launches": st_plain["climb_launches"], "steps": st_plain["climb_steps"],
                                                            "prune_nodes": st_plain["climb_nodes"], "moves": st_plain["climb_moves"],
                                                            "ms": st_plain["climb_ms_total"]},
-                                          "seconds_host_driven_batches": t_plain_h,
+                                          "seconds_host_driven_batches": t_plain_h, "roofline": climb_roof,
                                           "what": "pllOptimizeSprParsimony from a random tree: sweeps with dense moves run in the persistent kernel "
                                                   "k_climb (device-resident loop), sparse ones as whole-chip host-driven batches"}}
                 eng.ufboot_attach(samples, 0.5, shard=shard.online_shard(B, rank, world, args.shard_online), exchange=native_x)

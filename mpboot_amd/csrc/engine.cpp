@@ -226,14 +226,13 @@ int Engine::pack()
     // no intermediate can reach 2^16: a view entry is at most (tips below) x max cost, a candidate sums three terms
     const bool want16 = snk16_opt_ != 0 && 3ull * (uint64_t)n_ * (uint64_t)g_.highest_cost < 65536ull;
     if (wp != g_.Wp || !d_vec_ || (int)want16 != g_.snk16) {
-      if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
       g_.Wp = wp;
       g_.snk16 = want16 ? 1 : 0;
       vec_words_ = nslots_ * (size_t)g_.S * (size_t)(want16 ? g_.Wp / 2 : g_.Wp);
       // weighted mode keeps m(v) = min-plus transform of every vector next to v (second half of the allocation): a
       // transform costs 2 S^2 operations per pattern, and each stored one is used by up to three consumers
       g_.moff = vec_words_;
-      HIPCHK(hipMalloc((void **)&d_vec_, 2 * vec_words_ * sizeof(uint32_t)));
+      HIPCHK(vec_store_fit(2 * vec_words_ * sizeof(uint32_t)));
     }
     std::vector<uint32_t> pw((size_t)g_.Wp, 0u);
     for (int j = 0; j < ninf_; j++) pw[(size_t)j] = (uint32_t)wgt_[(size_t)inf_index_[(size_t)j]];
@@ -298,14 +297,13 @@ int Engine::pack()
   int wp = ((ce + 31) / 32) * 32;                      // our row pitch: whole 128-byte lines
   if (wp == 0) wp = 32;
   if (wp != g_.Wp || !d_vec_) {
-    if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; }
     g_.Wp = wp;
     vec_words_ = nslots_ * (size_t)g_.S * g_.Wp;
     // below 2 GiB the scan kernel addresses the whole store through one raw buffer (32-bit offsets); above, 64-bit bases
     g_.big = (force_big_ || vec_words_ * sizeof(uint32_t) >= ((size_t)1 << 31)) ? 1 : 0;
     // DNA below 2 GiB: room for the word-major copy the planned scan reads (Geometry::shoff)
     g_.shoff = (g_.S == 4 && vec_words_ * sizeof(uint32_t) < ((size_t)1 << 31)) ? vec_words_ : 0;
-    HIPCHK(hipMalloc((void **)&d_vec_, (vec_words_ + (g_.shoff ? vec_words_ : 0)) * sizeof(uint32_t)));
+    HIPCHK(vec_store_fit((vec_words_ + (g_.shoff ? vec_words_ : 0)) * sizeof(uint32_t)));
   }
   shadow_ok_ = false;                          // (until the tips' copies are rewritten below: invalidate_vectors sets it again)
   std::vector<int32_t> s2p((size_t)std::max(nsites_, 1));
@@ -318,6 +316,19 @@ int Engine::pack()
   HIPCHK(hipStreamSynchronize(st_));
   invalidate_vectors();                      // (re-weighting changes every vector, not the tree)
   return MPF_OK;
+}
+
+// The vector store follows the packing: a re-weighting changes the row pitch (a ratchet climb packs half of the informative sites once
+// more: +50 %, and the climb behind it the original sites again).  The ALLOCATION only ever grows -- rounds 1-5 freed and allocated
+// it on every change of the pitch, four times per ratchet iteration, and hipFree waits for the whole device: every other engine's
+// stream stood still each time (eight chains of an iteration-parallel -bb run spent more time there than in their kernels).
+hipError_t Engine::vec_store_fit(size_t bytes)
+{
+  if (d_vec_ && bytes <= vec_cap_bytes_) return hipSuccess;
+  if (d_vec_) { (void)hipFree(d_vec_); d_vec_ = nullptr; vec_cap_bytes_ = 0; }
+  const hipError_t e = hipMalloc((void **)&d_vec_, bytes);
+  if (e == hipSuccess) vec_cap_bytes_ = bytes;
+  return e;
 }
 
 int Engine::set_weights(const int32_t *weights)

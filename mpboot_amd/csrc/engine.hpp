@@ -358,6 +358,8 @@ class Engine {
   int ufboot_tree_logl(double *out) const;
   int ufboot_state(double *boot_logl, int32_t *boot_counts, int32_t *boot_trees) const;
   int ufboot_tree(int64_t tree_index, int32_t *back) const;
+  hipError_t vec_store_fit(size_t bytes);
+  size_t vec_cap_bytes_ = 0;
   int ufboot_adopt(int n_upd, const int32_t *sample, const uint32_t *score, const int32_t *tree_of, int n_trees, const int32_t *backs,
                    const uint32_t *lengths, int32_t *n_taken);
   int ufboot_counters(uint64_t *draws, uint64_t *events, uint64_t *gemm_rows, double *gemm_ms) const;
