@@ -24,11 +24,11 @@ run_leg () {   # name, bench args, counter groups...
   find $D/trace -name "*kernel_stats.csv" -exec cp {} $D/kernel_stats.csv \;
   rm -rf $D/trace $D/pmc_*
 }
-run_leg main "--steps 5 --warmup 1 --no-cpu --bootstrap-replicates 0 --ufboot-samples 0 --random-start-leg 0 --weighted-leg 0 --start-trees 0 --climb-engines 0 --tree-cache $OUT/tree $*" \
+run_leg main "--legs none --steps 5 --warmup 1 --no-cpu --bootstrap-replicates 0 --ufboot-samples 0 --random-start-leg 0 --weighted-leg 0 --start-trees 0 --climb-engines 0 --tree-cache $OUT/tree $*" \
   FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
   "SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" GRBM_GUI_ACTIVE
-run_leg ufboot "--steps 1 --warmup 0 --no-cpu --bootstrap-replicates 0 --random-start-leg 0 --weighted-leg 0 --start-trees 0 --climb-engines 0 --tree-cache $OUT/tree $*" \
+run_leg ufboot "--legs none --steps 1 --warmup 0 --no-cpu --bootstrap-replicates 0 --random-start-leg 0 --weighted-leg 0 --start-trees 0 --climb-engines 0 --tree-cache $OUT/tree $*" \
   FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
   "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES" \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" GRBM_GUI_ACTIVE
