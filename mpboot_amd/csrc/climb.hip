@@ -79,6 +79,7 @@ struct Sh {
   unsigned long long rng, hits, n_tests, n_ops, draws, n_nodes;
   uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, pn_base[kMaxB];
   uint32_t xcc, xm;                          // this workgroup's XCD and how many of the launch's workgroups share it
+  uint32_t gap_ema;                          // recent distance between accepted moves in prune nodes, x 8 (decide: the batch after a move)
   uint32_t qtail;                            // vectors the step's scans read, listed by the enumeration (validity looked at later)
   uint32_t moved, einv, inv5[5];             // the move decide_select applied: stamp and touched nodes for the invalidation walk
   Unit unit[kMaxUnits];
@@ -899,13 +900,20 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     sh.pos = pos;
     sh.steps++;
     sh.epoch += 2u;
-    const uint32_t since = moved ? 0u : sh.since_move + consumed;
+    const uint32_t gap = sh.since_move + consumed;      // prune nodes since the move before (this step's included)
+    const uint32_t since = moved ? 0u : gap;
     sh.since_move = since;
     // a batch is wasted behind the first accepted move; after a step without one the next looks twice as far ahead -- and after a
     // move that was sixteen or more prune nodes away half as far as that (moves come in stretches of similar density: a sweep near an
     // optimum does not start from two prune nodes again after each of its rare moves)
-    const uint32_t gap = sh.since_move + consumed;
-    uint32_t B = moved ? (gap >= 16u ? gap / 2u : P.batch_min) : sh.B * 2u;
+    // (round 6) ... and after a nearer one about three quarters of the recent average distance between moves: a climb from a
+    // random tree moves at every first or second prune node (batch_min it is), one from a tree perturbed by 498 NNIs at every
+    // sixth, where restarting from two prune nodes cost a step in three for nothing (C3: 798 -> ~620 steps per such climb)
+    // (round 5 took this distance AFTER the counter had been reset: it never saw more than the step's own prune nodes)
+    if (moved) sh.gap_ema = (3u * sh.gap_ema + 8u * (gap > 64u ? 64u : gap) + 2u) >> 2;
+    uint32_t b_near = (sh.gap_ema * 3u / 4u + 4u) >> 3;
+    b_near = b_near < P.batch_min ? P.batch_min : b_near;
+    uint32_t B = moved ? (gap >= 16u ? gap / 2u : b_near) : sh.B * 2u;
     B = B > P.batch_max ? P.batch_max : B;
     B = B < 1u ? 1u : B;
     if (pos <= P.total && B > P.total - pos + 1u) B = P.total - pos + 1u;      // (not beyond the end of the sweep)
@@ -1095,6 +1103,7 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
   if (tid == 0) {
     const ClimbHeader h = *P.hdr;
     sh.pos = h.pos; sh.B = h.batch ? h.batch : P.batch_min; sh.epoch = 1u; sh.exit_reason = CLIMB_RUNNING;
+    sh.gap_ema = 8u * P.batch_min;
     sh.since_move = h.since_move; sh.rtail = 0; sh.steps = 0; sh.xgen = 0; sh.n_moves = 0; sh.err = 0; sh.trace_n = 0;
     sh.last_ncand[0] = sh.last_ncand[1] = sh.last_ncand[2] = 0;
     sh.best = h.best; sh.randomMP = h.randomMP; sh.iter_hits = h.iter_hits; sh.ins = h.insert_cid; sh.rem = h.remove_cid;
@@ -1355,7 +1364,7 @@ bool climb_supported(const Geometry &g, int n_taxa, int maxtrav)
   if (maxtrav < 1 || maxtrav > kDepth) return false;
   if (slots_of(n_taxa) + 16u >= 0xFFFFu) return false;
   if (climb_tiles(g, 1) >= (1 << 20)) return false;
-  return climb_lds_bytes(g, n_taxa, 1) <= 150 * 1024;
+  return climb_lds_bytes(g, n_taxa, 1) <= kLdsBudget;
 }
 
 hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p)
