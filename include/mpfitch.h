@@ -36,7 +36,7 @@ extern "C" {
 
 #define MPF_ABI_VERSION 8   /* 2: mpf_stats grew (plan_kernel_ms_total, plan_launches), mpf_get_option; 3: mpf_stats grew (climb_*);
                                4: mpf_set_tie_state / mpf_get_tie_state; 5: mpf_ufboot_refine_sweep; 6: mpf_compute_parsimony_at;
-                               8: mpf_iq_* (the search loop's own steps between two climbs), mpf_ufboot_adopt */
+                               8: mpf_iq_* (the search loop's own steps between two climbs), mpf_ufboot_adopt, mpf_optimize_spr_many */
 
 enum {
   MPF_OK = 0,
@@ -213,6 +213,13 @@ int mpf_get_node_order(mpf_engine *e, int32_t *recs /* [2n-2] */);
    (read it back with mpf_get_tree).  *score = final length (tr->bestParsimony); the function's
    own return value in the reference (startMP) equals it. */
 int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *score);
+/* pllOptimizeSprParsimony on n INDEPENDENT engines at once (the 100 start trees of a run, phyloanalysis.cpp:1270-1317; the bootstrap
+   samples' refinement climbs, iqtree.cpp:2797-2862): each engine with its tree set, its weights, its tie rule and stream, as for
+   mpf_optimize_spr -- and each climb makes exactly the moves its own mpf_optimize_spr call would make.  Every sweep of every climb is
+   one resident workgroup of ONE launch per round (k_climb_many), fed by the calling thread; engines the batch cannot take (another
+   alignment shape, a tracker attached, the weighted engine, a host random_double() call-back) run their climb alone inside the call.
+   final_scores[n_engines]. */
+int mpf_optimize_spr_many(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint32_t *final_scores);
 
 /* _pllComputeRandomizedStepwiseAdditionParsimonyTree(tr, pr, sprDist, iqtree)
    (sprparsimony.cpp:3224-3235, :3107-3209): random addition order from PLL randum(seed),

@@ -239,6 +239,18 @@ int mpf_get_node_order(mpf_engine *e, int32_t *recs)
 
 int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *score) { NEED(e); return e->eng.optimize_spr(mintrav, maxtrav, score); }
 
+int mpf_optimize_spr_many(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint32_t *final_scores)
+{
+  if (n_engines < 0 || (n_engines && (!engines || !final_scores))) { set_error("mpf_optimize_spr_many: bad argument"); return MPF_E_INVALID; }
+  std::vector<mpf::Engine *> es((size_t)n_engines);
+  for (int k = 0; k < n_engines; k++) {
+    if (!engines[k]) { set_error("mpf_optimize_spr_many: null engine"); return MPF_E_INVALID; }
+    for (int j = 0; j < k; j++) if (engines[j] == engines[k]) { set_error("mpf_optimize_spr_many: an engine is listed twice"); return MPF_E_INVALID; }
+    es[(size_t)k] = &engines[k]->eng;
+  }
+  return mpf::Engine::climb_many(es.data(), n_engines, mintrav, maxtrav, final_scores);
+}
+
 int mpf_make_parsimony_tree(mpf_engine *e, int64_t seed, int32_t spr_dist, uint32_t *score)
 {
   NEED(e);

@@ -64,7 +64,7 @@ template <int KS, int VW> struct Cfg {
   static constexpr size_t kRegionMax = kPendBytes > 65536 ? kPendBytes : 65536;
   static constexpr size_t kRegionMin = kPendBytes > 40960 ? kPendBytes : 40960;
 };
-constexpr size_t kLdsBudget = 150 * 1024;
+constexpr size_t kLdsBudget = 152 * 1024;      // of the CU's 160 KB
 
 #include "quadtile.hpp"
 
@@ -110,6 +110,8 @@ struct Kx {
   uint16_t *OL;      // [kLcap] the first refresh ops, by index
   uint16_t *ord;     // [total] the sweep's visiting order
   uint16_t *Q;       // [ns] what the enumeration lists (lives in the stage / pend region, idle between decide and refresh)
+  uint32_t *PEND0;   // [kLcap] PEND as the link pass left it  } a workgroup that works through several tiles per step runs the
+  uint16_t *R0;      // [kLcap] the chain starts of the link pass } same refresh once per tile: what a run consumes is put back
   unsigned long long pre, ancl, lsub;   // heap-index relations of this lane (enumeration)
   uint32_t n, ns, SW4;
   uint32_t slots;    // operand slots the region holds
@@ -1014,6 +1016,8 @@ __host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns)
   at += (size_t)kLcap * 2;
   at += (((size_t)(ns / 2 + 1) * 2) + 15) & ~(size_t)15;      // the visiting order: 2n - 2 entries
   at += ns;
+  at = (at + 15) & ~(size_t)15;
+  at += (size_t)kLcap * 4 + (size_t)kLcap * 2;               // PEND0, R0 (multi-tile workgroups)
   return (at + 15) & ~(size_t)15;
 }
 
@@ -1029,14 +1033,18 @@ __host__ __device__ inline size_t region_bytes(uint32_t ns)
   return r;
 }
 
+// The body of a climb's workgroup: workgroup `tile` of the climb's T (k_climb: the launch's grid; k_climb_many: ONE workgroup per
+// climb, every workgroup of the launch another climb with its own ClimbParams).
 template <int KS, int VW>
-__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
+__device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t tile, const uint32_t T)
 {
   constexpr uint32_t kThreads = Cfg<KS, VW>::NT, kNW = Cfg<KS, VW>::NW;
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = (int)rfl((uint32_t)(tid >> 6));
-  const uint32_t tile = blockIdx.x, n = P.n, ns = P.nslots, T = P.tiles;
+  // workgroup `tile` of T; it owns the tiles tile, tile + T, ... of the alignment's TT (T == TT: exactly one)
+  const uint32_t n = P.n, ns = P.nslots, TT = P.tiles;
+  const uint32_t nmine = tile < TT ? (TT - tile + T - 1u) / T : 0u;
   // ---- carve the workgroup's LDS
   Sh &sh = *reinterpret_cast<Sh *>(smem);
   size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
@@ -1057,23 +1065,27 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
   K.cq = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kMaxParts * 128 * 2;
   K.OL = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kLcap * 2;
   K.ord = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)P.total * 2) + 15) & ~(size_t)15;
-  K.valid = reinterpret_cast<uint8_t *>(smem + at);
+  K.valid = reinterpret_cast<uint8_t *>(smem + at); at = (at + ns + 15) & ~(size_t)15;
+  K.PEND0 = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
+  K.R0 = reinterpret_cast<uint16_t *>(smem + at);
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
   { const size_t sl = region_bytes<KS, VW>(ns) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
   K.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
-  K.rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)(P.sct + (size_t)tile * ns * 16), 0, (int)(ns * 64u), 0x00020000);
   K.svoff = ((uint32_t)lane >> 2) * 4u;
   asm volatile("v_mov_b32 %0, 0" : "=v"(K.zero));
   K.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.vec, 0, 0x7FFFFFFF, 0x00020000);
-  {
+  // what depends on the tile of sites at hand: its rows of per-lane subtree scores, the lanes' offsets into a vector, which lanes count
+  auto set_tile = [&](uint32_t t) {
+    K.rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)(P.sct + (size_t)t * ns * 16), 0, (int)(ns * 64u), 0x00020000);
     const uint32_t w = (uint32_t)lane >> 2, g = (uint32_t)lane & 3u;
-    uint32_t word0 = (tile * 16u + w) * (uint32_t)VW;
+    uint32_t word0 = (t * 16u + w) * (uint32_t)VW;
     K.st_lane = word0 < P.Wp;
     if (!K.st_lane) word0 = P.Wp - (uint32_t)VW;         // lanes past the row end load real data and contribute nothing
     K.cnt_lane = K.st_lane && g == 0u;
 #pragma unroll
     for (int k = 0; k < KS; k++) K.voff[k] = ((g * (uint32_t)KS + (uint32_t)k) * P.Wp + word0) * 4u;
-  }
+  };
+  set_tile(tile);
   {
     // heap-index relations of lane h (complete binary tree, root 1): who comes before h in pre-order, which ancestors hold h
     // in their LEFT subtree, who sits in the subtree of h's left child
@@ -1175,51 +1187,108 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
     __syncthreads();
     beat(P, tile, tid, 4, sh.ncand); beat(P, tile, tid, 5, sh.nops); beat(P, tile, tid, 6, sh.rtail); beat(P, tile, tid, 1, 3);
     MPF_TMARK(2);
-    // ---- (3)
-    refresh<KS, VW>(K, sh, tile == 0 && wave == 0);
-    __syncthreads();
-    beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
-    MPF_TMARK(3);
-    // (the refresh's lists are done with: chain starts back to "none", consumer counts to zero -- nothing reads them before the
-    //  next closure, which runs several barriers on)
-    for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
-    if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
-    // ---- (4)
+    // ---- (3) + (4), once per tile of this workgroup.  One tile (the usual launch: a workgroup per tile): as before.  Several:
+    // the SAME refresh and the SAME scans run on the next tile's words of every vector -- what a refresh consumes of the closure's
+    // lists (PEND's counts, the ready list's appended chain starts; on the plain dataflow path the claim words' counts and the
+    // validity flags it raises) is put back in front of every further run, the candidates' counts keep adding up in K.cost, the
+    // base lengths in sh.pn_base.
     const uint32_t ncand = sh.ncand;
-    {
-      // length of the two sides of the prune branch (this tile's share): per-lane scores summed over the word groups -- wave j
-      // asks for prune node j's two score rows now and folds them after its scan tasks
-      // (workgroups of fewer than kMaxB waves: a wave takes prune nodes wave, wave + kNW)
-      constexpr int kBaseRounds = (kMaxB + (int)kNW - 1) / (int)kNW;
-      uint32_t bv[kBaseRounds];
-#pragma unroll
-      for (int rr = 0; rr < kBaseRounds; rr++) {
-        const uint32_t j = (uint32_t)wave + (uint32_t)rr * kNW;
-        bv[rr] = 0;
-        if (j < sh.Beff) {
-          const uint32_t p = rfl(sh.pn_p[j]), q = rfl((uint32_t)K.bk[p]);
-          bv[rr] = ld_sl<KS, VW>(K, p) + ld_sl<KS, VW>(K, q);
+    const bool multi = nmine > 1u;
+    const uint32_t nops_step = sh.nops, rtail0 = sh.rtail, use_static = sh.use_static;
+    uint32_t *snap = P.snap ? P.snap + (size_t)tile * ((size_t)ns + ns / 4u + 1u) : nullptr;
+    if ((uint32_t)tid < kMaxB) sh.pn_base[tid] = 0u;
+    if (multi && nops_step) {
+      if (use_static) {
+        for (uint32_t i = (uint32_t)tid; i < nops_step; i += kThreads) K.PEND0[i] = K.PEND[i];
+        for (uint32_t i = (uint32_t)tid; i < rtail0 && i < kLcap; i += kThreads) K.R0[i] = K.R[i];
+      } else {
+        // (closures beyond the link pass -- the first step of a launch recomputes every vector --: claim words, validity and the
+        //  ready list go to this workgroup's piece of global scratch)
+        for (uint32_t i = (uint32_t)tid; i < ns; i += kThreads) snap[i] = K.cl[i];
+        for (uint32_t i = (uint32_t)tid; i < (ns + 3u) / 4u; i += kThreads) {
+          uint32_t v = 0;
+          for (uint32_t k = 0; k < 4u; k++) if (4u * i + k < ns) v |= (uint32_t)K.valid[4u * i + k] << (8u * k);
+          snap[ns + i] = v;
+        }
+        for (uint32_t i = (uint32_t)tid; i < rtail0; i += kThreads) P.snap_r[(size_t)tile * ns + i] = K.R[i];
+      }
+    }
+    __syncthreads();
+    for (uint32_t tk = 0; tk < nmine; tk++) {
+      if (multi) {
+        set_tile(tile + tk * T);
+        if (tk > 0u && nops_step) {
+          const uint32_t rt_end = sh.rtail;
+          __syncthreads();
+          if (use_static) {
+            for (uint32_t i = (uint32_t)tid; i < nops_step; i += kThreads) K.PEND[i] = K.PEND0[i];
+            for (uint32_t i = (uint32_t)tid; i < rt_end; i += kThreads) K.R[i] = i < rtail0 ? K.R0[i] : (uint16_t)kNone16;
+          } else {
+            for (uint32_t i = (uint32_t)tid; i < ns; i += kThreads) K.cl[i] = snap[i];
+            for (uint32_t i = (uint32_t)tid; i < (ns + 3u) / 4u; i += kThreads) {
+              const uint32_t v = snap[ns + i];
+              for (uint32_t k = 0; k < 4u; k++) if (4u * i + k < ns) K.valid[4u * i + k] = (uint8_t)(v >> (8u * k));
+            }
+            for (uint32_t i = (uint32_t)tid; i < rt_end; i += kThreads) K.R[i] = i < rtail0 ? P.snap_r[(size_t)tile * ns + i] : (uint16_t)kNone16;
+          }
+          if (tid == 0) { sh.rtail = rtail0; sh.rhead = 0; sh.ndone = 0; }
+          __syncthreads();
         }
       }
-      const uint32_t ntasks = sh.ntasks;
-      for (uint32_t ti = (uint32_t)wave; ti < ntasks; ti += kNW) {
-        const uint32_t t = rfl((uint32_t)sh.tl[ti]);
-        scan_part<KS, VW>(K, sh, t >> 1, t & 1u);
+      refresh<KS, VW>(K, sh, tile == 0 && wave == 0);
+      __syncthreads();
+      if (tk + 1u == nmine) {
+        beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
+        MPF_TMARK(3);
+        // (the refresh's lists are done with: chain starts back to "none", consumer counts to zero -- nothing reads them before the
+        //  next closure, which runs several barriers on)
+        for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
+        if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
       }
+      // ---- (4)
+      {
+        // length of the two sides of the prune branch (this tile's share): per-lane scores summed over the word groups -- wave j
+        // asks for prune node j's two score rows now and folds them after its scan tasks
+        // (workgroups of fewer than kMaxB waves: a wave takes prune nodes wave, wave + kNW)
+        constexpr int kBaseRounds = (kMaxB + (int)kNW - 1) / (int)kNW;
+        uint32_t bv[kBaseRounds];
 #pragma unroll
-      for (int rr = 0; rr < kBaseRounds; rr++) {
-        const uint32_t j = (uint32_t)wave + (uint32_t)rr * kNW;
-        if (j < sh.Beff) {
-          const uint32_t tot = wave_total(K.cnt_lane ? bv[rr] : 0u);
-          if (lane == 0) sh.pn_base[j] = tot;
+        for (int rr = 0; rr < kBaseRounds; rr++) {
+          const uint32_t j = (uint32_t)wave + (uint32_t)rr * kNW;
+          bv[rr] = 0;
+          if (j < sh.Beff) {
+            const uint32_t p = rfl(sh.pn_p[j]), q = rfl((uint32_t)K.bk[p]);
+            bv[rr] = ld_sl<KS, VW>(K, p) + ld_sl<KS, VW>(K, q);
+          }
+        }
+        const uint32_t ntasks = sh.ntasks;
+        for (uint32_t ti = (uint32_t)wave; ti < ntasks; ti += kNW) {
+          const uint32_t t = rfl((uint32_t)sh.tl[ti]);
+          scan_part<KS, VW>(K, sh, t >> 1, t & 1u);
+        }
+#pragma unroll
+        for (int rr = 0; rr < kBaseRounds; rr++) {
+          const uint32_t j = (uint32_t)wave + (uint32_t)rr * kNW;
+          if (j < sh.Beff) {
+            const uint32_t tot = wave_total(K.cnt_lane ? bv[rr] : 0u);
+            if (lane == 0) sh.pn_base[j] += tot;            // (wave j alone owns prune node j's word)
+          }
         }
       }
+      if (multi) __syncthreads();                          // (the next tile's refresh stages into the region the scans parked their up-vectors in)
     }
     __syncthreads();
     beat(P, tile, tid, 1, 5);
     MPF_TMARK(4);
     // ---- (5) lengths = sum over tiles of (subtree scores at both ends of the prune branch + join cost)
-    if (ncand) {
+    if (ncand && T == 1u) {
+      // ONE workgroup holds every tile: the sums are complete where they are
+      for (uint32_t c = (uint32_t)tid; c < ncand; c += kThreads) {
+        uint32_t j = 0;
+        while (j + 1u < sh.Beff && c >= sh.pn_off[j + 1u]) j++;
+        K.cost[c] += sh.pn_base[j];
+      }
+    } else if (ncand) {
       const uint32_t slot = sh.xgen % 3u;
       unsigned long long *gs = P.gsum + (size_t)slot * kClimbCap;
       // level 1: the words of this workgroup's group (every eighth workgroup: 12-13 adds per word instead of 98 -- same-address
@@ -1322,6 +1391,19 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P)
 }
 
 template <int KS, int VW>
+__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P) { climb_body<KS, VW>(P, blockIdx.x, gridDim.x); }
+
+// MANY climbs in one launch, one resident workgroup each (ClimbParams::groups == 1 semantics: nothing crosses between workgroups,
+// so they need not be resident together -- a grid larger than the chip simply runs in turns).  The engines of such a batch share
+// the alignment's shape (state rows, tile width); every one has its own vector store, topology, tie stream and result block.
+template <int KS, int VW>
+__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb_many(const ClimbParams *__restrict__ PP)
+{
+  const ClimbParams P = PP[blockIdx.x];
+  climb_body<KS, VW>(P, 0u, 1u);
+}
+
+template <int KS, int VW>
 size_t lds_bytes(uint32_t ns)
 {
   return lds_fixed_bytes(ns) + region_bytes<KS, VW>(ns);
@@ -1339,7 +1421,23 @@ hipError_t launch_t(hipStream_t st, const ClimbParams &p)
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_climb<KS, VW>), dim3(p.tiles), dim3(Cfg<KS, VW>::NT), lds, st, p);
+  hipLaunchKernelGGL((k_climb<KS, VW>), dim3(p.groups ? p.groups : p.tiles), dim3(Cfg<KS, VW>::NT), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int KS, int VW>
+hipError_t launch_many_t(hipStream_t st, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots)
+{
+  const size_t lds = lds_bytes<KS, VW>(max_nslots);
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 || attr_dev != dev) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_climb_many<KS, VW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL((k_climb_many<KS, VW>), dim3((unsigned)n_climbs), dim3(Cfg<KS, VW>::NT), lds, st, d_params);
   return hipGetLastError();
 }
 
@@ -1377,6 +1475,19 @@ hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbPa
   }
   if (g.S == 32) return launch_t<8, 1>(st, p);           // 32-state data: eight states per lane
   return launch_t<5, 1>(st, p);
+}
+
+hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots)
+{
+  if (n_climbs <= 0) return hipSuccess;
+  if (g.S == 4) {
+    if (vw == 1) return launch_many_t<1, 1>(st, d_params, n_climbs, max_nslots);
+    if (vw == 2) return launch_many_t<1, 2>(st, d_params, n_climbs, max_nslots);
+    if (vw == 8) return launch_many_t<1, 8>(st, d_params, n_climbs, max_nslots);
+    return launch_many_t<1, 4>(st, d_params, n_climbs, max_nslots);
+  }
+  if (g.S == 32) return launch_many_t<8, 1>(st, d_params, n_climbs, max_nslots);
+  return launch_many_t<5, 1>(st, d_params, n_climbs, max_nslots);
 }
 
 }  // namespace mpf

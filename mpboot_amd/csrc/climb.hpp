@@ -74,6 +74,14 @@ struct ClimbParams {
   // this length (CLIMB_CUTOFF): with -bb and a logl_cutoff in force such a tree is the first one IQTree::saveCurrentTree would
   // book (iqtree.cpp:3343) -- up to there the climb is the plain one, from there on the host's tracked path takes over
   uint32_t stop_len;
+  // Workgroups of the launch (1 .. tiles).  groups == tiles: one tile of sites per workgroup, the form that gets a single climb through
+  // its chain of dependent steps fastest (98 workgroups at C3).  Fewer: workgroup g works through the tiles g, g + groups, ... one
+  // after the other inside every step (refresh + scan per tile, the candidates' sums accumulating in its LDS) and only `groups`
+  // sums meet in the exchange -- with groups == 1 nothing crosses between workgroups at all: a climb is ONE resident workgroup
+  // and a chip holds hundreds of them (engine option "climb_groups")
+  uint32_t groups;
+  uint16_t *snap_r;                // [groups][nslots] the ready list of such a step
+  uint32_t *snap;                  // [groups][nslots + nslots / 4 + 1] words: the claim words and validity flags of a step whose closure takes the plain dataflow path, restored per tile (groups < tiles only)
 };
 
 constexpr uint32_t kClimbCap = 1024;      // candidates per step
@@ -83,5 +91,7 @@ bool climb_supported(const Geometry &g, int n_taxa, int maxtrav);
 int climb_tiles(const Geometry &g, int vw);
 size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw);
 hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p);
+// n_climbs independent climbs, one workgroup each (k_climb_many): d_params[n_climbs] on the device, every entry with groups == 1
+hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots);
 
 }  // namespace mpf

@@ -2143,6 +2143,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max_sparse") { climb_batch_max_sparse_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "climb_groups") { climb_groups_ = v < 0 ? 0 : v > 4096 ? 4096 : (int)v; return MPF_OK; }
   if (key == "climb_fault") { climb_fault_ = v; return MPF_OK; }          // (tests of the recovery paths: climb.hpp)
   if (key == "views_waves") { nv_waves_ = (int)v; return MPF_OK; }         // waves per refresh workgroup: 0 = by level width, -1 = always sixteen, 2 .. 16
   if (key == "refine_chunk") { refine_chunk_ = v < 1 ? 1 : (int)std::min<int64_t>(v, 1 << 30); return MPF_OK; }
@@ -2229,6 +2230,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "refine_chunk") *v = refine_chunk_;
   else if (key == "views_waves") *v = nv_waves_;
   else if (key == "climb_trace") *v = climb_trace_;
+  else if (key == "climb_groups") *v = climb_groups_;
   else if (key.rfind("climb_ctr", 0) == 0 && key.size() == 10 && key[9] >= '0' && key[9] <= '3') *v = (int64_t)climb_ctr_[key[9] - '0'];   // refresh ops, closure rounds, invalidation rounds, chains
   else if (key.rfind("climb_phase_us", 0) == 0 && key.size() == 15 && ((key[14] >= '0' && key[14] <= '9') || (key[14] >= 'a' && key[14] <= 'f')))
     *v = (int64_t)(climb_phase_ticks_[key[14] <= '9' ? key[14] - '0' : key[14] - 'a' + 10] / 100ull);

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
 #include <map>
 #include <unordered_map>
@@ -463,7 +464,8 @@ class Engine {
   // (the kernel keeps its own); whatever runs next on the host path starts with a full refresh (0.08 ms at C3).
   struct ClimbDev {
     DevBuf<uint16_t> bk, order;
-    DevBuf<uint32_t> sct, trace;
+    DevBuf<uint32_t> sct, trace, snap;           // snap / snap_r: ClimbParams::snap (launches of fewer workgroups than tiles)
+    DevBuf<uint16_t> snap_r;
     DevBuf<unsigned long long> gsum;
     DevBuf<uint32_t> out;                        // [header | moves]
     PinBuf<uint16_t> h_bk, h_order;
@@ -476,8 +478,18 @@ class Engine {
   int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)
   int climb_batch_max_sparse_ = 16;              // option climb_batch_max_sparse: prune nodes per step of the quiet stretch of a tracked climb
   int climb_batch_min_ = 2, climb_batch_max_ = 8, climb_idle_ = 96, climb_trace_ = 0;
+  int climb_groups_ = 0;                         // option "climb_groups": workgroups per k_climb launch (0 = one per tile; ClimbParams::groups)
   inline int rec_of(uint32_t cid) const { return cid < (uint32_t)n_ ? 3 * ((int)cid + 1) : 3 * (n_ + 1 + (int)(cid - (uint32_t)n_) / 3) + (int)((cid - (uint32_t)n_) % 3u); }
   int climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle, uint32_t *reason, uint32_t *n_moves);
+  int climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, unsigned iter_hits, bool may_idle, int force_groups, hipStream_t st,
+                    ClimbParams &p, int *vw_out, int *tiles_out);
+  int climb_harvest(int total, int tiles, std::chrono::steady_clock::time_point t0, int *i, uint32_t *randomMP, unsigned *iter_hits, uint32_t *reason,
+                    uint32_t *n_moves);
+public:
+  // pllOptimizeSprParsimony on MANY engines at once (independent climbs: start trees, bootstrap refinements): every sweep of every
+  // climb is one workgroup of ONE launch (k_climb_many), a host thread feeds the lot (host/climb_host.cpp)
+  static int climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t *scores);
+private:
 
   // ---- device-resident stepwise addition (grow.hip; host/climb_host.cpp): one k_grow launch adds every taxon behind the start
   // tree, the insertions it reports are replayed onto the host's topology mirror

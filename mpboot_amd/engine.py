@@ -34,7 +34,7 @@ EXPORTS = [
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
-    "mpf_iq_random_nnis", "mpf_iq_perturb_weights", "mpf_iq_topology_key", "mpf_ufboot_adopt",
+    "mpf_iq_random_nnis", "mpf_iq_perturb_weights", "mpf_iq_topology_key", "mpf_ufboot_adopt", "mpf_optimize_spr_many",
 ]
 
 
@@ -159,6 +159,7 @@ def load_library():
         L.mpf_remain_bounds.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.mpf_cost_matrix_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, vp]
         L.mpf_cost_matrix_triangle_fix.argtypes = [C.c_int32, vp, vp]
+        L.mpf_optimize_spr_many.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
         L.mpf_ufboot_adopt.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.mpf_iq_random_nnis.argtypes = [C.c_int32, vp, C.c_int32, vp, vp]
         L.mpf_iq_perturb_weights.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
@@ -211,6 +212,16 @@ def remain_bounds(segment_upper, min_unit_pars, weight) -> np.ndarray:
     out = np.zeros(max(len(up) - 1, 1), dtype=np.int32)
     _chk(load_library().mpf_remain_bounds(len(m), len(up), _p(up), _p(m), _p(w), _p(out)))
     return out[:len(up) - 1]
+
+
+def optimize_spr_many(engines, mintrav: int = 1, maxtrav: int = 6):
+    """mpf_optimize_spr_many: one SPR hill climb per engine (tree, weights, tie stream set on each as for optimize_spr), all of them
+    side by side -- a resident workgroup per climb, one launch per round.  -> final lengths, one per engine."""
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e.h for e in engines])
+    out = np.zeros(n, dtype=np.uint32)
+    _chk(load_library().mpf_optimize_spr_many(hs, n, int(mintrav), int(maxtrav), _p(out)))
+    return out
 
 
 def iq_random_nnis(back: np.ndarray, num_nni: int, tie_state: int):

@@ -66,18 +66,24 @@ int Engine::climb_fit_vw()
     const size_t lds = climb_lds_bytes(g_, n_, vw);
     if (lds > 160 * 1024) continue;
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
-    if ((climb_tiles(g_, vw) + per_cu - 1) / per_cu <= cap) return vw;
+    const int tiles = climb_tiles(g_, vw);
+    const int wgs = climb_groups_ > 0 ? std::min(climb_groups_, tiles) : tiles;        // (fewer workgroups than tiles: each works through several)
+    if ((wgs + per_cu - 1) / per_cu <= cap) return vw;
   }
   return 0;
 }
 
-int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle,
-                          uint32_t *reason, uint32_t *n_moves)
+// One launch of the climb kernel in three parts: climb_prepare lays the segment out (staging, parameters) and enqueues its uploads,
+// the caller launches -- k_climb for this engine alone (climb_segment), or k_climb_many for a batch of engines (Engine::climb_many) --
+// and copies the result block back, climb_harvest takes the moves over.
+int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, unsigned iter_hits, bool may_idle, int force_groups,
+                          hipStream_t st, ClimbParams &p, int *vw_out, int *tiles_out)
 {
-  const auto t0 = std::chrono::steady_clock::now();
   const int vw = climb_fit_vw();
+  *vw_out = vw;
   if (vw <= 0) { set_error("device climb: the alignment's tiles do not fit the chip"); return MPF_E_STATE; }
   const int tiles = climb_tiles(g_, vw);
+  *tiles_out = tiles;
   const size_t ns = nslots_;
   const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
   const size_t out_words = hdr_words + 3 * (size_t)total;
@@ -102,15 +108,14 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   h.rng = rng_.state;
   h.hits = hits_;
   h.best = best_;
-  h.randomMP = *randomMP;
-  h.iter_hits = *iter_hits;
-  h.pos = (uint32_t)*i;
+  h.randomMP = randomMP;
+  h.iter_hits = iter_hits;
+  h.pos = (uint32_t)i;
   h.insert_cid = insert_rec_ >= 0 ? (int32_t)slot(insert_rec_) : -1;
   h.remove_cid = remove_rec_ >= 0 ? (int32_t)slot(remove_rec_) : -1;
   h.since_move = 0;
   h.batch = 0;
   std::memcpy(cd_.h_out.p, &h, sizeof(h));
-  ClimbParams p;
   p.vec = d_vec_;
   p.n = (uint32_t)n_;
   p.nslots = (uint32_t)ns;
@@ -139,6 +144,17 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   p.fault = (uint32_t)climb_fault_;
   climb_fault_ = 0;                                  // (one launch)
   p.stop_len = climb_stop_len_;
+  // option "climb_groups": 0 = a workgroup per tile; k = at most k workgroups, each working through its share of the tiles
+  const int groups = force_groups > 0 ? std::min(force_groups, tiles) : climb_groups_ > 0 ? std::min(climb_groups_, tiles) : tiles;
+  p.groups = (uint32_t)groups;
+  p.snap = nullptr;
+  p.snap_r = nullptr;
+  if (groups < tiles) {
+    HIPCHK(cd_.snap.reserve((size_t)groups * (ns + ns / 4 + 1)));
+    HIPCHK(cd_.snap_r.reserve((size_t)groups * ns));
+    p.snap = cd_.snap.p;
+    p.snap_r = cd_.snap_r.p;
+  }
   if (climb_trace_) {
     HIPCHK(cd_.h_beat.reserve(32));
     std::memset(cd_.h_beat.p, 0, 32 * sizeof(uint32_t));
@@ -148,6 +164,27 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     p.trace = cd_.trace.p;
     p.trace_cap = (uint32_t)cap;
   }
+  HIPCHK(hipMemcpyAsync(cd_.bk.p, cd_.h_bk.p, ns * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(cd_.order.p, cd_.h_order.p, (size_t)total * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(cd_.out.p, cd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(cd_.gsum.p, 0, gsum_words * sizeof(unsigned long long), st));
+  shadow_ok_ = false;                              // (k_climb rewrites vectors in the row-major store only)
+  return MPF_OK;
+}
+
+int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle,
+                          uint32_t *reason, uint32_t *n_moves)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  ClimbParams p;
+  int vw = 0, tiles = 0;
+  {
+    const int rc = climb_prepare(maxtrav_eff, total, *i, *randomMP, *iter_hits, may_idle, 0, st_, p, &vw, &tiles);
+    if (rc) return rc;
+  }
+  const int groups = (int)p.groups;
+  const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
+  const size_t out_words = hdr_words + 3 * (size_t)total;
   GateHold hold;
   {
     ClimbGate &g = g_gate[dev_ & 63];
@@ -160,7 +197,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
       g.cus = c;
     }
     // (counted in CU-equivalents of this launch's footprint: tiles / per_cu CUs)
-    const int need = (tiles + per_cu - 1) / per_cu;
+    const int need = (groups + per_cu - 1) / per_cu;
     // (not every CU takes a workgroup of this size at every moment -- other queues' kernels come and go -- so admission
     //  stops at 85 % of the chip: a launch beyond that waits its turn here instead of timing out in the kernel)
     const int cap = std::max(1, g.cus * 85 / 100);
@@ -169,11 +206,6 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     hold.g = &g;
     hold.n = need;
   }
-  HIPCHK(hipMemcpyAsync(cd_.bk.p, cd_.h_bk.p, ns * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemcpyAsync(cd_.order.p, cd_.h_order.p, (size_t)total * sizeof(uint16_t), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemcpyAsync(cd_.out.p, cd_.h_out.p, sizeof(h), hipMemcpyHostToDevice, st_));
-  HIPCHK(hipMemsetAsync(cd_.gsum.p, 0, gsum_words * sizeof(unsigned long long), st_));
-  shadow_ok_ = false;                              // (k_climb rewrites vectors in the row-major store only)
   HIPCHK(launch_climb(st_, g_, vw, p));
   HIPCHK(hipMemcpyAsync(cd_.h_out.p, cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   {
@@ -203,6 +235,14 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     if (q != hipSuccess) { invalidate_all(); set_error(std::string("device climb: ") + hipGetErrorString(q)); return MPF_E_HIP; }
   }
   hold.release();
+  return climb_harvest(total, tiles, t0, i, randomMP, iter_hits, reason, n_moves);
+}
+
+int Engine::climb_harvest(int total, int tiles, std::chrono::steady_clock::time_point t0, int *i, uint32_t *randomMP, unsigned *iter_hits,
+                          uint32_t *reason, uint32_t *n_moves)
+{
+  const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
+  ClimbHeader h;
   std::memcpy(&h, cd_.h_out.p, sizeof(h));
   *reason = h.reason;
   *n_moves = 0;
@@ -267,6 +307,119 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   stats.climb_nodes += h.n_scanned_nodes;
   stats.climb_moves += h.n_moves;
   stats.climb_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MPF_OK;
+}
+
+// ---- many independent climbs, one launch per round --------------------------------------------------------------------------
+// pllOptimizeSprParsimony (reference sprparsimony.cpp:3244-3319) on n engines at once -- the 100 start trees of a run
+// (phyloanalysis.cpp:1270-1317), the bootstrap samples' refinement climbs (iqtree.cpp:2797-2862): climbs that have nothing to do
+// with each other.  One engine alone gets through its chain of dependent steps fastest on a workgroup per tile (98 at C3) -- and
+// leaves most of the chip idle doing so; host threads with an engine each fill some of it (bench: concurrent_climbs), but every
+// persistent launch holds a hardware queue and its CUs while it waits.  Here every climb is ONE workgroup that works through all
+// tiles itself (ClimbParams::groups == 1: nothing crosses between workgroups), and a round = ONE launch of k_climb_many with a
+// workgroup per climb that still has a sweep to run: a round ends when every workgroup has finished its sweep (or filled its move
+// list), the host replays the moves on each engine's topology mirror and starts the next round with the climbs that are not at
+// their optimum yet.  Each climb: the same moves, draws and final tree as its solo mpf_optimize_spr (tests/test_gpu_climb_many.py).
+int Engine::climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t *scores)
+{
+  if (n <= 0) return MPF_OK;
+  if (!engs || !scores) { set_error("mpf_optimize_spr_many: null argument"); return MPF_E_INVALID; }
+  struct St { uint32_t startMP = 0, randomMP = 0; unsigned iter_hits = 1; int i = 1; bool in_sweep = false, done = false; int tiles = 0; };
+  std::vector<St> st((size_t)n);
+  Engine &e0 = *engs[0];
+  int vw0 = -1;
+  // every climb's preamble (the full evaluate of :3277) on its own engine; what does not fit the batch runs alone
+  for (int k = 0; k < n; k++) {
+    Engine &e = *engs[k];
+    if (!e.have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
+    const int mt_eff = std::min(maxtrav, e.n_ - 3);
+    const bool fits = e.dev_ == e0.dev_ && e.g_.S == e0.g_.S && !e.sankoff_ && !e.rand_fn_ && !(e.ufb_ && !e.ufb_->suspended) && mintrav == 1 &&
+                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff) && e.climb_fit_vw() > 0 &&
+                      (vw0 < 0 || e.climb_fit_vw() == vw0);
+    if (!fits) {
+      const int rc = e.optimize_spr(mintrav, maxtrav, &scores[k]);
+      if (rc) return rc;
+      st[(size_t)k].done = true;
+      continue;
+    }
+    if (vw0 < 0) vw0 = e.climb_fit_vw();
+    e.moves_.clear();
+    e.node_rectifier();
+    uint32_t len = 0;
+    e.invalidate_vectors();
+    const int rc = e.tree_length(&len);
+    if (rc) return rc;
+    e.best_ = len;
+    e.ntips_ = e.n_;
+    e.insert_rec_ = e.remove_rec_ = -1;
+    e.visits_done_ = 0;
+    st[(size_t)k].randomMP = len;
+  }
+  HIPCHK(hipSetDevice(e0.dev_));
+  DevBuf<ClimbParams> d_params;
+  PinBuf<ClimbParams> h_params;
+  HIPCHK(d_params.reserve((size_t)n));
+  HIPCHK(h_params.reserve((size_t)n));
+  std::vector<int> batch;
+  const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
+  for (;;) {
+    batch.clear();
+    uint32_t max_ns = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n; k++) {
+      St &s = st[(size_t)k];
+      if (s.done) continue;
+      Engine &e = *engs[k];
+      const int total = 2 * e.n_ - 2;
+      if (!s.in_sweep) { s.startMP = s.randomMP; e.node_rectifier(); s.i = 1; s.in_sweep = true; }
+      int vw = 0;
+      const int rc = e.climb_prepare(std::min(maxtrav, e.n_ - 3), total, s.i, s.randomMP, s.iter_hits, false, 1, e0.st_,
+                                     h_params.p[batch.size()], &vw, &s.tiles);
+      if (rc) return rc;
+      max_ns = std::max(max_ns, (uint32_t)e.nslots_);
+      batch.push_back(k);
+    }
+    if (batch.empty()) break;
+    HIPCHK(hipMemcpyAsync(d_params.p, h_params.p, batch.size() * sizeof(ClimbParams), hipMemcpyHostToDevice, e0.st_));
+    HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, d_params.p, (int)batch.size(), max_ns));
+    for (int k : batch) {
+      Engine &e = *engs[k];
+      const size_t out_words = hdr_words + 3 * (size_t)(2 * e.n_ - 2);
+      HIPCHK(hipMemcpyAsync(e.cd_.h_out.p, e.cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e0.st_));
+    }
+    {
+      // (bounded like every wait on this kernel: climb_segment)
+      const auto w0 = std::chrono::steady_clock::now();
+      hipError_t q;
+      long spins = 0;
+      while ((q = hipStreamQuery(e0.st_)) == hipErrorNotReady) {
+        { struct timespec ts = {0, 30000}; nanosleep(&ts, nullptr); }
+        if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 120.0) {
+          for (int k : batch) { engs[k]->invalidate_all(); engs[k]->broken_ = true; }
+          set_error("mpf_optimize_spr_many: the launch did not finish within 120 s");
+          return MPF_E_STATE;
+        }
+      }
+      if (q != hipSuccess) { for (int k : batch) engs[k]->invalidate_all(); set_error(std::string("mpf_optimize_spr_many: ") + hipGetErrorString(q)); return MPF_E_HIP; }
+    }
+    for (int k : batch) {
+      St &s = st[(size_t)k];
+      Engine &e = *engs[k];
+      const int total = 2 * e.n_ - 2;
+      uint32_t reason = 0, nm = 0;
+      const int rc = e.climb_harvest(total, s.tiles, t0, &s.i, &s.randomMP, &s.iter_hits, &reason, &nm);
+      if (rc) return rc;
+      if (reason == CLIMB_ABORT) { set_error("mpf_optimize_spr_many: a single-workgroup climb reported an abort"); return MPF_E_STATE; }
+      if (s.i > total) {                              // the sweep is through (:3316)
+        s.in_sweep = false;
+        if (!(s.randomMP < s.startMP)) {
+          e.climb_finished(total);
+          scores[k] = s.randomMP;
+          s.done = true;
+        }
+      }
+    }
+  }
   return MPF_OK;
 }
 
