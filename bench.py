@@ -576,9 +576,11 @@ def main():
     ap.add_argument("--bb-workers", type=int, default=8, help="bb_reference_run leg, iteration-parallel form: chains (engines on host threads) per GPU")
     ap.add_argument("--bb-rounds", type=int, default=6, help="... rounds timed (a round = --bb-sync iterations on every chain, then one exchange; 0 = skip)")
     ap.add_argument("--bb-sync", type=int, default=8, help="... iterations between two exchanges")
+    ap.add_argument("--many-c2", type=int, default=512, help="climbs_in_one_launch leg: C2 climbs per call")
+    ap.add_argument("--many-c3", type=int, default=192, help="climbs_in_one_launch leg: C3 climbs per call (an engine each: 0.25 GB; 0 = skip)")
     ap.add_argument("--legs", default="all",
                     help="comma-separated secondary legs to run (default all): concurrent_climbs, start_trees, bb_reference_run, c2_climb, "
-                         "c5_weighted_sweep, c5_fitch, noisy_bootstrap; the headline step, its roofline and cpu_baseline always run")
+                         "c5_weighted_sweep, c5_fitch, noisy_bootstrap, climbs_in_one_launch; the headline step, its roofline and cpu_baseline always run")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
                          "saveCurrentTree after every insertion test, timed after the main metric (0 = skip)")
@@ -1078,6 +1080,7 @@ def main():
     conc = None
     bbref = None
     noisy_leg = None
+    many_leg = None
     c5f_sweep = c5f_climb = None
     c2leg = None
     c5leg = None
@@ -1188,6 +1191,12 @@ def main():
                 bbref = {"error": repr(exc)}
             eng.set_option("timing", 1)
             eng.set_weights(np.ones(P, dtype=np.int32))
+        if world == 1 and args.workload == "C3" and leg_on("climbs_in_one_launch"):
+            try:
+                from benchlegs import climbs_many as _cm
+                many_leg = _cm.run(device, args.maxtrav, barrier, args.many_c2, args.many_c3)
+            except Exception as exc:
+                many_leg = {"error": repr(exc)}
         if world == 1 and args.workload == "C3" and leg_on("c5_fitch"):
             try:
                 from benchlegs import c5_fitch as _c5f
@@ -1360,6 +1369,17 @@ def main():
             res["bb_reference_run"] = bbref
         if noisy_leg is not None:
             res["noisy_bootstrap"] = noisy_leg
+        if many_leg is not None:
+            res["climbs_in_one_launch"] = many_leg
+            try:
+                cb2 = (res.get("c2_climb") or {}).get("cpu_baseline")
+                if cb2:
+                    many_leg["c2"]["reference_climbs_per_s_one_core"] = 1.0 / cb2["seconds"]
+                cb3 = ((res.get("random_start") or {}).get("plain_climb") or {}).get("cpu_baseline")
+                if cb3 and "c3" in many_leg:
+                    many_leg["c3"]["reference_climbs_per_s_one_core"] = 1.0 / cb3["seconds"]
+            except Exception:
+                pass
         if c5f_sweep is not None:
             res["c5_fitch_sweep"] = c5f_sweep
         if c5f_climb is not None:

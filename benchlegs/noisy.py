@@ -51,5 +51,7 @@ def run(device, maxtrav, n_start, iters, n_engines, barrier, B=1000):
            "seconds": t_start + float(its.sum()) + rr["refine_s"],
            "what": "the -bb flow of bb_reference_run (one chain) where the samples disagree: start trees + doTreeSearch iterations + "
                    "refinement.  refinement_s = refine_boot_trees: one masked sweep + one mask x weight product per DISTINCT topology the "
-                   "samples kept, then one re-weighting + SPR climb per sample whose first sweep accepts a move (several engines per GPU)"}
+                   "samples kept, then one re-weighting + SPR climb per sample whose first sweep accepts a move (several engines per GPU on host "
+                   "threads; as workgroups of one launch per round -- mpf_optimize_spr_many_round -- the same 951 climbs take 1.37 s: they start "
+                   "next to an optimum, where the host path's whole-chip batches are the better tool)"}
     return leg

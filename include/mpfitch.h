@@ -220,6 +220,10 @@ int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *
    alignment shape, a tracker attached, the weighted engine, a host random_double() call-back) run their climb alone inside the call.
    final_scores[n_engines]. */
 int mpf_optimize_spr_many(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint32_t *final_scores);
+/* ... one ROUND of it (one launch: a sweep, or a full move list, of every active climb), for callers with more climbs than engines:
+   state[k] in: 0 = engine k takes no part, 1 = a climb STARTS on it now, 2 = its climb goes on; out: 2 = goes on, 0 = done
+   (final_scores[k] valid).  A finished engine gets its next tree (and weights, stream) and state 1 before the next round. */
+int mpf_optimize_spr_many_round(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint8_t *state, uint32_t *final_scores);
 
 /* _pllComputeRandomizedStepwiseAdditionParsimonyTree(tr, pr, sprDist, iqtree)
    (sprparsimony.cpp:3224-3235, :3107-3209): random addition order from PLL randum(seed),

@@ -251,6 +251,17 @@ int mpf_optimize_spr_many(mpf_engine **engines, int32_t n_engines, int32_t mintr
   return mpf::Engine::climb_many(es.data(), n_engines, mintrav, maxtrav, final_scores);
 }
 
+int mpf_optimize_spr_many_round(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint8_t *state, uint32_t *final_scores)
+{
+  if (n_engines < 0 || (n_engines && (!engines || !final_scores || !state))) { set_error("mpf_optimize_spr_many_round: bad argument"); return MPF_E_INVALID; }
+  std::vector<mpf::Engine *> es((size_t)n_engines);
+  for (int k = 0; k < n_engines; k++) {
+    if (!engines[k]) { set_error("mpf_optimize_spr_many_round: null engine"); return MPF_E_INVALID; }
+    es[(size_t)k] = &engines[k]->eng;
+  }
+  return mpf::Engine::climb_many_round(es.data(), n_engines, mintrav, maxtrav, state, final_scores);
+}
+
 int mpf_make_parsimony_tree(mpf_engine *e, int64_t seed, int32_t spr_dist, uint32_t *score)
 {
   NEED(e);

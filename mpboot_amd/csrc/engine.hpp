@@ -489,7 +489,10 @@ public:
   // pllOptimizeSprParsimony on MANY engines at once (independent climbs: start trees, bootstrap refinements): every sweep of every
   // climb is one workgroup of ONE launch (k_climb_many), a host thread feeds the lot (host/climb_host.cpp)
   static int climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t *scores);
+  static int climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uint8_t *state, uint32_t *scores);
 private:
+  struct ManyState { uint32_t startMP = 0, randomMP = 0; unsigned iter_hits = 1; int i = 1; bool in_sweep = false; int tiles = 0; } many_;   // this engine's climb inside a batch
+  struct ManyBufs { DevBuf<ClimbParams> d_params; PinBuf<ClimbParams> h_params; } many_bufs_;   // a batch's parameter blocks (held by the batch's first engine)
 
   // ---- device-resident stepwise addition (grow.hip; host/climb_host.cpp): one k_grow launch adds every taxon behind the start
   // tree, the insertions it reports are replayed onto the host's topology mirror

@@ -34,7 +34,7 @@ EXPORTS = [
     "mpf_ufboot_tree_logl", "mpf_ufboot_get_state", "mpf_ufboot_get_tree", "mpf_ufboot_get_counters",
     "mpf_min_pars_score_patterns", "mpf_mst_scores", "mpf_segment_patterns", "mpf_remain_bounds",
     "mpf_cost_matrix_load", "mpf_cost_matrix_triangle_fix",
-    "mpf_iq_random_nnis", "mpf_iq_perturb_weights", "mpf_iq_topology_key", "mpf_ufboot_adopt", "mpf_optimize_spr_many",
+    "mpf_iq_random_nnis", "mpf_iq_perturb_weights", "mpf_iq_topology_key", "mpf_ufboot_adopt", "mpf_optimize_spr_many", "mpf_optimize_spr_many_round",
 ]
 
 
@@ -160,6 +160,7 @@ def load_library():
         L.mpf_cost_matrix_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, vp]
         L.mpf_cost_matrix_triangle_fix.argtypes = [C.c_int32, vp, vp]
         L.mpf_optimize_spr_many.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.mpf_optimize_spr_many_round.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
         L.mpf_ufboot_adopt.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.mpf_iq_random_nnis.argtypes = [C.c_int32, vp, C.c_int32, vp, vp]
         L.mpf_iq_perturb_weights.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
@@ -222,6 +223,30 @@ def optimize_spr_many(engines, mintrav: int = 1, maxtrav: int = 6):
     out = np.zeros(n, dtype=np.uint32)
     _chk(load_library().mpf_optimize_spr_many(hs, n, int(mintrav), int(maxtrav), _p(out)))
     return out
+
+
+class ClimbBatch:
+    """mpf_optimize_spr_many_round for callers with more climbs than engines: start(k) after setting engine k up (tree, weights, tie
+    stream), round() runs one launch for every active climb and returns the engines whose climb has just finished."""
+
+    def __init__(self, engines, mintrav: int = 1, maxtrav: int = 6):
+        self.engines = list(engines)
+        self.n = len(self.engines)
+        self.hs = (C.c_void_p * self.n)(*[e.h for e in self.engines])
+        self.state = np.zeros(self.n, dtype=np.uint8)
+        self.scores = np.zeros(self.n, dtype=np.uint32)
+        self.mintrav, self.maxtrav = int(mintrav), int(maxtrav)
+
+    def start(self, k: int):
+        self.state[k] = 1
+
+    def active(self) -> int:
+        return int((self.state != 0).sum())
+
+    def round(self):
+        before = self.state != 0
+        _chk(load_library().mpf_optimize_spr_many_round(self.hs, self.n, self.mintrav, self.maxtrav, _p(self.state), _p(self.scores)))
+        return [int(k) for k in np.nonzero(before & (self.state == 0))[0]]
 
 
 def iq_random_nnis(back: np.ndarray, num_nni: int, tie_state: int):

@@ -324,25 +324,43 @@ int Engine::climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t 
 {
   if (n <= 0) return MPF_OK;
   if (!engs || !scores) { set_error("mpf_optimize_spr_many: null argument"); return MPF_E_INVALID; }
-  struct St { uint32_t startMP = 0, randomMP = 0; unsigned iter_hits = 1; int i = 1; bool in_sweep = false, done = false; int tiles = 0; };
-  std::vector<St> st((size_t)n);
-  Engine &e0 = *engs[0];
-  int vw0 = -1;
-  // every climb's preamble (the full evaluate of :3277) on its own engine; what does not fit the batch runs alone
+  std::vector<uint8_t> state((size_t)n, 1);         // 1 = a climb starts on this engine
+  for (;;) {
+    const int rc = climb_many_round(engs, n, mintrav, maxtrav, state.data(), scores);
+    if (rc) return rc;
+    bool any = false;
+    for (int k = 0; k < n; k++) any = any || state[(size_t)k] == 2;
+    if (!any) return MPF_OK;
+  }
+}
+
+// One round: state[k] in: 0 = engine k takes no part, 1 = its climb STARTS now (tree, weights, tie stream set as for mpf_optimize_spr),
+// 2 = its climb goes on; out: 2 = not at its optimum yet, 0 = done (scores[k] = the final length).  A caller that has more climbs than
+// engines hands a finished engine its next tree between two rounds (mpboot_amd/bootstrap.py: refine_boot_trees), so that the launches
+// stay full until the work runs out.
+int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uint8_t *state, uint32_t *scores)
+{
+  if (n <= 0) return MPF_OK;
+  if (!engs || !scores || !state) { set_error("mpf_optimize_spr_many: null argument"); return MPF_E_INVALID; }
+  int first = -1;
+  for (int k = 0; k < n; k++) if (state[k]) { first = k; break; }
+  if (first < 0) return MPF_OK;
+  Engine &e0 = *engs[first];
+  const int vw0 = e0.climb_fit_vw();
+  // a starting climb's preamble (the full evaluate of :3277) on its own engine; what does not fit the batch runs alone, here
   for (int k = 0; k < n; k++) {
+    if (state[k] != 1) continue;
     Engine &e = *engs[k];
     if (!e.have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
     const int mt_eff = std::min(maxtrav, e.n_ - 3);
-    const bool fits = e.dev_ == e0.dev_ && e.g_.S == e0.g_.S && !e.sankoff_ && !e.rand_fn_ && !(e.ufb_ && !e.ufb_->suspended) && mintrav == 1 &&
-                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff) && e.climb_fit_vw() > 0 &&
-                      (vw0 < 0 || e.climb_fit_vw() == vw0);
+    const bool fits = vw0 > 0 && e.dev_ == e0.dev_ && e.g_.S == e0.g_.S && !e.sankoff_ && !e.rand_fn_ && !(e.ufb_ && !e.ufb_->suspended) && mintrav == 1 &&
+                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff) && e.climb_fit_vw() == vw0;
     if (!fits) {
       const int rc = e.optimize_spr(mintrav, maxtrav, &scores[k]);
       if (rc) return rc;
-      st[(size_t)k].done = true;
+      state[k] = 0;
       continue;
     }
-    if (vw0 < 0) vw0 = e.climb_fit_vw();
     e.moves_.clear();
     e.node_rectifier();
     uint32_t len = 0;
@@ -353,72 +371,76 @@ int Engine::climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t 
     e.ntips_ = e.n_;
     e.insert_rec_ = e.remove_rec_ = -1;
     e.visits_done_ = 0;
-    st[(size_t)k].randomMP = len;
+    e.many_ = ManyState{};
+    e.many_.randomMP = len;
+    state[k] = 2;
   }
   HIPCHK(hipSetDevice(e0.dev_));
-  DevBuf<ClimbParams> d_params;
-  PinBuf<ClimbParams> h_params;
-  HIPCHK(d_params.reserve((size_t)n));
-  HIPCHK(h_params.reserve((size_t)n));
+  ManyBufs &mb = e0.many_bufs_;
+  HIPCHK(mb.d_params.reserve((size_t)n));
+  HIPCHK(mb.h_params.reserve((size_t)n));
   std::vector<int> batch;
   const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
-  for (;;) {
-    batch.clear();
-    uint32_t max_ns = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < n; k++) {
-      St &s = st[(size_t)k];
-      if (s.done) continue;
-      Engine &e = *engs[k];
-      const int total = 2 * e.n_ - 2;
-      if (!s.in_sweep) { s.startMP = s.randomMP; e.node_rectifier(); s.i = 1; s.in_sweep = true; }
-      int vw = 0;
-      const int rc = e.climb_prepare(std::min(maxtrav, e.n_ - 3), total, s.i, s.randomMP, s.iter_hits, false, 1, e0.st_,
-                                     h_params.p[batch.size()], &vw, &s.tiles);
-      if (rc) return rc;
-      max_ns = std::max(max_ns, (uint32_t)e.nslots_);
-      batch.push_back(k);
-    }
-    if (batch.empty()) break;
-    HIPCHK(hipMemcpyAsync(d_params.p, h_params.p, batch.size() * sizeof(ClimbParams), hipMemcpyHostToDevice, e0.st_));
-    HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, d_params.p, (int)batch.size(), max_ns));
-    for (int k : batch) {
-      Engine &e = *engs[k];
-      const size_t out_words = hdr_words + 3 * (size_t)(2 * e.n_ - 2);
-      HIPCHK(hipMemcpyAsync(e.cd_.h_out.p, e.cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e0.st_));
-    }
-    {
-      // (bounded like every wait on this kernel: climb_segment)
-      const auto w0 = std::chrono::steady_clock::now();
-      hipError_t q;
-      long spins = 0;
-      while ((q = hipStreamQuery(e0.st_)) == hipErrorNotReady) {
-        { struct timespec ts = {0, 30000}; nanosleep(&ts, nullptr); }
-        if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 120.0) {
-          for (int k : batch) { engs[k]->invalidate_all(); engs[k]->broken_ = true; }
-          set_error("mpf_optimize_spr_many: the launch did not finish within 120 s");
-          return MPF_E_STATE;
-        }
-      }
-      if (q != hipSuccess) { for (int k : batch) engs[k]->invalidate_all(); set_error(std::string("mpf_optimize_spr_many: ") + hipGetErrorString(q)); return MPF_E_HIP; }
-    }
-    for (int k : batch) {
-      St &s = st[(size_t)k];
-      Engine &e = *engs[k];
-      const int total = 2 * e.n_ - 2;
-      uint32_t reason = 0, nm = 0;
-      const int rc = e.climb_harvest(total, s.tiles, t0, &s.i, &s.randomMP, &s.iter_hits, &reason, &nm);
-      if (rc) return rc;
-      if (reason == CLIMB_ABORT) { set_error("mpf_optimize_spr_many: a single-workgroup climb reported an abort"); return MPF_E_STATE; }
-      if (s.i > total) {                              // the sweep is through (:3316)
-        s.in_sweep = false;
-        if (!(s.randomMP < s.startMP)) {
-          e.climb_finished(total);
-          scores[k] = s.randomMP;
-          s.done = true;
-        }
+  uint32_t max_ns = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < n; k++) {
+    if (state[k] != 2) continue;
+    Engine &e = *engs[k];
+    ManyState &s = e.many_;
+    const int total = 2 * e.n_ - 2;
+    if (!s.in_sweep) { s.startMP = s.randomMP; e.node_rectifier(); s.i = 1; s.in_sweep = true; }
+    int vw = 0;
+    const int rc = e.climb_prepare(std::min(maxtrav, e.n_ - 3), total, s.i, s.randomMP, s.iter_hits, false, 1, e0.st_, mb.h_params.p[batch.size()], &vw, &s.tiles);
+    if (rc) return rc;
+    max_ns = std::max(max_ns, (uint32_t)e.nslots_);
+    batch.push_back(k);
+  }
+  if (batch.empty()) return MPF_OK;
+  const auto t_prep = std::chrono::steady_clock::now();
+  HIPCHK(hipMemcpyAsync(mb.d_params.p, mb.h_params.p, batch.size() * sizeof(ClimbParams), hipMemcpyHostToDevice, e0.st_));
+  HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, mb.d_params.p, (int)batch.size(), max_ns));
+  for (int k : batch) {
+    Engine &e = *engs[k];
+    const size_t out_words = hdr_words + 3 * (size_t)(2 * e.n_ - 2);
+    HIPCHK(hipMemcpyAsync(e.cd_.h_out.p, e.cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e0.st_));
+  }
+  {
+    // (bounded like every wait on this kernel: climb_segment)
+    const auto w0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    long spins = 0;
+    while ((q = hipStreamQuery(e0.st_)) == hipErrorNotReady) {
+      { struct timespec ts = {0, 30000}; nanosleep(&ts, nullptr); }
+      if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 120.0) {
+        for (int k : batch) { engs[k]->invalidate_all(); engs[k]->broken_ = true; }
+        set_error("mpf_optimize_spr_many: the launch did not finish within 120 s");
+        return MPF_E_STATE;
       }
     }
+    if (q != hipSuccess) { for (int k : batch) engs[k]->invalidate_all(); set_error(std::string("mpf_optimize_spr_many: ") + hipGetErrorString(q)); return MPF_E_HIP; }
+  }
+  const auto t_dev = std::chrono::steady_clock::now();
+  for (int k : batch) {
+    Engine &e = *engs[k];
+    ManyState &s = e.many_;
+    const int total = 2 * e.n_ - 2;
+    uint32_t reason = 0, nm = 0;
+    const int rc = e.climb_harvest(total, s.tiles, t0, &s.i, &s.randomMP, &s.iter_hits, &reason, &nm);
+    if (rc) return rc;
+    if (reason == CLIMB_ABORT) { set_error("mpf_optimize_spr_many: a single-workgroup climb reported an abort"); return MPF_E_STATE; }
+    if (s.i > total) {                              // the sweep is through (:3316)
+      s.in_sweep = false;
+      if (!(s.randomMP < s.startMP)) {
+        e.climb_finished(total);
+        scores[k] = s.randomMP;
+        state[k] = 0;
+      }
+    }
+  }
+  if (getenv("MPF_MANY_TRACE")) {
+    const auto t_end = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[many] round of %zu climbs: prepare %.2f ms, launch + wait %.2f ms, harvest %.2f ms\n", batch.size(), ms(t0, t_prep), ms(t_prep, t_dev), ms(t_dev, t_end));
   }
   return MPF_OK;
 }

@@ -223,3 +223,11 @@ def test_batched_refinement_from_many_distinct_trees_equals_per_sample_oracle_cl
         moved += int(not (o.get_tree() == boot_trees[b]).all())
     assert moved >= B // 2                      # the refinements really climb here
     assert (e.weights() == w0).all()
+    # many_launch: the unstable samples' climbs as workgroups of ONE launch per round (mpf_optimize_spr_many_round), a finished engine
+    # taking the next sample at once -- same lengths, same trees
+    pool9 = pool + [engine.FitchEngine(codes) for _ in range(6)]
+    sc_m, tr_m = bootstrap.refine_boot_trees(pool9, samples, boot_trees, 9, radius, batched=True, many_launch=True)
+    assert sc_m.tolist() == sc_b.tolist() and all((tr_m[b] == tr_b[b]).all() for b in range(B))
+    assert all((x.weights() == w0).all() for x in pool9)
+    sc_t, tr_t = bootstrap.refine_boot_trees(pool9, samples, boot_trees, 9, radius, batched=True, many_launch=False)
+    assert sc_t.tolist() == sc_b.tolist()
