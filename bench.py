@@ -579,7 +579,7 @@ def main():
     ap.add_argument("--many-c2", type=int, default=512, help="climbs_in_one_launch leg: C2 climbs per call")
     ap.add_argument("--many-c3", type=int, default=192, help="climbs_in_one_launch leg: C3 climbs per call (an engine each: 0.25 GB; 0 = skip)")
     ap.add_argument("--legs", default="all",
-                    help="comma-separated secondary legs to run (default all): concurrent_climbs, start_trees, bb_reference_run, c2_climb, "
+                    help="comma-separated secondary legs to run (default all): ufboot_online (with the refinement of its trees), random_start, concurrent_climbs, start_trees, bb_reference_run, c2_climb, "
                          "c5_weighted_sweep, c5_fitch, noisy_bootstrap, climbs_in_one_launch; the headline step, its roofline and cpu_baseline always run")
     ap.add_argument("--ufboot-samples", type=int, default=1000,
                     help="bootstrap samples of the online UFBoot-MP leg (-bb): one pllOptimizeSprParsimony call with "
@@ -787,7 +787,14 @@ def main():
                          "plan_kernel_ms_per_launch": st["plan_kernel_ms_total"] / max(1, st["plan_launches"]),
                          "loaded_bytes_per_launch": evals_per_launch * eng.S * eng.Wp * 4,
                          "valu": {"achieved": achieved_valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s", "frac": achieved_valu / VALU_PEAK_TOPS,
-                                  "lane_ops_per_eval_word": ops_per_eval_word},
+                                  "lane_ops_per_eval_word": ops_per_eval_word,
+                                  # the issue side priced with MEASURED issue times (tools/ubench/valu_rate, profiles/r3/valu_rate.txt): per
+                                  # insertion test and 64-word tile about 20 wave-instructions of the 1.1 ns class (v_bitop3_b32, v_and) and 6
+                                  # of the 1.76 ns class (v_bcnt, the DPP adds of the reduction, readlane / writelane) per SIMD
+                                  "issue_ms_per_launch_measured_rates": evals_per_launch * ((eng.Wp + 63) // 64) * (20 * 1.1e-9 + 6 * 1.76e-9) / 1024 * 1e3,
+                                  "frac_of_kernel_time_at_measured_rates": (evals_per_launch * ((eng.Wp + 63) // 64) * (20 * 1.1e-9 + 6 * 1.76e-9) / 1024) / scan_s if scan_s > 0 else None,
+                                  "note": "peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz assumes a 2-cycle issue nobody measured; at the measured "
+                                          "issue times the kernel's arithmetic alone takes issue_ms_per_launch_measured_rates of its time"},
                          "hbm": {"compulsory_bytes_per_launch": compulsory, "compulsory_GBps": compulsory / scan_s / 1e9 if scan_s > 0 else 0.0,
                                  "frac_of_hbm_peak": compulsory / scan_s / 1e9 / HBM_PEAK_GBS if scan_s > 0 else 0.0,
                                  "peak_GBps": HBM_PEAK_GBS,
@@ -855,9 +862,10 @@ def main():
     tb_persample = None
     n_distinct_trees = None
     if args.ufboot_samples > 0:
+        samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=args.ufboot_samples).astype(np.uint16)
+    if args.ufboot_samples > 0 and (leg_on("ufboot_online") or leg_on("random_start")):
         try:
             B = args.ufboot_samples
-            samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=B).astype(np.uint16)
             from mpboot_amd import shard
             back_u = shard.broadcast_tree(back, 0, len(back))      # the chain starts from rank 0's tree on every rank
             # a sample-sharded online phase exchanges its events through the library's own RCCL communicator (mpf_rccl_exchange:
@@ -942,7 +950,7 @@ def main():
                 eng.set_weights(np.ones(P, dtype=np.int32))
             # ---- the same flow from a start tree that is NOT a local optimum (the RAS tree of this alignment already is one:
             # zero moves above): a random topology, thousands of accepted moves, refinements that really climb
-            if args.random_start_leg:
+            if args.random_start_leg and leg_on("random_start"):
                 back_r = shard.broadcast_tree(trees.random_topology(n, np.random.default_rng(2024)), 0, len(back))
                 eng.set_tree(back_r)
                 eng.reset_node_order()
