@@ -577,7 +577,7 @@ def main():
     ap.add_argument("--bb-rounds", type=int, default=6, help="... rounds timed (a round = --bb-sync iterations on every chain, then one exchange; 0 = skip)")
     ap.add_argument("--bb-sync", type=int, default=8, help="... iterations between two exchanges")
     ap.add_argument("--many-c2", type=int, default=512, help="climbs_in_one_launch leg: C2 climbs per call")
-    ap.add_argument("--many-c3", type=int, default=192, help="climbs_in_one_launch leg: C3 climbs per call (an engine each: 0.25 GB; 0 = skip)")
+    ap.add_argument("--many-c3", type=int, default=256, help="climbs_in_one_launch leg: C3 climbs per call (an engine each: 0.25 GB; 0 = skip)")
     ap.add_argument("--legs", default="all",
                     help="comma-separated secondary legs to run (default all): ufboot_online (with the refinement of its trees), random_start, concurrent_climbs, start_trees, bb_reference_run, c2_climb, "
                          "c5_weighted_sweep, c5_fitch, noisy_bootstrap, climbs_in_one_launch; the headline step, its roofline and cpu_baseline always run")

@@ -79,6 +79,7 @@ struct Sh {
   unsigned long long rng, hits, n_tests, n_ops, draws, n_nodes;
   uint32_t wtail, rtail, rhead, ndone, nops, task, ok, trace_n, use_static, pn_base[kMaxB];
   uint32_t xcc, xm;                          // this workgroup's XCD and how many of the launch's workgroups share it
+  uint32_t startMP, sweeps;                  // ClimbParams::sweeps_inside: the sweep under way started at this length; sweeps begun inside the launch
   uint32_t gap_ema;                          // recent distance between accepted moves in prune nodes, x 8 (decide: the batch after a move)
   uint32_t qtail;                            // vectors the step's scans read, listed by the enumeration (validity looked at later)
   uint32_t moved, einv, inv5[5];             // the move decide_select applied: stamp and touched nodes for the invalidation walk
@@ -927,7 +928,7 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     else if (n_moves >= P.max_moves || sh.epoch > kEpochLimit) reason = CLIMB_MOVES_FULL;
     else if (P.idle_limit && since >= P.idle_limit) reason = CLIMB_IDLE;
     if (cut) reason = CLIMB_CUTOFF;
-    if ((consumed == 0u && !cut) || sh.steps > 4u * P.total + 16u) sh.err = sh.err ? sh.err : 7u;
+    if ((consumed == 0u && !cut) || sh.steps > 4u * P.total * (sh.sweeps + 1u) + 16u) sh.err = sh.err ? sh.err : 7u;
     if (sh.err) reason = CLIMB_ERROR;
     sh.exit_reason = reason;
   }
@@ -1116,6 +1117,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     const ClimbHeader h = *P.hdr;
     sh.pos = h.pos; sh.B = h.batch ? h.batch : P.batch_min; sh.epoch = 1u; sh.exit_reason = CLIMB_RUNNING;
     sh.gap_ema = 8u * P.batch_min;
+    sh.startMP = h.start_mp; sh.sweeps = 0;
     sh.since_move = h.since_move; sh.rtail = 0; sh.steps = 0; sh.xgen = 0; sh.n_moves = 0; sh.err = 0; sh.trace_n = 0;
     sh.last_ncand[0] = sh.last_ncand[1] = sh.last_ncand[2] = 0;
     sh.best = h.best; sh.randomMP = h.randomMP; sh.iter_hits = h.iter_hits; sh.ins = h.insert_cid; sh.rem = h.remove_cid;
@@ -1237,9 +1239,9 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
       }
       refresh<KS, VW>(K, sh, tile == 0 && wave == 0);
       __syncthreads();
+      MPF_TMARK(3);
       if (tk + 1u == nmine) {
         beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
-        MPF_TMARK(3);
         // (the refresh's lists are done with: chain starts back to "none", consumer counts to zero -- nothing reads them before the
         //  next closure, which runs several barriers on)
         for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
@@ -1275,7 +1277,10 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
           }
         }
       }
-      if (multi) __syncthreads();                          // (the next tile's refresh stages into the region the scans parked their up-vectors in)
+      if (multi) {
+        __syncthreads();                                   // (the next tile's refresh stages into the region the scans parked their up-vectors in)
+        MPF_TMARK(4);
+      }
     }
     __syncthreads();
     beat(P, tile, tid, 1, 5);
@@ -1359,7 +1364,35 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     __syncthreads();
     beat(P, tile, tid, 8, sh.err);
     MPF_TMARK(6);
-    if (sh.exit_reason != CLIMB_RUNNING) break;
+    const bool next_sweep = sh.exit_reason == CLIMB_SWEEP_END && P.sweeps_inside && sh.randomMP < sh.startMP && sh.n_moves < P.max_moves && sh.epoch + 64u < kEpochLimit;
+    const bool leave = !next_sweep && sh.exit_reason != CLIMB_RUNNING;
+    if (next_sweep) {
+      __syncthreads();                              // (everybody has read the words lane 0 is about to change)
+      // the next sweep, inside the launch: nodeRectifierPars on the topology as the last move left it -- a pre-order walk from the
+      // start tip's neighbour, first child first (reference :2046-2101; Engine::node_rectifier), the inner records in the order and
+      // by the record they are entered; one lane, the closure's work list as its stack
+      if (tid == 0) {
+        uint32_t count = 0, sp = 0;
+        K.W[sp++] = K.bk[K.ord[0]];
+        while (sp) {
+          const uint32_t p = K.W[--sp];
+          if (p < n) continue;
+          K.ord[n + count] = (uint16_t)p;
+          count++;
+          const uint32_t p1 = nxc(p, n);
+          K.W[sp++] = K.bk[nxc(p1, n)];
+          K.W[sp++] = K.bk[p1];
+        }
+        sh.startMP = sh.randomMP;
+        sh.pos = 1u;
+        sh.B = P.batch_min < P.total ? P.batch_min : P.total;
+        sh.since_move = 0u;
+        sh.sweeps++;
+        sh.exit_reason = CLIMB_RUNNING;
+      }
+      __syncthreads();
+    }
+    if (leave) break;
     // ---- (6b) side by side: wave 0 walks the invalidation the move causes, the other waves clear the candidate sums and enumerate
     // the NEXT step on the edited topology (pure topology work; what it lists is looked at for validity behind the barrier)
     if (wave == 0) {
@@ -1374,8 +1407,10 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   // ---- hand the state back
   if (tile == 0) {
     for (uint32_t i = (uint32_t)tid; i < ns; i += kThreads) P.bk[i] = K.bk[i];
+    if (P.sweeps_inside) for (uint32_t i = (uint32_t)tid; i < P.total; i += kThreads) P.order[i] = K.ord[i];
     if (tid == 0) {
       ClimbHeader *h = P.hdr;
+      h->start_mp = sh.startMP; h->sweeps = sh.sweeps;
       h->rng = sh.rng; h->hits = sh.hits; h->best = sh.best; h->randomMP = sh.randomMP; h->iter_hits = sh.iter_hits;
       h->pos = sh.pos; h->insert_cid = sh.ins; h->remove_cid = sh.rem; h->n_moves = sh.n_moves; h->reason = sh.exit_reason;
       h->err = sh.err; h->steps = sh.steps; h->n_tests = sh.n_tests; h->n_ops = sh.n_ops; h->draws = sh.draws;

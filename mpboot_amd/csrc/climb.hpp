@@ -43,6 +43,9 @@ struct ClimbHeader {
   uint32_t pad[4];
   uint32_t start_gate, pad2[3];    // 0 = undecided, 1 = every workgroup has arrived: go, 2 = somebody timed out: nobody starts (ONE compare-and-swap decides)
   unsigned long long tph[16];      // 100 MHz ticks workgroup 0 spent per phase: set-up, enumerate, closure, refresh, scan, exchange, decide
+  // ClimbParams::sweeps_inside: startMP of the sweep under way (in: the host's; out: of the sweep the launch ended in) and the sweeps
+  // that were started inside the launch
+  uint32_t start_mp, sweeps, pad3[2];
 };
 
 struct ClimbParams {
@@ -54,7 +57,7 @@ struct ClimbParams {
   uint32_t idle_limit;             // 0 = never leave for idleness
   uint32_t max_moves;
   uint32_t batch_min, batch_max;   // prune nodes per step (speculative; doubles after a step without a move)
-  const uint16_t *order;           // [total] vector ids of nodep[1..total]
+  uint16_t *order;                 // [total] vector ids of nodep[1..total] (in; out with sweeps_inside)
   uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
   uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch)
   unsigned long long *gsum;        // [3][kClimbCap] exchange ring (zeroed by the host before the launch)
@@ -80,6 +83,12 @@ struct ClimbParams {
   // sums meet in the exchange -- with groups == 1 nothing crosses between workgroups at all: a climb is ONE resident workgroup
   // and a chip holds hundreds of them (engine option "climb_groups")
   uint32_t groups;
+  // 1 = a sweep that ends with the climb not yet at its optimum (randomMP < startMP, reference :3316) is followed by the next one
+  // INSIDE the launch: nodeRectifierPars (:2046-2101) runs on the topology in LDS, the vectors stay valid (a new launch would have
+  // to recompute every one of them in its first step).  The launch then ends at the optimum, or with a full move list.  `order`
+  // comes back as the last rectification left it.  (k_climb_many: a climb is one launch; off for k_climb, whose 98 workgroups would
+  // each walk the tree for it)
+  uint32_t sweeps_inside;
   uint16_t *snap_r;                // [groups][nslots] the ready list of such a step
   uint32_t *snap;                  // [groups][nslots + nslots / 4 + 1] words: the claim words and validity flags of a step whose closure takes the plain dataflow path, restored per tile (groups < tiles only)
 };

@@ -2137,12 +2137,15 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_tile") {
     if (v != 1 && v != 2 && v != 4 && v != 8) { set_error("climb_tile: 1|2|4|8 words per lane group (tiles of 16, 32, 64, 128 words)"); return MPF_E_INVALID; }
     climb_vw_ = (int)v;
+    climb_vw_set_ = true;
     return MPF_OK;
   }
   if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max_sparse") { climb_batch_max_sparse_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "many_moves_cap") { many_moves_cap_ = v < 0 ? 0 : (int)std::min<long long>(v, 1 << 20); return MPF_OK; }
+  if (key == "many_sweeps_inside") { many_sweeps_inside_ = v != 0; return MPF_OK; }
   if (key == "climb_groups") { climb_groups_ = v < 0 ? 0 : v > 4096 ? 4096 : (int)v; return MPF_OK; }
   if (key == "climb_fault") { climb_fault_ = v; return MPF_OK; }          // (tests of the recovery paths: climb.hpp)
   if (key == "views_waves") { nv_waves_ = (int)v; return MPF_OK; }         // waves per refresh workgroup: 0 = by level width, -1 = always sixteen, 2 .. 16
@@ -2231,6 +2234,9 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "views_waves") *v = nv_waves_;
   else if (key == "climb_trace") *v = climb_trace_;
   else if (key == "climb_groups") *v = climb_groups_;
+  else if (key == "many_moves_cap") *v = many_moves_cap_;
+  else if (key == "climb_tile_many") *v = const_cast<Engine *>(this)->climb_fit_vw(true);      // the width mpf_optimize_spr_many runs this engine's climbs on
+  else if (key == "many_sweeps_inside") *v = many_sweeps_inside_ ? 1 : 0;
   else if (key.rfind("climb_ctr", 0) == 0 && key.size() == 10 && key[9] >= '0' && key[9] <= '3') *v = (int64_t)climb_ctr_[key[9] - '0'];   // refresh ops, closure rounds, invalidation rounds, chains
   else if (key.rfind("climb_phase_us", 0) == 0 && key.size() == 15 && ((key[14] >= '0' && key[14] <= '9') || (key[14] >= 'a' && key[14] <= 'f')))
     *v = (int64_t)(climb_phase_ticks_[key[14] <= '9' ? key[14] - '0' : key[14] - 'a' + 10] / 100ull);

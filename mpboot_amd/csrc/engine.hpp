@@ -32,6 +32,7 @@
 namespace mpf {
 
 void set_error(const std::string &msg);
+const std::string &last_error();
 
 template <typename T>
 struct DevBuf {
@@ -320,7 +321,7 @@ class Engine {
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
   // the first sweep of pllOptimizeSprParsimony from the current tree under every attached sample's weights at once
-  int climb_fit_vw();                            // tile width k_climb will run with on this device (0: does not fit)
+  int climb_fit_vw(bool one_workgroup = false);                            // tile width k_climb will run with on this device (0: does not fit)
   int ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit);
   int ufboot_set_mulhits(int on);
   int ufboot_set_cutoff_from_btrees(int on);
@@ -468,6 +469,7 @@ class Engine {
     DevBuf<uint16_t> snap_r;
     DevBuf<unsigned long long> gsum;
     DevBuf<uint32_t> out;                        // [header | moves]
+    uint32_t max_moves = 0;                      // capacity of the move list of the launch prepared last
     PinBuf<uint16_t> h_bk, h_order;
     PinBuf<uint32_t> h_out, h_beat;
     std::vector<uint32_t> h_trace;
@@ -475,14 +477,17 @@ class Engine {
   } cd_;
   unsigned long long climb_phase_ticks_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, climb_ctr_[4] = {0, 0, 0, 0};
   int climb_device_ = 1;                         // 0 = host-driven batches only, 1 = device climb while moves are dense, 2 = always
+  bool climb_vw_set_ = false;                    // option "climb_tile" was given: mpf_optimize_spr_many does not pick its own width
   int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)
   int climb_batch_max_sparse_ = 16;              // option climb_batch_max_sparse: prune nodes per step of the quiet stretch of a tracked climb
   int climb_batch_min_ = 2, climb_batch_max_ = 8, climb_idle_ = 96, climb_trace_ = 0;
+  int many_moves_cap_ = 0;                       // option "many_moves_cap" (tests): moves per launch of such a climb (0 = four sweeps' worth)
+  bool many_sweeps_inside_ = true;               // option "many_sweeps_inside": a climb of mpf_optimize_spr_many runs all its sweeps in one launch (ClimbParams::sweeps_inside)
   int climb_groups_ = 0;                         // option "climb_groups": workgroups per k_climb launch (0 = one per tile; ClimbParams::groups)
   inline int rec_of(uint32_t cid) const { return cid < (uint32_t)n_ ? 3 * ((int)cid + 1) : 3 * (n_ + 1 + (int)(cid - (uint32_t)n_) / 3) + (int)((cid - (uint32_t)n_) % 3u); }
   int climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP, unsigned *iter_hits, bool may_idle, uint32_t *reason, uint32_t *n_moves);
   int climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, unsigned iter_hits, bool may_idle, int force_groups, hipStream_t st,
-                    ClimbParams &p, int *vw_out, int *tiles_out);
+                    ClimbParams &p, int *vw_out, int *tiles_out, bool sweeps_inside, uint32_t start_mp);
   int climb_harvest(int total, int tiles, std::chrono::steady_clock::time_point t0, int *i, uint32_t *randomMP, unsigned *iter_hits, uint32_t *reason,
                     uint32_t *n_moves);
 public:

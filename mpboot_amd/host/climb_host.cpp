@@ -54,8 +54,19 @@ struct GateHold {
 // k_climb's workgroups wait for each other: a launch whose tiles cannot all be resident would spin until its start barrier times
 // out, every time.  The tile width the launch will use: option "climb_tile", widened (DNA: 2, 4, 8 words per lane group) until the
 // workgroups fit 85 % of the CUs (several per CU where the control state is small); 0 = this alignment is too long for the kernel.
-int Engine::climb_fit_vw()
+int Engine::climb_fit_vw(bool one_workgroup)
 {
+  if (one_workgroup && g_.S == 4 && !climb_vw_set_) {
+    // a climb as ONE workgroup (k_climb_many) goes through its tiles one after the other: wide tiles mean fewer passes through the
+    // per-tile part of a step -- the widest whose padding stays within 8 % of the narrowest's (C2, 313 words: 5 x 64; C3, 1563: 13 x 128)
+    size_t least = ~(size_t)0;
+    for (int vw = 1; vw <= 8; vw *= 2) least = std::min(least, (size_t)climb_tiles(g_, vw) * 16 * (size_t)vw);
+    for (int vw = 8; vw >= 1; vw /= 2) {
+      if (climb_lds_bytes(g_, n_, vw) > 160 * 1024) continue;
+      if ((size_t)climb_tiles(g_, vw) * 16 * (size_t)vw * 100 <= least * 108) return vw;
+    }
+    return 0;
+  }
   if (climb_cus_ <= 0) {
     int c = 0;
     if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || c <= 0) c = 256;
@@ -77,16 +88,20 @@ int Engine::climb_fit_vw()
 // the caller launches -- k_climb for this engine alone (climb_segment), or k_climb_many for a batch of engines (Engine::climb_many) --
 // and copies the result block back, climb_harvest takes the moves over.
 int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, unsigned iter_hits, bool may_idle, int force_groups,
-                          hipStream_t st, ClimbParams &p, int *vw_out, int *tiles_out)
+                          hipStream_t st, ClimbParams &p, int *vw_out, int *tiles_out, bool sweeps_inside, uint32_t start_mp)
 {
-  const int vw = climb_fit_vw();
+  const int vw = climb_fit_vw(force_groups == 1);
   *vw_out = vw;
   if (vw <= 0) { set_error("device climb: the alignment's tiles do not fit the chip"); return MPF_E_STATE; }
   const int tiles = climb_tiles(g_, vw);
   *tiles_out = tiles;
   const size_t ns = nslots_;
   const size_t hdr_words = (sizeof(ClimbHeader) + 3) / 4;
-  const size_t out_words = hdr_words + 3 * (size_t)total;
+  // (a launch that runs every sweep of a climb makes more moves than one sweep's: room for four sweeps' worth, then it hands back)
+  // (option many_moves_cap, tests: a short list, so that launches end in the middle of sweeps the device started)
+  const size_t max_moves = sweeps_inside ? (many_moves_cap_ > 0 ? std::min<size_t>((size_t)many_moves_cap_, 4 * (size_t)total) : 4 * (size_t)total) : (size_t)total;
+  cd_.max_moves = (uint32_t)max_moves;
+  const size_t out_words = hdr_words + 3 * max_moves;
   HIPCHK(cd_.bk.reserve(ns));
   HIPCHK(cd_.order.reserve((size_t)total));
   HIPCHK(cd_.sct.reserve((size_t)tiles * ns * 16));
@@ -115,6 +130,7 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   h.remove_cid = remove_rec_ >= 0 ? (int32_t)slot(remove_rec_) : -1;
   h.since_move = 0;
   h.batch = 0;
+  h.start_mp = start_mp;
   std::memcpy(cd_.h_out.p, &h, sizeof(h));
   p.vec = d_vec_;
   p.n = (uint32_t)n_;
@@ -125,7 +141,7 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   p.maxtrav = (uint32_t)maxtrav_eff;
   p.tie_mode = (uint32_t)tie_mode_;
   p.idle_limit = may_idle ? (uint32_t)climb_idle_ : 0u;
-  p.max_moves = (uint32_t)total;
+  p.max_moves = (uint32_t)max_moves;
   p.batch_min = (uint32_t)std::max(1, std::min(climb_batch_min_, 16));
   // (a climb under a stop length is a later iteration of a -bb search: it starts near an optimum, its moves are some 25-45 prune
   //  nodes apart -- sixteen prune nodes per step there)
@@ -147,6 +163,7 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   // option "climb_groups": 0 = a workgroup per tile; k = at most k workgroups, each working through its share of the tiles
   const int groups = force_groups > 0 ? std::min(force_groups, tiles) : climb_groups_ > 0 ? std::min(climb_groups_, tiles) : tiles;
   p.groups = (uint32_t)groups;
+  p.sweeps_inside = sweeps_inside ? 1u : 0u;
   p.snap = nullptr;
   p.snap_r = nullptr;
   if (groups < tiles) {
@@ -179,7 +196,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   ClimbParams p;
   int vw = 0, tiles = 0;
   {
-    const int rc = climb_prepare(maxtrav_eff, total, *i, *randomMP, *iter_hits, may_idle, 0, st_, p, &vw, &tiles);
+    const int rc = climb_prepare(maxtrav_eff, total, *i, *randomMP, *iter_hits, may_idle, 0, st_, p, &vw, &tiles, false, 0);
     if (rc) return rc;
   }
   const int groups = (int)p.groups;
@@ -260,7 +277,7 @@ int Engine::climb_harvest(int total, int tiles, std::chrono::steady_clock::time_
     *reason = CLIMB_ABORT;
     return MPF_OK;
   }
-  if (h.reason == CLIMB_ERROR || h.reason == CLIMB_RUNNING || h.n_moves > (uint32_t)total) {
+  if (h.reason == CLIMB_ERROR || h.reason == CLIMB_RUNNING || h.n_moves > cd_.max_moves) {
     invalidate_all();                             // (the kernel has rewritten vectors for topologies the mirror never saw)
     set_error("device climb: internal error " + std::to_string(h.err) + " (reason " + std::to_string(h.reason) + "; waiter " +
               std::to_string(h.pad2[0] & 0x7FFFFFFFu) + " of " + std::to_string(tiles) + " tiles, candidate " + std::to_string(h.pad2[1] & 0xFFFFu) + " of " +
@@ -287,6 +304,11 @@ int Engine::climb_harvest(int total, int tiles, std::chrono::steady_clock::time_
     hookup(nx(nx(pr)), r);
     stats.moves_applied++;
   }
+  if (h.sweeps) {
+    // (ClimbParams::sweeps_inside) nodeRectifierPars ran on the device: nodep[] as its last run left it
+    for (int k = n_ + 1; k <= total; k++) nodep_[(size_t)k] = rec_of((uint32_t)cd_.h_order.p[k - 1]);
+  }
+  many_.startMP = h.start_mp;
   invalidate_all();
   rng_.state = h.rng;
   hits_ = (unsigned long)h.hits;
@@ -346,34 +368,62 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
   for (int k = 0; k < n; k++) if (state[k]) { first = k; break; }
   if (first < 0) return MPF_OK;
   Engine &e0 = *engs[first];
-  const int vw0 = e0.climb_fit_vw();
+  const int vw0 = e0.climb_fit_vw(true);
   // a starting climb's preamble (the full evaluate of :3277) on its own engine; what does not fit the batch runs alone, here
+  std::vector<int> starting;
   for (int k = 0; k < n; k++) {
     if (state[k] != 1) continue;
     Engine &e = *engs[k];
     if (!e.have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
     const int mt_eff = std::min(maxtrav, e.n_ - 3);
     const bool fits = vw0 > 0 && e.dev_ == e0.dev_ && e.g_.S == e0.g_.S && !e.sankoff_ && !e.rand_fn_ && !(e.ufb_ && !e.ufb_->suspended) && mintrav == 1 &&
-                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff) && e.climb_fit_vw() == vw0;
+                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff) && e.climb_fit_vw(true) == vw0;
     if (!fits) {
       const int rc = e.optimize_spr(mintrav, maxtrav, &scores[k]);
       if (rc) return rc;
       state[k] = 0;
       continue;
     }
-    e.moves_.clear();
-    e.node_rectifier();
-    uint32_t len = 0;
-    e.invalidate_vectors();
-    const int rc = e.tree_length(&len);
-    if (rc) return rc;
-    e.best_ = len;
-    e.ntips_ = e.n_;
-    e.insert_rec_ = e.remove_rec_ = -1;
-    e.visits_done_ = 0;
-    e.many_ = ManyState{};
-    e.many_.randomMP = len;
-    state[k] = 2;
+    starting.push_back(k);
+  }
+  {
+    auto preamble = [&](int k) -> int {
+      Engine &e = *engs[k];
+      e.moves_.clear();
+      e.node_rectifier();
+      uint32_t len = 0;
+      e.invalidate_vectors();
+      const int rc = e.tree_length(&len);
+      if (rc) return rc;
+      e.best_ = len;
+      e.ntips_ = e.n_;
+      e.insert_rec_ = e.remove_rec_ = -1;
+      e.visits_done_ = 0;
+      e.many_ = ManyState{};
+      e.many_.randomMP = len;
+      return MPF_OK;
+    };
+    // (an evaluate per engine, each with its own stream and its own wait: a quarter of a millisecond one after the other --
+    //  a third of the whole call at 512 climbs of C2 --, so a handful of threads share them)
+    const int nthr = starting.size() >= 16 ? (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nthr <= 1) {
+      for (int k : starting) { const int rc = preamble(k); if (rc) return rc; }
+    } else {
+      std::vector<std::thread> th;
+      std::vector<int> rcs((size_t)nthr, MPF_OK);
+      std::vector<std::string> errs((size_t)nthr);
+      for (int t = 0; t < nthr; t++)
+        th.emplace_back([&, t] {
+          if (hipSetDevice(e0.dev_) != hipSuccess) { rcs[(size_t)t] = MPF_E_HIP; errs[(size_t)t] = "hipSetDevice failed"; return; }
+          for (size_t i = (size_t)t; i < starting.size(); i += (size_t)nthr) {
+            const int rc = preamble(starting[i]);
+            if (rc) { rcs[(size_t)t] = rc; errs[(size_t)t] = last_error(); return; }
+          }
+        });
+      for (auto &x : th) x.join();
+      for (int t = 0; t < nthr; t++) if (rcs[(size_t)t]) { set_error(errs[(size_t)t]); return rcs[(size_t)t]; }
+    }
+    for (int k : starting) state[k] = 2;
   }
   HIPCHK(hipSetDevice(e0.dev_));
   ManyBufs &mb = e0.many_bufs_;
@@ -390,7 +440,8 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
     const int total = 2 * e.n_ - 2;
     if (!s.in_sweep) { s.startMP = s.randomMP; e.node_rectifier(); s.i = 1; s.in_sweep = true; }
     int vw = 0;
-    const int rc = e.climb_prepare(std::min(maxtrav, e.n_ - 3), total, s.i, s.randomMP, s.iter_hits, false, 1, e0.st_, mb.h_params.p[batch.size()], &vw, &s.tiles);
+    const int rc = e.climb_prepare(std::min(maxtrav, e.n_ - 3), total, s.i, s.randomMP, s.iter_hits, false, 1, e0.st_, mb.h_params.p[batch.size()], &vw, &s.tiles,
+                                   e0.many_sweeps_inside_, s.startMP);
     if (rc) return rc;
     max_ns = std::max(max_ns, (uint32_t)e.nslots_);
     batch.push_back(k);
@@ -401,8 +452,9 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
   HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, mb.d_params.p, (int)batch.size(), max_ns));
   for (int k : batch) {
     Engine &e = *engs[k];
-    const size_t out_words = hdr_words + 3 * (size_t)(2 * e.n_ - 2);
+    const size_t out_words = hdr_words + 3 * (size_t)e.cd_.max_moves;
     HIPCHK(hipMemcpyAsync(e.cd_.h_out.p, e.cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e0.st_));
+    if (e0.many_sweeps_inside_) HIPCHK(hipMemcpyAsync(e.cd_.h_order.p, e.cd_.order.p, (size_t)(2 * e.n_ - 2) * sizeof(uint16_t), hipMemcpyDeviceToHost, e0.st_));
   }
   {
     // (bounded like every wait on this kernel: climb_segment)

@@ -77,6 +77,38 @@ def test_many_climbs_in_one_launch_equal_their_solo_runs(n, P, alphabet, n_eng, 
     assert again.tolist() == scores[:3].tolist()
 
 
+@pytest.mark.parametrize("n,P,n_eng", [(40, 1500, 5), (200, 4000, 9)])
+def test_sweeps_inside_the_launch_or_one_launch_per_sweep(n, P, n_eng):
+    """option many_sweeps_inside: the next sweep's nodeRectifierPars on the device (default) or on the host between launches -- the
+    same climbs either way, in fewer launches; a climb that makes more moves than a launch's move list holds
+    comes back in the middle of a sweep the DEVICE started and goes on from the order it left (option many_moves_cap forces that)."""
+    from mpboot_amd import engine, synth, trees
+    letters, _ = synth.synth_alignment(n, P, "DNA", 0.08, seed=n + P + 2)
+    codes = synth.letters_to_codes(letters, "DNA")
+    rng = np.random.default_rng(8)
+    starts = [trees.random_topology(n, rng) for _ in range(n_eng)]
+    res = {}
+    for inside in (1, 0, 2):
+        engs = []
+        for k, t in enumerate(starts):
+            e = engine.FitchEngine(codes)
+            e.set_option("many_sweeps_inside", min(inside, 1))
+            if inside == 2:
+                e.set_option("many_moves_cap", 3 * n // 4)
+            e.set_tree(t); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 40 + k)
+            engs.append(e)
+        sc = engine.optimize_spr_many(engs, 1, 6)
+        res[inside] = [(int(sc[k]), [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.tie_state()) for k, e in enumerate(engs)]
+        launches = [e.stats()["climb_launches"] for e in engs]
+        res[("launches", inside)] = launches
+    assert res[1] == res[0] and res[2] == res[0]
+    assert sum(res[("launches", 1)]) < sum(res[("launches", 0)])
+    assert max(res[("launches", 1)]) == 1 and min(res[("launches", 2)]) >= 2
+    for k, t in enumerate(starts[:3]):
+        _, sig = _solo(codes, engine.DNA, t, 40 + k, engine.TIE_RANDOM)
+        assert res[1][k] == sig, k
+
+
 def test_engines_the_batch_cannot_take_run_alone_inside_the_call():
     from mpboot_amd import engine, synth, trees
     letters, _ = synth.synth_alignment(30, 800, "DNA", 0.1, seed=4)

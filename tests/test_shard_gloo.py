@@ -52,12 +52,16 @@ def _run(nproc, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MPF_ROOT=ROOT)
-    if nproc == 1:
-        cmd = [sys.executable, str(script)]
-    else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(2):
+        if nproc == 1:
+            cmd = [sys.executable, str(script)]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        # (the port was free when it was picked, not necessarily when the rendezvous bound it: one more try with another)
+        if out.returncode == 0 or nproc == 1 or "RESULT " in out.stdout:
+            break
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
     import json

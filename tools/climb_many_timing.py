@@ -9,6 +9,7 @@ ap.add_argument("--workload", default="C2")
 ap.add_argument("--engines", default="64,128,256")
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--phases", action="store_true", help="per-phase time of three of the climbs (their workgroup's own clock)")
 a = ap.parse_args()
 cfg = synth.WORKLOADS[a.workload]
 letters, _ = synth.workload(a.workload)
@@ -35,4 +36,10 @@ for E in (int(x) for x in a.engines.split(",")):
         dt_s = time.perf_counter() - t0
     steps = sum(e.stats()["climb_steps"] for e in engs[:E]); launches = sum(e.stats()["climb_launches"] for e in engs[:E])
     print(f"{a.workload} {a.opt}: {E} climbs in {dt_s:.3f} s = {E / dt_s:.1f} climbs/s (scores {int(sc.min())}..{int(sc.max())}; "
-          f"{steps / E:.0f} kernel steps and {launches / E:.1f} sweeps per climb)", flush=True)
+          f"{steps / E:.0f} kernel steps and {launches / E:.1f} launches per climb)", flush=True)
+    if a.phases:
+        # (cumulative since the engine was made: the last repetition dominates only if reps == 1)
+        names = ["set-up", "enumerate", "closure", "refresh", "scan", "exchange", "decide"]
+        for k in (0, E // 2, E - 1):
+            us = [engs[k].get_option(f"climb_phase_us{j}") for j in range(7)]
+            print(f"  climb {k}: " + ", ".join(f"{nm} {u / 1e3:.1f} ms" for nm, u in zip(names, us)) + f"; sum {sum(us) / 1e3:.1f} ms", flush=True)
