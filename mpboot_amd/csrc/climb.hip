@@ -111,6 +111,7 @@ struct Kx {
   uint16_t *OL;      // [kLcap] the first refresh ops, by index
   uint16_t *ord;     // [total] the sweep's visiting order
   uint16_t *Q;       // [ns] what the enumeration lists (lives in the stage / pend region, idle between decide and refresh)
+  uint2 *SD;         // [kLcap] (in the stage / pend region) the refresh of a step as ONE sequence (schedule_private): r | how operand a comes << 16 | operand b << 18 ; a | b << 16
   uint32_t *PEND0;   // [kLcap] PEND as the link pass left it  } a workgroup that works through several tiles per step runs the
   uint16_t *R0;      // [kLcap] the chain starts of the link pass } same refresh once per tile: what a run consumes is put back
   unsigned long long pre, ancl, lsub;   // heap-index relations of this lane (enumeration)
@@ -263,7 +264,7 @@ __device__ __forceinline__ void enum_unit(const Kx<KS, VW> &K, Sh &sh, const Cli
 
 // ---- (2) wave 0: output layout of the step, then the closure of stale inputs
 template <int KS, int VW>
-__device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
+__device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh, const bool no_slots)
 {
   const int lane = K.lane;
   const uint32_t n = K.n, epoch = sh.epoch, B = sh.B;
@@ -430,7 +431,8 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh)
       nstart += (uint32_t)__builtin_popcountll(ms);
     }
     if (lane == 0) sh.rtail = nstart;
-    if (slot_base > K.slots) {
+    // (refresh_private stages nothing: there the closure keeps its descriptors however many operands it has)
+    if (slot_base > K.slots && !no_slots) {
       // slots ran out: this step's refresh takes the plain path, whose chain starts are vectors, not op indices
       for (uint32_t k = (uint32_t)lane; k < nstart; k += 64u) K.R[k] = K.OL[K.R[k]];
       mode = 0u;
@@ -685,6 +687,93 @@ __device__ __forceinline__ void refresh_dynamic(const Kx<KS, VW> &K, Sh &sh)
       if (lane == 0) __hip_atomic_fetch_add(&sh.ndone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (nr == 0) break;
       prev = r; lprev = lc; r = rdy0;
+    }
+  }
+}
+
+// ---- (3') a workgroup that holds SEVERAL tiles (fewer workgroups than tiles; k_climb_many: all of them).  Run tile after tile, the
+// cooperative refresh above pays its chain of dependent links -- a memory round trip, LDS hand-overs, two barriers -- once per
+// tile, and most waves watch (measured at C3 on 13 tiles of 128 words: 27 us per tile whatever its width, 350 of a step's 800 us).
+// Instead: the closure's ops are put into ONE order in which every op comes after its stale inputs (wave 0, once per step), and
+// every wave takes whole tiles of its own through that sequence, alone: nothing to wait for, nothing to hand over.  An operand
+// that was valid before the step -- or was written at least a block of four ops ago by this very wave: a wave's accesses to an
+// address arrive in program order -- is requested with its block's other operands in one go; the result of the op just before
+// stays in registers; what is left (the far input of a join, now and then) is read where it is needed.
+template <int KS, int VW>
+__device__ __forceinline__ void schedule_private(const Kx<KS, VW> &K, Sh &sh)
+{
+  if (K.lane != 0) return;
+  const uint32_t n = K.n, nops = sh.nops, nstart = sh.rtail;
+  uint32_t sp = 0, cnt = 0;
+  for (uint32_t k = 0; k < nstart; k++) K.R0[sp++] = K.R[nstart - 1u - k];
+  while (sp) {
+    const uint32_t i = K.R0[--sp];
+    const uint2 d = K.D[i];
+    const uint32_t a = d.y & 0xFFFFu, b = d.y >> 16;
+    uint32_t fl[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t v = u ? b : a;
+      uint32_t f = 1u;                                   // from memory, with the block's requests
+      if (v >= n && !K.valid[v]) {
+        const uint32_t at = K.PEND0[(K.cl[v] >> 3) & kIdxMask];      // where its op stands in the sequence (it does: it came first)
+        f = at + 1u == cnt ? 0u : at < (cnt & ~3u) ? 1u : 2u;
+      }
+      fl[u] = f;
+    }
+    K.PEND0[i] = cnt;
+    K.SD[cnt] = make_uint2((d.x & 0xFFFFu) | (fl[0] << 16) | (fl[1] << 18), d.y);
+    cnt++;
+    if (cnt > nops) break;
+    const uint32_t nc = K.NC[i] < 2u ? K.NC[i] : 2u;
+    for (uint32_t u = 0; u < nc; u++) {
+      const uint32_t ex_ = K.CONS[2u * i + u].x, j = ex_ & 0xFFu;
+      bool ready = ((ex_ >> 9) & 3u) == 1u;
+      if (!ready) { const uint32_t left = K.PEND[j] - 1u; K.PEND[j] = left; ready = left == 0u; }
+      if (ready) K.R0[sp++] = (uint16_t)j;
+    }
+  }
+  if (cnt != nops) sh.err = sh.err ? sh.err : 6u;
+}
+
+template <int KS, int VW>
+__device__ __forceinline__ void refresh_private(const Kx<KS, VW> &K, Sh &sh)
+{
+  const uint32_t nops = sh.nops;
+  const int lane = K.lane;
+  QT<KS, VW> c;
+  uint32_t lc = 0;
+  for (uint32_t k0 = 0; k0 < nops; k0 += 4u) {
+    QT<KS, VW> A[4], B[4];
+    uint32_t la[4], lb[4], sx[4], sy[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t k = k0 + (uint32_t)i;
+      const uint2 sd = K.SD[k < nops ? k : nops - 1u];
+      sx[i] = rfl(sd.x); sy[i] = rfl(sd.y);
+      la[i] = lb[i] = 0;
+      if (k < nops) {
+        if (((sx[i] >> 16) & 3u) == 1u) { ld<KS, VW>(K, A[i], sy[i] & 0xFFFFu); la[i] = ld_sl<KS, VW>(K, sy[i] & 0xFFFFu); }
+        if (((sx[i] >> 18) & 3u) == 1u) { ld<KS, VW>(K, B[i], sy[i] >> 16); lb[i] = ld_sl<KS, VW>(K, sy[i] >> 16); }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t k = k0 + (uint32_t)i;
+      if (k < nops) {
+        const uint32_t fa = (sx[i] >> 16) & 3u, fb = (sx[i] >> 18) & 3u, r = sx[i] & 0xFFFFu;
+        if (fa == 0u) { A[i] = c; la[i] = lc; }
+        else if (fa == 2u) { ld<KS, VW>(K, A[i], sy[i] & 0xFFFFu); la[i] = ld_sl<KS, VW>(K, sy[i] & 0xFFFFu); }
+        if (fb == 0u) { B[i] = c; lb[i] = lc; }
+        else if (fb == 2u) { ld<KS, VW>(K, B[i], sy[i] >> 16); lb[i] = ld_sl<KS, VW>(K, sy[i] >> 16); }
+        QT<KS, VW> o;
+        const uint32_t cost = q_fitch<KS, VW>(o, A[i], B[i]);
+        c = o;
+        lc = cost + la[i] + lb[i];
+        if (K.st_lane) qstore<KS, VW>(c, K.rsrc, K.voff, r * K.SW4);
+        st_sl<KS, VW>(K, r, lc);
+        if (lane == 0) K.valid[r] = 1;
+      }
     }
   }
 }
@@ -1036,7 +1125,10 @@ __host__ __device__ inline size_t region_bytes(uint32_t ns)
 
 // The body of a climb's workgroup: workgroup `tile` of the climb's T (k_climb: the launch's grid; k_climb_many: ONE workgroup per
 // climb, every workgroup of the launch another climb with its own ClimbParams).
-template <int KS, int VW>
+// MODE 0: a workgroup per tile (k_climb as launched by default: nothing of the several-tiles machinery is compiled in -- its
+// registers are the sixteen-wave shapes' scarce resource); 1: fewer workgroups than tiles, tile after tile (option climb_groups);
+// 2: k_climb_many (the waves take tiles of their own through the refresh: refresh_private)
+template <int KS, int VW, int MODE>
 __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t tile, const uint32_t T)
 {
   constexpr uint32_t kThreads = Cfg<KS, VW>::NT, kNW = Cfg<KS, VW>::NW;
@@ -1045,7 +1137,8 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   const int wave = (int)rfl((uint32_t)(tid >> 6));
   // workgroup `tile` of T; it owns the tiles tile, tile + T, ... of the alignment's TT (T == TT: exactly one)
   const uint32_t n = P.n, ns = P.nslots, TT = P.tiles;
-  const uint32_t nmine = tile < TT ? (TT - tile + T - 1u) / T : 0u;
+  constexpr bool PRIV = MODE == 2;
+  const uint32_t nmine = MODE == 0 ? 1u : tile < TT ? (TT - tile + T - 1u) / T : 0u;
   // ---- carve the workgroup's LDS
   Sh &sh = *reinterpret_cast<Sh *>(smem);
   size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
@@ -1069,6 +1162,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   K.valid = reinterpret_cast<uint8_t *>(smem + at); at = (at + ns + 15) & ~(size_t)15;
   K.PEND0 = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
   K.R0 = reinterpret_cast<uint16_t *>(smem + at);
+  K.SD = reinterpret_cast<uint2 *>(K.stage);            // (the region is idle between the enumeration's list and the scans' parked vectors: refresh_private stages nothing)
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
   { const size_t sl = region_bytes<KS, VW>(ns) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
   K.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
@@ -1185,7 +1279,17 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     beat(P, tile, tid, 1, 2);
     MPF_TMARK(0);
     // ---- (2)
-    if (wave == 0) plan_and_discover<KS, VW>(K, sh);
+    if (wave == 0) {
+      plan_and_discover<KS, VW>(K, sh, PRIV && nmine > 1u);
+      if constexpr (PRIV) {
+        if (nmine > 1u && sh.use_static) {
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+          schedule_private<KS, VW>(K, sh);
+          if (lane == 0) sh.tph[15] += __builtin_amdgcn_s_memrealtime() - ts0;
+        }
+      }
+    }
     __syncthreads();
     beat(P, tile, tid, 4, sh.ncand); beat(P, tile, tid, 5, sh.nops); beat(P, tile, tid, 6, sh.rtail); beat(P, tile, tid, 1, 3);
     MPF_TMARK(2);
@@ -1195,10 +1299,55 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     // validity flags it raises) is put back in front of every further run, the candidates' counts keep adding up in K.cost, the
     // base lengths in sh.pn_base.
     const uint32_t ncand = sh.ncand;
-    const bool multi = nmine > 1u;
+    const bool multi = MODE != 0 && nmine > 1u;
     const uint32_t nops_step = sh.nops, rtail0 = sh.rtail, use_static = sh.use_static;
     uint32_t *snap = P.snap ? P.snap + (size_t)tile * ((size_t)ns + ns / 4u + 1u) : nullptr;
+    // several tiles, and the step's closure has its sequence (or is empty): the waves take tiles of their own through the refresh,
+    // then the scans of all tiles are dealt out together (no barrier between one tile and the next)
+    // (k_climb_many only: k_climb's sixteen-wave shapes have no registers to spare for it)
+    const bool priv = PRIV && multi && (use_static || nops_step == 0u);
     if ((uint32_t)tid < kMaxB) sh.pn_base[tid] = 0u;
+    const unsigned long long tsec0 = (multi && !priv && tid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if constexpr (PRIV) if (priv) {
+      __syncthreads();
+      for (uint32_t tk = (uint32_t)wave; tk < nmine; tk += kNW) {
+        set_tile(tile + tk * T);
+        refresh_private<KS, VW>(K, sh);
+        // this tile's share of the two sides of every prune branch (per-lane scores summed over the word groups)
+        for (uint32_t j0 = 0; j0 < sh.Beff; j0 += 8u) {
+          uint32_t bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            bv[j] = 0;
+            if (j0 + (uint32_t)j < sh.Beff) {
+              const uint32_t p = rfl(sh.pn_p[j0 + (uint32_t)j]), q = rfl((uint32_t)K.bk[p]);
+              bv[j] = ld_sl<KS, VW>(K, p) + ld_sl<KS, VW>(K, q);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            if (j0 + (uint32_t)j < sh.Beff) {
+              const uint32_t tot = wave_total(K.cnt_lane ? bv[j] : 0u);
+              if (lane == 0) __hip_atomic_fetch_add(&sh.pn_base[j0 + (uint32_t)j], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
+      MPF_TMARK(3);
+      for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
+      if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
+      const uint32_t ntasks = sh.ntasks, items = nmine * ntasks, per = (items + kNW - 1u) / kNW;
+      uint32_t cur = 0xFFFFFFFFu;
+      for (uint32_t it = (uint32_t)wave * per; it < items && it < ((uint32_t)wave + 1u) * per; it++) {
+        const uint32_t tk = it / ntasks, ti = it - tk * ntasks;
+        if (tk != cur) { set_tile(tile + tk * T); cur = tk; }
+        const uint32_t t = rfl((uint32_t)sh.tl[ti]);
+        scan_part<KS, VW>(K, sh, t >> 1, t & 1u);
+      }
+    }
+    if (!priv) {
     if (multi && nops_step) {
       if (use_static) {
         for (uint32_t i = (uint32_t)tid; i < nops_step; i += kThreads) K.PEND0[i] = K.PEND[i];
@@ -1281,6 +1430,8 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
         __syncthreads();                                   // (the next tile's refresh stages into the region the scans parked their up-vectors in)
         MPF_TMARK(4);
       }
+    }
+    if (multi && tid == 0) { sh.tph[13] += __builtin_amdgcn_s_memrealtime() - tsec0; sh.tph[14] += 100ull; }   // (steps whose closure took the plain path, tile after tile)
     }
     __syncthreads();
     beat(P, tile, tid, 1, 5);
@@ -1425,8 +1576,8 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   }
 }
 
-template <int KS, int VW>
-__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P) { climb_body<KS, VW>(P, blockIdx.x, gridDim.x); }
+template <int KS, int VW, bool GROUPS>
+__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P) { climb_body<KS, VW, GROUPS ? 1 : 0>(P, blockIdx.x, gridDim.x); }
 
 // MANY climbs in one launch, one resident workgroup each (ClimbParams::groups == 1 semantics: nothing crosses between workgroups,
 // so they need not be resident together -- a grid larger than the chip simply runs in turns).  The engines of such a batch share
@@ -1435,7 +1586,7 @@ template <int KS, int VW>
 __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb_many(const ClimbParams *__restrict__ PP)
 {
   const ClimbParams P = PP[blockIdx.x];
-  climb_body<KS, VW>(P, 0u, 1u);
+  climb_body<KS, VW, 2>(P, 0u, 1u);
 }
 
 template <int KS, int VW>
@@ -1444,20 +1595,26 @@ size_t lds_bytes(uint32_t ns)
   return lds_fixed_bytes(ns) + region_bytes<KS, VW>(ns);
 }
 
-template <int KS, int VW>
-hipError_t launch_t(hipStream_t st, const ClimbParams &p)
+template <int KS, int VW, bool GROUPS>
+hipError_t launch_g(hipStream_t st, const ClimbParams &p)
 {
   const size_t lds = lds_bytes<KS, VW>(p.nslots);
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (lds > 64 * 1024 || attr_dev != dev) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_climb<KS, VW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_climb<KS, VW, GROUPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_climb<KS, VW>), dim3(p.groups ? p.groups : p.tiles), dim3(Cfg<KS, VW>::NT), lds, st, p);
+  hipLaunchKernelGGL((k_climb<KS, VW, GROUPS>), dim3(p.groups ? p.groups : p.tiles), dim3(Cfg<KS, VW>::NT), lds, st, p);
   return hipGetLastError();
+}
+
+template <int KS, int VW>
+hipError_t launch_t(hipStream_t st, const ClimbParams &p)
+{
+  return p.groups && p.groups < p.tiles ? launch_g<KS, VW, true>(st, p) : launch_g<KS, VW, false>(st, p);
 }
 
 template <int KS, int VW>

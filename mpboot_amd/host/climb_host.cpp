@@ -57,11 +57,12 @@ struct GateHold {
 int Engine::climb_fit_vw(bool one_workgroup)
 {
   if (one_workgroup && g_.S == 4 && !climb_vw_set_) {
-    // a climb as ONE workgroup (k_climb_many) goes through its tiles one after the other: wide tiles mean fewer passes through the
-    // per-tile part of a step -- the widest whose padding stays within 8 % of the narrowest's (C2, 313 words: 5 x 64; C3, 1563: 13 x 128)
+    // a climb as ONE workgroup (k_climb_many): its waves take whole tiles through the refresh and share out the scans of all tiles.
+    // 64-word tiles first (eight waves; 128-word tiles leave room for four: measured at C3 97 against 81 climbs/s), then 128, 32, 16 --
+    // whichever keeps the padding within 8 % of the narrowest's (C2, 313 words: 5 x 64; C3, 1563: 25 x 64)
     size_t least = ~(size_t)0;
     for (int vw = 1; vw <= 8; vw *= 2) least = std::min(least, (size_t)climb_tiles(g_, vw) * 16 * (size_t)vw);
-    for (int vw = 8; vw >= 1; vw /= 2) {
+    for (int vw : {4, 8, 2, 1}) {
       if (climb_lds_bytes(g_, n_, vw) > 160 * 1024) continue;
       if ((size_t)climb_tiles(g_, vw) * 16 * (size_t)vw * 100 <= least * 108) return vw;
     }

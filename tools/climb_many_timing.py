@@ -42,4 +42,7 @@ for E in (int(x) for x in a.engines.split(",")):
         names = ["set-up", "enumerate", "closure", "refresh", "scan", "exchange", "decide"]
         for k in (0, E // 2, E - 1):
             us = [engs[k].get_option(f"climb_phase_us{j}") for j in range(7)]
-            print(f"  climb {k}: " + ", ".join(f"{nm} {u / 1e3:.1f} ms" for nm, u in zip(names, us)) + f"; sum {sum(us) / 1e3:.1f} ms", flush=True)
+            print(f"  climb {k}: " + ", ".join(f"{nm} {u / 1e3:.1f} ms" for nm, u in zip(names, us)) + f"; sum {sum(us) / 1e3:.1f} ms; "
+                  f"refresh ops {engs[k].get_option('climb_ctr0')}, chains {engs[k].get_option('climb_ctr3')}, steps {engs[k].stats()['climb_steps']}, "
+                  f"tests {engs[k].stats()['insertion_tests']}; plain-path steps {engs[k].get_option('climb_phase_use')} took "
+                  f"{engs[k].get_option('climb_phase_usd') / 1e3:.1f} ms, sequence passes {engs[k].get_option('climb_phase_usf') / 1e3:.1f} ms", flush=True)
