@@ -134,12 +134,12 @@ __device__ __forceinline__ void ld(const Kx<KS, VW> &K, QT<KS, VW> &t, uint32_t 
 template <int KS, int VW>
 __device__ __forceinline__ uint32_t ld_sl(const Kx<KS, VW> &K, uint32_t cid)
 {
-  return cid < K.n ? 0u : __builtin_amdgcn_raw_buffer_load_b32(K.rsrc_s, K.svoff, cid * 64u, 0);
+  return cid < K.n ? 0u : __builtin_amdgcn_raw_buffer_load_b32(K.rsrc_s, K.svoff, cid * (kWordMajor<KS> ? 256u : 64u), 0);
 }
 template <int KS, int VW>
 __device__ __forceinline__ void st_sl(const Kx<KS, VW> &K, uint32_t cid, uint32_t v)
 {
-  if (K.cnt_lane) __builtin_amdgcn_raw_buffer_store_b32(v, K.rsrc_s, K.svoff, cid * 64u, 0);
+  if (K.cnt_lane) __builtin_amdgcn_raw_buffer_store_b32(v, K.rsrc_s, K.svoff, cid * (kWordMajor<KS> ? 256u : 64u), 0);
 }
 
 // a vector the scans of this step read: listed once per step (the claim word's epoch de-duplicates).  Whether it is stale is
@@ -702,8 +702,67 @@ __device__ __forceinline__ void refresh_dynamic(const Kx<KS, VW> &K, Sh &sh)
 template <int KS, int VW>
 __device__ __forceinline__ void schedule_private(const Kx<KS, VW> &K, Sh &sh)
 {
+  const uint32_t n = K.n, nops = rfl(sh.nops), nstart = rfl(sh.rtail);
+  if (nops <= 64u) {
+    // the usual closure: an op per lane, its descriptor, consumers and counts in registers; the walk itself runs on the scalar unit
+    // (v_readlane / v_writelane with a scalar lane index) -- a twentieth of a microsecond per op where the LDS form below, one
+    // dependent round trip after the other, takes a third
+    const int lane = K.lane;
+    const bool act = (uint32_t)lane < nops;
+    const uint2 d = act ? K.D[lane] : make_uint2(0u, 0u);
+    const uint32_t ncl = act ? (K.NC[lane] < 2u ? K.NC[lane] : 2u) : 0u;
+    const uint32_t c0 = act ? K.CONS[2 * lane].x : 0u, c1 = act ? K.CONS[2 * lane + 1].x : 0u;
+    int pend = act ? (int)K.PEND[lane] : 0;
+    const uint32_t a = d.y & 0xFFFFu, b = d.y >> 16;
+    uint32_t ia = 0xFFu, ib = 0xFFu;                   // the op that makes a stale operand
+    if (act && a >= n && !K.valid[a]) ia = (K.cl[a] >> 3) & 0x3Fu;
+    if (act && b >= n && !K.valid[b]) ib = (K.cl[b] >> 3) & 0x3Fu;
+    const int meta = (int)(ncl | (ia << 8) | (ib << 16));
+    int stackv = (uint32_t)lane < nstart ? (int)K.R[nstart - 1u - (uint32_t)lane] : 0;
+    int posv = 0, outx = 0, outy = 0;
+    uint32_t sp = nstart, cnt = 0;
+    while (sp) {
+      sp--;
+      const uint32_t i = (uint32_t)__builtin_amdgcn_readlane(stackv, (int)sp);
+      const uint32_t dx = (uint32_t)__builtin_amdgcn_readlane((int)d.x, (int)i), dy = (uint32_t)__builtin_amdgcn_readlane((int)d.y, (int)i);
+      const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane(meta, (int)i);
+      uint32_t fl[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t iv = (mt >> (8 + 8 * u)) & 0xFFu;
+        uint32_t f = 1u;
+        if (iv != 0xFFu) {
+          const uint32_t at = (uint32_t)__builtin_amdgcn_readlane(posv, (int)iv);
+          f = at + 1u == cnt ? 0u : at < (cnt & ~3u) ? 1u : 2u;
+        }
+        fl[u] = f;
+      }
+      posv = wlane((int)cnt, (int)i, posv);
+      outx = wlane((int)((dx & 0xFFFFu) | (fl[0] << 16) | (fl[1] << 18)), (int)cnt, outx);
+      outy = wlane((int)dy, (int)cnt, outy);
+      cnt++;
+      if (cnt > nops) break;
+      const uint32_t nc = mt & 0xFFu;
+      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, (int)i), e1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, (int)i);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if ((uint32_t)u < nc) {
+          const uint32_t ex_ = u ? e1 : e0, j = ex_ & 0xFFu;
+          bool ready = ((ex_ >> 9) & 3u) == 1u;
+          if (!ready) {
+            const int left = __builtin_amdgcn_readlane(pend, (int)j) - 1;
+            pend = wlane(left, (int)j, pend);
+            ready = left == 0;
+          }
+          if (ready) { stackv = wlane((int)j, (int)sp, stackv); sp++; }
+        }
+      }
+    }
+    if (act) K.SD[lane] = make_uint2((uint32_t)outx, (uint32_t)outy);
+    if (cnt != nops && lane == 0) sh.err = sh.err ? sh.err : 6u;
+    return;
+  }
   if (K.lane != 0) return;
-  const uint32_t n = K.n, nops = sh.nops, nstart = sh.rtail;
   uint32_t sp = 0, cnt = 0;
   for (uint32_t k = 0; k < nstart; k++) K.R0[sp++] = K.R[nstart - 1u - k];
   while (sp) {
@@ -850,6 +909,14 @@ __device__ __forceinline__ void scan_part(const Kx<KS, VW> &K, Sh &sh, uint32_t 
           // counts leave as one LDS add per candidate from the 16 quad leaders (no reduction across lanes, nothing to wait for)
           const uint32_t j1 = (m & 1u) ? q_join<KS, VW>(u1, d1[i], sv) : 0u;      // (all lanes: the quad ORs need their neighbours)
           const uint32_t j2 = (m & 2u) ? q_join<KS, VW>(u2, d2[i], sv) : 0u;
+          if constexpr (kWordMajor<KS>) {
+            // (64 counting lanes: summed across the wave first -- 64 adds to one LDS word would queue up)
+            const uint32_t t1 = (m & 1u) ? wave_total(K.cnt_lane ? j1 : 0u) : 0u, t2 = (m & 2u) ? wave_total(K.cnt_lane ? j2 : 0u) : 0u;
+            if (lane == 0) {
+              if (m & 1u) __hip_atomic_fetch_add(cbase + ((y >> 8) & 0xFFu), t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (m & 2u) __hip_atomic_fetch_add(cbase + ((y >> 16) & 0xFFu), t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          } else
           if (K.cnt_lane) {
             if (m & 1u) __hip_atomic_fetch_add(cbase + ((y >> 8) & 0xFFu) + K.zero, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (m & 2u) __hip_atomic_fetch_add(cbase + ((y >> 16) & 0xFFu) + K.zero, j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1165,13 +1232,23 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   K.SD = reinterpret_cast<uint2 *>(K.stage);            // (the region is idle between the enumeration's list and the scans' parked vectors: refresh_private stages nothing)
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
   { const size_t sl = region_bytes<KS, VW>(ns) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
-  K.SW4 = (uint32_t)(4 * KS) * P.Wp * 4u;
-  K.svoff = ((uint32_t)lane >> 2) * 4u;
+  K.SW4 = (uint32_t)(kWordMajor<KS> ? 4 : 4 * KS) * P.Wp * 4u;
+  K.svoff = kWordMajor<KS> ? (uint32_t)lane * 4u : ((uint32_t)lane >> 2) * 4u;
   asm volatile("v_mov_b32 %0, 0" : "=v"(K.zero));
   K.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.vec, 0, 0x7FFFFFFF, 0x00020000);
   // what depends on the tile of sites at hand: its rows of per-lane subtree scores, the lanes' offsets into a vector, which lanes count
   auto set_tile = [&](uint32_t t) {
-    K.rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)(P.sct + (size_t)t * ns * 16), 0, (int)(ns * 64u), 0x00020000);
+    constexpr uint32_t kRow = kWordMajor<KS> ? 64u : 16u;      // score words per vector and tile
+    K.rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)(P.sct + (size_t)t * ns * kRow), 0, (int)(ns * kRow * 4u), 0x00020000);
+    if constexpr (kWordMajor<KS>) {
+      // a lane = VW words with their four states (rows of the store: state k at k * Wp)
+      uint32_t word0 = (t * 64u + (uint32_t)lane) * (uint32_t)VW;
+      K.st_lane = word0 < P.Wp;
+      if (!K.st_lane) word0 = P.Wp - (uint32_t)VW;
+      K.cnt_lane = K.st_lane;
+#pragma unroll
+      for (int k = 0; k < KS; k++) K.voff[k] = ((uint32_t)k * P.Wp + word0) * 4u;
+    } else {
     const uint32_t w = (uint32_t)lane >> 2, g = (uint32_t)lane & 3u;
     uint32_t word0 = (t * 16u + w) * (uint32_t)VW;
     K.st_lane = word0 < P.Wp;
@@ -1179,6 +1256,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     K.cnt_lane = K.st_lane && g == 0u;
 #pragma unroll
     for (int k = 0; k < KS; k++) K.voff[k] = ((g * (uint32_t)KS + (uint32_t)k) * P.Wp + word0) * 4u;
+    }
   };
   set_tile(tile);
   {
@@ -1339,8 +1417,12 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
       for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
       if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
       const uint32_t ntasks = sh.ntasks, items = nmine * ntasks, per = (items + kNW - 1u) / kNW;
+      const uint32_t it_lo = (uint32_t)wave * per, it_hi = ((uint32_t)wave + 1u) * per < items ? ((uint32_t)wave + 1u) * per : items;
+      // (the same items as one stream of blocks -- the next block's vectors requested while the one at hand is combined -- was
+      //  built and measured slower, 1 470 against 1 290 ms of a C3 climb: with two waves a SIMD the scans are bound by their
+      //  arithmetic, not by the round trips; HISTORY.md)
       uint32_t cur = 0xFFFFFFFFu;
-      for (uint32_t it = (uint32_t)wave * per; it < items && it < ((uint32_t)wave + 1u) * per; it++) {
+      for (uint32_t it = it_lo; it < it_hi; it++) {
         const uint32_t tk = it / ntasks, ti = it - tk * ntasks;
         if (tk != cur) { set_tile(tile + tk * T); cur = tk; }
         const uint32_t t = rfl((uint32_t)sh.tl[ti]);
@@ -1669,9 +1751,13 @@ hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbPa
   return launch_t<5, 1>(st, p);
 }
 
-hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots)
+hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots, bool word_major)
 {
   if (n_climbs <= 0) return hipSuccess;
+  if (g.S == 4 && word_major) {
+    if (vw != 4) return hipErrorInvalidValue;               // (64-word tiles: a word per lane)
+    return launch_many_t<4, 1>(st, d_params, n_climbs, max_nslots);
+  }
   if (g.S == 4) {
     if (vw == 1) return launch_many_t<1, 1>(st, d_params, n_climbs, max_nslots);
     if (vw == 2) return launch_many_t<1, 2>(st, d_params, n_climbs, max_nslots);

@@ -59,7 +59,7 @@ struct ClimbParams {
   uint32_t batch_min, batch_max;   // prune nodes per step (speculative; doubles after a step without a move)
   uint16_t *order;                 // [total] vector ids of nodep[1..total] (in; out with sweeps_inside)
   uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
-  uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch)
+  uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch; [64] per-word ones in the word-major shape)
   unsigned long long *gsum;        // [3][kClimbCap] exchange ring (zeroed by the host before the launch)
   // two-level exchange: every eighth workgroup forms a group that first sums into words of its own, the group's last arrival
   // forwards the total -- same-address atomics are served one after the other: 12-13 + 8 deep instead of 98
@@ -101,6 +101,8 @@ int climb_tiles(const Geometry &g, int vw);
 size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw);
 hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p);
 // n_climbs independent climbs, one workgroup each (k_climb_many): d_params[n_climbs] on the device, every entry with groups == 1
-hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots);
+// word_major (four-state data on 64-word tiles, vw == 4): a lane holds the four states of a word (quadtile.hpp, kWordMajor); sct then
+// has 64 score words per vector and tile instead of 16
+hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots, bool word_major);
 
 }  // namespace mpf

@@ -11,6 +11,14 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// old with lane `lane` (wave-uniform) replaced by val (wave-uniform): v_writelane_b32 (one scalar operand besides m0 on gfx9)
+__device__ __forceinline__ int wlane(int val, int lane, int old)
+{
+  int keep;                                              // (m0 is the compiler's: handed back as it was)
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(old), "=&s"(keep) : "s"(val), "s"(lane));
+  return old;
+}
+
 __device__ __forceinline__ uint32_t quad_or(uint32_t v)
 {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
@@ -88,6 +96,12 @@ __device__ __forceinline__ void ring2(uint32_t c, uint32_t n, uint32_t &o1, uint
 template <int KS, int VW>
 struct QT { uint32_t v[KS][VW]; };
 
+// KS == 4 is the WORD-MAJOR shape of four-state data (k_climb_many): a lane holds all four states of its VW words -- 64 * VW words
+// per wavefront --, so Fitch's rule needs no step across lanes at all: 10 vector instructions per 64 words where the quad shape
+// (KS == 1: the four lanes of a quad are the four states, 16 * VW words per wavefront) spends 24.  The quad shape exists for the
+// single climb, which wants MANY small tiles (a workgroup each); a climb that is one workgroup wants the cheaper arithmetic.
+template <int KS> constexpr bool kWordMajor = KS == 4;
+
 template <int KS, int VW>
 __device__ __forceinline__ void qload(QT<KS, VW> &t, __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&voff)[KS], uint32_t soff)
 {
@@ -139,7 +153,7 @@ __device__ __forceinline__ uint32_t q_fitch(QT<KS, VW> &c, const QT<KS, VW> &a, 
     uint32_t t = a.v[0][j] & b.v[0][j];
 #pragma unroll
     for (int k = 1; k < KS; k++) t = b3_andor(a.v[k][j], b.v[k][j], t);
-    const uint32_t any = quad_or(t);
+    const uint32_t any = kWordMajor<KS> ? t : quad_or(t);
 #pragma unroll
     for (int k = 0; k < KS; k++) c.v[k][j] = b3_fitch(a.v[k][j], b.v[k][j], any);
     cost += (uint32_t)__builtin_popcount(~any);
@@ -158,11 +172,11 @@ __device__ __forceinline__ uint32_t q_join(const QT<KS, VW> &u, const QT<KS, VW>
     uint32_t t = u.v[0][j] & d.v[0][j];
 #pragma unroll
     for (int k = 1; k < KS; k++) t = b3_andor(u.v[k][j], d.v[k][j], t);
-    const uint32_t any = quad_or(t);
+    const uint32_t any = kWordMajor<KS> ? t : quad_or(t);
     uint32_t hit = b3_fitch(u.v[0][j], d.v[0][j], any) & s.v[0][j];
 #pragma unroll
     for (int k = 1; k < KS; k++) hit = b3_andor(b3_fitch(u.v[k][j], d.v[k][j], any), s.v[k][j], hit);
-    hit = quad_or(hit);
+    if constexpr (!kWordMajor<KS>) hit = quad_or(hit);
     cost += (uint32_t)__builtin_popcount(~hit);
   }
   return cost;

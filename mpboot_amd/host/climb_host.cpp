@@ -105,7 +105,8 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   const size_t out_words = hdr_words + 3 * max_moves;
   HIPCHK(cd_.bk.reserve(ns));
   HIPCHK(cd_.order.reserve((size_t)total));
-  HIPCHK(cd_.sct.reserve((size_t)tiles * ns * 16));
+  // (k_climb_many's word-major shape keeps a score per word: 64 per vector and tile)
+  HIPCHK(cd_.sct.reserve((size_t)tiles * ns * (force_groups == 1 ? 64 : 16)));
   // exchange ring | per-XCD level-1 words | per-XCD workgroup counts
   const size_t gsum_words = 3 * (size_t)kClimbCap + 8 * 3 * (size_t)kClimbCap + 8;
   HIPCHK(cd_.gsum.reserve(gsum_words));
@@ -450,7 +451,7 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
   if (batch.empty()) return MPF_OK;
   const auto t_prep = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(mb.d_params.p, mb.h_params.p, batch.size() * sizeof(ClimbParams), hipMemcpyHostToDevice, e0.st_));
-  HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, mb.d_params.p, (int)batch.size(), max_ns));
+  HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, mb.d_params.p, (int)batch.size(), max_ns, e0.g_.S == 4 && vw0 == 4 && e0.many_word_major_));
   for (int k : batch) {
     Engine &e = *engs[k];
     const size_t out_words = hdr_words + 3 * (size_t)e.cd_.max_moves;
