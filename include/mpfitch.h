@@ -215,12 +215,13 @@ int mpf_get_node_order(mpf_engine *e, int32_t *recs /* [2n-2] */);
 int mpf_optimize_spr(mpf_engine *e, int32_t mintrav, int32_t maxtrav, uint32_t *score);
 /* pllOptimizeSprParsimony on n INDEPENDENT engines at once (the 100 start trees of a run, phyloanalysis.cpp:1270-1317; the bootstrap
    samples' refinement climbs, iqtree.cpp:2797-2862): each engine with its tree set, its weights, its tie rule and stream, as for
-   mpf_optimize_spr -- and each climb makes exactly the moves its own mpf_optimize_spr call would make.  Every sweep of every climb is
-   one resident workgroup of ONE launch per round (k_climb_many), fed by the calling thread; engines the batch cannot take (another
+   mpf_optimize_spr -- and each climb makes exactly the moves its own mpf_optimize_spr call would make.  Every climb is one resident
+   workgroup of ONE launch (k_climb_many: all its sweeps inside, nodeRectifierPars on the device), fed by the calling thread; a climb
+   with more moves than the launch's list holds goes on in a second launch.  Engines the batch cannot take (another
    alignment shape, a tracker attached, the weighted engine, a host random_double() call-back) run their climb alone inside the call.
    final_scores[n_engines]. */
 int mpf_optimize_spr_many(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint32_t *final_scores);
-/* ... one ROUND of it (one launch: a sweep, or a full move list, of every active climb), for callers with more climbs than engines:
+/* ... one LAUNCH of it (every active climb to its optimum, or to a full move list), for callers with more climbs than engines:
    state[k] in: 0 = engine k takes no part, 1 = a climb STARTS on it now, 2 = its climb goes on; out: 2 = goes on, 0 = done
    (final_scores[k] valid).  A finished engine gets its next tree (and weights, stream) and state 1 before the next round. */
 int mpf_optimize_spr_many_round(mpf_engine **engines, int32_t n_engines, int32_t mintrav, int32_t maxtrav, uint8_t *state, uint32_t *final_scores);

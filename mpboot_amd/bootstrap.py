@@ -86,7 +86,7 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     attached = True: the tracker of the online phase is still attached to engine 0 with exactly these samples and this sharding
     (no second upload of the weights); it is released before any per-sample climb runs on engine 0.
 
-    many_launch = True (eight or more engines): the samples' own climbs as workgroups of ONE launch per round, an engine per sample,
+    many_launch = True (eight or more engines): the samples' own climbs as workgroups of ONE launch, an engine per sample,
     a finished engine taking the next sample at once (mpf_optimize_spr_many_round).  Same results; NOT the default: these climbs start
     next to an optimum -- two or three sweeps with a handful of moves --, and a move-less sweep of a thousand taxa costs one resident
     workgroup 18 ms where the host path's whole-chip batch takes 0.3 ms (C4N, 951 climbs: 1.37 s against 0.80 s on six host threads).
@@ -147,7 +147,7 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
         many = len(engines) >= 8 and all(hasattr(e, "h") for e in engines) and many_launch
         if many and todo:
             # the samples' own climbs side by side: an engine per sample of a chunk (re-weighted, seeded, its tree set), then ONE call --
-            # every climb a resident workgroup of one launch per round (mpf_optimize_spr_many)
+            # every climb a resident workgroup of one launch (mpf_optimize_spr_many_round)
             from concurrent.futures import ThreadPoolExecutor
 
             from . import engine as _engine

@@ -217,7 +217,7 @@ def remain_bounds(segment_upper, min_unit_pars, weight) -> np.ndarray:
 
 def optimize_spr_many(engines, mintrav: int = 1, maxtrav: int = 6):
     """mpf_optimize_spr_many: one SPR hill climb per engine (tree, weights, tie stream set on each as for optimize_spr), all of them
-    side by side -- a resident workgroup per climb, one launch per round.  -> final lengths, one per engine."""
+    side by side -- a resident workgroup per climb, all of its sweeps inside ONE launch.  -> final lengths, one per engine."""
     n = len(engines)
     hs = (C.c_void_p * n)(*[e.h for e in engines])
     out = np.zeros(n, dtype=np.uint32)

@@ -15,7 +15,7 @@ cases = bad = 0
 while time.time() < t_end:
     alphabet = ["DNA", "DNA", "AA", "GEN"][int(rng.integers(0, 4))]
     n = int(rng.integers(5, 140))
-    P = int(rng.integers(40, 6000 if alphabet == "DNA" else 1500))
+    P = int(rng.integers(40, 20000 if alphabet == "DNA" else 1500))
     rate = float(rng.choice([0.03, 0.08, 0.2, 0.5]))
     if alphabet == "GEN":
         letters, _ = synth.synth_alignment(n, P, "AA", rate, seed=int(rng.integers(1 << 30)))
@@ -35,9 +35,17 @@ while time.time() < t_end:
     if w is not None:
         w[: min(P, 6)] = 1
 
-    def mk(groups):
+    auto_tile = bool(rng.random() < 0.6)          # mpf_optimize_spr_many picks the width (four-state data: the word-major shape)
+    inside = int(rng.random() < 0.8)
+    cap = int(rng.integers(3, 60)) if rng.random() < 0.3 else 0
+
+    def mk(groups, many=False):
         e = engine.FitchEngine(codes, datatype=dt)
-        e.set_option("climb_device", 2); e.set_option("climb_tile", tile); e.set_option("climb_groups", groups)
+        e.set_option("climb_device", 2); e.set_option("climb_groups", groups)
+        if not (many and auto_tile):
+            e.set_option("climb_tile", tile)
+        if many:
+            e.set_option("many_sweeps_inside", inside); e.set_option("many_moves_cap", cap)
         if w is not None:
             e.set_weights(w)
         return e
@@ -54,7 +62,7 @@ while time.time() < t_end:
         e.set_tree(starts[0]); e.reset_node_order(); e.seed_ties(tie, seeds[0])
         s = e.optimize_spr(1, radius)
         ok1 = (s, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.tie_state()) == solo[0]
-        engs = [mk(0) for _ in range(k)]
+        engs = [mk(0, True) for _ in range(k)]
         for j, x in enumerate(engs):
             x.set_tree(starts[j]); x.reset_node_order(); x.seed_ties(tie, seeds[j])
         sc = engine.optimize_spr_many(engs, 1, radius)
@@ -65,5 +73,5 @@ while time.time() < t_end:
     cases += 1
     if not (ok1 and ok2):
         bad += 1
-        print(f"MISMATCH: {alphabet} n {n} P {P} rate {rate} tie {tie} radius {radius} tile {tile} groups {g} k {k} weights {w is not None}: groups ok {ok1}, many ok {ok2}", flush=True)
+        print(f"MISMATCH: {alphabet} n {n} P {P} rate {rate} tie {tie} radius {radius} tile {tile} groups {g} k {k} weights {w is not None} many: auto tile {auto_tile} sweeps inside {inside} cap {cap}: groups ok {ok1}, many ok {ok2}", flush=True)
 print(f"groups_soak: {cases} random cases (seed {a.seed}), {bad} mismatches", flush=True)
