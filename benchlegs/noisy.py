@@ -52,6 +52,6 @@ def run(device, maxtrav, n_start, iters, n_engines, barrier, B=1000):
            "what": "the -bb flow of bb_reference_run (one chain) where the samples disagree: start trees + doTreeSearch iterations + "
                    "refinement.  refinement_s = refine_boot_trees: one masked sweep + one mask x weight product per DISTINCT topology the "
                    "samples kept, then one re-weighting + SPR climb per sample whose first sweep accepts a move (several engines per GPU on host "
-                   "threads; as workgroups of one launch per round -- mpf_optimize_spr_many_round -- the same 951 climbs take 1.37 s: they start "
+                   "threads; as workgroups of one launch -- mpf_optimize_spr_many_round, 128 engines -- the same climbs take 1.0 s: they start "
                    "next to an optimum, where the host path's whole-chip batches are the better tool)"}
     return leg

@@ -89,8 +89,8 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     many_launch = True (eight or more engines): the samples' own climbs as workgroups of ONE launch, an engine per sample,
     a finished engine taking the next sample at once (mpf_optimize_spr_many_round).  Same results; NOT the default: these climbs start
     next to an optimum -- two or three sweeps with a handful of moves --, and a move-less sweep of a thousand taxa costs one resident
-    workgroup 18 ms where the host path's whole-chip batch takes 0.3 ms (C4N, 951 climbs: 1.37 s against 0.80 s on six host threads).
-    The one-launch form is for DENSE climbs (random start trees: C2 1 200 climbs/s against 345).
+    workgroup milliseconds where the host path's whole-chip batch takes 0.3 ms (C4N, 955 climbs on 128 engines: 1.0 s against 0.78 s on six
+    host threads, tools/refine_many_probe.py).  The one-launch form is for DENSE climbs (random start trees: C2 2 700 climbs/s against 345).
 
     Returns (scores[B] after the all-reduce, {b: refined tree} of this rank)."""
     samples = np.asarray(samples)
@@ -206,7 +206,7 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     return scores, trees
 
 
-def bb_run(eng, samples, start_trees, iters, maxtrav=6, seed=1, engines=None, verbose=False, refine=True, search_kw=None):
+def bb_run(eng, samples, start_trees, iters, maxtrav=6, seed=1, engines=None, verbose=False, refine=True, search_kw=None, refine_kw=None):
     """`-bb` as the reference runs it: the start trees enter the candidate set (phyloanalysis.cpp:1300-1313; they are
     not booked -- the start-tree phase runs without per-site scores, sprparsimony.cpp:3228), then IQTree::doTreeSearch's iterations
     (mpboot_amd.search.MpSearch: a random one of the 5 best candidate trees perturbed by floor(0.5 (n - 3)) random NNIs, every second
@@ -259,7 +259,8 @@ def bb_run(eng, samples, start_trees, iters, maxtrav=6, seed=1, engines=None, ve
            "unsuccess_iterations": S.unsuccess, "last_improved_iteration": S.last_improved, "online_scores": (-logl).astype(np.int64)}
     if refine:
         t0 = time.perf_counter()
-        sc, _ = refine_boot_trees(engines or [eng], samples, bts, 11, maxtrav)
+        sc, _ = refine_boot_trees(engines or [eng], samples, bts, 11, maxtrav, **(refine_kw or {}))
+        out["refined_scores"] = np.asarray(sc)
         out["refine_s"] = time.perf_counter() - t0
         out["mean_refined"] = float(np.mean(sc))
         out["samples_improved_by_refinement"] = int((np.asarray(sc) < out["online_scores"]).sum())

@@ -71,6 +71,8 @@ while time.time() < t_end:
         ok1 = ok2 = False
         print("EXCEPTION", repr(exc))
     cases += 1
+    if cases % 10 == 0:
+        print(f"  ... {cases} cases, {bad} mismatches", flush=True)
     if not (ok1 and ok2):
         bad += 1
         print(f"MISMATCH: {alphabet} n {n} P {P} rate {rate} tie {tie} radius {radius} tile {tile} groups {g} k {k} weights {w is not None} many: auto tile {auto_tile} sweeps inside {inside} cap {cap}: groups ok {ok1}, many ok {ok2}", flush=True)
