@@ -573,8 +573,8 @@ def main():
     ap.add_argument("--bb-iterations", type=int, default=200,
                     help="bb_reference_run leg, ONE chain: doTreeSearch iterations timed (random NNIs / ratchet alternating, tracked climbs "
                          "under the cut-off); the stop rule's horizon is extrapolated from them (0 = skip)")
-    ap.add_argument("--bb-workers", type=int, default=8, help="bb_reference_run leg, iteration-parallel form: chains (engines on host threads) per GPU")
-    ap.add_argument("--bb-rounds", type=int, default=6, help="... rounds timed (a round = --bb-sync iterations on every chain, then one exchange; 0 = skip)")
+    ap.add_argument("--bb-workers", type=int, default=16, help="bb_reference_run leg, iteration-parallel form: chains (engines on host threads) per GPU")
+    ap.add_argument("--bb-rounds", type=int, default=4, help="... rounds timed (a round = --bb-sync iterations on every chain, then one exchange; 0 = skip)")
     ap.add_argument("--bb-sync", type=int, default=8, help="... iterations between two exchanges")
     ap.add_argument("--many-c2", type=int, default=512, help="climbs_in_one_launch leg: C2 climbs per call")
     ap.add_argument("--many-c3", type=int, default=256, help="climbs_in_one_launch leg: C3 climbs per call (an engine each: 0.25 GB; 0 = skip)")

@@ -61,6 +61,10 @@ def run(pool, samples, starts, maxtrav, rank, world, barrier, iters_seq, workers
     par = None
     if workers > 0 and rounds_par > 0:
         W = min(workers, len(pool))
+        # (chains side by side: 64-word tiles -- 25 workgroups per climb instead of 98, 2.7 x less CU-time held per climb; measured on one
+        #  box: 8 / 16 / 24 chains 87 / 85 / 90 iterations/s on 16-word tiles, 92 / 108 / 113 on these.  Same trajectories on any width)
+        for x in pool[:W]:
+            x.set_option("climb_tile", 4)
         run_ = parsearch.ParallelBbRun(pool[:W], samples, starts, maxtrav=maxtrav, seed=1, sync_every=sync_every)
         run_.round(2)                                                                             # allocations
         barrier()
@@ -80,6 +84,8 @@ def run(pool, samples, starts, maxtrav, rank, world, barrier, iters_seq, workers
         lens, bts, n_distinct = run_.books()
         par["distinct_boot_trees"] = int(n_distinct)
         run_.detach()
+        for x in pool[:W]:
+            x.set_option("climb_tile", 1)
         # refinement of every sample's tree (sharded by sample over the ranks)
         barrier()
         t0 = time.perf_counter()
