@@ -1739,8 +1739,10 @@ bool climb_supported(const Geometry &g, int n_taxa, int maxtrav)
   return climb_lds_bytes(g, n_taxa, 1) <= kLdsBudget;
 }
 
-hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p)
+hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p, bool word_major)
 {
+  // (the word-major shape: 64-word tiles, a workgroup per tile)
+  if (g.S == 4 && word_major && vw == 4 && !(p.groups && p.groups < p.tiles)) return launch_g<4, 1, false>(st, p);
   if (g.S == 4) {
     if (vw == 1) return launch_t<1, 1>(st, p);
     if (vw == 2) return launch_t<1, 2>(st, p);

@@ -99,7 +99,7 @@ constexpr uint32_t kClimbCap = 1024;      // candidates per step
 bool climb_supported(const Geometry &g, int n_taxa, int maxtrav);
 int climb_tiles(const Geometry &g, int vw);
 size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw);
-hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p);
+hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p, bool word_major = false);
 // n_climbs independent climbs, one workgroup each (k_climb_many): d_params[n_climbs] on the device, every entry with groups == 1
 // word_major (four-state data on 64-word tiles, vw == 4): a lane holds the four states of a word (quadtile.hpp, kWordMajor); sct then
 // has 64 score words per vector and tile instead of 16

@@ -2144,6 +2144,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max_sparse") { climb_batch_max_sparse_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
+  if (key == "climb_word_major") { climb_word_major_ = v != 0; return MPF_OK; }
   if (key == "many_word_major") { many_word_major_ = v != 0; return MPF_OK; }
   if (key == "many_moves_cap") { many_moves_cap_ = v < 0 ? 0 : (int)std::min<long long>(v, 1 << 20); return MPF_OK; }
   if (key == "many_sweeps_inside") { many_sweeps_inside_ = v != 0; return MPF_OK; }
@@ -2236,6 +2237,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "climb_trace") *v = climb_trace_;
   else if (key == "climb_groups") *v = climb_groups_;
   else if (key == "many_moves_cap") *v = many_moves_cap_;
+  else if (key == "climb_word_major") *v = climb_word_major_ ? 1 : 0;
   else if (key == "many_word_major") *v = many_word_major_ ? 1 : 0;
   else if (key == "climb_tile_many") *v = const_cast<Engine *>(this)->climb_fit_vw(true);      // the width mpf_optimize_spr_many runs this engine's climbs on
   else if (key == "many_sweeps_inside") *v = many_sweeps_inside_ ? 1 : 0;

@@ -481,6 +481,7 @@ class Engine {
   int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)
   int climb_batch_max_sparse_ = 16;              // option climb_batch_max_sparse: prune nodes per step of the quiet stretch of a tracked climb
   int climb_batch_min_ = 2, climb_batch_max_ = 8, climb_idle_ = 96, climb_trace_ = 0;
+  bool climb_word_major_ = true;                 // option "climb_word_major": k_climb on 64-word tiles (climb_tile 4) runs four-state data in the word-major shape too (5 % faster; 0 = quads)
   bool many_word_major_ = true;                  // option "many_word_major": k_climb_many on 64-word tiles runs four-state data a word per lane (quadtile.hpp)
   int many_moves_cap_ = 0;                       // option "many_moves_cap" (tests): moves per launch of such a climb (0 = four sweeps' worth)
   bool many_sweeps_inside_ = true;               // option "many_sweeps_inside": a climb of mpf_optimize_spr_many runs all its sweeps in one launch (ClimbParams::sweeps_inside)

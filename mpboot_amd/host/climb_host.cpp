@@ -106,7 +106,7 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   HIPCHK(cd_.bk.reserve(ns));
   HIPCHK(cd_.order.reserve((size_t)total));
   // (k_climb_many's word-major shape keeps a score per word: 64 per vector and tile)
-  HIPCHK(cd_.sct.reserve((size_t)tiles * ns * (force_groups == 1 ? 64 : 16)));
+  HIPCHK(cd_.sct.reserve((size_t)tiles * ns * ((force_groups == 1 || climb_word_major_) ? 64 : 16)));
   // exchange ring | per-XCD level-1 words | per-XCD workgroup counts
   const size_t gsum_words = 3 * (size_t)kClimbCap + 8 * 3 * (size_t)kClimbCap + 8;
   HIPCHK(cd_.gsum.reserve(gsum_words));
@@ -225,7 +225,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
     hold.g = &g;
     hold.n = need;
   }
-  HIPCHK(launch_climb(st_, g_, vw, p));
+  HIPCHK(launch_climb(st_, g_, vw, p, climb_word_major_));
   HIPCHK(hipMemcpyAsync(cd_.h_out.p, cd_.out.p, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
   {
     // a sweep segment takes milliseconds; a launch that is still running after many seconds will not come back (every wait

@@ -32,6 +32,10 @@ def test_fewer_workgroups_than_tiles_take_the_same_path(n, P, alphabet, tile):
         assert e.stats()["climb_launches"] >= 1
         ref = ref or sig
         assert sig == ref, groups
+    if tile == 4 and alphabet == "DNA":
+        # 64-word tiles run four-state data a word per lane (quadtile.hpp, kWordMajor) unless told otherwise: the quad shape of the same tiles
+        e, sig = _solo(codes, dt, back, 9, engine.TIE_RANDOM, {"climb_device": 2, "climb_tile": 4, "climb_word_major": 0})
+        assert sig == ref
 
 
 @pytest.mark.parametrize("n,P,alphabet,n_eng,tie", [(40, 1500, "DNA", 7, "random"), (120, 3000, "DNA", 12, "random"), (60, 900, "AA", 5, "random"),
