@@ -439,6 +439,33 @@ def test_c3_device_climb_equals_host_batches(c3_climb, tile):
         assert e.tie_state() == rng
 
 
+@pytest.mark.parametrize("word_major", [1, 0])
+def test_c3_climbs_in_one_launch_equal_the_pinned_climb(c3_climb, word_major):
+    """bench.py's climbs_in_one_launch leg at ITS size: mpf_optimize_spr_many on C3 engines (k_climb_many: one workgroup per climb, 25
+    tiles of 64 words taken through the refresh by its eight waves, every sweep inside the launch, 110 KB of control state in LDS) --
+    the climb from the benchmarked start tree makes exactly the moves of the list the oracle is held to above, in both tile shapes;
+    the climbs beside it end where their solo runs end."""
+    from mpboot_amd import engine, trees
+    codes, dt, back, s, moves, final, rng = c3_climb
+    n = codes.shape[0]
+    backs = [back] + [trees.random_topology(n, np.random.default_rng(4000 + k)) for k in range(1, 4)]
+    engs = []
+    for k, b in enumerate(backs):
+        e = engine.FitchEngine(codes, datatype=dt)
+        e.set_option("many_word_major", word_major)
+        e.set_tree(b); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 1 + k)
+        engs.append(e)
+    sc = engine.optimize_spr_many(engs, 1, 6)
+    e = engs[0]
+    assert e.stats()["climb_launches"] >= 1 and e.get_option("climb_tile_many") == 4
+    assert int(sc[0]) == s and [x.tolist() for x in e.moves()] == moves
+    assert e.get_tree().tolist() == final and e.tie_state() == rng
+    if word_major:
+        for k in (1, 2):
+            es, ss, ms = _climb(codes, dt, backs[k], 2, 1, seed=1 + k)
+            assert int(sc[k]) == ss and [x.tolist() for x in engs[k].moves()] == ms and (engs[k].get_tree() == es.get_tree()).all()
+
+
 def test_c3_eight_concurrent_device_climbs_equal_their_solo_runs(c3_climb):
     """bench.py's concurrent_climbs leg: eight engines on eight host threads, 64-word tiles (25 workgroups per climb, the launches
     admitted together and polling each other's exchange rings on one chip) -- every engine's moves are those of its solo run."""
