@@ -479,9 +479,16 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
     ManyState &s = e.many_;
     const int total = 2 * e.n_ - 2;
     uint32_t reason = 0, nm = 0;
-    const int rc = e.climb_harvest(total, s.tiles, t0, &s.i, &s.randomMP, &s.iter_hits, &reason, &nm);
-    if (rc) return rc;
-    if (reason == CLIMB_ABORT) { set_error("mpf_optimize_spr_many: a single-workgroup climb reported an abort"); return MPF_E_STATE; }
+    int rc = e.climb_harvest(total, s.tiles, t0, &s.i, &s.randomMP, &s.iter_hits, &reason, &nm);
+    if (!rc && reason == CLIMB_ABORT) { set_error("mpf_optimize_spr_many: a single-workgroup climb reported an abort"); rc = MPF_E_STATE; }
+    if (rc) {
+      // the call fails as a whole.  The launch has rewritten vectors of EVERY engine of the batch; those not taken over yet keep the
+      // tree and the stream they had before it -- and must not trust a vector (their state says "goes on": the caller starts over)
+      const std::string msg = last_error();
+      for (int k2 : batch) if (engs[k2] != &e) engs[k2]->invalidate_all();
+      set_error(msg);
+      return rc;
+    }
     if (s.i > total) {                              // the sweep is through (:3316)
       s.in_sweep = false;
       if (!(s.randomMP < s.startMP)) {

@@ -136,3 +136,33 @@ def test_engines_the_batch_cannot_take_run_alone_inside_the_call():
     assert len(c.ufboot_tree_logl()) > 0 and int(got[2]) == c.score_tree()
     with pytest.raises(engine.MpfError):
         engine.optimize_spr_many([a, a], 1, 6)
+
+
+def test_a_failed_launch_leaves_every_engine_of_the_batch_usable():
+    """One climb of a batch comes back as an abort (option climb_fault on its engine): the call fails as a whole.  The launch has
+    rewritten vectors of every engine; each of them is consistent afterwards -- the climbs taken over before the failure was seen are
+    done, the others hold the tree they came with -- and scores and climbs from where it stands like a fresh engine on that tree."""
+    from mpboot_amd import engine, synth, trees
+    letters, _ = synth.synth_alignment(60, 5000, "DNA", 0.08, seed=77)
+    codes = synth.letters_to_codes(letters, "DNA")
+    rng = np.random.default_rng(2)
+    starts = [trees.random_topology(60, rng) for _ in range(4)]
+    engs = []
+    for k, t in enumerate(starts):
+        e = engine.FitchEngine(codes)
+        e.set_tree(t); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 20 + k)
+        engs.append(e)
+    engs[2].set_option("climb_fault", 0xFFFFFFFF)
+    with pytest.raises(engine.MpfError):
+        engine.optimize_spr_many(engs, 1, 6)
+    assert (engs[2].get_tree() == starts[2]).all() and (engs[3].get_tree() == starts[3]).all()
+    for k, e in enumerate(engs):
+        t = e.get_tree()
+        f = engine.FitchEngine(codes)
+        f.set_tree(t)
+        assert e.score_tree() == f.score_tree(), k
+        f.reset_node_order(); f.seed_ties(engine.TIE_RANDOM, 50 + k)
+        e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 50 + k)
+        assert e.optimize_spr(1, 6) == f.optimize_spr(1, 6) and (e.get_tree() == f.get_tree()).all() and e.tie_state() == f.tie_state(), k
+    again = engine.optimize_spr_many(engs, 1, 6)          # (and together: all at their optima now)
+    assert [int(x) for x in again] == [e.score_tree() for e in engs]
