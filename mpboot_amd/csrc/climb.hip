@@ -59,10 +59,15 @@ template <int KS, int VW> struct Cfg {
   // operand slots of the refresh (vector + per-lane subtree scores) and the parked up-vectors of the scan are never alive
   // together: one LDS region serves both
   static constexpr size_t kSlotBytes = (size_t)(R + 1) * 64 * 4;
-  static constexpr size_t kPendBytes = (size_t)NW * 5 * R * 64 * 4;
+  // k_climb_many on the word-major shape: TWELVE waves (three a SIMD, 168 registers each) -- a climb that is one workgroup is alone
+  // on its CU, and what it waits for most is its own LDS, scalar and L2 round trips: more waves in flight is what helps
+  static constexpr int NW_MANY = KS == 4 ? 12 : NW;
+  static constexpr int NT_MANY = NW_MANY * 64;
+  // the scans' parked up-vectors: [wave][depth 1..5][R][64]
+  __host__ __device__ static constexpr size_t pend_bytes(int nw) { return (size_t)nw * 5 * R * 64 * 4; }
   // (64 KB where the control state leaves them, down to 40 KB -- or the parked vectors' size -- at a thousand taxa: region_bytes)
-  static constexpr size_t kRegionMax = kPendBytes > 65536 ? kPendBytes : 65536;
-  static constexpr size_t kRegionMin = kPendBytes > 40960 ? kPendBytes : 40960;
+  __host__ __device__ static constexpr size_t region_max(int nw) { return pend_bytes(nw) > 65536 ? pend_bytes(nw) : 65536; }
+  __host__ __device__ static constexpr size_t region_min(int nw) { return pend_bytes(nw) > 40960 ? pend_bytes(nw) : 40960; }
 };
 constexpr size_t kLdsBudget = 152 * 1024;      // of the CU's 160 KB
 
@@ -451,13 +456,13 @@ __device__ __forceinline__ void plan_and_discover(const Kx<KS, VW> &K, Sh &sh, c
 // and its other operand are requested while the current link is combined.  Where two stale inputs meet, whoever arrives
 // second goes on (the first one's result is read back from memory: joins are one op in ten).
 template <int KS, int VW>
-__device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool prof)
+__device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool prof, const uint32_t nw)
 {
   constexpr int R = Cfg<KS, VW>::R;
   const uint32_t nops = sh.nops;
   const int lane = K.lane;
   // -- stage
-  for (uint32_t base = (uint32_t)K.wave * 4u; base < nops; base += (uint32_t)Cfg<KS, VW>::NW * 4u) {
+  for (uint32_t base = (uint32_t)K.wave * 4u; base < nops; base += nw * 4u) {
     QT<KS, VW> ta[4], tb[4];
     uint32_t la[4], lb[4], da[4], db[4];
 #pragma unroll
@@ -511,7 +516,7 @@ __device__ __forceinline__ void refresh_static(const Kx<KS, VW> &K, Sh &sh, bool
   };
   QT<KS, VW> c, ta, tb;
   uint32_t la = 0, lb = 0, lc = 0;
-  for (uint32_t si = (uint32_t)K.wave;; si += Cfg<KS, VW>::NW) {       // chain starts are dealt round-robin (late ones -- rare -- land behind the list)
+  for (uint32_t si = (uint32_t)K.wave;; si += nw) {       // chain starts are dealt round-robin (late ones -- rare -- land behind the list)
     uint32_t st = kNone16, spins = 0;
     for (;;) {
       st = *(volatile uint16_t *)&K.R[si];                // (entries beyond the starts written so far read "none")
@@ -838,10 +843,10 @@ __device__ __forceinline__ void refresh_private(const Kx<KS, VW> &K, Sh &sh)
 }
 
 template <int KS, int VW>
-__device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh, bool prof)
+__device__ __forceinline__ void refresh(const Kx<KS, VW> &K, Sh &sh, bool prof, const uint32_t nw)
 {
   if (sh.nops == 0) return;
-  if (sh.use_static) refresh_static<KS, VW>(K, sh, prof);
+  if (sh.use_static) refresh_static<KS, VW>(K, sh, prof, nw);
   else refresh_dynamic<KS, VW>(K, sh);
 }
 
@@ -1156,11 +1161,14 @@ __device__ __forceinline__ void invalidate_walk(const Kx<KS, VW> &K, Sh &sh)
 }
 
 // everything in a workgroup's LDS but the stage / pend region (the kernel carves in this order)
-__host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns)
+// (maxb = ClimbParams::batch_max: a step has at most 4 * maxb scan programs -- their entries and candidate lists are the largest
+//  arrays here, 48 KB at sixteen prune nodes per step, 24 KB at the plain climb's eight)
+__host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns, uint32_t maxb)
 {
+  const size_t parts = 4 * (size_t)(maxb < 1u ? 1u : maxb > (uint32_t)kMaxB ? (uint32_t)kMaxB : maxb);
   size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
   at += (((size_t)ns * 4) + 15) & ~(size_t)15;
-  at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
+  at += parts * kProgStride * sizeof(uint2);
   at += (size_t)kLcap * sizeof(uint2);
   at += (size_t)kLcap * 2 * sizeof(uint2);
   at += (size_t)kLcap * 4;
@@ -1169,7 +1177,7 @@ __host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns)
   at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   at += (((size_t)(ns + 16) * 2) + 15) & ~(size_t)15;
-  at += (size_t)kMaxParts * 128 * 2;
+  at += parts * 128 * 2;
   at += (size_t)kLcap * 2;
   at += (((size_t)(ns / 2 + 1) * 2) + 15) & ~(size_t)15;      // the visiting order: 2n - 2 entries
   at += ns;
@@ -1181,12 +1189,12 @@ __host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns)
 // the stage / pend region of a launch: what the budget leaves, between the configuration's bounds (host and kernel agree by
 // computing it from the same number of vector slots)
 template <int KS, int VW>
-__host__ __device__ inline size_t region_bytes(uint32_t ns)
+__host__ __device__ inline size_t region_bytes(uint32_t ns, uint32_t maxb, int nw)
 {
-  const size_t fixed = lds_fixed_bytes(ns);
+  const size_t fixed = lds_fixed_bytes(ns, maxb);
   size_t r = kLdsBudget > fixed ? (kLdsBudget - fixed) & ~(size_t)15 : 0;
-  r = r > Cfg<KS, VW>::kRegionMax ? Cfg<KS, VW>::kRegionMax : r;
-  r = r < Cfg<KS, VW>::kRegionMin ? Cfg<KS, VW>::kRegionMin : r;
+  r = r > Cfg<KS, VW>::region_max(nw) ? Cfg<KS, VW>::region_max(nw) : r;
+  r = r < Cfg<KS, VW>::region_min(nw) ? Cfg<KS, VW>::region_min(nw) : r;
   return r;
 }
 
@@ -1198,7 +1206,7 @@ __host__ __device__ inline size_t region_bytes(uint32_t ns)
 template <int KS, int VW, int MODE>
 __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t tile, const uint32_t T)
 {
-  constexpr uint32_t kThreads = Cfg<KS, VW>::NT, kNW = Cfg<KS, VW>::NW;
+  constexpr uint32_t kNW = MODE == 2 ? Cfg<KS, VW>::NW_MANY : Cfg<KS, VW>::NW, kThreads = kNW * 64u;
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = (int)rfl((uint32_t)(tid >> 6));
@@ -1211,10 +1219,11 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   size_t at = (sizeof(Sh) + 15) & ~(size_t)15;
   Kx<KS, VW> K;
   K.cl = reinterpret_cast<uint32_t *>(smem + at); at += (((size_t)ns * 4) + 15) & ~(size_t)15;
-  K.prog = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kMaxParts * kProgStride * sizeof(uint2);
+  const uint32_t maxb = P.batch_max < 1u ? 1u : P.batch_max > (uint32_t)kMaxB ? (uint32_t)kMaxB : P.batch_max;
+  K.prog = reinterpret_cast<uint2 *>(smem + at); at += (size_t)(4u * maxb) * kProgStride * sizeof(uint2);
   K.stage = reinterpret_cast<uint32_t *>(smem + at);
   K.pend = reinterpret_cast<uint32_t *>(smem + at);
-  K.Q = reinterpret_cast<uint16_t *>(smem + at); at += region_bytes<KS, VW>(ns);       // (ns entries of 2 bytes: fits the region for every ns the other arrays allow)
+  K.Q = reinterpret_cast<uint16_t *>(smem + at); at += region_bytes<KS, VW>(ns, maxb, (int)kNW);       // (ns entries of 2 bytes: fits the region for every ns the other arrays allow)
   K.D = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * sizeof(uint2);
   K.CONS = reinterpret_cast<uint2 *>(smem + at); at += (size_t)kLcap * 2 * sizeof(uint2);
   K.NC = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
@@ -1223,7 +1232,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   K.bk = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   K.W = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)ns * 2) + 15) & ~(size_t)15;
   K.R = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)(ns + 16) * 2) + 15) & ~(size_t)15;
-  K.cq = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kMaxParts * 128 * 2;
+  K.cq = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)(4u * maxb) * 128 * 2;
   K.OL = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kLcap * 2;
   K.ord = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)P.total * 2) + 15) & ~(size_t)15;
   K.valid = reinterpret_cast<uint8_t *>(smem + at); at = (at + ns + 15) & ~(size_t)15;
@@ -1231,7 +1240,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   K.R0 = reinterpret_cast<uint16_t *>(smem + at);
   K.SD = reinterpret_cast<uint2 *>(K.stage);            // (the region is idle between the enumeration's list and the scans' parked vectors: refresh_private stages nothing)
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
-  { const size_t sl = region_bytes<KS, VW>(ns) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
+  { const size_t sl = region_bytes<KS, VW>(ns, maxb, (int)kNW) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
   K.SW4 = (uint32_t)(kWordMajor<KS> ? 4 : 4 * KS) * P.Wp * 4u;
   K.svoff = kWordMajor<KS> ? (uint32_t)lane * 4u : ((uint32_t)lane >> 2) * 4u;
   asm volatile("v_mov_b32 %0, 0" : "=v"(K.zero));
@@ -1294,7 +1303,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     sh.last_ncand[0] = sh.last_ncand[1] = sh.last_ncand[2] = 0;
     sh.best = h.best; sh.randomMP = h.randomMP; sh.iter_hits = h.iter_hits; sh.ins = h.insert_cid; sh.rem = h.remove_cid;
     sh.rng = h.rng; sh.hits = h.hits; sh.n_tests = 0; sh.n_ops = 0; sh.draws = 0; sh.n_nodes = 0;
-    if (sh.B > (uint32_t)kMaxB) sh.B = kMaxB;
+    if (sh.B > maxb) sh.B = maxb;
     if (sh.pos <= P.total && sh.B > P.total - sh.pos + 1u) sh.B = P.total - sh.pos + 1u;
     sh.wtail = 0; sh.rhead = 0; sh.ndone = 0; sh.nops = 0; sh.task = 0; sh.qtail = 0; sh.moved = 0; sh.einv = 0;
     for (int i = 0; i < 16; i++) sh.tph[i] = 0;
@@ -1468,7 +1477,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
           __syncthreads();
         }
       }
-      refresh<KS, VW>(K, sh, tile == 0 && wave == 0);
+      refresh<KS, VW>(K, sh, tile == 0 && wave == 0, kNW);
       __syncthreads();
       MPF_TMARK(3);
       if (tk + 1u == nmine) {
@@ -1665,22 +1674,22 @@ __global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb(ClimbParams P) { cl
 // so they need not be resident together -- a grid larger than the chip simply runs in turns).  The engines of such a batch share
 // the alignment's shape (state rows, tile width); every one has its own vector store, topology, tie stream and result block.
 template <int KS, int VW>
-__global__ __launch_bounds__((Cfg<KS, VW>::NT)) void k_climb_many(const ClimbParams *__restrict__ PP)
+__global__ __launch_bounds__((Cfg<KS, VW>::NT_MANY)) void k_climb_many(const ClimbParams *__restrict__ PP)
 {
   const ClimbParams P = PP[blockIdx.x];
   climb_body<KS, VW, 2>(P, 0u, 1u);
 }
 
 template <int KS, int VW>
-size_t lds_bytes(uint32_t ns)
+size_t lds_bytes(uint32_t ns, uint32_t maxb, bool many)
 {
-  return lds_fixed_bytes(ns) + region_bytes<KS, VW>(ns);
+  return lds_fixed_bytes(ns, maxb) + region_bytes<KS, VW>(ns, maxb, many ? Cfg<KS, VW>::NW_MANY : Cfg<KS, VW>::NW);
 }
 
 template <int KS, int VW, bool GROUPS>
 hipError_t launch_g(hipStream_t st, const ClimbParams &p)
 {
-  const size_t lds = lds_bytes<KS, VW>(p.nslots);
+  const size_t lds = lds_bytes<KS, VW>(p.nslots, p.batch_max, false);
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1700,9 +1709,8 @@ hipError_t launch_t(hipStream_t st, const ClimbParams &p)
 }
 
 template <int KS, int VW>
-hipError_t launch_many_t(hipStream_t st, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots)
+hipError_t launch_many_t(hipStream_t st, const ClimbParams *d_params, int n_climbs, size_t lds)
 {
-  const size_t lds = lds_bytes<KS, VW>(max_nslots);
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1711,7 +1719,7 @@ hipError_t launch_many_t(hipStream_t st, const ClimbParams *d_params, int n_clim
     if (e != hipSuccess) return e;
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_climb_many<KS, VW>), dim3((unsigned)n_climbs), dim3(Cfg<KS, VW>::NT), lds, st, d_params);
+  hipLaunchKernelGGL((k_climb_many<KS, VW>), dim3((unsigned)n_climbs), dim3(Cfg<KS, VW>::NT_MANY), lds, st, d_params);
   return hipGetLastError();
 }
 
@@ -1721,12 +1729,13 @@ static inline uint32_t slots_of(int n) { return (uint32_t)n + 3u * (uint32_t)(n 
 
 int climb_tiles(const Geometry &g, int vw) { return (g.Wp + 16 * vw - 1) / (16 * vw); }
 
-size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw)
+size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw, int batch_max, bool many, bool word_major)
 {
-  const uint32_t ns = slots_of(n_taxa);
-  if (g.S == 4) return vw == 1 ? lds_bytes<1, 1>(ns) : vw == 2 ? lds_bytes<1, 2>(ns) : vw == 4 ? lds_bytes<1, 4>(ns) : lds_bytes<1, 8>(ns);
-  if (g.S == 32) return lds_bytes<8, 1>(ns);
-  return lds_bytes<5, 1>(ns);
+  const uint32_t ns = slots_of(n_taxa), mb = (uint32_t)batch_max;
+  if (g.S == 4 && word_major && vw == 4) return lds_bytes<4, 1>(ns, mb, many);
+  if (g.S == 4) return vw == 1 ? lds_bytes<1, 1>(ns, mb, many) : vw == 2 ? lds_bytes<1, 2>(ns, mb, many) : vw == 4 ? lds_bytes<1, 4>(ns, mb, many) : lds_bytes<1, 8>(ns, mb, many);
+  if (g.S == 32) return lds_bytes<8, 1>(ns, mb, many);
+  return lds_bytes<5, 1>(ns, mb, many);
 }
 
 bool climb_supported(const Geometry &g, int n_taxa, int maxtrav)
@@ -1736,7 +1745,7 @@ bool climb_supported(const Geometry &g, int n_taxa, int maxtrav)
   if (maxtrav < 1 || maxtrav > kDepth) return false;
   if (slots_of(n_taxa) + 16u >= 0xFFFFu) return false;
   if (climb_tiles(g, 1) >= (1 << 20)) return false;
-  return climb_lds_bytes(g, n_taxa, 1) <= kLdsBudget;
+  return climb_lds_bytes(g, n_taxa, 1, kMaxB, false, false) <= kLdsBudget;
 }
 
 hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p, bool word_major)
@@ -1753,21 +1762,21 @@ hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbPa
   return launch_t<5, 1>(st, p);
 }
 
-hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots, bool word_major)
+hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, size_t lds, bool word_major)
 {
   if (n_climbs <= 0) return hipSuccess;
   if (g.S == 4 && word_major) {
     if (vw != 4) return hipErrorInvalidValue;               // (64-word tiles: a word per lane)
-    return launch_many_t<4, 1>(st, d_params, n_climbs, max_nslots);
+    return launch_many_t<4, 1>(st, d_params, n_climbs, lds);
   }
   if (g.S == 4) {
-    if (vw == 1) return launch_many_t<1, 1>(st, d_params, n_climbs, max_nslots);
-    if (vw == 2) return launch_many_t<1, 2>(st, d_params, n_climbs, max_nslots);
-    if (vw == 8) return launch_many_t<1, 8>(st, d_params, n_climbs, max_nslots);
-    return launch_many_t<1, 4>(st, d_params, n_climbs, max_nslots);
+    if (vw == 1) return launch_many_t<1, 1>(st, d_params, n_climbs, lds);
+    if (vw == 2) return launch_many_t<1, 2>(st, d_params, n_climbs, lds);
+    if (vw == 8) return launch_many_t<1, 8>(st, d_params, n_climbs, lds);
+    return launch_many_t<1, 4>(st, d_params, n_climbs, lds);
   }
-  if (g.S == 32) return launch_many_t<8, 1>(st, d_params, n_climbs, max_nslots);
-  return launch_many_t<5, 1>(st, d_params, n_climbs, max_nslots);
+  if (g.S == 32) return launch_many_t<8, 1>(st, d_params, n_climbs, lds);
+  return launch_many_t<5, 1>(st, d_params, n_climbs, lds);
 }
 
 }  // namespace mpf

@@ -98,11 +98,13 @@ constexpr uint32_t kClimbCap = 1024;      // candidates per step
 // states per lane group: DNA 1 (four lanes = the four states of a word), protein 5
 bool climb_supported(const Geometry &g, int n_taxa, int maxtrav);
 int climb_tiles(const Geometry &g, int vw);
-size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw);
+// LDS of a workgroup: batch_max = ClimbParams::batch_max (a step's scan programs are sized by it), many = k_climb_many's wave count,
+// word_major = the word-major shape on 64-word tiles (vw 4)
+size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw, int batch_max = 16, bool many = false, bool word_major = false);
 hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p, bool word_major = false);
 // n_climbs independent climbs, one workgroup each (k_climb_many): d_params[n_climbs] on the device, every entry with groups == 1
 // word_major (four-state data on 64-word tiles, vw == 4): a lane holds the four states of a word (quadtile.hpp, kWordMajor); sct then
 // has 64 score words per vector and tile instead of 16
-hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, uint32_t max_nslots, bool word_major);
+hipError_t launch_climb_many(hipStream_t st, const Geometry &g, int vw, const ClimbParams *d_params, int n_climbs, size_t lds_bytes, bool word_major);
 
 }  // namespace mpf

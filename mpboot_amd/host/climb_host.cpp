@@ -63,7 +63,7 @@ int Engine::climb_fit_vw(bool one_workgroup)
     size_t least = ~(size_t)0;
     for (int vw = 1; vw <= 8; vw *= 2) least = std::min(least, (size_t)climb_tiles(g_, vw) * 16 * (size_t)vw);
     for (int vw : {4, 8, 2, 1}) {
-      if (climb_lds_bytes(g_, n_, vw) > 160 * 1024) continue;
+      if (climb_lds_bytes(g_, n_, vw, many_batch_max(), true, vw == 4 && many_word_major_) > 160 * 1024) continue;
       if ((size_t)climb_tiles(g_, vw) * 16 * (size_t)vw * 100 <= least * 108) return vw;
     }
     return 0;
@@ -207,7 +207,7 @@ int Engine::climb_segment(int maxtrav_eff, int total, int *i, uint32_t *randomMP
   GateHold hold;
   {
     ClimbGate &g = g_gate[dev_ & 63];
-    const size_t lds = climb_lds_bytes(g_, n_, vw);
+    const size_t lds = climb_lds_bytes(g_, n_, vw, (int)p.batch_max, false, vw == 4 && climb_word_major_ && g_.S == 4);
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
     std::unique_lock<std::mutex> lk(g.m);
     if (!g.cus) {
@@ -451,7 +451,13 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
   if (batch.empty()) return MPF_OK;
   const auto t_prep = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(mb.d_params.p, mb.h_params.p, batch.size() * sizeof(ClimbParams), hipMemcpyHostToDevice, e0.st_));
-  HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, mb.d_params.p, (int)batch.size(), max_ns, e0.g_.S == 4 && vw0 == 4 && e0.many_word_major_));
+  const bool wm = e0.g_.S == 4 && vw0 == 4 && e0.many_word_major_;
+  size_t lds = 0;
+  for (size_t b = 0; b < batch.size(); b++) {
+    Engine &e = *engs[batch[b]];
+    lds = std::max(lds, climb_lds_bytes(e.g_, e.n_, vw0, (int)mb.h_params.p[b].batch_max, true, wm));
+  }
+  HIPCHK(launch_climb_many(e0.st_, e0.g_, vw0, mb.d_params.p, (int)batch.size(), lds, wm));
   for (int k : batch) {
     Engine &e = *engs[k];
     const size_t out_words = hdr_words + 3 * (size_t)e.cd_.max_moves;
