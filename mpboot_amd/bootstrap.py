@@ -90,7 +90,7 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     a finished engine taking the next sample at once (mpf_optimize_spr_many_round).  Same results; NOT the default: these climbs start
     next to an optimum -- two or three sweeps with a handful of moves --, and a move-less sweep of a thousand taxa costs one resident
     workgroup milliseconds where the host path's whole-chip batch takes 0.3 ms (C4N, 955 climbs on 128 engines: 1.0 s against 0.78 s on six
-    host threads, tools/refine_many_probe.py).  The one-launch form is for DENSE climbs (random start trees: C2 2 700 climbs/s against 345).
+    host threads, tools/refine_many_probe.py).  The one-launch form is for DENSE climbs (random start trees: C2 3 000 climbs/s against 345).
 
     Returns (scores[B] after the all-reduce, {b: refined tree} of this rank)."""
     samples = np.asarray(samples)
