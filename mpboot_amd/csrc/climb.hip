@@ -69,7 +69,7 @@ template <int KS, int VW> struct Cfg {
   __host__ __device__ static constexpr size_t region_max(int nw) { return pend_bytes(nw) > 65536 ? pend_bytes(nw) : 65536; }
   __host__ __device__ static constexpr size_t region_min(int nw) { return pend_bytes(nw) > 40960 ? pend_bytes(nw) : 40960; }
 };
-constexpr size_t kLdsBudget = 152 * 1024;      // of the CU's 160 KB
+constexpr size_t kLdsBudget = 158 * 1024;      // of the CU's 160 KB (all of it dynamic: the kernels have no static LDS)
 
 #include "quadtile.hpp"
 
@@ -116,9 +116,10 @@ struct Kx {
   uint16_t *OL;      // [kLcap] the first refresh ops, by index
   uint16_t *ord;     // [total] the sweep's visiting order
   uint16_t *Q;       // [ns] what the enumeration lists (lives in the stage / pend region, idle between decide and refresh)
-  uint2 *SD;         // [kLcap] (in the stage / pend region) the refresh of a step as ONE sequence (schedule_private): r | how operand a comes << 16 | operand b << 18 ; a | b << 16
+  uint2 *SD;         // [kLcap] (over CONS) the refresh of a step as ONE sequence (schedule_private): r | how operand a comes << 16 | operand b << 18 ; a | b << 16
   uint32_t *PEND0;   // [kLcap] PEND as the link pass left it  } a workgroup that works through several tiles per step runs the
   uint16_t *R0;      // [kLcap] the chain starts of the link pass } same refresh once per tile: what a run consumes is put back
+  uint16_t *TF;      // [kLcap] k_climb_many: the step (its epoch) whose refresh tile k of this workgroup has been taken through
   unsigned long long pre, ancl, lsub;   // heap-index relations of this lane (enumeration)
   uint32_t n, ns, SW4;
   uint32_t slots;    // operand slots the region holds
@@ -767,7 +768,10 @@ __device__ __forceinline__ void schedule_private(const Kx<KS, VW> &K, Sh &sh)
     if (cnt != nops && lane == 0) sh.err = sh.err ? sh.err : 6u;
     return;
   }
-  if (K.lane != 0) return;
+  // (larger closures: one lane, LDS round trips.  The sequence is written beside the consumer entries it is made from -- into the
+  //  region, idle between the enumeration's list and the scans -- and moved over them at the end)
+  uint2 *seq = reinterpret_cast<uint2 *>(K.stage);
+  if (K.lane == 0) {
   uint32_t sp = 0, cnt = 0;
   for (uint32_t k = 0; k < nstart; k++) K.R0[sp++] = K.R[nstart - 1u - k];
   while (sp) {
@@ -786,7 +790,7 @@ __device__ __forceinline__ void schedule_private(const Kx<KS, VW> &K, Sh &sh)
       fl[u] = f;
     }
     K.PEND0[i] = cnt;
-    K.SD[cnt] = make_uint2((d.x & 0xFFFFu) | (fl[0] << 16) | (fl[1] << 18), d.y);
+    seq[cnt] = make_uint2((d.x & 0xFFFFu) | (fl[0] << 16) | (fl[1] << 18), d.y);
     cnt++;
     if (cnt > nops) break;
     const uint32_t nc = K.NC[i] < 2u ? K.NC[i] : 2u;
@@ -798,6 +802,9 @@ __device__ __forceinline__ void schedule_private(const Kx<KS, VW> &K, Sh &sh)
     }
   }
   if (cnt != nops) sh.err = sh.err ? sh.err : 6u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  for (uint32_t k = (uint32_t)K.lane; k < nops; k += 64u) K.SD[k] = seq[k];
 }
 
 template <int KS, int VW>
@@ -1183,6 +1190,7 @@ __host__ __device__ inline size_t lds_fixed_bytes(uint32_t ns, uint32_t maxb)
   at += ns;
   at = (at + 15) & ~(size_t)15;
   at += (size_t)kLcap * 4 + (size_t)kLcap * 2;               // PEND0, R0 (multi-tile workgroups)
+  at += (size_t)kLcap * 2;                                    // TF (k_climb_many: a tile's refresh of this step is through)
   return (at + 15) & ~(size_t)15;
 }
 
@@ -1237,8 +1245,9 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
   K.ord = reinterpret_cast<uint16_t *>(smem + at); at += (((size_t)P.total * 2) + 15) & ~(size_t)15;
   K.valid = reinterpret_cast<uint8_t *>(smem + at); at = (at + ns + 15) & ~(size_t)15;
   K.PEND0 = reinterpret_cast<uint32_t *>(smem + at); at += (size_t)kLcap * 4;
-  K.R0 = reinterpret_cast<uint16_t *>(smem + at);
-  K.SD = reinterpret_cast<uint2 *>(K.stage);            // (the region is idle between the enumeration's list and the scans' parked vectors: refresh_private stages nothing)
+  K.R0 = reinterpret_cast<uint16_t *>(smem + at); at += (size_t)kLcap * 2;
+  K.TF = reinterpret_cast<uint16_t *>(smem + at);
+  K.SD = K.CONS;                                        // (the consumer entries are done with once the sequence stands; the region is not free: early waves' scans park vectors there while late waves still refresh)
   K.n = n; K.ns = ns; K.lane = lane; K.wave = wave;
   { const size_t sl = region_bytes<KS, VW>(ns, maxb, (int)kNW) / Cfg<KS, VW>::kSlotBytes; K.slots = sl < 254 ? (uint32_t)sl : 254u; }
   K.SW4 = (uint32_t)(kWordMajor<KS> ? 4 : 4 * KS) * P.Wp * 4u;
@@ -1293,6 +1302,7 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
     K.cl[i] = 0u;
   }
   for (uint32_t i = (uint32_t)tid; i < ns + 16u; i += kThreads) K.R[i] = (uint16_t)kNone16;
+  for (uint32_t i = (uint32_t)tid; i < kLcap; i += kThreads) K.TF[i] = 0;
   for (uint32_t i = (uint32_t)tid; i < P.total; i += kThreads) K.ord[i] = P.order[i];
   if (tid == 0) {
     const ClimbHeader h = *P.hdr;
@@ -1419,24 +1429,43 @@ __device__ __forceinline__ void climb_body(const ClimbParams &P, const uint32_t 
             }
           }
         }
+        // this tile's vectors are as the step needs them: whoever scans it may start (the scans of ALL tiles are one queue, below)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *(volatile uint16_t *)&K.TF[tk < kLcap ? tk : kLcap - 1u] = (uint16_t)sh.epoch;
       }
-      __syncthreads();
-      beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
+      if (nmine > kLcap) __syncthreads();                 // (more tiles than flags: everybody waits for everybody, as before)
       MPF_TMARK(3);
-      for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
-      if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
-      const uint32_t ntasks = sh.ntasks, items = nmine * ntasks, per = (items + kNW - 1u) / kNW;
-      const uint32_t it_lo = (uint32_t)wave * per, it_hi = ((uint32_t)wave + 1u) * per < items ? ((uint32_t)wave + 1u) * per : items;
+      const uint32_t ntasks = sh.ntasks, items = nmine * ntasks;
       // (the same items as one stream of blocks -- the next block's vectors requested while the one at hand is combined -- was
-      //  built and measured slower, 1 470 against 1 290 ms of a C3 climb: with two waves a SIMD the scans are bound by their
-      //  arithmetic, not by the round trips; HISTORY.md)
+      //  built and measured slower, 1 470 against 1 290 ms of a C3 climb; HISTORY.md)
+      // The (tile, program) items are taken off ONE counter in tile order: a wave whose share of the refresh took a round longer (25
+      // tiles on twelve waves: one wave has three, the others two) simply arrives later and takes fewer -- no barrier between the
+      // refresh and the scans, only the flag of the tile an item belongs to.
       uint32_t cur = 0xFFFFFFFFu;
-      for (uint32_t it = it_lo; it < it_hi; it++) {
+      const uint32_t want = sh.epoch & 0xFFFFu;
+      for (;;) {
+        const uint32_t it = wave_fetch_add(&sh.task, 1u, lane);
+        if (it >= items) break;
         const uint32_t tk = it / ntasks, ti = it - tk * ntasks;
-        if (tk != cur) { set_tile(tile + tk * T); cur = tk; }
+        if (tk != cur) {
+          if (nmine <= kLcap) {
+            uint32_t spins = 0;
+            while (rfl((uint32_t) * (volatile uint16_t *)&K.TF[tk]) != want) {
+              if (++spins > (1u << 22)) { sh.err = sh.err ? sh.err : 8u; break; }      // (bounded like every wait in this kernel)
+              __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+          set_tile(tile + tk * T);
+          cur = tk;
+        }
         const uint32_t t = rfl((uint32_t)sh.tl[ti]);
         scan_part<KS, VW>(K, sh, t >> 1, t & 1u);
       }
+      __syncthreads();
+      beat(P, tile, tid, 7, sh.ndone); beat(P, tile, tid, 1, 4);
+      for (uint32_t i = (uint32_t)tid; i < sh.rtail; i += kThreads) K.R[i] = (uint16_t)kNone16;
+      if ((uint32_t)tid < kLcap) K.NC[tid] = 0u;
     }
     if (!priv) {
     if (multi && nops_step) {
