@@ -89,8 +89,8 @@ def refine_boot_trees(eng, samples, boot_trees, base_seed: int, radius: int = 6,
     many_launch = True (eight or more engines): the samples' own climbs as workgroups of ONE launch, an engine per sample,
     a finished engine taking the next sample at once (mpf_optimize_spr_many_round).  Same results; NOT the default: these climbs start
     next to an optimum -- two or three sweeps with a handful of moves --, and a move-less sweep of a thousand taxa costs one resident
-    workgroup milliseconds where the host path's whole-chip batch takes 0.3 ms (C4N, 955 climbs on 128 engines: 1.0 s against 0.78 s on six
-    host threads, tools/refine_many_probe.py).  The one-launch form is for DENSE climbs (random start trees: C2 3 000 climbs/s against 345).
+    workgroup milliseconds where the host path's whole-chip batch takes 0.3 ms (C4N, 955 climbs: 1.0 s on 128 engines, 0.76-0.81 s on 256,
+    against 0.77-0.81 s on six host threads; tools/refine_many_probe.py).  The one-launch form is for DENSE climbs (random start trees: C2 3 000 climbs/s against 345).
 
     Returns (scores[B] after the all-reduce, {b: refined tree} of this rank)."""
     samples = np.asarray(samples)
