@@ -175,10 +175,14 @@ class ParallelBbRun:
         self.prev_key = key
         # candidate sets and the run's best tree
         n_iter = len(all_cands)
+        # (a tree's topology digest once, not once per chain that takes it: 16 chains x 128 results were 50 ms of digests per exchange)
+        from . import engine as _engine
+        cand_trees = [np.frombuffer(tree, dtype=np.int32) for _g, _it, _score, tree in all_cands]
+        cand_keys = [_engine.iq_topology_key(t) for t in cand_trees]
         for i, s in enumerate(self.searches):
-            for g, _it, score, tree in all_cands:
+            for (g, _it, score, _tree), t, key in zip(all_cands, cand_trees, cand_keys):
                 if g != g0 + i:
-                    s.absorb(np.frombuffer(tree, dtype=np.int32), score)
+                    s.absorb(t, score, key)
         self.iterations += n_iter
         best_now = max(p[2] for p in box)
         improved = best_now > self.best_score

@@ -63,9 +63,11 @@ class CandidateSet:
                 del self._items[i]
                 return
 
-    def update(self, tree, score) -> bool:
-        """CandidateSet::update (candidateset.cpp:104-150) -> True when the topology is new to the set and was taken."""
-        key = _engine.iq_topology_key(tree)
+    def update(self, tree, score, key=None) -> bool:
+        """CandidateSet::update (candidateset.cpp:104-150) -> True when the topology is new to the set and was taken.
+        key: the tree's topology digest if the caller has it already (an exchange hands one tree to many sets)."""
+        if key is None:
+            key = _engine.iq_topology_key(tree)
         if score > self.best_score:
             self.best_score = score
         if key in self.topologies:
@@ -207,13 +209,15 @@ class MpSearch:
         """the tree an iteration ended on, as bytes (for the exchange of an iteration-parallel run)"""
         return np.ascontiguousarray(info["_tree"], dtype=np.int32).tobytes()
 
-    def absorb(self, tree, length: int):
+    def absorb(self, tree, length: int, key=None):
         """the result of ANOTHER chain's iteration: into the candidate set, and the best tree if it is one (iteration-parallel runs)"""
         tree = np.asarray(tree, dtype=np.int32).copy()
         cur = -float(length)
+        if key is None:
+            key = _engine.iq_topology_key(tree)
         if cur > self.best_score:
-            self.best_score, self.best_tree, self.best_key = cur, tree, _engine.iq_topology_key(tree)
-        self.cands.update(tree, cur)
+            self.best_score, self.best_tree, self.best_key = cur, tree, key
+        self.cands.update(tree, cur, key)
 
     def iterations_left(self) -> int:
         return max(0, self.last_improved + self.unsuccess - self.cur_it + 1)
