@@ -587,6 +587,13 @@ def main():
     args = ap.parse_args()
     legs_wanted = set(x.strip() for x in args.legs.split(","))
     leg_on = lambda name: "all" in legs_wanted or name in legs_wanted
+    # wall clock of the run, leg by leg (what the driver's own clock around this command is made of)
+    _laps, _lap_at = [], [time.perf_counter(), "set-up + headline"]
+
+    def _lap(name):
+        now = time.perf_counter()
+        _laps.append((_lap_at[1], now - _lap_at[0]))
+        _lap_at[0], _lap_at[1] = now, name
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process (which has made NO GPU call and never imports torch)
@@ -863,6 +870,7 @@ def main():
     n_distinct_trees = None
     if args.ufboot_samples > 0:
         samples = np.random.default_rng(4242).multinomial(P, np.ones(P) / P, size=args.ufboot_samples).astype(np.uint16)
+    _lap("ufboot_online")
     if args.ufboot_samples > 0 and (leg_on("ufboot_online") or leg_on("random_start")):
         try:
             B = args.ufboot_samples
@@ -950,6 +958,7 @@ def main():
                 eng.set_weights(np.ones(P, dtype=np.int32))
             # ---- the same flow from a start tree that is NOT a local optimum (the RAS tree of this alignment already is one:
             # zero moves above): a random topology, thousands of accepted moves, refinements that really climb
+            _lap("random_start")
             if args.random_start_leg and leg_on("random_start"):
                 back_r = shard.broadcast_tree(trees.random_topology(n, np.random.default_rng(2024)), 0, len(back))
                 eng.set_tree(back_r)
@@ -1113,6 +1122,7 @@ def main():
             for t in th: t.join()
             torch.cuda.synchronize()
             return time.perf_counter() - t0_, out
+        _lap("concurrent_climbs")
         if args.climb_engines > 0 and args.random_start_leg and leg_on("concurrent_climbs"):
             # independent climbs from random trees, one engine per host thread (the shape of the start trees / the refinements of
             # a run): every climb is a chain of dependent steps, concurrent engines fill the chip
@@ -1140,6 +1150,7 @@ def main():
                             "thread; each climb runs in the persistent kernel k_climb (%d-word tiles: %d workgroups per climb); "
                             "host_driven_batches = the same climbs with the loop on the host (engine option climb_device = 0).  "
                             "GPU_MAX_HW_QUEUES=%s" % (E, args.maxtrav, 16 * args.climb_tile, (eng.Wp + 16 * args.climb_tile - 1) // (16 * args.climb_tile), os.environ.get("GPU_MAX_HW_QUEUES"))}
+        _lap("start_trees")
         if args.start_trees > 0 and (leg_on("start_trees") or leg_on("bb_reference_run")):
             # the start-up phase of a run: numpars randomized-stepwise-addition trees, each SPR-optimised (phyloanalysis.cpp:1270-1317,
             # tools.cpp:767); unit u on rank u % n_gpus, several engines per GPU
@@ -1181,6 +1192,7 @@ def main():
                                "(phyloanalysis.cpp:1270-1317); tree u on rank u %% n_gpus.  The addition loop of a tree is ONE persistent kernel "
                                "launch (k_grow: the rooted tree in LDS, one vector load per branch and added taxon, the insertions replayed on "
                                "the host's mirror); trees_grown_in_k_grow counts the launches that came back clean" % (args.start_trees, args.maxtrav)}
+        _lap("bb_reference_run")
         if startup is not None and samples is not None and (args.bb_iterations > 0 or args.bb_rounds > 0) and leg_on("bb_reference_run"):
             # ---- BASELINE config 4: -bb 1000 as the reference runs it (benchlegs/bb_run.py).  The start trees of all ranks are the
             # candidate set of every chain.
@@ -1199,12 +1211,14 @@ def main():
                 bbref = {"error": repr(exc)}
             eng.set_option("timing", 1)
             eng.set_weights(np.ones(P, dtype=np.int32))
+        _lap("climbs_in_one_launch")
         if world == 1 and args.workload == "C3" and leg_on("climbs_in_one_launch"):
             try:
                 from benchlegs import climbs_many as _cm
                 many_leg = _cm.run(device, args.maxtrav, barrier, args.many_c2, args.many_c3)
             except Exception as exc:
                 many_leg = {"error": repr(exc)}
+        _lap("c5_fitch")
         if world == 1 and args.workload == "C3" and leg_on("c5_fitch"):
             try:
                 from benchlegs import c5_fitch as _c5f
@@ -1212,12 +1226,14 @@ def main():
                                                 None if args.no_cpu else climb_cpu_baseline, min(args.cpu_budget, 10.0))
             except Exception as exc:
                 c5f_sweep, c5f_climb = {"error": repr(exc)}, None
+        _lap("noisy_bootstrap")
         if world == 1 and args.workload == "C3" and leg_on("noisy_bootstrap"):
             try:
                 from benchlegs import noisy as _noisy
                 noisy_leg = _noisy.run(device, args.maxtrav, 12, 40, args.engines_per_gpu, barrier, B=max(1, args.ufboot_samples))
             except Exception as exc:
                 noisy_leg = {"error": repr(exc)}
+        _lap("c2_climb")
         if world == 1 and args.workload == "C3" and args.random_start_leg and leg_on("c2_climb"):
             # BASELINE config 2 (200 taxa x 10 000 patterns): a full SPR hill climb from a random tree
             letters2, names2 = synth.workload("C2")
@@ -1284,6 +1300,7 @@ def main():
                                    "what": "%d engines on host threads, %d climbs each from different random topologies, k_climb with 64-word tiles "
                                            "(5 workgroups per climb)" % (k2, per)}
             del es
+        _lap("c5_weighted_sweep")
         if world == 1 and args.workload == "C3" and args.weighted_leg and leg_on("c5_weighted_sweep"):
             # BASELINE config 5 in its `-cost` form: the weighted (Sankoff) engine on 500 taxa x 20 000 protein patterns, 20 states
             letters5, names5 = synth.workload("C5")
@@ -1493,6 +1510,12 @@ def main():
                         bbref["gpu_over_cpu_one_core"] = cbr["value"] / (sq["iterations_s"] + (bbref.get("parallel") or {}).get("refinement_s", 0.0))
                 except Exception as exc:
                     bbref["cpu_baseline"] = {"error": repr(exc)}
+        _lap("end")
+        agg = {}
+        for k, v in _laps:
+            agg[k] = agg.get(k, 0.0) + v
+        res["bench_wall_s"] = {k: round(v, 2) for k, v in agg.items()}
+        res["bench_wall_s"]["total"] = round(sum(agg.values()), 2)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
