@@ -334,16 +334,17 @@ int Engine::climb_harvest(int total, int tiles, std::chrono::steady_clock::time_
   return MPF_OK;
 }
 
-// ---- many independent climbs, one launch per round --------------------------------------------------------------------------
-// pllOptimizeSprParsimony (reference sprparsimony.cpp:3244-3319) on n engines at once -- the 100 start trees of a run
-// (phyloanalysis.cpp:1270-1317), the bootstrap samples' refinement climbs (iqtree.cpp:2797-2862): climbs that have nothing to do
-// with each other.  One engine alone gets through its chain of dependent steps fastest on a workgroup per tile (98 at C3) -- and
-// leaves most of the chip idle doing so; host threads with an engine each fill some of it (bench: concurrent_climbs), but every
-// persistent launch holds a hardware queue and its CUs while it waits.  Here every climb is ONE workgroup that works through all
-// tiles itself (ClimbParams::groups == 1: nothing crosses between workgroups), and a round = ONE launch of k_climb_many with a
-// workgroup per climb that still has a sweep to run: a round ends when every workgroup has finished its sweep (or filled its move
-// list), the host replays the moves on each engine's topology mirror and starts the next round with the climbs that are not at
-// their optimum yet.  Each climb: the same moves, draws and final tree as its solo mpf_optimize_spr (tests/test_gpu_climb_many.py).
+// ---- many independent climbs in one launch -----------------------------------------------------------------------------------
+// pllOptimizeSprParsimony (reference sprparsimony.cpp:3244-3319) on n engines at once -- random restarts, the bootstrap samples'
+// refinement climbs (iqtree.cpp:2797-2862): climbs that have nothing to do with each other.  One engine alone gets through its
+// chain of dependent steps fastest on a workgroup per tile (98 at C3) -- and leaves most of the chip idle doing so; host threads
+// with an engine each fill some of it (bench: concurrent_climbs), but every persistent launch holds a hardware queue and its CUs
+// while it waits.  Here every climb is ONE workgroup that works through all tiles itself (ClimbParams::groups == 1: nothing crosses
+// between workgroups) and through all its sweeps (ClimbParams::sweeps_inside: nodeRectifierPars on the device), and ONE launch of
+// k_climb_many holds a workgroup per climb.  A launch ends when every climb is at its optimum or has filled its move list (four
+// sweeps' worth); the host replays the moves on each engine's topology mirror and, for the rare climb that is not through, launches
+// again from the middle of the sweep the device was in.  Each climb: the same moves, draws and final tree as its solo
+// mpf_optimize_spr (tests/test_gpu_climb_many.py; at C3 size against the oracle-pinned climb: tests/test_gpu_configs.py).
 int Engine::climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t *scores)
 {
   if (n <= 0) return MPF_OK;
@@ -358,10 +359,9 @@ int Engine::climb_many(Engine **engs, int n, int mintrav, int maxtrav, uint32_t 
   }
 }
 
-// One round: state[k] in: 0 = engine k takes no part, 1 = its climb STARTS now (tree, weights, tie stream set as for mpf_optimize_spr),
+// One launch: state[k] in: 0 = engine k takes no part, 1 = its climb STARTS now (tree, weights, tie stream set as for mpf_optimize_spr),
 // 2 = its climb goes on; out: 2 = not at its optimum yet, 0 = done (scores[k] = the final length).  A caller that has more climbs than
-// engines hands a finished engine its next tree between two rounds (mpboot_amd/bootstrap.py: refine_boot_trees), so that the launches
-// stay full until the work runs out.
+// engines hands a finished engine its next tree between two launches (mpboot_amd/bootstrap.py: refine_boot_trees).
 int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uint8_t *state, uint32_t *scores)
 {
   if (n <= 0) return MPF_OK;
