@@ -867,9 +867,11 @@ def main():
                 dist.all_gather_object(box, [(u, t.tobytes(), sc) for u, t, sc in mine])
                 mine = sorted((u, np.frombuffer(t, dtype=np.int32), sc) for part in box for u, t, sc in part)
             starts_bb = [(t, sc) for _u, t, sc in mine]
-            grow(max(1, args.bb_workers))
+            # (chains are host threads: on a node that grants this job few cores -- the single-GPU boxes give 16 -- the ranks share them)
+            bb_workers = max(1, min(args.bb_workers, max(4, cpu_quota() // max(1, world))))
+            grow(bb_workers)
             try:
-                bbref = _bbleg.run(pool, samples, starts_bb, args.maxtrav, rank, world, barrier, args.bb_iterations, args.bb_workers, args.bb_rounds,
+                bbref = _bbleg.run(pool, samples, starts_bb, args.maxtrav, rank, world, barrier, args.bb_iterations, bb_workers, args.bb_rounds,
                                    args.bb_sync, startup["seconds"], pool[:max(1, min(len(pool), args.engines_per_gpu))])
             except Exception as exc:
                 bbref = {"error": repr(exc)}
