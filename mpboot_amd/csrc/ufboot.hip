@@ -678,8 +678,11 @@ __global__ __launch_bounds__(256) void k_ufb_layout(const uint16_t *__restrict__
                                                     const int32_t *__restrict__ cur, uint8_t *__restrict__ Wt, int Bp, int planes,
                                                     size_t plane_bytes)
 {
-  const int ptn = blockIdx.x * blockDim.x + threadIdx.x;
-  const int col = blockIdx.y;
+  // a workgroup = 16 patterns x 16 columns: the 16 x 16 bytes of a column group's 16 consecutive sites are ONE 256-byte piece of Wt
+  // (16 bytes per column), so a wave -- 4 columns x 16 patterns -- writes 64 consecutive bytes.  (A thread per pattern and a grid row per
+  // column, as before round 6's end, left every wave writing four 16-byte pieces 256 bytes apart, a byte per lane: 0.6 ms per call at C4.)
+  const int ptn = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int col = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (ptn >= P || col >= n_cols) return;
   const uint32_t w = src[(size_t)col * P + ptn];
   const int site = first[ptn];
@@ -913,7 +916,7 @@ hipError_t launch_ufb_layout(hipStream_t st, const uint16_t *src, int n_cols, in
 {
   hipError_t e = hipMemsetAsync(Wt, 0, plane_bytes * (size_t)planes, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_ufb_layout, dim3((P + 255) / 256, n_cols), dim3(256), 0, st, src, n_cols, P, first, cur, Wt, Bp, planes, plane_bytes);
+  hipLaunchKernelGGL(k_ufb_layout, dim3((P + 15) / 16, (n_cols + 15) / 16), dim3(256), 0, st, src, n_cols, P, first, cur, Wt, Bp, planes, plane_bytes);
   return hipGetLastError();
 }
 
