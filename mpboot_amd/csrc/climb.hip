@@ -1767,14 +1767,14 @@ size_t climb_lds_bytes(const Geometry &g, int n_taxa, int vw, int batch_max, boo
   return lds_bytes<5, 1>(ns, mb, many);
 }
 
-bool climb_supported(const Geometry &g, int n_taxa, int maxtrav)
+bool climb_supported(const Geometry &g, int n_taxa, int maxtrav, int batch_max)
 {
   if (g.sankoff || g.big) return false;
   if (g.S != 4 && g.S != 20 && g.S != 32) return false;
   if (maxtrav < 1 || maxtrav > kDepth) return false;
   if (slots_of(n_taxa) + 16u >= 0xFFFFu) return false;
   if (climb_tiles(g, 1) >= (1 << 20)) return false;
-  return climb_lds_bytes(g, n_taxa, 1, kMaxB, false, false) <= kLdsBudget;
+  return climb_lds_bytes(g, n_taxa, 1, batch_max < 1 ? 1 : batch_max > kMaxB ? kMaxB : batch_max, false, false) <= kLdsBudget;
 }
 
 hipError_t launch_climb(hipStream_t st, const Geometry &g, int vw, const ClimbParams &p, bool word_major)

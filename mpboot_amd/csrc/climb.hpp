@@ -96,7 +96,9 @@ struct ClimbParams {
 constexpr uint32_t kClimbCap = 1024;      // candidates per step
 
 // states per lane group: DNA 1 (four lanes = the four states of a word), protein 5
-bool climb_supported(const Geometry &g, int n_taxa, int maxtrav);
+// (batch_max: the launch's ClimbParams::batch_max -- the control state of a step's scan programs grows with it: 1000 taxa fit with
+//  sixteen prune nodes per step, about 1600 with the plain climb's eight)
+bool climb_supported(const Geometry &g, int n_taxa, int maxtrav, int batch_max = 16);
 int climb_tiles(const Geometry &g, int vw);
 // LDS of a workgroup: batch_max = ClimbParams::batch_max (a step's scan programs are sized by it), many = k_climb_many's wave count,
 // word_major = the word-major shape on 64-word tiles (vw 4)

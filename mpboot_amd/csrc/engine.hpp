@@ -321,8 +321,10 @@ class Engine {
                     mpf_ufb_exchange_fn exchange = nullptr, void *exchange_arg = nullptr);
   void ufboot_detach();
   // the first sweep of pllOptimizeSprParsimony from the current tree under every attached sample's weights at once
-  int climb_fit_vw(bool one_workgroup = false);
-  int many_batch_max() const { return std::max(1, std::min(climb_batch_max_, 16)); }      // ClimbParams::batch_max of a climb of mpf_optimize_spr_many                            // tile width k_climb will run with on this device (0: does not fit)
+  int climb_fit_vw(bool one_workgroup = false);  // tile width k_climb will run with on this device (0: does not fit)
+  // ClimbParams::batch_max of a k_climb launch: the plain climb's bound, or the quiet stretch's (a tracked climb under a cut-off)
+  int climb_batch_bound(bool quiet) const { return std::max(std::max(1, std::min(climb_batch_min_, 16)), std::min(quiet ? climb_batch_max_sparse_ : climb_batch_max_, 16)); }
+  int many_batch_max() const { return climb_batch_bound(false); }      // ClimbParams::batch_max of a climb of mpf_optimize_spr_many
   int ufboot_refine_sweep(int maxtrav, const int32_t *tie_seeds, uint32_t *scores, uint8_t *stable, int32_t *first_move_visit);
   int ufboot_set_mulhits(int on);
   int ufboot_set_cutoff_from_btrees(int on);

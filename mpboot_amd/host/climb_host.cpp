@@ -75,7 +75,7 @@ int Engine::climb_fit_vw(bool one_workgroup)
   }
   const int cap = std::max(1, climb_cus_ * 85 / 100);
   for (int vw = (g_.S == 4) ? std::max(1, climb_vw_) : 1; vw <= ((g_.S == 4) ? 8 : 1); vw *= 2) {
-    const size_t lds = climb_lds_bytes(g_, n_, vw);
+    const size_t lds = climb_lds_bytes(g_, n_, vw, climb_batch_bound(climb_stop_len_ != 0));
     if (lds > 160 * 1024) continue;
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
     const int tiles = climb_tiles(g_, vw);
@@ -147,7 +147,7 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   p.batch_min = (uint32_t)std::max(1, std::min(climb_batch_min_, 16));
   // (a climb under a stop length is a later iteration of a -bb search: it starts near an optimum, its moves are some 25-45 prune
   //  nodes apart -- sixteen prune nodes per step there)
-  p.batch_max = (uint32_t)std::max((int)p.batch_min, std::min(climb_stop_len_ ? climb_batch_max_sparse_ : climb_batch_max_, 16));
+  p.batch_max = (uint32_t)climb_batch_bound(climb_stop_len_ != 0);
   p.order = cd_.order.p;
   p.bk = cd_.bk.p;
   p.sct = cd_.sct.p;
@@ -379,7 +379,7 @@ int Engine::climb_many_round(Engine **engs, int n, int mintrav, int maxtrav, uin
     if (!e.have_tree_) { set_error("no tree set"); return MPF_E_STATE; }
     const int mt_eff = std::min(maxtrav, e.n_ - 3);
     const bool fits = vw0 > 0 && e.dev_ == e0.dev_ && e.g_.S == e0.g_.S && !e.sankoff_ && !e.rand_fn_ && !(e.ufb_ && !e.ufb_->suspended) && mintrav == 1 &&
-                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff) && e.climb_fit_vw(true) == vw0;
+                      e.max_visits_ == 0 && e.scan_mode_ == 1 && e.climb_device_ > 0 && climb_supported(e.g_, e.n_, mt_eff, e.many_batch_max()) && e.climb_fit_vw(true) == vw0;
     if (!fits) {
       const int rc = e.optimize_spr(mintrav, maxtrav, &scores[k]);
       if (rc) return rc;

@@ -83,7 +83,7 @@ int Engine::spr_sweeps_run(int mintrav, int maxtrav, SweepCursor &cur, uint32_t 
   // keeps the loop on the host.
   const int mt_eff = std::min(maxtrav, ntips_ - 3);
   // (... and only where all of the kernel's workgroups fit the chip together, if need be on wider tiles: climb_fit_vw)
-  bool dev_ok = climb_device_ > 0 && max_visits_ == 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff) &&
+  bool dev_ok = climb_device_ > 0 && max_visits_ == 0 && !rand_fn_ && !sankoff_ && mintrav == 1 && ntips_ == n_ && scan_mode_ == 1 && climb_supported(g_, n_, mt_eff, climb_batch_bound(stop_len != 0)) &&
                 climb_fit_vw() > 0;
   uint32_t sweep_moves = 0;
   bool first_sweep = true;

@@ -211,3 +211,22 @@ def test_a_lost_launch_falls_back_to_the_host_path_with_the_same_trajectory(mods
     e.reset_stats()
     assert e.optimize_spr(1, 6) == ref2[1] and [list(map(int, m)) for m in zip(*e.moves())] == ref2[2]
     assert e.stats()["climb_moves"] == len(ref2[2])
+
+
+def test_more_than_a_thousand_taxa_climb_in_the_kernel_with_the_plain_batch_bound():
+    """The kernel's control state grows with the taxa AND with the prune nodes a step may hold: 1000 taxa fit beside the quiet stretch's
+    sixteen, 1300 still fit beside the plain climb's eight (climb_supported takes the launch's bound) -- same climb as host-driven."""
+    from mpboot_amd import engine, synth, trees
+    n, P = 1300, 640
+    letters, _ = synth.synth_alignment(n, P, "DNA", 0.05, seed=31)
+    codes = synth.letters_to_codes(letters, "DNA")
+    back = trees.random_topology(n, np.random.default_rng(6))
+    res = []
+    for mode in (0, 1):
+        e = engine.FitchEngine(codes)
+        e.set_option("climb_device", mode)
+        e.set_tree(back); e.reset_node_order(); e.seed_ties(engine.TIE_RANDOM, 4)
+        s = e.optimize_spr(1, 6)
+        res.append((s, [x.tolist() for x in e.moves()], e.get_tree().tolist(), e.tie_state(), e.stats()["climb_launches"]))
+    assert res[0][:4] == res[1][:4]
+    assert res[0][4] == 0 and res[1][4] >= 1
