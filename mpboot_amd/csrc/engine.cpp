@@ -2140,7 +2140,7 @@ int Engine::set_option(const std::string &key, int64_t v)
     climb_vw_set_ = true;
     return MPF_OK;
   }
-  if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
+  if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; climb_batch_min_set_ = true; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_batch_max_sparse") { climb_batch_max_sparse_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }

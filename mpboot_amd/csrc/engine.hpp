@@ -480,6 +480,7 @@ class Engine {
   } cd_;
   unsigned long long climb_phase_ticks_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, climb_ctr_[4] = {0, 0, 0, 0};
   int climb_device_ = 1;                         // 0 = host-driven batches only, 1 = device climb while moves are dense, 2 = always
+  bool climb_batch_min_set_ = false;             // option "climb_batch_min" was given: mpf_optimize_spr_many does not use its own (1)
   bool climb_vw_set_ = false;                    // option "climb_tile" was given: mpf_optimize_spr_many does not pick its own width
   int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)
   int climb_batch_max_sparse_ = 16;              // option climb_batch_max_sparse: prune nodes per step of the quiet stretch of a tracked climb
