@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void decide(const Kx<KS, VW> &K, Sh &sh, const ClimbP
     // sixth, where restarting from two prune nodes cost a step in three for nothing (C3: 798 -> ~620 steps per such climb)
     // (round 5 took this distance AFTER the counter had been reset: it never saw more than the step's own prune nodes)
     if (moved) sh.gap_ema = (3u * sh.gap_ema + 8u * (gap > 64u ? 64u : gap) + 2u) >> 2;
-    uint32_t b_near = (sh.gap_ema * 3u / 4u + 4u) >> 3;
+    uint32_t b_near = (sh.gap_ema * P.near_q / 4u + 4u) >> 3;
     b_near = b_near < P.batch_min ? P.batch_min : b_near;
     uint32_t B = moved ? (gap >= 16u ? gap / 2u : b_near) : sh.B * 2u;
     B = B > P.batch_max ? P.batch_max : B;

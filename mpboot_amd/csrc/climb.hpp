@@ -57,6 +57,7 @@ struct ClimbParams {
   uint32_t idle_limit;             // 0 = never leave for idleness
   uint32_t max_moves;
   uint32_t batch_min, batch_max;   // prune nodes per step (speculative; doubles after a step without a move)
+  uint32_t near_q;                 // the batch behind a near move: this many quarters of the recent average distance between moves (3)
   uint16_t *order;                 // [total] vector ids of nodep[1..total] (in; out with sweeps_inside)
   uint16_t *bk;                    // [nslots] back links as vector ids (in: current tree, out: after the moves)
   uint32_t *sct;                   // [tiles][nslots][16] per-tile, per-word-group subtree scores (scratch of the launch; [64] per-word ones in the word-major shape)

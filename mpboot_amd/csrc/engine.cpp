@@ -2142,6 +2142,7 @@ int Engine::set_option(const std::string &key, int64_t v)
   }
   if (key == "climb_batch_min") { climb_batch_min_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; climb_batch_min_set_ = true; return MPF_OK; }
   if (key == "climb_batch_max") { climb_batch_max_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
+  if (key == "climb_near_q") { climb_near_q_ = v < 1 ? 1 : v > 32 ? 32 : (int)v; climb_near_q_set_ = true; return MPF_OK; }
   if (key == "climb_batch_max_sparse") { climb_batch_max_sparse_ = v < 1 ? 1 : v > 16 ? 16 : (int)v; return MPF_OK; }
   if (key == "climb_idle") { climb_idle_ = v < 1 ? 1 : (int)v; return MPF_OK; }
   if (key == "climb_word_major") { climb_word_major_ = v != 0; return MPF_OK; }
@@ -2231,6 +2232,7 @@ int Engine::get_option(const std::string &key, int64_t *v) const
   else if (key == "climb_batch_min") *v = climb_batch_min_;
   else if (key == "climb_batch_max") *v = climb_batch_max_;
   else if (key == "climb_batch_max_sparse") *v = climb_batch_max_sparse_;
+  else if (key == "climb_near_q") *v = climb_near_q_;
   else if (key == "climb_idle") *v = climb_idle_;
   else if (key == "refine_chunk") *v = refine_chunk_;
   else if (key == "views_waves") *v = nv_waves_;

@@ -480,6 +480,8 @@ class Engine {
   } cd_;
   unsigned long long climb_phase_ticks_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, climb_ctr_[4] = {0, 0, 0, 0};
   int climb_device_ = 1;                         // 0 = host-driven batches only, 1 = device climb while moves are dense, 2 = always
+  int climb_near_q_ = 3;                         // option climb_near_q: ClimbParams::near_q (mpf_optimize_spr_many: 1 unless the option was given)
+  bool climb_near_q_set_ = false;
   bool climb_batch_min_set_ = false;             // option "climb_batch_min" was given: mpf_optimize_spr_many does not use its own (1)
   bool climb_vw_set_ = false;                    // option "climb_tile" was given: mpf_optimize_spr_many does not pick its own width
   int climb_vw_ = 1;                             // words per lane group: a tile is 16 x this many words (more tiles = shorter dependent chains per CU)

@@ -161,6 +161,7 @@ int Engine::climb_prepare(int maxtrav_eff, int total, int i, uint32_t randomMP, 
   p.trace = nullptr;
   p.trace_cap = 0;
   p.beat = nullptr;
+  p.near_q = (force_groups == 1 && !climb_near_q_set_) ? 1u : (uint32_t)climb_near_q_;       // (one workgroup per climb: speculation is paid for -- 164 -> 171 climbs/s at C3)
   p.fault = (uint32_t)climb_fault_;
   climb_fault_ = 0;                                  // (one launch)
   p.stop_len = climb_stop_len_;
